@@ -1,0 +1,12 @@
+"""apex-solver_amd: MI355X-native bundle-adjustment inner loop behind apex-solver's
+Problem / LevenbergMarquardt / LinearSolverType surface.
+
+Host-side modules:
+  synthetic  deterministic BA problem generator
+  layout     the reference's lexicographic global column layout
+  capi       ctypes binding of the C-ABI library (include/apexgpu.h)
+  solver     Python mirror of the reference's Problem / LevenbergMarquardt surface
+"""
+from . import layout, synthetic  # noqa: F401
+
+__all__ = ["layout", "synthetic"]

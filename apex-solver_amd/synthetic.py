@@ -1,0 +1,243 @@
+"""Deterministic synthetic bundle-adjustment problems.
+
+Counter-based SplitMix64 streams (seed base 0xA9E50000 + config_id) so that every
+array element is a pure function of (seed, stream, index): the generator is
+vectorised, reproducible across machines, and any sub-range can be regenerated
+without the rest.
+
+Geometry: cameras on a ring of radius 10 looking at the origin in the BAL -Z
+convention (p_cam = R p_w + t, the scene sits near p_cam.z = -10 < -1e-6, the
+validity limit of the reference's BALPinholeCameraStrict,
+crates/apex-camera-models/src/bal_pinhole.rs:154-156); landmarks uniform in
+[-2,2]^3; landmark j is seen by k_j distinct cameras out of a window of 64
+consecutive ring cameras centred at floor(j*N_cam/N_pt), which gives the banded
+reduced camera matrix of a sequential capture.
+
+The parameter conventions are the reference's (bin/bundle_adjustment.rs:232-257):
+pose = [tx,ty,tz,qw,qx,qy,qz], intrinsics = [f,k1,k2], point = [x,y,z].
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_STREAM = np.uint64(0x632BE59BD9B4E019)
+SEED_BASE = 0xA9E50000
+
+#: The five BASELINE.json shapes: name -> (config_id, n_cam, n_pt, k_lo, k_hi)
+#: k_j ~ U{k_lo..k_hi}; (k_lo+k_hi)/2 matches N_obs/N_pt of the real dataset.
+SHAPES = {
+    "ladybug-49": (0, 49, 7776, 3, 5),
+    "ladybug-1723": (2, 1723, 156502, 3, 6),
+    "venice-1778": (3, 1778, 993923, 3, 7),
+    "final-13682": (4, 13682, 4456117, 3, 10),
+    "synthetic-10k": (5, 10000, 2000000, 3, 9),
+}
+
+
+def _mix64(z: np.ndarray) -> np.ndarray:
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+class SplitMix:
+    """Counter-based SplitMix64: u64(stream, i) = mix(seed + stream*C1 + (i+1)*golden)."""
+
+    def __init__(self, seed: int):
+        self.seed = np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+
+    def u64(self, stream: int, n: int, offset: int = 0) -> np.ndarray:
+        with np.errstate(over="ignore"):
+            i = np.arange(offset + 1, offset + n + 1, dtype=np.uint64)
+            z = self.seed + np.uint64(stream) * _STREAM + i * _GOLDEN
+            return _mix64(z)
+
+    def uniform(self, stream: int, n: int, offset: int = 0) -> np.ndarray:
+        """U[0,1) with 53 random bits."""
+        return (self.u64(stream, n, offset) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    def normal(self, stream: int, n: int, offset: int = 0) -> np.ndarray:
+        """N(0,1) by Box-Muller on streams (stream, stream+1)."""
+        u1 = self.uniform(stream, n, offset)
+        u2 = self.uniform(stream + 1, n, offset)
+        return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def quat_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Hamilton product, (w,x,y,z) rows."""
+    aw, ax, ay, az = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bw, bx, by, bz = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack(
+        [
+            aw * bw - ax * bx - ay * by - az * bz,
+            aw * bx + ax * bw + ay * bz - az * by,
+            aw * by - ax * bz + ay * bw + az * bx,
+            aw * bz + ax * by - ay * bx + az * bw,
+        ],
+        axis=-1,
+    )
+
+
+def quat_exp(theta: np.ndarray) -> np.ndarray:
+    """Unit quaternion of the rotation vector theta (n,3)."""
+    ang = np.linalg.norm(theta, axis=-1)
+    half = 0.5 * ang
+    s = np.where(ang > 1e-12, np.sin(half) / np.where(ang > 1e-12, ang, 1.0), 0.5)
+    return np.concatenate([np.cos(half)[..., None], theta * s[..., None]], axis=-1)
+
+
+def quat_rotate(q: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """q v q* for unit quaternions (rows broadcast)."""
+    qv = q[..., 1:]
+    t = 2.0 * np.cross(qv, v)
+    return v + q[..., :1] * t + np.cross(qv, t)
+
+
+def project_bal(poses: np.ndarray, intr: np.ndarray, points: np.ndarray) -> np.ndarray:
+    """BAL projection of matched rows (poses n×7, intr n×3, points n×3) → (n,2).
+    Formula of bal_pinhole.rs:273-296 (used only to synthesise observations)."""
+    pc = quat_rotate(poses[:, 3:7], points) + poses[:, 0:3]
+    inz = -1.0 / pc[:, 2]
+    xn = pc[:, 0] * inz
+    yn = pc[:, 1] * inz
+    r2 = xn * xn + yn * yn
+    d = 1.0 + intr[:, 1] * r2 + intr[:, 2] * r2 * r2
+    return np.stack([intr[:, 0] * xn * d, intr[:, 0] * yn * d], axis=-1)
+
+
+@dataclass
+class BAProblemData:
+    """A bundle-adjustment problem in the reference's parameter conventions.
+
+    Observations are in file order (not sorted); cam_idx/pt_idx index the camera
+    and landmark arrays.  `truth_*` are only set by the synthetic generator.
+    """
+
+    poses: np.ndarray  # (n_cam,7) tx,ty,tz,qw,qx,qy,qz
+    intr: np.ndarray  # (n_cam,3) f,k1,k2
+    points: np.ndarray  # (n_pt,3)
+    cam_idx: np.ndarray  # (n_obs,) uint32
+    pt_idx: np.ndarray  # (n_obs,) uint32
+    obs_uv: np.ndarray  # (n_obs,2)
+    name: str = "custom"
+    truth_poses: np.ndarray | None = None
+    truth_intr: np.ndarray | None = None
+    truth_points: np.ndarray | None = None
+
+    @property
+    def n_cam(self) -> int:
+        return int(self.poses.shape[0])
+
+    @property
+    def n_pt(self) -> int:
+        return int(self.points.shape[0])
+
+    @property
+    def n_obs(self) -> int:
+        return int(self.cam_idx.shape[0])
+
+
+def make_problem(
+    n_cam: int,
+    n_pt: int,
+    k_lo: int = 3,
+    k_hi: int = 9,
+    config_id: int = 99,
+    window: int = 64,
+    outlier_frac: float = 0.02,
+    name: str = "synthetic",
+    behind_frac: float = 0.0,
+) -> BAProblemData:
+    """Generate a synthetic BA problem (see module docstring).
+
+    `behind_frac` > 0 moves that fraction of the landmarks behind a camera's
+    image plane so that the cheirality branch (zero residual and Jacobian,
+    projection_factor.rs:227-238) is exercised.
+    """
+    rng = SplitMix(SEED_BASE + config_id)
+    W = min(window, n_cam)
+    k_hi = min(k_hi, W)
+    k_lo = min(k_lo, k_hi)
+
+    # --- cameras -----------------------------------------------------------
+    phi = 2.0 * np.pi * np.arange(n_cam) / n_cam
+    q_z = np.stack([np.cos(-phi / 2), np.zeros(n_cam), np.zeros(n_cam), np.sin(-phi / 2)], axis=-1)
+    q_p = np.broadcast_to(np.array([0.5, -0.5, -0.5, -0.5]), (n_cam, 4))
+    jitter = 0.01 * np.stack([rng.normal(10 + 2 * a, n_cam) for a in range(3)], axis=-1)
+    q_true = quat_mul(quat_mul(q_p, q_z), quat_exp(jitter))
+    t_true = np.tile(np.array([0.0, 0.0, -10.0]), (n_cam, 1))
+    truth_poses = np.concatenate([t_true, q_true], axis=-1)
+    f = 400.0 + 800.0 * rng.uniform(20, n_cam)
+    k1 = 1e-2 * rng.normal(21, n_cam)
+    k2 = 1e-3 * rng.normal(23, n_cam)
+    truth_intr = np.stack([f, k1, k2], axis=-1)
+
+    # --- landmarks ---------------------------------------------------------
+    truth_points = -2.0 + 4.0 * np.stack([rng.uniform(30 + a, n_pt) for a in range(3)], axis=-1)
+
+    # --- visibility: k_j distinct cameras, one per stratum of the window ----
+    kspan = k_hi - k_lo + 1
+    k = (k_lo + np.floor(rng.uniform(40, n_pt) * kspan)).astype(np.int64)
+    k = np.minimum(k, k_hi)
+    centre = (np.arange(n_pt, dtype=np.int64) * n_cam) // n_pt
+    pt_ptr = np.zeros(n_pt + 1, dtype=np.int64)
+    np.cumsum(k, out=pt_ptr[1:])
+    n_obs = int(pt_ptr[-1])
+    pt_idx = np.repeat(np.arange(n_pt, dtype=np.int64), k)
+    slot = np.arange(n_obs, dtype=np.int64) - pt_ptr[pt_idx]  # 0..k_j-1
+    kk = k[pt_idx]
+    stratum = W // kk
+    off = slot * stratum + np.floor(rng.uniform(41, n_obs) * stratum).astype(np.int64)
+    cam_idx = (centre[pt_idx] - W // 2 + off) % n_cam
+
+    # --- observations --------------------------------------------------------
+    uv = project_bal(truth_poses[cam_idx], truth_intr[cam_idx], truth_points[pt_idx])
+    uv += 0.5 * np.stack([rng.normal(50, n_obs), rng.normal(52, n_obs)], axis=-1)
+    is_out = rng.uniform(54, n_obs) < outlier_frac
+    uv += is_out[:, None] * (-20.0 + 40.0 * np.stack([rng.uniform(55, n_obs), rng.uniform(56, n_obs)], axis=-1))
+
+    # --- initial parameters = truth + noise ---------------------------------
+    points = truth_points + 1e-2 * np.stack([rng.normal(60 + 2 * a, n_pt) for a in range(3)], axis=-1)
+    if behind_frac > 0.0:
+        # push some landmarks far along +z of their first observing camera (behind it)
+        sel = rng.uniform(70, n_pt) < behind_frac
+        first_cam = cam_idx[pt_ptr[:-1]]
+        # camera centre direction in world: R^T e3 ; moving 25 along it puts p_cam.z > 0
+        qc = truth_poses[first_cam, 3:7] * np.array([1.0, -1.0, -1.0, -1.0])
+        dirw = quat_rotate(qc, np.tile(np.array([0.0, 0.0, 1.0]), (n_pt, 1)))
+        points = points + sel[:, None] * 25.0 * dirw
+    dtan = 1e-3 * np.stack([rng.normal(80 + 2 * a, n_cam) for a in range(6)], axis=-1)
+    # right-perturbation T*Exp(d) to first order is enough for an initial guess
+    q0 = quat_mul(q_true, quat_exp(dtan[:, 3:6]))
+    q0 /= np.linalg.norm(q0, axis=-1, keepdims=True)
+    t0 = t_true + quat_rotate(q_true, dtan[:, 0:3])
+    poses = np.concatenate([t0, q0], axis=-1)
+    intr = truth_intr.copy()
+    intr[:, 0] *= 1.0 + 1e-3 * rng.normal(90, n_cam)
+
+    return BAProblemData(
+        poses=np.ascontiguousarray(poses),
+        intr=np.ascontiguousarray(intr),
+        points=np.ascontiguousarray(points),
+        cam_idx=cam_idx.astype(np.uint32),
+        pt_idx=pt_idx.astype(np.uint32),
+        obs_uv=np.ascontiguousarray(uv),
+        name=name,
+        truth_poses=truth_poses,
+        truth_intr=truth_intr,
+        truth_points=truth_points,
+    )
+
+
+def make_named(shape: str, scale: float = 1.0) -> BAProblemData:
+    """One of the BASELINE.json shapes; `scale` < 1 shrinks cameras and landmarks
+    proportionally (same generator, same per-landmark statistics)."""
+    cid, n_cam, n_pt, k_lo, k_hi = SHAPES[shape]
+    if scale != 1.0:
+        n_cam = max(8, int(round(n_cam * scale)))
+        n_pt = max(16, int(round(n_pt * scale)))
+    nm = shape if scale == 1.0 else f"{shape}@{scale:g}"
+    return make_problem(n_cam, n_pt, k_lo, k_hi, config_id=cid, name=nm)
