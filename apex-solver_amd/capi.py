@@ -1,0 +1,153 @@
+"""ctypes binding of the C-ABI library (include/apexgpu.h).
+
+The library is the product: there is no Python/CPU fallback.  Loading fails loudly when
+`libapexgpu.so` is missing; every compute entry point returns an error when no MI355X is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libapexgpu.so")
+
+NUM_STAGES = 10
+STAGE_NAMES = ("cam_reduce", "landmark_reduce", "schur_scatter", "all_reduce", "factor", "tri_solve",
+               "back_substitute", "step_stats", "retract", "cost")
+
+# every symbol include/apexgpu.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = (
+    "apexgpu_create", "apexgpu_destroy", "apexgpu_last_error", "apexgpu_version", "apexgpu_set_structure",
+    "apexgpu_set_cg_params", "apexgpu_set_params", "apexgpu_get_params", "apexgpu_cost", "apexgpu_assemble", "apexgpu_solve_augmented",
+    "apexgpu_step_stats", "apexgpu_eval_step", "apexgpu_commit_step", "apexgpu_discard_step",
+    "apexgpu_parameter_norm", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
+    "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
+    "apexgpu_stage_times", "apexgpu_info", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_set_shard",
+)
+
+ERROR_NAMES = {
+    -1: "FactorizationFailed", -2: "SingularMatrix", -3: "SparseMatrixCreation", -4: "MatrixConversion",
+    -5: "InvalidInput", -6: "InvalidState", -10: "DeviceError",
+}
+
+
+class LinAlgError(RuntimeError):
+    """Mirror of apex-solver's LinAlgError (src/linalg/mod.rs:76-101): `.kind` is the variant name."""
+
+    def __init__(self, code: int, message: str):
+        self.code = code
+        self.kind = ERROR_NAMES.get(code, f"Error({code})")
+        super().__init__(f"{self.kind}: {message}")
+
+
+class LmConfigC(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int), ("cost_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double), ("damping", C.c_double), ("damping_min", C.c_double),
+        ("damping_max", C.c_double), ("damping_nu", C.c_double), ("trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double), ("min_cost_threshold", C.c_double), ("timeout_s", C.c_double),
+        ("variant", C.c_int),
+    ]
+
+
+class LmIterC(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("cost", "damping", "rho", "accepted", "gradient_norm", "step_norm",
+                                          "predicted_reduction", "trial_cost")]
+
+
+class LmResultC(C.Structure):
+    _fields_ = [
+        ("status", C.c_int), ("iterations", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("final_gradient_norm", C.c_double), ("final_step_norm", C.c_double), ("elapsed_s", C.c_double),
+        ("cost_evaluations", C.c_int), ("jacobian_evaluations", C.c_int), ("successful_steps", C.c_int),
+        ("unsuccessful_steps", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libapexgpu.so (built by __graft_entry__.build() / `make -C apex-solver_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')."
+            " There is no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
+    L.apexgpu_create.argtypes = [i64, i64, i64, C.c_int, C.c_int, C.POINTER(vp)]
+    L.apexgpu_destroy.argtypes = [vp]
+    L.apexgpu_destroy.restype = None
+    L.apexgpu_last_error.argtypes = [vp]
+    L.apexgpu_last_error.restype = C.c_char_p
+    L.apexgpu_version.restype = C.c_char_p
+    L.apexgpu_set_structure.argtypes = [vp] + [vp] * 9 + [dbl]
+    L.apexgpu_set_cg_params.argtypes = [vp, C.c_int, dbl]
+    L.apexgpu_set_params.argtypes = [vp, vp, vp, vp]
+    L.apexgpu_get_params.argtypes = [vp, vp, vp, vp]
+    L.apexgpu_cost.argtypes = [vp, C.POINTER(dbl)]
+    L.apexgpu_assemble.argtypes = [vp, dbl]
+    L.apexgpu_solve_augmented.argtypes = [vp, dbl, C.c_int, vp, vp]
+    L.apexgpu_step_stats.argtypes = [vp, C.POINTER(dbl * 3)]
+    L.apexgpu_eval_step.argtypes = [vp, C.POINTER(dbl)]
+    L.apexgpu_commit_step.argtypes = [vp]
+    L.apexgpu_discard_step.argtypes = [vp]
+    L.apexgpu_parameter_norm.argtypes = [vp, C.POINTER(dbl)]
+    L.apexgpu_lm_optimize.argtypes = [vp, C.POINTER(LmConfigC), C.POINTER(LmResultC), vp, C.c_int]
+    L.apexgpu_get_residual.argtypes = [vp, vp]
+    L.apexgpu_get_jacobian_blocks.argtypes = [vp, vp, vp]
+    L.apexgpu_get_schur.argtypes = [vp, vp, vp]
+    L.apexgpu_get_landmark_blocks.argtypes = [vp, vp, vp]
+    L.apexgpu_enable_stage_timing.argtypes = [vp, C.c_int]
+    L.apexgpu_reset_stage_times.argtypes = [vp]
+    L.apexgpu_stage_times.argtypes = [vp, C.POINTER(dbl * NUM_STAGES), C.POINTER(i64 * NUM_STAGES)]
+    L.apexgpu_info.argtypes = [vp, C.POINTER(dbl * 8)]
+    L.apexgpu_get_unique_id.argtypes = [vp]
+    L.apexgpu_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.apexgpu_set_shard.argtypes = [vp, C.c_int, C.c_int]
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if name not in ("apexgpu_destroy", "apexgpu_last_error", "apexgpu_version"):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def ptr(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Handle:
+    """RAII wrapper of an apexgpu_solver*."""
+
+    def __init__(self, n_cam: int, n_pt: int, n_obs: int, mode: int, device: int = 0):
+        self.L = load()
+        self.h = C.c_void_p()
+        rc = self.L.apexgpu_create(n_cam, n_pt, n_obs, mode, device, C.byref(self.h))
+        if rc != 0:
+            raise LinAlgError(rc, "apexgpu_create failed (no MI355X visible to HIP?)")
+        self.n_cam, self.n_pt, self.n_obs, self.mode = n_cam, n_pt, n_obs, mode
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise LinAlgError(rc, self.L.apexgpu_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.apexgpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

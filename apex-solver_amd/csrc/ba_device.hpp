@@ -1,0 +1,296 @@
+// ba_device.hpp -- per-observation bundle-adjustment math shared by every kernel.
+//
+// All functions are APEX_HD (host+device) so that tests/host_harness.cpp can run the very
+// same code on the CPU against the oracle; the kernels in ba_kernels.hip call them per lane.
+//
+// Reference semantics (file:line under the apex-solver tree):
+//   SE3::from(DVector)                crates/apex-manifolds/src/se3.rs:200-206, 107-113
+//   SE3::act / SO3::rotation_matrix    se3.rs:322-328 ; so3.rs:193-195, 359-366
+//   BALPinholeCameraStrict             crates/apex-camera-models/src/bal_pinhole.rs:154-156,
+//                                      273-296, 400-435, 528-556, 649-672
+//   ProjectionFactor::evaluate_internal src/factors/projection_factor.rs:184-296
+//   Huber + Corrector                  src/core/loss_functions.rs:364-380 ; corrector.rs:143-181
+//   3x3 inversion gate                 src/linalg/sparse/explicit_schur.rs:377-442
+//   SE3 right-plus retraction          se3.rs:569-583, 272-293 ; so3.rs:558-612
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#ifndef APEX_HD
+#if defined(__HIPCC__)
+#define APEX_HD __host__ __device__ __forceinline__
+#else
+#define APEX_HD inline
+#endif
+#endif
+
+namespace apex {
+
+constexpr double kMinDepth = 1e-6;          // apex-camera-models/src/lib.rs:80
+constexpr double kSmallAngle2 = 1e-10;      // apex-manifolds/src/lib.rs:61
+
+// Camera as the kernels see it: normalised quaternion, translation, intrinsics.
+struct Cam {
+    double t[3];
+    double q[4];  // w,x,y,z (unit)
+    double f, k1, k2;
+};
+
+// pose7 = [tx,ty,tz,qw,qx,qy,qz] as VariableEnum::to_vector() stores it (the quaternion may be
+// slightly non-unit after a compose); normalised twice like from_translation_quaternion.
+APEX_HD void load_cam(const double* __restrict__ pose7, const double* __restrict__ intr3, Cam& c) {
+    c.t[0] = pose7[0]; c.t[1] = pose7[1]; c.t[2] = pose7[2];
+    double w = pose7[3], x = pose7[4], y = pose7[5], z = pose7[6];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        double n = sqrt(w * w + x * x + y * y + z * z);
+        w /= n; x /= n; y /= n; z /= n;
+    }
+    c.q[0] = w; c.q[1] = x; c.q[2] = y; c.q[3] = z;
+    c.f = intr3[0]; c.k1 = intr3[1]; c.k2 = intr3[2];
+}
+
+APEX_HD void cross3(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// q v q*  as nalgebra's UnitQuaternion * Vector3: t = 2 (qv x v); t*w + qv x t + v
+APEX_HD void quat_rotate(const double q[4], const double v[3], double o[3]) {
+    double t[3], c[3];
+    cross3(q + 1, v, t);
+    t[0] *= 2.0; t[1] *= 2.0; t[2] *= 2.0;
+    cross3(q + 1, t, c);
+    o[0] = t[0] * q[0] + c[0] + v[0];
+    o[1] = t[1] * q[0] + c[1] + v[1];
+    o[2] = t[2] * q[0] + c[2] + v[2];
+}
+
+APEX_HD void quat_to_rot(const double q[4], double R[9]) {
+    double w = q[0], i = q[1], j = q[2], k = q[3];
+    double ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+    double ij = i * j * 2.0, wk = w * k * 2.0, wj = w * j * 2.0;
+    double ik = i * k * 2.0, jk = j * k * 2.0, wi = w * i * 2.0;
+    R[0] = ww + ii - jj - kk; R[1] = ij - wk;           R[2] = wj + ik;
+    R[3] = wk + ij;           R[4] = ww - ii + jj - kk; R[5] = jk - wi;
+    R[6] = ik - wj;           R[7] = wi + jk;           R[8] = ww - ii - jj + kk;
+}
+
+APEX_HD void quat_mul(const double a[4], const double b[4], double o[4]) {
+    double c[3];
+    cross3(a + 1, b + 1, c);
+    o[0] = a[0] * b[0] - (a[1] * b[1] + a[2] * b[2] + a[3] * b[3]);
+    o[1] = a[0] * b[1] + b[0] * a[1] + c[0];
+    o[2] = a[0] * b[2] + b[0] * a[2] + c[1];
+    o[3] = a[0] * b[3] + b[0] * a[3] + c[2];
+}
+
+// Huber weight sqrt(rho'(s)) for s = |r|^2 (delta <= 0: no loss function).  For Huber
+// rho'' <= 0, hence alpha = 0 and both J and r are scaled by sqrt(rho') (corrector.rs:156-162).
+APEX_HD double huber_sqrt_rho1(double delta, double s) {
+    if (delta > 0.0 && s > delta * delta) return sqrt(delta / sqrt(s));
+    return 1.0;
+}
+
+// Residual only (A16).  Returns validity; r is the CORRECTED residual.
+APEX_HD bool residual_obs(const Cam& c, const double pw[3], double u_obs, double v_obs,
+                          double huber_delta, double r[2]) {
+    double pc[3];
+    quat_rotate(c.q, pw, pc);
+    pc[0] += c.t[0]; pc[1] += c.t[1]; pc[2] += c.t[2];
+    if (!(pc[2] < -kMinDepth)) { r[0] = 0.0; r[1] = 0.0; return false; }
+    double inz = -1.0 / pc[2];
+    double xn = pc[0] * inz, yn = pc[1] * inz;
+    double r2 = xn * xn + yn * yn, r4 = r2 * r2;
+    double d = 1.0 + c.k1 * r2 + c.k2 * r4;
+    double r0 = c.f * (xn * d) - u_obs;
+    double r1 = c.f * (yn * d) - v_obs;
+    double w = huber_sqrt_rho1(huber_delta, r0 * r0 + r1 * r1);
+    r[0] = r0 * w; r[1] = r1 * w;
+    return true;
+}
+
+// Full linearisation of one observation (A1+A2+A4).  DC = 6: camera block = pose only
+// (BundleAdjustment keys [pose,pt]); DC = 9: [pose | intrinsics] (SelfCalibration).
+// Jc is 2 x DC (row-major [row][col]), Jl is 2 x 3; both CORRECTED (scaled by sqrt(rho')).
+template <int DC>
+APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, double v_obs,
+                           double huber_delta, double r[2], double Jc[2][DC], double Jl[2][3]) {
+    double pc[3];
+    quat_rotate(c.q, pw, pc);
+    pc[0] += c.t[0]; pc[1] += c.t[1]; pc[2] += c.t[2];
+    if (!(pc[2] < -kMinDepth)) {
+        r[0] = 0.0; r[1] = 0.0;
+#pragma unroll
+        for (int a = 0; a < DC; ++a) { Jc[0][a] = 0.0; Jc[1][a] = 0.0; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { Jl[0][a] = 0.0; Jl[1][a] = 0.0; }
+        return false;
+    }
+    const double f = c.f, k1 = c.k1, k2 = c.k2;
+    double inz = -1.0 / pc[2];
+    double xn = pc[0] * inz, yn = pc[1] * inz;
+    double r2 = xn * xn + yn * yn, r4 = r2 * r2;
+    double dist = 1.0 + k1 * r2 + k2 * r4;
+    double r0 = f * (xn * dist) - u_obs;
+    double r1 = f * (yn * dist) - v_obs;
+    // d(u,v)/d p_cam  (bal_pinhole.rs:400-435)
+    double dd = k1 + 2.0 * k2 * r2;
+    double dxn_dz = xn * inz, dyn_dz = yn * inz;
+    double dxd_dxn = dist + xn * dd * 2.0 * xn;
+    double dxd_dyn = xn * dd * 2.0 * yn;
+    double dyd_dxn = yn * dd * 2.0 * xn;
+    double dyd_dyn = dist + yn * dd * 2.0 * yn;
+    double Jp[2][3];
+    Jp[0][0] = f * (dxd_dxn * inz);
+    Jp[0][1] = f * (dxd_dyn * inz);
+    Jp[0][2] = f * (dxd_dxn * dxn_dz + dxd_dyn * dyn_dz);
+    Jp[1][0] = f * (dyd_dxn * inz);
+    Jp[1][1] = f * (dyd_dyn * inz);
+    Jp[1][2] = f * (dyd_dxn * dxn_dz + dyd_dyn * dyn_dz);
+    double R[9];
+    quat_to_rot(c.q, R);
+    double w = huber_sqrt_rho1(huber_delta, r0 * r0 + r1 * r1);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        // landmark block = Jp R ; pose block = [Jp R | -(Jp R)[p_w]x]  (bal_pinhole.rs:528-556:
+        // d p_cam/d delta = [R | -R [p_w]x], right perturbation delta = [rho; theta])
+        double a0 = Jp[rr][0] * R[0] + Jp[rr][1] * R[3] + Jp[rr][2] * R[6];
+        double a1 = Jp[rr][0] * R[1] + Jp[rr][1] * R[4] + Jp[rr][2] * R[7];
+        double a2 = Jp[rr][0] * R[2] + Jp[rr][1] * R[5] + Jp[rr][2] * R[8];
+        Jl[rr][0] = a0 * w; Jl[rr][1] = a1 * w; Jl[rr][2] = a2 * w;
+        Jc[rr][0] = a0 * w; Jc[rr][1] = a1 * w; Jc[rr][2] = a2 * w;
+        Jc[rr][3] = -(a1 * pw[2] - a2 * pw[1]) * w;
+        Jc[rr][4] = -(a2 * pw[0] - a0 * pw[2]) * w;
+        Jc[rr][5] = -(a0 * pw[1] - a1 * pw[0]) * w;
+    }
+    if (DC == 9) {
+        // d(u,v)/d(f,k1,k2)  (bal_pinhole.rs:649-672)
+        Jc[0][DC - 3] = (xn * dist) * w; Jc[0][DC - 2] = (f * xn * r2) * w; Jc[0][DC - 1] = (f * xn * r4) * w;
+        Jc[1][DC - 3] = (yn * dist) * w; Jc[1][DC - 2] = (f * yn * r2) * w; Jc[1][DC - 1] = (f * yn * r4) * w;
+    }
+    r[0] = r0 * w; r[1] = r1 * w;
+    return true;
+}
+
+// ---- 3x3 symmetric block: eigenvalue gate + inverse (A9) ---------------------------------
+// B (symmetric, row-major 9) -> Binv.  Returns false iff the (regularised) matrix has a zero
+// determinant (LinAlgError::SingularMatrix in the reference).
+APEX_HD void sym3_eig_minmax(const double B[9], double& mn, double& mx) {
+    double a[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = B[i];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+        if (off < 1e-300) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                double apq = a[3 * p + q];
+                if (apq != 0.0) {
+                    double app = a[3 * p + p], aqq = a[3 * q + q];
+                    double tau = (aqq - app) / (2.0 * apq);
+                    double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        double akp = a[3 * k + p], akq = a[3 * k + q];
+                        a[3 * k + p] = cs * akp - sn * akq;
+                        a[3 * k + q] = sn * akp + cs * akq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        double apk = a[3 * p + k], aqk = a[3 * q + k];
+                        a[3 * p + k] = cs * apk - sn * aqk;
+                        a[3 * q + k] = sn * apk + cs * aqk;
+                    }
+                }
+            }
+    }
+    mn = fmin(a[0], fmin(a[4], a[8]));
+    mx = fmax(a[0], fmax(a[4], a[8]));
+}
+
+APEX_HD bool mat3_try_inverse(const double m[9], double o[9]) {
+    double m11 = m[0], m12 = m[1], m13 = m[2];
+    double m21 = m[3], m22 = m[4], m23 = m[5];
+    double m31 = m[6], m32 = m[7], m33 = m[8];
+    double minor_m12_m23 = m22 * m33 - m32 * m23;
+    double minor_m11_m23 = m21 * m33 - m31 * m23;
+    double minor_m11_m22 = m21 * m32 - m31 * m22;
+    double det = m11 * minor_m12_m23 - m12 * minor_m11_m23 + m13 * minor_m11_m22;
+    if (det == 0.0) return false;
+    o[0] = minor_m12_m23 / det;
+    o[1] = (m13 * m32 - m33 * m12) / det;
+    o[2] = (m12 * m23 - m22 * m13) / det;
+    o[3] = -minor_m11_m23 / det;
+    o[4] = (m11 * m33 - m31 * m13) / det;
+    o[5] = (m13 * m21 - m23 * m11) / det;
+    o[6] = minor_m11_m22 / det;
+    o[7] = (m12 * m31 - m32 * m11) / det;
+    o[8] = (m11 * m22 - m21 * m12) / det;
+    return true;
+}
+
+// invert_landmark_blocks_with_lambda with lambda argument 0.0 (explicit_schur.rs:365-367)
+APEX_HD bool invert_landmark_block(const double B[9], double Binv[9]) {
+    double mn, mx, M[9];
+    sym3_eig_minmax(B, mn, mx);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] = B[i];
+    if (mn < 1e-12) {
+        double reg = 1e-6 + mx * 1e-6;  // lambda.max(1e-6) + max_ev * 1e-6 with lambda = 0
+        M[0] += reg; M[4] += reg; M[8] += reg;
+    } else if (mx / mn > 1e10) {
+        double reg = mx * 1e-6;
+        M[0] += reg; M[4] += reg; M[8] += reg;
+    }
+    return mat3_try_inverse(M, Binv);
+}
+
+// ---- SE3 right-plus (A15) -------------------------------------------------------------
+APEX_HD void so3_exp(const double th[3], double q[4]) {
+    double t2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+    if (t2 > kSmallAngle2) {
+        double hx = th[0] / 2.0, hy = th[1] / 2.0, hz = th[2] / 2.0;
+        double n = sqrt(hx * hx + hy * hy + hz * hz);
+        double s = sin(n) / n;
+        q[0] = cos(n); q[1] = hx * s; q[2] = hy * s; q[3] = hz * s;
+    } else {
+        double w = 1.0, x = th[0] / 2.0, y = th[1] / 2.0, z = th[2] / 2.0;
+        double n = sqrt(w * w + x * x + y * y + z * z);
+        q[0] = w / n; q[1] = x / n; q[2] = y / n; q[3] = z / n;
+    }
+}
+
+// V(theta) rho  with V = left Jacobian of SO(3) (so3.rs:595-612)
+APEX_HD void so3_left_jacobian_mul(const double th[3], const double rho[3], double o[3]) {
+    double a = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+    double k1[3], k2[3];
+    cross3(th, rho, k1);  // [th]x rho
+    cross3(th, k1, k2);   // [th]x^2 rho
+    if (a <= kSmallAngle2) {
+        o[0] = rho[0] + 0.5 * k1[0]; o[1] = rho[1] + 0.5 * k1[1]; o[2] = rho[2] + 0.5 * k1[2];
+        return;
+    }
+    double theta = sqrt(a), s = sin(theta), c = cos(theta);
+    double c1 = (1.0 - c) / a, c2 = (theta - s) / (a * theta);
+    o[0] = rho[0] + c1 * k1[0] + c2 * k2[0];
+    o[1] = rho[1] + c1 * k1[1] + c2 * k2[1];
+    o[2] = rho[2] + c1 * k1[2] + c2 * k2[2];
+}
+
+// pose7' = pose7 (+) delta6, stored un-normalised exactly like the reference keeps it.
+APEX_HD void se3_plus(const double pose[7], const double delta[6], double out[7]) {
+    double qe[4], te[3], qn[4], rt[3];
+    so3_exp(delta + 3, qe);
+    so3_left_jacobian_mul(delta + 3, delta, te);
+    quat_mul(pose + 3, qe, qn);
+    quat_rotate(pose + 3, te, rt);
+    out[0] = rt[0] + pose[0]; out[1] = rt[1] + pose[1]; out[2] = rt[2] + pose[2];
+    out[3] = qn[0]; out[4] = qn[1]; out[5] = qn[2]; out[6] = qn[3];
+}
+
+}  // namespace apex

@@ -1,0 +1,56 @@
+// ba_kernels.h -- host-visible declarations of the HIP kernels' launchers and argument PODs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace apex {
+
+constexpr int kNB = 144;          // S tile edge: 16*9 = 24*6, multiple of the 16-wide f64 MFMA
+constexpr int kScatterCap = 128;  // observations one Schur-scatter workgroup stages in LDS
+constexpr int kScatterBlk = 64;   // block size used to split landmarks with more observations
+
+// Read-only view of one parameter set + the landmark-major observation stream.
+struct BAView {
+    int64_t n_cam, n_pt, n_obs;
+    const double* poses;   // [n_cam][7]
+    const double* intr;    // [n_cam][3]
+    const double* pts;     // [n_pt][3]
+    const uint32_t* o_cam; // [n_obs] landmark-major
+    const uint32_t* o_pt;  // [n_obs]
+    const double2* o_uv;   // [n_obs]
+    const int* pt_ptr;     // [n_pt+1]
+    double huber_delta;
+};
+
+// Lower-triangular tile map of the reduced camera matrix S.
+struct TileMap {
+    double* tiles;       // slot-major tile storage
+    const int* slot;     // [nt*nt], slot[I*nt+J] for I >= J, -1 when the tile is structurally zero
+    int nt;
+};
+
+struct ScatterTask {
+    int i0, ni;  // first block of observations (landmark-major indices)
+    int j0, nj;  // second block (nj == 0: diagonal task)
+};
+
+void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* cam_ptr, const int* cam_obs,
+                       double lambda, int add_lambda, double* g_c, double* g_red, hipStream_t s);
+void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag,
+                            hipStream_t s);
+void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const ScatterTask* tasks, int n_tasks,
+                          const double* hinv, const double* g_l, double* g_red, hipStream_t s);
+void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
+                            double* dl, hipStream_t s);
+void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, const double* intr, const double* pts,
+                    const double* dcam, const double* dl, double sign, const uint8_t* fix_pose,
+                    const uint8_t* fix_intr, const uint8_t* fix_pt, double* poses_out, double* intr_out,
+                    double* pts_out, hipStream_t s);
+void launch_cost(const BAView& v, double* partial, int n_partial, double* out_sumsq, hipStream_t s);
+void launch_step_stats(int64_t n, const double* g, const double* d, double lambda, double* partial, int n_partial,
+                       double* out3, hipStream_t s);
+void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, double* out, hipStream_t s);
+void launch_export_linearization(int dc, const BAView& v, const int* o_orig, double* r_out, double* jc_out,
+                                 double* jl_out, hipStream_t s);
+
+}  // namespace apex

@@ -1,0 +1,555 @@
+// ba_kernels.hip -- CDNA4 (gfx950) kernels of the bundle-adjustment hot path.
+//
+// Data layout in HBM:
+//   observations   landmark-major (sorted by landmark): o_cam[n_obs] u32, o_pt[n_obs] u32,
+//                  o_uv[n_obs] double2 (one 16-B load per lane), pt_ptr[n_pt+1] i32
+//   cameras        poses[n_cam][7], intr[n_cam][3]   (<= 1.4 MB even for final-13682: L2-resident)
+//   landmarks      pts[n_pt][3]
+//   camera-major   cam_ptr[n_cam+1], cam_obs[n_obs] (indices into the sorted observation arrays)
+//   S              lower-triangular TILES of NB x NB = 144 x 144 doubles, tile (I,J) at
+//                  tiles + slot[I*nt+J]*NB*NB, row-major inside a tile.  144 = 16*9 = 24*6, so a
+//                  camera's 9 (or 6) rows never straddle a tile and 144 is a multiple of the
+//                  16-wide f64 MFMA.
+//
+// Kernels (one per stage; the per-observation math is recomputed from the 24-byte observation
+// record instead of streaming a 216-byte Jacobian row through HBM):
+//   k_cam_reduce       camera-major   H_cc diagonal blocks (+lambda), g_c, g_red := -g_c     (A6-A8)
+//   k_landmark_reduce  landmark-major H_ll, g_l, eigen-gated 3x3 inverse                     (A6, A8, A9)
+//   k_schur_scatter    landmark-major S -= (W Hll^-1) W^T, g_red += W Hll^-1 g_l             (A10, A11)
+//   k_back_substitute  landmark-major dl = Hll^-1 (-g_l - W^T dc)                            (A11)
+//   k_retract_*        x (+) d with the fixed-DOF mask                                       (A15)
+//   k_cost_partial     1/2 |r~|^2 on a (trial) parameter set                                 (A16)
+//   k_step_stats       |g|^2, |d|^2, d.(lambda d - g)                                        (A14)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ba_device.hpp"
+#include "ba_kernels.h"
+
+namespace apex {
+
+// ------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+
+// sum over the 256 threads of a block; result valid in thread 0.  `scratch` holds 4 doubles.
+__device__ __forceinline__ double block_sum_256(double v, double* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    __syncthreads();
+    return r;
+}
+
+template <int DC>
+__device__ __forceinline__ double* s_block_ptr(const TileMap& tm, uint32_t row_cam, uint32_t col_cam) {
+    constexpr int CPT = kNB / DC;  // cameras per tile
+    const uint32_t I = row_cam / CPT, J = col_cam / CPT;
+    const int slot = tm.slot[(size_t)I * tm.nt + J];
+    return tm.tiles + (size_t)slot * (kNB * kNB) + (size_t)((row_cam % CPT) * DC) * kNB + (col_cam % CPT) * DC;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: camera-major reduction.  One 256-thread workgroup per camera; every lane walks the
+// camera's observation list with stride 256, keeps the upper triangle of Jc^T Jc and Jc^T r in
+// registers, then a fixed-order wave/LDS reduction (bitwise reproducible).
+// Writes (plain stores, no atomics) the lower triangle of the camera's diagonal block of S
+// (+lambda on the diagonal when add_lambda), g_c and g_red := -g_c.
+// ------------------------------------------------------------------------------------------
+template <int DC>
+__global__ __launch_bounds__(256) void k_cam_reduce(BAView v, TileMap tm, const int* __restrict__ cam_ptr,
+                                                      const int* __restrict__ cam_obs, double lambda,
+                                                      int add_lambda, double* __restrict__ g_c,
+                                                      double* __restrict__ g_red) {
+    constexpr int NH = DC * (DC + 1) / 2;
+    const uint32_t c = blockIdx.x;
+    __shared__ double red[4][NH + DC];
+    double acc[NH + DC];
+#pragma unroll
+    for (int i = 0; i < NH + DC; ++i) acc[i] = 0.0;
+    Cam cam;
+    load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+    const int b = cam_ptr[c], e = cam_ptr[c + 1];
+    for (int k = b + (int)threadIdx.x; k < e; k += 256) {
+        const int i = cam_obs[k];
+        const uint32_t l = v.o_pt[i];
+        const double2 uv = v.o_uv[i];
+        const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
+        double r[2], Jc[2][DC], Jl[2][3];
+        linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < DC; ++a)
+#pragma unroll
+            for (int bb = 0; bb <= a; ++bb) acc[idx++] += Jc[0][a] * Jc[0][bb] + Jc[1][a] * Jc[1][bb];
+#pragma unroll
+        for (int a = 0; a < DC; ++a) acc[NH + a] += Jc[0][a] * r[0] + Jc[1][a] * r[1];
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NH + DC; ++i) {
+        double s = wave_sum(acc[i]);
+        if (lane == 0) red[w][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NH + DC) {
+        const int i = threadIdx.x;
+        const double s = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        if (i < NH) {
+            // packed lower index -> (a,b), a >= b
+            int a = 0;
+            while ((a + 1) * (a + 2) / 2 <= i) ++a;
+            const int bb = i - a * (a + 1) / 2;
+            double* blk = s_block_ptr<DC>(tm, c, c);
+            blk[a * kNB + bb] = s + ((a == bb && add_lambda) ? lambda : 0.0);
+        } else {
+            const int a = i - NH;
+            g_c[(size_t)c * DC + a] = s;
+            g_red[(size_t)c * DC + a] = -s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2a: landmark-major reduction, 8 lanes per landmark (32 landmarks per 256-thread block).
+// H_ll = sum Jl^T Jl + lambda I, g_l = sum Jl^T r, eigen-gated inverse.
+// ------------------------------------------------------------------------------------------
+template <int DC>
+__global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda, double* __restrict__ hinv,
+                                                           double* __restrict__ g_l, int* __restrict__ err_flag) {
+    const int g = threadIdx.x & 7;
+    const int64_t l = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool active = l < v.n_pt;
+    double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
+    if (active) {
+        const int b = v.pt_ptr[l], e = v.pt_ptr[l + 1];
+        const double pw[3] = {v.pts[3 * l], v.pts[3 * l + 1], v.pts[3 * l + 2]};
+        for (int i = b + g; i < e; i += 8) {
+            const uint32_t c = v.o_cam[i];
+            const double2 uv = v.o_uv[i];
+            Cam cam;
+            load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+            double r[2], Jc[2][DC], Jl[2][3];
+            linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
+            h[0] += Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0];
+            h[1] += Jl[0][1] * Jl[0][0] + Jl[1][1] * Jl[1][0];
+            h[2] += Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1];
+            h[3] += Jl[0][2] * Jl[0][0] + Jl[1][2] * Jl[1][0];
+            h[4] += Jl[0][2] * Jl[0][1] + Jl[1][2] * Jl[1][1];
+            h[5] += Jl[0][2] * Jl[0][2] + Jl[1][2] * Jl[1][2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) gl[a] += Jl[0][a] * r[0] + Jl[1][a] * r[1];
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) h[i] += __shfl_xor(h[i], m, 8);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gl[i] += __shfl_xor(gl[i], m, 8);
+    }
+    if (active && g == 0) {
+        double B[9] = {h[0] + lambda, h[1], h[3], h[1], h[2] + lambda, h[4], h[3], h[4], h[5] + lambda};
+        double Bi[9];
+        if (!invert_landmark_block(B, Bi)) {
+            atomicExch(err_flag, 1);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Bi[i] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) hinv[9 * l + i] = Bi[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g_l[3 * l + i] = gl[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2b: the Schur reduction.  One 256-thread workgroup per TASK.
+//   diagonal task  : observations [i0, i0+ni) (<= 128, whole landmarks or one block of a big
+//                    landmark); pairs (i <= j) inside the same landmark.
+//   off-diag task  : two disjoint blocks [i0,i0+ni), [j0,j0+nj) of ONE big landmark (<= 64 each);
+//                    all ni*nj pairs.
+// Phase 1: one lane per observation recomputes the Jacobian blocks, forms W = Jc^T Jl (DC x 3) and
+//          Y = W Hll^-1, parks both in LDS, and (diagonal tasks) adds Y g_l into g_red.
+// Phase 2: the DC*DC elements of each pair's block are spread over consecutive lanes, so one wave
+//          atomic instruction covers 64 consecutive elements (DC-long contiguous row segments of
+//          one S block) instead of 64 different blocks.
+// ------------------------------------------------------------------------------------------
+template <int DC>
+__global__ __launch_bounds__(256) void k_schur_scatter(BAView v, TileMap tm, const ScatterTask* __restrict__ tasks,
+                                                         const double* __restrict__ hinv,
+                                                         const double* __restrict__ g_l,
+                                                         double* __restrict__ g_red) {
+    constexpr int WY = DC * 3;
+    constexpr int E = DC * DC;
+    constexpr int PP = 256 / E;  // pairs per sweep
+    __shared__ double sW[kScatterCap * WY];
+    __shared__ double sY[kScatterCap * WY];
+    __shared__ uint32_t sCam[kScatterCap];
+    __shared__ int sEnd[kScatterCap];      // local index one past the last obs of this obs' landmark
+    __shared__ int sScan[kScatterCap + 1]; // pair offsets (diagonal tasks)
+    const ScatterTask t = tasks[blockIdx.x];
+    const int n = t.ni + t.nj;
+    const int tid = threadIdx.x;
+
+    if (tid < n) {
+        const int i = (tid < t.ni) ? t.i0 + tid : t.j0 + (tid - t.ni);
+        const uint32_t c = v.o_cam[i];
+        const uint32_t l = v.o_pt[i];
+        const double2 uv = v.o_uv[i];
+        Cam cam;
+        load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+        const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
+        double r[2], Jc[2][DC], Jl[2][3];
+        linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
+        double Hi[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Hi[k] = hinv[9 * (size_t)l + k];
+        double yg[DC];
+#pragma unroll
+        for (int a = 0; a < DC; ++a) {
+            const double w0 = Jc[0][a] * Jl[0][0] + Jc[1][a] * Jl[1][0];
+            const double w1 = Jc[0][a] * Jl[0][1] + Jc[1][a] * Jl[1][1];
+            const double w2 = Jc[0][a] * Jl[0][2] + Jc[1][a] * Jl[1][2];
+            const double y0 = w0 * Hi[0] + w1 * Hi[3] + w2 * Hi[6];
+            const double y1 = w0 * Hi[1] + w1 * Hi[4] + w2 * Hi[7];
+            const double y2 = w0 * Hi[2] + w1 * Hi[5] + w2 * Hi[8];
+            sW[tid * WY + 3 * a + 0] = w0; sW[tid * WY + 3 * a + 1] = w1; sW[tid * WY + 3 * a + 2] = w2;
+            sY[tid * WY + 3 * a + 0] = y0; sY[tid * WY + 3 * a + 1] = y1; sY[tid * WY + 3 * a + 2] = y2;
+            yg[a] = y0 * g_l[3 * (size_t)l] + y1 * g_l[3 * (size_t)l + 1] + y2 * g_l[3 * (size_t)l + 2];
+        }
+        sCam[tid] = c;
+        if (t.nj == 0) {
+            // g_red = -g_c + W Hll^-1 g_l   (explicit_schur.rs:928-977 with the signs folded)
+#pragma unroll
+            for (int a = 0; a < DC; ++a) unsafeAtomicAdd(&g_red[(size_t)c * DC + a], yg[a]);
+            int e = v.pt_ptr[l + 1] - t.i0;  // local end of this landmark, clipped to the task
+            sEnd[tid] = e < t.ni ? e : t.ni;
+        }
+    }
+    __syncthreads();
+
+    int n_pairs;
+    if (t.nj == 0) {
+        // exclusive scan of (end - i) over the task's observations (<= 128 values)
+        if (tid < kScatterCap) sScan[tid] = (tid < t.ni) ? (sEnd[tid] - tid) : 0;
+        __syncthreads();
+        for (int off = 1; off < kScatterCap; off <<= 1) {
+            int x = 0;
+            if (tid < kScatterCap && tid >= off) x = sScan[tid - off];
+            __syncthreads();
+            if (tid < kScatterCap) sScan[tid] += x;
+            __syncthreads();
+        }
+        n_pairs = sScan[kScatterCap - 1];  // inclusive total
+    } else {
+        n_pairs = t.ni * t.nj;
+    }
+
+    const int grp = tid / E, e = tid - grp * E;
+    if (grp < PP) {
+        const int a = e / DC, b = e - a * DC;
+        for (int p = grp; p < n_pairs; p += PP) {
+            int i, j;
+            if (t.nj == 0) {
+                // find i with excl(i) <= p < incl(i): binary search over inclusive sums
+                int lo = 0, hi = t.ni - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sScan[mid] > p) hi = mid; else lo = mid + 1;
+                }
+                i = lo;
+                const int excl = (i == 0) ? 0 : sScan[i - 1];
+                j = i + (p - excl);
+            } else {
+                i = p / t.nj;
+                j = t.ni + (p - i * t.nj);
+            }
+            const uint32_t ci = sCam[i], cj = sCam[j];
+            const double* Yi = sY + i * WY + 3 * a;
+            const double* Wj = sW + j * WY + 3 * b;
+            if (i == j) {
+                if (a >= b) {
+                    const double val = Yi[0] * Wj[0] + Yi[1] * Wj[1] + Yi[2] * Wj[2];
+                    unsafeAtomicAdd(s_block_ptr<DC>(tm, ci, ci) + a * kNB + b, -val);
+                }
+            } else if (ci == cj) {
+                if (a >= b) {
+                    const double* Yj = sY + j * WY + 3 * a;
+                    const double* Wi = sW + i * WY + 3 * b;
+                    const double val = (Yi[0] * Wj[0] + Yi[1] * Wj[1] + Yi[2] * Wj[2]) +
+                                       (Yj[0] * Wi[0] + Yj[1] * Wi[1] + Yj[2] * Wi[2]);
+                    unsafeAtomicAdd(s_block_ptr<DC>(tm, ci, ci) + a * kNB + b, -val);
+                }
+            } else if (ci > cj) {
+                const double val = Yi[0] * Wj[0] + Yi[1] * Wj[1] + Yi[2] * Wj[2];
+                unsafeAtomicAdd(s_block_ptr<DC>(tm, ci, cj) + a * kNB + b, -val);
+            } else {
+                const double* Yj = sY + j * WY + 3 * a;
+                const double* Wi = sW + i * WY + 3 * b;
+                const double val = Yj[0] * Wi[0] + Yj[1] * Wi[1] + Yj[2] * Wi[2];
+                unsafeAtomicAdd(s_block_ptr<DC>(tm, cj, ci) + a * kNB + b, -val);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: back-substitution, 8 lanes per landmark: dl = Hll^-1 ((-g)_l - H_cl^T dc)
+// (explicit_schur.rs:980-1029); H_cl^T dc = sum_i Jl_i^T (Jc_i dc_ci).
+// ------------------------------------------------------------------------------------------
+template <int DC>
+__global__ __launch_bounds__(256) void k_back_substitute(BAView v, const double* __restrict__ hinv,
+                                                           const double* __restrict__ g_l,
+                                                           const double* __restrict__ dc,
+                                                           double* __restrict__ dl) {
+    const int g = threadIdx.x & 7;
+    const int64_t l = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool active = l < v.n_pt;
+    double acc[3] = {0, 0, 0};
+    if (active) {
+        const int b = v.pt_ptr[l], e = v.pt_ptr[l + 1];
+        const double pw[3] = {v.pts[3 * l], v.pts[3 * l + 1], v.pts[3 * l + 2]};
+        for (int i = b + g; i < e; i += 8) {
+            const uint32_t c = v.o_cam[i];
+            const double2 uv = v.o_uv[i];
+            Cam cam;
+            load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+            double r[2], Jc[2][DC], Jl[2][3];
+            linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int a = 0; a < DC; ++a) {
+                const double d = dc[(size_t)c * DC + a];
+                s0 += Jc[0][a] * d; s1 += Jc[1][a] * d;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[a] += Jl[0][a] * s0 + Jl[1][a] * s1;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] += __shfl_xor(acc[i], m, 8);
+    if (active && g == 0) {
+        const double rhs[3] = {-g_l[3 * l] - acc[0], -g_l[3 * l + 1] - acc[1], -g_l[3 * l + 2] - acc[2]};
+        const double* Hi = hinv + 9 * l;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dl[3 * l + a] = Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// A15 retraction.  dc is camera-major [cam][DC] (pose tangent first, then intrinsics).
+// ------------------------------------------------------------------------------------------
+template <int DC>
+__global__ __launch_bounds__(256) void k_retract_cams(int64_t n_cam, const double* __restrict__ poses,
+                                                        const double* __restrict__ intr,
+                                                        const double* __restrict__ dc, double sign,
+                                                        const uint8_t* __restrict__ fix_pose,
+                                                        const uint8_t* __restrict__ fix_intr,
+                                                        double* __restrict__ poses_out,
+                                                        double* __restrict__ intr_out) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cam) return;
+    double d[6], p[7], o[7];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) d[a] = fix_pose[6 * c + a] ? 0.0 : sign * dc[c * DC + a];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) p[a] = poses[7 * c + a];
+    se3_plus(p, d, o);
+#pragma unroll
+    for (int a = 0; a < 7; ++a) poses_out[7 * c + a] = o[a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double di = 0.0;
+        if (DC == 9) di = fix_intr[3 * c + a] ? 0.0 : sign * dc[c * DC + 6 + a];
+        intr_out[3 * c + a] = intr[3 * c + a] + di;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_retract_points(int64_t n3, const double* __restrict__ pts,
+                                                          const double* __restrict__ dl, double sign,
+                                                          const uint8_t* __restrict__ fix_pt,
+                                                          double* __restrict__ pts_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n3) return;
+    const double d = fix_pt[i] ? 0.0 : sign * dl[i];
+    pts_out[i] = pts[i] + d;
+}
+
+// ------------------------------------------------------------------------------------------
+// A16 cost: per-block partial sums of |r~|^2 (grid-stride, fixed geometry -> reproducible).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cost_partial(BAView v, double* __restrict__ partial) {
+    __shared__ double scratch[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < v.n_obs; i += (int64_t)gridDim.x * 256) {
+        const uint32_t c = v.o_cam[i], l = v.o_pt[i];
+        const double2 uv = v.o_uv[i];
+        Cam cam;
+        load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+        const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
+        double r[2];
+        residual_obs(cam, pw, uv.x, uv.y, v.huber_delta, r);
+        s += r[0] * r[0] + r[1] * r[1];
+    }
+    s = block_sum_256(s, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// out[k] = sum_i partial[i*stride + k], k < nk, in index order (single block, reproducible)
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int n, int nk,
+                                                        double* __restrict__ out) {
+    __shared__ double scratch[4];
+    for (int k = 0; k < nk; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) s += partial[(size_t)i * nk + k];
+        s = block_sum_256(s, scratch);
+        if (threadIdx.x == 0) out[k] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// A14 step statistics over a vector pair (g, d): partial[b] = {sum g^2, sum d^2, sum d (lambda d - g)}
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_step_stats(int64_t n, const double* __restrict__ g,
+                                                      const double* __restrict__ d, double lambda,
+                                                      double* __restrict__ partial) {
+    __shared__ double scratch[4];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double gi = g[i], di = d[i];
+        a += gi * gi; b += di * di; c += di * (lambda * di - gi);
+    }
+    a = block_sum_256(a, scratch);
+    b = block_sum_256(b, scratch);
+    c = block_sum_256(c, scratch);
+    if (threadIdx.x == 0) { partial[3 * blockIdx.x] = a; partial[3 * blockIdx.x + 1] = b; partial[3 * blockIdx.x + 2] = c; }
+}
+
+// sum of squares of a parameter array (compute_parameter_norm, optimizer/mod.rs:458-467)
+__global__ __launch_bounds__(256) void k_sumsq_partial(int64_t n, const double* __restrict__ x,
+                                                         double* __restrict__ partial) {
+    __shared__ double scratch[4];
+    double a = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += x[i] * x[i];
+    a = block_sum_256(a, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+
+// per-observation corrected residual and Jacobian blocks in the CALLER's observation order
+// (parity/debug export: apexgpu_get_residual / apexgpu_get_jacobian_blocks)
+template <int DC>
+__global__ __launch_bounds__(256) void k_export_linearization(BAView v, const int* __restrict__ o_orig,
+                                                                double* __restrict__ r_out,
+                                                                double* __restrict__ jc_out,
+                                                                double* __restrict__ jl_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= v.n_obs) return;
+    const uint32_t c = v.o_cam[i], l = v.o_pt[i];
+    const double2 uv = v.o_uv[i];
+    Cam cam;
+    load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+    const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
+    double r[2], Jc[2][DC], Jl[2][3];
+    linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
+    const int64_t o = o_orig[i];
+    if (r_out) { r_out[2 * o] = r[0]; r_out[2 * o + 1] = r[1]; }
+    if (jc_out)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int a = 0; a < DC; ++a) jc_out[(2 * o + rr) * DC + a] = Jc[rr][a];
+    if (jl_out)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) jl_out[(2 * o + rr) * 3 + a] = Jl[rr][a];
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers (the only symbols the host code sees)
+// ------------------------------------------------------------------------------------------
+static inline int grid_for(int64_t n, int per_block, int cap) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (cap > 0 && g > cap) g = cap;
+    return (int)g;
+}
+
+void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* cam_ptr, const int* cam_obs,
+                       double lambda, int add_lambda, double* g_c, double* g_red, hipStream_t s) {
+    if (v.n_cam == 0) return;
+    if (dc == 9) hipLaunchKernelGGL(k_cam_reduce<9>, dim3((unsigned)v.n_cam), dim3(256), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, g_c, g_red);
+    else hipLaunchKernelGGL(k_cam_reduce<6>, dim3((unsigned)v.n_cam), dim3(256), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, g_c, g_red);
+}
+
+void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag, hipStream_t s) {
+    if (v.n_pt == 0) return;
+    const int grid = grid_for(v.n_pt, 32, 0);
+    if (dc == 9) hipLaunchKernelGGL(k_landmark_reduce<9>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag);
+    else hipLaunchKernelGGL(k_landmark_reduce<6>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag);
+}
+
+void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const ScatterTask* tasks, int n_tasks,
+                          const double* hinv, const double* g_l, double* g_red, hipStream_t s) {
+    if (n_tasks == 0) return;
+    if (dc == 9) hipLaunchKernelGGL(k_schur_scatter<9>, dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, hinv, g_l, g_red);
+    else hipLaunchKernelGGL(k_schur_scatter<6>, dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, hinv, g_l, g_red);
+}
+
+void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
+                            double* dl, hipStream_t s) {
+    if (v.n_pt == 0) return;
+    const int grid = grid_for(v.n_pt, 32, 0);
+    if (dc == 9) hipLaunchKernelGGL(k_back_substitute<9>, dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl);
+    else hipLaunchKernelGGL(k_back_substitute<6>, dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl);
+}
+
+void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, const double* intr, const double* pts,
+                    const double* dcam, const double* dl, double sign, const uint8_t* fix_pose,
+                    const uint8_t* fix_intr, const uint8_t* fix_pt, double* poses_out, double* intr_out,
+                    double* pts_out, hipStream_t s) {
+    if (n_cam > 0) {
+        const int grid = grid_for(n_cam, 256, 0);
+        if (dc == 9) hipLaunchKernelGGL(k_retract_cams<9>, dim3(grid), dim3(256), 0, s, n_cam, poses, intr, dcam, sign, fix_pose, fix_intr, poses_out, intr_out);
+        else hipLaunchKernelGGL(k_retract_cams<6>, dim3(grid), dim3(256), 0, s, n_cam, poses, intr, dcam, sign, fix_pose, fix_intr, poses_out, intr_out);
+    }
+    if (n_pt > 0)
+        hipLaunchKernelGGL(k_retract_points, dim3(grid_for(3 * n_pt, 256, 0)), dim3(256), 0, s, 3 * n_pt, pts, dl, sign, fix_pt, pts_out);
+}
+
+void launch_cost(const BAView& v, double* partial, int n_partial, double* out_sumsq, hipStream_t s) {
+    hipLaunchKernelGGL(k_cost_partial, dim3(n_partial), dim3(256), 0, s, v, partial);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n_partial, 1, out_sumsq);
+}
+
+void launch_step_stats(int64_t n, const double* g, const double* d, double lambda, double* partial, int n_partial,
+                       double* out3, hipStream_t s) {
+    hipLaunchKernelGGL(k_step_stats, dim3(n_partial), dim3(256), 0, s, n, g, d, lambda, partial);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n_partial, 3, out3);
+}
+
+void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sumsq_partial, dim3(n_partial), dim3(256), 0, s, n, x, partial);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n_partial, 1, out);
+}
+
+void launch_export_linearization(int dc, const BAView& v, const int* o_orig, double* r_out, double* jc_out,
+                                 double* jl_out, hipStream_t s) {
+    if (v.n_obs == 0) return;
+    const int grid = grid_for(v.n_obs, 256, 0);
+    if (dc == 9) hipLaunchKernelGGL(k_export_linearization<9>, dim3(grid), dim3(256), 0, s, v, o_orig, r_out, jc_out, jl_out);
+    else hipLaunchKernelGGL(k_export_linearization<6>, dim3(grid), dim3(256), 0, s, v, o_orig, r_out, jc_out, jl_out);
+}
+
+}  // namespace apex

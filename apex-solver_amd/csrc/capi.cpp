@@ -1,0 +1,139 @@
+// capi.cpp -- extern "C" surface declared in include/apexgpu.h.
+#include "../../include/apexgpu.h"
+
+#include <new>
+#include <string>
+
+#include "solver.h"
+#ifdef APEX_WITH_RCCL
+#include <rccl/rccl.h>
+#include <string.h>
+#endif
+
+struct apexgpu_solver {
+    apex::Solver* s;
+    std::string create_error;
+};
+
+static_assert(sizeof(apexgpu_lm_config) == sizeof(apex::LmConfig), "LmConfig layout");
+static_assert(sizeof(apexgpu_lm_iter) == sizeof(apex::LmIterRecord), "LmIterRecord layout");
+static_assert(sizeof(apexgpu_lm_result) == sizeof(apex::LmResult), "LmResult layout");
+static_assert(APEXGPU_NUM_STAGES == apex::kNumStages, "stage count");
+
+#define H_OR_FAIL            \
+    if (!h || !h->s) return APEXGPU_ERR_INVALID_STATE
+
+extern "C" {
+
+const char* apexgpu_version(void) { return "apexgpu 0.1 (gfx950)"; }
+
+int apexgpu_create(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device, apexgpu_solver** out) {
+    if (!out) return APEXGPU_ERR_INVALID_INPUT;
+    *out = nullptr;
+    if (mode != APEXGPU_MODE_BUNDLE_ADJUSTMENT && mode != APEXGPU_MODE_SELF_CALIBRATION) return APEXGPU_ERR_INVALID_INPUT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return APEXGPU_ERR_DEVICE;
+    apexgpu_solver* h = new (std::nothrow) apexgpu_solver();
+    if (!h) return APEXGPU_ERR_INVALID_STATE;
+    h->s = new (std::nothrow) apex::Solver(n_cam, n_pt, n_obs, mode, device);
+    if (!h->s) { delete h; return APEXGPU_ERR_INVALID_STATE; }
+    *out = h;
+    return APEXGPU_OK;
+}
+
+void apexgpu_destroy(apexgpu_solver* h) {
+    if (!h) return;
+    delete h->s;
+    delete h;
+}
+
+const char* apexgpu_last_error(const apexgpu_solver* h) { return (h && h->s) ? h->s->last_error() : "invalid handle"; }
+
+int apexgpu_set_structure(apexgpu_solver* h, const uint32_t* cam_idx, const uint32_t* pt_idx, const double* obs_uv,
+                          const int64_t* intr_col, const int64_t* pose_col, const int64_t* pt_col,
+                          const uint8_t* fix_pose, const uint8_t* fix_intr, const uint8_t* fix_pt, double huber_delta) {
+    H_OR_FAIL;
+    if (!cam_idx || !pt_idx || !obs_uv || !intr_col || !pose_col || !pt_col) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->set_structure(cam_idx, pt_idx, obs_uv, intr_col, pose_col, pt_col, fix_pose, fix_intr, fix_pt, huber_delta);
+}
+int apexgpu_set_cg_params(apexgpu_solver* h, int max_iterations, double tolerance) {
+    H_OR_FAIL;
+    h->s->set_cg_params(max_iterations, tolerance);
+    return APEXGPU_OK;
+}
+int apexgpu_set_params(apexgpu_solver* h, const double* poses, const double* intr, const double* points) {
+    H_OR_FAIL;
+    if (!poses || !intr || !points) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->set_params(poses, intr, points);
+}
+int apexgpu_get_params(apexgpu_solver* h, double* poses, double* intr, double* points) {
+    H_OR_FAIL;
+    if (!poses || !intr || !points) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->get_params(poses, intr, points);
+}
+int apexgpu_cost(apexgpu_solver* h, double* cost) { H_OR_FAIL; return h->s->cost(cost); }
+int apexgpu_solve_augmented(apexgpu_solver* h, double lambda, int variant, double* step_out, double* grad_out) {
+    H_OR_FAIL;
+    if (variant != APEXGPU_VARIANT_SPARSE && variant != APEXGPU_VARIANT_ITERATIVE) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->solve_augmented(lambda, variant, step_out, grad_out);
+}
+int apexgpu_assemble(apexgpu_solver* h, double lambda) { H_OR_FAIL; return h->s->assemble_only(lambda); }
+int apexgpu_step_stats(apexgpu_solver* h, double out3[3]) { H_OR_FAIL; return h->s->step_stats(out3); }
+int apexgpu_eval_step(apexgpu_solver* h, double* trial_cost) { H_OR_FAIL; return h->s->eval_step(1.0, trial_cost); }
+int apexgpu_commit_step(apexgpu_solver* h) { H_OR_FAIL; return h->s->commit_step(); }
+int apexgpu_discard_step(apexgpu_solver* h) { H_OR_FAIL; return h->s->discard_step(); }
+int apexgpu_parameter_norm(apexgpu_solver* h, double* out) { H_OR_FAIL; return h->s->parameter_norm(out); }
+
+int apexgpu_lm_optimize(apexgpu_solver* h, apexgpu_lm_config* cfg, apexgpu_lm_result* result, apexgpu_lm_iter* history,
+                        int history_capacity) {
+    H_OR_FAIL;
+    if (!cfg || !result) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->lm_optimize(reinterpret_cast<apex::LmConfig*>(cfg), reinterpret_cast<apex::LmResult*>(result),
+                             reinterpret_cast<apex::LmIterRecord*>(history), history ? history_capacity : 0);
+}
+
+int apexgpu_get_residual(apexgpu_solver* h, double* r_out) { H_OR_FAIL; return h->s->get_residual(r_out); }
+int apexgpu_get_jacobian_blocks(apexgpu_solver* h, double* jc_out, double* jl_out) {
+    H_OR_FAIL;
+    return h->s->get_jacobian_blocks(jc_out, jl_out);
+}
+int apexgpu_get_schur(apexgpu_solver* h, double* S_out, double* gred_out) { H_OR_FAIL; return h->s->get_schur(S_out, gred_out); }
+int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out, double* gl_out) {
+    H_OR_FAIL;
+    return h->s->get_landmark_blocks(hinv_out, gl_out);
+}
+
+int apexgpu_enable_stage_timing(apexgpu_solver* h, int on) { H_OR_FAIL; h->s->enable_stage_timing(on != 0); return APEXGPU_OK; }
+int apexgpu_reset_stage_times(apexgpu_solver* h) { H_OR_FAIL; h->s->reset_stage_times(); return APEXGPU_OK; }
+int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_t calls[APEXGPU_NUM_STAGES]) {
+    H_OR_FAIL;
+    h->s->stage_times(ms, calls);
+    return APEXGPU_OK;
+}
+int apexgpu_info(apexgpu_solver* h, double info[8]) {
+    H_OR_FAIL;
+    info[0] = h->s->n_tile_rows(); info[1] = (double)h->s->tile_count(); info[2] = h->s->schur_scatter_pairs();
+    info[3] = (double)h->s->cam_dof_internal(); info[4] = h->s->last_reg(); info[5] = h->s->last_pcg_iters();
+    info[6] = h->s->touched_tiles(); info[7] = h->s->local_obs();
+    return APEXGPU_OK;
+}
+
+int apexgpu_get_unique_id(void* out128) {
+#ifdef APEX_WITH_RCCL
+    if (!out128) return APEXGPU_ERR_INVALID_INPUT;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return APEXGPU_ERR_DEVICE;
+    memcpy(out128, &id, 128);
+    return APEXGPU_OK;
+#else
+    (void)out128;
+    return APEXGPU_ERR_INVALID_STATE;
+#endif
+}
+int apexgpu_comm_init(apexgpu_solver* h, int world, int rank, const void* unique_id128) {
+    H_OR_FAIL;
+    return h->s->comm_init(world, rank, unique_id128);
+}
+int apexgpu_set_shard(apexgpu_solver* h, int rank, int world) { H_OR_FAIL; return h->s->set_shard(rank, world); }
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// chol_kernels.h -- launchers of the tile Cholesky / triangular-solve / PCG kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ba_kernels.h"
+
+namespace apex {
+
+struct GemmTask {  // C = beta*C + alpha * A * B^T on 144x144 row-major tiles
+    double* C;
+    const double* A;
+    const double* B;
+};
+
+struct GemvTask {  // see k_tile_gemv for the modes
+    const double* A;
+    int xo, yo;    // element offsets of the 144-long x and y blocks
+    int mode;
+};
+
+struct SymEntry {  // one tile of block-row I of the symmetric tile matrix
+    int slot;      // tile slot
+    int other;     // the other block index (column block for kind 0/2, row block for kind 1)
+    int kind;      // 0: tile (I,other) other<I ; 1: tile (other,I) other>I (use transpose) ; 2: diagonal
+};
+
+void launch_potrf_inv(double* A, double* Linv, int K, int* fail, hipStream_t s);
+void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s);
+void launch_tile_gemv(const GemvTask* tasks, int n, double* y, const double* x, hipStream_t s);
+void launch_sym_tile_matvec(int nt, const int* row_ptr, const SymEntry* entries, const double* tiles, const double* x,
+                            double* y, hipStream_t s);
+void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double* diag, hipStream_t s);
+void launch_tile_add_diag(double* tiles, const int* diag_slot, int n_valid, int n_total, double add_valid,
+                          double set_pad, hipStream_t s);
+void launch_pcg_init(int n, const double* diag, const double* b, double* pre, double* x, double* r, double* z, double* p,
+                     hipStream_t s);
+void launch_dot(int n, const double* a, const double* b, double* out, hipStream_t s);
+void launch_pcg_update_xr(int n, double alpha, const double* p, const double* ap, double* x, double* r, hipStream_t s);
+void launch_pcg_precond(int n, const double* pre, const double* r, double* z, hipStream_t s);
+void launch_pcg_update_p(int n, double beta, const double* z, double* p, hipStream_t s);
+
+}  // namespace apex

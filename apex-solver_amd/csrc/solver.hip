@@ -1,0 +1,927 @@
+// solver.hip -- host orchestration of the MI355X bundle-adjustment backend (see solver.h).
+#include "solver.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <numeric>
+
+#ifdef APEX_WITH_RCCL
+#include <rccl/rccl.h>
+#endif
+
+namespace apex {
+
+#define HIP_TRY(expr)                                         \
+    do {                                                      \
+        int _rc = check_hip((expr), #expr);                   \
+        if (_rc != kOk) return _rc;                           \
+    } while (0)
+
+template <typename T>
+static hipError_t dev_alloc(T** p, size_t n) {
+    return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
+}
+
+Solver::Solver(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device)
+    : n_cam_(n_cam), n_pt_(n_pt), n_obs_(n_obs), mode_(mode), dc_(mode == 1 ? 9 : 6), device_(device) {
+    lm_lo_ = 0; lm_hi_ = n_pt;
+}
+
+Solver::~Solver() {
+    hipSetDevice(device_);
+    if (stream_) hipStreamSynchronize(stream_);
+    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
+                    cam_ptr_, cam_obs_, fix_pose_, fix_intr_, fix_pt_, tiles_, linv_, slot_, diag_slot_, g_c_, g_red_,
+                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, trsm_tasks_, upd_tasks_, fwd_tasks_,
+                    bwd_tasks_, diag_tasks_, sym_row_ptr_, sym_entries_, pcg_buf_};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    resolve_stage_events();
+    for (hipEvent_t e : ev_pool_) hipEventDestroy(e);
+#ifdef APEX_WITH_RCCL
+    if (comm_) ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm_));
+#endif
+    if (stream_) hipStreamDestroy(stream_);
+}
+
+int Solver::fail(int code, const std::string& msg) {
+    err_ = msg;
+    return code;
+}
+
+int Solver::check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return kOk;
+    return fail(kDeviceError, std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+
+BAView Solver::view(int which) const {
+    BAView v;
+    v.n_cam = n_cam_; v.n_pt = n_pt_; v.n_obs = (int64_t)o_orig_h_.size();
+    v.poses = poses_[which]; v.intr = intr_[which]; v.pts = pts_[which];
+    v.o_cam = o_cam_; v.o_pt = o_pt_; v.o_uv = o_uv_; v.pt_ptr = pt_ptr_;
+    v.huber_delta = huber_delta_;
+    return v;
+}
+
+TileMap Solver::tilemap() const {
+    TileMap tm;
+    tm.tiles = tiles_; tm.slot = slot_; tm.nt = nt_;
+    return tm;
+}
+
+// Stage timing records HIP events on the solver's own stream WITHOUT synchronising; the pairs are
+// resolved when stage_times() is called, so a timed region is not perturbed by the measurement.
+void Solver::stage_begin(int st) {
+    if (!timing_) return;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (!ev_pool_.empty()) { a = ev_pool_.back(); ev_pool_.pop_back(); } else hipEventCreate(&a);
+    if (!ev_pool_.empty()) { b = ev_pool_.back(); ev_pool_.pop_back(); } else hipEventCreate(&b);
+    hipEventRecord(a, stream_);
+    ev_open_[st] = {a, b};
+}
+void Solver::stage_end(int st) {
+    if (!timing_ || !ev_open_[st].first) return;
+    hipEventRecord(ev_open_[st].second, stream_);
+    ev_pending_.push_back({st, ev_open_[st]});
+    ev_open_[st] = {nullptr, nullptr};
+}
+void Solver::resolve_stage_events() {
+    for (auto& p : ev_pending_) {
+        hipEventSynchronize(p.second.second);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+            stage_ms_[p.first] += ms;
+            stage_n_[p.first] += 1;
+        }
+        ev_pool_.push_back(p.second.first);
+        ev_pool_.push_back(p.second.second);
+    }
+    ev_pending_.clear();
+}
+void Solver::reset_stage_times() {
+    resolve_stage_events();
+    for (int i = 0; i < kNumStages; ++i) { stage_ms_[i] = 0; stage_n_[i] = 0; }
+}
+int Solver::stage_times(double* ms, int64_t* launches) {
+    resolve_stage_events();
+    for (int i = 0; i < kNumStages; ++i) { ms[i] = stage_ms_[i]; launches[i] = stage_n_[i]; }
+    return kNumStages;
+}
+
+int Solver::set_shard(int rank, int world) {
+    if (have_structure_) return fail(kInvalidState, "set_shard must precede set_structure");
+    if (world < 1 || rank < 0 || rank >= world) return fail(kInvalidInput, "bad rank/world");
+    rank_ = rank; world_ = world;
+    return kOk;
+}
+
+int Solver::comm_init(int world, int rank, const void* unique_id128) {
+#ifdef APEX_WITH_RCCL
+    int rc = set_shard(rank, world);
+    if (rc != kOk) return rc;
+    HIP_TRY(hipSetDevice(device_));
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(&id, unique_id128, sizeof id);
+    ncclComm_t c;
+    ncclResult_t r = ncclCommInitRank(&c, world, id, rank);
+    if (r != ncclSuccess) return fail(kDeviceError, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    comm_ = reinterpret_cast<ncclComm*>(c);
+    return kOk;
+#else
+    (void)world; (void)rank; (void)unique_id128;
+    return fail(kInvalidState, "library built without RCCL");
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// structure
+// ---------------------------------------------------------------------------------------------
+int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const double* obs_uv,
+                          const int64_t* intr_col, const int64_t* pose_col, const int64_t* pt_col,
+                          const uint8_t* fix_pose, const uint8_t* fix_intr, const uint8_t* fix_pt,
+                          double huber_delta) {
+    if (n_cam_ <= 0 || n_pt_ <= 0) return fail(kInvalidInput, n_cam_ <= 0 ? "No camera variables found" : "No landmark variables found");
+    if (n_obs_ < 0 || n_obs_ > 2000000000LL) return fail(kInvalidInput, "observation count out of range");
+    for (int64_t i = 0; i < n_obs_; ++i)
+        if (cam_idx[i] >= (uint64_t)n_cam_ || pt_idx[i] >= (uint64_t)n_pt_)
+            return fail(kInvalidInput, "observation " + std::to_string(i) + " references a missing variable");
+    HIP_TRY(hipSetDevice(device_));
+    if (!stream_) HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    huber_delta_ = huber_delta;
+    intr_col_.assign(intr_col, intr_col + n_cam_);
+    pose_col_.assign(pose_col, pose_col + n_cam_);
+    pt_col_.assign(pt_col, pt_col + n_pt_);
+
+    // ---- landmark-major lists of the FULL problem (tile structure must match on all ranks) ----
+    std::vector<int64_t> full_ptr(n_pt_ + 1, 0);
+    for (int64_t i = 0; i < n_obs_; ++i) full_ptr[pt_idx[i] + 1]++;
+    for (int64_t l = 0; l < n_pt_; ++l) full_ptr[l + 1] += full_ptr[l];
+    std::vector<int> full_obs(n_obs_);
+    {
+        std::vector<int64_t> fill(full_ptr.begin(), full_ptr.end() - 1);
+        for (int64_t i = 0; i < n_obs_; ++i) full_obs[fill[pt_idx[i]]++] = (int)i;
+    }
+    // ---- shard: contiguous landmark range balanced by observation count --------------------
+    lm_lo_ = 0; lm_hi_ = n_pt_;
+    if (world_ > 1) {
+        auto cut = [&](int r) -> int64_t {
+            if (r <= 0) return 0;
+            if (r >= world_) return n_pt_;
+            const int64_t target = (n_obs_ * r) / world_;
+            return std::lower_bound(full_ptr.begin(), full_ptr.end(), target) - full_ptr.begin();
+        };
+        lm_lo_ = std::min<int64_t>(cut(rank_), n_pt_);
+        lm_hi_ = std::min<int64_t>(cut(rank_ + 1), n_pt_);
+        if (rank_ == world_ - 1) lm_hi_ = n_pt_;
+    }
+    const int64_t o_lo = full_ptr[lm_lo_], o_hi = full_ptr[lm_hi_];
+    const int64_t n_loc = o_hi - o_lo;
+
+    std::vector<uint32_t> o_cam(n_loc), o_pt(n_loc);
+    std::vector<double> o_uv(2 * n_loc);
+    o_orig_h_.resize(n_loc);
+    std::vector<int> pt_ptr(n_pt_ + 1);
+    for (int64_t l = 0; l <= n_pt_; ++l) {
+        int64_t p = full_ptr[l];
+        p = std::min(std::max(p, o_lo), o_hi) - o_lo;
+        pt_ptr[l] = (int)p;
+    }
+    for (int64_t k = 0; k < n_loc; ++k) {
+        const int i = full_obs[o_lo + k];
+        o_orig_h_[k] = i;
+        o_cam[k] = cam_idx[i]; o_pt[k] = pt_idx[i];
+        o_uv[2 * k] = obs_uv[2 * (int64_t)i]; o_uv[2 * k + 1] = obs_uv[2 * (int64_t)i + 1];
+    }
+    // ---- camera-major lists over the local observations -----------------------------------------
+    std::vector<int> cam_ptr(n_cam_ + 1, 0), cam_obs(n_loc);
+    for (int64_t k = 0; k < n_loc; ++k) cam_ptr[o_cam[k] + 1]++;
+    for (int64_t c = 0; c < n_cam_; ++c) cam_ptr[c + 1] += cam_ptr[c];
+    {
+        std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1);
+        for (int64_t k = 0; k < n_loc; ++k) cam_obs[fill[o_cam[k]]++] = (int)k;
+    }
+
+    // ---- tile structure of S (covisibility at tile granularity + symbolic Cholesky fill) -------------
+    n_c_ = n_cam_ * dc_;
+    nt_ = (int)((n_c_ + kNB - 1) / kNB);
+    n_c_pad_ = (int64_t)nt_ * kNB;
+    const int cpt = kNB / dc_;
+    std::vector<uint8_t> present((size_t)nt_ * nt_, 0);
+    {
+        std::vector<int> tl;
+        for (int64_t l = 0; l < n_pt_; ++l) {
+            tl.clear();
+            for (int64_t k = full_ptr[l]; k < full_ptr[l + 1]; ++k) tl.push_back((int)(cam_idx[full_obs[k]] / cpt));
+            std::sort(tl.begin(), tl.end());
+            tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
+            for (size_t a = 0; a < tl.size(); ++a)
+                for (size_t b = 0; b <= a; ++b) present[(size_t)tl[a] * nt_ + tl[b]] = 1;
+        }
+    }
+    col_rows_.assign(nt_, {});
+    for (int K = 0; K < nt_; ++K)
+        for (int I = K + 1; I < nt_; ++I)
+            if (present[(size_t)I * nt_ + K]) col_rows_[K].push_back(I);
+    for (int K = 0; K < nt_; ++K) {  // struct(L_K) \ {parent} merges into the parent column
+        auto& rows = col_rows_[K];
+        if (rows.size() < 2) continue;
+        const int parent = rows[0];
+        std::vector<int> merged;
+        std::set_union(col_rows_[parent].begin(), col_rows_[parent].end(), rows.begin() + 1, rows.end(),
+                       std::back_inserter(merged));
+        col_rows_[parent].swap(merged);
+    }
+    slot_h_.assign((size_t)nt_ * nt_, -1);
+    diag_slot_h_.assign(nt_, 0);
+    n_slots_ = 0;
+    max_col_ = 0;
+    for (int K = 0; K < nt_; ++K) {
+        diag_slot_h_[K] = (int)n_slots_;
+        slot_h_[(size_t)K * nt_ + K] = (int)n_slots_++;
+        for (int I : col_rows_[K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
+        max_col_ = std::max<int>(max_col_, (int)col_rows_[K].size());
+    }
+    const size_t tile_elems = (size_t)kNB * kNB;
+    {
+        size_t free_b = 0, total_b = 0;
+        hipMemGetInfo(&free_b, &total_b);
+        const double need = (double)(n_slots_ + nt_) * tile_elems * 8.0;
+        if (need > 0.9 * (double)free_b)
+            return fail(kInvalidInput, "reduced camera matrix needs " + std::to_string(need / 1e9) +
+                                           " GB of tiles; only " + std::to_string(free_b / 1e9) + " GB free");
+    }
+
+    // ---- Schur-scatter tasks over the local landmarks -----------------------------------------------
+    std::vector<ScatterTask> tasks;
+    n_pairs_ = 0;
+    {
+        int cur0 = -1, curn = 0;
+        auto flush = [&]() {
+            if (curn > 0) tasks.push_back({cur0, curn, 0, 0});
+            cur0 = -1; curn = 0;
+        };
+        for (int64_t l = lm_lo_; l < lm_hi_; ++l) {
+            const int b = pt_ptr[l], e = pt_ptr[l + 1], k = e - b;
+            if (k == 0) continue;
+            n_pairs_ += (int64_t)k * (k + 1) / 2;
+            if (k > kScatterBlk) {
+                flush();
+                const int nb = (k + kScatterBlk - 1) / kScatterBlk;
+                for (int bi = 0; bi < nb; ++bi) {
+                    const int i0 = b + bi * kScatterBlk, ni = std::min(kScatterBlk, e - i0);
+                    tasks.push_back({i0, ni, 0, 0});
+                    for (int bj = bi + 1; bj < nb; ++bj) {
+                        const int j0 = b + bj * kScatterBlk, nj = std::min(kScatterBlk, e - j0);
+                        tasks.push_back({i0, ni, j0, nj});
+                    }
+                }
+                continue;
+            }
+            if (curn + k > kScatterCap) flush();
+            if (curn == 0) cur0 = b;
+            curn += k;
+        }
+        flush();
+    }
+    n_tasks_ = (int)tasks.size();
+    n_present_ = 0;
+    for (uint8_t b : present) n_present_ += b;
+
+    // ---- uploads ------------------------------------------------------------------------------------
+    auto up = [&](auto** dptr, const auto& hv) -> hipError_t {
+        using T = typename std::remove_reference<decltype(hv)>::type::value_type;
+        if (*dptr) { hipFree(*dptr); *dptr = nullptr; }
+        hipError_t e = dev_alloc(reinterpret_cast<T**>(dptr), hv.size());
+        if (e != hipSuccess) return e;
+        if (hv.empty()) return hipSuccess;
+        return hipMemcpy(*dptr, hv.data(), hv.size() * sizeof(T), hipMemcpyHostToDevice);
+    };
+    HIP_TRY(up(&o_cam_, o_cam));
+    HIP_TRY(up(&o_pt_, o_pt));
+    HIP_TRY(up(reinterpret_cast<double**>(&o_uv_), o_uv));
+    HIP_TRY(up(&o_orig_, o_orig_h_));
+    HIP_TRY(up(&pt_ptr_, pt_ptr));
+    HIP_TRY(up(&cam_ptr_, cam_ptr));
+    HIP_TRY(up(&cam_obs_, cam_obs));
+    HIP_TRY(up(&slot_, slot_h_));
+    HIP_TRY(up(&diag_slot_, diag_slot_h_));
+    HIP_TRY(up(&tasks_, tasks));
+    {
+        std::vector<uint8_t> fp(6 * n_cam_, 0), fi(3 * n_cam_, 0), fl(3 * n_pt_, 0);
+        if (fix_pose) memcpy(fp.data(), fix_pose, fp.size());
+        if (fix_intr) memcpy(fi.data(), fix_intr, fi.size());
+        if (fix_pt) memcpy(fl.data(), fix_pt, fl.size());
+        HIP_TRY(up(&fix_pose_, fp));
+        HIP_TRY(up(&fix_intr_, fi));
+        HIP_TRY(up(&fix_pt_, fl));
+    }
+    auto alloc = [&](double** p, size_t n) -> hipError_t {
+        if (*p) { hipFree(*p); *p = nullptr; }
+        hipError_t e = dev_alloc(p, n);
+        if (e != hipSuccess) return e;
+        return hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(double));
+    };
+    for (int w = 0; w < 2; ++w) {
+        HIP_TRY(alloc(&poses_[w], 7 * n_cam_));
+        HIP_TRY(alloc(&intr_[w], 3 * n_cam_));
+        HIP_TRY(alloc(&pts_[w], 3 * n_pt_));
+    }
+    HIP_TRY(alloc(&tiles_, (size_t)n_slots_ * tile_elems));
+    HIP_TRY(alloc(&linv_, (size_t)nt_ * tile_elems));
+    HIP_TRY(alloc(&g_c_, n_c_pad_));
+    HIP_TRY(alloc(&g_red_, n_c_pad_));
+    HIP_TRY(alloc(&dcam_, n_c_pad_));
+    HIP_TRY(alloc(&hinv_, 9 * n_pt_));
+    HIP_TRY(alloc(&g_l_, 3 * n_pt_));
+    HIP_TRY(alloc(&dl_, 3 * n_pt_));
+    HIP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
+    HIP_TRY(alloc(&scal_, 16));
+    HIP_TRY(alloc(&pcg_buf_, 7 * (size_t)n_c_pad_));
+    if (flags_) hipFree(flags_);
+    HIP_TRY(dev_alloc(&flags_, 4));
+    HIP_TRY(hipMemset(flags_, 0, 4 * sizeof(int)));
+
+    // ---- factorisation / solve task lists ----------------------------------------------------------------
+    auto tile_ptr = [&](int I, int J) { return tiles_ + (size_t)slot_h_[(size_t)I * nt_ + J] * tile_elems; };
+    auto linv_ptr = [&](int K) { return linv_ + (size_t)K * tile_elems; };
+    std::vector<GemmTask> trsm, upd;
+    std::vector<GemvTask> fwd, bwd, dg;
+    col_off_.assign(nt_ + 1, 0);
+    upd_off_.assign(nt_ + 1, 0);
+    int64_t n_upd = 0;
+    for (int K = 0; K < nt_; ++K) n_upd += (int64_t)col_rows_[K].size() * (col_rows_[K].size() + 1) / 2;
+    if (n_upd > 80000000LL) return fail(kInvalidInput, "tile update list too large (" + std::to_string(n_upd) + ")");
+    upd.reserve(n_upd);
+    for (int K = 0; K < nt_; ++K) {
+        const auto& rows = col_rows_[K];
+        for (int I : rows) {
+            trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});
+            fwd.push_back({tile_ptr(I, K), K * kNB, I * kNB, 2});
+        }
+        for (size_t a = 0; a < rows.size(); ++a)
+            for (size_t b = 0; b <= a; ++b) upd.push_back({tile_ptr(rows[a], rows[b]), tile_ptr(rows[a], K), tile_ptr(rows[b], K)});
+        col_off_[K + 1] = (int)trsm.size();
+        upd_off_[K + 1] = (int64_t)upd.size();
+    }
+    // row lists (tiles (I,J), J < I) for the backward sweep and the symmetric matvec
+    std::vector<std::vector<int>> row_cols(nt_);
+    for (int K = 0; K < nt_; ++K)
+        for (int I : col_rows_[K]) row_cols[I].push_back(K);
+    row_off_.assign(nt_ + 1, 0);
+    for (int I = 0; I < nt_; ++I) {
+        for (int J : row_cols[I]) bwd.push_back({tile_ptr(I, J), I * kNB, J * kNB, 3});
+        row_off_[I + 1] = (int)bwd.size();
+    }
+    for (int K = 0; K < nt_; ++K) dg.push_back({linv_ptr(K), K * kNB, K * kNB, 0});
+    for (int K = 0; K < nt_; ++K) dg.push_back({linv_ptr(K), K * kNB, K * kNB, 1});
+    std::vector<int> sym_ptr(nt_ + 1, 0);
+    std::vector<SymEntry> sym;
+    for (int I = 0; I < nt_; ++I) {
+        for (int J : row_cols[I]) sym.push_back({slot_h_[(size_t)I * nt_ + J], J, 0});
+        sym.push_back({diag_slot_h_[I], I, 2});
+        for (int I2 : col_rows_[I]) sym.push_back({slot_h_[(size_t)I2 * nt_ + I], I2, 1});
+        sym_ptr[I + 1] = (int)sym.size();
+    }
+    HIP_TRY(up(&trsm_tasks_, trsm));
+    HIP_TRY(up(&upd_tasks_, upd));
+    HIP_TRY(up(&fwd_tasks_, fwd));
+    HIP_TRY(up(&bwd_tasks_, bwd));
+    HIP_TRY(up(&diag_tasks_, dg));
+    HIP_TRY(up(&sym_row_ptr_, sym_ptr));
+    HIP_TRY(up(&sym_entries_, sym));
+    HIP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on stream_
+
+    have_structure_ = true;
+    have_params_ = have_step_ = have_trial_ = false;
+    cur_ = 0;
+    return kOk;
+}
+
+int Solver::set_params(const double* poses, const double* intr, const double* points) {
+    if (!have_structure_) return fail(kInvalidState, "Block structure not built. Call set_structure() first.");
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipMemcpyAsync(poses_[cur_], poses, 7 * n_cam_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(intr_[cur_], intr, 3 * n_cam_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(pts_[cur_], points, 3 * n_pt_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    have_params_ = true; have_step_ = have_trial_ = false;
+    return kOk;
+}
+
+int Solver::get_params(double* poses, double* intr, double* points) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+#ifdef APEX_WITH_RCCL
+    if (comm_ && world_ > 1) {
+        // every rank owns a contiguous landmark range: gather the owners' points everywhere
+        // (ranges differ in size, so one broadcast per owner)
+        std::vector<int64_t> lo(world_ + 1);
+        // all ranks compute identical cuts from the replicated structure: re-derive from pt_ptr is not
+        // possible without the full lists, so exchange the range starts.
+        int64_t mine[2] = {lm_lo_, lm_hi_};
+        int64_t* d_rng = reinterpret_cast<int64_t*>(scal_ + 8);
+        HIP_TRY(hipMemcpyAsync(d_rng + 2 * rank_, mine, sizeof mine, hipMemcpyHostToDevice, stream_));
+        ncclAllGather(d_rng + 2 * rank_, d_rng, 2 * sizeof(int64_t), ncclChar, reinterpret_cast<ncclComm_t>(comm_), stream_);
+        std::vector<int64_t> rng(2 * world_);
+        HIP_TRY(hipMemcpyAsync(rng.data(), d_rng, rng.size() * 8, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        for (int r = 0; r < world_; ++r) {
+            const int64_t a = rng[2 * r], b = rng[2 * r + 1];
+            if (b > a) ncclBroadcast(pts_[cur_] + 3 * a, pts_[cur_] + 3 * a, 3 * (b - a), ncclDouble, r,
+                                     reinterpret_cast<ncclComm_t>(comm_), stream_);
+        }
+    }
+#endif
+    HIP_TRY(hipMemcpyAsync(poses, poses_[cur_], 7 * n_cam_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(intr, intr_[cur_], 3 * n_cam_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(points, pts_[cur_], 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return kOk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cost (A16)
+// ---------------------------------------------------------------------------------------------
+int Solver::cost_of(int which, double* out) {
+    stage_begin(kStCost);
+    launch_cost(view(which), partial_, n_partial_, scal_, stream_);
+#ifdef APEX_WITH_RCCL
+    if (comm_ && world_ > 1)
+        ncclAllReduce(scal_, scal_, 1, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
+#endif
+    stage_end(kStCost);
+    double ss = 0.0;
+    HIP_TRY(hipMemcpyAsync(&ss, scal_, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    const double nrm = sqrt(ss);  // compute_cost: 0.5 * norm_l2()^2 (optimizer/mod.rs:358-361)
+    *out = 0.5 * nrm * nrm;
+    return kOk;
+}
+
+int Solver::cost(double* out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    return cost_of(cur_, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// assembly of S, g_red, Hll^-1, g (A6-A11) at the current parameters
+// ---------------------------------------------------------------------------------------------
+int Solver::assemble(double lambda, double diag_extra) {
+    const size_t tile_elems = (size_t)kNB * kNB;
+    const BAView v = view(cur_);
+    const TileMap tm = tilemap();
+    stage_begin(kStAssembleCam);
+    HIP_TRY(hipMemsetAsync(tiles_, 0, (size_t)n_slots_ * tile_elems * sizeof(double), stream_));
+    HIP_TRY(hipMemsetAsync(g_red_, 0, n_c_pad_ * sizeof(double), stream_));
+    HIP_TRY(hipMemsetAsync(g_c_, 0, n_c_pad_ * sizeof(double), stream_));
+    HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
+    // identity on the padding rows of the last tile (rank 0 only: the all-reduce sums the ranks)
+    launch_tile_add_diag(tiles_, diag_slot_, (int)n_c_, (int)n_c_pad_, 0.0, rank_ == 0 ? 1.0 : 0.0, stream_);
+    launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, g_c_, g_red_, stream_);
+    stage_end(kStAssembleCam);
+    stage_begin(kStAssembleLm);
+    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, stream_);
+    stage_end(kStAssembleLm);
+    stage_begin(kStScatter);
+    launch_schur_scatter(dc_, v, tm, tasks_, n_tasks_, hinv_, g_l_, g_red_, stream_);
+    stage_end(kStScatter);
+#ifdef APEX_WITH_RCCL
+    if (comm_ && world_ > 1) {
+        stage_begin(kStAllReduce);
+        ncclComm_t c = reinterpret_cast<ncclComm_t>(comm_);
+        ncclGroupStart();
+        ncclAllReduce(tiles_, tiles_, (size_t)n_slots_ * tile_elems, ncclDouble, ncclSum, c, stream_);
+        ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
+        ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
+        ncclGroupEnd();
+        stage_end(kStAllReduce);
+    }
+#endif
+    return kOk;
+}
+
+int Solver::cholesky_attempt(int* failed_at) {
+    const size_t tile_elems = (size_t)kNB * kNB;
+    stage_begin(kStFactor);
+    for (int K = 0; K < nt_; ++K) {
+        launch_potrf_inv(tiles_ + (size_t)diag_slot_h_[K] * tile_elems, linv_ + (size_t)K * tile_elems, K, flags_ + 1, stream_);
+        const int n_col = col_off_[K + 1] - col_off_[K];
+        if (n_col > 0) {
+            launch_tile_gemm_nt(trsm_tasks_ + col_off_[K], n_col, 1.0, 0.0, stream_);
+            launch_tile_gemm_nt(upd_tasks_ + upd_off_[K], (int)(upd_off_[K + 1] - upd_off_[K]), -1.0, 1.0, stream_);
+        }
+    }
+    stage_end(kStFactor);
+    int f = 0;
+    HIP_TRY(hipMemcpyAsync(&f, flags_ + 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    *failed_at = f;
+    return kOk;
+}
+
+int Solver::tri_solve() {
+    stage_begin(kStTriSolve);
+    HIP_TRY(hipMemcpyAsync(dcam_, g_red_, n_c_pad_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    for (int K = 0; K < nt_; ++K) {  // L y = b
+        launch_tile_gemv(diag_tasks_ + K, 1, dcam_, dcam_, stream_);
+        launch_tile_gemv(fwd_tasks_ + col_off_[K], col_off_[K + 1] - col_off_[K], dcam_, dcam_, stream_);
+    }
+    for (int I = nt_ - 1; I >= 0; --I) {  // L^T x = y
+        launch_tile_gemv(diag_tasks_ + nt_ + I, 1, dcam_, dcam_, stream_);
+        launch_tile_gemv(bwd_tasks_ + row_off_[I], row_off_[I + 1] - row_off_[I], dcam_, dcam_, stream_);
+    }
+    stage_end(kStTriSolve);
+    return kOk;
+}
+
+// solve_with_cholesky (explicit_schur.rs:539-634) incl. the regularisation ladder
+int Solver::factor_and_solve(double lambda) {
+    int failed = 0;
+    last_reg_ = 0.0;
+    int rc = cholesky_attempt(&failed);
+    if (rc != kOk) return rc;
+    if (!failed) return tri_solve();
+    // the factorisation overwrote S: re-assemble it to read trace and max |diag| (:563-579)
+    rc = assemble(lambda, 0.0);
+    if (rc != kOk) return rc;
+    double* diag = pcg_buf_;
+    launch_tile_diag(tiles_, diag_slot_, nt_, diag, stream_);
+    std::vector<double> hd(n_c_);
+    HIP_TRY(hipMemcpyAsync(hd.data(), diag, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    // the reference's S also holds the 3 n_cam intrinsic rows when the factors do not touch them
+    // (BundleAdjustment mode): their diagonal is lambda.
+    double trace = 0.0, max_diag = 0.0;
+    for (double d : hd) { trace += d; max_diag = std::max(max_diag, fabs(d)); }
+    int64_t n_ref = n_c_;
+    if (dc_ == 6) { trace += 3.0 * n_cam_ * lambda; max_diag = std::max(max_diag, fabs(lambda)); n_ref = 9 * n_cam_; }
+    const double base = std::max(std::max(trace / (double)n_ref, max_diag), 1.0);
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        const double reg = base * pow(10.0, (double)(attempt - 4));
+        rc = assemble(lambda, reg);
+        if (rc != kOk) return rc;
+        rc = cholesky_attempt(&failed);
+        if (rc != kOk) return rc;
+        if (!failed) { last_reg_ = reg; return tri_solve(); }
+    }
+    return fail(kSingularMatrix, "Schur complement singular after 5 regularization attempts (max reg = " + std::to_string(base) + ")");
+}
+
+// solve_with_pcg (explicit_schur.rs:639-756): Jacobi-preconditioned CG on the explicit S
+int Solver::pcg_solve() {
+    stage_begin(kStFactor);
+    const int n = (int)n_c_pad_;
+    double *diag = pcg_buf_, *pre = pcg_buf_ + n, *x = dcam_, *r = pcg_buf_ + 2 * (size_t)n, *z = pcg_buf_ + 3 * (size_t)n,
+           *p = pcg_buf_ + 4 * (size_t)n, *ap = pcg_buf_ + 5 * (size_t)n;
+    launch_tile_diag(tiles_, diag_slot_, nt_, diag, stream_);
+    launch_pcg_init(n, diag, g_red_, pre, x, r, z, p, stream_);
+    auto dot = [&](const double* a, const double* b, double* out) -> int {
+        launch_dot(n, a, b, scal_ + 6, stream_);
+        HIP_TRY(hipMemcpyAsync(out, scal_ + 6, sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return kOk;
+    };
+    double rz_old = 0.0, rr = 0.0;
+    int rc = dot(r, z, &rz_old); if (rc != kOk) return rc;
+    rc = dot(r, r, &rr); if (rc != kOk) return rc;
+    const double abs_tol = cg_tol_ * std::max(sqrt(rr), 1.0);
+    int it = 0;
+    for (; it < cg_max_iter_; ++it) {
+        launch_sym_tile_matvec(nt_, sym_row_ptr_, sym_entries_, tiles_, p, ap, stream_);
+        double pap = 0.0;
+        rc = dot(p, ap, &pap); if (rc != kOk) return rc;
+        if (fabs(pap) < 1e-30) break;
+        const double alpha = rz_old / pap;
+        launch_pcg_update_xr(n, alpha, p, ap, x, r, stream_);
+        rc = dot(r, r, &rr); if (rc != kOk) return rc;
+        if (sqrt(rr) < abs_tol) { ++it; break; }
+        launch_pcg_precond(n, pre, r, z, stream_);
+        double rz_new = 0.0;
+        rc = dot(r, z, &rz_new); if (rc != kOk) return rc;
+        if (fabs(rz_old) < 1e-30) { ++it; break; }
+        const double beta = rz_new / rz_old;
+        launch_pcg_update_p(n, beta, z, p, stream_);
+        rz_old = rz_new;
+    }
+    last_pcg_iters_ = it;
+    stage_end(kStFactor);
+    return kOk;
+}
+
+int Solver::solve_augmented(double lambda, int variant, double* step_out, double* grad_out) {
+    if (!have_params_) return fail(kInvalidState, "Block structure not built or parameters not set");
+    HIP_TRY(hipSetDevice(device_));
+    have_step_ = false;
+    last_lambda_ = lambda;
+    int rc = assemble(lambda, 0.0);
+    if (rc != kOk) return rc;
+    int lm_err = 0;
+    HIP_TRY(hipMemcpyAsync(&lm_err, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    if (lm_err) return fail(kSingularMatrix, "Landmark block is singular");
+    rc = (variant == 1) ? pcg_solve() : factor_and_solve(lambda);
+    if (rc != kOk) return rc;
+    stage_begin(kStBackSub);
+    launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_);
+    stage_end(kStBackSub);
+    have_step_ = true;
+    if (step_out || grad_out) {
+        std::vector<double> hc(n_c_), hl(3 * n_pt_);
+        for (int pass = 0; pass < 2; ++pass) {
+            double* out = pass == 0 ? step_out : grad_out;
+            if (!out) continue;
+            HIP_TRY(hipMemcpyAsync(hc.data(), pass == 0 ? dcam_ : g_c_, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipMemcpyAsync(hl.data(), pass == 0 ? dl_ : g_l_, 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            for (int64_t c = 0; c < n_cam_; ++c) {
+                for (int a = 0; a < 6; ++a) out[pose_col_[c] + a] = hc[c * dc_ + a];
+                for (int a = 0; a < 3; ++a) out[intr_col_[c] + a] = (dc_ == 9) ? hc[c * dc_ + 6 + a] : 0.0;
+            }
+            for (int64_t l = 0; l < n_pt_; ++l)
+                for (int a = 0; a < 3; ++a) out[pt_col_[l] + a] = hl[3 * l + a];
+        }
+    } else {
+        HIP_TRY(hipStreamSynchronize(stream_));
+    }
+    return kOk;
+}
+
+int Solver::assemble_only(double lambda) {
+    if (!have_params_) return fail(kInvalidState, "Block structure not built or parameters not set");
+    HIP_TRY(hipSetDevice(device_));
+    have_step_ = false;
+    last_lambda_ = lambda;
+    int rc = assemble(lambda, 0.0);
+    if (rc != kOk) return rc;
+    int lm_err = 0;
+    HIP_TRY(hipMemcpyAsync(&lm_err, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    if (lm_err) return fail(kSingularMatrix, "Landmark block is singular");
+    return kOk;
+}
+
+int Solver::step_stats(double out3[3]) {
+    if (!have_step_) return fail(kInvalidState, "no step computed");
+    HIP_TRY(hipSetDevice(device_));
+    stage_begin(kStStats);
+    launch_step_stats(n_c_, g_c_, dcam_, last_lambda_, partial_, n_partial_, scal_, stream_);
+    launch_step_stats(3 * n_pt_, g_l_, dl_, last_lambda_, partial_, n_partial_, scal_ + 3, stream_);
+#ifdef APEX_WITH_RCCL
+    if (comm_ && world_ > 1)  // landmark part is sharded, camera part replicated
+        ncclAllReduce(scal_ + 3, scal_ + 3, 3, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
+#endif
+    stage_end(kStStats);
+    double h[6];
+    HIP_TRY(hipMemcpyAsync(h, scal_, sizeof h, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    out3[0] = sqrt(h[0] + h[3]);          // gradient.norm_l2()          (levenberg_marquardt.rs:746)
+    out3[1] = sqrt(h[1] + h[4]);          // step.norm_l2()              (:890)
+    out3[2] = 0.5 * (h[2] + h[5]);        // compute_predicted_reduction (:721-727)
+    return kOk;
+}
+
+int Solver::eval_step(double, double* trial_cost) {
+    if (!have_step_) return fail(kInvalidState, "no step computed");
+    HIP_TRY(hipSetDevice(device_));
+    const int t = cur_ ^ 1;
+    stage_begin(kStRetract);
+    launch_retract(dc_, n_cam_, n_pt_, poses_[cur_], intr_[cur_], pts_[cur_], dcam_, dl_, 1.0, fix_pose_, fix_intr_,
+                   fix_pt_, poses_[t], intr_[t], pts_[t], stream_);
+    stage_end(kStRetract);
+    have_trial_ = true;
+    return cost_of(t, trial_cost);
+}
+
+int Solver::commit_step() {
+    if (!have_trial_) return fail(kInvalidState, "no trial point");
+    cur_ ^= 1;
+    have_trial_ = false; have_step_ = false;
+    return kOk;
+}
+
+// apply_negative_parameter_step (optimizer/mod.rs:343-356): the rejected trial point is moved back
+// by the inverse retraction, it is NOT restored from a snapshot.
+int Solver::discard_step() {
+    if (!have_trial_) return fail(kInvalidState, "no trial point");
+    HIP_TRY(hipSetDevice(device_));
+    const int t = cur_ ^ 1;
+    stage_begin(kStRetract);
+    launch_retract(dc_, n_cam_, n_pt_, poses_[t], intr_[t], pts_[t], dcam_, dl_, -1.0, fix_pose_, fix_intr_, fix_pt_,
+                   poses_[cur_], intr_[cur_], pts_[cur_], stream_);
+    stage_end(kStRetract);
+    HIP_TRY(hipStreamSynchronize(stream_));
+    have_trial_ = false; have_step_ = false;
+    return kOk;
+}
+
+int Solver::parameter_norm(double* out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    launch_sumsq(7 * n_cam_, poses_[cur_], partial_, n_partial_, scal_ + 9, stream_);
+    launch_sumsq(3 * n_cam_, intr_[cur_], partial_, n_partial_, scal_ + 10, stream_);
+    // points: in a sharded run only the owned range is current on this rank
+    launch_sumsq(3 * (lm_hi_ - lm_lo_), pts_[cur_] + 3 * lm_lo_, partial_, n_partial_, scal_ + 11, stream_);
+#ifdef APEX_WITH_RCCL
+    if (comm_ && world_ > 1)
+        ncclAllReduce(scal_ + 11, scal_ + 11, 1, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
+#endif
+    double h[3];
+    HIP_TRY(hipMemcpyAsync(h, scal_ + 9, sizeof h, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    *out = sqrt(h[0] + h[1] + h[2]);
+    return kOk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The LM loop (optimize_with_mode, levenberg_marquardt.rs:823-1031) with the state on the device.
+// ---------------------------------------------------------------------------------------------
+int Solver::lm_optimize(LmConfig* cfg, LmResult* res, LmIterRecord* hist, int hist_cap) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    const auto t0 = std::chrono::steady_clock::now();
+    double lambda = cfg->damping, nu = cfg->damping_nu;
+    double cur_cost = 0.0;
+    int rc = cost(&cur_cost);  // initialize_optimization_state (optimizer/mod.rs:550-552)
+    if (rc != kOk) return rc;
+    memset(res, 0, sizeof *res);
+    res->initial_cost = cur_cost;
+    res->cost_evaluations = 1;
+    int iteration = 0, status = kMaxIterationsReached;
+    for (;;) {
+        rc = solve_augmented(lambda, cfg->variant, nullptr, nullptr);  // assemble + compute_step (:861-883)
+        res->jacobian_evaluations++;
+        if (rc != kOk) { status = kLinearSolveFailed; break; }
+        double st[3];
+        rc = step_stats(st);
+        if (rc != kOk) return rc;
+        const double gn = st[0], sn = st[1], pred = st[2];
+        double new_cost = 0.0;
+        rc = eval_step(1.0, &new_cost);  // evaluate_and_apply_step (:770-817)
+        if (rc != kOk) return rc;
+        res->cost_evaluations++;
+        const double actual = cur_cost - new_cost;  // compute_step_quality (optimizer/mod.rs:668-675)
+        const double rho = (fabs(pred) < 1e-15) ? (actual > 0.0 ? 1.0 : 0.0) : actual / pred;
+        int accepted;
+        double cost_reduction = 0.0;
+        if (rho > 0.0) {  // update_damping (:702-717)
+            const double coff = 2.0 * rho - 1.0;
+            lambda *= std::max(1.0 / 3.0, 1.0 - coff * coff * coff);
+            lambda = std::max(lambda, cfg->damping_min);
+            nu = 2.0;
+            accepted = 1;
+            cost_reduction = cur_cost - new_cost;
+            cur_cost = new_cost;
+            rc = commit_step();
+            res->successful_steps++;
+        } else {
+            lambda *= nu;
+            nu *= 2.0;
+            lambda = std::min(lambda, cfg->damping_max);
+            accepted = 0;
+            rc = discard_step();
+            res->unsuccessful_steps++;
+        }
+        if (rc != kOk) return rc;
+        if (hist && iteration < hist_cap) {
+            LmIterRecord& h = hist[iteration];
+            h.cost = cur_cost; h.damping = lambda; h.rho = rho; h.accepted = accepted; h.gradient_norm = gn;
+            h.step_norm = sn; h.predicted_reduction = pred; h.trial_cost = new_cost;
+        }
+        res->final_gradient_norm = gn;
+        res->final_step_norm = sn;
+        // check_convergence (optimizer/mod.rs:591-658)
+        double pnorm = 0.0;
+        rc = parameter_norm(&pnorm);
+        if (rc != kOk) return rc;
+        const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const double cost_before = accepted ? cur_cost + cost_reduction : cur_cost;
+        int stt = -1;
+        if (!std::isfinite(cur_cost) || !std::isfinite(sn) || !std::isfinite(gn)) stt = kInvalidNumericalValues;
+        else if (cfg->timeout_s > 0.0 && elapsed >= cfg->timeout_s) stt = kTimeout;
+        else if (iteration >= cfg->max_iterations) stt = kMaxIterationsReached;
+        else if (accepted) {
+            if (gn < cfg->gradient_tolerance) stt = kGradientToleranceReached;
+            if (stt < 0 && iteration > 0) {
+                const double rel_step_tol = cfg->parameter_tolerance * (pnorm + cfg->parameter_tolerance);
+                if (sn <= rel_step_tol) stt = kParameterToleranceReached;
+                else {
+                    const double cc = fabs(cost_before - cur_cost);
+                    if (cc / std::max(cost_before, 1e-10) < cfg->cost_tolerance) stt = kCostToleranceReached;
+                }
+            }
+            if (stt < 0 && cfg->min_cost_threshold >= 0.0 && cur_cost < cfg->min_cost_threshold) stt = kMinCostThresholdReached;
+            if (stt < 0 && cfg->trust_region_radius < cfg->min_trust_region_radius) stt = kTrustRegionRadiusTooSmall;
+        }
+        if (stt >= 0) { status = stt; ++iteration; break; }
+        ++iteration;
+    }
+    cfg->damping = lambda; cfg->damping_nu = nu;
+    res->status = status;
+    res->iterations = iteration;
+    res->final_cost = cur_cost;
+    res->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return kOk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// parity / debug exports
+// ---------------------------------------------------------------------------------------------
+int Solver::get_residual(double* r_out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    double* d = nullptr;
+    HIP_TRY(dev_alloc(&d, 2 * n_obs_));
+    hipMemsetAsync(d, 0, 2 * n_obs_ * sizeof(double), stream_);
+    launch_export_linearization(dc_, view(cur_), o_orig_, d, nullptr, nullptr, stream_);
+    hipError_t e = hipMemcpyAsync(r_out, d, 2 * n_obs_ * sizeof(double), hipMemcpyDeviceToHost, stream_);
+    hipStreamSynchronize(stream_);
+    hipFree(d);
+    return check_hip(e, "get_residual");
+}
+
+int Solver::get_jacobian_blocks(double* jc_out, double* jl_out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    double *dj = nullptr, *dl = nullptr;
+    HIP_TRY(dev_alloc(&dj, 2 * dc_ * n_obs_));
+    HIP_TRY(dev_alloc(&dl, 6 * n_obs_));
+    hipMemsetAsync(dj, 0, 2 * dc_ * n_obs_ * sizeof(double), stream_);
+    hipMemsetAsync(dl, 0, 6 * n_obs_ * sizeof(double), stream_);
+    launch_export_linearization(dc_, view(cur_), o_orig_, nullptr, dj, dl, stream_);
+    hipError_t e1 = hipMemcpyAsync(jc_out, dj, 2 * dc_ * n_obs_ * sizeof(double), hipMemcpyDeviceToHost, stream_);
+    hipError_t e2 = hipMemcpyAsync(jl_out, dl, 6 * n_obs_ * sizeof(double), hipMemcpyDeviceToHost, stream_);
+    hipStreamSynchronize(stream_);
+    hipFree(dj); hipFree(dl);
+    int rc = check_hip(e1, "get_jacobian_blocks");
+    return rc != kOk ? rc : check_hip(e2, "get_jacobian_blocks");
+}
+
+// Dense S (9 n_cam square, row-major) and g_red in the reference's camera-side column order,
+// re-assembled at the current parameters with the last lambda (the factorisation works in place).
+int Solver::get_schur(double* S_out, double* gred_out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    int rc = assemble(last_lambda_, 0.0);
+    if (rc != kOk) return rc;
+    const size_t tile_elems = (size_t)kNB * kNB;
+    const int64_t nref = 9 * n_cam_;
+    auto ref_row = [&](int64_t i) -> int64_t {
+        const int64_t c = i / dc_; const int a = (int)(i - c * dc_);
+        return a < 6 ? pose_col_[c] + a : intr_col_[c] + (a - 6);
+    };
+    if (gred_out) {
+        std::vector<double> h(n_c_);
+        HIP_TRY(hipMemcpyAsync(h.data(), g_red_, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        std::fill(gred_out, gred_out + nref, 0.0);
+        for (int64_t i = 0; i < n_c_; ++i) gred_out[ref_row(i)] = h[i];
+    }
+    if (S_out) {
+        std::fill(S_out, S_out + nref * nref, 0.0);
+        if (dc_ == 6)  // intrinsic variables exist but no factor touches them: S_ii = lambda
+            for (int64_t c = 0; c < n_cam_; ++c)
+                for (int a = 0; a < 3; ++a) S_out[(intr_col_[c] + a) * nref + intr_col_[c] + a] = last_lambda_;
+        std::vector<double> t(tile_elems);
+        for (int I = 0; I < nt_; ++I)
+            for (int J = 0; J <= I; ++J) {
+                const int s = slot_h_[(size_t)I * nt_ + J];
+                if (s < 0) continue;
+                HIP_TRY(hipMemcpyAsync(t.data(), tiles_ + (size_t)s * tile_elems, tile_elems * sizeof(double), hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(hipStreamSynchronize(stream_));
+                for (int r = 0; r < kNB; ++r)
+                    for (int c = 0; c < kNB; ++c) {
+                        const int64_t gi = (int64_t)I * kNB + r, gj = (int64_t)J * kNB + c;
+                        if (gi >= n_c_ || gj >= n_c_ || gj > gi) continue;
+                        const double val = t[(size_t)r * kNB + c];
+                        const int64_t ri = ref_row(gi), rj = ref_row(gj);
+                        S_out[ri * nref + rj] = val;
+                        S_out[rj * nref + ri] = val;
+                    }
+            }
+    }
+    return kOk;
+}
+
+int Solver::get_landmark_blocks(double* hinv_out, double* gl_out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    if (hinv_out) HIP_TRY(hipMemcpyAsync(hinv_out, hinv_, 9 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    if (gl_out) HIP_TRY(hipMemcpyAsync(gl_out, g_l_, 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return kOk;
+}
+
+int Solver::get_step_internal(double* dc_out, double* dl_out) {
+    if (!have_step_) return fail(kInvalidState, "no step computed");
+    HIP_TRY(hipSetDevice(device_));
+    if (dc_out) HIP_TRY(hipMemcpyAsync(dc_out, dcam_, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    if (dl_out) HIP_TRY(hipMemcpyAsync(dl_out, dl_, 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    return kOk;
+}
+
+}  // namespace apex

@@ -1,0 +1,405 @@
+"""Host-side mirror of the reference's interface for the bundle-adjustment path.
+
+Names, argument meaning and error behaviour follow apex-solver (Rust) so that the parity tests
+read like the reference's own tests:
+
+  Problem / fix_variable               src/core/problem.rs:465-489, 609-616 (BA subset: one BAL
+                                       ProjectionFactor + HuberLoss per observation, as
+                                       bin/bundle_adjustment.rs:232-298, 391-441 builds it)
+  LinearSolverType, SchurVariant       src/linalg/mod.rs:48-57 ; explicit_schur.rs:58-65
+  LevenbergMarquardtConfig             src/optimizer/levenberg_marquardt.rs:213-530
+  LevenbergMarquardt.optimize          :1034-1083 (dispatch) and :823-1031 (loop; the loop itself
+                                       runs in the library's C++ twin, apexgpu_lm_optimize)
+  GpuSchurComplementSolver             LinearSolver<M> + StructureAware (src/linalg/mod.rs:116-180)
+                                       as SparseSchurComplementSolver implements them
+                                       (explicit_schur.rs:1038-1243)
+  SolverResult, OptimizationStatus     src/optimizer/mod.rs:189-273
+
+All numerics run in libapexgpu.so (HIP, gfx950); nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass, field, replace
+
+import numpy as np
+
+from . import capi
+from .layout import ColumnLayout, reference_column_layout
+from .synthetic import BAProblemData
+
+
+class LinearSolverType(enum.Enum):
+    """src/linalg/mod.rs:48-57 (#[non_exhaustive]) + the variant this backend adds."""
+
+    SparseCholesky = "SparseCholesky"
+    SparseQR = "SparseQR"
+    SparseSchurComplement = "SparseSchurComplement"
+    DenseCholesky = "DenseCholesky"
+    DenseQR = "DenseQR"
+    GpuSchurComplement = "GpuSchurComplement"
+
+
+class SchurVariant(enum.Enum):
+    Sparse = 0      # explicit S + Cholesky
+    Iterative = 1   # explicit S + Jacobi-PCG (explicit_schur.rs:1117-1120)
+
+
+class SchurPreconditioner(enum.Enum):
+    """Stored but ignored on the LM path, exactly like the reference."""
+
+    None_ = 0
+    BlockDiagonal = 1
+    SchurJacobi = 2
+
+
+class OptimizationType(enum.Enum):
+    """bin/bundle_adjustment.rs:268-284 (the two types that involve the Schur path)."""
+
+    BundleAdjustment = 0  # factor keys [pose, pt]
+    SelfCalibration = 1   # factor keys [pose, pt, intr]  (the reference's default)
+
+
+class OptimizationStatus(enum.Enum):
+    Converged = 0
+    MaxIterationsReached = 1
+    CostToleranceReached = 2
+    ParameterToleranceReached = 3
+    GradientToleranceReached = 4
+    NumericalFailure = 5
+    UserTerminated = 6
+    Timeout = 7
+    TrustRegionRadiusTooSmall = 8
+    MinCostThresholdReached = 9
+    IllConditionedJacobian = 10
+    InvalidNumericalValues = 11
+    LinearSolveFailed = 100  # OptimizerError::LinearSolveFailed aborts optimize() in the reference
+
+
+@dataclass
+class LevenbergMarquardtConfig:
+    """Defaults of levenberg_marquardt.rs:318-358.  Fields the reference stores but never reads
+    (min_relative_decrease, good_step_quality, ... SURVEY.md §3.2) are not reproduced."""
+
+    linear_solver_type: LinearSolverType = LinearSolverType.GpuSchurComplement
+    max_iterations: int = 50
+    cost_tolerance: float = 1e-6
+    parameter_tolerance: float = 1e-8
+    gradient_tolerance: float = 1e-10
+    timeout: float | None = None
+    damping: float = 1e-3
+    damping_min: float = 1e-12
+    damping_max: float = 1e12
+    damping_nu: float = 2.0
+    trust_region_radius: float = 1e4
+    min_trust_region_radius: float = 1e-32
+    min_cost_threshold: float | None = None
+    schur_variant: SchurVariant = SchurVariant.Sparse
+    schur_preconditioner: SchurPreconditioner = SchurPreconditioner.None_
+
+    @classmethod
+    def new(cls) -> "LevenbergMarquardtConfig":
+        return cls()
+
+    @classmethod
+    def for_bundle_adjustment(cls) -> "LevenbergMarquardtConfig":
+        """:519-530 -- Schur complement, Iterative variant, 20 iterations, Ceres tolerances."""
+        return cls(max_iterations=20, schur_variant=SchurVariant.Iterative,
+                   schur_preconditioner=SchurPreconditioner.SchurJacobi)
+
+    # builder methods (:361-492)
+    def with_linear_solver_type(self, t): return replace(self, linear_solver_type=t)
+    def with_max_iterations(self, n): return replace(self, max_iterations=int(n))
+    def with_cost_tolerance(self, v): return replace(self, cost_tolerance=float(v))
+    def with_parameter_tolerance(self, v): return replace(self, parameter_tolerance=float(v))
+    def with_gradient_tolerance(self, v): return replace(self, gradient_tolerance=float(v))
+    def with_timeout(self, seconds): return replace(self, timeout=seconds)
+    def with_damping(self, v): return replace(self, damping=float(v))
+    def with_damping_bounds(self, lo, hi): return replace(self, damping_min=float(lo), damping_max=float(hi))
+    def with_min_cost_threshold(self, v): return replace(self, min_cost_threshold=v)
+    def with_schur_variant(self, v): return replace(self, schur_variant=v)
+    def with_schur_preconditioner(self, v): return replace(self, schur_preconditioner=v)
+
+    def to_c(self) -> capi.LmConfigC:
+        return capi.LmConfigC(
+            self.max_iterations, self.cost_tolerance, self.parameter_tolerance, self.gradient_tolerance,
+            self.damping, self.damping_min, self.damping_max, self.damping_nu, self.trust_region_radius,
+            self.min_trust_region_radius, -1.0 if self.min_cost_threshold is None else self.min_cost_threshold,
+            -1.0 if self.timeout is None else float(self.timeout), self.schur_variant.value)
+
+
+@dataclass
+class Problem:
+    """The factor graph bin/bundle_adjustment.rs builds: variables `pose_{i:04}` (SE3),
+    `intr_{i:04}` (Rn 3), `pt_{j:05}` (Rn 3); one ProjectionFactor<BALPinholeCameraStrict, OP>
+    with HuberLoss(1.0) per observation.  Only what the device backend has to ingest is kept."""
+
+    data: BAProblemData
+    optimization_type: OptimizationType = OptimizationType.SelfCalibration
+    huber_delta: float | None = 1.0
+    fix_pose: np.ndarray = field(default=None)
+    fix_intr: np.ndarray = field(default=None)
+    fix_pt: np.ndarray = field(default=None)
+
+    def __post_init__(self):
+        d = self.data
+        if self.fix_pose is None:
+            self.fix_pose = np.zeros((d.n_cam, 6), dtype=np.uint8)
+        if self.fix_intr is None:
+            self.fix_intr = np.zeros((d.n_cam, 3), dtype=np.uint8)
+        if self.fix_pt is None:
+            self.fix_pt = np.zeros((d.n_pt, 3), dtype=np.uint8)
+        self.layout: ColumnLayout = reference_column_layout(d.n_cam, d.n_pt)
+
+    @classmethod
+    def bundle_adjustment(cls, data: BAProblemData, optimization_type=OptimizationType.SelfCalibration,
+                          huber_delta: float | None = 1.0) -> "Problem":
+        """run_bundle_adjustment (bin/bundle_adjustment.rs:211-298): gauge fixed by all six DOF of
+        pose_0000."""
+        p = cls(data, optimization_type, huber_delta)
+        for dof in range(6):
+            p.fix_variable("pose_0000", dof)
+        return p
+
+    def fix_variable(self, name: str, dof: int):
+        """Problem::fix_variable (src/core/problem.rs:609-616)."""
+        kind, idx = name.split("_")
+        i = int(idx)
+        if kind == "pose":
+            self.fix_pose[i, dof] = 1
+        elif kind == "intr":
+            self.fix_intr[i, dof] = 1
+        elif kind == "pt":
+            self.fix_pt[i, dof] = 1
+        else:
+            raise KeyError(name)
+
+    @property
+    def total_dof(self) -> int:
+        return self.layout.total_dof
+
+    @property
+    def num_residual_blocks(self) -> int:
+        return self.data.n_obs
+
+
+class GpuSchurComplementSolver:
+    """Device-resident explicit-Schur solver behind the reference's LinearSolver surface.
+
+    Differences from SparseSchurComplementSolver that the boundary hides: the Jacobian is never
+    materialised (the solver linearises the factors itself, so `solve_augmented_equation` takes
+    only lambda), and the parameters live on the device between calls."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+        self.variant = SchurVariant.Sparse
+        self.cg_max_iterations = 200
+        self.cg_tolerance = 1e-6
+        self._h: capi.Handle | None = None
+        self._problem: Problem | None = None
+        self._gradient = None
+        self._shard = None
+        self._comm = None
+
+    # builder methods (explicit_schur.rs:219-238)
+    def with_variant(self, v: SchurVariant): self.variant = v; return self
+    def with_preconditioner(self, _p): return self  # ignored on this path, like the reference
+    def with_cg_params(self, max_iter: int, tol: float): self.cg_max_iterations, self.cg_tolerance = max_iter, tol; return self
+    def with_shard(self, rank: int, world: int): self._shard = (rank, world); return self
+    def with_communicator(self, world: int, rank: int, unique_id: bytes): self._comm = (world, rank, unique_id); return self
+
+    # StructureAware::initialize_structure
+    def initialize_structure(self, problem: Problem):
+        d = problem.data
+        mode = problem.optimization_type.value
+        self._h = capi.Handle(d.n_cam, d.n_pt, d.n_obs, mode, self.device)
+        h = self._h
+        if self._comm is not None:
+            world, rank, uid = self._comm
+            buf = (C.c_char * 128).from_buffer_copy(uid)
+            h.check(h.L.apexgpu_comm_init(h.h, world, rank, C.cast(buf, C.c_void_p)))
+        elif self._shard is not None:
+            h.check(h.L.apexgpu_set_shard(h.h, *self._shard))
+        lay = problem.layout
+        self._keep = [np.ascontiguousarray(a) for a in (
+            d.cam_idx.astype(np.uint32), d.pt_idx.astype(np.uint32), d.obs_uv.astype(np.float64),
+            lay.intr_col, lay.pose_col, lay.pt_col, problem.fix_pose, problem.fix_intr, problem.fix_pt)]
+        hd = -1.0 if problem.huber_delta is None else float(problem.huber_delta)
+        h.check(h.L.apexgpu_set_structure(h.h, *[capi.ptr(a) for a in self._keep], hd))
+        h.check(h.L.apexgpu_set_cg_params(h.h, self.cg_max_iterations, self.cg_tolerance))
+        self._problem = problem
+        return self
+
+    def _need(self) -> capi.Handle:
+        if self._h is None:
+            raise capi.LinAlgError(-5, "Block structure not built. Call initialize_structure() first.")
+        return self._h
+
+    def set_parameters(self, poses, intr, points):
+        h = self._need()
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (poses, intr, points)]
+        h.check(h.L.apexgpu_set_params(h.h, *[capi.ptr(x) for x in a]))
+
+    def get_parameters(self):
+        h = self._need()
+        poses = np.empty((h.n_cam, 7)); intr = np.empty((h.n_cam, 3)); pts = np.empty((h.n_pt, 3))
+        h.check(h.L.apexgpu_get_params(h.h, capi.ptr(poses), capi.ptr(intr), capi.ptr(pts)))
+        return poses, intr, pts
+
+    def compute_cost(self) -> float:
+        h = self._need(); c = C.c_double()
+        h.check(h.L.apexgpu_cost(h.h, C.byref(c)))
+        return c.value
+
+    def assemble(self, lam: float):
+        """A1-A11 only: S, g_red, H_ll^-1, g on the device at the current parameters."""
+        h = self._need()
+        h.check(h.L.apexgpu_assemble(h.h, float(lam)))
+
+    # LinearSolver::solve_augmented_equation / solve_normal_equation
+    def solve_augmented_equation(self, lam: float, want_step: bool = True):
+        h = self._need()
+        n = self._problem.total_dof
+        step = np.zeros(n) if want_step else None
+        grad = np.zeros(n) if want_step else None
+        h.check(h.L.apexgpu_solve_augmented(h.h, float(lam), self.variant.value, capi.ptr(step), capi.ptr(grad)))
+        self._gradient = grad
+        return step
+
+    def solve_normal_equation(self):
+        return self.solve_augmented_equation(0.0)
+
+    def get_gradient(self):
+        """+J^T r of the last solve (explicit_schur.rs:1240-1242); None before any solve."""
+        return self._gradient
+
+    def step_stats(self):
+        h = self._need(); out = (C.c_double * 3)()
+        h.check(h.L.apexgpu_step_stats(h.h, C.byref(out)))
+        return tuple(out)
+
+    def eval_step(self) -> float:
+        h = self._need(); c = C.c_double()
+        h.check(h.L.apexgpu_eval_step(h.h, C.byref(c)))
+        return c.value
+
+    def commit_step(self): h = self._need(); h.check(h.L.apexgpu_commit_step(h.h))
+    def discard_step(self): h = self._need(); h.check(h.L.apexgpu_discard_step(h.h))
+
+    def parameter_norm(self) -> float:
+        h = self._need(); c = C.c_double()
+        h.check(h.L.apexgpu_parameter_norm(h.h, C.byref(c)))
+        return c.value
+
+    # parity / debug
+    def get_residual(self):
+        h = self._need(); r = np.zeros(2 * h.n_obs)
+        h.check(h.L.apexgpu_get_residual(h.h, capi.ptr(r)))
+        return r
+
+    def get_jacobian_blocks(self):
+        h = self._need(); dc = 9 if h.mode == 1 else 6
+        jc = np.zeros((h.n_obs, 2, dc)); jl = np.zeros((h.n_obs, 2, 3))
+        h.check(h.L.apexgpu_get_jacobian_blocks(h.h, capi.ptr(jc), capi.ptr(jl)))
+        return jc, jl
+
+    def get_schur(self):
+        h = self._need(); n = 9 * h.n_cam
+        S = np.zeros((n, n)); g = np.zeros(n)
+        h.check(h.L.apexgpu_get_schur(h.h, capi.ptr(S), capi.ptr(g)))
+        return S, g
+
+    def get_landmark_blocks(self):
+        h = self._need()
+        hi = np.zeros((h.n_pt, 3, 3)); gl = np.zeros((h.n_pt, 3))
+        h.check(h.L.apexgpu_get_landmark_blocks(h.h, capi.ptr(hi), capi.ptr(gl)))
+        return hi, gl
+
+    def info(self) -> dict:
+        h = self._need(); out = (C.c_double * 8)()
+        h.check(h.L.apexgpu_info(h.h, C.byref(out)))
+        return dict(tile_rows=int(out[0]), tiles=int(out[1]), pair_blocks=float(out[2]), cam_dof=int(out[3]),
+                    last_reg=float(out[4]), pcg_iterations=int(out[5]), touched_tiles=int(out[6]), local_obs=int(out[7]))
+
+    def enable_stage_timing(self, on=True): h = self._need(); h.check(h.L.apexgpu_enable_stage_timing(h.h, int(on)))
+    def reset_stage_times(self): h = self._need(); h.check(h.L.apexgpu_reset_stage_times(h.h))
+
+    def stage_times(self) -> dict:
+        h = self._need()
+        ms = (C.c_double * capi.NUM_STAGES)(); n = (C.c_int64 * capi.NUM_STAGES)()
+        h.check(h.L.apexgpu_stage_times(h.h, C.byref(ms), C.byref(n)))
+        return {name: (ms[i], n[i]) for i, name in enumerate(capi.STAGE_NAMES)}
+
+    def lm_optimize(self, cfg: LevenbergMarquardtConfig):
+        h = self._need()
+        c = cfg.to_c()
+        c.variant = self.variant.value
+        res = capi.LmResultC()
+        cap = cfg.max_iterations + 2
+        hist = (capi.LmIterC * cap)()
+        h.check(h.L.apexgpu_lm_optimize(h.h, C.byref(c), C.byref(res), C.cast(hist, C.c_void_p), cap))
+        n = res.iterations
+        H = np.array([[getattr(hist[i], f) for f, _ in capi.LmIterC._fields_] for i in range(min(n, cap))])
+        return res, H.reshape(-1, 8), c
+
+    def close(self):
+        if self._h is not None:
+            self._h.close()
+            self._h = None
+
+
+@dataclass
+class SolverResult:
+    """src/optimizer/mod.rs:250-273 (BA subset)."""
+
+    status: OptimizationStatus
+    iterations: int
+    initial_cost: float
+    final_cost: float
+    parameters: tuple  # (poses, intr, points)
+    elapsed_time: float
+    final_gradient_norm: float
+    final_parameter_update_norm: float
+    cost_evaluations: int
+    jacobian_evaluations: int
+    successful_steps: int
+    unsuccessful_steps: int
+    history: np.ndarray  # per iteration: cost, damping, rho, accepted, |g|, |step|, predicted, trial cost
+    final_damping: float = 0.0
+
+
+class LevenbergMarquardt:
+    def __init__(self, config: LevenbergMarquardtConfig | None = None, device: int = 0):
+        self.config = config or LevenbergMarquardtConfig()
+        self.device = device
+        self.linear_solver: GpuSchurComplementSolver | None = None
+
+    @classmethod
+    def new(cls): return cls()
+
+    @classmethod
+    def with_config(cls, config: LevenbergMarquardtConfig, device: int = 0): return cls(config, device)
+
+    def optimize(self, problem: Problem, initial_values=None, solver: GpuSchurComplementSolver | None = None) -> SolverResult:
+        """LevenbergMarquardt::optimize (:1034-1083): the GpuSchurComplement arm builds the solver,
+        initialises its structure, uploads the initial values and runs the loop on the device."""
+        t = self.config.linear_solver_type
+        if t not in (LinearSolverType.GpuSchurComplement, LinearSolverType.SparseSchurComplement):
+            raise NotImplementedError(f"{t} is a CPU solver of the reference; this backend provides GpuSchurComplement")
+        d = problem.data
+        s = solver or GpuSchurComplementSolver(self.device)
+        s.with_variant(self.config.schur_variant).with_preconditioner(self.config.schur_preconditioner)
+        if s._h is None:
+            s.initialize_structure(problem)
+        poses, intr, pts = initial_values if initial_values is not None else (d.poses, d.intr, d.points)
+        s.set_parameters(poses, intr, pts)
+        self.linear_solver = s
+        res, hist, c = s.lm_optimize(self.config)
+        return SolverResult(
+            status=OptimizationStatus(res.status), iterations=res.iterations, initial_cost=res.initial_cost,
+            final_cost=res.final_cost, parameters=s.get_parameters(), elapsed_time=res.elapsed_s,
+            final_gradient_norm=res.final_gradient_norm, final_parameter_update_norm=res.final_step_norm,
+            cost_evaluations=res.cost_evaluations, jacobian_evaluations=res.jacobian_evaluations,
+            successful_steps=res.successful_steps, unsuccessful_steps=res.unsuccessful_steps, history=hist,
+            final_damping=c.damping)

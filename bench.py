@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- ms per Levenberg-Marquardt iteration of the MI355X bundle-adjustment backend.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--scale S]
+                  [--mode selfcal|ba] [--variant sparse|iterative] [--no-cpu-baseline]
+
+A "step" is one LM iteration on a synthetic BA problem of the named BASELINE.json shape:
+linearise all factors + explicit Schur complement + damped Cholesky of S + back-substitution
+(apexgpu_solve_augmented), step statistics, retraction to a trial point and its cost, and the
+accept/reject bookkeeping -- exactly the body of optimize_with_mode's loop
+(src/optimizer/levenberg_marquardt.rs:857-1029).  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
+
+For N > 1 launch with torch.distributed.run (one process per GPU); landmarks are sharded over the
+ranks, S and g_red are all-reduced over RCCL inside the library, so total work is fixed
+("scaling": "strong").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md): 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("APEX_BENCH_WORKLOAD", "final-13682"))
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--mode", default="selfcal", choices=["selfcal", "ba"])
+    ap.add_argument("--variant", default="sparse", choices=["sparse", "iterative"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0: choose for ~10-30 s of CPU work")
+    return ap.parse_args()
+
+
+def lm_step(s, state):
+    """One LM iteration through the C ABI (mirrors Solver::lm_optimize / the reference loop)."""
+    s.solve_augmented_equation(state["lam"], want_step=False)
+    gn, sn, pred = s.step_stats()
+    new_cost = s.eval_step()
+    actual = state["cost"] - new_cost
+    rho = (1.0 if actual > 0 else 0.0) if abs(pred) < 1e-15 else actual / pred
+    if rho > 0.0:
+        coff = 2.0 * rho - 1.0
+        state["lam"] = max(state["lam"] * max(1.0 / 3.0, 1.0 - coff**3), 1e-12)
+        state["nu"] = 2.0
+        state["cost"] = new_cost
+        s.commit_step()
+        state["accepted"] += 1
+    else:
+        state["lam"] = min(state["lam"] * state["nu"], 1e12)
+        state["nu"] *= 2.0
+        s.discard_step()
+    state["hist"].append((state["cost"], rho))
+
+
+def cpu_baseline(args, shape_scale, mode):
+    """The oracle (kind "port": C restatement of the reference CPU path, OpenMP) timed on this
+    box's host cores on a bounded sample of the same workload."""
+    import apex_solver_amd as pkg
+    from oracle import oracle as ora
+
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    d = pkg.synthetic.make_named(args.workload, shape_scale)
+    lay = pkg.layout.reference_column_layout(d.n_cam, d.n_pt)
+    o = ora.from_data(d, lay, mode=mode, native=True)
+    cost = o.residuals()[0]
+    t0 = time.perf_counter()
+    n_it = 0
+    lam = 1e-3
+    while n_it < 2:
+        o.linearize()
+        step, grad = o.solve_augmented(lam, 0)
+        o.apply_step(step, 1.0)
+        new_cost = o.residuals()[0]
+        if new_cost < cost:
+            cost = new_cost
+            lam = max(lam / 3.0, 1e-12)
+        else:
+            o.apply_step(step, -1.0)
+            lam *= 2.0
+        n_it += 1
+    ms = (time.perf_counter() - t0) * 1e3 / n_it
+    return {
+        "value": ms, "unit": "ms per LM iter on the sample", "cores": cores, "kind": "port",
+        "sample": f"{d.name}: {d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations, "
+                  f"{2} LM iterations of oracle/ba_oracle.c (linearise + explicit dense Schur + dense Cholesky + trial cost)",
+        "obs_per_s": d.n_obs / (ms * 1e-3),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+
+    import torch
+    import torch.distributed as dist
+
+    import apex_solver_amd as pkg
+    from apex_solver_amd.solver import GpuSchurComplementSolver, OptimizationType, Problem, SchurVariant
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    d = pkg.synthetic.make_named(args.workload, args.scale)
+    ot = OptimizationType.SelfCalibration if args.mode == "selfcal" else OptimizationType.BundleAdjustment
+    prob = Problem.bundle_adjustment(d, ot, 1.0)
+    s = GpuSchurComplementSolver(local_rank)
+    s.with_variant(SchurVariant.Sparse if args.variant == "sparse" else SchurVariant.Iterative)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        import ctypes as C
+
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            rc = pkg.capi.load().apexgpu_get_unique_id(C.cast(buf, C.c_void_p))
+            assert rc == 0
+            uid = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).cuda()
+        dist.broadcast(uid, 0)
+        s.with_communicator(world, rank, bytes(uid.cpu().numpy().tobytes()))
+    t_setup = time.perf_counter()
+    s.initialize_structure(prob)
+    s.set_parameters(d.poses, d.intr, d.points)
+    setup_s = time.perf_counter() - t_setup
+    info = s.info()
+
+    state = dict(lam=1e-3, nu=2.0, cost=s.compute_cost(), accepted=0, hist=[])
+    initial_cost = state["cost"]
+    for _ in range(args.warmup):
+        lm_step(s, state)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    s.enable_stage_timing(True)
+    s.reset_stage_times()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lm_step(s, state)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stages = s.stage_times()
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    # ---- roofline of the dominant Schur kernel (k_schur_scatter), per launch ------------------------
+    dc = 9 if args.mode == "selfcal" else 6
+    n_obs_local = info["local_obs"]
+    tile_bytes = 144 * 144 * 8
+    alg_bytes = (24.0 * n_obs_local            # observation stream: cam idx, landmark idx, (u,v)
+                 + 80.0 * d.n_cam + 24.0 * d.n_pt  # poses + intrinsics, points (each read once)
+                 + 96.0 * d.n_pt                # Hll^-1 and g_l per landmark
+                 + tile_bytes * info["touched_tiles"]  # S tiles that receive contributions
+                 + 8.0 * dc * d.n_cam)          # g_red
+    sc_ms, sc_n = stages["schur_scatter"]
+    sc_avg = sc_ms / max(sc_n, 1)
+    achieved = alg_bytes / (sc_avg * 1e-3) / 1e9 if sc_avg > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_schur_scatter", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
+                "avg_launch_ms": sc_avg, "launches": sc_n,
+                "pair_blocks_per_launch": info["pair_blocks"], "atomic_bytes_per_launch": info["pair_blocks"] * dc * dc * 8.0}
+
+    out = {
+        "metric": "ms per LM iter (Jacobian+Schur+solve)", "value": ms_per_step, "unit": "ms", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{d.name} synthetic ({d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations)",
+                   "optimization_type": args.mode, "camera_dof": dc, "schur_variant": args.variant, "huber": 1.0,
+                   "s_tile_rows": info["tile_rows"], "s_tiles": info["tiles"], "parallelism": f"landmark-shard x{world}"},
+        "roofline": roofline,
+        "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
+        "stage_launches": {k: int(v[1]) for k, v in stages.items()},
+        "setup_s": setup_s, "initial_cost": initial_cost, "final_cost": state["cost"], "accepted_steps": state["accepted"],
+        "obs_per_s": d.n_obs / (ms_per_step * 1e-3),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sc = args.cpu_sample_scale
+        if sc <= 0.0:  # ~0.6 M observations: tens of seconds of CPU work with the dense oracle
+            sc = min(1.0, 100000.0 / max(d.n_pt, 1)) if d.n_pt > 100000 else 1.0
+            sc = min(sc, 150.0 / max(d.n_cam, 1)) if d.n_cam > 150 else sc
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, sc * args.scale, args.mode)
+        except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+            out["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(out))
+    s.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

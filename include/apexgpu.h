@@ -1,0 +1,185 @@
+/*
+ * apexgpu.h -- C ABI of the MI355X-native bundle-adjustment backend for apex-solver.
+ *
+ * This is the drop-in boundary: what a thin Rust `extern "C"` shim that
+ * implements apex-solver's `LinearSolver<M>` / `StructureAware` / `AssemblyBackend` traits binds to
+ * (the shim itself is in INTEGRATION.md), and what the bundled C++ Levenberg-Marquardt twin and the
+ * Python host layer call.  Plain pointers and sizes only; all host buffers are caller-owned and are
+ * copied in/out during the call; one handle per `optimize()`; a handle is not re-entrant; no
+ * callbacks into the caller.
+ *
+ * Every function returns an int status: 0 = ok, negative = error class mirroring
+ * `LinAlgError` (src/linalg/mod.rs:76-101); the message is available from apexgpu_last_error().
+ *
+ * Conventions (the reference's): pose = [tx,ty,tz,qw,qx,qy,qz] (SE3 as
+ * VariableEnum::to_vector stores it, src/core/problem.rs:161-173), intrinsics = [f,k1,k2]
+ * (bal_pinhole.rs:160-181), point = [x,y,z]; tangent step of a pose = [rho(3); theta(3)]
+ * applied as the right-plus retraction T o Exp(delta) (apex-manifolds/src/lib.rs:269-283);
+ * vectors named *_out of length total_dof are in the reference's GLOBAL column order, i.e. the
+ * lexicographic order of the variable names (src/optimizer/mod.rs:530-536) that the caller passes
+ * as column offsets to apexgpu_set_structure.
+ */
+#ifndef APEXGPU_H
+#define APEXGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct apexgpu_solver apexgpu_solver;
+
+/* status codes = LinAlgError variants (src/linalg/mod.rs:76-101) */
+#define APEXGPU_OK 0
+#define APEXGPU_ERR_FACTORIZATION_FAILED (-1)
+#define APEXGPU_ERR_SINGULAR_MATRIX (-2)
+#define APEXGPU_ERR_SPARSE_MATRIX_CREATION (-3)
+#define APEXGPU_ERR_MATRIX_CONVERSION (-4)
+#define APEXGPU_ERR_INVALID_INPUT (-5)
+#define APEXGPU_ERR_INVALID_STATE (-6)
+#define APEXGPU_ERR_DEVICE (-10)
+
+/* OptimizationType of the projection factors (src/factors/mod.rs:82-101,
+ * bin/bundle_adjustment.rs:268-284): which variables each factor is keyed on. */
+#define APEXGPU_MODE_BUNDLE_ADJUSTMENT 0 /* keys [pose, pt]        -> 6 camera DOF per block */
+#define APEXGPU_MODE_SELF_CALIBRATION 1  /* keys [pose, pt, intr]  -> 9 camera DOF per block */
+
+/* SchurVariant (src/linalg/sparse/explicit_schur.rs:58-65) */
+#define APEXGPU_VARIANT_SPARSE 0    /* explicit S + Cholesky (solve_with_cholesky, :539-634) */
+#define APEXGPU_VARIANT_ITERATIVE 1 /* explicit S + Jacobi-PCG (solve_with_pcg, :639-756)    */
+
+/* ---- lifetime ------------------------------------------------------------------------------
+ * Replaces SparseSchurComplementSolver::new() (explicit_schur.rs:205-217) + the per-optimize
+ * state of optimize_with_mode (levenberg_marquardt.rs:823-848). */
+int apexgpu_create(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device, apexgpu_solver** out);
+void apexgpu_destroy(apexgpu_solver* h);
+const char* apexgpu_last_error(const apexgpu_solver* h);
+const char* apexgpu_version(void);
+
+/* ---- structure -------------------------------------------------------------------------------
+ * Replaces StructureAware::initialize_structure (src/linalg/mod.rs:116-123; explicit_schur.rs:
+ * 1038-1062, 244-323), build_symbolic_structure (src/linearizer/cpu/sparse.rs:54-105) and the
+ * problem description the reference keeps in Problem's residual blocks
+ * (bin/bundle_adjustment.rs:391-441): one BAL projection factor per observation.
+ *   cam_idx/pt_idx[n_obs]   variable indices of each factor, in residual-block insertion order
+ *   obs_uv[2*n_obs]         observed pixel (u,v) per factor
+ *   intr_col/pose_col[n_cam], pt_col[n_pt]  first global column of intr_i / pose_i / pt_j
+ *   fix_pose[6*n_cam], fix_intr[3*n_cam], fix_pt[3*n_pt]  per-DOF fixed masks (may be NULL);
+ *                           fixed DOF are zeroed in the step at apply time only
+ *                           (src/core/problem.rs:185-197), they stay in the linear system
+ *   huber_delta             HuberLoss scale on every factor (<= 0: no loss function)          */
+int apexgpu_set_structure(apexgpu_solver* h, const uint32_t* cam_idx, const uint32_t* pt_idx, const double* obs_uv,
+                          const int64_t* intr_col, const int64_t* pose_col, const int64_t* pt_col,
+                          const uint8_t* fix_pose, const uint8_t* fix_intr, const uint8_t* fix_pt, double huber_delta);
+
+/* CG limits of the Iterative variant (with_cg_params, explicit_schur.rs:234-238; defaults 200, 1e-6) */
+int apexgpu_set_cg_params(apexgpu_solver* h, int max_iterations, double tolerance);
+
+/* ---- parameters ------------------------------------------------------------------------------
+ * Replaces Problem::initialize_variables (src/core/problem.rs:686-808) / reading
+ * SolverResult.parameters back (src/optimizer/mod.rs:250-273). */
+int apexgpu_set_params(apexgpu_solver* h, const double* poses, const double* intr, const double* points);
+int apexgpu_get_params(apexgpu_solver* h, double* poses, double* intr, double* points);
+
+/* ---- hot path --------------------------------------------------------------------------------*/
+/* cost = 1/2 |r~|^2 of the Huber-corrected residuals at the current parameters:
+ * Problem::compute_residual_sparse + compute_cost (src/core/problem.rs:864-899,
+ * src/optimizer/mod.rs:358-361). */
+int apexgpu_cost(apexgpu_solver* h, double* cost);
+
+/* AssemblyBackend::assemble (src/linearizer/mod.rs:191-213, cpu/sparse.rs:119-184) fused with
+ * LinearSolver::solve_augmented_equation (src/linalg/mod.rs:143-180; explicit_schur.rs:1129-1234):
+ * linearises every factor at the current parameters, forms H_cc, H_ll^-1, S, g_red on the device,
+ * solves S dc = g_red and back-substitutes.  The Jacobian is never materialised.
+ *   step_out  (total_dof, may be NULL): the step, global column order
+ *   grad_out  (total_dof, may be NULL): +J^T r, what get_gradient() returns (:1240-1242)
+ * The step also stays on the device for apexgpu_eval_step. */
+int apexgpu_solve_augmented(apexgpu_solver* h, double lambda, int variant, double* step_out, double* grad_out);
+
+/* The assembly half alone (A1-A11: H_cc, H_ll^-1, S, g_red, g on the device at the current
+ * parameters, no solve) -- AssemblyBackend::assemble's slot (src/linearizer/mod.rs:191-213).  Used by
+ * tests and by callers that want S / g_red (apexgpu_get_schur) without a step. */
+int apexgpu_assemble(apexgpu_solver* h, double lambda);
+
+/* out3 = { gradient.norm_l2(), step.norm_l2(), predicted reduction 1/2 step^T (lambda step - g) }
+ * of the last solve (levenberg_marquardt.rs:743-746, 721-727, 890). */
+int apexgpu_step_stats(apexgpu_solver* h, double out3[3]);
+
+/* apply_parameter_step + compute_residual_sparse + compute_cost on a trial copy
+ * (levenberg_marquardt.rs:776-786; src/optimizer/mod.rs:309-331). */
+int apexgpu_eval_step(apexgpu_solver* h, double* trial_cost);
+/* accept: the trial copy becomes current (levenberg_marquardt.rs:797-801) */
+int apexgpu_commit_step(apexgpu_solver* h);
+/* reject: apply_negative_parameter_step (src/optimizer/mod.rs:343-356) -- the inverse retraction of
+ * the trial point, not a snapshot restore */
+int apexgpu_discard_step(apexgpu_solver* h);
+/* compute_parameter_norm (src/optimizer/mod.rs:458-467) */
+int apexgpu_parameter_norm(apexgpu_solver* h, double* out);
+
+/* ---- the LM loop (C++ twin of optimize_with_mode, levenberg_marquardt.rs:823-1031) ------------*/
+typedef struct {
+    int max_iterations;             /* 50   (for_bundle_adjustment: 20)            :323, :524 */
+    double cost_tolerance;          /* 1e-6                                         :325 */
+    double parameter_tolerance;     /* 1e-8                                         :327 */
+    double gradient_tolerance;      /* 1e-10                                        :330 */
+    double damping;                 /* 1e-3  (in/out: final value)                  :332 */
+    double damping_min;             /* 1e-12                                        :333 */
+    double damping_max;             /* 1e12                                         :334 */
+    double damping_nu;              /* 2.0   (in/out)                               :337 */
+    double trust_region_radius;     /* 1e4   constant, never shrinks                :338 */
+    double min_trust_region_radius; /* 1e-32                                        :345 */
+    double min_cost_threshold;      /* < 0: None                                    :344 */
+    double timeout_s;               /* <= 0: None                                   :331 */
+    int variant;                    /* APEXGPU_VARIANT_*                            :355 */
+} apexgpu_lm_config;
+
+typedef struct {
+    double cost, damping, rho, accepted, gradient_norm, step_norm, predicted_reduction, trial_cost;
+} apexgpu_lm_iter;
+
+typedef struct {
+    int status;     /* OptimizationStatus discriminant (src/optimizer/mod.rs:189-216); 100 = linear solve failed */
+    int iterations; /* SolverResult.iterations = last iteration index + 1 */
+    double initial_cost, final_cost, final_gradient_norm, final_step_norm, elapsed_s;
+    int cost_evaluations, jacobian_evaluations, successful_steps, unsuccessful_steps;
+} apexgpu_lm_result;
+
+int apexgpu_lm_optimize(apexgpu_solver* h, apexgpu_lm_config* cfg, apexgpu_lm_result* result,
+                        apexgpu_lm_iter* history, int history_capacity);
+
+/* ---- parity / debug exports (observers' set_matrix_data analogue, src/observers/mod.rs:201-260) */
+int apexgpu_get_residual(apexgpu_solver* h, double* r_out /* 2*n_obs, caller's factor order */);
+/* corrected blocks per factor: jc_out[n_obs][2][d_c] (pose columns first, then intrinsics when
+ * d_c = 9), jl_out[n_obs][2][3] */
+int apexgpu_get_jacobian_blocks(apexgpu_solver* h, double* jc_out, double* jl_out);
+/* dense S ((9 n_cam)^2 row-major, symmetric) and g_red (9 n_cam) in the reference's camera-side
+ * column order, for the last lambda; either may be NULL */
+int apexgpu_get_schur(apexgpu_solver* h, double* S_out, double* gred_out);
+int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out /* n_pt*9 */, double* gl_out /* n_pt*3 */);
+
+/* ---- measurement ------------------------------------------------------------------------------*/
+#define APEXGPU_NUM_STAGES 10
+/* stage order: cam-reduce(+memset), landmark-reduce, schur-scatter, all-reduce, factor (or PCG),
+ * triangular solves, back-substitute, step-stats, retract, cost */
+int apexgpu_enable_stage_timing(apexgpu_solver* h, int on);
+int apexgpu_reset_stage_times(apexgpu_solver* h);
+int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_t calls[APEXGPU_NUM_STAGES]);
+/* info[0] = S tile rows, [1] = allocated tiles, [2] = camera-pair contributions per Schur reduce,
+ * [3] = internal camera DOF, [4] = regularisation used by the last Cholesky, [5] = PCG iterations,
+ * [6] = S tiles that receive Schur contributions (before fill), [7] = observations on this rank */
+int apexgpu_info(apexgpu_solver* h, double info[8]);
+
+/* ---- multi-GPU: one process per GPU, landmarks sharded, RCCL all-reduce of S and g_red -----------
+ * apexgpu_get_unique_id fills 128 bytes on rank 0; broadcast them (any transport) and call
+ * apexgpu_comm_init on every rank BEFORE apexgpu_set_structure.  apexgpu_set_shard alone (no
+ * communicator) restricts the assembly to this rank's landmark range, for tests that sum the
+ * partial S / g_red themselves. */
+int apexgpu_get_unique_id(void* out128);
+int apexgpu_comm_init(apexgpu_solver* h, int world, int rank, const void* unique_id128);
+int apexgpu_set_shard(apexgpu_solver* h, int rank, int world);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APEXGPU_H */

@@ -1,0 +1,85 @@
+"""The per-lane device math (apex-solver_amd/csrc/ba_device.hpp), compiled for the host,
+against the oracle.  No GPU needed: this isolates formula errors from kernel-structure errors."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import apex_solver_amd as pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_f = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+@pytest.fixture(scope="module")
+def hh():
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libhost_harness.so")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC",
+                    "-I", os.path.join(ROOT, "apex-solver_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "host_harness.cpp"), "-o", so], check=True)
+    L = C.CDLL(so)
+    L.hh_linearize_obs.argtypes = [C.c_int, _f, _f, _f, _f, C.c_double, _f, _f, _f]
+    L.hh_residual_obs.argtypes = [_f, _f, _f, _f, C.c_double, _f]
+    L.hh_invert_block.argtypes = [_f, _f]
+    L.hh_se3_plus.argtypes = [_f, _f, _f]
+    return L
+
+
+def test_linearize_matches_oracle(hh, oracle):
+    d = pkg.synthetic.make_problem(9, 120, 3, 6, config_id=55, behind_frac=0.05)
+    # un-normalised quaternions, as they are after a retraction
+    poses = d.poses.copy(); poses[:, 3:] *= (1 + 1e-9 * np.arange(9))[:, None]
+    L = oracle.lib()
+    worst = 0.0
+    n_invalid = 0
+    for i in range(d.n_obs):
+        c, l = int(d.cam_idx[i]), int(d.pt_idx[i])
+        r0 = np.empty(2); Jp = np.empty(12); Jl0 = np.empty(6); Ji = np.empty(6)
+        ok0 = L.ora_linearize_obs(poses[c], d.intr[c], d.points[l], d.obs_uv[i], 1.0, 1, r0, Jp, Jl0, Ji)
+        for dc in (6, 9):
+            r = np.empty(2); Jc = np.empty(2 * dc); Jl = np.empty(6)
+            ok = hh.hh_linearize_obs(dc, poses[c], d.intr[c], d.points[l], d.obs_uv[i], 1.0, r, Jc, Jl)
+            assert ok == ok0
+            ref = np.concatenate([Jp.reshape(2, 6), Ji.reshape(2, 3)], 1)[:, :dc]
+            sc = max(np.abs(ref).max(), 1e-300)
+            worst = max(worst, np.abs(Jc.reshape(2, dc) - ref).max() / sc, np.abs(Jl - Jl0).max() / max(np.abs(Jl0).max(), 1e-300),
+                        np.abs(r - r0).max() / max(np.abs(r0).max(), 1.0))
+        r = np.empty(2)
+        assert hh.hh_residual_obs(poses[c], d.intr[c], d.points[l], d.obs_uv[i], 1.0, r) == ok0
+        assert np.abs(r - r0).max() <= 1e-13 * max(np.abs(r0).max(), 1.0)
+        n_invalid += (ok0 == 0)
+    assert n_invalid > 0  # the cheirality branch was exercised
+    assert worst < 1e-12, worst
+
+
+def test_invert_block_matches_oracle(hh, oracle):
+    rng = np.random.default_rng(3)
+    blocks = []
+    for _ in range(200):
+        A = rng.standard_normal((3, 3)); blocks.append(A @ A.T + 1e-3 * np.eye(3))
+    blocks += [np.diag([4.0, 1.0, 0.0]), np.diag([1e3, 1.0, 1e-9]), np.diag([2.0, 3.0, 4.0]), np.zeros((3, 3))]
+    v = np.array([1.0, 2.0, 3.0]); blocks.append(np.outer(v, v) + 1e-3 * np.eye(3))  # rank-1 + damping
+    for B in blocks:
+        B = np.ascontiguousarray(B.ravel())
+        o0 = np.empty(9); o1 = np.empty(9)
+        rc = oracle.lib().ora_invert_landmark_blocks(1, B, 0.0, o0)
+        ok = hh.hh_invert_block(B, o1)
+        assert (rc == 0) == bool(ok)
+        if ok:
+            assert np.allclose(o0, o1, rtol=1e-12, atol=1e-300)
+
+
+def test_se3_plus_matches_oracle(hh, oracle):
+    rng = np.random.default_rng(4)
+    for scale in (1e-7, 1e-3, 0.5):
+        for _ in range(20):
+            pose = rng.standard_normal(7); pose[3:] /= np.linalg.norm(pose[3:]) * (1 + 1e-10)
+            d = scale * rng.standard_normal(6)
+            a = np.empty(7); b = np.empty(7)
+            oracle.lib().ora_se3_plus(pose, d, a)
+            hh.hh_se3_plus(pose, d, b)
+            assert np.allclose(a, b, rtol=1e-13, atol=1e-15)

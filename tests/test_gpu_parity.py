@@ -1,0 +1,326 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
+Every test needs a real MI355X: run with `pytest -m gpu`.  Tolerances are written next to
+each assertion; integer/index work does not occur on this path, everything is fp64.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import apex_solver_amd as pkg
+import np_ref
+from apex_solver_amd.solver import (GpuSchurComplementSolver, LevenbergMarquardt, LevenbergMarquardtConfig,
+                                    OptimizationStatus, OptimizationType, Problem, SchurVariant)
+
+pytestmark = pytest.mark.gpu
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def rel(a, b):
+    a = np.ravel(a); b = np.ravel(b)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def gpu_solver(d, mode, huber=1.0, variant=SchurVariant.Sparse, fix_first=True, shard=None):
+    ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
+    prob = Problem.bundle_adjustment(d, ot, huber) if fix_first else Problem(d, ot, huber)
+    s = GpuSchurComplementSolver(0).with_variant(variant)
+    if shard:
+        s.with_shard(*shard)
+    s.initialize_structure(prob)
+    s.set_parameters(d.poses, d.intr, d.points)
+    return prob, s
+
+
+def oracle_problem(ora, d, prob, mode):
+    o = ora.from_data(d, prob.layout, mode=mode, huber_delta=prob.huber_delta if prob.huber_delta else -1.0)
+    return o
+
+
+def jc_to_blocks(jc, dc):
+    """GPU camera block [pose(6) | intr(3)] -> (Jpose, Jintr)"""
+    jp = jc[:, :, :6]
+    ji = jc[:, :, 6:9] if dc == 9 else np.zeros((jc.shape[0], 2, 3))
+    return jp, ji
+
+
+def data_from_golden(g):
+    from apex_solver_amd.synthetic import BAProblemData
+
+    return BAProblemData(poses=g["poses0"], intr=g["intr0"], points=g["points0"], cam_idx=g["cam_idx"],
+                         pt_idx=g["pt_idx"], obs_uv=g["obs_uv"], name="golden")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_golden_fixture_iterations(path):
+    """Three LM iterations of each committed fixture, stage by stage."""
+    g = np.load(path)
+    d = data_from_golden(g)
+    mode = str(g["mode"])
+    prob, s = gpu_solver(d, mode)
+    dc = 9 if mode == "selfcal" else 6
+    assert s.compute_cost() == pytest.approx(float(g["initial_cost"]), rel=1e-13)
+    for it in range(int(g["iters"])):
+        lam = float(g[f"it{it}_lambda"])
+        assert rel(s.get_residual(), g[f"it{it}_r"]) < 1e-12
+        jc, jl = s.get_jacobian_blocks()
+        jp, ji = jc_to_blocks(jc, dc)
+        assert rel(jp, g[f"it{it}_Jpose"]) < 1e-12 and rel(jl, g[f"it{it}_Jpt"]) < 1e-12
+        if dc == 9:
+            assert rel(ji, g[f"it{it}_Jintr"]) < 1e-12
+        step = s.solve_augmented_equation(lam)
+        grad = s.get_gradient()
+        S, gred = s.get_schur()
+        errs = dict(grad=rel(grad, g[f"it{it}_grad"]), S=rel(S, g[f"it{it}_S"]), gred=rel(gred, g[f"it{it}_gred"]),
+                    step=rel(step, g[f"it{it}_step"]))
+        print(os.path.basename(path), "iter", it, {k: f"{v:.1e}" for k, v in errs.items()})
+        assert errs["grad"] < 1e-12 and errs["S"] < 1e-12 and errs["gred"] < 1e-11
+        assert errs["step"] < 1e-9  # cond(S) ~ 1e9: forward error of two Cholesky codes
+        gn, sn, pred = s.step_stats()
+        assert gn == pytest.approx(np.linalg.norm(g[f"it{it}_grad"]), rel=1e-12)
+        assert pred == pytest.approx(float(g[f"it{it}_pred"]), rel=1e-8)
+        trial = s.eval_step()
+        assert trial == pytest.approx(float(g[f"it{it}_new_cost"]), rel=1e-9)
+        if bool(g[f"it{it}_accepted"]):
+            s.commit_step()
+        else:
+            s.discard_step()
+    poses, intr, pts = s.get_parameters()
+    assert rel(poses, g["poses_end"]) < 1e-9 and rel(pts, g["points_end"]) < 1e-9 and rel(intr, g["intr_end"]) < 1e-9
+    s.close()
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_golden_lm_history(path):
+    g = np.load(path)
+    d = data_from_golden(g)
+    mode = str(g["mode"])
+    ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
+    prob = Problem.bundle_adjustment(d, ot, 1.0)
+    res = LevenbergMarquardt.with_config(LevenbergMarquardtConfig().with_max_iterations(8)).optimize(prob)
+    hg = g["lm_history"]
+    assert res.status.name == str(g["lm_status"]) and res.iterations == int(g["lm_iterations"])
+    assert np.array_equal(res.history[:, 3], hg[:, 3])            # accept / reject pattern
+    assert np.allclose(res.history[:, 0], hg[:, 0], rtol=1e-7)    # cost per iteration
+    assert np.allclose(res.history[:, 1], hg[:, 1], rtol=1e-4)    # damping (depends on rho)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["selfcal", "ba"])
+@pytest.mark.parametrize("shape", [(40, 2000, 3, 7), (130, 4000, 3, 9)], ids=["40x2000", "130x4000"])
+def test_one_iteration_vs_oracle(oracle, mode, shape):
+    """Seeded synthetic problems (several S tiles, symbolic fill) against the oracle."""
+    n_cam, n_pt, klo, khi = shape
+    d = pkg.synthetic.make_problem(n_cam, n_pt, klo, khi, config_id=200 + n_cam)
+    prob, s = gpu_solver(d, mode)
+    o = oracle_problem(oracle, d, prob, mode)
+    assert s.compute_cost() == pytest.approx(o.residuals()[0], rel=1e-13)
+    lam = 1e-3
+    o.linearize()
+    ostep, ograd, oS, ogred = o.solve_augmented(lam, 0, want_schur=True)
+    step = s.solve_augmented_equation(lam)
+    S, gred = s.get_schur()
+    hinv, gl = s.get_landmark_blocks()
+    errs = dict(grad=rel(s.get_gradient(), ograd), S=rel(S, oS), gred=rel(gred, ogred), step=rel(step, ostep))
+    print(mode, shape, {k: f"{v:.1e}" for k, v in errs.items()}, s.info())
+    assert errs["grad"] < 1e-12 and errs["S"] < 1e-12 and errs["gred"] < 1e-10
+    # S dc = g_red holds to working precision whatever the conditioning ...
+    nc = prob.layout.cam_dof
+    bwd = np.linalg.norm(oS @ step[:nc] - ogred) / (np.linalg.norm(oS, 2) * np.linalg.norm(step[:nc]) + np.linalg.norm(ogred))
+    assert bwd < 1e-14
+    # ... and the step agrees with the oracle's to the north-star tolerance scaled by what the
+    # conditioning of S allows (1 ulp of noise on S moves dc by ~eps*cond(S))
+    tol = max(1e-10, 20 * np.finfo(float).eps * np.linalg.cond(oS))
+    assert errs["step"] < tol, (errs["step"], tol)
+    # trial point
+    o.apply_step(ostep, 1.0)
+    assert s.eval_step() == pytest.approx(o.residuals()[0], rel=1e-9)
+    s.close()
+
+
+@pytest.mark.parametrize("mode", ["selfcal", "ba"])
+def test_pcg_variant_vs_oracle(oracle, mode):
+    d = pkg.synthetic.make_problem(30, 1500, 3, 7, config_id=77)
+    prob, s = gpu_solver(d, mode, variant=SchurVariant.Iterative)
+    o = oracle_problem(oracle, d, prob, mode)
+    o.linearize()
+    ostep, ograd, oS, ogred = o.solve_augmented(1e-3, 1, want_schur=True)
+    step = s.solve_augmented_equation(1e-3)
+    nc = prob.layout.cam_dof
+    # both stop on |r| < 1e-6*max(|b|,1) (explicit_schur.rs:684) or after 200 iterations
+    print("pcg iterations gpu/oracle", s.info()["pcg_iterations"], o.last_pcg_iters)
+    assert abs(s.info()["pcg_iterations"] - o.last_pcg_iters) <= 2
+    r_gpu = np.linalg.norm(oS @ step[:nc] - ogred); r_ora = np.linalg.norm(oS @ ostep[:nc] - ogred)
+    assert r_gpu < 10 * max(r_ora, 1e-6 * max(np.linalg.norm(ogred), 1.0))
+    s.close()
+
+
+def test_full_normal_equations_from_exported_blocks():
+    """Size-independent property: with J rebuilt (scipy.sparse) from the blocks the GPU exports, the
+    returned step solves (J^T J + lambda I) dx = -J^T r and the returned gradient is J^T r."""
+    d = pkg.synthetic.make_problem(300, 20000, 3, 8, config_id=31)
+    for mode in ("selfcal", "ba"):
+        prob, s = gpu_solver(d, mode)
+        dc = 9 if mode == "selfcal" else 6
+        lam = 1e-2
+        step = s.solve_augmented_equation(lam)
+        jc, jl = s.get_jacobian_blocks()
+        jp, ji = jc_to_blocks(jc, dc)
+        r = s.get_residual()
+        J = np_ref.sparse_jacobian(jp, jl, ji, d.cam_idx, d.pt_idx, prob.layout, selfcal=(mode == "selfcal"))
+        g = J.T @ r
+        assert rel(s.get_gradient(), g) < 1e-12
+        A = (J.T @ J) + lam * np_ref.sp.identity(J.shape[1])
+        bwd = np.linalg.norm(A @ step + g) / (np_ref.spla.norm(A) * np.linalg.norm(step) + np.linalg.norm(g))
+        print(mode, "normal-equation backward error", bwd, s.info())
+        assert bwd < 1e-13
+        gn, sn, pred = s.step_stats()
+        assert gn == pytest.approx(np.linalg.norm(g), rel=1e-12) and sn == pytest.approx(np.linalg.norm(step), rel=1e-12)
+        assert pred == pytest.approx(0.5 * step @ (lam * step - g), rel=1e-10)
+        s.close()
+
+
+# ---- edge cases -----------------------------------------------------------------------------------
+def _custom(n_cam, n_pt, cam_lists, seed=5):
+    """A problem with explicit per-landmark camera lists (duplicates allowed)."""
+    base = pkg.synthetic.make_problem(n_cam, n_pt, 3, 3, config_id=seed)
+    cam_idx, pt_idx = [], []
+    for l, cams in enumerate(cam_lists):
+        cam_idx += list(cams); pt_idx += [l] * len(cams)
+    cam_idx = np.asarray(cam_idx, dtype=np.uint32); pt_idx = np.asarray(pt_idx, dtype=np.uint32)
+    rng = np.random.default_rng(seed)
+    # shuffle the factor order: the caller's order is arbitrary, the library sorts by landmark
+    perm = rng.permutation(len(cam_idx))
+    cam_idx, pt_idx = cam_idx[perm], pt_idx[perm]
+    uv = pkg.synthetic.project_bal(base.truth_poses[cam_idx], base.truth_intr[cam_idx], base.truth_points[pt_idx])
+    uv = uv + rng.normal(0, 0.7, uv.shape)
+    from apex_solver_amd.synthetic import BAProblemData
+
+    return BAProblemData(base.poses, base.intr, base.points, cam_idx, pt_idx, np.ascontiguousarray(uv))
+
+
+@pytest.mark.parametrize("mode", ["selfcal", "ba"])
+def test_ragged_landmarks(oracle, mode):
+    """k = 0 (unobserved landmark), k = 1, a duplicated camera, k = 64/65/129/200 (block-split
+    landmarks use the off-diagonal scatter tasks), mixed in one problem."""
+    n_cam = 210
+    rng = np.random.default_rng(9)
+    lists = [[], [3], [5, 5, 9], list(range(64)), list(range(65)), list(range(40, 169)), list(range(200)),
+             [7, 8, 7, 8, 100]]
+    lists += [sorted(rng.choice(n_cam, size=int(rng.integers(2, 12)), replace=False).tolist()) for _ in range(300)]
+    d = _custom(n_cam, len(lists), lists)
+    prob, s = gpu_solver(d, mode)
+    o = oracle_problem(oracle, d, prob, mode)
+    assert s.compute_cost() == pytest.approx(o.residuals()[0], rel=1e-13)
+    o.linearize()
+    ostep, ograd, oS, ogred = o.solve_augmented(1e-3, 0, want_schur=True)
+    step = s.solve_augmented_equation(1e-3)
+    S, gred = s.get_schur()
+    errs = dict(r=rel(s.get_residual(), o.residuals()[1]), grad=rel(s.get_gradient(), ograd), S=rel(S, oS),
+                gred=rel(gred, ogred), step=rel(step, ostep))
+    print(mode, {k: f"{v:.1e}" for k, v in errs.items()}, s.info())
+    assert errs["r"] < 1e-12 and errs["grad"] < 1e-12 and errs["S"] < 1e-12 and errs["gred"] < 1e-10
+    assert errs["step"] < max(1e-10, 20 * np.finfo(float).eps * np.linalg.cond(oS))
+    s.close()
+
+
+def test_cheirality_and_no_loss(oracle):
+    """Points behind a camera give zero residual/Jacobian (projection_factor.rs:227-238); without a
+    loss function the corrector is skipped (linearizer/mod.rs:144)."""
+    d = pkg.synthetic.make_problem(12, 400, 3, 6, config_id=102, behind_frac=0.05)
+    for huber in (1.0, None):
+        prob, s = gpu_solver(d, "selfcal", huber=huber)
+        o = oracle_problem(oracle, d, prob, "selfcal")
+        c, r = o.residuals()
+        assert np.sum((r.reshape(-1, 2) == 0).all(1)) > 0
+        assert s.compute_cost() == pytest.approx(c, rel=1e-13)
+        assert rel(s.get_residual(), r) < 1e-12
+        o.linearize()
+        ostep, ograd, oS, ogred = o.solve_augmented(1e-3, 0, want_schur=True)
+        step = s.solve_augmented_equation(1e-3)
+        S, gred = s.get_schur()
+        scale = np.abs(oS).max()
+        print("huber", huber, rel(S, oS), rel(step, ostep))
+        assert rel(s.get_gradient(), ograd) < 1e-12
+        # a landmark almost on a camera centre makes S = Hcc - E cancel terms ~1e12 (see
+        # tests/test_oracle_golden.py); compare against the size of what is cancelled
+        hinv, gl = s.get_landmark_blocks()
+        assert np.isfinite(S).all() and np.isfinite(step).all()
+        assert np.abs(S - oS).max() / scale < 1e-6
+        s.close()
+
+
+def test_rejected_step_round_trip(oracle):
+    """A rejected step is undone by the inverse retraction (optimizer/mod.rs:343-356)."""
+    d = pkg.synthetic.make_problem(10, 300, 3, 6, config_id=8)
+    prob, s = gpu_solver(d, "selfcal")
+    o = oracle_problem(oracle, d, prob, "selfcal")
+    o.linearize()
+    ostep, _ = o.solve_augmented(1e-3, 0)
+    s.solve_augmented_equation(1e-3)
+    s.eval_step(); s.discard_step()
+    o.apply_step(ostep, 1.0); o.apply_step(ostep, -1.0)
+    po, io, lo = o.get_params(); pg, ig, lg = s.get_parameters()
+    assert rel(pg, po) < 1e-12 and rel(lg, lo) < 1e-12 and rel(ig, io) < 1e-12
+    assert np.abs(lg - d.points).max() < 1e-12  # back where it started up to rounding
+    s.close()
+
+
+def test_error_behaviour():
+    """Error classes mirror LinAlgError (src/linalg/mod.rs:76-101)."""
+    from apex_solver_amd.capi import LinAlgError
+
+    d = pkg.synthetic.make_problem(6, 40, 3, 5, config_id=101)
+    s = GpuSchurComplementSolver(0)
+    with pytest.raises(LinAlgError) as e:  # solve before initialize_structure (explicit_schur.rs:1138-1142)
+        s.solve_augmented_equation(1e-3)
+    assert e.value.kind == "InvalidInput"
+    prob = Problem.bundle_adjustment(d)
+    s.initialize_structure(prob)
+    with pytest.raises(LinAlgError) as e:  # parameters not set
+        s.solve_augmented_equation(1e-3)
+    assert e.value.kind == "InvalidState"
+    assert s.get_gradient() is None  # LM turns this into NumericalInstability (levenberg_marquardt.rs:743-745)
+    bad = pkg.synthetic.make_problem(6, 40, 3, 5, config_id=101)
+    bad.cam_idx = bad.cam_idx.copy(); bad.cam_idx[3] = 99
+    with pytest.raises(LinAlgError) as e:
+        GpuSchurComplementSolver(0).initialize_structure(Problem.bundle_adjustment(bad))
+    assert e.value.kind == "InvalidInput"
+    s.close()
+
+
+def test_lm_converges_like_reference_integration_test(oracle):
+    """tests/bundle_adjustment_integration.rs:33-153 asserts only: converged status,
+    final_cost < initial_cost, RMSE decreased.  Same assertions, plus agreement with the oracle."""
+    d = pkg.synthetic.make_problem(21, 1100, 3, 8, config_id=21)
+    prob = Problem.bundle_adjustment(d, OptimizationType.SelfCalibration, 1.0)
+    cfg = LevenbergMarquardtConfig.for_bundle_adjustment().with_schur_variant(SchurVariant.Sparse).with_max_iterations(50)
+    res = LevenbergMarquardt.with_config(cfg).optimize(prob)
+    assert res.status in (OptimizationStatus.CostToleranceReached, OptimizationStatus.ParameterToleranceReached,
+                          OptimizationStatus.GradientToleranceReached, OptimizationStatus.MaxIterationsReached)
+    assert res.final_cost < res.initial_cost
+    o = oracle_problem(oracle, d, prob, "selfcal")
+    ores = o.optimize(oracle.LMConfig.default(max_iterations=50, variant=0))
+    print(res.status, res.iterations, res.final_cost, "| oracle", ores.status, ores.iterations, ores.final_cost)
+    assert res.status.name == ores.status and res.iterations == ores.iterations
+    assert res.final_cost == pytest.approx(ores.final_cost, rel=1e-6)
+
+
+def test_shard_partials_sum_to_full(oracle):
+    """Landmark shards (no communicator): partial S and g_red of the two halves add up to the full
+    ones -- the quantity the RCCL all-reduce sums."""
+    d = pkg.synthetic.make_problem(40, 2000, 3, 7, config_id=240)
+    prob, s = gpu_solver(d, "selfcal")
+    s.solve_augmented_equation(1e-3)
+    S, gred = s.get_schur()
+    parts = []
+    for r in range(2):
+        _, sr = gpu_solver(d, "selfcal", shard=(r, 2))
+        sr.assemble(1e-3)
+        parts.append(sr.get_schur())
+        sr.close()
+    S2 = parts[0][0] + parts[1][0]; g2 = parts[0][1] + parts[1][1]
+    assert rel(S2, S) < 1e-12 and rel(g2, gred) < 1e-11
+    s.close()
