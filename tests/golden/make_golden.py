@@ -60,6 +60,7 @@ def make(name, n_cam, n_pt, k_lo, k_hi, cid, mode, behind=0.0, iters=3):
         nc2 = np_ref.residuals(tp, ti, tl, d.cam_idx, d.pt_idx, d.obs_uv)[1]
         assert abs(new_cost - nc2) / nc2 < 1e-11, (new_cost, nc2)
         rho = (cost - new_cost) / pred
+        out.update({f"it{it}_poses": poses, f"it{it}_intr": intr, f"it{it}_points": pts})
         out.update({f"it{it}_lambda": lam, f"it{it}_cost": c, f"it{it}_r": r, f"it{it}_Jpose": Jp, f"it{it}_Jpt": Jl,
                     f"it{it}_Jintr": Ji, f"it{it}_grad": grad, f"it{it}_S": S, f"it{it}_gred": gred,
                     f"it{it}_step": step, f"it{it}_pred": pred, f"it{it}_new_cost": new_cost, f"it{it}_rho": rho})
