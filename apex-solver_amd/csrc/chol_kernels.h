@@ -19,6 +19,13 @@ struct GemvTask {  // see k_tile_gemv for the modes
     int mode;
 };
 
+struct TriTask {   // one workgroup of a triangular-solve step (k_tri_step)
+    const double* Mdiag;  // Linv of the step's diagonal tile
+    const double* Moff;   // the off-diagonal tile this workgroup applies (unused when other < 0)
+    int k;                // block solved in this step
+    int other;            // block updated by this workgroup; -1: store the solved block instead
+};
+
 struct SymEntry {  // one tile of block-row I of the symmetric tile matrix
     int slot;      // tile slot
     int other;     // the other block index (column block for kind 0/2, row block for kind 1)
@@ -28,6 +35,7 @@ struct SymEntry {  // one tile of block-row I of the symmetric tile matrix
 void launch_potrf_inv(double* A, double* Linv, int K, int* fail, hipStream_t s);
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s);
 void launch_tile_gemv(const GemvTask* tasks, int n, double* y, const double* x, hipStream_t s);
+void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s);
 void launch_sym_tile_matvec(int nt, const int* row_ptr, const SymEntry* entries, const double* tiles, const double* x,
                             double* y, hipStream_t s);
 void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double* diag, hipStream_t s);

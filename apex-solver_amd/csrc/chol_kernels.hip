@@ -20,72 +20,221 @@ namespace apex {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int NB = kNB;
-constexpr int kPacked = NB * (NB + 1) / 2;
-
-__device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
-
 // ------------------------------------------------------------------------------------------
-// potrf + triangular inverse of one diagonal tile, one 256-thread workgroup, tile held
-// lower-packed in LDS (83.5 KB).  Thread (ti,tk) of a 16x16 grid owns elements i=ti (mod 16),
-// k=tk (mod 16) of every rank-1 update, so the work stays balanced as the trailing block shrinks.
-// fail[0] is set to K+1 if a pivot is not positive (faer: NonPositivePivot).
+// potrf + triangular inverse of one diagonal tile: the latency-critical link of the tile Cholesky
+// (every column K waits for it).  One 256-thread workgroup; the tile lives in LDS as the 45 lower
+// 16x16 blocks (pitch 18 doubles -> conflict-free MFMA operand reads), 101 KB, plus the 9 inverted
+// diagonal blocks, 20 KB.  Blocked right-looking factorisation:
+//   per block column kb:  wave 0 factors the 16x16 diagonal block in registers (shuffles, no
+//   barriers) and inverts it by forward substitution; the panel solve X = A L_kk^-T and the rank-16
+//   trailing update run on v_mfma_f64_16x16x4_f64, blocks dealt round-robin to the 4 waves.
+// Then L is written out and inverted in place block-column by block-column (LAPACK dtrtri, lower):
+//   Linv(i,j) = -(sum_{k=j+1..i} Linv(i,k) L(k,j)) Linv(j,j).
+// fail[0] is set to K+1 if a pivot is not positive (faer's Llt: NonPositivePivot).
 // ------------------------------------------------------------------------------------------
+constexpr int BS = 16;            // block edge
+constexpr int NBK = NB / BS;      // 9 blocks per tile edge
+constexpr int BP = 18;            // block row pitch (doubles)
+constexpr int BSZ = BS * BP;      // 288 doubles per block
+constexpr int NLB = NBK * (NBK + 1) / 2;  // 45 lower blocks
+
+__device__ __forceinline__ int bidx(int bi, int bj) { return bi * (bi + 1) / 2 + bj; }  // bi >= bj
+
+// value of `v` in lane `src` (src must be wave-uniform; here always a compile-time constant)
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// D = X * Y^T (NT) or X * Y (NN) on 16x16 blocks held in LDS with pitch BP
+__device__ __forceinline__ double4_t blk_mma_nt(const double* X, const double* Y, double4_t acc, int lr, int lk, double sgn) {
+#pragma unroll
+    for (int kk = 0; kk < BS; kk += 4) {
+        const double a = sgn * X[lr * BP + kk + lk];
+        const double b = Y[lr * BP + kk + lk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ double4_t blk_mma_nn(const double* X, const double* Y, double4_t acc, int lr, int lk) {
+#pragma unroll
+    for (int kk = 0; kk < BS; kk += 4) {
+        const double a = X[lr * BP + kk + lk];
+        const double b = Y[(kk + lk) * BP + lr];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ double4_t blk_load_cd(const double* C, int lr, int lk) {
+    double4_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = C[(lk + 4 * r) * BP + lr];
+    return v;
+}
+__device__ __forceinline__ void blk_store_cd(double* C, double4_t v, int lr, int lk, double sgn) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[(lk + 4 * r) * BP + lr] = sgn * v[r];
+}
+
 __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ A, double* __restrict__ Linv, int K,
                                                      int* __restrict__ fail) {
-    __shared__ double s[kPacked];
-    __shared__ double col[NB];
+    __shared__ double sA[NLB * BSZ];
+    __shared__ double sD[NBK * BSZ];
     __shared__ int bad;
-    const int tid = threadIdx.x, ti = tid >> 4, tk = tid & 15;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
     if (tid == 0) bad = 0;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx / NB, j = idx - i * NB;
-        if (j <= i) s[pk(i, j)] = A[idx];
-    }
-    __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        if (tid == 0) {
-            const double d = s[pk(j, j)];
-            if (!(d > 0.0)) { bad = 1; s[pk(j, j)] = 1.0; }
-            else s[pk(j, j)] = sqrt(d);
-        }
-        __syncthreads();
-        const double d = s[pk(j, j)];
-        for (int i = j + 1 + tid; i < NB; i += 256) s[pk(i, j)] /= d;
-        __syncthreads();
-        for (int i = j + 1 + ti; i < NB; i += 16) {
-            const double aij = s[pk(i, j)];
-            for (int k = j + 1 + tk; k <= i; k += 16) s[pk(i, k)] -= aij * s[pk(k, j)];
-        }
-        // (next iteration's first barrier orders these writes before the pivot read)
-        __syncthreads();
-    }
-    // write L (lower; the strict upper part of a diagonal tile is never read)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx / NB, j = idx - i * NB;
-        if (j <= i) A[idx] = s[pk(i, j)];
-    }
-    __syncthreads();
-    // in-place inverse, columns from last to first (LAPACK dtrti2, lower):
-    //   x_jj = 1/l_jj ; x_(j+1:,j) = -x_jj * Linv(j+1:,j+1:) * l_(j+1:,j)
-    for (int j = NB - 1; j >= 0; --j) {
-        for (int i = j + 1 + tid; i < NB; i += 256) col[i] = s[pk(i, j)];
-        __syncthreads();
-        const double inv_jj = 1.0 / s[pk(j, j)];
-        for (int i = j + 1 + ti; i < NB; i += 16) {
-            double acc = 0.0;
-            for (int k = j + 1 + tk; k <= i; k += 16) acc += s[pk(i, k)] * col[k];
+    // lower blocks only, as 16-byte loads all issued before the first LDS store: block-row bi holds
+    // 16 rows x 8(bi+1) double2; 25 loads per lane cover the 5760 double2 of the lower blocks
+    {
+        double2 reg[25];
+        int n = 0;
 #pragma unroll
-            for (int m = 1; m < 16; m <<= 1) acc += __shfl_xor(acc, m, 16);
-            if (tk == 0) s[pk(i, j)] = -inv_jj * acc;
+        for (int bi = 0; bi < NBK; ++bi) {
+            const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
+#pragma unroll
+            for (int it = 0; it < (16 * 8 * (bi + 1) + 255) / 256; ++it, ++n) {
+                const int idx = tid + 256 * it;
+                if (idx < cnt) {
+                    const int rr = idx / per_row, c2 = idx - rr * per_row;
+                    reg[n] = *reinterpret_cast<const double2*>(A + (size_t)(16 * bi + rr) * NB + 2 * c2);
+                }
+            }
         }
-        __syncthreads();  // every lane has read l_jj before it is replaced by its inverse
-        if (tid == 0) s[pk(j, j)] = inv_jj;
-        // (the next step's barrier after the column copy orders this write before its readers)
+        n = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBK; ++bi) {
+            const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
+#pragma unroll
+            for (int it = 0; it < (16 * 8 * (bi + 1) + 255) / 256; ++it, ++n) {
+                const int idx = tid + 256 * it;
+                if (idx < cnt) {
+                    const int rr = idx / per_row, c2 = idx - rr * per_row;
+                    double* dst = sA + bidx(bi, c2 >> 3) * BSZ + rr * BP + 2 * (c2 & 7);
+                    dst[0] = reg[n].x; dst[1] = reg[n].y;
+                }
+            }
+        }
     }
     __syncthreads();
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx / NB, j = idx - i * NB;
-        Linv[idx] = (j <= i) ? s[pk(i, j)] : 0.0;
+
+    for (int kb = 0; kb < NBK; ++kb) {
+        double* D = sA + bidx(kb, kb) * BSZ;
+        if (w == 0) {
+            // ---- 16x16 Cholesky + inverse in registers: lane r (= lane & 15) owns row r; every
+            // cross-lane operand has a compile-time lane index, so it is a v_readlane (SGPR
+            // broadcast), not an LDS permute.
+            double a[BS], invd[BS];
+#pragma unroll
+            for (int c = 0; c < BS; ++c) a[c] = D[lr * BP + c];
+            int isbad = 0;
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+                const double djj = readlane_f64(a[j], j);
+                if (!(djj > 0.0)) isbad = 1;
+                const double sj = sqrt(djj > 0.0 ? djj : 1.0);
+                const double isj = 1.0 / sj;
+                invd[j] = isj;
+                const double lrj = a[j] * isj;  // L[r][j] for r > j
+#pragma unroll
+                for (int c = j + 1; c < BS; ++c) {
+                    const double lcj = readlane_f64(lrj, c);
+                    if (lr >= c) a[c] -= lrj * lcj;
+                }
+                a[j] = (lr > j) ? lrj : ((lr == j) ? sj : a[j]);
+            }
+            // inverse: lane c solves L x = e_c ; L[i][k] = row i's a[k]
+            double x[BS];
+#pragma unroll
+            for (int i = 0; i < BS; ++i) {
+                double acc = (i == lr) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) acc -= readlane_f64(a[k], i) * x[k];
+                x[i] = acc * invd[i];
+            }
+            if (lk == 0) {
+#pragma unroll
+                for (int c = 0; c < BS; ++c) D[lr * BP + c] = a[c];
+#pragma unroll
+                for (int i = 0; i < BS; ++i) sD[kb * BSZ + i * BP + lr] = x[i];
+            }
+            if (isbad) bad = 1;
+        }
+        __syncthreads();
+        // ---- panel: A(i,kb) <- A(i,kb) * L_kk^-T ------------------------------------------------------
+        for (int i = kb + 1 + w; i < NBK; i += 4) {
+            double* P = sA + bidx(i, kb) * BSZ;
+            double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+            acc = blk_mma_nt(P, sD + kb * BSZ, acc, lr, lk, 1.0);
+            blk_store_cd(P, acc, lr, lk, 1.0);
+        }
+        __syncthreads();
+        // ---- trailing update: A(i,j) -= A(i,kb) A(j,kb)^T, kb < j <= i -------------------------------------
+        {
+            const int m = NBK - 1 - kb;
+            const int n_upd = m * (m + 1) / 2;
+            for (int t = w; t < n_upd; t += 4) {
+                int ii = 0;
+                while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+                const int jj = t - ii * (ii + 1) / 2;
+                const int i = kb + 1 + ii, j = kb + 1 + jj;
+                double* Cb = sA + bidx(i, j) * BSZ;
+                double4_t acc = blk_load_cd(Cb, lr, lk);
+                acc = blk_mma_nt(sA + bidx(i, kb) * BSZ, sA + bidx(j, kb) * BSZ, acc, lr, lk, -1.0);
+                blk_store_cd(Cb, acc, lr, lk, 1.0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- write L (lower blocks; entries above the diagonal inside a diagonal block are never read) -----
+#pragma unroll
+    for (int bi = 0; bi < NBK; ++bi) {
+        const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
+        for (int idx = tid; idx < cnt; idx += 256) {
+            const int rr = idx / per_row, c2 = idx - rr * per_row;
+            const double* src = sA + bidx(bi, c2 >> 3) * BSZ + rr * BP + 2 * (c2 & 7);
+            double2 v; v.x = src[0]; v.y = src[1];
+            *reinterpret_cast<double2*>(A + (size_t)(16 * bi + rr) * NB + 2 * c2) = v;
+        }
+    }
+    __syncthreads();
+    // ---- in-place block inverse, block columns from last to first ------------------------------------------
+    for (int j = NBK - 2; j >= 0; --j) {
+        double4_t T[2];
+        int nt = 0;
+        for (int i = j + 1 + w; i < NBK; i += 4, ++nt) {
+            double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+            for (int k = j + 1; k <= i; ++k) {
+                const double* X = (k == i) ? (sD + i * BSZ) : (sA + bidx(i, k) * BSZ);
+                acc = blk_mma_nn(X, sA + bidx(k, j) * BSZ, acc, lr, lk);
+            }
+            T[nt] = acc;
+        }
+        __syncthreads();  // every wave is done reading the old block column j
+        nt = 0;
+        for (int i = j + 1 + w; i < NBK; i += 4, ++nt) blk_store_cd(sA + bidx(i, j) * BSZ, T[nt], lr, lk, 1.0);
+        __syncthreads();
+        for (int i = j + 1 + w; i < NBK; i += 4) {
+            double* Bk = sA + bidx(i, j) * BSZ;
+            double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+            acc = blk_mma_nn(Bk, sD + j * BSZ, acc, lr, lk);
+            blk_store_cd(Bk, acc, lr, lk, -1.0);
+        }
+        __syncthreads();
+    }
+    // Linv: lower blocks only (the buffer is zero-initialised once and nothing else writes it; the
+    // inverted diagonal blocks carry explicit zeros above their diagonal)
+#pragma unroll
+    for (int bi = 0; bi < NBK; ++bi) {
+        const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
+        for (int idx = tid; idx < cnt; idx += 256) {
+            const int rr = idx / per_row, c2 = idx - rr * per_row;
+            const int bj = c2 >> 3;
+            const double* src = ((bj == bi) ? (sD + bi * BSZ) : (sA + bidx(bi, bj) * BSZ)) + rr * BP + 2 * (c2 & 7);
+            double2 v; v.x = src[0]; v.y = src[1];
+            *reinterpret_cast<double2*>(Linv + (size_t)(16 * bi + rr) * NB + 2 * c2) = v;
+        }
     }
     if (tid == 0 && bad) atomicCAS(fail, 0, K + 1);
 }
@@ -102,28 +251,50 @@ __global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ A, doubl
 // ------------------------------------------------------------------------------------------
 constexpr int KC = 16;
 constexpr int PITCH = KC + 2;
+constexpr int STRIP = 48;          // output rows per workgroup (3 waves x 16)
+constexpr int NSTRIP = NB / STRIP; // 3 workgroups per tile: 3x the parallelism of one per tile
 
-__global__ __launch_bounds__(576) void k_tile_gemm_nt(const GemmTask* __restrict__ tasks, double alpha, double beta) {
-    __shared__ double sA[NB * PITCH];
+__global__ __launch_bounds__(192) void k_tile_gemm_nt(const GemmTask* __restrict__ tasks, double alpha, double beta) {
+    __shared__ double sA[STRIP * PITCH];
     __shared__ double sB[NB * PITCH];
-    const GemmTask t = tasks[blockIdx.x];
+    const GemmTask t = tasks[blockIdx.x / NSTRIP];
+    const int strip = blockIdx.x % NSTRIP;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
+    const double* __restrict__ Ag = t.A + (size_t)strip * STRIP * NB;
     double4_t acc[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    // staging assignment: 576 threads x 4 doubles = 144 rows x 16 columns
-    const int srow = tid >> 2, scol = (tid & 3) * 4;
+    // staging: a 16-column chunk is 8 double2 per row; B: 144 rows -> 1152 double2 = 6 per thread,
+    // A strip: 48 rows -> 384 double2 = 2 per thread
+    double2 rb[6], ra[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int idx = tid + 192 * i, row = idx >> 3, c2 = idx & 7;
+            rb[i] = *reinterpret_cast<const double2*>(t.B + (size_t)row * NB + k0 + 2 * c2);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 192 * i, row = idx >> 3, c2 = idx & 7;
+            ra[i] = *reinterpret_cast<const double2*>(Ag + (size_t)row * NB + k0 + 2 * c2);
+        }
+    };
+    gload(0);
     for (int k0 = 0; k0 < NB; k0 += KC) {
-        const double2* ga = reinterpret_cast<const double2*>(t.A + (size_t)srow * NB + k0 + scol);
-        const double2* gb = reinterpret_cast<const double2*>(t.B + (size_t)srow * NB + k0 + scol);
-        const double2 a0 = ga[0], a1 = ga[1], b0 = gb[0], b1 = gb[1];
         __syncthreads();  // previous chunk fully consumed
-        double* pa = sA + srow * PITCH + scol;
-        double* pb = sB + srow * PITCH + scol;
-        pa[0] = a0.x; pa[1] = a0.y; pa[2] = a1.x; pa[3] = a1.y;
-        pb[0] = b0.x; pb[1] = b0.y; pb[2] = b1.x; pb[3] = b1.y;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int idx = tid + 192 * i, row = idx >> 3, c2 = idx & 7;
+            sB[row * PITCH + 2 * c2] = rb[i].x; sB[row * PITCH + 2 * c2 + 1] = rb[i].y;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 192 * i, row = idx >> 3, c2 = idx & 7;
+            sA[row * PITCH + 2 * c2] = ra[i].x; sA[row * PITCH + 2 * c2 + 1] = ra[i].y;
+        }
         __syncthreads();
+        if (k0 + KC < NB) gload(k0 + KC);  // next chunk in flight while this one feeds the MFMAs
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
             const double a = sA[(16 * w + lr) * PITCH + kk + lk];
@@ -134,14 +305,14 @@ __global__ __launch_bounds__(576) void k_tile_gemm_nt(const GemmTask* __restrict
             }
         }
     }
-    double* C = t.C;
+    double* C = t.C + (size_t)strip * STRIP * NB;
 #pragma unroll
     for (int j = 0; j < 9; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const size_t off = (size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr;
             double v = alpha * acc[j][r];
-            if (beta != 0.0) v += beta * t.C[off];
+            if (beta != 0.0) v += beta * C[off];
             C[off] = v;
         }
 }
@@ -204,6 +375,82 @@ __global__ __launch_bounds__(256) void k_tile_gemv(const GemvTask* __restrict__ 
         else if (op == 1) *y -= sy[tid];
         else *y += sy[tid];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// One step of a tile triangular solve, ONE launch per tile column (forward) / tile row (backward):
+//   forward  K : y_K = Linv_KK b_K ;  b_I -= L_IK y_K  for every tile (I,K) below the diagonal
+//   backward I : x_I = Linv_II^T y_I ; y_J -= L_IJ^T x_I for every tile (I,J) left of the diagonal
+// Workgroup 0 of a step stores the solved block; every other workgroup recomputes the (cheap)
+// diagonal product itself instead of waiting for it, then applies its own tile.  A tile is pulled
+// through LDS in two 72-row halves with 21 16-byte loads per lane in flight (a tile GEMV is pure
+// latency otherwise), pitch 145 doubles so both the row walk (M v) and the column walk (M^T v) are
+// conflict-free.
+// ------------------------------------------------------------------------------------------
+constexpr int HROWS = NB / 2;       // 72
+constexpr int TP = NB + 1;          // 145
+
+template <bool TRANS>
+__device__ __forceinline__ void tile_gemv_lds(const double* __restrict__ M, const double* sv, double* sout, double* sT,
+                                              double* spart, int tid) {
+    double accT = 0.0;
+    for (int h = 0; h < 2; ++h) {
+        double2 reg[21];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < HROWS * (NB / 2)) {
+                const int row = idx / (NB / 2), c2 = idx - row * (NB / 2);
+                reg[i] = *reinterpret_cast<const double2*>(M + (size_t)(HROWS * h + row) * NB + 2 * c2);
+            }
+        }
+        __syncthreads();  // previous half consumed
+#pragma unroll
+        for (int i = 0; i < 21; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < HROWS * (NB / 2)) {
+                const int row = idx / (NB / 2), c2 = idx - row * (NB / 2);
+                sT[row * TP + 2 * c2] = reg[i].x; sT[row * TP + 2 * c2 + 1] = reg[i].y;
+            }
+        }
+        __syncthreads();
+        if (!TRANS) {
+            if (tid < NB) {
+                const int row = tid % HROWS, ch = tid / HROWS;
+                double a = 0.0;
+#pragma unroll 8
+                for (int c = 0; c < HROWS; ++c) a += sT[row * TP + ch * HROWS + c] * sv[ch * HROWS + c];
+                spart[ch * HROWS + row] = a;
+            }
+            __syncthreads();
+            if (tid < HROWS) sout[HROWS * h + tid] = spart[tid] + spart[HROWS + tid];
+        } else {
+            if (tid < NB) {
+#pragma unroll 8
+                for (int r = 0; r < HROWS; ++r) accT += sT[r * TP + tid] * sv[HROWS * h + r];
+            }
+        }
+    }
+    if (TRANS && tid < NB) sout[tid] = accT;
+    __syncthreads();
+}
+
+template <bool TRANS>
+__global__ __launch_bounds__(256) void k_tri_step(const TriTask* __restrict__ tasks, double* __restrict__ vwork,
+                                                    double* __restrict__ vout) {
+    __shared__ double sT[HROWS * TP];
+    __shared__ double sv[NB], sy[NB], sz[NB], spart[NB];
+    const TriTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid < NB) sv[tid] = vwork[(size_t)t.k * NB + tid];
+    __syncthreads();
+    tile_gemv_lds<TRANS>(t.Mdiag, sv, sy, sT, spart, tid);
+    if (t.other < 0) {
+        if (tid < NB) vout[(size_t)t.k * NB + tid] = sy[tid];
+        return;
+    }
+    tile_gemv_lds<TRANS>(t.Moff, sy, sz, sT, spart, tid);
+    if (tid < NB) vwork[(size_t)t.other * NB + tid] -= sz[tid];
 }
 
 // One workgroup per block-row I of the symmetric tile matrix: y_I = sum_J S_IJ x_J using the lower
@@ -325,10 +572,15 @@ void launch_potrf_inv(double* A, double* Linv, int K, int* fail, hipStream_t s) 
     hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), 0, s, A, Linv, K, fail);
 }
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_tile_gemm_nt, dim3(n), dim3(576), 0, s, tasks, alpha, beta);
+    if (n > 0) hipLaunchKernelGGL(k_tile_gemm_nt, dim3(n * NSTRIP), dim3(192), 0, s, tasks, alpha, beta);
 }
 void launch_tile_gemv(const GemvTask* tasks, int n, double* y, const double* x, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_tile_gemv, dim3(n), dim3(256), 0, s, tasks, y, x);
+}
+void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s) {
+    if (n <= 0) return;
+    if (trans) hipLaunchKernelGGL(k_tri_step<true>, dim3(n), dim3(256), 0, s, tasks, vwork, vout);
+    else hipLaunchKernelGGL(k_tri_step<false>, dim3(n), dim3(256), 0, s, tasks, vwork, vout);
 }
 void launch_sym_tile_matvec(int nt, const int* row_ptr, const SymEntry* entries, const double* tiles, const double* x,
                             double* y, hipStream_t s) {

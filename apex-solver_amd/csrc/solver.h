@@ -105,6 +105,7 @@ class Solver {
     int stage_times(double* ms, int64_t* launches);  // averaged HIP-event time per stage since reset
     void reset_stage_times();
     void enable_stage_timing(bool on) { timing_ = on; }
+    void enable_graphs(bool on) { use_graphs_ = on; }
     double schur_scatter_pairs() const { return (double)n_pairs_; }
     double touched_tiles() const { return (double)n_present_; }
     double local_obs() const { return (double)o_orig_h_.size(); }
@@ -126,6 +127,9 @@ class Solver {
     int factor_and_solve(double lambda);
     int cholesky_attempt(int* failed_at);
     int tri_solve();
+    void enqueue_factor();
+    void enqueue_tri_solve();
+    bool run_graph(int which);
     int pcg_solve();
     int cost_of(int which, double* out);
     void stage_begin(int st);
@@ -174,12 +178,18 @@ class Solver {
     ScatterTask* tasks_ = nullptr;
     int n_tasks_ = 0;
     GemmTask *trsm_tasks_ = nullptr, *upd_tasks_ = nullptr;
+    TriTask *tri_fwd_ = nullptr, *tri_bwd_ = nullptr;
     GemvTask *fwd_tasks_ = nullptr, *bwd_tasks_ = nullptr, *diag_tasks_ = nullptr;
     std::vector<int64_t> upd_off_;                 // per K offset into upd_tasks_
     int* sym_row_ptr_ = nullptr;
     SymEntry* sym_entries_ = nullptr;
     double* pcg_buf_ = nullptr;                    // 7 vectors of n_c_pad
     int n_partial_ = 1024;
+
+    // captured launch sequences: [0] factorisation, [1] triangular solves
+    hipGraphExec_t graph_exec_[2] = {nullptr, nullptr};
+    bool graph_failed_[2] = {false, false};
+    bool use_graphs_ = true;
 
     // timing
     bool timing_ = false;

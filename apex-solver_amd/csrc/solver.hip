@@ -36,11 +36,13 @@ Solver::~Solver() {
     void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, fix_pose_, fix_intr_, fix_pt_, tiles_, linv_, slot_, diag_slot_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, trsm_tasks_, upd_tasks_, fwd_tasks_,
-                    bwd_tasks_, diag_tasks_, sym_row_ptr_, sym_entries_, pcg_buf_};
+                    bwd_tasks_, diag_tasks_, tri_fwd_, tri_bwd_, sym_row_ptr_, sym_entries_, pcg_buf_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     resolve_stage_events();
     for (hipEvent_t e : ev_pool_) hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i)
+        if (graph_exec_[i]) hipGraphExecDestroy(graph_exec_[i]);
 #ifdef APEX_WITH_RCCL
     if (comm_) ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm_));
 #endif
@@ -386,6 +388,19 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         for (int I2 : col_rows_[I]) sym.push_back({slot_h_[(size_t)I2 * nt_ + I], I2, 1});
         sym_ptr[I + 1] = (int)sym.size();
     }
+    {
+        std::vector<TriTask> tf, tb;
+        for (int K = 0; K < nt_; ++K) {
+            tf.push_back({linv_ptr(K), nullptr, K, -1});
+            for (int I : col_rows_[K]) tf.push_back({linv_ptr(K), tile_ptr(I, K), K, I});
+        }
+        for (int I = 0; I < nt_; ++I) {
+            tb.push_back({linv_ptr(I), nullptr, I, -1});
+            for (int J : row_cols[I]) tb.push_back({linv_ptr(I), tile_ptr(I, J), I, J});
+        }
+        HIP_TRY(up(&tri_fwd_, tf));
+        HIP_TRY(up(&tri_bwd_, tb));
+    }
     HIP_TRY(up(&trsm_tasks_, trsm));
     HIP_TRY(up(&upd_tasks_, upd));
     HIP_TRY(up(&fwd_tasks_, fwd));
@@ -395,6 +410,10 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(up(&sym_entries_, sym));
     HIP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on stream_
 
+    for (int i = 0; i < 2; ++i) {
+        if (graph_exec_[i]) { hipGraphExecDestroy(graph_exec_[i]); graph_exec_[i] = nullptr; }
+        graph_failed_[i] = false;
+    }
     have_structure_ = true;
     have_params_ = have_step_ = have_trial_ = false;
     cur_ = 0;
@@ -505,9 +524,11 @@ int Solver::assemble(double lambda, double diag_extra) {
     return kOk;
 }
 
-int Solver::cholesky_attempt(int* failed_at) {
+// The factorisation and the triangular solves are static launch sequences for a given structure:
+// they are captured once into hipGraphs (a few thousand tiny dependent launches would otherwise be
+// paced by host launch overhead) and replayed every LM iteration.
+void Solver::enqueue_factor() {
     const size_t tile_elems = (size_t)kNB * kNB;
-    stage_begin(kStFactor);
     for (int K = 0; K < nt_; ++K) {
         launch_potrf_inv(tiles_ + (size_t)diag_slot_h_[K] * tile_elems, linv_ + (size_t)K * tile_elems, K, flags_ + 1, stream_);
         const int n_col = col_off_[K + 1] - col_off_[K];
@@ -516,6 +537,38 @@ int Solver::cholesky_attempt(int* failed_at) {
             launch_tile_gemm_nt(upd_tasks_ + upd_off_[K], (int)(upd_off_[K + 1] - upd_off_[K]), -1.0, 1.0, stream_);
         }
     }
+}
+
+void Solver::enqueue_tri_solve() {
+    // L y = g_red (work vector bvec), then L^T x = y (work vector yvec), x -> dcam_
+    double* bvec = pcg_buf_;
+    double* yvec = pcg_buf_ + n_c_pad_;
+    hipMemcpyAsync(bvec, g_red_, n_c_pad_ * sizeof(double), hipMemcpyDeviceToDevice, stream_);
+    for (int K = 0; K < nt_; ++K)
+        launch_tri_step(false, tri_fwd_ + (col_off_[K] + K), col_off_[K + 1] - col_off_[K] + 1, bvec, yvec, stream_);
+    for (int I = nt_ - 1; I >= 0; --I)
+        launch_tri_step(true, tri_bwd_ + (row_off_[I] + I), row_off_[I + 1] - row_off_[I] + 1, yvec, dcam_, stream_);
+}
+
+bool Solver::run_graph(int which) {
+    if (!use_graphs_) return false;
+    if (!graph_exec_[which]) {
+        if (graph_failed_[which]) return false;
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_failed_[which] = true; return false; }
+        if (which == 0) enqueue_factor(); else enqueue_tri_solve();
+        if (hipStreamEndCapture(stream_, &g) != hipSuccess || !g) { graph_failed_[which] = true; (void)hipGetLastError(); return false; }
+        hipGraphExec_t ex = nullptr;
+        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(g); graph_failed_[which] = true; (void)hipGetLastError(); return false; }
+        hipGraphDestroy(g);
+        graph_exec_[which] = ex;
+    }
+    return hipGraphLaunch(graph_exec_[which], stream_) == hipSuccess;
+}
+
+int Solver::cholesky_attempt(int* failed_at) {
+    stage_begin(kStFactor);
+    if (!run_graph(0)) enqueue_factor();
     stage_end(kStFactor);
     int f = 0;
     HIP_TRY(hipMemcpyAsync(&f, flags_ + 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -526,15 +579,7 @@ int Solver::cholesky_attempt(int* failed_at) {
 
 int Solver::tri_solve() {
     stage_begin(kStTriSolve);
-    HIP_TRY(hipMemcpyAsync(dcam_, g_red_, n_c_pad_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-    for (int K = 0; K < nt_; ++K) {  // L y = b
-        launch_tile_gemv(diag_tasks_ + K, 1, dcam_, dcam_, stream_);
-        launch_tile_gemv(fwd_tasks_ + col_off_[K], col_off_[K + 1] - col_off_[K], dcam_, dcam_, stream_);
-    }
-    for (int I = nt_ - 1; I >= 0; --I) {  // L^T x = y
-        launch_tile_gemv(diag_tasks_ + nt_ + I, 1, dcam_, dcam_, stream_);
-        launch_tile_gemv(bwd_tasks_ + row_off_[I], row_off_[I + 1] - row_off_[I], dcam_, dcam_, stream_);
-    }
+    if (!run_graph(1)) enqueue_tri_solve();
     stage_end(kStTriSolve);
     return kOk;
 }

@@ -89,6 +89,15 @@ def quat_exp(theta: np.ndarray) -> np.ndarray:
     return np.concatenate([np.cos(half)[..., None], theta * s[..., None]], axis=-1)
 
 
+def quat_to_rot(q: np.ndarray) -> np.ndarray:
+    """(n,4) unit quaternions (w,x,y,z) -> (n,9) row-major rotation matrices."""
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    return np.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], axis=-1)
+
+
 def quat_rotate(q: np.ndarray, v: np.ndarray) -> np.ndarray:
     """q v q* for unit quaternions (rows broadcast)."""
     qv = q[..., 1:]
@@ -194,10 +203,38 @@ def make_problem(
     cam_idx = (centre[pt_idx] - W // 2 + off) % n_cam
 
     # --- observations --------------------------------------------------------
-    uv = project_bal(truth_poses[cam_idx], truth_intr[cam_idx], truth_points[pt_idx])
-    uv += 0.5 * np.stack([rng.normal(50, n_obs), rng.normal(52, n_obs)], axis=-1)
+    # exact BAL projection of the truth (bal_pinhole.rs:273-296), structure-of-arrays and through
+    # per-camera rotation matrices: this loop is the generator's hot spot at 29 M observations
+    R = quat_to_rot(q_true)  # (n_cam, 9)
+    ci = cam_idx
+    px, py, pz = (np.take(truth_points[:, a], pt_idx) for a in range(3))
+    pc = []
+    for r in range(3):
+        acc = np.take(R[:, 3 * r], ci) * px
+        acc += np.take(R[:, 3 * r + 1], ci) * py
+        acc += np.take(R[:, 3 * r + 2], ci) * pz
+        acc += np.take(t_true[:, r], ci)
+        pc.append(acc)
+    del px, py, pz
+    inz = -1.0 / pc[2]
+    xn = pc[0] * inz
+    yn = pc[1] * inz
+    del pc, inz
+    r2 = xn * xn + yn * yn
+    dist = 1.0 + np.take(k1, ci) * r2 + np.take(k2, ci) * (r2 * r2)
+    del r2
+    fd = np.take(f, ci) * dist
+    del dist
+    uv = np.empty((n_obs, 2))
+    uv[:, 0] = fd * xn
+    uv[:, 1] = fd * yn
+    del fd, xn, yn
+    uv[:, 0] += 0.5 * rng.normal(50, n_obs)
+    uv[:, 1] += 0.5 * rng.normal(52, n_obs)
     is_out = rng.uniform(54, n_obs) < outlier_frac
-    uv += is_out[:, None] * (-20.0 + 40.0 * np.stack([rng.uniform(55, n_obs), rng.uniform(56, n_obs)], axis=-1))
+    uv[:, 0] += is_out * (-20.0 + 40.0 * rng.uniform(55, n_obs))
+    uv[:, 1] += is_out * (-20.0 + 40.0 * rng.uniform(56, n_obs))
+    del is_out
 
     # --- initial parameters = truth + noise ---------------------------------
     points = truth_points + 1e-2 * np.stack([rng.normal(60 + 2 * a, n_pt) for a in range(3)], axis=-1)
