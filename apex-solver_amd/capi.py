@@ -24,7 +24,7 @@ SYMBOLS = (
     "apexgpu_step_stats", "apexgpu_eval_step", "apexgpu_commit_step", "apexgpu_discard_step",
     "apexgpu_parameter_norm", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
     "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
-    "apexgpu_stage_times", "apexgpu_info", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_set_shard",
+    "apexgpu_stage_times", "apexgpu_info", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_set_shard", "apexgpu_shard_range",
 )
 
 ERROR_NAMES = {
@@ -111,12 +111,24 @@ def load() -> C.CDLL:
     L.apexgpu_get_unique_id.argtypes = [vp]
     L.apexgpu_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.apexgpu_set_shard.argtypes = [vp, C.c_int, C.c_int]
+    L.apexgpu_shard_range.argtypes = [i64, i64, vp, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
     for name in SYMBOLS:
         f = getattr(L, name)
         if name not in ("apexgpu_destroy", "apexgpu_last_error", "apexgpu_version"):
             f.restype = C.c_int
     _lib = L
     return L
+
+
+def shard_range(pt_idx: np.ndarray, n_pt: int, rank: int, world: int) -> tuple[int, int]:
+    """Landmark range owned by `rank` (host arithmetic in the library, no GPU needed)."""
+    L = load()
+    a = np.ascontiguousarray(pt_idx, dtype=np.uint32)
+    lo, hi = C.c_int64(), C.c_int64()
+    rc = L.apexgpu_shard_range(n_pt, a.shape[0], a.ctypes.data_as(C.c_void_p), rank, world, C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise LinAlgError(rc, "apexgpu_shard_range")
+    return lo.value, hi.value
 
 
 def ptr(a):

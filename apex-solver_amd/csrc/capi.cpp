@@ -3,6 +3,7 @@
 
 #include <new>
 #include <string>
+#include <vector>
 
 #include "solver.h"
 #ifdef APEX_WITH_RCCL
@@ -133,6 +134,17 @@ int apexgpu_get_unique_id(void* out128) {
 int apexgpu_comm_init(apexgpu_solver* h, int world, int rank, const void* unique_id128) {
     H_OR_FAIL;
     return h->s->comm_init(world, rank, unique_id128);
+}
+int apexgpu_shard_range(int64_t n_pt, int64_t n_obs, const uint32_t* pt_idx, int rank, int world, int64_t* lo, int64_t* hi) {
+    if (!pt_idx || !lo || !hi || world < 1 || rank < 0 || rank >= world || n_pt <= 0) return APEXGPU_ERR_INVALID_INPUT;
+    std::vector<int64_t> ptr(n_pt + 1, 0);
+    for (int64_t i = 0; i < n_obs; ++i) {
+        if (pt_idx[i] >= (uint64_t)n_pt) return APEXGPU_ERR_INVALID_INPUT;
+        ptr[pt_idx[i] + 1]++;
+    }
+    for (int64_t l = 0; l < n_pt; ++l) ptr[l + 1] += ptr[l];
+    apex::shard_range(n_pt, ptr.data(), rank, world, lo, hi);
+    return APEXGPU_OK;
 }
 int apexgpu_set_shard(apexgpu_solver* h, int rank, int world) { H_OR_FAIL; return h->s->set_shard(rank, world); }
 

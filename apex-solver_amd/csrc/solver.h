@@ -69,6 +69,8 @@ struct LmResult {
 enum Stage { kStAssembleCam = 0, kStAssembleLm, kStScatter, kStAllReduce, kStFactor, kStTriSolve, kStBackSub, kStStats,
              kStRetract, kStCost, kNumStages };
 
+void shard_range(int64_t n_pt, const int64_t* ptr, int rank, int world, int64_t* lo, int64_t* hi);
+
 class Solver {
    public:
     Solver(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device);

@@ -139,6 +139,20 @@ int Solver::comm_init(int world, int rank, const void* unique_id128) {
 #endif
 }
 
+// Landmark range [lo,hi) of `rank`: contiguous, balanced by observation count.  ptr[l] = number of
+// observations of landmarks < l (n_pt+1 entries).  Pure host arithmetic, identical on every rank.
+void shard_range(int64_t n_pt, const int64_t* ptr, int rank, int world, int64_t* lo, int64_t* hi) {
+    const int64_t n_obs = ptr[n_pt];
+    auto cut = [&](int r) -> int64_t {
+        if (r <= 0) return 0;
+        if (r >= world) return n_pt;
+        const int64_t target = (n_obs * r) / world;
+        return std::min<int64_t>(std::lower_bound(ptr, ptr + n_pt + 1, target) - ptr, n_pt);
+    };
+    *lo = cut(rank);
+    *hi = cut(rank + 1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // structure
 // ---------------------------------------------------------------------------------------------
@@ -168,18 +182,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         for (int64_t i = 0; i < n_obs_; ++i) full_obs[fill[pt_idx[i]]++] = (int)i;
     }
     // ---- shard: contiguous landmark range balanced by observation count --------------------
-    lm_lo_ = 0; lm_hi_ = n_pt_;
-    if (world_ > 1) {
-        auto cut = [&](int r) -> int64_t {
-            if (r <= 0) return 0;
-            if (r >= world_) return n_pt_;
-            const int64_t target = (n_obs_ * r) / world_;
-            return std::lower_bound(full_ptr.begin(), full_ptr.end(), target) - full_ptr.begin();
-        };
-        lm_lo_ = std::min<int64_t>(cut(rank_), n_pt_);
-        lm_hi_ = std::min<int64_t>(cut(rank_ + 1), n_pt_);
-        if (rank_ == world_ - 1) lm_hi_ = n_pt_;
-    }
+    shard_range(n_pt_, full_ptr.data(), rank_, world_, &lm_lo_, &lm_hi_);
     const int64_t o_lo = full_ptr[lm_lo_], o_hi = full_ptr[lm_hi_];
     const int64_t n_loc = o_hi - o_lo;
 

@@ -178,6 +178,10 @@ int apexgpu_info(apexgpu_solver* h, double info[8]);
 int apexgpu_get_unique_id(void* out128);
 int apexgpu_comm_init(apexgpu_solver* h, int world, int rank, const void* unique_id128);
 int apexgpu_set_shard(apexgpu_solver* h, int rank, int world);
+/* The landmark range [lo,hi) rank `rank` of `world` owns (contiguous, balanced by observation count).
+ * Host arithmetic only -- no device is touched -- so schedulers and tests can call it anywhere. */
+int apexgpu_shard_range(int64_t n_pt, int64_t n_obs, const uint32_t* pt_idx, int rank, int world, int64_t* lo,
+                        int64_t* hi);
 
 #ifdef __cplusplus
 }
