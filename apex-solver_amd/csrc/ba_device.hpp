@@ -29,15 +29,20 @@ namespace apex {
 constexpr double kMinDepth = 1e-6;          // apex-camera-models/src/lib.rs:80
 constexpr double kSmallAngle2 = 1e-10;      // apex-manifolds/src/lib.rs:61
 
-// Camera as the kernels see it: normalised quaternion, translation, intrinsics.
+// Camera as the kernels see it: rotation matrix of the (re)normalised quaternion, translation,
+// intrinsics.  k_prepare_cams builds this once per parameter set (16 doubles per camera) so that
+// the per-observation kernels pay no quaternion normalisation (2 sqrt + 8 div) per observation.
 struct Cam {
+    double R[9];  // row-major
     double t[3];
-    double q[4];  // w,x,y,z (unit)
     double f, k1, k2;
 };
+constexpr int kCamStride = 16;  // doubles per prepared camera: R(9) t(3) f k1 k2 pad
 
 // pose7 = [tx,ty,tz,qw,qx,qy,qz] as VariableEnum::to_vector() stores it (the quaternion may be
 // slightly non-unit after a compose); normalised twice like from_translation_quaternion.
+APEX_HD void quat_to_rot(const double q[4], double R[9]);
+
 APEX_HD void load_cam(const double* __restrict__ pose7, const double* __restrict__ intr3, Cam& c) {
     c.t[0] = pose7[0]; c.t[1] = pose7[1]; c.t[2] = pose7[2];
     double w = pose7[3], x = pose7[4], y = pose7[5], z = pose7[6];
@@ -46,8 +51,31 @@ APEX_HD void load_cam(const double* __restrict__ pose7, const double* __restrict
         double n = sqrt(w * w + x * x + y * y + z * z);
         w /= n; x /= n; y /= n; z /= n;
     }
-    c.q[0] = w; c.q[1] = x; c.q[2] = y; c.q[3] = z;
+    const double q[4] = {w, x, y, z};
+    quat_to_rot(q, c.R);
     c.f = intr3[0]; c.k1 = intr3[1]; c.k2 = intr3[2];
+}
+
+APEX_HD void store_cam_prepared(const Cam& c, double* __restrict__ o) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = c.R[i];
+    o[9] = c.t[0]; o[10] = c.t[1]; o[11] = c.t[2];
+    o[12] = c.f; o[13] = c.k1; o[14] = c.k2; o[15] = 0.0;
+}
+
+APEX_HD void load_cam_prepared(const double* __restrict__ p, Cam& c) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.R[i] = p[i];
+    c.t[0] = p[9]; c.t[1] = p[10]; c.t[2] = p[11];
+    c.f = p[12]; c.k1 = p[13]; c.k2 = p[14];
+}
+
+// p_cam = R p_w + t  (SE3::act, se3.rs:322-328; the reference rotates with the quaternion, this is
+// the same rotation through its matrix)
+APEX_HD void cam_transform(const Cam& c, const double pw[3], double pc[3]) {
+    pc[0] = c.R[0] * pw[0] + c.R[1] * pw[1] + c.R[2] * pw[2] + c.t[0];
+    pc[1] = c.R[3] * pw[0] + c.R[4] * pw[1] + c.R[5] * pw[2] + c.t[1];
+    pc[2] = c.R[6] * pw[0] + c.R[7] * pw[1] + c.R[8] * pw[2] + c.t[2];
 }
 
 APEX_HD void cross3(const double a[3], const double b[3], double o[3]) {
@@ -97,8 +125,7 @@ APEX_HD double huber_sqrt_rho1(double delta, double s) {
 APEX_HD bool residual_obs(const Cam& c, const double pw[3], double u_obs, double v_obs,
                           double huber_delta, double r[2]) {
     double pc[3];
-    quat_rotate(c.q, pw, pc);
-    pc[0] += c.t[0]; pc[1] += c.t[1]; pc[2] += c.t[2];
+    cam_transform(c, pw, pc);
     if (!(pc[2] < -kMinDepth)) { r[0] = 0.0; r[1] = 0.0; return false; }
     double inz = -1.0 / pc[2];
     double xn = pc[0] * inz, yn = pc[1] * inz;
@@ -118,8 +145,7 @@ template <int DC>
 APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, double v_obs,
                            double huber_delta, double r[2], double Jc[2][DC], double Jl[2][3]) {
     double pc[3];
-    quat_rotate(c.q, pw, pc);
-    pc[0] += c.t[0]; pc[1] += c.t[1]; pc[2] += c.t[2];
+    cam_transform(c, pw, pc);
     if (!(pc[2] < -kMinDepth)) {
         r[0] = 0.0; r[1] = 0.0;
 #pragma unroll
@@ -149,8 +175,7 @@ APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, doubl
     Jp[1][0] = f * (dyd_dxn * inz);
     Jp[1][1] = f * (dyd_dyn * inz);
     Jp[1][2] = f * (dyd_dxn * dxn_dz + dyd_dyn * dyn_dz);
-    double R[9];
-    quat_to_rot(c.q, R);
+    const double* R = c.R;
     double w = huber_sqrt_rho1(huber_delta, r0 * r0 + r1 * r1);
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {

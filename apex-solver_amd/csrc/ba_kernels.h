@@ -12,8 +12,7 @@ constexpr int kScatterBlk = 64;   // block size used to split landmarks with mor
 // Read-only view of one parameter set + the landmark-major observation stream.
 struct BAView {
     int64_t n_cam, n_pt, n_obs;
-    const double* poses;   // [n_cam][7]
-    const double* intr;    // [n_cam][3]
+    const double* camp;    // [n_cam][16] prepared cameras (R t f k1 k2), see k_prepare_cams
     const double* pts;     // [n_pt][3]
     const uint32_t* o_cam; // [n_obs] landmark-major
     const uint32_t* o_pt;  // [n_obs]
@@ -29,6 +28,23 @@ struct TileMap {
     int nt;
 };
 
+constexpr int kRowBatch = 256;  // (i,j) pairs one k_schur_rows workgroup handles per sweep
+constexpr int kRowCap9 = 112;   // neighbour cameras whose 9x9 blocks one workgroup keeps in LDS (72.6 KB)
+constexpr int kRowCap6 = 224;   // same for 6x6 blocks (64.5 KB)
+
+struct RowTask {   // one workgroup of k_schur_rows: camera `cam`, neighbours nbr[nbr0 .. nbr0+nnbr)
+    int cam;
+    int nbr0, nnbr;
+    int diag;            // this chunk holds the camera's own diagonal block (and its g sums)
+    int batch0, nbatch;  // the camera's batches
+};
+
+struct RowBatch {  // <= kRowBatch pairs: camera-major observations [first, first+count)
+    int first, count;
+    int jj0, njj;        // njj != 0: one observation with more partners than a batch; partners [jj0, jj0+njj)
+    int total;           // pairs in the batch
+};
+
 struct ScatterTask {
     int i0, ni;  // first block of observations (landmark-major indices)
     int j0, nj;  // second block (nj == 0: diagonal task)
@@ -40,6 +56,11 @@ void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv
                             hipStream_t s);
 void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const ScatterTask* tasks, int n_tasks,
                           const double* hinv, const double* g_l, double* g_red, hipStream_t s);
+void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, hipStream_t s);
+void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
+                       const RowBatch* batches, const int* cam_obs, const uint16_t* cam_obs_off, const int* nbr,
+                       const double* hinv, const double* g_l, double lambda, int add_lambda, double* g_c, double* g_red,
+                       hipStream_t s);
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
                             double* dl, hipStream_t s);
 void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, const double* intr, const double* pts,

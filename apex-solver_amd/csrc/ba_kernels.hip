@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_cam_reduce(BAView v, TileMap tm, const 
 #pragma unroll
     for (int i = 0; i < NH + DC; ++i) acc[i] = 0.0;
     Cam cam;
-    load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+    load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
     const int b = cam_ptr[c], e = cam_ptr[c + 1];
     for (int k = b + (int)threadIdx.x; k < e; k += 256) {
         const int i = cam_obs[k];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
             const uint32_t c = v.o_cam[i];
             const double2 uv = v.o_uv[i];
             Cam cam;
-            load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+            load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
             double r[2], Jc[2][DC], Jl[2][3];
             linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
             h[0] += Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0];
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_schur_scatter(BAView v, TileMap tm, con
         const uint32_t l = v.o_pt[i];
         const double2 uv = v.o_uv[i];
         Cam cam;
-        load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+        load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
         const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
         double r[2], Jc[2][DC], Jl[2][3];
         linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
@@ -303,6 +303,175 @@ __global__ __launch_bounds__(256) void k_schur_scatter(BAView v, TileMap tm, con
 }
 
 // ------------------------------------------------------------------------------------------
+// Prepared cameras: normalise the stored quaternion twice (SE3::from, se3.rs:200-206, 107-113), turn it
+// into R once, and park [R t f k1 k2] in 16 doubles per camera for every per-observation kernel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prepare_cams(int64_t n_cam, const double* __restrict__ poses,
+                                                        const double* __restrict__ intr, double* __restrict__ camp) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cam) return;
+    Cam cam;
+    load_cam(poses + 7 * c, intr + 3 * c, cam);
+    store_cam_prepared(cam, camp + kCamStride * c);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2c: the Schur reduction WITHOUT global atomics ("row" form).  One workgroup owns the row block
+// of S that belongs to one camera ci (or a <=CAP-neighbour chunk of it), keeps it in LDS, walks
+// the camera's observations, and for every observation i of landmark l visits the observations j of
+// l with cam_j <= cam_i (a prefix of l's list: observations are sorted by camera inside a landmark).
+// One lane per (i,j) pair recomputes both Jacobian blocks from the 24-byte observation records
+// (~0.5 kflop, cheaper than moving a DC x DC block through memory), forms Y_i = W_i Hll^-1 and adds
+// -Y_i W_j^T into the LDS block of camera pair (ci,cj) with ds_add_f64.  The self pair (j == i) also
+// folds in Jc^T Jc, Jc^T r and Y_i g_l, so H_cc, g_c and g_red need no separate pass.  At the end the
+// row block is stored once with plain stores: S = H_cc + lambda I - sum (W Hll^-1) W^T
+// (compute_schur_complement, explicit_schur.rs:771-925) and g_red = -g_c + W Hll^-1 g_l (:928-977).
+// HBM traffic is the observation stream times the mean track length plus S once; the atomics form
+// (k_schur_scatter) moves DC^2 doubles of atomic traffic per pair instead.
+// ------------------------------------------------------------------------------------------
+constexpr int kHashSize = 512;
+
+__device__ __forceinline__ int hash_slot(const int* hkey, const int* hval, int key) {
+    unsigned h = ((unsigned)key * 2654435761u) >> 23;  // 9 bits
+    for (int probe = 0; probe < kHashSize; ++probe) {
+        const int k = hkey[h];
+        if (k == key) return hval[h];
+        if (k < 0) return -1;
+        h = (h + 1) & (kHashSize - 1);
+    }
+    return -1;
+}
+
+template <int DC, int CAP>
+__global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const RowTask* __restrict__ tasks,
+                                                      const RowBatch* __restrict__ batches,
+                                                      const int* __restrict__ cam_obs,
+                                                      const uint16_t* __restrict__ cam_obs_off,
+                                                      const int* __restrict__ nbr, const double* __restrict__ hinv,
+                                                      const double* __restrict__ g_l, double lambda, int add_lambda,
+                                                      double* __restrict__ g_c, double* __restrict__ g_red) {
+    constexpr int E = DC * DC;
+    __shared__ double acc[CAP * E];
+    __shared__ double sg[2 * DC];
+    __shared__ int hkey[kHashSize], hval[kHashSize];
+    __shared__ int s_i[kRowBatch], s_j[kRowBatch];
+    const RowTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x;
+    const uint32_t ci = (uint32_t)t.cam;
+    for (int idx = tid; idx < CAP * E; idx += 256) acc[idx] = 0.0;
+    for (int idx = tid; idx < kHashSize; idx += 256) hkey[idx] = -1;
+    if (tid < 2 * DC) sg[tid] = 0.0;
+    __syncthreads();
+    if (tid < t.nnbr) {
+        const int key = nbr[t.nbr0 + tid];
+        unsigned h = ((unsigned)key * 2654435761u) >> 23;
+        while (atomicCAS(&hkey[h], -1, key) != -1) h = (h + 1) & (kHashSize - 1);
+        hval[h] = tid;
+    }
+    __syncthreads();
+    Cam cam_i;
+    load_cam_prepared(v.camp + kCamStride * (size_t)ci, cam_i);
+    const int diag_slot = t.diag ? t.nnbr - 1 : -1;  // ci itself is the last neighbour of its list
+
+    for (int b = t.batch0; b < t.batch0 + t.nbatch; ++b) {
+        const RowBatch bt = batches[b];
+        if (tid < bt.count) {
+            const int e = bt.first + tid;
+            const int i_s = cam_obs[e];
+            const int base = v.pt_ptr[v.o_pt[i_s]];
+            int off, n, j0;
+            if (bt.njj) { off = 0; n = bt.njj; j0 = base + bt.jj0; }
+            else { off = cam_obs_off[e]; n = i_s - base + 1; j0 = base; }
+            for (int q = 0; q < n; ++q) { s_i[off + q] = i_s; s_j[off + q] = j0 + q; }
+        }
+        __syncthreads();
+        if (tid < bt.total) {
+            const int i_s = s_i[tid], j_s = s_j[tid];
+            const uint32_t cj = v.o_cam[j_s];
+            const bool self = (j_s == i_s);
+            const int slot = hash_slot(hkey, hval, (int)cj);
+            if (slot >= 0 || (self && t.diag)) {
+                const uint32_t l = v.o_pt[i_s];
+                const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
+                const double2 uvi = v.o_uv[i_s];
+                double r[2], Jc[2][DC], Jl[2][3];
+                linearize_obs<DC>(cam_i, pw, uvi.x, uvi.y, v.huber_delta, r, Jc, Jl);
+                double Hi[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Hi[k] = hinv[9 * (size_t)l + k];
+                double W[DC][3], Y[DC][3];
+#pragma unroll
+                for (int a = 0; a < DC; ++a) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) W[a][c] = Jc[0][a] * Jl[0][c] + Jc[1][a] * Jl[1][c];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Y[a][c] = W[a][0] * Hi[c] + W[a][1] * Hi[3 + c] + W[a][2] * Hi[6 + c];
+                }
+                if (self && t.diag) {
+                    const double gl0 = g_l[3 * (size_t)l], gl1 = g_l[3 * (size_t)l + 1], gl2 = g_l[3 * (size_t)l + 2];
+                    double* dblk = acc + diag_slot * E;
+#pragma unroll
+                    for (int a = 0; a < DC; ++a) {
+#pragma unroll
+                        for (int bb = 0; bb <= a; ++bb)
+                            unsafeAtomicAdd(&dblk[a * DC + bb], Jc[0][a] * Jc[0][bb] + Jc[1][a] * Jc[1][bb]);
+                        unsafeAtomicAdd(&sg[a], Jc[0][a] * r[0] + Jc[1][a] * r[1]);
+                        unsafeAtomicAdd(&sg[DC + a], Y[a][0] * gl0 + Y[a][1] * gl1 + Y[a][2] * gl2);
+                    }
+                }
+                if (slot >= 0) {
+                    double* blk = acc + slot * E;
+                    if (self) {
+#pragma unroll
+                        for (int a = 0; a < DC; ++a)
+#pragma unroll
+                            for (int bb = 0; bb <= a; ++bb)
+                                unsafeAtomicAdd(&blk[a * DC + bb], -(Y[a][0] * W[bb][0] + Y[a][1] * W[bb][1] + Y[a][2] * W[bb][2]));
+                    } else {
+                        Cam cam_j;
+                        load_cam_prepared(v.camp + kCamStride * (size_t)cj, cam_j);
+                        const double2 uvj = v.o_uv[j_s];
+                        double rj[2], Jcj[2][DC], Jlj[2][3];
+                        linearize_obs<DC>(cam_j, pw, uvj.x, uvj.y, v.huber_delta, rj, Jcj, Jlj);
+                        const bool dup = (cj == ci);  // the same camera sees the landmark twice
+#pragma unroll
+                        for (int bb = 0; bb < DC; ++bb) {
+                            const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
+                            const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
+                            const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
+#pragma unroll
+                            for (int a = 0; a < DC; ++a) {
+                                const double val = -(Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2);
+                                if (!dup) unsafeAtomicAdd(&blk[a * DC + bb], val);
+                                else {  // B + B^T on the diagonal block, kept in its lower triangle
+                                    if (a >= bb) unsafeAtomicAdd(&blk[a * DC + bb], val);
+                                    if (bb >= a) unsafeAtomicAdd(&blk[bb * DC + a], val);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- store the row block once ---------------------------------------------------------------------
+    for (int idx = tid; idx < t.nnbr * E; idx += 256) {
+        const int s = idx / E, e = idx - s * E, a = e / DC, bb = e - a * DC;
+        const uint32_t cj = (uint32_t)nbr[t.nbr0 + s];
+        const bool dg = (cj == ci);
+        if (dg && bb > a) continue;
+        double val = acc[idx];
+        if (dg && a == bb && add_lambda) val += lambda;
+        s_block_ptr<DC>(tm, ci, cj)[a * kNB + bb] = val;
+    }
+    if (t.diag && tid < DC) {
+        g_c[(size_t)ci * DC + tid] = sg[tid];
+        g_red[(size_t)ci * DC + tid] = -sg[tid] + sg[DC + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K3: back-substitution, 8 lanes per landmark: dl = Hll^-1 ((-g)_l - H_cl^T dc)
 // (explicit_schur.rs:980-1029); H_cl^T dc = sum_i Jl_i^T (Jc_i dc_ci).
 // ------------------------------------------------------------------------------------------
@@ -322,7 +491,7 @@ __global__ __launch_bounds__(256) void k_back_substitute(BAView v, const double*
             const uint32_t c = v.o_cam[i];
             const double2 uv = v.o_uv[i];
             Cam cam;
-            load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+            load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
             double r[2], Jc[2][DC], Jl[2][3];
             linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
             double s0 = 0.0, s1 = 0.0;
@@ -396,7 +565,7 @@ __global__ __launch_bounds__(256) void k_cost_partial(BAView v, double* __restri
         const uint32_t c = v.o_cam[i], l = v.o_pt[i];
         const double2 uv = v.o_uv[i];
         Cam cam;
-        load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+        load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
         const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
         double r[2];
         residual_obs(cam, pw, uv.x, uv.y, v.huber_delta, r);
@@ -458,7 +627,7 @@ __global__ __launch_bounds__(256) void k_export_linearization(BAView v, const in
     const uint32_t c = v.o_cam[i], l = v.o_pt[i];
     const double2 uv = v.o_uv[i];
     Cam cam;
-    load_cam(v.poses + 7 * (size_t)c, v.intr + 3 * (size_t)c, cam);
+    load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
     const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
     double r[2], Jc[2][DC], Jl[2][3];
     linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
@@ -505,6 +674,19 @@ void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const Scat
     if (n_tasks == 0) return;
     if (dc == 9) hipLaunchKernelGGL(k_schur_scatter<9>, dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, hinv, g_l, g_red);
     else hipLaunchKernelGGL(k_schur_scatter<6>, dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, hinv, g_l, g_red);
+}
+
+void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, hipStream_t s) {
+    if (n_cam > 0) hipLaunchKernelGGL(k_prepare_cams, dim3(grid_for(n_cam, 256, 0)), dim3(256), 0, s, n_cam, poses, intr, camp);
+}
+
+void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
+                       const RowBatch* batches, const int* cam_obs, const uint16_t* cam_obs_off, const int* nbr,
+                       const double* hinv, const double* g_l, double lambda, int add_lambda, double* g_c, double* g_red,
+                       hipStream_t s) {
+    if (n_tasks == 0) return;
+    if (dc == 9) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, g_l, lambda, add_lambda, g_c, g_red);
+    else hipLaunchKernelGGL((k_schur_rows<6, kRowCap6>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, g_l, lambda, add_lambda, g_c, g_red);
 }
 
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,

@@ -104,6 +104,14 @@ int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out, double* gl_
     return h->s->get_landmark_blocks(hinv_out, gl_out);
 }
 
+int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
+    H_OR_FAIL;
+    const std::string n = name ? name : "";
+    if (n == "schur_rows") h->s->use_row_schur(value != 0);
+    else if (n == "graphs") h->s->enable_graphs(value != 0);
+    else return APEXGPU_ERR_INVALID_INPUT;
+    return APEXGPU_OK;
+}
 int apexgpu_enable_stage_timing(apexgpu_solver* h, int on) { H_OR_FAIL; h->s->enable_stage_timing(on != 0); return APEXGPU_OK; }
 int apexgpu_reset_stage_times(apexgpu_solver* h) { H_OR_FAIL; h->s->reset_stage_times(); return APEXGPU_OK; }
 int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_t calls[APEXGPU_NUM_STAGES]) {

@@ -108,6 +108,7 @@ class Solver {
     void reset_stage_times();
     void enable_stage_timing(bool on) { timing_ = on; }
     void enable_graphs(bool on) { use_graphs_ = on; }
+    void use_row_schur(bool on) { use_rows_ = on; }
     double schur_scatter_pairs() const { return (double)n_pairs_; }
     double touched_tiles() const { return (double)n_present_; }
     double local_obs() const { return (double)o_orig_h_.size(); }
@@ -168,6 +169,13 @@ class Solver {
     // device
     hipStream_t stream_ = nullptr;
     double *poses_[2] = {nullptr, nullptr}, *intr_[2] = {nullptr, nullptr}, *pts_[2] = {nullptr, nullptr};
+    double* camp_[2] = {nullptr, nullptr};  // prepared cameras of the two parameter sets
+    RowTask* rtasks_ = nullptr;
+    RowBatch* rbatches_ = nullptr;
+    uint16_t* cam_obs_off_ = nullptr;
+    int* nbr_ = nullptr;
+    int n_rtasks_ = 0;
+    bool use_rows_ = true;  // Schur reduction: LDS row form (default) or the global-atomics form
     uint32_t *o_cam_ = nullptr, *o_pt_ = nullptr;
     double2* o_uv_ = nullptr;
     int *o_orig_ = nullptr, *pt_ptr_ = nullptr, *cam_ptr_ = nullptr, *cam_obs_ = nullptr;

@@ -1,5 +1,6 @@
 // solver.hip -- host orchestration of the MI355X bundle-adjustment backend (see solver.h).
 #include "solver.h"
+#include "ba_device.hpp"
 
 #include <math.h>
 #include <string.h>
@@ -33,7 +34,7 @@ Solver::Solver(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device)
 Solver::~Solver() {
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
+    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, fix_pose_, fix_intr_, fix_pt_, tiles_, linv_, slot_, diag_slot_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, trsm_tasks_, upd_tasks_, fwd_tasks_,
                     bwd_tasks_, diag_tasks_, tri_fwd_, tri_bwd_, sym_row_ptr_, sym_entries_, pcg_buf_};
@@ -62,7 +63,7 @@ int Solver::check_hip(hipError_t e, const char* what) {
 BAView Solver::view(int which) const {
     BAView v;
     v.n_cam = n_cam_; v.n_pt = n_pt_; v.n_obs = (int64_t)o_orig_h_.size();
-    v.poses = poses_[which]; v.intr = intr_[which]; v.pts = pts_[which];
+    v.camp = camp_[which]; v.pts = pts_[which];
     v.o_cam = o_cam_; v.o_pt = o_pt_; v.o_uv = o_uv_; v.pt_ptr = pt_ptr_;
     v.huber_delta = huber_delta_;
     return v;
@@ -195,6 +196,11 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         p = std::min(std::max(p, o_lo), o_hi) - o_lo;
         pt_ptr[l] = (int)p;
     }
+    // inside a landmark the observations are ordered by camera: the partners (cam_j <= cam_i) of an
+    // observation are then a PREFIX of its landmark's list (k_schur_rows)
+    for (int64_t l = lm_lo_; l < lm_hi_; ++l)
+        std::stable_sort(full_obs.begin() + full_ptr[l], full_obs.begin() + full_ptr[l + 1],
+                         [&](int a, int b) { return cam_idx[a] < cam_idx[b]; });
     for (int64_t k = 0; k < n_loc; ++k) {
         const int i = full_obs[o_lo + k];
         o_orig_h_[k] = i;
@@ -293,6 +299,73 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         flush();
     }
     n_tasks_ = (int)tasks.size();
+
+    // ---- k_schur_rows: neighbour lists (cameras cj <= ci sharing a landmark with ci, from the FULL
+    // problem so that every rank writes the same blocks), per-camera pair batches, row tasks ------------
+    std::vector<int> nbr_ptr(n_cam_ + 1, 0), nbr;
+    {
+        std::vector<std::vector<int>> lists(n_cam_);
+        std::vector<int> stamp(n_cam_, -1);
+        // camera-major view of the full problem
+        std::vector<int64_t> fcp(n_cam_ + 1, 0);
+        for (int64_t i = 0; i < n_obs_; ++i) fcp[cam_idx[i] + 1]++;
+        for (int64_t c = 0; c < n_cam_; ++c) fcp[c + 1] += fcp[c];
+        std::vector<int> fco(n_obs_);
+        {
+            std::vector<int64_t> fill(fcp.begin(), fcp.end() - 1);
+            for (int64_t i = 0; i < n_obs_; ++i) fco[fill[cam_idx[i]]++] = (int)i;
+        }
+        for (int64_t c = 0; c < n_cam_; ++c) {
+            auto& L = lists[c];
+            for (int64_t e = fcp[c]; e < fcp[c + 1]; ++e) {
+                const uint32_t l = pt_idx[fco[e]];
+                for (int64_t k = full_ptr[l]; k < full_ptr[l + 1]; ++k) {
+                    const int cj = (int)cam_idx[full_obs[k]];
+                    if (cj < c && stamp[cj] != (int)c) { stamp[cj] = (int)c; L.push_back(cj); }
+                }
+            }
+            std::sort(L.begin(), L.end());
+            L.push_back((int)c);  // the camera itself closes its list
+            nbr_ptr[c + 1] = nbr_ptr[c] + (int)L.size();
+        }
+        nbr.reserve(nbr_ptr[n_cam_]);
+        for (auto& L : lists) nbr.insert(nbr.end(), L.begin(), L.end());
+    }
+    std::vector<RowBatch> rbatches;
+    std::vector<RowTask> rtasks;
+    std::vector<uint16_t> cam_obs_off(n_loc, 0);
+    {
+        const int cap = (dc_ == 9) ? kRowCap9 : kRowCap6;
+        for (int64_t c = 0; c < n_cam_; ++c) {
+            const int b0 = (int)rbatches.size();
+            RowBatch cur{-1, 0, 0, 0, 0};
+            auto flushb = [&]() { if (cur.count > 0) rbatches.push_back(cur); cur = RowBatch{-1, 0, 0, 0, 0}; };
+            for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
+                const int i_s = cam_obs[e];
+                const int np = i_s - pt_ptr[o_pt[i_s]] + 1;  // partners with cam_j <= cam_i (incl. itself)
+                if (np > kRowBatch) {
+                    flushb();
+                    for (int j0 = 0; j0 < np; j0 += kRowBatch) {
+                        const int n = std::min(kRowBatch, np - j0);
+                        rbatches.push_back(RowBatch{e, 1, j0, n, n});
+                    }
+                    continue;
+                }
+                if (cur.total + np > kRowBatch) flushb();
+                if (cur.count == 0) cur.first = e;
+                cam_obs_off[e] = (uint16_t)cur.total;
+                cur.count++; cur.total += np;
+            }
+            flushb();
+            const int nb = (int)rbatches.size() - b0;
+            const int n0 = nbr_ptr[c], nn = nbr_ptr[c + 1] - nbr_ptr[c];
+            for (int s0 = 0; s0 < nn; s0 += cap) {
+                const int cnt = std::min(cap, nn - s0);
+                rtasks.push_back(RowTask{(int)c, n0 + s0, cnt, (s0 + cnt == nn) ? 1 : 0, b0, nb});
+            }
+        }
+    }
+    n_rtasks_ = (int)rtasks.size();
     n_present_ = 0;
     for (uint8_t b : present) n_present_ += b;
 
@@ -315,6 +388,10 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(up(&slot_, slot_h_));
     HIP_TRY(up(&diag_slot_, diag_slot_h_));
     HIP_TRY(up(&tasks_, tasks));
+    HIP_TRY(up(&rtasks_, rtasks));
+    HIP_TRY(up(&rbatches_, rbatches));
+    HIP_TRY(up(&cam_obs_off_, cam_obs_off));
+    HIP_TRY(up(&nbr_, nbr));
     {
         std::vector<uint8_t> fp(6 * n_cam_, 0), fi(3 * n_cam_, 0), fl(3 * n_pt_, 0);
         if (fix_pose) memcpy(fp.data(), fix_pose, fp.size());
@@ -334,6 +411,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         HIP_TRY(alloc(&poses_[w], 7 * n_cam_));
         HIP_TRY(alloc(&intr_[w], 3 * n_cam_));
         HIP_TRY(alloc(&pts_[w], 3 * n_pt_));
+        HIP_TRY(alloc(&camp_[w], (size_t)kCamStride * n_cam_));
     }
     HIP_TRY(alloc(&tiles_, (size_t)n_slots_ * tile_elems));
     HIP_TRY(alloc(&linv_, (size_t)nt_ * tile_elems));
@@ -429,6 +507,7 @@ int Solver::set_params(const double* poses, const double* intr, const double* po
     HIP_TRY(hipMemcpyAsync(poses_[cur_], poses, 7 * n_cam_ * sizeof(double), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(intr_[cur_], intr, 3 * n_cam_ * sizeof(double), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(pts_[cur_], points, 3 * n_pt_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], stream_);
     HIP_TRY(hipStreamSynchronize(stream_));
     have_params_ = true; have_step_ = have_trial_ = false;
     return kOk;
@@ -504,13 +583,18 @@ int Solver::assemble(double lambda, double diag_extra) {
     HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
     // identity on the padding rows of the last tile (rank 0 only: the all-reduce sums the ranks)
     launch_tile_add_diag(tiles_, diag_slot_, (int)n_c_, (int)n_c_pad_, 0.0, rank_ == 0 ? 1.0 : 0.0, stream_);
-    launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, g_c_, g_red_, stream_);
+    if (!use_rows_)
+        launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, g_c_, g_red_, stream_);
     stage_end(kStAssembleCam);
     stage_begin(kStAssembleLm);
     launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, stream_);
     stage_end(kStAssembleLm);
     stage_begin(kStScatter);
-    launch_schur_scatter(dc_, v, tm, tasks_, n_tasks_, hinv_, g_l_, g_red_, stream_);
+    if (use_rows_)
+        launch_schur_rows(dc_, v, tm, rtasks_, n_rtasks_, rbatches_, cam_obs_, cam_obs_off_, nbr_, hinv_, g_l_,
+                          lambda + diag_extra, rank_ == 0 ? 1 : 0, g_c_, g_red_, stream_);
+    else
+        launch_schur_scatter(dc_, v, tm, tasks_, n_tasks_, hinv_, g_l_, g_red_, stream_);
     stage_end(kStScatter);
 #ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1) {
@@ -740,6 +824,7 @@ int Solver::eval_step(double, double* trial_cost) {
     stage_begin(kStRetract);
     launch_retract(dc_, n_cam_, n_pt_, poses_[cur_], intr_[cur_], pts_[cur_], dcam_, dl_, 1.0, fix_pose_, fix_intr_,
                    fix_pt_, poses_[t], intr_[t], pts_[t], stream_);
+    launch_prepare_cams(n_cam_, poses_[t], intr_[t], camp_[t], stream_);
     stage_end(kStRetract);
     have_trial_ = true;
     return cost_of(t, trial_cost);
@@ -761,6 +846,7 @@ int Solver::discard_step() {
     stage_begin(kStRetract);
     launch_retract(dc_, n_cam_, n_pt_, poses_[t], intr_[t], pts_[t], dcam_, dl_, -1.0, fix_pose_, fix_intr_, fix_pt_,
                    poses_[cur_], intr_[cur_], pts_[cur_], stream_);
+    launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], stream_);
     stage_end(kStRetract);
     HIP_TRY(hipStreamSynchronize(stream_));
     have_trial_ = false; have_step_ = false;

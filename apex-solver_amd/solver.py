@@ -322,6 +322,9 @@ class GpuSchurComplementSolver:
         return dict(tile_rows=int(out[0]), tiles=int(out[1]), pair_blocks=float(out[2]), cam_dof=int(out[3]),
                     last_reg=float(out[4]), pcg_iterations=int(out[5]), touched_tiles=int(out[6]), local_obs=int(out[7]))
 
+    def set_option(self, name: str, value: int):
+        h = self._need(); h.check(h.L.apexgpu_set_option(h.h, name.encode(), int(value)))
+
     def enable_stage_timing(self, on=True): h = self._need(); h.check(h.L.apexgpu_enable_stage_timing(h.h, int(on)))
     def reset_stage_times(self): h = self._need(); h.check(h.L.apexgpu_reset_stage_times(h.h))
 

@@ -158,6 +158,12 @@ int apexgpu_get_jacobian_blocks(apexgpu_solver* h, double* jc_out, double* jl_ou
 int apexgpu_get_schur(apexgpu_solver* h, double* S_out, double* gred_out);
 int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out /* n_pt*9 */, double* gl_out /* n_pt*3 */);
 
+/* Implementation switches (defaults in parentheses), for A/B tests and profiling:
+ *   "schur_rows" (1)  Schur reduction in the LDS row form (k_schur_rows, no global atomics); 0 selects
+ *                     the landmark-major global-atomics form (k_cam_reduce + k_schur_scatter)
+ *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs          */
+int apexgpu_set_option(apexgpu_solver* h, const char* name, int value);
+
 /* ---- measurement ------------------------------------------------------------------------------*/
 #define APEXGPU_NUM_STAGES 10
 /* stage order: cam-reduce(+memset), landmark-reduce, schur-scatter, all-reduce, factor (or PCG),

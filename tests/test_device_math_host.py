@@ -50,7 +50,7 @@ def test_linearize_matches_oracle(hh, oracle):
                         np.abs(r - r0).max() / max(np.abs(r0).max(), 1.0))
         r = np.empty(2)
         assert hh.hh_residual_obs(poses[c], d.intr[c], d.points[l], d.obs_uv[i], 1.0, r) == ok0
-        assert np.abs(r - r0).max() <= 1e-13 * max(np.abs(r0).max(), 1.0)
+        assert np.abs(r - r0).max() <= 1e-15 * max(np.abs(d.obs_uv[i]).max(), 1.0) * 64  # rounding of a ~1e3 px projection
         n_invalid += (ok0 == 0)
     assert n_invalid > 0  # the cheirality branch was exercised
     assert worst < 1e-12, worst

@@ -215,10 +215,12 @@ def _custom(n_cam, n_pt, cam_lists, seed=5):
 def test_ragged_landmarks(oracle, mode):
     """k = 0 (unobserved landmark), k = 1, a duplicated camera, k = 64/65/129/200 (block-split
     landmarks use the off-diagonal scatter tasks), mixed in one problem."""
-    n_cam = 210
+    n_cam = 320
     rng = np.random.default_rng(9)
+    # range(300): more partners than one k_schur_rows batch (256) and more neighbours than one LDS
+    # chunk (112 cameras at 9 DOF) -> split batches and several row tasks per camera
     lists = [[], [3], [5, 5, 9], list(range(64)), list(range(65)), list(range(40, 169)), list(range(200)),
-             [7, 8, 7, 8, 100]]
+             [7, 8, 7, 8, 100], list(range(300)), [319, 0, 319]]
     lists += [sorted(rng.choice(n_cam, size=int(rng.integers(2, 12)), replace=False).tolist()) for _ in range(300)]
     d = _custom(n_cam, len(lists), lists)
     prob, s = gpu_solver(d, mode)
@@ -234,6 +236,23 @@ def test_ragged_landmarks(oracle, mode):
     assert errs["r"] < 1e-12 and errs["grad"] < 1e-12 and errs["S"] < 1e-12 and errs["gred"] < 1e-10
     assert errs["step"] < max(1e-10, 20 * np.finfo(float).eps * np.linalg.cond(oS))
     s.close()
+
+
+@pytest.mark.parametrize("mode", ["selfcal", "ba"])
+def test_row_and_atomic_schur_forms_agree(mode):
+    """The two implementations of the Schur reduction (LDS row form, global-atomics form) build the
+    same S, g_red and gradient."""
+    d = pkg.synthetic.make_problem(150, 6000, 3, 9, config_id=61)
+    out = []
+    for rows in (1, 0):
+        prob, s = gpu_solver(d, mode)
+        s.set_option("schur_rows", rows)
+        step = s.solve_augmented_equation(1e-3)
+        S, gred = s.get_schur()
+        out.append((S, gred, s.get_gradient(), step))
+        s.close()
+    assert rel(out[0][0], out[1][0]) < 1e-13 and rel(out[0][1], out[1][1]) < 1e-12
+    assert rel(out[0][2], out[1][2]) < 1e-13
 
 
 def test_cheirality_and_no_loss(oracle):
