@@ -189,6 +189,18 @@ def main():
                 "pair_blocks_per_launch": info["pair_blocks"], "lds_atomic_adds_per_launch": info["pair_blocks"] * dc * dc,
                 "fp64_gflops": gflops, "fp64_vector_peak_gflops": 78600.0}
 
+    # HBM traffic of the same kernel from the committed PMC pass (rocprofv3 cannot run inside this
+    # process); only attached when the committed profile is of this very workload
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_final13682_pmc_summary.json")))
+        if world == 1 and args.workload == "final-13682" and args.scale == 1.0 and args.mode == "selfcal":
+            k = [v for n, v in pm["kernels"].items() if "k_schur_rows" in n]
+            if k:
+                roofline["traffic"] = k[0]["hbm_bytes_per_launch_corrected"]
+                roofline["traffic_source"] = "profiles/r01_final13682_pmc_summary.json"
+    except Exception:
+        pass
+
     out = {
         "metric": "ms per LM iter (Jacobian+Schur+solve)", "value": ms_per_step, "unit": "ms", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False,
