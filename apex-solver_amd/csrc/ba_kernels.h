@@ -51,7 +51,8 @@ struct ScatterTask {
 };
 
 void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* cam_ptr, const int* cam_obs,
-                       double lambda, int add_lambda, double* g_c, double* g_red, hipStream_t s);
+                       double lambda, int add_lambda, const double* hinv, const double* g_l, int with_self, double* g_c,
+                       double* g_red, hipStream_t s);
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag,
                             hipStream_t s);
 void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const ScatterTask* tasks, int n_tasks,
@@ -59,8 +60,7 @@ void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const Scat
 void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, hipStream_t s);
 void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
                        const RowBatch* batches, const int* cam_obs, const uint16_t* cam_obs_off, const int* nbr,
-                       const double* hinv, const double* g_l, double lambda, int add_lambda, double* g_c, double* g_red,
-                       hipStream_t s);
+                       const double* hinv, int dbg, hipStream_t s);
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
                             double* dl, hipStream_t s);
 void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, const double* intr, const double* pts,

@@ -67,14 +67,18 @@ __device__ __forceinline__ double* s_block_ptr(const TileMap& tm, uint32_t row_c
 template <int DC>
 __global__ __launch_bounds__(256) void k_cam_reduce(BAView v, TileMap tm, const int* __restrict__ cam_ptr,
                                                       const int* __restrict__ cam_obs, double lambda,
-                                                      int add_lambda, double* __restrict__ g_c,
-                                                      double* __restrict__ g_red) {
+                                                      int add_lambda, const double* __restrict__ hinv,
+                                                      const double* __restrict__ g_l, int with_self,
+                                                      double* __restrict__ g_c, double* __restrict__ g_red) {
+    // with_self (row form of the Schur reduction): the block also receives the camera's own Schur
+    // terms -sum_i Y_i W_i^T and g_red is completed with +sum_i Y_i g_l, so that k_schur_rows only
+    // has pairs of DIFFERENT observations left (no same-address LDS atomics).
     constexpr int NH = DC * (DC + 1) / 2;
     const uint32_t c = blockIdx.x;
-    __shared__ double red[4][NH + DC];
-    double acc[NH + DC];
+    __shared__ double red[4][NH + 2 * DC];
+    double acc[NH + 2 * DC];
 #pragma unroll
-    for (int i = 0; i < NH + DC; ++i) acc[i] = 0.0;
+    for (int i = 0; i < NH + 2 * DC; ++i) acc[i] = 0.0;
     Cam cam;
     load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
     const int b = cam_ptr[c], e = cam_ptr[c + 1];
@@ -92,10 +96,29 @@ __global__ __launch_bounds__(256) void k_cam_reduce(BAView v, TileMap tm, const 
             for (int bb = 0; bb <= a; ++bb) acc[idx++] += Jc[0][a] * Jc[0][bb] + Jc[1][a] * Jc[1][bb];
 #pragma unroll
         for (int a = 0; a < DC; ++a) acc[NH + a] += Jc[0][a] * r[0] + Jc[1][a] * r[1];
+        if (with_self) {
+            double Hi[9], W[DC][3], Y[DC][3];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) Hi[q] = hinv[9 * (size_t)l + q];
+            const double gl0 = g_l[3 * (size_t)l], gl1 = g_l[3 * (size_t)l + 1], gl2 = g_l[3 * (size_t)l + 2];
+#pragma unroll
+            for (int a = 0; a < DC; ++a) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) W[a][q] = Jc[0][a] * Jl[0][q] + Jc[1][a] * Jl[1][q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Y[a][q] = W[a][0] * Hi[q] + W[a][1] * Hi[3 + q] + W[a][2] * Hi[6 + q];
+                acc[NH + DC + a] += Y[a][0] * gl0 + Y[a][1] * gl1 + Y[a][2] * gl2;
+            }
+            idx = 0;
+#pragma unroll
+            for (int a = 0; a < DC; ++a)
+#pragma unroll
+                for (int bb = 0; bb <= a; ++bb) acc[idx++] -= Y[a][0] * W[bb][0] + Y[a][1] * W[bb][1] + Y[a][2] * W[bb][2];
+        }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NH + DC; ++i) {
+    for (int i = 0; i < NH + 2 * DC; ++i) {
         double s = wave_sum(acc[i]);
         if (lane == 0) red[w][i] = s;
     }
@@ -112,8 +135,10 @@ __global__ __launch_bounds__(256) void k_cam_reduce(BAView v, TileMap tm, const 
             blk[a * kNB + bb] = s + ((a == bb && add_lambda) ? lambda : 0.0);
         } else {
             const int a = i - NH;
+            const int j = NH + DC + a;
+            const double yg = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
             g_c[(size_t)c * DC + a] = s;
-            g_red[(size_t)c * DC + a] = -s;
+            g_red[(size_t)c * DC + a] = -s + yg;
         }
     }
 }
@@ -348,11 +373,9 @@ __global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const 
                                                       const int* __restrict__ cam_obs,
                                                       const uint16_t* __restrict__ cam_obs_off,
                                                       const int* __restrict__ nbr, const double* __restrict__ hinv,
-                                                      const double* __restrict__ g_l, double lambda, int add_lambda,
-                                                      double* __restrict__ g_c, double* __restrict__ g_red) {
+                                                      int dbg) {
     constexpr int E = DC * DC;
     __shared__ double acc[CAP * E];
-    __shared__ double sg[2 * DC];
     __shared__ int hkey[kHashSize], hval[kHashSize];
     __shared__ int s_i[kRowBatch], s_j[kRowBatch];
     const RowTask t = tasks[blockIdx.x];
@@ -360,7 +383,6 @@ __global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const 
     const uint32_t ci = (uint32_t)t.cam;
     for (int idx = tid; idx < CAP * E; idx += 256) acc[idx] = 0.0;
     for (int idx = tid; idx < kHashSize; idx += 256) hkey[idx] = -1;
-    if (tid < 2 * DC) sg[tid] = 0.0;
     __syncthreads();
     if (tid < t.nnbr) {
         const int key = nbr[t.nbr0 + tid];
@@ -371,7 +393,6 @@ __global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const 
     __syncthreads();
     Cam cam_i;
     load_cam_prepared(v.camp + kCamStride * (size_t)ci, cam_i);
-    const int diag_slot = t.diag ? t.nnbr - 1 : -1;  // ci itself is the last neighbour of its list
 
     for (int b = t.batch0; b < t.batch0 + t.nbatch; ++b) {
         const RowBatch bt = batches[b];
@@ -381,16 +402,15 @@ __global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const 
             const int base = v.pt_ptr[v.o_pt[i_s]];
             int off, n, j0;
             if (bt.njj) { off = 0; n = bt.njj; j0 = base + bt.jj0; }
-            else { off = cam_obs_off[e]; n = i_s - base + 1; j0 = base; }
+            else { off = cam_obs_off[e]; n = i_s - base; j0 = base; }  // partners: the observations BEFORE i
             for (int q = 0; q < n; ++q) { s_i[off + q] = i_s; s_j[off + q] = j0 + q; }
         }
         __syncthreads();
-        if (tid < bt.total) {
+        if (tid < bt.total && !(dbg & 4)) {
             const int i_s = s_i[tid], j_s = s_j[tid];
             const uint32_t cj = v.o_cam[j_s];
-            const bool self = (j_s == i_s);
             const int slot = hash_slot(hkey, hval, (int)cj);
-            if (slot >= 0 || (self && t.diag)) {
+            if (slot >= 0) {
                 const uint32_t l = v.o_pt[i_s];
                 const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
                 const double2 uvi = v.o_uv[i_s];
@@ -399,55 +419,42 @@ __global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const 
                 double Hi[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) Hi[k] = hinv[9 * (size_t)l + k];
-                double W[DC][3], Y[DC][3];
+                double Y[DC][3];
 #pragma unroll
                 for (int a = 0; a < DC; ++a) {
+                    const double w0 = Jc[0][a] * Jl[0][0] + Jc[1][a] * Jl[1][0];
+                    const double w1 = Jc[0][a] * Jl[0][1] + Jc[1][a] * Jl[1][1];
+                    const double w2 = Jc[0][a] * Jl[0][2] + Jc[1][a] * Jl[1][2];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) W[a][c] = Jc[0][a] * Jl[0][c] + Jc[1][a] * Jl[1][c];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) Y[a][c] = W[a][0] * Hi[c] + W[a][1] * Hi[3 + c] + W[a][2] * Hi[6 + c];
+                    for (int c = 0; c < 3; ++c) Y[a][c] = w0 * Hi[c] + w1 * Hi[3 + c] + w2 * Hi[6 + c];
                 }
-                if (self && t.diag) {
-                    const double gl0 = g_l[3 * (size_t)l], gl1 = g_l[3 * (size_t)l + 1], gl2 = g_l[3 * (size_t)l + 2];
-                    double* dblk = acc + diag_slot * E;
+                double* blk = acc + slot * E;
+                Cam cam_j;
+                double rj[2], Jcj[2][DC], Jlj[2][3];
+                if (!(dbg & 2)) {
+                    load_cam_prepared(v.camp + kCamStride * (size_t)cj, cam_j);
+                    const double2 uvj = v.o_uv[j_s];
+                    linearize_obs<DC>(cam_j, pw, uvj.x, uvj.y, v.huber_delta, rj, Jcj, Jlj);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < DC; ++a) { Jcj[0][a] = Jc[0][a]; Jcj[1][a] = Jc[1][a]; }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { Jlj[0][a] = Jl[0][a]; Jlj[1][a] = Jl[1][a]; }
+                }
+                const bool dup = (cj == ci);  // the same camera sees the landmark twice
+#pragma unroll
+                for (int bb = 0; bb < DC; ++bb) {
+                    const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
+                    const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
+                    const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
 #pragma unroll
                     for (int a = 0; a < DC; ++a) {
-#pragma unroll
-                        for (int bb = 0; bb <= a; ++bb)
-                            unsafeAtomicAdd(&dblk[a * DC + bb], Jc[0][a] * Jc[0][bb] + Jc[1][a] * Jc[1][bb]);
-                        unsafeAtomicAdd(&sg[a], Jc[0][a] * r[0] + Jc[1][a] * r[1]);
-                        unsafeAtomicAdd(&sg[DC + a], Y[a][0] * gl0 + Y[a][1] * gl1 + Y[a][2] * gl2);
-                    }
-                }
-                if (slot >= 0) {
-                    double* blk = acc + slot * E;
-                    if (self) {
-#pragma unroll
-                        for (int a = 0; a < DC; ++a)
-#pragma unroll
-                            for (int bb = 0; bb <= a; ++bb)
-                                unsafeAtomicAdd(&blk[a * DC + bb], -(Y[a][0] * W[bb][0] + Y[a][1] * W[bb][1] + Y[a][2] * W[bb][2]));
-                    } else {
-                        Cam cam_j;
-                        load_cam_prepared(v.camp + kCamStride * (size_t)cj, cam_j);
-                        const double2 uvj = v.o_uv[j_s];
-                        double rj[2], Jcj[2][DC], Jlj[2][3];
-                        linearize_obs<DC>(cam_j, pw, uvj.x, uvj.y, v.huber_delta, rj, Jcj, Jlj);
-                        const bool dup = (cj == ci);  // the same camera sees the landmark twice
-#pragma unroll
-                        for (int bb = 0; bb < DC; ++bb) {
-                            const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
-                            const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
-                            const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
-#pragma unroll
-                            for (int a = 0; a < DC; ++a) {
-                                const double val = -(Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2);
-                                if (!dup) unsafeAtomicAdd(&blk[a * DC + bb], val);
-                                else {  // B + B^T on the diagonal block, kept in its lower triangle
-                                    if (a >= bb) unsafeAtomicAdd(&blk[a * DC + bb], val);
-                                    if (bb >= a) unsafeAtomicAdd(&blk[bb * DC + a], val);
-                                }
-                            }
+                        const double val = -(Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2);
+                        if (dbg & 1) { if (val == 1.2345e300) blk[0] = val; }
+                        else if (!dup) unsafeAtomicAdd(&blk[a * DC + bb], val);
+                        else {  // B + B^T on the diagonal block, kept in its lower triangle
+                            if (a >= bb) unsafeAtomicAdd(&blk[a * DC + bb], val);
+                            if (bb >= a) unsafeAtomicAdd(&blk[bb * DC + a], val);
                         }
                     }
                 }
@@ -455,19 +462,14 @@ __global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const 
         }
         __syncthreads();
     }
-    // ---- store the row block once ---------------------------------------------------------------------
+    // ---- store the row block once; the diagonal block already holds H_cc + lambda I - sum Y_i W_i^T
+    // from k_cam_reduce and only receives the (rare) duplicate-observation cross terms ---------------------
     for (int idx = tid; idx < t.nnbr * E; idx += 256) {
         const int s = idx / E, e = idx - s * E, a = e / DC, bb = e - a * DC;
         const uint32_t cj = (uint32_t)nbr[t.nbr0 + s];
-        const bool dg = (cj == ci);
-        if (dg && bb > a) continue;
-        double val = acc[idx];
-        if (dg && a == bb && add_lambda) val += lambda;
-        s_block_ptr<DC>(tm, ci, cj)[a * kNB + bb] = val;
-    }
-    if (t.diag && tid < DC) {
-        g_c[(size_t)ci * DC + tid] = sg[tid];
-        g_red[(size_t)ci * DC + tid] = -sg[tid] + sg[DC + tid];
+        double* dst = s_block_ptr<DC>(tm, ci, cj) + a * kNB + bb;
+        if (cj == ci) { if (bb <= a && acc[idx] != 0.0) *dst += acc[idx]; }
+        else *dst = acc[idx];
     }
 }
 
@@ -656,10 +658,11 @@ static inline int grid_for(int64_t n, int per_block, int cap) {
 }
 
 void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* cam_ptr, const int* cam_obs,
-                       double lambda, int add_lambda, double* g_c, double* g_red, hipStream_t s) {
+                       double lambda, int add_lambda, const double* hinv, const double* g_l, int with_self, double* g_c,
+                       double* g_red, hipStream_t s) {
     if (v.n_cam == 0) return;
-    if (dc == 9) hipLaunchKernelGGL(k_cam_reduce<9>, dim3((unsigned)v.n_cam), dim3(256), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, g_c, g_red);
-    else hipLaunchKernelGGL(k_cam_reduce<6>, dim3((unsigned)v.n_cam), dim3(256), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, g_c, g_red);
+    if (dc == 9) hipLaunchKernelGGL(k_cam_reduce<9>, dim3((unsigned)v.n_cam), dim3(256), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
+    else hipLaunchKernelGGL(k_cam_reduce<6>, dim3((unsigned)v.n_cam), dim3(256), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
 }
 
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag, hipStream_t s) {
@@ -682,11 +685,10 @@ void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr,
 
 void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
                        const RowBatch* batches, const int* cam_obs, const uint16_t* cam_obs_off, const int* nbr,
-                       const double* hinv, const double* g_l, double lambda, int add_lambda, double* g_c, double* g_red,
-                       hipStream_t s) {
+                       const double* hinv, int dbg, hipStream_t s) {
     if (n_tasks == 0) return;
-    if (dc == 9) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, g_l, lambda, add_lambda, g_c, g_red);
-    else hipLaunchKernelGGL((k_schur_rows<6, kRowCap6>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, g_l, lambda, add_lambda, g_c, g_red);
+    if (dc == 9) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
+    else hipLaunchKernelGGL((k_schur_rows<6, kRowCap6>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
 }
 
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,

@@ -109,6 +109,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     const std::string n = name ? name : "";
     if (n == "schur_rows") h->s->use_row_schur(value != 0);
     else if (n == "graphs") h->s->enable_graphs(value != 0);
+    else if (n == "rows_debug") h->s->set_rows_debug(value);
     else return APEXGPU_ERR_INVALID_INPUT;
     return APEXGPU_OK;
 }

@@ -109,6 +109,7 @@ class Solver {
     void enable_stage_timing(bool on) { timing_ = on; }
     void enable_graphs(bool on) { use_graphs_ = on; }
     void use_row_schur(bool on) { use_rows_ = on; }
+    void set_rows_debug(int v) { rows_dbg_ = v; }
     double schur_scatter_pairs() const { return (double)n_pairs_; }
     double touched_tiles() const { return (double)n_present_; }
     double local_obs() const { return (double)o_orig_h_.size(); }
@@ -175,6 +176,7 @@ class Solver {
     uint16_t* cam_obs_off_ = nullptr;
     int* nbr_ = nullptr;
     int n_rtasks_ = 0;
+    int rows_dbg_ = 0;      // timing-only ablation switches of k_schur_rows (results are wrong when != 0)
     bool use_rows_ = true;  // Schur reduction: LDS row form (default) or the global-atomics form
     uint32_t *o_cam_ = nullptr, *o_pt_ = nullptr;
     double2* o_uv_ = nullptr;

@@ -339,10 +339,10 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         for (int64_t c = 0; c < n_cam_; ++c) {
             const int b0 = (int)rbatches.size();
             RowBatch cur{-1, 0, 0, 0, 0};
-            auto flushb = [&]() { if (cur.count > 0) rbatches.push_back(cur); cur = RowBatch{-1, 0, 0, 0, 0}; };
+            auto flushb = [&]() { if (cur.count > 0 && cur.total > 0) rbatches.push_back(cur); cur = RowBatch{-1, 0, 0, 0, 0}; };
             for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
                 const int i_s = cam_obs[e];
-                const int np = i_s - pt_ptr[o_pt[i_s]] + 1;  // partners with cam_j <= cam_i (incl. itself)
+                const int np = i_s - pt_ptr[o_pt[i_s]];  // partners: observations of the landmark before i (cam_j <= cam_i)
                 if (np > kRowBatch) {
                     flushb();
                     for (int j0 = 0; j0 < np; j0 += kRowBatch) {
@@ -351,7 +351,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
                     }
                     continue;
                 }
-                if (cur.total + np > kRowBatch) flushb();
+                if (cur.total + np > kRowBatch || cur.count == 256) flushb();  // one lane expands one observation
                 if (cur.count == 0) cur.first = e;
                 cam_obs_off[e] = (uint16_t)cur.total;
                 cur.count++; cur.total += np;
@@ -583,16 +583,17 @@ int Solver::assemble(double lambda, double diag_extra) {
     HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
     // identity on the padding rows of the last tile (rank 0 only: the all-reduce sums the ranks)
     launch_tile_add_diag(tiles_, diag_slot_, (int)n_c_, (int)n_c_pad_, 0.0, rank_ == 0 ? 1.0 : 0.0, stream_);
-    if (!use_rows_)
-        launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, g_c_, g_red_, stream_);
     stage_end(kStAssembleCam);
     stage_begin(kStAssembleLm);
     launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, stream_);
     stage_end(kStAssembleLm);
+    stage_begin(kStAssembleCam);
+    launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, hinv_, g_l_, use_rows_ ? 1 : 0,
+                      g_c_, g_red_, stream_);
+    stage_end(kStAssembleCam);
     stage_begin(kStScatter);
     if (use_rows_)
-        launch_schur_rows(dc_, v, tm, rtasks_, n_rtasks_, rbatches_, cam_obs_, cam_obs_off_, nbr_, hinv_, g_l_,
-                          lambda + diag_extra, rank_ == 0 ? 1 : 0, g_c_, g_red_, stream_);
+        launch_schur_rows(dc_, v, tm, rtasks_, n_rtasks_, rbatches_, cam_obs_, cam_obs_off_, nbr_, hinv_, rows_dbg_, stream_);
     else
         launch_schur_scatter(dc_, v, tm, tasks_, n_tasks_, hinv_, g_l_, g_red_, stream_);
     stage_end(kStScatter);
