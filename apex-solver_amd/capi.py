@@ -108,7 +108,7 @@ def load() -> C.CDLL:
     L.apexgpu_enable_stage_timing.argtypes = [vp, C.c_int]
     L.apexgpu_reset_stage_times.argtypes = [vp]
     L.apexgpu_stage_times.argtypes = [vp, C.POINTER(dbl * NUM_STAGES), C.POINTER(i64 * NUM_STAGES)]
-    L.apexgpu_info.argtypes = [vp, C.POINTER(dbl * 8)]
+    L.apexgpu_info.argtypes = [vp, C.POINTER(dbl * 16)]
     L.apexgpu_get_unique_id.argtypes = [vp]
     L.apexgpu_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.apexgpu_set_shard.argtypes = [vp, C.c_int, C.c_int]

@@ -110,6 +110,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     if (n == "schur_rows") h->s->use_row_schur(value != 0);
     else if (n == "graphs") h->s->enable_graphs(value != 0);
     else if (n == "rows_debug") h->s->set_rows_debug(value);
+    else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);  /* value > 1: leaf size */
     else return APEXGPU_ERR_INVALID_INPUT;
     return APEXGPU_OK;
 }
@@ -120,11 +121,13 @@ int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_
     h->s->stage_times(ms, calls);
     return APEXGPU_OK;
 }
-int apexgpu_info(apexgpu_solver* h, double info[8]) {
+int apexgpu_info(apexgpu_solver* h, double info[16]) {
     H_OR_FAIL;
     info[0] = h->s->n_tile_rows(); info[1] = (double)h->s->tile_count(); info[2] = h->s->schur_scatter_pairs();
     info[3] = (double)h->s->cam_dof_internal(); info[4] = h->s->last_reg(); info[5] = h->s->last_pcg_iters();
     info[6] = h->s->touched_tiles(); info[7] = h->s->local_obs();
+    info[8] = h->s->n_levels();
+    for (int i = 9; i < 16; ++i) info[i] = 0;
     return APEXGPU_OK;
 }
 

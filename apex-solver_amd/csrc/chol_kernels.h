@@ -13,6 +13,12 @@ struct GemmTask {  // C = beta*C + alpha * A * B^T on 144x144 row-major tiles
     const double* B;
 };
 
+struct PotrfTask {  // one diagonal tile: factor in place, inverse of the factor to Linv
+    double* A;
+    double* Linv;
+    int K;
+};
+
 struct GemvTask {  // see k_tile_gemv for the modes
     const double* A;
     int xo, yo;    // element offsets of the 144-long x and y blocks
@@ -32,7 +38,7 @@ struct SymEntry {  // one tile of block-row I of the symmetric tile matrix
     int kind;      // 0: tile (I,other) other<I ; 1: tile (other,I) other>I (use transpose) ; 2: diagonal
 };
 
-void launch_potrf_inv(double* A, double* Linv, int K, int* fail, hipStream_t s);
+void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s);
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s);
 void launch_tile_gemv(const GemvTask* tasks, int n, double* y, const double* x, hipStream_t s);
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s);

@@ -77,8 +77,11 @@ __device__ __forceinline__ void blk_store_cd(double* C, double4_t v, int lr, int
     for (int r = 0; r < 4; ++r) C[(lk + 4 * r) * BP + lr] = sgn * v[r];
 }
 
-__global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ A, double* __restrict__ Linv, int K,
-                                                     int* __restrict__ fail) {
+__global__ __launch_bounds__(256) void k_potrf_inv(const PotrfTask* __restrict__ tasks, int* __restrict__ fail) {
+    const PotrfTask pt = tasks[blockIdx.x];
+    double* __restrict__ A = pt.A;
+    double* __restrict__ Linv = pt.Linv;
+    const int K = pt.K;
     __shared__ double sA[NLB * BSZ];
     __shared__ double sD[NBK * BSZ];
     __shared__ int bad;
@@ -450,7 +453,11 @@ __global__ __launch_bounds__(256) void k_tri_step(const TriTask* __restrict__ ta
         return;
     }
     tile_gemv_lds<TRANS>(t.Moff, sy, sz, sT, spart, tid);
-    if (tid < NB) vwork[(size_t)t.other * NB + tid] -= sz[tid];
+    if (tid < NB) {
+        // forward: two columns of one elimination-tree level may update the same ancestor block
+        if (!TRANS) unsafeAtomicAdd(&vwork[(size_t)t.other * NB + tid], -sz[tid]);
+        else vwork[(size_t)t.other * NB + tid] -= sz[tid];
+    }
 }
 
 // One workgroup per block-row I of the symmetric tile matrix: y_I = sum_J S_IJ x_J using the lower
@@ -568,8 +575,8 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const 
 }
 
 // ------------------------------------------------------------------------------------------
-void launch_potrf_inv(double* A, double* Linv, int K, int* fail, hipStream_t s) {
-    hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), 0, s, A, Linv, K, fail);
+void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_potrf_inv, dim3(n), dim3(256), 0, s, tasks, fail);
 }
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_tile_gemm_nt, dim3(n * NSTRIP), dim3(192), 0, s, tasks, alpha, beta);

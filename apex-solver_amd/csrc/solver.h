@@ -110,6 +110,8 @@ class Solver {
     void enable_graphs(bool on) { use_graphs_ = on; }
     void use_row_schur(bool on) { use_rows_ = on; }
     void set_rows_debug(int v) { rows_dbg_ = v; }
+    void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
+    int n_levels() const { return n_levels_; }
     double schur_scatter_pairs() const { return (double)n_pairs_; }
     double touched_tiles() const { return (double)n_present_; }
     double local_obs() const { return (double)o_orig_h_.size(); }
@@ -163,8 +165,6 @@ class Solver {
     std::vector<int> o_orig_h_;
     std::vector<int> slot_h_, diag_slot_h_;
     std::vector<std::vector<int>> col_rows_;       // per tile column K: rows I > K present (after fill)
-    std::vector<int> col_off_;                     // offsets into the flattened column lists
-    std::vector<int> row_off_;                     // offsets into the flattened row lists
     int max_col_ = 0;
 
     // device
@@ -190,9 +190,14 @@ class Solver {
     ScatterTask* tasks_ = nullptr;
     int n_tasks_ = 0;
     GemmTask *trsm_tasks_ = nullptr, *upd_tasks_ = nullptr;
+    PotrfTask* potrf_tasks_ = nullptr;
+    int n_levels_ = 0;
+    std::vector<int> lv_potrf_, lv_trsm_, lv_fwd_, lv_bwd_, lv_upd_round_;
+    std::vector<std::pair<int64_t, int64_t>> upd_rounds_;  // (offset, count) of each update launch
+    std::vector<int> cmap_, cinv_;   // external camera -> internal camera and back
+    bool use_nd_ = true;
+    int nd_leaf_ = 16;
     TriTask *tri_fwd_ = nullptr, *tri_bwd_ = nullptr;
-    GemvTask *fwd_tasks_ = nullptr, *bwd_tasks_ = nullptr, *diag_tasks_ = nullptr;
-    std::vector<int64_t> upd_off_;                 // per K offset into upd_tasks_
     int* sym_row_ptr_ = nullptr;
     SymEntry* sym_entries_ = nullptr;
     double* pcg_buf_ = nullptr;                    // 7 vectors of n_c_pad

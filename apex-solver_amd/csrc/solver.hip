@@ -36,8 +36,8 @@ Solver::~Solver() {
     if (stream_) hipStreamSynchronize(stream_);
     void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, fix_pose_, fix_intr_, fix_pt_, tiles_, linv_, slot_, diag_slot_, g_c_, g_red_,
-                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, trsm_tasks_, upd_tasks_, fwd_tasks_,
-                    bwd_tasks_, diag_tasks_, tri_fwd_, tri_bwd_, sym_row_ptr_, sym_entries_, pcg_buf_};
+                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, trsm_tasks_, upd_tasks_,
+                    potrf_tasks_, tri_fwd_, tri_bwd_, sym_row_ptr_, sym_entries_, pcg_buf_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     resolve_stage_events();
@@ -140,6 +140,56 @@ int Solver::comm_init(int world, int rank, const void* unique_id128) {
 #endif
 }
 
+// Nested-dissection order of the nodes of an undirected graph: recursive bisection by BFS level
+// structures from a pseudo-peripheral node; the middle level is the separator and is ordered after
+// both halves.  Sub-graphs of at most `leaf` nodes (or that a level structure cannot split, e.g. a
+// clique) keep their natural order.  Deterministic.
+static void nested_dissection(const std::vector<std::vector<int>>& adj, std::vector<int> nodes, std::vector<int>& out,
+                              int leaf) {
+    std::sort(nodes.begin(), nodes.end());
+    if ((int)nodes.size() <= leaf) { out.insert(out.end(), nodes.begin(), nodes.end()); return; }
+    const int n = (int)adj.size();
+    std::vector<int> mark(n, -1), dist(n, -1);
+    for (int v : nodes) mark[v] = 0;
+    auto bfs = [&](int src, std::vector<int>& order) {
+        for (int v : nodes) dist[v] = -1;
+        order.clear();
+        order.push_back(src); dist[src] = 0;
+        for (size_t h = 0; h < order.size(); ++h)
+            for (int w : adj[order[h]])
+                if (mark[w] == 0 && dist[w] < 0) { dist[w] = dist[order[h]] + 1; order.push_back(w); }
+    };
+    std::vector<int> order;
+    bfs(nodes[0], order);
+    if (order.size() < nodes.size()) {  // disconnected: order the components independently
+        std::vector<int> comp(order), rest;
+        std::vector<char> in(n, 0);
+        for (int v : comp) in[v] = 1;
+        for (int v : nodes) if (!in[v]) rest.push_back(v);
+        nested_dissection(adj, comp, out, leaf);
+        nested_dissection(adj, rest, out, leaf);
+        return;
+    }
+    bfs(order.back(), order);  // from a far node: long, thin level structure
+    const int depth = dist[order.back()];
+    if (depth < 2) { out.insert(out.end(), nodes.begin(), nodes.end()); return; }
+    std::vector<int> cnt(depth + 1, 0);
+    for (int v : nodes) cnt[dist[v]]++;
+    int best = 1; long bestcost = -1; long below = cnt[0];
+    for (int m = 1; m < depth; ++m) {
+        const long above = (long)nodes.size() - below - cnt[m];
+        const long cost = std::labs(below - above) + 2L * cnt[m];  // balance + separator size
+        if (bestcost < 0 || cost < bestcost) { bestcost = cost; best = m; }
+        below += cnt[m];
+    }
+    std::vector<int> A, B, S;
+    for (int v : nodes) (dist[v] < best ? A : (dist[v] > best ? B : S)).push_back(v);
+    nested_dissection(adj, A, out, leaf);
+    nested_dissection(adj, B, out, leaf);
+    std::sort(S.begin(), S.end());
+    out.insert(out.end(), S.begin(), S.end());
+}
+
 // Landmark range [lo,hi) of `rank`: contiguous, balanced by observation count.  ptr[l] = number of
 // observations of landmarks < l (n_pt+1 entries).  Pure host arithmetic, identical on every rank.
 void shard_range(int64_t n_pt, const int64_t* ptr, int rank, int world, int64_t* lo, int64_t* hi) {
@@ -173,6 +223,57 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     pose_col_.assign(pose_col, pose_col + n_cam_);
     pt_col_.assign(pt_col, pt_col + n_pt_);
 
+    // ---- internal camera order ---------------------------------------------------------------------
+    // The device numbers cameras in its own order: whole 144-row tiles of cameras are permuted by a
+    // nested-dissection ordering of the tile covisibility graph, which turns the elimination tree of
+    // the tile Cholesky from one long chain (banded S in capture order) into a bushy tree whose
+    // levels factorise in parallel.  cmap_[external camera] = internal camera.
+    n_c_ = n_cam_ * dc_;
+    nt_ = (int)((n_c_ + kNB - 1) / kNB);
+    n_c_pad_ = (int64_t)nt_ * kNB;
+    const int cpt = kNB / dc_;
+    {
+        std::vector<int> tperm(nt_);
+        std::iota(tperm.begin(), tperm.end(), 0);
+        if (use_nd_ && nt_ >= 24) {
+            std::vector<uint8_t> adjm((size_t)nt_ * nt_, 0);
+            std::vector<int64_t> lp(n_pt_ + 1, 0);
+            for (int64_t i = 0; i < n_obs_; ++i) lp[pt_idx[i] + 1]++;
+            for (int64_t l = 0; l < n_pt_; ++l) lp[l + 1] += lp[l];
+            std::vector<int> lt(n_obs_);
+            {
+                std::vector<int64_t> fill(lp.begin(), lp.end() - 1);
+                for (int64_t i = 0; i < n_obs_; ++i) lt[fill[pt_idx[i]]++] = (int)(cam_idx[i] / cpt);
+            }
+            std::vector<int> tl;
+            for (int64_t l = 0; l < n_pt_; ++l) {
+                tl.assign(lt.begin() + lp[l], lt.begin() + lp[l + 1]);
+                std::sort(tl.begin(), tl.end());
+                tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
+                for (size_t a = 0; a < tl.size(); ++a)
+                    for (size_t b = 0; b < a; ++b) { adjm[(size_t)tl[a] * nt_ + tl[b]] = 1; adjm[(size_t)tl[b] * nt_ + tl[a]] = 1; }
+            }
+            // the last tile may be partial (padding rows): it stays last (= eliminated last, no fill)
+            std::vector<std::vector<int>> adj(nt_ - 1);
+            for (int a = 0; a < nt_ - 1; ++a)
+                for (int b = 0; b < nt_ - 1; ++b)
+                    if (adjm[(size_t)a * nt_ + b]) adj[a].push_back(b);
+            std::vector<int> nodes(nt_ - 1), order;
+            std::iota(nodes.begin(), nodes.end(), 0);
+            nested_dissection(adj, nodes, order, nd_leaf_);
+            for (int pos = 0; pos < (int)order.size(); ++pos) tperm[order[pos]] = pos;
+            tperm[nt_ - 1] = nt_ - 1;
+        }
+        cmap_.resize(n_cam_);
+        cinv_.assign(n_cam_, -1);
+        for (int64_t c = 0; c < n_cam_; ++c) {
+            cmap_[c] = (int)((int64_t)tperm[c / cpt] * cpt + c % cpt);
+            cinv_[cmap_[c]] = (int)c;
+        }
+    }
+    std::vector<uint32_t> cam_i(n_obs_);
+    for (int64_t i = 0; i < n_obs_; ++i) cam_i[i] = (uint32_t)cmap_[cam_idx[i]];
+
     // ---- landmark-major lists of the FULL problem (tile structure must match on all ranks) ----
     std::vector<int64_t> full_ptr(n_pt_ + 1, 0);
     for (int64_t i = 0; i < n_obs_; ++i) full_ptr[pt_idx[i] + 1]++;
@@ -200,11 +301,11 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     // observation are then a PREFIX of its landmark's list (k_schur_rows)
     for (int64_t l = lm_lo_; l < lm_hi_; ++l)
         std::stable_sort(full_obs.begin() + full_ptr[l], full_obs.begin() + full_ptr[l + 1],
-                         [&](int a, int b) { return cam_idx[a] < cam_idx[b]; });
+                         [&](int a, int b) { return cam_i[a] < cam_i[b]; });
     for (int64_t k = 0; k < n_loc; ++k) {
         const int i = full_obs[o_lo + k];
         o_orig_h_[k] = i;
-        o_cam[k] = cam_idx[i]; o_pt[k] = pt_idx[i];
+        o_cam[k] = cam_i[i]; o_pt[k] = pt_idx[i];
         o_uv[2 * k] = obs_uv[2 * (int64_t)i]; o_uv[2 * k + 1] = obs_uv[2 * (int64_t)i + 1];
     }
     // ---- camera-major lists over the local observations -----------------------------------------
@@ -217,16 +318,12 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     }
 
     // ---- tile structure of S (covisibility at tile granularity + symbolic Cholesky fill) -------------
-    n_c_ = n_cam_ * dc_;
-    nt_ = (int)((n_c_ + kNB - 1) / kNB);
-    n_c_pad_ = (int64_t)nt_ * kNB;
-    const int cpt = kNB / dc_;
     std::vector<uint8_t> present((size_t)nt_ * nt_, 0);
     {
         std::vector<int> tl;
         for (int64_t l = 0; l < n_pt_; ++l) {
             tl.clear();
-            for (int64_t k = full_ptr[l]; k < full_ptr[l + 1]; ++k) tl.push_back((int)(cam_idx[full_obs[k]] / cpt));
+            for (int64_t k = full_ptr[l]; k < full_ptr[l + 1]; ++k) tl.push_back((int)(cam_i[full_obs[k]] / cpt));
             std::sort(tl.begin(), tl.end());
             tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
             for (size_t a = 0; a < tl.size(); ++a)
@@ -308,19 +405,19 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         std::vector<int> stamp(n_cam_, -1);
         // camera-major view of the full problem
         std::vector<int64_t> fcp(n_cam_ + 1, 0);
-        for (int64_t i = 0; i < n_obs_; ++i) fcp[cam_idx[i] + 1]++;
+        for (int64_t i = 0; i < n_obs_; ++i) fcp[cam_i[i] + 1]++;
         for (int64_t c = 0; c < n_cam_; ++c) fcp[c + 1] += fcp[c];
         std::vector<int> fco(n_obs_);
         {
             std::vector<int64_t> fill(fcp.begin(), fcp.end() - 1);
-            for (int64_t i = 0; i < n_obs_; ++i) fco[fill[cam_idx[i]]++] = (int)i;
+            for (int64_t i = 0; i < n_obs_; ++i) fco[fill[cam_i[i]]++] = (int)i;
         }
         for (int64_t c = 0; c < n_cam_; ++c) {
             auto& L = lists[c];
             for (int64_t e = fcp[c]; e < fcp[c + 1]; ++e) {
                 const uint32_t l = pt_idx[fco[e]];
                 for (int64_t k = full_ptr[l]; k < full_ptr[l + 1]; ++k) {
-                    const int cj = (int)cam_idx[full_obs[k]];
+                    const int cj = (int)cam_i[full_obs[k]];
                     if (cj < c && stamp[cj] != (int)c) { stamp[cj] = (int)c; L.push_back(cj); }
                 }
             }
@@ -394,8 +491,10 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(up(&nbr_, nbr));
     {
         std::vector<uint8_t> fp(6 * n_cam_, 0), fi(3 * n_cam_, 0), fl(3 * n_pt_, 0);
-        if (fix_pose) memcpy(fp.data(), fix_pose, fp.size());
-        if (fix_intr) memcpy(fi.data(), fix_intr, fi.size());
+        for (int64_t c = 0; c < n_cam_; ++c) {
+            if (fix_pose) memcpy(fp.data() + 6 * (size_t)cmap_[c], fix_pose + 6 * c, 6);
+            if (fix_intr) memcpy(fi.data() + 3 * (size_t)cmap_[c], fix_intr + 3 * c, 3);
+        }
         if (fix_pt) memcpy(fl.data(), fix_pt, fl.size());
         HIP_TRY(up(&fix_pose_, fp));
         HIP_TRY(up(&fix_intr_, fi));
@@ -428,39 +527,73 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(dev_alloc(&flags_, 4));
     HIP_TRY(hipMemset(flags_, 0, 4 * sizeof(int)));
 
-    // ---- factorisation / solve task lists ----------------------------------------------------------------
+    // ---- factorisation / solve task lists, scheduled by elimination-tree LEVEL -----------------------
+    // parent(K) = first off-diagonal row of column K; level = height above the leaves.  Columns of one
+    // level are independent: their potrf / panel solves / trailing updates run as ONE batched launch
+    // each.  Two columns of a level may update the same ancestor tile: those updates are split into
+    // conflict-free rounds (deterministic), one launch per round.
     auto tile_ptr = [&](int I, int J) { return tiles_ + (size_t)slot_h_[(size_t)I * nt_ + J] * tile_elems; };
     auto linv_ptr = [&](int K) { return linv_ + (size_t)K * tile_elems; };
+    std::vector<int> level(nt_, 0);
+    for (int K = 0; K < nt_; ++K)
+        if (!col_rows_[K].empty()) level[col_rows_[K][0]] = std::max(level[col_rows_[K][0]], level[K] + 1);
+    n_levels_ = 1 + *std::max_element(level.begin(), level.end());
+    std::vector<std::vector<int>> level_cols(n_levels_);
+    for (int K = 0; K < nt_; ++K) level_cols[level[K]].push_back(K);
+    std::vector<std::vector<int>> row_cols(nt_);
+    for (int K = 0; K < nt_; ++K)
+        for (int I : col_rows_[K]) row_cols[I].push_back(K);
+    std::vector<PotrfTask> potrf;
     std::vector<GemmTask> trsm, upd;
-    std::vector<GemvTask> fwd, bwd, dg;
-    col_off_.assign(nt_ + 1, 0);
-    upd_off_.assign(nt_ + 1, 0);
+    std::vector<TriTask> tf, tb;
+    lv_potrf_.assign(n_levels_ + 1, 0); lv_trsm_.assign(n_levels_ + 1, 0);
+    lv_fwd_.assign(n_levels_ + 1, 0); lv_bwd_.assign(n_levels_ + 1, 0);
+    lv_upd_round_.assign(n_levels_ + 1, 0);
+    upd_rounds_.clear();
     int64_t n_upd = 0;
     for (int K = 0; K < nt_; ++K) n_upd += (int64_t)col_rows_[K].size() * (col_rows_[K].size() + 1) / 2;
     if (n_upd > 80000000LL) return fail(kInvalidInput, "tile update list too large (" + std::to_string(n_upd) + ")");
     upd.reserve(n_upd);
-    for (int K = 0; K < nt_; ++K) {
-        const auto& rows = col_rows_[K];
-        for (int I : rows) {
-            trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});
-            fwd.push_back({tile_ptr(I, K), K * kNB, I * kNB, 2});
+    for (int lv = 0; lv < n_levels_; ++lv) {
+        struct U { int64_t key; GemmTask t; };
+        std::vector<U> us;
+        for (int K : level_cols[lv]) {
+            const auto& rows = col_rows_[K];
+            potrf.push_back({tile_ptr(K, K), linv_ptr(K), K});
+            tf.push_back({linv_ptr(K), nullptr, K, -1});
+            for (int I : rows) {
+                trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});
+                tf.push_back({linv_ptr(K), tile_ptr(I, K), K, I});
+            }
+            for (size_t a = 0; a < rows.size(); ++a)
+                for (size_t b = 0; b <= a; ++b)
+                    us.push_back({(int64_t)rows[a] * nt_ + rows[b], {tile_ptr(rows[a], rows[b]), tile_ptr(rows[a], K), tile_ptr(rows[b], K)}});
         }
-        for (size_t a = 0; a < rows.size(); ++a)
-            for (size_t b = 0; b <= a; ++b) upd.push_back({tile_ptr(rows[a], rows[b]), tile_ptr(rows[a], K), tile_ptr(rows[b], K)});
-        col_off_[K + 1] = (int)trsm.size();
-        upd_off_[K + 1] = (int64_t)upd.size();
+        std::stable_sort(us.begin(), us.end(), [](const U& x, const U& y) { return x.key < y.key; });
+        std::vector<int> round(us.size(), 0);
+        int n_rounds = 0;
+        for (size_t i = 0; i < us.size(); ++i) {
+            round[i] = (i > 0 && us[i].key == us[i - 1].key) ? round[i - 1] + 1 : 0;
+            n_rounds = std::max(n_rounds, round[i] + 1);
+        }
+        for (int r = 0; r < n_rounds; ++r) {
+            const int64_t off = (int64_t)upd.size();
+            for (size_t i = 0; i < us.size(); ++i)
+                if (round[i] == r) upd.push_back(us[i].t);
+            upd_rounds_.push_back({off, (int64_t)upd.size() - off});
+        }
+        lv_potrf_[lv + 1] = (int)potrf.size();
+        lv_trsm_[lv + 1] = (int)trsm.size();
+        lv_fwd_[lv + 1] = (int)tf.size();
+        lv_upd_round_[lv + 1] = (int)upd_rounds_.size();
     }
-    // row lists (tiles (I,J), J < I) for the backward sweep and the symmetric matvec
-    std::vector<std::vector<int>> row_cols(nt_);
-    for (int K = 0; K < nt_; ++K)
-        for (int I : col_rows_[K]) row_cols[I].push_back(K);
-    row_off_.assign(nt_ + 1, 0);
-    for (int I = 0; I < nt_; ++I) {
-        for (int J : row_cols[I]) bwd.push_back({tile_ptr(I, J), I * kNB, J * kNB, 3});
-        row_off_[I + 1] = (int)bwd.size();
+    for (int lv = n_levels_ - 1; lv >= 0; --lv) {  // backward sweep: levels from the root down
+        for (int I : level_cols[lv]) {
+            tb.push_back({linv_ptr(I), nullptr, I, -1});
+            for (int J : row_cols[I]) tb.push_back({linv_ptr(I), tile_ptr(I, J), I, J});
+        }
+        lv_bwd_[n_levels_ - lv] = (int)tb.size();
     }
-    for (int K = 0; K < nt_; ++K) dg.push_back({linv_ptr(K), K * kNB, K * kNB, 0});
-    for (int K = 0; K < nt_; ++K) dg.push_back({linv_ptr(K), K * kNB, K * kNB, 1});
     std::vector<int> sym_ptr(nt_ + 1, 0);
     std::vector<SymEntry> sym;
     for (int I = 0; I < nt_; ++I) {
@@ -469,24 +602,11 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         for (int I2 : col_rows_[I]) sym.push_back({slot_h_[(size_t)I2 * nt_ + I], I2, 1});
         sym_ptr[I + 1] = (int)sym.size();
     }
-    {
-        std::vector<TriTask> tf, tb;
-        for (int K = 0; K < nt_; ++K) {
-            tf.push_back({linv_ptr(K), nullptr, K, -1});
-            for (int I : col_rows_[K]) tf.push_back({linv_ptr(K), tile_ptr(I, K), K, I});
-        }
-        for (int I = 0; I < nt_; ++I) {
-            tb.push_back({linv_ptr(I), nullptr, I, -1});
-            for (int J : row_cols[I]) tb.push_back({linv_ptr(I), tile_ptr(I, J), I, J});
-        }
-        HIP_TRY(up(&tri_fwd_, tf));
-        HIP_TRY(up(&tri_bwd_, tb));
-    }
+    HIP_TRY(up(&tri_fwd_, tf));
+    HIP_TRY(up(&tri_bwd_, tb));
+    HIP_TRY(up(&potrf_tasks_, potrf));
     HIP_TRY(up(&trsm_tasks_, trsm));
     HIP_TRY(up(&upd_tasks_, upd));
-    HIP_TRY(up(&fwd_tasks_, fwd));
-    HIP_TRY(up(&bwd_tasks_, bwd));
-    HIP_TRY(up(&diag_tasks_, dg));
     HIP_TRY(up(&sym_row_ptr_, sym_ptr));
     HIP_TRY(up(&sym_entries_, sym));
     HIP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on stream_
@@ -504,8 +624,13 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
 int Solver::set_params(const double* poses, const double* intr, const double* points) {
     if (!have_structure_) return fail(kInvalidState, "Block structure not built. Call set_structure() first.");
     HIP_TRY(hipSetDevice(device_));
-    HIP_TRY(hipMemcpyAsync(poses_[cur_], poses, 7 * n_cam_ * sizeof(double), hipMemcpyHostToDevice, stream_));
-    HIP_TRY(hipMemcpyAsync(intr_[cur_], intr, 3 * n_cam_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    std::vector<double> hp(7 * n_cam_), hi(3 * n_cam_);
+    for (int64_t c = 0; c < n_cam_; ++c) {
+        memcpy(hp.data() + 7 * (size_t)cmap_[c], poses + 7 * c, 7 * sizeof(double));
+        memcpy(hi.data() + 3 * (size_t)cmap_[c], intr + 3 * c, 3 * sizeof(double));
+    }
+    HIP_TRY(hipMemcpyAsync(poses_[cur_], hp.data(), 7 * n_cam_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(intr_[cur_], hi.data(), 3 * n_cam_ * sizeof(double), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(pts_[cur_], points, 3 * n_pt_ * sizeof(double), hipMemcpyHostToDevice, stream_));
     launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], stream_);
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -537,10 +662,15 @@ int Solver::get_params(double* poses, double* intr, double* points) {
         }
     }
 #endif
-    HIP_TRY(hipMemcpyAsync(poses, poses_[cur_], 7 * n_cam_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipMemcpyAsync(intr, intr_[cur_], 3 * n_cam_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    std::vector<double> hp(7 * n_cam_), hi(3 * n_cam_);
+    HIP_TRY(hipMemcpyAsync(hp.data(), poses_[cur_], 7 * n_cam_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(hi.data(), intr_[cur_], 3 * n_cam_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(points, pts_[cur_], 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
+    for (int64_t c = 0; c < n_cam_; ++c) {
+        memcpy(poses + 7 * c, hp.data() + 7 * (size_t)cmap_[c], 7 * sizeof(double));
+        memcpy(intr + 3 * c, hi.data() + 3 * (size_t)cmap_[c], 3 * sizeof(double));
+    }
     return kOk;
 }
 
@@ -616,26 +746,23 @@ int Solver::assemble(double lambda, double diag_extra) {
 // they are captured once into hipGraphs (a few thousand tiny dependent launches would otherwise be
 // paced by host launch overhead) and replayed every LM iteration.
 void Solver::enqueue_factor() {
-    const size_t tile_elems = (size_t)kNB * kNB;
-    for (int K = 0; K < nt_; ++K) {
-        launch_potrf_inv(tiles_ + (size_t)diag_slot_h_[K] * tile_elems, linv_ + (size_t)K * tile_elems, K, flags_ + 1, stream_);
-        const int n_col = col_off_[K + 1] - col_off_[K];
-        if (n_col > 0) {
-            launch_tile_gemm_nt(trsm_tasks_ + col_off_[K], n_col, 1.0, 0.0, stream_);
-            launch_tile_gemm_nt(upd_tasks_ + upd_off_[K], (int)(upd_off_[K + 1] - upd_off_[K]), -1.0, 1.0, stream_);
-        }
+    for (int lv = 0; lv < n_levels_; ++lv) {
+        launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flags_ + 1, stream_);
+        launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_);
+        for (int r = lv_upd_round_[lv]; r < lv_upd_round_[lv + 1]; ++r)
+            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, stream_);
     }
 }
 
 void Solver::enqueue_tri_solve() {
-    // L y = g_red (work vector bvec), then L^T x = y (work vector yvec), x -> dcam_
+    // L y = g_red (work vector bvec), then L^T x = y (work vector yvec), x -> dcam_; level by level
     double* bvec = pcg_buf_;
     double* yvec = pcg_buf_ + n_c_pad_;
     hipMemcpyAsync(bvec, g_red_, n_c_pad_ * sizeof(double), hipMemcpyDeviceToDevice, stream_);
-    for (int K = 0; K < nt_; ++K)
-        launch_tri_step(false, tri_fwd_ + (col_off_[K] + K), col_off_[K + 1] - col_off_[K] + 1, bvec, yvec, stream_);
-    for (int I = nt_ - 1; I >= 0; --I)
-        launch_tri_step(true, tri_bwd_ + (row_off_[I] + I), row_off_[I + 1] - row_off_[I] + 1, yvec, dcam_, stream_);
+    for (int lv = 0; lv < n_levels_; ++lv)
+        launch_tri_step(false, tri_fwd_ + lv_fwd_[lv], lv_fwd_[lv + 1] - lv_fwd_[lv], bvec, yvec, stream_);
+    for (int s = 0; s < n_levels_; ++s)
+        launch_tri_step(true, tri_bwd_ + lv_bwd_[s], lv_bwd_[s + 1] - lv_bwd_[s], yvec, dcam_, stream_);
 }
 
 bool Solver::run_graph(int which) {
@@ -772,8 +899,9 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
             HIP_TRY(hipMemcpyAsync(hl.data(), pass == 0 ? dl_ : g_l_, 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
             HIP_TRY(hipStreamSynchronize(stream_));
             for (int64_t c = 0; c < n_cam_; ++c) {
-                for (int a = 0; a < 6; ++a) out[pose_col_[c] + a] = hc[c * dc_ + a];
-                for (int a = 0; a < 3; ++a) out[intr_col_[c] + a] = (dc_ == 9) ? hc[c * dc_ + 6 + a] : 0.0;
+                const int64_t ci = cmap_[c];
+                for (int a = 0; a < 6; ++a) out[pose_col_[c] + a] = hc[ci * dc_ + a];
+                for (int a = 0; a < 3; ++a) out[intr_col_[c] + a] = (dc_ == 9) ? hc[ci * dc_ + 6 + a] : 0.0;
             }
             for (int64_t l = 0; l < n_pt_; ++l)
                 for (int a = 0; a < 3; ++a) out[pt_col_[l] + a] = hl[3 * l + a];
@@ -1005,7 +1133,8 @@ int Solver::get_schur(double* S_out, double* gred_out) {
     const size_t tile_elems = (size_t)kNB * kNB;
     const int64_t nref = 9 * n_cam_;
     auto ref_row = [&](int64_t i) -> int64_t {
-        const int64_t c = i / dc_; const int a = (int)(i - c * dc_);
+        const int64_t ci = i / dc_; const int a = (int)(i - ci * dc_);
+        const int64_t c = cinv_[ci];
         return a < 6 ? pose_col_[c] + a : intr_col_[c] + (a - 6);
     };
     if (gred_out) {

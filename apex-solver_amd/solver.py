@@ -201,11 +201,16 @@ class GpuSchurComplementSolver:
         self._gradient = None
         self._shard = None
         self._comm = None
+        self._pre_options = {}
 
     # builder methods (explicit_schur.rs:219-238)
     def with_variant(self, v: SchurVariant): self.variant = v; return self
     def with_preconditioner(self, _p): return self  # ignored on this path, like the reference
     def with_cg_params(self, max_iter: int, tol: float): self.cg_max_iterations, self.cg_tolerance = max_iter, tol; return self
+    def with_option(self, name: str, value: int):
+        """An implementation switch that must be set before initialize_structure (e.g. nested_dissection)."""
+        self._pre_options[name] = int(value); return self
+
     def with_shard(self, rank: int, world: int): self._shard = (rank, world); return self
     def with_communicator(self, world: int, rank: int, unique_id: bytes): self._comm = (world, rank, unique_id); return self
 
@@ -221,6 +226,8 @@ class GpuSchurComplementSolver:
             h.check(h.L.apexgpu_comm_init(h.h, world, rank, C.cast(buf, C.c_void_p)))
         elif self._shard is not None:
             h.check(h.L.apexgpu_set_shard(h.h, *self._shard))
+        for k, v in self._pre_options.items():
+            h.check(h.L.apexgpu_set_option(h.h, k.encode(), v))
         lay = problem.layout
         self._keep = [np.ascontiguousarray(a) for a in (
             d.cam_idx.astype(np.uint32), d.pt_idx.astype(np.uint32), d.obs_uv.astype(np.float64),
@@ -317,10 +324,10 @@ class GpuSchurComplementSolver:
         return hi, gl
 
     def info(self) -> dict:
-        h = self._need(); out = (C.c_double * 8)()
+        h = self._need(); out = (C.c_double * 16)()
         h.check(h.L.apexgpu_info(h.h, C.byref(out)))
         return dict(tile_rows=int(out[0]), tiles=int(out[1]), pair_blocks=float(out[2]), cam_dof=int(out[3]),
-                    last_reg=float(out[4]), pcg_iterations=int(out[5]), touched_tiles=int(out[6]), local_obs=int(out[7]))
+                    last_reg=float(out[4]), pcg_iterations=int(out[5]), touched_tiles=int(out[6]), local_obs=int(out[7]), etree_levels=int(out[8]))
 
     def set_option(self, name: str, value: int):
         h = self._need(); h.check(h.L.apexgpu_set_option(h.h, name.encode(), int(value)))

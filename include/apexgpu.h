@@ -161,7 +161,9 @@ int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out /* n_pt*9 */
 /* Implementation switches (defaults in parentheses), for A/B tests and profiling:
  *   "schur_rows" (1)  Schur reduction in the LDS row form (k_schur_rows, no global atomics); 0 selects
  *                     the landmark-major global-atomics form (k_cam_reduce + k_schur_scatter)
- *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs          */
+ *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
+ *   "nested_dissection" (1)  order camera tiles by nested dissection (call before set_structure);
+ *                     0 keeps the caller's camera order, a value > 1 sets the leaf size in tiles    */
 int apexgpu_set_option(apexgpu_solver* h, const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------------*/
@@ -173,8 +175,9 @@ int apexgpu_reset_stage_times(apexgpu_solver* h);
 int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_t calls[APEXGPU_NUM_STAGES]);
 /* info[0] = S tile rows, [1] = allocated tiles, [2] = camera-pair contributions per Schur reduce,
  * [3] = internal camera DOF, [4] = regularisation used by the last Cholesky, [5] = PCG iterations,
- * [6] = S tiles that receive Schur contributions (before fill), [7] = observations on this rank */
-int apexgpu_info(apexgpu_solver* h, double info[8]);
+ * [6] = S tiles that receive Schur contributions (before fill), [7] = observations on this rank,
+ * [8] = levels of the tile elimination tree (= dependent launch groups of the factorisation) */
+int apexgpu_info(apexgpu_solver* h, double info[16]);
 
 /* ---- multi-GPU: one process per GPU, landmarks sharded, RCCL all-reduce of S and g_red -----------
  * apexgpu_get_unique_id fills 128 bytes on rank 0; broadcast them (any transport) and call

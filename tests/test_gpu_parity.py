@@ -255,6 +255,43 @@ def test_row_and_atomic_schur_forms_agree(mode):
     assert rel(out[0][2], out[1][2]) < 1e-13
 
 
+@pytest.mark.parametrize("mode", ["selfcal", "ba"])
+def test_nested_dissection_ordering_matches_natural_and_oracle(oracle, mode):
+    """The internal camera permutation (nested dissection of the tile graph, level-scheduled
+    factorisation) is invisible at the boundary: same S, g_red and step as the caller's order and as
+    the oracle."""
+    d = pkg.synthetic.make_problem(720, 20000, 3, 8, config_id=71)
+    res = {}
+    for nd in (1, 0, 4):
+        ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
+        prob = Problem.bundle_adjustment(d, ot, 1.0)
+        s = GpuSchurComplementSolver(0).with_option("nested_dissection", nd).initialize_structure(prob)
+        s.set_parameters(d.poses, d.intr, d.points)
+        step = s.solve_augmented_equation(1e-3)
+        S, gred = s.get_schur()
+        res[nd] = (S, gred, step, s.get_gradient(), s.info())
+        trial = s.eval_step(); s.commit_step()
+        p2 = s.get_parameters()
+        res[nd] += (trial, p2)
+        s.close()
+    print({k: (v[4]["etree_levels"], v[4]["tiles"]) for k, v in res.items()})
+    assert res[1][4]["etree_levels"] < res[0][4]["etree_levels"]       # the chain became a tree
+    for nd in (1, 4):
+        assert rel(res[nd][0], res[0][0]) < 1e-12 and rel(res[nd][1], res[0][1]) < 1e-11
+        assert rel(res[nd][3], res[0][3]) < 1e-13
+        assert rel(res[nd][2], res[0][2]) < 1e-6
+        assert res[nd][5] == pytest.approx(res[0][5], rel=1e-9)
+        assert rel(res[nd][6][0], res[0][6][0]) < 1e-9 and rel(res[nd][6][2], res[0][6][2]) < 1e-8
+    o = oracle_problem(oracle, d, prob, mode)
+    o.linearize()
+    ostep, ograd, oS, ogred = o.solve_augmented(1e-3, 0, want_schur=True)
+    assert rel(res[1][0], oS) < 1e-12 and rel(res[1][1], ogred) < 1e-10 and rel(res[1][3], ograd) < 1e-12
+    nc = prob.layout.cam_dof
+    step = res[1][2]
+    bwd = np.linalg.norm(oS @ step[:nc] - ogred) / (np.linalg.norm(oS, 2) * np.linalg.norm(step[:nc]) + np.linalg.norm(ogred))
+    assert bwd < 1e-13
+
+
 def test_cheirality_and_no_loss(oracle):
     """Points behind a camera give zero residual/Jacobian (projection_factor.rs:227-238); without a
     loss function the corrector is skipped (linearizer/mod.rs:144)."""
