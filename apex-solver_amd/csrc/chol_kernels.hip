@@ -257,11 +257,20 @@ constexpr int PITCH = KC + 2;
 constexpr int STRIP = 48;          // output rows per workgroup (3 waves x 16)
 constexpr int NSTRIP = NB / STRIP; // 3 workgroups per tile: 3x the parallelism of one per tile
 
-__global__ __launch_bounds__(192) void k_tile_gemm_nt(const GemmTask* __restrict__ tasks, double alpha, double beta) {
+__global__ __launch_bounds__(192) void k_tile_gemm_nt(const GemmTask* __restrict__ tasks, int n_units, double alpha,
+                                                        double beta) {
     __shared__ double sA[STRIP * PITCH];
     __shared__ double sB[NB * PITCH];
-    const GemmTask t = tasks[blockIdx.x / NSTRIP];
-    const int strip = blockIdx.x % NSTRIP;
+    // XCD-aware unit order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each
+    // with its own L2.  Unit u = (task, strip) lists are sorted by source column, so giving every XCD
+    // one CONTIGUOUS eighth of the list makes the 3 strips of a task and the tasks of one column
+    // share their operand tiles in one L2 instead of fetching them 8 times from HBM.  (Placement
+    // is a speed assumption only: any mapping computes the same result.)
+    const int per_xcd = (n_units + 7) >> 3;
+    const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
+    const GemmTask t = tasks[unit / NSTRIP];
+    const int strip = unit % NSTRIP;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     const double* __restrict__ Ag = t.A + (size_t)strip * STRIP * NB;
@@ -308,16 +317,22 @@ __global__ __launch_bounds__(192) void k_tile_gemm_nt(const GemmTask* __restrict
             }
         }
     }
-    double* C = t.C + (size_t)strip * STRIP * NB;
+    // epilogue: per 16-column block, the 4 loads of C are issued before the 4 stores.  (A
+    // load-modify-store per element serialises 36 memory round trips -- the compiler cannot move
+    // loads across possibly aliasing stores -- and holding all 36 values costs 72 VGPRs, i.e. a
+    // wave per SIMD of occupancy; 4 at a time measured best: tools/gemm_var.hip.)
+    double* __restrict__ C = t.C + (size_t)strip * STRIP * NB;
 #pragma unroll
-    for (int j = 0; j < 9; ++j)
+    for (int j = 0; j < 9; ++j) {
+        double cv[4] = {0.0, 0.0, 0.0, 0.0};
+        if (beta != 0.0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const size_t off = (size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr;
-            double v = alpha * acc[j][r];
-            if (beta != 0.0) v += beta * C[off];
-            C[off] = v;
+            for (int r = 0; r < 4; ++r) cv[r] = C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr];
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = alpha * acc[j][r] + beta * cv[r];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -579,7 +594,9 @@ void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_potrf_inv, dim3(n), dim3(256), 0, s, tasks, fail);
 }
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_tile_gemm_nt, dim3(n * NSTRIP), dim3(192), 0, s, tasks, alpha, beta);
+    if (n <= 0) return;
+    const int units = n * NSTRIP, per_xcd = (units + 7) / 8;
+    hipLaunchKernelGGL(k_tile_gemm_nt, dim3(8 * per_xcd), dim3(192), 0, s, tasks, units, alpha, beta);
 }
 void launch_tile_gemv(const GemvTask* tasks, int n, double* y, const double* x, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_tile_gemv, dim3(n), dim3(256), 0, s, tasks, y, x);

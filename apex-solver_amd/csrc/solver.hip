@@ -555,7 +555,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     if (n_upd > 80000000LL) return fail(kInvalidInput, "tile update list too large (" + std::to_string(n_upd) + ")");
     upd.reserve(n_upd);
     for (int lv = 0; lv < n_levels_; ++lv) {
-        struct U { int64_t key; GemmTask t; };
+        struct U { int64_t key; int K; GemmTask t; };
         std::vector<U> us;
         for (int K : level_cols[lv]) {
             const auto& rows = col_rows_[K];
@@ -567,7 +567,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
             }
             for (size_t a = 0; a < rows.size(); ++a)
                 for (size_t b = 0; b <= a; ++b)
-                    us.push_back({(int64_t)rows[a] * nt_ + rows[b], {tile_ptr(rows[a], rows[b]), tile_ptr(rows[a], K), tile_ptr(rows[b], K)}});
+                    us.push_back({(int64_t)rows[a] * nt_ + rows[b], K, {tile_ptr(rows[a], rows[b]), tile_ptr(rows[a], K), tile_ptr(rows[b], K)}});
         }
         std::stable_sort(us.begin(), us.end(), [](const U& x, const U& y) { return x.key < y.key; });
         std::vector<int> round(us.size(), 0);
@@ -577,9 +577,13 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
             n_rounds = std::max(n_rounds, round[i] + 1);
         }
         for (int r = 0; r < n_rounds; ++r) {
-            const int64_t off = (int64_t)upd.size();
+            // inside a round: by source column, so that tasks sharing operand tiles are neighbours
+            std::vector<const U*> sel;
             for (size_t i = 0; i < us.size(); ++i)
-                if (round[i] == r) upd.push_back(us[i].t);
+                if (round[i] == r) sel.push_back(&us[i]);
+            std::stable_sort(sel.begin(), sel.end(), [](const U* x, const U* y) { return x->K < y->K; });
+            const int64_t off = (int64_t)upd.size();
+            for (const U* u : sel) upd.push_back(u->t);
             upd_rounds_.push_back({off, (int64_t)upd.size() - off});
         }
         lv_potrf_[lv + 1] = (int)potrf.size();
