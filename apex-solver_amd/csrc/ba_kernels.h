@@ -29,8 +29,9 @@ struct TileMap {
 };
 
 constexpr int kRowBatch = 256;  // (i,j) pairs one k_schur_rows workgroup handles per sweep
-constexpr int kRowCap9 = 112;   // neighbour cameras whose 9x9 blocks one workgroup keeps in LDS (72.6 KB)
-constexpr int kRowCap6 = 224;   // same for 6x6 blocks (64.5 KB)
+constexpr int kRowObs = 64;     // observations of the camera per sweep (their Y_i stay in LDS)
+constexpr int kRowCap9 = 96;    // neighbour cameras whose 9x9 blocks one workgroup keeps in LDS (62 KB: 2 workgroups per CU)
+constexpr int kRowCap6 = 160;   // same for 6x6 blocks (46 KB)
 
 struct RowTask {   // one workgroup of k_schur_rows: camera `cam`, neighbours nbr[nbr0 .. nbr0+nnbr)
     int cam;
