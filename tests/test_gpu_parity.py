@@ -260,7 +260,7 @@ def test_nested_dissection_ordering_matches_natural_and_oracle(oracle, mode):
     """The internal camera permutation (nested dissection of the tile graph, level-scheduled
     factorisation) is invisible at the boundary: same S, g_red and step as the caller's order and as
     the oracle."""
-    d = pkg.synthetic.make_problem(720, 20000, 3, 8, config_id=71)
+    d = pkg.synthetic.make_problem(560, 12000, 3, 8, config_id=71)
     res = {}
     for nd in (1, 0, 4):
         ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
@@ -372,6 +372,33 @@ def test_lm_converges_like_reference_integration_test(oracle):
     print(res.status, res.iterations, res.final_cost, "| oracle", ores.status, ores.iterations, ores.final_cost)
     assert res.status.name == ores.status and res.iterations == ores.iterations
     assert res.final_cost == pytest.approx(ores.final_cost, rel=1e-6)
+
+
+def test_rccl_communicator_single_rank():
+    """The collective code path (RCCL communicator, all-reduces on the solver's stream) with a
+    one-rank communicator gives the same step as the plain path.  (N > 1 needs N GPUs: the driver's
+    scaling run; the exchange arithmetic is covered by test_shard_partials_sum_to_full and, on CPU,
+    tests/test_multirank_gloo.py.)"""
+    import ctypes as C
+
+    d = pkg.synthetic.make_problem(40, 2000, 3, 7, config_id=240)
+    prob, s0 = gpu_solver(d, "selfcal")
+    step0 = s0.solve_augmented_equation(1e-3)
+    trial0 = s0.eval_step()
+    buf = (C.c_char * 128)()
+    assert pkg.capi.load().apexgpu_get_unique_id(C.cast(buf, C.c_void_p)) == 0
+    s1 = GpuSchurComplementSolver(0).with_communicator(1, 0, bytes(buf))
+    s1.initialize_structure(prob)
+    s1.set_parameters(d.poses, d.intr, d.points)
+    step1 = s1.solve_augmented_equation(1e-3)
+    assert rel(step1, step0) < 1e-9
+    assert s1.step_stats()[0] == pytest.approx(s0.step_stats()[0], rel=1e-12)
+    assert s1.eval_step() == pytest.approx(trial0, rel=1e-10)
+    s1.commit_step()
+    p1 = s1.get_parameters()
+    s0.commit_step()
+    assert rel(p1[2], s0.get_parameters()[2]) < 1e-9
+    s0.close(); s1.close()
 
 
 def test_shard_partials_sum_to_full(oracle):
