@@ -38,6 +38,15 @@ struct SymEntry {  // one tile of block-row I of the symmetric tile matrix
     int kind;      // 0: tile (I,other) other<I ; 1: tile (other,I) other>I (use transpose) ; 2: diagonal
 };
 
+struct SymTile { int slot, I, J; };  // a structurally non-zero tile (I >= J) of S
+
+void launch_sym_tile_products(const SymTile* list, int n, const double* tiles, const double* x, double* part, hipStream_t s);
+void launch_sym_tile_gather(int nt, const int* row_ptr, const SymEntry* entries, const double* part, const double* p,
+                            double* y, double* row_dot, hipStream_t s);
+void launch_pcg_step1(int n, int nt, const double* scal, const double* row_dot, const double* p, const double* ap,
+                      const double* pre, double* x, double* r, double* blk_part, double* out_pap, hipStream_t s);
+void launch_pcg_step2(int n, double* scal, const double* blk_part, const double* pre, const double* r, double* p,
+                      double* out2, hipStream_t s);
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s);
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s);
 void launch_tile_gemv(const GemvTask* tasks, int n, double* y, const double* x, hipStream_t s);

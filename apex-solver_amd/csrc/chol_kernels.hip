@@ -522,6 +522,169 @@ __global__ __launch_bounds__(256) void k_sym_tile_matvec(const int* __restrict__
     if (tid < NB) y[(size_t)I * NB + tid] = part[tid] + accT;
 }
 
+// ------------------------------------------------------------------------------------------
+// Symmetric tile matvec for the PCG variant, two deterministic passes (no atomics):
+//   k_sym_tile_products: one workgroup per STRUCTURALLY NON-ZERO tile (I,J) of S reads the tile ONCE
+//       (two 72-row halves through LDS) and writes u = A x_J and, off the diagonal, v = A^T x_I
+//       (diagonal tiles: u = sym(A) x_I from the lower triangle) to part[slot][0..143 | 144..287];
+//   k_sym_tile_gather: one workgroup per block row adds its partials in list order and also emits
+//       the block's share of p.Ap.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sym_tile_products(const SymTile* __restrict__ list,
+                                                             const double* __restrict__ tiles,
+                                                             const double* __restrict__ x, double* __restrict__ part) {
+    __shared__ double sT[HROWS * TP];
+    __shared__ double sxJ[NB], sxI[NB], sp[NB];
+    const SymTile st = list[blockIdx.x];
+    const double* __restrict__ M = tiles + (size_t)st.slot * (NB * NB);
+    const int tid = threadIdx.x;
+    const bool diag = (st.I == st.J);
+    if (tid < NB) { sxJ[tid] = x[(size_t)st.J * NB + tid]; sxI[tid] = x[(size_t)st.I * NB + tid]; }
+    double accT = 0.0;
+    double* pu = part + (size_t)st.slot * (2 * NB);
+    for (int h = 0; h < 2; ++h) {
+        double2 reg[21];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < HROWS * (NB / 2)) {
+                const int row = idx / (NB / 2), c2 = idx - row * (NB / 2);
+                reg[i] = *reinterpret_cast<const double2*>(M + (size_t)(HROWS * h + row) * NB + 2 * c2);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 21; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < HROWS * (NB / 2)) {
+                const int row = idx / (NB / 2), c2 = idx - row * (NB / 2);
+                const int gr = HROWS * h + row;
+                double vx = reg[i].x, vy = reg[i].y;
+                if (diag) {  // only the lower triangle of a diagonal tile is valid
+                    if (2 * c2 > gr) vx = 0.0;
+                    if (2 * c2 + 1 > gr) vy = 0.0;
+                }
+                sT[row * TP + 2 * c2] = vx; sT[row * TP + 2 * c2 + 1] = vy;
+            }
+        }
+        __syncthreads();
+        if (tid < NB) {  // u = M x_J, rows of this half; two column halves per row
+            const int row = tid % HROWS, ch = tid / HROWS;
+            double a = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < HROWS; ++c) a += sT[row * TP + ch * HROWS + c] * sxJ[ch * HROWS + c];
+            sp[ch * HROWS + row] = a;
+        }
+        __syncthreads();
+        if (tid < HROWS) pu[HROWS * h + tid] = sp[tid] + sp[HROWS + tid];
+        if (tid < NB) {  // v = M^T x_I (for a diagonal tile: the strictly-upper part of sym(M) x)
+#pragma unroll 8
+            for (int r = 0; r < HROWS; ++r) {
+                const int gr = HROWS * h + r;
+                const double m = sT[r * TP + tid];
+                accT += ((diag && gr == tid) ? 0.0 : m) * sxI[gr];
+            }
+        }
+    }
+    if (tid < NB) pu[NB + tid] = accT;
+}
+
+__global__ __launch_bounds__(256) void k_sym_tile_gather(const int* __restrict__ row_ptr,
+                                                           const SymEntry* __restrict__ entries,
+                                                           const double* __restrict__ part,
+                                                           const double* __restrict__ p, double* __restrict__ y,
+                                                           double* __restrict__ row_dot) {
+    __shared__ double sc[4];
+    const int I = blockIdx.x, tid = threadIdx.x;
+    double acc = 0.0;
+    if (tid < NB) {
+        for (int e = row_ptr[I]; e < row_ptr[I + 1]; ++e) {
+            const SymEntry en = entries[e];
+            const double* pu = part + (size_t)en.slot * (2 * NB);
+            if (en.kind == 0) acc += pu[tid];                 // tile (I, other): u
+            else if (en.kind == 1) acc += pu[NB + tid];       // tile (other, I): v
+            else acc += pu[tid] + pu[NB + tid];               // diagonal: lower part + mirrored upper part
+        }
+        y[(size_t)I * NB + tid] = acc;
+    }
+    double d = (tid < NB) ? acc * p[(size_t)I * NB + tid] : 0.0;
+    d = wave_sum64(d);
+    if ((tid & 63) == 0) sc[tid >> 6] = d;
+    __syncthreads();
+    if (tid == 0) row_dot[I] = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+}
+
+// PCG state update, part 1:  alpha = rz_old / pAp ; x += alpha p ; r -= alpha Ap ; per-block
+// partial sums of r.r and r.(pre r).   scal[0] = rz_old, row_dot[0..nt) = shares of p.Ap.
+__global__ __launch_bounds__(256) void k_pcg_step1(int n, int nt, const double* __restrict__ scal,
+                                                     const double* __restrict__ row_dot, const double* __restrict__ p,
+                                                     const double* __restrict__ ap, const double* __restrict__ pre,
+                                                     double* __restrict__ x, double* __restrict__ r,
+                                                     double* __restrict__ blk_part, double* __restrict__ out_pap) {
+    __shared__ double sc[4];
+    __shared__ double s_alpha;
+    const int tid = threadIdx.x;
+    double pap = 0.0;
+    for (int i = tid; i < nt; i += 256) pap += row_dot[i];
+    pap = wave_sum64(pap);
+    if ((tid & 63) == 0) sc[tid >> 6] = pap;
+    __syncthreads();
+    if (tid == 0) {
+        const double tot = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+        s_alpha = (fabs(tot) < 1e-30) ? 0.0 : scal[0] / tot;   // |pAp| < 1e-30: the host breaks (:703-705)
+        if (blockIdx.x == 0) out_pap[0] = tot;
+    }
+    __syncthreads();
+    const double alpha = s_alpha;
+    const int i = blockIdx.x * 256 + tid;
+    double rr = 0.0, rz = 0.0;
+    if (i < n) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * ap[i];
+        r[i] = ri;
+        rr = ri * ri; rz = ri * (pre[i] * ri);
+    }
+    rr = wave_sum64(rr); rz = wave_sum64(rz);
+    __syncthreads();
+    if ((tid & 63) == 0) { sc[tid >> 6] = rr; }
+    __syncthreads();
+    const double rr_b = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+    __syncthreads();
+    if ((tid & 63) == 0) { sc[tid >> 6] = rz; }
+    __syncthreads();
+    if (tid == 0) { blk_part[2 * blockIdx.x] = rr_b; blk_part[2 * blockIdx.x + 1] = (sc[0] + sc[1]) + (sc[2] + sc[3]); }
+}
+
+// part 2: totals of r.r and r.z ; beta = rz_new / rz_old ; z = pre r ; p = z + beta p ;
+// scal[0] <- rz_new (block 0 publishes {rr, rz_new} for the host's convergence test)
+__global__ __launch_bounds__(256) void k_pcg_step2(int n, int n_blk, double* __restrict__ scal,
+                                                     const double* __restrict__ blk_part, const double* __restrict__ pre,
+                                                     const double* __restrict__ r, double* __restrict__ p,
+                                                     double* __restrict__ out2) {
+    __shared__ double sc[4];
+    __shared__ double s_beta;
+    const int tid = threadIdx.x;
+    double rr = 0.0, rz = 0.0;
+    for (int i = tid; i < n_blk; i += 256) { rr += blk_part[2 * i]; rz += blk_part[2 * i + 1]; }
+    rr = wave_sum64(rr); rz = wave_sum64(rz);
+    if ((tid & 63) == 0) sc[tid >> 6] = rr;
+    __syncthreads();
+    const double rr_t = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+    __syncthreads();
+    if ((tid & 63) == 0) sc[tid >> 6] = rz;
+    __syncthreads();
+    const double rz_t = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+    if (tid == 0) s_beta = rz_t / scal[0];
+    __syncthreads();
+    const double beta = s_beta;
+    const int i = blockIdx.x * 256 + tid;
+    if (i < n) p[i] = pre[i] * r[i] + beta * p[i];
+    if (blockIdx.x == 0 && tid == 0) { out2[0] = rr_t; out2[1] = rz_t; }
+}
+// scal[0] <- v[0]  (rz_old for the next iteration; separate tiny launch so that every block of
+// k_pcg_step2 has read the old value first)
+__global__ void k_copy_scalar(double* dst, const double* src) { dst[0] = src[0]; }
+
 // diag[i] = S_ii for all tile rows; also pad rows' diagonal := 1 when set_pad
 __global__ __launch_bounds__(256) void k_tile_diag(const double* __restrict__ tiles, const int* __restrict__ diag_slot,
                                                      int nt, double* __restrict__ diag) {
@@ -609,6 +772,23 @@ void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, dou
 void launch_sym_tile_matvec(int nt, const int* row_ptr, const SymEntry* entries, const double* tiles, const double* x,
                             double* y, hipStream_t s) {
     hipLaunchKernelGGL(k_sym_tile_matvec, dim3(nt), dim3(256), 0, s, row_ptr, entries, tiles, x, y);
+}
+void launch_sym_tile_products(const SymTile* list, int n, const double* tiles, const double* x, double* part, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_sym_tile_products, dim3(n), dim3(256), 0, s, list, tiles, x, part);
+}
+void launch_sym_tile_gather(int nt, const int* row_ptr, const SymEntry* entries, const double* part, const double* p,
+                            double* y, double* row_dot, hipStream_t s) {
+    hipLaunchKernelGGL(k_sym_tile_gather, dim3(nt), dim3(256), 0, s, row_ptr, entries, part, p, y, row_dot);
+}
+void launch_pcg_step1(int n, int nt, const double* scal, const double* row_dot, const double* p, const double* ap,
+                      const double* pre, double* x, double* r, double* blk_part, double* out_pap, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_step1, dim3((n + 255) / 256), dim3(256), 0, s, n, nt, scal, row_dot, p, ap, pre, x, r, blk_part, out_pap);
+}
+void launch_pcg_step2(int n, double* scal, const double* blk_part, const double* pre, const double* r, double* p,
+                      double* out2, hipStream_t s) {
+    const int nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_pcg_step2, dim3(nb), dim3(256), 0, s, n, nb, scal, blk_part, pre, r, p, out2);
+    hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, s, scal, out2 + 1);
 }
 void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double* diag, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_diag, dim3((nt * NB + 255) / 256), dim3(256), 0, s, tiles, diag_slot, nt, diag);

@@ -198,6 +198,9 @@ class Solver {
     bool use_nd_ = true;
     int nd_leaf_ = 16;
     TriTask *tri_fwd_ = nullptr, *tri_bwd_ = nullptr;
+    SymTile* sym_tiles_ = nullptr;
+    int n_sym_tiles_ = 0;
+    double *sym_part_ = nullptr, *row_dot_ = nullptr, *blk_part_ = nullptr;
     int* sym_row_ptr_ = nullptr;
     SymEntry* sym_entries_ = nullptr;
     double* pcg_buf_ = nullptr;                    // 7 vectors of n_c_pad

@@ -37,7 +37,7 @@ Solver::~Solver() {
     void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, fix_pose_, fix_intr_, fix_pt_, tiles_, linv_, slot_, diag_slot_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, trsm_tasks_, upd_tasks_,
-                    potrf_tasks_, tri_fwd_, tri_bwd_, sym_row_ptr_, sym_entries_, pcg_buf_};
+                    potrf_tasks_, tri_fwd_, tri_bwd_, sym_tiles_, sym_part_, row_dot_, blk_part_, sym_row_ptr_, sym_entries_, pcg_buf_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     resolve_stage_events();
@@ -521,7 +521,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(alloc(&g_l_, 3 * n_pt_));
     HIP_TRY(alloc(&dl_, 3 * n_pt_));
     HIP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
-    HIP_TRY(alloc(&scal_, 16));
+    HIP_TRY(alloc(&scal_, 32));
     HIP_TRY(alloc(&pcg_buf_, 7 * (size_t)n_c_pad_));
     if (flags_) hipFree(flags_);
     HIP_TRY(dev_alloc(&flags_, 4));
@@ -598,14 +598,25 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         }
         lv_bwd_[n_levels_ - lv] = (int)tb.size();
     }
+    // symmetric matvec of the PCG variant: only tiles that are non-zero in S (before fill)
     std::vector<int> sym_ptr(nt_ + 1, 0);
     std::vector<SymEntry> sym;
+    std::vector<SymTile> symt;
     for (int I = 0; I < nt_; ++I) {
-        for (int J : row_cols[I]) sym.push_back({slot_h_[(size_t)I * nt_ + J], J, 0});
+        for (int J = 0; J < I; ++J)
+            if (present[(size_t)I * nt_ + J]) sym.push_back({slot_h_[(size_t)I * nt_ + J], J, 0});
         sym.push_back({diag_slot_h_[I], I, 2});
-        for (int I2 : col_rows_[I]) sym.push_back({slot_h_[(size_t)I2 * nt_ + I], I2, 1});
+        for (int I2 = I + 1; I2 < nt_; ++I2)
+            if (present[(size_t)I2 * nt_ + I]) sym.push_back({slot_h_[(size_t)I2 * nt_ + I], I2, 1});
         sym_ptr[I + 1] = (int)sym.size();
+        for (int J = 0; J <= I; ++J)
+            if (J == I || present[(size_t)I * nt_ + J]) symt.push_back({slot_h_[(size_t)I * nt_ + J], I, J});
     }
+    n_sym_tiles_ = (int)symt.size();
+    HIP_TRY(up(&sym_tiles_, symt));
+    HIP_TRY(alloc(&sym_part_, (size_t)n_slots_ * 2 * kNB));
+    HIP_TRY(alloc(&row_dot_, (size_t)nt_));
+    HIP_TRY(alloc(&blk_part_, 2 * (size_t)((n_c_pad_ + 255) / 256)));
     HIP_TRY(up(&tri_fwd_, tf));
     HIP_TRY(up(&tri_bwd_, tb));
     HIP_TRY(up(&potrf_tasks_, potrf));
@@ -836,41 +847,38 @@ int Solver::factor_and_solve(double lambda) {
     return fail(kSingularMatrix, "Schur complement singular after 5 regularization attempts (max reg = " + std::to_string(base) + ")");
 }
 
-// solve_with_pcg (explicit_schur.rs:639-756): Jacobi-preconditioned CG on the explicit S
+// solve_with_pcg (explicit_schur.rs:639-756): Jacobi-preconditioned CG on the explicit S.
+// Per iteration: one pass over the non-zero tiles of S (k_sym_tile_products + k_sym_tile_gather, which
+// also yields p.Ap), two fused vector kernels that keep alpha/beta on the device, and ONE host
+// read-back of {p.Ap, r.r, r.z} for the reference's three termination tests.
 int Solver::pcg_solve() {
     stage_begin(kStFactor);
     const int n = (int)n_c_pad_;
+    const int nb = (n + 255) / 256;
     double *diag = pcg_buf_, *pre = pcg_buf_ + n, *x = dcam_, *r = pcg_buf_ + 2 * (size_t)n, *z = pcg_buf_ + 3 * (size_t)n,
            *p = pcg_buf_ + 4 * (size_t)n, *ap = pcg_buf_ + 5 * (size_t)n;
+    double* sc = scal_ + 16;  // [0] rz_old  [1] p.Ap  [2] r.r  [3] r.z
     launch_tile_diag(tiles_, diag_slot_, nt_, diag, stream_);
     launch_pcg_init(n, diag, g_red_, pre, x, r, z, p, stream_);
-    auto dot = [&](const double* a, const double* b, double* out) -> int {
-        launch_dot(n, a, b, scal_ + 6, stream_);
-        HIP_TRY(hipMemcpyAsync(out, scal_ + 6, sizeof(double), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
-        return kOk;
-    };
-    double rz_old = 0.0, rr = 0.0;
-    int rc = dot(r, z, &rz_old); if (rc != kOk) return rc;
-    rc = dot(r, r, &rr); if (rc != kOk) return rc;
-    const double abs_tol = cg_tol_ * std::max(sqrt(rr), 1.0);
+    launch_dot(n, r, z, sc, stream_);
+    launch_dot(n, r, r, sc + 2, stream_);
+    double h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    double rz_old = h[0];
+    const double abs_tol = cg_tol_ * std::max(sqrt(h[2]), 1.0);
     int it = 0;
     for (; it < cg_max_iter_; ++it) {
-        launch_sym_tile_matvec(nt_, sym_row_ptr_, sym_entries_, tiles_, p, ap, stream_);
-        double pap = 0.0;
-        rc = dot(p, ap, &pap); if (rc != kOk) return rc;
-        if (fabs(pap) < 1e-30) break;
-        const double alpha = rz_old / pap;
-        launch_pcg_update_xr(n, alpha, p, ap, x, r, stream_);
-        rc = dot(r, r, &rr); if (rc != kOk) return rc;
-        if (sqrt(rr) < abs_tol) { ++it; break; }
-        launch_pcg_precond(n, pre, r, z, stream_);
-        double rz_new = 0.0;
-        rc = dot(r, z, &rz_new); if (rc != kOk) return rc;
-        if (fabs(rz_old) < 1e-30) { ++it; break; }
-        const double beta = rz_new / rz_old;
-        launch_pcg_update_p(n, beta, z, p, stream_);
-        rz_old = rz_new;
+        launch_sym_tile_products(sym_tiles_, n_sym_tiles_, tiles_, p, sym_part_, stream_);
+        launch_sym_tile_gather(nt_, sym_row_ptr_, sym_entries_, sym_part_, p, ap, row_dot_, stream_);
+        launch_pcg_step1(n, nt_, sc, row_dot_, p, ap, pre, x, r, blk_part_, sc + 1, stream_);
+        launch_pcg_step2(n, sc, blk_part_, pre, r, p, sc + 2, stream_);
+        HIP_TRY(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (fabs(h[1]) < 1e-30) break;                       // p.Ap (:703-705); x was left untouched
+        if (sqrt(h[2]) < abs_tol) { ++it; break; }           // |r| (:726-728)
+        if (fabs(rz_old) < 1e-30) { ++it; break; }           // (:741-743)
+        rz_old = h[3];
     }
     last_pcg_iters_ = it;
     stage_end(kStFactor);
