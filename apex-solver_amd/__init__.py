@@ -10,6 +10,6 @@ Host-side modules:
 from . import layout, synthetic  # noqa: F401
 
 __all__ = ["layout", "synthetic"]
-from . import capi, solver  # noqa: F401,E402
+from . import bal, capi, solver  # noqa: F401,E402
 from .solver import (GpuSchurComplementSolver, LevenbergMarquardt, LevenbergMarquardtConfig,  # noqa: F401,E402
                      LinearSolverType, OptimizationStatus, OptimizationType, Problem, SchurVariant, SolverResult)

@@ -25,6 +25,8 @@ SYMBOLS = (
     "apexgpu_parameter_norm", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
     "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
     "apexgpu_stage_times", "apexgpu_info", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_set_shard", "apexgpu_shard_range",
+    "apexgpu_bal_open", "apexgpu_bal_close", "apexgpu_bal_last_error", "apexgpu_bal_sizes", "apexgpu_bal_raw",
+    "apexgpu_bal_variables", "apexgpu_reference_columns",
 )
 
 ERROR_NAMES = {
@@ -113,9 +115,17 @@ def load() -> C.CDLL:
     L.apexgpu_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.apexgpu_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.apexgpu_shard_range.argtypes = [i64, i64, vp, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    L.apexgpu_bal_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.apexgpu_bal_close.argtypes = [vp]
+    L.apexgpu_bal_close.restype = None
+    L.apexgpu_bal_last_error.restype = C.c_char_p
+    L.apexgpu_bal_sizes.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.apexgpu_bal_raw.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.apexgpu_bal_variables.argtypes = [vp, vp, vp]
+    L.apexgpu_reference_columns.argtypes = [i64, i64, vp, vp, vp]
     for name in SYMBOLS:
         f = getattr(L, name)
-        if name not in ("apexgpu_destroy", "apexgpu_last_error", "apexgpu_version"):
+        if name not in ("apexgpu_destroy", "apexgpu_last_error", "apexgpu_version", "apexgpu_bal_close", "apexgpu_bal_last_error"):
             f.restype = C.c_int
     _lib = L
     return L

@@ -192,6 +192,30 @@ int apexgpu_set_shard(apexgpu_solver* h, int rank, int world);
 int apexgpu_shard_range(int64_t n_pt, int64_t n_obs, const uint32_t* pt_idx, int rank, int world, int64_t* lo,
                         int64_t* hi);
 
+/* ---- input path (host only, no GPU needed): BAL files and the reference's variable order ---------
+ * BalLoader::load (crates/apex-io/src/bal.rs:138-202): header "n_cam n_pt n_obs", n_obs lines
+ * "cam pt x y", 9 lines per camera (rx ry rz tx ty tz f k1 k2), 3 lines per point; blank lines are
+ * skipped; a non-positive or non-finite focal length becomes 500 (:100-114).  Error codes mirror
+ * IoError: Io, Parse, MissingFields, InvalidNumber; text via apexgpu_bal_last_error(). */
+typedef struct apexgpu_bal apexgpu_bal;
+#define APEXGPU_BAL_ERR_IO (-20)
+#define APEXGPU_BAL_ERR_PARSE (-21)
+#define APEXGPU_BAL_ERR_MISSING_FIELDS (-22)
+#define APEXGPU_BAL_ERR_INVALID_NUMBER (-23)
+int apexgpu_bal_open(const char* path, apexgpu_bal** out);
+void apexgpu_bal_close(apexgpu_bal* b);
+const char* apexgpu_bal_last_error(void);
+int apexgpu_bal_sizes(const apexgpu_bal* b, int64_t* n_cam, int64_t* n_pt, int64_t* n_obs);
+/* raw file contents: cameras9[n_cam][9] = rx ry rz tx ty tz f k1 k2; any pointer may be NULL */
+int apexgpu_bal_raw(const apexgpu_bal* b, uint32_t* cam_idx, uint32_t* pt_idx, double* obs_uv, double* cameras9,
+                    double* points3);
+/* the variables run_bundle_adjustment creates (bin/bundle_adjustment.rs:200-208, 232-257):
+ * poses7[n_cam][7] = [t, qw,qx,qy,qz] from the axis-angle, intr3[n_cam][3] = [f,k1,k2] */
+int apexgpu_bal_variables(const apexgpu_bal* b, double* poses7, double* intr3);
+/* first global column of intr_{i:04} / pose_{i:04} / pt_{j:05} in the sorted-name order of
+ * src/optimizer/mod.rs:530-536 (what apexgpu_set_structure expects) */
+int apexgpu_reference_columns(int64_t n_cam, int64_t n_pt, int64_t* intr_col, int64_t* pose_col, int64_t* pt_col);
+
 #ifdef __cplusplus
 }
 #endif
