@@ -146,7 +146,7 @@ class Solver {
     int mode_, dc_, device_;
     int64_t n_c_ = 0, n_c_pad_ = 0;
     int nt_ = 0;
-    int64_t n_slots_ = 0;
+    int64_t n_slots_ = 0, n_touched_slots_ = 0;
     double huber_delta_ = 1.0;
     bool have_structure_ = false, have_params_ = false, have_step_ = false, have_trial_ = false;
     int cur_ = 0;  // index of the current parameter set (0/1); the other one is the trial set

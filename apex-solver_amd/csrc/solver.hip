@@ -347,10 +347,18 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     diag_slot_h_.assign(nt_, 0);
     n_slots_ = 0;
     max_col_ = 0;
+    // slots: first every tile that S itself touches (diagonal + covisible pairs), then the tiles that
+    // exist only because of fill -- the multi-GPU all-reduce of S then moves the first group only
     for (int K = 0; K < nt_; ++K) {
         diag_slot_h_[K] = (int)n_slots_;
         slot_h_[(size_t)K * nt_ + K] = (int)n_slots_++;
-        for (int I : col_rows_[K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
+        for (int I : col_rows_[K])
+            if (present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
+    }
+    n_touched_slots_ = n_slots_;
+    for (int K = 0; K < nt_; ++K) {
+        for (int I : col_rows_[K])
+            if (!present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
         max_col_ = std::max<int>(max_col_, (int)col_rows_[K].size());
     }
     const size_t tile_elems = (size_t)kNB * kNB;
@@ -747,7 +755,7 @@ int Solver::assemble(double lambda, double diag_extra) {
         stage_begin(kStAllReduce);
         ncclComm_t c = reinterpret_cast<ncclComm_t>(comm_);
         ncclGroupStart();
-        ncclAllReduce(tiles_, tiles_, (size_t)n_slots_ * tile_elems, ncclDouble, ncclSum, c, stream_);
+        ncclAllReduce(tiles_, tiles_, (size_t)n_touched_slots_ * tile_elems, ncclDouble, ncclSum, c, stream_);
         ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
         ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
         ncclGroupEnd();

@@ -374,6 +374,27 @@ def test_lm_converges_like_reference_integration_test(oracle):
     assert res.final_cost == pytest.approx(ores.final_cost, rel=1e-6)
 
 
+def test_bal_file_end_to_end(oracle, tmp_path):
+    """A BAL text file drives the backend: C++ reader -> problem as
+    bin/bundle_adjustment.rs builds it -> LevenbergMarquardt; same trajectory as the oracle on the same
+    loaded data (the reference's integration test asserts: converged, cost decreased)."""
+    from apex_solver_amd.bal import BalLoader, write_bal
+
+    d0 = pkg.synthetic.make_problem(15, 500, 3, 7, config_id=33)
+    path = tmp_path / "problem-15-500-pre.txt"
+    write_bal(path, d0)
+    d = BalLoader.load(path).to_problem_data()
+    prob = Problem.bundle_adjustment(d, OptimizationType.SelfCalibration, 1.0)
+    cfg = LevenbergMarquardtConfig.for_bundle_adjustment().with_schur_variant(SchurVariant.Sparse).with_max_iterations(10)
+    res = LevenbergMarquardt.with_config(cfg).optimize(prob)
+    assert res.final_cost < res.initial_cost
+    o = oracle_problem(oracle, d, prob, "selfcal")
+    ores = o.optimize(oracle.LMConfig.default(max_iterations=10, variant=0))
+    assert res.iterations == ores.iterations and res.status.name == ores.status
+    assert res.initial_cost == pytest.approx(ores.initial_cost, rel=1e-13)
+    assert res.final_cost == pytest.approx(ores.final_cost, rel=1e-6)
+
+
 def test_rccl_communicator_single_rank():
     """The collective code path (RCCL communicator, all-reduces on the solver's stream) with a
     one-rank communicator gives the same step as the plain path.  (N > 1 needs N GPUs: the driver's
