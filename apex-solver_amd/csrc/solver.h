@@ -13,6 +13,7 @@
 
 #include "ba_kernels.h"
 #include "chol_kernels.h"
+#include "tile_plan.h"
 
 struct ncclComm;  // RCCL communicator (optional)
 
@@ -100,18 +101,18 @@ class Solver {
     int get_schur(double* S_out, double* gred_out);  // reference camera-side order, dense
     int get_landmark_blocks(double* hinv_out, double* gl_out);
     int get_step_internal(double* dc_out, double* dl_out);
-    int64_t tile_count() const { return n_slots_; }
+    int64_t tile_count() const { return tp_.n_slots(); }
     int n_tile_rows() const { return nt_; }
     double last_reg() const { return last_reg_; }
     int last_pcg_iters() const { return last_pcg_iters_; }
     int stage_times(double* ms, int64_t* launches);  // averaged HIP-event time per stage since reset
     void reset_stage_times();
     void enable_stage_timing(bool on) { timing_ = on; }
-    void enable_graphs(bool on) { use_graphs_ = on; }
+    void enable_graphs(bool on) { use_graphs_ = on; tp_.enable_graphs(on); }
     void use_row_schur(bool on) { use_rows_ = on; }
     void set_rows_debug(int v) { rows_dbg_ = v; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
-    int n_levels() const { return n_levels_; }
+    int n_levels() const { return tp_.n_levels(); }
     double schur_scatter_pairs() const { return (double)n_pairs_; }
     double touched_tiles() const { return (double)n_present_; }
     double local_obs() const { return (double)o_orig_h_.size(); }
@@ -133,9 +134,6 @@ class Solver {
     int factor_and_solve(double lambda);
     int cholesky_attempt(int* failed_at);
     int tri_solve();
-    void enqueue_factor();
-    void enqueue_tri_solve();
-    bool run_graph(int which);
     int pcg_solve();
     int cost_of(int which, double* out);
     void stage_begin(int st);
@@ -146,7 +144,6 @@ class Solver {
     int mode_, dc_, device_;
     int64_t n_c_ = 0, n_c_pad_ = 0;
     int nt_ = 0;
-    int64_t n_slots_ = 0, n_touched_slots_ = 0;
     double huber_delta_ = 1.0;
     bool have_structure_ = false, have_params_ = false, have_step_ = false, have_trial_ = false;
     int cur_ = 0;  // index of the current parameter set (0/1); the other one is the trial set
@@ -163,9 +160,6 @@ class Solver {
     // host copies
     std::vector<int64_t> intr_col_, pose_col_, pt_col_;
     std::vector<int> o_orig_h_;
-    std::vector<int> slot_h_, diag_slot_h_;
-    std::vector<std::vector<int>> col_rows_;       // per tile column K: rows I > K present (after fill)
-    int max_col_ = 0;
 
     // device
     hipStream_t stream_ = nullptr;
@@ -182,33 +176,18 @@ class Solver {
     double2* o_uv_ = nullptr;
     int *o_orig_ = nullptr, *pt_ptr_ = nullptr, *cam_ptr_ = nullptr, *cam_obs_ = nullptr;
     uint8_t *fix_pose_ = nullptr, *fix_intr_ = nullptr, *fix_pt_ = nullptr;
-    double *tiles_ = nullptr, *linv_ = nullptr;
-    int *slot_ = nullptr, *diag_slot_ = nullptr;
+    TilePlan tp_;  // tiles of S, their factorisation and solves
     double *g_c_ = nullptr, *g_red_ = nullptr, *dcam_ = nullptr, *hinv_ = nullptr, *g_l_ = nullptr, *dl_ = nullptr;
     double *partial_ = nullptr, *scal_ = nullptr;  // reduction scratch, scalar outputs
-    int* flags_ = nullptr;                          // [0] landmark inversion error, [1] potrf failure
+    int* flags_ = nullptr;                          // [0] landmark inversion error
     ScatterTask* tasks_ = nullptr;
     int n_tasks_ = 0;
-    GemmTask *trsm_tasks_ = nullptr, *upd_tasks_ = nullptr;
-    PotrfTask* potrf_tasks_ = nullptr;
-    int n_levels_ = 0;
-    std::vector<int> lv_potrf_, lv_trsm_, lv_fwd_, lv_bwd_, lv_upd_round_;
-    std::vector<std::pair<int64_t, int64_t>> upd_rounds_;  // (offset, count) of each update launch
     std::vector<int> cmap_, cinv_;   // external camera -> internal camera and back
     bool use_nd_ = true;
     int nd_leaf_ = 16;
-    TriTask *tri_fwd_ = nullptr, *tri_bwd_ = nullptr;
-    SymTile* sym_tiles_ = nullptr;
-    int n_sym_tiles_ = 0;
-    double *sym_part_ = nullptr, *row_dot_ = nullptr, *blk_part_ = nullptr;
-    int* sym_row_ptr_ = nullptr;
-    SymEntry* sym_entries_ = nullptr;
     double* pcg_buf_ = nullptr;                    // 7 vectors of n_c_pad
     int n_partial_ = 1024;
 
-    // captured launch sequences: [0] factorisation, [1] triangular solves
-    hipGraphExec_t graph_exec_[2] = {nullptr, nullptr};
-    bool graph_failed_[2] = {false, false};
     bool use_graphs_ = true;
 
     // timing

@@ -35,15 +35,12 @@ Solver::~Solver() {
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
     void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
-                    cam_ptr_, cam_obs_, fix_pose_, fix_intr_, fix_pt_, tiles_, linv_, slot_, diag_slot_, g_c_, g_red_,
-                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, trsm_tasks_, upd_tasks_,
-                    potrf_tasks_, tri_fwd_, tri_bwd_, sym_tiles_, sym_part_, row_dot_, blk_part_, sym_row_ptr_, sym_entries_, pcg_buf_};
+                    cam_ptr_, cam_obs_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
+                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     resolve_stage_events();
     for (hipEvent_t e : ev_pool_) hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i)
-        if (graph_exec_[i]) hipGraphExecDestroy(graph_exec_[i]);
 #ifdef APEX_WITH_RCCL
     if (comm_) ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm_));
 #endif
@@ -69,11 +66,7 @@ BAView Solver::view(int which) const {
     return v;
 }
 
-TileMap Solver::tilemap() const {
-    TileMap tm;
-    tm.tiles = tiles_; tm.slot = slot_; tm.nt = nt_;
-    return tm;
-}
+TileMap Solver::tilemap() const { return tp_.tilemap(); }
 
 // Stage timing records HIP events on the solver's own stream WITHOUT synchronising; the pairs are
 // resolved when stage_times() is called, so a timed region is not perturbed by the measurement.
@@ -140,56 +133,6 @@ int Solver::comm_init(int world, int rank, const void* unique_id128) {
 #endif
 }
 
-// Nested-dissection order of the nodes of an undirected graph: recursive bisection by BFS level
-// structures from a pseudo-peripheral node; the middle level is the separator and is ordered after
-// both halves.  Sub-graphs of at most `leaf` nodes (or that a level structure cannot split, e.g. a
-// clique) keep their natural order.  Deterministic.
-static void nested_dissection(const std::vector<std::vector<int>>& adj, std::vector<int> nodes, std::vector<int>& out,
-                              int leaf) {
-    std::sort(nodes.begin(), nodes.end());
-    if ((int)nodes.size() <= leaf) { out.insert(out.end(), nodes.begin(), nodes.end()); return; }
-    const int n = (int)adj.size();
-    std::vector<int> mark(n, -1), dist(n, -1);
-    for (int v : nodes) mark[v] = 0;
-    auto bfs = [&](int src, std::vector<int>& order) {
-        for (int v : nodes) dist[v] = -1;
-        order.clear();
-        order.push_back(src); dist[src] = 0;
-        for (size_t h = 0; h < order.size(); ++h)
-            for (int w : adj[order[h]])
-                if (mark[w] == 0 && dist[w] < 0) { dist[w] = dist[order[h]] + 1; order.push_back(w); }
-    };
-    std::vector<int> order;
-    bfs(nodes[0], order);
-    if (order.size() < nodes.size()) {  // disconnected: order the components independently
-        std::vector<int> comp(order), rest;
-        std::vector<char> in(n, 0);
-        for (int v : comp) in[v] = 1;
-        for (int v : nodes) if (!in[v]) rest.push_back(v);
-        nested_dissection(adj, comp, out, leaf);
-        nested_dissection(adj, rest, out, leaf);
-        return;
-    }
-    bfs(order.back(), order);  // from a far node: long, thin level structure
-    const int depth = dist[order.back()];
-    if (depth < 2) { out.insert(out.end(), nodes.begin(), nodes.end()); return; }
-    std::vector<int> cnt(depth + 1, 0);
-    for (int v : nodes) cnt[dist[v]]++;
-    int best = 1; long bestcost = -1; long below = cnt[0];
-    for (int m = 1; m < depth; ++m) {
-        const long above = (long)nodes.size() - below - cnt[m];
-        const long cost = std::labs(below - above) + 2L * cnt[m];  // balance + separator size
-        if (bestcost < 0 || cost < bestcost) { bestcost = cost; best = m; }
-        below += cnt[m];
-    }
-    std::vector<int> A, B, S;
-    for (int v : nodes) (dist[v] < best ? A : (dist[v] > best ? B : S)).push_back(v);
-    nested_dissection(adj, A, out, leaf);
-    nested_dissection(adj, B, out, leaf);
-    std::sort(S.begin(), S.end());
-    out.insert(out.end(), S.begin(), S.end());
-}
-
 // Landmark range [lo,hi) of `rank`: contiguous, balanced by observation count.  ptr[l] = number of
 // observations of landmarks < l (n_pt+1 entries).  Pure host arithmetic, identical on every rank.
 void shard_range(int64_t n_pt, const int64_t* ptr, int rank, int world, int64_t* lo, int64_t* hi) {
@@ -254,15 +197,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
                     for (size_t b = 0; b < a; ++b) { adjm[(size_t)tl[a] * nt_ + tl[b]] = 1; adjm[(size_t)tl[b] * nt_ + tl[a]] = 1; }
             }
             // the last tile may be partial (padding rows): it stays last (= eliminated last, no fill)
-            std::vector<std::vector<int>> adj(nt_ - 1);
-            for (int a = 0; a < nt_ - 1; ++a)
-                for (int b = 0; b < nt_ - 1; ++b)
-                    if (adjm[(size_t)a * nt_ + b]) adj[a].push_back(b);
-            std::vector<int> nodes(nt_ - 1), order;
-            std::iota(nodes.begin(), nodes.end(), 0);
-            nested_dissection(adj, nodes, order, nd_leaf_);
-            for (int pos = 0; pos < (int)order.size(); ++pos) tperm[order[pos]] = pos;
-            tperm[nt_ - 1] = nt_ - 1;
+            tperm = TilePlan::order(nt_, adjm, true, nd_leaf_);
         }
         cmap_.resize(n_cam_);
         cinv_.assign(n_cam_, -1);
@@ -330,45 +265,10 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
                 for (size_t b = 0; b <= a; ++b) present[(size_t)tl[a] * nt_ + tl[b]] = 1;
         }
     }
-    col_rows_.assign(nt_, {});
-    for (int K = 0; K < nt_; ++K)
-        for (int I = K + 1; I < nt_; ++I)
-            if (present[(size_t)I * nt_ + K]) col_rows_[K].push_back(I);
-    for (int K = 0; K < nt_; ++K) {  // struct(L_K) \ {parent} merges into the parent column
-        auto& rows = col_rows_[K];
-        if (rows.size() < 2) continue;
-        const int parent = rows[0];
-        std::vector<int> merged;
-        std::set_union(col_rows_[parent].begin(), col_rows_[parent].end(), rows.begin() + 1, rows.end(),
-                       std::back_inserter(merged));
-        col_rows_[parent].swap(merged);
-    }
-    slot_h_.assign((size_t)nt_ * nt_, -1);
-    diag_slot_h_.assign(nt_, 0);
-    n_slots_ = 0;
-    max_col_ = 0;
-    // slots: first every tile that S itself touches (diagonal + covisible pairs), then the tiles that
-    // exist only because of fill -- the multi-GPU all-reduce of S then moves the first group only
-    for (int K = 0; K < nt_; ++K) {
-        diag_slot_h_[K] = (int)n_slots_;
-        slot_h_[(size_t)K * nt_ + K] = (int)n_slots_++;
-        for (int I : col_rows_[K])
-            if (present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
-    }
-    n_touched_slots_ = n_slots_;
-    for (int K = 0; K < nt_; ++K) {
-        for (int I : col_rows_[K])
-            if (!present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
-        max_col_ = std::max<int>(max_col_, (int)col_rows_[K].size());
-    }
-    const size_t tile_elems = (size_t)kNB * kNB;
+    tp_.enable_graphs(use_graphs_);
     {
-        size_t free_b = 0, total_b = 0;
-        hipMemGetInfo(&free_b, &total_b);
-        const double need = (double)(n_slots_ + nt_) * tile_elems * 8.0;
-        if (need > 0.9 * (double)free_b)
-            return fail(kInvalidInput, "reduced camera matrix needs " + std::to_string(need / 1e9) +
-                                           " GB of tiles; only " + std::to_string(free_b / 1e9) + " GB free");
+        const std::string e = tp_.build(nt_, present, stream_);
+        if (!e.empty()) return fail(kInvalidInput, "reduced camera matrix: " + e);
     }
 
     // ---- Schur-scatter tasks over the local landmarks -----------------------------------------------
@@ -490,8 +390,6 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(up(&pt_ptr_, pt_ptr));
     HIP_TRY(up(&cam_ptr_, cam_ptr));
     HIP_TRY(up(&cam_obs_, cam_obs));
-    HIP_TRY(up(&slot_, slot_h_));
-    HIP_TRY(up(&diag_slot_, diag_slot_h_));
     HIP_TRY(up(&tasks_, tasks));
     HIP_TRY(up(&rtasks_, rtasks));
     HIP_TRY(up(&rbatches_, rbatches));
@@ -520,8 +418,6 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         HIP_TRY(alloc(&pts_[w], 3 * n_pt_));
         HIP_TRY(alloc(&camp_[w], (size_t)kCamStride * n_cam_));
     }
-    HIP_TRY(alloc(&tiles_, (size_t)n_slots_ * tile_elems));
-    HIP_TRY(alloc(&linv_, (size_t)nt_ * tile_elems));
     HIP_TRY(alloc(&g_c_, n_c_pad_));
     HIP_TRY(alloc(&g_red_, n_c_pad_));
     HIP_TRY(alloc(&dcam_, n_c_pad_));
@@ -535,109 +431,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(dev_alloc(&flags_, 4));
     HIP_TRY(hipMemset(flags_, 0, 4 * sizeof(int)));
 
-    // ---- factorisation / solve task lists, scheduled by elimination-tree LEVEL -----------------------
-    // parent(K) = first off-diagonal row of column K; level = height above the leaves.  Columns of one
-    // level are independent: their potrf / panel solves / trailing updates run as ONE batched launch
-    // each.  Two columns of a level may update the same ancestor tile: those updates are split into
-    // conflict-free rounds (deterministic), one launch per round.
-    auto tile_ptr = [&](int I, int J) { return tiles_ + (size_t)slot_h_[(size_t)I * nt_ + J] * tile_elems; };
-    auto linv_ptr = [&](int K) { return linv_ + (size_t)K * tile_elems; };
-    std::vector<int> level(nt_, 0);
-    for (int K = 0; K < nt_; ++K)
-        if (!col_rows_[K].empty()) level[col_rows_[K][0]] = std::max(level[col_rows_[K][0]], level[K] + 1);
-    n_levels_ = 1 + *std::max_element(level.begin(), level.end());
-    std::vector<std::vector<int>> level_cols(n_levels_);
-    for (int K = 0; K < nt_; ++K) level_cols[level[K]].push_back(K);
-    std::vector<std::vector<int>> row_cols(nt_);
-    for (int K = 0; K < nt_; ++K)
-        for (int I : col_rows_[K]) row_cols[I].push_back(K);
-    std::vector<PotrfTask> potrf;
-    std::vector<GemmTask> trsm, upd;
-    std::vector<TriTask> tf, tb;
-    lv_potrf_.assign(n_levels_ + 1, 0); lv_trsm_.assign(n_levels_ + 1, 0);
-    lv_fwd_.assign(n_levels_ + 1, 0); lv_bwd_.assign(n_levels_ + 1, 0);
-    lv_upd_round_.assign(n_levels_ + 1, 0);
-    upd_rounds_.clear();
-    int64_t n_upd = 0;
-    for (int K = 0; K < nt_; ++K) n_upd += (int64_t)col_rows_[K].size() * (col_rows_[K].size() + 1) / 2;
-    if (n_upd > 80000000LL) return fail(kInvalidInput, "tile update list too large (" + std::to_string(n_upd) + ")");
-    upd.reserve(n_upd);
-    for (int lv = 0; lv < n_levels_; ++lv) {
-        struct U { int64_t key; int K; GemmTask t; };
-        std::vector<U> us;
-        for (int K : level_cols[lv]) {
-            const auto& rows = col_rows_[K];
-            potrf.push_back({tile_ptr(K, K), linv_ptr(K), K});
-            tf.push_back({linv_ptr(K), nullptr, K, -1});
-            for (int I : rows) {
-                trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});
-                tf.push_back({linv_ptr(K), tile_ptr(I, K), K, I});
-            }
-            for (size_t a = 0; a < rows.size(); ++a)
-                for (size_t b = 0; b <= a; ++b)
-                    us.push_back({(int64_t)rows[a] * nt_ + rows[b], K, {tile_ptr(rows[a], rows[b]), tile_ptr(rows[a], K), tile_ptr(rows[b], K)}});
-        }
-        std::stable_sort(us.begin(), us.end(), [](const U& x, const U& y) { return x.key < y.key; });
-        std::vector<int> round(us.size(), 0);
-        int n_rounds = 0;
-        for (size_t i = 0; i < us.size(); ++i) {
-            round[i] = (i > 0 && us[i].key == us[i - 1].key) ? round[i - 1] + 1 : 0;
-            n_rounds = std::max(n_rounds, round[i] + 1);
-        }
-        for (int r = 0; r < n_rounds; ++r) {
-            // inside a round: by source column, so that tasks sharing operand tiles are neighbours
-            std::vector<const U*> sel;
-            for (size_t i = 0; i < us.size(); ++i)
-                if (round[i] == r) sel.push_back(&us[i]);
-            std::stable_sort(sel.begin(), sel.end(), [](const U* x, const U* y) { return x->K < y->K; });
-            const int64_t off = (int64_t)upd.size();
-            for (const U* u : sel) upd.push_back(u->t);
-            upd_rounds_.push_back({off, (int64_t)upd.size() - off});
-        }
-        lv_potrf_[lv + 1] = (int)potrf.size();
-        lv_trsm_[lv + 1] = (int)trsm.size();
-        lv_fwd_[lv + 1] = (int)tf.size();
-        lv_upd_round_[lv + 1] = (int)upd_rounds_.size();
-    }
-    for (int lv = n_levels_ - 1; lv >= 0; --lv) {  // backward sweep: levels from the root down
-        for (int I : level_cols[lv]) {
-            tb.push_back({linv_ptr(I), nullptr, I, -1});
-            for (int J : row_cols[I]) tb.push_back({linv_ptr(I), tile_ptr(I, J), I, J});
-        }
-        lv_bwd_[n_levels_ - lv] = (int)tb.size();
-    }
-    // symmetric matvec of the PCG variant: only tiles that are non-zero in S (before fill)
-    std::vector<int> sym_ptr(nt_ + 1, 0);
-    std::vector<SymEntry> sym;
-    std::vector<SymTile> symt;
-    for (int I = 0; I < nt_; ++I) {
-        for (int J = 0; J < I; ++J)
-            if (present[(size_t)I * nt_ + J]) sym.push_back({slot_h_[(size_t)I * nt_ + J], J, 0});
-        sym.push_back({diag_slot_h_[I], I, 2});
-        for (int I2 = I + 1; I2 < nt_; ++I2)
-            if (present[(size_t)I2 * nt_ + I]) sym.push_back({slot_h_[(size_t)I2 * nt_ + I], I2, 1});
-        sym_ptr[I + 1] = (int)sym.size();
-        for (int J = 0; J <= I; ++J)
-            if (J == I || present[(size_t)I * nt_ + J]) symt.push_back({slot_h_[(size_t)I * nt_ + J], I, J});
-    }
-    n_sym_tiles_ = (int)symt.size();
-    HIP_TRY(up(&sym_tiles_, symt));
-    HIP_TRY(alloc(&sym_part_, (size_t)n_slots_ * 2 * kNB));
-    HIP_TRY(alloc(&row_dot_, (size_t)nt_));
-    HIP_TRY(alloc(&blk_part_, 2 * (size_t)((n_c_pad_ + 255) / 256)));
-    HIP_TRY(up(&tri_fwd_, tf));
-    HIP_TRY(up(&tri_bwd_, tb));
-    HIP_TRY(up(&potrf_tasks_, potrf));
-    HIP_TRY(up(&trsm_tasks_, trsm));
-    HIP_TRY(up(&upd_tasks_, upd));
-    HIP_TRY(up(&sym_row_ptr_, sym_ptr));
-    HIP_TRY(up(&sym_entries_, sym));
     HIP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on stream_
 
-    for (int i = 0; i < 2; ++i) {
-        if (graph_exec_[i]) { hipGraphExecDestroy(graph_exec_[i]); graph_exec_[i] = nullptr; }
-        graph_failed_[i] = false;
-    }
     have_structure_ = true;
     have_params_ = have_step_ = have_trial_ = false;
     cur_ = 0;
@@ -730,12 +525,12 @@ int Solver::assemble(double lambda, double diag_extra) {
     const BAView v = view(cur_);
     const TileMap tm = tilemap();
     stage_begin(kStAssembleCam);
-    HIP_TRY(hipMemsetAsync(tiles_, 0, (size_t)n_slots_ * tile_elems * sizeof(double), stream_));
+    HIP_TRY(tp_.zero_tiles());
     HIP_TRY(hipMemsetAsync(g_red_, 0, n_c_pad_ * sizeof(double), stream_));
     HIP_TRY(hipMemsetAsync(g_c_, 0, n_c_pad_ * sizeof(double), stream_));
     HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
     // identity on the padding rows of the last tile (rank 0 only: the all-reduce sums the ranks)
-    launch_tile_add_diag(tiles_, diag_slot_, (int)n_c_, (int)n_c_pad_, 0.0, rank_ == 0 ? 1.0 : 0.0, stream_);
+    tp_.add_diag((int)n_c_, 0.0, rank_ == 0 ? 1.0 : 0.0);
     stage_end(kStAssembleCam);
     stage_begin(kStAssembleLm);
     launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, stream_);
@@ -755,7 +550,7 @@ int Solver::assemble(double lambda, double diag_extra) {
         stage_begin(kStAllReduce);
         ncclComm_t c = reinterpret_cast<ncclComm_t>(comm_);
         ncclGroupStart();
-        ncclAllReduce(tiles_, tiles_, (size_t)n_touched_slots_ * tile_elems, ncclDouble, ncclSum, c, stream_);
+        ncclAllReduce(tp_.tiles(), tp_.tiles(), (size_t)tp_.n_touched_slots() * tile_elems, ncclDouble, ncclSum, c, stream_);
         ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
         ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
         ncclGroupEnd();
@@ -765,59 +560,16 @@ int Solver::assemble(double lambda, double diag_extra) {
     return kOk;
 }
 
-// The factorisation and the triangular solves are static launch sequences for a given structure:
-// they are captured once into hipGraphs (a few thousand tiny dependent launches would otherwise be
-// paced by host launch overhead) and replayed every LM iteration.
-void Solver::enqueue_factor() {
-    for (int lv = 0; lv < n_levels_; ++lv) {
-        launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flags_ + 1, stream_);
-        launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_);
-        for (int r = lv_upd_round_[lv]; r < lv_upd_round_[lv + 1]; ++r)
-            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, stream_);
-    }
-}
-
-void Solver::enqueue_tri_solve() {
-    // L y = g_red (work vector bvec), then L^T x = y (work vector yvec), x -> dcam_; level by level
-    double* bvec = pcg_buf_;
-    double* yvec = pcg_buf_ + n_c_pad_;
-    hipMemcpyAsync(bvec, g_red_, n_c_pad_ * sizeof(double), hipMemcpyDeviceToDevice, stream_);
-    for (int lv = 0; lv < n_levels_; ++lv)
-        launch_tri_step(false, tri_fwd_ + lv_fwd_[lv], lv_fwd_[lv + 1] - lv_fwd_[lv], bvec, yvec, stream_);
-    for (int s = 0; s < n_levels_; ++s)
-        launch_tri_step(true, tri_bwd_ + lv_bwd_[s], lv_bwd_[s + 1] - lv_bwd_[s], yvec, dcam_, stream_);
-}
-
-bool Solver::run_graph(int which) {
-    if (!use_graphs_) return false;
-    if (!graph_exec_[which]) {
-        if (graph_failed_[which]) return false;
-        hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_failed_[which] = true; return false; }
-        if (which == 0) enqueue_factor(); else enqueue_tri_solve();
-        if (hipStreamEndCapture(stream_, &g) != hipSuccess || !g) { graph_failed_[which] = true; (void)hipGetLastError(); return false; }
-        hipGraphExec_t ex = nullptr;
-        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(g); graph_failed_[which] = true; (void)hipGetLastError(); return false; }
-        hipGraphDestroy(g);
-        graph_exec_[which] = ex;
-    }
-    return hipGraphLaunch(graph_exec_[which], stream_) == hipSuccess;
-}
-
 int Solver::cholesky_attempt(int* failed_at) {
     stage_begin(kStFactor);
-    if (!run_graph(0)) enqueue_factor();
+    HIP_TRY(tp_.factor(failed_at));
     stage_end(kStFactor);
-    int f = 0;
-    HIP_TRY(hipMemcpyAsync(&f, flags_ + 1, sizeof(int), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
-    *failed_at = f;
     return kOk;
 }
 
 int Solver::tri_solve() {
     stage_begin(kStTriSolve);
-    if (!run_graph(1)) enqueue_tri_solve();
+    tp_.solve(g_red_, dcam_, pcg_buf_);
     stage_end(kStTriSolve);
     return kOk;
 }
@@ -833,7 +585,7 @@ int Solver::factor_and_solve(double lambda) {
     rc = assemble(lambda, 0.0);
     if (rc != kOk) return rc;
     double* diag = pcg_buf_;
-    launch_tile_diag(tiles_, diag_slot_, nt_, diag, stream_);
+    tp_.diag(diag);
     std::vector<double> hd(n_c_);
     HIP_TRY(hipMemcpyAsync(hd.data(), diag, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -856,39 +608,9 @@ int Solver::factor_and_solve(double lambda) {
 }
 
 // solve_with_pcg (explicit_schur.rs:639-756): Jacobi-preconditioned CG on the explicit S.
-// Per iteration: one pass over the non-zero tiles of S (k_sym_tile_products + k_sym_tile_gather, which
-// also yields p.Ap), two fused vector kernels that keep alpha/beta on the device, and ONE host
-// read-back of {p.Ap, r.r, r.z} for the reference's three termination tests.
 int Solver::pcg_solve() {
     stage_begin(kStFactor);
-    const int n = (int)n_c_pad_;
-    const int nb = (n + 255) / 256;
-    double *diag = pcg_buf_, *pre = pcg_buf_ + n, *x = dcam_, *r = pcg_buf_ + 2 * (size_t)n, *z = pcg_buf_ + 3 * (size_t)n,
-           *p = pcg_buf_ + 4 * (size_t)n, *ap = pcg_buf_ + 5 * (size_t)n;
-    double* sc = scal_ + 16;  // [0] rz_old  [1] p.Ap  [2] r.r  [3] r.z
-    launch_tile_diag(tiles_, diag_slot_, nt_, diag, stream_);
-    launch_pcg_init(n, diag, g_red_, pre, x, r, z, p, stream_);
-    launch_dot(n, r, z, sc, stream_);
-    launch_dot(n, r, r, sc + 2, stream_);
-    double h[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
-    double rz_old = h[0];
-    const double abs_tol = cg_tol_ * std::max(sqrt(h[2]), 1.0);
-    int it = 0;
-    for (; it < cg_max_iter_; ++it) {
-        launch_sym_tile_products(sym_tiles_, n_sym_tiles_, tiles_, p, sym_part_, stream_);
-        launch_sym_tile_gather(nt_, sym_row_ptr_, sym_entries_, sym_part_, p, ap, row_dot_, stream_);
-        launch_pcg_step1(n, nt_, sc, row_dot_, p, ap, pre, x, r, blk_part_, sc + 1, stream_);
-        launch_pcg_step2(n, sc, blk_part_, pre, r, p, sc + 2, stream_);
-        HIP_TRY(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
-        if (fabs(h[1]) < 1e-30) break;                       // p.Ap (:703-705); x was left untouched
-        if (sqrt(h[2]) < abs_tol) { ++it; break; }           // |r| (:726-728)
-        if (fabs(rz_old) < 1e-30) { ++it; break; }           // (:741-743)
-        rz_old = h[3];
-    }
-    last_pcg_iters_ = it;
+    HIP_TRY(tp_.pcg(g_red_, dcam_, pcg_buf_, cg_max_iter_, cg_tol_, &last_pcg_iters_));
     stage_end(kStFactor);
     return kOk;
 }
@@ -1172,9 +894,9 @@ int Solver::get_schur(double* S_out, double* gred_out) {
         std::vector<double> t(tile_elems);
         for (int I = 0; I < nt_; ++I)
             for (int J = 0; J <= I; ++J) {
-                const int s = slot_h_[(size_t)I * nt_ + J];
+                const int s = tp_.slot(I, J);
                 if (s < 0) continue;
-                HIP_TRY(hipMemcpyAsync(t.data(), tiles_ + (size_t)s * tile_elems, tile_elems * sizeof(double), hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(hipMemcpyAsync(t.data(), tp_.tiles() + (size_t)s * tile_elems, tile_elems * sizeof(double), hipMemcpyDeviceToHost, stream_));
                 HIP_TRY(hipStreamSynchronize(stream_));
                 for (int r = 0; r < kNB; ++r)
                     for (int c = 0; c < kNB; ++c) {

@@ -1,0 +1,372 @@
+// tile_plan.hip -- see tile_plan.h
+#include "tile_plan.h"
+
+#include <math.h>
+
+#include <algorithm>
+#include <numeric>
+
+namespace apex {
+
+template <typename T>
+static hipError_t dev_alloc(T** p, size_t n) {
+    return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
+}
+template <typename T>
+static hipError_t upload(T** dptr, const std::vector<T>& hv) {
+    if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
+    hipError_t e = dev_alloc(dptr, hv.size());
+    if (e != hipSuccess || hv.empty()) return e;
+    return hipMemcpy(*dptr, hv.data(), hv.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+static hipError_t alloc_zero(double** p, size_t n) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    hipError_t e = dev_alloc(p, n);
+    if (e != hipSuccess) return e;
+    return hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(double));
+}
+
+// Nested-dissection order of the nodes of an undirected graph: recursive bisection by BFS level
+// structures from a pseudo-peripheral node; the middle level is the separator and is ordered after
+// both halves.  Sub-graphs of at most `leaf` nodes (or that a level structure cannot split, e.g. a
+// clique) keep their natural order.  Deterministic.
+static void nested_dissection(const std::vector<std::vector<int>>& adj, std::vector<int> nodes, std::vector<int>& out,
+                              int leaf) {
+    std::sort(nodes.begin(), nodes.end());
+    if ((int)nodes.size() <= leaf) { out.insert(out.end(), nodes.begin(), nodes.end()); return; }
+    const int n = (int)adj.size();
+    std::vector<int> mark(n, -1), dist(n, -1);
+    for (int v : nodes) mark[v] = 0;
+    auto bfs = [&](int src, std::vector<int>& order) {
+        for (int v : nodes) dist[v] = -1;
+        order.clear();
+        order.push_back(src); dist[src] = 0;
+        for (size_t h = 0; h < order.size(); ++h)
+            for (int w : adj[order[h]])
+                if (mark[w] == 0 && dist[w] < 0) { dist[w] = dist[order[h]] + 1; order.push_back(w); }
+    };
+    std::vector<int> order;
+    bfs(nodes[0], order);
+    if (order.size() < nodes.size()) {  // disconnected: order the components independently
+        std::vector<int> comp(order), rest;
+        std::vector<char> in(n, 0);
+        for (int v : comp) in[v] = 1;
+        for (int v : nodes) if (!in[v]) rest.push_back(v);
+        nested_dissection(adj, comp, out, leaf);
+        nested_dissection(adj, rest, out, leaf);
+        return;
+    }
+    bfs(order.back(), order);  // from a far node: long, thin level structure
+    const int depth = dist[order.back()];
+    if (depth < 2) { out.insert(out.end(), nodes.begin(), nodes.end()); return; }
+    std::vector<int> cnt(depth + 1, 0);
+    for (int v : nodes) cnt[dist[v]]++;
+    int best = 1; long bestcost = -1; long below = cnt[0];
+    for (int m = 1; m < depth; ++m) {
+        const long above = (long)nodes.size() - below - cnt[m];
+        const long cost = std::labs(below - above) + 2L * cnt[m];  // balance + separator size
+        if (bestcost < 0 || cost < bestcost) { bestcost = cost; best = m; }
+        below += cnt[m];
+    }
+    std::vector<int> A, B, S;
+    for (int v : nodes) (dist[v] < best ? A : (dist[v] > best ? B : S)).push_back(v);
+    nested_dissection(adj, A, out, leaf);
+    nested_dissection(adj, B, out, leaf);
+    std::sort(S.begin(), S.end());
+    out.insert(out.end(), S.begin(), S.end());
+}
+
+std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool nd, int leaf) {
+    std::vector<int> perm(nt);
+    std::iota(perm.begin(), perm.end(), 0);
+    if (!nd || nt < 24) return perm;
+    std::vector<std::vector<int>> adj(nt - 1);
+    for (int a = 0; a < nt - 1; ++a)
+        for (int b = 0; b < nt - 1; ++b)
+            if (a != b && adjm[(size_t)a * nt + b]) adj[a].push_back(b);
+    std::vector<int> nodes(nt - 1), ord;
+    std::iota(nodes.begin(), nodes.end(), 0);
+    nested_dissection(adj, nodes, ord, leaf);
+    for (int pos = 0; pos < (int)ord.size(); ++pos) perm[ord[pos]] = pos;
+    perm[nt - 1] = nt - 1;
+    return perm;
+}
+
+void TilePlan::release() {
+    void* ptrs[] = {tiles_, linv_, slot_, diag_slot_, flag_, potrf_tasks_, trsm_tasks_, upd_tasks_, tri_fwd_, tri_bwd_,
+                    sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = nullptr;
+    slot_ = diag_slot_ = flag_ = sym_row_ptr_ = nullptr;
+    potrf_tasks_ = nullptr; trsm_tasks_ = upd_tasks_ = nullptr; tri_fwd_ = tri_bwd_ = nullptr;
+    sym_tiles_ = nullptr; sym_entries_ = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        if (graph_exec_[i]) { (void)hipGraphExecDestroy(graph_exec_[i]); graph_exec_[i] = nullptr; }
+        graph_failed_[i] = false;
+    }
+}
+
+TilePlan::~TilePlan() { release(); }
+
+std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStream_t stream) {
+    release();
+    nt_ = nt;
+    stream_ = stream;
+    const size_t tile_elems = (size_t)kNB * kNB;
+    // symbolic Cholesky at tile granularity: struct(L_K) \ {parent} merges into the parent column
+    std::vector<std::vector<int>> col_rows(nt_);
+    for (int K = 0; K < nt_; ++K)
+        for (int I = K + 1; I < nt_; ++I)
+            if (present[(size_t)I * nt_ + K]) col_rows[K].push_back(I);
+    for (int K = 0; K < nt_; ++K) {
+        auto& rows = col_rows[K];
+        if (rows.size() < 2) continue;
+        const int parent = rows[0];
+        std::vector<int> merged;
+        std::set_union(col_rows[parent].begin(), col_rows[parent].end(), rows.begin() + 1, rows.end(),
+                       std::back_inserter(merged));
+        col_rows[parent].swap(merged);
+    }
+    // slots: first every tile the matrix itself touches (diagonal + structural non-zeros), then the
+    // tiles that exist only because of fill -- a multi-GPU all-reduce then moves the first group only
+    slot_h_.assign((size_t)nt_ * nt_, -1);
+    diag_slot_h_.assign(nt_, 0);
+    n_slots_ = 0;
+    for (int K = 0; K < nt_; ++K) {
+        diag_slot_h_[K] = (int)n_slots_;
+        slot_h_[(size_t)K * nt_ + K] = (int)n_slots_++;
+        for (int I : col_rows[K])
+            if (present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
+    }
+    n_touched_ = n_slots_;
+    for (int K = 0; K < nt_; ++K)
+        for (int I : col_rows[K])
+            if (!present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
+    {
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const double need = (double)(n_slots_ + nt_) * tile_elems * 8.0;
+        if (need > 0.9 * (double)free_b)
+            return "the tile matrix needs " + std::to_string(need / 1e9) + " GB; only " + std::to_string(free_b / 1e9) + " GB free";
+    }
+    int64_t n_upd = 0;
+    for (int K = 0; K < nt_; ++K) n_upd += (int64_t)col_rows[K].size() * (col_rows[K].size() + 1) / 2;
+    if (n_upd > 80000000LL) return "tile update list too large (" + std::to_string(n_upd) + ")";
+
+#define TP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return std::string("HIP error in " #expr ": ") + hipGetErrorString(_e); } while (0)
+    TP_TRY(alloc_zero(&tiles_, (size_t)n_slots_ * tile_elems));
+    TP_TRY(alloc_zero(&linv_, (size_t)nt_ * tile_elems));
+    TP_TRY(upload(&slot_, slot_h_));
+    TP_TRY(upload(&diag_slot_, diag_slot_h_));
+    if (flag_) (void)hipFree(flag_);
+    TP_TRY(dev_alloc(&flag_, 4));
+    TP_TRY(hipMemset(flag_, 0, 4 * sizeof(int)));
+
+    // ---- task lists scheduled by elimination-tree LEVEL ------------------------------------------------
+    // parent(K) = first off-diagonal row of column K; level = height above the leaves.  Columns of one
+    // level are independent: their potrf / panel solves / trailing updates run as ONE batched launch
+    // each.  Two columns of a level may update the same ancestor tile: those updates are split into
+    // conflict-free rounds (deterministic), one launch per round.
+    auto tile_ptr = [&](int I, int J) { return tiles_ + (size_t)slot_h_[(size_t)I * nt_ + J] * tile_elems; };
+    auto linv_ptr = [&](int K) { return linv_ + (size_t)K * tile_elems; };
+    std::vector<int> level(nt_, 0);
+    for (int K = 0; K < nt_; ++K)
+        if (!col_rows[K].empty()) level[col_rows[K][0]] = std::max(level[col_rows[K][0]], level[K] + 1);
+    n_levels_ = 1 + *std::max_element(level.begin(), level.end());
+    std::vector<std::vector<int>> level_cols(n_levels_);
+    for (int K = 0; K < nt_; ++K) level_cols[level[K]].push_back(K);
+    std::vector<std::vector<int>> row_cols(nt_);
+    for (int K = 0; K < nt_; ++K)
+        for (int I : col_rows[K]) row_cols[I].push_back(K);
+    std::vector<PotrfTask> potrf;
+    std::vector<GemmTask> trsm, upd;
+    std::vector<TriTask> tf, tb;
+    lv_potrf_.assign(n_levels_ + 1, 0); lv_trsm_.assign(n_levels_ + 1, 0);
+    lv_fwd_.assign(n_levels_ + 1, 0); lv_bwd_.assign(n_levels_ + 1, 0);
+    lv_upd_round_.assign(n_levels_ + 1, 0);
+    upd_rounds_.clear();
+    upd.reserve(n_upd);
+    for (int lv = 0; lv < n_levels_; ++lv) {
+        struct U { int64_t key; int K; GemmTask t; };
+        std::vector<U> us;
+        for (int K : level_cols[lv]) {
+            const auto& rows = col_rows[K];
+            potrf.push_back({tile_ptr(K, K), linv_ptr(K), K});
+            tf.push_back({linv_ptr(K), nullptr, K, -1});
+            for (int I : rows) {
+                trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});
+                tf.push_back({linv_ptr(K), tile_ptr(I, K), K, I});
+            }
+            for (size_t a = 0; a < rows.size(); ++a)
+                for (size_t b = 0; b <= a; ++b)
+                    us.push_back({(int64_t)rows[a] * nt_ + rows[b], K, {tile_ptr(rows[a], rows[b]), tile_ptr(rows[a], K), tile_ptr(rows[b], K)}});
+        }
+        std::stable_sort(us.begin(), us.end(), [](const U& x, const U& y) { return x.key < y.key; });
+        std::vector<int> round(us.size(), 0);
+        int n_rounds = 0;
+        for (size_t i = 0; i < us.size(); ++i) {
+            round[i] = (i > 0 && us[i].key == us[i - 1].key) ? round[i - 1] + 1 : 0;
+            n_rounds = std::max(n_rounds, round[i] + 1);
+        }
+        for (int r = 0; r < n_rounds; ++r) {
+            // inside a round: by source column, so that tasks sharing operand tiles are neighbours
+            std::vector<const U*> sel;
+            for (size_t i = 0; i < us.size(); ++i)
+                if (round[i] == r) sel.push_back(&us[i]);
+            std::stable_sort(sel.begin(), sel.end(), [](const U* x, const U* y) { return x->K < y->K; });
+            const int64_t off = (int64_t)upd.size();
+            for (const U* u : sel) upd.push_back(u->t);
+            upd_rounds_.push_back({off, (int64_t)upd.size() - off});
+        }
+        lv_potrf_[lv + 1] = (int)potrf.size();
+        lv_trsm_[lv + 1] = (int)trsm.size();
+        lv_fwd_[lv + 1] = (int)tf.size();
+        lv_upd_round_[lv + 1] = (int)upd_rounds_.size();
+    }
+    for (int lv = n_levels_ - 1; lv >= 0; --lv) {  // backward sweep: levels from the root down
+        for (int I : level_cols[lv]) {
+            tb.push_back({linv_ptr(I), nullptr, I, -1});
+            for (int J : row_cols[I]) tb.push_back({linv_ptr(I), tile_ptr(I, J), I, J});
+        }
+        lv_bwd_[n_levels_ - lv] = (int)tb.size();
+    }
+    // symmetric matvec of the PCG variant: only tiles that are non-zero before fill
+    std::vector<int> sym_ptr(nt_ + 1, 0);
+    std::vector<SymEntry> sym;
+    std::vector<SymTile> symt;
+    for (int I = 0; I < nt_; ++I) {
+        for (int J = 0; J < I; ++J)
+            if (present[(size_t)I * nt_ + J]) sym.push_back({slot_h_[(size_t)I * nt_ + J], J, 0});
+        sym.push_back({diag_slot_h_[I], I, 2});
+        for (int I2 = I + 1; I2 < nt_; ++I2)
+            if (present[(size_t)I2 * nt_ + I]) sym.push_back({slot_h_[(size_t)I2 * nt_ + I], I2, 1});
+        sym_ptr[I + 1] = (int)sym.size();
+        for (int J = 0; J <= I; ++J)
+            if (J == I || present[(size_t)I * nt_ + J]) symt.push_back({slot_h_[(size_t)I * nt_ + J], I, J});
+    }
+    n_sym_tiles_ = (int)symt.size();
+    TP_TRY(upload(&sym_tiles_, symt));
+    TP_TRY(alloc_zero(&sym_part_, (size_t)n_slots_ * 2 * kNB));
+    TP_TRY(alloc_zero(&row_dot_, (size_t)nt_));
+    TP_TRY(alloc_zero(&blk_part_, 2 * (size_t)((n_pad() + 255) / 256)));
+    TP_TRY(alloc_zero(&scal_, 8));
+    TP_TRY(upload(&tri_fwd_, tf));
+    TP_TRY(upload(&tri_bwd_, tb));
+    TP_TRY(upload(&potrf_tasks_, potrf));
+    TP_TRY(upload(&trsm_tasks_, trsm));
+    TP_TRY(upload(&upd_tasks_, upd));
+    TP_TRY(upload(&sym_row_ptr_, sym_ptr));
+    TP_TRY(upload(&sym_entries_, sym));
+    TP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on the stream
+#undef TP_TRY
+    return "";
+}
+
+hipError_t TilePlan::zero_tiles() {
+    hipError_t e = hipMemsetAsync(tiles_, 0, (size_t)n_slots_ * kNB * kNB * sizeof(double), stream_);
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(flag_, 0, 4 * sizeof(int), stream_);
+}
+
+void TilePlan::add_diag(int n_valid, double add_valid, double pad_value) {
+    launch_tile_add_diag(tiles_, diag_slot_, n_valid, (int)n_pad(), add_valid, pad_value, stream_);
+}
+
+void TilePlan::diag(double* out) const { launch_tile_diag(tiles_, diag_slot_, nt_, out, stream_); }
+
+// The factorisation and the triangular solves are static launch sequences for a given structure:
+// they are captured once into hipGraphs (a few hundred dependent launches would otherwise be paced by
+// host launch overhead) and replayed every iteration.
+void TilePlan::enqueue_factor() {
+    for (int lv = 0; lv < n_levels_; ++lv) {
+        launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flag_, stream_);
+        launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_);
+        for (int r = lv_upd_round_[lv]; r < lv_upd_round_[lv + 1]; ++r)
+            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, stream_);
+    }
+}
+
+void TilePlan::enqueue_solve(const double* rhs, double* x, double* work) {
+    // L y = rhs (work vector bvec), then L^T x = y (work vector yvec); level by level
+    double* bvec = work;
+    double* yvec = work + n_pad();
+    (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
+    for (int lv = 0; lv < n_levels_; ++lv)
+        launch_tri_step(false, tri_fwd_ + lv_fwd_[lv], lv_fwd_[lv + 1] - lv_fwd_[lv], bvec, yvec, stream_);
+    for (int s = 0; s < n_levels_; ++s)
+        launch_tri_step(true, tri_bwd_ + lv_bwd_[s], lv_bwd_[s + 1] - lv_bwd_[s], yvec, x, stream_);
+}
+
+bool TilePlan::run_graph(int which, const double* rhs, double* x, double* work) {
+    if (!use_graphs_) return false;
+    if (which == 1 && graph_exec_[1] && (rhs != graph_rhs_ || x != graph_x_ || work != graph_work_)) {
+        (void)hipGraphExecDestroy(graph_exec_[1]);  // the captured pointers changed
+        graph_exec_[1] = nullptr;
+    }
+    if (!graph_exec_[which]) {
+        if (graph_failed_[which]) return false;
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_failed_[which] = true; return false; }
+        if (which == 0) enqueue_factor(); else enqueue_solve(rhs, x, work);
+        if (hipStreamEndCapture(stream_, &g) != hipSuccess || !g) { graph_failed_[which] = true; (void)hipGetLastError(); return false; }
+        hipGraphExec_t ex = nullptr;
+        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); graph_failed_[which] = true; (void)hipGetLastError(); return false; }
+        (void)hipGraphDestroy(g);
+        graph_exec_[which] = ex;
+        if (which == 1) { graph_rhs_ = rhs; graph_x_ = x; graph_work_ = work; }
+    }
+    return hipGraphLaunch(graph_exec_[which], stream_) == hipSuccess;
+}
+
+hipError_t TilePlan::factor(int* failed_at) {
+    if (!run_graph(0, nullptr, nullptr, nullptr)) enqueue_factor();
+    int f = 0;
+    hipError_t e = hipMemcpyAsync(&f, flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream_);
+    *failed_at = f;
+    return e;
+}
+
+void TilePlan::solve(const double* rhs, double* x, double* work) {
+    if (!run_graph(1, rhs, x, work)) enqueue_solve(rhs, x, work);
+}
+
+// solve_with_pcg (explicit_schur.rs:639-756).  Per iteration: one pass over the non-zero tiles
+// (k_sym_tile_products + k_sym_tile_gather, which also yields p.Ap), two fused vector kernels that keep
+// alpha/beta on the device, and ONE host read-back of {p.Ap, r.r, r.z} for the reference's three
+// termination tests.
+hipError_t TilePlan::pcg(const double* rhs, double* x, double* work, int max_iter, double tol, int* iters) {
+    const int n = (int)n_pad();
+    double *dg = work, *pre = work + n, *r = work + 2 * (size_t)n, *z = work + 3 * (size_t)n, *p = work + 4 * (size_t)n,
+           *ap = work + 5 * (size_t)n;
+    double* sc = scal_;  // [0] rz_old  [1] p.Ap  [2] r.r  [3] r.z
+    launch_tile_diag(tiles_, diag_slot_, nt_, dg, stream_);
+    launch_pcg_init(n, dg, rhs, pre, x, r, z, p, stream_);
+    launch_dot(n, r, z, sc, stream_);
+    launch_dot(n, r, r, sc + 2, stream_);
+    double h[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_);
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream_)) != hipSuccess) return e;
+    double rz_old = h[0];
+    const double abs_tol = tol * std::max(sqrt(h[2]), 1.0);
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        launch_sym_tile_products(sym_tiles_, n_sym_tiles_, tiles_, p, sym_part_, stream_);
+        launch_sym_tile_gather(nt_, sym_row_ptr_, sym_entries_, sym_part_, p, ap, row_dot_, stream_);
+        launch_pcg_step1(n, nt_, sc, row_dot_, p, ap, pre, x, r, blk_part_, sc + 1, stream_);
+        launch_pcg_step2(n, sc, blk_part_, pre, r, p, sc + 2, stream_);
+        if ((e = hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream_)) != hipSuccess) return e;
+        if (fabs(h[1]) < 1e-30) break;                       // p.Ap (:703-705); x was left untouched
+        if (sqrt(h[2]) < abs_tol) { ++it; break; }           // |r| (:726-728)
+        if (fabs(rz_old) < 1e-30) { ++it; break; }           // (:741-743)
+        rz_old = h[3];
+    }
+    *iters = it;
+    return hipSuccess;
+}
+
+}  // namespace apex
