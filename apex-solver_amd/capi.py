@@ -27,7 +27,19 @@ SYMBOLS = (
     "apexgpu_stage_times", "apexgpu_info", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_set_shard", "apexgpu_shard_range",
     "apexgpu_bal_open", "apexgpu_bal_close", "apexgpu_bal_last_error", "apexgpu_bal_sizes", "apexgpu_bal_raw",
     "apexgpu_bal_variables", "apexgpu_reference_columns",
+    # SE3 pose-graph backend
+    "apexgpu_pg_create", "apexgpu_pg_destroy", "apexgpu_pg_last_error", "apexgpu_pg_set_structure", "apexgpu_pg_set_params",
+    "apexgpu_pg_get_params", "apexgpu_pg_cost", "apexgpu_pg_solve_augmented", "apexgpu_pg_step_stats", "apexgpu_pg_eval_step",
+    "apexgpu_pg_commit_step", "apexgpu_pg_discard_step", "apexgpu_pg_parameter_norm", "apexgpu_pg_lm_optimize",
+    "apexgpu_pg_get_residual", "apexgpu_pg_get_jacobian_blocks", "apexgpu_pg_get_hessian", "apexgpu_pg_set_option",
+    "apexgpu_pg_enable_stage_timing", "apexgpu_pg_reset_stage_times", "apexgpu_pg_stage_times", "apexgpu_pg_info",
+    "apexgpu_g2o_open", "apexgpu_g2o_close", "apexgpu_g2o_last_error", "apexgpu_g2o_sizes", "apexgpu_g2o_raw",
+    "apexgpu_g2o_problem", "apexgpu_pose_graph_columns",
 )
+PG_NUM_STAGES = 6
+PG_STAGE_NAMES = ("assemble", "factor", "tri_solve", "step_stats", "retract", "cost")
+_NON_INT = ("apexgpu_destroy", "apexgpu_last_error", "apexgpu_version", "apexgpu_bal_close", "apexgpu_bal_last_error",
+            "apexgpu_pg_destroy", "apexgpu_pg_last_error", "apexgpu_g2o_close", "apexgpu_g2o_last_error")
 
 ERROR_NAMES = {
     -1: "FactorizationFailed", -2: "SingularMatrix", -3: "SparseMatrixCreation", -4: "MatrixConversion",
@@ -123,9 +135,41 @@ def load() -> C.CDLL:
     L.apexgpu_bal_raw.argtypes = [vp, vp, vp, vp, vp, vp]
     L.apexgpu_bal_variables.argtypes = [vp, vp, vp]
     L.apexgpu_reference_columns.argtypes = [i64, i64, vp, vp, vp]
+    L.apexgpu_pg_create.argtypes = [i64, i64, C.c_int, C.POINTER(vp)]
+    L.apexgpu_pg_destroy.argtypes = [vp]
+    L.apexgpu_pg_destroy.restype = None
+    L.apexgpu_pg_last_error.argtypes = [vp]
+    L.apexgpu_pg_last_error.restype = C.c_char_p
+    L.apexgpu_pg_set_structure.argtypes = [vp, vp, vp, vp, vp, vp, dbl]
+    L.apexgpu_pg_set_params.argtypes = [vp, vp]
+    L.apexgpu_pg_get_params.argtypes = [vp, vp]
+    L.apexgpu_pg_cost.argtypes = [vp, C.POINTER(dbl)]
+    L.apexgpu_pg_solve_augmented.argtypes = [vp, dbl, vp, vp]
+    L.apexgpu_pg_step_stats.argtypes = [vp, C.POINTER(dbl * 3)]
+    L.apexgpu_pg_eval_step.argtypes = [vp, C.POINTER(dbl)]
+    L.apexgpu_pg_commit_step.argtypes = [vp]
+    L.apexgpu_pg_discard_step.argtypes = [vp]
+    L.apexgpu_pg_parameter_norm.argtypes = [vp, C.POINTER(dbl)]
+    L.apexgpu_pg_lm_optimize.argtypes = [vp, C.POINTER(LmConfigC), C.POINTER(LmResultC), vp, C.c_int]
+    L.apexgpu_pg_get_residual.argtypes = [vp, vp]
+    L.apexgpu_pg_get_jacobian_blocks.argtypes = [vp, vp]
+    L.apexgpu_pg_get_hessian.argtypes = [vp, dbl, vp, vp]
+    L.apexgpu_pg_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.apexgpu_pg_enable_stage_timing.argtypes = [vp, C.c_int]
+    L.apexgpu_pg_reset_stage_times.argtypes = [vp]
+    L.apexgpu_pg_stage_times.argtypes = [vp, C.POINTER(dbl * PG_NUM_STAGES), C.POINTER(i64 * PG_NUM_STAGES)]
+    L.apexgpu_pg_info.argtypes = [vp, C.POINTER(dbl * 8)]
+    L.apexgpu_g2o_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.apexgpu_g2o_close.argtypes = [vp]
+    L.apexgpu_g2o_close.restype = None
+    L.apexgpu_g2o_last_error.restype = C.c_char_p
+    L.apexgpu_g2o_sizes.argtypes = [vp] + [C.POINTER(i64)] * 4
+    L.apexgpu_g2o_raw.argtypes = [vp] * 7
+    L.apexgpu_g2o_problem.argtypes = [vp] * 8
+    L.apexgpu_pose_graph_columns.argtypes = [i64, vp, vp]
     for name in SYMBOLS:
         f = getattr(L, name)
-        if name not in ("apexgpu_destroy", "apexgpu_last_error", "apexgpu_version", "apexgpu_bal_close", "apexgpu_bal_last_error"):
+        if name not in _NON_INT:
             f.restype = C.c_int
     _lib = L
     return L
@@ -167,6 +211,33 @@ class Handle:
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
             self.L.apexgpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PgHandle:
+    """RAII wrapper of an apexgpu_pg_solver*."""
+
+    def __init__(self, n_vertices: int, n_edges: int, device: int = 0):
+        self.L = load()
+        self.h = C.c_void_p()
+        rc = self.L.apexgpu_pg_create(n_vertices, n_edges, device, C.byref(self.h))
+        if rc != 0:
+            raise LinAlgError(rc, "apexgpu_pg_create failed (no MI355X visible to HIP?)")
+        self.n_vertices, self.n_edges = n_vertices, n_edges
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise LinAlgError(rc, self.L.apexgpu_pg_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.apexgpu_pg_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

@@ -72,6 +72,8 @@ void launch_cost(const BAView& v, double* partial, int n_partial, double* out_su
 void launch_step_stats(int64_t n, const double* g, const double* d, double lambda, double* partial, int n_partial,
                        double* out3, hipStream_t s);
 void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, double* out, hipStream_t s);
+// out[k] = sum_i partial[i*nk + k] in index order (one block: reproducible)
+void launch_sum_partials(const double* partial, int n, int nk, double* out, hipStream_t s);
 void launch_export_linearization(int dc, const BAView& v, const int* o_orig, double* r_out, double* jc_out,
                                  double* jl_out, hipStream_t s);
 

@@ -728,6 +728,10 @@ void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, do
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n_partial, 1, out);
 }
 
+void launch_sum_partials(const double* partial, int n, int nk, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n, nk, out);
+}
+
 void launch_export_linearization(int dc, const BAView& v, const int* o_orig, double* r_out, double* jc_out,
                                  double* jl_out, hipStream_t s) {
     if (v.n_obs == 0) return;

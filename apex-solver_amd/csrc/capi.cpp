@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 
+#include "pg_solver.h"
 #include "solver.h"
 #ifdef APEX_WITH_RCCL
 #include <rccl/rccl.h>
@@ -20,6 +21,11 @@ static_assert(sizeof(apexgpu_lm_config) == sizeof(apex::LmConfig), "LmConfig lay
 static_assert(sizeof(apexgpu_lm_iter) == sizeof(apex::LmIterRecord), "LmIterRecord layout");
 static_assert(sizeof(apexgpu_lm_result) == sizeof(apex::LmResult), "LmResult layout");
 static_assert(APEXGPU_NUM_STAGES == apex::kNumStages, "stage count");
+static_assert(APEXGPU_PG_NUM_STAGES == apex::kPgNumStages, "pose-graph stage count");
+
+struct apexgpu_pg_solver {
+    apex::PoseGraphSolver* s;
+};
 
 #define H_OR_FAIL            \
     if (!h || !h->s) return APEXGPU_ERR_INVALID_STATE
@@ -80,7 +86,7 @@ int apexgpu_solve_augmented(apexgpu_solver* h, double lambda, int variant, doubl
 }
 int apexgpu_assemble(apexgpu_solver* h, double lambda) { H_OR_FAIL; return h->s->assemble_only(lambda); }
 int apexgpu_step_stats(apexgpu_solver* h, double out3[3]) { H_OR_FAIL; return h->s->step_stats(out3); }
-int apexgpu_eval_step(apexgpu_solver* h, double* trial_cost) { H_OR_FAIL; return h->s->eval_step(1.0, trial_cost); }
+int apexgpu_eval_step(apexgpu_solver* h, double* trial_cost) { H_OR_FAIL; return h->s->eval_step(trial_cost); }
 int apexgpu_commit_step(apexgpu_solver* h) { H_OR_FAIL; return h->s->commit_step(); }
 int apexgpu_discard_step(apexgpu_solver* h) { H_OR_FAIL; return h->s->discard_step(); }
 int apexgpu_parameter_norm(apexgpu_solver* h, double* out) { H_OR_FAIL; return h->s->parameter_norm(out); }
@@ -159,5 +165,90 @@ int apexgpu_shard_range(int64_t n_pt, int64_t n_obs, const uint32_t* pt_idx, int
     return APEXGPU_OK;
 }
 int apexgpu_set_shard(apexgpu_solver* h, int rank, int world) { H_OR_FAIL; return h->s->set_shard(rank, world); }
+
+
+/* ---- SE3 pose-graph backend --------------------------------------------------------------------- */
+#define PG_OR_FAIL \
+    if (!h || !h->s) return APEXGPU_ERR_INVALID_STATE
+
+int apexgpu_pg_create(int64_t n_vertices, int64_t n_edges, int device, apexgpu_pg_solver** out) {
+    if (!out) return APEXGPU_ERR_INVALID_INPUT;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return APEXGPU_ERR_DEVICE;
+    apexgpu_pg_solver* h = new (std::nothrow) apexgpu_pg_solver();
+    if (!h) return APEXGPU_ERR_INVALID_STATE;
+    h->s = new (std::nothrow) apex::PoseGraphSolver(n_vertices, n_edges, device);
+    if (!h->s) { delete h; return APEXGPU_ERR_INVALID_STATE; }
+    *out = h;
+    return APEXGPU_OK;
+}
+void apexgpu_pg_destroy(apexgpu_pg_solver* h) {
+    if (!h) return;
+    delete h->s;
+    delete h;
+}
+const char* apexgpu_pg_last_error(const apexgpu_pg_solver* h) { return (h && h->s) ? h->s->last_error() : "invalid handle"; }
+int apexgpu_pg_set_structure(apexgpu_pg_solver* h, const uint32_t* e_from, const uint32_t* e_to, const double* meas7,
+                             const int64_t* pose_col, const uint8_t* fix6, double huber_delta) {
+    PG_OR_FAIL;
+    if (!e_from || !e_to || !meas7 || !pose_col) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->set_structure(e_from, e_to, meas7, pose_col, fix6, huber_delta);
+}
+int apexgpu_pg_set_params(apexgpu_pg_solver* h, const double* poses7) {
+    PG_OR_FAIL;
+    if (!poses7) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->set_params(poses7);
+}
+int apexgpu_pg_get_params(apexgpu_pg_solver* h, double* poses7) {
+    PG_OR_FAIL;
+    if (!poses7) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->get_params(poses7);
+}
+int apexgpu_pg_cost(apexgpu_pg_solver* h, double* cost) { PG_OR_FAIL; return h->s->cost(cost); }
+int apexgpu_pg_solve_augmented(apexgpu_pg_solver* h, double lambda, double* step_out, double* grad_out) {
+    PG_OR_FAIL;
+    return h->s->solve_augmented(lambda, 0, step_out, grad_out);
+}
+int apexgpu_pg_step_stats(apexgpu_pg_solver* h, double out3[3]) { PG_OR_FAIL; return h->s->step_stats(out3); }
+int apexgpu_pg_eval_step(apexgpu_pg_solver* h, double* trial_cost) { PG_OR_FAIL; return h->s->eval_step(trial_cost); }
+int apexgpu_pg_commit_step(apexgpu_pg_solver* h) { PG_OR_FAIL; return h->s->commit_step(); }
+int apexgpu_pg_discard_step(apexgpu_pg_solver* h) { PG_OR_FAIL; return h->s->discard_step(); }
+int apexgpu_pg_parameter_norm(apexgpu_pg_solver* h, double* out) { PG_OR_FAIL; return h->s->parameter_norm(out); }
+int apexgpu_pg_lm_optimize(apexgpu_pg_solver* h, apexgpu_lm_config* cfg, apexgpu_lm_result* result, apexgpu_lm_iter* history,
+                           int history_capacity) {
+    PG_OR_FAIL;
+    if (!cfg || !result) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->lm_optimize(reinterpret_cast<apex::LmConfig*>(cfg), reinterpret_cast<apex::LmResult*>(result),
+                             reinterpret_cast<apex::LmIterRecord*>(history), history ? history_capacity : 0);
+}
+int apexgpu_pg_get_residual(apexgpu_pg_solver* h, double* r_out) { PG_OR_FAIL; return h->s->get_residual(r_out); }
+int apexgpu_pg_get_jacobian_blocks(apexgpu_pg_solver* h, double* j_out) { PG_OR_FAIL; return h->s->get_jacobian_blocks(j_out); }
+int apexgpu_pg_get_hessian(apexgpu_pg_solver* h, double lambda, double* H_out, double* g_out) {
+    PG_OR_FAIL;
+    return h->s->get_hessian(lambda, H_out, g_out);
+}
+int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
+    PG_OR_FAIL;
+    const std::string n = name ? name : "";
+    if (n == "graphs") h->s->enable_graphs(value != 0);
+    else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);
+    else return APEXGPU_ERR_INVALID_INPUT;
+    return APEXGPU_OK;
+}
+int apexgpu_pg_enable_stage_timing(apexgpu_pg_solver* h, int on) { PG_OR_FAIL; h->s->enable_stage_timing(on != 0); return APEXGPU_OK; }
+int apexgpu_pg_reset_stage_times(apexgpu_pg_solver* h) { PG_OR_FAIL; h->s->reset_stage_times(); return APEXGPU_OK; }
+int apexgpu_pg_stage_times(apexgpu_pg_solver* h, double ms[APEXGPU_PG_NUM_STAGES], int64_t calls[APEXGPU_PG_NUM_STAGES]) {
+    PG_OR_FAIL;
+    h->s->stage_times(ms, calls);
+    return APEXGPU_OK;
+}
+int apexgpu_pg_info(apexgpu_pg_solver* h, double info[8]) {
+    PG_OR_FAIL;
+    info[0] = h->s->n_tile_rows(); info[1] = (double)h->s->tile_count(); info[2] = (double)h->s->touched_tiles();
+    info[3] = h->s->n_levels(); info[4] = 6.0 * (double)h->s->n_vertices();
+    for (int i = 5; i < 8; ++i) info[i] = 0;
+    return APEXGPU_OK;
+}
 
 }  // extern "C"

@@ -1,0 +1,90 @@
+// pg_solver.h -- host side of the MI355X SE3 pose-graph backend (BASELINE.json configs[1]).
+//
+// Mirrors SparseCholeskySolver (src/linalg/sparse/cholesky.rs:159-230) driven by the LM loop
+// (src/optimizer/levenberg_marquardt.rs:823-1031) on a problem of BetweenFactor<SE3> blocks
+// (src/factors/between_factor.rs:268-322) as bin/pose_graph_g2o.rs:748-830 builds it:
+// H = J^T J is assembled block-sparse (6x6 blocks) straight from the edges into 144x144 tiles,
+// H + lambda I is factorised by the level-scheduled tile Cholesky of TilePlan -- no Schur complement.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "lm_loop.h"
+#include "pg_kernels.h"
+#include "stage_timer.h"
+#include "tile_plan.h"
+
+namespace apex {
+
+enum PgStage { kPgAssemble = 0, kPgFactor, kPgTriSolve, kPgStats, kPgRetract, kPgCost, kPgNumStages };
+
+class PoseGraphSolver : public LmBackend {
+   public:
+    PoseGraphSolver(int64_t n_v, int64_t n_e, int device);
+    ~PoseGraphSolver() override;
+
+    int set_structure(const uint32_t* e_from, const uint32_t* e_to, const double* meas7, const int64_t* pose_col,
+                      const uint8_t* fix6, double huber_delta);
+    int set_params(const double* poses7);
+    int get_params(double* poses7);
+
+    int cost(double* out) override;
+    int solve_augmented(double lambda, int variant, double* step_out, double* grad_out) override;
+    int step_stats(double out3[3]) override;
+    int eval_step(double* trial_cost) override;
+    int commit_step() override;
+    int discard_step() override;
+    int parameter_norm(double* out) override;
+    int lm_optimize(LmConfig* cfg, LmResult* res, LmIterRecord* hist, int hist_cap);
+
+    // parity / debug exports (caller's edge and column order)
+    int get_residual(double* r_out);
+    int get_jacobian_blocks(double* j_out);
+    int get_hessian(double lambda, double* H_out, double* g_out);  // dense J^T J + lambda I, J^T r
+
+    void enable_graphs(bool on) { tp_.enable_graphs(on); }
+    void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
+    void enable_stage_timing(bool on) { timer_.enable(on); }
+    void reset_stage_times() { timer_.reset(); }
+    int stage_times(double* ms, int64_t* n) { return timer_.times(ms, n); }
+    int64_t n_vertices() const { return n_v_; }
+    int n_tile_rows() const { return tp_.nt(); }
+    int64_t tile_count() const { return tp_.n_slots(); }
+    int64_t touched_tiles() const { return tp_.n_touched_slots(); }
+    int n_levels() const { return tp_.n_levels(); }
+    const char* last_error() const override { return err_.c_str(); }
+
+   private:
+    int fail(int code, const std::string& msg) { err_ = msg; return code; }
+    int check_hip(hipError_t e, const char* what);
+    PGView view(int which) const;
+    int assemble(double lambda);
+    int cost_of(int which, double* out);
+
+    int64_t n_v_, n_e_;
+    int device_;
+    int64_t n_ = 0, n_pad_ = 0;
+    double huber_delta_ = 0.0;
+    bool have_structure_ = false, have_params_ = false, have_step_ = false, have_trial_ = false;
+    int cur_ = 0;
+    double last_lambda_ = 0.0;
+    bool use_nd_ = true;
+    int nd_leaf_ = 2;
+    std::vector<int64_t> pose_col_;
+    std::vector<int> vmap_;  // caller's vertex -> internal vertex
+    hipStream_t stream_ = nullptr;
+    TilePlan tp_;
+    double *poses_[2] = {nullptr, nullptr}, *posep_[2] = {nullptr, nullptr};
+    uint32_t *e_from_ = nullptr, *e_to_ = nullptr;
+    double* meas_ = nullptr;
+    uint8_t* fix_ = nullptr;
+    double *g_ = nullptr, *rhs_ = nullptr, *d_ = nullptr, *work_ = nullptr, *partial_ = nullptr, *scal_ = nullptr;
+    int n_partial_ = 256;
+    StageTimer<kPgNumStages> timer_;
+    std::string err_;
+};
+
+}  // namespace apex

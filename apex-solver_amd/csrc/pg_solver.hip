@@ -1,0 +1,341 @@
+// pg_solver.hip -- see pg_solver.h
+#include "pg_solver.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+
+#include "pg_device.hpp"
+
+namespace apex {
+
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) return check_hip(_e, #expr); \
+    } while (0)
+
+template <typename T>
+static hipError_t dev_alloc(T** p, size_t n) {
+    return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
+}
+template <typename T>
+static hipError_t upload(T** dptr, const std::vector<T>& hv) {
+    if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
+    hipError_t e = dev_alloc(dptr, hv.size());
+    if (e != hipSuccess || hv.empty()) return e;
+    return hipMemcpy(*dptr, hv.data(), hv.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+static hipError_t alloc_zero(double** p, size_t n) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    hipError_t e = dev_alloc(p, n);
+    if (e != hipSuccess) return e;
+    return hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(double));
+}
+
+PoseGraphSolver::PoseGraphSolver(int64_t n_v, int64_t n_e, int device) : n_v_(n_v), n_e_(n_e), device_(device) {}
+
+PoseGraphSolver::~PoseGraphSolver() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    void* ptrs[] = {poses_[0], poses_[1], posep_[0], posep_[1], e_from_, e_to_, meas_, fix_, g_, rhs_, d_, work_, partial_, scal_};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+int PoseGraphSolver::check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return kOk;
+    return fail(kDeviceError, std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+
+PGView PoseGraphSolver::view(int which) const {
+    PGView v;
+    v.n_v = n_v_; v.n_e = n_e_;
+    v.posep = posep_[which]; v.e_from = e_from_; v.e_to = e_to_; v.meas = meas_;
+    v.huber_delta = huber_delta_;
+    return v;
+}
+
+int PoseGraphSolver::set_structure(const uint32_t* e_from, const uint32_t* e_to, const double* meas7,
+                                   const int64_t* pose_col, const uint8_t* fix6, double huber_delta) {
+    if (n_v_ <= 0) return fail(kInvalidInput, "No pose variables found");
+    if (n_e_ < 0 || n_e_ > 2000000000LL) return fail(kInvalidInput, "edge count out of range");
+    for (int64_t e = 0; e < n_e_; ++e)
+        if (e_from[e] >= (uint64_t)n_v_ || e_to[e] >= (uint64_t)n_v_)
+            return fail(kInvalidInput, "edge " + std::to_string(e) + " references a missing variable");
+    HIP_TRY(hipSetDevice(device_));
+    if (!stream_) HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    huber_delta_ = huber_delta;
+    pose_col_.assign(pose_col, pose_col + n_v_);
+    n_ = 6 * n_v_;
+    const int nt = (int)((n_ + kNB - 1) / kNB);
+    n_pad_ = (int64_t)nt * kNB;
+
+    // ---- internal vertex order: whole tiles of 24 consecutive vertices, permuted by a nested-dissection
+    // ordering of the tile graph (see TilePlan::order) -----------------------------------------------
+    std::vector<uint8_t> adjm((size_t)nt * nt, 0);
+    for (int64_t e = 0; e < n_e_; ++e) {
+        const int a = (int)(e_from[e] / kVertsPerTile), b = (int)(e_to[e] / kVertsPerTile);
+        if (a != b) { adjm[(size_t)a * nt + b] = 1; adjm[(size_t)b * nt + a] = 1; }
+    }
+    const std::vector<int> tperm = TilePlan::order(nt, adjm, use_nd_, nd_leaf_);
+    vmap_.resize(n_v_);
+    for (int64_t v = 0; v < n_v_; ++v) vmap_[v] = (int)((int64_t)tperm[v / kVertsPerTile] * kVertsPerTile + v % kVertsPerTile);
+    std::vector<uint8_t> present((size_t)nt * nt, 0);
+    for (int I = 0; I < nt; ++I) present[(size_t)I * nt + I] = 1;
+    std::vector<uint32_t> ef(n_e_), et(n_e_);
+    for (int64_t e = 0; e < n_e_; ++e) {
+        ef[e] = (uint32_t)vmap_[e_from[e]]; et[e] = (uint32_t)vmap_[e_to[e]];
+        int a = (int)(ef[e] / kVertsPerTile), b = (int)(et[e] / kVertsPerTile);
+        if (a < b) std::swap(a, b);
+        present[(size_t)a * nt + b] = 1;
+    }
+    {
+        const std::string err = tp_.build(nt, present, stream_);
+        if (!err.empty()) return fail(kInvalidInput, "Hessian tiles: " + err);
+    }
+    // measurements are constants: normalise once (SE3::from_translation_quaternion, se3.rs:107-113)
+    std::vector<double> mp((size_t)n_e_ * kPoseStride, 0.0);
+    for (int64_t e = 0; e < n_e_; ++e) pose_normalise(meas7 + 7 * e, mp.data() + kPoseStride * e);
+    std::vector<uint8_t> fx((size_t)6 * n_v_, 0);
+    if (fix6)
+        for (int64_t v = 0; v < n_v_; ++v) memcpy(fx.data() + 6 * (size_t)vmap_[v], fix6 + 6 * v, 6);
+    HIP_TRY(upload(&e_from_, ef));
+    HIP_TRY(upload(&e_to_, et));
+    HIP_TRY(upload(&meas_, mp));
+    HIP_TRY(upload(&fix_, fx));
+    for (int w = 0; w < 2; ++w) {
+        HIP_TRY(alloc_zero(&poses_[w], 7 * (size_t)n_v_));
+        HIP_TRY(alloc_zero(&posep_[w], kPoseStride * (size_t)n_v_));
+    }
+    HIP_TRY(alloc_zero(&g_, n_pad_));
+    HIP_TRY(alloc_zero(&rhs_, n_pad_));
+    HIP_TRY(alloc_zero(&d_, n_pad_));
+    HIP_TRY(alloc_zero(&work_, 6 * (size_t)n_pad_));
+    HIP_TRY(alloc_zero(&partial_, 3 * (size_t)n_partial_));
+    HIP_TRY(alloc_zero(&scal_, 16));
+    HIP_TRY(hipDeviceSynchronize());
+    have_structure_ = true;
+    have_params_ = have_step_ = have_trial_ = false;
+    cur_ = 0;
+    return kOk;
+}
+
+int PoseGraphSolver::set_params(const double* poses7) {
+    if (!have_structure_) return fail(kInvalidState, "Block structure not built. Call set_structure() first.");
+    HIP_TRY(hipSetDevice(device_));
+    std::vector<double> hp(7 * (size_t)n_v_);
+    for (int64_t v = 0; v < n_v_; ++v) memcpy(hp.data() + 7 * (size_t)vmap_[v], poses7 + 7 * v, 7 * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(poses_[cur_], hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+    launch_pg_prepare(n_v_, poses_[cur_], posep_[cur_], stream_);
+    HIP_TRY(hipStreamSynchronize(stream_));
+    have_params_ = true; have_step_ = have_trial_ = false;
+    return kOk;
+}
+
+int PoseGraphSolver::get_params(double* poses7) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    std::vector<double> hp(7 * (size_t)n_v_);
+    HIP_TRY(hipMemcpyAsync(hp.data(), poses_[cur_], hp.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (int64_t v = 0; v < n_v_; ++v) memcpy(poses7 + 7 * v, hp.data() + 7 * (size_t)vmap_[v], 7 * sizeof(double));
+    return kOk;
+}
+
+int PoseGraphSolver::cost_of(int which, double* out) {
+    timer_.begin(kPgCost, stream_);
+    launch_pg_cost(view(which), partial_, n_partial_, scal_, stream_);
+    timer_.end(kPgCost, stream_);
+    double ss = 0.0;
+    HIP_TRY(hipMemcpyAsync(&ss, scal_, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    const double nrm = sqrt(ss);  // compute_cost: 0.5 * norm_l2()^2 (optimizer/mod.rs:358-361)
+    *out = 0.5 * nrm * nrm;
+    return kOk;
+}
+
+int PoseGraphSolver::cost(double* out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    return cost_of(cur_, out);
+}
+
+// H + lambda I (tiles) and g = J^T r at the current parameters
+int PoseGraphSolver::assemble(double lambda) {
+    timer_.begin(kPgAssemble, stream_);
+    HIP_TRY(tp_.zero_tiles());
+    HIP_TRY(hipMemsetAsync(g_, 0, n_pad_ * sizeof(double), stream_));
+    tp_.add_diag((int)n_, lambda, 1.0);  // lambda on the real rows, identity on the padding rows
+    launch_pg_edges(view(cur_), tp_.tilemap(), g_, stream_);
+    timer_.end(kPgAssemble, stream_);
+    return kOk;
+}
+
+// SparseCholeskySolver::solve_augmented_equation (cholesky.rs:159-230): (J^T J + lambda I) dx = -J^T r
+int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_out, double* grad_out) {
+    if (!have_params_) return fail(kInvalidState, "Block structure not built or parameters not set");
+    if (variant != 0) return fail(kInvalidInput, "the pose-graph backend has the sparse Cholesky solver only");
+    HIP_TRY(hipSetDevice(device_));
+    have_step_ = false;
+    last_lambda_ = lambda;
+    int rc = assemble(lambda);
+    if (rc != kOk) return rc;
+    launch_pg_negate(n_pad_, g_, rhs_, stream_);
+    timer_.begin(kPgFactor, stream_);
+    int failed = 0;
+    HIP_TRY(tp_.factor(&failed));
+    timer_.end(kPgFactor, stream_);
+    if (failed) return fail(kSingularMatrix, "Cholesky factorization failed (matrix may be singular)");
+    timer_.begin(kPgTriSolve, stream_);
+    tp_.solve(rhs_, d_, work_);
+    timer_.end(kPgTriSolve, stream_);
+    have_step_ = true;
+    if (step_out || grad_out) {
+        std::vector<double> h(n_);
+        for (int pass = 0; pass < 2; ++pass) {
+            double* out = pass == 0 ? step_out : grad_out;
+            if (!out) continue;
+            HIP_TRY(hipMemcpyAsync(h.data(), pass == 0 ? d_ : g_, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            for (int64_t v = 0; v < n_v_; ++v)
+                for (int a = 0; a < 6; ++a) out[pose_col_[v] + a] = h[6 * (size_t)vmap_[v] + a];
+        }
+    } else {
+        HIP_TRY(hipStreamSynchronize(stream_));
+    }
+    return kOk;
+}
+
+int PoseGraphSolver::step_stats(double out3[3]) {
+    if (!have_step_) return fail(kInvalidState, "no step computed");
+    HIP_TRY(hipSetDevice(device_));
+    timer_.begin(kPgStats, stream_);
+    launch_step_stats(n_, g_, d_, last_lambda_, partial_, n_partial_, scal_ + 1, stream_);
+    timer_.end(kPgStats, stream_);
+    double h[3];
+    HIP_TRY(hipMemcpyAsync(h, scal_ + 1, sizeof h, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    out3[0] = sqrt(h[0]);   // gradient.norm_l2()          (levenberg_marquardt.rs:746)
+    out3[1] = sqrt(h[1]);   // step.norm_l2()              (:890)
+    out3[2] = 0.5 * h[2];   // compute_predicted_reduction (:721-727)
+    return kOk;
+}
+
+int PoseGraphSolver::eval_step(double* trial_cost) {
+    if (!have_step_) return fail(kInvalidState, "no step computed");
+    HIP_TRY(hipSetDevice(device_));
+    const int t = cur_ ^ 1;
+    timer_.begin(kPgRetract, stream_);
+    launch_pg_retract(n_v_, poses_[cur_], d_, 1.0, fix_, poses_[t], stream_);
+    launch_pg_prepare(n_v_, poses_[t], posep_[t], stream_);
+    timer_.end(kPgRetract, stream_);
+    have_trial_ = true;
+    return cost_of(t, trial_cost);
+}
+
+int PoseGraphSolver::commit_step() {
+    if (!have_trial_) return fail(kInvalidState, "no trial point");
+    cur_ ^= 1;
+    have_trial_ = false; have_step_ = false;
+    return kOk;
+}
+
+// apply_negative_parameter_step (optimizer/mod.rs:343-356): inverse retraction of the trial point
+int PoseGraphSolver::discard_step() {
+    if (!have_trial_) return fail(kInvalidState, "no trial point");
+    HIP_TRY(hipSetDevice(device_));
+    const int t = cur_ ^ 1;
+    timer_.begin(kPgRetract, stream_);
+    launch_pg_retract(n_v_, poses_[t], d_, -1.0, fix_, poses_[cur_], stream_);
+    launch_pg_prepare(n_v_, poses_[cur_], posep_[cur_], stream_);
+    timer_.end(kPgRetract, stream_);
+    HIP_TRY(hipStreamSynchronize(stream_));
+    have_trial_ = false; have_step_ = false;
+    return kOk;
+}
+
+int PoseGraphSolver::parameter_norm(double* out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    launch_sumsq(7 * n_v_, poses_[cur_], partial_, n_partial_, scal_ + 4, stream_);
+    double h = 0.0;
+    HIP_TRY(hipMemcpyAsync(&h, scal_ + 4, sizeof h, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    *out = sqrt(h);
+    return kOk;
+}
+
+int PoseGraphSolver::lm_optimize(LmConfig* cfg, LmResult* res, LmIterRecord* hist, int hist_cap) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    return run_lm(*this, cfg, res, hist, hist_cap);
+}
+
+// ---- parity / debug exports ------------------------------------------------------------------
+int PoseGraphSolver::get_residual(double* r_out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    double* d = nullptr;
+    HIP_TRY(dev_alloc(&d, 6 * (size_t)n_e_));
+    launch_pg_export(view(cur_), d, nullptr, stream_);
+    hipError_t e = hipMemcpyAsync(r_out, d, 6 * n_e_ * sizeof(double), hipMemcpyDeviceToHost, stream_);
+    (void)hipStreamSynchronize(stream_);
+    (void)hipFree(d);
+    return check_hip(e, "get_residual");
+}
+
+int PoseGraphSolver::get_jacobian_blocks(double* j_out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    double* d = nullptr;
+    HIP_TRY(dev_alloc(&d, 72 * (size_t)n_e_));
+    launch_pg_export(view(cur_), nullptr, d, stream_);
+    hipError_t e = hipMemcpyAsync(j_out, d, 72 * n_e_ * sizeof(double), hipMemcpyDeviceToHost, stream_);
+    (void)hipStreamSynchronize(stream_);
+    (void)hipFree(d);
+    return check_hip(e, "get_jacobian_blocks");
+}
+
+int PoseGraphSolver::get_hessian(double lambda, double* H_out, double* g_out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    int rc = assemble(lambda);
+    if (rc != kOk) return rc;
+    have_step_ = false;
+    const size_t tile_elems = (size_t)kNB * kNB;
+    std::vector<int64_t> col(n_, -1);
+    for (int64_t v = 0; v < n_v_; ++v)
+        for (int a = 0; a < 6; ++a) col[6 * (size_t)vmap_[v] + a] = pose_col_[v] + a;
+    if (g_out) {
+        std::vector<double> h(n_);
+        HIP_TRY(hipMemcpyAsync(h.data(), g_, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        for (int64_t i = 0; i < n_; ++i) g_out[col[i]] = h[i];
+    }
+    if (H_out) {
+        memset(H_out, 0, (size_t)n_ * (size_t)n_ * sizeof(double));
+        std::vector<double> t(tile_elems);
+        const int nt = tp_.nt();
+        for (int I = 0; I < nt; ++I)
+            for (int J = 0; J <= I; ++J) {
+                const int s = tp_.slot(I, J);
+                if (s < 0 || s >= tp_.n_touched_slots()) continue;
+                HIP_TRY(hipMemcpyAsync(t.data(), tp_.tiles() + (size_t)s * tile_elems, tile_elems * sizeof(double), hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(hipStreamSynchronize(stream_));
+                for (int r = 0; r < kNB; ++r)
+                    for (int c = 0; c < kNB; ++c) {
+                        const int64_t gi = (int64_t)I * kNB + r, gj = (int64_t)J * kNB + c;
+                        if (gi >= n_ || gj >= n_ || gj > gi) continue;
+                        const double val = t[(size_t)r * kNB + c];
+                        H_out[col[gi] * n_ + col[gj]] = val;
+                        H_out[col[gj] * n_ + col[gi]] = val;
+                    }
+            }
+    }
+    return kOk;
+}
+
+}  // namespace apex

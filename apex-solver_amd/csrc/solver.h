@@ -13,66 +13,20 @@
 
 #include "ba_kernels.h"
 #include "chol_kernels.h"
+#include "lm_loop.h"
+#include "stage_timer.h"
 #include "tile_plan.h"
 
 struct ncclComm;  // RCCL communicator (optional)
 
 namespace apex {
 
-// status codes: 0 ok; negative values mirror LinAlgError (src/linalg/mod.rs:76-101)
-enum Status : int {
-    kOk = 0,
-    kFactorizationFailed = -1,
-    kSingularMatrix = -2,
-    kSparseMatrixCreation = -3,
-    kMatrixConversion = -4,
-    kInvalidInput = -5,
-    kInvalidState = -6,
-    kDeviceError = -10,
-};
-
-// OptimizationStatus discriminants (src/optimizer/mod.rs:189-216) + one for a failed linear solve
-enum LmStatus : int {
-    kConverged = 0, kMaxIterationsReached = 1, kCostToleranceReached = 2, kParameterToleranceReached = 3,
-    kGradientToleranceReached = 4, kNumericalFailure = 5, kTimeout = 7, kTrustRegionRadiusTooSmall = 8,
-    kMinCostThresholdReached = 9, kInvalidNumericalValues = 11, kLinearSolveFailed = 100,
-};
-
-struct LmConfig {               // LevenbergMarquardtConfig (levenberg_marquardt.rs:213-358)
-    int max_iterations;         // 50 (20 in for_bundle_adjustment)
-    double cost_tolerance;      // 1e-6
-    double parameter_tolerance; // 1e-8
-    double gradient_tolerance;  // 1e-10
-    double damping;             // 1e-3
-    double damping_min;         // 1e-12
-    double damping_max;         // 1e12
-    double damping_nu;          // 2.0
-    double trust_region_radius;     // 1e4
-    double min_trust_region_radius; // 1e-32
-    double min_cost_threshold;      // < 0: None
-    double timeout_s;               // <= 0: None
-    int variant;                    // 0 Sparse (Cholesky), 1 Iterative (Jacobi-PCG on explicit S)
-};
-
-struct LmIterRecord {  // one row of the per-iteration history
-    double cost, damping, rho, accepted, gradient_norm, step_norm, predicted_reduction, trial_cost;
-};
-
-struct LmResult {
-    int status;
-    int iterations;
-    double initial_cost, final_cost;
-    double final_gradient_norm, final_step_norm;
-    double elapsed_s;
-    int cost_evaluations, jacobian_evaluations, successful_steps, unsuccessful_steps;
-};
-
 enum Stage { kStAssembleCam = 0, kStAssembleLm, kStScatter, kStAllReduce, kStFactor, kStTriSolve, kStBackSub, kStStats,
              kStRetract, kStCost, kNumStages };
 
 void shard_range(int64_t n_pt, const int64_t* ptr, int rank, int world, int64_t* lo, int64_t* hi);
 
-class Solver {
+class Solver : public LmBackend {
    public:
     Solver(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device);
     ~Solver();
@@ -85,14 +39,14 @@ class Solver {
     void set_cg_params(int max_iter, double tol) { cg_max_iter_ = max_iter; cg_tol_ = tol; }
 
     // hot path
-    int cost(double* out);                                  // A16 on the current parameters
-    int solve_augmented(double lambda, int variant, double* step_out, double* grad_out);
+    int cost(double* out) override;                         // A16 on the current parameters
+    int solve_augmented(double lambda, int variant, double* step_out, double* grad_out) override;
     int assemble_only(double lambda);
-    int step_stats(double out3[3]);                         // |g|, |step|, predicted reduction
-    int eval_step(double sign_unused, double* trial_cost);  // x (+) step into the trial set, A16 there
-    int commit_step();
-    int discard_step();                                     // reference semantics: trial (+) (-step)
-    int parameter_norm(double* out);
+    int step_stats(double out3[3]) override;                // |g|, |step|, predicted reduction
+    int eval_step(double* trial_cost) override;             // x (+) step into the trial set, A16 there
+    int commit_step() override;
+    int discard_step() override;                            // reference semantics: trial (+) (-step)
+    int parameter_norm(double* out) override;
     int lm_optimize(LmConfig* cfg, LmResult* res, LmIterRecord* hist, int hist_cap);
 
     // parity / debug exports
@@ -107,7 +61,7 @@ class Solver {
     int last_pcg_iters() const { return last_pcg_iters_; }
     int stage_times(double* ms, int64_t* launches);  // averaged HIP-event time per stage since reset
     void reset_stage_times();
-    void enable_stage_timing(bool on) { timing_ = on; }
+    void enable_stage_timing(bool on) { timer_.enable(on); }
     void enable_graphs(bool on) { use_graphs_ = on; tp_.enable_graphs(on); }
     void use_row_schur(bool on) { use_rows_ = on; }
     void set_rows_debug(int v) { rows_dbg_ = v; }
@@ -121,7 +75,7 @@ class Solver {
     int comm_init(int world, int rank, const void* unique_id128);
     int set_shard(int rank, int world);  // without RCCL: assemble only this rank's landmark range
 
-    const char* last_error() const { return err_.c_str(); }
+    const char* last_error() const override { return err_.c_str(); }
     int dc() const { return dc_; }
     int64_t cam_dof_internal() const { return n_c_; }
 
@@ -190,14 +144,7 @@ class Solver {
 
     bool use_graphs_ = true;
 
-    // timing
-    bool timing_ = false;
-    std::vector<hipEvent_t> ev_pool_;
-    std::pair<hipEvent_t, hipEvent_t> ev_open_[kNumStages] = {};
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending_;
-    void resolve_stage_events();
-    double stage_ms_[kNumStages] = {0};
-    int64_t stage_n_[kNumStages] = {0};
+    StageTimer<kNumStages> timer_;
 
     std::string err_;
 };

@@ -39,8 +39,6 @@ Solver::~Solver() {
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_};
     for (void* p : ptrs)
         if (p) hipFree(p);
-    resolve_stage_events();
-    for (hipEvent_t e : ev_pool_) hipEventDestroy(e);
 #ifdef APEX_WITH_RCCL
     if (comm_) ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm_));
 #endif
@@ -68,44 +66,10 @@ BAView Solver::view(int which) const {
 
 TileMap Solver::tilemap() const { return tp_.tilemap(); }
 
-// Stage timing records HIP events on the solver's own stream WITHOUT synchronising; the pairs are
-// resolved when stage_times() is called, so a timed region is not perturbed by the measurement.
-void Solver::stage_begin(int st) {
-    if (!timing_) return;
-    hipEvent_t a = nullptr, b = nullptr;
-    if (!ev_pool_.empty()) { a = ev_pool_.back(); ev_pool_.pop_back(); } else hipEventCreate(&a);
-    if (!ev_pool_.empty()) { b = ev_pool_.back(); ev_pool_.pop_back(); } else hipEventCreate(&b);
-    hipEventRecord(a, stream_);
-    ev_open_[st] = {a, b};
-}
-void Solver::stage_end(int st) {
-    if (!timing_ || !ev_open_[st].first) return;
-    hipEventRecord(ev_open_[st].second, stream_);
-    ev_pending_.push_back({st, ev_open_[st]});
-    ev_open_[st] = {nullptr, nullptr};
-}
-void Solver::resolve_stage_events() {
-    for (auto& p : ev_pending_) {
-        hipEventSynchronize(p.second.second);
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
-            stage_ms_[p.first] += ms;
-            stage_n_[p.first] += 1;
-        }
-        ev_pool_.push_back(p.second.first);
-        ev_pool_.push_back(p.second.second);
-    }
-    ev_pending_.clear();
-}
-void Solver::reset_stage_times() {
-    resolve_stage_events();
-    for (int i = 0; i < kNumStages; ++i) { stage_ms_[i] = 0; stage_n_[i] = 0; }
-}
-int Solver::stage_times(double* ms, int64_t* launches) {
-    resolve_stage_events();
-    for (int i = 0; i < kNumStages; ++i) { ms[i] = stage_ms_[i]; launches[i] = stage_n_[i]; }
-    return kNumStages;
-}
+void Solver::stage_begin(int st) { timer_.begin(st, stream_); }
+void Solver::stage_end(int st) { timer_.end(st, stream_); }
+void Solver::reset_stage_times() { timer_.reset(); }
+int Solver::stage_times(double* ms, int64_t* launches) { return timer_.times(ms, launches); }
 
 int Solver::set_shard(int rank, int world) {
     if (have_structure_) return fail(kInvalidState, "set_shard must precede set_structure");
@@ -688,7 +652,7 @@ int Solver::step_stats(double out3[3]) {
     return kOk;
 }
 
-int Solver::eval_step(double, double* trial_cost) {
+int Solver::eval_step(double* trial_cost) {
     if (!have_step_) return fail(kInvalidState, "no step computed");
     HIP_TRY(hipSetDevice(device_));
     const int t = cur_ ^ 1;
@@ -747,89 +711,7 @@ int Solver::parameter_norm(double* out) {
 // ---------------------------------------------------------------------------------------------
 int Solver::lm_optimize(LmConfig* cfg, LmResult* res, LmIterRecord* hist, int hist_cap) {
     if (!have_params_) return fail(kInvalidState, "no parameters set");
-    const auto t0 = std::chrono::steady_clock::now();
-    double lambda = cfg->damping, nu = cfg->damping_nu;
-    double cur_cost = 0.0;
-    int rc = cost(&cur_cost);  // initialize_optimization_state (optimizer/mod.rs:550-552)
-    if (rc != kOk) return rc;
-    memset(res, 0, sizeof *res);
-    res->initial_cost = cur_cost;
-    res->cost_evaluations = 1;
-    int iteration = 0, status = kMaxIterationsReached;
-    for (;;) {
-        rc = solve_augmented(lambda, cfg->variant, nullptr, nullptr);  // assemble + compute_step (:861-883)
-        res->jacobian_evaluations++;
-        if (rc != kOk) { status = kLinearSolveFailed; break; }
-        double st[3];
-        rc = step_stats(st);
-        if (rc != kOk) return rc;
-        const double gn = st[0], sn = st[1], pred = st[2];
-        double new_cost = 0.0;
-        rc = eval_step(1.0, &new_cost);  // evaluate_and_apply_step (:770-817)
-        if (rc != kOk) return rc;
-        res->cost_evaluations++;
-        const double actual = cur_cost - new_cost;  // compute_step_quality (optimizer/mod.rs:668-675)
-        const double rho = (fabs(pred) < 1e-15) ? (actual > 0.0 ? 1.0 : 0.0) : actual / pred;
-        int accepted;
-        double cost_reduction = 0.0;
-        if (rho > 0.0) {  // update_damping (:702-717)
-            const double coff = 2.0 * rho - 1.0;
-            lambda *= std::max(1.0 / 3.0, 1.0 - coff * coff * coff);
-            lambda = std::max(lambda, cfg->damping_min);
-            nu = 2.0;
-            accepted = 1;
-            cost_reduction = cur_cost - new_cost;
-            cur_cost = new_cost;
-            rc = commit_step();
-            res->successful_steps++;
-        } else {
-            lambda *= nu;
-            nu *= 2.0;
-            lambda = std::min(lambda, cfg->damping_max);
-            accepted = 0;
-            rc = discard_step();
-            res->unsuccessful_steps++;
-        }
-        if (rc != kOk) return rc;
-        if (hist && iteration < hist_cap) {
-            LmIterRecord& h = hist[iteration];
-            h.cost = cur_cost; h.damping = lambda; h.rho = rho; h.accepted = accepted; h.gradient_norm = gn;
-            h.step_norm = sn; h.predicted_reduction = pred; h.trial_cost = new_cost;
-        }
-        res->final_gradient_norm = gn;
-        res->final_step_norm = sn;
-        // check_convergence (optimizer/mod.rs:591-658)
-        double pnorm = 0.0;
-        rc = parameter_norm(&pnorm);
-        if (rc != kOk) return rc;
-        const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        const double cost_before = accepted ? cur_cost + cost_reduction : cur_cost;
-        int stt = -1;
-        if (!std::isfinite(cur_cost) || !std::isfinite(sn) || !std::isfinite(gn)) stt = kInvalidNumericalValues;
-        else if (cfg->timeout_s > 0.0 && elapsed >= cfg->timeout_s) stt = kTimeout;
-        else if (iteration >= cfg->max_iterations) stt = kMaxIterationsReached;
-        else if (accepted) {
-            if (gn < cfg->gradient_tolerance) stt = kGradientToleranceReached;
-            if (stt < 0 && iteration > 0) {
-                const double rel_step_tol = cfg->parameter_tolerance * (pnorm + cfg->parameter_tolerance);
-                if (sn <= rel_step_tol) stt = kParameterToleranceReached;
-                else {
-                    const double cc = fabs(cost_before - cur_cost);
-                    if (cc / std::max(cost_before, 1e-10) < cfg->cost_tolerance) stt = kCostToleranceReached;
-                }
-            }
-            if (stt < 0 && cfg->min_cost_threshold >= 0.0 && cur_cost < cfg->min_cost_threshold) stt = kMinCostThresholdReached;
-            if (stt < 0 && cfg->trust_region_radius < cfg->min_trust_region_radius) stt = kTrustRegionRadiusTooSmall;
-        }
-        if (stt >= 0) { status = stt; ++iteration; break; }
-        ++iteration;
-    }
-    cfg->damping = lambda; cfg->damping_nu = nu;
-    res->status = status;
-    res->iterations = iteration;
-    res->final_cost = cur_cost;
-    res->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    return kOk;
+    return run_lm(*this, cfg, res, hist, hist_cap);
 }
 
 // ---------------------------------------------------------------------------------------------

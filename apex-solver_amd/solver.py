@@ -39,6 +39,7 @@ class LinearSolverType(enum.Enum):
     DenseCholesky = "DenseCholesky"
     DenseQR = "DenseQR"
     GpuSchurComplement = "GpuSchurComplement"
+    GpuSparseCholesky = "GpuSparseCholesky"
 
 
 class SchurVariant(enum.Enum):
@@ -395,6 +396,24 @@ class LevenbergMarquardt:
         """LevenbergMarquardt::optimize (:1034-1083): the GpuSchurComplement arm builds the solver,
         initialises its structure, uploads the initial values and runs the loop on the device."""
         t = self.config.linear_solver_type
+        from .pose_graph import GpuSparseCholeskySolver, PoseGraphProblem
+        if isinstance(problem, PoseGraphProblem):
+            # the SparseCholesky arm (levenberg_marquardt.rs:1055-1062) on the device
+            if t not in (LinearSolverType.GpuSparseCholesky, LinearSolverType.SparseCholesky):
+                raise NotImplementedError(f"{t}: a pose graph has no landmarks to eliminate; use SparseCholesky")
+            s = solver or GpuSparseCholeskySolver(self.device)
+            if s._h is None:
+                s.initialize_structure(problem)
+            s.set_parameters(problem.data.poses if initial_values is None else initial_values)
+            self.linear_solver = s
+            res, hist, c = s.lm_optimize(self.config)
+            return SolverResult(
+                status=OptimizationStatus(res.status), iterations=res.iterations, initial_cost=res.initial_cost,
+                final_cost=res.final_cost, parameters=(s.get_parameters(),), elapsed_time=res.elapsed_s,
+                final_gradient_norm=res.final_gradient_norm, final_parameter_update_norm=res.final_step_norm,
+                cost_evaluations=res.cost_evaluations, jacobian_evaluations=res.jacobian_evaluations,
+                successful_steps=res.successful_steps, unsuccessful_steps=res.unsuccessful_steps, history=hist,
+                final_damping=c.damping)
         if t not in (LinearSolverType.GpuSchurComplement, LinearSolverType.SparseSchurComplement):
             raise NotImplementedError(f"{t} is a CPU solver of the reference; this backend provides GpuSchurComplement")
         d = problem.data

@@ -278,3 +278,87 @@ def make_named(shape: str, scale: float = 1.0) -> BAProblemData:
         n_pt = max(16, int(round(n_pt * scale)))
     nm = shape if scale == 1.0 else f"{shape}@{scale:g}"
     return make_problem(n_cam, n_pt, k_lo, k_hi, config_id=cid, name=nm)
+
+
+# ---------------------------------------------------------------------------------------------------
+# SE3 pose graphs (BASELINE.json configs[1]; SURVEY.md §8(d): "50x50 sphere of SE3 poses, odometry +
+# loop edges (2,500 v / 4,949 e), noise N(0, 0.05^2) on the tangent")
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class PoseGraphData:
+    """What bin/pose_graph_g2o.rs:748-830 feeds the optimiser: vertices sorted by id with
+    pose = [tx,ty,tz,qw,qx,qy,qz]; edge e is BetweenFactor(meas[e]) on (x{ids[e_from[e]]}, x{ids[e_to[e]]})."""
+
+    ids: np.ndarray       # (n_v,) int64, ascending
+    poses: np.ndarray     # (n_v, 7) initial values
+    e_from: np.ndarray    # (n_e,) uint32 index into ids
+    e_to: np.ndarray      # (n_e,) uint32
+    meas: np.ndarray      # (n_e, 7)
+    truth: np.ndarray | None = None
+    name: str = "pose-graph"
+
+    @property
+    def n_v(self) -> int:
+        return int(self.poses.shape[0])
+
+    @property
+    def n_e(self) -> int:
+        return int(self.meas.shape[0])
+
+
+def se3_exp(tau: np.ndarray) -> np.ndarray:
+    """Exp of (n,6) tangents [rho, theta] -> (n,7) poses (generator-side helper)."""
+    th = tau[:, 3:6]
+    ang = np.linalg.norm(th, axis=-1)
+    small = ang < 1e-8
+    a = np.where(small, 1.0, ang)
+    c1 = np.where(small, 0.5, (1.0 - np.cos(a)) / (a * a))
+    c2 = np.where(small, 1.0 / 6.0, (a - np.sin(a)) / (a * a * a))
+    k1 = np.cross(th, tau[:, 0:3])
+    k2 = np.cross(th, k1)
+    t = tau[:, 0:3] + c1[:, None] * k1 + c2[:, None] * k2
+    return np.concatenate([t, quat_exp(th)], axis=-1)
+
+
+def se3_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    return np.concatenate([quat_rotate(a[:, 3:7], b[:, 0:3]) + a[:, 0:3], quat_mul(a[:, 3:7], b[:, 3:7])], axis=-1)
+
+
+def se3_inv(a: np.ndarray) -> np.ndarray:
+    qi = a[:, 3:7] * np.array([1.0, -1.0, -1.0, -1.0])
+    return np.concatenate([-quat_rotate(qi, a[:, 0:3]), qi], axis=-1)
+
+
+def make_sphere(rings: int = 50, per_ring: int = 50, noise: float = 0.05, radius: float = 50.0, config_id: int = 1,
+                id_stride: int = 1) -> PoseGraphData:
+    """sphere2500-shaped pose graph: rings*per_ring poses spiralling up a sphere, an odometry edge
+    i -> i+1 for every consecutive pair and a loop-closure edge i -> i+per_ring between neighbouring
+    rings (2,499 + 2,450 = 4,949 edges for 50x50).  Measurements are the true relative poses times
+    Exp(N(0, noise^2)); initial values are the odometry chain from the true first pose (drifted)."""
+    n = rings * per_ring
+    rng = SplitMix(SEED_BASE + config_id)
+    i = np.arange(n, dtype=np.float64)
+    az = 2.0 * np.pi * (i % per_ring) / per_ring
+    el = -0.45 * np.pi + 0.9 * np.pi * i / max(n - 1, 1)
+    pos = radius * np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], axis=-1)
+    # heading along the ring, small tilt: yaw about z then pitch about the local y axis
+    yaw = az + 0.5 * np.pi
+    qz = np.stack([np.cos(0.5 * yaw), 0 * yaw, 0 * yaw, np.sin(0.5 * yaw)], axis=-1)
+    qy = np.stack([np.cos(0.5 * el), 0 * el, np.sin(0.5 * el), 0 * el], axis=-1)
+    q = quat_mul(qz, qy)
+    truth = np.concatenate([pos, q], axis=-1)
+    ef = np.concatenate([np.arange(n - 1), np.arange(n - per_ring)]).astype(np.uint32)
+    et = np.concatenate([np.arange(1, n), np.arange(per_ring, n)]).astype(np.uint32)
+    m = ef.shape[0]
+    rel = se3_mul(se3_inv(truth[ef]), truth[et])
+    tau = noise * np.stack([rng.normal(10 + 2 * k, m) for k in range(6)], axis=-1)
+    tau[:, 3:6] *= 0.2  # rotational noise in radians: a fifth of the translational sigma
+    meas = se3_mul(rel, se3_exp(tau))
+    meas[:, 3:7] /= np.linalg.norm(meas[:, 3:7], axis=-1, keepdims=True)
+    init = np.empty_like(truth)
+    init[0] = truth[0]
+    for k in range(n - 1):  # odometry edges are the first n-1, edge k is k -> k+1
+        init[k + 1] = se3_mul(init[k:k + 1], meas[k:k + 1])[0]
+    init[:, 3:7] /= np.linalg.norm(init[:, 3:7], axis=-1, keepdims=True)
+    ids = np.arange(n, dtype=np.int64) * id_stride
+    return PoseGraphData(ids=ids, poses=init, e_from=ef, e_to=et, meas=meas, truth=truth, name=f"sphere-{n}")

@@ -216,6 +216,99 @@ int apexgpu_bal_variables(const apexgpu_bal* b, double* poses7, double* intr3);
  * src/optimizer/mod.rs:530-536 (what apexgpu_set_structure expects) */
 int apexgpu_reference_columns(int64_t n_cam, int64_t n_pt, int64_t* intr_col, int64_t* pose_col, int64_t* pt_col);
 
+/* =================================================================================================
+ * SE3 pose-graph backend (BASELINE.json configs[1]: block-sparse J^T J assembly + Cholesky, no Schur)
+ *
+ * Replaces, for problems made of BetweenFactor<SE3> residual blocks (bin/pose_graph_g2o.rs:748-830):
+ *   BetweenFactor<SE3>::linearize                         src/factors/between_factor.rs:268-322
+ *   SparseCholeskySolver::solve_augmented_equation        src/linalg/sparse/cholesky.rs:159-230
+ *   the LM loop around them                               src/optimizer/levenberg_marquardt.rs:823-1031
+ * Edge information matrices are NOT used (the reference passes only edge.measurement,
+ * bin/pose_graph_g2o.rs:805-826).  Vertices are numbered by the caller 0..n_v-1 (the reference sorts
+ * the vertex ids); pose_col[v] is the first global column of variable "x{id_v}" in the sorted-name order
+ * (apexgpu_pose_graph_columns); tangent order [rho(3); theta(3)], right-plus retraction as above.
+ * The same status codes; messages via apexgpu_pg_last_error().
+ * ================================================================================================= */
+typedef struct apexgpu_pg_solver apexgpu_pg_solver;
+
+/* SparseCholeskySolver::new (cholesky.rs:60-70) + per-optimize state */
+int apexgpu_pg_create(int64_t n_vertices, int64_t n_edges, int device, apexgpu_pg_solver** out);
+void apexgpu_pg_destroy(apexgpu_pg_solver* h);
+const char* apexgpu_pg_last_error(const apexgpu_pg_solver* h);
+
+/* build_symbolic_structure (src/linearizer/cpu/sparse.rs:54-105) + the cached SymbolicLlt
+ * (cholesky.rs:190-208): e_from[e] = k0 and e_to[e] = k1 of BetweenFactor e (residual block order),
+ * meas7[e] = [t, qw,qx,qy,qz] of the measured k0->k1 transform, fix6[v][a] != 0 fixes tangent DOF a of
+ * vertex v (Problem::fix_variable, src/core/problem.rs:185-197), huber_delta <= 0: no loss function,
+ * > 0: HuberLoss(delta) on every block. */
+int apexgpu_pg_set_structure(apexgpu_pg_solver* h, const uint32_t* e_from, const uint32_t* e_to, const double* meas7,
+                             const int64_t* pose_col, const uint8_t* fix6, double huber_delta);
+/* Problem::initialize_variables (src/core/problem.rs:686-808): poses7[v] = [t, qw,qx,qy,qz] */
+int apexgpu_pg_set_params(apexgpu_pg_solver* h, const double* poses7);
+int apexgpu_pg_get_params(apexgpu_pg_solver* h, double* poses7);
+
+/* compute_cost on the current parameters (src/optimizer/mod.rs:358-361) */
+int apexgpu_pg_cost(apexgpu_pg_solver* h, double* cost);
+/* assemble (src/linearizer/mod.rs:191-213) + solve_augmented_equation (cholesky.rs:159-230):
+ * (J^T J + lambda I) dx = -J^T r.  step_out / grad_out (= +J^T r, get_gradient) have 6 n_vertices entries in
+ * the global column order and may be NULL.  A non-positive pivot returns APEXGPU_ERR_SINGULAR_MATRIX
+ * ("Cholesky factorization failed (matrix may be singular)", cholesky.rs:213-219). */
+int apexgpu_pg_solve_augmented(apexgpu_pg_solver* h, double lambda, double* step_out, double* grad_out);
+/* out3 = { |g|, |step|, predicted reduction } (levenberg_marquardt.rs:721-746) */
+int apexgpu_pg_step_stats(apexgpu_pg_solver* h, double out3[3]);
+/* apply_parameter_step into a trial set + its cost; commit = accept; discard = apply_negative_parameter_step
+ * (src/optimizer/mod.rs:309-356) */
+int apexgpu_pg_eval_step(apexgpu_pg_solver* h, double* trial_cost);
+int apexgpu_pg_commit_step(apexgpu_pg_solver* h);
+int apexgpu_pg_discard_step(apexgpu_pg_solver* h);
+int apexgpu_pg_parameter_norm(apexgpu_pg_solver* h, double* out);
+/* optimize_with_mode (levenberg_marquardt.rs:823-1031), device-resident; cfg->variant must be 0 */
+int apexgpu_pg_lm_optimize(apexgpu_pg_solver* h, apexgpu_lm_config* cfg, apexgpu_lm_result* result,
+                           apexgpu_lm_iter* history, int history_capacity);
+
+/* parity / debug exports: loss-corrected residuals [n_edges][6], Jacobians [n_edges][6][12] = [dr/dk0 | dr/dk1]
+ * in residual-block order; dense H = J^T J + lambda I ([6 n_v]^2 row-major) and g = J^T r in the global column order */
+int apexgpu_pg_get_residual(apexgpu_pg_solver* h, double* r_out);
+int apexgpu_pg_get_jacobian_blocks(apexgpu_pg_solver* h, double* j_out);
+int apexgpu_pg_get_hessian(apexgpu_pg_solver* h, double lambda, double* H_out, double* g_out);
+
+/* name: "graphs" (hipGraph replay of factor / solves), "nested_dissection" (0 off, 1 on, > 1 leaf size;
+ * before apexgpu_pg_set_structure) */
+int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value);
+#define APEXGPU_PG_NUM_STAGES 6 /* assemble, factor, tri_solve, step_stats, retract, cost */
+int apexgpu_pg_enable_stage_timing(apexgpu_pg_solver* h, int on);
+int apexgpu_pg_reset_stage_times(apexgpu_pg_solver* h);
+int apexgpu_pg_stage_times(apexgpu_pg_solver* h, double ms[APEXGPU_PG_NUM_STAGES], int64_t calls[APEXGPU_PG_NUM_STAGES]);
+/* info[0] tile rows, [1] tiles incl. fill, [2] tiles of H itself, [3] elimination-tree levels, [4] total dof */
+int apexgpu_pg_info(apexgpu_pg_solver* h, double info[8]);
+
+/* ---- input path (host only): G2O files ------------------------------------------------------------
+ * G2oLoader::load (crates/apex-io/src/g2o.rs:140-620): VERTEX_SE3:QUAT id x y z qx qy qz qw (norm checked to
+ * 1 +- 0.01, then normalised), EDGE_SE3:QUAT from to x y z qx qy qz qw + 21 upper-triangular information
+ * values; '#' comments, blank lines and unknown tags are skipped; SE2 lines are validated and counted only.
+ * Error codes mirror IoError: Io, Parse, MissingFields, InvalidNumber, DuplicateVertex, InvalidQuaternion. */
+typedef struct apexgpu_g2o apexgpu_g2o;
+#define APEXGPU_G2O_ERR_IO (-30)
+#define APEXGPU_G2O_ERR_PARSE (-31)
+#define APEXGPU_G2O_ERR_MISSING_FIELDS (-32)
+#define APEXGPU_G2O_ERR_INVALID_NUMBER (-33)
+#define APEXGPU_G2O_ERR_DUPLICATE_VERTEX (-34)
+#define APEXGPU_G2O_ERR_INVALID_QUATERNION (-35)
+int apexgpu_g2o_open(const char* path, apexgpu_g2o** out);
+void apexgpu_g2o_close(apexgpu_g2o* g);
+const char* apexgpu_g2o_last_error(void);
+int apexgpu_g2o_sizes(const apexgpu_g2o* g, int64_t* n_vertices_se3, int64_t* n_edges_se3, int64_t* n_vertices_se2,
+                      int64_t* n_edges_se2);
+/* file order; poses7 / meas7 = [t, qw,qx,qy,qz]; e_from / e_to are vertex IDS; info36 row-major; any may be NULL */
+int apexgpu_g2o_raw(const apexgpu_g2o* g, int64_t* ids, double* poses7, int64_t* e_from, int64_t* e_to, double* meas7,
+                    double* info36);
+/* the problem bin/pose_graph_g2o.rs:748-830 builds with the LM optimiser: vertices sorted by id, edge endpoints as
+ * indices into that order, pose_col from apexgpu_pose_graph_columns, all 6 DOF of the first vertex fixed */
+int apexgpu_g2o_problem(const apexgpu_g2o* g, int64_t* sorted_ids, double* poses7, uint32_t* e_from, uint32_t* e_to,
+                        double* meas7, int64_t* pose_col, uint8_t* fix6);
+/* first global column of variable "x{ids[v]}" in the sorted-name order of src/optimizer/mod.rs:530-536 */
+int apexgpu_pose_graph_columns(int64_t n_vertices, const int64_t* ids, int64_t* pose_col);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,3 +21,36 @@ int hh_residual_obs(const double* pose, const double* intr, const double* pt, co
 int hh_invert_block(const double* B, double* Binv) { return invert_landmark_block(B, Binv); }
 void hh_se3_plus(const double* pose, const double* delta, double* out) { se3_plus(pose, delta, out); }
 }
+
+// ---- pose-graph device math (pg_device.hpp) ---------------------------------------------------
+#include "pg_device.hpp"
+extern "C" {
+// r[6], J[6][12] = [dr/dk0 | dr/dk1] from raw (un-normalised) 7-vectors, loss-corrected like k_pg_edges
+void hh_between_linearize(const double* k0, const double* k1, const double* meas, double delta, double* r, double* J) {
+    double a[7], b[7], m[7];
+    pose_normalise(k0, a); pose_normalise(k1, b); pose_normalise(meas, m);
+    Jac6 Jx[2];
+    between_linearize(a, b, m, r, Jx[0], Jx[1]);
+    const double sc = pg_huber_scale(delta, r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3] + r[4] * r[4] + r[5] * r[5]);
+    for (int i = 0; i < 6; ++i) r[i] *= sc;
+    for (int w = 0; w < 2; ++w)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double* o = J + 6 * w;
+                o[12 * i + j] = sc * Jx[w].P[3 * i + j];
+                o[12 * i + 3 + j] = sc * Jx[w].T[3 * i + j];
+                o[12 * (i + 3) + j] = 0.0;
+                o[12 * (i + 3) + 3 + j] = sc * Jx[w].P[3 * i + j];
+            }
+}
+// H = Ja^T Jb (6x6) and g = Ja^T r through the structured products the kernel uses
+void hh_between_normal(const double* k0, const double* k1, const double* meas, double* H00, double* H11, double* H10, double* g0,
+                       double* g1) {
+    double a[7], b[7], m[7], r[6];
+    pose_normalise(k0, a); pose_normalise(k1, b); pose_normalise(meas, m);
+    Jac6 J0, J1;
+    between_linearize(a, b, m, r, J0, J1);
+    jtj(J0, J0, H00); jtj(J1, J1, H11); jtj(J1, J0, H10);
+    jtr(J0, r, g0); jtr(J1, r, g1);
+}
+}
