@@ -14,7 +14,7 @@ from apex_solver_amd.solver import (GpuSchurComplementSolver, LevenbergMarquardt
                                     OptimizationStatus, OptimizationType, Problem, SchurVariant)
 
 pytestmark = pytest.mark.gpu
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ba*.npz")))
 
 
 def rel(a, b):
