@@ -28,7 +28,8 @@ struct TileMap {
     int nt;
 };
 
-constexpr int kRowBatch = 256;  // (i,j) pairs one k_schur_rows workgroup handles per sweep
+constexpr int kRowThreads = 512;  // k_schur_rows workgroup size: 8 waves share one LDS row block
+constexpr int kRowBatch = kRowThreads;  // (i,j) pairs one k_schur_rows workgroup handles per sweep
 constexpr int kRowObs = 64;     // observations of the camera per sweep (their Y_i stay in LDS)
 constexpr int kRowCap9 = 96;    // neighbour cameras whose 9x9 blocks one workgroup keeps in LDS (62 KB: 2 workgroups per CU)
 constexpr int kRowCap6 = 160;   // same for 6x6 blocks (46 KB)

@@ -354,10 +354,11 @@ __global__ __launch_bounds__(256) void k_prepare_cams(int64_t n_cam, const doubl
 // HBM traffic is the observation stream times the mean track length plus S once; the atomics form
 // (k_schur_scatter) moves DC^2 doubles of atomic traffic per pair instead.
 // ------------------------------------------------------------------------------------------
-constexpr int kHashSize = 512;
+constexpr int kHashSize = 256;   // >= 1.6 x the largest CAP
+constexpr int kCamPitch = 17;    // doubles per neighbour camera in LDS: odd pitch spreads the lanes over the banks
 
 __device__ __forceinline__ int hash_slot(const int* hkey, const int* hval, int key) {
-    unsigned h = ((unsigned)key * 2654435761u) >> 23;  // 9 bits
+    unsigned h = ((unsigned)key * 2654435761u) >> 24;  // 8 bits
     for (int probe = 0; probe < kHashSize; ++probe) {
         const int k = hkey[h];
         if (k == key) return hval[h];
@@ -367,8 +368,8 @@ __device__ __forceinline__ int hash_slot(const int* hkey, const int* hval, int k
     return -1;
 }
 
-template <int DC, int CAP>
-__global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const RowTask* __restrict__ tasks,
+template <int DC, int CAP, bool DBG>
+__global__ __launch_bounds__(kRowThreads, 4) void k_schur_rows(BAView v, TileMap tm, const RowTask* __restrict__ tasks,
                                                       const RowBatch* __restrict__ batches,
                                                       const int* __restrict__ cam_obs,
                                                       const uint16_t* __restrict__ cam_obs_off,
@@ -376,19 +377,26 @@ __global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const 
                                                       int dbg) {
     constexpr int E = DC * DC;
     __shared__ double acc[CAP * E];
+    __shared__ double scam[CAP * kCamPitch];
     __shared__ int hkey[kHashSize], hval[kHashSize];
     __shared__ int s_i[kRowBatch], s_j[kRowBatch];
     const RowTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x;
     const uint32_t ci = (uint32_t)t.cam;
-    for (int idx = tid; idx < CAP * E; idx += 256) acc[idx] = 0.0;
-    for (int idx = tid; idx < kHashSize; idx += 256) hkey[idx] = -1;
+    for (int idx = tid; idx < CAP * E; idx += kRowThreads) acc[idx] = 0.0;
+    for (int idx = tid; idx < kHashSize; idx += kRowThreads) hkey[idx] = -1;
     __syncthreads();
     if (tid < t.nnbr) {
         const int key = nbr[t.nbr0 + tid];
-        unsigned h = ((unsigned)key * 2654435761u) >> 23;
+        unsigned h = ((unsigned)key * 2654435761u) >> 24;
         while (atomicCAS(&hkey[h], -1, key) != -1) h = (h + 1) & (kHashSize - 1);
         hval[h] = tid;
+    }
+    // the prepared cameras of all neighbours, staged once: a pair lane then reads its partner camera
+    // from LDS instead of gathering 128 bytes per pair through the vector cache
+    for (int idx = tid; idx < t.nnbr * kCamStride; idx += kRowThreads) {
+        const int sl = idx / kCamStride, k = idx - sl * kCamStride;
+        scam[sl * kCamPitch + k] = v.camp[(size_t)nbr[t.nbr0 + sl] * kCamStride + k];
     }
     __syncthreads();
     Cam cam_i;
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const 
             for (int q = 0; q < n; ++q) { s_i[off + q] = i_s; s_j[off + q] = j0 + q; }
         }
         __syncthreads();
-        if (tid < bt.total && !(dbg & 4)) {
+        if (tid < bt.total && !(DBG && (dbg & 4))) {
             const int i_s = s_i[tid], j_s = s_j[tid];
             const uint32_t cj = v.o_cam[j_s];
             const int slot = hash_slot(hkey, hval, (int)cj);
@@ -419,20 +427,20 @@ __global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const 
                 double Hi[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) Hi[k] = hinv[9 * (size_t)l + k];
-                double Y[DC][3];
+                double Y[DC][3];  // -Y_i: the sign of the Schur term is folded in here
 #pragma unroll
                 for (int a = 0; a < DC; ++a) {
-                    const double w0 = Jc[0][a] * Jl[0][0] + Jc[1][a] * Jl[1][0];
-                    const double w1 = Jc[0][a] * Jl[0][1] + Jc[1][a] * Jl[1][1];
-                    const double w2 = Jc[0][a] * Jl[0][2] + Jc[1][a] * Jl[1][2];
+                    const double w0 = -(Jc[0][a] * Jl[0][0] + Jc[1][a] * Jl[1][0]);
+                    const double w1 = -(Jc[0][a] * Jl[0][1] + Jc[1][a] * Jl[1][1]);
+                    const double w2 = -(Jc[0][a] * Jl[0][2] + Jc[1][a] * Jl[1][2]);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) Y[a][c] = w0 * Hi[c] + w1 * Hi[3 + c] + w2 * Hi[6 + c];
                 }
                 double* blk = acc + slot * E;
                 Cam cam_j;
                 double rj[2], Jcj[2][DC], Jlj[2][3];
-                if (!(dbg & 2)) {
-                    load_cam_prepared(v.camp + kCamStride * (size_t)cj, cam_j);
+                if (!(DBG && (dbg & 2))) {
+                    load_cam_prepared(scam + slot * kCamPitch, cam_j);
                     const double2 uvj = v.o_uv[j_s];
                     linearize_obs<DC>(cam_j, pw, uvj.x, uvj.y, v.huber_delta, rj, Jcj, Jlj);
                 } else {
@@ -441,21 +449,33 @@ __global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const 
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { Jlj[0][a] = Jl[0][a]; Jlj[1][a] = Jl[1][a]; }
                 }
-                const bool dup = (cj == ci);  // the same camera sees the landmark twice
+                const bool dup = (cj == ci);  // the same camera sees the landmark twice (practically never)
+                if (DBG || dup) {
 #pragma unroll
-                for (int bb = 0; bb < DC; ++bb) {
-                    const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
-                    const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
-                    const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
+                    for (int bb = 0; bb < DC; ++bb) {
+                        const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
+                        const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
+                        const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
 #pragma unroll
-                    for (int a = 0; a < DC; ++a) {
-                        const double val = -(Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2);
-                        if (dbg & 1) { if (val == 1.2345e300) blk[0] = val; }
-                        else if (!dup) unsafeAtomicAdd(&blk[a * DC + bb], val);
-                        else {  // B + B^T on the diagonal block, kept in its lower triangle
-                            if (a >= bb) unsafeAtomicAdd(&blk[a * DC + bb], val);
-                            if (bb >= a) unsafeAtomicAdd(&blk[bb * DC + a], val);
+                        for (int a = 0; a < DC; ++a) {
+                            const double val = Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2;
+                            if (DBG && (dbg & 1)) { if (val == 1.2345e300) blk[0] = val; }
+                            else if (!dup) unsafeAtomicAdd(&blk[a * DC + bb], val);
+                            else {  // B + B^T on the diagonal block, kept in its lower triangle
+                                if (a >= bb) unsafeAtomicAdd(&blk[a * DC + bb], val);
+                                if (bb >= a) unsafeAtomicAdd(&blk[bb * DC + a], val);
+                            }
                         }
+                    }
+                } else {  // straight-line: 243 FMA + 81 ds_add_f64, no per-element control flow
+#pragma unroll
+                    for (int bb = 0; bb < DC; ++bb) {
+                        const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
+                        const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
+                        const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
+#pragma unroll
+                        for (int a = 0; a < DC; ++a)
+                            unsafeAtomicAdd(&blk[a * DC + bb], Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2);
                     }
                 }
             }
@@ -464,7 +484,7 @@ __global__ __launch_bounds__(256) void k_schur_rows(BAView v, TileMap tm, const 
     }
     // ---- store the row block once; the diagonal block already holds H_cc + lambda I - sum Y_i W_i^T
     // from k_cam_reduce and only receives the (rare) duplicate-observation cross terms ---------------------
-    for (int idx = tid; idx < t.nnbr * E; idx += 256) {
+    for (int idx = tid; idx < t.nnbr * E; idx += kRowThreads) {
         const int s = idx / E, e = idx - s * E, a = e / DC, bb = e - a * DC;
         const uint32_t cj = (uint32_t)nbr[t.nbr0 + s];
         double* dst = s_block_ptr<DC>(tm, ci, cj) + a * kNB + bb;
@@ -687,8 +707,11 @@ void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask
                        const RowBatch* batches, const int* cam_obs, const uint16_t* cam_obs_off, const int* nbr,
                        const double* hinv, int dbg, hipStream_t s) {
     if (n_tasks == 0) return;
-    if (dc == 9) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
-    else hipLaunchKernelGGL((k_schur_rows<6, kRowCap6>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
+    // dbg != 0 selects the instrumented build of the kernel (timing ablations only)
+    if (dc == 9 && dbg == 0) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9, false>), dim3(n_tasks), dim3(kRowThreads), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
+    else if (dc == 9) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9, true>), dim3(n_tasks), dim3(kRowThreads), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
+    else if (dbg == 0) hipLaunchKernelGGL((k_schur_rows<6, kRowCap6, false>), dim3(n_tasks), dim3(kRowThreads), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
+    else hipLaunchKernelGGL((k_schur_rows<6, kRowCap6, true>), dim3(n_tasks), dim3(kRowThreads), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
 }
 
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,

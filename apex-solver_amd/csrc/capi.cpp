@@ -115,6 +115,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     const std::string n = name ? name : "";
     if (n == "schur_rows") h->s->use_row_schur(value != 0);
     else if (n == "graphs") h->s->enable_graphs(value != 0);
+    else if (n == "update_overlap") h->s->enable_overlap(value != 0);
     else if (n == "rows_debug") h->s->set_rows_debug(value);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);  /* value > 1: leaf size */
     else return APEXGPU_ERR_INVALID_INPUT;
@@ -133,7 +134,10 @@ int apexgpu_info(apexgpu_solver* h, double info[16]) {
     info[3] = (double)h->s->cam_dof_internal(); info[4] = h->s->last_reg(); info[5] = h->s->last_pcg_iters();
     info[6] = h->s->touched_tiles(); info[7] = h->s->local_obs();
     info[8] = h->s->n_levels();
-    for (int i = 9; i < 16; ++i) info[i] = 0;
+    int64_t a = 0, b = 0, c = 0;
+    h->s->plan().op_counts(&a, &b, &c);
+    info[9] = (double)a; info[10] = (double)b; info[11] = (double)c;
+    for (int i = 12; i < 16; ++i) info[i] = 0;
     return APEXGPU_OK;
 }
 
@@ -232,6 +236,7 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     PG_OR_FAIL;
     const std::string n = name ? name : "";
     if (n == "graphs") h->s->enable_graphs(value != 0);
+    else if (n == "update_overlap") h->s->enable_overlap(value != 0);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);
     else return APEXGPU_ERR_INVALID_INPUT;
     return APEXGPU_OK;
@@ -247,7 +252,9 @@ int apexgpu_pg_info(apexgpu_pg_solver* h, double info[8]) {
     PG_OR_FAIL;
     info[0] = h->s->n_tile_rows(); info[1] = (double)h->s->tile_count(); info[2] = (double)h->s->touched_tiles();
     info[3] = h->s->n_levels(); info[4] = 6.0 * (double)h->s->n_vertices();
-    for (int i = 5; i < 8; ++i) info[i] = 0;
+    int64_t a = 0, b = 0, c = 0;
+    h->s->plan().op_counts(&a, &b, &c);
+    info[5] = (double)a; info[6] = (double)b; info[7] = (double)c;
     return APEXGPU_OK;
 }
 

@@ -136,8 +136,15 @@ __global__ __launch_bounds__(256) void k_potrf_inv(const PotrfTask* __restrict__
             for (int j = 0; j < BS; ++j) {
                 const double djj = readlane_f64(a[j], j);
                 if (!(djj > 0.0)) isbad = 1;
-                const double sj = sqrt(djj > 0.0 ? djj : 1.0);
-                const double isj = 1.0 / sj;
+                // 1/sqrt(d) from the hardware estimate + two Newton steps (to the last bit or two), then
+                // sqrt(d) = d * (1/sqrt(d)) with one correction: no v_sqrt_f64 fix-up and no division on
+                // the critical path of the 16 dependent pivot steps
+                const double dj = djj > 0.0 ? djj : 1.0;
+                double isj = __builtin_amdgcn_rsq(dj);
+                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
+                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
+                double sj = dj * isj;
+                sj = fma(0.5 * isj, fma(-sj, sj, dj), sj);
                 invd[j] = isj;
                 const double lrj = a[j] * isj;  // L[r][j] for r > j
 #pragma unroll

@@ -46,6 +46,7 @@ class PoseGraphSolver : public LmBackend {
     int get_hessian(double lambda, double* H_out, double* g_out);  // dense J^T J + lambda I, J^T r
 
     void enable_graphs(bool on) { tp_.enable_graphs(on); }
+    void enable_overlap(bool on) { tp_.enable_overlap(on); }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void enable_stage_timing(bool on) { timer_.enable(on); }
     void reset_stage_times() { timer_.reset(); }
@@ -55,6 +56,7 @@ class PoseGraphSolver : public LmBackend {
     int64_t tile_count() const { return tp_.n_slots(); }
     int64_t touched_tiles() const { return tp_.n_touched_slots(); }
     int n_levels() const { return tp_.n_levels(); }
+    const TilePlan& plan() const { return tp_; }
     const char* last_error() const override { return err_.c_str(); }
 
    private:

@@ -63,10 +63,12 @@ class Solver : public LmBackend {
     void reset_stage_times();
     void enable_stage_timing(bool on) { timer_.enable(on); }
     void enable_graphs(bool on) { use_graphs_ = on; tp_.enable_graphs(on); }
+    void enable_overlap(bool on) { tp_.enable_overlap(on); }
     void use_row_schur(bool on) { use_rows_ = on; }
     void set_rows_debug(int v) { rows_dbg_ = v; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     int n_levels() const { return tp_.n_levels(); }
+    const TilePlan& plan() const { return tp_; }
     double schur_scatter_pairs() const { return (double)n_pairs_; }
     double touched_tiles() const { return (double)n_present_; }
     double local_obs() const { return (double)o_orig_h_.size(); }

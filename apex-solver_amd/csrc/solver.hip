@@ -320,7 +320,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
                     }
                     continue;
                 }
-                if (cur.total + np > kRowBatch || cur.count == 256) flushb();  // one lane expands one observation
+                if (cur.total + np > kRowBatch || cur.count == kRowThreads) flushb();  // one lane expands one observation
                 if (cur.count == 0) cur.first = e;
                 cam_obs_off[e] = (uint16_t)cur.total;
                 cur.count++; cur.total += np;

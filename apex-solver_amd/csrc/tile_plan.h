@@ -38,12 +38,15 @@ class TilePlan {
     int64_t n_slots() const { return n_slots_; }
     int64_t n_touched_slots() const { return n_touched_; }  // tiles non-zero before fill come first
     int n_levels() const { return n_levels_; }
+    // tile operations of one factorisation: potrf+inverse, panel products, trailing updates (each 2*144^3 flop for the last two)
+    void op_counts(int64_t* potrf, int64_t* trsm, int64_t* upd) const { *potrf = n_potrf_; *trsm = n_trsm_; *upd = n_upd_; }
     double* tiles() const { return tiles_; }
     const int* slot_host() const { return slot_h_.data(); }
     int slot(int I, int J) const { return slot_h_[(size_t)I * nt_ + J]; }
     TileMap tilemap() const { return TileMap{tiles_, slot_, nt_}; }
     const int* diag_slot_dev() const { return diag_slot_; }
     void enable_graphs(bool on) { use_graphs_ = on; }
+    void enable_overlap(bool on) { overlap_ = on; }  // before the first factor()
 
     hipError_t zero_tiles();                             // async on the plan's stream
     void add_diag(int n_valid, double add_valid, double pad_value);  // diagonal += / padding rows := value
@@ -63,9 +66,14 @@ class TilePlan {
 
     int nt_ = 0, n_levels_ = 0;
     int64_t n_slots_ = 0, n_touched_ = 0;
+    int64_t n_potrf_ = 0, n_trsm_ = 0, n_upd_ = 0;
     hipStream_t stream_ = nullptr;
     std::vector<int> slot_h_, diag_slot_h_;
-    std::vector<int> lv_potrf_, lv_trsm_, lv_fwd_, lv_bwd_, lv_upd_round_;
+    std::vector<int> lv_potrf_, lv_trsm_, lv_fwd_, lv_bwd_, lv_upd_round_, lv_upd_split_;
+    hipStream_t side_ = nullptr;  // trailing updates that the next level does not need (enqueue_factor)
+    std::vector<hipEvent_t> ev_t_, ev_u2_;
+    std::vector<bool> u2_pending_;
+    bool overlap_ = true;
     std::vector<std::pair<int64_t, int64_t>> upd_rounds_;
     double *tiles_ = nullptr, *linv_ = nullptr;
     int *slot_ = nullptr, *diag_slot_ = nullptr, *flag_ = nullptr;

@@ -105,9 +105,15 @@ void TilePlan::release() {
         if (graph_exec_[i]) { (void)hipGraphExecDestroy(graph_exec_[i]); graph_exec_[i] = nullptr; }
         graph_failed_[i] = false;
     }
+    for (hipEvent_t e : ev_t_) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_u2_) (void)hipEventDestroy(e);
+    ev_t_.clear(); ev_u2_.clear();
 }
 
-TilePlan::~TilePlan() { release(); }
+TilePlan::~TilePlan() {
+    release();
+    if (side_) (void)hipStreamDestroy(side_);
+}
 
 std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStream_t stream) {
     release();
@@ -185,6 +191,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     lv_potrf_.assign(n_levels_ + 1, 0); lv_trsm_.assign(n_levels_ + 1, 0);
     lv_fwd_.assign(n_levels_ + 1, 0); lv_bwd_.assign(n_levels_ + 1, 0);
     lv_upd_round_.assign(n_levels_ + 1, 0);
+    lv_upd_split_.assign(n_levels_ + 1, 0);
     upd_rounds_.clear();
     upd.reserve(n_upd);
     for (int lv = 0; lv < n_levels_; ++lv) {
@@ -203,21 +210,32 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
                     us.push_back({(int64_t)rows[a] * nt_ + rows[b], K, {tile_ptr(rows[a], rows[b]), tile_ptr(rows[a], K), tile_ptr(rows[b], K)}});
         }
         std::stable_sort(us.begin(), us.end(), [](const U& x, const U& y) { return x.key < y.key; });
-        std::vector<int> round(us.size(), 0);
-        int n_rounds = 0;
-        for (size_t i = 0; i < us.size(); ++i) {
-            round[i] = (i > 0 && us[i].key == us[i - 1].key) ? round[i - 1] + 1 : 0;
-            n_rounds = std::max(n_rounds, round[i] + 1);
-        }
-        for (int r = 0; r < n_rounds; ++r) {
-            // inside a round: by source column, so that tasks sharing operand tiles are neighbours
-            std::vector<const U*> sel;
-            for (size_t i = 0; i < us.size(); ++i)
-                if (round[i] == r) sel.push_back(&us[i]);
-            std::stable_sort(sel.begin(), sel.end(), [](const U* x, const U* y) { return x->K < y->K; });
-            const int64_t off = (int64_t)upd.size();
-            for (const U* u : sel) upd.push_back(u->t);
-            upd_rounds_.push_back({off, (int64_t)upd.size() - off});
+        // U1: targets in a column of the NEXT level (needed by its potrf / panel solves right away);
+        // U2: targets further up the tree -- these run on the side stream, overlapped with the next
+        // level's potrf and panel solves (see enqueue_factor)
+        for (int part = 0; part < 2; ++part) {
+            std::vector<const U*> mine;
+            for (const U& u : us) {
+                const int tcol = (int)(u.key % nt_);
+                if ((level[tcol] == lv + 1) == (part == 0)) mine.push_back(&u);
+            }
+            std::vector<int> round(mine.size(), 0);
+            int n_rounds = 0;
+            for (size_t i = 0; i < mine.size(); ++i) {
+                round[i] = (i > 0 && mine[i]->key == mine[i - 1]->key) ? round[i - 1] + 1 : 0;
+                n_rounds = std::max(n_rounds, round[i] + 1);
+            }
+            for (int r = 0; r < n_rounds; ++r) {
+                // inside a round: by source column, so that tasks sharing operand tiles are neighbours
+                std::vector<const U*> sel;
+                for (size_t i = 0; i < mine.size(); ++i)
+                    if (round[i] == r) sel.push_back(mine[i]);
+                std::stable_sort(sel.begin(), sel.end(), [](const U* x, const U* y) { return x->K < y->K; });
+                const int64_t off = (int64_t)upd.size();
+                for (const U* u : sel) upd.push_back(u->t);
+                upd_rounds_.push_back({off, (int64_t)upd.size() - off});
+            }
+            if (part == 0) lv_upd_split_[lv] = (int)upd_rounds_.size();
         }
         lv_potrf_[lv + 1] = (int)potrf.size();
         lv_trsm_[lv + 1] = (int)trsm.size();
@@ -245,6 +263,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         for (int J = 0; J <= I; ++J)
             if (J == I || present[(size_t)I * nt_ + J]) symt.push_back({slot_h_[(size_t)I * nt_ + J], I, J});
     }
+    n_potrf_ = (int64_t)potrf.size(); n_trsm_ = (int64_t)trsm.size(); n_upd_ = (int64_t)upd.size();
     n_sym_tiles_ = (int)symt.size();
     TP_TRY(upload(&sym_tiles_, symt));
     TP_TRY(alloc_zero(&sym_part_, (size_t)n_slots_ * 2 * kNB));
@@ -258,6 +277,13 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     TP_TRY(upload(&upd_tasks_, upd));
     TP_TRY(upload(&sym_row_ptr_, sym_ptr));
     TP_TRY(upload(&sym_entries_, sym));
+    if (!side_) TP_TRY(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_);
+    u2_pending_.assign(n_levels_, false);
+    for (int i = 0; i < n_levels_; ++i) {
+        TP_TRY(hipEventCreateWithFlags(&ev_t_[i], hipEventDisableTiming));
+        TP_TRY(hipEventCreateWithFlags(&ev_u2_[i], hipEventDisableTiming));
+    }
     TP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on the stream
 #undef TP_TRY
     return "";
@@ -279,12 +305,34 @@ void TilePlan::diag(double* out) const { launch_tile_diag(tiles_, diag_slot_, nt
 // they are captured once into hipGraphs (a few hundred dependent launches would otherwise be paced by
 // host launch overhead) and replayed every iteration.
 void TilePlan::enqueue_factor() {
+    // Two streams.  Main: potrf(lv), panel solves(lv), U1(lv) = the updates the next level needs.
+    // Side: U2(lv) = every other update of level lv, overlapped with potrf / panel solves of level lv+1
+    // (one workgroup resp. a few dozen: they leave the chip nearly empty).  Ordering that keeps every
+    // tile's read-modify-write sequence race free:
+    //   U2(lv) after the panel solves of lv;  U1(lv) after U2(lv-1) (both may hit columns of level lv+1);
+    //   potrf(lv) after U1(lv-1) [stream order] and U2(<= lv-2) [main already waited for it before U1(lv-1)].
+    const bool two = overlap_ && side_ != nullptr && n_levels_ > 2;
     for (int lv = 0; lv < n_levels_; ++lv) {
         launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flag_, stream_);
         launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_);
-        for (int r = lv_upd_round_[lv]; r < lv_upd_round_[lv + 1]; ++r)
+        const int r0 = lv_upd_round_[lv], rs = lv_upd_split_[lv], r1 = lv_upd_round_[lv + 1];
+        const bool has_u2 = two && r1 > rs;
+        if (has_u2) {
+            (void)hipEventRecord(ev_t_[lv], stream_);
+            (void)hipStreamWaitEvent(side_, ev_t_[lv], 0);
+        }
+        if (two && lv > 0 && u2_pending_[lv - 1]) (void)hipStreamWaitEvent(stream_, ev_u2_[lv - 1], 0);
+        for (int r = r0; r < rs; ++r)
             launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, stream_);
+        hipStream_t s2 = has_u2 ? side_ : stream_;
+        for (int r = rs; r < r1; ++r)
+            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s2);
+        u2_pending_[lv] = has_u2;
+        if (has_u2) (void)hipEventRecord(ev_u2_[lv], side_);
     }
+    if (two)  // join: the last side-stream work precedes whatever follows on the main stream
+        for (int lv = n_levels_ - 1; lv >= 0; --lv)
+            if (u2_pending_[lv]) { (void)hipStreamWaitEvent(stream_, ev_u2_[lv], 0); break; }
 }
 
 void TilePlan::enqueue_solve(const double* rhs, double* x, double* work) {

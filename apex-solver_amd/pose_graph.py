@@ -261,7 +261,7 @@ class GpuSparseCholeskySolver:
         a = (C.c_double * 8)()
         h.check(h.L.apexgpu_pg_info(h.h, C.byref(a)))
         return {"tile_rows": int(a[0]), "tiles": int(a[1]), "touched_tiles": int(a[2]), "etree_levels": int(a[3]),
-                "total_dof": int(a[4])}
+                "total_dof": int(a[4]), "n_potrf": int(a[5]), "n_trsm": int(a[6]), "n_update": int(a[7])}
 
     def enable_stage_timing(self, on=True): h = self._need(); h.check(h.L.apexgpu_pg_enable_stage_timing(h.h, int(on)))
     def reset_stage_times(self): h = self._need(); h.check(h.L.apexgpu_pg_reset_stage_times(h.h))

@@ -328,7 +328,8 @@ class GpuSchurComplementSolver:
         h = self._need(); out = (C.c_double * 16)()
         h.check(h.L.apexgpu_info(h.h, C.byref(out)))
         return dict(tile_rows=int(out[0]), tiles=int(out[1]), pair_blocks=float(out[2]), cam_dof=int(out[3]),
-                    last_reg=float(out[4]), pcg_iterations=int(out[5]), touched_tiles=int(out[6]), local_obs=int(out[7]), etree_levels=int(out[8]))
+                    last_reg=float(out[4]), pcg_iterations=int(out[5]), touched_tiles=int(out[6]), local_obs=int(out[7]), etree_levels=int(out[8]),
+                    n_potrf=int(out[9]), n_trsm=int(out[10]), n_update=int(out[11]))
 
     def set_option(self, name: str, value: int):
         h = self._need(); h.check(h.L.apexgpu_set_option(h.h, name.encode(), int(value)))

@@ -162,6 +162,8 @@ int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out /* n_pt*9 */
  *   "schur_rows" (1)  Schur reduction in the LDS row form (k_schur_rows, no global atomics); 0 selects
  *                     the landmark-major global-atomics form (k_cam_reduce + k_schur_scatter)
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
+ *   "update_overlap" (1)  run the trailing updates the next elimination level does not need on a second
+ *                     stream, overlapped with that level's potrf / panel solves (before the first solve)
  *   "nested_dissection" (1)  order camera tiles by nested dissection (call before set_structure);
  *                     0 keeps the caller's camera order, a value > 1 sets the leaf size in tiles    */
 int apexgpu_set_option(apexgpu_solver* h, const char* name, int value);
@@ -176,7 +178,8 @@ int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_
 /* info[0] = S tile rows, [1] = allocated tiles, [2] = camera-pair contributions per Schur reduce,
  * [3] = internal camera DOF, [4] = regularisation used by the last Cholesky, [5] = PCG iterations,
  * [6] = S tiles that receive Schur contributions (before fill), [7] = observations on this rank,
- * [8] = levels of the tile elimination tree (= dependent launch groups of the factorisation) */
+ * [8] = levels of the tile elimination tree (= dependent launch groups of the factorisation),
+ * [9..11] = tile operations per factorisation: potrf, panel products, trailing updates (2*144^3 flop each for the last two) */
 int apexgpu_info(apexgpu_solver* h, double info[16]);
 
 /* ---- multi-GPU: one process per GPU, landmarks sharded, RCCL all-reduce of S and g_red -----------
@@ -272,14 +275,15 @@ int apexgpu_pg_get_residual(apexgpu_pg_solver* h, double* r_out);
 int apexgpu_pg_get_jacobian_blocks(apexgpu_pg_solver* h, double* j_out);
 int apexgpu_pg_get_hessian(apexgpu_pg_solver* h, double lambda, double* H_out, double* g_out);
 
-/* name: "graphs" (hipGraph replay of factor / solves), "nested_dissection" (0 off, 1 on, > 1 leaf size;
- * before apexgpu_pg_set_structure) */
+/* name: "graphs" (hipGraph replay of factor / solves), "update_overlap" (second stream for trailing updates),
+ * "nested_dissection" (0 off, 1 on, > 1 leaf size; before apexgpu_pg_set_structure) */
 int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value);
 #define APEXGPU_PG_NUM_STAGES 6 /* assemble, factor, tri_solve, step_stats, retract, cost */
 int apexgpu_pg_enable_stage_timing(apexgpu_pg_solver* h, int on);
 int apexgpu_pg_reset_stage_times(apexgpu_pg_solver* h);
 int apexgpu_pg_stage_times(apexgpu_pg_solver* h, double ms[APEXGPU_PG_NUM_STAGES], int64_t calls[APEXGPU_PG_NUM_STAGES]);
-/* info[0] tile rows, [1] tiles incl. fill, [2] tiles of H itself, [3] elimination-tree levels, [4] total dof */
+/* info[0] tile rows, [1] tiles incl. fill, [2] tiles of H itself, [3] elimination-tree levels, [4] total dof,
+ * [5..7] tile operations per factorisation: potrf, panel products, trailing updates */
 int apexgpu_pg_info(apexgpu_pg_solver* h, double info[8]);
 
 /* ---- input path (host only): G2O files ------------------------------------------------------------
