@@ -19,7 +19,14 @@ struct BAView {
     const double2* o_uv;   // [n_obs]
     const int* pt_ptr;     // [n_pt+1]
     double huber_delta;
+    const uint32_t* co_pt; // [n_obs] camera-major copies (entry k of the camera lists): landmark index
+    const double2* co_uv;  // [n_obs]                                                   and measurement
 };
+
+// Per-landmark record written by k_landmark_reduce and read by the camera-major kernels: everything a
+// camera-major gather needs from a landmark sits in ONE 128-byte line instead of three arrays.
+constexpr int kLmStride = 16;  // doubles: Hll^-1 (9, row-major) | g_l (3) | point (3) | pad
+constexpr int kLmG = 9, kLmPt = 12;
 
 // Lower-triangular tile map of the reduced camera matrix S.
 struct TileMap {

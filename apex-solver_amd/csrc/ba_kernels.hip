@@ -49,6 +49,13 @@ __device__ __forceinline__ double block_sum_256(double v, double* scratch) {
     return r;
 }
 
+// one landmark record = eight aligned 16-byte loads
+__device__ __forceinline__ void load_lm_record(const double* __restrict__ rec, size_t l, double out[kLmStride]) {
+    const double2* q = reinterpret_cast<const double2*>(rec + kLmStride * l);
+#pragma unroll
+    for (int i = 0; i < kLmStride / 2; ++i) { const double2 t = q[i]; out[2 * i] = t.x; out[2 * i + 1] = t.y; }
+}
+
 template <int DC>
 __device__ __forceinline__ double* s_block_ptr(const TileMap& tm, uint32_t row_cam, uint32_t col_cam) {
     constexpr int CPT = kNB / DC;  // cameras per tile
@@ -64,8 +71,9 @@ __device__ __forceinline__ double* s_block_ptr(const TileMap& tm, uint32_t row_c
 // Writes (plain stores, no atomics) the lower triangle of the camera's diagonal block of S
 // (+lambda on the diagonal when add_lambda), g_c and g_red := -g_c.
 // ------------------------------------------------------------------------------------------
+constexpr int kCamThreads = 64;  // one wave per camera: ~30 observations per lane amortise the 63-value reduction
 template <int DC>
-__global__ __launch_bounds__(256) void k_cam_reduce(BAView v, TileMap tm, const int* __restrict__ cam_ptr,
+__global__ __launch_bounds__(kCamThreads) void k_cam_reduce(BAView v, TileMap tm, const int* __restrict__ cam_ptr,
                                                       const int* __restrict__ cam_obs, double lambda,
                                                       int add_lambda, const double* __restrict__ hinv,
                                                       const double* __restrict__ g_l, int with_self,
@@ -75,18 +83,20 @@ __global__ __launch_bounds__(256) void k_cam_reduce(BAView v, TileMap tm, const 
     // has pairs of DIFFERENT observations left (no same-address LDS atomics).
     constexpr int NH = DC * (DC + 1) / 2;
     const uint32_t c = blockIdx.x;
-    __shared__ double red[4][NH + 2 * DC];
+    constexpr int NW = kCamThreads / 64;
+    __shared__ double red[NW][NH + 2 * DC];
     double acc[NH + 2 * DC];
 #pragma unroll
     for (int i = 0; i < NH + 2 * DC; ++i) acc[i] = 0.0;
     Cam cam;
     load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
     const int b = cam_ptr[c], e = cam_ptr[c + 1];
-    for (int k = b + (int)threadIdx.x; k < e; k += 256) {
-        const int i = cam_obs[k];
-        const uint32_t l = v.o_pt[i];
-        const double2 uv = v.o_uv[i];
-        const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
+    for (int k = b + (int)threadIdx.x; k < e; k += kCamThreads) {
+        const uint32_t l = v.co_pt[k];   // camera-major copies: coalesced
+        const double2 uv = v.co_uv[k];
+        double rec[kLmStride];
+        load_lm_record(hinv, l, rec);     // Hll^-1, g_l and the point: one 128-byte line
+        const double pw[3] = {rec[kLmPt], rec[kLmPt + 1], rec[kLmPt + 2]};
         double r[2], Jc[2][DC], Jl[2][3];
         linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
         int idx = 0;
@@ -97,10 +107,9 @@ __global__ __launch_bounds__(256) void k_cam_reduce(BAView v, TileMap tm, const 
 #pragma unroll
         for (int a = 0; a < DC; ++a) acc[NH + a] += Jc[0][a] * r[0] + Jc[1][a] * r[1];
         if (with_self) {
-            double Hi[9], W[DC][3], Y[DC][3];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) Hi[q] = hinv[9 * (size_t)l + q];
-            const double gl0 = g_l[3 * (size_t)l], gl1 = g_l[3 * (size_t)l + 1], gl2 = g_l[3 * (size_t)l + 2];
+            double W[DC][3], Y[DC][3];
+            const double* Hi = rec;
+            const double gl0 = rec[kLmG], gl1 = rec[kLmG + 1], gl2 = rec[kLmG + 2];
 #pragma unroll
             for (int a = 0; a < DC; ++a) {
 #pragma unroll
@@ -125,7 +134,9 @@ __global__ __launch_bounds__(256) void k_cam_reduce(BAView v, TileMap tm, const 
     __syncthreads();
     if (threadIdx.x < NH + DC) {
         const int i = threadIdx.x;
-        const double s = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        double s = red[0][i];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) s += red[q][i];
         if (i < NH) {
             // packed lower index -> (a,b), a >= b
             int a = 0;
@@ -136,7 +147,9 @@ __global__ __launch_bounds__(256) void k_cam_reduce(BAView v, TileMap tm, const 
         } else {
             const int a = i - NH;
             const int j = NH + DC + a;
-            const double yg = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+            double yg = red[0][j];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) yg += red[q][j];
             g_c[(size_t)c * DC + a] = s;
             g_red[(size_t)c * DC + a] = -s + yg;
         }
@@ -153,10 +166,10 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
     const int g = threadIdx.x & 7;
     const int64_t l = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     const bool active = l < v.n_pt;
-    double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0};
+    double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0}, pw[3] = {0, 0, 0};
     if (active) {
         const int b = v.pt_ptr[l], e = v.pt_ptr[l + 1];
-        const double pw[3] = {v.pts[3 * l], v.pts[3 * l + 1], v.pts[3 * l + 2]};
+        pw[0] = v.pts[3 * l]; pw[1] = v.pts[3 * l + 1]; pw[2] = v.pts[3 * l + 2];
         for (int i = b + g; i < e; i += 8) {
             const uint32_t c = v.o_cam[i];
             const double2 uv = v.o_uv[i];
@@ -190,7 +203,9 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
             for (int i = 0; i < 9; ++i) Bi[i] = 0.0;
         }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) hinv[9 * l + i] = Bi[i];
+        for (int i = 0; i < 9; ++i) hinv[kLmStride * l + i] = Bi[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { hinv[kLmStride * l + kLmG + i] = gl[i]; hinv[kLmStride * l + kLmPt + i] = pw[i]; }
 #pragma unroll
         for (int i = 0; i < 3; ++i) g_l[3 * l + i] = gl[i];
     }
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(256) void k_schur_scatter(BAView v, TileMap tm, con
         linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
         double Hi[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Hi[k] = hinv[9 * (size_t)l + k];
+        for (int k = 0; k < 9; ++k) Hi[k] = hinv[kLmStride * (size_t)l + k];
         double yg[DC];
 #pragma unroll
         for (int a = 0; a < DC; ++a) {
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(256) void k_schur_scatter(BAView v, TileMap tm, con
             const double y2 = w0 * Hi[2] + w1 * Hi[5] + w2 * Hi[8];
             sW[tid * WY + 3 * a + 0] = w0; sW[tid * WY + 3 * a + 1] = w1; sW[tid * WY + 3 * a + 2] = w2;
             sY[tid * WY + 3 * a + 0] = y0; sY[tid * WY + 3 * a + 1] = y1; sY[tid * WY + 3 * a + 2] = y2;
-            yg[a] = y0 * g_l[3 * (size_t)l] + y1 * g_l[3 * (size_t)l + 1] + y2 * g_l[3 * (size_t)l + 2];
+            yg[a] = y0 * hinv[kLmStride * (size_t)l + kLmG] + y1 * hinv[kLmStride * (size_t)l + kLmG + 1] + y2 * hinv[kLmStride * (size_t)l + kLmG + 2];
         }
         sCam[tid] = c;
         if (t.nj == 0) {
@@ -420,13 +435,16 @@ __global__ __launch_bounds__(kRowThreads, 4) void k_schur_rows(BAView v, TileMap
             const int slot = hash_slot(hkey, hval, (int)cj);
             if (slot >= 0) {
                 const uint32_t l = v.o_pt[i_s];
-                const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
+                double Hi[9], pw[3];
+                {   // Hll^-1 and the point from the landmark record: aligned 16-byte loads of one line
+                    const double2* q = reinterpret_cast<const double2*>(hinv + kLmStride * (size_t)l);
+                    const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a6 = q[6], a7 = q[7];
+                    Hi[0] = a0.x; Hi[1] = a0.y; Hi[2] = a1.x; Hi[3] = a1.y; Hi[4] = a2.x; Hi[5] = a2.y; Hi[6] = a3.x; Hi[7] = a3.y;
+                    Hi[8] = a4.x; pw[0] = a6.x; pw[1] = a6.y; pw[2] = a7.x;
+                }
                 const double2 uvi = v.o_uv[i_s];
                 double r[2], Jc[2][DC], Jl[2][3];
                 linearize_obs<DC>(cam_i, pw, uvi.x, uvi.y, v.huber_delta, r, Jc, Jl);
-                double Hi[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) Hi[k] = hinv[9 * (size_t)l + k];
                 double Y[DC][3];  // -Y_i: the sign of the Schur term is folded in here
 #pragma unroll
                 for (int a = 0; a < DC; ++a) {
@@ -531,8 +549,8 @@ __global__ __launch_bounds__(256) void k_back_substitute(BAView v, const double*
 #pragma unroll
         for (int i = 0; i < 3; ++i) acc[i] += __shfl_xor(acc[i], m, 8);
     if (active && g == 0) {
-        const double rhs[3] = {-g_l[3 * l] - acc[0], -g_l[3 * l + 1] - acc[1], -g_l[3 * l + 2] - acc[2]};
-        const double* Hi = hinv + 9 * l;
+        const double* Hi = hinv + kLmStride * l;
+        const double rhs[3] = {-Hi[kLmG] - acc[0], -Hi[kLmG + 1] - acc[1], -Hi[kLmG + 2] - acc[2]};
 #pragma unroll
         for (int a = 0; a < 3; ++a) dl[3 * l + a] = Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2];
     }
@@ -681,8 +699,8 @@ void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* ca
                        double lambda, int add_lambda, const double* hinv, const double* g_l, int with_self, double* g_c,
                        double* g_red, hipStream_t s) {
     if (v.n_cam == 0) return;
-    if (dc == 9) hipLaunchKernelGGL(k_cam_reduce<9>, dim3((unsigned)v.n_cam), dim3(256), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
-    else hipLaunchKernelGGL(k_cam_reduce<6>, dim3((unsigned)v.n_cam), dim3(256), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
+    if (dc == 9) hipLaunchKernelGGL(k_cam_reduce<9>, dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
+    else hipLaunchKernelGGL(k_cam_reduce<6>, dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
 }
 
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag, hipStream_t s) {

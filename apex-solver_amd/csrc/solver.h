@@ -128,7 +128,8 @@ class Solver : public LmBackend {
     int n_rtasks_ = 0;
     int rows_dbg_ = 0;      // timing-only ablation switches of k_schur_rows (results are wrong when != 0)
     bool use_rows_ = true;  // Schur reduction: LDS row form (default) or the global-atomics form
-    uint32_t *o_cam_ = nullptr, *o_pt_ = nullptr;
+    uint32_t *o_cam_ = nullptr, *o_pt_ = nullptr, *co_pt_ = nullptr;
+    double2* co_uv_ = nullptr;
     double2* o_uv_ = nullptr;
     int *o_orig_ = nullptr, *pt_ptr_ = nullptr, *cam_ptr_ = nullptr, *cam_obs_ = nullptr;
     uint8_t *fix_pose_ = nullptr, *fix_intr_ = nullptr, *fix_pt_ = nullptr;
