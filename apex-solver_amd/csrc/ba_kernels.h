@@ -21,6 +21,7 @@ struct BAView {
     double huber_delta;
     const uint32_t* co_pt; // [n_obs] camera-major copies (entry k of the camera lists): landmark index
     const double2* co_uv;  // [n_obs]                                                   and measurement
+    const int* co_rank;    // [n_obs] position of the observation inside its landmark's list
 };
 
 // Per-landmark record written by k_landmark_reduce and read by the camera-major kernels: everything a
@@ -35,7 +36,8 @@ struct TileMap {
     int nt;
 };
 
-constexpr int kRowThreads = 512;  // k_schur_rows workgroup size: 8 waves share one LDS row block
+constexpr int kRowThreads = 256;  // k_schur_rows workgroup size (512 threads need <= 128 VGPRs per lane to keep two
+                                 // workgroups per CU: that spills to scratch -> +10 GB of HBM writes per launch, same time)
 constexpr int kRowBatch = kRowThreads;  // (i,j) pairs one k_schur_rows workgroup handles per sweep
 constexpr int kRowObs = 64;     // observations of the camera per sweep (their Y_i stay in LDS)
 constexpr int kRowCap9 = 96;    // neighbour cameras whose 9x9 blocks one workgroup keeps in LDS (62 KB: 2 workgroups per CU)

@@ -384,7 +384,7 @@ __device__ __forceinline__ int hash_slot(const int* hkey, const int* hval, int k
 }
 
 template <int DC, int CAP, bool DBG>
-__global__ __launch_bounds__(kRowThreads, 4) void k_schur_rows(BAView v, TileMap tm, const RowTask* __restrict__ tasks,
+__global__ __launch_bounds__(kRowThreads) void k_schur_rows(BAView v, TileMap tm, const RowTask* __restrict__ tasks,
                                                       const RowBatch* __restrict__ batches,
                                                       const int* __restrict__ cam_obs,
                                                       const uint16_t* __restrict__ cam_obs_off,
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kRowThreads, 4) void k_schur_rows(BAView v, TileMap
         if (tid < bt.count) {
             const int e = bt.first + tid;
             const int i_s = cam_obs[e];
-            const int base = v.pt_ptr[v.o_pt[i_s]];
+            const int base = i_s - v.co_rank[e];  // first observation of the landmark (no pt_ptr / o_pt gathers)
             int off, n, j0;
             if (bt.njj) { off = 0; n = bt.njj; j0 = base + bt.jj0; }
             else { off = cam_obs_off[e]; n = i_s - base; j0 = base; }  // partners: the observations BEFORE i
@@ -725,11 +725,12 @@ void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask
                        const RowBatch* batches, const int* cam_obs, const uint16_t* cam_obs_off, const int* nbr,
                        const double* hinv, int dbg, hipStream_t s) {
     if (n_tasks == 0) return;
+    const unsigned dyn = (unsigned)(dbg >> 8) * 1024u;  // ablation: extra dynamic LDS lowers the occupancy
     // dbg != 0 selects the instrumented build of the kernel (timing ablations only)
-    if (dc == 9 && dbg == 0) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9, false>), dim3(n_tasks), dim3(kRowThreads), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
-    else if (dc == 9) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9, true>), dim3(n_tasks), dim3(kRowThreads), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
-    else if (dbg == 0) hipLaunchKernelGGL((k_schur_rows<6, kRowCap6, false>), dim3(n_tasks), dim3(kRowThreads), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
-    else hipLaunchKernelGGL((k_schur_rows<6, kRowCap6, true>), dim3(n_tasks), dim3(kRowThreads), 0, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
+    if (dc == 9 && dbg == 0) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9, false>), dim3(n_tasks), dim3(kRowThreads), dyn, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
+    else if (dc == 9) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9, true>), dim3(n_tasks), dim3(kRowThreads), dyn, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
+    else if (dbg == 0) hipLaunchKernelGGL((k_schur_rows<6, kRowCap6, false>), dim3(n_tasks), dim3(kRowThreads), dyn, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
+    else hipLaunchKernelGGL((k_schur_rows<6, kRowCap6, true>), dim3(n_tasks), dim3(kRowThreads), dyn, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
 }
 
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,

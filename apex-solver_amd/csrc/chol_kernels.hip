@@ -259,12 +259,12 @@ __global__ __launch_bounds__(256) void k_potrf_inv(const PotrfTask* __restrict__
 // C may alias A (L_IK = S_IK L_KK^-T in place): every global read of A is staged into LDS before the
 // last barrier of the K loop and the epilogue stores come after it.
 // ------------------------------------------------------------------------------------------
-constexpr int KC = 16;
+constexpr int KC = 16;  // 24 (6 chunks) measured the same: the chunk size is not the limiter
 constexpr int PITCH = KC + 2;
 constexpr int STRIP = 48;          // output rows per workgroup (3 waves x 16)
 constexpr int NSTRIP = NB / STRIP; // 3 workgroups per tile: 3x the parallelism of one per tile
 
-__global__ __launch_bounds__(192) void k_tile_gemm_nt(const GemmTask* __restrict__ tasks, int n_units, double alpha,
+__global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restrict__ tasks, int n_units, double alpha,
                                                         double beta) {
     __shared__ double sA[STRIP * PITCH];
     __shared__ double sB[NB * PITCH];
@@ -284,18 +284,19 @@ __global__ __launch_bounds__(192) void k_tile_gemm_nt(const GemmTask* __restrict
     double4_t acc[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    // staging: a 16-column chunk is 8 double2 per row; B: 144 rows -> 1152 double2 = 6 per thread,
-    // A strip: 48 rows -> 384 double2 = 2 per thread
-    double2 rb[6], ra[2];
+    // staging: a KC-column chunk is KC/2 double2 per row; B: 144 rows, A strip: 48 rows
+    constexpr int C2 = KC / 2, NRB = NB * C2 / 192, NRA = STRIP * C2 / 192;
+    static_assert(NB * C2 % 192 == 0 && STRIP * C2 % 192 == 0 && NB % KC == 0 && KC % 4 == 0, "staging loops assume whole rounds");
+    double2 rb[NRB], ra[NRA];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int idx = tid + 192 * i, row = idx >> 3, c2 = idx & 7;
+        for (int i = 0; i < NRB; ++i) {
+            const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
             rb[i] = *reinterpret_cast<const double2*>(t.B + (size_t)row * NB + k0 + 2 * c2);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 192 * i, row = idx >> 3, c2 = idx & 7;
+        for (int i = 0; i < NRA; ++i) {
+            const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
             ra[i] = *reinterpret_cast<const double2*>(Ag + (size_t)row * NB + k0 + 2 * c2);
         }
     };
@@ -303,13 +304,13 @@ __global__ __launch_bounds__(192) void k_tile_gemm_nt(const GemmTask* __restrict
     for (int k0 = 0; k0 < NB; k0 += KC) {
         __syncthreads();  // previous chunk fully consumed
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int idx = tid + 192 * i, row = idx >> 3, c2 = idx & 7;
+        for (int i = 0; i < NRB; ++i) {
+            const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
             sB[row * PITCH + 2 * c2] = rb[i].x; sB[row * PITCH + 2 * c2 + 1] = rb[i].y;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 192 * i, row = idx >> 3, c2 = idx & 7;
+        for (int i = 0; i < NRA; ++i) {
+            const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
             sA[row * PITCH + 2 * c2] = ra[i].x; sA[row * PITCH + 2 * c2 + 1] = ra[i].y;
         }
         __syncthreads();
@@ -329,16 +330,29 @@ __global__ __launch_bounds__(192) void k_tile_gemm_nt(const GemmTask* __restrict
     // loads across possibly aliasing stores -- and holding all 36 values costs 72 VGPRs, i.e. a
     // wave per SIMD of occupancy; 4 at a time measured best: tools/gemm_var.hip.)
     double* __restrict__ C = t.C + (size_t)strip * STRIP * NB;
+    if (beta == 0.0) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = alpha * acc[j][r];
+        return;
+    }
+    // software-pipelined read-modify-write: the loads of column block j+2 are in flight while block j
+    // is stored (three 4-value buffers), so the 9 blocks cost ~3 memory round trips instead of 9
+    double cv[3][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cv[0][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + lr];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cv[1][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + 16 + lr];
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-        double cv[4] = {0.0, 0.0, 0.0, 0.0};
-        if (beta != 0.0) {
+        if (j + 2 < 9) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cv[r] = C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr];
+            for (int r = 0; r < 4; ++r) cv[(j + 2) % 3][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * (j + 2) + lr];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = alpha * acc[j][r] + beta * cv[r];
+            C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = alpha * acc[j][r] + beta * cv[j % 3][r];
     }
 }
 

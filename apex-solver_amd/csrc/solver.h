@@ -130,6 +130,7 @@ class Solver : public LmBackend {
     bool use_rows_ = true;  // Schur reduction: LDS row form (default) or the global-atomics form
     uint32_t *o_cam_ = nullptr, *o_pt_ = nullptr, *co_pt_ = nullptr;
     double2* co_uv_ = nullptr;
+    int* co_rank_ = nullptr;
     double2* o_uv_ = nullptr;
     int *o_orig_ = nullptr, *pt_ptr_ = nullptr, *cam_ptr_ = nullptr, *cam_obs_ = nullptr;
     uint8_t *fix_pose_ = nullptr, *fix_intr_ = nullptr, *fix_pt_ = nullptr;

@@ -35,7 +35,7 @@ Solver::~Solver() {
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
     void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
-                    cam_ptr_, cam_obs_, co_pt_, co_uv_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
+                    cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -61,7 +61,7 @@ BAView Solver::view(int which) const {
     v.camp = camp_[which]; v.pts = pts_[which];
     v.o_cam = o_cam_; v.o_pt = o_pt_; v.o_uv = o_uv_; v.pt_ptr = pt_ptr_;
     v.huber_delta = huber_delta_;
-    v.co_pt = co_pt_; v.co_uv = co_uv_;
+    v.co_pt = co_pt_; v.co_uv = co_uv_; v.co_rank = co_rank_;
     return v;
 }
 
@@ -220,9 +220,11 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     // camera-major copies of (landmark, measurement): k_cam_reduce streams them instead of gathering
     std::vector<uint32_t> co_pt(n_loc);
     std::vector<double> co_uv(2 * n_loc);
+    std::vector<int> co_rank(n_loc);
     for (int64_t k = 0; k < n_loc; ++k) {
         const int i = cam_obs[k];
         co_pt[k] = o_pt[i]; co_uv[2 * k] = o_uv[2 * (size_t)i]; co_uv[2 * k + 1] = o_uv[2 * (size_t)i + 1];
+        co_rank[k] = i - pt_ptr[o_pt[i]];
     }
 
     // ---- tile structure of S (covisibility at tile granularity + symbolic Cholesky fill) -------------
@@ -364,6 +366,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(up(&cam_ptr_, cam_ptr));
     HIP_TRY(up(&cam_obs_, cam_obs));
     HIP_TRY(up(&co_pt_, co_pt));
+    HIP_TRY(up(&co_rank_, co_rank));
     HIP_TRY(up(reinterpret_cast<double**>(&co_uv_), co_uv));
     HIP_TRY(up(&tasks_, tasks));
     HIP_TRY(up(&rtasks_, rtasks));
