@@ -28,6 +28,7 @@ struct BAView {
 // camera-major gather needs from a landmark sits in ONE 128-byte line instead of three arrays.
 constexpr int kLmStride = 16;  // doubles: Hll^-1 (9, row-major) | g_l (3) | point (3) | pad
 constexpr int kLmG = 9, kLmPt = 12;
+constexpr int kLmuStride = 8;  // matrix-free Schur operator: {point(3), -, u_l(3), -} per landmark, 64 bytes
 
 // Lower-triangular tile map of the reduced camera matrix S.
 struct TileMap {
@@ -65,7 +66,13 @@ void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* ca
                        double lambda, int add_lambda, const double* hinv, const double* g_l, int with_self, double* g_c,
                        double* g_red, hipStream_t s);
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag,
-                            hipStream_t s);
+                            double* lmu /* may be NULL */, hipStream_t s);
+// A18 (implicit_schur.rs): y = S x matrix-free, the Schur-Jacobi preconditioner blocks and their application
+void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
+                            double lambda, double* y, hipStream_t s);
+void launch_extract_diag_blocks(int dc, int64_t n_cam, const TileMap& tm, double* sd, hipStream_t s);
+void launch_precond_blocks(int dc, int64_t n_cam, const double* sd, double* minv, hipStream_t s);
+void launch_precond_apply(int dc, int64_t n_cam, const double* minv, const double* r, double* z, hipStream_t s);
 void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const ScatterTask* tasks, int n_tasks,
                           const double* hinv, const double* g_l, double* g_red, hipStream_t s);
 void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, hipStream_t s);
@@ -82,6 +89,9 @@ void launch_cost(const BAView& v, double* partial, int n_partial, double* out_su
 void launch_step_stats(int64_t n, const double* g, const double* d, double lambda, double* partial, int n_partial,
                        double* out3, hipStream_t s);
 void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, double* out, hipStream_t s);
+// out[0] = a1.b1, out[1] = a2.b2 in one pass over the vectors (fixed two-level reduction: reproducible)
+void launch_dot2(int64_t n, const double* a1, const double* b1, const double* a2, const double* b2, double* partial,
+                 int n_partial, double* out, hipStream_t s);
 // out[k] = sum_i partial[i*nk + k] in index order (one block: reproducible)
 void launch_sum_partials(const double* partial, int n, int nk, double* out, hipStream_t s);
 void launch_export_linearization(int dc, const BAView& v, const int* o_orig, double* r_out, double* jc_out,

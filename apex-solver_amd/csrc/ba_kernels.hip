@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "ba_device.hpp"
 #include "ba_kernels.h"
 
@@ -162,7 +164,8 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_reduce(BAView v, TileMap tm
 // ------------------------------------------------------------------------------------------
 template <int DC>
 __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda, double* __restrict__ hinv,
-                                                           double* __restrict__ g_l, int* __restrict__ err_flag) {
+                                                           double* __restrict__ g_l, int* __restrict__ err_flag,
+                                                           double* __restrict__ lmu) {
     const int g = threadIdx.x & 7;
     const int64_t l = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     const bool active = l < v.n_pt;
@@ -208,6 +211,10 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
         for (int i = 0; i < 3; ++i) { hinv[kLmStride * l + kLmG + i] = gl[i]; hinv[kLmStride * l + kLmPt + i] = pw[i]; }
 #pragma unroll
         for (int i = 0; i < 3; ++i) g_l[3 * l + i] = gl[i];
+        if (lmu) {  // matrix-free variant: the point travels with u_l in a 64-byte record
+#pragma unroll
+            for (int i = 0; i < 3; ++i) lmu[kLmuStride * l + i] = pw[i];
+        }
     }
 }
 
@@ -515,7 +522,9 @@ __global__ __launch_bounds__(kRowThreads) void k_schur_rows(BAView v, TileMap tm
 // K3: back-substitution, 8 lanes per landmark: dl = Hll^-1 ((-g)_l - H_cl^T dc)
 // (explicit_schur.rs:980-1029); H_cl^T dc = sum_i Jl_i^T (Jc_i dc_ci).
 // ------------------------------------------------------------------------------------------
-template <int DC>
+// MATVEC = true is the landmark half of the matrix-free Schur operator (A18, implicit_schur.rs:186-226):
+// u_l = Hll^-1 (H_cl^T x), written next to the point into the 64-byte record lmu[l] = {pt, -, u, -}.
+template <int DC, bool MATVEC>
 __global__ __launch_bounds__(256) void k_back_substitute(BAView v, const double* __restrict__ hinv,
                                                            const double* __restrict__ g_l,
                                                            const double* __restrict__ dc,
@@ -550,10 +559,148 @@ __global__ __launch_bounds__(256) void k_back_substitute(BAView v, const double*
         for (int i = 0; i < 3; ++i) acc[i] += __shfl_xor(acc[i], m, 8);
     if (active && g == 0) {
         const double* Hi = hinv + kLmStride * l;
-        const double rhs[3] = {-Hi[kLmG] - acc[0], -Hi[kLmG + 1] - acc[1], -Hi[kLmG + 2] - acc[2]};
+        if (MATVEC) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) dl[3 * l + a] = Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2];
+            for (int a = 0; a < 3; ++a) dl[kLmuStride * l + 4 + a] = Hi[3 * a] * acc[0] + Hi[3 * a + 1] * acc[1] + Hi[3 * a + 2] * acc[2];
+        } else {
+            const double rhs[3] = {-Hi[kLmG] - acc[0], -Hi[kLmG + 1] - acc[1], -Hi[kLmG + 2] - acc[2]};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) dl[3 * l + a] = Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2];
+        }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// A18 camera half of the matrix-free Schur operator, one wave per camera:
+//   y_c = lambda x_c + sum_i Jc_i^T (Jc_i x_c - Jl_i u_l)      (= H_cc x - H_cl Hll^-1 H_cl^T x)
+// ------------------------------------------------------------------------------------------
+template <int DC>
+__global__ __launch_bounds__(64) void k_implicit_cam(BAView v, const int* __restrict__ cam_ptr,
+                                                       const double* __restrict__ lmu, const double* __restrict__ x,
+                                                       double lambda, double* __restrict__ y) {
+    const uint32_t c = blockIdx.x;
+    Cam cam;
+    load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
+    double xc[DC], acc[DC];
+#pragma unroll
+    for (int a = 0; a < DC; ++a) { xc[a] = x[(size_t)c * DC + a]; acc[a] = 0.0; }
+    const int b = cam_ptr[c], e = cam_ptr[c + 1];
+    for (int k = b + (int)threadIdx.x; k < e; k += 64) {
+        const uint32_t l = v.co_pt[k];
+        const double2 uv = v.co_uv[k];
+        const double2* q = reinterpret_cast<const double2*>(lmu + kLmuStride * (size_t)l);
+        const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        const double pw[3] = {q0.x, q0.y, q1.x}, u[3] = {q2.x, q2.y, q3.x};
+        double r[2], Jc[2][DC], Jl[2][3];
+        linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
+        double s0 = -(Jl[0][0] * u[0] + Jl[0][1] * u[1] + Jl[0][2] * u[2]);
+        double s1 = -(Jl[1][0] * u[0] + Jl[1][1] * u[1] + Jl[1][2] * u[2]);
+#pragma unroll
+        for (int a = 0; a < DC; ++a) { s0 += Jc[0][a] * xc[a]; s1 += Jc[1][a] * xc[a]; }
+#pragma unroll
+        for (int a = 0; a < DC; ++a) acc[a] += Jc[0][a] * s0 + Jc[1][a] * s1;
+    }
+#pragma unroll
+    for (int a = 0; a < DC; ++a) {
+        const double t = wave_sum(acc[a]);
+        if (threadIdx.x == 0) y[(size_t)c * DC + a] = t + lambda * xc[a];
+    }
+}
+
+// diagonal DC x DC block of S per camera (lower triangle of the diagonal tile, written by k_cam_reduce with
+// with_self) -> compact symmetric array sd[c][DC*DC]
+template <int DC>
+__global__ __launch_bounds__(256) void k_extract_diag_blocks(int64_t n_cam, TileMap tm, double* __restrict__ sd) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_cam * DC * DC) return;
+    const uint32_t c = (uint32_t)(i / (DC * DC));
+    const int e = (int)(i - (int64_t)c * DC * DC), a = e / DC, b = e - a * DC;
+    const double* blk = s_block_ptr<DC>(tm, c, c);
+    sd[i] = (a >= b) ? blk[a * kNB + b] : blk[b * kNB + a];
+}
+
+// General inverse by Gauss-Jordan with partial pivoting; false when a pivot is exactly zero
+// (nalgebra's try_inverse -> None).
+template <int N>
+__device__ bool try_inverse(const double* A, double* inv) {
+    double M[N][2 * N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) { M[i][j] = A[i * N + j]; M[i][N + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < N; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < N; ++r)
+            if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+        if (M[piv][c] == 0.0) return false;
+        if (piv != c)
+            for (int j = 0; j < 2 * N; ++j) { const double t = M[c][j]; M[c][j] = M[piv][j]; M[piv][j] = t; }
+        const double d = M[c][c];
+        for (int j = 0; j < 2 * N; ++j) M[c][j] /= d;
+        for (int r = 0; r < N; ++r) {
+            if (r == c) continue;
+            const double f = M[r][c];
+            if (f != 0.0)
+                for (int j = 0; j < 2 * N; ++j) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) inv[i * N + j] = M[i][N + j];
+    return true;
+}
+
+// Schur-Jacobi preconditioner (compute_schur_jacobi_preconditioner, implicit_schur.rs:456-573): the
+// reference inverts S_ii per camera-side VARIABLE, i.e. the 6x6 pose block and the 3x3 intrinsics block
+// separately; singular -> + max(1e-6 |trace| / n, 1e-8) I -> identity.  One lane per (camera, block).
+template <int N>
+__device__ void precond_block(const double* sd, int DC, int off, double* minv) {
+    double A[N * N], I[N * N];
+    for (int a = 0; a < N; ++a)
+        for (int b = 0; b < N; ++b) A[a * N + b] = sd[(off + a) * DC + off + b];
+    if (!try_inverse<N>(A, I)) {
+        double tr = 0.0;
+        for (int a = 0; a < N; ++a) tr += A[a * N + a];
+        const double reg = fmax(1e-6 * fabs(tr) / (double)N, 1e-8);
+        for (int a = 0; a < N; ++a) A[a * N + a] += reg;
+        if (!try_inverse<N>(A, I))
+            for (int a = 0; a < N; ++a)
+                for (int b = 0; b < N; ++b) I[a * N + b] = (a == b) ? 1.0 : 0.0;
+    }
+    for (int a = 0; a < N; ++a)
+        for (int b = 0; b < N; ++b) minv[(off + a) * DC + off + b] = I[a * N + b];
+}
+
+template <int DC>
+__global__ __launch_bounds__(64) void k_precond_blocks(int64_t n_cam, const double* __restrict__ sd, double* __restrict__ minv) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t c = t >> 1;
+    const int which = (int)(t & 1);
+    if (c >= n_cam) return;
+    const double* S = sd + (size_t)c * DC * DC;
+    double* M = minv + (size_t)c * DC * DC;
+    if (which == 0) {
+        precond_block<6>(S, DC, 0, M);
+    } else if (DC == 9) {
+        precond_block<3>(S, DC, 6, M);
+        for (int a = 0; a < 6; ++a)
+            for (int b = 6; b < 9; ++b) { M[a * DC + b] = 0.0; M[b * DC + a] = 0.0; }
+    }
+}
+
+// z_c = Minv_c r_c
+template <int DC>
+__global__ __launch_bounds__(256) void k_precond_apply(int64_t n, const double* __restrict__ minv, const double* __restrict__ r,
+                                                         double* __restrict__ z) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t c = i / DC;
+    const int a = (int)(i - c * DC);
+    const double* M = minv + (size_t)c * DC * DC + a * DC;
+    const double* rc = r + (size_t)c * DC;
+    double sacc = 0.0;
+#pragma unroll
+    for (int b = 0; b < DC; ++b) sacc += M[b] * rc[b];
+    z[i] = sacc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -703,11 +850,12 @@ void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* ca
     else hipLaunchKernelGGL(k_cam_reduce<6>, dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
 }
 
-void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag, hipStream_t s) {
+void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag, double* lmu,
+                            hipStream_t s) {
     if (v.n_pt == 0) return;
     const int grid = grid_for(v.n_pt, 32, 0);
-    if (dc == 9) hipLaunchKernelGGL(k_landmark_reduce<9>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag);
-    else hipLaunchKernelGGL(k_landmark_reduce<6>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag);
+    if (dc == 9) hipLaunchKernelGGL(k_landmark_reduce<9>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag, lmu);
+    else hipLaunchKernelGGL(k_landmark_reduce<6>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag, lmu);
 }
 
 void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const ScatterTask* tasks, int n_tasks,
@@ -737,8 +885,8 @@ void launch_back_substitute(int dc, const BAView& v, const double* hinv, const d
                             double* dl, hipStream_t s) {
     if (v.n_pt == 0) return;
     const int grid = grid_for(v.n_pt, 32, 0);
-    if (dc == 9) hipLaunchKernelGGL(k_back_substitute<9>, dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl);
-    else hipLaunchKernelGGL(k_back_substitute<6>, dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl);
+    if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl);
+    else hipLaunchKernelGGL((k_back_substitute<6, false>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl);
 }
 
 void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, const double* intr, const double* pts,
@@ -768,6 +916,55 @@ void launch_step_stats(int64_t n, const double* g, const double* d, double lambd
 void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_sumsq_partial, dim3(n_partial), dim3(256), 0, s, n, x, partial);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n_partial, 1, out);
+}
+
+// y = S x without S: landmark half (u_l into lmu), then camera half
+void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
+                            double lambda, double* y, hipStream_t s) {
+    if (v.n_pt > 0) {
+        const int grid = (int)((v.n_pt + 31) / 32);
+        if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu);
+        else hipLaunchKernelGGL((k_back_substitute<6, true>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu);
+    }
+    if (dc == 9) hipLaunchKernelGGL(k_implicit_cam<9>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, lmu, x, lambda, y);
+    else hipLaunchKernelGGL(k_implicit_cam<6>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, lmu, x, lambda, y);
+}
+void launch_extract_diag_blocks(int dc, int64_t n_cam, const TileMap& tm, double* sd, hipStream_t s) {
+    const int64_t n = n_cam * dc * dc;
+    if (dc == 9) hipLaunchKernelGGL(k_extract_diag_blocks<9>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n_cam, tm, sd);
+    else hipLaunchKernelGGL(k_extract_diag_blocks<6>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n_cam, tm, sd);
+}
+void launch_precond_blocks(int dc, int64_t n_cam, const double* sd, double* minv, hipStream_t s) {
+    const unsigned grid = (unsigned)((2 * n_cam + 63) / 64);
+    if (dc == 9) hipLaunchKernelGGL(k_precond_blocks<9>, dim3(grid), dim3(64), 0, s, n_cam, sd, minv);
+    else hipLaunchKernelGGL(k_precond_blocks<6>, dim3(grid), dim3(64), 0, s, n_cam, sd, minv);
+}
+void launch_precond_apply(int dc, int64_t n_cam, const double* minv, const double* r, double* z, hipStream_t s) {
+    const int64_t n = n_cam * dc;
+    if (dc == 9) hipLaunchKernelGGL(k_precond_apply<9>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, minv, r, z);
+    else hipLaunchKernelGGL(k_precond_apply<6>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, minv, r, z);
+}
+
+// two dot products in one pass: partial[b] = {sum a1 b1, sum a2 b2}
+__global__ __launch_bounds__(256) void k_dot2_partial(int64_t n, const double* __restrict__ a1, const double* __restrict__ b1,
+                                                        const double* __restrict__ a2, const double* __restrict__ b2,
+                                                        double* __restrict__ partial) {
+    __shared__ double scratch[4];
+    double x = 0.0, y = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        x += a1[i] * b1[i];
+        y += a2[i] * b2[i];
+    }
+    x = block_sum_256(x, scratch);
+    y = block_sum_256(y, scratch);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = x; partial[2 * blockIdx.x + 1] = y; }
+}
+// out[0] = a1.b1, out[1] = a2.b2 (fixed geometry: reproducible)
+void launch_dot2(int64_t n, const double* a1, const double* b1, const double* a2, const double* b2, double* partial,
+                 int n_partial, double* out, hipStream_t s) {
+    const int grid = (int)std::min<int64_t>(n_partial, std::max<int64_t>(1, (n + 1023) / 1024));
+    hipLaunchKernelGGL(k_dot2_partial, dim3(grid), dim3(256), 0, s, n, a1, b1, a2, b2, partial);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, grid, 2, out);
 }
 
 void launch_sum_partials(const double* partial, int n, int nk, double* out, hipStream_t s) {

@@ -81,7 +81,8 @@ int apexgpu_get_params(apexgpu_solver* h, double* poses, double* intr, double* p
 int apexgpu_cost(apexgpu_solver* h, double* cost) { H_OR_FAIL; return h->s->cost(cost); }
 int apexgpu_solve_augmented(apexgpu_solver* h, double lambda, int variant, double* step_out, double* grad_out) {
     H_OR_FAIL;
-    if (variant != APEXGPU_VARIANT_SPARSE && variant != APEXGPU_VARIANT_ITERATIVE) return APEXGPU_ERR_INVALID_INPUT;
+    if (variant != APEXGPU_VARIANT_SPARSE && variant != APEXGPU_VARIANT_ITERATIVE && variant != APEXGPU_VARIANT_IMPLICIT)
+        return APEXGPU_ERR_INVALID_INPUT;
     return h->s->solve_augmented(lambda, variant, step_out, grad_out);
 }
 int apexgpu_assemble(apexgpu_solver* h, double lambda) { H_OR_FAIL; return h->s->assemble_only(lambda); }

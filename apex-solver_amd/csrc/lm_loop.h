@@ -41,7 +41,7 @@ struct LmConfig {               // LevenbergMarquardtConfig (levenberg_marquardt
     double min_trust_region_radius; // 1e-32
     double min_cost_threshold;      // < 0: None
     double timeout_s;               // <= 0: None
-    int variant;                    // 0 Sparse (Cholesky), 1 Iterative (Jacobi-PCG on explicit S)
+    int variant;                    // 0 Sparse (Cholesky), 1 Iterative (Jacobi-PCG on explicit S), 2 matrix-free PCG
 };
 
 struct LmIterRecord {  // one row of the per-iteration history

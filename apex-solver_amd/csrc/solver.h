@@ -87,6 +87,8 @@ class Solver : public LmBackend {
     BAView view(int which) const;
     TileMap tilemap() const;
     int assemble(double lambda, double diag_extra);
+    int assemble_implicit(double lambda);
+    int implicit_pcg_solve(double lambda);
     int factor_and_solve(double lambda);
     int cholesky_attempt(int* failed_at);
     int tri_solve();
@@ -144,6 +146,7 @@ class Solver : public LmBackend {
     bool use_nd_ = true;
     int nd_leaf_ = 16;
     double* pcg_buf_ = nullptr;                    // 7 vectors of n_c_pad
+    double *lmu_ = nullptr, *sd_ = nullptr, *minv_ = nullptr;  // matrix-free variant: {pt, u_l} records, diag blocks of S, their inverses
     int n_partial_ = 1024;
 
     bool use_graphs_ = true;

@@ -36,7 +36,7 @@ Solver::~Solver() {
     if (stream_) hipStreamSynchronize(stream_);
     void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
-                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_};
+                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_, lmu_, sd_, minv_};
     for (void* p : ptrs)
         if (p) hipFree(p);
 #ifdef APEX_WITH_RCCL
@@ -405,6 +405,9 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
     HIP_TRY(alloc(&scal_, 32));
     HIP_TRY(alloc(&pcg_buf_, 7 * (size_t)n_c_pad_));
+    HIP_TRY(alloc(&lmu_, (size_t)kLmuStride * n_pt_));
+    HIP_TRY(alloc(&sd_, (size_t)n_cam_ * dc_ * dc_));
+    HIP_TRY(alloc(&minv_, (size_t)n_cam_ * dc_ * dc_));
     if (flags_) hipFree(flags_);
     HIP_TRY(dev_alloc(&flags_, 4));
     HIP_TRY(hipMemset(flags_, 0, 4 * sizeof(int)));
@@ -511,7 +514,7 @@ int Solver::assemble(double lambda, double diag_extra) {
     tp_.add_diag((int)n_c_, 0.0, rank_ == 0 ? 1.0 : 0.0);
     stage_end(kStAssembleCam);
     stage_begin(kStAssembleLm);
-    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, stream_);
+    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_);
     stage_end(kStAssembleLm);
     stage_begin(kStAssembleCam);
     launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, hinv_, g_l_, use_rows_ ? 1 : 0,
@@ -593,18 +596,100 @@ int Solver::pcg_solve() {
     return kOk;
 }
 
+// ---------------------------------------------------------------------------------------------
+// A18: IterativeSchurSolver (src/linalg/sparse/implicit_schur.rs) -- S is never formed.
+//   assemble_implicit : Hll^-1 / g_l (k_landmark_reduce), g_c and g_red plus the DIAGONAL blocks of S
+//                       (k_cam_reduce with its self terms), Schur-Jacobi blocks inverted per variable
+//   implicit_pcg_solve: solve_pcg_block (:577-679); every S p is two passes over the observations
+//                       (landmark-major, then camera-major), nothing but 64 bytes per landmark in between
+// Sharded: g_red, g_c and the diagonal blocks are all-reduced once, every S p once per iteration.
+// ---------------------------------------------------------------------------------------------
+int Solver::assemble_implicit(double lambda) {
+    const BAView v = view(cur_);
+    stage_begin(kStAssembleLm);
+    HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
+    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, lmu_, stream_);
+    stage_end(kStAssembleLm);
+    stage_begin(kStAssembleCam);
+    launch_cam_reduce(dc_, v, tilemap(), cam_ptr_, cam_obs_, lambda, rank_ == 0 ? 1 : 0, hinv_, g_l_, 1, g_c_, g_red_, stream_);
+    launch_extract_diag_blocks(dc_, n_cam_, tilemap(), sd_, stream_);
+    stage_end(kStAssembleCam);
+#ifdef APEX_WITH_RCCL
+    if (comm_ && world_ > 1) {
+        stage_begin(kStAllReduce);
+        ncclComm_t c = reinterpret_cast<ncclComm_t>(comm_);
+        ncclGroupStart();
+        ncclAllReduce(sd_, sd_, (size_t)n_cam_ * dc_ * dc_, ncclDouble, ncclSum, c, stream_);
+        ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
+        ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
+        ncclGroupEnd();
+        stage_end(kStAllReduce);
+    }
+#endif
+    stage_begin(kStAssembleCam);
+    launch_precond_blocks(dc_, n_cam_, sd_, minv_, stream_);
+    stage_end(kStAssembleCam);
+    return kOk;
+}
+
+int Solver::implicit_pcg_solve(double lambda) {
+    stage_begin(kStFactor);
+    const int n = (int)n_c_;
+    const BAView v = view(cur_);
+    double *x = dcam_, *r = pcg_buf_, *z = pcg_buf_ + n_c_pad_, *p = pcg_buf_ + 2 * n_c_pad_, *ap = pcg_buf_ + 3 * n_c_pad_;
+    double* sc = scal_ + 16;
+    HIP_TRY(hipMemsetAsync(x, 0, n_c_pad_ * sizeof(double), stream_));
+    HIP_TRY(hipMemcpyAsync(r, g_red_, n_c_pad_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    launch_precond_apply(dc_, n_cam_, minv_, r, z, stream_);
+    HIP_TRY(hipMemcpyAsync(p, z, n_c_pad_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    launch_dot2(n, r, z, r, r, partial_, n_partial_, sc, stream_);
+    double h[2];
+    HIP_TRY(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    double rz_old = h[0];
+    const double abs_tol = cg_tol_ * std::max(sqrt(h[1]), 1.0);
+    const double lam_local = (rank_ == 0) ? lambda : 0.0;  // the all-reduce sums the ranks' partial S p
+    int it = 0;
+    for (; it < cg_max_iter_; ++it) {
+        launch_implicit_matvec(dc_, v, cam_ptr_, hinv_, lmu_, p, lam_local, ap, stream_);
+#ifdef APEX_WITH_RCCL
+        if (comm_ && world_ > 1)
+            ncclAllReduce(ap, ap, (size_t)n_c_, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
+#endif
+        launch_dot2(n, p, ap, p, ap, partial_, n_partial_, sc, stream_);
+        double pap = 0.0;
+        HIP_TRY(hipMemcpyAsync(&pap, sc, sizeof pap, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (fabs(pap) < 1e-20) break;                          // :610-613
+        const double alpha = rz_old / pap;
+        launch_pcg_update_xr(n, alpha, p, ap, x, r, stream_);
+        launch_precond_apply(dc_, n_cam_, minv_, r, z, stream_);  // used only when the test below does not stop
+        launch_dot2(n, r, r, r, z, partial_, n_partial_, sc, stream_);
+        HIP_TRY(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (sqrt(h[0]) < abs_tol) { ++it; break; }             // :634-641
+        if (fabs(rz_old) < 1e-30) { ++it; break; }             // :652-654
+        const double beta = h[1] / rz_old;
+        launch_pcg_update_p(n, beta, z, p, stream_);
+        rz_old = h[1];
+    }
+    last_pcg_iters_ = it;
+    stage_end(kStFactor);
+    return kOk;
+}
+
 int Solver::solve_augmented(double lambda, int variant, double* step_out, double* grad_out) {
     if (!have_params_) return fail(kInvalidState, "Block structure not built or parameters not set");
     HIP_TRY(hipSetDevice(device_));
     have_step_ = false;
     last_lambda_ = lambda;
-    int rc = assemble(lambda, 0.0);
+    int rc = (variant == 2) ? assemble_implicit(lambda) : assemble(lambda, 0.0);
     if (rc != kOk) return rc;
     int lm_err = 0;
     HIP_TRY(hipMemcpyAsync(&lm_err, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     if (lm_err) return fail(kSingularMatrix, "Landmark block is singular");
-    rc = (variant == 1) ? pcg_solve() : factor_and_solve(lambda);
+    rc = (variant == 2) ? implicit_pcg_solve(lambda) : (variant == 1) ? pcg_solve() : factor_and_solve(lambda);
     if (rc != kOk) return rc;
     stage_begin(kStBackSub);
     launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_);

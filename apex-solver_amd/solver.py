@@ -45,6 +45,8 @@ class LinearSolverType(enum.Enum):
 class SchurVariant(enum.Enum):
     Sparse = 0      # explicit S + Cholesky
     Iterative = 1   # explicit S + Jacobi-PCG (explicit_schur.rs:1117-1120)
+    Implicit = 2    # this backend only: IterativeSchurSolver's matrix-free PCG (implicit_schur.rs), not reachable
+                    # through the reference's LevenbergMarquardt (its Iterative arm forms S explicitly)
 
 
 class SchurPreconditioner(enum.Enum):
@@ -207,7 +209,11 @@ class GpuSchurComplementSolver:
     # builder methods (explicit_schur.rs:219-238)
     def with_variant(self, v: SchurVariant): self.variant = v; return self
     def with_preconditioner(self, _p): return self  # ignored on this path, like the reference
-    def with_cg_params(self, max_iter: int, tol: float): self.cg_max_iterations, self.cg_tolerance = max_iter, tol; return self
+    def with_cg_params(self, max_iter: int, tol: float):
+        self.cg_max_iterations, self.cg_tolerance = int(max_iter), float(tol)
+        if self._h is not None:
+            self._h.check(self._h.L.apexgpu_set_cg_params(self._h.h, self.cg_max_iterations, self.cg_tolerance))
+        return self
     def with_option(self, name: str, value: int):
         """An implementation switch that must be set before initialize_structure (e.g. nested_dissection)."""
         self._pre_options[name] = int(value); return self

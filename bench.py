@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--workload", default=os.environ.get("APEX_BENCH_WORKLOAD", "final-13682"))
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--mode", default="selfcal", choices=["selfcal", "ba"])
-    ap.add_argument("--variant", default="sparse", choices=["sparse", "iterative"])
+    ap.add_argument("--variant", default="sparse", choices=["sparse", "iterative", "implicit"])
+    ap.add_argument("--cg", default="", help="max_iter,tol of the PCG variants (default: the reference's 200,1e-6 / implicit 500,1e-9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0: choose for ~10-30 s of CPU work")
     return ap.parse_args()
@@ -46,6 +47,7 @@ def parse():
 def lm_step(s, state):
     """One LM iteration through the C ABI (mirrors Solver::lm_optimize / the reference loop)."""
     s.solve_augmented_equation(state["lam"], want_step=False)
+    state["pcg"].append(s.info()["pcg_iterations"])
     gn, sn, pred = s.step_stats()
     new_cost = s.eval_step()
     actual = state["cost"] - new_cost
@@ -122,7 +124,11 @@ def main():
     ot = OptimizationType.SelfCalibration if args.mode == "selfcal" else OptimizationType.BundleAdjustment
     prob = Problem.bundle_adjustment(d, ot, 1.0)
     s = GpuSchurComplementSolver(local_rank)
-    s.with_variant(SchurVariant.Sparse if args.variant == "sparse" else SchurVariant.Iterative)
+    s.with_variant({"sparse": SchurVariant.Sparse, "iterative": SchurVariant.Iterative, "implicit": SchurVariant.Implicit}[args.variant])
+    if args.cg:
+        s.with_cg_params(int(args.cg.split(",")[0]), float(args.cg.split(",")[1]))
+    elif args.variant == "implicit":
+        s.with_cg_params(500, 1e-9)  # IterativeSchurSolver::new (implicit_schur.rs:94-95)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         import ctypes as C
@@ -141,7 +147,7 @@ def main():
     setup_s = time.perf_counter() - t_setup
     info = s.info()
 
-    state = dict(lam=1e-3, nu=2.0, cost=s.compute_cost(), accepted=0, hist=[])
+    state = dict(lam=1e-3, nu=2.0, cost=s.compute_cost(), accepted=0, hist=[], pcg=[])
     initial_cost = state["cost"]
     for _ in range(args.warmup):
         lm_step(s, state)
@@ -214,6 +220,8 @@ def main():
         "setup_s": setup_s, "initial_cost": initial_cost, "final_cost": state["cost"], "accepted_steps": state["accepted"],
         "obs_per_s": d.n_obs / (ms_per_step * 1e-3),
     }
+    if args.variant != "sparse":
+        out["pcg_iterations_per_step"] = state["pcg"][args.warmup:]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sc = args.cpu_sample_scale
         if sc <= 0.0:  # ~1000 cameras (dense S of 9000^2, as the reference forms it): 10-30 s of CPU work

@@ -48,6 +48,12 @@ typedef struct apexgpu_solver apexgpu_solver;
 /* SchurVariant (src/linalg/sparse/explicit_schur.rs:58-65) */
 #define APEXGPU_VARIANT_SPARSE 0    /* explicit S + Cholesky (solve_with_cholesky, :539-634) */
 #define APEXGPU_VARIANT_ITERATIVE 1 /* explicit S + Jacobi-PCG (solve_with_pcg, :639-756)    */
+/* IterativeSchurSolver (src/linalg/sparse/implicit_schur.rs:163-251, 456-679, 835-946): S is never formed; PCG on the
+ * matrix-free operator S x = H_cc x - H_cp (H_pp^-1 (H_cp^T x)) with the Schur-Jacobi preconditioner (inverse diagonal
+ * blocks of S per pose / intrinsics variable); tolerance tol*max(|b|,1) with apexgpu_set_cg_params (reference default of
+ * IterativeSchurSolver::new: 500 iterations, 1e-9).  grad_out stays +J^T r as for the other variants (the reference's
+ * IterativeSchurSolver::get_gradient returns -J^T r, :1053-1057, which its LM loop never consumes). */
+#define APEXGPU_VARIANT_IMPLICIT 2
 
 /* ---- lifetime ------------------------------------------------------------------------------
  * Replaces SparseSchurComplementSolver::new() (explicit_schur.rs:205-217) + the per-optimize

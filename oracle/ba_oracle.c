@@ -632,6 +632,146 @@ int ora_solve_pcg(int64_t n, const double *S, const double *b, int64_t max_iter,
     return ORA_OK;
 }
 
+/* ------------------------------------------------------------------------- */
+/* A18: IterativeSchurSolver (src/linalg/sparse/implicit_schur.rs): the reduced  */
+/* system is never formed; S x = H_cc x - H_cp (H_pp^-1 (H_cp^T x))             */
+/* (apply_schur_operator_fast :163-251), Schur-Jacobi preconditioner = inverse  */
+/* of the diagonal blocks of S per camera-side VARIABLE (:456-573: pose 6x6 and */
+/* intrinsics 3x3 blocks), PCG with tol*max(|b|,1) (:577-679).                  */
+/* ------------------------------------------------------------------------- */
+/* general inverse by Gauss-Jordan with partial pivoting; 0 when a pivot is exactly zero
+ * (DMatrix::try_inverse -> None) */
+static int dense_try_inverse(int n, const double *A, double *inv) {
+    double M[9 * 18];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) { M[i * 2 * n + j] = A[i * n + j]; M[i * 2 * n + n + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r)
+            if (fabs(M[r * 2 * n + c]) > fabs(M[piv * 2 * n + c])) piv = r;
+        if (M[piv * 2 * n + c] == 0.0) return 0;
+        if (piv != c)
+            for (int j = 0; j < 2 * n; ++j) { double t = M[c * 2 * n + j]; M[c * 2 * n + j] = M[piv * 2 * n + j]; M[piv * 2 * n + j] = t; }
+        double d = M[c * 2 * n + c];
+        for (int j = 0; j < 2 * n; ++j) M[c * 2 * n + j] /= d;
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            double f = M[r * 2 * n + c];
+            if (f != 0.0)
+                for (int j = 0; j < 2 * n; ++j) M[r * 2 * n + j] -= f * M[c * 2 * n + j];
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) inv[i * n + j] = M[i * 2 * n + n + j];
+    return 1;
+}
+
+/* y = S x without S (implicit_schur.rs:163-251).  Hcc dense nc x nc (damped); H_cp as the per-landmark
+ * merged row lists used above; Hinv = damped, gated 3x3 inverses. */
+static void implicit_apply(int64_t nc, const double *Hcc, int64_t npt, const int64_t *row_ptr, const int64_t *cam_rows,
+                           const double *hcl, const double *Hinv, const double *x, double *y, double *tmp_lm) {
+    for (int64_t i = 0; i < nc; ++i) {
+        double s = 0.0;
+        const double *row = Hcc + i * nc;
+        for (int64_t j = 0; j < nc; ++j) s += row[j] * x[j];
+        y[i] = s;
+    }
+    for (int64_t b = 0; b < npt; ++b) {
+        double t[3] = {0, 0, 0};
+        for (int64_t k = row_ptr[b]; k < row_ptr[b + 1]; ++k)
+            for (int c = 0; c < 3; ++c) t[c] += hcl[3 * k + c] * x[cam_rows[k]];
+        const double *Hi = Hinv + 9 * b;
+        for (int a = 0; a < 3; ++a) tmp_lm[3 * b + a] = Hi[3 * a] * t[0] + Hi[3 * a + 1] * t[1] + Hi[3 * a + 2] * t[2];
+    }
+    for (int64_t b = 0; b < npt; ++b)
+        for (int64_t k = row_ptr[b]; k < row_ptr[b + 1]; ++k)
+            y[cam_rows[k]] -= hcl[3 * k] * tmp_lm[3 * b] + hcl[3 * k + 1] * tmp_lm[3 * b + 1] + hcl[3 * k + 2] * tmp_lm[3 * b + 2];
+}
+
+/* blocks: n_blocks x (start column, size <= 9).  Returns iterations in *iters. */
+int ora_solve_implicit_pcg(int64_t nc, const double *Hcc, int64_t npt, const int64_t *row_ptr, const int64_t *cam_rows,
+                           const double *hcl, const double *Hinv, const double *b, int64_t n_blocks,
+                           const int64_t *blk_start, const int64_t *blk_size, int64_t max_iter, double tol, double *x,
+                           int64_t *iters) {
+    /* Schur-Jacobi blocks: S_ii = H_cc[ii] - sum_l H_cp[i,l] H_pp^-1 H_cp[i,l]^T, inverted (:456-573) */
+    double *Minv = (double *)calloc((size_t)n_blocks * 81, 8);
+    double *Sii = (double *)calloc((size_t)n_blocks * 81, 8);
+    int64_t *blk_of_row = (int64_t *)malloc((size_t)nc * 8);
+    for (int64_t i = 0; i < nc; ++i) blk_of_row[i] = -1;
+    for (int64_t q = 0; q < n_blocks; ++q) {
+        const int64_t s0 = blk_start[q], n = blk_size[q];
+        for (int64_t a = 0; a < n; ++a) {
+            blk_of_row[s0 + a] = q;
+            for (int64_t c = 0; c < n; ++c) Sii[81 * q + a * n + c] = Hcc[(s0 + a) * nc + (s0 + c)];
+        }
+    }
+    for (int64_t l = 0; l < npt; ++l) {
+        const double *Hi = Hinv + 9 * l;
+        for (int64_t k1 = row_ptr[l]; k1 < row_ptr[l + 1]; ++k1) {
+            const int64_t q = blk_of_row[cam_rows[k1]];
+            const int64_t s0 = blk_start[q], n = blk_size[q];
+            double t[3];
+            for (int c = 0; c < 3; ++c) t[c] = hcl[3 * k1] * Hi[c] + hcl[3 * k1 + 1] * Hi[3 + c] + hcl[3 * k1 + 2] * Hi[6 + c];
+            for (int64_t k2 = row_ptr[l]; k2 < row_ptr[l + 1]; ++k2) {
+                if (blk_of_row[cam_rows[k2]] != q) continue;
+                Sii[81 * q + (cam_rows[k1] - s0) * n + (cam_rows[k2] - s0)] -=
+                    t[0] * hcl[3 * k2] + t[1] * hcl[3 * k2 + 1] + t[2] * hcl[3 * k2 + 2];
+            }
+        }
+    }
+    for (int64_t q = 0; q < n_blocks; ++q) {
+        const int n = (int)blk_size[q];
+        double *A = Sii + 81 * q, *I = Minv + 81 * q;
+        if (!dense_try_inverse(n, A, I)) {
+            double tr = 0.0;
+            for (int a = 0; a < n; ++a) tr += A[a * n + a];
+            double reg = fmax(1e-6 * fabs(tr) / (double)n, 1e-8);
+            for (int a = 0; a < n; ++a) A[a * n + a] += reg;
+            if (!dense_try_inverse(n, A, I))
+                for (int a = 0; a < n; ++a)
+                    for (int c = 0; c < n; ++c) I[a * n + c] = (a == c) ? 1.0 : 0.0;
+        }
+    }
+#define APPLY_PRECOND(src, dst)                                                         \
+    for (int64_t q = 0; q < n_blocks; ++q) {                                            \
+        const int64_t s0 = blk_start[q], n = blk_size[q];                               \
+        for (int64_t a = 0; a < n; ++a) {                                               \
+            double s = 0.0;                                                             \
+            for (int64_t c = 0; c < n; ++c) s += Minv[81 * q + a * n + c] * (src)[s0 + c]; \
+            (dst)[s0 + a] = s;                                                          \
+        }                                                                               \
+    }
+    double *r = (double *)malloc((size_t)nc * 8), *z = (double *)calloc((size_t)nc, 8), *pp = (double *)malloc((size_t)nc * 8);
+    double *ap = (double *)malloc((size_t)nc * 8), *tmp = (double *)malloc((size_t)npt * 3 * 8 + 8);
+    double bn = 0.0, rz_old = 0.0;
+    for (int64_t i = 0; i < nc; ++i) { x[i] = 0.0; r[i] = b[i]; bn += b[i] * b[i]; }
+    APPLY_PRECOND(r, z)
+    for (int64_t i = 0; i < nc; ++i) { pp[i] = z[i]; rz_old += r[i] * z[i]; }
+    const double abs_tol = tol * fmax(sqrt(bn), 1.0);
+    int64_t it = 0;
+    for (; it < max_iter; ++it) {
+        implicit_apply(nc, Hcc, npt, row_ptr, cam_rows, hcl, Hinv, pp, ap, tmp);
+        double pap = 0.0;
+        for (int64_t i = 0; i < nc; ++i) pap += pp[i] * ap[i];
+        if (fabs(pap) < 1e-20) break;
+        const double alpha = rz_old / pap;
+        double rn = 0.0;
+        for (int64_t i = 0; i < nc; ++i) { x[i] += alpha * pp[i]; r[i] -= alpha * ap[i]; rn += r[i] * r[i]; }
+        if (sqrt(rn) < abs_tol) { ++it; break; }
+        APPLY_PRECOND(r, z)
+        double rz_new = 0.0;
+        for (int64_t i = 0; i < nc; ++i) rz_new += r[i] * z[i];
+        if (fabs(rz_old) < 1e-30) { ++it; break; }
+        const double beta = rz_new / rz_old;
+        for (int64_t i = 0; i < nc; ++i) pp[i] = z[i] + beta * pp[i];
+        rz_old = rz_new;
+    }
+#undef APPLY_PRECOND
+    if (iters) *iters = it;
+    free(Minv); free(Sii); free(blk_of_row); free(r); free(z); free(pp); free(ap); free(tmp);
+    return ORA_OK;
+}
+
 /* A6-A13 on an arbitrary dense Jacobian whose columns are [cam_dof camera columns |
  * 3*n_pt landmark columns] -- the shape of the reference's unit-test fixture
  * create_schur_test_setup (explicit_schur.rs:1304-1363).  Same sequence as
@@ -822,7 +962,8 @@ static int cmp_i64(const void *a, const void *b) {
 
 /* A6-A13: SparseSchurComplementSolver::solve_augmented_equation
  * (explicit_schur.rs:1129-1234) on the last linearisation.
- * variant 0 = Sparse (Cholesky), 1 = Iterative (Jacobi-PCG on explicit S).
+ * variant 0 = Sparse (Cholesky), 1 = Iterative (Jacobi-PCG on explicit S),
+ * 2 = IterativeSchurSolver semantics (matrix-free PCG, Schur-Jacobi preconditioner; implicit_schur.rs).
  * step_out / grad_out: total_dof, reference global column order.
  * S_out (cam_dof^2, row-major, camera-side columns in reference order) and
  * gred_out (cam_dof) are optional. */
@@ -941,7 +1082,17 @@ int ora_solve_augmented(ora_problem *p, double lambda, int variant, double *step
         ora_reduced_gradient(nc, g_c, npt, g_p, row_ptr, cam_rows, hcl, Hinv, gred);
         if (S_out) memcpy(S_out, S, (size_t)nc * (size_t)nc * 8);
         if (gred_out) memcpy(gred_out, gred, (size_t)nc * 8);
-        if (variant == 1) rc = ora_solve_pcg(nc, S, gred, p->cg_max_iter, p->cg_tol, dc, &p->last_pcg_iters);
+        if (variant == 2) {
+            /* camera-side variable blocks of the reference's SchurBlockStructure: one per intr_* (3) and pose_* (6) */
+            int64_t nb = 2 * p->n_cam, *bs = (int64_t *)malloc((size_t)nb * 8), *bz = (int64_t *)malloc((size_t)nb * 8);
+            for (int64_t c = 0; c < p->n_cam; ++c) {
+                bs[2 * c] = p->pose_col[c] - cam0; bz[2 * c] = 6;
+                bs[2 * c + 1] = p->intr_col[c] - cam0; bz[2 * c + 1] = 3;
+            }
+            rc = ora_solve_implicit_pcg(nc, Hcc, npt, row_ptr, cam_rows, hcl, Hinv, gred, nb, bs, bz, p->cg_max_iter, p->cg_tol,
+                                        dc, &p->last_pcg_iters);
+            free(bs); free(bz);
+        } else if (variant == 1) rc = ora_solve_pcg(nc, S, gred, p->cg_max_iter, p->cg_tol, dc, &p->last_pcg_iters);
         else rc = ora_solve_cholesky(nc, S, gred, dc, &p->last_reg);
     }
     if (rc == ORA_OK) {

@@ -167,6 +167,51 @@ def test_pcg_variant_vs_oracle(oracle, mode):
     s.close()
 
 
+@pytest.mark.parametrize("mode", ["selfcal", "ba"])
+def test_implicit_schur_pcg_vs_oracle(oracle, mode):
+    """A18 / BASELINE configs[4] semantics: matrix-free PCG with the Schur-Jacobi preconditioner
+    (IterativeSchurSolver, implicit_schur.rs) against the oracle's restatement of the same iteration."""
+    d = pkg.synthetic.make_problem(30, 1500, 3, 7, config_id=78)
+    prob, s = gpu_solver(d, mode, variant=SchurVariant.Implicit)
+    s.with_cg_params(500, 1e-9)
+    o = oracle_problem(oracle, d, prob, mode)
+    o.set_cg_params(500, 1e-9)
+    o.linearize()
+    ostep, ograd, oS, ogred = o.solve_augmented(1e-3, 0, want_schur=True)
+    istep, _ = o.solve_augmented(1e-3, 2)
+    step = s.solve_augmented_equation(1e-3)
+    nc = prob.layout.cam_dof
+    print("implicit pcg iterations gpu/oracle", s.info()["pcg_iterations"], o.last_pcg_iters)
+    assert abs(s.info()["pcg_iterations"] - o.last_pcg_iters) <= max(3, o.last_pcg_iters // 20)
+    assert rel(s.get_gradient(), ograd) < 1e-12
+    r_gpu = np.linalg.norm(oS @ step[:nc] - ogred); r_ora = np.linalg.norm(oS @ istep[:nc] - ogred)
+    assert r_gpu < 10 * max(r_ora, 1e-9 * max(np.linalg.norm(ogred), 1.0))
+    # landmark part: back-substitution of the camera step it found
+    lay = prob.layout
+    A = np.linalg.norm(step - istep) / np.linalg.norm(istep)
+    print("step vs oracle implicit", A, "vs Cholesky", np.linalg.norm(step - ostep) / np.linalg.norm(ostep))
+    gn, sn, pred = s.step_stats()
+    nc_cost = s.eval_step()
+    assert nc_cost < s.compute_cost() or pred > 0
+    s.discard_step()
+    s.close()
+
+
+def test_implicit_variant_lm_converges():
+    d = pkg.synthetic.make_problem(40, 3000, 3, 7, config_id=79)
+    prob = Problem.bundle_adjustment(d, OptimizationType.SelfCalibration, 1.0)
+    res = {}
+    for v in (SchurVariant.Sparse, SchurVariant.Implicit):
+        cfg = LevenbergMarquardtConfig.for_bundle_adjustment().with_schur_variant(v).with_max_iterations(8)
+        lm = LevenbergMarquardt.with_config(cfg)
+        s = GpuSchurComplementSolver(0).with_cg_params(500, 1e-9)
+        res[v] = lm.optimize(prob, solver=s)
+        s.close()
+    a, b = res[SchurVariant.Sparse], res[SchurVariant.Implicit]
+    assert b.final_cost < 0.5 * b.initial_cost
+    assert abs(a.final_cost - b.final_cost) <= 1e-3 * a.final_cost
+
+
 def test_full_normal_equations_from_exported_blocks():
     """Size-independent property: with J rebuilt (scipy.sparse) from the blocks the GPU exports, the
     returned step solves (J^T J + lambda I) dx = -J^T r and the returned gradient is J^T r."""
