@@ -173,7 +173,7 @@ def main():
     stages = s.stage_times()
     ms_per_step = elapsed * 1e3 / args.steps
 
-    # ---- roofline of the dominant Schur kernel (k_schur_scatter), per launch ------------------------
+    # ---- roofline of the graded Schur-reduction kernel (k_schur_rows), per launch -----------------------
     dc = 9 if args.mode == "selfcal" else 6
     n_obs_local = info["local_obs"]
     tile_bytes = 144 * 144 * 8

@@ -822,7 +822,13 @@ int ora_schur_solve_dense_jacobian(int64_t n_rows, int64_t cam_dof, int64_t n_pt
         ora_schur_complement(cam_dof, Hcc, n_pt, row_ptr, cam_rows, hcl, Hinv, S);
         ora_reduced_gradient(cam_dof, g_c, n_pt, g_p, row_ptr, cam_rows, hcl, Hinv, gred);
         int64_t its;
-        if (variant == 1) rc = ora_solve_pcg(cam_dof, S, gred, cg_max_iter, cg_tol, step_out, &its);
+        if (variant == 2) { /* IterativeSchurSolver on the fixture: camera variables are 6-DOF blocks */
+            int64_t nb = cam_dof / 6, *bs = (int64_t *)malloc((size_t)nb * 8), *bz = (int64_t *)malloc((size_t)nb * 8);
+            for (int64_t q = 0; q < nb; ++q) { bs[q] = 6 * q; bz[q] = 6; }
+            rc = ora_solve_implicit_pcg(cam_dof, Hcc, n_pt, row_ptr, cam_rows, hcl, Hinv, gred, nb, bs, bz, cg_max_iter, cg_tol,
+                                        step_out, &its);
+            free(bs); free(bz);
+        } else if (variant == 1) rc = ora_solve_pcg(cam_dof, S, gred, cg_max_iter, cg_tol, step_out, &its);
         else rc = ora_solve_cholesky(cam_dof, S, gred, step_out, NULL);
     }
     if (rc == ORA_OK) ora_back_substitute(n_pt, step_out, g_p, row_ptr, cam_rows, hcl, Hinv, step_out + cam_dof);

@@ -159,6 +159,19 @@ def test_schur_fixture_structure(oracle):
     assert np.allclose(H[:12, :12], 3 * np.eye(12)) and np.allclose(H[12:, 12:], 4 * np.eye(9))
 
 
+def test_iterative_schur_fixture(oracle):
+    """implicit_schur.rs:1231-1260, 1371-1394 on the same fixture: 21-vector, different lambda -> different
+    update; and, stronger, the matrix-free PCG lands on the damped normal equations' solution."""
+    sols = []
+    for lam in (0.001, 100.0):
+        rc, step, grad, J, r = _fixture_solve(oracle, lam, 2)
+        assert rc == 0 and step.shape == (21,)
+        H = J.T @ J + lam * np.eye(21)
+        assert np.linalg.norm(H @ step + J.T @ r) <= 1e-5 * max(np.linalg.norm(J.T @ r), 1.0)
+        sols.append(step)
+    assert np.sum((sols[0] - sols[1]) ** 2) > 1e-10
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_explicit_schur_augmented_solves_damped_normal_equations(oracle, variant):
     """solve_augmented_equation (explicit_schur.rs:1129-1234) == (J^T J + lambda I) dx = -J^T r."""
