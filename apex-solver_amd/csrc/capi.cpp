@@ -111,6 +111,12 @@ int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out, double* gl_
     return h->s->get_landmark_blocks(hinv_out, gl_out);
 }
 
+int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, double* y_explicit, double* y_implicit) {
+    H_OR_FAIL;
+    if (!x_in) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->schur_matvec(lambda, x_in, y_explicit, y_implicit);
+}
+
 int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     H_OR_FAIL;
     const std::string n = name ? name : "";

@@ -893,6 +893,42 @@ int Solver::get_schur(double* S_out, double* gred_out) {
     return kOk;
 }
 
+// Parity export: y = S x through BOTH implementations of the reduced camera matrix -- the explicit tiles
+// (k_cam_reduce + k_schur_rows, multiplied by the symmetric tile product) and the matrix-free operator of
+// the implicit variant -- for the same lambda.  x and the outputs are in the reference's camera-side column
+// order (9 n_cam entries).  Two independent code paths that must agree at any problem size.
+int Solver::schur_matvec(double lambda, const double* x_in, double* y_explicit, double* y_implicit) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    have_step_ = false;
+    const int64_t nref = 9 * n_cam_;
+    auto ref_row = [&](int64_t i) -> int64_t {
+        const int64_t ci = i / dc_; const int a = (int)(i - ci * dc_);
+        const int64_t c = cinv_[ci];
+        return a < 6 ? pose_col_[c] + a : intr_col_[c] + (a - 6);
+    };
+    std::vector<double> h(n_c_pad_, 0.0);
+    for (int64_t i = 0; i < n_c_; ++i) h[i] = x_in[ref_row(i)];
+    double *xd = pcg_buf_, *yd = pcg_buf_ + n_c_pad_;
+    HIP_TRY(hipMemcpyAsync(xd, h.data(), n_c_pad_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    for (int pass = 0; pass < 2; ++pass) {
+        double* out = pass == 0 ? y_explicit : y_implicit;
+        if (!out) continue;
+        int rc = pass == 0 ? assemble(lambda, 0.0) : assemble_implicit(lambda);
+        if (rc != kOk) return rc;
+        if (pass == 0) tp_.sym_matvec(xd, yd);
+        else launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xd, lambda, yd, stream_);
+        HIP_TRY(hipMemcpyAsync(h.data(), yd, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        std::fill(out, out + nref, 0.0);
+        for (int64_t i = 0; i < n_c_; ++i) out[ref_row(i)] = h[i];
+        if (dc_ == 6)  // intrinsic variables exist but no factor touches them: S_ii = lambda
+            for (int64_t c = 0; c < n_cam_; ++c)
+                for (int a = 0; a < 3; ++a) out[intr_col_[c] + a] = lambda * x_in[intr_col_[c] + a];
+    }
+    return kOk;
+}
+
 int Solver::get_landmark_blocks(double* hinv_out, double* gl_out) {
     if (!have_params_) return fail(kInvalidState, "no parameters set");
     HIP_TRY(hipSetDevice(device_));

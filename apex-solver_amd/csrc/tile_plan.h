@@ -55,6 +55,8 @@ class TilePlan {
     hipError_t factor(int* failed_at);
     // x = (L L^T)^-1 rhs ; work: 2*n_pad doubles ; all on the plan's stream, no sync
     void solve(const double* rhs, double* x, double* work);
+    // y = A x on the UNFACTORED tiles (deterministic two-pass symmetric product), no sync
+    void sym_matvec(const double* x, double* y);
     // Jacobi-PCG on the UNFACTORED tiles; work: 6*n_pad doubles; syncs once per iteration
     hipError_t pcg(const double* rhs, double* x, double* work, int max_iter, double tol, int* iters);
 

@@ -381,6 +381,11 @@ void TilePlan::solve(const double* rhs, double* x, double* work) {
     if (!run_graph(1, rhs, x, work)) enqueue_solve(rhs, x, work);
 }
 
+void TilePlan::sym_matvec(const double* x, double* y) {
+    launch_sym_tile_products(sym_tiles_, n_sym_tiles_, tiles_, x, sym_part_, stream_);
+    launch_sym_tile_gather(nt_, sym_row_ptr_, sym_entries_, sym_part_, x, y, row_dot_, stream_);
+}
+
 // solve_with_pcg (explicit_schur.rs:639-756).  Per iteration: one pass over the non-zero tiles
 // (k_sym_tile_products + k_sym_tile_gather, which also yields p.Ap), two fused vector kernels that keep
 // alpha/beta on the device, and ONE host read-back of {p.Ap, r.r, r.z} for the reference's three

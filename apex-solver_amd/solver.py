@@ -324,6 +324,15 @@ class GpuSchurComplementSolver:
         h.check(h.L.apexgpu_get_schur(h.h, capi.ptr(S), capi.ptr(g)))
         return S, g
 
+    def schur_matvec(self, lam: float, x: np.ndarray, explicit=True, implicit=True):
+        """y = S x (reference camera-side column order) through the explicit tiles and the matrix-free operator."""
+        h = self._need()
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        ye = np.zeros_like(x) if explicit else None
+        yi = np.zeros_like(x) if implicit else None
+        h.check(h.L.apexgpu_schur_matvec(h.h, float(lam), capi.ptr(x), capi.ptr(ye), capi.ptr(yi)))
+        return ye, yi
+
     def get_landmark_blocks(self):
         h = self._need()
         hi = np.zeros((h.n_pt, 3, 3)); gl = np.zeros((h.n_pt, 3))

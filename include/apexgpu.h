@@ -163,6 +163,11 @@ int apexgpu_get_jacobian_blocks(apexgpu_solver* h, double* jc_out, double* jl_ou
  * column order, for the last lambda; either may be NULL */
 int apexgpu_get_schur(apexgpu_solver* h, double* S_out, double* gred_out);
 int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out /* n_pt*9 */, double* gl_out /* n_pt*3 */);
+/* y = S x at the current parameters through both implementations of the reduced camera matrix: the explicit tiles
+ * (compute_schur_complement, explicit_schur.rs:771-925) and the matrix-free operator (apply_schur_operator_fast,
+ * implicit_schur.rs:163-251).  x_in and the outputs have 9 n_cam entries in the reference's camera-side column
+ * order; either output may be NULL.  A size-independent parity property: the two must agree. */
+int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, double* y_explicit, double* y_implicit);
 
 /* Implementation switches (defaults in parentheses), for A/B tests and profiling:
  *   "schur_rows" (1)  Schur reduction in the LDS row form (k_schur_rows, no global atomics); 0 selects
