@@ -264,6 +264,12 @@ constexpr int PITCH = KC + 2;
 constexpr int STRIP = 48;          // output rows per workgroup (3 waves x 16)
 constexpr int NSTRIP = NB / STRIP; // 3 workgroups per tile: 3x the parallelism of one per tile
 
+
+typedef double __attribute__((address_space(1)))* GlobalF64;
+typedef const double __attribute__((address_space(1)))* GlobalCF64;
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+typedef const f64x2_t __attribute__((address_space(1)))* GlobalCF64x2;
+
 __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restrict__ tasks, int n_units, double alpha,
                                                         double beta) {
     __shared__ double sA[STRIP * PITCH];
@@ -276,11 +282,16 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
     const int per_xcd = (n_units + 7) >> 3;
     const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
-    const GemmTask t = tasks[unit / NSTRIP];
+    const GemmTask tg = tasks[unit / NSTRIP];
+    // The task's pointers are loaded from memory, so the compiler only knows them as generic (flat)
+    // addresses; flat loads count on lgkmcnt as well as vmcnt, which makes every wait for an LDS read also
+    // wait for the global prefetch of the next chunk.  Re-typed as global (address space 1) they become
+    // global_load / global_store and the prefetch stays asynchronous.
+    struct { GlobalF64 C; GlobalCF64 A; GlobalCF64 B; } t = {(GlobalF64)tg.C, (GlobalCF64)tg.A, (GlobalCF64)tg.B};
     const int strip = unit % NSTRIP;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
-    const double* __restrict__ Ag = t.A + (size_t)strip * STRIP * NB;
+    GlobalCF64 Ag = t.A + (size_t)strip * STRIP * NB;
     double4_t acc[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -292,12 +303,12 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
 #pragma unroll
         for (int i = 0; i < NRB; ++i) {
             const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
-            rb[i] = *reinterpret_cast<const double2*>(t.B + (size_t)row * NB + k0 + 2 * c2);
+            { const f64x2_t q = *reinterpret_cast<GlobalCF64x2>(t.B + (size_t)row * NB + k0 + 2 * c2); rb[i].x = q.x; rb[i].y = q.y; }
         }
 #pragma unroll
         for (int i = 0; i < NRA; ++i) {
             const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
-            ra[i] = *reinterpret_cast<const double2*>(Ag + (size_t)row * NB + k0 + 2 * c2);
+            { const f64x2_t q = *reinterpret_cast<GlobalCF64x2>(Ag + (size_t)row * NB + k0 + 2 * c2); ra[i].x = q.x; ra[i].y = q.y; }
         }
     };
     gload(0);
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
     // load-modify-store per element serialises 36 memory round trips -- the compiler cannot move
     // loads across possibly aliasing stores -- and holding all 36 values costs 72 VGPRs, i.e. a
     // wave per SIMD of occupancy; 4 at a time measured best: tools/gemm_var.hip.)
-    double* __restrict__ C = t.C + (size_t)strip * STRIP * NB;
+    GlobalF64 C = t.C + (size_t)strip * STRIP * NB;
     if (beta == 0.0) {
 #pragma unroll
         for (int j = 0; j < 9; ++j)
@@ -339,6 +350,86 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
     }
     // software-pipelined read-modify-write: the loads of column block j+2 are in flight while block j
     // is stored (three 4-value buffers), so the 9 blocks cost ~3 memory round trips instead of 9
+    double cv[3][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cv[0][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + lr];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cv[1][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + 16 + lr];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        if (j + 2 < 9) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[(j + 2) % 3][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * (j + 2) + lr];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = alpha * acc[j][r] + beta * cv[j % 3][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Large batches: ONE 576-thread workgroup (9 waves) per task.  B is staged once per tile instead of once
+// per 48-row strip, the K chunks alternate between two LDS buffers (one barrier per chunk), so a wave's
+// global prefetch, LDS stores and MFMAs of neighbouring chunks overlap.  42-45 TF/s on batches of
+// thousands of tasks against 35 for the strip kernel (tools/gemm_var.hip); the strip kernel keeps the
+// small batches near the root of the elimination tree, where 3x the workgroups matter more.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(576) void k_tile_gemm_nt_full(const GemmTask* __restrict__ tasks, int n_tasks, double alpha,
+                                                             double beta) {
+    __shared__ double sA[2][NB * PITCH];
+    __shared__ double sB[2][NB * PITCH];
+    const int per_xcd = (n_tasks + 7) >> 3;
+    const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_tasks) return;
+    const GemmTask tg = tasks[unit];
+    struct { GlobalF64 C; GlobalCF64 A; GlobalCF64 B; } t = {(GlobalF64)tg.C, (GlobalCF64)tg.A, (GlobalCF64)tg.B};
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    double4_t acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    constexpr int C2 = KC / 2, NR = NB * C2 / 576;  // 1152 double2 per operand chunk: 2 per thread
+    static_assert(NB * C2 % 576 == 0, "staging loops assume whole rounds");
+    f64x2_t rb[NR], ra[NR];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            rb[i] = *reinterpret_cast<GlobalCF64x2>(t.B + (size_t)row * NB + k0 + 2 * c2);
+            ra[i] = *reinterpret_cast<GlobalCF64x2>(t.A + (size_t)row * NB + k0 + 2 * c2);
+        }
+    };
+    gload(0);
+    int buf = 0;
+    for (int k0 = 0; k0 < NB; k0 += KC, buf ^= 1) {
+        // buffer `buf` was last read two chunks ago; the barrier of the previous chunk separates those reads
+        // from these stores
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            sB[buf][row * PITCH + 2 * c2] = rb[i].x; sB[buf][row * PITCH + 2 * c2 + 1] = rb[i].y;
+            sA[buf][row * PITCH + 2 * c2] = ra[i].x; sA[buf][row * PITCH + 2 * c2 + 1] = ra[i].y;
+        }
+        __syncthreads();
+        if (k0 + KC < NB) gload(k0 + KC);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            const double a = sA[buf][(16 * w + lr) * PITCH + kk + lk];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const double b = sB[buf][(16 * j + lr) * PITCH + kk + lk];
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    GlobalF64 C = t.C;
+    if (beta == 0.0) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = alpha * acc[j][r];
+        return;
+    }
     double cv[3][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) cv[0][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + lr];
@@ -777,8 +868,13 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const 
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_potrf_inv, dim3(n), dim3(256), 0, s, tasks, fail);
 }
-void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s) {
+void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, int full_tile_min) {
     if (n <= 0) return;
+    if (n >= full_tile_min) {  // one task per CU and more: the full-tile kernel
+        const int per_xcd = (n + 7) / 8;
+        hipLaunchKernelGGL(k_tile_gemm_nt_full, dim3(8 * per_xcd), dim3(576), 0, s, tasks, n, alpha, beta);
+        return;
+    }
     const int units = n * NSTRIP, per_xcd = (units + 7) / 8;
     hipLaunchKernelGGL(k_tile_gemm_nt, dim3(8 * per_xcd), dim3(192), 0, s, tasks, units, alpha, beta);
 }

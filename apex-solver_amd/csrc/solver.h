@@ -65,6 +65,7 @@ class Solver : public LmBackend {
     void enable_stage_timing(bool on) { timer_.enable(on); }
     void enable_graphs(bool on) { use_graphs_ = on; tp_.enable_graphs(on); }
     void enable_overlap(bool on) { tp_.enable_overlap(on); }
+    void set_gemm_full_tile_min(int n) { tp_.set_gemm_full_tile_min(n); }
     void use_row_schur(bool on) { use_rows_ = on; }
     void set_rows_debug(int v) { rows_dbg_ = v; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }

@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--variant", default="sparse", choices=["sparse", "iterative", "implicit"])
     ap.add_argument("--cg", default="", help="max_iter,tol of the PCG variants (default: the reference's 200,1e-6 / implicit 500,1e-9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="implementation switch name=value (apexgpu_set_option), repeatable")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0: choose for ~10-30 s of CPU work")
     return ap.parse_args()
 
@@ -129,6 +130,8 @@ def main():
         s.with_cg_params(int(args.cg.split(",")[0]), float(args.cg.split(",")[1]))
     elif args.variant == "implicit":
         s.with_cg_params(500, 1e-9)  # IterativeSchurSolver::new (implicit_schur.rs:94-95)
+    for o in args.opt:
+        s.with_option(o.split("=")[0], int(o.split("=")[1]))
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         import ctypes as C

@@ -4,6 +4,11 @@
 #include <stdio.h>
 #include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef const d2v __attribute__((address_space(1)))* GC2;
+typedef double __attribute__((address_space(1)))* GD;
+// the task pointers are re-typed as global (address space 1): flat loads would count on lgkmcnt and
+// serialise the prefetch with the LDS reads
 struct Task { double* C; const double* A; const double* B; };
 constexpr int NB = 144;
 
@@ -31,13 +36,13 @@ __global__ __launch_bounds__(64 * NW) void k_gemm(const Task* __restrict__ tasks
         for (int i = 0; i < LB; ++i) {
             const int idx = tid + NT * i;
             if (idx < NB2) { const int row = idx / D2_PER_ROW, c2 = idx % D2_PER_ROW;
-                rb[slot][i] = *reinterpret_cast<const double2*>(t.B + (size_t)row * NB + k0 + 2 * c2); }
+                const d2v q = *(GC2)(t.B + (size_t)row * NB + k0 + 2 * c2); rb[slot][i].x = q.x; rb[slot][i].y = q.y; }
         }
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int idx = tid + NT * i;
             if (idx < NA2) { const int row = idx / D2_PER_ROW, c2 = idx % D2_PER_ROW;
-                ra[slot][i] = *reinterpret_cast<const double2*>(Ag + (size_t)row * NB + k0 + 2 * c2); }
+                const d2v q = *(GC2)(Ag + (size_t)row * NB + k0 + 2 * c2); ra[slot][i].x = q.x; ra[slot][i].y = q.y; }
         }
     };
 #pragma unroll
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm(const Task* __restrict__ tasks
             for (int j = 0; j < 9; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[(16 * j + lr) * PITCH + kk + lk], acc[j], 0, 0, 0);
         }
     }
-    double* __restrict__ C = t.C + (size_t)strip * ROWS * NB;
+    GD C = (GD)(t.C + (size_t)strip * ROWS * NB);
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         double cv[4];
@@ -103,10 +108,10 @@ int main(int argc, char** argv) {
         printf("mode %d (%s)\n", mode, mode == 2 ? "cache resident" : "streaming");
         run<16, 1, 3>("KC16 PF1 3 waves", d, n_tasks);
         run<16, 2, 3>("KC16 PF2 3 waves", d, n_tasks);
-        run<32, 1, 3>("KC32 PF1 3 waves", d, n_tasks);
+        run<24, 1, 3>("KC24 PF1 3 waves", d, n_tasks);
         run<16, 1, 9>("KC16 PF1 9 waves", d, n_tasks);
         run<16, 2, 9>("KC16 PF2 9 waves", d, n_tasks);
-        run<32, 1, 9>("KC32 PF1 9 waves", d, n_tasks);
+        run<24, 1, 9>("KC24 PF1 9 waves", d, n_tasks);
         run<16, 1, 3, 1>("KC16 PF1 3 waves dbuf", d, n_tasks);
         run<16, 1, 9, 1>("KC16 PF1 9 waves dbuf", d, n_tasks);
         run<8, 1, 3, 1>("KC8 PF1 3 waves dbuf", d, n_tasks);

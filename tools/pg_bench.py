@@ -15,7 +15,7 @@ from apex_solver_amd.pose_graph import GpuSparseCholeskySolver, PoseGraphProblem
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for i, a in enumerate(sys.argv[1:]) if not a.startswith("--") and not sys.argv[i].startswith("--")]
     rings, per = (int(args[0]), int(args[1])) if len(args) >= 2 else (50, 50)
     nd = 2
     if "--nd" in sys.argv:
@@ -23,6 +23,9 @@ def main():
     d = pkg.synthetic.make_sphere(rings, per)
     prob = PoseGraphProblem.pose_graph(d)
     s = GpuSparseCholeskySolver().with_option("nested_dissection", nd)
+    for opt in ("update_overlap", "gemm_full_tile_min"):
+        if "--" + opt in sys.argv:
+            s.with_option(opt, int(sys.argv[sys.argv.index("--" + opt) + 1]))
     t0 = time.perf_counter(); s.initialize_structure(prob); setup = time.perf_counter() - t0
     s.set_parameters(d.poses)
     lam = 1e-3
