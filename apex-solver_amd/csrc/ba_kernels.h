@@ -57,6 +57,19 @@ struct RowBatch {  // <= kRowBatch pairs: camera-major observations [first, firs
     int total;           // pairs in the batch
 };
 
+// k_schur_rows2: one lane per observation i of the row camera, looping over its partner observations.
+struct RowEntry {  // (a piece of) one observation of the row camera
+    int k;         // camera-major index (co_pt / co_uv)
+    int j0;        // landmark-major index of the first partner handled by this entry
+    int n;         // partners handled: observations j0 .. j0+n-1 (all BEFORE i in the landmark's list), 1..kRowMaxPartners
+    int pad;
+};
+struct RowChunk {  // <= 64 entries with (nearly) equal partner counts: the work of one wave
+    int first, count;
+    int nmax;      // largest n in the chunk = trip count of the wave's partner loop
+};
+constexpr int kRowMaxPartners = 64;  // an observation with more partners is split into several entries
+
 struct ScatterTask {
     int i0, ni;  // first block of observations (landmark-major indices)
     int j0, nj;  // second block (nj == 0: diagonal task)
@@ -79,6 +92,8 @@ void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr,
 void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
                        const RowBatch* batches, const int* cam_obs, const uint16_t* cam_obs_off, const int* nbr,
                        const double* hinv, int dbg, hipStream_t s);
+void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
+                        const RowChunk* chunks, const RowEntry* entries, const int* nbr, const double* hinv, hipStream_t s);
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
                             double* dl, hipStream_t s);
 void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, const double* intr, const double* pts,

@@ -519,6 +519,121 @@ __global__ __launch_bounds__(kRowThreads) void k_schur_rows(BAView v, TileMap tm
 }
 
 // ------------------------------------------------------------------------------------------
+// K2d: the row form again, one lane per OBSERVATION.  k_schur_rows gives every (i, j) pair its own lane, so
+// the ~3 lanes that share an observation i repeat its linearisation and Y_i = W_i Hll^-1, and every batch of
+// pairs needs an expansion phase with two workgroup barriers.  Here a lane owns an observation i of the row
+// camera: it linearises i once, keeps -Y_i in registers and walks its partner observations j (the ones before
+// i in the landmark's list) in a loop; entries are sorted by partner count on the host, so the 64 lanes of a
+// wave run the same number of trips.  No pair expansion, no LDS index arrays, no barrier between the initial
+// staging and the final store: the four waves of a workgroup drift apart and hide each other's gathers.
+// Same arithmetic and the same LDS accumulation (81 ds_add_f64 per pair) as k_schur_rows.
+// ------------------------------------------------------------------------------------------
+template <int DC, int CAP>
+__global__ __launch_bounds__(256) void k_schur_rows2(BAView v, TileMap tm, const RowTask* __restrict__ tasks,
+                                                       const RowChunk* __restrict__ chunks,
+                                                       const RowEntry* __restrict__ entries,
+                                                       const int* __restrict__ nbr, const double* __restrict__ hinv) {
+    constexpr int E = DC * DC;
+    __shared__ double acc[CAP * E];
+    __shared__ double scam[CAP * kCamPitch];
+    __shared__ int hkey[kHashSize], hval[kHashSize];
+    const RowTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t ci = (uint32_t)t.cam;
+    for (int idx = tid; idx < CAP * E; idx += 256) acc[idx] = 0.0;
+    for (int idx = tid; idx < kHashSize; idx += 256) hkey[idx] = -1;
+    __syncthreads();
+    if (tid < t.nnbr) {
+        const int key = nbr[t.nbr0 + tid];
+        unsigned h = ((unsigned)key * 2654435761u) >> 24;
+        while (atomicCAS(&hkey[h], -1, key) != -1) h = (h + 1) & (kHashSize - 1);
+        hval[h] = tid;
+    }
+    for (int idx = tid; idx < t.nnbr * kCamStride; idx += 256) {
+        const int sl = idx / kCamStride, k = idx - sl * kCamStride;
+        scam[sl * kCamPitch + k] = v.camp[(size_t)nbr[t.nbr0 + sl] * kCamStride + k];
+    }
+    __syncthreads();
+    Cam cam_i;
+    load_cam_prepared(v.camp + kCamStride * (size_t)ci, cam_i);
+
+    for (int ch = t.batch0 + w; ch < t.batch0 + t.nbatch; ch += 4) {
+        const RowChunk ck = chunks[ch];
+        const bool act = lane < ck.count;
+        int j0 = 0, n = 0;
+        double Y[DC][3], pw[3] = {0.0, 0.0, 0.0};
+        if (act) {
+            const int4 en = *reinterpret_cast<const int4*>(entries + ck.first + lane);
+            j0 = en.y; n = en.z;
+            const uint32_t l = v.co_pt[en.x];
+            const double2 uvi = v.co_uv[en.x];
+            double Hi[9];
+            {
+                const double2* q = reinterpret_cast<const double2*>(hinv + kLmStride * (size_t)l);
+                const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a6 = q[6], a7 = q[7];
+                Hi[0] = a0.x; Hi[1] = a0.y; Hi[2] = a1.x; Hi[3] = a1.y; Hi[4] = a2.x; Hi[5] = a2.y; Hi[6] = a3.x; Hi[7] = a3.y;
+                Hi[8] = a4.x; pw[0] = a6.x; pw[1] = a6.y; pw[2] = a7.x;
+            }
+            double r[2], Jc[2][DC], Jl[2][3];
+            linearize_obs<DC>(cam_i, pw, uvi.x, uvi.y, v.huber_delta, r, Jc, Jl);
+#pragma unroll
+            for (int a = 0; a < DC; ++a) {  // -Y_i: the sign of the Schur term is folded in here
+                const double w0 = -(Jc[0][a] * Jl[0][0] + Jc[1][a] * Jl[1][0]);
+                const double w1 = -(Jc[0][a] * Jl[0][1] + Jc[1][a] * Jl[1][1]);
+                const double w2 = -(Jc[0][a] * Jl[0][2] + Jc[1][a] * Jl[1][2]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Y[a][c] = w0 * Hi[c] + w1 * Hi[3 + c] + w2 * Hi[6 + c];
+            }
+        }
+        for (int q = 0; q < ck.nmax; ++q) {
+            if (!(act && q < n)) continue;
+            const int j_s = j0 + q;
+            const uint32_t cj = v.o_cam[j_s];
+            const int slot = hash_slot(hkey, hval, (int)cj);
+            if (slot < 0) continue;  // partner camera belongs to another chunk of this row
+            const double2 uvj = v.o_uv[j_s];
+            Cam cam_j;
+            load_cam_prepared(scam + slot * kCamPitch, cam_j);
+            double rj[2], Jcj[2][DC], Jlj[2][3];
+            linearize_obs<DC>(cam_j, pw, uvj.x, uvj.y, v.huber_delta, rj, Jcj, Jlj);
+            double* blk = acc + slot * E;
+            if (cj == ci) {  // the same camera sees the landmark twice: B + B^T, kept in the lower triangle
+#pragma unroll
+                for (int bb = 0; bb < DC; ++bb) {
+                    const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
+                    const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
+                    const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
+#pragma unroll
+                    for (int a = 0; a < DC; ++a) {
+                        const double val = Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2;
+                        if (a >= bb) unsafeAtomicAdd(&blk[a * DC + bb], val);
+                        if (bb >= a) unsafeAtomicAdd(&blk[bb * DC + a], val);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int bb = 0; bb < DC; ++bb) {
+                    const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
+                    const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
+                    const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
+#pragma unroll
+                    for (int a = 0; a < DC; ++a)
+                        unsafeAtomicAdd(&blk[a * DC + bb], Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < t.nnbr * E; idx += 256) {
+        const int s = idx / E, e = idx - s * E, a = e / DC, bb = e - a * DC;
+        const uint32_t cj = (uint32_t)nbr[t.nbr0 + s];
+        double* dst = s_block_ptr<DC>(tm, ci, cj) + a * kNB + bb;
+        if (cj == ci) { if (bb <= a && acc[idx] != 0.0) *dst += acc[idx]; }
+        else *dst = acc[idx];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K3: back-substitution, 8 lanes per landmark: dl = Hll^-1 ((-g)_l - H_cl^T dc)
 // (explicit_schur.rs:980-1029); H_cl^T dc = sum_i Jl_i^T (Jc_i dc_ci).
 // ------------------------------------------------------------------------------------------
@@ -879,6 +994,13 @@ void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask
     else if (dc == 9) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9, true>), dim3(n_tasks), dim3(kRowThreads), dyn, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
     else if (dbg == 0) hipLaunchKernelGGL((k_schur_rows<6, kRowCap6, false>), dim3(n_tasks), dim3(kRowThreads), dyn, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
     else hipLaunchKernelGGL((k_schur_rows<6, kRowCap6, true>), dim3(n_tasks), dim3(kRowThreads), dyn, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
+}
+
+void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
+                        const RowChunk* chunks, const RowEntry* entries, const int* nbr, const double* hinv, hipStream_t s) {
+    if (n_tasks == 0) return;
+    if (dc == 9) hipLaunchKernelGGL((k_schur_rows2<9, kRowCap9>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, chunks, entries, nbr, hinv);
+    else hipLaunchKernelGGL((k_schur_rows2<6, kRowCap6>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, chunks, entries, nbr, hinv);
 }
 
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,

@@ -120,7 +120,7 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
 int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     H_OR_FAIL;
     const std::string n = name ? name : "";
-    if (n == "schur_rows") h->s->use_row_schur(value != 0);
+    if (n == "schur_rows") h->s->use_row_schur(value);
     else if (n == "graphs") h->s->enable_graphs(value != 0);
     else if (n == "update_overlap") h->s->enable_overlap(value != 0);
     else if (n == "gemm_full_tile_min") h->s->set_gemm_full_tile_min(value);

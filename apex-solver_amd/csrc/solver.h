@@ -66,7 +66,7 @@ class Solver : public LmBackend {
     void enable_graphs(bool on) { use_graphs_ = on; tp_.enable_graphs(on); }
     void enable_overlap(bool on) { tp_.enable_overlap(on); }
     void set_gemm_full_tile_min(int n) { tp_.set_gemm_full_tile_min(n); }
-    void use_row_schur(bool on) { use_rows_ = on; }
+    void use_row_schur(int v) { use_rows_ = v != 0; if (v) rows_form_ = v; }
     void set_rows_debug(int v) { rows_dbg_ = v; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     int n_levels() const { return tp_.n_levels(); }
@@ -127,6 +127,12 @@ class Solver : public LmBackend {
     double* camp_[2] = {nullptr, nullptr};  // prepared cameras of the two parameter sets
     RowTask* rtasks_ = nullptr;
     RowBatch* rbatches_ = nullptr;
+    RowTask* rtasks2_ = nullptr;     // k_schur_rows2: the same row tasks over chunks of entries
+    RowChunk* rchunks_ = nullptr;
+    RowEntry* rentries_ = nullptr;
+    int rows_form_ = 1;              // 1: one lane per pair (k_schur_rows, default), 2: one lane per observation
+                                     // (k_schur_rows2; select before set_structure).  Measured equal within 2 %:
+                                     // both are bound by the LDS atomic unit, not by the per-pair recomputation.
     uint16_t* cam_obs_off_ = nullptr;
     int* nbr_ = nullptr;
     int n_rtasks_ = 0;

@@ -34,7 +34,7 @@ Solver::Solver(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device)
 Solver::~Solver() {
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
+    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, rtasks2_, rchunks_, rentries_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_, lmu_, sd_, minv_};
     for (void* p : ptrs)
@@ -346,6 +346,37 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         }
     }
     n_rtasks_ = (int)rtasks.size();
+    // k_schur_rows2: one entry per observation of a camera (split at kRowMaxPartners partners), sorted by partner
+    // count so that the 64 lanes of a wave loop the same number of times; chunks of <= 64 entries, largest first
+    std::vector<RowEntry> rentries;
+    std::vector<RowChunk> rchunks;
+    std::vector<RowTask> rtasks2;
+    if (rows_form_ == 2) {  // built only when that form is selected (16 bytes per observation)
+        const int cap = (dc_ == 9) ? kRowCap9 : kRowCap6;
+        std::vector<RowEntry> ce;
+        for (int64_t c = 0; c < n_cam_; ++c) {
+            ce.clear();
+            for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
+                const int i_s = cam_obs[e];
+                const int base = pt_ptr[o_pt[i_s]], np = i_s - base;
+                for (int q0 = 0; q0 < np; q0 += kRowMaxPartners)
+                    ce.push_back(RowEntry{e, base + q0, std::min(kRowMaxPartners, np - q0), 0});
+            }
+            std::stable_sort(ce.begin(), ce.end(), [](const RowEntry& a, const RowEntry& b) { return a.n > b.n; });
+            const int c0 = (int)rchunks.size();
+            for (size_t f = 0; f < ce.size(); f += 64) {
+                const int cnt = (int)std::min<size_t>(64, ce.size() - f);
+                rchunks.push_back(RowChunk{(int)(rentries.size() + f), cnt, ce[f].n});
+            }
+            rentries.insert(rentries.end(), ce.begin(), ce.end());
+            const int nc2 = (int)rchunks.size() - c0;
+            const int n0 = nbr_ptr[c], nn = nbr_ptr[c + 1] - nbr_ptr[c];
+            for (int s0 = 0; s0 < nn; s0 += cap) {
+                const int cnt = std::min(cap, nn - s0);
+                rtasks2.push_back(RowTask{(int)c, n0 + s0, cnt, (s0 + cnt == nn) ? 1 : 0, c0, nc2});
+            }
+        }
+    }
     n_present_ = 0;
     for (uint8_t b : present) n_present_ += b;
 
@@ -371,6 +402,9 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(up(&tasks_, tasks));
     HIP_TRY(up(&rtasks_, rtasks));
     HIP_TRY(up(&rbatches_, rbatches));
+    HIP_TRY(up(&rtasks2_, rtasks2));
+    HIP_TRY(up(&rchunks_, rchunks));
+    HIP_TRY(up(&rentries_, rentries));
     HIP_TRY(up(&cam_obs_off_, cam_obs_off));
     HIP_TRY(up(&nbr_, nbr));
     {
@@ -521,7 +555,9 @@ int Solver::assemble(double lambda, double diag_extra) {
                       g_c_, g_red_, stream_);
     stage_end(kStAssembleCam);
     stage_begin(kStScatter);
-    if (use_rows_)
+    if (use_rows_ && rows_form_ == 2 && rows_dbg_ == 0)
+        launch_schur_rows2(dc_, v, tm, rtasks2_, n_rtasks_, rchunks_, rentries_, nbr_, hinv_, stream_);
+    else if (use_rows_)
         launch_schur_rows(dc_, v, tm, rtasks_, n_rtasks_, rbatches_, cam_obs_, cam_obs_off_, nbr_, hinv_, rows_dbg_, stream_);
     else
         launch_schur_scatter(dc_, v, tm, tasks_, n_tasks_, hinv_, g_l_, g_red_, stream_);

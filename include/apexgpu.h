@@ -170,8 +170,9 @@ int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out /* n_pt*9 */
 int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, double* y_explicit, double* y_implicit);
 
 /* Implementation switches (defaults in parentheses), for A/B tests and profiling:
- *   "schur_rows" (1)  Schur reduction in the LDS row form (k_schur_rows, no global atomics); 0 selects
- *                     the landmark-major global-atomics form (k_cam_reduce + k_schur_scatter)
+ *   "schur_rows" (1)  Schur reduction in the LDS row form without global atomics: 1 = one lane per camera pair
+ *                     (k_schur_rows), 2 = one lane per observation (k_schur_rows2; set before set_structure);
+ *                     0 selects the landmark-major global-atomics form (k_schur_scatter)
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
  *   "update_overlap" (1)  run the trailing updates the next elimination level does not need on a second
  *                     stream, overlapped with that level's potrf / panel solves (before the first solve)

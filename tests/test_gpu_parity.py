@@ -323,19 +323,28 @@ def test_ragged_landmarks(oracle, mode):
 
 @pytest.mark.parametrize("mode", ["selfcal", "ba"])
 def test_row_and_atomic_schur_forms_agree(mode):
-    """The two implementations of the Schur reduction (LDS row form, global-atomics form) build the
-    same S, g_red and gradient."""
-    d = pkg.synthetic.make_problem(150, 6000, 3, 9, config_id=61)
-    out = []
-    for rows in (1, 0):
-        prob, s = gpu_solver(d, mode)
-        s.set_option("schur_rows", rows)
-        step = s.solve_augmented_equation(1e-3)
-        S, gred = s.get_schur()
-        out.append((S, gred, s.get_gradient(), step))
-        s.close()
-    assert rel(out[0][0], out[1][0]) < 1e-13 and rel(out[0][1], out[1][1]) < 1e-12
-    assert rel(out[0][2], out[1][2]) < 1e-13
+    """The three implementations of the Schur reduction (LDS row form with one lane per camera pair, with one
+    lane per observation, global-atomics form) build the same S, g_red and gradient -- also on landmarks with
+    more than 64 partners per observation (split entries) and more neighbours than one LDS chunk."""
+    rng = np.random.default_rng(5)
+    base = pkg.synthetic.make_problem(150, 6000, 3, 9, config_id=61)
+    lists = [sorted(rng.choice(150, size=int(k), replace=False).tolist()) for k in rng.integers(2, 9, size=500)]
+    lists += [list(range(150)), list(range(0, 150, 2)), list(range(140))]       # 150 / 75 / 140 observations
+    wide = _custom(150, len(lists), lists)
+    for d in (base, wide):
+        out = []
+        for rows in (1, 2, 0):
+            ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
+            prob = Problem.bundle_adjustment(d, ot, 1.0)
+            s = GpuSchurComplementSolver(0).with_option("schur_rows", rows).initialize_structure(prob)
+            s.set_parameters(d.poses, d.intr, d.points)
+            step = s.solve_augmented_equation(1e-3)
+            S, gred = s.get_schur()
+            out.append((S, gred, s.get_gradient(), step))
+            s.close()
+        for k in (1, 2):
+            assert rel(out[0][0], out[k][0]) < 1e-13 and rel(out[0][1], out[k][1]) < 1e-12
+            assert rel(out[0][2], out[k][2]) < 1e-13
 
 
 @pytest.mark.parametrize("mode", ["selfcal", "ba"])
