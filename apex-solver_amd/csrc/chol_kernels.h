@@ -48,6 +48,7 @@ void launch_pcg_step1(int n, int nt, const double* scal, const double* row_dot, 
 void launch_pcg_step2(int n, double* scal, const double* blk_part, const double* pre, const double* r, double* p,
                       double* out2, hipStream_t s);
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s);
+void set_potrf_lookahead(bool on);  // process-wide A/B switch between k_potrf_inv_la (default) and k_potrf_inv
 // batches of at least full_tile_min tasks use the 9-wave full-tile kernel, smaller ones the 3 x 3-wave strip kernel
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, int full_tile_min = 1 << 30);
 void launch_tile_gemv(const GemvTask* tasks, int n, double* y, const double* x, hipStream_t s);

@@ -250,6 +250,222 @@ __global__ __launch_bounds__(256) void k_potrf_inv(const PotrfTask* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// potrf + inverse with look-ahead (default).  Same blocked algorithm and the same LDS layout as
+// k_potrf_inv, rescheduled so that the serial part -- the 16x16 register Cholesky of the next diagonal
+// block on wave 0 -- runs while waves 1-3 do the bulk of the previous step's trailing update and turn one
+// more row of L into a row of L^-1:
+//   step kb:  P1  wave 0: potrf16 + inverse of D_kb            | waves 1-3: trailing update of step kb-1 for the
+//                                                               | columns > kb; row kb-1 of L^-1 (into registers)
+//             --  barrier; waves 1-3 put row kb-1 of L^-1 in place of row kb-1 of L~
+//             P2  panel A(i,kb) <- A(i,kb) D_kb^-T (i > kb);  row kb of L goes to global memory and becomes
+//                 L~(kb,k) = D_kb^-1 L(kb,k) in place (k < kb)
+//             --  barrier
+//             P3  look-ahead: column kb+1 receives the rank-16 update of step kb (the only part of the trailing
+//                 update the next potrf16 and panel need)
+//             --  barrier
+// with  L^-1(r,j) = - sum_{k=j}^{r-1} L~(r,k) L^-1(k,j),  L^-1(k,k) = D_k^-1  (row-oriented dtrtri).
+// Row r of L is dead once step r has used it, so its blocks are reused for L~ and then L^-1: no extra LDS.
+// The 8 x 3 barriers of the separate inversion phase of k_potrf_inv are gone and the trailing update is off
+// the critical path: 85 -> ~45 us per tile (one launch per elimination-tree level).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void blk_to_global(const double* __restrict__ src, double* __restrict__ dst_tile, int bi, int bj,
+                                              int t, int nthreads) {
+    // 16 rows x 8 double2 per block
+    for (int idx = t; idx < 128; idx += nthreads) {
+        const int rr = idx >> 3, c2 = idx & 7;
+        double2 v; v.x = src[rr * BP + 2 * c2]; v.y = src[rr * BP + 2 * c2 + 1];
+        *reinterpret_cast<double2*>(dst_tile + (size_t)(16 * bi + rr) * NB + 16 * bj + 2 * c2) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restrict__ tasks, int* __restrict__ fail) {
+    const PotrfTask pt = tasks[blockIdx.x];
+    double* __restrict__ A = pt.A;
+    double* __restrict__ Linv = pt.Linv;
+    const int K = pt.K;
+    __shared__ double sA[NLB * BSZ];
+    __shared__ double sD[NBK * BSZ];
+    __shared__ int bad;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    if (tid == 0) bad = 0;
+    {
+        double2 reg[25];
+        int n = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBK; ++bi) {
+            const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
+#pragma unroll
+            for (int it = 0; it < (16 * 8 * (bi + 1) + 255) / 256; ++it, ++n) {
+                const int idx = tid + 256 * it;
+                if (idx < cnt) {
+                    const int rr = idx / per_row, c2 = idx - rr * per_row;
+                    reg[n] = *reinterpret_cast<const double2*>(A + (size_t)(16 * bi + rr) * NB + 2 * c2);
+                }
+            }
+        }
+        n = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBK; ++bi) {
+            const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
+#pragma unroll
+            for (int it = 0; it < (16 * 8 * (bi + 1) + 255) / 256; ++it, ++n) {
+                const int idx = tid + 256 * it;
+                if (idx < cnt) {
+                    const int rr = idx / per_row, c2 = idx - rr * per_row;
+                    double* dst = sA + bidx(bi, c2 >> 3) * BSZ + rr * BP + 2 * (c2 & 7);
+                    dst[0] = reg[n].x; dst[1] = reg[n].y;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int kb = 0; kb < NBK; ++kb) {
+        // ---------------- P1 ------------------------------------------------------------------------------
+        double4_t T[3];   // row kb-1 of L^-1: blocks j = (w-1), (w-1)+3, (w-1)+6 of waves 1..3
+        if (w == 0) {
+            double* D = sA + bidx(kb, kb) * BSZ;
+            double a[BS], invd[BS];
+#pragma unroll
+            for (int c = 0; c < BS; ++c) a[c] = D[lr * BP + c];
+            int isbad = 0;
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+                const double djj = readlane_f64(a[j], j);
+                if (!(djj > 0.0)) isbad = 1;
+                const double dj = djj > 0.0 ? djj : 1.0;
+                double isj = __builtin_amdgcn_rsq(dj);
+                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
+                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
+                double sj = dj * isj;
+                sj = fma(0.5 * isj, fma(-sj, sj, dj), sj);
+                invd[j] = isj;
+                const double lrj = a[j] * isj;
+#pragma unroll
+                for (int c = j + 1; c < BS; ++c) {
+                    const double lcj = readlane_f64(lrj, c);
+                    if (lr >= c) a[c] -= lrj * lcj;
+                }
+                a[j] = (lr > j) ? lrj : ((lr == j) ? sj : a[j]);
+            }
+            double x[BS];
+#pragma unroll
+            for (int i = 0; i < BS; ++i) {
+                double acc = (i == lr) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) acc -= readlane_f64(a[k], i) * x[k];
+                x[i] = acc * invd[i];
+            }
+            if (lk == 0) {
+#pragma unroll
+                for (int c = 0; c < BS; ++c) D[lr * BP + c] = a[c];
+#pragma unroll
+                for (int i = 0; i < BS; ++i) sD[kb * BSZ + i * BP + lr] = x[i];
+            }
+            if (isbad) bad = 1;
+        } else {
+            if (kb >= 1) {
+                const int ks = kb - 1;
+                // rest of the trailing update of step ks: targets (i, j) with kb < j <= i
+                const int m = NBK - 1 - kb;
+                const int n_upd = m * (m + 1) / 2;
+                for (int t = w - 1; t < n_upd; t += 3) {
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+                    const int jj = t - ii * (ii + 1) / 2;
+                    const int i = kb + 1 + ii, j = kb + 1 + jj;
+                    double* Cb = sA + bidx(i, j) * BSZ;
+                    double4_t acc = blk_load_cd(Cb, lr, lk);
+                    acc = blk_mma_nt(sA + bidx(i, ks) * BSZ, sA + bidx(j, ks) * BSZ, acc, lr, lk, -1.0);
+                    blk_store_cd(Cb, acc, lr, lk, 1.0);
+                }
+                // row r = ks of L^-1 from L~(r,.) and the rows above (kept in registers until the barrier)
+                const int r = ks;
+                int nt = 0;
+                for (int j = w - 1; j < r; j += 3, ++nt) {
+                    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+                    for (int k = j; k < r; ++k) {
+                        const double* Y = (k == j) ? (sD + j * BSZ) : (sA + bidx(k, j) * BSZ);
+                        acc = blk_mma_nn(sA + bidx(r, k) * BSZ, Y, acc, lr, lk);
+                    }
+                    T[nt] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        if (w > 0 && kb >= 1) {
+            const int r = kb - 1;
+            int nt = 0;
+            for (int j = w - 1; j < r; j += 3, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
+        }
+        // ---------------- P2 ------------------------------------------------------------------------------
+        // tasks 0 .. m-1: panel blocks (kb+1+t, kb); tasks m .. m+kb-1: row block (kb, t-m) -> global, then L~
+        {
+            const int m = NBK - 1 - kb;
+            for (int t = w; t < m + kb; t += 4) {
+                if (t < m) {
+                    double* P = sA + bidx(kb + 1 + t, kb) * BSZ;
+                    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+                    acc = blk_mma_nt(P, sD + kb * BSZ, acc, lr, lk, 1.0);
+                    blk_store_cd(P, acc, lr, lk, 1.0);
+                } else {
+                    const int k = t - m;
+                    double* Bk = sA + bidx(kb, k) * BSZ;
+                    blk_to_global(Bk, A, kb, k, lane, 64);
+                    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+                    acc = blk_mma_nn(sD + kb * BSZ, Bk, acc, lr, lk);
+                    blk_store_cd(Bk, acc, lr, lk, 1.0);  // same wave read it: LDS accesses of one wave stay in order
+                }
+            }
+            if (w == 3) blk_to_global(sA + bidx(kb, kb) * BSZ, A, kb, kb, lane, 64);  // the diagonal block of L
+        }
+        __syncthreads();
+        // ---------------- P3: look-ahead update of column kb+1 ---------------------------------------------------
+        if (kb + 1 < NBK) {
+            const int jc = kb + 1;
+            for (int i = jc + w; i < NBK; i += 4) {
+                double* Cb = sA + bidx(i, jc) * BSZ;
+                double4_t acc = blk_load_cd(Cb, lr, lk);
+                acc = blk_mma_nt(sA + bidx(i, kb) * BSZ, sA + bidx(jc, kb) * BSZ, acc, lr, lk, -1.0);
+                blk_store_cd(Cb, acc, lr, lk, 1.0);
+            }
+        }
+        __syncthreads();
+    }
+    // last row of L^-1 (r = NBK-1), all four waves
+    {
+        const int r = NBK - 1;
+        double4_t T[2];
+        int nt = 0;
+        for (int j = w; j < r; j += 4, ++nt) {
+            double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+            for (int k = j; k < r; ++k) {
+                const double* Y = (k == j) ? (sD + j * BSZ) : (sA + bidx(k, j) * BSZ);
+                acc = blk_mma_nn(sA + bidx(r, k) * BSZ, Y, acc, lr, lk);
+            }
+            T[nt] = acc;
+        }
+        __syncthreads();
+        nt = 0;
+        for (int j = w; j < r; j += 4, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int bi = 0; bi < NBK; ++bi) {
+        const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
+        for (int idx = tid; idx < cnt; idx += 256) {
+            const int rr = idx / per_row, c2 = idx - rr * per_row;
+            const int bj = c2 >> 3;
+            const double* src = ((bj == bi) ? (sD + bi * BSZ) : (sA + bidx(bi, bj) * BSZ)) + rr * BP + 2 * (c2 & 7);
+            double2 v; v.x = src[0]; v.y = src[1];
+            *reinterpret_cast<double2*>(Linv + (size_t)(16 * bi + rr) * NB + 2 * c2) = v;
+        }
+    }
+    if (tid == 0 && bad) atomicCAS(fail, 0, K + 1);
+}
+
+// ------------------------------------------------------------------------------------------
 // Batched 144^3 tile GEMM, NT form:  C = beta*C + alpha * A * B^T   (all row-major tiles).
 // One 576-thread workgroup (9 waves) per task; wave w owns the 16-row strip w and keeps 9
 // 16x16 fp64 accumulators (v_mfma_f64_16x16x4_f64: lane l supplies A[i=l&15][k=l>>4] and
@@ -865,8 +1081,12 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const 
 }
 
 // ------------------------------------------------------------------------------------------
+static bool g_potrf_lookahead = true;
+void set_potrf_lookahead(bool on) { g_potrf_lookahead = on; }
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_potrf_inv, dim3(n), dim3(256), 0, s, tasks, fail);
+    if (n <= 0) return;
+    if (g_potrf_lookahead) hipLaunchKernelGGL(k_potrf_inv_la, dim3(n), dim3(256), 0, s, tasks, fail);
+    else hipLaunchKernelGGL(k_potrf_inv, dim3(n), dim3(256), 0, s, tasks, fail);
 }
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, int full_tile_min) {
     if (n <= 0) return;
