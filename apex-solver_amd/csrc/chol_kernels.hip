@@ -349,13 +349,16 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
                 }
                 a[j] = (lr > j) ? lrj : ((lr == j) ? sj : a[j]);
             }
+            // inverse: lane c solves L x = e_c, column-oriented so that the 16 steps form a chain of only two
+            // dependent operations each (the updates of the rows below k are independent of one another)
             double x[BS];
 #pragma unroll
-            for (int i = 0; i < BS; ++i) {
-                double acc = (i == lr) ? 1.0 : 0.0;
+            for (int i = 0; i < BS; ++i) x[i] = (i == lr) ? 1.0 : 0.0;
 #pragma unroll
-                for (int k = 0; k < i; ++k) acc -= readlane_f64(a[k], i) * x[k];
-                x[i] = acc * invd[i];
+            for (int k = 0; k < BS; ++k) {
+                x[k] *= invd[k];
+#pragma unroll
+                for (int i = k + 1; i < BS; ++i) x[i] -= readlane_f64(a[k], i) * x[k];
             }
             if (lk == 0) {
 #pragma unroll

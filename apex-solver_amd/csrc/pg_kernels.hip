@@ -102,6 +102,13 @@ __global__ __launch_bounds__(256) void k_pg_edges(PGView v, TileMap tm, double* 
         for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int j = 0; j < 6; ++j) unsafeAtomicAdd(blk + i * kNB + j, H[6 * i + j]);
+    } else {  // self-loop: both Jacobians hit the same columns, the cross terms land on the diagonal block
+        jtj(J0, J1, H);
+        double* blk = h_block_ptr(tm, a, a);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) unsafeAtomicAdd(blk + i * kNB + j, H[6 * i + j] + H[6 * j + i]);
     }
     jtr(J0, r, gv);
 #pragma unroll

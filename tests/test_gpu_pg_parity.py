@@ -213,3 +213,35 @@ def test_g2o_end_to_end(tmp_path):
     ref = o.lm_optimize(po.lm_config(max_iterations=30))
     assert res.iterations == ref["iterations"] and abs(res.final_cost - ref["final_cost"]) <= 1e-6 * ref["final_cost"]
     assert res.final_cost < res.initial_cost
+
+
+def test_tiny_and_degenerate_graphs():
+    """2 vertices / 1 edge (one tile, no nested dissection), an isolated vertex (kept finite by the damping),
+    a multi-edge and a self-loop: the assembled J^T J equals the oracle's."""
+    d = pkg.synthetic.make_sphere(3, 4)
+    for ef, et, nv in (([0], [1], 2), ([0, 1, 1, 2, 3, 3], [1, 2, 2, 3, 3, 0], 5)):
+        data = pkg.synthetic.PoseGraphData(ids=np.arange(nv, dtype=np.int64), poses=d.truth[:nv].copy(),
+                                           e_from=np.asarray(ef, np.uint32), e_to=np.asarray(et, np.uint32), meas=d.meas[:len(ef)].copy())
+        prob = PoseGraphProblem.pose_graph(data)
+        s = GpuSparseCholeskySolver().initialize_structure(prob)
+        s.set_parameters(data.poses)
+        o = po.PgOracle.from_problem(prob)
+        c, r, J = o.linearize()
+        assert abs(s.compute_cost() - c) <= 1e-12 * c
+        H, g = s.get_hessian(0.5)
+        Ho, go = o.normal_equations()
+        assert rel(H, Ho + 0.5 * np.eye(Ho.shape[0])) < 1e-12 and rel(g, go) < 1e-12
+        step = s.solve_augmented_equation(0.5)
+        assert np.linalg.norm((Ho + 0.5 * np.eye(Ho.shape[0])) @ step + go) <= 1e-12 * max(np.linalg.norm(go), 1e-30)
+        s.close()
+
+
+def test_empty_edge_list_is_an_identity_system():
+    d = pkg.synthetic.make_sphere(3, 4)
+    data = pkg.synthetic.PoseGraphData(ids=d.ids, poses=d.poses, e_from=np.zeros(0, np.uint32), e_to=np.zeros(0, np.uint32), meas=np.zeros((0, 7)))
+    s = GpuSparseCholeskySolver().initialize_structure(PoseGraphProblem.pose_graph(data))
+    s.set_parameters(d.poses)
+    assert s.compute_cost() == 0.0
+    step = s.solve_augmented_equation(1e-3)
+    assert np.all(step == 0.0)
+    s.close()
