@@ -40,7 +40,6 @@ struct TileMap {
 constexpr int kRowThreads = 256;  // k_schur_rows workgroup size (512 threads need <= 128 VGPRs per lane to keep two
                                  // workgroups per CU: that spills to scratch -> +10 GB of HBM writes per launch, same time)
 constexpr int kRowBatch = kRowThreads;  // (i,j) pairs one k_schur_rows workgroup handles per sweep
-constexpr int kRowObs = 64;     // observations of the camera per sweep (their Y_i stay in LDS)
 constexpr int kRowCap9 = 96;    // neighbour cameras whose 9x9 blocks one workgroup keeps in LDS (62 KB: 2 workgroups per CU)
 constexpr int kRowCap6 = 160;   // same for 6x6 blocks (46 KB)
 

@@ -19,12 +19,6 @@ struct PotrfTask {  // one diagonal tile: factor in place, inverse of the factor
     int K;
 };
 
-struct GemvTask {  // see k_tile_gemv for the modes
-    const double* A;
-    int xo, yo;    // element offsets of the 144-long x and y blocks
-    int mode;
-};
-
 struct TriTask {   // one workgroup of a triangular-solve step (k_tri_step)
     const double* Mdiag;  // Linv of the step's diagonal tile
     const double* Moff;   // the off-diagonal tile this workgroup applies (unused when other < 0)
@@ -51,10 +45,7 @@ void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s);
 void set_potrf_lookahead(bool on);  // process-wide A/B switch between k_potrf_inv_la (default) and k_potrf_inv
 // batches of at least full_tile_min tasks use the 9-wave full-tile kernel, smaller ones the 3 x 3-wave strip kernel
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, int full_tile_min = 1 << 30);
-void launch_tile_gemv(const GemvTask* tasks, int n, double* y, const double* x, hipStream_t s);
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s);
-void launch_sym_tile_matvec(int nt, const int* row_ptr, const SymEntry* entries, const double* tiles, const double* x,
-                            double* y, hipStream_t s);
 void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double* diag, hipStream_t s);
 void launch_tile_add_diag(double* tiles, const int* diag_slot, int n_valid, int n_total, double add_valid,
                           double set_pad, hipStream_t s);
@@ -62,7 +53,6 @@ void launch_pcg_init(int n, const double* diag, const double* b, double* pre, do
                      hipStream_t s);
 void launch_dot(int n, const double* a, const double* b, double* out, hipStream_t s);
 void launch_pcg_update_xr(int n, double alpha, const double* p, const double* ap, double* x, double* r, hipStream_t s);
-void launch_pcg_precond(int n, const double* pre, const double* r, double* z, hipStream_t s);
 void launch_pcg_update_p(int n, double beta, const double* z, double* p, hipStream_t s);
 
 }  // namespace apex

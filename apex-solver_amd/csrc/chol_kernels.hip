@@ -666,64 +666,10 @@ __global__ __launch_bounds__(576) void k_tile_gemm_nt_full(const GemmTask* __res
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Tile GEMV tasks for the triangular solves and the PCG matvec.
-//   mode 0: y[yo..] = A x            mode 1: y = A^T x
-//   mode 2: y -= A x                 mode 3: y -= A^T x
-//   mode 4: y += A x                 mode 5: y += A^T x
-//   mode 6: y += sym(A) x  (diagonal tile, only its lower triangle is valid)
-// x and y blocks are 144 long; x is staged in LDS first so y may alias x (modes 0/1).
-// 256 threads; A x uses one wave per row (coalesced row reads + wave reduction), A^T x one lane
-// per column (coalesced across lanes).
-// ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum64(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
-}
-
-__global__ __launch_bounds__(256) void k_tile_gemv(const GemvTask* __restrict__ tasks, double* __restrict__ vec_y,
-                                                     const double* __restrict__ vec_x) {
-    __shared__ double sx[NB];
-    __shared__ double sy[NB];
-    const GemvTask t = tasks[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid < NB) sx[tid] = vec_x[(size_t)t.xo + tid];
-    __syncthreads();
-    const int base = t.mode & 1;  // transpose?
-    if (t.mode == 6) {
-        // y_r = sum_{c<=r} A[r][c] x_c + sum_{c>r} A[c][r] x_c
-        for (int r = w; r < NB; r += 4) {
-            double s = 0.0;
-            for (int c = lane; c < NB; c += 64) {
-                const double a = (c <= r) ? t.A[(size_t)r * NB + c] : t.A[(size_t)c * NB + r];
-                s += a * sx[c];
-            }
-            s = wave_sum64(s);
-            if (lane == 0) sy[r] = s;
-        }
-    } else if (!base) {
-        for (int r = w; r < NB; r += 4) {
-            double s = 0.0;
-            for (int c = lane; c < NB; c += 64) s += t.A[(size_t)r * NB + c] * sx[c];
-            s = wave_sum64(s);
-            if (lane == 0) sy[r] = s;
-        }
-    } else {
-        if (tid < NB) {
-            double s = 0.0;
-            for (int r = 0; r < NB; ++r) s += t.A[(size_t)r * NB + tid] * sx[r];
-            sy[tid] = s;
-        }
-    }
-    __syncthreads();
-    if (tid < NB) {
-        double* y = vec_y + (size_t)t.yo + tid;
-        const int op = t.mode >> 1;  // 0 assign, 1 subtract, 2 add, 3 add(sym)
-        if (op == 0) *y = sy[tid];
-        else if (op == 1) *y -= sy[tid];
-        else *y += sy[tid];
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -804,53 +750,6 @@ __global__ __launch_bounds__(256) void k_tri_step(const TriTask* __restrict__ ta
         if (!TRANS) unsafeAtomicAdd(&vwork[(size_t)t.other * NB + tid], -sz[tid]);
         else vwork[(size_t)t.other * NB + tid] -= sz[tid];
     }
-}
-
-// One workgroup per block-row I of the symmetric tile matrix: y_I = sum_J S_IJ x_J using the lower
-// tiles (row list) and the transposes of the tiles below the diagonal (column list).  No atomics,
-// fixed order: the PCG matvec (solve_with_pcg, explicit_schur.rs:687-695) reproducibly.
-__global__ __launch_bounds__(256) void k_sym_tile_matvec(const int* __restrict__ row_ptr,
-                                                           const SymEntry* __restrict__ entries,
-                                                           const double* __restrict__ tiles,
-                                                           const double* __restrict__ x, double* __restrict__ y) {
-    __shared__ double sx[NB];
-    __shared__ double part[NB];
-    const int I = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    double accT = 0.0;  // transposed contributions: thread tid (< NB) owns y[tid]
-    for (int r = tid; r < NB; r += 256) part[r] = 0.0;
-    __syncthreads();
-    for (int e = row_ptr[I]; e < row_ptr[I + 1]; ++e) {
-        const SymEntry en = entries[e];
-        const double* A = tiles + (size_t)en.slot * (NB * NB);
-        if (tid < NB) sx[tid] = x[(size_t)en.other * NB + tid];
-        __syncthreads();
-        if (en.kind == 0) {            // tile (I, other), other < I : y_I += A x_other
-            for (int r = w; r < NB; r += 4) {
-                double s = 0.0;
-                for (int c = lane; c < NB; c += 64) s += A[(size_t)r * NB + c] * sx[c];
-                s = wave_sum64(s);
-                if (lane == 0) part[r] += s;
-            }
-        } else if (en.kind == 1) {     // tile (other, I), other > I : y_I += A^T x_other
-            if (tid < NB) {
-                double s = 0.0;
-                for (int r = 0; r < NB; ++r) s += A[(size_t)r * NB + tid] * sx[r];
-                accT += s;
-            }
-        } else {                       // diagonal tile, lower triangle valid
-            for (int r = w; r < NB; r += 4) {
-                double s = 0.0;
-                for (int c = lane; c < NB; c += 64) {
-                    const double a = (c <= r) ? A[(size_t)r * NB + c] : A[(size_t)c * NB + r];
-                    s += a * sx[c];
-                }
-                s = wave_sum64(s);
-                if (lane == 0) part[r] += s;
-            }
-        }
-        __syncthreads();
-    }
-    if (tid < NB) y[(size_t)I * NB + tid] = part[tid] + accT;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1070,12 +969,6 @@ __global__ __launch_bounds__(256) void k_pcg_update_xr(int n, double alpha, cons
     x[i] += alpha * p[i];
     r[i] -= alpha * ap[i];
 }
-// z = pre .* r
-__global__ __launch_bounds__(256) void k_pcg_precond(int n, const double* __restrict__ pre, const double* __restrict__ r,
-                                                       double* __restrict__ z) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) z[i] = pre[i] * r[i];
-}
 // p = z + beta p
 __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const double* __restrict__ z,
                                                         double* __restrict__ p) {
@@ -1101,17 +994,10 @@ void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta
     const int units = n * NSTRIP, per_xcd = (units + 7) / 8;
     hipLaunchKernelGGL(k_tile_gemm_nt, dim3(8 * per_xcd), dim3(192), 0, s, tasks, units, alpha, beta);
 }
-void launch_tile_gemv(const GemvTask* tasks, int n, double* y, const double* x, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_tile_gemv, dim3(n), dim3(256), 0, s, tasks, y, x);
-}
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s) {
     if (n <= 0) return;
     if (trans) hipLaunchKernelGGL(k_tri_step<true>, dim3(n), dim3(256), 0, s, tasks, vwork, vout);
     else hipLaunchKernelGGL(k_tri_step<false>, dim3(n), dim3(256), 0, s, tasks, vwork, vout);
-}
-void launch_sym_tile_matvec(int nt, const int* row_ptr, const SymEntry* entries, const double* tiles, const double* x,
-                            double* y, hipStream_t s) {
-    hipLaunchKernelGGL(k_sym_tile_matvec, dim3(nt), dim3(256), 0, s, row_ptr, entries, tiles, x, y);
 }
 void launch_sym_tile_products(const SymTile* list, int n, const double* tiles, const double* x, double* part, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_sym_tile_products, dim3(n), dim3(256), 0, s, list, tiles, x, part);
@@ -1146,9 +1032,6 @@ void launch_dot(int n, const double* a, const double* b, double* out, hipStream_
 }
 void launch_pcg_update_xr(int n, double alpha, const double* p, const double* ap, double* x, double* r, hipStream_t s) {
     hipLaunchKernelGGL(k_pcg_update_xr, dim3((n + 255) / 256), dim3(256), 0, s, n, alpha, p, ap, x, r);
-}
-void launch_pcg_precond(int n, const double* pre, const double* r, double* z, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_precond, dim3((n + 255) / 256), dim3(256), 0, s, n, pre, r, z);
 }
 void launch_pcg_update_p(int n, double beta, const double* z, double* p, hipStream_t s) {
     hipLaunchKernelGGL(k_pcg_update_p, dim3((n + 255) / 256), dim3(256), 0, s, n, beta, z, p);

@@ -55,7 +55,6 @@ class Solver : public LmBackend {
     int get_schur(double* S_out, double* gred_out);  // reference camera-side order, dense
     int get_landmark_blocks(double* hinv_out, double* gl_out);
     int schur_matvec(double lambda, const double* x_in, double* y_explicit, double* y_implicit);
-    int get_step_internal(double* dc_out, double* dl_out);
     int64_t tile_count() const { return tp_.n_slots(); }
     int n_tile_rows() const { return nt_; }
     double last_reg() const { return last_reg_; }

@@ -976,13 +976,5 @@ int Solver::get_landmark_blocks(double* hinv_out, double* gl_out) {
     return kOk;
 }
 
-int Solver::get_step_internal(double* dc_out, double* dl_out) {
-    if (!have_step_) return fail(kInvalidState, "no step computed");
-    HIP_TRY(hipSetDevice(device_));
-    if (dc_out) HIP_TRY(hipMemcpyAsync(dc_out, dcam_, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    if (dl_out) HIP_TRY(hipMemcpyAsync(dl_out, dl_, 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
-    return kOk;
-}
 
 }  // namespace apex
