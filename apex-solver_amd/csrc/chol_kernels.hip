@@ -482,6 +482,7 @@ constexpr int KC = 16;  // 24 (6 chunks) measured the same: the chunk size is no
 constexpr int PITCH = KC + 2;
 constexpr int STRIP = 48;          // output rows per workgroup (3 waves x 16)
 constexpr int NSTRIP = NB / STRIP; // 3 workgroups per tile: 3x the parallelism of one per tile
+constexpr int kGemmSmallMax = 56;  // batches of at most this many tasks use the 9-workgroups-per-task latency kernel
 
 
 typedef double __attribute__((address_space(1)))* GlobalF64;
@@ -584,6 +585,154 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
         for (int r = 0; r < 4; ++r)
             C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = alpha * acc[j][r] + beta * cv[j % 3][r];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small batches (the upper levels of the elimination tree, pose graphs): latency matters, not throughput.
+// NINE workgroups per task, one per 48 x 48 block of C, three waves each (wave w: rows 16w.., three 16-wide
+// column blocks -> 3 accumulators, 108 MFMAs instead of 324 per wave), K in three 48-wide chunks so that only
+// three dependent global-load latencies remain instead of nine.  A lone tile product takes ~8 us instead of
+// ~18 us; it moves 1 MB through L2 per task instead of 0.66 MB, which is irrelevant at these batch sizes.
+// ------------------------------------------------------------------------------------------
+constexpr int KS = 48;            // K chunk of the small-batch kernel
+constexpr int PS = KS + 2;        // LDS pitch: 50 doubles = 100 dwords, rows shift by 36 banks -> conflict-free b64 reads
+
+__global__ __launch_bounds__(192) void k_tile_gemm_nt_small(const GemmTask* __restrict__ tasks, int n_units, double alpha,
+                                                              double beta) {
+    __shared__ double sA[48 * PS];
+    __shared__ double sB[48 * PS];
+    const int unit = blockIdx.x;
+    if (unit >= n_units) return;
+    const GemmTask tg = tasks[unit / 9];
+    const int blk = unit % 9, bi = blk / 3, bj = blk % 3;
+    GlobalCF64 Ag = (GlobalCF64)tg.A + (size_t)bi * 48 * NB;
+    GlobalCF64 Bg = (GlobalCF64)tg.B + (size_t)bj * 48 * NB;
+    GlobalF64 C = (GlobalF64)tg.C + (size_t)bi * 48 * NB + bj * 48;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    double4_t acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    constexpr int C2 = KS / 2, NR = 48 * C2 / 192;  // 1152 double2 per operand chunk: 6 per thread
+    static_assert(48 * C2 % 192 == 0 && NB % KS == 0, "staging loops assume whole rounds");
+    f64x2_t ra[NR], rb[NR];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
+            ra[i] = *reinterpret_cast<GlobalCF64x2>(Ag + (size_t)row * NB + k0 + 2 * c2);
+            rb[i] = *reinterpret_cast<GlobalCF64x2>(Bg + (size_t)row * NB + k0 + 2 * c2);
+        }
+    };
+    // the C block for the read-modify-write: requested first, consumed last
+    double cv[3][4];
+    if (beta != 0.0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[j][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr];
+    }
+    gload(0);
+    for (int k0 = 0; k0 < NB; k0 += KS) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
+            sA[row * PS + 2 * c2] = ra[i].x; sA[row * PS + 2 * c2 + 1] = ra[i].y;
+            sB[row * PS + 2 * c2] = rb[i].x; sB[row * PS + 2 * c2 + 1] = rb[i].y;
+        }
+        __syncthreads();
+        if (k0 + KS < NB) gload(k0 + KS);
+#pragma unroll
+        for (int kk = 0; kk < KS; kk += 4) {
+            const double a = sA[(16 * w + lr) * PS + kk + lk];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double b = sB[(16 * j + lr) * PS + kk + lk];
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // C may alias A (in-place panel solve, beta == 0): a workgroup of block row bi reads A rows [48 bi, +48) over ALL of K
+    // while the workgroups (bi, 0..2) write exactly those rows of C.  The launcher therefore never uses this kernel
+    // for aliased tasks (launch_tile_gemm_nt: alpha == 1 && beta == 0 is the panel solve).
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = alpha * acc[j][r];
+            C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = (beta != 0.0) ? v + beta * cv[j][r] : v;
+        }
+}
+
+// The in-place panel solves (C aliases A) of small batches: THREE workgroups per task, one per 48-row strip (a
+// workgroup then reads only the rows it writes, all of them staged before its last barrier), NINE waves each
+// (wave w: row block w / 3, column blocks 3 (w % 3) .. +2 -> 3 accumulators), the same 48-wide K chunks.
+__global__ __launch_bounds__(576) void k_tile_gemm_nt_small_strip(const GemmTask* __restrict__ tasks, int n_units, double alpha,
+                                                                    double beta) {
+    __shared__ double sA[48 * PS];
+    __shared__ double sB[NB * PS];
+    const int unit = blockIdx.x;
+    if (unit >= n_units) return;
+    const GemmTask tg = tasks[unit / 3];
+    const int bi = unit % 3;
+    GlobalCF64 Ag = (GlobalCF64)tg.A + (size_t)bi * 48 * NB;
+    GlobalCF64 Bg = (GlobalCF64)tg.B;
+    GlobalF64 C = (GlobalF64)tg.C + (size_t)bi * 48 * NB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int wr = w / 3, wc = w % 3;
+    double4_t acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    constexpr int C2 = KS / 2, NRA = 48 * C2 / 576, NRB = NB * C2 / 576;  // 2 and 6 double2 per thread
+    static_assert(48 * C2 % 576 == 0 && NB * C2 % 576 == 0, "staging loops assume whole rounds");
+    f64x2_t ra[NRA], rb[NRB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            ra[i] = *reinterpret_cast<GlobalCF64x2>(Ag + (size_t)row * NB + k0 + 2 * c2);
+        }
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            rb[i] = *reinterpret_cast<GlobalCF64x2>(Bg + (size_t)row * NB + k0 + 2 * c2);
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < NB; k0 += KS) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            sA[row * PS + 2 * c2] = ra[i].x; sA[row * PS + 2 * c2 + 1] = ra[i].y;
+        }
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            sB[row * PS + 2 * c2] = rb[i].x; sB[row * PS + 2 * c2 + 1] = rb[i].y;
+        }
+        __syncthreads();
+        if (k0 + KS < NB) gload(k0 + KS);
+#pragma unroll
+        for (int kk = 0; kk < KS; kk += 4) {
+            const double a = sA[(16 * wr + lr) * PS + kk + lk];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double b = sB[(48 * wc + 16 * j + lr) * PS + kk + lk];
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            GlobalF64 dst = C + (size_t)(16 * wr + lk + 4 * r) * NB + 48 * wc + 16 * j + lr;
+            const double v = alpha * acc[j][r];
+            *dst = (beta != 0.0) ? v + beta * *dst : v;
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -986,6 +1135,11 @@ void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s) {
 }
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, int full_tile_min) {
     if (n <= 0) return;
+    if (n <= kGemmSmallMax) {  // latency kernels; the 9-workgroup form never for the in-place panel solves (C aliases A)
+        if (beta != 0.0) hipLaunchKernelGGL(k_tile_gemm_nt_small, dim3(9 * n), dim3(192), 0, s, tasks, 9 * n, alpha, beta);
+        else hipLaunchKernelGGL(k_tile_gemm_nt_small_strip, dim3(3 * n), dim3(576), 0, s, tasks, 3 * n, alpha, beta);
+        return;
+    }
     if (n >= full_tile_min) {  // one task per CU and more: the full-tile kernel
         const int per_xcd = (n + 7) / 8;
         hipLaunchKernelGGL(k_tile_gemm_nt_full, dim3(8 * per_xcd), dim3(576), 0, s, tasks, n, alpha, beta);
