@@ -125,6 +125,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "update_overlap") h->s->enable_overlap(value != 0);
     else if (n == "gemm_full_tile_min") h->s->set_gemm_full_tile_min(value);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value != 0);
+    else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "rows_debug") h->s->set_rows_debug(value);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);  /* value > 1: leaf size */
     else return APEXGPU_ERR_INVALID_INPUT;
@@ -248,6 +249,7 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     else if (n == "update_overlap") h->s->enable_overlap(value != 0);
     else if (n == "gemm_full_tile_min") h->s->set_gemm_full_tile_min(value);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value != 0);
+    else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);
     else return APEXGPU_ERR_INVALID_INPUT;
     return APEXGPU_OK;

@@ -189,7 +189,7 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
     launch_pg_negate(n_pad_, g_, rhs_, stream_);
     timer_.begin(kPgFactor, stream_);
     int failed = 0;
-    HIP_TRY(tp_.factor(&failed));
+    HIP_TRY(tp_.factor(&failed, rhs_, work_));  // the forward sweep rides along
     timer_.end(kPgFactor, stream_);
     if (failed) return fail(kSingularMatrix, "Cholesky factorization failed (matrix may be singular)");
     timer_.begin(kPgTriSolve, stream_);

@@ -579,7 +579,7 @@ int Solver::assemble(double lambda, double diag_extra) {
 
 int Solver::cholesky_attempt(int* failed_at) {
     stage_begin(kStFactor);
-    HIP_TRY(tp_.factor(failed_at));
+    HIP_TRY(tp_.factor(failed_at, g_red_, pcg_buf_));  // the forward sweep for g_red rides along
     stage_end(kStFactor);
     return kOk;
 }

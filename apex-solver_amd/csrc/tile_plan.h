@@ -54,7 +54,10 @@ class TilePlan {
     void add_diag(int n_valid, double add_valid, double pad_value);  // diagonal += / padding rows := value
     void diag(double* out) const;                        // out[n_pad] = diagonal
     // Cholesky in place; *failed_at = 0 or (tile column + 1) of the first non-positive pivot.  Syncs.
-    hipError_t factor(int* failed_at);
+    // With rhs/work (2*n_pad doubles) the forward sweep L y = rhs rides along on a third stream; the next
+    // solve(rhs, x, work) with the same pointers then only runs the backward sweep.
+    hipError_t factor(int* failed_at, const double* rhs = nullptr, double* work = nullptr);
+    void enable_fused_forward(bool on) { fuse_forward_ = on; }
     // x = (L L^T)^-1 rhs ; work: 2*n_pad doubles ; all on the plan's stream, no sync
     void solve(const double* rhs, double* x, double* work);
     // y = A x on the UNFACTORED tiles (deterministic two-pass symmetric product), no sync
@@ -63,8 +66,8 @@ class TilePlan {
     hipError_t pcg(const double* rhs, double* x, double* work, int max_iter, double tol, int* iters);
 
    private:
-    void enqueue_factor();
-    void enqueue_solve(const double* rhs, double* x, double* work);
+    void enqueue_factor(const double* rhs, double* work);
+    void enqueue_solve(const double* rhs, double* x, double* work, bool backward_only);
     bool run_graph(int which, const double* rhs, double* x, double* work);
     void release();
 
@@ -90,10 +93,15 @@ class TilePlan {
     int* sym_row_ptr_ = nullptr;
     SymEntry* sym_entries_ = nullptr;
     double *sym_part_ = nullptr, *row_dot_ = nullptr, *blk_part_ = nullptr, *scal_ = nullptr;
-    hipGraphExec_t graph_exec_[2] = {nullptr, nullptr};
-    const double* graph_rhs_ = nullptr;
-    double *graph_x_ = nullptr, *graph_work_ = nullptr;
-    bool graph_failed_[2] = {false, false};
+    hipGraphExec_t graph_exec_[3] = {nullptr, nullptr, nullptr};
+    const double* graph_rhs_[3] = {nullptr, nullptr, nullptr};
+    double *graph_x_[3] = {nullptr, nullptr, nullptr}, *graph_work_[3] = {nullptr, nullptr, nullptr};
+    bool graph_failed_[3] = {false, false, false};
+    hipStream_t fwd_ = nullptr;       // fused forward sweep
+    hipEvent_t ev_fwd_ = nullptr;
+    const double* fwd_rhs_ = nullptr;  // right-hand side whose forward sweep the last factor() carried
+    double* fwd_work_ = nullptr;
+    bool fuse_forward_ = false;  // measured: the extra cross-stream edges cost the factorisation more than the sweep saves (+0.3 ms)
     bool use_graphs_ = true;
 };
 

@@ -101,10 +101,12 @@ void TilePlan::release() {
     slot_ = diag_slot_ = flag_ = sym_row_ptr_ = nullptr;
     potrf_tasks_ = nullptr; trsm_tasks_ = upd_tasks_ = nullptr; tri_fwd_ = tri_bwd_ = nullptr;
     sym_tiles_ = nullptr; sym_entries_ = nullptr;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         if (graph_exec_[i]) { (void)hipGraphExecDestroy(graph_exec_[i]); graph_exec_[i] = nullptr; }
         graph_failed_[i] = false;
     }
+    fwd_rhs_ = nullptr;
+    if (ev_fwd_) { (void)hipEventDestroy(ev_fwd_); ev_fwd_ = nullptr; }
     for (hipEvent_t e : ev_t_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_u2_) (void)hipEventDestroy(e);
     ev_t_.clear(); ev_u2_.clear();
@@ -113,6 +115,7 @@ void TilePlan::release() {
 TilePlan::~TilePlan() {
     release();
     if (side_) (void)hipStreamDestroy(side_);
+    if (fwd_) (void)hipStreamDestroy(fwd_);
 }
 
 std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStream_t stream) {
@@ -278,6 +281,8 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     TP_TRY(upload(&sym_row_ptr_, sym_ptr));
     TP_TRY(upload(&sym_entries_, sym));
     if (!side_) TP_TRY(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    if (!fwd_) TP_TRY(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
+    TP_TRY(hipEventCreateWithFlags(&ev_fwd_, hipEventDisableTiming));
     ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_);
     u2_pending_.assign(n_levels_, false);
     for (int i = 0; i < n_levels_; ++i) {
@@ -290,6 +295,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
 }
 
 hipError_t TilePlan::zero_tiles() {
+    fwd_rhs_ = nullptr;
     hipError_t e = hipMemsetAsync(tiles_, 0, (size_t)n_slots_ * kNB * kNB * sizeof(double), stream_);
     if (e != hipSuccess) return e;
     return hipMemsetAsync(flag_, 0, 4 * sizeof(int), stream_);
@@ -304,7 +310,7 @@ void TilePlan::diag(double* out) const { launch_tile_diag(tiles_, diag_slot_, nt
 // The factorisation and the triangular solves are static launch sequences for a given structure:
 // they are captured once into hipGraphs (a few hundred dependent launches would otherwise be paced by
 // host launch overhead) and replayed every iteration.
-void TilePlan::enqueue_factor() {
+void TilePlan::enqueue_factor(const double* rhs, double* work) {
     // Two streams.  Main: potrf(lv), panel solves(lv), U1(lv) = the updates the next level needs.
     // Side: U2(lv) = every other update of level lv, overlapped with potrf / panel solves of level lv+1
     // (one workgroup resp. a few dozen: they leave the chip nearly empty).  Ordering that keeps every
@@ -312,14 +318,24 @@ void TilePlan::enqueue_factor() {
     //   U2(lv) after the panel solves of lv;  U1(lv) after U2(lv-1) (both may hit columns of level lv+1);
     //   potrf(lv) after U1(lv-1) [stream order] and U2(<= lv-2) [main already waited for it before U1(lv-1)].
     const bool two = overlap_ && side_ != nullptr && n_levels_ > 2;
+    // Forward substitution L y = rhs fused into the factorisation (when the right-hand side is known now): the
+    // step of level lv needs only that level's L^-1 and panel tiles, which are final after its panel solves, so it
+    // runs on a third stream beside the trailing updates -- a chain of tiny latency-bound launches that costs
+    // nothing there.  solve() then starts at the backward sweep.
+    const bool fwd = rhs != nullptr && work != nullptr && fwd_ != nullptr;
+    double* bvec = work;
+    double* yvec = work ? work + n_pad() : nullptr;
+    if (fwd) (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
     for (int lv = 0; lv < n_levels_; ++lv) {
         launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flag_, stream_);
         launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_, gemm_full_min_);
         const int r0 = lv_upd_round_[lv], rs = lv_upd_split_[lv], r1 = lv_upd_round_[lv + 1];
         const bool has_u2 = two && r1 > rs;
-        if (has_u2) {
-            (void)hipEventRecord(ev_t_[lv], stream_);
-            (void)hipStreamWaitEvent(side_, ev_t_[lv], 0);
+        if (has_u2 || fwd) (void)hipEventRecord(ev_t_[lv], stream_);
+        if (has_u2) (void)hipStreamWaitEvent(side_, ev_t_[lv], 0);
+        if (fwd) {
+            (void)hipStreamWaitEvent(fwd_, ev_t_[lv], 0);
+            launch_tri_step(false, tri_fwd_ + lv_fwd_[lv], lv_fwd_[lv + 1] - lv_fwd_[lv], bvec, yvec, fwd_);
         }
         if (two && lv > 0 && u2_pending_[lv - 1]) (void)hipStreamWaitEvent(stream_, ev_u2_[lv - 1], 0);
         for (int r = r0; r < rs; ++r)
@@ -333,42 +349,51 @@ void TilePlan::enqueue_factor() {
     if (two)  // join: the last side-stream work precedes whatever follows on the main stream
         for (int lv = n_levels_ - 1; lv >= 0; --lv)
             if (u2_pending_[lv]) { (void)hipStreamWaitEvent(stream_, ev_u2_[lv], 0); break; }
+    if (fwd) {
+        (void)hipEventRecord(ev_fwd_, fwd_);
+        (void)hipStreamWaitEvent(stream_, ev_fwd_, 0);
+    }
 }
 
-void TilePlan::enqueue_solve(const double* rhs, double* x, double* work) {
+void TilePlan::enqueue_solve(const double* rhs, double* x, double* work, bool backward_only) {
     // L y = rhs (work vector bvec), then L^T x = y (work vector yvec); level by level
     double* bvec = work;
     double* yvec = work + n_pad();
-    (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
-    for (int lv = 0; lv < n_levels_; ++lv)
-        launch_tri_step(false, tri_fwd_ + lv_fwd_[lv], lv_fwd_[lv + 1] - lv_fwd_[lv], bvec, yvec, stream_);
+    if (!backward_only) {
+        (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
+        for (int lv = 0; lv < n_levels_; ++lv)
+            launch_tri_step(false, tri_fwd_ + lv_fwd_[lv], lv_fwd_[lv + 1] - lv_fwd_[lv], bvec, yvec, stream_);
+    }
     for (int s = 0; s < n_levels_; ++s)
         launch_tri_step(true, tri_bwd_ + lv_bwd_[s], lv_bwd_[s + 1] - lv_bwd_[s], yvec, x, stream_);
 }
 
+// graph 0: factorisation (+ fused forward sweep when rhs/work are given), 1: both sweeps, 2: backward sweep only
 bool TilePlan::run_graph(int which, const double* rhs, double* x, double* work) {
     if (!use_graphs_) return false;
-    if (which == 1 && graph_exec_[1] && (rhs != graph_rhs_ || x != graph_x_ || work != graph_work_)) {
-        (void)hipGraphExecDestroy(graph_exec_[1]);  // the captured pointers changed
-        graph_exec_[1] = nullptr;
+    if (graph_exec_[which] && (rhs != graph_rhs_[which] || x != graph_x_[which] || work != graph_work_[which])) {
+        (void)hipGraphExecDestroy(graph_exec_[which]);  // the captured pointers changed
+        graph_exec_[which] = nullptr;
     }
     if (!graph_exec_[which]) {
         if (graph_failed_[which]) return false;
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_failed_[which] = true; return false; }
-        if (which == 0) enqueue_factor(); else enqueue_solve(rhs, x, work);
+        if (which == 0) enqueue_factor(rhs, work); else enqueue_solve(rhs, x, work, which == 2);
         if (hipStreamEndCapture(stream_, &g) != hipSuccess || !g) { graph_failed_[which] = true; (void)hipGetLastError(); return false; }
         hipGraphExec_t ex = nullptr;
         if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); graph_failed_[which] = true; (void)hipGetLastError(); return false; }
         (void)hipGraphDestroy(g);
         graph_exec_[which] = ex;
-        if (which == 1) { graph_rhs_ = rhs; graph_x_ = x; graph_work_ = work; }
+        graph_rhs_[which] = rhs; graph_x_[which] = x; graph_work_[which] = work;
     }
     return hipGraphLaunch(graph_exec_[which], stream_) == hipSuccess;
 }
 
-hipError_t TilePlan::factor(int* failed_at) {
-    if (!run_graph(0, nullptr, nullptr, nullptr)) enqueue_factor();
+hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
+    if (!fuse_forward_) { rhs = nullptr; work = nullptr; }
+    if (!run_graph(0, rhs, nullptr, work)) enqueue_factor(rhs, work);
+    fwd_rhs_ = rhs; fwd_work_ = work;  // the forward sweep for this right-hand side is part of the factorisation
     int f = 0;
     hipError_t e = hipMemcpyAsync(&f, flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
     if (e != hipSuccess) return e;
@@ -378,7 +403,9 @@ hipError_t TilePlan::factor(int* failed_at) {
 }
 
 void TilePlan::solve(const double* rhs, double* x, double* work) {
-    if (!run_graph(1, rhs, x, work)) enqueue_solve(rhs, x, work);
+    const bool backward_only = fwd_rhs_ != nullptr && rhs == fwd_rhs_ && work == fwd_work_;
+    fwd_rhs_ = nullptr;  // one solve per fused sweep: the backward sweep consumes yvec's partner bvec
+    if (!run_graph(backward_only ? 2 : 1, rhs, x, work)) enqueue_solve(rhs, x, work, backward_only);
 }
 
 void TilePlan::sym_matvec(const double* x, double* y) {
