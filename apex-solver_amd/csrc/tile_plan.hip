@@ -330,7 +330,10 @@ void TilePlan::enqueue_factor(const double* rhs, double* work) {
         launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flag_, stream_);
         launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_, gemm_full_min_);
         const int r0 = lv_upd_round_[lv], rs = lv_upd_split_[lv], r1 = lv_upd_round_[lv + 1];
-        const bool has_u2 = two && r1 > rs;
+        int64_t n_u2 = 0;
+        for (int r = rs; r < r1; ++r) n_u2 += upd_rounds_[r].second;
+        // a cross-stream edge costs a few microseconds in the graph: only worth it when U2 is a real batch
+        const bool has_u2 = two && n_u2 >= overlap_min_;
         if (has_u2 || fwd) (void)hipEventRecord(ev_t_[lv], stream_);
         if (has_u2) (void)hipStreamWaitEvent(side_, ev_t_[lv], 0);
         if (fwd) {
