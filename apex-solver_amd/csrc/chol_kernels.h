@@ -43,8 +43,8 @@ void launch_pcg_step2(int n, double* scal, const double* blk_part, const double*
                       double* out2, hipStream_t s);
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s);
 void set_potrf_lookahead(bool on);  // process-wide A/B switch between k_potrf_inv_la (default) and k_potrf_inv
-// batches of at least full_tile_min tasks use the 9-wave full-tile kernel, smaller ones the 3 x 3-wave strip kernel
-void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, int full_tile_min = 1 << 30);
+// batches of <= 56 tasks use the latency kernels, larger ones the 3 x 3-wave strip kernel
+void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s);
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s);
 void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double* diag, hipStream_t s);
 void launch_tile_add_diag(double* tiles, const int* diag_slot, int n_valid, int n_total, double add_valid,

@@ -548,12 +548,18 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
         if (k0 + KC < NB) gload(k0 + KC);  // next chunk in flight while this one feeds the MFMAs
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
-            const double a = sA[(16 * w + lr) * PITCH + kk + lk];
+            // wave w owns the 48 x 48 block of columns 48w..: 3 a-reads and 3 b-reads feed 9 MFMAs (a 16 x 144
+            // row per wave needs 1 + 9 reads for the same 9 MFMAs and makes the LDS, not the MFMA pipe, the limit)
+            double av[3], bv[3];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const double b = sB[(16 * j + lr) * PITCH + kk + lk];
-                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
-            }
+            for (int i = 0; i < 3; ++i) av[i] = sA[(16 * i + lr) * PITCH + kk + lk];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bv[j] = sB[(48 * w + 16 * j + lr) * PITCH + kk + lk];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[3 * i + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[3 * i + j], 0, 0, 0);
         }
     }
     // epilogue: per 16-column block, the 4 loads of C are issued before the 4 stores.  (A
@@ -565,25 +571,25 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
 #pragma unroll
         for (int j = 0; j < 9; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = alpha * acc[j][r];
+            for (int r = 0; r < 4; ++r) C[(size_t)(16 * (j / 3) + lk + 4 * r) * NB + 48 * w + 16 * (j % 3) + lr] = alpha * acc[j][r];
         return;
     }
     // software-pipelined read-modify-write: the loads of column block j+2 are in flight while block j
     // is stored (three 4-value buffers), so the 9 blocks cost ~3 memory round trips instead of 9
     double cv[3][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cv[0][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + lr];
+    for (int r = 0; r < 4; ++r) cv[0][r] = C[(size_t)(lk + 4 * r) * NB + 48 * w + lr];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cv[1][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + 16 + lr];
+    for (int r = 0; r < 4; ++r) cv[1][r] = C[(size_t)(lk + 4 * r) * NB + 48 * w + 16 + lr];
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         if (j + 2 < 9) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cv[(j + 2) % 3][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * (j + 2) + lr];
+            for (int r = 0; r < 4; ++r) cv[(j + 2) % 3][r] = C[(size_t)(16 * ((j + 2) / 3) + lk + 4 * r) * NB + 48 * w + 16 * ((j + 2) % 3) + lr];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = alpha * acc[j][r] + beta * cv[j % 3][r];
+            C[(size_t)(16 * (j / 3) + lk + 4 * r) * NB + 48 * w + 16 * (j % 3) + lr] = alpha * acc[j][r] + beta * cv[j % 3][r];
     }
 }
 
@@ -733,86 +739,6 @@ __global__ __launch_bounds__(576) void k_tile_gemm_nt_small_strip(const GemmTask
             const double v = alpha * acc[j][r];
             *dst = (beta != 0.0) ? v + beta * *dst : v;
         }
-}
-
-// ------------------------------------------------------------------------------------------
-// Large batches: ONE 576-thread workgroup (9 waves) per task.  B is staged once per tile instead of once
-// per 48-row strip, the K chunks alternate between two LDS buffers (one barrier per chunk), so a wave's
-// global prefetch, LDS stores and MFMAs of neighbouring chunks overlap.  42-45 TF/s on batches of
-// thousands of tasks against 35 for the strip kernel (tools/gemm_var.hip); the strip kernel keeps the
-// small batches near the root of the elimination tree, where 3x the workgroups matter more.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(576) void k_tile_gemm_nt_full(const GemmTask* __restrict__ tasks, int n_tasks, double alpha,
-                                                             double beta) {
-    __shared__ double sA[2][NB * PITCH];
-    __shared__ double sB[2][NB * PITCH];
-    const int per_xcd = (n_tasks + 7) >> 3;
-    const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_tasks) return;
-    const GemmTask tg = tasks[unit];
-    struct { GlobalF64 C; GlobalCF64 A; GlobalCF64 B; } t = {(GlobalF64)tg.C, (GlobalCF64)tg.A, (GlobalCF64)tg.B};
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int lr = lane & 15, lk = lane >> 4;
-    double4_t acc[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    constexpr int C2 = KC / 2, NR = NB * C2 / 576;  // 1152 double2 per operand chunk: 2 per thread
-    static_assert(NB * C2 % 576 == 0, "staging loops assume whole rounds");
-    f64x2_t rb[NR], ra[NR];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
-            rb[i] = *reinterpret_cast<GlobalCF64x2>(t.B + (size_t)row * NB + k0 + 2 * c2);
-            ra[i] = *reinterpret_cast<GlobalCF64x2>(t.A + (size_t)row * NB + k0 + 2 * c2);
-        }
-    };
-    gload(0);
-    int buf = 0;
-    for (int k0 = 0; k0 < NB; k0 += KC, buf ^= 1) {
-        // buffer `buf` was last read two chunks ago; the barrier of the previous chunk separates those reads
-        // from these stores
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
-            sB[buf][row * PITCH + 2 * c2] = rb[i].x; sB[buf][row * PITCH + 2 * c2 + 1] = rb[i].y;
-            sA[buf][row * PITCH + 2 * c2] = ra[i].x; sA[buf][row * PITCH + 2 * c2 + 1] = ra[i].y;
-        }
-        __syncthreads();
-        if (k0 + KC < NB) gload(k0 + KC);
-#pragma unroll
-        for (int kk = 0; kk < KC; kk += 4) {
-            const double a = sA[buf][(16 * w + lr) * PITCH + kk + lk];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const double b = sB[buf][(16 * j + lr) * PITCH + kk + lk];
-                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
-            }
-        }
-    }
-    GlobalF64 C = t.C;
-    if (beta == 0.0) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = alpha * acc[j][r];
-        return;
-    }
-    double cv[3][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) cv[0][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + lr];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) cv[1][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + 16 + lr];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        if (j + 2 < 9) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cv[(j + 2) % 3][r] = C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * (j + 2) + lr];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = alpha * acc[j][r] + beta * cv[j % 3][r];
-    }
 }
 
 __device__ __forceinline__ double wave_sum64(double v) {
@@ -1133,16 +1059,11 @@ void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s) {
     if (g_potrf_lookahead) hipLaunchKernelGGL(k_potrf_inv_la, dim3(n), dim3(256), 0, s, tasks, fail);
     else hipLaunchKernelGGL(k_potrf_inv, dim3(n), dim3(256), 0, s, tasks, fail);
 }
-void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, int full_tile_min) {
+void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s) {
     if (n <= 0) return;
     if (n <= kGemmSmallMax) {  // latency kernels; the 9-workgroup form never for the in-place panel solves (C aliases A)
         if (beta != 0.0) hipLaunchKernelGGL(k_tile_gemm_nt_small, dim3(9 * n), dim3(192), 0, s, tasks, 9 * n, alpha, beta);
         else hipLaunchKernelGGL(k_tile_gemm_nt_small_strip, dim3(3 * n), dim3(576), 0, s, tasks, 3 * n, alpha, beta);
-        return;
-    }
-    if (n >= full_tile_min) {  // one task per CU and more: the full-tile kernel
-        const int per_xcd = (n + 7) / 8;
-        hipLaunchKernelGGL(k_tile_gemm_nt_full, dim3(8 * per_xcd), dim3(576), 0, s, tasks, n, alpha, beta);
         return;
     }
     const int units = n * NSTRIP, per_xcd = (units + 7) / 8;

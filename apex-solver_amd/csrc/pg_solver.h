@@ -48,7 +48,6 @@ class PoseGraphSolver : public LmBackend {
     void enable_graphs(bool on) { tp_.enable_graphs(on); }
     void enable_overlap(bool on) { tp_.enable_overlap(on); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
-    void set_gemm_full_tile_min(int n) { tp_.set_gemm_full_tile_min(n); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void enable_stage_timing(bool on) { timer_.enable(on); }

@@ -35,9 +35,7 @@ static hipError_t alloc_zero(double** p, size_t n) {
     return hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(double));
 }
 
-PoseGraphSolver::PoseGraphSolver(int64_t n_v, int64_t n_e, int device) : n_v_(n_v), n_e_(n_e), device_(device) {
-    tp_.set_gemm_full_tile_min(1 << 30);  // pose-graph trees: the strip kernel is faster at every batch size measured
-}
+PoseGraphSolver::PoseGraphSolver(int64_t n_v, int64_t n_e, int device) : n_v_(n_v), n_e_(n_e), device_(device) {}
 
 PoseGraphSolver::~PoseGraphSolver() {
     (void)hipSetDevice(device_);

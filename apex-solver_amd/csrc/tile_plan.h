@@ -48,8 +48,6 @@ class TilePlan {
     void enable_graphs(bool on) { use_graphs_ = on; }
     void enable_overlap(bool on) { overlap_ = on; }  // before the first factor()
     void set_overlap_min(int n) { overlap_min_ = n; }
-    // batches of at least n tile products use the full-tile GEMM kernel (before the first factor(): graphs capture it)
-    void set_gemm_full_tile_min(int n) { gemm_full_min_ = n; }
 
     hipError_t zero_tiles();                             // async on the plan's stream
     void add_diag(int n_valid, double add_valid, double pad_value);  // diagonal += / padding rows := value
@@ -83,7 +81,6 @@ class TilePlan {
     std::vector<bool> u2_pending_;
     bool overlap_ = true;
     int overlap_min_ = 2;   // U2 batches smaller than this stay on the main stream (swept 1..1024: flat up to 64)
-    int gemm_full_min_ = 512;  // measured: helps the BA trees (many tasks per source column), not the pose-graph ones
     std::vector<std::pair<int64_t, int64_t>> upd_rounds_;
     double *tiles_ = nullptr, *linv_ = nullptr;
     int *slot_ = nullptr, *diag_slot_ = nullptr, *flag_ = nullptr;

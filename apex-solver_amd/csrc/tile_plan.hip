@@ -328,7 +328,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work) {
     if (fwd) (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
     for (int lv = 0; lv < n_levels_; ++lv) {
         launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flag_, stream_);
-        launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_, gemm_full_min_);
+        launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_);
         const int r0 = lv_upd_round_[lv], rs = lv_upd_split_[lv], r1 = lv_upd_round_[lv + 1];
         int64_t n_u2 = 0;
         for (int r = rs; r < r1; ++r) n_u2 += upd_rounds_[r].second;
@@ -342,10 +342,10 @@ void TilePlan::enqueue_factor(const double* rhs, double* work) {
         }
         if (two && lv > 0 && u2_pending_[lv - 1]) (void)hipStreamWaitEvent(stream_, ev_u2_[lv - 1], 0);
         for (int r = r0; r < rs; ++r)
-            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, stream_, gemm_full_min_);
+            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, stream_);
         hipStream_t s2 = has_u2 ? side_ : stream_;
         for (int r = rs; r < r1; ++r)
-            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s2, gemm_full_min_);
+            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s2);
         u2_pending_[lv] = has_u2;
         if (has_u2) (void)hipEventRecord(ev_u2_[lv], side_);
     }

@@ -176,7 +176,6 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
  *   "update_overlap" (1)  run the trailing updates the next elimination level does not need on a second
  *                     stream, overlapped with that level's potrf / panel solves (before the first solve)
- *   "gemm_full_tile_min" (512)  batches of at least this many tile products use the 9-wave full-tile GEMM kernel
  *   "potrf_lookahead" (1)  look-ahead schedule of the diagonal-tile Cholesky + inverse
  *   "fused_forward" (0)  run the forward triangular sweep inside the factorisation graph on a third stream
  *   "nested_dissection" (1)  order camera tiles by nested dissection (call before set_structure);
