@@ -1,0 +1,42 @@
+"""bench.py's one-line JSON contract (metric / value / roofline / cpu_baseline ...) on a small workload."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def run(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_ba_line():
+    out = run("--workload", "ladybug-49", "--steps", "3", "--warmup", "1")
+    for k in REQUIRED:
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["higher_is_better"] is False
+    assert out["dtype"] == "f64" and out["data"] == "synthetic" and out["vs_baseline"] is None and "workload" in out["config"]
+    assert out["value"] == pytest.approx(out["ms_per_step"]) and out["value"] > 0
+    r = out["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    c = out["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert out["final_cost"] < out["initial_cost"]
+
+
+def test_pose_graph_line():
+    out = run("--workload", "sphere2500", "--scale", "0.04", "--steps", "3", "--warmup", "1")
+    for k in REQUIRED:
+        assert k in out, k
+    assert out["roofline"]["bound"] == "mfma" and out["scaling"] == "weak" and out["final_cost"] < out["initial_cost"]
