@@ -545,6 +545,50 @@ int pgo_solve_augmented(pgo_problem *p, double lambda, double *step_out, double 
     return rc;
 }
 
+/* SparseCholeskySolver::solve_augmented_equation on an arbitrary dense Jacobian (row-major n_rows x n_cols):
+ * (J^T J + lambda I) dx = -J^T r by LL^T; PG_ERR_SINGULAR on a non-positive pivot ("Cholesky factorization
+ * failed (matrix may be singular)", cholesky.rs:213-219).  Used to replay the reference's own solver unit tests
+ * (cholesky.rs:266-470) on the same factorisation code path semantics. */
+int pgo_solve_dense_jacobian(int64_t n_rows, int64_t n_cols, const double *J, const double *r, double lambda, double *dx,
+                             double *grad_out) {
+    const int64_t n = n_cols;
+    if (n == 0) return PG_OK;
+    double *H = (double *)calloc((size_t)n * (size_t)n, 8), *g = (double *)calloc((size_t)n, 8);
+    for (int64_t k = 0; k < n_rows; ++k)
+        for (int64_t a = 0; a < n; ++a) {
+            const double ja = J[k * n + a];
+            if (ja == 0.0) continue;
+            g[a] += ja * r[k];
+            for (int64_t b = 0; b <= a; ++b) H[a * n + b] += ja * J[k * n + b];
+        }
+    for (int64_t a = 0; a < n; ++a) H[a * n + a] += lambda;
+    int rc = PG_OK;
+    for (int64_t i = 0; i < n && rc == PG_OK; ++i)
+        for (int64_t j = 0; j <= i; ++j) {
+            double sacc = H[i * n + j];
+            for (int64_t k = 0; k < j; ++k) sacc -= H[i * n + k] * H[j * n + k];
+            if (j < i) H[i * n + j] = sacc / H[j * n + j];
+            else {
+                if (!(sacc > 0.0)) { rc = PG_ERR_SINGULAR; break; }
+                H[i * n + i] = sqrt(sacc);
+            }
+        }
+    if (rc == PG_OK) {
+        for (int64_t i = 0; i < n; ++i) {
+            double sacc = -g[i];
+            for (int64_t k = 0; k < i; ++k) sacc -= H[i * n + k] * dx[k];
+            dx[i] = sacc / H[i * n + i];
+        }
+        for (int64_t i = n - 1; i >= 0; --i) {
+            dx[i] /= H[i * n + i];
+            for (int64_t k = 0; k < i; ++k) dx[k] -= H[i * n + k] * dx[i];
+        }
+    }
+    if (grad_out) memcpy(grad_out, g, (size_t)n * 8);
+    free(H); free(g);
+    return rc;
+}
+
 /* apply_parameter_step / apply_negative_parameter_step (optimizer/mod.rs:309-356): fixed DOF are
  * zeroed in the step first (problem.rs:185-197). */
 void pgo_apply_step(pgo_problem *p, const double *step, double sign) {

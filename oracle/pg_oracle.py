@@ -56,6 +56,8 @@ def lib() -> C.CDLL:
     L.pgo_normal_equations.argtypes = [C.c_void_p, _Opt, _f64]
     L.pgo_solve_augmented.argtypes = [C.c_void_p, C.c_double, _Opt, _Opt]
     L.pgo_solve_augmented.restype = C.c_int
+    L.pgo_solve_dense_jacobian.argtypes = [C.c_int64, C.c_int64, _f64, _f64, C.c_double, _f64, _Opt]
+    L.pgo_solve_dense_jacobian.restype = C.c_int
     L.pgo_apply_step.argtypes = [C.c_void_p, _f64, C.c_double]
     L.pgo_parameter_norm.argtypes = [C.c_void_p]
     L.pgo_parameter_norm.restype = C.c_double
@@ -81,6 +83,14 @@ def between_linearize(k0, k1, meas, want_jac=True):
     L.pgo_between_linearize(np.ascontiguousarray(k0, dtype=np.float64), np.ascontiguousarray(k1, dtype=np.float64),
                             np.ascontiguousarray(meas, dtype=np.float64), r, J)
     return r, J
+
+
+def solve_dense_jacobian(J, r, lam=0.0):
+    """(J^T J + lam I) dx = -J^T r with the oracle's LL^T; returns (rc, dx, grad)."""
+    J = np.ascontiguousarray(J, dtype=np.float64); r = np.ascontiguousarray(r, dtype=np.float64)
+    dx = np.zeros(J.shape[1]); g = np.zeros(J.shape[1])
+    rc = lib().pgo_solve_dense_jacobian(J.shape[0], J.shape[1], J, r, float(lam), dx, g)
+    return rc, dx, g
 
 
 def lm_config(max_iterations=50, cost_tolerance=1e-6, parameter_tolerance=1e-8, gradient_tolerance=1e-10, damping=1e-3,

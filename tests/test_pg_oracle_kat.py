@@ -243,3 +243,46 @@ def test_huber_scales_residual_and_jacobian(small_problem):
     assert np.any(sc < 1.0)
     assert np.allclose(r1, r2 * sc[:, None], rtol=1e-14, atol=0)
     assert np.allclose(J1, J2 * sc[:, None, None], rtol=1e-14, atol=0)
+
+
+# ---- SparseCholeskySolver unit tests of the reference (src/linalg/sparse/cholesky.rs:266-470) -------------------
+def _cholesky_fixture():
+    """create_test_data (cholesky.rs:272-296): overdetermined 4 x 3 system."""
+    J = np.zeros((4, 3))
+    for i, j, v in ((0, 0, 2.0), (0, 1, 1.0), (1, 0, 1.0), (1, 1, 3.0), (1, 2, 1.0), (2, 1, 1.0), (2, 2, 2.0), (3, 0, 1.5), (3, 2, 0.5)):
+        J[i, j] = v
+    return J, np.array([1.0, -2.0, 0.5, 1.2])
+
+
+def test_sparse_cholesky_numerical_accuracy():
+    """cholesky.rs:448-468: J = I, r = [-1, -2] -> dx = [1, 2] within 1e-10."""
+    rc, dx, _ = po.solve_dense_jacobian(np.eye(2), np.array([-1.0, -2.0]))
+    assert rc == 0 and abs(dx[0] - 1.0) < 1e-10 and abs(dx[1] - 2.0) < 1e-10
+
+
+def test_sparse_cholesky_well_conditioned_and_augmented():
+    """cholesky.rs:311-325, 349-402: the step solves the (damped) normal equations; different lambdas differ."""
+    J, r = _cholesky_fixture()
+    sols = []
+    for lam in (0.0, 0.01, 0.1, 1.0):
+        rc, dx, g = po.solve_dense_jacobian(J, r, lam)
+        assert rc == 0 and dx.shape == (3,)
+        assert np.allclose(g, J.T @ r)
+        assert np.linalg.norm((J.T @ J + lam * np.eye(3)) @ dx + J.T @ r) < 1e-12
+        sols.append(dx)
+    assert np.abs(sols[1] - sols[3]).max() > 1e-10
+
+
+def test_sparse_cholesky_singular_matrix_is_an_error():
+    """cholesky.rs:404-426: second row = 2 x first row, no damping -> Err."""
+    J = np.array([[1.0, 2.0], [2.0, 4.0]])
+    rc, _, _ = po.solve_dense_jacobian(J, np.array([0.0, 1.0]))
+    assert rc == -2
+    rc, _, _ = po.solve_dense_jacobian(J, np.array([0.0, 1.0]), 1e-3)   # damping regularises it
+    assert rc == 0
+
+
+def test_sparse_cholesky_empty_matrix():
+    """cholesky.rs:429-445"""
+    rc, dx, _ = po.solve_dense_jacobian(np.zeros((0, 0)), np.zeros(0))
+    assert rc == 0 and dx.shape == (0,)
