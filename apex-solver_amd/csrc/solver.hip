@@ -953,12 +953,12 @@ int Solver::schur_matvec(double lambda, const double* x_in, double* y_explicit, 
         int rc = pass == 0 ? assemble(lambda, 0.0) : assemble_implicit(lambda);
         if (rc != kOk) return rc;
         if (pass == 0) tp_.sym_matvec(xd, yd);
-        else launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xd, lambda, yd, stream_);
+        else launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xd, rank_ == 0 ? lambda : 0.0, yd, stream_);  // a shard's partial
         HIP_TRY(hipMemcpyAsync(h.data(), yd, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         std::fill(out, out + nref, 0.0);
         for (int64_t i = 0; i < n_c_; ++i) out[ref_row(i)] = h[i];
-        if (dc_ == 6)  // intrinsic variables exist but no factor touches them: S_ii = lambda
+        if (dc_ == 6 && rank_ == 0)  // intrinsic variables exist but no factor touches them: S_ii = lambda
             for (int64_t c = 0; c < n_cam_; ++c)
                 for (int a = 0; a < 3; ++a) out[intr_col_[c] + a] = lambda * x_in[intr_col_[c] + a];
     }

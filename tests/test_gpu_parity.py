@@ -529,4 +529,15 @@ def test_shard_partials_sum_to_full(oracle):
         sr.close()
     S2 = parts[0][0] + parts[1][0]; g2 = parts[0][1] + parts[1][1]
     assert rel(S2, S) < 1e-12 and rel(g2, gred) < 1e-11
+    # the matrix-free operator shards the same way: every S p is a sum of the ranks' partial products
+    # (what the implicit variant all-reduces once per PCG iteration)
+    x = np.random.default_rng(3).normal(size=prob.layout.cam_dof)
+    ye, yi = s.schur_matvec(1e-3, x)
+    pe = np.zeros_like(ye); pi = np.zeros_like(yi)
+    for r in range(3):
+        _, sr = gpu_solver(d, "selfcal", shard=(r, 3))
+        a, b = sr.schur_matvec(1e-3, x)
+        pe += a; pi += b
+        sr.close()
+    assert rel(pe, ye) < 1e-12 and rel(pi, yi) < 1e-12 and rel(yi, ye) < 1e-12
     s.close()
