@@ -22,7 +22,7 @@ SYMBOLS = (
     "apexgpu_create", "apexgpu_destroy", "apexgpu_last_error", "apexgpu_version", "apexgpu_set_structure",
     "apexgpu_set_cg_params", "apexgpu_set_params", "apexgpu_get_params", "apexgpu_cost", "apexgpu_assemble", "apexgpu_solve_augmented",
     "apexgpu_step_stats", "apexgpu_eval_step", "apexgpu_commit_step", "apexgpu_discard_step",
-    "apexgpu_parameter_norm", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
+    "apexgpu_parameter_norm", "apexgpu_column_norms", "apexgpu_set_column_scaling", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
     "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
     "apexgpu_stage_times", "apexgpu_info", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_set_shard", "apexgpu_shard_range",
     "apexgpu_bal_open", "apexgpu_bal_close", "apexgpu_bal_last_error", "apexgpu_bal_sizes", "apexgpu_bal_raw",
@@ -30,7 +30,8 @@ SYMBOLS = (
     # SE3 pose-graph backend
     "apexgpu_pg_create", "apexgpu_pg_destroy", "apexgpu_pg_last_error", "apexgpu_pg_set_structure", "apexgpu_pg_set_params",
     "apexgpu_pg_get_params", "apexgpu_pg_cost", "apexgpu_pg_solve_augmented", "apexgpu_pg_step_stats", "apexgpu_pg_eval_step",
-    "apexgpu_pg_commit_step", "apexgpu_pg_discard_step", "apexgpu_pg_parameter_norm", "apexgpu_pg_lm_optimize",
+    "apexgpu_pg_commit_step", "apexgpu_pg_discard_step", "apexgpu_pg_parameter_norm", "apexgpu_pg_column_norms",
+    "apexgpu_pg_set_column_scaling", "apexgpu_pg_lm_optimize",
     "apexgpu_pg_get_residual", "apexgpu_pg_get_jacobian_blocks", "apexgpu_pg_get_hessian", "apexgpu_pg_set_option",
     "apexgpu_pg_enable_stage_timing", "apexgpu_pg_reset_stage_times", "apexgpu_pg_stage_times", "apexgpu_pg_info",
     "apexgpu_g2o_open", "apexgpu_g2o_close", "apexgpu_g2o_last_error", "apexgpu_g2o_sizes", "apexgpu_g2o_raw",
@@ -62,7 +63,7 @@ class LmConfigC(C.Structure):
         ("gradient_tolerance", C.c_double), ("damping", C.c_double), ("damping_min", C.c_double),
         ("damping_max", C.c_double), ("damping_nu", C.c_double), ("trust_region_radius", C.c_double),
         ("min_trust_region_radius", C.c_double), ("min_cost_threshold", C.c_double), ("timeout_s", C.c_double),
-        ("variant", C.c_int),
+        ("variant", C.c_int), ("use_jacobi_scaling", C.c_int),
     ]
 
 
@@ -113,6 +114,8 @@ def load() -> C.CDLL:
     L.apexgpu_commit_step.argtypes = [vp]
     L.apexgpu_discard_step.argtypes = [vp]
     L.apexgpu_parameter_norm.argtypes = [vp, C.POINTER(dbl)]
+    L.apexgpu_column_norms.argtypes = [vp, vp]
+    L.apexgpu_set_column_scaling.argtypes = [vp, vp]
     L.apexgpu_lm_optimize.argtypes = [vp, C.POINTER(LmConfigC), C.POINTER(LmResultC), vp, C.c_int]
     L.apexgpu_get_residual.argtypes = [vp, vp]
     L.apexgpu_get_jacobian_blocks.argtypes = [vp, vp, vp]
@@ -151,6 +154,8 @@ def load() -> C.CDLL:
     L.apexgpu_pg_commit_step.argtypes = [vp]
     L.apexgpu_pg_discard_step.argtypes = [vp]
     L.apexgpu_pg_parameter_norm.argtypes = [vp, C.POINTER(dbl)]
+    L.apexgpu_pg_column_norms.argtypes = [vp, vp]
+    L.apexgpu_pg_set_column_scaling.argtypes = [vp, vp]
     L.apexgpu_pg_lm_optimize.argtypes = [vp, C.POINTER(LmConfigC), C.POINTER(LmResultC), vp, C.c_int]
     L.apexgpu_pg_get_residual.argtypes = [vp, vp]
     L.apexgpu_pg_get_jacobian_blocks.argtypes = [vp, vp]

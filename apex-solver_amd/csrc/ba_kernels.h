@@ -22,6 +22,11 @@ struct BAView {
     const uint32_t* co_pt; // [n_obs] camera-major copies (entry k of the camera lists): landmark index
     const double2* co_uv;  // [n_obs]                                                   and measurement
     const int* co_rank;    // [n_obs] position of the observation inside its landmark's list
+    // Jacobi column scaling (optimizer/mod.rs:749-763), NULL when off.  The kernels keep working on the
+    // UNSCALED blocks: (D J^T J D + lambda I) y = -D J^T r  <=>  (J^T J + lambda D^-2) (D y) = -J^T r, so the
+    // damping becomes lambda / s^2 per column and S is rescaled once after the reduction (solver.hip).
+    const double* cam_scale;  // [n_cam][d_c]
+    const double* pt_scale;   // [n_pt][3]
 };
 
 // Per-landmark record written by k_landmark_reduce and read by the camera-major kernels: everything a
@@ -100,8 +105,16 @@ void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, co
                     const uint8_t* fix_intr, const uint8_t* fix_pt, double* poses_out, double* intr_out,
                     double* pts_out, hipStream_t s);
 void launch_cost(const BAView& v, double* partial, int n_partial, double* out_sumsq, hipStream_t s);
-void launch_step_stats(int64_t n, const double* g, const double* d, double lambda, double* partial, int n_partial,
-                       double* out3, hipStream_t s);
+// gscale (may be NULL): the gradient the statistics use is g .* gscale (the scaled gradient of Jacobi scaling)
+void launch_step_stats(int64_t n, const double* g, const double* d, double lambda, const double* gscale, double* partial,
+                       int n_partial, double* out3, hipStream_t s);
+// Jacobi scaling: n2_cam[c][d_c], n2_pt[l][3] += squared entries of the corrected Jacobian's columns (atomics; a
+// one-off per optimize), and s = 1 / (1 + sqrt(n2)) (process_jacobian_generic, optimizer/mod.rs:754-757)
+void launch_column_norms_sq(int dc, const BAView& v, double* n2_cam, double* n2_pt, hipStream_t s);
+void launch_scaling_from_norms_sq(int64_t n, const double* n2, double* scale, hipStream_t s);
+void launch_vec_mul(int64_t n, const double* a, const double* b, double* out, hipStream_t s);  // out = a .* b (in place ok)
+// sd[c][a][b] *= s[c][a] s[c][b]: the Schur-Jacobi diagonal blocks in the scaled variables
+void launch_scale_diag_blocks(int dc, int64_t n_cam, const double* scale, double* sd, hipStream_t s);
 void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, double* out, hipStream_t s);
 // out[0] = a1.b1, out[1] = a2.b2 in one pass over the vectors (fixed two-level reduction: reproducible)
 void launch_dot2(int64_t n, const double* a1, const double* b1, const double* a2, const double* b2, double* partial,

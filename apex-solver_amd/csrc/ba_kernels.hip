@@ -145,7 +145,9 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_reduce(BAView v, TileMap tm
             while ((a + 1) * (a + 2) / 2 <= i) ++a;
             const int bb = i - a * (a + 1) / 2;
             double* blk = s_block_ptr<DC>(tm, c, c);
-            blk[a * kNB + bb] = s + ((a == bb && add_lambda) ? lambda : 0.0);
+            double lam = lambda;
+            if (v.cam_scale) { const double sc = v.cam_scale[(size_t)c * DC + a]; lam = lambda / (sc * sc); }
+            blk[a * kNB + bb] = s + ((a == bb && add_lambda) ? lam : 0.0);
         } else {
             const int a = i - NH;
             const int j = NH + DC + a;
@@ -198,12 +200,24 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
         for (int i = 0; i < 3; ++i) gl[i] += __shfl_xor(gl[i], m, 8);
     }
     if (active && g == 0) {
-        double B[9] = {h[0] + lambda, h[1], h[3], h[1], h[2] + lambda, h[4], h[3], h[4], h[5] + lambda};
+        // With Jacobi scaling the reference inverts the block of the SCALED system, D Hll D + lambda I (eigenvalue
+        // gate included); D (.)^-1 D is then the inverse of Hll + lambda D^-2 that the unscaled kernels need.
+        double sc[3] = {1.0, 1.0, 1.0};
+        if (v.pt_scale) { sc[0] = v.pt_scale[3 * l]; sc[1] = v.pt_scale[3 * l + 1]; sc[2] = v.pt_scale[3 * l + 2]; }
+        double B[9] = {sc[0] * sc[0] * h[0] + lambda, sc[1] * sc[0] * h[1], sc[2] * sc[0] * h[3],
+                       sc[1] * sc[0] * h[1], sc[1] * sc[1] * h[2] + lambda, sc[2] * sc[1] * h[4],
+                       sc[2] * sc[0] * h[3], sc[2] * sc[1] * h[4], sc[2] * sc[2] * h[5] + lambda};
         double Bi[9];
         if (!invert_landmark_block(B, Bi)) {
             atomicExch(err_flag, 1);
 #pragma unroll
             for (int i = 0; i < 9; ++i) Bi[i] = 0.0;
+        }
+        if (v.pt_scale) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) Bi[3 * a + b] *= sc[a] * sc[b];
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) hinv[kLmStride * l + i] = Bi[i];
@@ -718,7 +732,9 @@ __global__ __launch_bounds__(64) void k_implicit_cam(BAView v, const int* __rest
 #pragma unroll
     for (int a = 0; a < DC; ++a) {
         const double t = wave_sum(acc[a]);
-        if (threadIdx.x == 0) y[(size_t)c * DC + a] = t + lambda * xc[a];
+        double lam = lambda;
+        if (v.cam_scale) { const double sc = v.cam_scale[(size_t)c * DC + a]; lam = lambda / (sc * sc); }
+        if (threadIdx.x == 0) y[(size_t)c * DC + a] = t + lam * xc[a];
     }
 }
 
@@ -894,11 +910,13 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_step_stats(int64_t n, const double* __restrict__ g,
                                                       const double* __restrict__ d, double lambda,
-                                                      double* __restrict__ partial) {
+                                                      const double* __restrict__ gscale, double* __restrict__ partial) {
     __shared__ double scratch[4];
     double a = 0.0, b = 0.0, c = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double gi = g[i], di = d[i];
+        // with Jacobi scaling compute_step_generic prices the UNSCALED step against the SCALED gradient
+        // (levenberg_marquardt.rs:746-760): restated as coded
+        const double gi = gscale ? g[i] * gscale[i] : g[i], di = d[i];
         a += gi * gi; b += di * di; c += di * (lambda * di - gi);
     }
     a = block_sum_256(a, scratch);
@@ -915,6 +933,46 @@ __global__ __launch_bounds__(256) void k_sumsq_partial(int64_t n, const double* 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += x[i] * x[i];
     a = block_sum_256(a, scratch);
     if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+
+// ------------------------------------------------------------------------------------------
+// Jacobi column scaling (process_jacobian_generic, optimizer/mod.rs:749-763): squared column norms of the
+// corrected Jacobian (compute_column_norms, linearizer/mod.rs:229-239).  Runs once per optimize.
+// ------------------------------------------------------------------------------------------
+template <int DC>
+__global__ __launch_bounds__(256) void k_column_norms_sq(BAView v, double* __restrict__ n2_cam, double* __restrict__ n2_pt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= v.n_obs) return;
+    const uint32_t c = v.o_cam[i], l = v.o_pt[i];
+    const double2 uv = v.o_uv[i];
+    Cam cam;
+    load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
+    const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
+    double r[2], Jc[2][DC], Jl[2][3];
+    linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
+#pragma unroll
+    for (int a = 0; a < DC; ++a) atomicAdd(n2_cam + (size_t)c * DC + a, Jc[0][a] * Jc[0][a] + Jc[1][a] * Jc[1][a]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) atomicAdd(n2_pt + 3 * (size_t)l + a, Jl[0][a] * Jl[0][a] + Jl[1][a] * Jl[1][a]);
+}
+
+__global__ __launch_bounds__(256) void k_scaling_from_norms_sq(int64_t n, const double* __restrict__ n2, double* __restrict__ scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) scale[i] = 1.0 / (1.0 + sqrt(n2[i]));
+}
+
+__global__ __launch_bounds__(256) void k_vec_mul(int64_t n, const double* a, const double* b, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+
+template <int DC>
+__global__ __launch_bounds__(256) void k_scale_diag_blocks(int64_t n_cam, const double* __restrict__ scale, double* __restrict__ sd) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_cam * DC * DC) return;
+    const int64_t c = i / (DC * DC);
+    const int e = (int)(i - c * DC * DC), a = e / DC, b = e - a * DC;
+    sd[i] *= scale[c * DC + a] * scale[c * DC + b];
 }
 
 // per-observation corrected residual and Jacobian blocks in the CALLER's observation order
@@ -1029,10 +1087,29 @@ void launch_cost(const BAView& v, double* partial, int n_partial, double* out_su
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n_partial, 1, out_sumsq);
 }
 
-void launch_step_stats(int64_t n, const double* g, const double* d, double lambda, double* partial, int n_partial,
-                       double* out3, hipStream_t s) {
-    hipLaunchKernelGGL(k_step_stats, dim3(n_partial), dim3(256), 0, s, n, g, d, lambda, partial);
+void launch_step_stats(int64_t n, const double* g, const double* d, double lambda, const double* gscale, double* partial,
+                       int n_partial, double* out3, hipStream_t s) {
+    hipLaunchKernelGGL(k_step_stats, dim3(n_partial), dim3(256), 0, s, n, g, d, lambda, gscale, partial);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n_partial, 3, out3);
+}
+
+void launch_column_norms_sq(int dc, const BAView& v, double* n2_cam, double* n2_pt, hipStream_t s) {
+    if (v.n_obs == 0) return;
+    const unsigned grid = (unsigned)((v.n_obs + 255) / 256);
+    if (dc == 9) hipLaunchKernelGGL(k_column_norms_sq<9>, dim3(grid), dim3(256), 0, s, v, n2_cam, n2_pt);
+    else hipLaunchKernelGGL(k_column_norms_sq<6>, dim3(grid), dim3(256), 0, s, v, n2_cam, n2_pt);
+}
+void launch_scaling_from_norms_sq(int64_t n, const double* n2, double* scale, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_scaling_from_norms_sq, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, n2, scale);
+}
+void launch_vec_mul(int64_t n, const double* a, const double* b, double* out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_vec_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a, b, out);
+}
+void launch_scale_diag_blocks(int dc, int64_t n_cam, const double* scale, double* sd, hipStream_t s) {
+    const int64_t n = n_cam * dc * dc;
+    if (n == 0) return;
+    if (dc == 9) hipLaunchKernelGGL(k_scale_diag_blocks<9>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n_cam, scale, sd);
+    else hipLaunchKernelGGL(k_scale_diag_blocks<6>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n_cam, scale, sd);
 }
 
 void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, double* out, hipStream_t s) {

@@ -92,6 +92,13 @@ int apexgpu_commit_step(apexgpu_solver* h) { H_OR_FAIL; return h->s->commit_step
 int apexgpu_discard_step(apexgpu_solver* h) { H_OR_FAIL; return h->s->discard_step(); }
 int apexgpu_parameter_norm(apexgpu_solver* h, double* out) { H_OR_FAIL; return h->s->parameter_norm(out); }
 
+int apexgpu_column_norms(apexgpu_solver* h, double* norms_out) {
+    H_OR_FAIL;
+    if (!norms_out) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->column_norms(norms_out);
+}
+int apexgpu_set_column_scaling(apexgpu_solver* h, const double* scaling) { H_OR_FAIL; return h->s->set_column_scaling(scaling); }
+
 int apexgpu_lm_optimize(apexgpu_solver* h, apexgpu_lm_config* cfg, apexgpu_lm_result* result, apexgpu_lm_iter* history,
                         int history_capacity) {
     H_OR_FAIL;
@@ -228,6 +235,13 @@ int apexgpu_pg_eval_step(apexgpu_pg_solver* h, double* trial_cost) { PG_OR_FAIL;
 int apexgpu_pg_commit_step(apexgpu_pg_solver* h) { PG_OR_FAIL; return h->s->commit_step(); }
 int apexgpu_pg_discard_step(apexgpu_pg_solver* h) { PG_OR_FAIL; return h->s->discard_step(); }
 int apexgpu_pg_parameter_norm(apexgpu_pg_solver* h, double* out) { PG_OR_FAIL; return h->s->parameter_norm(out); }
+int apexgpu_pg_column_norms(apexgpu_pg_solver* h, double* norms_out) {
+    PG_OR_FAIL;
+    if (!norms_out) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->column_norms(norms_out);
+}
+int apexgpu_pg_set_column_scaling(apexgpu_pg_solver* h, const double* scaling) { PG_OR_FAIL; return h->s->set_column_scaling(scaling); }
+
 int apexgpu_pg_lm_optimize(apexgpu_pg_solver* h, apexgpu_lm_config* cfg, apexgpu_lm_result* result, apexgpu_lm_iter* history,
                            int history_capacity) {
     PG_OR_FAIL;

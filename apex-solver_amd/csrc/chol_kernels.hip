@@ -470,9 +470,10 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
 
 // ------------------------------------------------------------------------------------------
 // Batched 144^3 tile GEMM, NT form:  C = beta*C + alpha * A * B^T   (all row-major tiles).
-// One 576-thread workgroup (9 waves) per task; wave w owns the 16-row strip w and keeps 9
-// 16x16 fp64 accumulators (v_mfma_f64_16x16x4_f64: lane l supplies A[i=l&15][k=l>>4] and
-// B^T[k=l>>4][j=l&15] = B[j][k]; result reg r of lane l is C[(l>>4)+4r][l&15]).
+// Three 192-thread workgroups per task, one per 48-row strip of C; wave w of a workgroup owns the
+// 48x48 block at columns 48w and keeps 3x3 16x16 fp64 accumulators (v_mfma_f64_16x16x4_f64: lane l
+// supplies A[i=l&15][k=l>>4] and B^T[k=l>>4][j=l&15] = B[j][k]; result reg r of lane l is
+// C[(l>>4)+4r][l&15]), so 3 a-reads + 3 b-reads from LDS feed 9 MFMAs.
 // K is consumed in 16-wide chunks staged through LDS with an 18-double row pitch: the 16 rows x
 // 2 k-values read by each half-wave of a ds_read_b64 then hit 32 distinct bank pairs.
 // C may alias A (L_IK = S_IK L_KK^-T in place): every global read of A is staged into LDS before the
@@ -1009,6 +1010,19 @@ __global__ __launch_bounds__(256) void k_tile_add_diag(double* __restrict__ tile
     else *d = set_pad;
 }
 
+// A := D A D on the structurally non-zero tiles (Jacobi scaling of the reduced system): one workgroup per tile
+__global__ __launch_bounds__(256) void k_tile_scale_sym(const SymTile* __restrict__ list, double* __restrict__ tiles,
+                                                          const double* __restrict__ scale) {
+    const SymTile t = list[blockIdx.x];
+    double* T = tiles + (size_t)t.slot * (NB * NB);
+    const double* sr = scale + (size_t)t.I * NB;
+    const double* sc = scale + (size_t)t.J * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e - r * NB;
+        T[e] *= sr[r] * sc[c];
+    }
+}
+
 // ---- small vector kernels for PCG (explicit_schur.rs:639-756) -----------------------------------
 __global__ __launch_bounds__(256) void k_pcg_init(int n, const double* __restrict__ diag, const double* __restrict__ b,
                                                     double* __restrict__ pre, double* __restrict__ x,
@@ -1097,6 +1111,9 @@ void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double*
 void launch_tile_add_diag(double* tiles, const int* diag_slot, int n_valid, int n_total, double add_valid,
                           double set_pad, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_add_diag, dim3((n_total + 255) / 256), dim3(256), 0, s, tiles, diag_slot, n_valid, n_total, add_valid, set_pad);
+}
+void launch_tile_scale_sym(const SymTile* list, int n, double* tiles, const double* scale, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_tile_scale_sym, dim3(n), dim3(256), 0, s, list, tiles, scale);
 }
 void launch_pcg_init(int n, const double* diag, const double* b, double* pre, double* x, double* r, double* z, double* p,
                      hipStream_t s) {

@@ -18,6 +18,17 @@ int run_lm(LmBackend& b, LmConfig* cfg, LmResult* res, LmIterRecord* hist, int h
     memset(res, 0, sizeof *res);
     res->initial_cost = cur_cost;
     res->cost_evaluations = 1;
+    // process_jacobian_generic (optimizer/mod.rs:749-763): the scaling is taken from the Jacobian of iteration 0
+    // and lives in the optimizer for this optimize() only.
+    struct ScalingGuard {
+        LmBackend& b; bool on;
+        ~ScalingGuard() { if (on) b.set_jacobi_scaling(false); }
+    } scaling{b, false};
+    if (cfg->use_jacobi_scaling) {
+        rc = b.set_jacobi_scaling(true);
+        if (rc != kOk) return rc;
+        scaling.on = true;
+    }
     int iteration = 0, status = kMaxIterationsReached;
     for (;;) {
         rc = b.solve_augmented(lambda, cfg->variant, nullptr, nullptr);  // assemble + compute_step (:861-883)

@@ -42,6 +42,7 @@ struct LmConfig {               // LevenbergMarquardtConfig (levenberg_marquardt
     double min_cost_threshold;      // < 0: None
     double timeout_s;               // <= 0: None
     int variant;                    // 0 Sparse (Cholesky), 1 Iterative (Jacobi-PCG on explicit S), 2 matrix-free PCG
+    int use_jacobi_scaling;         // false (:352): s = 1/(1 + column norm) from iteration 0 (optimizer/mod.rs:749-763)
 };
 
 struct LmIterRecord {  // one row of the per-iteration history
@@ -67,6 +68,7 @@ class LmBackend {
     virtual int commit_step() = 0;
     virtual int discard_step() = 0;                                                   // trial (+) (-step)
     virtual int parameter_norm(double* out) = 0;
+    virtual int set_jacobi_scaling(bool on) = 0;  // on: column scaling from the Jacobian at the current point; off: none
     virtual const char* last_error() const = 0;
 };
 

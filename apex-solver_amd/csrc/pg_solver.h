@@ -39,6 +39,10 @@ class PoseGraphSolver : public LmBackend {
     int discard_step() override;
     int parameter_norm(double* out) override;
     int lm_optimize(LmConfig* cfg, LmResult* res, LmIterRecord* hist, int hist_cap);
+    // Jacobi column scaling (optimizer/mod.rs:749-763), same contract as Solver's
+    int column_norms(double* norms_out);
+    int set_column_scaling(const double* scaling);
+    int set_jacobi_scaling(bool on) override;
 
     // parity / debug exports (caller's edge and column order)
     int get_residual(double* r_out);
@@ -66,6 +70,7 @@ class PoseGraphSolver : public LmBackend {
     int check_hip(hipError_t e, const char* what);
     PGView view(int which) const;
     int assemble(double lambda);
+    int ensure_scale_buffer();
     int cost_of(int which, double* out);
 
     int64_t n_v_, n_e_;
@@ -86,6 +91,9 @@ class PoseGraphSolver : public LmBackend {
     double* meas_ = nullptr;
     uint8_t* fix_ = nullptr;
     double *g_ = nullptr, *rhs_ = nullptr, *d_ = nullptr, *work_ = nullptr, *partial_ = nullptr, *scal_ = nullptr;
+    double* scale_ = nullptr;        // Jacobi scaling, internal order, [n_pad] with 1 on the padding
+    std::vector<double> scale_h_;
+    bool scaled_ = false;
     int n_partial_ = 256;
     StageTimer<kPgNumStages> timer_;
     std::string err_;

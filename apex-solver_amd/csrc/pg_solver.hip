@@ -40,7 +40,7 @@ PoseGraphSolver::PoseGraphSolver(int64_t n_v, int64_t n_e, int device) : n_v_(n_
 PoseGraphSolver::~PoseGraphSolver() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], posep_[0], posep_[1], e_from_, e_to_, meas_, fix_, g_, rhs_, d_, work_, partial_, scal_};
+    void* ptrs[] = {poses_[0], poses_[1], posep_[0], posep_[1], e_from_, e_to_, meas_, fix_, g_, rhs_, d_, work_, partial_, scal_, scale_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -169,8 +169,12 @@ int PoseGraphSolver::assemble(double lambda) {
     timer_.begin(kPgAssemble, stream_);
     HIP_TRY(tp_.zero_tiles());
     HIP_TRY(hipMemsetAsync(g_, 0, n_pad_ * sizeof(double), stream_));
-    tp_.add_diag((int)n_, lambda, 1.0);  // lambda on the real rows, identity on the padding rows
+    tp_.add_diag((int)n_, scaled_ ? 0.0 : lambda, 1.0);  // lambda on the real rows, identity on the padding rows
     launch_pg_edges(view(cur_), tp_.tilemap(), g_, stream_);
+    if (scaled_) {  // Jacobi scaling: H := D H D, then the damping of the scaled system
+        tp_.scale_sym(scale_);
+        tp_.add_diag((int)n_, lambda, 1.0);
+    }
     timer_.end(kPgAssemble, stream_);
     return kOk;
 }
@@ -185,6 +189,7 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
     int rc = assemble(lambda);
     if (rc != kOk) return rc;
     launch_pg_negate(n_pad_, g_, rhs_, stream_);
+    if (scaled_) launch_vec_mul(n_pad_, rhs_, scale_, rhs_, stream_);  // -D g
     timer_.begin(kPgFactor, stream_);
     int failed = 0;
     HIP_TRY(tp_.factor(&failed, rhs_, work_));  // the forward sweep rides along
@@ -192,6 +197,7 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
     if (failed) return fail(kSingularMatrix, "Cholesky factorization failed (matrix may be singular)");
     timer_.begin(kPgTriSolve, stream_);
     tp_.solve(rhs_, d_, work_);
+    if (scaled_) launch_vec_mul(n_pad_, d_, scale_, d_, stream_);  // apply_inverse_scaling: step = D y
     timer_.end(kPgTriSolve, stream_);
     have_step_ = true;
     if (step_out || grad_out) {
@@ -201,6 +207,8 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
             if (!out) continue;
             HIP_TRY(hipMemcpyAsync(h.data(), pass == 0 ? d_ : g_, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
             HIP_TRY(hipStreamSynchronize(stream_));
+            if (scaled_)  // the caller's variables are the scaled ones: y = step / s, gradient = s g
+                for (int64_t i = 0; i < n_; ++i) h[i] = pass == 0 ? h[i] / scale_h_[i] : h[i] * scale_h_[i];
             for (int64_t v = 0; v < n_v_; ++v)
                 for (int a = 0; a < 6; ++a) out[pose_col_[v] + a] = h[6 * (size_t)vmap_[v] + a];
         }
@@ -214,7 +222,7 @@ int PoseGraphSolver::step_stats(double out3[3]) {
     if (!have_step_) return fail(kInvalidState, "no step computed");
     HIP_TRY(hipSetDevice(device_));
     timer_.begin(kPgStats, stream_);
-    launch_step_stats(n_, g_, d_, last_lambda_, partial_, n_partial_, scal_ + 1, stream_);
+    launch_step_stats(n_, g_, d_, last_lambda_, scaled_ ? scale_ : nullptr, partial_, n_partial_, scal_ + 1, stream_);
     timer_.end(kPgStats, stream_);
     double h[3];
     HIP_TRY(hipMemcpyAsync(h, scal_ + 1, sizeof h, hipMemcpyDeviceToHost, stream_));
@@ -269,6 +277,70 @@ int PoseGraphSolver::parameter_norm(double* out) {
     return kOk;
 }
 
+// ---- Jacobi column scaling (process_jacobian_generic, optimizer/mod.rs:749-763) -------------------
+int PoseGraphSolver::ensure_scale_buffer() {
+    if (scale_) return kOk;
+    HIP_TRY(dev_alloc(&scale_, (size_t)n_pad_));
+    std::vector<double> ones(n_pad_, 1.0);
+    HIP_TRY(hipMemcpy(scale_, ones.data(), n_pad_ * sizeof(double), hipMemcpyHostToDevice));
+    return kOk;
+}
+
+// compute_column_norms (linearizer/mod.rs:229-239): the squared column norms of the corrected Jacobian are the
+// diagonal of J^T J, which the edge kernel already assembles.
+int PoseGraphSolver::column_norms(double* norms_out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    const bool was = scaled_;
+    scaled_ = false;
+    int rc = assemble(0.0);
+    scaled_ = was;
+    if (rc != kOk) return rc;
+    have_step_ = false;
+    tp_.diag(work_);
+    std::vector<double> h(n_);
+    HIP_TRY(hipMemcpyAsync(h.data(), work_, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (int64_t v = 0; v < n_v_; ++v)
+        for (int a = 0; a < 6; ++a) norms_out[pose_col_[v] + a] = sqrt(h[6 * (size_t)vmap_[v] + a]);
+    return kOk;
+}
+
+int PoseGraphSolver::set_column_scaling(const double* scaling) {
+    if (!have_structure_) return fail(kInvalidState, "Block structure not built");
+    HIP_TRY(hipSetDevice(device_));
+    have_step_ = false;
+    if (!scaling) { scaled_ = false; return kOk; }
+    int rc = ensure_scale_buffer();
+    if (rc != kOk) return rc;
+    scale_h_.assign(n_, 1.0);
+    for (int64_t v = 0; v < n_v_; ++v)
+        for (int a = 0; a < 6; ++a) scale_h_[6 * (size_t)vmap_[v] + a] = scaling[pose_col_[v] + a];
+    for (double v : scale_h_) if (!(v > 0.0) || !std::isfinite(v)) return fail(kInvalidInput, "column scaling must be positive and finite");
+    HIP_TRY(hipMemcpyAsync(scale_, scale_h_.data(), n_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    scaled_ = true;
+    return kOk;
+}
+
+int PoseGraphSolver::set_jacobi_scaling(bool on) {
+    if (!on) { scaled_ = false; have_step_ = false; return kOk; }
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    int rc = ensure_scale_buffer();
+    if (rc != kOk) return rc;
+    scaled_ = false;
+    rc = assemble(0.0);
+    if (rc != kOk) return rc;
+    tp_.diag(work_);
+    launch_scaling_from_norms_sq(n_, work_, scale_, stream_);  // the padding keeps its 1
+    scale_h_.resize(n_);
+    HIP_TRY(hipMemcpyAsync(scale_h_.data(), scale_, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    scaled_ = true; have_step_ = false;
+    return kOk;
+}
+
 int PoseGraphSolver::lm_optimize(LmConfig* cfg, LmResult* res, LmIterRecord* hist, int hist_cap) {
     if (!have_params_) return fail(kInvalidState, "no parameters set");
     return run_lm(*this, cfg, res, hist, hist_cap);
@@ -313,7 +385,7 @@ int PoseGraphSolver::get_hessian(double lambda, double* H_out, double* g_out) {
         std::vector<double> h(n_);
         HIP_TRY(hipMemcpyAsync(h.data(), g_, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
-        for (int64_t i = 0; i < n_; ++i) g_out[col[i]] = h[i];
+        for (int64_t i = 0; i < n_; ++i) g_out[col[i]] = scaled_ ? h[i] * scale_h_[i] : h[i];
     }
     if (H_out) {
         memset(H_out, 0, (size_t)n_ * (size_t)n_ * sizeof(double));

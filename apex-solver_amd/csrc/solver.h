@@ -48,6 +48,12 @@ class Solver : public LmBackend {
     int discard_step() override;                            // reference semantics: trial (+) (-step)
     int parameter_norm(double* out) override;
     int lm_optimize(LmConfig* cfg, LmResult* res, LmIterRecord* hist, int hist_cap);
+    // Jacobi column scaling (optimizer/mod.rs:749-763; AssemblyBackend::compute_column_norms / apply_column_scaling,
+    // linearizer/mod.rs:229-262).  With a scaling set, solve_augmented returns the SCALED step and gradient (what the
+    // reference's solver returns for J diag(s)); the unscaled step stays on the device for eval_step.
+    int column_norms(double* norms_out);                    // total_dof, global column order, at the current parameters
+    int set_column_scaling(const double* scaling);          // total_dof, global column order; NULL: off
+    int set_jacobi_scaling(bool on) override;               // on: s = 1 / (1 + norms) at the current parameters
 
     // parity / debug exports
     int get_residual(double* r_out);
@@ -91,6 +97,9 @@ class Solver : public LmBackend {
     int assemble(double lambda, double diag_extra);
     int assemble_implicit(double lambda);
     int implicit_pcg_solve(double lambda);
+    int implicit_matvec(const double* x, double lam_local, double* y, bool reduce);
+    int ensure_scale_buffers();
+    int column_norms_sq_device();   // -> n2 in cam_scale_ / pt_scale_ (camera part all-reduced over the shards)
     int factor_and_solve(double lambda);
     int cholesky_attempt(int* failed_at);
     int tri_solve();
@@ -155,6 +164,9 @@ class Solver : public LmBackend {
     int nd_leaf_ = 16;
     double* pcg_buf_ = nullptr;                    // 7 vectors of n_c_pad
     double *lmu_ = nullptr, *sd_ = nullptr, *minv_ = nullptr;  // matrix-free variant: {pt, u_l} records, diag blocks of S, their inverses
+    double *cam_scale_ = nullptr, *pt_scale_ = nullptr;   // Jacobi scaling, internal order ([n_c_pad] with 1 on the padding, [3 n_pt])
+    std::vector<double> cam_scale_h_, pt_scale_h_;
+    bool scaled_ = false;
     int n_partial_ = 1024;
 
     bool use_graphs_ = true;

@@ -36,7 +36,7 @@ Solver::~Solver() {
     if (stream_) hipStreamSynchronize(stream_);
     void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, rtasks2_, rchunks_, rentries_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
-                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_, lmu_, sd_, minv_};
+                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_};
     for (void* p : ptrs)
         if (p) hipFree(p);
 #ifdef APEX_WITH_RCCL
@@ -62,6 +62,8 @@ BAView Solver::view(int which) const {
     v.o_cam = o_cam_; v.o_pt = o_pt_; v.o_uv = o_uv_; v.pt_ptr = pt_ptr_;
     v.huber_delta = huber_delta_;
     v.co_pt = co_pt_; v.co_uv = co_uv_; v.co_rank = co_rank_;
+    v.cam_scale = scaled_ ? cam_scale_ : nullptr;
+    v.pt_scale = scaled_ ? pt_scale_ : nullptr;
     return v;
 }
 
@@ -574,6 +576,12 @@ int Solver::assemble(double lambda, double diag_extra) {
         stage_end(kStAllReduce);
     }
 #endif
+    if (scaled_) {  // the reduced system in the scaled variables: S := D_c S D_c, g_red := D_c g_red
+        stage_begin(kStAssembleCam);
+        tp_.scale_sym(cam_scale_);
+        launch_vec_mul(n_c_pad_, g_red_, cam_scale_, g_red_, stream_);
+        stage_end(kStAssembleCam);
+    }
     return kOk;
 }
 
@@ -663,15 +671,36 @@ int Solver::assemble_implicit(double lambda) {
     }
 #endif
     stage_begin(kStAssembleCam);
+    if (scaled_) {
+        launch_scale_diag_blocks(dc_, n_cam_, cam_scale_, sd_, stream_);
+        launch_vec_mul(n_c_pad_, g_red_, cam_scale_, g_red_, stream_);
+    }
     launch_precond_blocks(dc_, n_cam_, sd_, minv_, stream_);
     stage_end(kStAssembleCam);
+    return kOk;
+}
+
+// y = S x of the matrix-free operator (in the scaled variables when a scaling is set: D_c S0 D_c x, where S0 carries
+// lambda / s^2 on its diagonal).  lam_local: lambda on rank 0, 0 elsewhere (the all-reduce sums the ranks' partial products).
+int Solver::implicit_matvec(const double* x, double lam_local, double* y, bool reduce) {
+    const double* xin = x;
+    if (scaled_) {
+        double* t = pcg_buf_ + 4 * n_c_pad_;
+        launch_vec_mul(n_c_, x, cam_scale_, t, stream_);
+        xin = t;
+    }
+    launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xin, lam_local, y, stream_);
+#ifdef APEX_WITH_RCCL
+    if (reduce && comm_ && world_ > 1)
+        ncclAllReduce(y, y, (size_t)n_c_, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
+#endif
+    if (scaled_) launch_vec_mul(n_c_, y, cam_scale_, y, stream_);
     return kOk;
 }
 
 int Solver::implicit_pcg_solve(double lambda) {
     stage_begin(kStFactor);
     const int n = (int)n_c_;
-    const BAView v = view(cur_);
     double *x = dcam_, *r = pcg_buf_, *z = pcg_buf_ + n_c_pad_, *p = pcg_buf_ + 2 * n_c_pad_, *ap = pcg_buf_ + 3 * n_c_pad_;
     double* sc = scal_ + 16;
     HIP_TRY(hipMemsetAsync(x, 0, n_c_pad_ * sizeof(double), stream_));
@@ -687,11 +716,7 @@ int Solver::implicit_pcg_solve(double lambda) {
     const double lam_local = (rank_ == 0) ? lambda : 0.0;  // the all-reduce sums the ranks' partial S p
     int it = 0;
     for (; it < cg_max_iter_; ++it) {
-        launch_implicit_matvec(dc_, v, cam_ptr_, hinv_, lmu_, p, lam_local, ap, stream_);
-#ifdef APEX_WITH_RCCL
-        if (comm_ && world_ > 1)
-            ncclAllReduce(ap, ap, (size_t)n_c_, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
-#endif
+        implicit_matvec(p, lam_local, ap, true);
         launch_dot2(n, p, ap, p, ap, partial_, n_partial_, sc, stream_);
         double pap = 0.0;
         HIP_TRY(hipMemcpyAsync(&pap, sc, sizeof pap, hipMemcpyDeviceToHost, stream_));
@@ -728,6 +753,7 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     rc = (variant == 2) ? implicit_pcg_solve(lambda) : (variant == 1) ? pcg_solve() : factor_and_solve(lambda);
     if (rc != kOk) return rc;
     stage_begin(kStBackSub);
+    if (scaled_) launch_vec_mul(n_c_, dcam_, cam_scale_, dcam_, stream_);  // apply_inverse_scaling: dc = D_c y
     launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_);
     stage_end(kStBackSub);
     have_step_ = true;
@@ -739,6 +765,10 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
             HIP_TRY(hipMemcpyAsync(hc.data(), pass == 0 ? dcam_ : g_c_, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
             HIP_TRY(hipMemcpyAsync(hl.data(), pass == 0 ? dl_ : g_l_, 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
             HIP_TRY(hipStreamSynchronize(stream_));
+            if (scaled_) {  // the caller's variables are the scaled ones: y = step / s, gradient = s g
+                for (int64_t i = 0; i < n_c_; ++i) hc[i] = pass == 0 ? hc[i] / cam_scale_h_[i] : hc[i] * cam_scale_h_[i];
+                for (int64_t i = 0; i < 3 * n_pt_; ++i) hl[i] = pass == 0 ? hl[i] / pt_scale_h_[i] : hl[i] * pt_scale_h_[i];
+            }
             for (int64_t c = 0; c < n_cam_; ++c) {
                 const int64_t ci = cmap_[c];
                 for (int a = 0; a < 6; ++a) out[pose_col_[c] + a] = hc[ci * dc_ + a];
@@ -771,8 +801,8 @@ int Solver::step_stats(double out3[3]) {
     if (!have_step_) return fail(kInvalidState, "no step computed");
     HIP_TRY(hipSetDevice(device_));
     stage_begin(kStStats);
-    launch_step_stats(n_c_, g_c_, dcam_, last_lambda_, partial_, n_partial_, scal_, stream_);
-    launch_step_stats(3 * n_pt_, g_l_, dl_, last_lambda_, partial_, n_partial_, scal_ + 3, stream_);
+    launch_step_stats(n_c_, g_c_, dcam_, last_lambda_, scaled_ ? cam_scale_ : nullptr, partial_, n_partial_, scal_, stream_);
+    launch_step_stats(3 * n_pt_, g_l_, dl_, last_lambda_, scaled_ ? pt_scale_ : nullptr, partial_, n_partial_, scal_ + 3, stream_);
 #ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1)  // landmark part is sharded, camera part replicated
         ncclAllReduce(scal_ + 3, scal_ + 3, 3, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
@@ -838,6 +868,108 @@ int Solver::parameter_norm(double* out) {
     HIP_TRY(hipMemcpyAsync(h, scal_ + 9, sizeof h, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     *out = sqrt(h[0] + h[1] + h[2]);
+    return kOk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Jacobi column scaling (process_jacobian_generic, optimizer/mod.rs:749-763)
+// ---------------------------------------------------------------------------------------------
+int Solver::ensure_scale_buffers() {
+    if (cam_scale_) return kOk;
+    HIP_TRY(dev_alloc(&cam_scale_, (size_t)n_c_pad_));
+    HIP_TRY(dev_alloc(&pt_scale_, (size_t)std::max<int64_t>(3 * n_pt_, 1)));
+    return kOk;
+}
+
+// squared column norms of the corrected Jacobian at the current parameters, left in cam_scale_ / pt_scale_
+int Solver::column_norms_sq_device() {
+    int rc = ensure_scale_buffers();
+    if (rc != kOk) return rc;
+    const bool was = scaled_;
+    scaled_ = false;
+    const BAView v = view(cur_);
+    scaled_ = was;
+    HIP_TRY(hipMemsetAsync(cam_scale_, 0, n_c_pad_ * sizeof(double), stream_));
+    HIP_TRY(hipMemsetAsync(pt_scale_, 0, std::max<int64_t>(3 * n_pt_, 1) * sizeof(double), stream_));
+    launch_column_norms_sq(dc_, v, cam_scale_, pt_scale_, stream_);
+#ifdef APEX_WITH_RCCL
+    if (comm_ && world_ > 1)  // every rank sees all cameras but only its own landmarks
+        ncclAllReduce(cam_scale_, cam_scale_, (size_t)n_c_, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
+#endif
+    return kOk;
+}
+
+int Solver::column_norms(double* norms_out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    const bool was = scaled_;
+    std::vector<double> keep_c, keep_p;
+    if (was) { keep_c = cam_scale_h_; keep_p = pt_scale_h_; }
+    int rc = column_norms_sq_device();
+    if (rc != kOk) return rc;
+    std::vector<double> hc(n_c_), hl(3 * n_pt_);
+    HIP_TRY(hipMemcpyAsync(hc.data(), cam_scale_, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(hl.data(), pt_scale_, 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    for (int64_t c = 0; c < n_cam_; ++c) {
+        const int64_t ci = cmap_[c];
+        for (int a = 0; a < 6; ++a) norms_out[pose_col_[c] + a] = sqrt(hc[ci * dc_ + a]);
+        for (int a = 0; a < 3; ++a) norms_out[intr_col_[c] + a] = (dc_ == 9) ? sqrt(hc[ci * dc_ + 6 + a]) : 0.0;
+    }
+    for (int64_t l = 0; l < n_pt_; ++l)
+        for (int a = 0; a < 3; ++a) norms_out[pt_col_[l] + a] = sqrt(hl[3 * l + a]);
+    if (was) {  // the buffers held the active scaling: put it back
+        std::vector<double> pad(n_c_pad_, 1.0);
+        std::copy(keep_c.begin(), keep_c.end(), pad.begin());
+        HIP_TRY(hipMemcpyAsync(cam_scale_, pad.data(), n_c_pad_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipMemcpyAsync(pt_scale_, keep_p.data(), 3 * n_pt_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+    }
+    return kOk;
+}
+
+int Solver::set_column_scaling(const double* scaling) {
+    if (!have_structure_) return fail(kInvalidState, "Block structure not built");
+    HIP_TRY(hipSetDevice(device_));
+    have_step_ = false;
+    if (!scaling) { scaled_ = false; return kOk; }
+    int rc = ensure_scale_buffers();
+    if (rc != kOk) return rc;
+    cam_scale_h_.assign(n_c_, 1.0);
+    pt_scale_h_.assign(3 * n_pt_, 1.0);
+    for (int64_t c = 0; c < n_cam_; ++c) {
+        const int64_t ci = cmap_[c];
+        for (int a = 0; a < 6; ++a) cam_scale_h_[ci * dc_ + a] = scaling[pose_col_[c] + a];
+        if (dc_ == 9)
+            for (int a = 0; a < 3; ++a) cam_scale_h_[ci * dc_ + 6 + a] = scaling[intr_col_[c] + a];
+    }
+    for (int64_t l = 0; l < n_pt_; ++l)
+        for (int a = 0; a < 3; ++a) pt_scale_h_[3 * l + a] = scaling[pt_col_[l] + a];
+    for (double v : cam_scale_h_) if (!(v > 0.0) || !std::isfinite(v)) return fail(kInvalidInput, "column scaling must be positive and finite");
+    for (double v : pt_scale_h_) if (!(v > 0.0) || !std::isfinite(v)) return fail(kInvalidInput, "column scaling must be positive and finite");
+    std::vector<double> pad(n_c_pad_, 1.0);
+    std::copy(cam_scale_h_.begin(), cam_scale_h_.end(), pad.begin());
+    HIP_TRY(hipMemcpyAsync(cam_scale_, pad.data(), n_c_pad_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipMemcpyAsync(pt_scale_, pt_scale_h_.data(), 3 * n_pt_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    scaled_ = true;
+    return kOk;
+}
+
+// iteration 0 of the reference's loop: norms of the current Jacobian -> s = 1 / (1 + norm), kept for the whole optimize
+int Solver::set_jacobi_scaling(bool on) {
+    if (!on) { scaled_ = false; have_step_ = false; return kOk; }
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    HIP_TRY(hipSetDevice(device_));
+    int rc = column_norms_sq_device();
+    if (rc != kOk) return rc;
+    launch_scaling_from_norms_sq(n_c_pad_, cam_scale_, cam_scale_, stream_);  // padding: n2 = 0 -> 1
+    launch_scaling_from_norms_sq(3 * n_pt_, pt_scale_, pt_scale_, stream_);
+    cam_scale_h_.resize(n_c_); pt_scale_h_.resize(3 * n_pt_);
+    HIP_TRY(hipMemcpyAsync(cam_scale_h_.data(), cam_scale_, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipMemcpyAsync(pt_scale_h_.data(), pt_scale_, 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    scaled_ = true; have_step_ = false;
     return kOk;
 }
 
@@ -953,7 +1085,7 @@ int Solver::schur_matvec(double lambda, const double* x_in, double* y_explicit, 
         int rc = pass == 0 ? assemble(lambda, 0.0) : assemble_implicit(lambda);
         if (rc != kOk) return rc;
         if (pass == 0) tp_.sym_matvec(xd, yd);
-        else launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xd, rank_ == 0 ? lambda : 0.0, yd, stream_);  // a shard's partial
+        else implicit_matvec(xd, rank_ == 0 ? lambda : 0.0, yd, false);  // a shard's partial
         HIP_TRY(hipMemcpyAsync(h.data(), yd, n_c_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         std::fill(out, out + nref, 0.0);

@@ -52,6 +52,7 @@ class TilePlan {
     hipError_t zero_tiles();                             // async on the plan's stream
     void add_diag(int n_valid, double add_valid, double pad_value);  // diagonal += / padding rows := value
     void diag(double* out) const;                        // out[n_pad] = diagonal
+    void scale_sym(const double* scale);                 // A := D A D on the unfactored tiles, D = diag(scale[n_pad])
     // Cholesky in place; *failed_at = 0 or (tile column + 1) of the first non-positive pivot.  Syncs.
     // With rhs/work (2*n_pad doubles) the forward sweep L y = rhs rides along on a third stream; the next
     // solve(rhs, x, work) with the same pointers then only runs the backward sweep.

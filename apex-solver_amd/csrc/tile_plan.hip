@@ -305,6 +305,8 @@ void TilePlan::add_diag(int n_valid, double add_valid, double pad_value) {
     launch_tile_add_diag(tiles_, diag_slot_, n_valid, (int)n_pad(), add_valid, pad_value, stream_);
 }
 
+void TilePlan::scale_sym(const double* scale) { launch_tile_scale_sym(sym_tiles_, n_sym_tiles_, tiles_, scale, stream_); }
+
 void TilePlan::diag(double* out) const { launch_tile_diag(tiles_, diag_slot_, nt_, out, stream_); }
 
 // The factorisation and the triangular solves are static launch sequences for a given structure:

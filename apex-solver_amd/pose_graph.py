@@ -216,6 +216,25 @@ class GpuSparseCholeskySolver:
     def get_gradient(self):
         return getattr(self, "_grad", None)
 
+    # AssemblyBackend::compute_column_norms / apply_column_scaling / apply_inverse_scaling (linearizer/mod.rs:229-262)
+    def compute_column_norms(self) -> np.ndarray:
+        h = self._need()
+        n = np.zeros(6 * h.n_vertices)
+        h.check(h.L.apexgpu_pg_column_norms(h.h, capi.ptr(n)))
+        return n
+
+    def apply_column_scaling(self, scaling):
+        h = self._need()
+        a = None if scaling is None else np.ascontiguousarray(scaling, dtype=np.float64)
+        if a is not None and a.shape != (6 * h.n_vertices,):
+            raise ValueError("scaling must have total_dof entries")
+        h.check(h.L.apexgpu_pg_set_column_scaling(h.h, capi.ptr(a)))
+        self._scaling = a
+
+    def apply_inverse_scaling(self, step):
+        s = getattr(self, "_scaling", None)
+        return step if s is None else step * s
+
     def step_stats(self):
         h = self._need()
         o = (C.c_double * 3)()

@@ -100,6 +100,7 @@ class LevenbergMarquardtConfig:
     min_cost_threshold: float | None = None
     schur_variant: SchurVariant = SchurVariant.Sparse
     schur_preconditioner: SchurPreconditioner = SchurPreconditioner.None_
+    use_jacobi_scaling: bool = False  # :352
 
     @classmethod
     def new(cls) -> "LevenbergMarquardtConfig":
@@ -123,13 +124,15 @@ class LevenbergMarquardtConfig:
     def with_min_cost_threshold(self, v): return replace(self, min_cost_threshold=v)
     def with_schur_variant(self, v): return replace(self, schur_variant=v)
     def with_schur_preconditioner(self, v): return replace(self, schur_preconditioner=v)
+    def with_jacobi_scaling(self, on): return replace(self, use_jacobi_scaling=bool(on))  # :474-477
 
     def to_c(self) -> capi.LmConfigC:
         return capi.LmConfigC(
             self.max_iterations, self.cost_tolerance, self.parameter_tolerance, self.gradient_tolerance,
             self.damping, self.damping_min, self.damping_max, self.damping_nu, self.trust_region_radius,
             self.min_trust_region_radius, -1.0 if self.min_cost_threshold is None else self.min_cost_threshold,
-            -1.0 if self.timeout is None else float(self.timeout), self.schur_variant.value)
+            -1.0 if self.timeout is None else float(self.timeout), self.schur_variant.value,
+            1 if self.use_jacobi_scaling else 0)
 
 
 @dataclass
@@ -287,6 +290,27 @@ class GpuSchurComplementSolver:
     def get_gradient(self):
         """+J^T r of the last solve (explicit_schur.rs:1240-1242); None before any solve."""
         return self._gradient
+
+    # AssemblyBackend::compute_column_norms / apply_column_scaling / apply_inverse_scaling (linearizer/mod.rs:229-262)
+    def compute_column_norms(self) -> np.ndarray:
+        h = self._need()
+        n = np.zeros(self._problem.total_dof)
+        h.check(h.L.apexgpu_column_norms(h.h, capi.ptr(n)))
+        return n
+
+    def apply_column_scaling(self, scaling):
+        """J -> J diag(scaling) for the following solves (None: off).  solve_augmented_equation then returns the
+        scaled step and get_gradient the scaled gradient, like the reference's solver fed with the scaled Jacobian."""
+        h = self._need()
+        a = None if scaling is None else np.ascontiguousarray(scaling, dtype=np.float64)
+        if a is not None and a.shape != (self._problem.total_dof,):
+            raise ValueError("scaling must have total_dof entries")
+        h.check(h.L.apexgpu_set_column_scaling(h.h, capi.ptr(a)))
+        self._scaling = a
+
+    def apply_inverse_scaling(self, step):
+        s = getattr(self, "_scaling", None)
+        return step if s is None else step * s
 
     def step_stats(self):
         h = self._need(); out = (C.c_double * 3)()

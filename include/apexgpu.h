@@ -123,6 +123,24 @@ int apexgpu_discard_step(apexgpu_solver* h);
 /* compute_parameter_norm (src/optimizer/mod.rs:458-467) */
 int apexgpu_parameter_norm(apexgpu_solver* h, double* out);
 
+/* ---- Jacobi column scaling -------------------------------------------------------------------
+ * Replaces AssemblyBackend::compute_column_norms / apply_column_scaling / apply_inverse_scaling
+ * (src/linearizer/mod.rs:202-209, 229-262) as process_jacobian_generic and compute_step_generic use them
+ * (src/optimizer/mod.rs:749-763; levenberg_marquardt.rs:746-760).  The Jacobian is never materialised here, so
+ * "scaling J" is a state of the solver:
+ *   apexgpu_column_norms        norms_out[total_dof] = l2 norms of the corrected Jacobian's columns at the
+ *                               current parameters, global column order (0 for columns no factor touches)
+ *   apexgpu_set_column_scaling  scaling[total_dof] > 0 (the reference uses 1 / (1 + norm) of iteration 0), NULL = off.
+ * While a scaling is set, apexgpu_solve_augmented solves (D J^T J D + lambda I) y = -D J^T r -- eigenvalue gate,
+ * regularisation ladder and PCG tolerances in the scaled variables like the reference -- and returns
+ * step_out = y and grad_out = D J^T r, exactly what LinearSolver::solve_augmented_equation / get_gradient return
+ * for J D; the caller applies step = D y (apply_inverse_scaling).  On the device the unscaled step D y is kept for
+ * apexgpu_eval_step, and apexgpu_step_stats prices it against the scaled gradient as compute_step_generic does.
+ * apexgpu_get_schur then returns the scaled S and g_red.  apexgpu_lm_optimize with use_jacobi_scaling does all
+ * of this internally (scaling from the Jacobian at the starting point, dropped when the loop returns). */
+int apexgpu_column_norms(apexgpu_solver* h, double* norms_out);
+int apexgpu_set_column_scaling(apexgpu_solver* h, const double* scaling);
+
 /* ---- the LM loop (C++ twin of optimize_with_mode, levenberg_marquardt.rs:823-1031) ------------*/
 typedef struct {
     int max_iterations;             /* 50   (for_bundle_adjustment: 20)            :323, :524 */
@@ -138,6 +156,7 @@ typedef struct {
     double min_cost_threshold;      /* < 0: None                                    :344 */
     double timeout_s;               /* <= 0: None                                   :331 */
     int variant;                    /* APEXGPU_VARIANT_*                            :355 */
+    int use_jacobi_scaling;         /* 0     with_jacobi_scaling                    :352, :474 */
 } apexgpu_lm_config;
 
 typedef struct {
@@ -280,6 +299,9 @@ int apexgpu_pg_commit_step(apexgpu_pg_solver* h);
 int apexgpu_pg_discard_step(apexgpu_pg_solver* h);
 int apexgpu_pg_parameter_norm(apexgpu_pg_solver* h, double* out);
 /* optimize_with_mode (levenberg_marquardt.rs:823-1031), device-resident; cfg->variant must be 0 */
+/* Jacobi column scaling, as apexgpu_column_norms / apexgpu_set_column_scaling */
+int apexgpu_pg_column_norms(apexgpu_pg_solver* h, double* norms_out);
+int apexgpu_pg_set_column_scaling(apexgpu_pg_solver* h, const double* scaling);
 int apexgpu_pg_lm_optimize(apexgpu_pg_solver* h, apexgpu_lm_config* cfg, apexgpu_lm_result* result,
                            apexgpu_lm_iter* history, int history_capacity);
 

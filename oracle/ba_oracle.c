@@ -857,6 +857,7 @@ typedef struct {
     double *r, *Jpose, *Jpt, *Jintr;
     double *grad; /* +J^T r, global column order (get_gradient, :1240-1242) */
     int cg_max_iter; double cg_tol; int64_t last_pcg_iters; double last_reg;
+    double *scaling; /* Jacobi column scaling (optimizer/mod.rs:749-763), total_dof; NULL = off */
 } ora_problem;
 
 void ora_problem_destroy(ora_problem *p) {
@@ -864,7 +865,7 @@ void ora_problem_destroy(ora_problem *p) {
     free(p->cam_idx); free(p->pt_idx); free(p->obs_uv); free(p->intr_col); free(p->pose_col);
     free(p->pt_col); free(p->fix_pose); free(p->fix_intr); free(p->fix_pt); free(p->poses);
     free(p->intr); free(p->points); free(p->pt_ptr); free(p->pt_obs); free(p->r); free(p->Jpose);
-    free(p->Jpt); free(p->Jintr); free(p->grad);
+    free(p->Jpt); free(p->Jintr); free(p->grad); free(p->scaling);
     free(p);
 }
 
@@ -977,6 +978,23 @@ int ora_solve_augmented(ora_problem *p, double lambda, int variant, double *step
                         double *grad_out, double *S_out, double *gred_out) {
     const int64_t nc = p->cam_dof, npt = p->n_pt, nobs = p->n_obs, cam0 = 0, land0 = nc;
     const int has_intr = p->mode == 1;
+    /* With Jacobi scaling the LM loop hands the solver J * diag(scaling) (process_jacobian_generic,
+     * optimizer/mod.rs:749-763; apply_column_scaling, linearizer/mod.rs:241-253): everything below then
+     * runs on the scaled blocks and step_out / grad_out are the SCALED step and gradient, exactly what
+     * LinearSolver::solve_augmented_equation / get_gradient return to compute_step_generic. */
+    double *JPOSE = p->Jpose, *JPT = p->Jpt, *JINTR = p->Jintr;
+    if (p->scaling) {
+        JPOSE = (double *)malloc((size_t)nobs * 12 * 8 + 8); JPT = (double *)malloc((size_t)nobs * 6 * 8 + 8);
+        JINTR = (double *)malloc((size_t)nobs * 6 * 8 + 8);
+        for (int64_t i = 0; i < nobs; ++i) {
+            uint32_t c = p->cam_idx[i], l = p->pt_idx[i];
+            for (int rr = 0; rr < 2; ++rr) {
+                for (int a = 0; a < 6; ++a) JPOSE[12 * i + 6 * rr + a] = p->Jpose[12 * i + 6 * rr + a] * p->scaling[p->pose_col[c] + a];
+                for (int a = 0; a < 3; ++a) JPT[6 * i + 3 * rr + a] = p->Jpt[6 * i + 3 * rr + a] * p->scaling[p->pt_col[l] + a];
+                for (int a = 0; a < 3; ++a) JINTR[6 * i + 3 * rr + a] = p->Jintr[6 * i + 3 * rr + a] * p->scaling[p->intr_col[c] + a];
+            }
+        }
+    }
     /* H = J^T J (:1146-1150) restricted to the three block families; g = J^T r (:1151) */
     double *Hcc = (double *)calloc((size_t)nc * (size_t)nc, 8);
     double *Hll = (double *)calloc((size_t)npt * 9, 8);
@@ -985,7 +1003,7 @@ int ora_solve_augmented(ora_problem *p, double lambda, int variant, double *step
     if (!Hcc || !Hll) { free(Hcc); free(Hll); return ORA_ERR_INPUT; }
     for (int64_t i = 0; i < nobs; ++i) {
         uint32_t c = p->cam_idx[i], l = p->pt_idx[i];
-        const double *Jp = p->Jpose + 12 * i, *Jl = p->Jpt + 6 * i, *Ji = p->Jintr + 6 * i;
+        const double *Jp = JPOSE + 12 * i, *Jl = JPT + 6 * i, *Ji = JINTR + 6 * i;
         const double *r = p->r + 2 * i;
         int64_t pc = p->pose_col[c], ic = p->intr_col[c], lc = p->pt_col[l];
         for (int a = 0; a < 6; ++a) {
@@ -1057,7 +1075,7 @@ int ora_solve_augmented(ora_problem *p, double lambda, int variant, double *step
         for (int64_t k = p->pt_ptr[l]; k < p->pt_ptr[l + 1]; ++k) {
             int64_t i = p->pt_obs[k];
             uint32_t c = p->cam_idx[i];
-            const double *Jp = p->Jpose + 12 * i, *Jl = p->Jpt + 6 * i, *Ji = p->Jintr + 6 * i;
+            const double *Jp = JPOSE + 12 * i, *Jl = JPT + 6 * i, *Ji = JINTR + 6 * i;
             for (int a = 0; a < rows_per_obs; ++a) {
                 int64_t row = (a < 6) ? p->pose_col[c] + a : p->intr_col[c] + (a - 6);
                 int64_t *f = (int64_t *)bsearch(&row, cam_rows + base, (size_t)(w - base), 8, cmp_i64);
@@ -1110,7 +1128,33 @@ int ora_solve_augmented(ora_problem *p, double lambda, int variant, double *step
     free(Hcc); free(Hll); free(blk_of_pt); free(pt_of_blk); free(row_ptr); free(cams_sorted);
     free(lst_ptr); free(cam_rows); free(hcl); free(g_c); free(g_p); free(Hinv); free(S); free(gred);
     free(dc); free(dp);
+    if (p->scaling) { free(JPOSE); free(JPT); free(JINTR); }
     return rc;
+}
+
+/* AssemblyBackend::compute_column_norms (linearizer/mod.rs:229-239) of the last linearisation's corrected
+ * Jacobian, global column order.  Columns no factor touches (intr_* in BundleAdjustment mode) have norm 0. */
+int ora_column_norms(const ora_problem *p, double *norms_out) {
+    memset(norms_out, 0, (size_t)p->total_dof * 8);
+    for (int64_t i = 0; i < p->n_obs; ++i) {
+        uint32_t c = p->cam_idx[i], l = p->pt_idx[i];
+        for (int rr = 0; rr < 2; ++rr) {
+            for (int a = 0; a < 6; ++a) { double v = p->Jpose[12 * i + 6 * rr + a]; norms_out[p->pose_col[c] + a] += v * v; }
+            for (int a = 0; a < 3; ++a) { double v = p->Jpt[6 * i + 3 * rr + a]; norms_out[p->pt_col[l] + a] += v * v; }
+            if (p->mode == 1)
+                for (int a = 0; a < 3; ++a) { double v = p->Jintr[6 * i + 3 * rr + a]; norms_out[p->intr_col[c] + a] += v * v; }
+        }
+    }
+    for (int64_t j = 0; j < p->total_dof; ++j) norms_out[j] = sqrt(norms_out[j]);
+    return ORA_OK;
+}
+
+/* The scaling vector process_jacobian_generic keeps from iteration 0 (optimizer/mod.rs:754-758);
+ * NULL switches scaling off. */
+int ora_set_column_scaling(ora_problem *p, const double *scaling) {
+    free(p->scaling); p->scaling = NULL;
+    if (scaling) p->scaling = (double *)dupmem(scaling, (size_t)p->total_dof * 8);
+    return ORA_OK;
 }
 
 int64_t ora_last_pcg_iters(const ora_problem *p) { return p->last_pcg_iters; }
@@ -1178,6 +1222,7 @@ typedef struct {
     double min_trust_region_radius; /* 1e-32 */
     double min_cost_threshold;      /* <0: None */
     int variant;                    /* 0 Sparse(Cholesky) 1 Iterative(PCG) */
+    int use_jacobi_scaling;         /* false by default (:352) */
 } ora_lm_config;
 
 /* update_damping (levenberg_marquardt.rs:702-717).  Returns 1 if the step is accepted. */
@@ -1217,8 +1262,15 @@ int ora_lm_optimize(ora_problem *p, ora_lm_config *cfg, double *hist, int hist_r
     int iteration = 0, status = ORA_ST_MAX_ITER;
     for (;;) {
         ora_linearize(p, NULL, NULL, NULL, NULL);
+        if (cfg->use_jacobi_scaling && iteration == 0) { /* process_jacobian_generic (mod.rs:749-763) */
+            ora_column_norms(p, step);
+            for (int64_t i = 0; i < p->total_dof; ++i) step[i] = 1.0 / (1.0 + step[i]);
+            ora_set_column_scaling(p, step);
+        }
         int rc = ora_solve_augmented(p, lambda, cfg->variant, step, grad, NULL, NULL);
         if (rc != ORA_OK) { status = ORA_ST_LINEAR_SOLVE_FAILED; break; }
+        if (p->scaling) /* apply_inverse_scaling (:749-757); the gradient stays the scaled one */
+            for (int64_t i = 0; i < p->total_dof; ++i) step[i] *= p->scaling[i];
         double gn = 0.0, sn = 0.0, pred = 0.0;
         for (int64_t i = 0; i < p->total_dof; ++i) {
             gn += grad[i] * grad[i];
@@ -1268,6 +1320,7 @@ int ora_lm_optimize(ora_problem *p, ora_lm_config *cfg, double *hist, int hist_r
     cfg->damping = lambda; cfg->damping_nu = nu;
     if (iterations_out) *iterations_out = iteration;
     if (final_cost_out) *final_cost_out = cost;
+    if (cfg->use_jacobi_scaling) ora_set_column_scaling(p, NULL); /* the scaling lives in the optimizer, not the problem */
     free(step); free(grad);
     return status;
 }

@@ -52,12 +52,13 @@ class LMConfig(C.Structure):
         ("gradient_tolerance", C.c_double), ("damping", C.c_double), ("damping_min", C.c_double),
         ("damping_max", C.c_double), ("damping_nu", C.c_double), ("trust_region_radius", C.c_double),
         ("min_trust_region_radius", C.c_double), ("min_cost_threshold", C.c_double), ("variant", C.c_int),
+        ("use_jacobi_scaling", C.c_int),
     ]
 
     @classmethod
     def default(cls, **kw) -> "LMConfig":
         """LevenbergMarquardtConfig::default (levenberg_marquardt.rs:318-358)."""
-        c = cls(50, 1e-6, 1e-8, 1e-10, 1e-3, 1e-12, 1e12, 2.0, 1e4, 1e-32, -1.0, 0)
+        c = cls(50, 1e-6, 1e-8, 1e-10, 1e-3, 1e-12, 1e12, 2.0, 1e4, 1e-32, -1.0, 0, 0)
         for k, v in kw.items():
             setattr(c, k, v)
         return c
@@ -124,6 +125,10 @@ def lib(native: bool = False):
     L.ora_linearize.restype = C.c_double
     L.ora_solve_augmented.argtypes = [vp, C.c_double, C.c_int, _f64p, _f64p, vp, vp]
     L.ora_solve_augmented.restype = C.c_int
+    L.ora_column_norms.argtypes = [vp, _f64p]
+    L.ora_column_norms.restype = C.c_int
+    L.ora_set_column_scaling.argtypes = [vp, _OptF64]
+    L.ora_set_column_scaling.restype = C.c_int
     L.ora_last_pcg_iters.argtypes = [vp]
     L.ora_last_pcg_iters.restype = C.c_int64
     L.ora_last_reg.argtypes = [vp]
@@ -240,6 +245,17 @@ class OracleProblem:
         if rc != 0:
             raise RuntimeError(f"oracle solve_augmented failed: {rc}")
         return (step, grad, S, gred) if want_schur else (step, grad)
+
+    def column_norms(self) -> np.ndarray:
+        """compute_column_norms of the last linearisation (linearizer/mod.rs:229-239)."""
+        n = np.empty(self.total_dof)
+        self._L.ora_column_norms(self._h, n)
+        return n
+
+    def set_column_scaling(self, scaling):
+        """J -> J diag(scaling) for the following solves (None: off); solve_augmented then returns the
+        scaled step and gradient, as the reference's solver does for a scaled Jacobian."""
+        self._L.ora_set_column_scaling(self._h, None if scaling is None else np.ascontiguousarray(scaling, dtype=np.float64))
 
     def apply_step(self, step, sign: float = 1.0) -> float:
         return self._L.ora_apply_step(self._h, np.ascontiguousarray(step, dtype=np.float64), float(sign))

@@ -376,6 +376,7 @@ typedef struct {
     uint8_t *fix; /* [n_v][6] */
     double huber_delta;
     double *r, *J; /* last linearisation: [n_e][6], [n_e][72] */
+    double *scaling; /* Jacobi column scaling (optimizer/mod.rs:749-763), caller's column order; NULL = off */
 } pgo_problem;
 
 static void *dupmem(const void *src, size_t bytes) {
@@ -401,6 +402,7 @@ pgo_problem *pgo_create(int64_t n_v, int64_t n_e, const int64_t *from, const int
 void pgo_destroy(pgo_problem *p) {
     if (!p) return;
     free(p->from); free(p->to); free(p->pose_col); free(p->meas); free(p->poses); free(p->fix); free(p->r); free(p->J);
+    free(p->scaling);
     free(p);
 }
 void pgo_set_params(pgo_problem *p, const double *poses) { memcpy(p->poses, poses, (size_t)p->n_v * 56); }
@@ -471,6 +473,25 @@ void pgo_normal_equations(const pgo_problem *p, double *H /* may be NULL */, dou
     }
 }
 
+/* compute_column_norms (linearizer/mod.rs:229-239) of the last linearisation, caller's column order */
+void pgo_column_norms(const pgo_problem *p, double *norms_out) {
+    memset(norms_out, 0, (size_t)p->total_dof * 8);
+    for (int64_t e = 0; e < p->n_e; ++e) {
+        const double *J = p->J + 72 * e;
+        const int64_t col[2] = {p->pose_col[p->from[e]], p->pose_col[p->to[e]]};
+        for (int a = 0; a < 12; ++a)
+            for (int k = 0; k < 6; ++k) norms_out[col[a / 6] + a % 6] += J[12 * k + a] * J[12 * k + a];
+    }
+    for (int64_t i = 0; i < p->total_dof; ++i) norms_out[i] = sqrt(norms_out[i]);
+}
+
+/* apply_column_scaling (linearizer/mod.rs:241-253) as a state of the problem: the following solves run on
+ * J diag(scaling) and return the scaled step and gradient; NULL switches it off. */
+void pgo_set_column_scaling(pgo_problem *p, const double *scaling) {
+    free(p->scaling); p->scaling = NULL;
+    if (scaling) p->scaling = (double *)dupmem(scaling, (size_t)p->total_dof * 8);
+}
+
 /* (J^T J + lambda I) dx = -J^T r by an envelope Cholesky in VERTEX order (cholesky.rs:159-230).
  * step/grad come back in the caller's column order.  PG_ERR_SINGULAR on a non-positive pivot. */
 int pgo_solve_augmented(pgo_problem *p, double lambda, double *step_out, double *grad_out) {
@@ -491,8 +512,17 @@ int pgo_solve_augmented(pgo_problem *p, double lambda, double *step_out, double 
     double *L = (double *)calloc((size_t)rs[n], 8), *g = (double *)calloc((size_t)n, 8);
 #define ENV(i, j) L[rs[i] + ((j) - f[i])]
     for (int64_t e = 0; e < p->n_e; ++e) {
-        const double *J = p->J + 72 * e, *r = p->r + 6 * e;
+        const double *J0 = p->J + 72 * e, *r = p->r + 6 * e;
         const int64_t vv[2] = {p->from[e], p->to[e]};
+        double Js[72];
+        const double *J = J0;
+        if (p->scaling) {
+            for (int a = 0; a < 12; ++a) {
+                const double sc = p->scaling[p->pose_col[vv[a / 6]] + a % 6];
+                for (int k = 0; k < 6; ++k) Js[12 * k + a] = J0[12 * k + a] * sc;
+            }
+            J = Js;
+        }
         for (int a = 0; a < 12; ++a) {
             const int64_t ia = 6 * vv[a / 6] + a % 6;
             double s = 0.0;
@@ -610,7 +640,7 @@ double pgo_parameter_norm(const pgo_problem *p) { /* optimizer/mod.rs:458-467 */
 
 /* LM loop (levenberg_marquardt.rs:823-1031); same conventions as ba_oracle.c's ora_lm_optimize.
  * cfg: [max_iterations, cost_tol, param_tol, grad_tol, damping, damping_min, damping_max, nu,
- *       trust_region_radius, min_trust_region_radius, min_cost_threshold]; hist rows of 8:
+ *       trust_region_radius, min_trust_region_radius, min_cost_threshold, use_jacobi_scaling]; hist rows of 8:
  * [cost_after, damping_after, rho, accepted, grad_norm, step_norm, predicted_reduction, trial_cost] */
 int pgo_lm_optimize(pgo_problem *p, double *cfg, double *hist, int hist_rows, int *iterations_out,
                     double *initial_cost_out, double *final_cost_out, double *params_out /* optional: hist_rows x 7 n_v, params BEFORE each iteration */) {
@@ -625,7 +655,14 @@ int pgo_lm_optimize(pgo_problem *p, double *cfg, double *hist, int hist_rows, in
     for (;;) {
         if (params_out && iteration < hist_rows) memcpy(params_out + (size_t)iteration * 7 * p->n_v, p->poses, (size_t)p->n_v * 56);
         pgo_linearize(p, NULL, NULL);
+        if (cfg[11] != 0.0 && iteration == 0) { /* process_jacobian_generic (optimizer/mod.rs:749-763) */
+            pgo_column_norms(p, step);
+            for (int64_t i = 0; i < n; ++i) step[i] = 1.0 / (1.0 + step[i]);
+            pgo_set_column_scaling(p, step);
+        }
         if (pgo_solve_augmented(p, lambda, step, grad) != PG_OK) { status = 100; break; }
+        if (p->scaling) /* apply_inverse_scaling (levenberg_marquardt.rs:749-757); the gradient stays scaled */
+            for (int64_t i = 0; i < n; ++i) step[i] *= p->scaling[i];
         double gn = 0.0, sn = 0.0, pred = 0.0;
         for (int64_t i = 0; i < n; ++i) {
             gn += grad[i] * grad[i];
@@ -674,6 +711,7 @@ int pgo_lm_optimize(pgo_problem *p, double *cfg, double *hist, int hist_rows, in
     cfg[4] = lambda; cfg[7] = nu;
     if (iterations_out) *iterations_out = iteration;
     if (final_cost_out) *final_cost_out = cost;
+    if (cfg[11] != 0.0) pgo_set_column_scaling(p, NULL);
     free(step); free(grad);
     return status;
 }

@@ -58,6 +58,10 @@ def lib() -> C.CDLL:
     L.pgo_solve_augmented.restype = C.c_int
     L.pgo_solve_dense_jacobian.argtypes = [C.c_int64, C.c_int64, _f64, _f64, C.c_double, _f64, _Opt]
     L.pgo_solve_dense_jacobian.restype = C.c_int
+    L.pgo_column_norms.argtypes = [C.c_void_p, _f64]
+    L.pgo_column_norms.restype = None
+    L.pgo_set_column_scaling.argtypes = [C.c_void_p, _Opt]
+    L.pgo_set_column_scaling.restype = None
     L.pgo_apply_step.argtypes = [C.c_void_p, _f64, C.c_double]
     L.pgo_parameter_norm.argtypes = [C.c_void_p]
     L.pgo_parameter_norm.restype = C.c_double
@@ -95,10 +99,11 @@ def solve_dense_jacobian(J, r, lam=0.0):
 
 def lm_config(max_iterations=50, cost_tolerance=1e-6, parameter_tolerance=1e-8, gradient_tolerance=1e-10, damping=1e-3,
               damping_min=1e-12, damping_max=1e12, nu=2.0, trust_region_radius=1e4, min_trust_region_radius=1e-32,
-              min_cost_threshold=-1.0) -> np.ndarray:
+              min_cost_threshold=-1.0, use_jacobi_scaling=False) -> np.ndarray:
     """LevenbergMarquardtConfig::default (levenberg_marquardt.rs:318-358) as the array pgo_lm_optimize takes."""
     return np.array([max_iterations, cost_tolerance, parameter_tolerance, gradient_tolerance, damping, damping_min,
-                     damping_max, nu, trust_region_radius, min_trust_region_radius, min_cost_threshold], dtype=np.float64)
+                     damping_max, nu, trust_region_radius, min_trust_region_radius, min_cost_threshold,
+                     1.0 if use_jacobi_scaling else 0.0], dtype=np.float64)
 
 
 class PgOracle:
@@ -153,6 +158,14 @@ class PgOracle:
         step = np.zeros(n); grad = np.zeros(n)
         rc = self.L.pgo_solve_augmented(self.p, float(lam), step, grad)
         return rc, step, grad
+
+    def column_norms(self):
+        n = np.zeros(6 * self.n_v)
+        self.L.pgo_column_norms(self.p, n)
+        return n
+
+    def set_column_scaling(self, scaling):
+        self.L.pgo_set_column_scaling(self.p, None if scaling is None else np.ascontiguousarray(scaling, dtype=np.float64))
 
     def apply_step(self, step, sign=1.0): self.L.pgo_apply_step(self.p, np.ascontiguousarray(step, dtype=np.float64), float(sign))
     def parameter_norm(self): return self.L.pgo_parameter_norm(self.p)

@@ -541,3 +541,97 @@ def test_shard_partials_sum_to_full(oracle):
         sr.close()
     assert rel(pe, ye) < 1e-12 and rel(pi, yi) < 1e-12 and rel(yi, ye) < 1e-12
     s.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# Jacobi column scaling (optimizer/mod.rs:749-763; linearizer/mod.rs:229-262)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["selfcal", "ba"])
+def test_jacobi_scaling_one_iteration_vs_oracle(oracle, mode):
+    """Column norms, the scaled Schur system (S, g_red), the scaled step / gradient the solver returns, the
+    statistics compute_step_generic derives from them, and the trial cost of the unscaled step."""
+    d = pkg.synthetic.make_problem(40, 2000, 3, 7, config_id=240)
+    prob, s = gpu_solver(d, mode)
+    o = oracle_problem(oracle, d, prob, mode)
+    o.linearize()
+    norms = s.compute_column_norms()
+    onorms = o.column_norms()
+    assert rel(norms, onorms) < 1e-12
+    scal = 1.0 / (1.0 + onorms)
+    s.apply_column_scaling(scal)
+    o.set_column_scaling(scal)
+    lam = 1e-3
+    oy, ogs, oS, ogred = o.solve_augmented(lam, 0, want_schur=True)
+    y = s.solve_augmented_equation(lam)
+    S, gred = s.get_schur()
+    errs = dict(grad=rel(s.get_gradient(), ogs), S=rel(S, oS), gred=rel(gred, ogred), step=rel(y, oy))
+    print(mode, {k: f"{v:.1e}" for k, v in errs.items()})
+    assert errs["grad"] < 1e-12 and errs["S"] < 1e-12 and errs["gred"] < 1e-10
+    tol = max(1e-10, 20 * np.finfo(float).eps * np.linalg.cond(oS))
+    assert errs["step"] < tol, (errs["step"], tol)
+    # compute_step_generic (levenberg_marquardt.rs:746-760): |scaled gradient|, |unscaled step|,
+    # predicted reduction from the unscaled step and the scaled gradient
+    ostep = oy * scal
+    gn, sn, pred = s.step_stats()
+    assert gn == pytest.approx(np.linalg.norm(ogs), rel=1e-12)
+    assert sn == pytest.approx(np.linalg.norm(ostep), rel=1e-8)
+    assert pred == pytest.approx(0.5 * ostep @ (lam * ostep - ogs), rel=1e-7)
+    assert rel(s.apply_inverse_scaling(y), ostep) < tol
+    o.apply_step(ostep, 1.0)
+    assert s.eval_step() == pytest.approx(o.residuals()[0], rel=1e-9)
+    s.discard_step()
+    # switching the scaling off restores the plain solve
+    s.apply_column_scaling(None)
+    o.apply_step(ostep, -1.0); o.set_column_scaling(None); o.linearize()
+    ostep0, ograd0 = o.solve_augmented(lam, 0)
+    step0 = s.solve_augmented_equation(lam)
+    assert rel(s.get_gradient(), ograd0) < 1e-11 and rel(step0, ostep0) < 1e-7
+    s.close()
+
+
+@pytest.mark.parametrize("variant", [SchurVariant.Iterative, SchurVariant.Implicit])
+def test_jacobi_scaling_pcg_variants_vs_oracle(oracle, variant):
+    """Both PCG variants iterate on the scaled system (tolerance on the scaled residual)."""
+    d = pkg.synthetic.make_problem(30, 1500, 3, 7, config_id=241)
+    prob, s = gpu_solver(d, "selfcal", variant=variant)
+    o = oracle_problem(oracle, d, prob, "selfcal")
+    if variant == SchurVariant.Implicit:
+        s.with_cg_params(500, 1e-9); o.set_cg_params(500, 1e-9)
+    o.linearize()
+    scal = 1.0 / (1.0 + o.column_norms())
+    s.apply_column_scaling(scal); o.set_column_scaling(scal)
+    oy_chol, ogs, oS, ogred = o.solve_augmented(1e-3, 0, want_schur=True)
+    oy, _ = o.solve_augmented(1e-3, variant.value)
+    y = s.solve_augmented_equation(1e-3)
+    nc = prob.layout.cam_dof
+    it_gpu, it_ora = s.info()["pcg_iterations"], o.last_pcg_iters
+    print(variant.name, "pcg iterations gpu/oracle", it_gpu, it_ora)
+    assert abs(it_gpu - it_ora) <= max(3, it_ora // 20)
+    assert rel(s.get_gradient(), ogs) < 1e-12
+    tol = 1e-6 if variant == SchurVariant.Iterative else 1e-9
+    r_gpu = np.linalg.norm(oS @ y[:nc] - ogred); r_ora = np.linalg.norm(oS @ oy[:nc] - ogred)
+    assert r_gpu < 10 * max(r_ora, tol * max(np.linalg.norm(ogred), 1.0))
+    if variant == SchurVariant.Implicit:  # both operator forms agree in the scaled variables too
+        x = np.random.default_rng(5).standard_normal(nc)
+        ye, yi = s.schur_matvec(1e-3, x)
+        assert rel(ye, oS @ x) < 1e-11 and rel(yi, oS @ x) < 1e-11
+    s.close()
+
+
+def test_jacobi_scaling_lm_history_vs_oracle(oracle):
+    """LevenbergMarquardtConfig::with_jacobi_scaling(true): scaling from the Jacobian of iteration 0, same
+    accept / reject pattern, costs and damping as the oracle's loop."""
+    d = pkg.synthetic.make_problem(20, 600, 3, 7, config_id=242)
+    prob = Problem.bundle_adjustment(d, OptimizationType.SelfCalibration, 1.0)
+    cfg = LevenbergMarquardtConfig().with_max_iterations(10).with_jacobi_scaling(True)
+    res = LevenbergMarquardt.with_config(cfg).optimize(prob)
+    o = oracle.from_data(d, prob.layout, mode="selfcal")
+    ores = o.optimize(oracle.LMConfig.default(max_iterations=10, use_jacobi_scaling=1))
+    assert res.status.name == ores.status and res.iterations == ores.iterations
+    assert np.array_equal(res.history[:, 3], ores.history[:, 3])
+    assert np.allclose(res.history[:, 0], ores.history[:, 0], rtol=1e-7)
+    assert np.allclose(res.history[:, 4], ores.history[:, 4], rtol=1e-6)   # |scaled gradient|
+    assert np.allclose(res.history[:, 1], ores.history[:, 1], rtol=1e-4)
+    # and the unscaled loop takes a different path from the same start
+    res0 = LevenbergMarquardt.with_config(cfg.with_jacobi_scaling(False)).optimize(prob)
+    assert not np.allclose(res0.history[:2, 5], res.history[:2, 5], rtol=1e-3)

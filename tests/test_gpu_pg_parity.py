@@ -245,3 +245,56 @@ def test_empty_edge_list_is_an_identity_system():
     step = s.solve_augmented_equation(1e-3)
     assert np.all(step == 0.0)
     s.close()
+
+
+# ---- Jacobi column scaling (optimizer/mod.rs:749-763; linearizer/mod.rs:229-262) -----------------------------
+@pytest.mark.parametrize("huber", [None, 0.8])
+def test_jacobi_scaling_vs_oracle(huber):
+    d = pkg.synthetic.make_sphere(20, 30, id_stride=3)
+    prob = PoseGraphProblem.pose_graph(d, huber)
+    o = po.PgOracle.from_problem(prob)
+    s = GpuSparseCholeskySolver().initialize_structure(prob)
+    s.set_parameters(d.poses)
+    o.linearize()
+    norms, onorms = s.compute_column_norms(), o.column_norms()
+    assert rel(norms, onorms) < 1e-12
+    scal = 1.0 / (1.0 + onorms)
+    s.apply_column_scaling(scal); o.set_column_scaling(scal)
+    lam = 1e-3
+    Ho, go = o.normal_equations()
+    Hs = Ho * scal[:, None] * scal[None, :] + lam * np.eye(len(go))
+    H, g = s.get_hessian(lam)
+    assert rel(H, Hs) < 1e-12 and rel(g, scal * go) < 1e-12
+    y = s.solve_augmented_equation(lam)
+    rc, yo, gso = o.solve_augmented(lam)
+    assert rc == 0 and rel(s.get_gradient(), gso) < 1e-12
+    assert rel(y, yo) < max(1e-10, 20 * EPS * np.linalg.cond(Hs))
+    assert np.linalg.norm(Hs @ y + scal * go) <= 1e-13 * (np.linalg.norm(Hs, 2) * np.linalg.norm(y) + np.linalg.norm(go))
+    step = yo * scal
+    gn, sn, pred = s.step_stats()   # compute_step_generic: scaled gradient, unscaled step
+    assert abs(gn - np.linalg.norm(gso)) <= 1e-12 * gn and abs(sn - np.linalg.norm(step)) <= 1e-8 * sn
+    assert abs(pred - 0.5 * step @ (lam * step - gso)) <= 1e-7 * abs(pred)
+    o.apply_step(step, 1.0)
+    assert abs(s.eval_step() - o.residuals()[0]) <= 1e-9 * o.residuals()[0]
+    s.discard_step()
+    s.apply_column_scaling(None)
+    o.apply_step(step, -1.0); o.set_column_scaling(None); o.linearize()
+    rc, so, _ = o.solve_augmented(lam)
+    assert rel(s.solve_augmented_equation(lam), so) < 1e-7
+    s.close()
+
+
+def test_jacobi_scaling_lm_history_vs_oracle():
+    d = pkg.synthetic.make_sphere(12, 16)
+    prob = PoseGraphProblem.pose_graph(d)
+    cfg = (LevenbergMarquardtConfig.new().with_max_iterations(15).with_jacobi_scaling(True)
+           .with_linear_solver_type(LinearSolverType.SparseCholesky))
+    res = LevenbergMarquardt.with_config(cfg).optimize(prob)
+    o = po.PgOracle.from_problem(prob)
+    ref = o.lm_optimize(po.lm_config(max_iterations=15, use_jacobi_scaling=True))
+    assert res.status.value == ref["status"] and res.iterations == ref["iterations"]
+    H = ref["history"]
+    assert np.allclose(res.history[:, 3], H[:, 3])
+    assert np.allclose(res.history[:, 0], H[:, 0], rtol=1e-7) and np.allclose(res.history[:, 4], H[:, 4], rtol=1e-6)
+    assert np.allclose(res.history[:, 1], H[:, 1], rtol=1e-4)
+    assert res.final_cost < 0.05 * res.initial_cost

@@ -286,3 +286,39 @@ def test_sparse_cholesky_empty_matrix():
     """cholesky.rs:429-445"""
     rc, dx, _ = po.solve_dense_jacobian(np.zeros((0, 0)), np.zeros(0))
     assert rc == 0 and dx.shape == (0,)
+
+
+# ---- Jacobi column scaling (optimizer/mod.rs:749-763; linearizer/mod.rs:229-262) ---------------------------
+def test_jacobi_scaling_solves_the_scaled_system(small_problem):
+    """compute_column_norms / apply_column_scaling / the solve on J D against dense numpy:
+    (D H D + lam I) y = -D g, get_gradient = D g; D y solves (H + lam D^-2) step = -g."""
+    o = po.PgOracle.from_problem(small_problem)
+    o.linearize()
+    H, g = o.normal_equations()
+    norms = o.column_norms()
+    assert np.allclose(norms, np.sqrt(np.diag(H)), rtol=1e-13)
+    s = 1.0 / (1.0 + norms)
+    o.set_column_scaling(s)
+    lam = 1e-2
+    rc, y, gs = o.solve_augmented(lam)
+    assert rc == 0
+    Hs = H * s[:, None] * s[None, :]
+    y2 = np.linalg.solve(Hs + lam * np.eye(len(g)), -(s * g))
+    assert np.allclose(gs, s * g, rtol=1e-13, atol=1e-15)
+    assert np.linalg.norm(y - y2) < 1e-9 * np.linalg.norm(y2)
+    step = s * y
+    assert np.linalg.norm((H + lam * np.diag(1 / s**2)) @ step + g) < 1e-8 * np.linalg.norm(g)
+    o.set_column_scaling(None)
+    rc, y0, g0 = o.solve_augmented(lam)
+    assert np.allclose(g0, g) and np.linalg.norm(y0 - step) > 1e-3 * np.linalg.norm(step)
+
+
+def test_lm_loop_with_jacobi_scaling(small_problem):
+    """test_lm_jacobi_scaling_enabled (levenberg_marquardt.rs:1426-1435) on a pose graph."""
+    o = po.PgOracle.from_problem(small_problem)
+    res = o.lm_optimize(po.lm_config(max_iterations=30, use_jacobi_scaling=True))
+    assert res["final_cost"] < 0.05 * res["initial_cost"]
+    o2 = po.PgOracle.from_problem(small_problem)
+    res2 = o2.lm_optimize(po.lm_config(max_iterations=30))
+    assert res2["final_cost"] < 0.05 * res2["initial_cost"]
+    assert not np.allclose(res["history"][:2, 5], res2["history"][:2, 5], rtol=1e-3)  # a different path
