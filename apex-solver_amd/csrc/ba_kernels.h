@@ -113,6 +113,7 @@ void launch_step_stats(int64_t n, const double* g, const double* d, double lambd
 void launch_column_norms_sq(int dc, const BAView& v, double* n2_cam, double* n2_pt, hipStream_t s);
 void launch_scaling_from_norms_sq(int64_t n, const double* n2, double* scale, hipStream_t s);
 void launch_vec_mul(int64_t n, const double* a, const double* b, double* out, hipStream_t s);  // out = a .* b (in place ok)
+void launch_vec_add(int64_t n, const double* a, const double* b, double* out, hipStream_t s);  // out = a + b (in place ok)
 // sd[c][a][b] *= s[c][a] s[c][b]: the Schur-Jacobi diagonal blocks in the scaled variables
 void launch_scale_diag_blocks(int dc, int64_t n_cam, const double* scale, double* sd, hipStream_t s);
 void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, double* out, hipStream_t s);

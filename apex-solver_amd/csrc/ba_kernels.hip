@@ -966,6 +966,11 @@ __global__ __launch_bounds__(256) void k_vec_mul(int64_t n, const double* a, con
     if (i < n) out[i] = a[i] * b[i];
 }
 
+__global__ __launch_bounds__(256) void k_vec_add(int64_t n, const double* a, const double* b, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
 template <int DC>
 __global__ __launch_bounds__(256) void k_scale_diag_blocks(int64_t n_cam, const double* __restrict__ scale, double* __restrict__ sd) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1104,6 +1109,9 @@ void launch_scaling_from_norms_sq(int64_t n, const double* n2, double* scale, hi
 }
 void launch_vec_mul(int64_t n, const double* a, const double* b, double* out, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_vec_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a, b, out);
+}
+void launch_vec_add(int64_t n, const double* a, const double* b, double* out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_vec_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a, b, out);
 }
 void launch_scale_diag_blocks(int dc, int64_t n_cam, const double* scale, double* sd, hipStream_t s) {
     const int64_t n = n_cam * dc * dc;

@@ -124,6 +124,41 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
     return h->s->schur_matvec(lambda, x_in, y_explicit, y_implicit);
 }
 
+// Test entry: the `n` handles are the ranks 0..n-1 of one sharded problem (apexgpu_set_shard(r, n) before
+// set_structure, same parameters), all on this process's GPU.  Runs ONE distributed Cholesky solve in lockstep --
+// every rank executes phase p, then this function plays the communicator for the exchange that follows it (sums in
+// rank order, max for the failure flag) -- and leaves the step on every handle (apexgpu_export_step).
+int apexgpu_debug_lockstep_solve(apexgpu_solver** hs, int n, double lambda) {
+    if (!hs || n < 2) return APEXGPU_ERR_INVALID_INPUT;
+    for (int r = 0; r < n; ++r) if (!hs[r] || !hs[r]->s) return APEXGPU_ERR_INVALID_INPUT;
+    for (int phase = 0; phase <= 5; ++phase) {
+        for (int r = 0; r < n; ++r) {
+            const int rc = hs[r]->s->dist_phase(phase, lambda);
+            if (rc != 0) return rc;
+        }
+        if (hipDeviceSynchronize() != hipSuccess) return APEXGPU_ERR_DEVICE;
+        if (phase == 5) break;
+        std::vector<std::vector<std::pair<double*, size_t>>> bufs(n);
+        std::vector<int*> flags(n, nullptr);
+        for (int r = 0; r < n; ++r) hs[r]->s->dist_buffers(phase, &bufs[r], &flags[r]);
+        for (size_t b = 0; b < bufs[0].size(); ++b) {
+            const size_t len = bufs[0][b].second;
+            for (int r = 1; r < n; ++r) if (bufs[r].size() != bufs[0].size() || bufs[r][b].second != len) return APEXGPU_ERR_INVALID_STATE;
+            for (int r = 1; r < n; ++r) apex::launch_vec_add((int64_t)len, bufs[0][b].first, bufs[r][b].first, bufs[0][b].first, nullptr);
+            for (int r = 1; r < n; ++r)
+                if (hipMemcpyAsync(bufs[r][b].first, bufs[0][b].first, len * sizeof(double), hipMemcpyDeviceToDevice, nullptr) != hipSuccess) return APEXGPU_ERR_DEVICE;
+        }
+        if (flags[0]) {
+            int mx = 0;
+            for (int r = 0; r < n; ++r) { int f = 0; if (hipMemcpy(&f, flags[r], sizeof f, hipMemcpyDeviceToHost) != hipSuccess) return APEXGPU_ERR_DEVICE; mx = std::max(mx, f); }
+            for (int r = 0; r < n; ++r) if (hipMemcpy(flags[r], &mx, sizeof mx, hipMemcpyHostToDevice) != hipSuccess) return APEXGPU_ERR_DEVICE;
+        }
+        if (hipDeviceSynchronize() != hipSuccess) return APEXGPU_ERR_DEVICE;
+    }
+    return APEXGPU_OK;
+}
+int apexgpu_export_step(apexgpu_solver* h, double* step_out, double* grad_out) { H_OR_FAIL; return h->s->export_step(step_out, grad_out); }
+
 int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     H_OR_FAIL;
     const std::string n = name ? name : "";
@@ -133,6 +168,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value != 0);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "rows_debug") h->s->set_rows_debug(value);
+    else if (n == "dist_factor") h->s->set_dist_factor(value != 0);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);  /* value > 1: leaf size */
     else return APEXGPU_ERR_INVALID_INPUT;
     return APEXGPU_OK;
@@ -153,7 +189,8 @@ int apexgpu_info(apexgpu_solver* h, double info[16]) {
     int64_t a = 0, b = 0, c = 0;
     h->s->plan().op_counts(&a, &b, &c);
     info[9] = (double)a; info[10] = (double)b; info[11] = (double)c;
-    for (int i = 12; i < 16; ++i) info[i] = 0;
+    info[12] = h->s->dist_top_columns(); info[13] = h->s->dist_local_fraction();
+    for (int i = 14; i < 16; ++i) info[i] = 0;
     return APEXGPU_OK;
 }
 

@@ -49,6 +49,9 @@ void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, dou
 void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double* diag, hipStream_t s);
 void launch_tile_add_diag(double* tiles, const int* diag_slot, int n_valid, int n_total, double add_valid,
                           double set_pad, hipStream_t s);
+// distributed triangular solves: per-tile class masks (bit 1 << cls[tile]); in must not alias out for select
+void launch_vec_select(int n, const double* in, const int* cls, int mask, double* out, hipStream_t s);
+void launch_vec_merge(int n, const double* src, const int* cls, int mask, double* dst, hipStream_t s);
 void launch_tile_scale_sym(const SymTile* list, int n, double* tiles, const double* scale /* n_pad */, hipStream_t s);
 void launch_pcg_init(int n, const double* diag, const double* b, double* pre, double* x, double* r, double* z, double* p,
                      hipStream_t s);

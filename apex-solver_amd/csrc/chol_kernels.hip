@@ -1023,6 +1023,19 @@ __global__ __launch_bounds__(256) void k_tile_scale_sym(const SymTile* __restric
     }
 }
 
+// Block-class masks of the distributed triangular solves: cls[tile] in {0,1,2}, bit (1 << cls) of mask selects.
+// select: out = in on the selected 144-blocks, 0 elsewhere;  merge: dst = src on the selected blocks only.
+__global__ __launch_bounds__(256) void k_vec_select(int n, const double* __restrict__ in, const int* __restrict__ cls, int mask,
+                                                      double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = ((mask >> cls[i / NB]) & 1) ? in[i] : 0.0;
+}
+__global__ __launch_bounds__(256) void k_vec_merge(int n, const double* __restrict__ src, const int* __restrict__ cls, int mask,
+                                                     double* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && ((mask >> cls[i / NB]) & 1)) dst[i] = src[i];
+}
+
 // ---- small vector kernels for PCG (explicit_schur.rs:639-756) -----------------------------------
 __global__ __launch_bounds__(256) void k_pcg_init(int n, const double* __restrict__ diag, const double* __restrict__ b,
                                                     double* __restrict__ pre, double* __restrict__ x,
@@ -1111,6 +1124,12 @@ void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double*
 void launch_tile_add_diag(double* tiles, const int* diag_slot, int n_valid, int n_total, double add_valid,
                           double set_pad, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_add_diag, dim3((n_total + 255) / 256), dim3(256), 0, s, tiles, diag_slot, n_valid, n_total, add_valid, set_pad);
+}
+void launch_vec_select(int n, const double* in, const int* cls, int mask, double* out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_vec_select, dim3((n + 255) / 256), dim3(256), 0, s, n, in, cls, mask, out);
+}
+void launch_vec_merge(int n, const double* src, const int* cls, int mask, double* dst, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_vec_merge, dim3((n + 255) / 256), dim3(256), 0, s, n, src, cls, mask, dst);
 }
 void launch_tile_scale_sym(const SymTile* list, int n, double* tiles, const double* scale, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_tile_scale_sym, dim3(n), dim3(256), 0, s, list, tiles, scale);

@@ -55,6 +55,13 @@ class Solver : public LmBackend {
     int set_column_scaling(const double* scaling);          // total_dof, global column order; NULL: off
     int set_jacobi_scaling(bool on) override;               // on: s = 1 / (1 + norms) at the current parameters
 
+    // the phases of the distributed Cholesky solve, for the single-process lockstep test (see solver.hip)
+    int dist_phase(int phase, double lambda);
+    void dist_buffers(int point, std::vector<std::pair<double*, size_t>>* sums, int** max_flag);
+    int export_step(double* step_out, double* grad_out);
+    double dist_local_fraction() const { return tp_.local_work_fraction(); }
+    int dist_top_columns() const { return tp_.n_top_columns(); }
+
     // parity / debug exports
     int get_residual(double* r_out);
     int get_jacobian_blocks(double* jc_out, double* jl_out);
@@ -75,6 +82,7 @@ class Solver : public LmBackend {
     void use_row_schur(int v) { use_rows_ = v != 0; if (v) rows_form_ = v; }
     void set_rows_debug(int v) { rows_dbg_ = v; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
+    void set_dist_factor(bool on) { dist_factor_ = on; }   // before set_structure
     int n_levels() const { return tp_.n_levels(); }
     const TilePlan& plan() const { return tp_; }
     double schur_scatter_pairs() const { return (double)n_pairs_; }
@@ -94,7 +102,11 @@ class Solver : public LmBackend {
     int check_hip(hipError_t e, const char* what);
     BAView view(int which) const;
     TileMap tilemap() const;
-    int assemble(double lambda, double diag_extra);
+    // for_factor: the result feeds tp_.factor() (a distributed plan then leaves the top tiles to the factorisation's
+    // own exchange); otherwise S is complete on every rank (PCG, exports, the ladder's diagonal read)
+    int assemble(double lambda, double diag_extra, bool for_factor = false);
+    int assemble_local(double lambda, double diag_extra);
+    int assemble_finish();
     int assemble_implicit(double lambda);
     int implicit_pcg_solve(double lambda);
     int implicit_matvec(const double* x, double lam_local, double* y, bool reduce);
@@ -162,6 +174,7 @@ class Solver : public LmBackend {
     std::vector<int> cmap_, cinv_;   // external camera -> internal camera and back
     bool use_nd_ = true;
     int nd_leaf_ = 16;
+    bool dist_factor_ = true;   // world > 1: factorise the elimination tree's subtrees on their owner ranks (tile_plan.h)
     double* pcg_buf_ = nullptr;                    // 7 vectors of n_c_pad
     double *lmu_ = nullptr, *sd_ = nullptr, *minv_ = nullptr;  // matrix-free variant: {pt, u_l} records, diag blocks of S, their inverses
     double *cam_scale_ = nullptr, *pt_scale_ = nullptr;   // Jacobi scaling, internal order ([n_c_pad] with 1 on the padding, [3 n_pt])

@@ -93,6 +93,10 @@ int Solver::comm_init(int world, int rank, const void* unique_id128) {
     ncclResult_t r = ncclCommInitRank(&c, world, id, rank);
     if (r != ncclSuccess) return fail(kDeviceError, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
     comm_ = reinterpret_cast<ncclComm*>(c);
+    TilePlan::Comm tc;
+    tc.sum = [c](double* buf, size_t n, hipStream_t st) { ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, c, st); };
+    tc.max_int = [c](int* buf, size_t n, hipStream_t st) { ncclAllReduce(buf, buf, n, ncclInt, ncclMax, c, st); };
+    tp_.set_comm(std::move(tc));
     return kOk;
 #else
     (void)world; (void)rank; (void)unique_id128;
@@ -243,6 +247,14 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         }
     }
     tp_.enable_graphs(use_graphs_);
+    tp_.set_partition(rank_, (dist_factor_ && world_ > 1) ? world_ : 1);
+    if (const char* st = getenv("APEX_DIST_SELFTEST")) {  // debugging aid: the two-phase schedule on one rank, no exchange
+        tp_.set_partition(0, atoi(st));
+        TilePlan::Comm tc;
+        tc.sum = [](double*, size_t, hipStream_t) {};
+        tc.max_int = [](int*, size_t, hipStream_t) {};
+        tp_.set_comm(std::move(tc));
+    }
     {
         const std::string e = tp_.build(nt_, present, stream_);
         if (!e.empty()) return fail(kInvalidInput, "reduced camera matrix: " + e);
@@ -537,8 +549,28 @@ int Solver::cost(double* out) {
 // ---------------------------------------------------------------------------------------------
 // assembly of S, g_red, Hll^-1, g (A6-A11) at the current parameters
 // ---------------------------------------------------------------------------------------------
-int Solver::assemble(double lambda, double diag_extra) {
-    const size_t tile_elems = (size_t)kNB * kNB;
+int Solver::assemble(double lambda, double diag_extra, bool for_factor) {
+    int rc = assemble_local(lambda, diag_extra);
+    if (rc != kOk) return rc;
+#ifdef APEX_WITH_RCCL
+    if (comm_ && world_ > 1) {
+        stage_begin(kStAllReduce);
+        ncclComm_t c = reinterpret_cast<ncclComm_t>(comm_);
+        // a distributed factorisation sums the shared top tiles itself, after the local levels (tile_plan.h)
+        const int64_t n_red = for_factor ? tp_.n_reduce_slots() : tp_.n_touched_slots();
+        ncclGroupStart();
+        ncclAllReduce(tp_.tiles(), tp_.tiles(), (size_t)n_red * kNB * kNB, ncclDouble, ncclSum, c, stream_);
+        ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
+        ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
+        ncclGroupEnd();
+        stage_end(kStAllReduce);
+    }
+#endif
+    return assemble_finish();
+}
+
+// this rank's part of S, g_red, g_c (its landmarks), before any exchange
+int Solver::assemble_local(double lambda, double diag_extra) {
     const BAView v = view(cur_);
     const TileMap tm = tilemap();
     stage_begin(kStAssembleCam);
@@ -564,18 +596,12 @@ int Solver::assemble(double lambda, double diag_extra) {
     else
         launch_schur_scatter(dc_, v, tm, tasks_, n_tasks_, hinv_, g_l_, g_red_, stream_);
     stage_end(kStScatter);
-#ifdef APEX_WITH_RCCL
-    if (comm_ && world_ > 1) {
-        stage_begin(kStAllReduce);
-        ncclComm_t c = reinterpret_cast<ncclComm_t>(comm_);
-        ncclGroupStart();
-        ncclAllReduce(tp_.tiles(), tp_.tiles(), (size_t)tp_.n_touched_slots() * tile_elems, ncclDouble, ncclSum, c, stream_);
-        ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
-        ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
-        ncclGroupEnd();
-        stage_end(kStAllReduce);
-    }
-#endif
+    return kOk;
+}
+
+// after the exchange: the reduced system in the scaled variables when Jacobi scaling is on (linear, so it also
+// commutes with the later sum of the top tiles of a distributed factorisation)
+int Solver::assemble_finish() {
     if (scaled_) {  // the reduced system in the scaled variables: S := D_c S D_c, g_red := D_c g_red
         stage_begin(kStAssembleCam);
         tp_.scale_sym(cam_scale_);
@@ -623,7 +649,7 @@ int Solver::factor_and_solve(double lambda) {
     const double base = std::max(std::max(trace / (double)n_ref, max_diag), 1.0);
     for (int attempt = 0; attempt < 5; ++attempt) {
         const double reg = base * pow(10.0, (double)(attempt - 4));
-        rc = assemble(lambda, reg);
+        rc = assemble(lambda, reg, true);
         if (rc != kOk) return rc;
         rc = cholesky_attempt(&failed);
         if (rc != kOk) return rc;
@@ -744,7 +770,7 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     HIP_TRY(hipSetDevice(device_));
     have_step_ = false;
     last_lambda_ = lambda;
-    int rc = (variant == 2) ? assemble_implicit(lambda) : assemble(lambda, 0.0);
+    int rc = (variant == 2) ? assemble_implicit(lambda) : assemble(lambda, 0.0, variant == 0);
     if (rc != kOk) return rc;
     int lm_err = 0;
     HIP_TRY(hipMemcpyAsync(&lm_err, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -757,6 +783,11 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_);
     stage_end(kStBackSub);
     have_step_ = true;
+    return export_step(step_out, grad_out);
+}
+
+// the last step / gradient in the reference's global column order (syncs)
+int Solver::export_step(double* step_out, double* grad_out) {
     if (step_out || grad_out) {
         std::vector<double> hc(n_c_), hl(3 * n_pt_);
         for (int pass = 0; pass < 2; ++pass) {
@@ -781,6 +812,68 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
         HIP_TRY(hipStreamSynchronize(stream_));
     }
     return kOk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The distributed Cholesky solve cut into its phases, so that a test can drive the `world` instances of a
+// sharded problem in lockstep inside ONE process and play the communicator itself (capi: apexgpu_debug_lockstep_solve).
+// The production path (solve_augmented with an RCCL communicator) runs exactly these pieces with ncclAllReduce on the
+// same buffers in between.  Exchange point p follows phase p:
+//   0: S tiles [0, n_reduce_slots), g_red, g_c   1: the top tile ranges   2: the failure flag (max)
+//   3, 4: TilePlan's exchange vector
+// ---------------------------------------------------------------------------------------------
+int Solver::dist_phase(int phase, double lambda) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    if (!tp_.distributed()) return fail(kInvalidState, "the plan is not distributed (set_shard with world > 1, dist_factor on)");
+    HIP_TRY(hipSetDevice(device_));
+    switch (phase) {
+        case 0: have_step_ = false; last_lambda_ = lambda; return assemble_local(lambda, 0.0);
+        case 1: {
+            int rc = assemble_finish();
+            if (rc != kOk) return rc;
+            tp_.factor_phase(0);
+            return kOk;
+        }
+        case 2: tp_.factor_phase(1); return kOk;
+        case 3: {
+            int f[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(&f[0], tp_.flag_dev(), sizeof(int), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipMemcpyAsync(&f[1], flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            if (f[1]) return fail(kSingularMatrix, "Landmark block is singular");
+            if (f[0]) return fail(kFactorizationFailed, "non-positive pivot in tile column " + std::to_string(f[0] - 1));
+            tp_.solve_phase(0, g_red_, dcam_, pcg_buf_);
+            return kOk;
+        }
+        case 4: tp_.solve_phase(1, g_red_, dcam_, pcg_buf_); return kOk;
+        case 5:
+            tp_.solve_phase(2, g_red_, dcam_, pcg_buf_);
+            if (scaled_) launch_vec_mul(n_c_, dcam_, cam_scale_, dcam_, stream_);
+            launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_);
+            HIP_TRY(hipStreamSynchronize(stream_));
+            have_step_ = true;
+            return kOk;
+        default: return fail(kInvalidInput, "phase out of range");
+    }
+}
+
+void Solver::dist_buffers(int point, std::vector<std::pair<double*, size_t>>* sums, int** max_flag) {
+    const size_t te = (size_t)kNB * kNB;
+    sums->clear(); *max_flag = nullptr;
+    if (point == 0) {
+        sums->push_back({tp_.tiles(), (size_t)tp_.n_reduce_slots() * te});
+        sums->push_back({g_red_, (size_t)n_c_pad_});
+        sums->push_back({g_c_, (size_t)n_c_pad_});
+    } else if (point == 1) {
+        std::pair<int64_t, int64_t> rg[2];
+        tp_.top_slot_ranges(rg);
+        for (int i = 0; i < 2; ++i)
+            if (rg[i].second > 0) sums->push_back({tp_.tiles() + (size_t)rg[i].first * te, (size_t)rg[i].second * te});
+    } else if (point == 2) {
+        *max_flag = tp_.flag_dev();
+    } else if (point == 3 || point == 4) {
+        sums->push_back({tp_.exch_buffer(), (size_t)tp_.n_pad()});
+    }
 }
 
 int Solver::assemble_only(double lambda) {

@@ -6,10 +6,20 @@
 //   build()   symbolic Cholesky fill, elimination-tree levels, slot map, batched task lists, uploads
 //   factor() / solve()   level-scheduled tile Cholesky and triangular solves, replayed as hipGraphs
 //   pcg()     Jacobi-preconditioned CG on the unfactored tiles (solve_with_pcg, explicit_schur.rs:639-756)
+//
+// Distributed factorisation (set_partition(rank, world) before build()): the elimination tree is cut below its top
+// separators into `world` groups of independent subtrees.  A rank factorises the columns of ITS subtrees only (the
+// "local" levels), the updates every rank adds to the shared top tiles are summed in ONE exchange, and the few top
+// columns -- latency-bound, a small fraction of the flops -- are factorised redundantly by every rank.  The
+// triangular solves follow the same pattern: local forward sweep, one n_pad-vector exchange for the top blocks,
+// replicated top sweeps, local backward sweep, one n_pad-vector exchange that assembles x on every rank.
+// factor()/solve() run the phases and call the communicator hooks in between; factor_phase()/solve_phase() expose the
+// same phases so that several instances can be driven in lockstep inside one process (tests).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -32,6 +42,28 @@ class TilePlan {
     // present: lower-triangular nt x nt 0/1 structure (I >= J) in the FINAL order.
     // Returns "" on success or an error message.
     std::string build(int nt, const std::vector<uint8_t>& present, hipStream_t stream);
+
+    // ---- distributed factorisation ----
+    struct Comm {  // in-place reductions over the ranks, enqueued on `stream`
+        std::function<void(double* buf, size_t n, hipStream_t stream)> sum;
+        std::function<void(int* buf, size_t n, hipStream_t stream)> max_int;
+    };
+    void set_partition(int rank, int world) { part_rank_ = rank; part_world_ = world; }  // before build()
+    void set_comm(Comm c) { comm_ = std::move(c); }
+    bool distributed() const { return n_local_groups_ < n_levels_; }
+    int n_top_columns() const { return n_top_cols_; }
+    double local_work_fraction() const { return local_frac_; }  // this rank's share of the tile operations below the top
+    // tiles every rank owns a copy of after the matrix all-reduce: [0, n_reduce_slots()); in a distributed plan the
+    // top tiles are left out (they are summed after the local factorisation instead), otherwise = n_touched_slots()
+    int64_t n_reduce_slots() const { return distributed() ? n_t_nt_ : n_touched_; }
+    // the slot ranges [first, count) summed after the local phase (touched top tiles, fill top tiles)
+    void top_slot_ranges(std::pair<int64_t, int64_t> out[2]) const;
+    void factor_phase(int phase);                  // 0: local levels, 1: top levels (after the top tiles were summed)
+    int* flag_dev() const { return flag_; }       // first failed tile column + 1 (max over the ranks after the factorisation)
+    // 0: local forward sweep, top blocks of the right-hand side packed into exch_buffer() [sum it over the ranks];
+    // 1: top sweeps + local backward sweep, this rank's blocks of x packed into exch_buffer() [sum it]; 2: x := buffer
+    void solve_phase(int phase, const double* rhs, double* x, double* work);
+    double* exch_buffer() const { return exch_; }
 
     int nt() const { return nt_; }
     int64_t n_pad() const { return (int64_t)nt_ * kNB; }
@@ -66,17 +98,29 @@ class TilePlan {
     hipError_t pcg(const double* rhs, double* x, double* work, int max_iter, double tol, int* iters);
 
    private:
-    void enqueue_factor(const double* rhs, double* work);
+    void enqueue_factor(const double* rhs, double* work, int g0, int g1);
     void enqueue_solve(const double* rhs, double* x, double* work, bool backward_only);
+    void launch_fwd_group(int lv, double* bvec, double* yvec, hipStream_t s);
+    void enqueue_dist_solve(int phase, const double* rhs, double* x, double* work);
     bool run_graph(int which, const double* rhs, double* x, double* work);
     void release();
+    void partition_columns(const std::vector<std::vector<int>>& col_rows);
 
-    int nt_ = 0, n_levels_ = 0;
+    int nt_ = 0, n_levels_ = 0;   // n_levels_: number of level GROUPS (local groups first, then the top groups)
+    int n_local_groups_ = 0, n_top_cols_ = 0;
+    int part_rank_ = 0, part_world_ = 1;
+    double local_frac_ = 1.0;
+    std::vector<int> cls_h_;      // per tile column: 0 another rank's, 1 this rank's, 2 top (shared)
+    int* cls_ = nullptr;
+    double* exch_ = nullptr;
+    Comm comm_;
+    int64_t n_t_nt_ = 0, n_f_nt_ = 0;   // slot order: touched non-top | touched top | fill non-top | fill top
     int64_t n_slots_ = 0, n_touched_ = 0;
     int64_t n_potrf_ = 0, n_trsm_ = 0, n_upd_ = 0;
     hipStream_t stream_ = nullptr;
     std::vector<int> slot_h_, diag_slot_h_;
     std::vector<int> lv_potrf_, lv_trsm_, lv_fwd_, lv_bwd_, lv_upd_round_, lv_upd_split_;
+    std::vector<std::vector<int>> fwd_cut_;  // per group: first forward task of each column that gets its own launch
     hipStream_t side_ = nullptr;  // trailing updates that the next level does not need (enqueue_factor)
     std::vector<hipEvent_t> ev_t_, ev_u2_;
     std::vector<bool> u2_pending_;
@@ -93,10 +137,11 @@ class TilePlan {
     int* sym_row_ptr_ = nullptr;
     SymEntry* sym_entries_ = nullptr;
     double *sym_part_ = nullptr, *row_dot_ = nullptr, *blk_part_ = nullptr, *scal_ = nullptr;
-    hipGraphExec_t graph_exec_[3] = {nullptr, nullptr, nullptr};
-    const double* graph_rhs_[3] = {nullptr, nullptr, nullptr};
-    double *graph_x_[3] = {nullptr, nullptr, nullptr}, *graph_work_[3] = {nullptr, nullptr, nullptr};
-    bool graph_failed_[3] = {false, false, false};
+    static constexpr int kGraphs = 6;  // 0 factor (local levels), 1 both sweeps, 2 backward sweep, 3 factor (top levels), 4/5 distributed solve phases
+    hipGraphExec_t graph_exec_[kGraphs] = {};
+    const double* graph_rhs_[kGraphs] = {};
+    double *graph_x_[kGraphs] = {}, *graph_work_[kGraphs] = {};
+    bool graph_failed_[kGraphs] = {};
     hipStream_t fwd_ = nullptr;       // fused forward sweep
     hipEvent_t ev_fwd_ = nullptr;
     const double* fwd_rhs_ = nullptr;  // right-hand side whose forward sweep the last factor() carried

@@ -1,6 +1,8 @@
 // tile_plan.hip -- see tile_plan.h
 #include "tile_plan.h"
 
+#include <stdlib.h>
+
 #include <math.h>
 
 #include <algorithm>
@@ -94,14 +96,14 @@ std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool 
 
 void TilePlan::release() {
     void* ptrs[] = {tiles_, linv_, slot_, diag_slot_, flag_, potrf_tasks_, trsm_tasks_, upd_tasks_, tri_fwd_, tri_bwd_,
-                    sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_};
+                    sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = nullptr;
-    slot_ = diag_slot_ = flag_ = sym_row_ptr_ = nullptr;
+    tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = exch_ = nullptr;
+    slot_ = diag_slot_ = flag_ = sym_row_ptr_ = cls_ = nullptr;
     potrf_tasks_ = nullptr; trsm_tasks_ = upd_tasks_ = nullptr; tri_fwd_ = tri_bwd_ = nullptr;
     sym_tiles_ = nullptr; sym_entries_ = nullptr;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < kGraphs; ++i) {
         if (graph_exec_[i]) { (void)hipGraphExecDestroy(graph_exec_[i]); graph_exec_[i] = nullptr; }
         graph_failed_[i] = false;
     }
@@ -116,6 +118,91 @@ TilePlan::~TilePlan() {
     release();
     if (side_) (void)hipStreamDestroy(side_);
     if (fwd_) (void)hipStreamDestroy(fwd_);
+}
+
+// Cut the elimination tree into part_world_ groups of subtrees plus a shared top.  Deterministic: every rank
+// computes the same cut.  Starting from the roots, the heaviest subtree is split (its root joins the top, its
+// children become subtrees) until a longest-processing-time assignment of the subtrees balances within 8 %.
+void TilePlan::partition_columns(const std::vector<std::vector<int>>& col_rows) {
+    cls_h_.assign(nt_, 1);
+    n_top_cols_ = 0; local_frac_ = 1.0;
+    if (part_world_ <= 1) return;
+    const int N = part_world_;
+    std::vector<int> parent(nt_, -1);
+    std::vector<std::vector<int>> children(nt_);
+    std::vector<double> sub(nt_, 0.0);
+    for (int K = 0; K < nt_; ++K) {
+        const double m = (double)col_rows[K].size();
+        sub[K] += 1.0 + m + 0.5 * m * (m + 1.0);   // potrf + panel products + trailing updates of column K
+        if (!col_rows[K].empty()) {
+            parent[K] = col_rows[K][0];
+            children[parent[K]].push_back(K);
+            sub[parent[K]] += sub[K];               // parent > K: its subtree sum is complete before it is read
+        }
+    }
+    std::vector<int> S;
+    for (int K = 0; K < nt_; ++K) if (parent[K] < 0) S.push_back(K);
+    std::vector<char> top(nt_, 0);
+    std::vector<int> owner_of_root;
+    auto lpt = [&](const std::vector<int>& roots, std::vector<int>* assign) {
+        std::vector<int> idx(roots.size());
+        std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return sub[roots[a]] > sub[roots[b]]; });
+        std::vector<double> load(N, 0.0);
+        if (assign) assign->assign(roots.size(), 0);
+        for (int i : idx) {
+            const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            load[r] += sub[roots[i]];
+            if (assign) (*assign)[i] = r;
+        }
+        return load;
+    };
+    // Walk down the tree (always splitting the heaviest subtree) and keep the cut with the smallest estimated
+    // critical path: the most loaded rank's subtrees plus the replicated top, whose columns are latency-bound
+    // (three dependent launches each, ~200 tile products' worth) and run at a fraction of the batched rate.
+    std::vector<double> own_w(nt_);
+    for (int K = 0; K < nt_; ++K) { const double m = (double)col_rows[K].size(); own_w[K] = 1.0 + m + 0.5 * m * (m + 1.0); }
+    int n_top = 0;
+    double top_cost = 0.0, best_cost = -1.0;
+    std::vector<int> best_S;
+    std::vector<char> best_top;
+    int best_ntop = 0;
+    int extra = getenv("APEX_DIST_EXTRA_SPLITS") ? atoi(getenv("APEX_DIST_EXTRA_SPLITS")) : 0;  // debugging aid
+    for (;;) {
+        if ((int)S.size() >= N && n_top > 0) {
+            const std::vector<double> load = lpt(S, nullptr);
+            const double cost = *std::max_element(load.begin(), load.end()) + top_cost;
+            if (best_cost < 0.0 || cost < best_cost || extra > 0) {
+                best_cost = cost; best_S = S; best_top = top; best_ntop = n_top;
+                if (extra > 0) --extra;
+            }
+        }
+        int best = -1;
+        for (int i = 0; i < (int)S.size(); ++i)
+            if (!children[S[i]].empty() && (best < 0 || sub[S[i]] > sub[S[best]])) best = i;
+        if (best < 0 || n_top + 1 > nt_ / 2) break;
+        const int R = S[best];
+        top[R] = 1; ++n_top;
+        top_cost += std::max(3.0 * own_w[R], 200.0);
+        S.erase(S.begin() + best);
+        S.insert(S.end(), children[R].begin(), children[R].end());
+        std::sort(S.begin(), S.end());
+    }
+    if (best_cost < 0.0) return;  // nothing to share (a forest, or no cut with a subtree per rank): replicated factorisation
+    S = best_S; top = best_top; n_top = best_ntop;
+    if (n_top == 0) return;  // nothing shared (a forest that balances as it is): keep the replicated factorisation
+    std::vector<int> assign;
+    const std::vector<double> load = lpt(S, &assign);
+    std::vector<int> owner(nt_, -1);
+    for (size_t i = 0; i < S.size(); ++i) owner[S[i]] = assign[i];
+    for (int K = nt_ - 1; K >= 0; --K)
+        if (!top[K] && owner[K] < 0) owner[K] = owner[parent[K]];
+    double sum = 0.0;
+    for (double l : load) sum += l;
+    local_frac_ = sum > 0.0 ? load[part_rank_] / sum : 0.0;
+    const bool own_all = getenv("APEX_DIST_SELFTEST") != nullptr;  // debugging aid: one rank plays every owner
+    for (int K = 0; K < nt_; ++K) cls_h_[K] = top[K] ? 2 : ((owner[K] == part_rank_ || own_all) ? 1 : 0);
+    n_top_cols_ = n_top;
 }
 
 std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStream_t stream) {
@@ -139,19 +226,31 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     }
     // slots: first every tile the matrix itself touches (diagonal + structural non-zeros), then the
     // tiles that exist only because of fill -- a multi-GPU all-reduce then moves the first group only
+    // A distributed plan (partition_columns) keeps the tiles of the shared top columns at the end of either group:
+    // touched non-top | touched top | fill non-top | fill top.
+    partition_columns(col_rows);
     slot_h_.assign((size_t)nt_ * nt_, -1);
     diag_slot_h_.assign(nt_, 0);
     n_slots_ = 0;
-    for (int K = 0; K < nt_; ++K) {
-        diag_slot_h_[K] = (int)n_slots_;
-        slot_h_[(size_t)K * nt_ + K] = (int)n_slots_++;
-        for (int I : col_rows[K])
-            if (present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int K = 0; K < nt_; ++K) {
+            if ((cls_h_[K] == 2) != (pass == 1)) continue;
+            diag_slot_h_[K] = (int)n_slots_;
+            slot_h_[(size_t)K * nt_ + K] = (int)n_slots_++;
+            for (int I : col_rows[K])
+                if (present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
+        }
+        if (pass == 0) n_t_nt_ = n_slots_;
     }
     n_touched_ = n_slots_;
-    for (int K = 0; K < nt_; ++K)
-        for (int I : col_rows[K])
-            if (!present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int K = 0; K < nt_; ++K) {
+            if ((cls_h_[K] == 2) != (pass == 1)) continue;
+            for (int I : col_rows[K])
+                if (!present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
+        }
+        if (pass == 0) n_f_nt_ = n_slots_;
+    }
     {
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
@@ -182,17 +281,34 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     std::vector<int> level(nt_, 0);
     for (int K = 0; K < nt_; ++K)
         if (!col_rows[K].empty()) level[col_rows[K][0]] = std::max(level[col_rows[K][0]], level[K] + 1);
-    n_levels_ = 1 + *std::max_element(level.begin(), level.end());
-    std::vector<std::vector<int>> level_cols(n_levels_);
-    for (int K = 0; K < nt_; ++K) level_cols[level[K]].push_back(K);
+    // Level GROUPS in execution order: this rank's columns level by level, then the shared top columns level by
+    // level (a plan that is not distributed has the first kind only); other ranks' columns get no tasks at all.
+    const int n_true_levels = 1 + *std::max_element(level.begin(), level.end());
+    std::vector<std::vector<int>> level_cols;
+    std::vector<int> group_of(nt_, -1);
+    n_local_groups_ = 0;
+    for (int want = 1; want <= 2; ++want) {
+        for (int lv = 0; lv < n_true_levels; ++lv) {
+            std::vector<int> cols;
+            for (int K = 0; K < nt_; ++K)
+                if (level[K] == lv && cls_h_[K] == want) cols.push_back(K);
+            if (cols.empty()) continue;
+            for (int K : cols) group_of[K] = (int)level_cols.size();
+            level_cols.push_back(std::move(cols));
+        }
+        if (want == 1) n_local_groups_ = (int)level_cols.size();
+    }
+    n_levels_ = (int)level_cols.size();
     std::vector<std::vector<int>> row_cols(nt_);
     for (int K = 0; K < nt_; ++K)
-        for (int I : col_rows[K]) row_cols[I].push_back(K);
+        if (cls_h_[K] != 0)
+            for (int I : col_rows[K]) row_cols[I].push_back(K);
     std::vector<PotrfTask> potrf;
     std::vector<GemmTask> trsm, upd;
     std::vector<TriTask> tf, tb;
     lv_potrf_.assign(n_levels_ + 1, 0); lv_trsm_.assign(n_levels_ + 1, 0);
     lv_fwd_.assign(n_levels_ + 1, 0); lv_bwd_.assign(n_levels_ + 1, 0);
+    fwd_cut_.assign(n_levels_, std::vector<int>());
     lv_upd_round_.assign(n_levels_ + 1, 0);
     lv_upd_split_.assign(n_levels_ + 1, 0);
     upd_rounds_.clear();
@@ -203,6 +319,12 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         for (int K : level_cols[lv]) {
             const auto& rows = col_rows[K];
             potrf.push_back({tile_ptr(K, K), linv_ptr(K), K});
+            // The top columns of a distributed plan are swept by every rank, and the ranks' copies of the top solution
+            // must be BITWISE equal (a rank's own blocks are back-substituted from its copy, the result takes rank 0's;
+            // with cond(S) ~ 1e9 a last-bit difference shows up as a 1e-11 residual).  The forward step adds into shared
+            // ancestor blocks with atomics, which is order-dependent when two columns of a level run in one launch:
+            // top columns therefore get one launch each.
+            if (cls_h_[K] == 2) fwd_cut_[lv].push_back((int)tf.size());
             tf.push_back({linv_ptr(K), nullptr, K, -1});
             for (int I : rows) {
                 trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});
@@ -220,7 +342,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             std::vector<const U*> mine;
             for (const U& u : us) {
                 const int tcol = (int)(u.key % nt_);
-                if ((level[tcol] == lv + 1) == (part == 0)) mine.push_back(&u);
+                if ((group_of[tcol] == lv + 1) == (part == 0)) mine.push_back(&u);
             }
             std::vector<int> round(mine.size(), 0);
             int n_rounds = 0;
@@ -279,6 +401,8 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     TP_TRY(upload(&trsm_tasks_, trsm));
     TP_TRY(upload(&upd_tasks_, upd));
     TP_TRY(upload(&sym_row_ptr_, sym_ptr));
+    TP_TRY(upload(&cls_, cls_h_));
+    TP_TRY(alloc_zero(&exch_, (size_t)n_pad()));
     TP_TRY(upload(&sym_entries_, sym));
     if (!side_) TP_TRY(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
     if (!fwd_) TP_TRY(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
@@ -309,10 +433,23 @@ void TilePlan::scale_sym(const double* scale) { launch_tile_scale_sym(sym_tiles_
 
 void TilePlan::diag(double* out) const { launch_tile_diag(tiles_, diag_slot_, nt_, out, stream_); }
 
+// forward step of level group lv: one launch, or one per column where the plan asks for it (fwd_cut_)
+void TilePlan::launch_fwd_group(int lv, double* bvec, double* yvec, hipStream_t s) {
+    const std::vector<int>& cut = fwd_cut_[lv];
+    if (cut.size() < 2) {
+        launch_tri_step(false, tri_fwd_ + lv_fwd_[lv], lv_fwd_[lv + 1] - lv_fwd_[lv], bvec, yvec, s);
+        return;
+    }
+    for (size_t i = 0; i < cut.size(); ++i) {
+        const int b = cut[i], e = i + 1 < cut.size() ? cut[i + 1] : lv_fwd_[lv + 1];
+        launch_tri_step(false, tri_fwd_ + b, e - b, bvec, yvec, s);
+    }
+}
+
 // The factorisation and the triangular solves are static launch sequences for a given structure:
 // they are captured once into hipGraphs (a few hundred dependent launches would otherwise be paced by
 // host launch overhead) and replayed every iteration.
-void TilePlan::enqueue_factor(const double* rhs, double* work) {
+void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     // Two streams.  Main: potrf(lv), panel solves(lv), U1(lv) = the updates the next level needs.
     // Side: U2(lv) = every other update of level lv, overlapped with potrf / panel solves of level lv+1
     // (one workgroup resp. a few dozen: they leave the chip nearly empty).  Ordering that keeps every
@@ -324,11 +461,11 @@ void TilePlan::enqueue_factor(const double* rhs, double* work) {
     // step of level lv needs only that level's L^-1 and panel tiles, which are final after its panel solves, so it
     // runs on a third stream beside the trailing updates -- a chain of tiny latency-bound launches that costs
     // nothing there.  solve() then starts at the backward sweep.
-    const bool fwd = rhs != nullptr && work != nullptr && fwd_ != nullptr;
+    const bool fwd = rhs != nullptr && work != nullptr && fwd_ != nullptr && !distributed();
     double* bvec = work;
     double* yvec = work ? work + n_pad() : nullptr;
     if (fwd) (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
-    for (int lv = 0; lv < n_levels_; ++lv) {
+    for (int lv = g0; lv < g1; ++lv) {
         launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flag_, stream_);
         launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_);
         const int r0 = lv_upd_round_[lv], rs = lv_upd_split_[lv], r1 = lv_upd_round_[lv + 1];
@@ -340,9 +477,9 @@ void TilePlan::enqueue_factor(const double* rhs, double* work) {
         if (has_u2) (void)hipStreamWaitEvent(side_, ev_t_[lv], 0);
         if (fwd) {
             (void)hipStreamWaitEvent(fwd_, ev_t_[lv], 0);
-            launch_tri_step(false, tri_fwd_ + lv_fwd_[lv], lv_fwd_[lv + 1] - lv_fwd_[lv], bvec, yvec, fwd_);
+            launch_fwd_group(lv, bvec, yvec, fwd_);
         }
-        if (two && lv > 0 && u2_pending_[lv - 1]) (void)hipStreamWaitEvent(stream_, ev_u2_[lv - 1], 0);
+        if (two && lv > g0 && u2_pending_[lv - 1]) (void)hipStreamWaitEvent(stream_, ev_u2_[lv - 1], 0);
         for (int r = r0; r < rs; ++r)
             launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, stream_);
         hipStream_t s2 = has_u2 ? side_ : stream_;
@@ -352,7 +489,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work) {
         if (has_u2) (void)hipEventRecord(ev_u2_[lv], side_);
     }
     if (two)  // join: the last side-stream work precedes whatever follows on the main stream
-        for (int lv = n_levels_ - 1; lv >= 0; --lv)
+        for (int lv = g1 - 1; lv >= g0; --lv)
             if (u2_pending_[lv]) { (void)hipStreamWaitEvent(stream_, ev_u2_[lv], 0); break; }
     if (fwd) {
         (void)hipEventRecord(ev_fwd_, fwd_);
@@ -367,13 +504,39 @@ void TilePlan::enqueue_solve(const double* rhs, double* x, double* work, bool ba
     if (!backward_only) {
         (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
         for (int lv = 0; lv < n_levels_; ++lv)
-            launch_tri_step(false, tri_fwd_ + lv_fwd_[lv], lv_fwd_[lv + 1] - lv_fwd_[lv], bvec, yvec, stream_);
+            launch_fwd_group(lv, bvec, yvec, stream_);
     }
     for (int s = 0; s < n_levels_; ++s)
         launch_tri_step(true, tri_bwd_ + lv_bwd_[s], lv_bwd_[s + 1] - lv_bwd_[s], yvec, x, stream_);
 }
 
-// graph 0: factorisation (+ fused forward sweep when rhs/work are given), 1: both sweeps, 2: backward sweep only
+// The distributed triangular solves (see tile_plan.h).  bvec/yvec as in enqueue_solve; masks: bit (1 << class).
+void TilePlan::enqueue_dist_solve(int phase, const double* rhs, double* x, double* work) {
+    double* bvec = work;
+    double* yvec = work + n_pad();
+    const int n = (int)n_pad();
+    const int L1 = n_local_groups_;
+    if (phase == 0) {
+        // the top blocks of the right-hand side enter the sum once (rank 0); every rank adds its columns' updates
+        launch_vec_select(n, rhs, cls_, part_rank_ == 0 ? 7 : 3, bvec, stream_);
+        for (int lv = 0; lv < L1; ++lv)
+            launch_fwd_group(lv, bvec, yvec, stream_);
+        launch_vec_select(n, bvec, cls_, 4, exch_, stream_);
+    } else if (phase == 1) {
+        launch_vec_merge(n, exch_, cls_, 4, bvec, stream_);
+        for (int lv = L1; lv < n_levels_; ++lv)
+            launch_fwd_group(lv, bvec, yvec, stream_);
+        for (int s = 0; s < n_levels_; ++s)  // top groups first, then this rank's
+            launch_tri_step(true, tri_bwd_ + lv_bwd_[s], lv_bwd_[s + 1] - lv_bwd_[s], yvec, x, stream_);
+        launch_vec_select(n, x, cls_, part_rank_ == 0 ? 6 : 2, exch_, stream_);
+    } else {
+        (void)hipMemcpyAsync(x, exch_, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
+    }
+}
+
+// graph 0: factorisation of the local levels (all levels, + fused forward sweep when rhs/work are given, in a plan
+// that is not distributed), 1: both sweeps, 2: backward sweep only, 3: factorisation of the top levels,
+// 4/5: phases 0/1 of the distributed solve
 bool TilePlan::run_graph(int which, const double* rhs, double* x, double* work) {
     if (!use_graphs_) return false;
     if (graph_exec_[which] && (rhs != graph_rhs_[which] || x != graph_x_[which] || work != graph_work_[which])) {
@@ -384,7 +547,10 @@ bool TilePlan::run_graph(int which, const double* rhs, double* x, double* work) 
         if (graph_failed_[which]) return false;
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_failed_[which] = true; return false; }
-        if (which == 0) enqueue_factor(rhs, work); else enqueue_solve(rhs, x, work, which == 2);
+        if (which == 0) enqueue_factor(rhs, work, 0, n_local_groups_);
+        else if (which == 3) enqueue_factor(nullptr, nullptr, n_local_groups_, n_levels_);
+        else if (which >= 4) enqueue_dist_solve(which - 4, rhs, x, work);
+        else enqueue_solve(rhs, x, work, which == 2);
         if (hipStreamEndCapture(stream_, &g) != hipSuccess || !g) { graph_failed_[which] = true; (void)hipGetLastError(); return false; }
         hipGraphExec_t ex = nullptr;
         if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); graph_failed_[which] = true; (void)hipGetLastError(); return false; }
@@ -395,9 +561,41 @@ bool TilePlan::run_graph(int which, const double* rhs, double* x, double* work) 
     return hipGraphLaunch(graph_exec_[which], stream_) == hipSuccess;
 }
 
+void TilePlan::top_slot_ranges(std::pair<int64_t, int64_t> out[2]) const {
+    out[0] = {n_t_nt_, n_touched_ - n_t_nt_};
+    out[1] = {n_f_nt_, n_slots_ - n_f_nt_};
+}
+
+void TilePlan::factor_phase(int phase) {
+    if (phase == 0) { if (!run_graph(0, nullptr, nullptr, nullptr)) enqueue_factor(nullptr, nullptr, 0, n_local_groups_); }
+    else if (!run_graph(3, nullptr, nullptr, nullptr)) enqueue_factor(nullptr, nullptr, n_local_groups_, n_levels_);
+}
+
+void TilePlan::solve_phase(int phase, const double* rhs, double* x, double* work) {
+    if (phase == 2 || !run_graph(4 + phase, rhs, x, work)) enqueue_dist_solve(phase, rhs, x, work);
+}
+
 hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
+    if (distributed()) {
+        if (!comm_.sum || !comm_.max_int) return hipErrorNotInitialized;  // a distributed plan needs its communicator
+        fwd_rhs_ = nullptr;
+        factor_phase(0);
+        std::pair<int64_t, int64_t> rg[2];
+        top_slot_ranges(rg);
+        const size_t te = (size_t)kNB * kNB;
+        for (int i = 0; i < 2; ++i)
+            if (rg[i].second > 0) comm_.sum(tiles_ + (size_t)rg[i].first * te, (size_t)rg[i].second * te, stream_);
+        factor_phase(1);
+        comm_.max_int(flag_, 1, stream_);  // a failed pivot anywhere fails the factorisation everywhere
+        int f = 0;
+        hipError_t e = hipMemcpyAsync(&f, flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream_);
+        *failed_at = f;
+        return e;
+    }
     if (!fuse_forward_) { rhs = nullptr; work = nullptr; }
-    if (!run_graph(0, rhs, nullptr, work)) enqueue_factor(rhs, work);
+    if (!run_graph(0, rhs, nullptr, work)) enqueue_factor(rhs, work, 0, n_levels_);
     fwd_rhs_ = rhs; fwd_work_ = work;  // the forward sweep for this right-hand side is part of the factorisation
     int f = 0;
     hipError_t e = hipMemcpyAsync(&f, flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
@@ -408,6 +606,15 @@ hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
 }
 
 void TilePlan::solve(const double* rhs, double* x, double* work) {
+    if (distributed()) {
+        if (!comm_.sum) return;
+        solve_phase(0, rhs, x, work);
+        comm_.sum(exch_, (size_t)n_pad(), stream_);
+        solve_phase(1, rhs, x, work);
+        comm_.sum(exch_, (size_t)n_pad(), stream_);
+        solve_phase(2, rhs, x, work);
+        return;
+    }
     const bool backward_only = fwd_rhs_ != nullptr && rhs == fwd_rhs_ && work == fwd_work_;
     fwd_rhs_ = nullptr;  // one solve per fused sweep: the backward sweep consumes yvec's partner bvec
     if (!run_graph(backward_only ? 2 : 1, rhs, x, work)) enqueue_solve(rhs, x, work, backward_only);

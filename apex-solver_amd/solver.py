@@ -342,9 +342,10 @@ class GpuSchurComplementSolver:
         h.check(h.L.apexgpu_get_jacobian_blocks(h.h, capi.ptr(jc), capi.ptr(jl)))
         return jc, jl
 
-    def get_schur(self):
+    def get_schur(self, want_S: bool = True):
         h = self._need(); n = 9 * h.n_cam
-        S = np.zeros((n, n)); g = np.zeros(n)
+        S = np.zeros((n, n)) if want_S else None
+        g = np.zeros(n)
         h.check(h.L.apexgpu_get_schur(h.h, capi.ptr(S), capi.ptr(g)))
         return S, g
 
@@ -368,10 +369,32 @@ class GpuSchurComplementSolver:
         h.check(h.L.apexgpu_info(h.h, C.byref(out)))
         return dict(tile_rows=int(out[0]), tiles=int(out[1]), pair_blocks=float(out[2]), cam_dof=int(out[3]),
                     last_reg=float(out[4]), pcg_iterations=int(out[5]), touched_tiles=int(out[6]), local_obs=int(out[7]), etree_levels=int(out[8]),
-                    n_potrf=int(out[9]), n_trsm=int(out[10]), n_update=int(out[11]))
+                    n_potrf=int(out[9]), n_trsm=int(out[10]), n_update=int(out[11]),
+                    dist_top_columns=int(out[12]), dist_local_fraction=float(out[13]))
 
     def set_option(self, name: str, value: int):
         h = self._need(); h.check(h.L.apexgpu_set_option(h.h, name.encode(), int(value)))
+
+    def export_step(self):
+        """Step and gradient of the last solve on this handle (global column order)."""
+        h = self._need()
+        step = np.zeros(self._problem.total_dof); grad = np.zeros(self._problem.total_dof)
+        h.check(h.L.apexgpu_export_step(h.h, capi.ptr(step), capi.ptr(grad)))
+        return step, grad
+
+    @staticmethod
+    def lockstep_solve(solvers, lam: float):
+        """Test helper: `solvers` are the ranks 0..n-1 of one sharded problem in this process (with_shard(r, n));
+        runs one distributed Cholesky solve in lockstep, the library playing the all-reduces (apexgpu.h)."""
+        hs = (C.c_void_p * len(solvers))(*[s._need().h for s in solvers])
+        h0 = solvers[0]._need()
+        rc = h0.L.apexgpu_debug_lockstep_solve(hs, len(solvers), float(lam))
+        if rc != 0:
+            for s in solvers:
+                msg = s._need().L.apexgpu_last_error(s._need().h)
+                if msg:
+                    raise capi.LinAlgError(rc, msg.decode())
+            raise capi.LinAlgError(rc, "lockstep solve")
 
     def enable_stage_timing(self, on=True): h = self._need(); h.check(h.L.apexgpu_enable_stage_timing(h.h, int(on)))
     def reset_stage_times(self): h = self._need(); h.check(h.L.apexgpu_reset_stage_times(h.h))

@@ -212,17 +212,30 @@ int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_
  * [3] = internal camera DOF, [4] = regularisation used by the last Cholesky, [5] = PCG iterations,
  * [6] = S tiles that receive Schur contributions (before fill), [7] = observations on this rank,
  * [8] = levels of the tile elimination tree (= dependent launch groups of the factorisation),
- * [9..11] = tile operations per factorisation: potrf, panel products, trailing updates (2*144^3 flop each for the last two) */
+ * [9..11] = tile operations per factorisation: potrf, panel products, trailing updates (2*144^3 flop each for the last two),
+ * [12] = shared top tile columns of a distributed factorisation (0: replicated), [13] = this rank's share of the tile
+ * operations below them (1 when not distributed) */
 int apexgpu_info(apexgpu_solver* h, double info[16]);
 
 /* ---- multi-GPU: one process per GPU, landmarks sharded, RCCL all-reduce of S and g_red -----------
  * apexgpu_get_unique_id fills 128 bytes on rank 0; broadcast them (any transport) and call
  * apexgpu_comm_init on every rank BEFORE apexgpu_set_structure.  apexgpu_set_shard alone (no
  * communicator) restricts the assembly to this rank's landmark range, for tests that sum the
- * partial S / g_red themselves. */
+ * partial S / g_red themselves.
+ * With world > 1 the Cholesky of S is distributed as well (option "dist_factor", default 1; set 0 before
+ * apexgpu_set_structure for a factorisation replicated on every rank): the nested-dissection elimination tree is cut
+ * into `world` groups of subtrees below a shared top; a rank factorises its own subtrees, the updates to the top
+ * tiles are summed in one all-reduce (those tiles are left out of the all-reduce of S), the top columns are factorised
+ * by every rank, and the triangular sweeps exchange two n-vectors (csrc/tile_plan.h). */
 int apexgpu_get_unique_id(void* out128);
 int apexgpu_comm_init(apexgpu_solver* h, int world, int rank, const void* unique_id128);
 int apexgpu_set_shard(apexgpu_solver* h, int rank, int world);
+/* Test entry for the distributed solve without a communicator: hs[0..n) are the ranks of ONE sharded problem
+ * (apexgpu_set_shard(r, n), same structure and parameters) living in this process on one GPU; one Cholesky solve of
+ * (S, g_red) at `lambda` runs in lockstep, the function itself playing the all-reduces between the phases.  Every
+ * handle then holds the step (apexgpu_export_step: camera part complete, landmark part for the rank's own range). */
+int apexgpu_debug_lockstep_solve(apexgpu_solver** hs, int n, double lambda);
+int apexgpu_export_step(apexgpu_solver* h, double* step_out, double* grad_out);
 /* The landmark range [lo,hi) rank `rank` of `world` owns (contiguous, balanced by observation count).
  * Host arithmetic only -- no device is touched -- so schedulers and tests can call it anywhere. */
 int apexgpu_shard_range(int64_t n_pt, int64_t n_obs, const uint32_t* pt_idx, int rank, int world, int64_t* lo,

@@ -1,0 +1,112 @@
+"""The distributed Cholesky of the reduced camera system (csrc/tile_plan.h: subtrees of the nested-dissection
+elimination tree on their owner ranks, shared top, two vector exchanges in the triangular sweeps) driven in LOCKSTEP:
+the `world` ranks of one sharded problem live in this process on one GPU and the library plays the all-reduces between
+the phases (apexgpu_debug_lockstep_solve).  The production path runs the same phases with ncclAllReduce on the same
+buffers.  Every result is held to the single-rank solve of the same system."""
+import numpy as np
+import pytest
+
+import apex_solver_amd as pkg
+from apex_solver_amd.capi import LinAlgError
+from apex_solver_amd.solver import GpuSchurComplementSolver, OptimizationType, Problem
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.ravel(a) - np.ravel(b)) / max(np.linalg.norm(np.ravel(b)), 1e-300))
+
+
+def make(d, mode, shard=None, opts=()):
+    ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
+    prob = Problem.bundle_adjustment(d, ot, 1.0)
+    s = GpuSchurComplementSolver(0)
+    for k, v in opts:
+        s.with_option(k, v)
+    if shard:
+        s.with_shard(*shard)
+    s.initialize_structure(prob)
+    s.set_parameters(d.poses, d.intr, d.points)
+    return prob, s
+
+
+def single_rank_reference(d, mode, lam, scaling=None):
+    prob, s = make(d, mode)
+    if scaling is not None:
+        s.apply_column_scaling(scaling)
+    step = s.solve_augmented_equation(lam)
+    _, gred = s.get_schur(want_S=False)
+    return prob, s, step, gred
+
+
+def lockstep(d, mode, world, lam, scaling=None):
+    ranks = [make(d, mode, shard=(r, world))[1] for r in range(world)]
+    if scaling is not None:
+        for s in ranks:
+            s.apply_column_scaling(scaling)
+    GpuSchurComplementSolver.lockstep_solve(ranks, lam)
+    return ranks
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_lockstep_distributed_solve_matches_single_rank(world):
+    d = pkg.synthetic.make_problem(1500, 30000, 3, 7, config_id=310)     # 94 tile rows, banded covisibility
+    lam = 1e-3
+    prob, s1, step1, gred = single_rank_reference(d, "selfcal", lam)
+    ranks = lockstep(d, "selfcal", world, lam)
+    infos = [s.info() for s in ranks]
+    print("world", world, "tile rows", infos[0]["tile_rows"], "top columns", infos[0]["dist_top_columns"],
+          "local fractions", [round(i["dist_local_fraction"], 3) for i in infos])
+    assert infos[0]["dist_top_columns"] > 0 and all(i["dist_top_columns"] == infos[0]["dist_top_columns"] for i in infos)
+    assert abs(sum(i["dist_local_fraction"] for i in infos) - 1.0) < 1e-9
+    # the cut balances as far as a 94-column tree allows (the estimate trades balance against the replicated top)
+    assert max(i["dist_local_fraction"] for i in infos) < {2: 0.6, 3: 0.55, 4: 0.35, 8: 0.3}[world]
+    nc = prob.layout.cam_dof
+    lay = prob.layout
+    steps = [s.export_step()[0] for s in ranks]
+    for r in range(1, world):                                              # every rank ends with the same camera step
+        assert np.array_equal(steps[r][:nc], steps[0][:nc])
+    # camera part: backward error against the single-rank S (explicit tiles), and agreement with its step
+    Sx, _ = s1.schur_matvec(lam, steps[0][:nc], implicit=False)
+    S1, _ = s1.schur_matvec(lam, step1[:nc], implicit=False)
+    r_dist = np.linalg.norm(Sx - gred) / np.linalg.norm(gred)
+    r_one = np.linalg.norm(S1 - gred) / np.linalg.norm(gred)
+    print("residual distributed / single", r_dist, r_one, "step difference", rel(steps[0][:nc], step1[:nc]))
+    assert r_dist < 10 * max(r_one, 1e-13)
+    assert rel(steps[0][:nc], step1[:nc]) < 1e-7
+    # landmark part: each rank back-substitutes its own range
+    owned = np.zeros(d.n_pt, dtype=int)
+    for r, s in enumerate(ranks):
+        lo, hi = pkg.capi.shard_range(d.pt_idx, d.n_pt, r, world)
+        owned[lo:hi] += 1
+        cols = (lay.pt_col[lo:hi, None] + np.arange(3)[None]).ravel()
+        assert rel(steps[r][cols], step1[cols]) < 1e-6
+    assert np.all(owned == 1)
+    for s in ranks + [s1]:
+        s.close()
+
+
+def test_lockstep_with_jacobi_scaling_and_ba_mode():
+    d = pkg.synthetic.make_problem(1200, 20000, 3, 7, config_id=311)
+    lam = 1e-2
+    prob, s0 = make(d, "ba")
+    scal = 1.0 / (1.0 + s0.compute_column_norms())
+    s0.close()
+    prob, s1, y1, gred = single_rank_reference(d, "ba", lam, scaling=scal)
+    ranks = lockstep(d, "ba", 2, lam, scaling=scal)
+    nc = prob.layout.cam_dof
+    y = ranks[0].export_step()[0]
+    assert rel(y[:nc], y1[:nc]) < 1e-7
+    for s in ranks + [s1]:
+        s.close()
+
+
+def test_lockstep_needs_a_distributed_plan():
+    d = pkg.synthetic.make_problem(1200, 20000, 3, 7, config_id=312)
+    ranks = [make(d, "selfcal", shard=(r, 2), opts=(("dist_factor", 0),))[1] for r in range(2)]
+    assert ranks[0].info()["dist_top_columns"] == 0
+    with pytest.raises(LinAlgError) as e:
+        GpuSchurComplementSolver.lockstep_solve(ranks, 1e-3)
+    assert e.value.kind == "InvalidState"
+    for s in ranks:
+        s.close()
