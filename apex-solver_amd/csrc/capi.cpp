@@ -135,18 +135,25 @@ int apexgpu_debug_lockstep_solve(apexgpu_solver** hs, int n, double lambda) {
         for (int r = 0; r < n; ++r) {
             const int rc = hs[r]->s->dist_phase(phase, lambda);
             if (rc != 0) return rc;
+            // one rank at a time: the ranks share this GPU, and their stage timers then show what each would take alone
+            if (hipDeviceSynchronize() != hipSuccess) return APEXGPU_ERR_DEVICE;
         }
-        if (hipDeviceSynchronize() != hipSuccess) return APEXGPU_ERR_DEVICE;
         if (phase == 5) break;
-        std::vector<std::vector<std::pair<double*, size_t>>> bufs(n);
+        std::vector<std::vector<apex::Solver::DistBuf>> bufs(n);
         std::vector<int*> flags(n, nullptr);
         for (int r = 0; r < n; ++r) hs[r]->s->dist_buffers(phase, &bufs[r], &flags[r]);
         for (size_t b = 0; b < bufs[0].size(); ++b) {
-            const size_t len = bufs[0][b].second;
-            for (int r = 1; r < n; ++r) if (bufs[r].size() != bufs[0].size() || bufs[r][b].second != len) return APEXGPU_ERR_INVALID_STATE;
-            for (int r = 1; r < n; ++r) apex::launch_vec_add((int64_t)len, bufs[0][b].first, bufs[r][b].first, bufs[0][b].first, nullptr);
+            const size_t len = bufs[0][b].n;
+            const int root = bufs[0][b].root;
             for (int r = 1; r < n; ++r)
-                if (hipMemcpyAsync(bufs[r][b].first, bufs[0][b].first, len * sizeof(double), hipMemcpyDeviceToDevice, nullptr) != hipSuccess) return APEXGPU_ERR_DEVICE;
+                if (bufs[r].size() != bufs[0].size() || bufs[r][b].n != len || bufs[r][b].root != root) return APEXGPU_ERR_INVALID_STATE;
+            if (len == 0) continue;
+            const int dst = root >= 0 ? root : 0;   // ncclReduce(root) / ncclAllReduce: ranks summed in rank order
+            for (int r = 0; r < n; ++r)
+                if (r != dst) apex::launch_vec_add((int64_t)len, bufs[dst][b].ptr, bufs[r][b].ptr, bufs[dst][b].ptr, nullptr);
+            if (root < 0)
+                for (int r = 1; r < n; ++r)
+                    if (hipMemcpyAsync(bufs[r][b].ptr, bufs[0][b].ptr, len * sizeof(double), hipMemcpyDeviceToDevice, nullptr) != hipSuccess) return APEXGPU_ERR_DEVICE;
         }
         if (flags[0]) {
             int mx = 0;

@@ -57,7 +57,8 @@ class Solver : public LmBackend {
 
     // the phases of the distributed Cholesky solve, for the single-process lockstep test (see solver.hip)
     int dist_phase(int phase, double lambda);
-    void dist_buffers(int point, std::vector<std::pair<double*, size_t>>* sums, int** max_flag);
+    struct DistBuf { double* ptr; size_t n; int root; };   // root >= 0: the sum is needed on that rank only; -1: everywhere
+    void dist_buffers(int point, std::vector<DistBuf>* sums, int** max_flag);
     int export_step(double* step_out, double* grad_out);
     double dist_local_fraction() const { return tp_.local_work_fraction(); }
     int dist_top_columns() const { return tp_.n_top_columns(); }

@@ -556,10 +556,20 @@ int Solver::assemble(double lambda, double diag_extra, bool for_factor) {
     if (comm_ && world_ > 1) {
         stage_begin(kStAllReduce);
         ncclComm_t c = reinterpret_cast<ncclComm_t>(comm_);
-        // a distributed factorisation sums the shared top tiles itself, after the local levels (tile_plan.h)
-        const int64_t n_red = for_factor ? tp_.n_reduce_slots() : tp_.n_touched_slots();
+        // A distributed factorisation sums the shared top tiles itself, after the local levels, and a rank's local
+        // levels read its own columns only: every column's tiles are reduced to their owner (tile_plan.h).
+        const size_t te = (size_t)kNB * kNB;
         ncclGroupStart();
-        ncclAllReduce(tp_.tiles(), tp_.tiles(), (size_t)n_red * kNB * kNB, ncclDouble, ncclSum, c, stream_);
+        if (for_factor && tp_.distributed()) {
+            for (int o = 0; o < tp_.part_world(); ++o) {
+                const std::pair<int64_t, int64_t> rg = tp_.owner_slot_range(o);
+                if (rg.second > 0)
+                    ncclReduce(tp_.tiles() + (size_t)rg.first * te, tp_.tiles() + (size_t)rg.first * te, (size_t)rg.second * te,
+                               ncclDouble, ncclSum, o, c, stream_);
+            }
+        } else {
+            ncclAllReduce(tp_.tiles(), tp_.tiles(), (size_t)tp_.n_touched_slots() * te, ncclDouble, ncclSum, c, stream_);
+        }
         ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
         ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
         ncclGroupEnd();
@@ -819,7 +829,7 @@ int Solver::export_step(double* step_out, double* grad_out) {
 // sharded problem in lockstep inside ONE process and play the communicator itself (capi: apexgpu_debug_lockstep_solve).
 // The production path (solve_augmented with an RCCL communicator) runs exactly these pieces with ncclAllReduce on the
 // same buffers in between.  Exchange point p follows phase p:
-//   0: S tiles [0, n_reduce_slots), g_red, g_c   1: the top tile ranges   2: the failure flag (max)
+//   0: each rank's column tiles (reduce to the owner), g_red, g_c   1: the top tile ranges   2: the failure flag (max)
 //   3, 4: TilePlan's exchange vector
 // ---------------------------------------------------------------------------------------------
 int Solver::dist_phase(int phase, double lambda) {
@@ -831,10 +841,16 @@ int Solver::dist_phase(int phase, double lambda) {
         case 1: {
             int rc = assemble_finish();
             if (rc != kOk) return rc;
+            stage_begin(kStFactor);
             tp_.factor_phase(0);
+            stage_end(kStFactor);
             return kOk;
         }
-        case 2: tp_.factor_phase(1); return kOk;
+        case 2:
+            stage_begin(kStAllReduce);   // lockstep runs only: the replicated top levels are booked under this stage's
+            tp_.factor_phase(1);         // name so that they can be told apart from the local levels
+            stage_end(kStAllReduce);
+            return kOk;
         case 3: {
             int f[2] = {0, 0};
             HIP_TRY(hipMemcpyAsync(&f[0], tp_.flag_dev(), sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -842,10 +858,16 @@ int Solver::dist_phase(int phase, double lambda) {
             HIP_TRY(hipStreamSynchronize(stream_));
             if (f[1]) return fail(kSingularMatrix, "Landmark block is singular");
             if (f[0]) return fail(kFactorizationFailed, "non-positive pivot in tile column " + std::to_string(f[0] - 1));
+            stage_begin(kStTriSolve);
             tp_.solve_phase(0, g_red_, dcam_, pcg_buf_);
+            stage_end(kStTriSolve);
             return kOk;
         }
-        case 4: tp_.solve_phase(1, g_red_, dcam_, pcg_buf_); return kOk;
+        case 4:
+            stage_begin(kStTriSolve);
+            tp_.solve_phase(1, g_red_, dcam_, pcg_buf_);
+            stage_end(kStTriSolve);
+            return kOk;
         case 5:
             tp_.solve_phase(2, g_red_, dcam_, pcg_buf_);
             if (scaled_) launch_vec_mul(n_c_, dcam_, cam_scale_, dcam_, stream_);
@@ -857,22 +879,25 @@ int Solver::dist_phase(int phase, double lambda) {
     }
 }
 
-void Solver::dist_buffers(int point, std::vector<std::pair<double*, size_t>>* sums, int** max_flag) {
+void Solver::dist_buffers(int point, std::vector<DistBuf>* sums, int** max_flag) {
     const size_t te = (size_t)kNB * kNB;
     sums->clear(); *max_flag = nullptr;
     if (point == 0) {
-        sums->push_back({tp_.tiles(), (size_t)tp_.n_reduce_slots() * te});
-        sums->push_back({g_red_, (size_t)n_c_pad_});
-        sums->push_back({g_c_, (size_t)n_c_pad_});
+        for (int o = 0; o < tp_.part_world(); ++o) {   // every column's tiles are reduced to their owner
+            const std::pair<int64_t, int64_t> rg = tp_.owner_slot_range(o);
+            sums->push_back({tp_.tiles() + (size_t)rg.first * te, (size_t)rg.second * te, o});
+        }
+        sums->push_back({g_red_, (size_t)n_c_pad_, -1});
+        sums->push_back({g_c_, (size_t)n_c_pad_, -1});
     } else if (point == 1) {
         std::pair<int64_t, int64_t> rg[2];
         tp_.top_slot_ranges(rg);
         for (int i = 0; i < 2; ++i)
-            if (rg[i].second > 0) sums->push_back({tp_.tiles() + (size_t)rg[i].first * te, (size_t)rg[i].second * te});
+            if (rg[i].second > 0) sums->push_back({tp_.tiles() + (size_t)rg[i].first * te, (size_t)rg[i].second * te, -1});
     } else if (point == 2) {
         *max_flag = tp_.flag_dev();
     } else if (point == 3 || point == 4) {
-        sums->push_back({tp_.exch_buffer(), (size_t)tp_.n_pad()});
+        sums->push_back({tp_.exch_buffer(), (size_t)tp_.n_pad(), -1});
     }
 }
 

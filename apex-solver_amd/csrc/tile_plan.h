@@ -56,6 +56,10 @@ class TilePlan {
     // tiles every rank owns a copy of after the matrix all-reduce: [0, n_reduce_slots()); in a distributed plan the
     // top tiles are left out (they are summed after the local factorisation instead), otherwise = n_touched_slots()
     int64_t n_reduce_slots() const { return distributed() ? n_t_nt_ : n_touched_; }
+    // ... and inside that range the tiles of rank o's columns are contiguous: [first, first + count).  The local phase
+    // of rank o reads no other rank's columns, so a reduce to their owner (half the traffic of an all-reduce) is enough.
+    int part_world() const { return part_world_; }
+    std::pair<int64_t, int64_t> owner_slot_range(int o) const { return own_range_[o]; }
     // the slot ranges [first, count) summed after the local phase (touched top tiles, fill top tiles)
     void top_slot_ranges(std::pair<int64_t, int64_t> out[2]) const;
     void factor_phase(int phase);                  // 0: local levels, 1: top levels (after the top tiles were summed)
@@ -111,6 +115,8 @@ class TilePlan {
     int part_rank_ = 0, part_world_ = 1;
     double local_frac_ = 1.0;
     std::vector<int> cls_h_;      // per tile column: 0 another rank's, 1 this rank's, 2 top (shared)
+    std::vector<int> owner_h_;    // per tile column: owning rank, -1 top
+    std::vector<std::pair<int64_t, int64_t>> own_range_;  // per rank: slots of the touched tiles of its columns
     int* cls_ = nullptr;
     double* exch_ = nullptr;
     Comm comm_;

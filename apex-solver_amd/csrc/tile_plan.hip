@@ -125,6 +125,7 @@ TilePlan::~TilePlan() {
 // children become subtrees) until a longest-processing-time assignment of the subtrees balances within 8 %.
 void TilePlan::partition_columns(const std::vector<std::vector<int>>& col_rows) {
     cls_h_.assign(nt_, 1);
+    owner_h_.assign(nt_, 0);
     n_top_cols_ = 0; local_frac_ = 1.0;
     if (part_world_ <= 1) return;
     const int N = part_world_;
@@ -202,6 +203,7 @@ void TilePlan::partition_columns(const std::vector<std::vector<int>>& col_rows) 
     local_frac_ = sum > 0.0 ? load[part_rank_] / sum : 0.0;
     const bool own_all = getenv("APEX_DIST_SELFTEST") != nullptr;  // debugging aid: one rank plays every owner
     for (int K = 0; K < nt_; ++K) cls_h_[K] = top[K] ? 2 : ((owner[K] == part_rank_ || own_all) ? 1 : 0);
+    for (int K = 0; K < nt_; ++K) owner_h_[K] = top[K] ? -1 : owner[K];
     n_top_cols_ = n_top;
 }
 
@@ -232,15 +234,20 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     slot_h_.assign((size_t)nt_ * nt_, -1);
     diag_slot_h_.assign(nt_, 0);
     n_slots_ = 0;
-    for (int pass = 0; pass < 2; ++pass) {
+    const int n_owner = n_top_cols_ > 0 ? part_world_ : 1;
+    own_range_.assign(n_owner, {0, 0});
+    for (int pass = 0; pass <= n_owner; ++pass) {   // owners 0..n_owner-1 (their columns contiguous), then the top
+        const int64_t first = n_slots_;
         for (int K = 0; K < nt_; ++K) {
-            if ((cls_h_[K] == 2) != (pass == 1)) continue;
+            const bool is_top = cls_h_[K] == 2;
+            if (pass < n_owner ? (is_top || (n_top_cols_ > 0 && owner_h_[K] != pass)) : !is_top) continue;
             diag_slot_h_[K] = (int)n_slots_;
             slot_h_[(size_t)K * nt_ + K] = (int)n_slots_++;
             for (int I : col_rows[K])
                 if (present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
         }
-        if (pass == 0) n_t_nt_ = n_slots_;
+        if (pass < n_owner) own_range_[pass] = {first, n_slots_ - first};
+        if (pass == n_owner - 1) n_t_nt_ = n_slots_;
     }
     n_touched_ = n_slots_;
     for (int pass = 0; pass < 2; ++pass) {
