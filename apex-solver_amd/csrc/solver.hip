@@ -572,6 +572,7 @@ int Solver::assemble(double lambda, double diag_extra, bool for_factor) {
         }
         ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
         ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
+        ncclAllReduce(flags_, flags_, 1, ncclInt, ncclMax, c, stream_);  // a singular landmark block anywhere fails the solve on every rank
         ncclGroupEnd();
         stage_end(kStAllReduce);
     }
@@ -702,6 +703,7 @@ int Solver::assemble_implicit(double lambda) {
         ncclAllReduce(sd_, sd_, (size_t)n_cam_ * dc_ * dc_, ncclDouble, ncclSum, c, stream_);
         ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
         ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
+        ncclAllReduce(flags_, flags_, 1, ncclInt, ncclMax, c, stream_);  // a singular landmark block anywhere fails the solve on every rank
         ncclGroupEnd();
         stage_end(kStAllReduce);
     }
