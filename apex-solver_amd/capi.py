@@ -25,7 +25,7 @@ SYMBOLS = (
     "apexgpu_parameter_norm", "apexgpu_column_norms", "apexgpu_set_column_scaling", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
     "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
     "apexgpu_stage_times", "apexgpu_info", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_set_shard", "apexgpu_shard_range",
-    "apexgpu_debug_lockstep_solve", "apexgpu_export_step",
+    "apexgpu_debug_lockstep_solve", "apexgpu_export_step", "apexgpu_owned_landmarks",
     "apexgpu_bal_open", "apexgpu_bal_close", "apexgpu_bal_last_error", "apexgpu_bal_sizes", "apexgpu_bal_raw",
     "apexgpu_bal_variables", "apexgpu_reference_columns",
     # SE3 pose-graph backend
@@ -118,6 +118,7 @@ def load() -> C.CDLL:
     L.apexgpu_column_norms.argtypes = [vp, vp]
     L.apexgpu_debug_lockstep_solve.argtypes = [vp, C.c_int, C.c_double]
     L.apexgpu_export_step.argtypes = [vp, vp, vp]
+    L.apexgpu_owned_landmarks.argtypes = [vp, vp]
     L.apexgpu_set_column_scaling.argtypes = [vp, vp]
     L.apexgpu_lm_optimize.argtypes = [vp, C.POINTER(LmConfigC), C.POINTER(LmResultC), vp, C.c_int]
     L.apexgpu_get_residual.argtypes = [vp, vp]

@@ -27,6 +27,9 @@ struct BAView {
     // damping becomes lambda / s^2 per column and S is rescaled once after the reduction (solver.hip).
     const double* cam_scale;  // [n_cam][d_c]
     const double* pt_scale;   // [n_pt][3]
+    // which rank adds lambda to a camera's diagonal block: NULL = rank 0 for every camera (all partial S are summed);
+    // tree sharding: the owner of the camera's tile column (its tiles are never summed), rank 0 for the shared top
+    const uint8_t* lam_mask;  // [n_cam]
 };
 
 // Per-landmark record written by k_landmark_reduce and read by the camera-major kernels: everything a

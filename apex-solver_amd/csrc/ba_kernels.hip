@@ -147,7 +147,8 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_reduce(BAView v, TileMap tm
             double* blk = s_block_ptr<DC>(tm, c, c);
             double lam = lambda;
             if (v.cam_scale) { const double sc = v.cam_scale[(size_t)c * DC + a]; lam = lambda / (sc * sc); }
-            blk[a * kNB + bb] = s + ((a == bb && add_lambda) ? lam : 0.0);
+            const bool addl = v.lam_mask ? v.lam_mask[c] != 0 : add_lambda != 0;
+            blk[a * kNB + bb] = s + ((a == bb && addl) ? lam : 0.0);
         } else {
             const int a = i - NH;
             const int j = NH + DC + a;

@@ -164,6 +164,11 @@ int apexgpu_debug_lockstep_solve(apexgpu_solver** hs, int n, double lambda) {
     }
     return APEXGPU_OK;
 }
+int apexgpu_owned_landmarks(apexgpu_solver* h, uint8_t* mask) {
+    H_OR_FAIL;
+    if (!mask) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->owned_landmarks(mask);
+}
 int apexgpu_export_step(apexgpu_solver* h, double* step_out, double* grad_out) { H_OR_FAIL; return h->s->export_step(step_out, grad_out); }
 
 int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
@@ -176,6 +181,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "rows_debug") h->s->set_rows_debug(value);
     else if (n == "dist_factor") h->s->set_dist_factor(value != 0);
+    else if (n == "tree_sharding") h->s->set_tree_sharding(value != 0);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);  /* value > 1: leaf size */
     else return APEXGPU_ERR_INVALID_INPUT;
     return APEXGPU_OK;
@@ -197,7 +203,8 @@ int apexgpu_info(apexgpu_solver* h, double info[16]) {
     h->s->plan().op_counts(&a, &b, &c);
     info[9] = (double)a; info[10] = (double)b; info[11] = (double)c;
     info[12] = h->s->dist_top_columns(); info[13] = h->s->dist_local_fraction();
-    for (int i = 14; i < 16; ++i) info[i] = 0;
+    info[14] = h->s->tree_sharded() ? 1.0 : 0.0;
+    info[15] = 0;
     return APEXGPU_OK;
 }
 

@@ -84,6 +84,9 @@ class Solver : public LmBackend {
     void set_rows_debug(int v) { rows_dbg_ = v; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void set_dist_factor(bool on) { dist_factor_ = on; }   // before set_structure
+    void set_tree_sharding(bool on) { tree_sharding_ = on; }  // before set_structure
+    int owned_landmarks(uint8_t* mask) const;
+    bool tree_sharded() const { return tree_shard_; }
     int n_levels() const { return tp_.n_levels(); }
     const TilePlan& plan() const { return tp_; }
     double schur_scatter_pairs() const { return (double)n_pairs_; }
@@ -176,6 +179,10 @@ class Solver : public LmBackend {
     bool use_nd_ = true;
     int nd_leaf_ = 16;
     bool dist_factor_ = true;   // world > 1: factorise the elimination tree's subtrees on their owner ranks (tile_plan.h)
+    bool tree_sharding_ = true; // ... and give every landmark to the rank whose columns it touches (set_structure)
+    bool tree_shard_ = false;   // what set_structure arrived at
+    std::vector<int> lmap_;     // external landmark -> internal landmark (identity unless tree sharded)
+    uint8_t* lam_mask_ = nullptr;  // tree sharding: cameras whose diagonal block gets lambda on this rank
     double* pcg_buf_ = nullptr;                    // 7 vectors of n_c_pad
     double *lmu_ = nullptr, *sd_ = nullptr, *minv_ = nullptr;  // matrix-free variant: {pt, u_l} records, diag blocks of S, their inverses
     double *cam_scale_ = nullptr, *pt_scale_ = nullptr;   // Jacobi scaling, internal order ([n_c_pad] with 1 on the padding, [3 n_pt])

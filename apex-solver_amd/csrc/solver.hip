@@ -36,7 +36,7 @@ Solver::~Solver() {
     if (stream_) hipStreamSynchronize(stream_);
     void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, rtasks2_, rchunks_, rentries_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
-                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_};
+                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_, lam_mask_};
     for (void* p : ptrs)
         if (p) hipFree(p);
 #ifdef APEX_WITH_RCCL
@@ -64,6 +64,7 @@ BAView Solver::view(int which) const {
     v.co_pt = co_pt_; v.co_uv = co_uv_; v.co_rank = co_rank_;
     v.cam_scale = scaled_ ? cam_scale_ : nullptr;
     v.pt_scale = scaled_ ? pt_scale_ : nullptr;
+    v.lam_mask = tree_shard_ ? lam_mask_ : nullptr;
     return v;
 }
 
@@ -180,17 +181,91 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     std::vector<uint32_t> cam_i(n_obs_);
     for (int64_t i = 0; i < n_obs_; ++i) cam_i[i] = (uint32_t)cmap_[cam_idx[i]];
 
+    // ---- tile structure of S (covisibility at tile granularity) from the FULL problem: identical on all ranks ----
+    std::vector<uint8_t> present((size_t)nt_ * nt_, 0);
+    std::vector<int> lm_owner;   // tree sharding only: owner rank of every landmark
+    lmap_.resize(n_pt_);
+    std::iota(lmap_.begin(), lmap_.end(), 0);
+    tree_shard_ = false;
+    tp_.set_partition(rank_, (dist_factor_ && world_ > 1) ? world_ : 1);
+    if (const char* st = getenv("APEX_DIST_SELFTEST")) {  // debugging aid: the two-phase schedule on one rank, no exchange
+        tp_.set_partition(0, atoi(st));
+        TilePlan::Comm tc;
+        tc.sum = [](double*, size_t, hipStream_t) {};
+        tc.max_int = [](int*, size_t, hipStream_t) {};
+        tp_.set_comm(std::move(tc));
+    }
+    {
+        std::vector<int64_t> lp(n_pt_ + 1, 0);
+        for (int64_t i = 0; i < n_obs_; ++i) lp[pt_idx[i] + 1]++;
+        for (int64_t l = 0; l < n_pt_; ++l) lp[l + 1] += lp[l];
+        std::vector<int> lt(n_obs_);
+        {
+            std::vector<int64_t> fill(lp.begin(), lp.end() - 1);
+            for (int64_t i = 0; i < n_obs_; ++i) lt[fill[pt_idx[i]]++] = (int)(cam_i[i] / cpt);
+        }
+        std::vector<int> tl;
+        for (int64_t l = 0; l < n_pt_; ++l) {
+            tl.assign(lt.begin() + lp[l], lt.begin() + lp[l + 1]);
+            std::sort(tl.begin(), tl.end());
+            tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
+            for (size_t a = 0; a < tl.size(); ++a)
+                for (size_t b = 0; b <= a; ++b) present[(size_t)tl[a] * nt_ + tl[b]] = 1;
+        }
+        // Tree sharding (distributed Cholesky, no communicator-less test shards): a landmark's cameras form a clique of
+        // S, so their tile columns lie on ONE root path of the elimination tree -- below the shared top they all belong
+        // to one rank.  Giving every landmark to that rank makes the tiles of a rank's own columns COMPLETE locally:
+        // no reduce of S at all, only the top tiles are summed (which the distributed factorisation does anyway).
+        // Landmarks seen by top cameras only go to the least loaded rank.  Landmarks are renumbered so that every
+        // rank's set is one contiguous internal range.
+        const std::vector<int> owner = (world_ > 1 && dist_factor_ && tree_sharding_) ? tp_.preview_owners(nt_, present) : std::vector<int>();
+        if (!owner.empty() && !getenv("APEX_DIST_SELFTEST")) {
+            lm_owner.assign(n_pt_, -1);
+            std::vector<int64_t> load(world_, 0);
+            for (int64_t l = 0; l < n_pt_; ++l) {
+                for (int64_t k = lp[l]; k < lp[l + 1]; ++k)
+                    if (owner[lt[k]] >= 0) { lm_owner[l] = owner[lt[k]]; break; }
+                if (lm_owner[l] >= 0) load[lm_owner[l]] += lp[l + 1] - lp[l];
+            }
+            for (int64_t l = 0; l < n_pt_; ++l)
+                if (lm_owner[l] < 0) {
+                    const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                    lm_owner[l] = r;
+                    load[r] += lp[l + 1] - lp[l];
+                }
+            std::vector<int64_t> first(world_ + 1, 0);
+            for (int64_t l = 0; l < n_pt_; ++l) first[lm_owner[l] + 1]++;
+            for (int r = 0; r < world_; ++r) first[r + 1] += first[r];
+            lm_lo_ = first[rank_]; lm_hi_ = first[rank_ + 1];
+            for (int64_t l = 0; l < n_pt_; ++l) lmap_[l] = (int)first[lm_owner[l]]++;
+            tree_shard_ = true;
+        }
+    }
+    if (tree_shard_) {  // lambda on a camera's diagonal block: by the owner of its column, rank 0 for the shared top
+        const std::vector<int> owner = tp_.preview_owners(nt_, present);
+        std::vector<uint8_t> mask(n_cam_);
+        for (int64_t ci = 0; ci < n_cam_; ++ci) {
+            const int o = owner[ci / cpt];
+            mask[ci] = (o == rank_ || (o < 0 && rank_ == 0)) ? 1 : 0;
+        }
+        if (lam_mask_) { hipFree(lam_mask_); lam_mask_ = nullptr; }
+        HIP_TRY(dev_alloc(&lam_mask_, mask.size()));
+        HIP_TRY(hipMemcpy(lam_mask_, mask.data(), mask.size(), hipMemcpyHostToDevice));
+    }
+    std::vector<uint32_t> pt_i(n_obs_);   // internal landmark index of every observation
+    for (int64_t i = 0; i < n_obs_; ++i) pt_i[i] = (uint32_t)lmap_[pt_idx[i]];
+
     // ---- landmark-major lists of the FULL problem (tile structure must match on all ranks) ----
     std::vector<int64_t> full_ptr(n_pt_ + 1, 0);
-    for (int64_t i = 0; i < n_obs_; ++i) full_ptr[pt_idx[i] + 1]++;
+    for (int64_t i = 0; i < n_obs_; ++i) full_ptr[pt_i[i] + 1]++;
     for (int64_t l = 0; l < n_pt_; ++l) full_ptr[l + 1] += full_ptr[l];
     std::vector<int> full_obs(n_obs_);
     {
         std::vector<int64_t> fill(full_ptr.begin(), full_ptr.end() - 1);
-        for (int64_t i = 0; i < n_obs_; ++i) full_obs[fill[pt_idx[i]]++] = (int)i;
+        for (int64_t i = 0; i < n_obs_; ++i) full_obs[fill[pt_i[i]]++] = (int)i;
     }
-    // ---- shard: contiguous landmark range balanced by observation count --------------------
-    shard_range(n_pt_, full_ptr.data(), rank_, world_, &lm_lo_, &lm_hi_);
+    // ---- shard: contiguous landmark range balanced by observation count (tree sharding: set above) --------
+    if (!tree_shard_) shard_range(n_pt_, full_ptr.data(), rank_, world_, &lm_lo_, &lm_hi_);
     const int64_t o_lo = full_ptr[lm_lo_], o_hi = full_ptr[lm_hi_];
     const int64_t n_loc = o_hi - o_lo;
 
@@ -211,7 +286,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     for (int64_t k = 0; k < n_loc; ++k) {
         const int i = full_obs[o_lo + k];
         o_orig_h_[k] = i;
-        o_cam[k] = cam_i[i]; o_pt[k] = pt_idx[i];
+        o_cam[k] = cam_i[i]; o_pt[k] = pt_i[i];
         o_uv[2 * k] = obs_uv[2 * (int64_t)i]; o_uv[2 * k + 1] = obs_uv[2 * (int64_t)i + 1];
     }
     // ---- camera-major lists over the local observations -----------------------------------------
@@ -233,28 +308,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         co_rank[k] = i - pt_ptr[o_pt[i]];
     }
 
-    // ---- tile structure of S (covisibility at tile granularity + symbolic Cholesky fill) -------------
-    std::vector<uint8_t> present((size_t)nt_ * nt_, 0);
-    {
-        std::vector<int> tl;
-        for (int64_t l = 0; l < n_pt_; ++l) {
-            tl.clear();
-            for (int64_t k = full_ptr[l]; k < full_ptr[l + 1]; ++k) tl.push_back((int)(cam_i[full_obs[k]] / cpt));
-            std::sort(tl.begin(), tl.end());
-            tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
-            for (size_t a = 0; a < tl.size(); ++a)
-                for (size_t b = 0; b <= a; ++b) present[(size_t)tl[a] * nt_ + tl[b]] = 1;
-        }
-    }
+    // ---- symbolic Cholesky fill, slot map and task lists of the tile plan -------------
     tp_.enable_graphs(use_graphs_);
-    tp_.set_partition(rank_, (dist_factor_ && world_ > 1) ? world_ : 1);
-    if (const char* st = getenv("APEX_DIST_SELFTEST")) {  // debugging aid: the two-phase schedule on one rank, no exchange
-        tp_.set_partition(0, atoi(st));
-        TilePlan::Comm tc;
-        tc.sum = [](double*, size_t, hipStream_t) {};
-        tc.max_int = [](int*, size_t, hipStream_t) {};
-        tp_.set_comm(std::move(tc));
-    }
     {
         const std::string e = tp_.build(nt_, present, stream_);
         if (!e.empty()) return fail(kInvalidInput, "reduced camera matrix: " + e);
@@ -312,7 +367,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         for (int64_t c = 0; c < n_cam_; ++c) {
             auto& L = lists[c];
             for (int64_t e = fcp[c]; e < fcp[c + 1]; ++e) {
-                const uint32_t l = pt_idx[fco[e]];
+                const uint32_t l = pt_i[fco[e]];
                 for (int64_t k = full_ptr[l]; k < full_ptr[l + 1]; ++k) {
                     const int cj = (int)cam_i[full_obs[k]];
                     if (cj < c && stamp[cj] != (int)c) { stamp[cj] = (int)c; L.push_back(cj); }
@@ -427,7 +482,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
             if (fix_pose) memcpy(fp.data() + 6 * (size_t)cmap_[c], fix_pose + 6 * c, 6);
             if (fix_intr) memcpy(fi.data() + 3 * (size_t)cmap_[c], fix_intr + 3 * c, 3);
         }
-        if (fix_pt) memcpy(fl.data(), fix_pt, fl.size());
+        if (fix_pt)
+            for (int64_t l = 0; l < n_pt_; ++l) memcpy(fl.data() + 3 * (size_t)lmap_[l], fix_pt + 3 * l, 3);
         HIP_TRY(up(&fix_pose_, fp));
         HIP_TRY(up(&fix_intr_, fi));
         HIP_TRY(up(&fix_pt_, fl));
@@ -478,7 +534,14 @@ int Solver::set_params(const double* poses, const double* intr, const double* po
     }
     HIP_TRY(hipMemcpyAsync(poses_[cur_], hp.data(), 7 * n_cam_ * sizeof(double), hipMemcpyHostToDevice, stream_));
     HIP_TRY(hipMemcpyAsync(intr_[cur_], hi.data(), 3 * n_cam_ * sizeof(double), hipMemcpyHostToDevice, stream_));
-    HIP_TRY(hipMemcpyAsync(pts_[cur_], points, 3 * n_pt_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+    std::vector<double> hpt;
+    const double* src_pts = points;
+    if (tree_shard_) {  // landmarks are renumbered so that every rank's set is one internal range
+        hpt.resize(3 * n_pt_);
+        for (int64_t l = 0; l < n_pt_; ++l) memcpy(hpt.data() + 3 * (size_t)lmap_[l], points + 3 * l, 3 * sizeof(double));
+        src_pts = hpt.data();
+    }
+    HIP_TRY(hipMemcpyAsync(pts_[cur_], src_pts, 3 * n_pt_ * sizeof(double), hipMemcpyHostToDevice, stream_));
     launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], stream_);
     HIP_TRY(hipStreamSynchronize(stream_));
     have_params_ = true; have_step_ = have_trial_ = false;
@@ -512,8 +575,11 @@ int Solver::get_params(double* poses, double* intr, double* points) {
     std::vector<double> hp(7 * n_cam_), hi(3 * n_cam_);
     HIP_TRY(hipMemcpyAsync(hp.data(), poses_[cur_], 7 * n_cam_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(hi.data(), intr_[cur_], 3 * n_cam_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipMemcpyAsync(points, pts_[cur_], 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    std::vector<double> hpt(tree_shard_ ? 3 * n_pt_ : 0);
+    HIP_TRY(hipMemcpyAsync(tree_shard_ ? hpt.data() : points, pts_[cur_], 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
+    if (tree_shard_)
+        for (int64_t l = 0; l < n_pt_; ++l) memcpy(points + 3 * l, hpt.data() + 3 * (size_t)lmap_[l], 3 * sizeof(double));
     for (int64_t c = 0; c < n_cam_; ++c) {
         memcpy(poses + 7 * c, hp.data() + 7 * (size_t)cmap_[c], 7 * sizeof(double));
         memcpy(intr + 3 * c, hi.data() + 3 * (size_t)cmap_[c], 3 * sizeof(double));
@@ -560,7 +626,9 @@ int Solver::assemble(double lambda, double diag_extra, bool for_factor) {
         // levels read its own columns only: every column's tiles are reduced to their owner (tile_plan.h).
         const size_t te = (size_t)kNB * kNB;
         ncclGroupStart();
-        if (for_factor && tp_.distributed()) {
+        if (for_factor && tp_.distributed() && tree_shard_) {
+            // tree sharding: a rank's landmarks are exactly those that touch its columns -- its tiles are complete
+        } else if (for_factor && tp_.distributed()) {
             for (int o = 0; o < tp_.part_world(); ++o) {
                 const std::pair<int64_t, int64_t> rg = tp_.owner_slot_range(o);
                 if (rg.second > 0)
@@ -818,7 +886,7 @@ int Solver::export_step(double* step_out, double* grad_out) {
                 for (int a = 0; a < 3; ++a) out[intr_col_[c] + a] = (dc_ == 9) ? hc[ci * dc_ + 6 + a] : 0.0;
             }
             for (int64_t l = 0; l < n_pt_; ++l)
-                for (int a = 0; a < 3; ++a) out[pt_col_[l] + a] = hl[3 * l + a];
+                for (int a = 0; a < 3; ++a) out[pt_col_[l] + a] = hl[3 * (size_t)lmap_[l] + a];
         }
     } else {
         HIP_TRY(hipStreamSynchronize(stream_));
@@ -885,7 +953,7 @@ void Solver::dist_buffers(int point, std::vector<DistBuf>* sums, int** max_flag)
     const size_t te = (size_t)kNB * kNB;
     sums->clear(); *max_flag = nullptr;
     if (point == 0) {
-        for (int o = 0; o < tp_.part_world(); ++o) {   // every column's tiles are reduced to their owner
+        for (int o = 0; o < tp_.part_world() && !tree_shard_; ++o) {   // every column's tiles are reduced to their owner
             const std::pair<int64_t, int64_t> rg = tp_.owner_slot_range(o);
             sums->push_back({tp_.tiles() + (size_t)rg.first * te, (size_t)rg.second * te, o});
         }
@@ -1037,7 +1105,7 @@ int Solver::column_norms(double* norms_out) {
         for (int a = 0; a < 3; ++a) norms_out[intr_col_[c] + a] = (dc_ == 9) ? sqrt(hc[ci * dc_ + 6 + a]) : 0.0;
     }
     for (int64_t l = 0; l < n_pt_; ++l)
-        for (int a = 0; a < 3; ++a) norms_out[pt_col_[l] + a] = sqrt(hl[3 * l + a]);
+        for (int a = 0; a < 3; ++a) norms_out[pt_col_[l] + a] = sqrt(hl[3 * (size_t)lmap_[l] + a]);
     if (was) {  // the buffers held the active scaling: put it back
         std::vector<double> pad(n_c_pad_, 1.0);
         std::copy(keep_c.begin(), keep_c.end(), pad.begin());
@@ -1064,7 +1132,7 @@ int Solver::set_column_scaling(const double* scaling) {
             for (int a = 0; a < 3; ++a) cam_scale_h_[ci * dc_ + 6 + a] = scaling[intr_col_[c] + a];
     }
     for (int64_t l = 0; l < n_pt_; ++l)
-        for (int a = 0; a < 3; ++a) pt_scale_h_[3 * l + a] = scaling[pt_col_[l] + a];
+        for (int a = 0; a < 3; ++a) pt_scale_h_[3 * (size_t)lmap_[l] + a] = scaling[pt_col_[l] + a];
     for (double v : cam_scale_h_) if (!(v > 0.0) || !std::isfinite(v)) return fail(kInvalidInput, "column scaling must be positive and finite");
     for (double v : pt_scale_h_) if (!(v > 0.0) || !std::isfinite(v)) return fail(kInvalidInput, "column scaling must be positive and finite");
     std::vector<double> pad(n_c_pad_, 1.0);
@@ -1217,6 +1285,12 @@ int Solver::schur_matvec(double lambda, const double* x_in, double* y_explicit, 
     return kOk;
 }
 
+// mask[l] = 1 for the landmarks this rank assembles and back-substitutes (the caller's landmark numbering)
+int Solver::owned_landmarks(uint8_t* mask) const {
+    for (int64_t l = 0; l < n_pt_; ++l) mask[l] = (lmap_[l] >= lm_lo_ && lmap_[l] < lm_hi_) ? 1 : 0;
+    return kOk;
+}
+
 int Solver::get_landmark_blocks(double* hinv_out, double* gl_out) {
     if (!have_params_) return fail(kInvalidState, "no parameters set");
     HIP_TRY(hipSetDevice(device_));
@@ -1225,6 +1299,11 @@ int Solver::get_landmark_blocks(double* hinv_out, double* gl_out) {
                                  hipMemcpyDeviceToHost, stream_));
     if (gl_out) HIP_TRY(hipMemcpyAsync(gl_out, g_l_, 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
+    if (tree_shard_) {  // back to the caller's landmark order
+        std::vector<double> t;
+        if (hinv_out) { t.assign(hinv_out, hinv_out + 9 * n_pt_); for (int64_t l = 0; l < n_pt_; ++l) memcpy(hinv_out + 9 * l, t.data() + 9 * (size_t)lmap_[l], 9 * sizeof(double)); }
+        if (gl_out) { t.assign(gl_out, gl_out + 3 * n_pt_); for (int64_t l = 0; l < n_pt_; ++l) memcpy(gl_out + 3 * l, t.data() + 3 * (size_t)lmap_[l], 3 * sizeof(double)); }
+    }
     return kOk;
 }
 

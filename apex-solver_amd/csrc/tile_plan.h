@@ -50,6 +50,7 @@ class TilePlan {
     };
     void set_partition(int rank, int world) { part_rank_ = rank; part_world_ = world; }  // before build()
     void set_comm(Comm c) { comm_ = std::move(c); }
+    std::vector<int> preview_owners(int nt, const std::vector<uint8_t>& present);  // after set_partition, before build
     bool distributed() const { return n_local_groups_ < n_levels_; }
     int n_top_columns() const { return n_top_cols_; }
     double local_work_fraction() const { return local_frac_; }  // this rank's share of the tile operations below the top

@@ -207,17 +207,13 @@ void TilePlan::partition_columns(const std::vector<std::vector<int>>& col_rows) 
     n_top_cols_ = n_top;
 }
 
-std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStream_t stream) {
-    release();
-    nt_ = nt;
-    stream_ = stream;
-    const size_t tile_elems = (size_t)kNB * kNB;
-    // symbolic Cholesky at tile granularity: struct(L_K) \ {parent} merges into the parent column
-    std::vector<std::vector<int>> col_rows(nt_);
-    for (int K = 0; K < nt_; ++K)
-        for (int I = K + 1; I < nt_; ++I)
-            if (present[(size_t)I * nt_ + K]) col_rows[K].push_back(I);
-    for (int K = 0; K < nt_; ++K) {
+// symbolic Cholesky at tile granularity: struct(L_K) \ {parent} merges into the parent column
+static std::vector<std::vector<int>> symbolic_fill(int nt, const std::vector<uint8_t>& present) {
+    std::vector<std::vector<int>> col_rows(nt);
+    for (int K = 0; K < nt; ++K)
+        for (int I = K + 1; I < nt; ++I)
+            if (present[(size_t)I * nt + K]) col_rows[K].push_back(I);
+    for (int K = 0; K < nt; ++K) {
         auto& rows = col_rows[K];
         if (rows.size() < 2) continue;
         const int parent = rows[0];
@@ -226,6 +222,25 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
                        std::back_inserter(merged));
         col_rows[parent].swap(merged);
     }
+    return col_rows;
+}
+
+// The owner rank of every tile column (-1: shared top) that build() will arrive at for the same structure and
+// partition; empty when the plan will not be distributed.  Host arithmetic only.
+std::vector<int> TilePlan::preview_owners(int nt, const std::vector<uint8_t>& present) {
+    const int keep = nt_;
+    nt_ = nt;
+    partition_columns(symbolic_fill(nt, present));
+    nt_ = keep;
+    return n_top_cols_ > 0 ? owner_h_ : std::vector<int>();
+}
+
+std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStream_t stream) {
+    release();
+    nt_ = nt;
+    stream_ = stream;
+    const size_t tile_elems = (size_t)kNB * kNB;
+    std::vector<std::vector<int>> col_rows = symbolic_fill(nt_, present);
     // slots: first every tile the matrix itself touches (diagonal + structural non-zeros), then the
     // tiles that exist only because of fill -- a multi-GPU all-reduce then moves the first group only
     // A distributed plan (partition_columns) keeps the tiles of the shared top columns at the end of either group:

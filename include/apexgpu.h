@@ -214,7 +214,7 @@ int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_
  * [8] = levels of the tile elimination tree (= dependent launch groups of the factorisation),
  * [9..11] = tile operations per factorisation: potrf, panel products, trailing updates (2*144^3 flop each for the last two),
  * [12] = shared top tile columns of a distributed factorisation (0: replicated), [13] = this rank's share of the tile
- * operations below them (1 when not distributed) */
+ * operations below them (1 when not distributed), [14] = 1 when the landmarks are sharded by the elimination tree */
 int apexgpu_info(apexgpu_solver* h, double info[16]);
 
 /* ---- multi-GPU: one process per GPU, landmarks sharded, RCCL all-reduce of S and g_red -----------
@@ -235,6 +235,11 @@ int apexgpu_set_shard(apexgpu_solver* h, int rank, int world);
  * (S, g_red) at `lambda` runs in lockstep, the function itself playing the all-reduces between the phases.  Every
  * handle then holds the step (apexgpu_export_step: camera part complete, landmark part for the rank's own range). */
 int apexgpu_debug_lockstep_solve(apexgpu_solver** hs, int n, double lambda);
+/* mask[n_pt] (caller's numbering): 1 for the landmarks this rank assembles and back-substitutes.  Contiguous
+ * apexgpu_shard_range ranges with a replicated factorisation ("dist_factor" = 0) or with option "tree_sharding" = 0;
+ * by default (world > 1) a landmark belongs to the rank whose tile columns its cameras touch below the shared top of
+ * the elimination tree, which makes that rank's tiles of S complete without any reduction. */
+int apexgpu_owned_landmarks(apexgpu_solver* h, uint8_t* mask);
 int apexgpu_export_step(apexgpu_solver* h, double* step_out, double* grad_out);
 /* The landmark range [lo,hi) rank `rank` of `world` owns (contiguous, balanced by observation count).
  * Host arithmetic only -- no device is touched -- so schedulers and tests can call it anywhere. */

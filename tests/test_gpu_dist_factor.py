@@ -39,8 +39,8 @@ def single_rank_reference(d, mode, lam, scaling=None):
     return prob, s, step, gred
 
 
-def lockstep(d, mode, world, lam, scaling=None):
-    ranks = [make(d, mode, shard=(r, world))[1] for r in range(world)]
+def lockstep(d, mode, world, lam, scaling=None, opts=()):
+    ranks = [make(d, mode, shard=(r, world), opts=opts)[1] for r in range(world)]
     if scaling is not None:
         for s in ranks:
             s.apply_column_scaling(scaling)
@@ -48,13 +48,18 @@ def lockstep(d, mode, world, lam, scaling=None):
     return ranks
 
 
+@pytest.mark.parametrize("tree", [1, 0], ids=["tree-sharded", "range-sharded"])
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
-def test_lockstep_distributed_solve_matches_single_rank(world):
+def test_lockstep_distributed_solve_matches_single_rank(world, tree):
+    """tree-sharded (default): a landmark belongs to the rank whose columns it touches -- no reduction of S at all;
+    range-sharded: contiguous landmark ranges, every column's tiles reduced to the owner."""
     d = pkg.synthetic.make_problem(1500, 30000, 3, 7, config_id=310)     # 94 tile rows, banded covisibility
     lam = 1e-3
     prob, s1, step1, gred = single_rank_reference(d, "selfcal", lam)
-    ranks = lockstep(d, "selfcal", world, lam)
+    ranks = lockstep(d, "selfcal", world, lam, opts=(("tree_sharding", tree),))
     infos = [s.info() for s in ranks]
+    assert all(i["tree_sharded"] == bool(tree) for i in infos)
+    print("observations per rank", [i["local_obs"] for i in infos])
     print("world", world, "tile rows", infos[0]["tile_rows"], "top columns", infos[0]["dist_top_columns"],
           "local fractions", [round(i["dist_local_fraction"], 3) for i in infos])
     assert infos[0]["dist_top_columns"] > 0 and all(i["dist_top_columns"] == infos[0]["dist_top_columns"] for i in infos)
@@ -77,9 +82,12 @@ def test_lockstep_distributed_solve_matches_single_rank(world):
     # landmark part: each rank back-substitutes its own range
     owned = np.zeros(d.n_pt, dtype=int)
     for r, s in enumerate(ranks):
-        lo, hi = pkg.capi.shard_range(d.pt_idx, d.n_pt, r, world)
-        owned[lo:hi] += 1
-        cols = (lay.pt_col[lo:hi, None] + np.arange(3)[None]).ravel()
+        m = s.owned_landmarks()
+        if not tree:
+            lo, hi = pkg.capi.shard_range(d.pt_idx, d.n_pt, r, world)
+            assert np.array_equal(np.flatnonzero(m), np.arange(lo, hi))
+        owned += m
+        cols = (lay.pt_col[m][:, None] + np.arange(3)[None]).ravel()
         assert rel(steps[r][cols], step1[cols]) < 1e-6
     assert np.all(owned == 1)
     for s in ranks + [s1]:
