@@ -12,9 +12,10 @@ accept/reject bookkeeping -- exactly the body of optimize_with_mode's loop
 (src/optimizer/levenberg_marquardt.rs:857-1029).  Inputs are resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line.
 
-For N > 1 launch with torch.distributed.run (one process per GPU); landmarks are sharded over the
-ranks, S's column tiles are reduced to the ranks that own them in the distributed Cholesky (g_red all-reduced)
-over RCCL inside the library, so total work is fixed ("scaling": "strong").
+For N > 1 launch with torch.distributed.run (one process per GPU); landmarks and the Cholesky of S are
+distributed along the elimination tree (a rank's column tiles are complete locally; the top tiles, two
+n-vectors and the reduced gradient are all-reduced over RCCL inside the library), so total work is fixed
+("scaling": "strong").
 """
 import argparse
 import json
@@ -310,7 +311,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{d.name} synthetic ({d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations)",
                    "optimization_type": args.mode, "camera_dof": dc, "schur_variant": args.variant, "huber": 1.0,
-                   "s_tile_rows": info["tile_rows"], "s_tiles": info["tiles"], "parallelism": f"landmark-shard x{world}" + (f", Cholesky distributed by elimination subtree ({info['dist_top_columns']} shared top tile columns)" if info.get("dist_top_columns") else "")},
+                   "s_tile_rows": info["tile_rows"], "s_tiles": info["tiles"], "parallelism": f"landmark-shard x{world}" + (f", landmarks and Cholesky distributed by elimination subtree ({info['dist_top_columns']} shared top tile columns, tree_sharded={info.get('tree_sharded')})" if info.get("dist_top_columns") else "")},
         "roofline": roofline,
         "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
         "stage_launches": {k: int(v[1]) for k, v in stages.items()},
