@@ -182,6 +182,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "rows_debug") h->s->set_rows_debug(value);
     else if (n == "dist_factor") h->s->set_dist_factor(value != 0);
     else if (n == "tree_sharding") h->s->set_tree_sharding(value != 0);
+    else if (n == "dist_selftest") h->s->set_dist_selftest(value);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);  /* value > 1: leaf size */
     else return APEXGPU_ERR_INVALID_INPUT;
     return APEXGPU_OK;

@@ -85,6 +85,7 @@ class Solver : public LmBackend {
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void set_dist_factor(bool on) { dist_factor_ = on; }   // before set_structure
     void set_tree_sharding(bool on) { tree_sharding_ = on; }  // before set_structure
+    void set_dist_selftest(int world) { dist_selftest_ = world; }  // before set_structure; single rank only
     int owned_landmarks(uint8_t* mask) const;
     bool tree_sharded() const { return tree_shard_; }
     int n_levels() const { return tp_.n_levels(); }
@@ -181,6 +182,7 @@ class Solver : public LmBackend {
     bool dist_factor_ = true;   // world > 1: factorise the elimination tree's subtrees on their owner ranks (tile_plan.h)
     bool tree_sharding_ = true; // ... and give every landmark to the rank whose columns it touches (set_structure)
     bool tree_shard_ = false;   // what set_structure arrived at
+    int dist_selftest_ = 0;
     std::vector<int> lmap_;     // external landmark -> internal landmark (identity unless tree sharded)
     uint8_t* lam_mask_ = nullptr;  // tree sharding: cameras whose diagonal block gets lambda on this rank
     double* pcg_buf_ = nullptr;                    // 7 vectors of n_c_pad

@@ -188,8 +188,10 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     std::iota(lmap_.begin(), lmap_.end(), 0);
     tree_shard_ = false;
     tp_.set_partition(rank_, (dist_factor_ && world_ > 1) ? world_ : 1);
-    if (const char* st = getenv("APEX_DIST_SELFTEST")) {  // debugging aid: the two-phase schedule on one rank, no exchange
-        tp_.set_partition(0, atoi(st));
+    tp_.set_own_all(false);
+    if (dist_selftest_ > 1 && world_ == 1) {  // self-test: the distributed schedule for that many ranks, all played by this one
+        tp_.set_partition(0, dist_selftest_);
+        tp_.set_own_all(true);
         TilePlan::Comm tc;
         tc.sum = [](double*, size_t, hipStream_t) {};
         tc.max_int = [](int*, size_t, hipStream_t) {};
@@ -219,7 +221,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         // Landmarks seen by top cameras only go to the least loaded rank.  Landmarks are renumbered so that every
         // rank's set is one contiguous internal range.
         const std::vector<int> owner = (world_ > 1 && dist_factor_ && tree_sharding_) ? tp_.preview_owners(nt_, present) : std::vector<int>();
-        if (!owner.empty() && !getenv("APEX_DIST_SELFTEST")) {
+        if (!owner.empty()) {
             lm_owner.assign(n_pt_, -1);
             std::vector<int64_t> load(world_, 0);
             for (int64_t l = 0; l < n_pt_; ++l) {

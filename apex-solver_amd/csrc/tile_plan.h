@@ -49,6 +49,9 @@ class TilePlan {
         std::function<void(int* buf, size_t n, hipStream_t stream)> max_int;
     };
     void set_partition(int rank, int world) { part_rank_ = rank; part_world_ = world; }  // before build()
+    // self-test: cut the tree for `world` ranks but let THIS rank own every subtree -- the distributed schedule
+    // (local levels, top levels, phased sweeps) then runs complete on one rank with no-op exchanges
+    void set_own_all(bool on) { own_all_ = on; }
     void set_comm(Comm c) { comm_ = std::move(c); }
     std::vector<int> preview_owners(int nt, const std::vector<uint8_t>& present);  // after set_partition, before build
     bool distributed() const { return n_local_groups_ < n_levels_; }
@@ -114,6 +117,7 @@ class TilePlan {
     int nt_ = 0, n_levels_ = 0;   // n_levels_: number of level GROUPS (local groups first, then the top groups)
     int n_local_groups_ = 0, n_top_cols_ = 0;
     int part_rank_ = 0, part_world_ = 1;
+    bool own_all_ = false;
     double local_frac_ = 1.0;
     std::vector<int> cls_h_;      // per tile column: 0 another rank's, 1 this rank's, 2 top (shared)
     std::vector<int> owner_h_;    // per tile column: owning rank, -1 top

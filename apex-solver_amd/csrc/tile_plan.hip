@@ -168,15 +168,11 @@ void TilePlan::partition_columns(const std::vector<std::vector<int>>& col_rows) 
     std::vector<int> best_S;
     std::vector<char> best_top;
     int best_ntop = 0;
-    int extra = getenv("APEX_DIST_EXTRA_SPLITS") ? atoi(getenv("APEX_DIST_EXTRA_SPLITS")) : 0;  // debugging aid
     for (;;) {
         if ((int)S.size() >= N && n_top > 0) {
             const std::vector<double> load = lpt(S, nullptr);
             const double cost = *std::max_element(load.begin(), load.end()) + top_cost;
-            if (best_cost < 0.0 || cost < best_cost || extra > 0) {
-                best_cost = cost; best_S = S; best_top = top; best_ntop = n_top;
-                if (extra > 0) --extra;
-            }
+            if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best_S = S; best_top = top; best_ntop = n_top; }
         }
         int best = -1;
         for (int i = 0; i < (int)S.size(); ++i)
@@ -201,7 +197,7 @@ void TilePlan::partition_columns(const std::vector<std::vector<int>>& col_rows) 
     double sum = 0.0;
     for (double l : load) sum += l;
     local_frac_ = sum > 0.0 ? load[part_rank_] / sum : 0.0;
-    const bool own_all = getenv("APEX_DIST_SELFTEST") != nullptr;  // debugging aid: one rank plays every owner
+    const bool own_all = own_all_;  // self-test: one rank plays every owner (the two-phase schedule without exchanges)
     for (int K = 0; K < nt_; ++K) cls_h_[K] = top[K] ? 2 : ((owner[K] == part_rank_ || own_all) ? 1 : 0);
     for (int K = 0; K < nt_; ++K) owner_h_[K] = top[K] ? -1 : owner[K];
     n_top_cols_ = n_top;

@@ -198,7 +198,11 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "potrf_lookahead" (1)  look-ahead schedule of the diagonal-tile Cholesky + inverse
  *   "fused_forward" (0)  run the forward triangular sweep inside the factorisation graph on a third stream
  *   "nested_dissection" (1)  order camera tiles by nested dissection (call before set_structure);
- *                     0 keeps the caller's camera order, a value > 1 sets the leaf size in tiles    */
+ *                     0 keeps the caller's camera order, a value > 1 sets the leaf size in tiles
+ *   "dist_factor" (1), "tree_sharding" (1)  multi-GPU only, before set_structure: see the multi-GPU section
+ *   "dist_selftest" (0)  single rank, before set_structure: cut the elimination tree as for that many ranks and run
+ *                     the distributed schedule (own levels, top levels, phased triangular sweeps) with this rank
+ *                     owning every subtree and no-op exchanges -- results must equal the plain schedule's      */
 int apexgpu_set_option(apexgpu_solver* h, const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------------*/

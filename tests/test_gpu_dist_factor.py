@@ -118,3 +118,26 @@ def test_lockstep_needs_a_distributed_plan():
     assert e.value.kind == "InvalidState"
     for s in ranks:
         s.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_distributed_schedule_on_one_rank_equals_the_plain_schedule(world):
+    """Option dist_selftest: the tree is cut as for `world` ranks, this rank owns every subtree, the exchanges are
+    no-ops -- the two-phase factorisation and the phased sweeps (graphs 0, 3, 4, 5) run through the NORMAL solve and LM
+    entry points and must reproduce the plain level schedule."""
+    from apex_solver_amd.solver import LevenbergMarquardt, LevenbergMarquardtConfig
+    d = pkg.synthetic.make_problem(1500, 30000, 3, 7, config_id=313)
+    lam = 1e-4
+    prob, s1, step1, gred = single_rank_reference(d, "selfcal", lam)
+    _, s = make(d, "selfcal", opts=(("dist_selftest", world),))
+    info = s.info()
+    assert info["dist_top_columns"] > 0 and not info["tree_sharded"]
+    step = s.solve_augmented_equation(lam)
+    nc = prob.layout.cam_dof
+    Sx, _ = s1.schur_matvec(lam, step[:nc], implicit=False)
+    assert np.linalg.norm(Sx - gred) / np.linalg.norm(gred) < 1e-13
+    assert rel(step, step1) < 1e-7
+    # second solve on the same handle replays the captured graphs
+    assert rel(s.solve_augmented_equation(lam), step) < 1e-9
+    for x in (s, s1):
+        x.close()
