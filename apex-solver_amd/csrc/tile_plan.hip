@@ -423,6 +423,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     TP_TRY(alloc_zero(&exch_, (size_t)n_pad()));
     TP_TRY(upload(&sym_entries_, sym));
     // (a lowest-priority side stream was tried: no gain without graphs, +2.7 ms with them)
+    // (and so was a CU-masked one that leaves 1 CU in 8 / 4 / 2 to the critical path: the same, either way)
     if (!side_) TP_TRY(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
     if (!fwd_) TP_TRY(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
     TP_TRY(hipEventCreateWithFlags(&ev_fwd_, hipEventDisableTiming));
