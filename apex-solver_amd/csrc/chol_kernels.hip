@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(const PotrfTask* __restrict__
 // with  L^-1(r,j) = - sum_{k=j}^{r-1} L~(r,k) L^-1(k,j),  L^-1(k,k) = D_k^-1  (row-oriented dtrtri).
 // Row r of L is dead once step r has used it, so its blocks are reused for L~ and then L^-1: no extra LDS.
 // The 8 x 3 barriers of the separate inversion phase of k_potrf_inv are gone and the trailing update is off
-// the critical path: 85 -> ~45 us per tile (one launch per elimination-tree level).
+// the critical path: 85 -> 65 us per tile with 4 waves, 58 us with 8 (one launch per elimination-tree level).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void blk_to_global(const double* __restrict__ src, double* __restrict__ dst_tile, int bi, int bj,
                                               int t, int nthreads) {
@@ -278,7 +278,22 @@ __device__ __forceinline__ void blk_to_global(const double* __restrict__ src, do
     }
 }
 
-__global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restrict__ tasks, int* __restrict__ fail) {
+// NW waves per workgroup: wave 0 factorises the 16 x 16 diagonal block in registers while the other NW-1 waves do
+// the previous step's trailing update and one row of L^-1 -- with 4 waves those three take ~3 us per block step
+// against wave 0's ~1.2 us and are the critical path of the tile; 8 waves balance the two.
+#ifdef APEX_POTRF_TRACE
+__device__ unsigned long long g_potrf_trace[64];
+__device__ int g_potrf_trace_n;
+#endif
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_potrf_inv_la(const PotrfTask* __restrict__ tasks, int* __restrict__ fail) {
+    constexpr int NT = 64 * NW;
+#ifdef APEX_POTRF_TRACE   // tools/potrf_bench.hip: wall-clock stamps of workgroup 0 at the phase boundaries
+#define POTRF_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_potrf_trace[g_potrf_trace_n++] = wall_clock64(); } while (0)
+#else
+#define POTRF_STAMP() do {} while (0)
+#endif
+    POTRF_STAMP();
     const PotrfTask pt = tasks[blockIdx.x];
     double* __restrict__ A = pt.A;
     double* __restrict__ Linv = pt.Linv;
@@ -290,14 +305,15 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
     const int lr = lane & 15, lk = lane >> 4;
     if (tid == 0) bad = 0;
     {
-        double2 reg[25];
+        constexpr int NREG = (128 * 45 + NT - 1) / NT + NBK;
+        double2 reg[NREG];
         int n = 0;
 #pragma unroll
         for (int bi = 0; bi < NBK; ++bi) {
             const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
 #pragma unroll
-            for (int it = 0; it < (16 * 8 * (bi + 1) + 255) / 256; ++it, ++n) {
-                const int idx = tid + 256 * it;
+            for (int it = 0; it < (16 * 8 * (bi + 1) + NT - 1) / NT; ++it, ++n) {
+                const int idx = tid + NT * it;
                 if (idx < cnt) {
                     const int rr = idx / per_row, c2 = idx - rr * per_row;
                     reg[n] = *reinterpret_cast<const double2*>(A + (size_t)(16 * bi + rr) * NB + 2 * c2);
@@ -309,8 +325,8 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
         for (int bi = 0; bi < NBK; ++bi) {
             const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
 #pragma unroll
-            for (int it = 0; it < (16 * 8 * (bi + 1) + 255) / 256; ++it, ++n) {
-                const int idx = tid + 256 * it;
+            for (int it = 0; it < (16 * 8 * (bi + 1) + NT - 1) / NT; ++it, ++n) {
+                const int idx = tid + NT * it;
                 if (idx < cnt) {
                     const int rr = idx / per_row, c2 = idx - rr * per_row;
                     double* dst = sA + bidx(bi, c2 >> 3) * BSZ + rr * BP + 2 * (c2 & 7);
@@ -320,10 +336,11 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
         }
     }
     __syncthreads();
+    POTRF_STAMP();
 
     for (int kb = 0; kb < NBK; ++kb) {
         // ---------------- P1 ------------------------------------------------------------------------------
-        double4_t T[3];   // row kb-1 of L^-1: blocks j = (w-1), (w-1)+3, (w-1)+6 of waves 1..3
+        double4_t T[(NBK - 1 + NW - 2) / (NW - 1)];   // row kb-1 of L^-1: blocks j = (w-1), (w-1)+(NW-1), ... of waves 1..NW-1
         if (w == 0) {
             double* D = sA + bidx(kb, kb) * BSZ;
             double a[BS], invd[BS];
@@ -344,25 +361,50 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
                 const double lrj = a[j] * isj;
 #pragma unroll
                 for (int c = j + 1; c < BS; ++c) {
+                    // rows above the diagonal (lr < c) pick up garbage here: nothing below reads it and it is masked at
+                    // the store (a predicate per update costs 0.5 us per block step on this serial path)
                     const double lcj = readlane_f64(lrj, c);
-                    if (lr >= c) a[c] -= lrj * lcj;
+                    a[c] -= lrj * lcj;
                 }
                 a[j] = (lr > j) ? lrj : ((lr == j) ? sj : a[j]);
             }
+            // L of the block goes to LDS, and its transpose into the (still unused) slot of the inverse: the inverse
+            // below then takes column k of L as broadcast 16-byte LDS reads of one contiguous row of L^T (one address
+            // for the whole wave), fetched one step ahead, instead of two v_readlane per multiplier.
+            double* Lt = sD + kb * BSZ;
+            if (lk == 0) {
+#pragma unroll
+                for (int c = 0; c < BS; ++c) {
+                    D[lr * BP + c] = (lr >= c) ? a[c] : 0.0;
+                    Lt[c * BP + lr] = a[c];      // entries with lr < c are never read
+                }
+            }
             // inverse: lane c solves L x = e_c, column-oriented so that the 16 steps form a chain of only two
             // dependent operations each (the updates of the rows below k are independent of one another)
-            double x[BS];
+            double x[BS], cur[BS], nxt[BS];
 #pragma unroll
             for (int i = 0; i < BS; ++i) x[i] = (i == lr) ? 1.0 : 0.0;
 #pragma unroll
+            for (int i = 0; i < BS; i += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(Lt + i);
+                cur[i] = v.x; cur[i + 1] = v.y;
+            }
+#pragma unroll
             for (int k = 0; k < BS; ++k) {
+                if (k + 1 < BS) {
+#pragma unroll
+                    for (int i = (k + 2) & ~1; i < BS; i += 2) {
+                        const double2 v = *reinterpret_cast<const double2*>(Lt + (k + 1) * BP + i);
+                        nxt[i] = v.x; nxt[i + 1] = v.y;
+                    }
+                }
                 x[k] *= invd[k];
 #pragma unroll
-                for (int i = k + 1; i < BS; ++i) x[i] -= readlane_f64(a[k], i) * x[k];
+                for (int i = k + 1; i < BS; ++i) x[i] -= cur[i] * x[k];
+#pragma unroll
+                for (int i = 0; i < BS; ++i) cur[i] = nxt[i];
             }
             if (lk == 0) {
-#pragma unroll
-                for (int c = 0; c < BS; ++c) D[lr * BP + c] = a[c];
 #pragma unroll
                 for (int i = 0; i < BS; ++i) sD[kb * BSZ + i * BP + lr] = x[i];
             }
@@ -373,7 +415,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
                 // rest of the trailing update of step ks: targets (i, j) with kb < j <= i
                 const int m = NBK - 1 - kb;
                 const int n_upd = m * (m + 1) / 2;
-                for (int t = w - 1; t < n_upd; t += 3) {
+                for (int t = w - 1; t < n_upd; t += NW - 1) {
                     int ii = 0;
                     while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
                     const int jj = t - ii * (ii + 1) / 2;
@@ -386,7 +428,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
                 // row r = ks of L^-1 from L~(r,.) and the rows above (kept in registers until the barrier)
                 const int r = ks;
                 int nt = 0;
-                for (int j = w - 1; j < r; j += 3, ++nt) {
+                for (int j = w - 1; j < r; j += NW - 1, ++nt) {
                     double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
                     for (int k = j; k < r; ++k) {
                         const double* Y = (k == j) ? (sD + j * BSZ) : (sA + bidx(k, j) * BSZ);
@@ -397,16 +439,17 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
             }
         }
         __syncthreads();
+        POTRF_STAMP();
         if (w > 0 && kb >= 1) {
             const int r = kb - 1;
             int nt = 0;
-            for (int j = w - 1; j < r; j += 3, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
+            for (int j = w - 1; j < r; j += NW - 1, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
         }
         // ---------------- P2 ------------------------------------------------------------------------------
         // tasks 0 .. m-1: panel blocks (kb+1+t, kb); tasks m .. m+kb-1: row block (kb, t-m) -> global, then L~
         {
             const int m = NBK - 1 - kb;
-            for (int t = w; t < m + kb; t += 4) {
+            for (int t = w; t < m + kb; t += NW) {
                 if (t < m) {
                     double* P = sA + bidx(kb + 1 + t, kb) * BSZ;
                     double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -421,13 +464,14 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
                     blk_store_cd(Bk, acc, lr, lk, 1.0);  // same wave read it: LDS accesses of one wave stay in order
                 }
             }
-            if (w == 3) blk_to_global(sA + bidx(kb, kb) * BSZ, A, kb, kb, lane, 64);  // the diagonal block of L
+            if (w == NW - 1) blk_to_global(sA + bidx(kb, kb) * BSZ, A, kb, kb, lane, 64);  // the diagonal block of L
         }
         __syncthreads();
+        POTRF_STAMP();
         // ---------------- P3: look-ahead update of column kb+1 ---------------------------------------------------
         if (kb + 1 < NBK) {
             const int jc = kb + 1;
-            for (int i = jc + w; i < NBK; i += 4) {
+            for (int i = jc + w; i < NBK; i += NW) {
                 double* Cb = sA + bidx(i, jc) * BSZ;
                 double4_t acc = blk_load_cd(Cb, lr, lk);
                 acc = blk_mma_nt(sA + bidx(i, kb) * BSZ, sA + bidx(jc, kb) * BSZ, acc, lr, lk, -1.0);
@@ -435,13 +479,14 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
             }
         }
         __syncthreads();
+        POTRF_STAMP();
     }
     // last row of L^-1 (r = NBK-1), all four waves
     {
         const int r = NBK - 1;
-        double4_t T[2];
+        double4_t T[(NBK - 1 + NW - 1) / NW];
         int nt = 0;
-        for (int j = w; j < r; j += 4, ++nt) {
+        for (int j = w; j < r; j += NW, ++nt) {
             double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
             for (int k = j; k < r; ++k) {
                 const double* Y = (k == j) ? (sD + j * BSZ) : (sA + bidx(k, j) * BSZ);
@@ -451,13 +496,13 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
         }
         __syncthreads();
         nt = 0;
-        for (int j = w; j < r; j += 4, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
+        for (int j = w; j < r; j += NW, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
         __syncthreads();
     }
 #pragma unroll
     for (int bi = 0; bi < NBK; ++bi) {
         const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
-        for (int idx = tid; idx < cnt; idx += 256) {
+        for (int idx = tid; idx < cnt; idx += NT) {
             const int rr = idx / per_row, c2 = idx - rr * per_row;
             const int bj = c2 >> 3;
             const double* src = ((bj == bi) ? (sD + bi * BSZ) : (sA + bidx(bi, bj) * BSZ)) + rr * BP + 2 * (c2 & 7);
@@ -466,6 +511,8 @@ __global__ __launch_bounds__(256) void k_potrf_inv_la(const PotrfTask* __restric
         }
     }
     if (tid == 0 && bad) atomicCAS(fail, 0, K + 1);
+    POTRF_STAMP();
+#undef POTRF_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1079,11 +1126,13 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const 
 }
 
 // ------------------------------------------------------------------------------------------
-static bool g_potrf_lookahead = true;
-void set_potrf_lookahead(bool on) { g_potrf_lookahead = on; }
+static int g_potrf_lookahead = 8;   // 0: k_potrf_inv; 1: look-ahead kernel with 4 waves; 6 / 8 (default): with 6 / 8 waves
+void set_potrf_lookahead(int mode) { g_potrf_lookahead = mode; }
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s) {
     if (n <= 0) return;
-    if (g_potrf_lookahead) hipLaunchKernelGGL(k_potrf_inv_la, dim3(n), dim3(256), 0, s, tasks, fail);
+    if (g_potrf_lookahead == 1) hipLaunchKernelGGL(k_potrf_inv_la<4>, dim3(n), dim3(256), 0, s, tasks, fail);
+    else if (g_potrf_lookahead == 6) hipLaunchKernelGGL(k_potrf_inv_la<6>, dim3(n), dim3(384), 0, s, tasks, fail);
+    else if (g_potrf_lookahead) hipLaunchKernelGGL(k_potrf_inv_la<8>, dim3(n), dim3(512), 0, s, tasks, fail);
     else hipLaunchKernelGGL(k_potrf_inv, dim3(n), dim3(256), 0, s, tasks, fail);
 }
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s) {

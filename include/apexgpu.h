@@ -195,7 +195,8 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
  *   "update_overlap" (1)  run the trailing updates the next elimination level does not need on a second
  *                     stream, overlapped with that level's potrf / panel solves (before the first solve)
- *   "potrf_lookahead" (1)  look-ahead schedule of the diagonal-tile Cholesky + inverse
+ *   "potrf_lookahead" (8)  diagonal-tile Cholesky + inverse: 8 / 6 / 1 = look-ahead schedule with 8 / 6 / 4 waves
+ *                     per workgroup, 0 = the schedule without look-ahead
  *   "fused_forward" (0)  run the forward triangular sweep inside the factorisation graph on a third stream
  *   "nested_dissection" (1)  order camera tiles by nested dissection (call before set_structure);
  *                     0 keeps the caller's camera order, a value > 1 sets the leaf size in tiles

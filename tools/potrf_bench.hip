@@ -1,0 +1,49 @@
+// Latency of the diagonal-tile Cholesky + inverse (k_potrf_inv_la) on one tile and on a batch, with wall-clock
+// stamps of workgroup 0 at the phase boundaries (P1 | P2 | P3 per 16-pivot block step).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAPEX_POTRF_TRACE -I apex-solver_amd/csrc tools/potrf_bench.hip -o tools/potrf_bench
+#include "../apex-solver_amd/csrc/chol_kernels.hip"
+#include <stdio.h>
+#include <vector>
+using namespace apex;
+int main() {
+    const size_t te = (size_t)kNB * kNB;
+    const int nb = 64;
+    std::vector<double> h(te);
+    for (int i = 0; i < kNB; ++i)
+        for (int j = 0; j < kNB; ++j) h[(size_t)i * kNB + j] = (i == j ? 200.0 : 0.0) + 1.0 / (1.0 + abs(i - j));
+    double *src, *A, *Li; int* fail; PotrfTask* d;
+    hipMalloc(&src, te * 8); hipMalloc(&A, nb * te * 8); hipMalloc(&Li, nb * te * 8); hipMalloc(&fail, 16); hipMalloc(&d, nb * sizeof(PotrfTask));
+    hipMemcpy(src, h.data(), te * 8, hipMemcpyHostToDevice);
+    hipMemset(Li, 0, nb * te * 8); hipMemset(fail, 0, 16);
+    std::vector<PotrfTask> t(nb);
+    for (int i = 0; i < nb; ++i) t[i] = {A + i * te, Li + i * te, i};
+    hipMemcpy(d, t.data(), nb * sizeof(PotrfTask), hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode : {1, 6, 8}) {
+        set_potrf_lookahead(mode);
+        for (int n : {1, 64}) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                for (int i = 0; i < n; ++i) hipMemcpyAsync(A + i * te, src, te * 8, hipMemcpyDeviceToDevice, 0);
+                int zero = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_potrf_trace_n), &zero, sizeof zero);
+                hipDeviceSynchronize();
+                hipEventRecord(e0); launch_potrf_inv(d, n, fail, 0); hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
+            }
+            printf("waves mode %d, %2d tiles: %.1f us\n", mode, n, best * 1e3);
+            if (n == 1) {
+                unsigned long long tr[64]; int cnt = 0;
+                hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_potrf_trace), sizeof tr); hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_potrf_trace_n), sizeof cnt);
+                // wall_clock64 ticks at 100 MHz on gfx9: 10 ns per tick
+                printf("   stamps (us since start): ");
+                for (int i = 0; i < cnt && i < 64; ++i) printf("%.1f ", (tr[i] - tr[0]) * 0.01);
+                printf("\n   load %.1f | ", (tr[1] - tr[0]) * 0.01);
+                for (int kb = 0; kb < 9 && 2 + 3 * kb + 2 < cnt; ++kb)
+                    printf("[P1 %.1f P2 %.1f P3 %.1f] ", (tr[2 + 3 * kb] - tr[1 + 3 * kb]) * 0.01, (tr[3 + 3 * kb] - tr[2 + 3 * kb]) * 0.01, (tr[4 + 3 * kb] - tr[3 + 3 * kb]) * 0.01);
+                printf("| tail %.1f\n", (tr[cnt - 1] - tr[cnt - 2]) * 0.01);
+            }
+        }
+    }
+    int f; hipMemcpy(&f, fail, 4, hipMemcpyDeviceToHost); printf("fail flag %d\n", f);
+    return 0;
+}
