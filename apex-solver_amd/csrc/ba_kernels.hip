@@ -543,8 +543,11 @@ __global__ __launch_bounds__(kRowThreads) void k_schur_rows(BAView v, TileMap tm
 // staging and the final store: the four waves of a workgroup drift apart and hide each other's gathers.
 // Same arithmetic and the same LDS accumulation (81 ds_add_f64 per pair) as k_schur_rows.
 // ------------------------------------------------------------------------------------------
+// 256 threads: 218 VGPRs and 77 KB of LDS give 2 workgroups = 8 waves per CU; 384 / 512-thread variants forced to 3 / 4
+// waves per SIMD spill and run at 9.1 / 8.5 ms instead of 6.1.
+constexpr int kRow2Threads = 256;
 template <int DC, int CAP>
-__global__ __launch_bounds__(256) void k_schur_rows2(BAView v, TileMap tm, const RowTask* __restrict__ tasks,
+__global__ __launch_bounds__(kRow2Threads) void k_schur_rows2(BAView v, TileMap tm, const RowTask* __restrict__ tasks,
                                                        const RowChunk* __restrict__ chunks,
                                                        const RowEntry* __restrict__ entries,
                                                        const int* __restrict__ nbr, const double* __restrict__ hinv) {
@@ -555,8 +558,8 @@ __global__ __launch_bounds__(256) void k_schur_rows2(BAView v, TileMap tm, const
     const RowTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t ci = (uint32_t)t.cam;
-    for (int idx = tid; idx < CAP * E; idx += 256) acc[idx] = 0.0;
-    for (int idx = tid; idx < kHashSize; idx += 256) hkey[idx] = -1;
+    for (int idx = tid; idx < CAP * E; idx += kRow2Threads) acc[idx] = 0.0;
+    for (int idx = tid; idx < kHashSize; idx += kRow2Threads) hkey[idx] = -1;
     __syncthreads();
     if (tid < t.nnbr) {
         const int key = nbr[t.nbr0 + tid];
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(256) void k_schur_rows2(BAView v, TileMap tm, const
         while (atomicCAS(&hkey[h], -1, key) != -1) h = (h + 1) & (kHashSize - 1);
         hval[h] = tid;
     }
-    for (int idx = tid; idx < t.nnbr * kCamStride; idx += 256) {
+    for (int idx = tid; idx < t.nnbr * kCamStride; idx += kRow2Threads) {
         const int sl = idx / kCamStride, k = idx - sl * kCamStride;
         scam[sl * kCamPitch + k] = v.camp[(size_t)nbr[t.nbr0 + sl] * kCamStride + k];
     }
@@ -572,11 +575,19 @@ __global__ __launch_bounds__(256) void k_schur_rows2(BAView v, TileMap tm, const
     Cam cam_i;
     load_cam_prepared(v.camp + kCamStride * (size_t)ci, cam_i);
 
-    for (int ch = t.batch0 + w; ch < t.batch0 + t.nbatch; ch += 4) {
+    for (int ch = t.batch0 + w; ch < t.batch0 + t.nbatch; ch += kRow2Threads / 64) {
         const RowChunk ck = chunks[ch];
         const bool act = lane < ck.count;
         int j0 = 0, n = 0;
         double Y[DC][3], pw[3] = {0.0, 0.0, 0.0};
+        // Lanes that hit the same neighbour block in the same step would add to the same 81 addresses in the same order
+        // (adjacent observations of a camera see nearly the same cameras): the LDS atomic unit serialises them.  Every
+        // lane therefore walks the block rows in its own cyclic order: its copy of -Y_i is rotated by rot = lane % DC rows
+        // once per observation, and register row a goes to block row (a + rot) % DC.
+        const int rot = lane % DC;
+        int roff[DC];
+#pragma unroll
+        for (int a = 0; a < DC; ++a) { const int ra = a + rot; roff[a] = (ra >= DC ? ra - DC : ra) * DC; }
         if (act) {
             const int4 en = *reinterpret_cast<const int4*>(entries + ck.first + lane);
             j0 = en.y; n = en.z;
@@ -598,6 +609,20 @@ __global__ __launch_bounds__(256) void k_schur_rows2(BAView v, TileMap tm, const
                 const double w2 = -(Jc[0][a] * Jl[0][2] + Jc[1][a] * Jl[1][2]);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) Y[a][c] = w0 * Hi[c] + w1 * Hi[3 + c] + w2 * Hi[6 + c];
+            }
+            // barrel rotation: Y[a] <- Y[(a + rot) % DC]
+#pragma unroll
+            for (int sh = 1; sh < DC; sh <<= 1) {
+                const bool on = (rot & sh) != 0;
+                double T[DC][3];
+#pragma unroll
+                for (int a = 0; a < DC; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) T[a][c] = on ? Y[(a + sh) % DC][c] : Y[a][c];
+#pragma unroll
+                for (int a = 0; a < DC; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Y[a][c] = T[a][c];
             }
         }
         for (int q = 0; q < ck.nmax; ++q) {
@@ -621,8 +646,9 @@ __global__ __launch_bounds__(256) void k_schur_rows2(BAView v, TileMap tm, const
 #pragma unroll
                     for (int a = 0; a < DC; ++a) {
                         const double val = Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2;
-                        if (a >= bb) unsafeAtomicAdd(&blk[a * DC + bb], val);
-                        if (bb >= a) unsafeAtomicAdd(&blk[bb * DC + a], val);
+                        const int ra = roff[a] / DC;   // the block row this register row stands for
+                        if (ra >= bb) unsafeAtomicAdd(&blk[ra * DC + bb], val);
+                        if (bb >= ra) unsafeAtomicAdd(&blk[bb * DC + ra], val);
                     }
                 }
             } else {
@@ -633,13 +659,13 @@ __global__ __launch_bounds__(256) void k_schur_rows2(BAView v, TileMap tm, const
                     const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
 #pragma unroll
                     for (int a = 0; a < DC; ++a)
-                        unsafeAtomicAdd(&blk[a * DC + bb], Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2);
+                        unsafeAtomicAdd(&blk[roff[a] + bb], Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2);
                 }
             }
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < t.nnbr * E; idx += 256) {
+    for (int idx = tid; idx < t.nnbr * E; idx += kRow2Threads) {
         const int s = idx / E, e = idx - s * E, a = e / DC, bb = e - a * DC;
         const uint32_t cj = (uint32_t)nbr[t.nbr0 + s];
         double* dst = s_block_ptr<DC>(tm, ci, cj) + a * kNB + bb;
@@ -1063,8 +1089,8 @@ void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask
 void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
                         const RowChunk* chunks, const RowEntry* entries, const int* nbr, const double* hinv, hipStream_t s) {
     if (n_tasks == 0) return;
-    if (dc == 9) hipLaunchKernelGGL((k_schur_rows2<9, kRowCap9>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, chunks, entries, nbr, hinv);
-    else hipLaunchKernelGGL((k_schur_rows2<6, kRowCap6>), dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, chunks, entries, nbr, hinv);
+    if (dc == 9) hipLaunchKernelGGL((k_schur_rows2<9, kRowCap9>), dim3(n_tasks), dim3(kRow2Threads), 0, s, v, tm, tasks, chunks, entries, nbr, hinv);
+    else hipLaunchKernelGGL((k_schur_rows2<6, kRowCap6>), dim3(n_tasks), dim3(kRow2Threads), 0, s, v, tm, tasks, chunks, entries, nbr, hinv);
 }
 
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,

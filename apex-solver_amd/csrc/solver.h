@@ -156,9 +156,10 @@ class Solver : public LmBackend {
     RowTask* rtasks2_ = nullptr;     // k_schur_rows2: the same row tasks over chunks of entries
     RowChunk* rchunks_ = nullptr;
     RowEntry* rentries_ = nullptr;
-    int rows_form_ = 1;              // 1: one lane per pair (k_schur_rows, default), 2: one lane per observation
-                                     // (k_schur_rows2; select before set_structure).  Measured equal within 2 %:
-                                     // both are bound by the LDS atomic unit, not by the per-pair recomputation.
+    int rows_form_ = 2;              // 2: one lane per observation (k_schur_rows2, default: every lane walks the rows of
+                                     // a neighbour block in its own rotated order, which takes the same-address
+                                     // conflicts out of the LDS atomics: 9.7 -> 6.1 ms on final-13682); 1: one lane
+                                     // per pair (k_schur_rows).  Select before set_structure.
     uint16_t* cam_obs_off_ = nullptr;
     int* nbr_ = nullptr;
     int n_rtasks_ = 0;

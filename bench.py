@@ -283,11 +283,12 @@ def main():
     sc_ms, sc_n = stages["schur_scatter"]
     sc_avg = sc_ms / max(sc_n, 1)
     achieved = alg_bytes / (sc_avg * 1e-3) / 1e9 if sc_avg > 0 else 0.0
-    # the kernel recomputes both Jacobian blocks per camera pair: ~2 linearisations (2 x 250 flop),
-    # W_i, Y_i, W_j (54 + 81 + 54 FMA) and the d_c x d_c x 3 block product
-    flop_per_pair = 2 * 250 + 2 * (2 * dc * 3 + dc * 9) + 2 * 3 * dc * dc
-    gflops = info["pair_blocks"] * flop_per_pair / (sc_avg * 1e-3) / 1e9 if sc_avg > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_schur_rows", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # one lane per observation: the observation's linearisation, W_i and Y_i once (250 flop + 54 + 81 FMA), then per
+    # partner its linearisation, W_j (54 FMA) and the d_c x d_c x 3 block product
+    flop_per_pair = 250 + 2 * (dc * 3 + 3 * dc * dc)
+    flop_per_obs = 250 + 2 * (dc * 3 + dc * 9)
+    gflops = (info["pair_blocks"] * flop_per_pair + n_obs_local * flop_per_obs) / (sc_avg * 1e-3) / 1e9 if sc_avg > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_schur_rows2", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
                 "avg_launch_ms": sc_avg, "launches": sc_n,
                 "pair_blocks_per_launch": info["pair_blocks"], "lds_atomic_adds_per_launch": info["pair_blocks"] * dc * dc,

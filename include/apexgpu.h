@@ -189,8 +189,9 @@ int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out /* n_pt*9 */
 int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, double* y_explicit, double* y_implicit);
 
 /* Implementation switches (defaults in parentheses), for A/B tests and profiling:
- *   "schur_rows" (1)  Schur reduction in the LDS row form without global atomics: 1 = one lane per camera pair
- *                     (k_schur_rows), 2 = one lane per observation (k_schur_rows2; set before set_structure);
+ *   "schur_rows" (2)  Schur reduction in the LDS row form without global atomics: 2 = one lane per observation,
+ *                     block rows walked in a per-lane rotated order (k_schur_rows2), 1 = one lane per camera pair
+ *                     (k_schur_rows); set before set_structure;
  *                     0 selects the landmark-major global-atomics form (k_schur_scatter)
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
  *   "update_overlap" (1)  run the trailing updates the next elimination level does not need on a second
