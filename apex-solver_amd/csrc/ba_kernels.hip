@@ -625,13 +625,18 @@ __global__ __launch_bounds__(kRow2Threads) void k_schur_rows2(BAView v, TileMap 
                     for (int c = 0; c < 3; ++c) Y[a][c] = T[a][c];
             }
         }
+        // the partner's camera index and measurement are fetched one trip ahead: a trip is ~500 dependent VALU
+        // instructions, about as long as the gather it would otherwise wait for at 2 waves per SIMD
+        uint32_t cj_next = 0;
+        double2 uv_next = make_double2(0.0, 0.0);
+        if (act && n > 0) { cj_next = v.o_cam[j0]; uv_next = v.o_uv[j0]; }
         for (int q = 0; q < ck.nmax; ++q) {
+            const uint32_t cj = cj_next;
+            const double2 uvj = uv_next;
+            if (act && q + 1 < n) { cj_next = v.o_cam[j0 + q + 1]; uv_next = v.o_uv[j0 + q + 1]; }
             if (!(act && q < n)) continue;
-            const int j_s = j0 + q;
-            const uint32_t cj = v.o_cam[j_s];
             const int slot = hash_slot(hkey, hval, (int)cj);
             if (slot < 0) continue;  // partner camera belongs to another chunk of this row
-            const double2 uvj = v.o_uv[j_s];
             Cam cam_j;
             load_cam_prepared(scam + slot * kCamPitch, cam_j);
             double rj[2], Jcj[2][DC], Jlj[2][3];
