@@ -109,22 +109,23 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_reduce(BAView v, TileMap tm
 #pragma unroll
         for (int a = 0; a < DC; ++a) acc[NH + a] += Jc[0][a] * r[0] + Jc[1][a] * r[1];
         if (with_self) {
-            double W[DC][3], Y[DC][3];
+            // row a of Y = W Hll^-1 is used as soon as it exists (the self term only needs W(bb), bb <= a): no Y array,
+            // which keeps the kernel under 256 VGPRs = 2 waves per SIMD (it was 300 = 1 wave, nothing to hide a gather)
+            double W[DC][3];
             const double* Hi = rec;
             const double gl0 = rec[kLmG], gl1 = rec[kLmG + 1], gl2 = rec[kLmG + 2];
+            int idx2 = 0;
 #pragma unroll
             for (int a = 0; a < DC; ++a) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) W[a][q] = Jc[0][a] * Jl[0][q] + Jc[1][a] * Jl[1][q];
+                double Ya[3];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) Y[a][q] = W[a][0] * Hi[q] + W[a][1] * Hi[3 + q] + W[a][2] * Hi[6 + q];
-                acc[NH + DC + a] += Y[a][0] * gl0 + Y[a][1] * gl1 + Y[a][2] * gl2;
+                for (int q = 0; q < 3; ++q) Ya[q] = W[a][0] * Hi[q] + W[a][1] * Hi[3 + q] + W[a][2] * Hi[6 + q];
+                acc[NH + DC + a] += Ya[0] * gl0 + Ya[1] * gl1 + Ya[2] * gl2;
+#pragma unroll
+                for (int bb = 0; bb <= a; ++bb) acc[idx2++] -= Ya[0] * W[bb][0] + Ya[1] * W[bb][1] + Ya[2] * W[bb][2];
             }
-            idx = 0;
-#pragma unroll
-            for (int a = 0; a < DC; ++a)
-#pragma unroll
-                for (int bb = 0; bb <= a; ++bb) acc[idx++] -= Y[a][0] * W[bb][0] + Y[a][1] * W[bb][1] + Y[a][2] * W[bb][2];
         }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
