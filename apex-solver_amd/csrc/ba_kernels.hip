@@ -166,18 +166,21 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_reduce(BAView v, TileMap tm
 // K2a: landmark-major reduction, 8 lanes per landmark (32 landmarks per 256-thread block).
 // H_ll = sum Jl^T Jl + lambda I, g_l = sum Jl^T r, eigen-gated inverse.
 // ------------------------------------------------------------------------------------------
+constexpr int kLmLanes = 4;   // lanes per landmark in the landmark-major kernels.  final-13682 (3..9 observations per landmark): 8 lanes
+                              // 1.05 + 0.97 ms (k_landmark_reduce + k_back_substitute), 4 lanes 0.87 + 0.77, 2 lanes 0.74 + 0.68, 1 lane
+                              // 0.75 + 0.73; 4 keeps the tail of a landmark with a thousand observations at a few hundred microseconds
 template <int DC>
 __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda, double* __restrict__ hinv,
                                                            double* __restrict__ g_l, int* __restrict__ err_flag,
                                                            double* __restrict__ lmu) {
-    const int g = threadIdx.x & 7;
-    const int64_t l = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int g = threadIdx.x & (kLmLanes - 1);
+    const int64_t l = (int64_t)blockIdx.x * (256 / kLmLanes) + threadIdx.x / kLmLanes;
     const bool active = l < v.n_pt;
     double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0}, pw[3] = {0, 0, 0};
     if (active) {
         const int b = v.pt_ptr[l], e = v.pt_ptr[l + 1];
         pw[0] = v.pts[3 * l]; pw[1] = v.pts[3 * l + 1]; pw[2] = v.pts[3 * l + 2];
-        for (int i = b + g; i < e; i += 8) {
+        for (int i = b + g; i < e; i += kLmLanes) {
             const uint32_t c = v.o_cam[i];
             const double2 uv = v.o_uv[i];
             Cam cam;
@@ -195,11 +198,11 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
         }
     }
 #pragma unroll
-    for (int m = 1; m < 8; m <<= 1) {
+    for (int m = 1; m < kLmLanes; m <<= 1) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) h[i] += __shfl_xor(h[i], m, 8);
+        for (int i = 0; i < 6; ++i) h[i] += __shfl_xor(h[i], m, kLmLanes);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) gl[i] += __shfl_xor(gl[i], m, 8);
+        for (int i = 0; i < 3; ++i) gl[i] += __shfl_xor(gl[i], m, kLmLanes);
     }
     if (active && g == 0) {
         // With Jacobi scaling the reference inverts the block of the SCALED system, D Hll D + lambda I (eigenvalue
@@ -691,14 +694,14 @@ __global__ __launch_bounds__(256) void k_back_substitute(BAView v, const double*
                                                            const double* __restrict__ g_l,
                                                            const double* __restrict__ dc,
                                                            double* __restrict__ dl) {
-    const int g = threadIdx.x & 7;
-    const int64_t l = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int g = threadIdx.x & (kLmLanes - 1);
+    const int64_t l = (int64_t)blockIdx.x * (256 / kLmLanes) + threadIdx.x / kLmLanes;
     const bool active = l < v.n_pt;
     double acc[3] = {0, 0, 0};
     if (active) {
         const int b = v.pt_ptr[l], e = v.pt_ptr[l + 1];
         const double pw[3] = {v.pts[3 * l], v.pts[3 * l + 1], v.pts[3 * l + 2]};
-        for (int i = b + g; i < e; i += 8) {
+        for (int i = b + g; i < e; i += kLmLanes) {
             const uint32_t c = v.o_cam[i];
             const double2 uv = v.o_uv[i];
             Cam cam;
@@ -716,9 +719,9 @@ __global__ __launch_bounds__(256) void k_back_substitute(BAView v, const double*
         }
     }
 #pragma unroll
-    for (int m = 1; m < 8; m <<= 1)
+    for (int m = 1; m < kLmLanes; m <<= 1)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc[i] += __shfl_xor(acc[i], m, 8);
+        for (int i = 0; i < 3; ++i) acc[i] += __shfl_xor(acc[i], m, kLmLanes);
     if (active && g == 0) {
         const double* Hi = hinv + kLmStride * l;
         if (MATVEC) {
@@ -1064,7 +1067,7 @@ void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* ca
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag, double* lmu,
                             hipStream_t s) {
     if (v.n_pt == 0) return;
-    const int grid = grid_for(v.n_pt, 32, 0);
+    const int grid = grid_for(v.n_pt, 256 / kLmLanes, 0);
     if (dc == 9) hipLaunchKernelGGL(k_landmark_reduce<9>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag, lmu);
     else hipLaunchKernelGGL(k_landmark_reduce<6>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag, lmu);
 }
@@ -1102,7 +1105,7 @@ void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTas
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
                             double* dl, hipStream_t s) {
     if (v.n_pt == 0) return;
-    const int grid = grid_for(v.n_pt, 32, 0);
+    const int grid = grid_for(v.n_pt, 256 / kLmLanes, 0);
     if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl);
     else hipLaunchKernelGGL((k_back_substitute<6, false>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl);
 }
@@ -1162,7 +1165,7 @@ void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, do
 void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
                             double lambda, double* y, hipStream_t s) {
     if (v.n_pt > 0) {
-        const int grid = (int)((v.n_pt + 31) / 32);
+        const int grid = (int)((v.n_pt + 256 / kLmLanes - 1) / (256 / kLmLanes));
         if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu);
         else hipLaunchKernelGGL((k_back_substitute<6, true>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu);
     }
