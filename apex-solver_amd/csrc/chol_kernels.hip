@@ -854,11 +854,17 @@ __device__ __forceinline__ void tile_gemv_lds(const double* __restrict__ M, cons
 }
 
 template <bool TRANS>
-__global__ __launch_bounds__(256) void k_tri_step(const TriTask* __restrict__ tasks, double* __restrict__ vwork,
+__global__ __launch_bounds__(256) void k_tri_step(const TriTask* __restrict__ tasks, int n_tasks, double* __restrict__ vwork,
                                                     double* __restrict__ vout) {
     __shared__ double sT[HROWS * TP];
     __shared__ double sv[NB], sy[NB], sz[NB], spart[NB];
-    const TriTask t = tasks[blockIdx.x];
+    // XCD-contiguous task order (as in k_tile_gemm_nt): the tasks of one column -- which all re-read that column's
+    // L^-1 tile for the diagonal product -- are consecutive in the list; dealing every XCD one contiguous eighth keeps
+    // them on one L2 instead of fetching the tile through eight
+    const int per_xcd = (n_tasks + 7) >> 3;
+    const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_tasks) return;
+    const TriTask t = tasks[unit];
     const int tid = threadIdx.x;
     if (tid < NB) sv[tid] = vwork[(size_t)t.k * NB + tid];
     __syncthreads();
@@ -1147,8 +1153,9 @@ void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta
 }
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s) {
     if (n <= 0) return;
-    if (trans) hipLaunchKernelGGL(k_tri_step<true>, dim3(n), dim3(256), 0, s, tasks, vwork, vout);
-    else hipLaunchKernelGGL(k_tri_step<false>, dim3(n), dim3(256), 0, s, tasks, vwork, vout);
+    const int grid = 8 * ((n + 7) / 8);
+    if (trans) hipLaunchKernelGGL(k_tri_step<true>, dim3(grid), dim3(256), 0, s, tasks, n, vwork, vout);
+    else hipLaunchKernelGGL(k_tri_step<false>, dim3(grid), dim3(256), 0, s, tasks, n, vwork, vout);
 }
 void launch_sym_tile_products(const SymTile* list, int n, const double* tiles, const double* x, double* part, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_sym_tile_products, dim3(n), dim3(256), 0, s, list, tiles, x, part);
