@@ -25,7 +25,7 @@ SYMBOLS = (
     "apexgpu_parameter_norm", "apexgpu_column_norms", "apexgpu_set_column_scaling", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
     "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
     "apexgpu_stage_times", "apexgpu_info", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_set_shard", "apexgpu_shard_range",
-    "apexgpu_debug_lockstep_solve", "apexgpu_export_step", "apexgpu_owned_landmarks",
+    "apexgpu_debug_lockstep_solve", "apexgpu_export_step", "apexgpu_owned_landmarks", "apexgpu_debug_partition",
     "apexgpu_bal_open", "apexgpu_bal_close", "apexgpu_bal_last_error", "apexgpu_bal_sizes", "apexgpu_bal_raw",
     "apexgpu_bal_variables", "apexgpu_reference_columns",
     # SE3 pose-graph backend
@@ -119,6 +119,7 @@ def load() -> C.CDLL:
     L.apexgpu_debug_lockstep_solve.argtypes = [vp, C.c_int, C.c_double]
     L.apexgpu_export_step.argtypes = [vp, vp, vp]
     L.apexgpu_owned_landmarks.argtypes = [vp, vp]
+    L.apexgpu_debug_partition.argtypes = [C.c_int, vp, C.c_int, vp]
     L.apexgpu_set_column_scaling.argtypes = [vp, vp]
     L.apexgpu_lm_optimize.argtypes = [vp, C.POINTER(LmConfigC), C.POINTER(LmResultC), vp, C.c_int]
     L.apexgpu_get_residual.argtypes = [vp, vp]
@@ -183,6 +184,19 @@ def load() -> C.CDLL:
             f.restype = C.c_int
     _lib = L
     return L
+
+
+def tile_partition(present: np.ndarray, world: int):
+    """Owner rank of every tile column (-1: shared top) for a distributed plan of `world` ranks; host arithmetic in the
+    library, no GPU needed.  present: (nt, nt) lower-triangular 0/1 structure."""
+    L = load()
+    pr = np.ascontiguousarray(present, dtype=np.uint8)
+    nt = pr.shape[0]
+    owner = np.zeros(nt, dtype=np.int32)
+    n_top = L.apexgpu_debug_partition(nt, pr.ctypes.data_as(C.c_void_p), int(world), owner.ctypes.data_as(C.c_void_p))
+    if n_top < 0:
+        raise LinAlgError(n_top, "apexgpu_debug_partition")
+    return owner, n_top
 
 
 def shard_range(pt_idx: np.ndarray, n_pt: int, rank: int, world: int) -> tuple[int, int]:

@@ -164,6 +164,21 @@ int apexgpu_debug_lockstep_solve(apexgpu_solver** hs, int n, double lambda) {
     }
     return APEXGPU_OK;
 }
+// Host arithmetic only (no device is touched): the cut of the tile elimination tree that a distributed plan of `world`
+// ranks makes for the lower-triangular tile structure `present` (nt x nt, row-major, I >= J).  owner_out[nt]: owning
+// rank of every tile column, -1 for the shared top; returns the number of top columns (0: the plan stays replicated).
+int apexgpu_debug_partition(int nt, const uint8_t* present, int world, int* owner_out) {
+    if (nt <= 0 || !present || !owner_out || world < 1) return APEXGPU_ERR_INVALID_INPUT;
+    apex::TilePlan tp;
+    tp.set_partition(0, world);
+    const std::vector<uint8_t> pr(present, present + (size_t)nt * nt);
+    const std::vector<int> owner = tp.preview_owners(nt, pr);
+    if (owner.empty()) { for (int i = 0; i < nt; ++i) owner_out[i] = 0; return 0; }
+    int n_top = 0;
+    for (int i = 0; i < nt; ++i) { owner_out[i] = owner[i]; n_top += owner[i] < 0; }
+    return n_top;
+}
+
 int apexgpu_owned_landmarks(apexgpu_solver* h, uint8_t* mask) {
     H_OR_FAIL;
     if (!mask) return APEXGPU_ERR_INVALID_INPUT;

@@ -246,6 +246,11 @@ int apexgpu_debug_lockstep_solve(apexgpu_solver** hs, int n, double lambda);
  * by default (world > 1) a landmark belongs to the rank whose tile columns its cameras touch below the shared top of
  * the elimination tree, which makes that rank's tiles of S complete without any reduction. */
 int apexgpu_owned_landmarks(apexgpu_solver* h, uint8_t* mask);
+/* Host arithmetic only: the cut of the tile elimination tree a distributed plan of `world` ranks makes for the
+ * lower-triangular tile structure present[nt*nt] (row-major, I >= J).  owner_out[nt] = owning rank of every tile
+ * column, -1 for the shared top; returns the number of top columns (0: the plan stays replicated) or a negative
+ * status. */
+int apexgpu_debug_partition(int nt, const uint8_t* present, int world, int* owner_out);
 int apexgpu_export_step(apexgpu_solver* h, double* step_out, double* grad_out);
 /* The landmark range [lo,hi) rank `rank` of `world` owns (contiguous, balanced by observation count).
  * Host arithmetic only -- no device is touched -- so schedulers and tests can call it anywhere. */
