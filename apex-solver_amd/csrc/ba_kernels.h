@@ -125,6 +125,7 @@ void launch_dot2(int64_t n, const double* a1, const double* b1, const double* a2
                  int n_partial, double* out, hipStream_t s);
 // out[k] = sum_i partial[i*nk + k] in index order (one block: reproducible)
 void launch_sum_partials(const double* partial, int n, int nk, double* out, hipStream_t s);
+void launch_debug_invert_blocks(int64_t n, const double* in, double* out, int* ok, hipStream_t s);
 void launch_export_linearization(int dc, const BAView& v, const int* o_orig, double* r_out, double* jc_out,
                                  double* jl_out, hipStream_t s);
 

@@ -1214,6 +1214,25 @@ void launch_sum_partials(const double* partial, int n, int nk, double* out, hipS
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n, nk, out);
 }
 
+// the device's 3x3 gate + inverse on caller-supplied blocks (apexgpu_debug_invert_blocks): the same function
+// k_landmark_reduce calls per landmark, so that the three regimes of explicit_schur.rs:377-442 and the margins of the
+// trace / determinant shortcut can be probed on the GPU with exact inputs
+__global__ __launch_bounds__(256) void k_debug_invert_blocks(int64_t n, const double* __restrict__ in, double* __restrict__ out,
+                                                               int* __restrict__ ok) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double B[9], Bi[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) B[k] = in[9 * i + k];
+    const bool good = invert_landmark_block(B, Bi);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[9 * i + k] = good ? Bi[k] : 0.0;
+    ok[i] = good ? 1 : 0;
+}
+void launch_debug_invert_blocks(int64_t n, const double* in, double* out, int* ok, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_debug_invert_blocks, dim3(grid_for(n, 256, 0)), dim3(256), 0, s, n, in, out, ok);
+}
+
 void launch_export_linearization(int dc, const BAView& v, const int* o_orig, double* r_out, double* jc_out,
                                  double* jl_out, hipStream_t s) {
     if (v.n_obs == 0) return;

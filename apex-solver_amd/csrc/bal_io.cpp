@@ -17,6 +17,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -97,7 +99,22 @@ extern "C" {
 
 const char* apexgpu_bal_last_error(void) { return g_bal_err.c_str(); }
 
+static int bal_open_impl(const char* path, apexgpu_bal** out);
+// No exception crosses the C boundary: allocation failures (sizes come from an untrusted header) are a parse error.
 int apexgpu_bal_open(const char* path, apexgpu_bal** out) {
+    try {
+        return bal_open_impl(path, out);
+    } catch (const std::exception& e) {
+        if (out) *out = nullptr;
+        return bal_fail(APEXGPU_BAL_ERR_PARSE, std::string("BAL file too large for this host: ") + e.what());
+    } catch (...) {
+        if (out) *out = nullptr;
+        return bal_fail(APEXGPU_BAL_ERR_PARSE, "unexpected failure while reading the BAL file");
+    }
+}
+}  // extern "C"
+
+static int bal_open_impl(const char* path, apexgpu_bal** out) {
     if (!path || !out) return bal_fail(APEXGPU_ERR_INVALID_INPUT, "null argument");
     *out = nullptr;
     FILE* f = fopen(path, "rb");
@@ -113,8 +130,8 @@ int apexgpu_bal_open(const char* path, apexgpu_bal** out) {
     LineIter it{content.data(), content.data() + content.size()};
     Line l;
     const char *tb[8], *te[8];
-    auto ds = new apexgpu_bal();
-    auto bad = [&](int code, const std::string& m) { delete ds; return bal_fail(code, m); };
+    std::unique_ptr<apexgpu_bal> ds(new apexgpu_bal());
+    auto bad = [&](int code, const std::string& m) { return bal_fail(code, m); };
     // header (bal.rs:205-241)
     if (!it.next(l)) return bad(APEXGPU_BAL_ERR_PARSE, "line 1: Missing header line");
     if (split_ws(l, tb, te) != 3) return bad(APEXGPU_BAL_ERR_MISSING_FIELDS, "line " + std::to_string(l.no) + ": missing fields");
@@ -122,6 +139,13 @@ int apexgpu_bal_open(const char* path, apexgpu_bal** out) {
     if (!parse_usize(tb[0], te[0], hc)) return bad(APEXGPU_BAL_ERR_INVALID_NUMBER, "line " + std::to_string(l.no) + ": invalid number '" + std::string(tb[0], te[0]) + "'");
     if (!parse_usize(tb[1], te[1], hp)) return bad(APEXGPU_BAL_ERR_INVALID_NUMBER, "line " + std::to_string(l.no) + ": invalid number '" + std::string(tb[1], te[1]) + "'");
     if (!parse_usize(tb[2], te[2], ho)) return bad(APEXGPU_BAL_ERR_INVALID_NUMBER, "line " + std::to_string(l.no) + ": invalid number '" + std::string(tb[2], te[2]) + "'");
+    // The header is untrusted: every observation line needs >= 8 bytes ("0 0 0 0\n"), every camera / point value >= 2,
+    // so counts the file cannot hold are the reference's "Unexpected end of file" before anything is reserved.
+    // (The reference's Vec::with_capacity(num_observations) panics on such a header, bal.rs:247.)
+    const uint64_t fsz = (uint64_t)content.size();
+    if (ho > fsz / 8 + 1) return bad(APEXGPU_BAL_ERR_PARSE, "Unexpected end of file in observations section");
+    if (hc > fsz / 18 + 1) return bad(APEXGPU_BAL_ERR_PARSE, "Unexpected end of file in camera 0 parameter 0");
+    if (hp > fsz / 6 + 1) return bad(APEXGPU_BAL_ERR_PARSE, "Unexpected end of file in point 0 coordinate 0");
     ds->n_cam = (int64_t)hc; ds->n_pt = (int64_t)hp; ds->n_obs = (int64_t)ho;
     // observations (:243-300)
     ds->cam_idx.reserve(ho); ds->pt_idx.reserve(ho); ds->obs_uv.reserve(2 * ho);
@@ -133,6 +157,11 @@ int apexgpu_bal_open(const char* path, apexgpu_bal** out) {
         if (!parse_usize(tb[1], te[1], p)) return bad(APEXGPU_BAL_ERR_INVALID_NUMBER, "line " + std::to_string(l.no) + ": invalid number '" + std::string(tb[1], te[1]) + "'");
         if (!parse_f64(tb[2], te[2], x)) return bad(APEXGPU_BAL_ERR_INVALID_NUMBER, "line " + std::to_string(l.no) + ": invalid number '" + std::string(tb[2], te[2]) + "'");
         if (!parse_f64(tb[3], te[3], y)) return bad(APEXGPU_BAL_ERR_INVALID_NUMBER, "line " + std::to_string(l.no) + ": invalid number '" + std::string(tb[3], te[3]) + "'");
+        // indices are stored as u32 (the C ABI's index type); the reference keeps usize and never range-checks them in
+        // the loader, so an index >= the header count still loads (set_structure rejects it), but one that does not fit
+        // u32 would alias a valid index here: refuse it as an invalid number
+        if (c > 0xFFFFFFFFull) return bad(APEXGPU_BAL_ERR_INVALID_NUMBER, "line " + std::to_string(l.no) + ": invalid number '" + std::string(tb[0], te[0]) + "' (camera index exceeds 32 bits)");
+        if (p > 0xFFFFFFFFull) return bad(APEXGPU_BAL_ERR_INVALID_NUMBER, "line " + std::to_string(l.no) + ": invalid number '" + std::string(tb[1], te[1]) + "' (point index exceeds 32 bits)");
         ds->cam_idx.push_back((uint32_t)c); ds->pt_idx.push_back((uint32_t)p);
         ds->obs_uv.push_back(x); ds->obs_uv.push_back(y);
     }
@@ -155,9 +184,11 @@ int apexgpu_bal_open(const char* path, apexgpu_bal** out) {
             if (!parse_f64(l.b, l.e, v)) return bad(APEXGPU_BAL_ERR_INVALID_NUMBER, "line " + std::to_string(l.no) + ": invalid number '" + std::string(l.b, l.e) + "'");
             ds->points.push_back(v);
         }
-    *out = ds;
+    *out = ds.release();
     return APEXGPU_OK;
 }
+
+extern "C" {
 
 void apexgpu_bal_close(apexgpu_bal* b) { delete b; }
 

@@ -1,6 +1,7 @@
 // capi.cpp -- extern "C" surface declared in include/apexgpu.h.
 #include "../../include/apexgpu.h"
 
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -29,6 +30,22 @@ struct apexgpu_pg_solver {
 
 #define H_OR_FAIL            \
     if (!h || !h->s) return APEXGPU_ERR_INVALID_STATE
+
+// No C++ exception may cross the C boundary (a caller in Rust / C / ctypes cannot unwind it): entry points that
+// allocate run their body through this guard.  bad_alloc / length_error (e.g. sizes taken from an untrusted header)
+// become APEXGPU_ERR_INVALID_INPUT.
+template <typename F>
+static int guarded(F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return APEXGPU_ERR_INVALID_INPUT;
+    } catch (const std::exception&) {
+        return APEXGPU_ERR_INVALID_INPUT;
+    } catch (...) {
+        return APEXGPU_ERR_INVALID_STATE;
+    }
+}
 
 extern "C" {
 
@@ -61,7 +78,7 @@ int apexgpu_set_structure(apexgpu_solver* h, const uint32_t* cam_idx, const uint
                           const uint8_t* fix_pose, const uint8_t* fix_intr, const uint8_t* fix_pt, double huber_delta) {
     H_OR_FAIL;
     if (!cam_idx || !pt_idx || !obs_uv || !intr_col || !pose_col || !pt_col) return APEXGPU_ERR_INVALID_INPUT;
-    return h->s->set_structure(cam_idx, pt_idx, obs_uv, intr_col, pose_col, pt_col, fix_pose, fix_intr, fix_pt, huber_delta);
+    return guarded([&] { return h->s->set_structure(cam_idx, pt_idx, obs_uv, intr_col, pose_col, pt_col, fix_pose, fix_intr, fix_pt, huber_delta); });
 }
 int apexgpu_set_cg_params(apexgpu_solver* h, int max_iterations, double tolerance) {
     H_OR_FAIL;
@@ -71,21 +88,21 @@ int apexgpu_set_cg_params(apexgpu_solver* h, int max_iterations, double toleranc
 int apexgpu_set_params(apexgpu_solver* h, const double* poses, const double* intr, const double* points) {
     H_OR_FAIL;
     if (!poses || !intr || !points) return APEXGPU_ERR_INVALID_INPUT;
-    return h->s->set_params(poses, intr, points);
+    return guarded([&] { return h->s->set_params(poses, intr, points); });
 }
 int apexgpu_get_params(apexgpu_solver* h, double* poses, double* intr, double* points) {
     H_OR_FAIL;
     if (!poses || !intr || !points) return APEXGPU_ERR_INVALID_INPUT;
-    return h->s->get_params(poses, intr, points);
+    return guarded([&] { return h->s->get_params(poses, intr, points); });
 }
-int apexgpu_cost(apexgpu_solver* h, double* cost) { H_OR_FAIL; return h->s->cost(cost); }
+int apexgpu_cost(apexgpu_solver* h, double* cost) { H_OR_FAIL; return guarded([&] { return h->s->cost(cost); }); }
 int apexgpu_solve_augmented(apexgpu_solver* h, double lambda, int variant, double* step_out, double* grad_out) {
     H_OR_FAIL;
     if (variant != APEXGPU_VARIANT_SPARSE && variant != APEXGPU_VARIANT_ITERATIVE && variant != APEXGPU_VARIANT_IMPLICIT)
         return APEXGPU_ERR_INVALID_INPUT;
-    return h->s->solve_augmented(lambda, variant, step_out, grad_out);
+    return guarded([&] { return h->s->solve_augmented(lambda, variant, step_out, grad_out); });
 }
-int apexgpu_assemble(apexgpu_solver* h, double lambda) { H_OR_FAIL; return h->s->assemble_only(lambda); }
+int apexgpu_assemble(apexgpu_solver* h, double lambda) { H_OR_FAIL; return guarded([&] { return h->s->assemble_only(lambda); }); }
 int apexgpu_step_stats(apexgpu_solver* h, double out3[3]) { H_OR_FAIL; return h->s->step_stats(out3); }
 int apexgpu_eval_step(apexgpu_solver* h, double* trial_cost) { H_OR_FAIL; return h->s->eval_step(trial_cost); }
 int apexgpu_commit_step(apexgpu_solver* h) { H_OR_FAIL; return h->s->commit_step(); }
@@ -95,40 +112,45 @@ int apexgpu_parameter_norm(apexgpu_solver* h, double* out) { H_OR_FAIL; return h
 int apexgpu_column_norms(apexgpu_solver* h, double* norms_out) {
     H_OR_FAIL;
     if (!norms_out) return APEXGPU_ERR_INVALID_INPUT;
-    return h->s->column_norms(norms_out);
+    return guarded([&] { return h->s->column_norms(norms_out); });
 }
-int apexgpu_set_column_scaling(apexgpu_solver* h, const double* scaling) { H_OR_FAIL; return h->s->set_column_scaling(scaling); }
+int apexgpu_set_column_scaling(apexgpu_solver* h, const double* scaling) { H_OR_FAIL; return guarded([&] { return h->s->set_column_scaling(scaling); }); }
 
 int apexgpu_lm_optimize(apexgpu_solver* h, apexgpu_lm_config* cfg, apexgpu_lm_result* result, apexgpu_lm_iter* history,
                         int history_capacity) {
     H_OR_FAIL;
     if (!cfg || !result) return APEXGPU_ERR_INVALID_INPUT;
-    return h->s->lm_optimize(reinterpret_cast<apex::LmConfig*>(cfg), reinterpret_cast<apex::LmResult*>(result),
-                             reinterpret_cast<apex::LmIterRecord*>(history), history ? history_capacity : 0);
+    return guarded([&] { return h->s->lm_optimize(reinterpret_cast<apex::LmConfig*>(cfg), reinterpret_cast<apex::LmResult*>(result),
+                                                  reinterpret_cast<apex::LmIterRecord*>(history), history ? history_capacity : 0); });
 }
 
-int apexgpu_get_residual(apexgpu_solver* h, double* r_out) { H_OR_FAIL; return h->s->get_residual(r_out); }
+int apexgpu_get_residual(apexgpu_solver* h, double* r_out) { H_OR_FAIL; return guarded([&] { return h->s->get_residual(r_out); }); }
 int apexgpu_get_jacobian_blocks(apexgpu_solver* h, double* jc_out, double* jl_out) {
     H_OR_FAIL;
-    return h->s->get_jacobian_blocks(jc_out, jl_out);
+    return guarded([&] { return h->s->get_jacobian_blocks(jc_out, jl_out); });
 }
-int apexgpu_get_schur(apexgpu_solver* h, double* S_out, double* gred_out) { H_OR_FAIL; return h->s->get_schur(S_out, gred_out); }
+int apexgpu_get_schur(apexgpu_solver* h, double* S_out, double* gred_out) { H_OR_FAIL; return guarded([&] { return h->s->get_schur(S_out, gred_out); }); }
 int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out, double* gl_out) {
     H_OR_FAIL;
-    return h->s->get_landmark_blocks(hinv_out, gl_out);
+    return guarded([&] { return h->s->get_landmark_blocks(hinv_out, gl_out); });
 }
 
 int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, double* y_explicit, double* y_implicit) {
     H_OR_FAIL;
     if (!x_in) return APEXGPU_ERR_INVALID_INPUT;
-    return h->s->schur_matvec(lambda, x_in, y_explicit, y_implicit);
+    return guarded([&] { return h->s->schur_matvec(lambda, x_in, y_explicit, y_implicit); });
 }
 
 // Test entry: the `n` handles are the ranks 0..n-1 of one sharded problem (apexgpu_set_shard(r, n) before
 // set_structure, same parameters), all on this process's GPU.  Runs ONE distributed Cholesky solve in lockstep --
 // every rank executes phase p, then this function plays the communicator for the exchange that follows it (sums in
 // rank order, max for the failure flag) -- and leaves the step on every handle (apexgpu_export_step).
+static int lockstep_solve_impl(apexgpu_solver** hs, int n, double lambda);
 int apexgpu_debug_lockstep_solve(apexgpu_solver** hs, int n, double lambda) {
+    return guarded([&] { return lockstep_solve_impl(hs, n, lambda); });
+}
+}  // extern "C"
+static int lockstep_solve_impl(apexgpu_solver** hs, int n, double lambda) {
     if (!hs || n < 2) return APEXGPU_ERR_INVALID_INPUT;
     for (int r = 0; r < n; ++r) if (!hs[r] || !hs[r]->s) return APEXGPU_ERR_INVALID_INPUT;
     for (int phase = 0; phase <= 5; ++phase) {
@@ -164,11 +186,13 @@ int apexgpu_debug_lockstep_solve(apexgpu_solver** hs, int n, double lambda) {
     }
     return APEXGPU_OK;
 }
+extern "C" {
 // Host arithmetic only (no device is touched): the cut of the tile elimination tree that a distributed plan of `world`
 // ranks makes for the lower-triangular tile structure `present` (nt x nt, row-major, I >= J).  owner_out[nt]: owning
 // rank of every tile column, -1 for the shared top; returns the number of top columns (0: the plan stays replicated).
 int apexgpu_debug_partition(int nt, const uint8_t* present, int world, int* owner_out) {
     if (nt <= 0 || !present || !owner_out || world < 1) return APEXGPU_ERR_INVALID_INPUT;
+    return guarded([&]() -> int {
     apex::TilePlan tp;
     tp.set_partition(0, world);
     const std::vector<uint8_t> pr(present, present + (size_t)nt * nt);
@@ -177,6 +201,7 @@ int apexgpu_debug_partition(int nt, const uint8_t* present, int world, int* owne
     int n_top = 0;
     for (int i = 0; i < nt; ++i) { owner_out[i] = owner[i]; n_top += owner[i] < 0; }
     return n_top;
+    });
 }
 
 int apexgpu_owned_landmarks(apexgpu_solver* h, uint8_t* mask) {
@@ -184,11 +209,19 @@ int apexgpu_owned_landmarks(apexgpu_solver* h, uint8_t* mask) {
     if (!mask) return APEXGPU_ERR_INVALID_INPUT;
     return h->s->owned_landmarks(mask);
 }
-int apexgpu_export_step(apexgpu_solver* h, double* step_out, double* grad_out) { H_OR_FAIL; return h->s->export_step(step_out, grad_out); }
+int apexgpu_export_step(apexgpu_solver* h, double* step_out, double* grad_out) { H_OR_FAIL; return guarded([&] { return h->s->export_step(step_out, grad_out); }); }
 
 int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     H_OR_FAIL;
     const std::string n = name ? name : "";
+    // Switches that shape what set_structure builds (task lists, tile order, partition) or what the captured hipGraphs
+    // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
+    // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
+    static const char* const structural[] = {"schur_rows", "schur_form", "potrf_lookahead", "dist_factor", "tree_sharding", "dist_selftest",
+                                             "nested_dissection", "update_overlap", "fused_forward"};
+    if (h->s->has_structure())
+        for (const char* k : structural)
+            if (n == k) return APEXGPU_ERR_INVALID_STATE;
     if (n == "schur_rows") h->s->use_row_schur(value);
     else if (n == "graphs") h->s->enable_graphs(value != 0);
     else if (n == "update_overlap") { h->s->enable_overlap(value != 0); if (value > 1) h->s->set_overlap_min(value); }
@@ -242,16 +275,41 @@ int apexgpu_comm_init(apexgpu_solver* h, int world, int rank, const void* unique
 }
 int apexgpu_shard_range(int64_t n_pt, int64_t n_obs, const uint32_t* pt_idx, int rank, int world, int64_t* lo, int64_t* hi) {
     if (!pt_idx || !lo || !hi || world < 1 || rank < 0 || rank >= world || n_pt <= 0) return APEXGPU_ERR_INVALID_INPUT;
-    std::vector<int64_t> ptr(n_pt + 1, 0);
-    for (int64_t i = 0; i < n_obs; ++i) {
-        if (pt_idx[i] >= (uint64_t)n_pt) return APEXGPU_ERR_INVALID_INPUT;
-        ptr[pt_idx[i] + 1]++;
-    }
-    for (int64_t l = 0; l < n_pt; ++l) ptr[l + 1] += ptr[l];
-    apex::shard_range(n_pt, ptr.data(), rank, world, lo, hi);
-    return APEXGPU_OK;
+    return guarded([&]() -> int {
+        std::vector<int64_t> ptr(n_pt + 1, 0);
+        for (int64_t i = 0; i < n_obs; ++i) {
+            if (pt_idx[i] >= (uint64_t)n_pt) return APEXGPU_ERR_INVALID_INPUT;
+            ptr[pt_idx[i] + 1]++;
+        }
+        for (int64_t l = 0; l < n_pt; ++l) ptr[l + 1] += ptr[l];
+        apex::shard_range(n_pt, ptr.data(), rank, world, lo, hi);
+        return APEXGPU_OK;
+    });
 }
 int apexgpu_set_shard(apexgpu_solver* h, int rank, int world) { H_OR_FAIL; return h->s->set_shard(rank, world); }
+
+// Parity probe: the device's eigenvalue-gated 3x3 inverse (invert_landmark_blocks_with_lambda with lambda = 0,
+// explicit_schur.rs:365-442) applied to n caller-supplied symmetric blocks on GPU `device`.
+int apexgpu_debug_invert_blocks(int device, int64_t n, const double* blocks9, double* inv9_out, int32_t* ok_out) {
+    if (n < 0 || (n > 0 && (!blocks9 || !inv9_out || !ok_out))) return APEXGPU_ERR_INVALID_INPUT;
+    if (n == 0) return APEXGPU_OK;
+    if (hipSetDevice(device) != hipSuccess) return APEXGPU_ERR_DEVICE;
+    double *din = nullptr, *dout = nullptr;
+    int* dok = nullptr;
+    int rc = APEXGPU_ERR_DEVICE;
+    if (hipMalloc((void**)&din, 9 * n * sizeof(double)) == hipSuccess && hipMalloc((void**)&dout, 9 * n * sizeof(double)) == hipSuccess &&
+        hipMalloc((void**)&dok, n * sizeof(int)) == hipSuccess &&
+        hipMemcpy(din, blocks9, 9 * n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess) {
+        apex::launch_debug_invert_blocks(n, din, dout, dok, nullptr);
+        if (hipMemcpy(inv9_out, dout, 9 * n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(ok_out, dok, n * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess)
+            rc = APEXGPU_OK;
+    }
+    if (din) (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    if (dok) (void)hipFree(dok);
+    return rc;
+}
 
 
 /* ---- SE3 pose-graph backend --------------------------------------------------------------------- */
@@ -280,7 +338,7 @@ int apexgpu_pg_set_structure(apexgpu_pg_solver* h, const uint32_t* e_from, const
                              const int64_t* pose_col, const uint8_t* fix6, double huber_delta) {
     PG_OR_FAIL;
     if (!e_from || !e_to || !meas7 || !pose_col) return APEXGPU_ERR_INVALID_INPUT;
-    return h->s->set_structure(e_from, e_to, meas7, pose_col, fix6, huber_delta);
+    return guarded([&] { return h->s->set_structure(e_from, e_to, meas7, pose_col, fix6, huber_delta); });
 }
 int apexgpu_pg_set_params(apexgpu_pg_solver* h, const double* poses7) {
     PG_OR_FAIL;
@@ -295,7 +353,7 @@ int apexgpu_pg_get_params(apexgpu_pg_solver* h, double* poses7) {
 int apexgpu_pg_cost(apexgpu_pg_solver* h, double* cost) { PG_OR_FAIL; return h->s->cost(cost); }
 int apexgpu_pg_solve_augmented(apexgpu_pg_solver* h, double lambda, double* step_out, double* grad_out) {
     PG_OR_FAIL;
-    return h->s->solve_augmented(lambda, 0, step_out, grad_out);
+    return guarded([&] { return h->s->solve_augmented(lambda, 0, step_out, grad_out); });
 }
 int apexgpu_pg_step_stats(apexgpu_pg_solver* h, double out3[3]) { PG_OR_FAIL; return h->s->step_stats(out3); }
 int apexgpu_pg_eval_step(apexgpu_pg_solver* h, double* trial_cost) { PG_OR_FAIL; return h->s->eval_step(trial_cost); }

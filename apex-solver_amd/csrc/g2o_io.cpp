@@ -18,6 +18,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
+#include <stdexcept>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -99,7 +101,20 @@ const char* apexgpu_g2o_last_error(void) { return g_g2o_err.c_str(); }
 
 void apexgpu_g2o_close(apexgpu_g2o* g) { delete g; }
 
-int apexgpu_g2o_open(const char* path, apexgpu_g2o** out) {
+static int g2o_open_impl(const char* path, apexgpu_g2o** out);
+int apexgpu_g2o_open(const char* path, apexgpu_g2o** out) {  // no exception crosses the C boundary
+    try {
+        return g2o_open_impl(path, out);
+    } catch (const std::exception& e) {
+        if (out) *out = nullptr;
+        return g2o_fail(APEXGPU_G2O_ERR_IO, std::string("IO error: out of memory while reading (") + e.what() + ")");
+    } catch (...) {
+        if (out) *out = nullptr;
+        return g2o_fail(APEXGPU_G2O_ERR_IO, "IO error: unexpected failure while reading");
+    }
+}
+}  // extern "C"
+static int g2o_open_impl(const char* path, apexgpu_g2o** out) {
     if (!path || !out) return g2o_fail(APEXGPU_G2O_ERR_IO, "IO error: null argument");
     *out = nullptr;
     FILE* f = fopen(path, "rb");
@@ -111,7 +126,8 @@ int apexgpu_g2o_open(const char* path, apexgpu_g2o** out) {
         while ((n = fread(chunk, 1, sizeof chunk, f)) > 0) buf.append(chunk, n);
         fclose(f);
     }
-    apexgpu_g2o* g = new apexgpu_g2o();
+    std::unique_ptr<apexgpu_g2o> gown(new apexgpu_g2o());
+    apexgpu_g2o* g = gown.get();
     std::unordered_set<int64_t> seen3, seen2;
     std::vector<Tok> parts;
     const char* p = buf.data();
@@ -229,10 +245,12 @@ int apexgpu_g2o_open(const char* path, apexgpu_g2o** out) {
         }
         // unknown tags are skipped silently (g2o.rs:268-270)
     }
-    if (rc != 0) { delete g; return rc; }
-    *out = g;
+    if (rc != 0) return rc;
+    *out = gown.release();
     return 0;
 }
+
+extern "C" {
 
 int apexgpu_g2o_sizes(const apexgpu_g2o* g, int64_t* n_vertices_se3, int64_t* n_edges_se3, int64_t* n_vertices_se2,
                       int64_t* n_edges_se2) {

@@ -196,7 +196,7 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
     timer_.end(kPgFactor, stream_);
     if (failed) return fail(kSingularMatrix, "Cholesky factorization failed (matrix may be singular)");
     timer_.begin(kPgTriSolve, stream_);
-    tp_.solve(rhs_, d_, work_);
+    HIP_TRY(tp_.solve(rhs_, d_, work_));
     if (scaled_) launch_vec_mul(n_pad_, d_, scale_, d_, stream_);  // apply_inverse_scaling: step = D y
     timer_.end(kPgTriSolve, stream_);
     have_step_ = true;

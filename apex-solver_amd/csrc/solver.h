@@ -81,6 +81,7 @@ class Solver : public LmBackend {
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void use_row_schur(int v) { use_rows_ = v != 0; if (v) rows_form_ = v; }
+    bool has_structure() const { return have_structure_; }
     void set_rows_debug(int v) { rows_dbg_ = v; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void set_dist_factor(bool on) { dist_factor_ = on; }   // before set_structure
@@ -140,6 +141,8 @@ class Solver : public LmBackend {
     int64_t n_pairs_ = 0, n_present_ = 0;
     // shard
     int rank_ = 0, world_ = 1;
+    int pad_rank_ = 0;          // rank that writes the identity on the padding rows of the last tile (assemble_local)
+    std::string comm_err_;      // text of the last failed collective inside TilePlan's hooks
     int64_t lm_lo_ = 0, lm_hi_ = 0;  // landmark range owned by this rank
     ncclComm* comm_ = nullptr;
 

@@ -21,6 +21,15 @@ namespace apex {
         if (_rc != kOk) return _rc;                           \
     } while (0)
 
+#ifdef APEX_WITH_RCCL
+// every collective's return code is surfaced as APEXGPU_ERR_DEVICE with RCCL's own text
+#define NCCL_TRY(expr)                                                                                      \
+    do {                                                                                                    \
+        ncclResult_t _r = (expr);                                                                           \
+        if (_r != ncclSuccess) return fail(kDeviceError, std::string("RCCL error in " #expr ": ") + ncclGetErrorString(_r)); \
+    } while (0)
+#endif
+
 template <typename T>
 static hipError_t dev_alloc(T** p, size_t n) {
     return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
@@ -95,8 +104,12 @@ int Solver::comm_init(int world, int rank, const void* unique_id128) {
     if (r != ncclSuccess) return fail(kDeviceError, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
     comm_ = reinterpret_cast<ncclComm*>(c);
     TilePlan::Comm tc;
-    tc.sum = [c](double* buf, size_t n, hipStream_t st) { ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, c, st); };
-    tc.max_int = [c](int* buf, size_t n, hipStream_t st) { ncclAllReduce(buf, buf, n, ncclInt, ncclMax, c, st); };
+    auto note = [this](ncclResult_t r, const char* what) {
+        if (r != ncclSuccess) comm_err_ = std::string("RCCL error in ") + what + ": " + ncclGetErrorString(r);
+        return r == ncclSuccess;
+    };
+    tc.sum = [c, note](double* buf, size_t n, hipStream_t st) { return note(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, c, st), "all-reduce (sum)"); };
+    tc.max_int = [c, note](int* buf, size_t n, hipStream_t st) { return note(ncclAllReduce(buf, buf, n, ncclInt, ncclMax, c, st), "all-reduce (max)"); };
     tp_.set_comm(std::move(tc));
     return kOk;
 #else
@@ -193,8 +206,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         tp_.set_partition(0, dist_selftest_);
         tp_.set_own_all(true);
         TilePlan::Comm tc;
-        tc.sum = [](double*, size_t, hipStream_t) {};
-        tc.max_int = [](int*, size_t, hipStream_t) {};
+        tc.sum = [](double*, size_t, hipStream_t) { return true; };
+        tc.max_int = [](int*, size_t, hipStream_t) { return true; };
         tp_.set_comm(std::move(tc));
     }
     {
@@ -243,8 +256,13 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
             tree_shard_ = true;
         }
     }
+    pad_rank_ = 0;
     if (tree_shard_) {  // lambda on a camera's diagonal block: by the owner of its column, rank 0 for the shared top
         const std::vector<int> owner = tp_.preview_owners(nt_, present);
+        // The identity on the padding rows of the last tile follows the same rule: the elimination tree can be a forest
+        // (disconnected covisibility), the last column is then a subtree root below the shared top, and its owner's
+        // copy of the diagonal tile is the only one that is ever factorised.
+        pad_rank_ = owner[nt_ - 1] >= 0 ? owner[nt_ - 1] : 0;
         std::vector<uint8_t> mask(n_cam_);
         for (int64_t ci = 0; ci < n_cam_; ++ci) {
             const int o = owner[ci / cpt];
@@ -563,14 +581,14 @@ int Solver::get_params(double* poses, double* intr, double* points) {
         int64_t mine[2] = {lm_lo_, lm_hi_};
         int64_t* d_rng = reinterpret_cast<int64_t*>(scal_ + 8);
         HIP_TRY(hipMemcpyAsync(d_rng + 2 * rank_, mine, sizeof mine, hipMemcpyHostToDevice, stream_));
-        ncclAllGather(d_rng + 2 * rank_, d_rng, 2 * sizeof(int64_t), ncclChar, reinterpret_cast<ncclComm_t>(comm_), stream_);
+        NCCL_TRY(ncclAllGather(d_rng + 2 * rank_, d_rng, 2 * sizeof(int64_t), ncclChar, reinterpret_cast<ncclComm_t>(comm_), stream_));
         std::vector<int64_t> rng(2 * world_);
         HIP_TRY(hipMemcpyAsync(rng.data(), d_rng, rng.size() * 8, hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         for (int r = 0; r < world_; ++r) {
             const int64_t a = rng[2 * r], b = rng[2 * r + 1];
-            if (b > a) ncclBroadcast(pts_[cur_] + 3 * a, pts_[cur_] + 3 * a, 3 * (b - a), ncclDouble, r,
-                                     reinterpret_cast<ncclComm_t>(comm_), stream_);
+            if (b > a) NCCL_TRY(ncclBroadcast(pts_[cur_] + 3 * a, pts_[cur_] + 3 * a, 3 * (b - a), ncclDouble, r,
+                                              reinterpret_cast<ncclComm_t>(comm_), stream_));
         }
     }
 #endif
@@ -597,9 +615,10 @@ int Solver::cost_of(int which, double* out) {
     launch_cost(view(which), partial_, n_partial_, scal_, stream_);
 #ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1)
-        ncclAllReduce(scal_, scal_, 1, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
+        NCCL_TRY(ncclAllReduce(scal_, scal_, 1, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_));
 #endif
     stage_end(kStCost);
+    HIP_TRY(hipGetLastError());
     double ss = 0.0;
     HIP_TRY(hipMemcpyAsync(&ss, scal_, sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -627,23 +646,23 @@ int Solver::assemble(double lambda, double diag_extra, bool for_factor) {
         // A distributed factorisation sums the shared top tiles itself, after the local levels, and a rank's local
         // levels read its own columns only: every column's tiles are reduced to their owner (tile_plan.h).
         const size_t te = (size_t)kNB * kNB;
-        ncclGroupStart();
+        NCCL_TRY(ncclGroupStart());
         if (for_factor && tp_.distributed() && tree_shard_) {
             // tree sharding: a rank's landmarks are exactly those that touch its columns -- its tiles are complete
         } else if (for_factor && tp_.distributed()) {
             for (int o = 0; o < tp_.part_world(); ++o) {
                 const std::pair<int64_t, int64_t> rg = tp_.owner_slot_range(o);
                 if (rg.second > 0)
-                    ncclReduce(tp_.tiles() + (size_t)rg.first * te, tp_.tiles() + (size_t)rg.first * te, (size_t)rg.second * te,
-                               ncclDouble, ncclSum, o, c, stream_);
+                    NCCL_TRY(ncclReduce(tp_.tiles() + (size_t)rg.first * te, tp_.tiles() + (size_t)rg.first * te, (size_t)rg.second * te,
+                                        ncclDouble, ncclSum, o, c, stream_));
             }
         } else {
-            ncclAllReduce(tp_.tiles(), tp_.tiles(), (size_t)tp_.n_touched_slots() * te, ncclDouble, ncclSum, c, stream_);
+            NCCL_TRY(ncclAllReduce(tp_.tiles(), tp_.tiles(), (size_t)tp_.n_touched_slots() * te, ncclDouble, ncclSum, c, stream_));
         }
-        ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
-        ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
-        ncclAllReduce(flags_, flags_, 1, ncclInt, ncclMax, c, stream_);  // a singular landmark block anywhere fails the solve on every rank
-        ncclGroupEnd();
+        NCCL_TRY(ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_));
+        NCCL_TRY(ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_));
+        NCCL_TRY(ncclAllReduce(flags_, flags_, 1, ncclInt, ncclMax, c, stream_));  // a singular landmark block anywhere fails the solve on every rank
+        NCCL_TRY(ncclGroupEnd());
         stage_end(kStAllReduce);
     }
 #endif
@@ -660,7 +679,8 @@ int Solver::assemble_local(double lambda, double diag_extra) {
     HIP_TRY(hipMemsetAsync(g_c_, 0, n_c_pad_ * sizeof(double), stream_));
     HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
     // identity on the padding rows of the last tile (rank 0 only: the all-reduce sums the ranks)
-    tp_.add_diag((int)n_c_, 0.0, rank_ == 0 ? 1.0 : 0.0);
+    // (tree sharding: by the owner of the last tile column, whose tiles are never summed -- pad_rank_)
+    tp_.add_diag((int)n_c_, 0.0, rank_ == pad_rank_ ? 1.0 : 0.0);
     stage_end(kStAssembleCam);
     stage_begin(kStAssembleLm);
     launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_);
@@ -677,7 +697,7 @@ int Solver::assemble_local(double lambda, double diag_extra) {
     else
         launch_schur_scatter(dc_, v, tm, tasks_, n_tasks_, hinv_, g_l_, g_red_, stream_);
     stage_end(kStScatter);
-    return kOk;
+    return check_hip(hipGetLastError(), "assembly kernels");
 }
 
 // after the exchange: the reduced system in the scaled variables when Jacobi scaling is on (linear, so it also
@@ -694,14 +714,18 @@ int Solver::assemble_finish() {
 
 int Solver::cholesky_attempt(int* failed_at) {
     stage_begin(kStFactor);
-    HIP_TRY(tp_.factor(failed_at, g_red_, pcg_buf_));  // the forward sweep for g_red rides along
+    const hipError_t fe = tp_.factor(failed_at, g_red_, pcg_buf_);  // the forward sweep for g_red rides along
+    if (fe != hipSuccess && !comm_err_.empty()) return fail(kDeviceError, comm_err_);
+    HIP_TRY(fe);
     stage_end(kStFactor);
     return kOk;
 }
 
 int Solver::tri_solve() {
     stage_begin(kStTriSolve);
-    tp_.solve(g_red_, dcam_, pcg_buf_);
+    const hipError_t se = tp_.solve(g_red_, dcam_, pcg_buf_);
+    if (se != hipSuccess && !comm_err_.empty()) return fail(kDeviceError, comm_err_);
+    HIP_TRY(se);
     stage_end(kStTriSolve);
     return kOk;
 }
@@ -769,12 +793,12 @@ int Solver::assemble_implicit(double lambda) {
     if (comm_ && world_ > 1) {
         stage_begin(kStAllReduce);
         ncclComm_t c = reinterpret_cast<ncclComm_t>(comm_);
-        ncclGroupStart();
-        ncclAllReduce(sd_, sd_, (size_t)n_cam_ * dc_ * dc_, ncclDouble, ncclSum, c, stream_);
-        ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
-        ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_);
-        ncclAllReduce(flags_, flags_, 1, ncclInt, ncclMax, c, stream_);  // a singular landmark block anywhere fails the solve on every rank
-        ncclGroupEnd();
+        NCCL_TRY(ncclGroupStart());
+        NCCL_TRY(ncclAllReduce(sd_, sd_, (size_t)n_cam_ * dc_ * dc_, ncclDouble, ncclSum, c, stream_));
+        NCCL_TRY(ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_));
+        NCCL_TRY(ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_));
+        NCCL_TRY(ncclAllReduce(flags_, flags_, 1, ncclInt, ncclMax, c, stream_));  // a singular landmark block anywhere fails the solve on every rank
+        NCCL_TRY(ncclGroupEnd());
         stage_end(kStAllReduce);
     }
 #endif
@@ -800,10 +824,10 @@ int Solver::implicit_matvec(const double* x, double lam_local, double* y, bool r
     launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xin, lam_local, y, stream_);
 #ifdef APEX_WITH_RCCL
     if (reduce && comm_ && world_ > 1)
-        ncclAllReduce(y, y, (size_t)n_c_, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
+        NCCL_TRY(ncclAllReduce(y, y, (size_t)n_c_, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_));
 #endif
     if (scaled_) launch_vec_mul(n_c_, y, cam_scale_, y, stream_);
-    return kOk;
+    return check_hip(hipGetLastError(), "implicit_matvec");
 }
 
 int Solver::implicit_pcg_solve(double lambda) {
@@ -824,7 +848,8 @@ int Solver::implicit_pcg_solve(double lambda) {
     const double lam_local = (rank_ == 0) ? lambda : 0.0;  // the all-reduce sums the ranks' partial S p
     int it = 0;
     for (; it < cg_max_iter_; ++it) {
-        implicit_matvec(p, lam_local, ap, true);
+        const int mrc = implicit_matvec(p, lam_local, ap, true);
+        if (mrc != kOk) return mrc;
         launch_dot2(n, p, ap, p, ap, partial_, n_partial_, sc, stream_);
         double pap = 0.0;
         HIP_TRY(hipMemcpyAsync(&pap, sc, sizeof pap, hipMemcpyDeviceToHost, stream_));
@@ -864,6 +889,7 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     if (scaled_) launch_vec_mul(n_c_, dcam_, cam_scale_, dcam_, stream_);  // apply_inverse_scaling: dc = D_c y
     launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_);
     stage_end(kStBackSub);
+    HIP_TRY(hipGetLastError());
     have_step_ = true;
     return export_step(step_out, grad_out);
 }
@@ -995,7 +1021,7 @@ int Solver::step_stats(double out3[3]) {
     launch_step_stats(3 * n_pt_, g_l_, dl_, last_lambda_, scaled_ ? pt_scale_ : nullptr, partial_, n_partial_, scal_ + 3, stream_);
 #ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1)  // landmark part is sharded, camera part replicated
-        ncclAllReduce(scal_ + 3, scal_ + 3, 3, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
+        NCCL_TRY(ncclAllReduce(scal_ + 3, scal_ + 3, 3, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_));
 #endif
     stage_end(kStStats);
     double h[6];
@@ -1052,7 +1078,7 @@ int Solver::parameter_norm(double* out) {
     launch_sumsq(3 * (lm_hi_ - lm_lo_), pts_[cur_] + 3 * lm_lo_, partial_, n_partial_, scal_ + 11, stream_);
 #ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1)
-        ncclAllReduce(scal_ + 11, scal_ + 11, 1, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
+        NCCL_TRY(ncclAllReduce(scal_ + 11, scal_ + 11, 1, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_));
 #endif
     double h[3];
     HIP_TRY(hipMemcpyAsync(h, scal_ + 9, sizeof h, hipMemcpyDeviceToHost, stream_));
@@ -1084,7 +1110,7 @@ int Solver::column_norms_sq_device() {
     launch_column_norms_sq(dc_, v, cam_scale_, pt_scale_, stream_);
 #ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1)  // every rank sees all cameras but only its own landmarks
-        ncclAllReduce(cam_scale_, cam_scale_, (size_t)n_c_, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_);
+        NCCL_TRY(ncclAllReduce(cam_scale_, cam_scale_, (size_t)n_c_, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_));
 #endif
     return kOk;
 }

@@ -44,9 +44,9 @@ class TilePlan {
     std::string build(int nt, const std::vector<uint8_t>& present, hipStream_t stream);
 
     // ---- distributed factorisation ----
-    struct Comm {  // in-place reductions over the ranks, enqueued on `stream`
-        std::function<void(double* buf, size_t n, hipStream_t stream)> sum;
-        std::function<void(int* buf, size_t n, hipStream_t stream)> max_int;
+    struct Comm {  // in-place reductions over the ranks, enqueued on `stream`; false = the collective failed
+        std::function<bool(double* buf, size_t n, hipStream_t stream)> sum;
+        std::function<bool(int* buf, size_t n, hipStream_t stream)> max_int;
     };
     void set_partition(int rank, int world) { part_rank_ = rank; part_world_ = world; }  // before build()
     // self-test: cut the tree for `world` ranks but let THIS rank own every subtree -- the distributed schedule
@@ -98,8 +98,9 @@ class TilePlan {
     // solve(rhs, x, work) with the same pointers then only runs the backward sweep.
     hipError_t factor(int* failed_at, const double* rhs = nullptr, double* work = nullptr);
     void enable_fused_forward(bool on) { fuse_forward_ = on; }
-    // x = (L L^T)^-1 rhs ; work: 2*n_pad doubles ; all on the plan's stream, no sync
-    void solve(const double* rhs, double* x, double* work);
+    // x = (L L^T)^-1 rhs ; work: 2*n_pad doubles ; all on the plan's stream, no sync.  hipErrorUnknown: a collective of
+    // the distributed sweeps failed (the communicator's own message is with the caller)
+    hipError_t solve(const double* rhs, double* x, double* work);
     // y = A x on the UNFACTORED tiles (deterministic two-pass symmetric product), no sync
     void sym_matvec(const double* x, double* y);
     // Jacobi-PCG on the UNFACTORED tiles; work: 6*n_pad doubles; syncs once per iteration

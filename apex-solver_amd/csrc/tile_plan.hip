@@ -604,9 +604,9 @@ hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
         top_slot_ranges(rg);
         const size_t te = (size_t)kNB * kNB;
         for (int i = 0; i < 2; ++i)
-            if (rg[i].second > 0) comm_.sum(tiles_ + (size_t)rg[i].first * te, (size_t)rg[i].second * te, stream_);
+            if (rg[i].second > 0 && !comm_.sum(tiles_ + (size_t)rg[i].first * te, (size_t)rg[i].second * te, stream_)) return hipErrorUnknown;
         factor_phase(1);
-        comm_.max_int(flag_, 1, stream_);  // a failed pivot anywhere fails the factorisation everywhere
+        if (!comm_.max_int(flag_, 1, stream_)) return hipErrorUnknown;  // a failed pivot anywhere fails the factorisation everywhere
         int f = 0;
         hipError_t e = hipMemcpyAsync(&f, flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
         if (e != hipSuccess) return e;
@@ -625,19 +625,20 @@ hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
     return e;
 }
 
-void TilePlan::solve(const double* rhs, double* x, double* work) {
+hipError_t TilePlan::solve(const double* rhs, double* x, double* work) {
     if (distributed()) {
-        if (!comm_.sum) return;
+        if (!comm_.sum) return hipErrorNotInitialized;
         solve_phase(0, rhs, x, work);
-        comm_.sum(exch_, (size_t)n_pad(), stream_);
+        if (!comm_.sum(exch_, (size_t)n_pad(), stream_)) return hipErrorUnknown;
         solve_phase(1, rhs, x, work);
-        comm_.sum(exch_, (size_t)n_pad(), stream_);
+        if (!comm_.sum(exch_, (size_t)n_pad(), stream_)) return hipErrorUnknown;
         solve_phase(2, rhs, x, work);
-        return;
+        return hipGetLastError();
     }
     const bool backward_only = fwd_rhs_ != nullptr && rhs == fwd_rhs_ && work == fwd_work_;
     fwd_rhs_ = nullptr;  // one solve per fused sweep: the backward sweep consumes yvec's partner bvec
     if (!run_graph(backward_only ? 2 : 1, rhs, x, work)) enqueue_solve(rhs, x, work, backward_only);
+    return hipGetLastError();
 }
 
 void TilePlan::sym_matvec(const double* x, double* y) {

@@ -12,8 +12,10 @@ accept/reject bookkeeping -- exactly the body of optimize_with_mode's loop
 (src/optimizer/levenberg_marquardt.rs:857-1029).  Inputs are resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line.
 
-For N > 1 launch with torch.distributed.run (one process per GPU); landmarks and the Cholesky of S are
-distributed along the elimination tree (a rank's column tiles are complete locally; the top tiles, two
+For N > 1 the driver launches this file under torch.distributed.run (one process per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment).  Started plainly as `python bench.py --gpus N` (no WORLD_SIZE) it spawns that
+launcher itself as a child process -- before anything in this process touches the GPU -- and exits with its code.
+Landmarks and the Cholesky of S are distributed along the elimination tree (a rank's column tiles are complete locally; the top tiles, two
 n-vectors and the reduced gradient are all-reduced over RCCL inside the library), so total work is fixed
 ("scaling": "strong").
 """
@@ -196,15 +198,37 @@ def bench_pose_graph(args):
         dist.destroy_process_group()
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this very command under torch.distributed.run as a
+    CHILD process (never an exec: this process may not replace itself once a GPU runtime is loaded, and it has not
+    touched the GPU yet -- torch.cuda.device_count() does not initialise it) and pass its exit code on."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s)")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
     if args.workload.startswith("sphere"):
         return bench_pose_graph(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
     import torch.distributed as dist

@@ -182,6 +182,11 @@ int apexgpu_get_jacobian_blocks(apexgpu_solver* h, double* jc_out, double* jl_ou
  * column order, for the last lambda; either may be NULL */
 int apexgpu_get_schur(apexgpu_solver* h, double* S_out, double* gred_out);
 int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out /* n_pt*9 */, double* gl_out /* n_pt*3 */);
+/* Parity probe of row A9: invert_landmark_blocks_with_lambda(.., 0.0) (explicit_schur.rs:365-442) -- the eigenvalue gate
+ * (min_ev < 1e-12 -> + (1e-6 + max_ev 1e-6) I; max_ev / min_ev > 1e10 -> + max_ev 1e-6 I; else plain inverse) exactly as
+ * the landmark-reduce kernel applies it, run on GPU `device` over n caller-supplied symmetric 3x3 blocks (row-major).
+ * ok_out[i] = 0 where the (regularised) block has a zero determinant (LinAlgError::SingularMatrix). */
+int apexgpu_debug_invert_blocks(int device, int64_t n, const double* blocks9, double* inv9_out, int32_t* ok_out);
 /* y = S x at the current parameters through both implementations of the reduced camera matrix: the explicit tiles
  * (compute_schur_complement, explicit_schur.rs:771-925) and the matrix-free operator (apply_schur_operator_fast,
  * implicit_schur.rs:163-251).  x_in and the outputs have 9 n_cam entries in the reference's camera-side column
@@ -189,6 +194,9 @@ int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out /* n_pt*9 */
 int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, double* y_explicit, double* y_implicit);
 
 /* Implementation switches (defaults in parentheses), for A/B tests and profiling:
+ * Switches that shape what apexgpu_set_structure builds or what the captured hipGraphs hold ("schur_rows",
+ * "potrf_lookahead", "update_overlap", "fused_forward", "nested_dissection", "dist_factor", "tree_sharding",
+ * "dist_selftest") return APEXGPU_ERR_INVALID_STATE once the structure is set.
  *   "schur_rows" (2)  Schur reduction in the LDS row form without global atomics: 2 = one lane per observation,
  *                     block rows walked in a per-lane rotated order (k_schur_rows2), 1 = one lane per camera pair
  *                     (k_schur_rows); set before set_structure;

@@ -14,6 +14,11 @@ from apex_solver_amd.solver import (GpuSchurComplementSolver, LevenbergMarquardt
                                     OptimizationStatus, OptimizationType, Problem, SchurVariant)
 
 pytestmark = pytest.mark.gpu
+# Forward bound on |step - oracle step| / |oracle step| wherever the two are compared.  The north star's 1e-10 is met where
+# cond(S) <= ~1e5 (pose graphs, well-damped systems); on gauge-free BA systems (cond 1e9..1e10) two correct Choleskys of
+# the same S differ by up to ~1e-9, so the bound that every case must meet is 1e-8 -- four orders tighter than the
+# eps*cond(S) allowance it replaces -- NEXT TO a 1e-13 normwise backward error on the system actually solved.
+STEP_FORWARD_BOUND = 1e-8
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ba*.npz")))
 
 
@@ -80,10 +85,11 @@ def test_golden_fixture_iterations(path):
                     step=rel(step, g[f"it{it}_step"]))
         print(os.path.basename(path), "iter", it, {k: f"{v:.1e}" for k, v in errs.items()})
         assert errs["grad"] < 1e-12 and errs["S"] < 1e-12 and errs["gred"] < 1e-11
-        # forward error of two Cholesky codes on the same S: ~eps*cond(S) (cond is 1e9..1e10 here:
-        # the gauge is only damped, explicit_schur.rs keeps the fixed camera's columns)
+        # The step is held to (i) a normwise backward error of 1e-13 on S dc = g_red and (ii) a FIXED forward bound of
+        # 1e-8 against the fixture (two correct fp64 Choleskys of the same S differ by ~eps*cond(S); cond is 1e9..1e10
+        # here because the gauge is only damped -- the measured value is printed above and recorded in DESIGN.md §2)
         Sg = g[f"it{it}_S"]
-        assert errs["step"] < max(1e-10, 20 * np.finfo(float).eps * np.linalg.cond(Sg)), errs
+        assert errs["step"] < STEP_FORWARD_BOUND, errs
         nc = prob.layout.cam_dof
         bwd = np.linalg.norm(Sg @ step[:nc] - g[f"it{it}_gred"]) / (np.linalg.norm(Sg, 2) * np.linalg.norm(step[:nc]) + np.linalg.norm(g[f"it{it}_gred"]))
         assert bwd < 1e-13, bwd
@@ -140,10 +146,9 @@ def test_one_iteration_vs_oracle(oracle, mode, shape):
     nc = prob.layout.cam_dof
     bwd = np.linalg.norm(oS @ step[:nc] - ogred) / (np.linalg.norm(oS, 2) * np.linalg.norm(step[:nc]) + np.linalg.norm(ogred))
     assert bwd < 1e-13
-    # ... and the step agrees with the oracle's to the north-star tolerance scaled by what the
-    # conditioning of S allows (1 ulp of noise on S moves dc by ~eps*cond(S))
-    tol = max(1e-10, 20 * np.finfo(float).eps * np.linalg.cond(oS))
-    assert errs["step"] < tol, (errs["step"], tol)
+    # ... and the step agrees with the oracle's within the fixed forward bound (north star: 1e-10 where cond(S) allows)
+    print("step vs oracle", errs["step"], "cond(S)", np.linalg.cond(oS), "meets 1e-10:", errs["step"] < 1e-10)
+    assert errs["step"] < STEP_FORWARD_BOUND, errs["step"]
     # trial point
     o.apply_step(ostep, 1.0)
     assert s.eval_step() == pytest.approx(o.residuals()[0], rel=1e-9)
@@ -317,7 +322,9 @@ def test_ragged_landmarks(oracle, mode):
                 gred=rel(gred, ogred), step=rel(step, ostep))
     print(mode, {k: f"{v:.1e}" for k, v in errs.items()}, s.info())
     assert errs["r"] < 1e-12 and errs["grad"] < 1e-12 and errs["S"] < 1e-12 and errs["gred"] < 1e-10
-    assert errs["step"] < max(1e-10, 20 * np.finfo(float).eps * np.linalg.cond(oS))
+    nc = prob.layout.cam_dof
+    bwd = np.linalg.norm(oS @ step[:nc] - ogred) / (np.linalg.norm(oS, 2) * np.linalg.norm(step[:nc]) + np.linalg.norm(ogred))
+    assert bwd < 1e-13 and errs["step"] < STEP_FORWARD_BOUND, (bwd, errs["step"])
     s.close()
 
 
@@ -567,8 +574,10 @@ def test_jacobi_scaling_one_iteration_vs_oracle(oracle, mode):
     errs = dict(grad=rel(s.get_gradient(), ogs), S=rel(S, oS), gred=rel(gred, ogred), step=rel(y, oy))
     print(mode, {k: f"{v:.1e}" for k, v in errs.items()})
     assert errs["grad"] < 1e-12 and errs["S"] < 1e-12 and errs["gred"] < 1e-10
-    tol = max(1e-10, 20 * np.finfo(float).eps * np.linalg.cond(oS))
-    assert errs["step"] < tol, (errs["step"], tol)
+    tol = STEP_FORWARD_BOUND
+    nc = prob.layout.cam_dof
+    bwd = np.linalg.norm(oS @ y[:nc] - ogred) / (np.linalg.norm(oS, 2) * np.linalg.norm(y[:nc]) + np.linalg.norm(ogred))
+    assert bwd < 1e-13 and errs["step"] < tol, (bwd, errs["step"], tol)
     # compute_step_generic (levenberg_marquardt.rs:746-760): |scaled gradient|, |unscaled step|,
     # predicted reduction from the unscaled step and the scaled gradient
     ostep = oy * scal
