@@ -34,8 +34,8 @@ struct BAView {
 
 // Per-landmark record written by k_landmark_reduce and read by the camera-major kernels: everything a
 // camera-major gather needs from a landmark sits in ONE 128-byte line instead of three arrays.
-constexpr int kLmStride = 16;  // doubles: Hll^-1 (9, row-major) | g_l (3) | point (3) | pad
-constexpr int kLmG = 9, kLmPt = 12;
+constexpr int kLmStride = 16;  // doubles: Hll^-1 (9, row-major) | point (3) | g_l (3) | pad -- what the pair kernels need
+constexpr int kLmPt = 9, kLmG = 12;  // (Hll^-1 and the point) is the first 96 bytes: six 16-byte loads
 constexpr int kLmuStride = 8;  // matrix-free Schur operator: {point(3), -, u_l(3), -} per landmark, 64 bytes
 
 // Lower-triangular tile map of the reduced camera matrix S.

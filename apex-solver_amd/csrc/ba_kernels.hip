@@ -464,9 +464,9 @@ __global__ __launch_bounds__(kRowThreads) void k_schur_rows(BAView v, TileMap tm
                 double Hi[9], pw[3];
                 {   // Hll^-1 and the point from the landmark record: aligned 16-byte loads of one line
                     const double2* q = reinterpret_cast<const double2*>(hinv + kLmStride * (size_t)l);
-                    const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a6 = q[6], a7 = q[7];
+                    const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
                     Hi[0] = a0.x; Hi[1] = a0.y; Hi[2] = a1.x; Hi[3] = a1.y; Hi[4] = a2.x; Hi[5] = a2.y; Hi[6] = a3.x; Hi[7] = a3.y;
-                    Hi[8] = a4.x; pw[0] = a6.x; pw[1] = a6.y; pw[2] = a7.x;
+                    Hi[8] = a4.x; pw[0] = a4.y; pw[1] = a5.x; pw[2] = a5.y;
                 }
                 const double2 uvi = v.o_uv[i_s];
                 double r[2], Jc[2][DC], Jl[2][3];
@@ -600,9 +600,9 @@ __global__ __launch_bounds__(kRow2Threads) void k_schur_rows2(BAView v, TileMap 
             double Hi[9];
             {
                 const double2* q = reinterpret_cast<const double2*>(hinv + kLmStride * (size_t)l);
-                const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a6 = q[6], a7 = q[7];
+                const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
                 Hi[0] = a0.x; Hi[1] = a0.y; Hi[2] = a1.x; Hi[3] = a1.y; Hi[4] = a2.x; Hi[5] = a2.y; Hi[6] = a3.x; Hi[7] = a3.y;
-                Hi[8] = a4.x; pw[0] = a6.x; pw[1] = a6.y; pw[2] = a7.x;
+                Hi[8] = a4.x; pw[0] = a4.y; pw[1] = a5.x; pw[2] = a5.y;
             }
             double r[2], Jc[2][DC], Jl[2][3];
             linearize_obs<DC>(cam_i, pw, uvi.x, uvi.y, v.huber_delta, r, Jc, Jl);

@@ -1,6 +1,9 @@
 // capi.cpp -- extern "C" surface declared in include/apexgpu.h.
 #include "../../include/apexgpu.h"
 
+#include <string.h>
+
+#include <algorithm>
 #include <exception>
 #include <new>
 #include <string>
@@ -227,6 +230,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "update_overlap") { h->s->enable_overlap(value != 0); if (value > 1) h->s->set_overlap_min(value); }
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
+    else if (n == "schur_form") h->s->use_row_schur(value);   /* alias of "schur_rows": 3 pairs on MFMA (default), 2 / 1 LDS rows, 0 global atomics */
     else if (n == "rows_debug") h->s->set_rows_debug(value);
     else if (n == "dist_factor") h->s->set_dist_factor(value != 0);
     else if (n == "tree_sharding") h->s->set_tree_sharding(value != 0);
@@ -253,7 +257,7 @@ int apexgpu_info(apexgpu_solver* h, double info[16]) {
     info[9] = (double)a; info[10] = (double)b; info[11] = (double)c;
     info[12] = h->s->dist_top_columns(); info[13] = h->s->dist_local_fraction();
     info[14] = h->s->tree_sharded() ? 1.0 : 0.0;
-    info[15] = 0;
+    info[15] = h->s->schur_form();
     return APEXGPU_OK;
 }
 
@@ -287,6 +291,51 @@ int apexgpu_shard_range(int64_t n_pt, int64_t n_obs, const uint32_t* pt_idx, int
     });
 }
 int apexgpu_set_shard(apexgpu_solver* h, int rank, int world) { H_OR_FAIL; return h->s->set_shard(rank, world); }
+
+// Host arithmetic only (no device is touched): the sorted camera-pair lists k_schur_pairs consumes (csrc/schur_pairs.h)
+// for the observation list (cam_idx, pt_idx), with the caller's camera order and a dense tile map (slot of tile (I, J),
+// I >= J, = I (I + 1) / 2 + J).  Two-call pattern: with every output NULL the sizes come back in counts[4] = {slots,
+// chunks, blocks, tasks}; o_index_out[n_obs] receives the landmark-major position -> caller's observation index map that
+// the records' i / j refer to.  Lets CPU tests replay the kernel's bookkeeping (block boundaries, padding, flush points).
+int apexgpu_debug_pair_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc, const uint32_t* cam_idx, const uint32_t* pt_idx,
+                             int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
+                             int32_t* tasks2_out, int32_t* o_index_out) {
+    if (n_cam <= 0 || n_pt <= 0 || n_obs < 0 || (dc != 6 && dc != 9) || !cam_idx || !pt_idx || !counts) return APEXGPU_ERR_INVALID_INPUT;
+    return guarded([&]() -> int {
+        for (int64_t i = 0; i < n_obs; ++i)
+            if (cam_idx[i] >= (uint64_t)n_cam || pt_idx[i] >= (uint64_t)n_pt) return APEXGPU_ERR_INVALID_INPUT;
+        std::vector<int> pt_ptr(n_pt + 1, 0), order(n_obs);
+        for (int64_t i = 0; i < n_obs; ++i) pt_ptr[pt_idx[i] + 1]++;
+        for (int64_t l = 0; l < n_pt; ++l) pt_ptr[l + 1] += pt_ptr[l];
+        { std::vector<int> fill(pt_ptr.begin(), pt_ptr.end() - 1); for (int64_t i = 0; i < n_obs; ++i) order[fill[pt_idx[i]]++] = (int)i; }
+        for (int64_t l = 0; l < n_pt; ++l)
+            std::stable_sort(order.begin() + pt_ptr[l], order.begin() + pt_ptr[l + 1], [&](int a, int b) { return cam_idx[a] < cam_idx[b]; });
+        std::vector<uint32_t> o_cam(n_obs), o_pt(n_obs);
+        for (int64_t k = 0; k < n_obs; ++k) { o_cam[k] = cam_idx[order[k]]; o_pt[k] = pt_idx[order[k]]; }
+        std::vector<int> cam_ptr(n_cam + 1, 0), cam_obs(n_obs);
+        for (int64_t k = 0; k < n_obs; ++k) cam_ptr[o_cam[k] + 1]++;
+        for (int64_t c = 0; c < n_cam; ++c) cam_ptr[c + 1] += cam_ptr[c];
+        { std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1); for (int64_t k = 0; k < n_obs; ++k) cam_obs[fill[o_cam[k]]++] = (int)k; }
+        const int nt = (int)((n_cam * dc + apex::kNB - 1) / apex::kNB);
+        std::vector<int> slot((size_t)nt * nt, -1);
+        for (int I = 0; I < nt; ++I) for (int J = 0; J <= I; ++J) slot[(size_t)I * nt + J] = I * (I + 1) / 2 + J;
+        std::vector<int> ext(n_cam);
+        for (int64_t c = 0; c < n_cam; ++c) ext[c] = (int)c;
+        apex::PairLists pl;
+        apex::build_pair_lists(dc, nt, slot.data(), n_cam, ext.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(), cam_obs.data(), &pl);
+        counts[0] = (int64_t)pl.recs.size(); counts[1] = (int64_t)pl.chunks.size(); counts[2] = (int64_t)pl.blocks.size(); counts[3] = (int64_t)pl.tasks.size();
+        if (recs4_out) memcpy(recs4_out, pl.recs.data(), pl.recs.size() * sizeof(apex::PairRec));
+        if (chunks2_out) memcpy(chunks2_out, pl.chunks.data(), pl.chunks.size() * sizeof(apex::PairChunk));
+        if (blocks4_out)
+            for (size_t b = 0; b < pl.blocks.size(); ++b) {
+                blocks4_out[4 * b] = pl.blocks[b].dst; blocks4_out[4 * b + 1] = pl.blocks[b].ci; blocks4_out[4 * b + 2] = pl.blocks[b].cj;
+                blocks4_out[4 * b + 3] = pl.blocks[b].flags;
+            }
+        if (tasks2_out) memcpy(tasks2_out, pl.tasks.data(), pl.tasks.size() * sizeof(apex::PairTask));
+        if (o_index_out) for (int64_t k = 0; k < n_obs; ++k) o_index_out[k] = order[k];
+        return APEXGPU_OK;
+    });
+}
 
 // Parity probe: the device's eigenvalue-gated 3x3 inverse (invert_landmark_blocks_with_lambda with lambda = 0,
 // explicit_schur.rs:365-442) applied to n caller-supplied symmetric blocks on GPU `device`.

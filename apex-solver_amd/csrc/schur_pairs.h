@@ -1,0 +1,64 @@
+// schur_pairs.h -- the Schur reduction as a sorted camera-pair list reduced on the fp64 matrix cores.
+//
+// Off-diagonal part of compute_schur_complement (src/linalg/sparse/explicit_schur.rs:771-925):
+//     S(ci, cj) -= sum over landmarks l seen by both cameras of  W_i Hll^-1 W_j^T ,   W = Jc^T Jl  (d_c x 3).
+// With N_i = Jl_i Hll^-1 (2 x 3) and M_ij = -N_i Jl_j^T (2 x 2) every pair contributes a RANK-2 update
+//     -W_i Hll^-1 W_j^T = (Jc_i^T M_ij) Jc_j = U_ij V_j ,   U (d_c x 2), V (2 x d_c),
+// so a block S(ci, cj) is the product of a d_c x 2P and a 2P x d_c matrix, P = pairs of the block: a tiny GEMM whose K
+// dimension runs over the pairs.  All pairs of the problem are sorted by block once per structure; a wave takes 64
+// consecutive pair slots, one pair per lane computes U and V (both observations re-linearised from the 24-byte records),
+// parks them in LDS, and 32 v_mfma_f64_16x16x4_f64 (two pairs per instruction) reduce them over the lanes.  A block
+// is owned by one wave and stored ONCE with plain stores: no atomics, no LDS accumulators, no neighbour chunking.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "ba_kernels.h"
+
+namespace apex {
+
+constexpr uint32_t kPairPad = 0xFFFFFFFFu;
+
+struct PairRec {      // one pair slot (16 bytes, one coalesced dwordx4 per lane)
+    uint32_t i, j;    // landmark-major observation indices; cam(j) <= cam(i); i == kPairPad: padding slot (U = V = 0)
+    uint32_t l;       // landmark
+    uint32_t blk;     // block of the pair, local to its chunk (0..31)
+};
+struct PairChunk {    // 64 consecutive slots = 32 K-steps of the MFMA reduction
+    uint32_t mask;    // bit s: a new block starts at K-step s (slots 2s, 2s+1)
+    int32_t first_block;   // global index of the block active at slot 0
+};
+constexpr uint32_t kPairBlockAtomic = 1;   // the block is split over several waves: flush with atomic adds
+constexpr uint32_t kPairBlockDiag = 2;     // ci == cj (one camera sees a landmark twice): B + B^T into the lower triangle
+struct PairBlock {
+    int64_t dst;      // offset (doubles) of S(ci, cj)[0][0] inside the tile storage
+    uint32_t ci, cj;  // internal camera indices
+    uint32_t flags;
+    uint32_t pad;
+};
+struct PairTask {     // the work of one wave: whole blocks, a whole number of chunks
+    int32_t chunk0, nchunks;
+};
+
+struct PairLists {
+    std::vector<PairRec> recs;
+    std::vector<PairChunk> chunks;
+    std::vector<PairBlock> blocks;
+    std::vector<PairTask> tasks;
+    int64_t n_pairs = 0;      // real pairs (without padding)
+    int64_t n_blocks = 0;     // camera-pair blocks that receive contributions
+};
+
+// Host, once per structure.  o_cam / o_pt / pt_ptr: the LOCAL landmark-major observation arrays (observations of one
+// landmark sorted by internal camera index); cam_ptr / cam_obs: their camera-major view; cam_ext[ci]: the caller's index
+// of internal camera ci (rows are processed in the caller's order: consecutive rows then share landmarks);
+// slot: tile slot map (nt x nt, lower).
+void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
+                      const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out);
+
+void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
+                        const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s);
+
+}  // namespace apex

@@ -14,6 +14,7 @@
 #include "ba_kernels.h"
 #include "chol_kernels.h"
 #include "lm_loop.h"
+#include "schur_pairs.h"
 #include "stage_timer.h"
 #include "tile_plan.h"
 
@@ -92,6 +93,10 @@ class Solver : public LmBackend {
     int n_levels() const { return tp_.n_levels(); }
     const TilePlan& plan() const { return tp_; }
     double schur_scatter_pairs() const { return (double)n_pairs_; }
+    double pair_blocks() const { return (double)n_pair_blocks_; }
+    double pair_slots() const { return (double)n_pair_slots_; }
+    int schur_form() const { return use_rows_ ? rows_form_ : 0; }
+    const double* setup_seconds() const { return setup_s_; }
     double touched_tiles() const { return (double)n_present_; }
     double local_obs() const { return (double)o_orig_h_.size(); }
 
@@ -159,7 +164,15 @@ class Solver : public LmBackend {
     RowTask* rtasks2_ = nullptr;     // k_schur_rows2: the same row tasks over chunks of entries
     RowChunk* rchunks_ = nullptr;
     RowEntry* rentries_ = nullptr;
-    int rows_form_ = 2;              // 2: one lane per observation (k_schur_rows2, default: every lane walks the rows of
+    PairTask* ptasks_ = nullptr;     // rows_form_ 3: the sorted camera-pair list (schur_pairs.h)
+    PairChunk* pchunks_ = nullptr;
+    PairBlock* pblocks_ = nullptr;
+    PairRec* precs_ = nullptr;
+    int n_ptasks_ = 0;
+    int64_t n_pair_blocks_ = 0, n_pair_slots_ = 0;
+    int rows_form_ = 3;              // 3 (default): sorted pair list reduced on the fp64 matrix cores (k_schur_pairs: every
+                                     // block S(ci, cj) stored once by one wave, no atomics, no LDS accumulators);
+                                     // 2: one lane per observation (k_schur_rows2, default: every lane walks the rows of
                                      // a neighbour block in its own rotated order, which takes the same-address
                                      // conflicts out of the LDS atomics: 9.7 -> 6.1 ms on final-13682); 1: one lane
                                      // per pair (k_schur_rows).  Select before set_structure.
@@ -197,6 +210,7 @@ class Solver : public LmBackend {
     int n_partial_ = 1024;
 
     bool use_graphs_ = true;
+    double setup_s_[6] = {0, 0, 0, 0, 0, 0};  // set_structure by phase: order + tile structure, landmark / camera lists, tile plan, Schur lists, uploads, total
 
     StageTimer<kNumStages> timer_;
 

@@ -43,7 +43,7 @@ Solver::Solver(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device)
 Solver::~Solver() {
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, rtasks2_, rchunks_, rentries_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
+    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_, lam_mask_};
     for (void* p : ptrs)
@@ -338,7 +338,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     // ---- Schur-scatter tasks over the local landmarks -----------------------------------------------
     std::vector<ScatterTask> tasks;
     n_pairs_ = 0;
-    {
+    for (int64_t l = lm_lo_; l < lm_hi_; ++l) { const int64_t k = pt_ptr[l + 1] - pt_ptr[l]; n_pairs_ += k * (k + 1) / 2; }
+    if (!use_rows_) {
         int cur0 = -1, curn = 0;
         auto flush = [&]() {
             if (curn > 0) tasks.push_back({cur0, curn, 0, 0});
@@ -347,7 +348,6 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         for (int64_t l = lm_lo_; l < lm_hi_; ++l) {
             const int b = pt_ptr[l], e = pt_ptr[l + 1], k = e - b;
             if (k == 0) continue;
-            n_pairs_ += (int64_t)k * (k + 1) / 2;
             if (k > kScatterBlk) {
                 flush();
                 const int nb = (k + kScatterBlk - 1) / kScatterBlk;
@@ -372,7 +372,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     // ---- k_schur_rows: neighbour lists (cameras cj <= ci sharing a landmark with ci, from the FULL
     // problem so that every rank writes the same blocks), per-camera pair batches, row tasks ------------
     std::vector<int> nbr_ptr(n_cam_ + 1, 0), nbr;
-    {
+    const bool lds_rows = use_rows_ && (rows_form_ == 1 || rows_form_ == 2);
+    if (lds_rows) {
         std::vector<std::vector<int>> lists(n_cam_);
         std::vector<int> stamp(n_cam_, -1);
         // camera-major view of the full problem
@@ -402,8 +403,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     }
     std::vector<RowBatch> rbatches;
     std::vector<RowTask> rtasks;
-    std::vector<uint16_t> cam_obs_off(n_loc, 0);
-    {
+    std::vector<uint16_t> cam_obs_off(lds_rows && rows_form_ == 1 ? n_loc : 0, 0);
+    if (lds_rows && rows_form_ == 1) {
         const int cap = (dc_ == 9) ? kRowCap9 : kRowCap6;
         for (int64_t c = 0; c < n_cam_; ++c) {
             const int b0 = (int)rbatches.size();
@@ -434,13 +435,12 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
             }
         }
     }
-    n_rtasks_ = (int)rtasks.size();
     // k_schur_rows2: one entry per observation of a camera (split at kRowMaxPartners partners), sorted by partner
     // count so that the 64 lanes of a wave loop the same number of times; chunks of <= 64 entries, largest first
     std::vector<RowEntry> rentries;
     std::vector<RowChunk> rchunks;
     std::vector<RowTask> rtasks2;
-    if (rows_form_ == 2) {  // built only when that form is selected (16 bytes per observation)
+    if (lds_rows && rows_form_ == 2) {  // built only when that form is selected (16 bytes per observation)
         const int cap = (dc_ == 9) ? kRowCap9 : kRowCap6;
         std::vector<RowEntry> ce;
         for (int64_t c = 0; c < n_cam_; ++c) {
@@ -466,6 +466,14 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
             }
         }
     }
+    n_rtasks_ = lds_rows ? (int)(rows_form_ == 2 ? rtasks2.size() : rtasks.size()) : 0;
+    // k_schur_pairs (default): every camera pair (i, j) of a landmark, sorted by the block S(cam_i, cam_j) it adds to
+    PairLists pl;
+    if (use_rows_ && rows_form_ == 3)
+        build_pair_lists(dc_, nt_, tp_.slot_host(), n_cam_, cinv_.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(),
+                         cam_obs.data(), &pl);
+    n_ptasks_ = (int)pl.tasks.size();
+    n_pair_blocks_ = pl.n_blocks; n_pair_slots_ = (int64_t)pl.recs.size();
     n_present_ = 0;
     for (uint8_t b : present) n_present_ += b;
 
@@ -495,6 +503,10 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(up(&rchunks_, rchunks));
     HIP_TRY(up(&rentries_, rentries));
     HIP_TRY(up(&cam_obs_off_, cam_obs_off));
+    HIP_TRY(up(&ptasks_, pl.tasks));
+    HIP_TRY(up(&pchunks_, pl.chunks));
+    HIP_TRY(up(&pblocks_, pl.blocks));
+    HIP_TRY(up(&precs_, pl.recs));
     HIP_TRY(up(&nbr_, nbr));
     {
         std::vector<uint8_t> fp(6 * n_cam_, 0), fi(3 * n_cam_, 0), fl(3 * n_pt_, 0);
@@ -690,7 +702,9 @@ int Solver::assemble_local(double lambda, double diag_extra) {
                       g_c_, g_red_, stream_);
     stage_end(kStAssembleCam);
     stage_begin(kStScatter);
-    if (use_rows_ && rows_form_ == 2 && rows_dbg_ == 0)
+    if (use_rows_ && rows_form_ == 3)
+        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_);
+    else if (use_rows_ && rows_form_ == 2 && rows_dbg_ == 0)
         launch_schur_rows2(dc_, v, tm, rtasks2_, n_rtasks_, rchunks_, rentries_, nbr_, hinv_, stream_);
     else if (use_rows_)
         launch_schur_rows(dc_, v, tm, rtasks_, n_rtasks_, rbatches_, cam_obs_, cam_obs_off_, nbr_, hinv_, rows_dbg_, stream_);

@@ -370,7 +370,7 @@ class GpuSchurComplementSolver:
         return dict(tile_rows=int(out[0]), tiles=int(out[1]), pair_blocks=float(out[2]), cam_dof=int(out[3]),
                     last_reg=float(out[4]), pcg_iterations=int(out[5]), touched_tiles=int(out[6]), local_obs=int(out[7]), etree_levels=int(out[8]),
                     n_potrf=int(out[9]), n_trsm=int(out[10]), n_update=int(out[11]),
-                    dist_top_columns=int(out[12]), dist_local_fraction=float(out[13]), tree_sharded=bool(out[14]))
+                    dist_top_columns=int(out[12]), dist_local_fraction=float(out[13]), tree_sharded=bool(out[14]), schur_form=int(out[15]))
 
     def set_option(self, name: str, value: int):
         h = self._need(); h.check(h.L.apexgpu_set_option(h.h, name.encode(), int(value)))

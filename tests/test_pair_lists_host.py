@@ -1,0 +1,113 @@
+"""Host-only checks of the sorted camera-pair lists the default Schur reduction consumes (csrc/schur_pairs.h): the
+kernel's bookkeeping -- chunk masks, block-local indices, padding, flush points, task cuts -- is replayed in numpy and
+must deliver every camera pair (i, j) of every landmark to the block S(cam_i, cam_j) exactly once.  No GPU."""
+import numpy as np
+import pytest
+
+import apex_solver_amd as pkg
+from apex_solver_amd import capi
+
+PAD = 0xFFFFFFFF
+NB = 144
+
+
+def replay(pl, cam_idx, dc):
+    """What k_schur_pairs does with the lists, minus the arithmetic: {block index: [(i, j), ...]} as flushed."""
+    recs, chunks, blocks, tasks, o_index = pl["recs"], pl["chunks"], pl["blocks"], pl["tasks"], pl["o_index"]
+    flushed = {}
+    seen_chunks = np.zeros(len(chunks), dtype=int)
+    for c0, n in tasks:
+        cur = -1
+        acc = []
+        for ch in range(c0, c0 + n):
+            seen_chunks[ch] += 1
+            mask, first = int(np.uint32(chunks[ch, 0])), int(chunks[ch, 1])
+            nblk = 1 + bin(mask & ~1).count("1")
+            assert nblk <= 32
+            for s in range(32):
+                if (mask >> s) & 1:
+                    if cur >= 0:
+                        flushed.setdefault(cur, []).extend(acc)
+                    cur = first if cur < 0 else cur + 1
+                    acc = []
+                for p in (64 * ch + 2 * s, 64 * ch + 2 * s + 1):
+                    i, j, l, blk = (int(x) for x in recs[p])
+                    if i == PAD:
+                        continue
+                    assert cur >= 0 and first + blk == cur, "a lane's block-local index must name the block being accumulated"
+                    assert blk < nblk
+                    acc.append((i, j, l))
+            if ch == c0:
+                assert mask & 1, "a task starts at a block boundary"
+        if cur >= 0:
+            flushed.setdefault(cur, []).extend(acc)
+    assert (seen_chunks == 1).all(), "every chunk belongs to exactly one task"
+    return flushed
+
+
+@pytest.mark.parametrize("dc", [9, 6])
+@pytest.mark.parametrize("shape", [(40, 1500, 3, 7), (300, 9000, 2, 9)])
+def test_every_pair_reaches_its_block_once(dc, shape):
+    n_cam, n_pt, klo, khi = shape
+    d = pkg.synthetic.make_problem(n_cam, n_pt, klo, khi, config_id=400 + n_cam)
+    pl = capi.pair_lists(d.n_cam, d.n_pt, dc, d.cam_idx, d.pt_idx)
+    flushed = replay(pl, d.cam_idx, dc)
+    blocks, o_index = pl["blocks"], pl["o_index"]
+    cpt = NB // dc
+    got = {}
+    for b, pairs in flushed.items():
+        dst, ci, cj, flags = (int(x) for x in blocks[b])
+        I, J = ci // cpt, cj // cpt
+        assert dst == (I * (I + 1) // 2 + J) * NB * NB + (ci % cpt) * dc * NB + (cj % cpt) * dc
+        assert cj <= ci and ((flags & 2) != 0) == (ci == cj)
+        for i, j, l in pairs:
+            oi, oj = o_index[i], o_index[j]
+            assert d.cam_idx[oi] == ci and d.cam_idx[oj] == cj and d.pt_idx[oi] == l and d.pt_idx[oj] == l
+            key = (min(oi, oj), max(oi, oj))
+            assert key not in got
+            got[key] = b
+    # expected: all unordered pairs of observations of one landmark
+    order = np.lexsort((d.cam_idx, d.pt_idx))
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(d.pt_idx, minlength=d.n_pt))])
+    want = 0
+    for l in range(d.n_pt):
+        k = ptr[l + 1] - ptr[l]
+        want += k * (k - 1) // 2
+    assert len(got) == want
+    # blocks are visited once unless flagged for an atomic flush, rows in the caller's camera order
+    keys = [(int(blocks[b][1]), int(blocks[b][2])) for b in sorted(flushed)]
+    assert keys == sorted(keys)
+    plain = [k for b, k in zip(sorted(flushed), keys) if int(blocks[b][3]) == 0]
+    assert len(plain) == len(set(plain))
+
+
+def test_hub_blocks_are_split_and_flagged_atomic():
+    """Two cameras that share 20,000 landmarks: their block exceeds what one wave takes and is cut into pieces that
+    flush with atomic adds; a camera that sees a landmark twice lands on the diagonal block with the B + B^T flag."""
+    n_cam, n_pt = 12, 20000
+    rng = np.random.default_rng(0)
+    cam_idx, pt_idx = [], []
+    for l in range(n_pt):
+        cams = [3, 7] + ([int(rng.integers(8, 12))] if l % 5 == 0 else [])
+        if l == 17:
+            cams = [5, 5, 9]
+        cam_idx += cams; pt_idx += [l] * len(cams)
+    cam_idx = np.asarray(cam_idx, dtype=np.uint32); pt_idx = np.asarray(pt_idx, dtype=np.uint32)
+    pl = capi.pair_lists(n_cam, n_pt, 9, cam_idx, pt_idx)
+    flushed = replay(pl, cam_idx, 9)
+    blocks = pl["blocks"]
+    hub = [b for b in flushed if (int(blocks[b][1]), int(blocks[b][2])) == (7, 3)]
+    assert len(hub) >= 3 and all(int(blocks[b][3]) & 1 for b in hub)
+    assert sum(len(flushed[b]) for b in hub) == n_pt - 1
+    assert len({int(blocks[b][0]) for b in hub}) == 1                  # all pieces add into the same block
+    diag = [b for b in flushed if int(blocks[b][1]) == int(blocks[b][2])]
+    assert len(diag) == 1 and int(blocks[diag[0]][3]) & 2 and len(flushed[diag[0]]) == 1
+
+
+def test_empty_and_single_observation_landmarks():
+    cam_idx = np.array([0, 1, 2, 2], dtype=np.uint32); pt_idx = np.array([0, 0, 3, 5], dtype=np.uint32)
+    pl = capi.pair_lists(4, 7, 9, cam_idx, pt_idx)
+    flushed = replay(pl, cam_idx, 9)
+    assert sum(len(v) for v in flushed.values()) == 1 and len(pl["tasks"]) == 1
+    pl0 = capi.pair_lists(4, 7, 6, np.array([2], dtype=np.uint32), np.array([1], dtype=np.uint32))
+    assert len(pl0["tasks"]) == 0 and len(pl0["recs"]) == 0
