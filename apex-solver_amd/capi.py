@@ -23,7 +23,7 @@ SYMBOLS = (
     "apexgpu_set_cg_params", "apexgpu_set_params", "apexgpu_get_params", "apexgpu_cost", "apexgpu_assemble", "apexgpu_solve_augmented",
     "apexgpu_step_stats", "apexgpu_eval_step", "apexgpu_commit_step", "apexgpu_discard_step",
     "apexgpu_parameter_norm", "apexgpu_column_norms", "apexgpu_set_column_scaling", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
-    "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_debug_invert_blocks", "apexgpu_debug_pair_lists", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
+    "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_debug_invert_blocks", "apexgpu_debug_pair_lists", "apexgpu_debug_host_structure", "apexgpu_setup_times", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
     "apexgpu_stage_times", "apexgpu_info", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_set_shard", "apexgpu_shard_range",
     "apexgpu_debug_lockstep_solve", "apexgpu_export_step", "apexgpu_owned_landmarks", "apexgpu_debug_partition",
     "apexgpu_bal_open", "apexgpu_bal_close", "apexgpu_bal_last_error", "apexgpu_bal_sizes", "apexgpu_bal_raw",
@@ -129,6 +129,8 @@ def load() -> C.CDLL:
     L.apexgpu_schur_matvec.argtypes = [vp, dbl, vp, vp, vp]
     L.apexgpu_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.apexgpu_debug_invert_blocks.argtypes = [C.c_int, C.c_int64, vp, vp, vp]
+    L.apexgpu_debug_host_structure.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.apexgpu_setup_times.argtypes = [vp, vp, vp]
     L.apexgpu_debug_pair_lists.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.apexgpu_enable_stage_timing.argtypes = [vp, C.c_int]
     L.apexgpu_reset_stage_times.argtypes = [vp]
@@ -199,6 +201,28 @@ def tile_partition(present: np.ndarray, world: int):
     if n_top < 0:
         raise LinAlgError(n_top, "apexgpu_debug_partition")
     return owner, n_top
+
+
+HOST_STRUCTURE_STATS = ("tile_rows", "hub_cameras", "border_tiles", "touched_tiles", "tiles", "etree_levels", "top_columns",
+                        "tree_sharded", "s_order", "s_lists", "s_plan", "s_schur_lists", "s_uploads", "s_total", "pair_contributions",
+                        "pair_blocks")
+
+
+def host_structure(n_cam: int, n_pt: int, cam_idx: np.ndarray, pt_idx: np.ndarray, mode: int = 1, rank: int = 0, world: int = 1,
+                   nested_dissection: int = 1, hubs_last: int = 1, dist_factor: int = 1, tree_sharding: int = 1, schur_form: int = 3):
+    """Host only: what apexgpu_set_structure derives from the observation list before it touches the device."""
+    ci = np.ascontiguousarray(cam_idx, dtype=np.uint32); pi = np.ascontiguousarray(pt_idx, dtype=np.uint32)
+    opts = np.array([nested_dissection, hubs_last, dist_factor, tree_sharding, schur_form], dtype=np.int32)
+    stats = np.zeros(16); dc = 9 if mode == 1 else 6
+    nt = (n_cam * dc + 143) // 144
+    cmap = np.zeros(n_cam, dtype=np.int32); owned = np.zeros(n_pt, dtype=np.uint8); towner = np.zeros(nt, dtype=np.int32)
+    rc = load().apexgpu_debug_host_structure(n_cam, n_pt, len(ci), mode, ptr(ci), ptr(pi), rank, world, ptr(opts), ptr(stats),
+                                             ptr(cmap), ptr(owned), ptr(towner))
+    if rc != 0:
+        raise LinAlgError(rc, "apexgpu_debug_host_structure failed")
+    out = dict(zip(HOST_STRUCTURE_STATS, stats.tolist()))
+    out.update(cmap=cmap, owned=owned.astype(bool), tile_owner=towner)
+    return out
 
 
 def pair_lists(n_cam: int, n_pt: int, dc: int, cam_idx: np.ndarray, pt_idx: np.ndarray):

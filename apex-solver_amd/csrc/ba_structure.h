@@ -1,0 +1,77 @@
+// ba_structure.h -- everything Solver::set_structure derives from the observation list on the HOST (no device call):
+// internal camera order (hub cameras last, nested dissection of the tile graph), tile structure of S, landmark
+// sharding, landmark-major / camera-major observation lists, and the task lists of the Schur reduction.
+// Replaces, for this backend, StructureAware::initialize_structure + build_block_structure
+// (src/linalg/sparse/explicit_schur.rs:1038-1062, 244-323) and build_symbolic_structure (src/linearizer/cpu/sparse.rs:54-105).
+// Kept apart from the device code so that CPU tests can run it (capi: apexgpu_debug_host_structure).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "ba_kernels.h"
+#include "schur_pairs.h"
+#include "tile_plan.h"
+
+namespace apex {
+
+struct BaStructOptions {
+    int dc = 9;
+    bool use_nd = true;
+    int nd_leaf = 16;
+    double strong_edge_frac = 0.02;   // tile-graph edges lighter than this share of the weaker end's heaviest edge are left out of the ORDERING
+    bool hubs_last = true;     // a vertex cover of the camera pairs that share landmarks across weakly connected tiles (hub cameras,
+                               // accidental long-range matches) is ordered last: a dense border instead of dense rows everywhere
+    int rank = 0, world = 1;
+    bool dist_factor = true, tree_sharding = true;
+    int dist_selftest = 0;
+    int schur_form = 3;        // 3 sorted pair list on MFMA, 2 / 1 LDS rows, 0 global atomics
+};
+
+struct BaHostStructure {
+    int64_t n_cam = 0, n_pt = 0, n_obs = 0;
+    int dc = 9, nt = 0;
+    int64_t n_c = 0, n_c_pad = 0;
+    std::vector<int> cmap, cinv;       // caller's camera -> internal camera and back
+    int n_hubs = 0, n_border_tiles = 1;   // border cameras (ordered last) and the tiles they occupy
+    std::vector<uint8_t> present;      // nt x nt lower-triangular tile structure, final order
+    std::vector<int> lmap;             // caller's landmark -> internal landmark (identity unless tree sharded)
+    int64_t lm_lo = 0, lm_hi = 0;      // internal landmark range of this rank
+    bool tree_shard = false;
+    int pad_rank = 0;
+    std::vector<uint8_t> lam_mask;     // tree sharding: cameras whose diagonal block gets lambda on this rank
+    // local observation lists (this rank's landmarks)
+    std::vector<uint32_t> o_cam, o_pt;
+    std::vector<double> o_uv;
+    std::vector<int> o_orig, pt_ptr, cam_ptr, cam_obs;
+    std::vector<uint32_t> co_pt;
+    std::vector<double> co_uv;
+    std::vector<int> co_rank;
+    int64_t n_pairs = 0, n_present = 0;
+    // Schur task lists (only the selected form is built)
+    std::vector<ScatterTask> tasks;
+    std::vector<int> nbr;
+    std::vector<RowBatch> rbatches;
+    std::vector<RowTask> rtasks, rtasks2;
+    std::vector<uint16_t> cam_obs_off;
+    std::vector<RowEntry> rentries;
+    std::vector<RowChunk> rchunks;
+    PairLists pl;
+    double seconds[6] = {0, 0, 0, 0, 0, 0};  // order + tile structure | sharding + lists | tile plan | Schur lists | uploads | total
+
+    // Step 1: camera order, tile structure, sharding, observation lists.  Applies the partition settings to `tp`
+    // (host calls only).  Returns "" or an error message.
+    std::string build_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, const uint32_t* cam_idx, const uint32_t* pt_idx,
+                            const double* obs_uv, const BaStructOptions& o, TilePlan& tp);
+    // Step 2, after tp.build() / tp.build_symbolic(): the task lists of the selected Schur form
+    void build_schur_lists(const BaStructOptions& o, const int* slot_host);
+    void release_scratch();   // the full-problem lists step 2 needed
+
+   private:
+    std::vector<uint32_t> cam_i_, pt_i_;         // internal camera / landmark of every observation (caller's order)
+    std::vector<int64_t> full_ptr_;
+    std::vector<int> full_obs_;
+};
+
+}  // namespace apex

@@ -1,0 +1,462 @@
+// ba_structure.hip -- see ba_structure.h.  Host code only.
+#include "ba_structure.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <numeric>
+
+#include "host_parallel.h"
+
+namespace apex {
+
+void shard_range(int64_t n_pt, const int64_t* ptr, int rank, int world, int64_t* lo, int64_t* hi);  // solver.hip
+
+namespace {
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t n_obs_, const uint32_t* cam_idx,
+                                         const uint32_t* pt_idx, const double* obs_uv, const BaStructOptions& o, TilePlan& tp) {
+    const double t_begin = now_s();
+    n_cam = n_cam_; n_pt = n_pt_; n_obs = n_obs_; dc = o.dc;
+    n_c = n_cam * dc;
+    nt = (int)((n_c + kNB - 1) / kNB);
+    n_c_pad = (int64_t)nt * kNB;
+    const int cpt = kNB / dc;
+    const int rank = o.rank, world = o.world;
+
+    // ---- landmark-major view of the full problem in the caller's numbering (counting sort) ------------------------------
+    std::vector<int64_t> lp(n_pt + 1, 0);
+    for (int64_t i = 0; i < n_obs; ++i) lp[pt_idx[i] + 1]++;
+    for (int64_t l = 0; l < n_pt; ++l) lp[l + 1] += lp[l];
+    std::vector<int> lobs(n_obs);
+    {
+        std::vector<int64_t> fill(lp.begin(), lp.end() - 1);
+        for (int64_t i = 0; i < n_obs; ++i) lobs[fill[pt_idx[i]]++] = (int)i;
+    }
+
+    // weight of a tile pair = number of (landmark, tile pair) incidences: thousands for tiles that overlap in a capture
+    // sequence, one or two for an accidental long-range match.  An edge of the tile graph is STRONG when it carries at
+    // least strong_edge_frac of the heaviest off-diagonal weight of its weaker end.
+    auto tile_weights = [&](const std::vector<int>& pos, std::vector<uint32_t>& acnt, std::vector<uint8_t>& strong) {
+        acnt.assign((size_t)nt * nt, 0);
+        parallel_ranges(n_pt, 4096, [&](int64_t b, int64_t e) {
+            std::vector<int> tl;
+            for (int64_t l = b; l < e; ++l) {
+                tl.clear();
+                for (int64_t x = lp[l]; x < lp[l + 1]; ++x) tl.push_back(pos[cam_idx[lobs[x]]] / cpt);
+                std::sort(tl.begin(), tl.end());
+                tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
+                for (size_t a = 0; a < tl.size(); ++a)
+                    for (size_t bb = 0; bb <= a; ++bb) __atomic_fetch_add(&acnt[(size_t)tl[a] * nt + tl[bb]], 1u, __ATOMIC_RELAXED);
+            }
+        });
+        for (int a = 0; a < nt; ++a)
+            for (int b = 0; b < a; ++b) acnt[(size_t)b * nt + a] = acnt[(size_t)a * nt + b];
+        std::vector<uint32_t> rowmax(nt, 0);
+        for (int a = 0; a < nt; ++a)
+            for (int b = 0; b < nt; ++b)
+                if (a != b) rowmax[a] = std::max(rowmax[a], acnt[(size_t)a * nt + b]);
+        strong.assign((size_t)nt * nt, 0);
+        for (int a = 0; a < nt; ++a)
+            for (int b = 0; b < nt; ++b) {
+                const uint32_t w = acnt[(size_t)a * nt + b];
+                if (w == 0) continue;
+                const double need = o.strong_edge_frac * (double)std::min(rowmax[a], rowmax[b]);
+                if (a == b || (double)w >= need) strong[(size_t)a * nt + b] = 1;
+            }
+    };
+
+    // ---- border cameras ------------------------------------------------------------------------------------------------------
+    // A tile Cholesky wants a tile graph with geometry: bands, trees, grids.  Two things in real captures destroy it at
+    // tile granularity although they involve few CAMERAS: hub cameras (an overview photograph covisible with a large
+    // part of the collection makes its whole 16-camera tile a dense row of S) and accidental long-range matches (one
+    // camera far away sees a landmark of this neighbourhood: its tile couples with the four or five tiles of the
+    // landmark's window).  Both show up as camera pairs that share a landmark while their tiles are NOT strongly
+    // connected.  A greedy vertex cover of those pairs (highest degree first: hubs go first) is ordered LAST: S becomes
+    // the geometric part plus a dense border.  The order is a heuristic; the fill below is computed on the true structure.
+    std::vector<int> pre(n_cam);
+    std::iota(pre.begin(), pre.end(), 0);
+    n_hubs = 0;
+    std::vector<uint32_t> acnt;
+    std::vector<uint8_t> adjm;
+    tile_weights(pre, acnt, adjm);
+    if (o.hubs_last && nt >= 24) {
+        // "not strongly connected" = more than two strong hops apart: the far ends of a capture window (tiles that
+        // overlap in a few landmarks only but have common strong neighbours) are geometry, not long-range matches
+        std::vector<uint8_t> near2((size_t)nt * nt, 0);
+        {
+            const int words = (nt + 63) / 64;
+            std::vector<uint64_t> rowbits((size_t)nt * words, 0);
+            for (int a = 0; a < nt; ++a)
+                for (int b = 0; b < nt; ++b)
+                    if (adjm[(size_t)a * nt + b]) rowbits[(size_t)a * words + (b >> 6)] |= 1ull << (b & 63);
+            parallel_rows(nt, [&](int64_t a) {
+                std::vector<uint64_t> acc(rowbits.begin() + a * words, rowbits.begin() + (a + 1) * words);
+                for (int b = 0; b < nt; ++b)
+                    if (adjm[(size_t)a * nt + b])
+                        for (int w = 0; w < words; ++w) acc[w] |= rowbits[(size_t)b * words + w];
+                for (int b = 0; b < nt; ++b) near2[(size_t)a * nt + b] = (acc[b >> 6] >> (b & 63)) & 1;
+            });
+        }
+        const unsigned nth = host_threads();
+        std::vector<std::vector<uint64_t>> parts(nth);
+        std::atomic<unsigned> slot_id(0);
+        std::atomic<int64_t> total(0);
+        const int64_t kMaxEdges = 1LL << 26;
+        parallel_ranges(n_pt, 4096, [&](int64_t b, int64_t e) {
+            thread_local unsigned my = ~0u;
+            thread_local const void* owner_tag = nullptr;
+            if (owner_tag != (const void*)&parts) { my = slot_id.fetch_add(1) % nth; owner_tag = (const void*)&parts; }
+            std::vector<uint64_t>& out = parts[my];
+            if (total.load(std::memory_order_relaxed) > kMaxEdges) return;
+            int64_t added = 0;
+            for (int64_t l = b; l < e; ++l)
+                for (int64_t x = lp[l]; x < lp[l + 1]; ++x) {
+                    const uint32_t ca = cam_idx[lobs[x]];
+                    for (int64_t y = x + 1; y < lp[l + 1]; ++y) {
+                        const uint32_t cb = cam_idx[lobs[y]];
+                        if (ca == cb || near2[(size_t)(ca / cpt) * nt + cb / cpt]) continue;
+                        out.push_back(((uint64_t)std::min(ca, cb) << 32) | std::max(ca, cb));
+                        ++added;
+                    }
+                }
+            total.fetch_add(added, std::memory_order_relaxed);
+        });
+        if (total.load() <= kMaxEdges && total.load() > 0) {
+            std::vector<uint64_t> edges;
+            edges.reserve((size_t)total.load());
+            for (auto& pvec : parts) { edges.insert(edges.end(), pvec.begin(), pvec.end()); std::vector<uint64_t>().swap(pvec); }
+            std::sort(edges.begin(), edges.end());
+            edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+            // adjacency of the long-range graph
+            std::vector<int> deg(n_cam, 0);
+            for (uint64_t k : edges) { deg[k >> 32]++; deg[(uint32_t)k]++; }
+            std::vector<int64_t> ap(n_cam + 1, 0);
+            for (int64_t c = 0; c < n_cam; ++c) ap[c + 1] = ap[c] + deg[c];
+            std::vector<int> an(ap[n_cam]);
+            {
+                std::vector<int64_t> fill(ap.begin(), ap.end() - 1);
+                for (uint64_t k : edges) { const int a = (int)(k >> 32), b = (int)(uint32_t)k; an[fill[a]++] = b; an[fill[b]++] = a; }
+            }
+            // greedy cover, highest remaining degree first (lazy max-heap)
+            std::vector<std::pair<int, int>> heap;
+            for (int64_t c = 0; c < n_cam; ++c) if (deg[c] > 0) heap.push_back({deg[c], (int)c});
+            std::make_heap(heap.begin(), heap.end());
+            std::vector<char> in_cover(n_cam, 0);
+            std::vector<int> cover;
+            int64_t alive = (int64_t)edges.size();
+            while (alive > 0 && !heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end());
+                const std::pair<int, int> top = heap.back();
+                heap.pop_back();
+                const int c = top.second;
+                if (in_cover[c] || top.first != deg[c] || deg[c] == 0) { if (!in_cover[c] && deg[c] > 0 && top.first != deg[c]) { heap.push_back({deg[c], c}); std::push_heap(heap.begin(), heap.end()); } continue; }
+                in_cover[c] = 1;
+                cover.push_back(c);
+                for (int64_t k = ap[c]; k < ap[c + 1]; ++k) {
+                    const int nb = an[k];
+                    if (in_cover[nb]) continue;
+                    deg[nb]--; alive--;
+                }
+                deg[c] = 0;
+            }
+            if (!cover.empty() && (int64_t)cover.size() * 8 <= n_cam) {
+                n_hubs = (int)cover.size();
+                int pos = 0;
+                for (int64_t c = 0; c < n_cam; ++c) if (!in_cover[c]) pre[c] = pos++;
+                std::sort(cover.begin(), cover.end());
+                for (int c : cover) pre[c] = pos++;
+                tile_weights(pre, acnt, adjm);   // the tile graph of the new camera order
+            }
+        }
+    }
+    // border = the tiles from the first hub camera on (at least the last tile, which may hold padding rows and stays
+    // last = eliminated last, no fill)
+    n_border_tiles = n_hubs > 0 ? nt - (int)((n_cam - n_hubs) / cpt) : 1;
+    n_border_tiles = std::max(1, std::min(n_border_tiles, nt));
+    std::vector<int> tperm(nt);
+    std::iota(tperm.begin(), tperm.end(), 0);
+    if (o.use_nd && nt - n_border_tiles >= 23) tperm = TilePlan::order(nt, adjm, true, o.nd_leaf, n_border_tiles);
+    cmap.resize(n_cam);
+    cinv.assign(n_cam, -1);
+    for (int64_t c = 0; c < n_cam; ++c) {
+        cmap[c] = (int)((int64_t)tperm[pre[c] / cpt] * cpt + pre[c] % cpt);
+        cinv[cmap[c]] = (int)c;
+    }
+    present.assign((size_t)nt * nt, 0);
+    for (int a = 0; a < nt; ++a)
+        for (int b = 0; b < nt; ++b)
+            if (acnt[(size_t)a * nt + b]) {
+                const int I = std::max(tperm[a], tperm[b]), J = std::min(tperm[a], tperm[b]);
+                present[(size_t)I * nt + J] = 1;
+            }
+    { std::vector<uint8_t>().swap(adjm); std::vector<uint32_t>().swap(acnt); }
+    cam_i_.resize(n_obs);
+    parallel_ranges(n_obs, 1 << 16, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) cam_i_[i] = (uint32_t)cmap[cam_idx[i]]; });
+    seconds[0] = now_s() - t_begin;
+
+    // ---- partition of the elimination tree, landmark sharding ----------------------------------------------------------------
+    const double t1 = now_s();
+    lmap.resize(n_pt);
+    std::iota(lmap.begin(), lmap.end(), 0);
+    tree_shard = false;
+    lm_lo = 0; lm_hi = n_pt;
+    tp.set_partition(rank, (o.dist_factor && world > 1) ? world : 1);
+    tp.set_own_all(false);
+    if (o.dist_selftest > 1 && world == 1) {  // self-test: the distributed schedule for that many ranks, all played by this one
+        tp.set_partition(0, o.dist_selftest);
+        tp.set_own_all(true);
+        TilePlan::Comm tc;
+        tc.sum = [](double*, size_t, hipStream_t) { return true; };
+        tc.max_int = [](int*, size_t, hipStream_t) { return true; };
+        tp.set_comm(std::move(tc));
+    }
+    pad_rank = 0;
+    lam_mask.clear();
+    // Tree sharding (distributed Cholesky, no communicator-less test shards): a landmark's cameras form a clique of
+    // S, so their tile columns lie on ONE root path of the elimination tree -- below the shared top they all belong
+    // to one rank.  Giving every landmark to that rank makes the tiles of a rank's own columns COMPLETE locally:
+    // no reduce of S at all, only the top tiles are summed (which the distributed factorisation does anyway).
+    // Landmarks seen by top cameras only go to the least loaded rank.  Landmarks are renumbered so that every
+    // rank's set is one contiguous internal range.
+    const std::vector<int> owner = (world > 1 && o.dist_factor && o.tree_sharding) ? tp.preview_owners(nt, present) : std::vector<int>();
+    if (!owner.empty()) {
+        std::vector<int> lm_owner(n_pt, -1);
+        std::vector<int64_t> load(world, 0);
+        for (int64_t l = 0; l < n_pt; ++l) {
+            for (int64_t k = lp[l]; k < lp[l + 1]; ++k) {
+                const int ow = owner[cam_i_[lobs[k]] / cpt];
+                if (ow >= 0) { lm_owner[l] = ow; break; }
+            }
+            if (lm_owner[l] >= 0) load[lm_owner[l]] += lp[l + 1] - lp[l];
+        }
+        for (int64_t l = 0; l < n_pt; ++l)
+            if (lm_owner[l] < 0) {
+                const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                lm_owner[l] = r;
+                load[r] += lp[l + 1] - lp[l];
+            }
+        std::vector<int64_t> first(world + 1, 0);
+        for (int64_t l = 0; l < n_pt; ++l) first[lm_owner[l] + 1]++;
+        for (int r = 0; r < world; ++r) first[r + 1] += first[r];
+        lm_lo = first[rank]; lm_hi = first[rank + 1];
+        for (int64_t l = 0; l < n_pt; ++l) lmap[l] = (int)first[lm_owner[l]]++;
+        tree_shard = true;
+        // lambda on a camera's diagonal block: by the owner of its column, rank 0 for the shared top.  The identity on
+        // the padding rows of the last tile follows the same rule: the elimination tree can be a forest (disconnected
+        // covisibility), the last column is then a subtree root below the shared top, and its owner's copy of the
+        // diagonal tile is the only one that is ever factorised.
+        pad_rank = owner[nt - 1] >= 0 ? owner[nt - 1] : 0;
+        lam_mask.resize(n_cam);
+        for (int64_t ci = 0; ci < n_cam; ++ci) {
+            const int ow = owner[ci / cpt];
+            lam_mask[ci] = (ow == rank || (ow < 0 && rank == 0)) ? 1 : 0;
+        }
+    }
+
+    // ---- landmark-major lists of the full problem in the INTERNAL landmark numbering --------------------------------------
+    pt_i_.resize(n_obs);
+    parallel_ranges(n_obs, 1 << 16, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) pt_i_[i] = (uint32_t)lmap[pt_idx[i]]; });
+    full_ptr_.assign(n_pt + 1, 0);
+    for (int64_t l = 0; l < n_pt; ++l) full_ptr_[lmap[l] + 1] = lp[l + 1] - lp[l];
+    for (int64_t l = 0; l < n_pt; ++l) full_ptr_[l + 1] += full_ptr_[l];
+    full_obs_.resize(n_obs);
+    parallel_ranges(n_pt, 8192, [&](int64_t b, int64_t e) {
+        for (int64_t l = b; l < e; ++l) {
+            int* dst = full_obs_.data() + full_ptr_[lmap[l]];
+            const int64_t k = lp[l + 1] - lp[l];
+            memcpy(dst, lobs.data() + lp[l], (size_t)k * sizeof(int));
+            // inside a landmark the observations are ordered by camera: the partners (cam_j <= cam_i) of an
+            // observation are then a PREFIX of its landmark's list
+            std::stable_sort(dst, dst + k, [&](int a, int bb) { return cam_i_[a] < cam_i_[bb]; });
+        }
+    });
+    { std::vector<int>().swap(lobs); std::vector<int64_t>().swap(lp); }
+    // ---- shard: contiguous landmark range balanced by observation count (tree sharding: set above) --------
+    if (!tree_shard) shard_range(n_pt, full_ptr_.data(), rank, world, &lm_lo, &lm_hi);
+    const int64_t o_lo = full_ptr_[lm_lo], o_hi = full_ptr_[lm_hi];
+    const int64_t n_loc = o_hi - o_lo;
+    if (n_loc > 2000000000LL) return "too many observations on one rank";
+    o_cam.resize(n_loc); o_pt.resize(n_loc); o_uv.resize(2 * n_loc); o_orig.resize(n_loc);
+    pt_ptr.resize(n_pt + 1);
+    for (int64_t l = 0; l <= n_pt; ++l) {
+        int64_t p = full_ptr_[l];
+        p = std::min(std::max(p, o_lo), o_hi) - o_lo;
+        pt_ptr[l] = (int)p;
+    }
+    parallel_ranges(n_loc, 1 << 16, [&](int64_t b, int64_t e) {
+        for (int64_t k = b; k < e; ++k) {
+            const int i = full_obs_[o_lo + k];
+            o_orig[k] = i;
+            o_cam[k] = cam_i_[i]; o_pt[k] = pt_i_[i];
+            o_uv[2 * k] = obs_uv[2 * (int64_t)i]; o_uv[2 * k + 1] = obs_uv[2 * (int64_t)i + 1];
+        }
+    });
+    // ---- camera-major lists over the local observations (+ copies of landmark and measurement) -----------------------------
+    cam_ptr.assign(n_cam + 1, 0);
+    cam_obs.resize(n_loc);
+    for (int64_t k = 0; k < n_loc; ++k) cam_ptr[o_cam[k] + 1]++;
+    for (int64_t c = 0; c < n_cam; ++c) cam_ptr[c + 1] += cam_ptr[c];
+    {
+        std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1);
+        for (int64_t k = 0; k < n_loc; ++k) cam_obs[fill[o_cam[k]]++] = (int)k;
+    }
+    co_pt.resize(n_loc); co_uv.resize(2 * n_loc); co_rank.resize(n_loc);
+    parallel_ranges(n_loc, 1 << 16, [&](int64_t b, int64_t e) {
+        for (int64_t k = b; k < e; ++k) {
+            const int i = cam_obs[k];
+            co_pt[k] = o_pt[i]; co_uv[2 * k] = o_uv[2 * (size_t)i]; co_uv[2 * k + 1] = o_uv[2 * (size_t)i + 1];
+            co_rank[k] = i - pt_ptr[o_pt[i]];
+        }
+    });
+    n_pairs = 0;
+    for (int64_t l = lm_lo; l < lm_hi; ++l) { const int64_t k = pt_ptr[l + 1] - pt_ptr[l]; n_pairs += k * (k + 1) / 2; }
+    n_present = 0;
+    for (uint8_t b : present) n_present += b;
+    seconds[1] = now_s() - t1;
+    return "";
+}
+
+void BaHostStructure::release_scratch() {
+    std::vector<uint32_t>().swap(cam_i_); std::vector<uint32_t>().swap(pt_i_);
+    std::vector<int64_t>().swap(full_ptr_); std::vector<int>().swap(full_obs_);
+}
+
+void BaHostStructure::build_schur_lists(const BaStructOptions& o, const int* slot_host) {
+    const double t0 = now_s();
+    tasks.clear(); nbr.clear(); rbatches.clear(); rtasks.clear(); rtasks2.clear(); cam_obs_off.clear(); rentries.clear(); rchunks.clear();
+    pl = PairLists();
+    const int64_t n_loc = (int64_t)o_cam.size();
+    if (o.schur_form == 3) {
+        // every camera pair (i, j) of a landmark, sorted by the block S(cam_i, cam_j) it adds to
+        build_pair_lists(dc, nt, slot_host, n_cam, cinv.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(),
+                         cam_obs.data(), &pl);
+    } else if (o.schur_form == 0) {
+        // ---- Schur-scatter tasks over the local landmarks (global-atomics form) --------------------------------------
+        int cur0 = -1, curn = 0;
+        auto flush = [&]() {
+            if (curn > 0) tasks.push_back({cur0, curn, 0, 0});
+            cur0 = -1; curn = 0;
+        };
+        for (int64_t l = lm_lo; l < lm_hi; ++l) {
+            const int b = pt_ptr[l], e = pt_ptr[l + 1], k = e - b;
+            if (k == 0) continue;
+            if (k > kScatterBlk) {
+                flush();
+                const int nb = (k + kScatterBlk - 1) / kScatterBlk;
+                for (int bi = 0; bi < nb; ++bi) {
+                    const int i0 = b + bi * kScatterBlk, ni = std::min(kScatterBlk, e - i0);
+                    tasks.push_back({i0, ni, 0, 0});
+                    for (int bj = bi + 1; bj < nb; ++bj) {
+                        const int j0 = b + bj * kScatterBlk, nj = std::min(kScatterBlk, e - j0);
+                        tasks.push_back({i0, ni, j0, nj});
+                    }
+                }
+                continue;
+            }
+            if (curn + k > kScatterCap) flush();
+            if (curn == 0) cur0 = b;
+            curn += k;
+        }
+        flush();
+    } else {
+        // ---- k_schur_rows / k_schur_rows2: neighbour lists (cameras cj <= ci sharing a landmark with ci, from the FULL
+        // problem so that every rank writes the same blocks), per-camera pair batches, row tasks ------------------------
+        std::vector<int> nbr_ptr(n_cam + 1, 0);
+        {
+            std::vector<std::vector<int>> lists(n_cam);
+            std::vector<int64_t> fcp(n_cam + 1, 0);
+            for (int64_t i = 0; i < n_obs; ++i) fcp[cam_i_[i] + 1]++;
+            for (int64_t c = 0; c < n_cam; ++c) fcp[c + 1] += fcp[c];
+            std::vector<int> fco(n_obs);
+            {
+                std::vector<int64_t> fill(fcp.begin(), fcp.end() - 1);
+                for (int64_t i = 0; i < n_obs; ++i) fco[fill[cam_i_[i]]++] = (int)i;
+            }
+            parallel_ranges(n_cam, 16, [&](int64_t cb, int64_t ce) {
+                std::vector<int> stamp(n_cam, -1);
+                for (int64_t c = cb; c < ce; ++c) {
+                    auto& L = lists[c];
+                    for (int64_t e = fcp[c]; e < fcp[c + 1]; ++e) {
+                        const uint32_t l = pt_i_[fco[e]];
+                        for (int64_t k = full_ptr_[l]; k < full_ptr_[l + 1]; ++k) {
+                            const int cj = (int)cam_i_[full_obs_[k]];
+                            if (cj < c && stamp[cj] != (int)c) { stamp[cj] = (int)c; L.push_back(cj); }
+                        }
+                    }
+                    std::sort(L.begin(), L.end());
+                    L.push_back((int)c);  // the camera itself closes its list
+                }
+            });
+            for (int64_t c = 0; c < n_cam; ++c) nbr_ptr[c + 1] = nbr_ptr[c] + (int)lists[c].size();
+            nbr.reserve(nbr_ptr[n_cam]);
+            for (auto& L : lists) nbr.insert(nbr.end(), L.begin(), L.end());
+        }
+        const int cap = (dc == 9) ? kRowCap9 : kRowCap6;
+        if (o.schur_form == 1) {
+            cam_obs_off.assign(n_loc, 0);
+            for (int64_t c = 0; c < n_cam; ++c) {
+                const int b0 = (int)rbatches.size();
+                RowBatch cur{-1, 0, 0, 0, 0};
+                auto flushb = [&]() { if (cur.count > 0 && cur.total > 0) rbatches.push_back(cur); cur = RowBatch{-1, 0, 0, 0, 0}; };
+                for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
+                    const int i_s = cam_obs[e];
+                    const int np = i_s - pt_ptr[o_pt[i_s]];  // partners: observations of the landmark before i (cam_j <= cam_i)
+                    if (np > kRowBatch) {
+                        flushb();
+                        for (int j0 = 0; j0 < np; j0 += kRowBatch) {
+                            const int n = std::min(kRowBatch, np - j0);
+                            rbatches.push_back(RowBatch{e, 1, j0, n, n});
+                        }
+                        continue;
+                    }
+                    if (cur.total + np > kRowBatch || cur.count == kRowThreads) flushb();  // one lane expands one observation
+                    if (cur.count == 0) cur.first = e;
+                    cam_obs_off[e] = (uint16_t)cur.total;
+                    cur.count++; cur.total += np;
+                }
+                flushb();
+                const int nb = (int)rbatches.size() - b0;
+                const int n0 = nbr_ptr[c], nn = nbr_ptr[c + 1] - nbr_ptr[c];
+                for (int s0 = 0; s0 < nn; s0 += cap) {
+                    const int cnt = std::min(cap, nn - s0);
+                    rtasks.push_back(RowTask{(int)c, n0 + s0, cnt, (s0 + cnt == nn) ? 1 : 0, b0, nb});
+                }
+            }
+        } else {
+            // k_schur_rows2: one entry per observation of a camera (split at kRowMaxPartners partners), sorted by partner
+            // count so that the 64 lanes of a wave loop the same number of times; chunks of <= 64 entries, largest first
+            std::vector<RowEntry> ce;
+            for (int64_t c = 0; c < n_cam; ++c) {
+                ce.clear();
+                for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
+                    const int i_s = cam_obs[e];
+                    const int base = pt_ptr[o_pt[i_s]], np = i_s - base;
+                    for (int q0 = 0; q0 < np; q0 += kRowMaxPartners)
+                        ce.push_back(RowEntry{e, base + q0, std::min(kRowMaxPartners, np - q0), 0});
+                }
+                std::stable_sort(ce.begin(), ce.end(), [](const RowEntry& a, const RowEntry& b) { return a.n > b.n; });
+                const int c0 = (int)rchunks.size();
+                for (size_t f = 0; f < ce.size(); f += 64) {
+                    const int cnt = (int)std::min<size_t>(64, ce.size() - f);
+                    rchunks.push_back(RowChunk{(int)(rentries.size() + f), cnt, ce[f].n});
+                }
+                rentries.insert(rentries.end(), ce.begin(), ce.end());
+                const int nc2 = (int)rchunks.size() - c0;
+                const int n0 = nbr_ptr[c], nn = nbr_ptr[c + 1] - nbr_ptr[c];
+                for (int s0 = 0; s0 < nn; s0 += cap) {
+                    const int cnt = std::min(cap, nn - s0);
+                    rtasks2.push_back(RowTask{(int)c, n0 + s0, cnt, (s0 + cnt == nn) ? 1 : 0, c0, nc2});
+                }
+            }
+        }
+    }
+    seconds[3] = now_s() - t0;
+}
+
+}  // namespace apex

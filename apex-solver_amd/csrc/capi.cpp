@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "ba_structure.h"
 #include "pg_solver.h"
 #include "solver.h"
 #ifdef APEX_WITH_RCCL
@@ -220,7 +221,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     // Switches that shape what set_structure builds (task lists, tile order, partition) or what the captured hipGraphs
     // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
     // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
-    static const char* const structural[] = {"schur_rows", "schur_form", "potrf_lookahead", "dist_factor", "tree_sharding", "dist_selftest",
+    static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "potrf_lookahead", "dist_factor", "tree_sharding", "dist_selftest",
                                              "nested_dissection", "update_overlap", "fused_forward"};
     if (h->s->has_structure())
         for (const char* k : structural)
@@ -232,6 +233,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "schur_form") h->s->use_row_schur(value);   /* alias of "schur_rows": 3 pairs on MFMA (default), 2 / 1 LDS rows, 0 global atomics */
     else if (n == "rows_debug") h->s->set_rows_debug(value);
+    else if (n == "hubs_last") h->s->set_hubs_last(value != 0);
     else if (n == "dist_factor") h->s->set_dist_factor(value != 0);
     else if (n == "tree_sharding") h->s->set_tree_sharding(value != 0);
     else if (n == "dist_selftest") h->s->set_dist_selftest(value);
@@ -244,6 +246,13 @@ int apexgpu_reset_stage_times(apexgpu_solver* h) { H_OR_FAIL; h->s->reset_stage_
 int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_t calls[APEXGPU_NUM_STAGES]) {
     H_OR_FAIL;
     h->s->stage_times(ms, calls);
+    return APEXGPU_OK;
+}
+int apexgpu_setup_times(apexgpu_solver* h, double seconds[6], double counts[4]) {
+    H_OR_FAIL;
+    if (!seconds) return APEXGPU_ERR_INVALID_INPUT;
+    for (int k = 0; k < 6; ++k) seconds[k] = h->s->setup_seconds()[k];
+    if (counts) { counts[0] = h->s->n_hubs(); counts[1] = h->s->pair_blocks(); counts[2] = h->s->pair_slots(); counts[3] = h->s->schur_form(); }
     return APEXGPU_OK;
 }
 int apexgpu_info(apexgpu_solver* h, double info[16]) {
@@ -333,6 +342,50 @@ int apexgpu_debug_pair_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc,
             }
         if (tasks2_out) memcpy(tasks2_out, pl.tasks.data(), pl.tasks.size() * sizeof(apex::PairTask));
         if (o_index_out) for (int64_t k = 0; k < n_obs; ++k) o_index_out[k] = order[k];
+        return APEXGPU_OK;
+    });
+}
+
+// Host arithmetic only: everything apexgpu_set_structure derives from the observation list before it touches the device
+// (csrc/ba_structure.h) -- camera order with hub cameras last and nested dissection of the tile graph, symbolic fill,
+// partition of the elimination tree, landmark sharding, the lists of the Schur reduction -- for rank `rank` of `world`.
+// opts[5] = {nested_dissection (0 off, 1 on, > 1 leaf size), hubs_last, dist_factor, tree_sharding, schur_form}.
+// stats_out[16] = {tile rows, hub cameras, border tiles, tiles S touches, tiles after fill, elimination-tree levels,
+// shared top columns, tree sharded, seconds: order+structure, sharding+lists, (unused), Schur lists, (unused), total,
+// pair contributions incl. self pairs, camera-pair blocks}.  cmap_out[n_cam] (caller's camera -> internal), owned_out[n_pt]
+// (1: this rank assembles the landmark), tile_owner_out[tile rows] (-1: shared top / not distributed) may be NULL.
+int apexgpu_debug_host_structure(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, const uint32_t* cam_idx,
+                                 const uint32_t* pt_idx, int rank, int world, const int opts[5], double stats_out[16],
+                                 int32_t* cmap_out, uint8_t* owned_out, int32_t* tile_owner_out) {
+    if (n_cam <= 0 || n_pt <= 0 || n_obs < 0 || !cam_idx || !pt_idx || !opts || !stats_out || world < 1 || rank < 0 || rank >= world)
+        return APEXGPU_ERR_INVALID_INPUT;
+    if (mode != APEXGPU_MODE_BUNDLE_ADJUSTMENT && mode != APEXGPU_MODE_SELF_CALIBRATION) return APEXGPU_ERR_INVALID_INPUT;
+    return guarded([&]() -> int {
+        for (int64_t i = 0; i < n_obs; ++i)
+            if (cam_idx[i] >= (uint64_t)n_cam || pt_idx[i] >= (uint64_t)n_pt) return APEXGPU_ERR_INVALID_INPUT;
+        apex::BaStructOptions so;
+        so.dc = mode == APEXGPU_MODE_SELF_CALIBRATION ? 9 : 6;
+        so.use_nd = opts[0] != 0; if (opts[0] > 1) so.nd_leaf = opts[0];
+        so.hubs_last = opts[1] != 0; so.dist_factor = opts[2] != 0; so.tree_sharding = opts[3] != 0; so.schur_form = opts[4];
+        so.rank = rank; so.world = world;
+        apex::TilePlan tp;
+        apex::BaHostStructure hs;
+        std::vector<double> uv(2 * (size_t)n_obs, 0.0);
+        const std::string e = hs.build_lists(n_cam, n_pt, n_obs, cam_idx, pt_idx, uv.data(), so, tp);
+        if (!e.empty()) return APEXGPU_ERR_INVALID_INPUT;
+        tp.build_symbolic(hs.nt, hs.present);
+        hs.build_schur_lists(so, tp.slot_host());
+        const double t_all = hs.seconds[0] + hs.seconds[1] + hs.seconds[3];
+        const double st[16] = {(double)hs.nt, (double)hs.n_hubs, (double)hs.n_border_tiles, (double)hs.n_present, (double)tp.n_slots(),
+                               (double)tp.n_levels(), (double)tp.n_top_columns(), hs.tree_shard ? 1.0 : 0.0, hs.seconds[0], hs.seconds[1],
+                               0.0, hs.seconds[3], 0.0, t_all, (double)hs.n_pairs, (double)hs.pl.n_blocks};
+        for (int k = 0; k < 16; ++k) stats_out[k] = st[k];
+        if (cmap_out) for (int64_t c = 0; c < n_cam; ++c) cmap_out[c] = hs.cmap[c];
+        if (owned_out) for (int64_t l = 0; l < n_pt; ++l) owned_out[l] = (hs.lmap[l] >= hs.lm_lo && hs.lmap[l] < hs.lm_hi) ? 1 : 0;
+        if (tile_owner_out) {
+            const std::vector<int> ow = tp.preview_owners(hs.nt, hs.present);
+            for (int t = 0; t < hs.nt; ++t) tile_owner_out[t] = ow.empty() ? -1 : ow[t];
+        }
         return APEXGPU_OK;
     });
 }

@@ -2,10 +2,9 @@
 #include "schur_pairs.h"
 
 #include <algorithm>
-#include <atomic>
-#include <thread>
 
 #include "ba_device.hpp"
+#include "host_parallel.h"
 
 namespace apex {
 
@@ -21,24 +20,6 @@ constexpr int kPairCamPitch = 18;        // doubles per staged camera: 144 B kee
 namespace {
 struct RawPair { uint32_t cj, i, j; };
 
-template <typename F>
-void parallel_rows(int64_t n, F&& f) {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 4;
-    nt = std::min<unsigned>(nt, 64);
-    if (n < 256 || nt == 1) { for (int64_t r = 0; r < n; ++r) f(r); return; }
-    std::atomic<int64_t> next(0);
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t)
-        th.emplace_back([&] {
-            for (;;) {
-                const int64_t r0 = next.fetch_add(16);
-                if (r0 >= n) break;
-                for (int64_t r = r0; r < std::min<int64_t>(n, r0 + 16); ++r) f(r);
-            }
-        });
-    for (auto& t : th) t.join();
-}
 }  // namespace
 
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
@@ -169,6 +150,33 @@ __device__ __forceinline__ void pairs_flush(double* __restrict__ tiles, const Pa
     }
 }
 
+// The data one lane needs for its pair, fetched one chunk AHEAD (while the previous chunk's sums run on the matrix
+// cores): both measurements, Hll^-1 and the point, and -- in the first 2 nblk lanes -- one camera of the chunk's blocks.
+struct PairData {
+    double2 uvi, uvj;
+    double2 lm[6];
+    double2 cam[8];
+};
+
+__device__ __forceinline__ void pairs_issue_loads(const BAView& v, const PairBlock* __restrict__ blocks,
+                                                  const double* __restrict__ lmrec, const PairChunk ck, const uint4 rr, int lane,
+                                                  PairData& d) {
+    const bool valid = rr.x != kPairPad;
+    const uint32_t i = valid ? rr.x : 0u, j = valid ? rr.y : 0u, l = valid ? rr.z : 0u;   // padding lanes read element 0
+    d.uvi = v.o_uv[i];
+    d.uvj = v.o_uv[j];
+    const double2* q = reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)l);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d.lm[k] = q[k];
+    const int nblk = 1 + __popc(ck.mask & ~1u);
+    const int bsel = min(lane >> 1, nblk - 1);
+    const PairBlock* pb = blocks + ck.first_block + bsel;
+    const uint32_t cam = (lane & 1) ? pb->cj : pb->ci;
+    const double2* src = reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)cam);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d.cam[k] = src[k];
+}
+
 template <int DC>
 __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restrict__ tiles, const PairTask* __restrict__ tasks,
                                                        int n_tasks, const PairChunk* __restrict__ chunks,
@@ -193,44 +201,45 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
     double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     int cur = -1;
 
-    for (int ch = task.chunk0; ch < task.chunk0 + task.nchunks; ++ch) {
-        const PairChunk ck = chunks[ch];
-        const int nblk = 1 + __popc(ck.mask & ~1u);
-        // ---- the cameras of the chunk's blocks: staged once, read by every lane of the block (LDS broadcast) ------
-        if (lane < 2 * nblk) {
-            const PairBlock* pb = blocks + ck.first_block + (lane >> 1);
-            const uint32_t cam = (lane & 1) ? pb->cj : pb->ci;
-            const double2* src = reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)cam);
+    // Software pipeline over the task's chunks: the gathers of chunk n+1 are issued before the matrix-core phase of
+    // chunk n and land while it runs; the 16-byte records run two chunks ahead.
+    const int ch_end = task.chunk0 + task.nchunks;
+    int ch = task.chunk0;
+    PairChunk ck = chunks[ch];
+    uint4 rr = reinterpret_cast<const uint4*>(recs)[(size_t)ch * 64 + lane];
+    PairData dat;
+    pairs_issue_loads(v, blocks, lmrec, ck, rr, lane, dat);
+    PairChunk ck_next = ck;
+    uint4 rr_next = rr;
+    if (ch + 1 < ch_end) { ck_next = chunks[ch + 1]; rr_next = reinterpret_cast<const uint4*>(recs)[(size_t)(ch + 1) * 64 + lane]; }
+
+    for (; ch < ch_end; ++ch) {
+        // ---- A: the cameras of the chunk's blocks -> LDS (read back by every lane of the block: broadcast) -------------
+        {
             double2* dstc = reinterpret_cast<double2*>(U + lane * kPairCamPitch);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) dstc[k] = src[k];
+            for (int k = 0; k < 8; ++k) dstc[k] = dat.cam[k];
         }
-        const uint4 rr = reinterpret_cast<const uint4*>(recs)[(size_t)ch * 64 + lane];
         const bool valid = rr.x != kPairPad;
-        double u[UV], vv[UV];
-#pragma unroll
-        for (int k = 0; k < UV; ++k) { u[k] = 0.0; vv[k] = 0.0; }
         __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            const double2 uvi = v.o_uv[rr.x], uvj = v.o_uv[rr.y];
+        // ---- B: one pair per lane: both observations linearised, U = Jc_i^T M, V = Jc_j ---------------------------------
+        double u[UV];
+        {
             double Hi[9], pw[3];
-            {
-                const double2* q = reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)rr.z);
-                const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
-                Hi[0] = a0.x; Hi[1] = a0.y; Hi[2] = a1.x; Hi[3] = a1.y; Hi[4] = a2.x; Hi[5] = a2.y; Hi[6] = a3.x; Hi[7] = a3.y;
-                Hi[8] = a4.x; pw[0] = a4.y; pw[1] = a5.x; pw[2] = a5.y;
-            }
+            Hi[0] = dat.lm[0].x; Hi[1] = dat.lm[0].y; Hi[2] = dat.lm[1].x; Hi[3] = dat.lm[1].y; Hi[4] = dat.lm[2].x; Hi[5] = dat.lm[2].y;
+            Hi[6] = dat.lm[3].x; Hi[7] = dat.lm[3].y; Hi[8] = dat.lm[4].x; pw[0] = dat.lm[4].y; pw[1] = dat.lm[5].x; pw[2] = dat.lm[5].y;
+            const uint32_t blk = valid ? rr.w : 0u;
             double N[2][3];
             double Jci[2][DC];
             {
                 Cam cam;
-                const double2* c2 = reinterpret_cast<const double2*>(U + (2 * rr.w) * kPairCamPitch);
+                const double2* c2 = reinterpret_cast<const double2*>(U + (2 * blk) * kPairCamPitch);
                 double cv[16];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 tq = c2[k]; cv[2 * k] = tq.x; cv[2 * k + 1] = tq.y; }
                 load_cam_prepared(cv, cam);
                 double r[2], Jl[2][3];
-                linearize_obs<DC>(cam, pw, uvi.x, uvi.y, v.huber_delta, r, Jci, Jl);
+                linearize_obs<DC>(cam, pw, dat.uvi.x, dat.uvi.y, v.huber_delta, r, Jci, Jl);
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -239,50 +248,78 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
             double M[2][2];
             {
                 Cam cam;
-                const double2* c2 = reinterpret_cast<const double2*>(U + (2 * rr.w + 1) * kPairCamPitch);
+                const double2* c2 = reinterpret_cast<const double2*>(U + (2 * blk + 1) * kPairCamPitch);
                 double cv[16];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 tq = c2[k]; cv[2 * k] = tq.x; cv[2 * k + 1] = tq.y; }
                 load_cam_prepared(cv, cam);
                 double r[2], Jcj[2][DC], Jl[2][3];
-                linearize_obs<DC>(cam, pw, uvj.x, uvj.y, v.huber_delta, r, Jcj, Jl);
+                linearize_obs<DC>(cam, pw, dat.uvj.x, dat.uvj.y, v.huber_delta, r, Jcj, Jl);
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) M[n][m] = -(N[n][0] * Jl[m][0] + N[n][1] * Jl[m][1] + N[n][2] * Jl[m][2]);
+                // V goes to its own LDS region straight away (it never overlaps the staged cameras)
+                double2* pv = reinterpret_cast<double2*>(V + lane * UV);
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int c = 0; c < DC; ++c) vv[m * DC + c] = Jcj[m][c];
+                for (int k = 0; k < DC; ++k) {
+                    const int e0 = 2 * k, e1 = 2 * k + 1;   // element e of V = Jcj[e / DC][e % DC]
+                    const double x0 = valid ? Jcj[e0 / DC][e0 % DC] : 0.0, x1 = valid ? Jcj[e1 / DC][e1 % DC] : 0.0;
+                    pv[k] = make_double2(x0, x1);
+                }
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < DC; ++r) u[m * DC + r] = Jci[0][r] * M[0][m] + Jci[1][r] * M[1][m];
+                for (int r = 0; r < DC; ++r) u[m * DC + r] = valid ? Jci[0][r] * M[0][m] + Jci[1][r] * M[1][m] : 0.0;
         }
         // every lane has read its cameras (program order, one wave): U may now overwrite the staging area
         __builtin_amdgcn_wave_barrier();
         {
             double2* pu = reinterpret_cast<double2*>(U + lane * UV);
-            double2* pv = reinterpret_cast<double2*>(V + lane * UV);
 #pragma unroll
-            for (int k = 0; k < UV / 2; ++k) { pu[k] = make_double2(u[2 * k], u[2 * k + 1]); pv[k] = make_double2(vv[2 * k], vv[2 * k + 1]); }
+            for (int k = 0; k < UV / 2; ++k) pu[k] = make_double2(u[2 * k], u[2 * k + 1]);
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- reduce over the lanes: 32 K-steps of two pairs each --------------------------------------------------
-        uint32_t mask = ck.mask;
-#pragma unroll 4
-        for (int s = 0; s < 32; ++s) {
-            if (mask & 1u) {   // wave-uniform: a new block starts here
-                if (cur >= 0) pairs_flush<DC>(tiles, blocks, cur, acc0 + acc1, kk, r16);
-                cur = cur < 0 ? ck.first_block : cur + 1;
-                acc0 = double4_t{0.0, 0.0, 0.0, 0.0}; acc1 = double4_t{0.0, 0.0, 0.0, 0.0};
+        // ---- D: the next chunk's gathers go out now and land during the matrix-core phase ------------------------------
+        const PairChunk ck_cur = ck;
+        if (ch + 1 < ch_end) {
+            ck = ck_next; rr = rr_next;
+            pairs_issue_loads(v, blocks, lmrec, ck, rr, lane, dat);
+            if (ch + 2 < ch_end) { ck_next = chunks[ch + 2]; rr_next = reinterpret_cast<const uint4*>(recs)[(size_t)(ch + 2) * 64 + lane]; }
+        }
+        // ---- E: reduce over the lanes: 32 K-steps of two pairs each, four at a time --------------------------------------
+        const double* pa = U + aoff;
+        const double* pb = V + aoff;
+        double an[4], bn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { an[k] = pa[k * 2 * UV]; bn[k] = pb[k * 2 * UV]; }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            double a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k] = an[k]; b[k] = bn[k]; }
+            if (g < 7) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { an[k] = pa[((g + 1) * 4 + k) * 2 * UV]; bn[k] = pb[((g + 1) * 4 + k) * 2 * UV]; }
             }
-            mask >>= 1;
-            const double a = U[s * 2 * UV + aoff];
-            const double b = V[s * 2 * UV + aoff];
-            if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
-            else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+            const uint32_t m4 = (ck_cur.mask >> (4 * g)) & 0xFu;
+            if (m4 == 0u) {   // wave-uniform: no block starts inside these four K-steps
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if ((m4 >> k) & 1u) {
+                        if (cur >= 0) pairs_flush<DC>(tiles, blocks, cur, acc0 + acc1, kk, r16);
+                        cur = cur < 0 ? ck_cur.first_block : cur + 1;
+                        acc0 = double4_t{0.0, 0.0, 0.0, 0.0}; acc1 = double4_t{0.0, 0.0, 0.0, 0.0};
+                    }
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], b[k], acc0, 0, 0, 0);
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();   // the next chunk's camera staging overwrites U
     }

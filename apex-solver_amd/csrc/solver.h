@@ -85,6 +85,8 @@ class Solver : public LmBackend {
     bool has_structure() const { return have_structure_; }
     void set_rows_debug(int v) { rows_dbg_ = v; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
+    void set_hubs_last(bool on) { hubs_last_ = on; }
+    int n_hubs() const { return n_hubs_; }
     void set_dist_factor(bool on) { dist_factor_ = on; }   // before set_structure
     void set_tree_sharding(bool on) { tree_sharding_ = on; }  // before set_structure
     void set_dist_selftest(int world) { dist_selftest_ = world; }  // before set_structure; single rank only
@@ -195,6 +197,8 @@ class Solver : public LmBackend {
     int n_tasks_ = 0;
     std::vector<int> cmap_, cinv_;   // external camera -> internal camera and back
     bool use_nd_ = true;
+    bool hubs_last_ = true;     // order cameras covisible with > max(16, 10 sqrt(n_cam)) others last (ba_structure.h)
+    int n_hubs_ = 0, n_border_tiles_ = 1;
     int nd_leaf_ = 16;
     bool dist_factor_ = true;   // world > 1: factorise the elimination tree's subtrees on their owner ranks (tile_plan.h)
     bool tree_sharding_ = true; // ... and give every landmark to the rank whose columns it touches (set_structure)

@@ -1,6 +1,7 @@
 // solver.hip -- host orchestration of the MI355X bundle-adjustment backend (see solver.h).
 #include "solver.h"
 #include "ba_device.hpp"
+#include "ba_structure.h"
 
 #include <math.h>
 #include <string.h>
@@ -151,331 +152,58 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     pose_col_.assign(pose_col, pose_col + n_cam_);
     pt_col_.assign(pt_col, pt_col + n_pt_);
 
-    // ---- internal camera order ---------------------------------------------------------------------
-    // The device numbers cameras in its own order: whole 144-row tiles of cameras are permuted by a
-    // nested-dissection ordering of the tile covisibility graph, which turns the elimination tree of
-    // the tile Cholesky from one long chain (banded S in capture order) into a bushy tree whose
-    // levels factorise in parallel.  cmap_[external camera] = internal camera.
-    n_c_ = n_cam_ * dc_;
-    nt_ = (int)((n_c_ + kNB - 1) / kNB);
-    n_c_pad_ = (int64_t)nt_ * kNB;
-    const int cpt = kNB / dc_;
+    // ---- everything derived from the observation list on the host (ba_structure.h): internal camera order (hub
+    // cameras last, nested dissection of the tile graph), tile structure, landmark sharding, observation lists ------
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    BaStructOptions so;
+    so.dc = dc_; so.use_nd = use_nd_; so.nd_leaf = nd_leaf_; so.hubs_last = hubs_last_;
+    so.rank = rank_; so.world = world_; so.dist_factor = dist_factor_; so.tree_sharding = tree_sharding_;
+    so.dist_selftest = dist_selftest_; so.schur_form = use_rows_ ? rows_form_ : 0;
+    BaHostStructure hs;
     {
-        std::vector<int> tperm(nt_);
-        std::iota(tperm.begin(), tperm.end(), 0);
-        if (use_nd_ && nt_ >= 24) {
-            std::vector<uint8_t> adjm((size_t)nt_ * nt_, 0);
-            std::vector<int64_t> lp(n_pt_ + 1, 0);
-            for (int64_t i = 0; i < n_obs_; ++i) lp[pt_idx[i] + 1]++;
-            for (int64_t l = 0; l < n_pt_; ++l) lp[l + 1] += lp[l];
-            std::vector<int> lt(n_obs_);
-            {
-                std::vector<int64_t> fill(lp.begin(), lp.end() - 1);
-                for (int64_t i = 0; i < n_obs_; ++i) lt[fill[pt_idx[i]]++] = (int)(cam_idx[i] / cpt);
-            }
-            std::vector<int> tl;
-            for (int64_t l = 0; l < n_pt_; ++l) {
-                tl.assign(lt.begin() + lp[l], lt.begin() + lp[l + 1]);
-                std::sort(tl.begin(), tl.end());
-                tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
-                for (size_t a = 0; a < tl.size(); ++a)
-                    for (size_t b = 0; b < a; ++b) { adjm[(size_t)tl[a] * nt_ + tl[b]] = 1; adjm[(size_t)tl[b] * nt_ + tl[a]] = 1; }
-            }
-            // the last tile may be partial (padding rows): it stays last (= eliminated last, no fill)
-            tperm = TilePlan::order(nt_, adjm, true, nd_leaf_);
-        }
-        cmap_.resize(n_cam_);
-        cinv_.assign(n_cam_, -1);
-        for (int64_t c = 0; c < n_cam_; ++c) {
-            cmap_[c] = (int)((int64_t)tperm[c / cpt] * cpt + c % cpt);
-            cinv_[cmap_[c]] = (int)c;
-        }
+        const std::string e = hs.build_lists(n_cam_, n_pt_, n_obs_, cam_idx, pt_idx, obs_uv, so, tp_);
+        if (!e.empty()) return fail(kInvalidInput, e);
     }
-    std::vector<uint32_t> cam_i(n_obs_);
-    for (int64_t i = 0; i < n_obs_; ++i) cam_i[i] = (uint32_t)cmap_[cam_idx[i]];
-
-    // ---- tile structure of S (covisibility at tile granularity) from the FULL problem: identical on all ranks ----
-    std::vector<uint8_t> present((size_t)nt_ * nt_, 0);
-    std::vector<int> lm_owner;   // tree sharding only: owner rank of every landmark
-    lmap_.resize(n_pt_);
-    std::iota(lmap_.begin(), lmap_.end(), 0);
-    tree_shard_ = false;
-    tp_.set_partition(rank_, (dist_factor_ && world_ > 1) ? world_ : 1);
-    tp_.set_own_all(false);
-    if (dist_selftest_ > 1 && world_ == 1) {  // self-test: the distributed schedule for that many ranks, all played by this one
-        tp_.set_partition(0, dist_selftest_);
-        tp_.set_own_all(true);
-        TilePlan::Comm tc;
-        tc.sum = [](double*, size_t, hipStream_t) { return true; };
-        tc.max_int = [](int*, size_t, hipStream_t) { return true; };
-        tp_.set_comm(std::move(tc));
+    n_c_ = hs.n_c; nt_ = hs.nt; n_c_pad_ = hs.n_c_pad;
+    cmap_ = hs.cmap; cinv_ = hs.cinv; lmap_ = hs.lmap;
+    lm_lo_ = hs.lm_lo; lm_hi_ = hs.lm_hi; tree_shard_ = hs.tree_shard; pad_rank_ = hs.pad_rank;
+    n_hubs_ = hs.n_hubs; n_border_tiles_ = hs.n_border_tiles;
+    o_orig_h_ = hs.o_orig;
+    n_pairs_ = hs.n_pairs; n_present_ = hs.n_present;
+    if (lam_mask_) { hipFree(lam_mask_); lam_mask_ = nullptr; }
+    if (tree_shard_) {
+        HIP_TRY(dev_alloc(&lam_mask_, hs.lam_mask.size()));
+        HIP_TRY(hipMemcpy(lam_mask_, hs.lam_mask.data(), hs.lam_mask.size(), hipMemcpyHostToDevice));
     }
-    {
-        std::vector<int64_t> lp(n_pt_ + 1, 0);
-        for (int64_t i = 0; i < n_obs_; ++i) lp[pt_idx[i] + 1]++;
-        for (int64_t l = 0; l < n_pt_; ++l) lp[l + 1] += lp[l];
-        std::vector<int> lt(n_obs_);
-        {
-            std::vector<int64_t> fill(lp.begin(), lp.end() - 1);
-            for (int64_t i = 0; i < n_obs_; ++i) lt[fill[pt_idx[i]]++] = (int)(cam_i[i] / cpt);
-        }
-        std::vector<int> tl;
-        for (int64_t l = 0; l < n_pt_; ++l) {
-            tl.assign(lt.begin() + lp[l], lt.begin() + lp[l + 1]);
-            std::sort(tl.begin(), tl.end());
-            tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
-            for (size_t a = 0; a < tl.size(); ++a)
-                for (size_t b = 0; b <= a; ++b) present[(size_t)tl[a] * nt_ + tl[b]] = 1;
-        }
-        // Tree sharding (distributed Cholesky, no communicator-less test shards): a landmark's cameras form a clique of
-        // S, so their tile columns lie on ONE root path of the elimination tree -- below the shared top they all belong
-        // to one rank.  Giving every landmark to that rank makes the tiles of a rank's own columns COMPLETE locally:
-        // no reduce of S at all, only the top tiles are summed (which the distributed factorisation does anyway).
-        // Landmarks seen by top cameras only go to the least loaded rank.  Landmarks are renumbered so that every
-        // rank's set is one contiguous internal range.
-        const std::vector<int> owner = (world_ > 1 && dist_factor_ && tree_sharding_) ? tp_.preview_owners(nt_, present) : std::vector<int>();
-        if (!owner.empty()) {
-            lm_owner.assign(n_pt_, -1);
-            std::vector<int64_t> load(world_, 0);
-            for (int64_t l = 0; l < n_pt_; ++l) {
-                for (int64_t k = lp[l]; k < lp[l + 1]; ++k)
-                    if (owner[lt[k]] >= 0) { lm_owner[l] = owner[lt[k]]; break; }
-                if (lm_owner[l] >= 0) load[lm_owner[l]] += lp[l + 1] - lp[l];
-            }
-            for (int64_t l = 0; l < n_pt_; ++l)
-                if (lm_owner[l] < 0) {
-                    const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-                    lm_owner[l] = r;
-                    load[r] += lp[l + 1] - lp[l];
-                }
-            std::vector<int64_t> first(world_ + 1, 0);
-            for (int64_t l = 0; l < n_pt_; ++l) first[lm_owner[l] + 1]++;
-            for (int r = 0; r < world_; ++r) first[r + 1] += first[r];
-            lm_lo_ = first[rank_]; lm_hi_ = first[rank_ + 1];
-            for (int64_t l = 0; l < n_pt_; ++l) lmap_[l] = (int)first[lm_owner[l]]++;
-            tree_shard_ = true;
-        }
-    }
-    pad_rank_ = 0;
-    if (tree_shard_) {  // lambda on a camera's diagonal block: by the owner of its column, rank 0 for the shared top
-        const std::vector<int> owner = tp_.preview_owners(nt_, present);
-        // The identity on the padding rows of the last tile follows the same rule: the elimination tree can be a forest
-        // (disconnected covisibility), the last column is then a subtree root below the shared top, and its owner's
-        // copy of the diagonal tile is the only one that is ever factorised.
-        pad_rank_ = owner[nt_ - 1] >= 0 ? owner[nt_ - 1] : 0;
-        std::vector<uint8_t> mask(n_cam_);
-        for (int64_t ci = 0; ci < n_cam_; ++ci) {
-            const int o = owner[ci / cpt];
-            mask[ci] = (o == rank_ || (o < 0 && rank_ == 0)) ? 1 : 0;
-        }
-        if (lam_mask_) { hipFree(lam_mask_); lam_mask_ = nullptr; }
-        HIP_TRY(dev_alloc(&lam_mask_, mask.size()));
-        HIP_TRY(hipMemcpy(lam_mask_, mask.data(), mask.size(), hipMemcpyHostToDevice));
-    }
-    std::vector<uint32_t> pt_i(n_obs_);   // internal landmark index of every observation
-    for (int64_t i = 0; i < n_obs_; ++i) pt_i[i] = (uint32_t)lmap_[pt_idx[i]];
-
-    // ---- landmark-major lists of the FULL problem (tile structure must match on all ranks) ----
-    std::vector<int64_t> full_ptr(n_pt_ + 1, 0);
-    for (int64_t i = 0; i < n_obs_; ++i) full_ptr[pt_i[i] + 1]++;
-    for (int64_t l = 0; l < n_pt_; ++l) full_ptr[l + 1] += full_ptr[l];
-    std::vector<int> full_obs(n_obs_);
-    {
-        std::vector<int64_t> fill(full_ptr.begin(), full_ptr.end() - 1);
-        for (int64_t i = 0; i < n_obs_; ++i) full_obs[fill[pt_i[i]]++] = (int)i;
-    }
-    // ---- shard: contiguous landmark range balanced by observation count (tree sharding: set above) --------
-    if (!tree_shard_) shard_range(n_pt_, full_ptr.data(), rank_, world_, &lm_lo_, &lm_hi_);
-    const int64_t o_lo = full_ptr[lm_lo_], o_hi = full_ptr[lm_hi_];
-    const int64_t n_loc = o_hi - o_lo;
-
-    std::vector<uint32_t> o_cam(n_loc), o_pt(n_loc);
-    std::vector<double> o_uv(2 * n_loc);
-    o_orig_h_.resize(n_loc);
-    std::vector<int> pt_ptr(n_pt_ + 1);
-    for (int64_t l = 0; l <= n_pt_; ++l) {
-        int64_t p = full_ptr[l];
-        p = std::min(std::max(p, o_lo), o_hi) - o_lo;
-        pt_ptr[l] = (int)p;
-    }
-    // inside a landmark the observations are ordered by camera: the partners (cam_j <= cam_i) of an
-    // observation are then a PREFIX of its landmark's list (k_schur_rows)
-    for (int64_t l = lm_lo_; l < lm_hi_; ++l)
-        std::stable_sort(full_obs.begin() + full_ptr[l], full_obs.begin() + full_ptr[l + 1],
-                         [&](int a, int b) { return cam_i[a] < cam_i[b]; });
-    for (int64_t k = 0; k < n_loc; ++k) {
-        const int i = full_obs[o_lo + k];
-        o_orig_h_[k] = i;
-        o_cam[k] = cam_i[i]; o_pt[k] = pt_i[i];
-        o_uv[2 * k] = obs_uv[2 * (int64_t)i]; o_uv[2 * k + 1] = obs_uv[2 * (int64_t)i + 1];
-    }
-    // ---- camera-major lists over the local observations -----------------------------------------
-    std::vector<int> cam_ptr(n_cam_ + 1, 0), cam_obs(n_loc);
-    for (int64_t k = 0; k < n_loc; ++k) cam_ptr[o_cam[k] + 1]++;
-    for (int64_t c = 0; c < n_cam_; ++c) cam_ptr[c + 1] += cam_ptr[c];
-    {
-        std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1);
-        for (int64_t k = 0; k < n_loc; ++k) cam_obs[fill[o_cam[k]]++] = (int)k;
-    }
-
-    // camera-major copies of (landmark, measurement): k_cam_reduce streams them instead of gathering
-    std::vector<uint32_t> co_pt(n_loc);
-    std::vector<double> co_uv(2 * n_loc);
-    std::vector<int> co_rank(n_loc);
-    for (int64_t k = 0; k < n_loc; ++k) {
-        const int i = cam_obs[k];
-        co_pt[k] = o_pt[i]; co_uv[2 * k] = o_uv[2 * (size_t)i]; co_uv[2 * k + 1] = o_uv[2 * (size_t)i + 1];
-        co_rank[k] = i - pt_ptr[o_pt[i]];
-    }
-
     // ---- symbolic Cholesky fill, slot map and task lists of the tile plan -------------
+    const auto t_plan = std::chrono::steady_clock::now();
     tp_.enable_graphs(use_graphs_);
     {
-        const std::string e = tp_.build(nt_, present, stream_);
+        const std::string e = tp_.build(nt_, hs.present, stream_);
         if (!e.empty()) return fail(kInvalidInput, "reduced camera matrix: " + e);
     }
-
-    // ---- Schur-scatter tasks over the local landmarks -----------------------------------------------
-    std::vector<ScatterTask> tasks;
-    n_pairs_ = 0;
-    for (int64_t l = lm_lo_; l < lm_hi_; ++l) { const int64_t k = pt_ptr[l + 1] - pt_ptr[l]; n_pairs_ += k * (k + 1) / 2; }
-    if (!use_rows_) {
-        int cur0 = -1, curn = 0;
-        auto flush = [&]() {
-            if (curn > 0) tasks.push_back({cur0, curn, 0, 0});
-            cur0 = -1; curn = 0;
-        };
-        for (int64_t l = lm_lo_; l < lm_hi_; ++l) {
-            const int b = pt_ptr[l], e = pt_ptr[l + 1], k = e - b;
-            if (k == 0) continue;
-            if (k > kScatterBlk) {
-                flush();
-                const int nb = (k + kScatterBlk - 1) / kScatterBlk;
-                for (int bi = 0; bi < nb; ++bi) {
-                    const int i0 = b + bi * kScatterBlk, ni = std::min(kScatterBlk, e - i0);
-                    tasks.push_back({i0, ni, 0, 0});
-                    for (int bj = bi + 1; bj < nb; ++bj) {
-                        const int j0 = b + bj * kScatterBlk, nj = std::min(kScatterBlk, e - j0);
-                        tasks.push_back({i0, ni, j0, nj});
-                    }
-                }
-                continue;
-            }
-            if (curn + k > kScatterCap) flush();
-            if (curn == 0) cur0 = b;
-            curn += k;
-        }
-        flush();
-    }
-    n_tasks_ = (int)tasks.size();
-
-    // ---- k_schur_rows: neighbour lists (cameras cj <= ci sharing a landmark with ci, from the FULL
-    // problem so that every rank writes the same blocks), per-camera pair batches, row tasks ------------
-    std::vector<int> nbr_ptr(n_cam_ + 1, 0), nbr;
-    const bool lds_rows = use_rows_ && (rows_form_ == 1 || rows_form_ == 2);
-    if (lds_rows) {
-        std::vector<std::vector<int>> lists(n_cam_);
-        std::vector<int> stamp(n_cam_, -1);
-        // camera-major view of the full problem
-        std::vector<int64_t> fcp(n_cam_ + 1, 0);
-        for (int64_t i = 0; i < n_obs_; ++i) fcp[cam_i[i] + 1]++;
-        for (int64_t c = 0; c < n_cam_; ++c) fcp[c + 1] += fcp[c];
-        std::vector<int> fco(n_obs_);
-        {
-            std::vector<int64_t> fill(fcp.begin(), fcp.end() - 1);
-            for (int64_t i = 0; i < n_obs_; ++i) fco[fill[cam_i[i]]++] = (int)i;
-        }
-        for (int64_t c = 0; c < n_cam_; ++c) {
-            auto& L = lists[c];
-            for (int64_t e = fcp[c]; e < fcp[c + 1]; ++e) {
-                const uint32_t l = pt_i[fco[e]];
-                for (int64_t k = full_ptr[l]; k < full_ptr[l + 1]; ++k) {
-                    const int cj = (int)cam_i[full_obs[k]];
-                    if (cj < c && stamp[cj] != (int)c) { stamp[cj] = (int)c; L.push_back(cj); }
-                }
-            }
-            std::sort(L.begin(), L.end());
-            L.push_back((int)c);  // the camera itself closes its list
-            nbr_ptr[c + 1] = nbr_ptr[c] + (int)L.size();
-        }
-        nbr.reserve(nbr_ptr[n_cam_]);
-        for (auto& L : lists) nbr.insert(nbr.end(), L.begin(), L.end());
-    }
-    std::vector<RowBatch> rbatches;
-    std::vector<RowTask> rtasks;
-    std::vector<uint16_t> cam_obs_off(lds_rows && rows_form_ == 1 ? n_loc : 0, 0);
-    if (lds_rows && rows_form_ == 1) {
-        const int cap = (dc_ == 9) ? kRowCap9 : kRowCap6;
-        for (int64_t c = 0; c < n_cam_; ++c) {
-            const int b0 = (int)rbatches.size();
-            RowBatch cur{-1, 0, 0, 0, 0};
-            auto flushb = [&]() { if (cur.count > 0 && cur.total > 0) rbatches.push_back(cur); cur = RowBatch{-1, 0, 0, 0, 0}; };
-            for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
-                const int i_s = cam_obs[e];
-                const int np = i_s - pt_ptr[o_pt[i_s]];  // partners: observations of the landmark before i (cam_j <= cam_i)
-                if (np > kRowBatch) {
-                    flushb();
-                    for (int j0 = 0; j0 < np; j0 += kRowBatch) {
-                        const int n = std::min(kRowBatch, np - j0);
-                        rbatches.push_back(RowBatch{e, 1, j0, n, n});
-                    }
-                    continue;
-                }
-                if (cur.total + np > kRowBatch || cur.count == kRowThreads) flushb();  // one lane expands one observation
-                if (cur.count == 0) cur.first = e;
-                cam_obs_off[e] = (uint16_t)cur.total;
-                cur.count++; cur.total += np;
-            }
-            flushb();
-            const int nb = (int)rbatches.size() - b0;
-            const int n0 = nbr_ptr[c], nn = nbr_ptr[c + 1] - nbr_ptr[c];
-            for (int s0 = 0; s0 < nn; s0 += cap) {
-                const int cnt = std::min(cap, nn - s0);
-                rtasks.push_back(RowTask{(int)c, n0 + s0, cnt, (s0 + cnt == nn) ? 1 : 0, b0, nb});
-            }
-        }
-    }
-    // k_schur_rows2: one entry per observation of a camera (split at kRowMaxPartners partners), sorted by partner
-    // count so that the 64 lanes of a wave loop the same number of times; chunks of <= 64 entries, largest first
-    std::vector<RowEntry> rentries;
-    std::vector<RowChunk> rchunks;
-    std::vector<RowTask> rtasks2;
-    if (lds_rows && rows_form_ == 2) {  // built only when that form is selected (16 bytes per observation)
-        const int cap = (dc_ == 9) ? kRowCap9 : kRowCap6;
-        std::vector<RowEntry> ce;
-        for (int64_t c = 0; c < n_cam_; ++c) {
-            ce.clear();
-            for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
-                const int i_s = cam_obs[e];
-                const int base = pt_ptr[o_pt[i_s]], np = i_s - base;
-                for (int q0 = 0; q0 < np; q0 += kRowMaxPartners)
-                    ce.push_back(RowEntry{e, base + q0, std::min(kRowMaxPartners, np - q0), 0});
-            }
-            std::stable_sort(ce.begin(), ce.end(), [](const RowEntry& a, const RowEntry& b) { return a.n > b.n; });
-            const int c0 = (int)rchunks.size();
-            for (size_t f = 0; f < ce.size(); f += 64) {
-                const int cnt = (int)std::min<size_t>(64, ce.size() - f);
-                rchunks.push_back(RowChunk{(int)(rentries.size() + f), cnt, ce[f].n});
-            }
-            rentries.insert(rentries.end(), ce.begin(), ce.end());
-            const int nc2 = (int)rchunks.size() - c0;
-            const int n0 = nbr_ptr[c], nn = nbr_ptr[c + 1] - nbr_ptr[c];
-            for (int s0 = 0; s0 < nn; s0 += cap) {
-                const int cnt = std::min(cap, nn - s0);
-                rtasks2.push_back(RowTask{(int)c, n0 + s0, cnt, (s0 + cnt == nn) ? 1 : 0, c0, nc2});
-            }
-        }
-    }
-    n_rtasks_ = lds_rows ? (int)(rows_form_ == 2 ? rtasks2.size() : rtasks.size()) : 0;
-    // k_schur_pairs (default): every camera pair (i, j) of a landmark, sorted by the block S(cam_i, cam_j) it adds to
-    PairLists pl;
-    if (use_rows_ && rows_form_ == 3)
-        build_pair_lists(dc_, nt_, tp_.slot_host(), n_cam_, cinv_.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(),
-                         cam_obs.data(), &pl);
-    n_ptasks_ = (int)pl.tasks.size();
-    n_pair_blocks_ = pl.n_blocks; n_pair_slots_ = (int64_t)pl.recs.size();
-    n_present_ = 0;
-    for (uint8_t b : present) n_present_ += b;
+    hs.seconds[2] = since(t_plan);
+    // ---- task lists of the selected form of the Schur reduction (they need the slot map) ------------------------------
+    hs.build_schur_lists(so, tp_.slot_host());
+    hs.release_scratch();
+    n_tasks_ = (int)hs.tasks.size();
+    n_rtasks_ = (int)(so.schur_form == 2 ? hs.rtasks2.size() : hs.rtasks.size());
+    n_ptasks_ = (int)hs.pl.tasks.size();
+    n_pair_blocks_ = hs.pl.n_blocks; n_pair_slots_ = (int64_t)hs.pl.recs.size();
+    const int64_t n_loc = (int64_t)hs.o_cam.size();
+    const auto t_up = std::chrono::steady_clock::now();
+    const std::vector<uint32_t>&o_cam = hs.o_cam, &o_pt = hs.o_pt, &co_pt = hs.co_pt;
+    const std::vector<double>&o_uv = hs.o_uv, &co_uv = hs.co_uv;
+    const std::vector<int>&pt_ptr = hs.pt_ptr, &cam_ptr = hs.cam_ptr, &cam_obs = hs.cam_obs, &co_rank = hs.co_rank, &nbr = hs.nbr;
+    const std::vector<ScatterTask>& tasks = hs.tasks;
+    const std::vector<RowTask>&rtasks = hs.rtasks, &rtasks2 = hs.rtasks2;
+    const std::vector<RowBatch>& rbatches = hs.rbatches;
+    const std::vector<RowChunk>& rchunks = hs.rchunks;
+    const std::vector<RowEntry>& rentries = hs.rentries;
+    const std::vector<uint16_t>& cam_obs_off = hs.cam_obs_off;
+    const PairLists& pl = hs.pl;
+    (void)n_loc;
 
     // ---- uploads ------------------------------------------------------------------------------------
     auto up = [&](auto** dptr, const auto& hv) -> hipError_t {
@@ -549,6 +277,9 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(hipMemset(flags_, 0, 4 * sizeof(int)));
 
     HIP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on stream_
+    hs.seconds[4] = since(t_up);
+    hs.seconds[5] = since(t_begin);
+    for (int k = 0; k < 6; ++k) setup_s_[k] = hs.seconds[k];
 
     have_structure_ = true;
     have_params_ = have_step_ = have_trial_ = false;

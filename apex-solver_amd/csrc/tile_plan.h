@@ -36,12 +36,16 @@ class TilePlan {
     TilePlan& operator=(const TilePlan&) = delete;
 
     // adj: symmetric nt x nt 0/1 adjacency in the CALLER's tile order.  Returns perm[old] = new.
-    // The last tile (it may hold padding rows) stays last.
-    static std::vector<int> order(int nt, const std::vector<uint8_t>& adj, bool nested_dissection, int leaf);
+    // The last n_fixed_last tiles keep their places (the last tile may hold padding rows; a bundle-adjustment problem
+    // also parks its hub cameras there): they are eliminated last and left out of the dissection.
+    static std::vector<int> order(int nt, const std::vector<uint8_t>& adj, bool nested_dissection, int leaf, int n_fixed_last = 1);
 
     // present: lower-triangular nt x nt 0/1 structure (I >= J) in the FINAL order.
     // Returns "" on success or an error message.
     std::string build(int nt, const std::vector<uint8_t>& present, hipStream_t stream);
+    // The host half of build() alone: symbolic fill, partition, slot map, level count (slot_host(), n_slots(),
+    // n_touched_slots(), n_levels(), op_counts() are valid afterwards; nothing is allocated on a device).
+    void build_symbolic(int nt, const std::vector<uint8_t>& present);
 
     // ---- distributed factorisation ----
     struct Comm {  // in-place reductions over the ranks, enqueued on `stream`; false = the collective failed
@@ -107,6 +111,7 @@ class TilePlan {
     hipError_t pcg(const double* rhs, double* x, double* work, int max_iter, double tol, int* iters);
 
    private:
+    std::vector<std::vector<int>> symbolic_slots(const std::vector<uint8_t>& present);
     void enqueue_factor(const double* rhs, double* work, int g0, int g1);
     void enqueue_solve(const double* rhs, double* x, double* work, bool backward_only);
     void launch_fwd_group(int lv, double* bvec, double* yvec, hipStream_t s);

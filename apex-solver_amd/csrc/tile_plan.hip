@@ -78,19 +78,19 @@ static void nested_dissection(const std::vector<std::vector<int>>& adj, std::vec
     out.insert(out.end(), S.begin(), S.end());
 }
 
-std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool nd, int leaf) {
+std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool nd, int leaf, int n_fixed_last) {
     std::vector<int> perm(nt);
     std::iota(perm.begin(), perm.end(), 0);
-    if (!nd || nt < 24) return perm;
-    std::vector<std::vector<int>> adj(nt - 1);
-    for (int a = 0; a < nt - 1; ++a)
-        for (int b = 0; b < nt - 1; ++b)
+    const int nf = nt - std::max(1, std::min(n_fixed_last, nt));   // tiles that take part in the dissection
+    if (!nd || nf < 23) return perm;
+    std::vector<std::vector<int>> adj(nf);
+    for (int a = 0; a < nf; ++a)
+        for (int b = 0; b < nf; ++b)
             if (a != b && adjm[(size_t)a * nt + b]) adj[a].push_back(b);
-    std::vector<int> nodes(nt - 1), ord;
+    std::vector<int> nodes(nf), ord;
     std::iota(nodes.begin(), nodes.end(), 0);
     nested_dissection(adj, nodes, ord, leaf);
     for (int pos = 0; pos < (int)ord.size(); ++pos) perm[ord[pos]] = pos;
-    perm[nt - 1] = nt - 1;
     return perm;
 }
 
@@ -231,11 +231,8 @@ std::vector<int> TilePlan::preview_owners(int nt, const std::vector<uint8_t>& pr
     return n_top_cols_ > 0 ? owner_h_ : std::vector<int>();
 }
 
-std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStream_t stream) {
-    release();
-    nt_ = nt;
-    stream_ = stream;
-    const size_t tile_elems = (size_t)kNB * kNB;
+// host half of build(): symbolic fill, partition, slot map.  Returns the filled column structure.
+std::vector<std::vector<int>> TilePlan::symbolic_slots(const std::vector<uint8_t>& present) {
     std::vector<std::vector<int>> col_rows = symbolic_fill(nt_, present);
     // slots: first every tile the matrix itself touches (diagonal + structural non-zeros), then the
     // tiles that exist only because of fill -- a multi-GPU all-reduce then moves the first group only
@@ -269,6 +266,30 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         }
         if (pass == 0) n_f_nt_ = n_slots_;
     }
+    n_potrf_ = nt_; n_trsm_ = 0; n_upd_ = 0;
+    for (int K = 0; K < nt_; ++K) {
+        n_trsm_ += (int64_t)col_rows[K].size();
+        n_upd_ += (int64_t)col_rows[K].size() * ((int64_t)col_rows[K].size() + 1) / 2;
+    }
+    return col_rows;
+}
+
+void TilePlan::build_symbolic(int nt, const std::vector<uint8_t>& present) {
+    nt_ = nt;
+    const std::vector<std::vector<int>> col_rows = symbolic_slots(present);
+    std::vector<int> level(nt_, 0);
+    for (int K = 0; K < nt_; ++K)
+        if (!col_rows[K].empty()) level[col_rows[K][0]] = std::max(level[col_rows[K][0]], level[K] + 1);
+    n_levels_ = 1 + *std::max_element(level.begin(), level.end());
+    n_local_groups_ = n_levels_;
+}
+
+std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStream_t stream) {
+    release();
+    nt_ = nt;
+    stream_ = stream;
+    const size_t tile_elems = (size_t)kNB * kNB;
+    std::vector<std::vector<int>> col_rows = symbolic_slots(present);
     {
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);

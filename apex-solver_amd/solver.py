@@ -372,6 +372,13 @@ class GpuSchurComplementSolver:
                     n_potrf=int(out[9]), n_trsm=int(out[10]), n_update=int(out[11]),
                     dist_top_columns=int(out[12]), dist_local_fraction=float(out[13]), tree_sharded=bool(out[14]), schur_form=int(out[15]))
 
+    def setup_times(self) -> dict:
+        """Wall time of initialize_structure by phase (seconds) and the counts that go with it."""
+        h = self._need(); sec = (C.c_double * 6)(); cnt = (C.c_double * 4)()
+        h.check(h.L.apexgpu_setup_times(h.h, C.byref(sec), C.byref(cnt)))
+        return dict(order=sec[0], lists=sec[1], tile_plan=sec[2], schur_lists=sec[3], uploads=sec[4], total=sec[5],
+                    hub_cameras=int(cnt[0]), pair_blocks=int(cnt[1]), pair_slots=int(cnt[2]), schur_form=int(cnt[3]))
+
     def set_option(self, name: str, value: int):
         h = self._need(); h.check(h.L.apexgpu_set_option(h.h, name.encode(), int(value)))
 

@@ -159,12 +159,21 @@ def make_problem(
     outlier_frac: float = 0.02,
     name: str = "synthetic",
     behind_frac: float = 0.0,
+    hub_frac: float = 0.0,
+    hub_obs_prob: float = 0.25,
+    long_range_prob: float = 0.0001,
 ) -> BAProblemData:
     """Generate a synthetic BA problem (see module docstring).
 
     `behind_frac` > 0 moves that fraction of the landmarks behind a camera's
     image plane so that the cheirality branch (zero residual and Jacobian,
     projection_factor.rs:227-238) is exercised.
+
+    `hub_frac` > 0 is the NON-BANDED stress variant ("<shape>-hub"): that fraction of the cameras (evenly spread over
+    the ring) are hubs; a landmark anywhere on the ring swaps one of its window cameras for a random hub with
+    probability `hub_obs_prob` (so a hub is covisible with every camera, like the landmark-rich overview photographs of
+    a community collection) and another one for a uniformly random camera with probability `long_range_prob` (random
+    long-range pairs).  Sizes, observation counts and noise are those of the banded shape.
     """
     rng = SplitMix(SEED_BASE + config_id)
     W = min(window, n_cam)
@@ -201,6 +210,23 @@ def make_problem(
     stratum = W // kk
     off = slot * stratum + np.floor(rng.uniform(41, n_obs) * stratum).astype(np.int64)
     cam_idx = (centre[pt_idx] - W // 2 + off) % n_cam
+    if hub_frac > 0.0:
+        n_hub = max(1, int(round(hub_frac * n_cam)))
+        hubs = (np.arange(n_hub, dtype=np.int64) * n_cam) // n_hub + (n_cam // (2 * n_hub))
+        first = pt_ptr[:-1]
+        # slot 0 of a landmark -> a random hub (kept only when the hub is not one of the landmark's cameras already:
+        # window cameras of slots >= 1 lie at least one stratum after slot 0's, so only slot 0's own camera can clash)
+        take = rng.uniform(42, n_pt) < hub_obs_prob
+        hub_pick = hubs[np.minimum((rng.uniform(43, n_pt) * n_hub).astype(np.int64), n_hub - 1)]
+        lo = (centre - W // 2) % n_cam
+        inside = ((hub_pick - lo) % n_cam) < W          # the hub sits inside this landmark's own window: leave it
+        sel = take & ~inside
+        cam_idx[first[sel]] = hub_pick[sel]
+        # slot 1 -> any camera of the ring (a long-range pair), outside the window and not the hub just chosen
+        take2 = (rng.uniform(44, n_pt) < long_range_prob) & (k >= 2)
+        far = np.minimum((rng.uniform(45, n_pt) * n_cam).astype(np.int64), n_cam - 1)
+        ok2 = take2 & (((far - lo) % n_cam) >= W) & (far != cam_idx[first])
+        cam_idx[first[ok2] + 1] = far[ok2]
 
     # --- observations --------------------------------------------------------
     # exact BAL projection of the truth (bal_pinhole.rs:273-296), structure-of-arrays and through
@@ -272,12 +298,13 @@ def make_problem(
 def make_named(shape: str, scale: float = 1.0) -> BAProblemData:
     """One of the BASELINE.json shapes; `scale` < 1 shrinks cameras and landmarks
     proportionally (same generator, same per-landmark statistics)."""
-    cid, n_cam, n_pt, k_lo, k_hi = SHAPES[shape]
+    hub = shape.endswith("-hub")
+    cid, n_cam, n_pt, k_lo, k_hi = SHAPES[shape[:-4] if hub else shape]
     if scale != 1.0:
         n_cam = max(8, int(round(n_cam * scale)))
         n_pt = max(16, int(round(n_pt * scale)))
     nm = shape if scale == 1.0 else f"{shape}@{scale:g}"
-    return make_problem(n_cam, n_pt, k_lo, k_hi, config_id=cid, name=nm)
+    return make_problem(n_cam, n_pt, k_lo, k_hi, config_id=cid, name=nm, hub_frac=0.015 if hub else 0.0)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -212,6 +212,8 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "fused_forward" (0)  run the forward triangular sweep inside the factorisation graph on a third stream
  *   "nested_dissection" (1)  order camera tiles by nested dissection (call before set_structure);
  *                     0 keeps the caller's camera order, a value > 1 sets the leaf size in tiles
+ *   "hubs_last" (1)   order cameras that are covisible with more than max(16, 10 sqrt(n_cam)) others after all the
+ *                     others (a dense border of S instead of dense rows everywhere), before set_structure
  *   "dist_factor" (1), "tree_sharding" (1)  multi-GPU only, before set_structure: see the multi-GPU section
  *   "dist_selftest" (0)  single rank, before set_structure: cut the elimination tree as for that many ranks and run
  *                     the distributed schedule (own levels, top levels, phased triangular sweeps) with this rank
@@ -234,6 +236,10 @@ int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_
  * operations below them (1 when not distributed), [14] = 1 when the landmarks are sharded by the elimination tree,
  * [15] = form of the Schur reduction in use ("schur_rows") */
 int apexgpu_info(apexgpu_solver* h, double info[16]);
+/* Wall time of the last apexgpu_set_structure by phase, seconds[6] = {camera order + tile structure, landmark sharding +
+ * observation lists, tile plan (symbolic fill, task lists, allocation), lists of the Schur reduction, uploads, total};
+ * counts[4] (may be NULL) = {hub cameras ordered last, camera-pair blocks, pair slots incl. padding, Schur form}. */
+int apexgpu_setup_times(apexgpu_solver* h, double seconds[6], double counts[4]);
 
 /* ---- multi-GPU: one process per GPU, landmarks sharded, RCCL all-reduce of S and g_red -----------
  * apexgpu_get_unique_id fills 128 bytes on rank 0; broadcast them (any transport) and call
@@ -269,6 +275,15 @@ int apexgpu_debug_partition(int nt, const uint8_t* present, int world, int* owne
  * padding), chunks2 [chunks][2] = {K-step mask of block starts, first block}, blocks4 [blocks][4] = {offset of
  * S(ci, cj) in the tile storage, ci, cj, flags}, tasks2 [tasks][2] = {first chunk, chunks}; o_index[n_obs]: caller's index
  * of landmark-major observation k (what i / j count in). */
+/* Host arithmetic only: the whole host half of apexgpu_set_structure for rank `rank` of `world` (camera order with hub
+ * cameras last, nested dissection, symbolic fill, partition of the elimination tree, landmark sharding, Schur lists).
+ * opts[5] = {nested_dissection, hubs_last, dist_factor, tree_sharding, schur_form}; stats_out[16] = {tile rows, hub
+ * cameras, border tiles, tiles S touches, tiles after fill, elimination-tree levels, shared top columns, tree sharded,
+ * seconds[6] as apexgpu_setup_times (device phases 0), pair contributions, camera-pair blocks}; cmap_out[n_cam],
+ * owned_out[n_pt], tile_owner_out[tile rows] may be NULL. */
+int apexgpu_debug_host_structure(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, const uint32_t* cam_idx,
+                                 const uint32_t* pt_idx, int rank, int world, const int opts[5], double stats_out[16],
+                                 int32_t* cmap_out, uint8_t* owned_out, int32_t* tile_owner_out);
 int apexgpu_debug_pair_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc, const uint32_t* cam_idx, const uint32_t* pt_idx,
                              int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
                              int32_t* tasks2_out, int32_t* o_index_out);

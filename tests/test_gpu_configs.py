@@ -122,7 +122,8 @@ def oracle_sample_check(oracle, shape, scale, mode, variant=0, cg=None):
         assert abs(it_g - it_o) <= max(3, it_o // 4)
         assert r_gpu < 10 * max(r_ora, cg[1] * max(np.linalg.norm(ogred), 1.0))
     o.apply_step(ostep if variant == 0 else istep, 1.0)
-    assert s.eval_step() == pytest.approx(o.residuals()[0], rel=1e-6)
+    # (two PCG runs that stop at the same tolerance still differ by that tolerance's worth of step)
+    assert s.eval_step() == pytest.approx(o.residuals()[0], rel=1e-6 if variant == 0 else 1e-4)
     s.close()
 
 
