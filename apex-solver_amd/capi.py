@@ -23,7 +23,7 @@ SYMBOLS = (
     "apexgpu_set_cg_params", "apexgpu_set_params", "apexgpu_get_params", "apexgpu_cost", "apexgpu_assemble", "apexgpu_solve_augmented",
     "apexgpu_step_stats", "apexgpu_eval_step", "apexgpu_commit_step", "apexgpu_discard_step",
     "apexgpu_parameter_norm", "apexgpu_column_norms", "apexgpu_set_column_scaling", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
-    "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_debug_invert_blocks", "apexgpu_debug_pair_lists", "apexgpu_debug_host_structure", "apexgpu_setup_times", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
+    "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_get_hessian_csc", "apexgpu_debug_invert_blocks", "apexgpu_debug_pair_lists", "apexgpu_debug_host_structure", "apexgpu_setup_times", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
     "apexgpu_stage_times", "apexgpu_info", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_set_shard", "apexgpu_shard_range",
     "apexgpu_debug_lockstep_solve", "apexgpu_export_step", "apexgpu_owned_landmarks", "apexgpu_debug_partition",
     "apexgpu_bal_open", "apexgpu_bal_close", "apexgpu_bal_last_error", "apexgpu_bal_sizes", "apexgpu_bal_raw",
@@ -128,6 +128,7 @@ def load() -> C.CDLL:
     L.apexgpu_get_landmark_blocks.argtypes = [vp, vp, vp]
     L.apexgpu_schur_matvec.argtypes = [vp, dbl, vp, vp, vp]
     L.apexgpu_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.apexgpu_get_hessian_csc.argtypes = [vp, vp, vp, vp, vp]
     L.apexgpu_debug_invert_blocks.argtypes = [C.c_int, C.c_int64, vp, vp, vp]
     L.apexgpu_debug_host_structure.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.apexgpu_setup_times.argtypes = [vp, vp, vp]

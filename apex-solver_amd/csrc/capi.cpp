@@ -139,6 +139,11 @@ int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out, double* gl_
     return guarded([&] { return h->s->get_landmark_blocks(hinv_out, gl_out); });
 }
 
+int apexgpu_get_hessian_csc(apexgpu_solver* h, int64_t* nnz_out, int64_t* colptr_out, int64_t* rowidx_out, double* values_out) {
+    H_OR_FAIL;
+    return guarded([&] { return h->s->get_hessian_csc(nnz_out, colptr_out, rowidx_out, values_out); });
+}
+
 int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, double* y_explicit, double* y_implicit) {
     H_OR_FAIL;
     if (!x_in) return APEXGPU_ERR_INVALID_INPUT;

@@ -69,6 +69,10 @@ class Solver : public LmBackend {
     int get_jacobian_blocks(double* jc_out, double* jl_out);
     int get_schur(double* S_out, double* gred_out);  // reference camera-side order, dense
     int get_landmark_blocks(double* hinv_out, double* gl_out);
+    // H = J^T J of the corrected Jacobian at the current parameters as a full symmetric CSC matrix in the global column
+    // order (what SparseSchurComplementSolver::get_hessian caches, explicit_schur.rs:1146-1160, 1236-1238).  Two-call
+    // pattern: with colptr == NULL only *nnz_out is set.
+    int get_hessian_csc(int64_t* nnz_out, int64_t* colptr, int64_t* rowidx, double* values);
     int schur_matvec(double lambda, const double* x_in, double* y_explicit, double* y_implicit);
     int64_t tile_count() const { return tp_.n_slots(); }
     int n_tile_rows() const { return nt_; }
@@ -156,6 +160,7 @@ class Solver : public LmBackend {
     // host copies
     std::vector<int64_t> intr_col_, pose_col_, pt_col_;
     std::vector<int> o_orig_h_;
+    std::vector<uint32_t> cam_idx_h_, pt_idx_h_;   // the caller's factor list (kept for the Hessian export)
 
     // device
     hipStream_t stream_ = nullptr;

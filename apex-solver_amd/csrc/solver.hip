@@ -151,6 +151,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     intr_col_.assign(intr_col, intr_col + n_cam_);
     pose_col_.assign(pose_col, pose_col + n_cam_);
     pt_col_.assign(pt_col, pt_col + n_pt_);
+    cam_idx_h_.assign(cam_idx, cam_idx + n_obs_);
+    pt_idx_h_.assign(pt_idx, pt_idx + n_obs_);
 
     // ---- everything derived from the observation list on the host (ba_structure.h): internal camera order (hub
     // cameras last, nested dissection of the tile graph), tile structure, landmark sharding, observation lists ------
@@ -1055,6 +1057,95 @@ int Solver::schur_matvec(double lambda, const double* x_in, double* y_explicit, 
             for (int64_t c = 0; c < n_cam_; ++c)
                 for (int a = 0; a < 3; ++a) out[intr_col_[c] + a] = lambda * x_in[intr_col_[c] + a];
     }
+    return kOk;
+}
+
+// get_hessian (explicit_schur.rs:1236-1238): H = J^T J, undamped, full symmetric, CSC in the global column order.  The
+// device never forms it; this export rebuilds it on the host from the per-factor blocks the device linearises (an
+// observer / DogLeg path, not the hot path): structural entries of every factor are kept even when a block is zero
+// (a point behind its camera), as the reference's sparse product keeps them.
+int Solver::get_hessian_csc(int64_t* nnz_out, int64_t* colptr, int64_t* rowidx, double* values) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    if (world_ > 1) return fail(kInvalidState, "the Hessian export is single-rank");
+    if (!nnz_out) return fail(kInvalidInput, "nnz_out is NULL");
+    const int64_t total = 9 * n_cam_ + 3 * n_pt_;
+    // unique (camera, landmark) couplings and the variables that carry entries
+    std::vector<int64_t> order(n_obs_);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        return pt_idx_h_[a] != pt_idx_h_[b] ? pt_idx_h_[a] < pt_idx_h_[b] : cam_idx_h_[a] < cam_idx_h_[b];
+    });
+    std::vector<uint8_t> cam_seen(n_cam_, 0), pt_seen(n_pt_, 0);
+    int64_t n_cl = 0;
+    for (int64_t k = 0; k < n_obs_; ++k) {
+        const int64_t i = order[k];
+        cam_seen[cam_idx_h_[i]] = 1; pt_seen[pt_idx_h_[i]] = 1;
+        if (k == 0 || pt_idx_h_[i] != pt_idx_h_[order[k - 1]] || cam_idx_h_[i] != cam_idx_h_[order[k - 1]]) ++n_cl;
+    }
+    int64_t nnz = 2 * n_cl * dc_ * 3;
+    for (int64_t c = 0; c < n_cam_; ++c) if (cam_seen[c]) nnz += dc_ * dc_;
+    for (int64_t l = 0; l < n_pt_; ++l) if (pt_seen[l]) nnz += 9;
+    *nnz_out = nnz;
+    if (!colptr) return kOk;
+    if (!rowidx || !values) return fail(kInvalidInput, "rowidx / values are NULL");
+    std::vector<double> jc((size_t)2 * dc_ * n_obs_), jl((size_t)6 * n_obs_);
+    int rc = get_jacobian_blocks(jc.data(), jl.data());
+    if (rc != kOk) return rc;
+    auto cam_col = [&](int64_t c, int a) -> int64_t { return a < 6 ? pose_col_[c] + a : intr_col_[c] + (a - 6); };
+    struct Trip { int64_t col, row; double v; };
+    std::vector<Trip> t;
+    t.reserve((size_t)nnz);
+    {   // camera blocks
+        std::vector<double> hcc((size_t)n_cam_ * dc_ * dc_, 0.0);
+        for (int64_t i = 0; i < n_obs_; ++i) {
+            const double* J = jc.data() + (size_t)2 * dc_ * i;
+            double* H = hcc.data() + (size_t)cam_idx_h_[i] * dc_ * dc_;
+            for (int a = 0; a < dc_; ++a)
+                for (int b = 0; b < dc_; ++b) H[a * dc_ + b] += J[a] * J[b] + J[dc_ + a] * J[dc_ + b];
+        }
+        for (int64_t c = 0; c < n_cam_; ++c)
+            if (cam_seen[c])
+                for (int a = 0; a < dc_; ++a)
+                    for (int b = 0; b < dc_; ++b) t.push_back({cam_col(c, b), cam_col(c, a), hcc[(size_t)c * dc_ * dc_ + a * dc_ + b]});
+    }
+    {   // landmark blocks
+        std::vector<double> hll((size_t)n_pt_ * 9, 0.0);
+        for (int64_t i = 0; i < n_obs_; ++i) {
+            const double* J = jl.data() + (size_t)6 * i;
+            double* H = hll.data() + (size_t)pt_idx_h_[i] * 9;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) H[3 * a + b] += J[a] * J[b] + J[3 + a] * J[3 + b];
+        }
+        for (int64_t l = 0; l < n_pt_; ++l)
+            if (pt_seen[l])
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) t.push_back({pt_col_[l] + b, pt_col_[l] + a, hll[(size_t)l * 9 + 3 * a + b]});
+    }
+    {   // couplings, duplicated (camera, landmark) factors merged
+        std::vector<double> w((size_t)dc_ * 3);
+        for (int64_t k = 0; k < n_obs_;) {
+            const int64_t i0 = order[k];
+            const uint32_t c = cam_idx_h_[i0], l = pt_idx_h_[i0];
+            std::fill(w.begin(), w.end(), 0.0);
+            for (; k < n_obs_ && cam_idx_h_[order[k]] == c && pt_idx_h_[order[k]] == l; ++k) {
+                const double* Jc = jc.data() + (size_t)2 * dc_ * order[k];
+                const double* Jl = jl.data() + (size_t)6 * order[k];
+                for (int a = 0; a < dc_; ++a)
+                    for (int b = 0; b < 3; ++b) w[a * 3 + b] += Jc[a] * Jl[b] + Jc[dc_ + a] * Jl[3 + b];
+            }
+            for (int a = 0; a < dc_; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    t.push_back({pt_col_[l] + b, cam_col(c, a), w[a * 3 + b]});
+                    t.push_back({cam_col(c, a), pt_col_[l] + b, w[a * 3 + b]});
+                }
+        }
+    }
+    if ((int64_t)t.size() != nnz) return fail(kInvalidState, "Hessian export: entry count mismatch");
+    std::sort(t.begin(), t.end(), [](const Trip& a, const Trip& b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
+    std::fill(colptr, colptr + total + 1, 0);
+    for (const Trip& e : t) colptr[e.col + 1]++;
+    for (int64_t j = 0; j < total; ++j) colptr[j + 1] += colptr[j];
+    for (int64_t k = 0; k < nnz; ++k) { rowidx[k] = t[k].row; values[k] = t[k].v; }
     return kOk;
 }
 

@@ -358,6 +358,18 @@ class GpuSchurComplementSolver:
         h.check(h.L.apexgpu_schur_matvec(h.h, float(lam), capi.ptr(x), capi.ptr(ye), capi.ptr(yi)))
         return ye, yi
 
+    def get_hessian(self):
+        """LinearSolver::get_hessian: H = J^T J (undamped) as a scipy.sparse.csc_matrix in the global column order."""
+        import scipy.sparse as sp
+
+        h = self._need()
+        nnz = C.c_int64(0)
+        h.check(h.L.apexgpu_get_hessian_csc(h.h, C.byref(nnz), None, None, None))
+        n = self._problem.total_dof
+        colptr = np.zeros(n + 1, dtype=np.int64); rowidx = np.zeros(nnz.value, dtype=np.int64); vals = np.zeros(nnz.value)
+        h.check(h.L.apexgpu_get_hessian_csc(h.h, C.byref(nnz), capi.ptr(colptr), capi.ptr(rowidx), capi.ptr(vals)))
+        return sp.csc_matrix((vals, rowidx, colptr), shape=(n, n))
+
     def get_landmark_blocks(self):
         h = self._need()
         hi = np.zeros((h.n_pt, 3, 3)); gl = np.zeros((h.n_pt, 3))

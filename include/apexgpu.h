@@ -187,6 +187,13 @@ int apexgpu_get_landmark_blocks(apexgpu_solver* h, double* hinv_out /* n_pt*9 */
  * the landmark-reduce kernel applies it, run on GPU `device` over n caller-supplied symmetric 3x3 blocks (row-major).
  * ok_out[i] = 0 where the (regularised) block has a zero determinant (LinAlgError::SingularMatrix). */
 int apexgpu_debug_invert_blocks(int device, int64_t n, const double* blocks9, double* inv9_out, int32_t* ok_out);
+/* LinearSolver::get_hessian (src/linalg/mod.rs:158; SparseSchurComplementSolver caches it, explicit_schur.rs:1146-1160,
+ * 1236-1238; consumed by the observers, src/optimizer/mod.rs:701-720, and by DogLeg): H = J^T J of the corrected
+ * Jacobian at the current parameters -- undamped, full symmetric, CSC, global column order, total_dof = 9 n_cam + 3 n_pt
+ * columns (the intrinsics' columns are empty in BundleAdjustment mode).  The device never forms H: this export
+ * rebuilds it from the per-factor blocks, on demand.  Two calls: with colptr_out == NULL only *nnz_out is written;
+ * then colptr_out[total_dof + 1], rowidx_out[nnz], values_out[nnz]. */
+int apexgpu_get_hessian_csc(apexgpu_solver* h, int64_t* nnz_out, int64_t* colptr_out, int64_t* rowidx_out, double* values_out);
 /* y = S x at the current parameters through both implementations of the reduced camera matrix: the explicit tiles
  * (compute_schur_complement, explicit_schur.rs:771-925) and the matrix-free operator (apply_schur_operator_fast,
  * implicit_schur.rs:163-251).  x_in and the outputs have 9 n_cam entries in the reference's camera-side column
