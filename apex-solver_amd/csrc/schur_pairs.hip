@@ -8,7 +8,6 @@
 
 namespace apex {
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kPairTaskSlots = 768;      // a wave's task is closed once it holds this many slots (12 chunks)
 constexpr int kPairMaxBlockSlots = 8192; // a block with more slots is split over several waves (atomic flush)
@@ -128,30 +127,77 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
 // ------------------------------------------------------------------------------------------------------------------
 // device
 // ------------------------------------------------------------------------------------------------------------------
+// Branch-free linearisation for this kernel: same formulas as linearize_obs (ba_device.hpp), with the division and the
+// Huber weight on the reciprocal / reciprocal-square-root units refined by Newton steps (full double precision, a
+// quarter of the instructions of the IEEE sequences) and the cheirality test as a select -- the 64 lanes of a wave
+// linearise 64 different observations and must not serialise on each other's branches.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {   // x > 0
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    return y;
+}
+
+// J = [Jl | -Jl [pw]x | e] scaled by the Huber weight (0 for a point behind the camera): Jl 2x3, the rest derived
 template <int DC>
-__device__ __forceinline__ void pairs_flush(double* __restrict__ tiles, const PairBlock* __restrict__ blocks, int b,
-                                            const double4_t acc, int row0, int col) {
-    const PairBlock pb = blocks[b];
-    double* dst = tiles + pb.dst;
-    if (col >= DC) return;
+__device__ __forceinline__ void linearize_pairside(const double* __restrict__ cv, const double pw[3], double u_obs, double v_obs,
+                                                   double huber_delta, double Jc[2][DC], double Jl[2][3]) {
+    const double pcx = cv[0] * pw[0] + cv[1] * pw[1] + cv[2] * pw[2] + cv[9];
+    const double pcy = cv[3] * pw[0] + cv[4] * pw[1] + cv[5] * pw[2] + cv[10];
+    const double pcz = cv[6] * pw[0] + cv[7] * pw[1] + cv[8] * pw[2] + cv[11];
+    const bool ok = pcz < -kMinDepth;
+    const double f = cv[12], k1 = cv[13], k2 = cv[14];
+    const double inz = -fast_rcp(ok ? pcz : -1.0);
+    const double xn = pcx * inz, yn = pcy * inz;
+    const double r2 = xn * xn + yn * yn, r4 = r2 * r2;
+    const double dist = 1.0 + k1 * r2 + k2 * r4;
+    const double r0 = f * (xn * dist) - u_obs, r1 = f * (yn * dist) - v_obs;
+    const double sn = r0 * r0 + r1 * r1;
+    // Huber: sqrt(rho') = sqrt(delta / sqrt(s)) for s > delta^2, else 1 (corrector.rs:156-162)
+    double w = 1.0;
+    {
+        const bool out = huber_delta > 0.0 && sn > huber_delta * huber_delta;
+        const double ss = out ? sn : 1.0;
+        const double t = huber_delta * fast_rsqrt(ss);      // delta / sqrt(s)
+        const double wq = t * fast_rsqrt(t);                // sqrt(t)
+        w = out ? wq : 1.0;
+    }
+    w = ok ? w : 0.0;
+    const double dd = k1 + 2.0 * k2 * r2;
+    const double dxn_dz = xn * inz, dyn_dz = yn * inz;
+    const double dxd_dxn = dist + xn * dd * 2.0 * xn, dxd_dyn = xn * dd * 2.0 * yn;
+    const double dyd_dxn = yn * dd * 2.0 * xn, dyd_dyn = dist + yn * dd * 2.0 * yn;
+    const double fw = f * w;
+    double Jp[2][3];
+    Jp[0][0] = fw * (dxd_dxn * inz); Jp[0][1] = fw * (dxd_dyn * inz); Jp[0][2] = fw * (dxd_dxn * dxn_dz + dxd_dyn * dyn_dz);
+    Jp[1][0] = fw * (dyd_dxn * inz); Jp[1][1] = fw * (dyd_dyn * inz); Jp[1][2] = fw * (dyd_dxn * dxn_dz + dyd_dyn * dyn_dz);
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int row = row0 + 4 * reg;
-        if (row >= DC) continue;
-        const double val = acc[reg];
-        if (pb.flags == 0) {
-            dst[row * kNB + col] = val;
-        } else if (pb.flags & kPairBlockDiag) {   // B + B^T, kept in the lower triangle of the diagonal block
-            if (row >= col) unsafeAtomicAdd(&dst[row * kNB + col], val);
-            if (col >= row) unsafeAtomicAdd(&dst[col * kNB + row], val);
-        } else {
-            unsafeAtomicAdd(&dst[row * kNB + col], val);
-        }
+    for (int rr = 0; rr < 2; ++rr) {
+        const double a0 = Jp[rr][0] * cv[0] + Jp[rr][1] * cv[3] + Jp[rr][2] * cv[6];
+        const double a1 = Jp[rr][0] * cv[1] + Jp[rr][1] * cv[4] + Jp[rr][2] * cv[7];
+        const double a2 = Jp[rr][0] * cv[2] + Jp[rr][1] * cv[5] + Jp[rr][2] * cv[8];
+        Jl[rr][0] = a0; Jl[rr][1] = a1; Jl[rr][2] = a2;
+        Jc[rr][0] = a0; Jc[rr][1] = a1; Jc[rr][2] = a2;
+        Jc[rr][3] = a2 * pw[1] - a1 * pw[2];
+        Jc[rr][4] = a0 * pw[2] - a2 * pw[0];
+        Jc[rr][5] = a1 * pw[0] - a0 * pw[1];
+    }
+    if (DC == 9) {
+        const double xw = xn * w, yw = yn * w, fr2 = f * r2, fr4 = f * r4;
+        Jc[0][DC - 3] = xw * dist; Jc[0][DC - 2] = xw * fr2; Jc[0][DC - 1] = xw * fr4;
+        Jc[1][DC - 3] = yw * dist; Jc[1][DC - 2] = yw * fr2; Jc[1][DC - 1] = yw * fr4;
     }
 }
 
-// The data one lane needs for its pair, fetched one chunk AHEAD (while the previous chunk's sums run on the matrix
-// cores): both measurements, Hll^-1 and the point, and -- in the first 2 nblk lanes -- one camera of the chunk's blocks.
+// The data one lane needs for its pair, fetched one chunk AHEAD (while the previous chunk's block products run): both
+// measurements, Hll^-1 and the point, and -- in the first 2 nblk lanes -- one camera of the chunk's blocks.
 struct PairData {
     double2 uvi, uvj;
     double2 lm[6];
@@ -177,12 +223,56 @@ __device__ __forceinline__ void pairs_issue_loads(const BAView& v, const PairBlo
     for (int k = 0; k < 8; ++k) d.cam[k] = src[k];
 }
 
+// Sum of the lane groups' partial blocks and the ONE store of S(ci, cj).  Lane L = 9 g + sub (DC = 9; 4 g + sub for DC = 6)
+// holds the 3 x 3 sub-block (bi, bj) = (sub / NB3, sub % NB3) of group g's partial sum.
+template <int DC>
+__device__ __forceinline__ void pairs_flush(double* __restrict__ tiles, const PairBlock* __restrict__ blocks, int b,
+                                            double acc[9], int lane) {
+    constexpr int NB3 = DC / 3, GL = NB3 * NB3;
+    constexpr int NG = (DC == 9) ? 7 : 16, P2 = (DC == 9) ? 8 : 16;
+    const int g = lane / GL;
+    // groups g >= 1 fold into group 0 in log2 steps (a group beyond the last one contributes nothing)
+#pragma unroll
+    for (int st = P2 / 2; st >= 1; st >>= 1) {
+        const bool take = g < st && g + st < NG;
+        const int src = take ? lane + st * GL : lane;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const double other = __shfl(acc[k], src, 64);
+            if (take) acc[k] += other;
+        }
+    }
+    if (lane < GL) {
+        const PairBlock pb = blocks[b];
+        double* dst = tiles + pb.dst;
+        const int bi = lane / NB3, bj = lane % NB3;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int row = 3 * bi + r, col = 3 * bj + c;
+                const double val = acc[3 * r + c];
+                if (pb.flags == 0) {
+                    dst[row * kNB + col] = val;
+                } else if (pb.flags & kPairBlockDiag) {   // B + B^T, kept in the lower triangle of the diagonal block
+                    if (row >= col) unsafeAtomicAdd(&dst[row * kNB + col], val);
+                    if (col >= row) unsafeAtomicAdd(&dst[col * kNB + row], val);
+                } else {
+                    unsafeAtomicAdd(&dst[row * kNB + col], val);
+                }
+            }
+    }
+}
+
 template <int DC>
 __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restrict__ tiles, const PairTask* __restrict__ tasks,
                                                        int n_tasks, const PairChunk* __restrict__ chunks,
                                                        const PairBlock* __restrict__ blocks, const PairRec* __restrict__ recs,
                                                        const double* __restrict__ lmrec) {
     constexpr int UV = 2 * DC;                    // doubles of U (and of V) per pair
+    constexpr int NB3 = DC / 3;                   // 3 x 3 sub-blocks per block edge
+    constexpr int GL = NB3 * NB3;                 // lanes of one group = sub-blocks of a block (9 / 4)
+    constexpr int NG = (DC == 9) ? 7 : 16;        // lane groups that split a segment's pairs (63 / 64 lanes busy)
     constexpr int REG_A = 64 * kPairCamPitch;     // U[64][UV] overlays the staged cameras (64 x 18 doubles >= 64 x UV)
     constexpr int WAVE_LDS = REG_A + 64 * UV;     // | V[64][UV]
     static_assert(64 * UV <= REG_A, "U must fit the camera staging area");
@@ -194,15 +284,17 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
     double* U = lds_all + w * WAVE_LDS;
     double* V = U + REG_A;
     const PairTask task = tasks[t];
-    const int r16 = lane & 15, kk = lane >> 4;
-    // operand element of this lane for K-step s: U[(2s + (kk >> 1)) * UV + (kk & 1) * DC + r] = U[s * 2 UV + kk DC + r].
-    // Rows / columns >= DC of the 16 x 16 product are never stored, so those lanes may read anything (clamped index).
-    const int aoff = kk * DC + (r16 < DC ? r16 : DC - 1);
-    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // product phase: lane = (group g, sub-block (bi, bj)); U and V are stored per pair as [sub-row][m][3] so that a lane's
+    // six U values (and six V values) are 48 contiguous, 16-byte aligned bytes
+    const int g = lane / GL, sub = lane - g * GL, bi = sub / NB3, bj = sub - bi * NB3;
+    const bool worker = g < NG;
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
     int cur = -1;
 
-    // Software pipeline over the task's chunks: the gathers of chunk n+1 are issued before the matrix-core phase of
-    // chunk n and land while it runs; the 16-byte records run two chunks ahead.
+    // Software pipeline over the task's chunks: the gathers of chunk n+1 are issued before the product phase of chunk n
+    // and land while it runs; the 16-byte records run two chunks ahead.
     const int ch_end = task.chunk0 + task.nchunks;
     int ch = task.chunk0;
     PairChunk ck = chunks[ch];
@@ -232,14 +324,12 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
             double N[2][3];
             double Jci[2][DC];
             {
-                Cam cam;
                 const double2* c2 = reinterpret_cast<const double2*>(U + (2 * blk) * kPairCamPitch);
                 double cv[16];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 tq = c2[k]; cv[2 * k] = tq.x; cv[2 * k + 1] = tq.y; }
-                load_cam_prepared(cv, cam);
-                double r[2], Jl[2][3];
-                linearize_obs<DC>(cam, pw, dat.uvi.x, dat.uvi.y, v.huber_delta, r, Jci, Jl);
+                double Jl[2][3];
+                linearize_pairside<DC>(cv, pw, dat.uvi.x, dat.uvi.y, v.huber_delta, Jci, Jl);
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -247,31 +337,32 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
             }
             double M[2][2];
             {
-                Cam cam;
                 const double2* c2 = reinterpret_cast<const double2*>(U + (2 * blk + 1) * kPairCamPitch);
                 double cv[16];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 tq = c2[k]; cv[2 * k] = tq.x; cv[2 * k + 1] = tq.y; }
-                load_cam_prepared(cv, cam);
-                double r[2], Jcj[2][DC], Jl[2][3];
-                linearize_obs<DC>(cam, pw, dat.uvj.x, dat.uvj.y, v.huber_delta, r, Jcj, Jl);
+                double Jcj[2][DC], Jl[2][3];
+                linearize_pairside<DC>(cv, pw, dat.uvj.x, dat.uvj.y, v.huber_delta, Jcj, Jl);
+                const double sgn = valid ? -1.0 : 0.0;     // a padding slot contributes U = 0
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) M[n][m] = -(N[n][0] * Jl[m][0] + N[n][1] * Jl[m][1] + N[n][2] * Jl[m][2]);
-                // V goes to its own LDS region straight away (it never overlaps the staged cameras)
+                    for (int m = 0; m < 2; ++m) M[n][m] = sgn * (N[n][0] * Jl[m][0] + N[n][1] * Jl[m][1] + N[n][2] * Jl[m][2]);
+                // V goes to its own LDS region straight away (it never overlaps the staged cameras); element order
+                // [sub-column bj][m][3]: V[m][3 bj + c]
                 double2* pv = reinterpret_cast<double2*>(V + lane * UV);
 #pragma unroll
                 for (int k = 0; k < DC; ++k) {
-                    const int e0 = 2 * k, e1 = 2 * k + 1;   // element e of V = Jcj[e / DC][e % DC]
-                    const double x0 = valid ? Jcj[e0 / DC][e0 % DC] : 0.0, x1 = valid ? Jcj[e1 / DC][e1 % DC] : 0.0;
-                    pv[k] = make_double2(x0, x1);
+                    const int e0 = 2 * k, e1 = 2 * k + 1;
+                    const int s0 = e0 / 6, m0 = (e0 % 6) / 3, c0 = e0 % 3, s1 = e1 / 6, m1 = (e1 % 6) / 3, c1 = e1 % 3;
+                    pv[k] = make_double2(Jcj[m0][3 * s0 + c0], Jcj[m1][3 * s1 + c1]);
                 }
             }
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < DC; ++r) u[m * DC + r] = valid ? Jci[0][r] * M[0][m] + Jci[1][r] * M[1][m] : 0.0;
+            for (int e = 0; e < UV; ++e) {   // U[m][3 bi + c] in the order [bi][m][3]
+                const int s0 = e / 6, m = (e % 6) / 3, c = e % 3;
+                u[e] = Jci[0][3 * s0 + c] * M[0][m] + Jci[1][3 * s0 + c] * M[1][m];
+            }
         }
         // every lane has read its cameras (program order, one wave): U may now overwrite the staging area
         __builtin_amdgcn_wave_barrier();
@@ -281,49 +372,50 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
             for (int k = 0; k < UV / 2; ++k) pu[k] = make_double2(u[2 * k], u[2 * k + 1]);
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- D: the next chunk's gathers go out now and land during the matrix-core phase ------------------------------
+        // ---- D: the next chunk's gathers go out now and land during the product phase ---------------------------------
         const PairChunk ck_cur = ck;
         if (ch + 1 < ch_end) {
             ck = ck_next; rr = rr_next;
             pairs_issue_loads(v, blocks, lmrec, ck, rr, lane, dat);
             if (ch + 2 < ch_end) { ck_next = chunks[ch + 2]; rr_next = reinterpret_cast<const uint4*>(recs)[(size_t)(ch + 2) * 64 + lane]; }
         }
-        // ---- E: reduce over the lanes: 32 K-steps of two pairs each, four at a time --------------------------------------
-        const double* pa = U + aoff;
-        const double* pb = V + aoff;
-        double an[4], bn[4];
+        // ---- E: block products.  The chunk is a sequence of segments (runs of pairs of one block); the NG lane groups deal
+        // a segment's pairs among themselves, every lane adds its 3 x 3 sub-block of U_p V_p (18 FMA per pair) --------------
+        uint32_t mask = ck_cur.mask;
+        int seg0 = 0;
+        if (mask & 1u) {   // the chunk opens a new block
+            if (cur >= 0) pairs_flush<DC>(tiles, blocks, cur, acc, lane);
+            cur = cur < 0 ? ck_cur.first_block : cur + 1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { an[k] = pa[k * 2 * UV]; bn[k] = pb[k * 2 * UV]; }
+            for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+        }
+        mask &= ~1u;
+        for (;;) {
+            const int seg1 = mask ? 2 * (__ffs(mask) - 1) : 64;      // wave-uniform
+            for (int p = seg0 + g; p < seg1; p += NG) {
+                if (worker) {
+                    const double2* qu = reinterpret_cast<const double2*>(U + p * UV + bi * 6);
+                    const double2* qv = reinterpret_cast<const double2*>(V + p * UV + bj * 6);
+                    const double2 u0 = qu[0], u1 = qu[1], u2 = qu[2], v0 = qv[0], v1 = qv[1], v2 = qv[2];
+                    const double um0[3] = {u0.x, u0.y, u1.x}, um1[3] = {u1.y, u2.x, u2.y};
+                    const double vm0[3] = {v0.x, v0.y, v1.x}, vm1[3] = {v1.y, v2.x, v2.y};
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            double a[4], b[4];
+                    for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { a[k] = an[k]; b[k] = bn[k]; }
-            if (g < 7) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { an[k] = pa[((g + 1) * 4 + k) * 2 * UV]; bn[k] = pb[((g + 1) * 4 + k) * 2 * UV]; }
-            }
-            const uint32_t m4 = (ck_cur.mask >> (4 * g)) & 0xFu;
-            if (m4 == 0u) {   // wave-uniform: no block starts inside these four K-steps
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if ((m4 >> k) & 1u) {
-                        if (cur >= 0) pairs_flush<DC>(tiles, blocks, cur, acc0 + acc1, kk, r16);
-                        cur = cur < 0 ? ck_cur.first_block : cur + 1;
-                        acc0 = double4_t{0.0, 0.0, 0.0, 0.0}; acc1 = double4_t{0.0, 0.0, 0.0, 0.0};
-                    }
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], b[k], acc0, 0, 0, 0);
+                        for (int c = 0; c < 3; ++c) acc[3 * r + c] += um0[r] * vm0[c] + um1[r] * vm1[c];
                 }
             }
+            if (!mask) break;
+            pairs_flush<DC>(tiles, blocks, cur, acc, lane);
+            ++cur;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+            seg0 = seg1;
+            mask &= mask - 1;
         }
         __builtin_amdgcn_wave_barrier();   // the next chunk's camera staging overwrites U
     }
-    if (cur >= 0) pairs_flush<DC>(tiles, blocks, cur, acc0 + acc1, kk, r16);
+    if (cur >= 0) pairs_flush<DC>(tiles, blocks, cur, acc, lane);
 }
 
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,

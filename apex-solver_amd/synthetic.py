@@ -304,6 +304,25 @@ def make_named(shape: str, scale: float = 1.0) -> BAProblemData:
         n_cam = max(8, int(round(n_cam * scale)))
         n_pt = max(16, int(round(n_pt * scale)))
     nm = shape if scale == 1.0 else f"{shape}@{scale:g}"
+    # Generating 29 M observations takes about a minute of numpy: tools that run several processes on the same box
+    # (profiles, A/B benches) may share one copy through APEX_SYNTH_CACHE=<directory>.  Pure cache: same arrays.
+    import os
+    cache = os.environ.get("APEX_SYNTH_CACHE")
+    path = os.path.join(cache, f"{nm}.npz") if cache else None
+    if path and os.path.exists(path):
+        z = np.load(path)
+        return BAProblemData(**{k: z[k] for k in z.files}, name=nm)
+    d = _make_named_uncached(shape, scale, nm, hub, cid, n_cam, n_pt, k_lo, k_hi)
+    if path:
+        os.makedirs(cache, exist_ok=True)
+        tmp = path + f".{os.getpid()}.tmp.npz"
+        np.savez(tmp, poses=d.poses, intr=d.intr, points=d.points, cam_idx=d.cam_idx, pt_idx=d.pt_idx, obs_uv=d.obs_uv,
+                 truth_poses=d.truth_poses, truth_intr=d.truth_intr, truth_points=d.truth_points)
+        os.replace(tmp, path)
+    return d
+
+
+def _make_named_uncached(shape, scale, nm, hub, cid, n_cam, n_pt, k_lo, k_hi) -> BAProblemData:
     return make_problem(n_cam, n_pt, k_lo, k_hi, config_id=cid, name=nm, hub_frac=0.015 if hub else 0.0)
 
 

@@ -1,10 +1,18 @@
 /* A plain-C client of include/apexgpu.h: what a compiled host (the reference's Rust shim)
  * does through the FFI -- no Python, no torch types.  Reads a problem dumped by the test as raw little-endian arrays,
  * runs the device-resident LM loop and prints the result as one JSON line.
- *   capi_client ba <file>   |   capi_client pg <file>
+ *   capi_client ba <file>   |   capi_client pg <file>   |   capi_client ba-level1 <file>
+ * "ba-level1" replays, call by call, what the Rust binding of rust/ makes out of the reference's UNCHANGED loop
+ * (optimize_with_mode::<GpuBaMode>): the optimiser owns the variables on the host; every iteration GpuBaMode::assemble
+ * uploads them (apexgpu_set_params), solve_augmented_equation is apexgpu_solve_augmented, the gradient / step norms and
+ * the predicted reduction are host arithmetic on the returned vectors, apply_parameter_step retracts on the host (the
+ * CPU path: ora_se3_plus of the oracle library stands in for apex-manifolds), and the trial cost is the residual
+ * evaluation at the trial point (the reference calls Problem::compute_residual_sparse on the CPU; here the device's
+ * cost kernel after an upload of the trial point, equal to 1e-13).  Must reproduce apexgpu_lm_optimize ("ba").
  * BA file: i64 n_cam, n_pt, n_obs, mode; u32 cam_idx[n_obs], pt_idx[n_obs]; f64 obs_uv[2 n_obs]; f64 poses[7 n_cam],
  *          intr[3 n_cam], points[3 n_pt]
  * PG file: i64 n_v, n_e; i64 ids[n_v]; u32 e_from[n_e], e_to[n_e]; f64 meas[7 n_e]; f64 poses[7 n_v]            */
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,12 +35,88 @@ static apexgpu_lm_config default_config(int max_iterations) {  /* LevenbergMarqu
     return c;
 }
 
+/* oracle/ba_oracle.c (test infrastructure): SE3 right-plus as apply_tangent_step does it on the CPU */
+void ora_se3_plus(const double pose[7], const double delta[6], double out[7]);
+
+static double norm2(const double* x, int64_t n) { double s = 0; for (int64_t i = 0; i < n; ++i) s += x[i] * x[i]; return sqrt(s); }
+
+/* apply_parameter_step / apply_negative_parameter_step (src/optimizer/mod.rs:309-356): fixed DOF zeroed first */
+static void host_apply(int64_t n_cam, int64_t n_pt, const int64_t* ic, const int64_t* pc, const int64_t* lc, const uint8_t* fixp,
+                       const double* step, double sign, int selfcal, double* poses, double* intr, double* pts) {
+    for (int64_t c = 0; c < n_cam; ++c) {
+        double d[6], o[7];
+        for (int a = 0; a < 6; ++a) d[a] = fixp[6 * c + a] ? 0.0 : sign * step[pc[c] + a];
+        ora_se3_plus(poses + 7 * c, d, o);
+        memcpy(poses + 7 * c, o, sizeof o);
+        if (selfcal) for (int a = 0; a < 3; ++a) intr[3 * c + a] += sign * step[ic[c] + a];
+    }
+    for (int64_t l = 0; l < n_pt; ++l)
+        for (int a = 0; a < 3; ++a) pts[3 * l + a] += sign * step[lc[l] + a];
+}
+
+static int level1_sequence(apexgpu_solver* h, int64_t n_cam, int64_t n_pt, const int64_t* ic, const int64_t* pc, const int64_t* lc,
+                           const uint8_t* fixp, int selfcal, double* poses, double* intr, double* pts, apexgpu_lm_config* cfg,
+                           apexgpu_lm_result* res) {
+    const int64_t total = 9 * n_cam + 3 * n_pt;
+    double* step = malloc(8 * total); double* grad = malloc(8 * total);
+    double lambda = cfg->damping, nu = cfg->damping_nu, cur = 0.0;
+    int rc = apexgpu_set_params(h, poses, intr, pts);                 /* initialize_optimization_state: cost at the start */
+    if (!rc) rc = apexgpu_cost(h, &cur);
+    if (rc) return rc;
+    memset(res, 0, sizeof *res);
+    res->initial_cost = cur;
+    int iteration = 0, status = 0 /* MaxIterationsReached */;
+    for (;;) {
+        rc = apexgpu_set_params(h, poses, intr, pts);                  /* GpuBaMode::assemble: upload state.variables */
+        if (!rc) rc = apexgpu_solve_augmented(h, lambda, cfg->variant, step, grad);   /* solve_augmented_equation */
+        if (rc) return rc;
+        const double gn = norm2(grad, total), sn = norm2(step, total);
+        double pred = 0.0;                                               /* compute_predicted_reduction (:721-727) */
+        for (int64_t i = 0; i < total; ++i) pred += step[i] * (lambda * step[i] - grad[i]);
+        pred *= 0.5;
+        host_apply(n_cam, n_pt, ic, pc, lc, fixp, step, 1.0, selfcal, poses, intr, pts);   /* apply_parameter_step */
+        double trial = 0.0;
+        rc = apexgpu_set_params(h, poses, intr, pts);                  /* compute_residual_sparse at the trial point */
+        if (!rc) rc = apexgpu_cost(h, &trial);
+        if (rc) return rc;
+        const double actual = cur - trial;
+        const double rho = (fabs(pred) < 1e-15) ? (actual > 0.0 ? 1.0 : 0.0) : actual / pred;
+        int accepted; double reduction = 0.0;
+        if (rho > 0.0) {
+            const double coff = 2.0 * rho - 1.0, f = 1.0 - coff * coff * coff;
+            lambda *= f > 1.0 / 3.0 ? f : 1.0 / 3.0; if (lambda < cfg->damping_min) lambda = cfg->damping_min;
+            nu = 2.0; accepted = 1; reduction = cur - trial; cur = trial; res->successful_steps++;
+        } else {
+            lambda *= nu; nu *= 2.0; if (lambda > cfg->damping_max) lambda = cfg->damping_max;
+            accepted = 0; res->unsuccessful_steps++;
+            host_apply(n_cam, n_pt, ic, pc, lc, fixp, step, -1.0, selfcal, poses, intr, pts);  /* apply_negative_parameter_step */
+        }
+        double pn = 0.0;                                                /* compute_parameter_norm (:458-467) */
+        { const double a = norm2(poses, 7 * n_cam), b = norm2(intr, 3 * n_cam), c = norm2(pts, 3 * n_pt); pn = sqrt(a * a + b * b + c * c); }
+        const double before = accepted ? cur + reduction : cur;
+        int st = -1;
+        if (iteration >= cfg->max_iterations) st = 0;
+        else if (accepted) {
+            if (gn < cfg->gradient_tolerance) st = 3;
+            if (st < 0 && iteration > 0) {
+                if (sn <= cfg->parameter_tolerance * (pn + cfg->parameter_tolerance)) st = 2;
+                else if (fabs(before - cur) / (before > 1e-10 ? before : 1e-10) < cfg->cost_tolerance) st = 1;
+            }
+        }
+        ++iteration;
+        if (st >= 0) { status = st; break; }
+    }
+    res->status = status; res->iterations = iteration; res->final_cost = cur;
+    free(step); free(grad);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
     FILE* f = fopen(argv[2], "rb");
     if (!f) return 2;
     apexgpu_lm_result res;
-    if (strcmp(argv[1], "ba") == 0) {
+    if (strcmp(argv[1], "ba") == 0 || strcmp(argv[1], "ba-level1") == 0) {
         int64_t hdr[4];
         if (fread(hdr, 8, 4, f) != 4) return 2;
         const int64_t n_cam = hdr[0], n_pt = hdr[1], n_obs = hdr[2];
@@ -47,9 +131,13 @@ int main(int argc, char** argv) {
         int rc = apexgpu_create(n_cam, n_pt, n_obs, (int)hdr[3], 0, &h);
         if (rc) { fprintf(stderr, "create: %d\n", rc); return 3; }
         rc = apexgpu_set_structure(h, cam, pt, uv, ic, pc, lc, fixp, NULL, NULL, 1.0);
-        if (!rc) rc = apexgpu_set_params(h, poses, intr, pts);
         apexgpu_lm_config cfg = default_config(20);
-        if (!rc) rc = apexgpu_lm_optimize(h, &cfg, &res, NULL, 0);
+        if (!rc && strcmp(argv[1], "ba") == 0) {
+            rc = apexgpu_set_params(h, poses, intr, pts);
+            if (!rc) rc = apexgpu_lm_optimize(h, &cfg, &res, NULL, 0);
+        } else if (!rc) {
+            rc = level1_sequence(h, n_cam, n_pt, ic, pc, lc, fixp, hdr[3] == 1, poses, intr, pts, &cfg, &res);
+        }
         if (rc) { fprintf(stderr, "error %d: %s\n", rc, apexgpu_last_error(h)); return 4; }
         apexgpu_destroy(h);
     } else {
