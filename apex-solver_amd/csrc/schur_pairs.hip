@@ -9,7 +9,8 @@
 namespace apex {
 
 
-constexpr int kPairTaskSlots = 768;      // a wave's task is closed once it holds this many slots (12 chunks)
+constexpr int kPairTaskSlots = 1536;     // a wave's task is closed once it holds this many slots (24 chunks: the pipeline's
+                                         // prologue -- three dependent loads -- is paid once per task)
 constexpr int kPairMaxBlockSlots = 8192; // a block with more slots is split over several waves (atomic flush)
 constexpr int kPairCamPitch = 18;        // doubles per staged camera: 144 B keeps 16-byte alignment and spreads the banks
 
@@ -201,12 +202,31 @@ __device__ __forceinline__ void linearize_pairside(const double* __restrict__ cv
 struct PairData {
     double2 uvi, uvj;
     double2 lm[6];
-    double2 cam[8];
 };
+constexpr int kPairDmaBlocks = 4;   // a chunk with at most this many blocks stages its <= 8 cameras by ONE LDS-DMA
 
-__device__ __forceinline__ void pairs_issue_loads(const BAView& v, const PairBlock* __restrict__ blocks,
-                                                  const double* __restrict__ lmrec, const PairChunk ck, const uint4 rr, int lane,
-                                                  PairData& d) {
+// Camera staging.  Fast path (a chunk with <= kPairDmaBlocks blocks, i.e. nearly every chunk of a capture with real
+// overlap): the 8 lanes t = 8 c .. 8 c + 7 copy the 128-byte prepared camera c of the chunk (camera c & 1 of block c >> 1)
+// straight into the wave's camera area with one global_load_lds_dwordx4 -- no registers, no ds_write, issued a chunk ahead.
+// Slow path (many tiny blocks): lane t < 2 nblk loads camera t through registers into the area U will overwrite.
+__device__ __forceinline__ uint32_t pairs_dma_cam(const PairBlock* __restrict__ blocks, const PairChunk ck, int lane) {
+    const int nblk = 1 + __popc(ck.mask & ~1u);
+    const int c = lane >> 3;
+    const PairBlock* pb = blocks + ck.first_block + min(c >> 1, nblk - 1);
+    return (c & 1) ? pb->cj : pb->ci;
+}
+__device__ __forceinline__ uint32_t pairs_slow_cam(const PairBlock* __restrict__ blocks, const PairChunk ck, int lane) {
+    const int nblk = 1 + __popc(ck.mask & ~1u);
+    const PairBlock* pb = blocks + ck.first_block + min(lane >> 1, nblk - 1);
+    return (lane & 1) ? pb->cj : pb->ci;
+}
+__device__ __forceinline__ void pairs_dma_issue(const BAView& v, uint32_t cam, int lane, double* lds_cams) {
+    const char* src = reinterpret_cast<const char*>(v.camp + kCamStride * (size_t)cam) + 16 * (lane & 7);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_cams, 16, 0, 0);
+}
+
+__device__ __forceinline__ void pairs_issue_loads(const BAView& v, const double* __restrict__ lmrec, const uint4 rr, PairData& d) {
     const bool valid = rr.x != kPairPad;
     const uint32_t i = valid ? rr.x : 0u, j = valid ? rr.y : 0u, l = valid ? rr.z : 0u;   // padding lanes read element 0
     d.uvi = v.o_uv[i];
@@ -214,19 +234,12 @@ __device__ __forceinline__ void pairs_issue_loads(const BAView& v, const PairBlo
     const double2* q = reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)l);
 #pragma unroll
     for (int k = 0; k < 6; ++k) d.lm[k] = q[k];
-    const int nblk = 1 + __popc(ck.mask & ~1u);
-    const int bsel = min(lane >> 1, nblk - 1);
-    const PairBlock* pb = blocks + ck.first_block + bsel;
-    const uint32_t cam = (lane & 1) ? pb->cj : pb->ci;
-    const double2* src = reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)cam);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) d.cam[k] = src[k];
 }
 
 // Sum of the lane groups' partial blocks and the ONE store of S(ci, cj).  Lane L = 9 g + sub (DC = 9; 4 g + sub for DC = 6)
 // holds the 3 x 3 sub-block (bi, bj) = (sub / NB3, sub % NB3) of group g's partial sum.
 template <int DC>
-__device__ __forceinline__ void pairs_flush(double* __restrict__ tiles, const PairBlock* __restrict__ blocks, int b,
+__device__ __forceinline__ void pairs_flush(double* __restrict__ tiles, const int64_t pb_dst, const uint32_t pb_flags,
                                             double acc[9], int lane) {
     constexpr int NB3 = DC / 3, GL = NB3 * NB3;
     constexpr int NG = (DC == 9) ? 7 : 16, P2 = (DC == 9) ? 8 : 16;
@@ -243,7 +256,7 @@ __device__ __forceinline__ void pairs_flush(double* __restrict__ tiles, const Pa
         }
     }
     if (lane < GL) {
-        const PairBlock pb = blocks[b];
+        struct { int64_t dst; uint32_t flags; } pb = {pb_dst, pb_flags};
         double* dst = tiles + pb.dst;
         const int bi = lane / NB3, bj = lane % NB3;
 #pragma unroll
@@ -264,7 +277,9 @@ __device__ __forceinline__ void pairs_flush(double* __restrict__ tiles, const Pa
     }
 }
 
-template <int DC>
+// ABL: timing-only ablation switches (results are wrong when != 0): 1 = the per-pair gathers (measurements, landmark
+// record) replaced by registers, 2 = no block products, 4 = no linearisation (U, V from the loaded data directly)
+template <int DC, int ABL>
 __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restrict__ tiles, const PairTask* __restrict__ tasks,
                                                        int n_tasks, const PairChunk* __restrict__ chunks,
                                                        const PairBlock* __restrict__ blocks, const PairRec* __restrict__ recs,
@@ -274,15 +289,25 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
     constexpr int GL = NB3 * NB3;                 // lanes of one group = sub-blocks of a block (9 / 4)
     constexpr int NG = (DC == 9) ? 7 : 16;        // lane groups that split a segment's pairs (63 / 64 lanes busy)
     constexpr int REG_A = 64 * kPairCamPitch;     // U[64][UV] overlays the staged cameras (64 x 18 doubles >= 64 x UV)
-    constexpr int WAVE_LDS = REG_A + 64 * UV;     // | V[64][UV]
+    constexpr int WAVE_LDS = REG_A + 64 * UV + 8 * kCamStride;   // | V[64][UV] | 8 cameras staged by LDS-DMA
     static_assert(64 * UV <= REG_A, "U must fit the camera staging area");
     __shared__ double lds_all[4 * WAVE_LDS];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = blockIdx.x * 4 + w;
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Tasks are ordered by row camera, and the
+    // ~17 pairs that use one landmark record sit in rows a capture window apart: giving every XCD a CONTIGUOUS eighth of
+    // the task list keeps a landmark's pairs behind one L2 (measured: L2 hit rate 36 % -> see DESIGN.md) instead of
+    // spreading them over all eight.  Speed only: any mapping is correct.
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    const int t = wg * 4 + w;
     if (t >= n_tasks) return;                     // no workgroup barrier anywhere: the four waves are independent
     double* U = lds_all + w * WAVE_LDS;
     double* V = U + REG_A;
+    double* CAMS = V + 64 * UV;
     const PairTask task = tasks[t];
     // product phase: lane = (group g, sub-block (bi, bj)); U and V are stored per pair as [sub-row][m][3] so that a lane's
     // six U values (and six V values) are 48 contiguous, 16-byte aligned bytes
@@ -292,6 +317,8 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.0;
     int cur = -1;
+    int64_t cur_dst = 0;       // descriptor of the block being accumulated, fetched when the block STARTS (a scalar load
+    uint32_t cur_flags = 0;    // whose latency the block's own pairs hide), not when it is flushed
 
     // Software pipeline over the task's chunks: the gathers of chunk n+1 are issued before the product phase of chunk n
     // and land while it runs; the 16-byte records run two chunks ahead.
@@ -300,18 +327,33 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
     PairChunk ck = chunks[ch];
     uint4 rr = reinterpret_cast<const uint4*>(recs)[(size_t)ch * 64 + lane];
     PairData dat;
-    pairs_issue_loads(v, blocks, lmrec, ck, rr, lane, dat);
+    pairs_issue_loads(v, lmrec, rr, dat);
+    bool dma = 1 + __popc(ck.mask & ~1u) <= kPairDmaBlocks;
+    if (dma) pairs_dma_issue(v, pairs_dma_cam(blocks, ck, lane), lane, CAMS);
+    // two chunks ahead: the 16-byte record, the chunk descriptor and the camera index this lane will stage (so that the
+    // gathers one chunk ahead depend on nothing that is still in flight)
     PairChunk ck_next = ck;
     uint4 rr_next = rr;
-    if (ch + 1 < ch_end) { ck_next = chunks[ch + 1]; rr_next = reinterpret_cast<const uint4*>(recs)[(size_t)(ch + 1) * 64 + lane]; }
+    uint32_t cam_next = 0;
+    if (ch + 1 < ch_end) {
+        ck_next = chunks[ch + 1];
+        rr_next = reinterpret_cast<const uint4*>(recs)[(size_t)(ch + 1) * 64 + lane];
+        cam_next = pairs_dma_cam(blocks, ck_next, lane);
+    }
 
     for (; ch < ch_end; ++ch) {
-        // ---- A: the cameras of the chunk's blocks -> LDS (read back by every lane of the block: broadcast) -------------
-        {
+        // ---- A: the chunk's cameras are in LDS: by the DMA issued a chunk ago, or (many tiny blocks) staged now ----------
+        const double* cam_base = CAMS;
+        int cam_pitch = kCamStride;
+        if (!dma) {
+            const uint32_t cam = pairs_slow_cam(blocks, ck, lane);
+            const double2* src = reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)cam);
             double2* dstc = reinterpret_cast<double2*>(U + lane * kPairCamPitch);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) dstc[k] = dat.cam[k];
+            for (int k = 0; k < 8; ++k) dstc[k] = src[k];
+            cam_base = U; cam_pitch = kPairCamPitch;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA writes LDS behind the VM counter
         const bool valid = rr.x != kPairPad;
         __builtin_amdgcn_wave_barrier();
         // ---- B: one pair per lane: both observations linearised, U = Jc_i^T M, V = Jc_j ---------------------------------
@@ -324,11 +366,17 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
             double N[2][3];
             double Jci[2][DC];
             {
-                const double2* c2 = reinterpret_cast<const double2*>(U + (2 * blk) * kPairCamPitch);
+                const double2* c2 = reinterpret_cast<const double2*>(cam_base + (2 * blk) * cam_pitch);
                 double cv[16];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 tq = c2[k]; cv[2 * k] = tq.x; cv[2 * k + 1] = tq.y; }
                 double Jl[2][3];
+                if (ABL & 4) {
+#pragma unroll
+                    for (int a = 0; a < DC; ++a) { Jci[0][a] = cv[a] + dat.uvi.x; Jci[1][a] = cv[a + 6] * dat.uvi.y; }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { Jl[0][a] = pw[a]; Jl[1][a] = cv[a]; }
+                } else
                 linearize_pairside<DC>(cv, pw, dat.uvi.x, dat.uvi.y, v.huber_delta, Jci, Jl);
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
@@ -337,11 +385,17 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
             }
             double M[2][2];
             {
-                const double2* c2 = reinterpret_cast<const double2*>(U + (2 * blk + 1) * kPairCamPitch);
+                const double2* c2 = reinterpret_cast<const double2*>(cam_base + (2 * blk + 1) * cam_pitch);
                 double cv[16];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 tq = c2[k]; cv[2 * k] = tq.x; cv[2 * k + 1] = tq.y; }
                 double Jcj[2][DC], Jl[2][3];
+                if (ABL & 4) {
+#pragma unroll
+                    for (int a = 0; a < DC; ++a) { Jcj[0][a] = cv[a] + dat.uvj.x; Jcj[1][a] = cv[a + 6] * dat.uvj.y; }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { Jl[0][a] = pw[a]; Jl[1][a] = cv[a]; }
+                } else
                 linearize_pairside<DC>(cv, pw, dat.uvj.x, dat.uvj.y, v.huber_delta, Jcj, Jl);
                 const double sgn = valid ? -1.0 : 0.0;     // a padding slot contributes U = 0
 #pragma unroll
@@ -355,7 +409,8 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
                 for (int k = 0; k < DC; ++k) {
                     const int e0 = 2 * k, e1 = 2 * k + 1;
                     const int s0 = e0 / 6, m0 = (e0 % 6) / 3, c0 = e0 % 3, s1 = e1 / 6, m1 = (e1 % 6) / 3, c1 = e1 % 3;
-                    pv[k] = make_double2(Jcj[m0][3 * s0 + c0], Jcj[m1][3 * s1 + c1]);
+                    if (!(ABL & 16) || k == 0) pv[k] = make_double2(Jcj[m0][3 * s0 + c0], Jcj[m1][3 * s1 + c1]);
+                    else asm volatile("" ::"v"(Jcj[m0][3 * s0 + c0]), "v"(Jcj[m1][3 * s1 + c1]));
                 }
             }
 #pragma unroll
@@ -369,23 +424,34 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
         {
             double2* pu = reinterpret_cast<double2*>(U + lane * UV);
 #pragma unroll
-            for (int k = 0; k < UV / 2; ++k) pu[k] = make_double2(u[2 * k], u[2 * k + 1]);
+            for (int k = 0; k < UV / 2; ++k) {
+                if (!(ABL & 16) || k == 0) pu[k] = make_double2(u[2 * k], u[2 * k + 1]);
+                else asm volatile("" ::"v"(u[2 * k]), "v"(u[2 * k + 1]));
+            }
         }
         __builtin_amdgcn_wave_barrier();
         // ---- D: the next chunk's gathers go out now and land during the product phase ---------------------------------
         const PairChunk ck_cur = ck;
         if (ch + 1 < ch_end) {
             ck = ck_next; rr = rr_next;
-            pairs_issue_loads(v, blocks, lmrec, ck, rr, lane, dat);
-            if (ch + 2 < ch_end) { ck_next = chunks[ch + 2]; rr_next = reinterpret_cast<const uint4*>(recs)[(size_t)(ch + 2) * 64 + lane]; }
+            if (!(ABL & 1)) pairs_issue_loads(v, lmrec, rr, dat);
+            // (the camera area is free: every lane read its cameras in phase B, before the wave barriers above)
+            dma = 1 + __popc(ck.mask & ~1u) <= kPairDmaBlocks;
+            if (dma) pairs_dma_issue(v, cam_next, lane, CAMS);
+            if (ch + 2 < ch_end) {
+                ck_next = chunks[ch + 2];
+                rr_next = reinterpret_cast<const uint4*>(recs)[(size_t)(ch + 2) * 64 + lane];
+                cam_next = pairs_dma_cam(blocks, ck_next, lane);
+            }
         }
         // ---- E: block products.  The chunk is a sequence of segments (runs of pairs of one block); the NG lane groups deal
         // a segment's pairs among themselves, every lane adds its 3 x 3 sub-block of U_p V_p (18 FMA per pair) --------------
         uint32_t mask = ck_cur.mask;
         int seg0 = 0;
         if (mask & 1u) {   // the chunk opens a new block
-            if (cur >= 0) pairs_flush<DC>(tiles, blocks, cur, acc, lane);
+            if (cur >= 0) pairs_flush<DC>(tiles, cur_dst, cur_flags, acc, lane);
             cur = cur < 0 ? ck_cur.first_block : cur + 1;
+            cur_dst = blocks[cur].dst; cur_flags = blocks[cur].flags;
 #pragma unroll
             for (int k = 0; k < 9; ++k) acc[k] = 0.0;
         }
@@ -393,7 +459,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
         for (;;) {
             const int seg1 = mask ? 2 * (__ffs(mask) - 1) : 64;      // wave-uniform
             for (int p = seg0 + g; p < seg1; p += NG) {
-                if (worker) {
+                if (worker && !(ABL & 2)) {
                     const double2* qu = reinterpret_cast<const double2*>(U + p * UV + bi * 6);
                     const double2* qv = reinterpret_cast<const double2*>(V + p * UV + bj * 6);
                     const double2 u0 = qu[0], u1 = qu[1], u2 = qu[2], v0 = qv[0], v1 = qv[1], v2 = qv[2];
@@ -402,12 +468,13 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) acc[3 * r + c] += um0[r] * vm0[c] + um1[r] * vm1[c];
+                        for (int c = 0; c < 3; ++c) acc[3 * r + c] = fma(um1[r], vm1[c], fma(um0[r], vm0[c], acc[3 * r + c]));
                 }
             }
             if (!mask) break;
-            pairs_flush<DC>(tiles, blocks, cur, acc, lane);
+            pairs_flush<DC>(tiles, cur_dst, cur_flags, acc, lane);
             ++cur;
+            cur_dst = blocks[cur].dst; cur_flags = blocks[cur].flags;
 #pragma unroll
             for (int k = 0; k < 9; ++k) acc[k] = 0.0;
             seg0 = seg1;
@@ -415,15 +482,33 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
         }
         __builtin_amdgcn_wave_barrier();   // the next chunk's camera staging overwrites U
     }
-    if (cur >= 0) pairs_flush<DC>(tiles, blocks, cur, acc, lane);
+    if (cur >= 0) pairs_flush<DC>(tiles, cur_dst, cur_flags, acc, lane);
 }
+
+static int g_pairs_ablation = 0;   // timing experiments only (tools/schur_bench.py --abl)
+void set_pairs_ablation(int bits) { g_pairs_ablation = bits; }
 
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
                         const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s) {
     if (n_tasks == 0) return;
     const unsigned grid = (unsigned)((n_tasks + 3) / 4);
-    if (dc == 9) hipLaunchKernelGGL(k_schur_pairs<9>, dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec);
-    else hipLaunchKernelGGL(k_schur_pairs<6>, dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec);
+#define PAIRS_LAUNCH(DCV, A) hipLaunchKernelGGL((k_schur_pairs<DCV, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec)
+    if (dc == 9) {
+        switch (g_pairs_ablation) {
+            case 1: PAIRS_LAUNCH(9, 1); break;
+            case 2: PAIRS_LAUNCH(9, 2); break;
+            case 4: PAIRS_LAUNCH(9, 4); break;
+            case 6: PAIRS_LAUNCH(9, 6); break;
+            case 7: PAIRS_LAUNCH(9, 7); break;
+            case 15: PAIRS_LAUNCH(9, 15); break;
+            case 23: PAIRS_LAUNCH(9, 23); break;
+            case 31: PAIRS_LAUNCH(9, 31); break;
+            default: PAIRS_LAUNCH(9, 0);
+        }
+    } else {
+        PAIRS_LAUNCH(6, 0);
+    }
+#undef PAIRS_LAUNCH
 }
 
 }  // namespace apex

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--forms", default="3,2")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--mode", default="selfcal")
+    ap.add_argument("--abl", default="0", help="comma list of ablation bit sets for the pair kernel (timing only)")
     ap.add_argument("--check", action="store_true", help="compare S x of every form with the first one's")
     a = ap.parse_args()
     t = time.time()
@@ -40,12 +41,17 @@ def main():
         setup = time.time() - t
         for _ in range(2):
             s.assemble(1e-3)
-        s.enable_stage_timing(True); s.reset_stage_times()
-        for _ in range(a.iters):
+        for abl in [int(x) for x in a.abl.split(",")]:
+            s.set_option("pairs_ablation", abl)
             s.assemble(1e-3)
-        st = s.stage_times()
-        line = {k: round(v[0] / max(v[1], 1), 3) for k, v in st.items() if v[1] > 0}
-        print(f"form {form}: {line}  setup {setup:.2f} s  {s.setup_times()}", flush=True)
+            s.enable_stage_timing(True); s.reset_stage_times()
+            for _ in range(a.iters):
+                s.assemble(1e-3)
+            st = s.stage_times()
+            line = {k: round(v[0] / max(v[1], 1), 3) for k, v in st.items() if v[1] > 0}
+            print(f"form {form} abl {abl}: {line}", flush=True)
+        s.set_option("pairs_ablation", 0)
+        print(f"   setup {setup:.2f} s  {s.setup_times()}", flush=True)
         if a.check:
             y, _ = s.schur_matvec(1e-3, x, implicit=False)
             if ref is None:
