@@ -214,7 +214,7 @@ def host_structure(n_cam: int, n_pt: int, cam_idx: np.ndarray, pt_idx: np.ndarra
     """Host only: what apexgpu_set_structure derives from the observation list before it touches the device."""
     ci = np.ascontiguousarray(cam_idx, dtype=np.uint32); pi = np.ascontiguousarray(pt_idx, dtype=np.uint32)
     opts = np.array([nested_dissection, hubs_last, dist_factor, tree_sharding, schur_form], dtype=np.int32)
-    stats = np.zeros(16); dc = 9 if mode == 1 else 6
+    stats = np.zeros(16); dc = 9 if mode in (1, 4, 5, 6) else 6
     nt = (n_cam * dc + 143) // 144
     cmap = np.zeros(n_cam, dtype=np.int32); owned = np.zeros(n_pt, dtype=np.uint8); towner = np.zeros(nt, dtype=np.int32)
     rc = load().apexgpu_debug_host_structure(n_cam, n_pt, len(ci), mode, ptr(ci), ptr(pi), rank, world, ptr(opts), ptr(stats),

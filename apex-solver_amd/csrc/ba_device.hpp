@@ -36,8 +36,13 @@ struct Cam {
     double R[9];  // row-major
     double t[3];
     double f, k1, k2;
+    // OptimizeParams<POSE, LANDMARK, INTRINSIC> (src/factors/mod.rs:66-101) as column masks of the factor's Jacobian: a
+    // block that is not optimised has no columns in the reference, i.e. zero columns here (its variables then get a zero
+    // step from the damped system, exactly as the reference's unreferenced variables do)
+    double m_pose = 1.0, m_lm = 1.0, m_intr = 1.0;
 };
-constexpr int kCamStride = 16;  // doubles per prepared camera: R(9) t(3) f k1 k2 pad
+constexpr int kCamStride = 16;  // doubles per prepared camera: R(9) t(3) f k1 k2 | mask code (4 POSE + 2 LANDMARK + INTRINSIC)
+constexpr double kMaskAll = 7.0;
 
 // pose7 = [tx,ty,tz,qw,qx,qy,qz] as VariableEnum::to_vector() stores it (the quaternion may be
 // slightly non-unit after a compose); normalised twice like from_translation_quaternion.
@@ -60,7 +65,8 @@ APEX_HD void store_cam_prepared(const Cam& c, double* __restrict__ o) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) o[i] = c.R[i];
     o[9] = c.t[0]; o[10] = c.t[1]; o[11] = c.t[2];
-    o[12] = c.f; o[13] = c.k1; o[14] = c.k2; o[15] = 0.0;
+    o[12] = c.f; o[13] = c.k1; o[14] = c.k2;
+    o[15] = 4.0 * c.m_pose + 2.0 * c.m_lm + c.m_intr;
 }
 
 APEX_HD void load_cam_prepared(const double* __restrict__ p, Cam& c) {
@@ -68,6 +74,8 @@ APEX_HD void load_cam_prepared(const double* __restrict__ p, Cam& c) {
     for (int i = 0; i < 9; ++i) c.R[i] = p[i];
     c.t[0] = p[9]; c.t[1] = p[10]; c.t[2] = p[11];
     c.f = p[12]; c.k1 = p[13]; c.k2 = p[14];
+    const int code = (int)p[15];
+    c.m_pose = (code & 4) ? 1.0 : 0.0; c.m_lm = (code & 2) ? 1.0 : 0.0; c.m_intr = (code & 1) ? 1.0 : 0.0;
 }
 
 // p_cam = R p_w + t  (SE3::act, se3.rs:322-328; the reference rotates with the quaternion, this is
@@ -184,16 +192,18 @@ APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, doubl
         double a0 = Jp[rr][0] * R[0] + Jp[rr][1] * R[3] + Jp[rr][2] * R[6];
         double a1 = Jp[rr][0] * R[1] + Jp[rr][1] * R[4] + Jp[rr][2] * R[7];
         double a2 = Jp[rr][0] * R[2] + Jp[rr][1] * R[5] + Jp[rr][2] * R[8];
-        Jl[rr][0] = a0 * w; Jl[rr][1] = a1 * w; Jl[rr][2] = a2 * w;
-        Jc[rr][0] = a0 * w; Jc[rr][1] = a1 * w; Jc[rr][2] = a2 * w;
-        Jc[rr][3] = -(a1 * pw[2] - a2 * pw[1]) * w;
-        Jc[rr][4] = -(a2 * pw[0] - a0 * pw[2]) * w;
-        Jc[rr][5] = -(a0 * pw[1] - a1 * pw[0]) * w;
+        const double wl = w * c.m_lm, wp = w * c.m_pose;
+        Jl[rr][0] = a0 * wl; Jl[rr][1] = a1 * wl; Jl[rr][2] = a2 * wl;
+        Jc[rr][0] = a0 * wp; Jc[rr][1] = a1 * wp; Jc[rr][2] = a2 * wp;
+        Jc[rr][3] = -(a1 * pw[2] - a2 * pw[1]) * wp;
+        Jc[rr][4] = -(a2 * pw[0] - a0 * pw[2]) * wp;
+        Jc[rr][5] = -(a0 * pw[1] - a1 * pw[0]) * wp;
     }
     if (DC == 9) {
         // d(u,v)/d(f,k1,k2)  (bal_pinhole.rs:649-672)
-        Jc[0][DC - 3] = (xn * dist) * w; Jc[0][DC - 2] = (f * xn * r2) * w; Jc[0][DC - 1] = (f * xn * r4) * w;
-        Jc[1][DC - 3] = (yn * dist) * w; Jc[1][DC - 2] = (f * yn * r2) * w; Jc[1][DC - 1] = (f * yn * r4) * w;
+        const double wi = w * c.m_intr;
+        Jc[0][DC - 3] = (xn * dist) * wi; Jc[0][DC - 2] = (f * xn * r2) * wi; Jc[0][DC - 1] = (f * xn * r4) * wi;
+        Jc[1][DC - 3] = (yn * dist) * wi; Jc[1][DC - 2] = (f * yn * r2) * wi; Jc[1][DC - 1] = (f * yn * r4) * wi;
     }
     r[0] = r0 * w; r[1] = r1 * w;
     return true;

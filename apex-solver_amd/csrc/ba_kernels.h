@@ -95,7 +95,8 @@ void launch_precond_blocks(int dc, int64_t n_cam, const double* sd, double* minv
 void launch_precond_apply(int dc, int64_t n_cam, const double* minv, const double* r, double* z, hipStream_t s);
 void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const ScatterTask* tasks, int n_tasks,
                           const double* hinv, const double* g_l, double* g_red, hipStream_t s);
-void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, hipStream_t s);
+// mask_code = 4 POSE + 2 LANDMARK + INTRINSIC: which blocks of the factors' Jacobians exist (OptimizeParams, src/factors/mod.rs:66-101)
+void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, int mask_code, hipStream_t s);
 void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
                        const RowBatch* batches, const int* cam_obs, const uint16_t* cam_obs_off, const int* nbr,
                        const double* hinv, int dbg, hipStream_t s);

@@ -373,11 +373,12 @@ __global__ __launch_bounds__(256) void k_schur_scatter(BAView v, TileMap tm, con
 // into R once, and park [R t f k1 k2] in 16 doubles per camera for every per-observation kernel.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepare_cams(int64_t n_cam, const double* __restrict__ poses,
-                                                        const double* __restrict__ intr, double* __restrict__ camp) {
+                                                        const double* __restrict__ intr, double* __restrict__ camp, int mask_code) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= n_cam) return;
     Cam cam;
     load_cam(poses + 7 * c, intr + 3 * c, cam);
+    cam.m_pose = (mask_code & 4) ? 1.0 : 0.0; cam.m_lm = (mask_code & 2) ? 1.0 : 0.0; cam.m_intr = (mask_code & 1) ? 1.0 : 0.0;
     store_cam_prepared(cam, camp + kCamStride * c);
 }
 
@@ -1079,8 +1080,8 @@ void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const Scat
     else hipLaunchKernelGGL(k_schur_scatter<6>, dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, hinv, g_l, g_red);
 }
 
-void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, hipStream_t s) {
-    if (n_cam > 0) hipLaunchKernelGGL(k_prepare_cams, dim3(grid_for(n_cam, 256, 0)), dim3(256), 0, s, n_cam, poses, intr, camp);
+void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, int mask_code, hipStream_t s) {
+    if (n_cam > 0) hipLaunchKernelGGL(k_prepare_cams, dim3(grid_for(n_cam, 256, 0)), dim3(256), 0, s, n_cam, poses, intr, camp, mask_code);
 }
 
 void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,

@@ -58,7 +58,7 @@ const char* apexgpu_version(void) { return "apexgpu 0.1 (gfx950)"; }
 int apexgpu_create(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device, apexgpu_solver** out) {
     if (!out) return APEXGPU_ERR_INVALID_INPUT;
     *out = nullptr;
-    if (mode != APEXGPU_MODE_BUNDLE_ADJUSTMENT && mode != APEXGPU_MODE_SELF_CALIBRATION) return APEXGPU_ERR_INVALID_INPUT;
+    if (mode < APEXGPU_MODE_BUNDLE_ADJUSTMENT || mode > APEXGPU_MODE_LANDMARKS_AND_INTRINSICS) return APEXGPU_ERR_INVALID_INPUT;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return APEXGPU_ERR_DEVICE;
     apexgpu_solver* h = new (std::nothrow) apexgpu_solver();
@@ -365,12 +365,12 @@ int apexgpu_debug_host_structure(int64_t n_cam, int64_t n_pt, int64_t n_obs, int
                                  int32_t* cmap_out, uint8_t* owned_out, int32_t* tile_owner_out) {
     if (n_cam <= 0 || n_pt <= 0 || n_obs < 0 || !cam_idx || !pt_idx || !opts || !stats_out || world < 1 || rank < 0 || rank >= world)
         return APEXGPU_ERR_INVALID_INPUT;
-    if (mode != APEXGPU_MODE_BUNDLE_ADJUSTMENT && mode != APEXGPU_MODE_SELF_CALIBRATION) return APEXGPU_ERR_INVALID_INPUT;
+    if (mode < APEXGPU_MODE_BUNDLE_ADJUSTMENT || mode > APEXGPU_MODE_LANDMARKS_AND_INTRINSICS) return APEXGPU_ERR_INVALID_INPUT;
     return guarded([&]() -> int {
         for (int64_t i = 0; i < n_obs; ++i)
             if (cam_idx[i] >= (uint64_t)n_cam || pt_idx[i] >= (uint64_t)n_pt) return APEXGPU_ERR_INVALID_INPUT;
         apex::BaStructOptions so;
-        so.dc = mode == APEXGPU_MODE_SELF_CALIBRATION ? 9 : 6;
+        so.dc = (apex::mode_mask(mode) & 1) ? 9 : 6;
         so.use_nd = opts[0] != 0; if (opts[0] > 1) so.nd_leaf = opts[0];
         so.hubs_last = opts[1] != 0; so.dist_factor = opts[2] != 0; so.tree_sharding = opts[3] != 0; so.schur_form = opts[4];
         so.rank = rank; so.world = world;

@@ -171,6 +171,8 @@ __device__ __forceinline__ void linearize_pairside(const double* __restrict__ cv
         w = out ? wq : 1.0;
     }
     w = ok ? w : 0.0;
+    const int mcode = (int)cv[15];   // OptimizeParams column masks (ba_device.hpp): 4 POSE + 2 LANDMARK + INTRINSIC
+    const double mp = (mcode & 4) ? 1.0 : 0.0, ml = (mcode & 2) ? 1.0 : 0.0, mi = (mcode & 1) ? 1.0 : 0.0;
     const double dd = k1 + 2.0 * k2 * r2;
     const double dxn_dz = xn * inz, dyn_dz = yn * inz;
     const double dxd_dxn = dist + xn * dd * 2.0 * xn, dxd_dyn = xn * dd * 2.0 * yn;
@@ -184,14 +186,14 @@ __device__ __forceinline__ void linearize_pairside(const double* __restrict__ cv
         const double a0 = Jp[rr][0] * cv[0] + Jp[rr][1] * cv[3] + Jp[rr][2] * cv[6];
         const double a1 = Jp[rr][0] * cv[1] + Jp[rr][1] * cv[4] + Jp[rr][2] * cv[7];
         const double a2 = Jp[rr][0] * cv[2] + Jp[rr][1] * cv[5] + Jp[rr][2] * cv[8];
-        Jl[rr][0] = a0; Jl[rr][1] = a1; Jl[rr][2] = a2;
-        Jc[rr][0] = a0; Jc[rr][1] = a1; Jc[rr][2] = a2;
-        Jc[rr][3] = a2 * pw[1] - a1 * pw[2];
-        Jc[rr][4] = a0 * pw[2] - a2 * pw[0];
-        Jc[rr][5] = a1 * pw[0] - a0 * pw[1];
+        Jl[rr][0] = a0 * ml; Jl[rr][1] = a1 * ml; Jl[rr][2] = a2 * ml;
+        Jc[rr][0] = a0 * mp; Jc[rr][1] = a1 * mp; Jc[rr][2] = a2 * mp;
+        Jc[rr][3] = (a2 * pw[1] - a1 * pw[2]) * mp;
+        Jc[rr][4] = (a0 * pw[2] - a2 * pw[0]) * mp;
+        Jc[rr][5] = (a1 * pw[0] - a0 * pw[1]) * mp;
     }
     if (DC == 9) {
-        const double xw = xn * w, yw = yn * w, fr2 = f * r2, fr4 = f * r4;
+        const double xw = xn * w * mi, yw = yn * w * mi, fr2 = f * r2, fr4 = f * r4;
         Jc[0][DC - 3] = xw * dist; Jc[0][DC - 2] = xw * fr2; Jc[0][DC - 1] = xw * fr4;
         Jc[1][DC - 3] = yw * dist; Jc[1][DC - 2] = yw * fr2; Jc[1][DC - 1] = yw * fr4;
     }

@@ -25,6 +25,7 @@ namespace apex {
 enum Stage { kStAssembleCam = 0, kStAssembleLm, kStScatter, kStAllReduce, kStFactor, kStTriSolve, kStBackSub, kStStats,
              kStRetract, kStCost, kNumStages };
 
+int mode_mask(int mode);  // 4 POSE + 2 LANDMARK + INTRINSIC of an APEXGPU_MODE_*
 void shard_range(int64_t n_pt, const int64_t* ptr, int rank, int world, int64_t* lo, int64_t* hi);
 
 class Solver : public LmBackend {

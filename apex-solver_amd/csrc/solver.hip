@@ -36,8 +36,15 @@ static hipError_t dev_alloc(T** p, size_t n) {
     return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
 }
 
+// OptimizeParams<POSE, LANDMARK, INTRINSIC> of every mode as 4 POSE + 2 LANDMARK + INTRINSIC (src/factors/mod.rs:82-101)
+int mode_mask(int mode) {
+    static const int m[7] = {6 /* BundleAdjustment */, 7 /* SelfCalibration */, 4 /* OnlyPose */, 2 /* OnlyLandmarks */,
+                             1 /* OnlyIntrinsics */, 5 /* PoseAndIntrinsics */, 3 /* LandmarksAndIntrinsics */};
+    return (mode >= 0 && mode < 7) ? m[mode] : 7;
+}
+
 Solver::Solver(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device)
-    : n_cam_(n_cam), n_pt_(n_pt), n_obs_(n_obs), mode_(mode), dc_(mode == 1 ? 9 : 6), device_(device) {
+    : n_cam_(n_cam), n_pt_(n_pt), n_obs_(n_obs), mode_(mode), dc_(mode_mask(mode) & 1 ? 9 : 6), device_(device) {
     lm_lo_ = 0; lm_hi_ = n_pt;
 }
 
@@ -307,7 +314,7 @@ int Solver::set_params(const double* poses, const double* intr, const double* po
         src_pts = hpt.data();
     }
     HIP_TRY(hipMemcpyAsync(pts_[cur_], src_pts, 3 * n_pt_ * sizeof(double), hipMemcpyHostToDevice, stream_));
-    launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], stream_);
+    launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], mode_mask(mode_), stream_);
     HIP_TRY(hipStreamSynchronize(stream_));
     have_params_ = true; have_step_ = have_trial_ = false;
     return kOk;
@@ -787,7 +794,7 @@ int Solver::eval_step(double* trial_cost) {
     stage_begin(kStRetract);
     launch_retract(dc_, n_cam_, n_pt_, poses_[cur_], intr_[cur_], pts_[cur_], dcam_, dl_, 1.0, fix_pose_, fix_intr_,
                    fix_pt_, poses_[t], intr_[t], pts_[t], stream_);
-    launch_prepare_cams(n_cam_, poses_[t], intr_[t], camp_[t], stream_);
+    launch_prepare_cams(n_cam_, poses_[t], intr_[t], camp_[t], mode_mask(mode_), stream_);
     stage_end(kStRetract);
     have_trial_ = true;
     return cost_of(t, trial_cost);
@@ -809,7 +816,7 @@ int Solver::discard_step() {
     stage_begin(kStRetract);
     launch_retract(dc_, n_cam_, n_pt_, poses_[t], intr_[t], pts_[t], dcam_, dl_, -1.0, fix_pose_, fix_intr_, fix_pt_,
                    poses_[cur_], intr_[cur_], pts_[cur_], stream_);
-    launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], stream_);
+    launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], mode_mask(mode_), stream_);
     stage_end(kStRetract);
     HIP_TRY(hipStreamSynchronize(stream_));
     have_trial_ = false; have_step_ = false;

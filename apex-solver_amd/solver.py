@@ -58,10 +58,20 @@ class SchurPreconditioner(enum.Enum):
 
 
 class OptimizationType(enum.Enum):
-    """bin/bundle_adjustment.rs:268-284 (the two types that involve the Schur path)."""
+    """OptimizeParams<POSE, LANDMARK, INTRINSIC> (src/factors/mod.rs:66-101; bin/bundle_adjustment.rs:268-292)."""
 
     BundleAdjustment = 0  # factor keys [pose, pt]
     SelfCalibration = 1   # factor keys [pose, pt, intr]  (the reference's default)
+    OnlyPose = 2                # <true, false, false>: landmarks and intrinsics are constants of the factors
+    OnlyLandmarks = 3           # <false, true, false>
+    OnlyIntrinsics = 4          # <false, false, true>
+    PoseAndIntrinsics = 5       # <true, false, true>
+    LandmarksAndIntrinsics = 6  # <false, true, true>
+
+    @property
+    def flags(self):
+        """(POSE, LANDMARK, INTRINSIC)"""
+        return {0: (1, 1, 0), 1: (1, 1, 1), 2: (1, 0, 0), 3: (0, 1, 0), 4: (0, 0, 1), 5: (1, 0, 1), 6: (0, 1, 1)}[self.value]
 
 
 class OptimizationStatus(enum.Enum):
@@ -337,7 +347,7 @@ class GpuSchurComplementSolver:
         return r
 
     def get_jacobian_blocks(self):
-        h = self._need(); dc = 9 if h.mode == 1 else 6
+        h = self._need(); dc = 9 if h.mode in (1, 4, 5, 6) else 6
         jc = np.zeros((h.n_obs, 2, dc)); jl = np.zeros((h.n_obs, 2, 3))
         h.check(h.L.apexgpu_get_jacobian_blocks(h.h, capi.ptr(jc), capi.ptr(jl)))
         return jc, jl

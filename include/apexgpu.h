@@ -44,6 +44,16 @@ typedef struct apexgpu_solver apexgpu_solver;
  * bin/bundle_adjustment.rs:268-284): which variables each factor is keyed on. */
 #define APEXGPU_MODE_BUNDLE_ADJUSTMENT 0 /* keys [pose, pt]        -> 6 camera DOF per block */
 #define APEXGPU_MODE_SELF_CALIBRATION 1  /* keys [pose, pt, intr]  -> 9 camera DOF per block */
+/* The other OptimizeParams<POSE, LANDMARK, INTRINSIC> configurations (src/factors/mod.rs:88-101): a factor keyed on the
+ * optimised blocks only, the rest constants of the factor (with_fixed_pose / with_fixed_landmarks / its camera model).
+ * The variable set and the global column order are unchanged (every pose_*, intr_*, pt_* variable exists, as in the
+ * reference's bin, bundle_adjustment.rs:232-257); the blocks that are not optimised have no Jacobian columns, so the
+ * damped system gives them a zero step.  Same kernels with the Jacobian's column groups masked. */
+#define APEXGPU_MODE_ONLY_POSE 2                /* <true,  false, false> */
+#define APEXGPU_MODE_ONLY_LANDMARKS 3           /* <false, true,  false> */
+#define APEXGPU_MODE_ONLY_INTRINSICS 4          /* <false, false, true > */
+#define APEXGPU_MODE_POSE_AND_INTRINSICS 5      /* <true,  false, true > */
+#define APEXGPU_MODE_LANDMARKS_AND_INTRINSICS 6 /* <false, true,  true > */
 
 /* SchurVariant (src/linalg/sparse/explicit_schur.rs:58-65) */
 #define APEXGPU_VARIANT_SPARSE 0    /* explicit S + Cholesky (solve_with_cholesky, :539-634) */

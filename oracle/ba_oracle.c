@@ -843,7 +843,8 @@ int ora_schur_solve_dense_jacobian(int64_t n_rows, int64_t cam_dof, int64_t n_pt
 
 typedef struct {
     int64_t n_cam, n_pt, n_obs;
-    int mode; /* 0: BundleAdjustment keys [pose,pt]; 1: SelfCalibration keys [pose,pt,intr] */
+    int mode; /* 0: BundleAdjustment keys [pose,pt]; 1: SelfCalibration keys [pose,pt,intr]; 2..6: OnlyPose, OnlyLandmarks,
+               * OnlyIntrinsics, PoseAndIntrinsics, LandmarksAndIntrinsics (src/factors/mod.rs:82-101) */
     uint32_t *cam_idx, *pt_idx;
     double *obs_uv;
     int64_t *intr_col, *pose_col, *pt_col; /* reference global columns */
@@ -944,6 +945,16 @@ double ora_residuals(ora_problem *p, double *r_out) {
     return ora_compute_cost(2 * p->n_obs, p->r);
 }
 
+/* OptimizeParams<POSE, LANDMARK, INTRINSIC> of a mode as 4 POSE + 2 LANDMARK + INTRINSIC (src/factors/mod.rs:66-101):
+ * evaluate_internal (projection_factor.rs:184-296) allocates Jacobian columns for the optimised blocks only; the blocks
+ * that are not optimised are constants of the factor (fixed_pose / fixed_landmarks / its camera model).  The variable set
+ * is the bin's (every pose_*, intr_*, pt_* exists, bundle_adjustment.rs:232-257), so a block without columns is a block
+ * of zero columns in the global Jacobian. */
+static int ora_mode_mask(int mode) {
+    static const int m[7] = {6, 7, 4, 2, 1, 5, 3};
+    return (mode >= 0 && mode < 7) ? m[mode] : 7;
+}
+
 /* A5: assemble (linearizer/cpu/sparse.rs:119-184): residual + Jacobian blocks.
  * In mode 0 the factor has no intrinsics key; Jintr is kept (for inspection) but is not
  * part of the Jacobian. Outputs may be NULL. */
@@ -954,6 +965,10 @@ double ora_linearize(ora_problem *p, double *r_out, double *Jpose_out, double *J
         ora_linearize_obs(p->poses + 7 * c, p->intr + 3 * c, p->points + 3 * l, p->obs_uv + 2 * i,
                           p->huber_delta, 1, p->r + 2 * i, p->Jpose + 12 * i, p->Jpt + 6 * i,
                           p->Jintr + 6 * i);
+        const int mk = ora_mode_mask(p->mode);
+        if (!(mk & 4)) memset(p->Jpose + 12 * i, 0, 96);
+        if (!(mk & 2)) memset(p->Jpt + 6 * i, 0, 48);
+        if (!(mk & 1) && p->mode >= 2) memset(p->Jintr + 6 * i, 0, 48);   /* (mode 0 keeps it for inspection, as before) */
     }
     if (r_out) memcpy(r_out, p->r, (size_t)p->n_obs * 16);
     if (Jpose_out) memcpy(Jpose_out, p->Jpose, (size_t)p->n_obs * 96);
@@ -977,7 +992,7 @@ static int cmp_i64(const void *a, const void *b) {
 int ora_solve_augmented(ora_problem *p, double lambda, int variant, double *step_out,
                         double *grad_out, double *S_out, double *gred_out) {
     const int64_t nc = p->cam_dof, npt = p->n_pt, nobs = p->n_obs, cam0 = 0, land0 = nc;
-    const int has_intr = p->mode == 1;
+    const int has_intr = ora_mode_mask(p->mode) & 1;
     /* With Jacobi scaling the LM loop hands the solver J * diag(scaling) (process_jacobian_generic,
      * optimizer/mod.rs:749-763; apply_column_scaling, linearizer/mod.rs:241-253): everything below then
      * runs on the scaled blocks and step_out / grad_out are the SCALED step and gradient, exactly what
@@ -1141,7 +1156,7 @@ int ora_column_norms(const ora_problem *p, double *norms_out) {
         for (int rr = 0; rr < 2; ++rr) {
             for (int a = 0; a < 6; ++a) { double v = p->Jpose[12 * i + 6 * rr + a]; norms_out[p->pose_col[c] + a] += v * v; }
             for (int a = 0; a < 3; ++a) { double v = p->Jpt[6 * i + 3 * rr + a]; norms_out[p->pt_col[l] + a] += v * v; }
-            if (p->mode == 1)
+            if (ora_mode_mask(p->mode) & 1)
                 for (int a = 0; a < 3; ++a) { double v = p->Jintr[6 * i + 3 * rr + a]; norms_out[p->intr_col[c] + a] += v * v; }
         }
     }

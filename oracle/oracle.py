@@ -145,6 +145,10 @@ def lib(native: bool = False):
     return L
 
 
+MODES = {"ba": 0, "selfcal": 1, "only_pose": 2, "only_landmarks": 3, "only_intrinsics": 4, "pose_and_intrinsics": 5,
+         "landmarks_and_intrinsics": 6}
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -199,7 +203,7 @@ class OracleProblem:
         ft = None if self.fix_pt is None else np.ascontiguousarray(self.fix_pt, dtype=np.uint8)
         self._keep = (fp, fi, ft)
         self._h = self._L.ora_problem_create(
-            self.n_cam, self.n_pt, self.n_obs, 1 if self.mode == "selfcal" else 0,
+            self.n_cam, self.n_pt, self.n_obs, MODES[self.mode],
             self.cam_idx, self.pt_idx, self.obs_uv, self.intr_col, self.pose_col, self.pt_col,
             float(self.huber_delta), _ptr(fp), _ptr(fi), _ptr(ft))
 

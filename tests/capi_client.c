@@ -65,7 +65,7 @@ static int level1_sequence(apexgpu_solver* h, int64_t n_cam, int64_t n_pt, const
     if (rc) return rc;
     memset(res, 0, sizeof *res);
     res->initial_cost = cur;
-    int iteration = 0, status = 0 /* MaxIterationsReached */;
+    int iteration = 0, status = 1 /* OptimizationStatus::MaxIterationsReached (src/optimizer/mod.rs:189-216) */;
     for (;;) {
         rc = apexgpu_set_params(h, poses, intr, pts);                  /* GpuBaMode::assemble: upload state.variables */
         if (!rc) rc = apexgpu_solve_augmented(h, lambda, cfg->variant, step, grad);   /* solve_augmented_equation */
@@ -95,12 +95,12 @@ static int level1_sequence(apexgpu_solver* h, int64_t n_cam, int64_t n_pt, const
         { const double a = norm2(poses, 7 * n_cam), b = norm2(intr, 3 * n_cam), c = norm2(pts, 3 * n_pt); pn = sqrt(a * a + b * b + c * c); }
         const double before = accepted ? cur + reduction : cur;
         int st = -1;
-        if (iteration >= cfg->max_iterations) st = 0;
+        if (iteration >= cfg->max_iterations) st = 1;
         else if (accepted) {
-            if (gn < cfg->gradient_tolerance) st = 3;
+            if (gn < cfg->gradient_tolerance) st = 4;   /* GradientToleranceReached */
             if (st < 0 && iteration > 0) {
-                if (sn <= cfg->parameter_tolerance * (pn + cfg->parameter_tolerance)) st = 2;
-                else if (fabs(before - cur) / (before > 1e-10 ? before : 1e-10) < cfg->cost_tolerance) st = 1;
+                if (sn <= cfg->parameter_tolerance * (pn + cfg->parameter_tolerance)) st = 3;   /* ParameterToleranceReached */
+                else if (fabs(before - cur) / (before > 1e-10 ? before : 1e-10) < cfg->cost_tolerance) st = 2;   /* CostToleranceReached */
             }
         }
         ++iteration;
