@@ -71,15 +71,13 @@ def lm_step(s, state):
     state["hist"].append((state["cost"], rho))
 
 
-def cpu_baseline(args, shape_scale, mode):
-    """The oracle (kind "port": C restatement of the reference CPU path, OpenMP) timed on this
-    box's host cores on a bounded sample of the same workload."""
+def cpu_baseline_worker(workload, shape_scale, mode):
+    """Runs in a child process (OMP_NUM_THREADS / OMP_PROC_BIND set by the parent): 2 LM iterations of the oracle."""
     import apex_solver_amd as pkg
     from oracle import oracle as ora
 
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    d = pkg.synthetic.make_named(args.workload, shape_scale)
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    d = pkg.synthetic.make_named(workload, shape_scale)
     lay = pkg.layout.reference_column_layout(d.n_cam, d.n_pt)
     o = ora.from_data(d, lay, mode=mode, native=True)
     cost = o.residuals()[0]
@@ -105,6 +103,31 @@ def cpu_baseline(args, shape_scale, mode):
                   f"{2} LM iterations of oracle/ba_oracle.c (linearise + explicit dense Schur + dense Cholesky + trial cost)",
         "obs_per_s": d.n_obs / (ms * 1e-3),
     }
+
+
+def cpu_baseline(args, shape_scale, mode):
+    """The oracle (kind "port": C restatement of the reference CPU path, OpenMP, pinned threads) timed on this box's host
+    cores on bounded samples of the same workload: all cores on the ~1000-camera sample (the reference forms S densely:
+    9000^2), and ONE thread on a third of it (SURVEY §8d asks for both; a single thread on the larger sample would take
+    minutes).  Each runs in its own child process so that the OpenMP runtime starts with the wanted thread count."""
+    import subprocess
+
+    cores = os.cpu_count() or 1
+    out = None
+    for threads, sc in ((cores, shape_scale), (1, shape_scale / 3.0)):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+        code = (f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; "
+                f"print('CPUBASE ' + json.dumps(bench.cpu_baseline_worker({args.workload!r}, {sc!r}, {mode!r})))")
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        line = [l for l in p.stdout.splitlines() if l.startswith("CPUBASE ")]
+        if not line:
+            raise RuntimeError(p.stderr[-500:])
+        r = json.loads(line[0][8:])
+        if out is None:
+            out = r
+        else:
+            out["one_thread"] = {k: r[k] for k in ("value", "unit", "cores", "sample", "obs_per_s")}
+    return out
 
 
 def bench_pose_graph(args):
@@ -282,6 +305,7 @@ def main():
 
     s.enable_stage_timing(True)
     s.reset_stage_times()
+    accepted_before = state["accepted"]
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -295,38 +319,54 @@ def main():
     stages = s.stage_times()
     ms_per_step = elapsed * 1e3 / args.steps
 
-    # ---- roofline of the graded Schur-reduction kernel (k_schur_rows), per launch -----------------------
+    # ---- roofline of the graded Schur-reduction kernel, per launch -------------------------------------------------------
     dc = 9 if args.mode == "selfcal" else 6
+    form = info.get("schur_form", 3)
+    kernel = {3: "k_schur_pairs", 2: "k_schur_rows2", 1: "k_schur_rows", 0: "k_schur_scatter"}[form]
     n_obs_local = info["local_obs"]
     tile_bytes = 144 * 144 * 8
+    # SURVEY §8(d), fused form (J never stored): each input read once, each output written once
     alg_bytes = (24.0 * n_obs_local            # observation stream: cam idx, landmark idx, (u,v)
                  + 80.0 * d.n_cam + 24.0 * d.n_pt  # poses + intrinsics, points (each read once)
                  + 96.0 * d.n_pt                # Hll^-1 and g_l per landmark
                  + tile_bytes * info["touched_tiles"]  # S tiles that receive contributions
                  + 8.0 * dc * d.n_cam)          # g_red
+    st = s.setup_times()
+    pair_list_bytes = 16.0 * st["pair_slots"]   # the sorted pair list the default form streams (an index, like cam/pt idx)
     sc_ms, sc_n = stages["schur_scatter"]
     sc_avg = sc_ms / max(sc_n, 1)
     achieved = alg_bytes / (sc_avg * 1e-3) / 1e9 if sc_avg > 0 else 0.0
-    # one lane per observation: the observation's linearisation, W_i and Y_i once (250 flop + 54 + 81 FMA), then per
-    # partner its linearisation, W_j (54 FMA) and the d_c x d_c x 3 block product
-    flop_per_pair = 250 + 2 * (dc * 3 + 3 * dc * dc)
-    flop_per_obs = 250 + 2 * (dc * 3 + dc * 9)
-    gflops = (info["pair_blocks"] * flop_per_pair + n_obs_local * flop_per_obs) / (sc_avg * 1e-3) / 1e9 if sc_avg > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_schur_rows2", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # useful fp64 work of the reduction: every camera pair of a landmark once (rank-2 form: 12 + 36 + 162 FMA) and every
+    # observation linearised once (~125 fp64 operations); the kernel re-linearises both observations of every pair
+    off_pairs = info["pair_blocks"] - n_obs_local      # pair contributions without the self pairs
+    useful_flop = 2.0 * (12 + 4 * dc + 2 * dc * dc) * off_pairs + 250.0 * n_obs_local
+    executed_flop = (2.0 * (12 + 4 * dc + 2 * dc * dc) + 2 * 250.0 + 36.0) * off_pairs
+    stage_ms = sum(stages[k][0] / max(stages[k][1], 1) * (2 if k == "cam_reduce" else 1) for k in ("landmark_reduce", "cam_reduce", "schur_scatter"))
+    stage_ms = (stages["landmark_reduce"][0] + stages["cam_reduce"][0] + stages["schur_scatter"][0]) / max(sc_n, 1)
+    roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
+                "pair_list_bytes": pair_list_bytes if form == 3 else 0.0,
                 "avg_launch_ms": sc_avg, "launches": sc_n,
-                "pair_blocks_per_launch": info["pair_blocks"], "lds_atomic_adds_per_launch": info["pair_blocks"] * dc * dc,
-                "fp64_gflops": gflops, "fp64_vector_peak_gflops": 78600.0}
+                "actual_bound": "fp64 vector unit + LDS (the fused form moves 2 GB but executes ~60 GFLOP: DESIGN.md §4)",
+                "pair_contributions_per_launch": off_pairs,
+                "fp64_useful_gflops": useful_flop / (sc_avg * 1e-3) / 1e9 if sc_avg > 0 else 0.0,
+                "fp64_executed_gflops": executed_flop / (sc_avg * 1e-3) / 1e9 if sc_avg > 0 else 0.0,
+                "fp64_vector_peak_gflops": 78600.0,
+                "fp64_useful_frac": useful_flop / (sc_avg * 1e-3) / 78.6e12 if sc_avg > 0 else 0.0,
+                "schur_stage": {"kernels": "k_landmark_reduce + k_cam_reduce + " + kernel, "ms": stage_ms,
+                                "achieved": alg_bytes / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0,
+                                "frac": alg_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms > 0 else 0.0}}
 
     # HBM traffic of the same kernel from the committed PMC pass (rocprofv3 cannot run inside this
-    # process); only attached when the committed profile is of this very workload
+    # process); only attached when the committed profile is of this very workload and kernel
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_final13682_pmc_summary.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_final13682_pmc_summary.json")))
         if world == 1 and args.workload == "final-13682" and args.scale == 1.0 and args.mode == "selfcal":
-            k = [v for n, v in pm["kernels"].items() if "k_schur_rows" in n]
+            k = [v for n, v in pm["kernels"].items() if kernel in n]
             if k:
                 roofline["traffic"] = k[0]["hbm_bytes_per_launch_corrected"]
-                roofline["traffic_source"] = "profiles/r01_final13682_pmc_summary.json"
+                roofline["traffic_raw"] = k[0].get("hbm_bytes_per_launch_raw")
+                roofline["traffic_source"] = "profiles/r02_final13682_pmc_summary.json"
     except Exception:
         pass
 
@@ -336,11 +376,14 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{d.name} synthetic ({d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations)",
                    "optimization_type": args.mode, "camera_dof": dc, "schur_variant": args.variant, "huber": 1.0,
-                   "s_tile_rows": info["tile_rows"], "s_tiles": info["tiles"], "parallelism": f"landmark-shard x{world}" + (f", landmarks and Cholesky distributed by elimination subtree ({info['dist_top_columns']} shared top tile columns, tree_sharded={info.get('tree_sharded')})" if info.get("dist_top_columns") else "")},
+                   "s_tile_rows": info["tile_rows"], "s_tiles": info["tiles"], "s_tiles_touched": info["touched_tiles"],
+                   "etree_levels": info["etree_levels"], "border_cameras": st["hub_cameras"], "schur_form": form, "parallelism": f"landmark-shard x{world}" + (f", landmarks and Cholesky distributed by elimination subtree ({info['dist_top_columns']} shared top tile columns, tree_sharded={info.get('tree_sharded')})" if info.get("dist_top_columns") else "")},
         "roofline": roofline,
         "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
         "stage_launches": {k: int(v[1]) for k, v in stages.items()},
-        "setup_s": setup_s, "initial_cost": initial_cost, "final_cost": state["cost"], "accepted_steps": state["accepted"],
+        "setup_s": setup_s, "setup_by_phase_s": {k: st[k] for k in ("order", "lists", "tile_plan", "schur_lists", "uploads", "total")},
+        "initial_cost": initial_cost, "final_cost": state["cost"], "accepted_steps": state["accepted"] - accepted_before,
+        "accepted_steps_incl_warmup": state["accepted"],
         "obs_per_s": d.n_obs / (ms_per_step * 1e-3),
     }
     if args.variant != "sparse":
