@@ -122,10 +122,39 @@ APEX_HD void quat_mul(const double a[4], const double b[4], double o[4]) {
     o[3] = a[0] * b[3] + b[0] * a[3] + c[2];
 }
 
+// Reciprocal and reciprocal square root.  On the device: the hardware approximations refined by two Newton steps (full
+// double precision, a third of the instructions of the IEEE division / square-root sequences: every per-observation
+// kernel executes them once or twice per observation); on the host (tests/host_harness.cpp) the plain operations.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double apex_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double apex_rsqrt(double x) {   // x > 0
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    return y;
+}
+#else
+inline double apex_rcp(double x) { return 1.0 / x; }
+inline double apex_rsqrt(double x) { return 1.0 / sqrt(x); }
+#endif
+
 // Huber weight sqrt(rho'(s)) for s = |r|^2 (delta <= 0: no loss function).  For Huber
 // rho'' <= 0, hence alpha = 0 and both J and r are scaled by sqrt(rho') (corrector.rs:156-162).
 APEX_HD double huber_sqrt_rho1(double delta, double s) {
-    if (delta > 0.0 && s > delta * delta) return sqrt(delta / sqrt(s));
+    if (delta > 0.0 && s > delta * delta) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double t = delta * apex_rsqrt(s);   // delta / sqrt(s)
+        return t * apex_rsqrt(t);                 // sqrt(t)
+#else
+        return sqrt(delta / sqrt(s));
+#endif
+    }
     return 1.0;
 }
 
@@ -135,7 +164,7 @@ APEX_HD bool residual_obs(const Cam& c, const double pw[3], double u_obs, double
     double pc[3];
     cam_transform(c, pw, pc);
     if (!(pc[2] < -kMinDepth)) { r[0] = 0.0; r[1] = 0.0; return false; }
-    double inz = -1.0 / pc[2];
+    double inz = -apex_rcp(pc[2]);
     double xn = pc[0] * inz, yn = pc[1] * inz;
     double r2 = xn * xn + yn * yn, r4 = r2 * r2;
     double d = 1.0 + c.k1 * r2 + c.k2 * r4;
@@ -149,7 +178,9 @@ APEX_HD bool residual_obs(const Cam& c, const double pw[3], double u_obs, double
 // Full linearisation of one observation (A1+A2+A4).  DC = 6: camera block = pose only
 // (BundleAdjustment keys [pose,pt]); DC = 9: [pose | intrinsics] (SelfCalibration).
 // Jc is 2 x DC (row-major [row][col]), Jl is 2 x 3; both CORRECTED (scaled by sqrt(rho')).
-template <int DC>
+// MASKED = false: every block the factor has columns for is optimised (SelfCalibration; BundleAdjustment at DC = 6) -- the
+// column masks are all ones and are not read (the register-critical kernels instantiate this form for those modes).
+template <int DC, bool MASKED = true>
 APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, double v_obs,
                            double huber_delta, double r[2], double Jc[2][DC], double Jl[2][3]) {
     double pc[3];
@@ -163,7 +194,7 @@ APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, doubl
         return false;
     }
     const double f = c.f, k1 = c.k1, k2 = c.k2;
-    double inz = -1.0 / pc[2];
+    double inz = -apex_rcp(pc[2]);
     double xn = pc[0] * inz, yn = pc[1] * inz;
     double r2 = xn * xn + yn * yn, r4 = r2 * r2;
     double dist = 1.0 + k1 * r2 + k2 * r4;
@@ -192,7 +223,7 @@ APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, doubl
         double a0 = Jp[rr][0] * R[0] + Jp[rr][1] * R[3] + Jp[rr][2] * R[6];
         double a1 = Jp[rr][0] * R[1] + Jp[rr][1] * R[4] + Jp[rr][2] * R[7];
         double a2 = Jp[rr][0] * R[2] + Jp[rr][1] * R[5] + Jp[rr][2] * R[8];
-        const double wl = w * c.m_lm, wp = w * c.m_pose;
+        const double wl = MASKED ? w * c.m_lm : w, wp = MASKED ? w * c.m_pose : w;
         Jl[rr][0] = a0 * wl; Jl[rr][1] = a1 * wl; Jl[rr][2] = a2 * wl;
         Jc[rr][0] = a0 * wp; Jc[rr][1] = a1 * wp; Jc[rr][2] = a2 * wp;
         Jc[rr][3] = -(a1 * pw[2] - a2 * pw[1]) * wp;
@@ -201,7 +232,7 @@ APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, doubl
     }
     if (DC == 9) {
         // d(u,v)/d(f,k1,k2)  (bal_pinhole.rs:649-672)
-        const double wi = w * c.m_intr;
+        const double wi = MASKED ? w * c.m_intr : w;
         Jc[0][DC - 3] = (xn * dist) * wi; Jc[0][DC - 2] = (f * xn * r2) * wi; Jc[0][DC - 1] = (f * xn * r4) * wi;
         Jc[1][DC - 3] = (yn * dist) * wi; Jc[1][DC - 2] = (f * yn * r2) * wi; Jc[1][DC - 1] = (f * yn * r4) * wi;
     }

@@ -19,6 +19,7 @@ struct BAView {
     const double2* o_uv;   // [n_obs]
     const int* pt_ptr;     // [n_pt+1]
     double huber_delta;
+    int mask_code;         // 4 POSE + 2 LANDMARK + INTRINSIC (OptimizeParams); 7 (6 at d_c = 6): no column group is masked
     const uint32_t* co_pt; // [n_obs] camera-major copies (entry k of the camera lists): landmark index
     const double2* co_uv;  // [n_obs]                                                   and measurement
     const int* co_rank;    // [n_obs] position of the observation inside its landmark's list

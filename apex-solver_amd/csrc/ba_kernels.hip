@@ -74,8 +74,8 @@ __device__ __forceinline__ double* s_block_ptr(const TileMap& tm, uint32_t row_c
 // (+lambda on the diagonal when add_lambda), g_c and g_red := -g_c.
 // ------------------------------------------------------------------------------------------
 constexpr int kCamThreads = 64;  // one wave per camera: ~30 observations per lane amortise the 63-value reduction
-template <int DC>
-__global__ __launch_bounds__(kCamThreads) void k_cam_reduce(BAView v, TileMap tm, const int* __restrict__ cam_ptr,
+template <int DC, bool MASKED>
+__global__ __launch_bounds__(kCamThreads, 2) void k_cam_reduce(BAView v, TileMap tm, const int* __restrict__ cam_ptr,
                                                       const int* __restrict__ cam_obs, double lambda,
                                                       int add_lambda, const double* __restrict__ hinv,
                                                       const double* __restrict__ g_l, int with_self,
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kCamThreads) void k_cam_reduce(BAView v, TileMap tm
         load_lm_record(hinv, l, rec);     // Hll^-1, g_l and the point: one 128-byte line
         const double pw[3] = {rec[kLmPt], rec[kLmPt + 1], rec[kLmPt + 2]};
         double r[2], Jc[2][DC], Jl[2][3];
-        linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
+        linearize_obs<DC, MASKED>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
         int idx = 0;
 #pragma unroll
         for (int a = 0; a < DC; ++a)
@@ -1061,8 +1061,11 @@ void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* ca
                        double lambda, int add_lambda, const double* hinv, const double* g_l, int with_self, double* g_c,
                        double* g_red, hipStream_t s) {
     if (v.n_cam == 0) return;
-    if (dc == 9) hipLaunchKernelGGL(k_cam_reduce<9>, dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
-    else hipLaunchKernelGGL(k_cam_reduce<6>, dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
+    const bool masked = !(v.mask_code == 7 || (dc == 6 && v.mask_code == 6));   // (the masked form costs a wave per SIMD at d_c = 9)
+    if (dc == 9 && !masked) hipLaunchKernelGGL((k_cam_reduce<9, false>), dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
+    else if (dc == 9) hipLaunchKernelGGL((k_cam_reduce<9, true>), dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
+    else if (!masked) hipLaunchKernelGGL((k_cam_reduce<6, false>), dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
+    else hipLaunchKernelGGL((k_cam_reduce<6, true>), dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
 }
 
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag, double* lmu,

@@ -26,7 +26,8 @@ struct BaStructOptions {
     int rank = 0, world = 1;
     bool dist_factor = true, tree_sharding = true;
     int dist_selftest = 0;
-    int schur_form = 3;        // 3 sorted pair list on MFMA, 2 / 1 LDS rows, 0 global atomics
+    int schur_form = 3;        // 3 sorted pair list, 2 / 1 LDS rows, 0 global atomics
+    int pair_task_slots = 0;   // pair slots per wave task of the pair list (0: default)
 };
 
 struct BaHostStructure {

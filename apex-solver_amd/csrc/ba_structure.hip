@@ -335,7 +335,7 @@ void BaHostStructure::build_schur_lists(const BaStructOptions& o, const int* slo
     if (o.schur_form == 3) {
         // every camera pair (i, j) of a landmark, sorted by the block S(cam_i, cam_j) it adds to
         build_pair_lists(dc, nt, slot_host, n_cam, cinv.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(),
-                         cam_obs.data(), &pl);
+                         cam_obs.data(), &pl, o.pair_task_slots);
     } else if (o.schur_form == 0) {
         // ---- Schur-scatter tasks over the local landmarks (global-atomics form) --------------------------------------
         int cur0 = -1, curn = 0;

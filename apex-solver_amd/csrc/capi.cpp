@@ -226,7 +226,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     // Switches that shape what set_structure builds (task lists, tile order, partition) or what the captured hipGraphs
     // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
     // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
-    static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "potrf_lookahead", "dist_factor", "tree_sharding", "dist_selftest",
+    static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "dist_factor", "tree_sharding", "dist_selftest",
                                              "nested_dissection", "update_overlap", "fused_forward"};
     if (h->s->has_structure())
         for (const char* k : structural)
@@ -240,6 +240,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "rows_debug") h->s->set_rows_debug(value);
     else if (n == "pairs_ablation") apex::set_pairs_ablation(value);   /* timing experiments only */
     else if (n == "hubs_last") h->s->set_hubs_last(value != 0);
+    else if (n == "pair_task_slots") h->s->set_pair_task_slots(value);
     else if (n == "dist_factor") h->s->set_dist_factor(value != 0);
     else if (n == "tree_sharding") h->s->set_tree_sharding(value != 0);
     else if (n == "dist_selftest") h->s->set_dist_selftest(value);

@@ -56,7 +56,8 @@ struct PairLists {
 // of internal camera ci (rows are processed in the caller's order: consecutive rows then share landmarks);
 // slot: tile slot map (nt x nt, lower).
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
-                      const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out);
+                      const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
+                      int task_slots = 0 /* 0: default */);
 
 void set_pairs_ablation(int bits);   // timing experiments only: results are wrong when != 0
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,

@@ -23,8 +23,10 @@ struct RawPair { uint32_t cj, i, j; };
 }  // namespace
 
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
-                      const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out) {
+                      const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
+                      int task_slots) {
     const int cpt = kNB / dc;
+    const int kTask = task_slots > 0 ? (task_slots + 63) / 64 * 64 : kPairTaskSlots;
     // rows in the caller's camera order
     std::vector<int> rows(n_cam);
     for (int64_t c = 0; c < n_cam; ++c) rows[c] = (int)c;
@@ -93,14 +95,14 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
             while (len > 0) {
                 const int take = (int)std::min<int64_t>(len, split ? kPairMaxBlockSlots : len);
                 const int padded = (take + 1) / 2 * 2;
-                if (!split && slot_pos - task_begin > 0 && slot_pos - task_begin + padded > 2 * kPairTaskSlots) close_task();
+                if (!split && slot_pos - task_begin > 0 && slot_pos - task_begin + padded > 2 * kTask) close_task();
                 const int bi = (int)out->blocks.size();
                 out->blocks.push_back(PairBlock{dst, (uint32_t)ci, cj, diag | ((split || diag) ? kPairBlockAtomic : 0u), 0u});
                 pieces.push_back(Piece{q, take, slot_pos});
                 chunk_touch(slot_pos, slot_pos + padded, bi, true);
                 slot_pos += padded;
                 q += take; len -= take;
-                if (split || slot_pos - task_begin >= kPairTaskSlots) close_task();
+                if (split || slot_pos - task_begin >= kTask) close_task();
             }
         }
     }

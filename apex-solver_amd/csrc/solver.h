@@ -91,6 +91,7 @@ class Solver : public LmBackend {
     void set_rows_debug(int v) { rows_dbg_ = v; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void set_hubs_last(bool on) { hubs_last_ = on; }
+    void set_pair_task_slots(int n) { pair_task_slots_ = n; }
     int n_hubs() const { return n_hubs_; }
     void set_dist_factor(bool on) { dist_factor_ = on; }   // before set_structure
     void set_tree_sharding(bool on) { tree_sharding_ = on; }  // before set_structure
@@ -203,6 +204,7 @@ class Solver : public LmBackend {
     int n_tasks_ = 0;
     std::vector<int> cmap_, cinv_;   // external camera -> internal camera and back
     bool use_nd_ = true;
+    int pair_task_slots_ = 0;
     bool hubs_last_ = true;     // order cameras covisible with > max(16, 10 sqrt(n_cam)) others last (ba_structure.h)
     int n_hubs_ = 0, n_border_tiles_ = 1;
     int nd_leaf_ = 16;

@@ -78,6 +78,7 @@ BAView Solver::view(int which) const {
     v.camp = camp_[which]; v.pts = pts_[which];
     v.o_cam = o_cam_; v.o_pt = o_pt_; v.o_uv = o_uv_; v.pt_ptr = pt_ptr_;
     v.huber_delta = huber_delta_;
+    v.mask_code = mode_mask(mode_);
     v.co_pt = co_pt_; v.co_uv = co_uv_; v.co_rank = co_rank_;
     v.cam_scale = scaled_ ? cam_scale_ : nullptr;
     v.pt_scale = scaled_ ? pt_scale_ : nullptr;
@@ -168,7 +169,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     BaStructOptions so;
     so.dc = dc_; so.use_nd = use_nd_; so.nd_leaf = nd_leaf_; so.hubs_last = hubs_last_;
     so.rank = rank_; so.world = world_; so.dist_factor = dist_factor_; so.tree_sharding = tree_sharding_;
-    so.dist_selftest = dist_selftest_; so.schur_form = use_rows_ ? rows_form_ : 0;
+    so.dist_selftest = dist_selftest_; so.schur_form = use_rows_ ? rows_form_ : 0; so.pair_task_slots = pair_task_slots_;
     BaHostStructure hs;
     {
         const std::string e = hs.build_lists(n_cam_, n_pt_, n_obs_, cam_idx, pt_idx, obs_uv, so, tp_);
