@@ -76,18 +76,19 @@ impl GpuSchurComplementSolver {
         blocks.sort_by_key(|b| b.residual_row_start_idx);
         let n_obs = blocks.len();
         let (mut cam_idx, mut pt_idx, mut uv) = (Vec::with_capacity(n_obs), Vec::with_capacity(n_obs), Vec::with_capacity(2 * n_obs));
-        let mut selfcal: Option<bool> = None;
+        let mut mode: Option<i32> = None;
         let mut huber: Option<f64> = None; // Some(-1.0): no loss function on any block
         for b in &blocks {
             let d = b.factor.device_descriptor().ok_or_else(|| bad("a factor has no device descriptor".into()))?;
-            if *selfcal.get_or_insert(d.optimizes_intrinsics) != d.optimizes_intrinsics {
-                return Err(bad("mixed optimization types".into()));
-            }
-            let want = if d.optimizes_intrinsics { 3 } else { 2 };
-            if b.variable_key_list.len() != want { return Err(bad("unexpected key list of a projection factor".into())); }
+            let m = d.device_mode().ok_or_else(|| bad("a projection factor that optimises nothing".into()))?;
+            if *mode.get_or_insert(m) != m { return Err(bad("mixed optimization types".into())); }
+            // key lists as bin/bundle_adjustment.rs:391-441 builds them for EVERY OptimizeParams configuration:
+            // [pose, pt] or [pose, pt, intr]; which of them the factor optimises is the device mode (Jacobian column masks)
+            let keyed_intr = b.variable_key_list.len() == 3;
+            if b.variable_key_list.len() != 2 && !keyed_intr { return Err(bad("unexpected key list of a projection factor".into())); }
             let ci = *pose_index.get(b.variable_key_list[0].as_str()).ok_or_else(|| bad(format!("{} is not a pose", b.variable_key_list[0])))?;
             let pi = *pt_index.get(b.variable_key_list[1].as_str()).ok_or_else(|| bad(format!("{} is not a landmark", b.variable_key_list[1])))?;
-            if d.optimizes_intrinsics {
+            if keyed_intr {
                 let n = &b.variable_key_list[2];
                 match &intr_name[ci] {
                     None => intr_name[ci] = Some(n.clone()),
@@ -107,7 +108,7 @@ impl GpuSchurComplementSolver {
             if *huber.get_or_insert(scale) != scale { return Err(bad("mixed loss functions".into())); }
             cam_idx.push(ci as u32); pt_idx.push(pi as u32); uv.extend_from_slice(&d.uv);
         }
-        let selfcal = selfcal.unwrap_or(true);
+        let mode = mode.unwrap_or(APEXGPU_MODE_SELF_CALIBRATION);
         // columns and fixed masks (Variable::fixed_indices: zeroed in the step at apply time, src/core/problem.rs:185-197)
         let mut pose_col = vec![0i64; n_cam]; let mut intr_col = vec![0i64; n_cam];
         let mut fix_pose = vec![0u8; 6 * n_cam]; let mut fix_intr = vec![0u8; 3 * n_cam]; let mut fix_pt = vec![0u8; 3 * self.pt_vars.len()];
@@ -126,7 +127,6 @@ impl GpuSchurComplementSolver {
             for &k in self.fixed.get(&v.0).map(|x| x.as_slice()).unwrap_or(&[]) { if k < 3 { fix_pt[3 * j + k] = 1; } }
         }
         let mut h: *mut ApexGpuSolver = std::ptr::null_mut();
-        let mode = if selfcal { APEXGPU_MODE_SELF_CALIBRATION } else { APEXGPU_MODE_BUNDLE_ADJUSTMENT };
         let rc = unsafe { apexgpu_create(n_cam as i64, self.pt_vars.len() as i64, n_obs as i64, mode, self.device, &mut h) };
         if rc != 0 { return Err(LinAlgError::InvalidState(format!("apexgpu_create failed ({rc}): no MI355X device {}?", self.device))); }
         let ctx = Arc::new(GpuContext {

@@ -31,6 +31,11 @@ pub struct ApexGpuSolver {
 
 pub const APEXGPU_MODE_BUNDLE_ADJUSTMENT: c_int = 0;
 pub const APEXGPU_MODE_SELF_CALIBRATION: c_int = 1;
+pub const APEXGPU_MODE_ONLY_POSE: c_int = 2;
+pub const APEXGPU_MODE_ONLY_LANDMARKS: c_int = 3;
+pub const APEXGPU_MODE_ONLY_INTRINSICS: c_int = 4;
+pub const APEXGPU_MODE_POSE_AND_INTRINSICS: c_int = 5;
+pub const APEXGPU_MODE_LANDMARKS_AND_INTRINSICS: c_int = 6;
 
 extern "C" {
     pub fn apexgpu_create(n_cam: i64, n_pt: i64, n_obs: i64, mode: c_int, device: c_int, out: *mut *mut ApexGpuSolver) -> c_int;
@@ -80,8 +85,24 @@ pub struct DeviceFactorDesc {
     pub uv: [f64; 2],
     /// `[f, k1, k2]` of the factor's camera: the intrinsics the device uses when they are not variables (BundleAdjustment)
     pub intrinsics: [f64; 3],
-    /// true: keys `[pose, pt, intr]` (SelfCalibration), false: `[pose, pt]` (BundleAdjustment)
-    pub optimizes_intrinsics: bool,
+    /// `OP::POSE`, `OP::LANDMARK`, `OP::INTRINSIC` of the factor's `OptimizeParams` (src/factors/mod.rs:66-101): the key
+    /// list holds exactly the optimised ones, in this order
+    pub optimizes: [bool; 3],
+}
+impl DeviceFactorDesc {
+    /// The `mode` of `apexgpu_create` (include/apexgpu.h, `APEXGPU_MODE_*`) for this `OptimizeParams` configuration
+    pub fn device_mode(&self) -> Option<i32> {
+        match self.optimizes {
+            [true, true, false] => Some(APEXGPU_MODE_BUNDLE_ADJUSTMENT),
+            [true, true, true] => Some(APEXGPU_MODE_SELF_CALIBRATION),
+            [true, false, false] => Some(APEXGPU_MODE_ONLY_POSE),
+            [false, true, false] => Some(APEXGPU_MODE_ONLY_LANDMARKS),
+            [false, false, true] => Some(APEXGPU_MODE_ONLY_INTRINSICS),
+            [true, false, true] => Some(APEXGPU_MODE_POSE_AND_INTRINSICS),
+            [false, true, true] => Some(APEXGPU_MODE_LANDMARKS_AND_INTRINSICS),
+            [false, false, false] => None,
+        }
+    }
 }
 /// Returned by `LossFunction::device_descriptor()`; `HuberLoss` answers `Some(Huber { scale })`.
 #[derive(Clone, Copy, Debug, PartialEq)]
