@@ -882,6 +882,157 @@ __global__ __launch_bounds__(256) void k_tri_step(const TriTask* __restrict__ ta
 }
 
 // ------------------------------------------------------------------------------------------
+// The triangular sweeps as ONE dataflow launch each (single-GPU plans), one workgroup per tile column:
+//     forward   y_K = Linv_K   ( b_K - sum over the tiles (K, J) of block ROW K,    J < K, of  L_KJ   y_J )   leaves first
+//     backward  x_I = Linv_I^T ( y_I - sum over the tiles (K, I) of block COLUMN I, K > I, of  L_KI^T x_K )   root first
+// Every workgroup PULLS, so nothing is shared between workgroups but the solution vector: no atomics, a fixed summation
+// order (bitwise reproducible), and a workgroup waits -- on a per-column flag -- only for columns that come EARLIER in
+// the launch (its elimination-tree descendants resp. ancestors).  Workgroups are dispatched in blockIdx order, so the
+// smallest unfinished index always runs and has its inputs: no deadlock whatever the residency.  The tiles of far
+// relatives are folded while the near ones are still being solved and the next tile (last: Linv) is in flight during
+// every wait; what stays on the critical path of a level is one tile GEMV, the fold and the GEMV with Linv: a few
+// microseconds instead of two launches (level by level with k_tri_step: 82 launches, 1.8 ms on final-13682).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flow_wait(const int* flag, int tid) {
+    if (tid == 0)
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();   // also: the previous tile's vector in LDS is consumed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void flow_publish(int* flag, int tid) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// backward: 72 column pairs x 8 row partitions of 18 rows; every load is one coalesced double2
+constexpr int kBwdParts = 8, kFlowRows = NB / kBwdParts, kBwdThreads = (NB / 2) * kBwdParts;   // 18 rows, 576 threads
+
+__global__ __launch_bounds__(kBwdThreads) void k_tri_bwd_flow(const FlowCol* __restrict__ cols, const FlowEnt* __restrict__ ents,
+                                                             const double* __restrict__ y, double* __restrict__ x,
+                                                             int* __restrict__ flags) {
+    __shared__ double sx[NB];
+    __shared__ double spart[kBwdParts][NB];
+    const FlowCol c = cols[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int part = tid / (NB / 2), j2 = tid - part * (NB / 2);   // columns 2 j2, 2 j2 + 1; rows part * 18 ...
+    const int r0 = part * kFlowRows;
+    const size_t off = (size_t)r0 * NB + 2 * j2;
+    double2 m[kFlowRows];
+    auto fetch = [&](const double* __restrict__ M) {
+#pragma unroll
+        for (int r = 0; r < kFlowRows; ++r) m[r] = *reinterpret_cast<const double2*>(M + off + (size_t)r * NB);
+    };
+    FlowEnt en = c.count > 0 ? ents[c.first] : FlowEnt{c.linv, -1, 0};
+    fetch(en.tile);   // L is final: the tile is in flight while the column waits
+    double a0 = 0.0, a1 = 0.0;
+    for (int e = 0; e < c.count; ++e) {
+        flow_wait(flags + en.k, tid);
+        if (tid < NB) sx[tid] = x[(size_t)en.k * NB + tid];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kFlowRows; ++r) {
+            const double xv = sx[r0 + r];
+            a0 = fma(m[r].x, xv, a0); a1 = fma(m[r].y, xv, a1);
+        }
+        en = e + 1 < c.count ? ents[c.first + e + 1] : FlowEnt{c.linv, -1, 0};
+        fetch(en.tile);
+    }
+    spart[part][2 * j2] = a0; spart[part][2 * j2 + 1] = a1;
+    __syncthreads();
+    if (tid < NB) {
+        double v = y[(size_t)c.col * NB + tid];
+#pragma unroll
+        for (int p = 0; p < kBwdParts; ++p) v -= spart[p][tid];
+        sx[tid] = v;
+    }
+    __syncthreads();
+    a0 = 0.0; a1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < kFlowRows; ++r) {
+        const double xv = sx[r0 + r];
+        a0 = fma(m[r].x, xv, a0); a1 = fma(m[r].y, xv, a1);
+    }
+    spart[part][2 * j2] = a0; spart[part][2 * j2 + 1] = a1;
+    __syncthreads();
+    if (tid < NB) {
+        double v = 0.0;
+#pragma unroll
+        for (int p = 0; p < kBwdParts; ++p) v += spart[p][tid];
+        x[(size_t)c.col * NB + tid] = v;
+    }
+    flow_publish(flags + c.col, tid);
+}
+
+// forward: 8 waves x 18 rows; a lane holds columns lane, lane + 64, lane + 128 of its wave's rows (coalesced 8-byte
+// loads), the row sums are folded over the lanes once per column
+constexpr int kFwdWaves = NB / kFlowRows, kFwdThreads = 64 * kFwdWaves;   // 8 waves, 512 threads
+
+__device__ __forceinline__ void flow_row_sums(double (&acc)[kFlowRows]) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1)
+#pragma unroll
+        for (int r = 0; r < kFlowRows; ++r) acc[r] += __shfl_xor(acc[r], s, 64);
+}
+
+__global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowCol* __restrict__ cols, const FlowEnt* __restrict__ ents,
+                                                             const double* __restrict__ b, double* __restrict__ y,
+                                                             int* __restrict__ flags) {
+    __shared__ double sx[NB + 64];
+    const FlowCol c = cols[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r0 = w * kFlowRows;
+    const bool third = lane < NB - 128;
+    const size_t off = (size_t)r0 * NB + lane;
+    double m[kFlowRows][3];
+    auto fetch = [&](const double* __restrict__ M) {
+#pragma unroll
+        for (int r = 0; r < kFlowRows; ++r) {
+            const double* row = M + off + (size_t)r * NB;
+            m[r][0] = row[0]; m[r][1] = row[64]; m[r][2] = third ? row[128] : 0.0;
+        }
+    };
+    FlowEnt en = c.count > 0 ? ents[c.first] : FlowEnt{c.linv, -1, 0};
+    fetch(en.tile);
+    double acc[kFlowRows];
+#pragma unroll
+    for (int r = 0; r < kFlowRows; ++r) acc[r] = 0.0;
+    if (tid < 64) sx[NB + tid] = 0.0;   // columns 144 .. 207 of the padded vector
+    for (int e = 0; e < c.count; ++e) {
+        flow_wait(flags + en.k, tid);
+        if (tid < NB) sx[tid] = y[(size_t)en.k * NB + tid];
+        __syncthreads();
+        const double v0 = sx[lane], v1 = sx[lane + 64], v2 = sx[lane + 128];
+#pragma unroll
+        for (int r = 0; r < kFlowRows; ++r) acc[r] = fma(m[r][2], v2, fma(m[r][1], v1, fma(m[r][0], v0, acc[r])));
+        en = e + 1 < c.count ? ents[c.first + e + 1] : FlowEnt{c.linv, -1, 0};
+        fetch(en.tile);
+    }
+    flow_row_sums(acc);
+    __syncthreads();   // the last vector is consumed
+    {
+        double mine = 0.0;
+#pragma unroll
+        for (int r = 0; r < kFlowRows; ++r) mine = lane == r ? acc[r] : mine;
+        if (lane < kFlowRows) sx[r0 + lane] = b[(size_t)c.col * NB + r0 + lane] - mine;
+    }
+    __syncthreads();
+    {
+        const double v0 = sx[lane], v1 = sx[lane + 64], v2 = sx[lane + 128];
+#pragma unroll
+        for (int r = 0; r < kFlowRows; ++r) acc[r] = fma(m[r][2], v2, fma(m[r][1], v1, m[r][0] * v0));
+    }
+    flow_row_sums(acc);
+    {
+        double mine = 0.0;
+#pragma unroll
+        for (int r = 0; r < kFlowRows; ++r) mine = lane == r ? acc[r] : mine;
+        if (lane < kFlowRows) y[(size_t)c.col * NB + r0 + lane] = mine;
+    }
+    flow_publish(flags + c.col, tid);
+}
+
+// ------------------------------------------------------------------------------------------
 // Symmetric tile matvec for the PCG variant, two deterministic passes (no atomics):
 //   k_sym_tile_products: one workgroup per STRUCTURALLY NON-ZERO tile (I,J) of S reads the tile ONCE
 //       (two 72-row halves through LDS) and writes u = A x_J and, off the diagonal, v = A^T x_I
@@ -1156,6 +1307,13 @@ void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, dou
     const int grid = 8 * ((n + 7) / 8);
     if (trans) hipLaunchKernelGGL(k_tri_step<true>, dim3(grid), dim3(256), 0, s, tasks, n, vwork, vout);
     else hipLaunchKernelGGL(k_tri_step<false>, dim3(grid), dim3(256), 0, s, tasks, n, vwork, vout);
+}
+void launch_tri_flow(bool backward, const FlowCol* cols, int n_cols, const FlowEnt* ents, const double* in, double* out, int* flags,
+                     int nt, hipStream_t s) {
+    if (n_cols <= 0) return;
+    (void)hipMemsetAsync(flags, 0, (size_t)nt * sizeof(int), s);
+    if (backward) hipLaunchKernelGGL(k_tri_bwd_flow, dim3(n_cols), dim3(kBwdThreads), 0, s, cols, ents, in, out, flags);
+    else hipLaunchKernelGGL(k_tri_fwd_flow, dim3(n_cols), dim3(kFwdThreads), 0, s, cols, ents, in, out, flags);
 }
 void launch_sym_tile_products(const SymTile* list, int n, const double* tiles, const double* x, double* part, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_sym_tile_products, dim3(n), dim3(256), 0, s, list, tiles, x, part);
