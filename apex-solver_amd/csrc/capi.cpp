@@ -234,10 +234,10 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     if (n == "schur_rows") h->s->use_row_schur(value);
     else if (n == "graphs") h->s->enable_graphs(value != 0);
     else if (n == "update_overlap") { h->s->enable_overlap(value != 0); if (value > 1) h->s->set_overlap_min(value); }
-    else if (n == "tri_dataflow") h->s->enable_bwd_flow(value != 0);
+    else if (n == "tri_dataflow") h->s->enable_tri_flow(value != 0);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
-    else if (n == "schur_form") h->s->use_row_schur(value);   /* alias of "schur_rows": 3 pairs on MFMA (default), 2 / 1 LDS rows, 0 global atomics */
+    else if (n == "schur_form") h->s->use_row_schur(value);   /* alias of "schur_rows": 3 sorted pair list (default), 2 / 1 LDS rows, 0 global atomics */
     else if (n == "rows_debug") h->s->set_rows_debug(value);
     else if (n == "pairs_ablation") apex::set_pairs_ablation(value);   /* timing experiments only */
     else if (n == "hubs_last") h->s->set_hubs_last(value != 0);
@@ -495,7 +495,7 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     const std::string n = name ? name : "";
     if (n == "graphs") h->s->enable_graphs(value != 0);
     else if (n == "update_overlap") { h->s->enable_overlap(value != 0); if (value > 1) h->s->set_overlap_min(value); }
-    else if (n == "tri_dataflow") h->s->enable_bwd_flow(value != 0);
+    else if (n == "tri_dataflow") h->s->enable_tri_flow(value != 0);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);

@@ -26,14 +26,12 @@ struct TriTask {   // one workgroup of a triangular-solve step (k_tri_step)
     int other;            // block updated by this workgroup; -1: store the solved block instead
 };
 
-struct FlowCol {      // one workgroup of a dataflow triangular sweep (k_tri_fwd_flow / k_tri_bwd_flow): a tile column
-    const double* linv;   // L^-1 of the column's diagonal tile
-    int first, count;     // the tiles it pulls from (FlowEnt): forward its block row, backward its block column
-    int col, pad;
-};
-struct FlowEnt {
-    const double* tile;   // forward L(col, k), backward L(k, col)
-    int k, pad;           // the column whose solution the tile multiplies
+struct FlowTask {     // one workgroup of a dataflow triangular sweep (k_tri_fwd_flow / k_tri_bwd_flow)
+    const double* mat;    // product task: the off-diagonal tile; solve task: L^-1 of the diagonal tile
+    int src;              // product: the block whose solution the tile multiplies; solve: -1
+    int dst;              // product: the block the product belongs to; solve: the block solved
+    int part;             // product: its slot in the partial array; solve: first slot of the block's products
+    int count;            // solve: number of products to wait for and fold
 };
 
 struct SymEntry {  // one tile of block-row I of the symmetric tile matrix
@@ -55,7 +53,7 @@ void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s);
 void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 1 / 6 / 8 k_potrf_inv_la with 4 / 6 / 8 waves (default 8)
 // batches of <= 56 tasks use the latency kernels, larger ones the 3 x 3-wave strip kernel
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s);
-void launch_tri_flow(bool backward, const FlowCol* cols, int n_cols, const FlowEnt* ents, const double* in, double* out, int* flags,
+void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const double* in, double* out, double* part, int* flags,
                      int nt, hipStream_t s);
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s);
 void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double* diag, hipStream_t s);

@@ -882,154 +882,167 @@ __global__ __launch_bounds__(256) void k_tri_step(const TriTask* __restrict__ ta
 }
 
 // ------------------------------------------------------------------------------------------
-// The triangular sweeps as ONE dataflow launch each (single-GPU plans), one workgroup per tile column:
+// The triangular sweeps as ONE dataflow launch each (single-GPU plans), one workgroup per TILE:
 //     forward   y_K = Linv_K   ( b_K - sum over the tiles (K, J) of block ROW K,    J < K, of  L_KJ   y_J )   leaves first
 //     backward  x_I = Linv_I^T ( y_I - sum over the tiles (K, I) of block COLUMN I, K > I, of  L_KI^T x_K )   root first
-// Every workgroup PULLS, so nothing is shared between workgroups but the solution vector: no atomics, a fixed summation
-// order (bitwise reproducible), and a workgroup waits -- on a per-column flag -- only for columns that come EARLIER in
-// the launch (its elimination-tree descendants resp. ancestors).  Workgroups are dispatched in blockIdx order, so the
-// smallest unfinished index always runs and has its inputs: no deadlock whatever the residency.  The tiles of far
-// relatives are folded while the near ones are still being solved and the next tile (last: Linv) is in flight during
-// every wait; what stays on the critical path of a level is one tile GEMV, the fold and the GEMV with Linv: a few
-// microseconds instead of two launches (level by level with k_tri_step: 82 launches, 1.8 ms on final-13682).
+// Two kinds of task.  A PRODUCT task owns one off-diagonal tile: it fetches the tile into registers, waits until the
+// solution block it multiplies is published (done[src]), writes the product to ITS OWN slot of the partial array and
+// counts itself in (cnt[dst]).  A SOLVE task owns one diagonal block: it fetches Linv, waits until all products of its
+// block row (column) are counted in, folds them IN LIST ORDER (no atomics on data: bitwise reproducible), multiplies
+// and publishes.  Tasks are listed level by level (the solves of a level, then the products they feed), so a task
+// waits only for tasks EARLIER in the launch; workgroups are dispatched in blockIdx order, hence the smallest
+// unfinished index always runs and has its inputs: no deadlock whatever the residency.  Every tile is read exactly
+// once with all of its loads in flight before the wait: the leaf levels run at HBM rate, the upper levels at two
+// short hops per level instead of two launches (level by level with k_tri_step: 82 launches, 1.8 ms on final-13682).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void flow_wait(const int* flag, int tid) {
+// Synchronisation without cache maintenance: everything produced inside the launch (solution blocks, partial products,
+// counters) is written and read with agent-scope relaxed atomics -- plain sc1 stores / loads that are coherent across
+// the eight L2s by themselves -- and ordered by "all my stores are acknowledged" (s_waitcnt) + workgroup barrier before
+// the flag update, resp. flag seen + barrier before the loads.  An acquire / release FENCE at agent scope instead
+// costs a buffer_inv / buffer_wbl2 of the whole L2 per workgroup: measured 4x slower than the level-by-level launches.
+__device__ __forceinline__ double flow_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flow_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flow_wait(const int* flag, int want, int tid) {
     if (tid == 0)
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
-    __syncthreads();   // also: the previous tile's vector in LDS is consumed
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
 }
 __device__ __forceinline__ void flow_publish(int* flag, int tid) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = expcnt = 0: this wave's stores are acknowledged
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// backward: 72 column pairs x 8 row partitions of 18 rows; every load is one coalesced double2
-constexpr int kBwdParts = 8, kFlowRows = NB / kBwdParts, kBwdThreads = (NB / 2) * kBwdParts;   // 18 rows, 576 threads
+constexpr int kFlowRows = NB / 8;   // 18
 
-__global__ __launch_bounds__(kBwdThreads) void k_tri_bwd_flow(const FlowCol* __restrict__ cols, const FlowEnt* __restrict__ ents,
-                                                             const double* __restrict__ y, double* __restrict__ x,
-                                                             int* __restrict__ flags) {
+// backward (transposed products): 72 column pairs x 8 row partitions of 18 rows; every load is one coalesced double2
+constexpr int kBwdParts = 8, kBwdThreads = (NB / 2) * kBwdParts;   // 576 threads
+
+__global__ __launch_bounds__(kBwdThreads) void k_tri_bwd_flow(const FlowTask* __restrict__ tasks, const double* __restrict__ y,
+                                                             double* __restrict__ x, double* __restrict__ part,
+                                                             int* __restrict__ cnt, int* __restrict__ done) {
     __shared__ double sx[NB];
     __shared__ double spart[kBwdParts][NB];
-    const FlowCol c = cols[blockIdx.x];
+    const FlowTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x;
-    const int part = tid / (NB / 2), j2 = tid - part * (NB / 2);   // columns 2 j2, 2 j2 + 1; rows part * 18 ...
-    const int r0 = part * kFlowRows;
-    const size_t off = (size_t)r0 * NB + 2 * j2;
+    const int p = tid / (NB / 2), j2 = tid - p * (NB / 2);   // columns 2 j2, 2 j2 + 1; rows p * 18 ...
+    const int r0 = p * kFlowRows;
     double2 m[kFlowRows];
-    auto fetch = [&](const double* __restrict__ M) {
+    {
+        const double* __restrict__ M = t.mat + (size_t)r0 * NB + 2 * j2;   // L resp. Linv is final: in flight during the wait
 #pragma unroll
-        for (int r = 0; r < kFlowRows; ++r) m[r] = *reinterpret_cast<const double2*>(M + off + (size_t)r * NB);
-    };
-    FlowEnt en = c.count > 0 ? ents[c.first] : FlowEnt{c.linv, -1, 0};
-    fetch(en.tile);   // L is final: the tile is in flight while the column waits
-    double a0 = 0.0, a1 = 0.0;
-    for (int e = 0; e < c.count; ++e) {
-        flow_wait(flags + en.k, tid);
-        if (tid < NB) sx[tid] = x[(size_t)en.k * NB + tid];
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kFlowRows; ++r) {
-            const double xv = sx[r0 + r];
-            a0 = fma(m[r].x, xv, a0); a1 = fma(m[r].y, xv, a1);
+        for (int r = 0; r < kFlowRows; ++r) m[r] = *reinterpret_cast<const double2*>(M + (size_t)r * NB);
+    }
+    if (t.src >= 0) {
+        flow_wait(done + t.src, 1, tid);
+        if (tid < NB) sx[tid] = flow_ld(x + (size_t)t.src * NB + tid);
+    } else {
+        flow_wait(cnt + t.dst, t.count, tid);
+        // fold the block's products: four groups of 144 threads take every fourth one (all loads of a thread
+        // independent), then the groups are added in a fixed order
+        const int g = tid / NB, c = tid - g * NB;
+        double v = 0.0;
+        {
+            const double* __restrict__ pp = part + (size_t)t.part * NB + c;
+            int q = g;
+            for (; q + 12 < t.count; q += 16) {
+                const double p0 = flow_ld(pp + (size_t)q * NB), p1 = flow_ld(pp + (size_t)(q + 4) * NB);
+                const double p2 = flow_ld(pp + (size_t)(q + 8) * NB), p3 = flow_ld(pp + (size_t)(q + 12) * NB);
+                v += (p0 + p1) + (p2 + p3);
+            }
+            for (; q < t.count; q += 4) v += flow_ld(pp + (size_t)q * NB);
         }
-        en = e + 1 < c.count ? ents[c.first + e + 1] : FlowEnt{c.linv, -1, 0};
-        fetch(en.tile);
-    }
-    spart[part][2 * j2] = a0; spart[part][2 * j2 + 1] = a1;
-    __syncthreads();
-    if (tid < NB) {
-        double v = y[(size_t)c.col * NB + tid];
-#pragma unroll
-        for (int p = 0; p < kBwdParts; ++p) v -= spart[p][tid];
-        sx[tid] = v;
+        spart[g][c] = v;
+        __syncthreads();
+        if (tid < NB) sx[tid] = y[(size_t)t.dst * NB + tid] - ((spart[0][tid] + spart[1][tid]) + (spart[2][tid] + spart[3][tid]));
     }
     __syncthreads();
-    a0 = 0.0; a1 = 0.0;
+    double a0 = 0.0, a1 = 0.0;
 #pragma unroll
     for (int r = 0; r < kFlowRows; ++r) {
         const double xv = sx[r0 + r];
         a0 = fma(m[r].x, xv, a0); a1 = fma(m[r].y, xv, a1);
     }
-    spart[part][2 * j2] = a0; spart[part][2 * j2 + 1] = a1;
+    spart[p][2 * j2] = a0; spart[p][2 * j2 + 1] = a1;
     __syncthreads();
     if (tid < NB) {
         double v = 0.0;
 #pragma unroll
-        for (int p = 0; p < kBwdParts; ++p) v += spart[p][tid];
-        x[(size_t)c.col * NB + tid] = v;
+        for (int q = 0; q < kBwdParts; ++q) v += spart[q][tid];
+        flow_st(t.src >= 0 ? part + (size_t)t.part * NB + tid : x + (size_t)t.dst * NB + tid, v);
     }
-    flow_publish(flags + c.col, tid);
+    flow_publish(t.src >= 0 ? cnt + t.dst : done + t.dst, tid);
 }
 
-// forward: 8 waves x 18 rows; a lane holds columns lane, lane + 64, lane + 128 of its wave's rows (coalesced 8-byte
-// loads), the row sums are folded over the lanes once per column
-constexpr int kFwdWaves = NB / kFlowRows, kFwdThreads = 64 * kFwdWaves;   // 8 waves, 512 threads
+// forward (plain products): 8 waves x 18 rows; a lane holds columns lane, lane + 64, lane + 128 of its wave's rows
+// (coalesced 8-byte loads); the row sums are folded over the lanes
+constexpr int kFwdThreads = 64 * (NB / kFlowRows);   // 8 waves, 512 threads
 
-__device__ __forceinline__ void flow_row_sums(double (&acc)[kFlowRows]) {
+__global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowTask* __restrict__ tasks, const double* __restrict__ b,
+                                                             double* __restrict__ y, double* __restrict__ part,
+                                                             int* __restrict__ cnt, int* __restrict__ done) {
+    __shared__ double sfold[NB / kFlowRows][192];
+    const FlowTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r0 = w * kFlowRows;
+    const bool third = lane < NB - 128;
+    double m[kFlowRows][3];
+    {
+        const double* __restrict__ M = t.mat + (size_t)r0 * NB + lane;
+#pragma unroll
+        for (int r = 0; r < kFlowRows; ++r) {
+            const double* row = M + (size_t)r * NB;
+            m[r][0] = row[0]; m[r][1] = row[64]; m[r][2] = third ? row[128] : 0.0;
+        }
+    }
+    double v0, v1, v2 = 0.0;
+    if (t.src >= 0) {
+        flow_wait(done + t.src, 1, tid);
+        const double* __restrict__ ys = y + (size_t)t.src * NB + lane;
+        v0 = flow_ld(ys); v1 = flow_ld(ys + 64);
+        if (third) v2 = flow_ld(ys + 128);
+    } else {
+        flow_wait(cnt + t.dst, t.count, tid);
+        // fold the block's products: wave w takes every eighth one (its loads independent), the waves' sums are added
+        // in a fixed order
+        double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+        const double* __restrict__ pp = part + (size_t)t.part * NB + lane;
+        int q = w;
+        for (; q + 8 < t.count; q += 16) {
+            const double* pa = pp + (size_t)q * NB;
+            const double* pb = pa + (size_t)8 * NB;
+            const double a0 = flow_ld(pa), a1 = flow_ld(pa + 64), b0 = flow_ld(pb), b1 = flow_ld(pb + 64);
+            double a2 = 0.0, b2 = 0.0;
+            if (third) { a2 = flow_ld(pa + 128); b2 = flow_ld(pb + 128); }
+            f0 += a0 + b0; f1 += a1 + b1; f2 += a2 + b2;
+        }
+        for (; q < t.count; q += 8) {
+            const double* pa = pp + (size_t)q * NB;
+            f0 += flow_ld(pa); f1 += flow_ld(pa + 64);
+            if (third) f2 += flow_ld(pa + 128);
+        }
+        sfold[w][lane] = f0; sfold[w][lane + 64] = f1; sfold[w][lane + 128] = f2;
+        __syncthreads();
+        const double* __restrict__ bs = b + (size_t)t.dst * NB + lane;
+        v0 = bs[0]; v1 = bs[64];
+        if (third) v2 = bs[128];
+#pragma unroll
+        for (int u = 0; u < NB / kFlowRows; ++u) { v0 -= sfold[u][lane]; v1 -= sfold[u][lane + 64]; v2 -= sfold[u][lane + 128]; }
+    }
+    double acc[kFlowRows];
+#pragma unroll
+    for (int r = 0; r < kFlowRows; ++r) acc[r] = fma(m[r][2], v2, fma(m[r][1], v1, m[r][0] * v0));
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1)
 #pragma unroll
         for (int r = 0; r < kFlowRows; ++r) acc[r] += __shfl_xor(acc[r], s, 64);
-}
-
-__global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowCol* __restrict__ cols, const FlowEnt* __restrict__ ents,
-                                                             const double* __restrict__ b, double* __restrict__ y,
-                                                             int* __restrict__ flags) {
-    __shared__ double sx[NB + 64];
-    const FlowCol c = cols[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r0 = w * kFlowRows;
-    const bool third = lane < NB - 128;
-    const size_t off = (size_t)r0 * NB + lane;
-    double m[kFlowRows][3];
-    auto fetch = [&](const double* __restrict__ M) {
+    double mine = 0.0;
 #pragma unroll
-        for (int r = 0; r < kFlowRows; ++r) {
-            const double* row = M + off + (size_t)r * NB;
-            m[r][0] = row[0]; m[r][1] = row[64]; m[r][2] = third ? row[128] : 0.0;
-        }
-    };
-    FlowEnt en = c.count > 0 ? ents[c.first] : FlowEnt{c.linv, -1, 0};
-    fetch(en.tile);
-    double acc[kFlowRows];
-#pragma unroll
-    for (int r = 0; r < kFlowRows; ++r) acc[r] = 0.0;
-    if (tid < 64) sx[NB + tid] = 0.0;   // columns 144 .. 207 of the padded vector
-    for (int e = 0; e < c.count; ++e) {
-        flow_wait(flags + en.k, tid);
-        if (tid < NB) sx[tid] = y[(size_t)en.k * NB + tid];
-        __syncthreads();
-        const double v0 = sx[lane], v1 = sx[lane + 64], v2 = sx[lane + 128];
-#pragma unroll
-        for (int r = 0; r < kFlowRows; ++r) acc[r] = fma(m[r][2], v2, fma(m[r][1], v1, fma(m[r][0], v0, acc[r])));
-        en = e + 1 < c.count ? ents[c.first + e + 1] : FlowEnt{c.linv, -1, 0};
-        fetch(en.tile);
+    for (int r = 0; r < kFlowRows; ++r) mine = lane == r ? acc[r] : mine;
+    if (lane < kFlowRows) {
+        flow_st(t.src >= 0 ? part + (size_t)t.part * NB + r0 + lane : y + (size_t)t.dst * NB + r0 + lane, mine);
     }
-    flow_row_sums(acc);
-    __syncthreads();   // the last vector is consumed
-    {
-        double mine = 0.0;
-#pragma unroll
-        for (int r = 0; r < kFlowRows; ++r) mine = lane == r ? acc[r] : mine;
-        if (lane < kFlowRows) sx[r0 + lane] = b[(size_t)c.col * NB + r0 + lane] - mine;
-    }
-    __syncthreads();
-    {
-        const double v0 = sx[lane], v1 = sx[lane + 64], v2 = sx[lane + 128];
-#pragma unroll
-        for (int r = 0; r < kFlowRows; ++r) acc[r] = fma(m[r][2], v2, fma(m[r][1], v1, m[r][0] * v0));
-    }
-    flow_row_sums(acc);
-    {
-        double mine = 0.0;
-#pragma unroll
-        for (int r = 0; r < kFlowRows; ++r) mine = lane == r ? acc[r] : mine;
-        if (lane < kFlowRows) y[(size_t)c.col * NB + r0 + lane] = mine;
-    }
-    flow_publish(flags + c.col, tid);
+    flow_publish(t.src >= 0 ? cnt + t.dst : done + t.dst, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1308,12 +1321,12 @@ void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, dou
     if (trans) hipLaunchKernelGGL(k_tri_step<true>, dim3(grid), dim3(256), 0, s, tasks, n, vwork, vout);
     else hipLaunchKernelGGL(k_tri_step<false>, dim3(grid), dim3(256), 0, s, tasks, n, vwork, vout);
 }
-void launch_tri_flow(bool backward, const FlowCol* cols, int n_cols, const FlowEnt* ents, const double* in, double* out, int* flags,
+void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const double* in, double* out, double* part, int* flags,
                      int nt, hipStream_t s) {
-    if (n_cols <= 0) return;
-    (void)hipMemsetAsync(flags, 0, (size_t)nt * sizeof(int), s);
-    if (backward) hipLaunchKernelGGL(k_tri_bwd_flow, dim3(n_cols), dim3(kBwdThreads), 0, s, cols, ents, in, out, flags);
-    else hipLaunchKernelGGL(k_tri_fwd_flow, dim3(n_cols), dim3(kFwdThreads), 0, s, cols, ents, in, out, flags);
+    if (n_tasks <= 0) return;
+    (void)hipMemsetAsync(flags, 0, (size_t)2 * nt * sizeof(int), s);   // cnt[nt] | done[nt]
+    if (backward) hipLaunchKernelGGL(k_tri_bwd_flow, dim3(n_tasks), dim3(kBwdThreads), 0, s, tasks, in, out, part, flags, flags + nt);
+    else hipLaunchKernelGGL(k_tri_fwd_flow, dim3(n_tasks), dim3(kFwdThreads), 0, s, tasks, in, out, part, flags, flags + nt);
 }
 void launch_sym_tile_products(const SymTile* list, int n, const double* tiles, const double* x, double* part, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_sym_tile_products, dim3(n), dim3(256), 0, s, list, tiles, x, part);

@@ -1,4 +1,4 @@
-// schur_pairs.h -- the Schur reduction as a sorted camera-pair list reduced on the fp64 matrix cores.
+// schur_pairs.h -- the Schur reduction as a camera-pair list sorted by destination block, reduced over the lanes of a wave.
 //
 // Off-diagonal part of compute_schur_complement (src/linalg/sparse/explicit_schur.rs:771-925):
 //     S(ci, cj) -= sum over landmarks l seen by both cameras of  W_i Hll^-1 W_j^T ,   W = Jc^T Jl  (d_c x 3).
@@ -6,9 +6,12 @@
 //     -W_i Hll^-1 W_j^T = (Jc_i^T M_ij) Jc_j = U_ij V_j ,   U (d_c x 2), V (2 x d_c),
 // so a block S(ci, cj) is the product of a d_c x 2P and a 2P x d_c matrix, P = pairs of the block: a tiny GEMM whose K
 // dimension runs over the pairs.  All pairs of the problem are sorted by block once per structure; a wave takes 64
-// consecutive pair slots, one pair per lane computes U and V (both observations re-linearised from the 24-byte records),
-// parks them in LDS, and 32 v_mfma_f64_16x16x4_f64 (two pairs per instruction) reduce them over the lanes.  A block
+// consecutive pair slots, one pair per lane computes U and V (both observations re-linearised from the 24-byte records)
+// and parks them in LDS; then lane (g, bi, bj) owns the 3 x 3 sub-block (bi, bj) of the running block and adds the pairs
+// g, g + NG, ... of the segment (18 FMA per pair), the NG groups are folded with shuffles at a block boundary.  A block
 // is owned by one wave and stored ONCE with plain stores: no atomics, no LDS accumulators, no neighbour chunking.
+// (v_mfma_f64_16x16x4_f64 was the first design: it occupies the fp64 datapath for 64 cycles whatever the tile holds,
+// a 9 x 9 block fills 32 % of it, and it cannot overlap the linearisation's vector work: DESIGN.md section 4.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -84,7 +84,7 @@ class Solver : public LmBackend {
     void enable_stage_timing(bool on) { timer_.enable(on); }
     void enable_graphs(bool on) { use_graphs_ = on; tp_.enable_graphs(on); }
     void enable_overlap(bool on) { tp_.enable_overlap(on); }
-    void enable_bwd_flow(bool on) { tp_.enable_bwd_flow(on); }
+    void enable_tri_flow(bool on) { tp_.enable_tri_flow(on); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void use_row_schur(int v) { use_rows_ = v != 0; if (v) rows_form_ = v; }

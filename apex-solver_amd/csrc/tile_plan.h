@@ -92,7 +92,7 @@ class TilePlan {
     void enable_graphs(bool on) { use_graphs_ = on; }
     void enable_overlap(bool on) { overlap_ = on; }  // before the first factor()
     void set_overlap_min(int n) { overlap_min_ = n; }
-    void enable_bwd_flow(bool on);   // backward sweep as one dataflow launch (default) or level by level
+    void enable_tri_flow(bool on);   // triangular sweeps as one dataflow launch each (default) or level by level
 
     hipError_t zero_tiles();                             // async on the plan's stream
     void add_diag(int n_valid, double add_valid, double pad_value);  // diagonal += / padding rows := value
@@ -150,11 +150,11 @@ class TilePlan {
     PotrfTask* potrf_tasks_ = nullptr;
     GemmTask *trsm_tasks_ = nullptr, *upd_tasks_ = nullptr;
     TriTask *tri_fwd_ = nullptr, *tri_bwd_ = nullptr;
-    FlowCol *fwd_cols_ = nullptr, *bwd_cols_ = nullptr;     // dataflow sweeps (single-GPU plans)
-    FlowEnt *fwd_ents_ = nullptr, *bwd_ents_ = nullptr;
-    int* bwd_flags_ = nullptr;
-    int n_bwd_cols_ = 0;
-    bool bwd_flow_ = true;
+    FlowTask *flow_fwd_ = nullptr, *flow_bwd_ = nullptr;   // dataflow triangular sweeps (single-GPU plans)
+    double* flow_part_ = nullptr;                          // one 144-vector per off-diagonal tile
+    int* flow_flags_ = nullptr;                            // cnt[nt] | done[nt]
+    int n_flow_tasks_ = 0, n_flow_parts_ = 0;
+    bool tri_flow_ = true;
     SymTile* sym_tiles_ = nullptr;
     int n_sym_tiles_ = 0;
     int* sym_row_ptr_ = nullptr;

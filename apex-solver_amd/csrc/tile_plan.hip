@@ -96,13 +96,13 @@ std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool 
 
 void TilePlan::release() {
     void* ptrs[] = {tiles_, linv_, slot_, diag_slot_, flag_, potrf_tasks_, trsm_tasks_, upd_tasks_, tri_fwd_, tri_bwd_,
-                    fwd_cols_, fwd_ents_, bwd_cols_, bwd_ents_, bwd_flags_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_};
+                    flow_fwd_, flow_bwd_, flow_part_, flow_flags_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = exch_ = nullptr;
     slot_ = diag_slot_ = flag_ = sym_row_ptr_ = cls_ = nullptr;
     potrf_tasks_ = nullptr; trsm_tasks_ = upd_tasks_ = nullptr; tri_fwd_ = tri_bwd_ = nullptr;
-    fwd_cols_ = bwd_cols_ = nullptr; fwd_ents_ = bwd_ents_ = nullptr; bwd_flags_ = nullptr; n_bwd_cols_ = 0;
+    flow_fwd_ = flow_bwd_ = nullptr; flow_part_ = nullptr; flow_flags_ = nullptr; n_flow_tasks_ = 0;
     sym_tiles_ = nullptr; sym_entries_ = nullptr;
     for (int i = 0; i < kGraphs; ++i) {
         if (graph_exec_[i]) { (void)hipGraphExecDestroy(graph_exec_[i]); graph_exec_[i] = nullptr; }
@@ -414,28 +414,35 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         }
         lv_bwd_[n_levels_ - lv] = (int)tb.size();
     }
-    // both sweeps as one dataflow launch each (k_tri_fwd_flow / k_tri_bwd_flow; plans that are not distributed): a
-    // column pulls from its own tiles; columns in launch order = the order of the level sweeps; the tiles of far
-    // relatives first, so that the one a column has to wait for longest comes last
-    std::vector<FlowCol> fc, bc;
-    std::vector<FlowEnt> fe, be;
+    // both sweeps as one dataflow launch each (k_tri_fwd_flow / k_tri_bwd_flow; plans that are not distributed): level
+    // by level the solve tasks of the level's blocks, then the product tasks of the tiles those solutions multiply.
+    // A block's products own consecutive slots of the partial array, in the order the solve task folds them.
+    std::vector<FlowTask> ft, bt;
     if (!distributed()) {
-        for (int lv = 0; lv < n_levels_; ++lv)
-            for (int K : level_cols[lv]) {
-                std::vector<int> src(row_cols[K]);
-                std::stable_sort(src.begin(), src.end(), [&](int a, int b) { return group_of[a] < group_of[b]; });
-                fc.push_back({linv_ptr(K), (int)fe.size(), (int)src.size(), K, 0});
-                for (int J : src) fe.push_back({tile_ptr(K, J), J, 0});
-            }
-        for (int lv = n_levels_ - 1; lv >= 0; --lv)
-            for (int I : level_cols[lv]) {
-                std::vector<int> rows(col_rows[I]);
-                std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return group_of[a] > group_of[b]; });
-                bc.push_back({linv_ptr(I), (int)be.size(), (int)rows.size(), I, 0});
-                for (int K : rows) be.push_back({tile_ptr(K, I), K, 0});
-            }
+        std::vector<int> first(nt_ + 1, 0);
+        for (int K = 0; K < nt_; ++K) first[K + 1] = first[K] + (int)row_cols[K].size();      // forward: slots by block row
+        for (int lv = 0; lv < n_levels_; ++lv) {
+            for (int K : level_cols[lv]) ft.push_back({linv_ptr(K), -1, K, first[K], (int)row_cols[K].size()});
+            for (int K : level_cols[lv])
+                for (int I : col_rows[K]) {
+                    const auto& rc = row_cols[I];
+                    const int pos = (int)(std::lower_bound(rc.begin(), rc.end(), K) - rc.begin());
+                    ft.push_back({tile_ptr(I, K), K, I, first[I] + pos, 0});
+                }
+        }
+        for (int K = 0; K < nt_; ++K) first[K + 1] = first[K] + (int)col_rows[K].size();      // backward: by block column
+        for (int lv = n_levels_ - 1; lv >= 0; --lv) {
+            for (int I : level_cols[lv]) bt.push_back({linv_ptr(I), -1, I, first[I], (int)col_rows[I].size()});
+            for (int I : level_cols[lv])
+                for (int J : row_cols[I]) {
+                    const auto& cr = col_rows[J];
+                    const int pos = (int)(std::lower_bound(cr.begin(), cr.end(), I) - cr.begin());
+                    bt.push_back({tile_ptr(I, J), I, J, first[J] + pos, 0});
+                }
+        }
+        n_flow_parts_ = first[nt_];
     }
-    n_bwd_cols_ = (int)bc.size();
+    n_flow_tasks_ = (int)ft.size();
     // symmetric matvec of the PCG variant: only tiles that are non-zero before fill
     std::vector<int> sym_ptr(nt_ + 1, 0);
     std::vector<SymEntry> sym;
@@ -459,13 +466,12 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     TP_TRY(alloc_zero(&scal_, 8));
     TP_TRY(upload(&tri_fwd_, tf));
     TP_TRY(upload(&tri_bwd_, tb));
-    TP_TRY(upload(&fwd_cols_, fc));
-    TP_TRY(upload(&fwd_ents_, fe));
-    TP_TRY(upload(&bwd_cols_, bc));
-    TP_TRY(upload(&bwd_ents_, be));
-    if (bwd_flags_) { (void)hipFree(bwd_flags_); bwd_flags_ = nullptr; }
-    TP_TRY(dev_alloc(&bwd_flags_, (size_t)nt_));
-    TP_TRY(hipMemset(bwd_flags_, 0, (size_t)nt_ * sizeof(int)));
+    TP_TRY(upload(&flow_fwd_, ft));
+    TP_TRY(upload(&flow_bwd_, bt));
+    TP_TRY(alloc_zero(&flow_part_, (size_t)std::max(n_flow_parts_, 1) * kNB));
+    if (flow_flags_) { (void)hipFree(flow_flags_); flow_flags_ = nullptr; }
+    TP_TRY(dev_alloc(&flow_flags_, (size_t)2 * nt_));
+    TP_TRY(hipMemset(flow_flags_, 0, (size_t)2 * nt_ * sizeof(int)));
     TP_TRY(upload(&potrf_tasks_, potrf));
     TP_TRY(upload(&trsm_tasks_, trsm));
     TP_TRY(upload(&upd_tasks_, upd));
@@ -572,10 +578,10 @@ void TilePlan::enqueue_solve(const double* rhs, double* x, double* work, bool ba
     // L y = rhs (work vector bvec), then L^T x = y (work vector yvec); level by level
     double* bvec = work;
     double* yvec = work + n_pad();
-    const bool flow = bwd_flow_ && n_bwd_cols_ > 0;
+    const bool flow = tri_flow_ && n_flow_tasks_ > 0;
     if (!backward_only) {
         if (flow) {
-            launch_tri_flow(false, fwd_cols_, n_bwd_cols_, fwd_ents_, rhs, yvec, bwd_flags_, nt_, stream_);
+            launch_tri_flow(false, flow_fwd_, n_flow_tasks_, rhs, yvec, flow_part_, flow_flags_, nt_, stream_);
         } else {
             (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
             for (int lv = 0; lv < n_levels_; ++lv)
@@ -583,7 +589,7 @@ void TilePlan::enqueue_solve(const double* rhs, double* x, double* work, bool ba
         }
     }
     if (flow) {
-        launch_tri_flow(true, bwd_cols_, n_bwd_cols_, bwd_ents_, yvec, x, bwd_flags_, nt_, stream_);
+        launch_tri_flow(true, flow_bwd_, n_flow_tasks_, yvec, x, flow_part_, flow_flags_, nt_, stream_);
         return;
     }
     for (int s = 0; s < n_levels_; ++s)
@@ -641,9 +647,9 @@ bool TilePlan::run_graph(int which, const double* rhs, double* x, double* work) 
     return hipGraphLaunch(graph_exec_[which], stream_) == hipSuccess;
 }
 
-void TilePlan::enable_bwd_flow(bool on) {
-    if (on == bwd_flow_) return;
-    bwd_flow_ = on;
+void TilePlan::enable_tri_flow(bool on) {
+    if (on == tri_flow_) return;
+    tri_flow_ = on;
     for (int which = 1; which <= 2; ++which)   // the captured sweeps change
         if (graph_exec_[which]) { (void)hipGraphExecDestroy(graph_exec_[which]); graph_exec_[which] = nullptr; }
 }

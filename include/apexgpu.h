@@ -216,8 +216,8 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  * "dist_selftest") return APEXGPU_ERR_INVALID_STATE once the structure is set.
  *   "schur_rows" (3)  form of the Schur reduction (alias "schur_form"); set before set_structure:
  *                     3 = every camera pair of a landmark in a list sorted by the block S(ci, cj) it adds to, one pair per
- *                     lane, the block sums taken over the lanes by v_mfma_f64_16x16x4_f64 as rank-2 updates, every block
- *                     stored once (k_schur_pairs, csrc/schur_pairs.h);
+ *                     lane as a rank-2 update U V parked in LDS, the block sums taken over the lanes as 3 x 3 sub-block
+ *                     products on the vector unit, every block stored once (k_schur_pairs, csrc/schur_pairs.h);
  *                     2 = LDS row form, one lane per observation, block rows walked in a per-lane rotated order
  *                     (k_schur_rows2); 1 = LDS row form, one lane per camera pair (k_schur_rows);
  *                     0 = the landmark-major global-atomics form (k_schur_scatter)
@@ -227,10 +227,13 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "potrf_lookahead" (8)  diagonal-tile Cholesky + inverse: 8 / 6 / 1 = look-ahead schedule with 8 / 6 / 4 waves
  *                     per workgroup, 0 = the schedule without look-ahead
  *   "fused_forward" (0)  run the forward triangular sweep inside the factorisation graph on a third stream
+ *   "tri_dataflow" (1)  triangular sweeps of a single-GPU plan as ONE launch each: one workgroup per tile, dependencies
+ *                     through per-block flags (k_tri_fwd_flow / k_tri_bwd_flow); 0 = one launch per elimination-tree level
  *   "nested_dissection" (1)  order camera tiles by nested dissection (call before set_structure);
  *                     0 keeps the caller's camera order, a value > 1 sets the leaf size in tiles
- *   "hubs_last" (1)   order cameras that are covisible with more than max(16, 10 sqrt(n_cam)) others after all the
- *                     others (a dense border of S instead of dense rows everywhere), before set_structure
+ *   "hubs_last" (1)   order a vertex cover of the camera pairs that share landmarks across tiles more than two strong
+ *                     hops apart (hub cameras, accidental long-range matches) after all the others: a dense border of S
+ *                     instead of fill everywhere (csrc/ba_structure.h); before set_structure
  *   "dist_factor" (1), "tree_sharding" (1)  multi-GPU only, before set_structure: see the multi-GPU section
  *   "dist_selftest" (0)  single rank, before set_structure: cut the elimination tree as for that many ranks and run
  *                     the distributed schedule (own levels, top levels, phased triangular sweeps) with this rank
@@ -394,7 +397,7 @@ int apexgpu_pg_get_jacobian_blocks(apexgpu_pg_solver* h, double* j_out);
 int apexgpu_pg_get_hessian(apexgpu_pg_solver* h, double lambda, double* H_out, double* g_out);
 
 /* name: "graphs" (hipGraph replay of factor / solves), "update_overlap" (second stream for trailing updates),
- * "nested_dissection" (0 off, 1 on, > 1 leaf size; before apexgpu_pg_set_structure) */
+ * "tri_dataflow" (triangular sweeps as one dataflow launch each), "nested_dissection" (0 off, 1 on, > 1 leaf size; before apexgpu_pg_set_structure) */
 int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value);
 #define APEXGPU_PG_NUM_STAGES 6 /* assemble, factor, tri_solve, step_stats, retract, cost */
 int apexgpu_pg_enable_stage_timing(apexgpu_pg_solver* h, int on);
