@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "ba_kernels.h"
+#include "host_parallel.h"
 #include "schur_pairs.h"
 #include "tile_plan.h"
 
@@ -43,12 +44,13 @@ struct BaHostStructure {
     int pad_rank = 0;
     std::vector<uint8_t> lam_mask;     // tree sharding: cameras whose diagonal block gets lambda on this rank
     // local observation lists (this rank's landmarks)
-    std::vector<uint32_t> o_cam, o_pt;
-    std::vector<double> o_uv;
-    std::vector<int> o_orig, pt_ptr, cam_ptr, cam_obs;
-    std::vector<uint32_t> co_pt;
-    std::vector<double> co_uv;
-    std::vector<int> co_rank;
+    raw_vector<uint32_t> o_cam, o_pt;     // (raw_vector: filled from parallel loops, never value-initialised)
+    raw_vector<double> o_uv;
+    raw_vector<int> o_orig, cam_obs;
+    std::vector<int> pt_ptr, cam_ptr;
+    raw_vector<uint32_t> co_pt;
+    raw_vector<double> co_uv;
+    raw_vector<int> co_rank;
     int64_t n_pairs = 0, n_present = 0;
     // Schur task lists (only the selected form is built)
     std::vector<ScatterTask> tasks;
@@ -70,9 +72,9 @@ struct BaHostStructure {
     void release_scratch();   // the full-problem lists step 2 needed
 
    private:
-    std::vector<uint32_t> cam_i_, pt_i_;         // internal camera / landmark of every observation (caller's order)
+    raw_vector<uint32_t> cam_i_, pt_i_;          // internal camera / landmark of every observation (caller's order)
     std::vector<int64_t> full_ptr_;
-    std::vector<int> full_obs_;
+    raw_vector<int> full_obs_;
 };
 
 }  // namespace apex

@@ -22,6 +22,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t n_obs_, const uint32_t* cam_idx,
                                          const uint32_t* pt_idx, const double* obs_uv, const BaStructOptions& o, TilePlan& tp) {
     const double t_begin = now_s();
+    SetupTrace tr;
     n_cam = n_cam_; n_pt = n_pt_; n_obs = n_obs_; dc = o.dc;
     n_c = n_cam * dc;
     nt = (int)((n_c + kNB - 1) / kNB);
@@ -30,14 +31,10 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
     const int rank = o.rank, world = o.world;
 
     // ---- landmark-major view of the full problem in the caller's numbering (counting sort) ------------------------------
-    std::vector<int64_t> lp(n_pt + 1, 0);
-    for (int64_t i = 0; i < n_obs; ++i) lp[pt_idx[i] + 1]++;
-    for (int64_t l = 0; l < n_pt; ++l) lp[l + 1] += lp[l];
-    std::vector<int> lobs(n_obs);
-    {
-        std::vector<int64_t> fill(lp.begin(), lp.end() - 1);
-        for (int64_t i = 0; i < n_obs; ++i) lobs[fill[pt_idx[i]]++] = (int)i;
-    }
+    std::vector<int64_t> lp;
+    raw_vector<int> lobs;
+    parallel_bucket_large(n_obs, n_pt, pt_idx, lp, lobs);
+    tr.mark("order: landmark buckets");
 
     // weight of a tile pair = number of (landmark, tile pair) incidences: thousands for tiles that overlap in a capture
     // sequence, one or two for an accidental long-range match.  An edge of the tile graph is STRONG when it carries at
@@ -45,14 +42,26 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
     auto tile_weights = [&](const std::vector<int>& pos, std::vector<uint32_t>& acnt, std::vector<uint8_t>& strong) {
         acnt.assign((size_t)nt * nt, 0);
         parallel_ranges(n_pt, 4096, [&](int64_t b, int64_t e) {
+            // the incidences of a landmark range fall on a handful of tile pairs: count them locally (sort + run
+            // lengths) and add every distinct pair ONCE -- per-incidence atomics from all threads on the same few
+            // counters were two thirds of the ordering time
             std::vector<int> tl;
+            std::vector<uint32_t> keys;
+            keys.reserve(32768);
             for (int64_t l = b; l < e; ++l) {
                 tl.clear();
                 for (int64_t x = lp[l]; x < lp[l + 1]; ++x) tl.push_back(pos[cam_idx[lobs[x]]] / cpt);
                 std::sort(tl.begin(), tl.end());
                 tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
                 for (size_t a = 0; a < tl.size(); ++a)
-                    for (size_t bb = 0; bb <= a; ++bb) __atomic_fetch_add(&acnt[(size_t)tl[a] * nt + tl[bb]], 1u, __ATOMIC_RELAXED);
+                    for (size_t bb = 0; bb <= a; ++bb) keys.push_back((uint32_t)tl[a] * (uint32_t)nt + (uint32_t)tl[bb]);
+            }
+            std::sort(keys.begin(), keys.end());
+            for (size_t i = 0; i < keys.size();) {
+                size_t j = i;
+                while (j < keys.size() && keys[j] == keys[i]) ++j;
+                __atomic_fetch_add(&acnt[keys[i]], (uint32_t)(j - i), __ATOMIC_RELAXED);
+                i = j;
             }
         });
         for (int a = 0; a < nt; ++a)
@@ -85,6 +94,7 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
     std::vector<uint32_t> acnt;
     std::vector<uint8_t> adjm;
     tile_weights(pre, acnt, adjm);
+    tr.mark("order: tile weights");
     if (o.hubs_last && nt >= 24) {
         // "not strongly connected" = more than two strong hops apart: the far ends of a capture window (tiles that
         // overlap in a few landmarks only but have common strong neighbours) are geometry, not long-range matches
@@ -103,6 +113,7 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
                 for (int b = 0; b < nt; ++b) near2[(size_t)a * nt + b] = (acc[b >> 6] >> (b & 63)) & 1;
             });
         }
+        tr.mark("order: two-hop closure");
         const unsigned nth = host_threads();
         std::vector<std::vector<uint64_t>> parts(nth);
         std::atomic<unsigned> slot_id(0);
@@ -127,6 +138,7 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
                 }
             total.fetch_add(added, std::memory_order_relaxed);
         });
+        tr.mark("order: long-range pairs");
         if (total.load() <= kMaxEdges && total.load() > 0) {
             std::vector<uint64_t> edges;
             edges.reserve((size_t)total.load());
@@ -177,11 +189,13 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
     }
     // border = the tiles from the first hub camera on (at least the last tile, which may hold padding rows and stays
     // last = eliminated last, no fill)
+    tr.mark("order: vertex cover");
     n_border_tiles = n_hubs > 0 ? nt - (int)((n_cam - n_hubs) / cpt) : 1;
     n_border_tiles = std::max(1, std::min(n_border_tiles, nt));
     std::vector<int> tperm(nt);
     std::iota(tperm.begin(), tperm.end(), 0);
     if (o.use_nd && nt - n_border_tiles >= 23) tperm = TilePlan::order(nt, adjm, true, o.nd_leaf, n_border_tiles);
+    tr.mark("order: nested dissection");
     cmap.resize(n_cam);
     cinv.assign(n_cam, -1);
     for (int64_t c = 0; c < n_cam; ++c) {
@@ -199,6 +213,7 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
     cam_i_.resize(n_obs);
     parallel_ranges(n_obs, 1 << 16, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) cam_i_[i] = (uint32_t)cmap[cam_idx[i]]; });
     seconds[0] = now_s() - t_begin;
+    tr.mark("order: maps");
 
     // ---- partition of the elimination tree, landmark sharding ----------------------------------------------------------------
     const double t1 = now_s();
@@ -265,18 +280,26 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
     full_ptr_.assign(n_pt + 1, 0);
     for (int64_t l = 0; l < n_pt; ++l) full_ptr_[lmap[l] + 1] = lp[l + 1] - lp[l];
     for (int64_t l = 0; l < n_pt; ++l) full_ptr_[l + 1] += full_ptr_[l];
+    tr.mark("lists: sharding, pointers");
     full_obs_.resize(n_obs);
     parallel_ranges(n_pt, 8192, [&](int64_t b, int64_t e) {
+        std::vector<std::pair<uint32_t, int>> tmp;
         for (int64_t l = b; l < e; ++l) {
             int* dst = full_obs_.data() + full_ptr_[lmap[l]];
             const int64_t k = lp[l + 1] - lp[l];
-            memcpy(dst, lobs.data() + lp[l], (size_t)k * sizeof(int));
             // inside a landmark the observations are ordered by camera: the partners (cam_j <= cam_i) of an
-            // observation are then a PREFIX of its landmark's list
-            std::stable_sort(dst, dst + k, [&](int a, int bb) { return cam_i_[a] < cam_i_[bb]; });
+            // observation are then a PREFIX of its landmark's list.  (camera, position) pairs: a stable order without
+            // gathering the camera of an observation at every comparison
+            tmp.resize((size_t)k);
+            for (int64_t x = 0; x < k; ++x) { const int i = lobs[lp[l] + x]; tmp[x] = {cam_i_[i], i}; }
+            bool ordered = true;
+            for (int64_t x = 1; x < k; ++x) ordered = ordered && tmp[x - 1].first <= tmp[x].first;
+            if (!ordered) std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<uint32_t, int>& a, const std::pair<uint32_t, int>& bb) { return a.first < bb.first; });
+            for (int64_t x = 0; x < k; ++x) dst[x] = tmp[x].second;
         }
     });
-    { std::vector<int>().swap(lobs); std::vector<int64_t>().swap(lp); }
+    { raw_vector<int>().swap(lobs); std::vector<int64_t>().swap(lp); }
+    tr.mark("lists: sort inside landmarks");
     // ---- shard: contiguous landmark range balanced by observation count (tree sharding: set above) --------
     if (!tree_shard) shard_range(n_pt, full_ptr_.data(), rank, world, &lm_lo, &lm_hi);
     const int64_t o_lo = full_ptr_[lm_lo], o_hi = full_ptr_[lm_hi];
@@ -297,15 +320,9 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
             o_uv[2 * k] = obs_uv[2 * (int64_t)i]; o_uv[2 * k + 1] = obs_uv[2 * (int64_t)i + 1];
         }
     });
+    tr.mark("lists: landmark-major copies");
     // ---- camera-major lists over the local observations (+ copies of landmark and measurement) -----------------------------
-    cam_ptr.assign(n_cam + 1, 0);
-    cam_obs.resize(n_loc);
-    for (int64_t k = 0; k < n_loc; ++k) cam_ptr[o_cam[k] + 1]++;
-    for (int64_t c = 0; c < n_cam; ++c) cam_ptr[c + 1] += cam_ptr[c];
-    {
-        std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1);
-        for (int64_t k = 0; k < n_loc; ++k) cam_obs[fill[o_cam[k]]++] = (int)k;
-    }
+    parallel_bucket_small(n_loc, n_cam, o_cam.data(), cam_ptr, cam_obs);
     co_pt.resize(n_loc); co_uv.resize(2 * n_loc); co_rank.resize(n_loc);
     parallel_ranges(n_loc, 1 << 16, [&](int64_t b, int64_t e) {
         for (int64_t k = b; k < e; ++k) {
@@ -315,7 +332,8 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
         }
     });
     n_pairs = 0;
-    for (int64_t l = lm_lo; l < lm_hi; ++l) { const int64_t k = pt_ptr[l + 1] - pt_ptr[l]; n_pairs += k * (k + 1) / 2; }
+    for (int64_t l = lm_lo; l < lm_hi; ++l) { const int64_t k = pt_ptr[l + 1] - pt_ptr[l]; n_pairs += k * (k + 1) / 2; }   // 4 M adds
+    tr.mark("lists: camera-major");
     n_present = 0;
     for (uint8_t b : present) n_present += b;
     seconds[1] = now_s() - t1;
@@ -323,8 +341,8 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
 }
 
 void BaHostStructure::release_scratch() {
-    std::vector<uint32_t>().swap(cam_i_); std::vector<uint32_t>().swap(pt_i_);
-    std::vector<int64_t>().swap(full_ptr_); std::vector<int>().swap(full_obs_);
+    raw_vector<uint32_t>().swap(cam_i_); raw_vector<uint32_t>().swap(pt_i_);
+    std::vector<int64_t>().swap(full_ptr_); raw_vector<int>().swap(full_obs_);
 }
 
 void BaHostStructure::build_schur_lists(const BaStructOptions& o, const int* slot_host) {

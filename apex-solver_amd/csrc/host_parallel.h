@@ -2,10 +2,17 @@
 // dependency in the product library).
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <memory>
+#include <new>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace apex {
@@ -13,7 +20,7 @@ namespace apex {
 inline unsigned host_threads() {
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 4;
-    return std::min<unsigned>(nt, 64);
+    return std::min<unsigned>(nt, 128);
 }
 
 // f(begin, end) over [0, n) in dynamic chunks of `grain`; serial when the range is small
@@ -39,6 +46,111 @@ void parallel_ranges(int64_t n, int64_t grain, F&& f) {
 template <typename F>
 void parallel_rows(int64_t n, F&& f, int64_t grain = 16) {
     parallel_ranges(n, grain, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) f(i); });
+}
+
+// APEX_SETUP_TRACE=1: sub-phase times of the structure set-up on stderr
+struct SetupTrace {
+    bool on; double t0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    SetupTrace() : on(getenv("APEX_SETUP_TRACE") != nullptr), t0(now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        const double t = now();
+        fprintf(stderr, "[setup] %-28s %7.1f ms\n", what, (t - t0) * 1e3);
+        t0 = t;
+    }
+};
+
+// A vector whose resize() leaves trivially constructible elements UNINITIALISED: the set-up fills hundreds of megabytes
+// of lists from parallel loops, and a value-initialising resize would first touch (and page in) all of it from one thread.
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <typename U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    // big blocks: 2 MB aligned and advised for transparent huge pages (first touch of a fresh 1.5 GB list is otherwise
+    // 400 K page faults)
+    T* allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= (size_t)32 << 20) {
+            void* p = nullptr;
+            if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0 || !p) throw std::bad_alloc();
+            (void)madvise(p, bytes, MADV_HUGEPAGE);
+            return static_cast<T*>(p);
+        }
+        void* p = malloc(bytes ? bytes : 1);
+        if (!p) throw std::bad_alloc();
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, size_t) { free(p); }
+    template <typename U> void construct(U* p) { ::new (static_cast<void*>(p)) U; }
+    template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <typename T> using raw_vector = std::vector<T, NoInitAlloc<T>>;
+
+// Stable counting sort of the indices 0..n-1 by key[i] in [0, n_keys): ptr[k] .. ptr[k+1] = the indices with key k, in
+// increasing order.  Few keys (cameras): per-thread histograms over contiguous index chunks.
+template <typename K>
+void parallel_bucket_small(int64_t n, int64_t n_keys, const K* key, std::vector<int>& ptr, raw_vector<int>& idx) {
+    const int64_t nth = std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 65536));
+    const int64_t per = (n + nth - 1) / nth;
+    std::vector<std::vector<int>> hist(nth, std::vector<int>());
+    parallel_rows(nth, [&](int64_t t) {
+        auto& h = hist[t]; h.assign(n_keys, 0);
+        for (int64_t i = t * per; i < std::min(n, (t + 1) * per); ++i) h[key[i]]++;
+    }, 1);
+    ptr.assign(n_keys + 1, 0);
+    int64_t run = 0;
+    for (int64_t k = 0; k < n_keys; ++k) {
+        ptr[k] = (int)run;
+        for (int64_t t = 0; t < nth; ++t) { const int c = hist[t][k]; hist[t][k] = (int)run; run += c; }
+    }
+    ptr[n_keys] = (int)run;
+    idx.resize(n);
+    parallel_rows(nth, [&](int64_t t) {
+        auto& h = hist[t];
+        for (int64_t i = t * per; i < std::min(n, (t + 1) * per); ++i) idx[h[key[i]]++] = (int)i;
+    }, 1);
+}
+
+// The same with many keys (landmarks): every thread owns a contiguous KEY range, streams over all indices and takes the
+// ones in its range -- its output range is contiguous, no histogram per thread.
+template <typename K, typename P>
+void parallel_bucket_large(int64_t n, int64_t n_keys, const K* key, std::vector<P>& ptr, raw_vector<int>& idx) {
+    // already grouped (BAL files list the observations landmark by landmark): the buckets are the runs
+    std::atomic<int> sorted(1);
+    parallel_ranges(n, 1 << 18, [&](int64_t b, int64_t e) {
+        for (int64_t i = std::max<int64_t>(b, 1); i < e; ++i)
+            if (key[i] < key[i - 1]) { sorted.store(0, std::memory_order_relaxed); return; }
+    });
+    if (sorted.load() && n > 0) {
+        ptr.assign(n_keys + 1, 0);
+        idx.resize(n);
+        parallel_ranges(n, 1 << 18, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) {
+                idx[i] = (int)i;
+                const int64_t prev = i > 0 ? (int64_t)key[i - 1] : -1;
+                for (int64_t k = prev + 1; k <= (int64_t)key[i]; ++k) ptr[k] = (P)i;   // first index with key >= k
+            }
+        });
+        for (int64_t k = (int64_t)key[n - 1] + 1; k <= n_keys; ++k) ptr[k] = (P)n;
+        return;
+    }
+    const int64_t nth = std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 65536));
+    const int64_t per = (n_keys + nth - 1) / nth;
+    ptr.assign(n_keys + 1, 0);
+    parallel_rows(nth, [&](int64_t t) {
+        const int64_t k0 = t * per, k1 = std::min(n_keys, (t + 1) * per);
+        for (int64_t i = 0; i < n; ++i) { const int64_t k = (int64_t)key[i]; if (k >= k0 && k < k1) ptr[k + 1]++; }
+    }, 1);
+    for (int64_t k = 0; k < n_keys; ++k) ptr[k + 1] += ptr[k];
+    idx.resize(n);
+    parallel_rows(nth, [&](int64_t t) {
+        const int64_t k0 = t * per, k1 = std::min(n_keys, (t + 1) * per);
+        if (k0 >= k1) return;
+        std::vector<P> fill(ptr.begin() + k0, ptr.begin() + k1);
+        for (int64_t i = 0; i < n; ++i) { const int64_t k = (int64_t)key[i]; if (k >= k0 && k < k1) idx[fill[k - k0]++] = (int)i; }
+    }, 1);
 }
 
 }  // namespace apex

@@ -18,13 +18,13 @@ constexpr int kPairCamPitch = 18;        // doubles per staged camera: 144 B kee
 // host: the sorted pair list
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
-struct RawPair { uint32_t cj, i, j; };
 
 }  // namespace
 
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
                       int task_slots) {
+    SetupTrace tr;
     const int cpt = kNB / dc;
     const int kTask = task_slots > 0 ? (task_slots + 63) / 64 * 64 : kPairTaskSlots;
     // rows in the caller's camera order
@@ -33,37 +33,47 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
     std::sort(rows.begin(), rows.end(), [&](int a, int b) { return cam_ext[a] < cam_ext[b]; });
     // pairs per row: an observation pairs with the observations BEFORE it in its landmark's list
     std::vector<int64_t> rp(n_cam + 1, 0);
-    for (int64_t r = 0; r < n_cam; ++r) {
+    parallel_rows(n_cam, [&](int64_t r) {
         const int c = rows[r];
         int64_t n = 0;
         for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) { const int i = cam_obs[e]; n += i - pt_ptr[o_pt[i]]; }
-        rp[r + 1] = rp[r] + n;
-    }
-    const int64_t n_pairs = rp[n_cam];
-    std::vector<RawPair> raw((size_t)n_pairs);
-    // per row: its pairs sorted by (partner camera, observation) and the number of blocks
-    std::vector<int> row_blocks(n_cam, 0);
-    parallel_rows(n_cam, [&](int64_t r) {
-        const int c = rows[r];
-        RawPair* p = raw.data() + rp[r];
-        for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
-            const int i = cam_obs[e];
-            for (int j = pt_ptr[o_pt[i]]; j < i; ++j) *p++ = RawPair{o_cam[j], (uint32_t)i, (uint32_t)j};
-        }
-        RawPair* b = raw.data() + rp[r];
-        std::sort(b, p, [](const RawPair& x, const RawPair& y) { return x.cj != y.cj ? x.cj < y.cj : x.i < y.i; });
-        int nb = 0;
-        for (RawPair* q = b; q < p; ++q) nb += (q == b || q->cj != q[-1].cj);
-        row_blocks[r] = nb;
+        rp[r + 1] = n;
     });
-    // ---- serial pass over the blocks: slot offsets, block table, chunk descriptors, tasks ---------------------------
+    for (int64_t r = 0; r < n_cam; ++r) rp[r + 1] += rp[r];
+    const int64_t n_pairs = rp[n_cam];
+    tr.mark("pairs: count");
+    // Pass A, per row: its blocks = the partner cameras it has pairs with (sorted) and how many.  A counting pass over
+    // the partner lists; no pair is stored yet.
+    struct Run { uint32_t cj; int len; int piece0; };
+    std::vector<std::vector<Run>> row_runs(n_cam);
+    parallel_ranges(n_cam, 16, [&](int64_t rb, int64_t re) {
+        std::vector<int> cnt(n_cam, 0), touched;
+        for (int64_t r = rb; r < re; ++r) {
+            const int c = rows[r];
+            touched.clear();
+            for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
+                const int i = cam_obs[e];
+                for (int j = pt_ptr[o_pt[i]]; j < i; ++j) {
+                    const int cj = (int)o_cam[j];
+                    if (cnt[cj]++ == 0) touched.push_back(cj);
+                }
+            }
+            std::sort(touched.begin(), touched.end());
+            auto& runs = row_runs[r];
+            runs.reserve(touched.size());
+            for (int cj : touched) { runs.push_back(Run{(uint32_t)cj, cnt[cj], 0}); cnt[cj] = 0; }
+        }
+    });
+    tr.mark("pairs: blocks of every row");
+    // ---- serial pass over the BLOCKS (not the pairs): slot offsets, block table, chunk descriptors, tasks ------------
     out->blocks.clear(); out->chunks.clear(); out->tasks.clear();
-    struct Piece { int64_t raw0; int len; int64_t slot0; };   // a block (or a piece of a split block): raw pairs -> slots
+    struct Piece { int64_t slot0; int len; };   // a block (or a piece of a split block) -> its slots
     std::vector<Piece> pieces;
     int64_t n_blocks = 0;
-    for (int64_t r = 0; r < n_cam; ++r) n_blocks += row_blocks[r];
+    for (int64_t r = 0; r < n_cam; ++r) n_blocks += (int64_t)row_runs[r].size();
     pieces.reserve(n_blocks + 16);
     out->blocks.reserve(n_blocks + 16);
+    out->chunks.reserve((size_t)(n_pairs / 64 + n_blocks / 32 + 1024));
     int64_t slot_pos = 0, task_begin = 0;
     auto chunk_touch = [&](int64_t s0, int64_t s1, int block_index, bool starts) {
         const int64_t c1 = (s1 - 1) / 64;
@@ -80,28 +90,26 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
     };
     for (int64_t r = 0; r < n_cam; ++r) {
         const int ci = rows[r];
-        int64_t q = rp[r];
-        while (q < rp[r + 1]) {
-            int64_t e = q;
-            const uint32_t cj = raw[q].cj;
-            while (e < rp[r + 1] && raw[e].cj == cj) ++e;
+        for (Run& run : row_runs[r]) {
+            const uint32_t cj = run.cj;
             const int I = ci / cpt, J = (int)cj / cpt;
             const int sl = slot[(size_t)I * nt + J];
             const int64_t dst = (int64_t)sl * kNB * kNB + (int64_t)((ci % cpt) * dc) * kNB + ((int)cj % cpt) * dc;
             const uint32_t diag = ((int)cj == ci) ? kPairBlockDiag : 0u;
-            int64_t len = e - q;
+            int64_t len = run.len;
             const bool split = (len + 1) / 2 * 2 > kPairMaxBlockSlots;
             if (split) close_task();
+            run.piece0 = (int)pieces.size();
             while (len > 0) {
                 const int take = (int)std::min<int64_t>(len, split ? kPairMaxBlockSlots : len);
                 const int padded = (take + 1) / 2 * 2;
                 if (!split && slot_pos - task_begin > 0 && slot_pos - task_begin + padded > 2 * kTask) close_task();
                 const int bi = (int)out->blocks.size();
                 out->blocks.push_back(PairBlock{dst, (uint32_t)ci, cj, diag | ((split || diag) ? kPairBlockAtomic : 0u), 0u});
-                pieces.push_back(Piece{q, take, slot_pos});
+                pieces.push_back(Piece{slot_pos, take});
                 chunk_touch(slot_pos, slot_pos + padded, bi, true);
                 slot_pos += padded;
-                q += take; len -= take;
+                len -= take;
                 if (split || slot_pos - task_begin >= kTask) close_task();
             }
         }
@@ -109,20 +117,44 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
     close_task();
     const int64_t n_slots = slot_pos;
     out->chunks.resize(n_slots / 64, PairChunk{0u, -1});
-    // ---- records -----------------------------------------------------------------------------------------------------
-    out->recs.assign((size_t)n_slots, PairRec{kPairPad, 0u, 0u, 0u});
-    parallel_rows((int64_t)pieces.size(), [&](int64_t b) {
-        const Piece& pc = pieces[b];
-        for (int k = 0; k < pc.len; ++k) {
-            const RawPair& rw = raw[pc.raw0 + k];
-            const int64_t s = pc.slot0 + k;
-            out->recs[s] = PairRec{rw.i, rw.j, o_pt[rw.i], (uint32_t)((int)b - out->chunks[s / 64].first_block)};
-        }
-        if (pc.len & 1) {   // the odd block's last K-step: a zero pair that still belongs to the block
-            const int64_t s = pc.slot0 + pc.len;
-            out->recs[s].blk = (uint32_t)((int)b - out->chunks[s / 64].first_block);
+    tr.mark("pairs: blocks, tasks");
+    // ---- records, written straight to their slots.  Pass B, per row: the observations of a camera are visited in
+    // increasing landmark-major index i, so the pairs of one partner arrive ordered by i: a cursor per partner is the
+    // whole sort.  Every slot is written exactly once (pairs here; the odd block's zero pair and the padding behind a
+    // task in the loop over the pieces).
+    out->recs.resize((size_t)n_slots);
+    parallel_ranges(n_cam, 16, [&](int64_t rb, int64_t re) {
+        std::vector<int> pos(n_cam, 0), ridx(n_cam, 0);
+        for (int64_t r = rb; r < re; ++r) {
+            const int c = rows[r];
+            const auto& runs = row_runs[r];
+            for (size_t q = 0; q < runs.size(); ++q) { ridx[runs[q].cj] = (int)q; pos[runs[q].cj] = 0; }
+            for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
+                const int i = cam_obs[e];
+                const uint32_t l = o_pt[i];
+                for (int j = pt_ptr[l]; j < i; ++j) {
+                    const uint32_t cj = o_cam[j];
+                    const Run& run = runs[ridx[cj]];
+                    const int k = pos[cj]++;
+                    const int pi = run.piece0 + k / kPairMaxBlockSlots;   // (only a split block has more than one piece)
+                    const int64_t s = pieces[pi].slot0 + k % kPairMaxBlockSlots;
+                    out->recs[s] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)(pi - out->chunks[s / 64].first_block)};
+                }
+            }
         }
     });
+    const int64_t n_pieces = (int64_t)pieces.size();
+    parallel_rows(n_pieces, [&](int64_t b) {
+        const Piece& pc = pieces[b];
+        int64_t s = pc.slot0 + pc.len;
+        if (pc.len & 1) {   // the odd block's last K-step: a zero pair that still belongs to the block
+            out->recs[s] = PairRec{kPairPad, 0u, 0u, (uint32_t)((int)b - out->chunks[s / 64].first_block)};
+            ++s;
+        }
+        const int64_t next = b + 1 < n_pieces ? pieces[b + 1].slot0 : n_slots;
+        for (; s < next; ++s) out->recs[s] = PairRec{kPairPad, 0u, 0u, 0u};
+    }, 1024);
+    tr.mark("pairs: records");
     out->n_pairs = n_pairs;
     out->n_blocks = n_blocks;
 }

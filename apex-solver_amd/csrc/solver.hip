@@ -179,7 +179,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     cmap_ = hs.cmap; cinv_ = hs.cinv; lmap_ = hs.lmap;
     lm_lo_ = hs.lm_lo; lm_hi_ = hs.lm_hi; tree_shard_ = hs.tree_shard; pad_rank_ = hs.pad_rank;
     n_hubs_ = hs.n_hubs; n_border_tiles_ = hs.n_border_tiles;
-    o_orig_h_ = hs.o_orig;
+    o_orig_h_.assign(hs.o_orig.begin(), hs.o_orig.end());
     n_pairs_ = hs.n_pairs; n_present_ = hs.n_present;
     if (lam_mask_) { hipFree(lam_mask_); lam_mask_ = nullptr; }
     if (tree_shard_) {
@@ -203,9 +203,11 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     n_pair_blocks_ = hs.pl.n_blocks; n_pair_slots_ = (int64_t)hs.pl.recs.size();
     const int64_t n_loc = (int64_t)hs.o_cam.size();
     const auto t_up = std::chrono::steady_clock::now();
-    const std::vector<uint32_t>&o_cam = hs.o_cam, &o_pt = hs.o_pt, &co_pt = hs.co_pt;
-    const std::vector<double>&o_uv = hs.o_uv, &co_uv = hs.co_uv;
-    const std::vector<int>&pt_ptr = hs.pt_ptr, &cam_ptr = hs.cam_ptr, &cam_obs = hs.cam_obs, &co_rank = hs.co_rank, &nbr = hs.nbr;
+    const auto &o_cam = hs.o_cam, &o_pt = hs.o_pt, &co_pt = hs.co_pt;
+    const auto &o_uv = hs.o_uv, &co_uv = hs.co_uv;
+    const auto &pt_ptr = hs.pt_ptr, &cam_ptr = hs.cam_ptr;
+    const auto &cam_obs = hs.cam_obs, &co_rank = hs.co_rank;
+    const auto& nbr = hs.nbr;
     const std::vector<ScatterTask>& tasks = hs.tasks;
     const std::vector<RowTask>&rtasks = hs.rtasks, &rtasks2 = hs.rtasks2;
     const std::vector<RowBatch>& rbatches = hs.rbatches;

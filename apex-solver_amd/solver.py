@@ -250,7 +250,7 @@ class GpuSchurComplementSolver:
             h.check(h.L.apexgpu_set_option(h.h, k.encode(), v))
         lay = problem.layout
         self._keep = [np.ascontiguousarray(a) for a in (
-            d.cam_idx.astype(np.uint32), d.pt_idx.astype(np.uint32), d.obs_uv.astype(np.float64),
+            d.cam_idx.astype(np.uint32, copy=False), d.pt_idx.astype(np.uint32, copy=False), d.obs_uv.astype(np.float64, copy=False),
             lay.intr_col, lay.pose_col, lay.pt_col, problem.fix_pose, problem.fix_intr, problem.fix_pt)]
         hd = -1.0 if problem.huber_delta is None else float(problem.huber_delta)
         h.check(h.L.apexgpu_set_structure(h.h, *[capi.ptr(a) for a in self._keep], hd))

@@ -49,3 +49,15 @@ def test_tree_sharding_partitions_the_landmarks(world):
     # range sharding: contiguous, balanced by observations
     st = capi.host_structure(d.n_cam, d.n_pt, d.cam_idx, d.pt_idx, rank=0, world=world, tree_sharding=0)
     assert st["tree_sharded"] == 0.0 and st["owned"][: int(st["owned"].sum())].all()
+
+
+def test_observation_order_does_not_change_the_structure():
+    """Observations grouped by landmark (BAL files, the synthetic generator: the set-up's fast path) or in any order:
+    same camera order, same tile structure, same pair count."""
+    d = pkg.synthetic.make_problem(700, 20000, 3, 8, config_id=77)
+    a = capi.host_structure(d.n_cam, d.n_pt, d.cam_idx, d.pt_idx)
+    perm = np.random.default_rng(3).permutation(d.n_obs)
+    b = capi.host_structure(d.n_cam, d.n_pt, d.cam_idx[perm], d.pt_idx[perm])
+    assert np.array_equal(a["cmap"], b["cmap"])
+    for k in ("tiles", "touched_tiles", "etree_levels", "pair_contributions", "pair_blocks", "hub_cameras"):
+        assert a[k] == b[k], k

@@ -46,10 +46,14 @@ def replay(pl, cam_idx, dc):
 
 
 @pytest.mark.parametrize("dc", [9, 6])
+@pytest.mark.parametrize("shuffled", [False, True], ids=["grouped", "shuffled"])
 @pytest.mark.parametrize("shape", [(40, 1500, 3, 7), (300, 9000, 2, 9)])
-def test_every_pair_reaches_its_block_once(dc, shape):
+def test_every_pair_reaches_its_block_once(dc, shape, shuffled):
     n_cam, n_pt, klo, khi = shape
     d = pkg.synthetic.make_problem(n_cam, n_pt, klo, khi, config_id=400 + n_cam)
+    if shuffled:   # the generator lists observations landmark by landmark (the set-up's fast path); any order must do
+        perm = np.random.default_rng(7).permutation(d.n_obs)
+        d.cam_idx, d.pt_idx, d.obs_uv = d.cam_idx[perm], d.pt_idx[perm], d.obs_uv[perm]
     pl = capi.pair_lists(d.n_cam, d.n_pt, dc, d.cam_idx, d.pt_idx)
     flushed = replay(pl, d.cam_idx, dc)
     blocks, o_index = pl["blocks"], pl["o_index"]
