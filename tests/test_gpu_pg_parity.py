@@ -1,7 +1,7 @@
 """GPU parity of the SE3 pose-graph backend (BASELINE.json configs[1]) through the C ABI
 (apexgpu_pg_*) against the oracle, the committed golden fixtures and size-independent properties at
 sphere2500 scale.  Tolerances: r, J, J^T J, J^T r <= 1e-12 relative; the step within
-max(1e-10, 20 eps cond(H + lambda I)) with backward error <= 1e-13."""
+1e-10 (the north star's figure; cond(H + lambda I) <= 1e5 on these graphs, measured 1e-13 .. 1e-12) with backward error <= 1e-13."""
 import os
 
 import numpy as np
@@ -15,6 +15,7 @@ from oracle import pg_oracle as po
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 EPS = np.finfo(np.float64).eps
+STEP_FORWARD_BOUND = 1e-10   # |step - oracle step| / |oracle step|: the north star's figure, fixed (not scaled by cond)
 
 
 def rel(a, b):
@@ -43,7 +44,7 @@ def test_golden_iterations(name):
         assert rel(s.get_jacobian_blocks(), g[f"it{it}_J"]) < 1e-12
         step = s.solve_augmented_equation(lam)
         assert rel(s.get_gradient(), g[f"it{it}_grad"]) < 1e-12
-        tol = max(1e-10, 20 * EPS * float(g[f"it{it}_cond"]))
+        tol = STEP_FORWARD_BOUND
         assert rel(step, g[f"it{it}_step"]) < tol
         gn, sn, pred = s.step_stats()
         assert abs(pred - float(g[f"it{it}_pred"])) <= 1e-9 * abs(pred)
@@ -87,7 +88,7 @@ def test_oracle_parity_mid_size(huber):
     rc, so, _ = o.solve_augmented(lam)
     assert rc == 0
     cond = np.linalg.cond(Ho)
-    assert rel(step, so) < max(1e-10, 20 * EPS * cond)
+    assert rel(step, so) < STEP_FORWARD_BOUND, (rel(step, so), cond)
     assert np.linalg.norm(Ho @ step + go) <= 1e-13 * (np.linalg.norm(Ho, 2) * np.linalg.norm(step) + np.linalg.norm(go))
     info = s.info()
     assert info["tile_rows"] == 25 and info["total_dof"] == 3600
@@ -268,7 +269,7 @@ def test_jacobi_scaling_vs_oracle(huber):
     y = s.solve_augmented_equation(lam)
     rc, yo, gso = o.solve_augmented(lam)
     assert rc == 0 and rel(s.get_gradient(), gso) < 1e-12
-    assert rel(y, yo) < max(1e-10, 20 * EPS * np.linalg.cond(Hs))
+    assert rel(y, yo) < STEP_FORWARD_BOUND
     assert np.linalg.norm(Hs @ y + scal * go) <= 1e-13 * (np.linalg.norm(Hs, 2) * np.linalg.norm(y) + np.linalg.norm(go))
     step = yo * scal
     gn, sn, pred = s.step_stats()   # compute_step_generic: scaled gradient, unscaled step
