@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <numeric>
 
 #include "host_parallel.h"
@@ -114,18 +115,13 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
             });
         }
         tr.mark("order: two-hop closure");
-        const unsigned nth = host_threads();
-        std::vector<std::vector<uint64_t>> parts(nth);
-        std::atomic<unsigned> slot_id(0);
+        std::vector<uint64_t> edges;
+        std::mutex edges_mu;
         std::atomic<int64_t> total(0);
         const int64_t kMaxEdges = 1LL << 26;
         parallel_ranges(n_pt, 4096, [&](int64_t b, int64_t e) {
-            thread_local unsigned my = ~0u;
-            thread_local const void* owner_tag = nullptr;
-            if (owner_tag != (const void*)&parts) { my = slot_id.fetch_add(1) % nth; owner_tag = (const void*)&parts; }
-            std::vector<uint64_t>& out = parts[my];
             if (total.load(std::memory_order_relaxed) > kMaxEdges) return;
-            int64_t added = 0;
+            std::vector<uint64_t> out;
             for (int64_t l = b; l < e; ++l)
                 for (int64_t x = lp[l]; x < lp[l + 1]; ++x) {
                     const uint32_t ca = cam_idx[lobs[x]];
@@ -133,16 +129,15 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
                         const uint32_t cb = cam_idx[lobs[y]];
                         if (ca == cb || near2[(size_t)(ca / cpt) * nt + cb / cpt]) continue;
                         out.push_back(((uint64_t)std::min(ca, cb) << 32) | std::max(ca, cb));
-                        ++added;
                     }
                 }
-            total.fetch_add(added, std::memory_order_relaxed);
+            if (out.empty()) return;
+            total.fetch_add((int64_t)out.size(), std::memory_order_relaxed);
+            std::lock_guard<std::mutex> lk(edges_mu);
+            if ((int64_t)edges.size() <= kMaxEdges) edges.insert(edges.end(), out.begin(), out.end());
         });
         tr.mark("order: long-range pairs");
         if (total.load() <= kMaxEdges && total.load() > 0) {
-            std::vector<uint64_t> edges;
-            edges.reserve((size_t)total.load());
-            for (auto& pvec : parts) { edges.insert(edges.end(), pvec.begin(), pvec.end()); std::vector<uint64_t>().swap(pvec); }
             std::sort(edges.begin(), edges.end());
             edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
             // adjacency of the long-range graph

@@ -8,6 +8,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdio>
 #include <memory>
 #include <new>
@@ -23,23 +26,86 @@ inline unsigned host_threads() {
     return std::min<unsigned>(nt, 128);
 }
 
+// A persistent pool: the set-up runs some thirty parallel loops and creating 128 threads for each costs more than most of
+// the loops themselves.  Workers are created on first use and live until the process ends; one loop at a time (callers
+// are serialised), the calling thread works too.
+class HostPool {
+   public:
+    static HostPool& get() { static HostPool p; return p; }
+    // run job(worker) on `use` workers (including the caller) and wait
+    template <typename J>
+    void run(unsigned use, J&& job) {
+        std::lock_guard<std::mutex> serial(run_mu_);
+        if (use <= 1) { job(); return; }
+        ensure(use - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = [&job]() { job(); };
+            want_ = use - 1; started_ = 0; pending_ = use - 1;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        job();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+   private:
+    HostPool() = default;
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void ensure(unsigned n) {
+        while (th_.size() < n) th_.emplace_back([this] { loop(); });
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void()> fn;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && started_ < want_); });
+                if (stop_) return;
+                seen = epoch_;
+                ++started_;
+                fn = fn_;
+            }
+            fn();
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    std::mutex run_mu_, mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> th_;
+    std::function<void()> fn_;
+    unsigned want_ = 0, started_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
+
 // f(begin, end) over [0, n) in dynamic chunks of `grain`; serial when the range is small
 template <typename F>
 void parallel_ranges(int64_t n, int64_t grain, F&& f) {
     const unsigned nt = host_threads();
-    if (n <= grain || nt == 1) { if (n > 0) f((int64_t)0, n); return; }
+    static thread_local bool inside = false;   // a loop started from inside a loop runs serially
+    if (n <= grain || nt == 1 || inside) { if (n > 0) f((int64_t)0, n); return; }
     std::atomic<int64_t> next(0);
-    std::vector<std::thread> th;
     const unsigned use = (unsigned)std::min<int64_t>(nt, (n + grain - 1) / grain);
-    for (unsigned t = 0; t < use; ++t)
-        th.emplace_back([&] {
-            for (;;) {
-                const int64_t b = next.fetch_add(grain);
-                if (b >= n) break;
-                f(b, std::min<int64_t>(n, b + grain));
-            }
-        });
-    for (auto& t : th) t.join();
+    HostPool::get().run(use, [&] {
+        inside = true;
+        for (;;) {
+            const int64_t b = next.fetch_add(grain);
+            if (b >= n) break;
+            f(b, std::min<int64_t>(n, b + grain));
+        }
+        inside = false;
+    });
 }
 
 // f(i) for i in [0, n)

@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -163,7 +164,8 @@ class Solver : public LmBackend {
     // host copies
     std::vector<int64_t> intr_col_, pose_col_, pt_col_;
     std::vector<int> o_orig_h_;
-    std::vector<uint32_t> cam_idx_h_, pt_idx_h_;   // the caller's factor list (kept for the Hessian export)
+    std::thread free_thread_;   // unmaps the set-up's host lists off the caller's path
+    raw_vector<uint32_t> cam_idx_h_, pt_idx_h_;    // the caller's factor list (kept for the Hessian export)
 
     // device
     hipStream_t stream_ = nullptr;

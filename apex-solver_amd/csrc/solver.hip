@@ -49,6 +49,7 @@ Solver::Solver(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device)
 }
 
 Solver::~Solver() {
+    if (free_thread_.joinable()) free_thread_.join();
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
     void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
@@ -150,17 +151,31 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
                           double huber_delta) {
     if (n_cam_ <= 0 || n_pt_ <= 0) return fail(kInvalidInput, n_cam_ <= 0 ? "No camera variables found" : "No landmark variables found");
     if (n_obs_ < 0 || n_obs_ > 2000000000LL) return fail(kInvalidInput, "observation count out of range");
-    for (int64_t i = 0; i < n_obs_; ++i)
-        if (cam_idx[i] >= (uint64_t)n_cam_ || pt_idx[i] >= (uint64_t)n_pt_)
-            return fail(kInvalidInput, "observation " + std::to_string(i) + " references a missing variable");
+    SetupTrace tr;
+    {
+        std::atomic<int64_t> bad(n_obs_);   // first observation that references a missing variable
+        parallel_ranges(n_obs_, 1 << 18, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i)
+                if (cam_idx[i] >= (uint64_t)n_cam_ || pt_idx[i] >= (uint64_t)n_pt_) {
+                    int64_t cur = bad.load();
+                    while (i < cur && !bad.compare_exchange_weak(cur, i)) {}
+                    return;
+                }
+        });
+        if (bad.load() < n_obs_) return fail(kInvalidInput, "observation " + std::to_string(bad.load()) + " references a missing variable");
+    }
     HIP_TRY(hipSetDevice(device_));
     if (!stream_) HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     huber_delta_ = huber_delta;
     intr_col_.assign(intr_col, intr_col + n_cam_);
     pose_col_.assign(pose_col, pose_col + n_cam_);
     pt_col_.assign(pt_col, pt_col + n_pt_);
-    cam_idx_h_.assign(cam_idx, cam_idx + n_obs_);
-    pt_idx_h_.assign(pt_idx, pt_idx + n_obs_);
+    cam_idx_h_.resize(n_obs_); pt_idx_h_.resize(n_obs_);   // kept for get_hessian_csc
+    parallel_ranges(n_obs_, 1 << 18, [&](int64_t b, int64_t e) {
+        memcpy(cam_idx_h_.data() + b, cam_idx + b, (size_t)(e - b) * sizeof(uint32_t));
+        memcpy(pt_idx_h_.data() + b, pt_idx + b, (size_t)(e - b) * sizeof(uint32_t));
+    });
+    tr.mark("validate, keep the index lists");
 
     // ---- everything derived from the observation list on the host (ba_structure.h): internal camera order (hub
     // cameras last, nested dissection of the tile graph), tile structure, landmark sharding, observation lists ------
@@ -170,7 +185,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     so.dc = dc_; so.use_nd = use_nd_; so.nd_leaf = nd_leaf_; so.hubs_last = hubs_last_;
     so.rank = rank_; so.world = world_; so.dist_factor = dist_factor_; so.tree_sharding = tree_sharding_;
     so.dist_selftest = dist_selftest_; so.schur_form = use_rows_ ? rows_form_ : 0; so.pair_task_slots = pair_task_slots_;
-    BaHostStructure hs;
+    std::unique_ptr<BaHostStructure> hs_owner(new BaHostStructure);
+    BaHostStructure& hs = *hs_owner;
     {
         const std::string e = hs.build_lists(n_cam_, n_pt_, n_obs_, cam_idx, pt_idx, obs_uv, so, tp_);
         if (!e.empty()) return fail(kInvalidInput, e);
@@ -292,6 +308,10 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     hs.seconds[4] = since(t_up);
     hs.seconds[5] = since(t_begin);
     for (int k = 0; k < 6; ++k) setup_s_[k] = hs.seconds[k];
+    tr.mark("set_structure body");
+    // the host lists (3.7 GB on final-13682) are unmapped off the caller's path: 0.2 s
+    if (free_thread_.joinable()) free_thread_.join();
+    free_thread_ = std::thread([p = hs_owner.release()] { delete p; });
 
     have_structure_ = true;
     have_params_ = have_step_ = have_trial_ = false;
