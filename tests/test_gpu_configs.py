@@ -262,3 +262,35 @@ def test_synthetic_10k_full_size_implicit_pcg():
 def test_synthetic_10k_sample_vs_oracle(oracle):
     oracle_sample_check(oracle, "synthetic-10k", 0.02, "selfcal", variant=2, cg=(500, 1e-9))
     oracle_sample_check(oracle, "synthetic-10k", 0.02, "selfcal", variant=0)
+
+
+# ---- the non-banded stress shape: hub cameras + long-range matches, border ordering on the device path ---------------------
+@pytest.mark.parametrize("mode", ["selfcal", "ba"])
+def test_hub_shape_vs_oracle(oracle, mode):
+    """The "-hub" generator at a size the oracle's dense Schur handles (640 cameras, 40 tiles): cameras seen from anywhere
+    and accidental long-range matches are ordered last (a dense border of S, 228 tiles instead of 795); the internal
+    order is invisible at the boundary -- S, g_red, gradient and the step equal the oracle's with and without it."""
+    d = pkg.synthetic.make_problem(640, 16000, 3, 8, config_id=97, window=16, hub_frac=0.04, hub_obs_prob=0.04, long_range_prob=3e-4)
+    lam = 1e-3
+    out = {}
+    for hubs_last in (1, 0):
+        prob, s = make(d, mode, opts=(("hubs_last", hubs_last),))
+        info = dict(s.info(), border_cameras=s.setup_times()["hub_cameras"])
+        step = s.solve_augmented_equation(lam)
+        S, gred = s.get_schur()
+        out[hubs_last] = (info, step.copy(), S, gred, s.get_gradient())
+        s.close()
+        print("border", "on :" if hubs_last else "off:", {q: info[q] for q in ("tiles", "etree_levels", "border_cameras")})
+    assert out[1][0]["border_cameras"] > 0 and out[0][0]["border_cameras"] == 0
+    assert out[1][0]["tiles"] < out[0][0]["tiles"]
+    o = oracle.from_data(d, prob.layout, mode=mode, huber_delta=1.0)
+    o.linearize()
+    ostep, ograd, oS, ogred = o.solve_augmented(lam, 0, want_schur=True)
+    nc = prob.layout.cam_dof
+    for hubs_last in (1, 0):
+        _, step, S, gred, grad = out[hubs_last]
+        bwd = np.linalg.norm(oS @ step[:nc] - ogred) / (np.linalg.norm(oS, 2) * np.linalg.norm(step[:nc]) + np.linalg.norm(ogred))
+        errs = dict(S=rel(S, oS), gred=rel(gred, ogred), grad=rel(grad, ograd), step=rel(step, ostep))
+        print("hubs_last", hubs_last, {k: f"{v:.1e}" for k, v in errs.items()}, f"backward {bwd:.1e}")
+        assert errs["S"] < 1e-12 and errs["gred"] < 1e-10 and errs["grad"] < 1e-12
+        assert bwd < 1e-13 and errs["step"] < 1e-7
