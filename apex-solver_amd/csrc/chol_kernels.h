@@ -28,7 +28,8 @@ struct TriTask {   // one workgroup of a triangular-solve step (k_tri_step)
 
 struct FlowTask {     // one workgroup of a dataflow triangular sweep (k_tri_fwd_flow / k_tri_bwd_flow)
     const double* mat;    // product task: the off-diagonal tile; solve task: L^-1 of the diagonal tile
-    int src;              // product: the block whose solution the tile multiplies; solve: -1
+    int src;              // product: the block whose solution the tile multiplies; solve: -1; fold only (distributed
+                          // forward, a shared top block: right-hand side minus this rank's products, no solve): -2
     int dst;              // product: the block the product belongs to; solve: the block solved
     int part;             // product: its slot in the partial array; solve: first slot of the block's products
     int count;            // solve: number of products to wait for and fold
@@ -54,7 +55,7 @@ void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 
 // batches of <= 56 tasks use the latency kernels, larger ones the 3 x 3-wave strip kernel
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s);
 void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const double* in, double* out, double* part, int* flags,
-                     int nt, hipStream_t s);
+                     int nt, hipStream_t s, const double* fold_b, double* fold_out);
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s);
 void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double* diag, hipStream_t s);
 void launch_tile_add_diag(double* tiles, const int* diag_slot, int n_valid, int n_total, double add_valid,

@@ -980,7 +980,8 @@ constexpr int kFwdThreads = 64 * (NB / kFlowRows);   // 8 waves, 512 threads
 
 __global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowTask* __restrict__ tasks, const double* __restrict__ b,
                                                              double* __restrict__ y, double* __restrict__ part,
-                                                             int* __restrict__ cnt, int* __restrict__ done) {
+                                                             int* __restrict__ cnt, int* __restrict__ done,
+                                                             const double* __restrict__ fold_b, double* __restrict__ fold_out) {
     __shared__ double sfold[NB / kFlowRows][192];
     const FlowTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1023,11 +1024,23 @@ __global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowTask* __
         }
         sfold[w][lane] = f0; sfold[w][lane + 64] = f1; sfold[w][lane + 128] = f2;
         __syncthreads();
-        const double* __restrict__ bs = b + (size_t)t.dst * NB + lane;
-        v0 = bs[0]; v1 = bs[64];
-        if (third) v2 = bs[128];
+        const double* __restrict__ bsrc = t.src == -2 ? fold_b : b;
+        v0 = 0.0; v1 = 0.0;
+        if (bsrc) {
+            const double* __restrict__ bs = bsrc + (size_t)t.dst * NB + lane;
+            v0 = bs[0]; v1 = bs[64];
+            if (third) v2 = bs[128];
+        }
 #pragma unroll
         for (int u = 0; u < NB / kFlowRows; ++u) { v0 -= sfold[u][lane]; v1 -= sfold[u][lane + 64]; v2 -= sfold[u][lane + 128]; }
+        if (t.src == -2) {   // fold only: this rank's share of a shared top block of the right-hand side, no solve, no flag
+            if (w == 0) {
+                double* __restrict__ o = fold_out + (size_t)t.dst * NB + lane;
+                o[0] = v0; o[64] = v1;
+                if (third) o[128] = v2;
+            }
+            return;
+        }
     }
     double acc[kFlowRows];
 #pragma unroll
@@ -1322,11 +1335,11 @@ void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, dou
     else hipLaunchKernelGGL(k_tri_step<false>, dim3(grid), dim3(256), 0, s, tasks, n, vwork, vout);
 }
 void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const double* in, double* out, double* part, int* flags,
-                     int nt, hipStream_t s) {
+                     int nt, hipStream_t s, const double* fold_b, double* fold_out) {
     if (n_tasks <= 0) return;
     (void)hipMemsetAsync(flags, 0, (size_t)2 * nt * sizeof(int), s);   // cnt[nt] | done[nt]
     if (backward) hipLaunchKernelGGL(k_tri_bwd_flow, dim3(n_tasks), dim3(kBwdThreads), 0, s, tasks, in, out, part, flags, flags + nt);
-    else hipLaunchKernelGGL(k_tri_fwd_flow, dim3(n_tasks), dim3(kFwdThreads), 0, s, tasks, in, out, part, flags, flags + nt);
+    else hipLaunchKernelGGL(k_tri_fwd_flow, dim3(n_tasks), dim3(kFwdThreads), 0, s, tasks, in, out, part, flags, flags + nt, fold_b, fold_out);
 }
 void launch_sym_tile_products(const SymTile* list, int n, const double* tiles, const double* x, double* part, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_sym_tile_products, dim3(n), dim3(256), 0, s, list, tiles, x, part);

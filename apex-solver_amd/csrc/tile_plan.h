@@ -153,7 +153,8 @@ class TilePlan {
     FlowTask *flow_fwd_ = nullptr, *flow_bwd_ = nullptr;   // dataflow triangular sweeps (single-GPU plans)
     double* flow_part_ = nullptr;                          // one 144-vector per off-diagonal tile
     int* flow_flags_ = nullptr;                            // cnt[nt] | done[nt]
-    int n_flow_tasks_ = 0, n_flow_parts_ = 0;
+    int n_flow_tasks_ = 0, n_flow_bwd_ = 0, n_flow_parts_ = 0;
+    int n_flow_local_ = 0;   // distributed plans: the forward tasks of phase 0 (the rest: the top columns, phase 1)
     bool tri_flow_ = true;
     SymTile* sym_tiles_ = nullptr;
     int n_sym_tiles_ = 0;

@@ -418,30 +418,64 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     // by level the solve tasks of the level's blocks, then the product tasks of the tiles those solutions multiply.
     // A block's products own consecutive slots of the partial array, in the order the solve task folds them.
     std::vector<FlowTask> ft, bt;
-    if (!distributed()) {
-        std::vector<int> first(nt_ + 1, 0);
-        for (int K = 0; K < nt_; ++K) first[K + 1] = first[K] + (int)row_cols[K].size();      // forward: slots by block row
-        for (int lv = 0; lv < n_levels_; ++lv) {
-            for (int K : level_cols[lv]) ft.push_back({linv_ptr(K), -1, K, first[K], (int)row_cols[K].size()});
-            for (int K : level_cols[lv])
-                for (int I : col_rows[K]) {
-                    const auto& rc = row_cols[I];
-                    const int pos = (int)(std::lower_bound(rc.begin(), rc.end(), K) - rc.begin());
-                    ft.push_back({tile_ptr(I, K), K, I, first[I] + pos, 0});
-                }
+    n_flow_local_ = 0;
+    {
+        // forward: slots by block row.  In a distributed plan a shared top row takes products from this rank's columns
+        // (phase 0: folded into the exchange vector, no solve) and from top columns (phase 1): the rank's sources get the
+        // first slots of the row, the top sources the rest, each in column order -- so the fold of the top sources is
+        // the same sequence of additions on every rank (the ranks' copies of the top solution must be bitwise equal).
+        std::vector<int> first(nt_ + 1, 0), own_src(nt_, 0);
+        std::vector<std::vector<int>> slot_of(nt_);
+        for (int K = 0; K < nt_; ++K) {
+            first[K + 1] = first[K] + (int)row_cols[K].size();
+            for (int J : row_cols[K]) own_src[K] += cls_h_[J] == 1;
+            int a = 0, b = own_src[K];
+            slot_of[K].reserve(row_cols[K].size());
+            for (int J : row_cols[K]) slot_of[K].push_back(cls_h_[J] == 1 ? a++ : b++);
         }
-        for (int K = 0; K < nt_; ++K) first[K + 1] = first[K] + (int)col_rows[K].size();      // backward: by block column
-        for (int lv = n_levels_ - 1; lv >= 0; --lv) {
-            for (int I : level_cols[lv]) bt.push_back({linv_ptr(I), -1, I, first[I], (int)col_rows[I].size()});
-            for (int I : level_cols[lv])
-                for (int J : row_cols[I]) {
-                    const auto& cr = col_rows[J];
-                    const int pos = (int)(std::lower_bound(cr.begin(), cr.end(), I) - cr.begin());
-                    bt.push_back({tile_ptr(I, J), I, J, first[J] + pos, 0});
-                }
+        auto products_of = [&](int K) {
+            for (int I : col_rows[K]) {
+                const auto& rc = row_cols[I];
+                const int pos = (int)(std::lower_bound(rc.begin(), rc.end(), K) - rc.begin());
+                ft.push_back({tile_ptr(I, K), K, I, first[I] + slot_of[I][pos], 0});
+            }
+        };
+        if (!distributed()) {
+            for (int lv = 0; lv < n_levels_; ++lv) {
+                for (int K : level_cols[lv]) ft.push_back({linv_ptr(K), -1, K, first[K], (int)row_cols[K].size()});
+                for (int K : level_cols[lv]) products_of(K);
+            }
+        } else {
+            for (int lv = 0; lv < n_local_groups_; ++lv) {          // phase 0: this rank's columns ...
+                for (int K : level_cols[lv]) ft.push_back({linv_ptr(K), -1, K, first[K], (int)row_cols[K].size()});
+                for (int K : level_cols[lv]) products_of(K);
+            }
+            for (int lv = n_local_groups_; lv < n_levels_; ++lv)    // ... and what they add to the shared top blocks
+                for (int K : level_cols[lv]) ft.push_back({linv_ptr(K), -2, K, first[K], own_src[K]});
+            n_flow_local_ = (int)ft.size();
+            for (int lv = n_local_groups_; lv < n_levels_; ++lv) {  // phase 1: the top columns, every rank alike
+                for (int K : level_cols[lv])
+                    ft.push_back({linv_ptr(K), -1, K, first[K] + own_src[K], (int)row_cols[K].size() - own_src[K]});
+                for (int K : level_cols[lv]) products_of(K);
+            }
         }
-        n_flow_parts_ = first[nt_];
+        if (!ft.empty()) {
+            for (int K = 0; K < nt_; ++K) first[K + 1] = first[K] + (int)col_rows[K].size();      // backward: by block column
+            for (int lv = n_levels_ - 1; lv >= 0; --lv) {
+                for (int I : level_cols[lv]) bt.push_back({linv_ptr(I), -1, I, first[I], (int)col_rows[I].size()});
+                for (int I : level_cols[lv])
+                    for (int J : row_cols[I]) {
+                        const auto& cr = col_rows[J];
+                        const int pos = (int)(std::lower_bound(cr.begin(), cr.end(), I) - cr.begin());
+                        bt.push_back({tile_ptr(I, J), I, J, first[J] + pos, 0});
+                    }
+            }
+        }
+        int64_t a = 0, b = 0;
+        for (int K = 0; K < nt_; ++K) { a += (int64_t)row_cols[K].size(); b += (int64_t)col_rows[K].size(); }
+        n_flow_parts_ = (int)std::max(a, b);
     }
+    n_flow_bwd_ = (int)bt.size();
     n_flow_tasks_ = (int)ft.size();
     // symmetric matvec of the PCG variant: only tiles that are non-zero before fill
     std::vector<int> sym_ptr(nt_ + 1, 0);
@@ -581,7 +615,7 @@ void TilePlan::enqueue_solve(const double* rhs, double* x, double* work, bool ba
     const bool flow = tri_flow_ && n_flow_tasks_ > 0;
     if (!backward_only) {
         if (flow) {
-            launch_tri_flow(false, flow_fwd_, n_flow_tasks_, rhs, yvec, flow_part_, flow_flags_, nt_, stream_);
+            launch_tri_flow(false, flow_fwd_, n_flow_tasks_, rhs, yvec, flow_part_, flow_flags_, nt_, stream_, nullptr, nullptr);
         } else {
             (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
             for (int lv = 0; lv < n_levels_; ++lv)
@@ -589,7 +623,7 @@ void TilePlan::enqueue_solve(const double* rhs, double* x, double* work, bool ba
         }
     }
     if (flow) {
-        launch_tri_flow(true, flow_bwd_, n_flow_tasks_, yvec, x, flow_part_, flow_flags_, nt_, stream_);
+        launch_tri_flow(true, flow_bwd_, n_flow_bwd_, yvec, x, flow_part_, flow_flags_, nt_, stream_, nullptr, nullptr);
         return;
     }
     for (int s = 0; s < n_levels_; ++s)
@@ -602,7 +636,21 @@ void TilePlan::enqueue_dist_solve(int phase, const double* rhs, double* x, doubl
     double* yvec = work + n_pad();
     const int n = (int)n_pad();
     const int L1 = n_local_groups_;
-    if (phase == 0) {
+    const bool flow = tri_flow_ && n_flow_local_ > 0;
+    if (phase == 0 && flow) {
+        // dataflow form: this rank's columns in one launch; its contributions to the shared top blocks are folded
+        // straight into the exchange vector (the top blocks of the right-hand side enter the sum once, on rank 0)
+        (void)hipMemsetAsync(exch_, 0, n_pad() * sizeof(double), stream_);
+        launch_tri_flow(false, flow_fwd_, n_flow_local_, rhs, yvec, flow_part_, flow_flags_, nt_, stream_,
+                        part_rank_ == 0 ? rhs : nullptr, exch_);
+    } else if (phase == 1 && flow) {
+        // the top columns forward (right-hand side = the summed exchange vector), then everything backward, top first.
+        // Pull form, fixed fold order: the ranks' copies of the top solution are bitwise equal by construction.
+        launch_tri_flow(false, flow_fwd_ + n_flow_local_, n_flow_tasks_ - n_flow_local_, exch_, yvec, flow_part_, flow_flags_, nt_,
+                        stream_, nullptr, nullptr);
+        launch_tri_flow(true, flow_bwd_, n_flow_bwd_, yvec, x, flow_part_, flow_flags_, nt_, stream_, nullptr, nullptr);
+        launch_vec_select(n, x, cls_, part_rank_ == 0 ? 6 : 2, exch_, stream_);
+    } else if (phase == 0) {
         // the top blocks of the right-hand side enter the sum once (rank 0); every rank adds its columns' updates
         launch_vec_select(n, rhs, cls_, part_rank_ == 0 ? 7 : 3, bvec, stream_);
         for (int lv = 0; lv < L1; ++lv)
@@ -650,7 +698,7 @@ bool TilePlan::run_graph(int which, const double* rhs, double* x, double* work) 
 void TilePlan::enable_tri_flow(bool on) {
     if (on == tri_flow_) return;
     tri_flow_ = on;
-    for (int which = 1; which <= 2; ++which)   // the captured sweeps change
+    for (int which : {1, 2, 4, 5})   // the captured sweeps change
         if (graph_exec_[which]) { (void)hipGraphExecDestroy(graph_exec_[which]); graph_exec_[which] = nullptr; }
 }
 

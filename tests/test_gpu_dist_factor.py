@@ -3,6 +3,8 @@ elimination tree on their owner ranks, shared top, two vector exchanges in the t
 the `world` ranks of one sharded problem live in this process on one GPU and the library plays the all-reduces between
 the phases (apexgpu_debug_lockstep_solve).  The production path runs the same phases with ncclAllReduce on the same
 buffers.  Every result is held to the single-rank solve of the same system."""
+import os
+
 import numpy as np
 import pytest
 

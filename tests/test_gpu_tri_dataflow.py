@@ -45,5 +45,6 @@ def test_pose_graph_dataflow_sweeps_match_level_sweeps():
         b = s.solve_augmented_equation(1e-3).copy()
         steps[flow] = (a, b)
         s.close()
-    assert np.array_equal(steps[1][0], steps[1][1])
-    assert rel(steps[1][0], steps[0][0]) < 1e-9   # H is assembled with fp64 atomics: last-bit differences times cond(H)
+    # (H is assembled with fp64 atomics here: two solves differ by last bits times cond(H) whatever the sweeps do)
+    assert rel(steps[1][0], steps[1][1]) < 1e-9
+    assert rel(steps[1][0], steps[0][0]) < 1e-9
