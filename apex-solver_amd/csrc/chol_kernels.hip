@@ -902,9 +902,18 @@ __global__ __launch_bounds__(256) void k_tri_step(const TriTask* __restrict__ ta
 // costs a buffer_inv / buffer_wbl2 of the whole L2 per workgroup: measured 4x slower than the level-by-level launches.
 __device__ __forceinline__ double flow_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void flow_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void flow_wait(const int* flag, int want, int tid) {
-    if (tid == 0)
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+// A wait is bounded: the scheme rests on workgroups being dispatched in blockIdx order; should that ever fail, a workgroup
+// gives up after ~2 s of polling, raises the error word (read back with the next factorisation's pivot flag) and lets the
+// launch end with a wrong result instead of hanging the device.
+constexpr int kFlowSpinLimit = 1 << 21;
+__device__ __forceinline__ void flow_wait(const int* flag, int want, int tid, int* err) {
+    if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kFlowSpinLimit) { atomicOr(err, 1); break; }
+        }
+    }
     __syncthreads();
 }
 __device__ __forceinline__ void flow_publish(int* flag, int tid) {
@@ -920,7 +929,7 @@ constexpr int kBwdParts = 8, kBwdThreads = (NB / 2) * kBwdParts;   // 576 thread
 
 __global__ __launch_bounds__(kBwdThreads) void k_tri_bwd_flow(const FlowTask* __restrict__ tasks, const double* __restrict__ y,
                                                              double* __restrict__ x, double* __restrict__ part,
-                                                             int* __restrict__ cnt, int* __restrict__ done) {
+                                                             int* __restrict__ cnt, int* __restrict__ done, int* __restrict__ err) {
     __shared__ double sx[NB];
     __shared__ double spart[kBwdParts][NB];
     const FlowTask t = tasks[blockIdx.x];
@@ -934,10 +943,10 @@ __global__ __launch_bounds__(kBwdThreads) void k_tri_bwd_flow(const FlowTask* __
         for (int r = 0; r < kFlowRows; ++r) m[r] = *reinterpret_cast<const double2*>(M + (size_t)r * NB);
     }
     if (t.src >= 0) {
-        flow_wait(done + t.src, 1, tid);
+        flow_wait(done + t.src, 1, tid, err);
         if (tid < NB) sx[tid] = flow_ld(x + (size_t)t.src * NB + tid);
     } else {
-        flow_wait(cnt + t.dst, t.count, tid);
+        flow_wait(cnt + t.dst, t.count, tid, err);
         // fold the block's products: four groups of 144 threads take every fourth one (all loads of a thread
         // independent), then the groups are added in a fixed order
         const int g = tid / NB, c = tid - g * NB;
@@ -980,7 +989,7 @@ constexpr int kFwdThreads = 64 * (NB / kFlowRows);   // 8 waves, 512 threads
 
 __global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowTask* __restrict__ tasks, const double* __restrict__ b,
                                                              double* __restrict__ y, double* __restrict__ part,
-                                                             int* __restrict__ cnt, int* __restrict__ done,
+                                                             int* __restrict__ cnt, int* __restrict__ done, int* __restrict__ err,
                                                              const double* __restrict__ fold_b, double* __restrict__ fold_out) {
     __shared__ double sfold[NB / kFlowRows][192];
     const FlowTask t = tasks[blockIdx.x];
@@ -998,12 +1007,12 @@ __global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowTask* __
     }
     double v0, v1, v2 = 0.0;
     if (t.src >= 0) {
-        flow_wait(done + t.src, 1, tid);
+        flow_wait(done + t.src, 1, tid, err);
         const double* __restrict__ ys = y + (size_t)t.src * NB + lane;
         v0 = flow_ld(ys); v1 = flow_ld(ys + 64);
         if (third) v2 = flow_ld(ys + 128);
     } else {
-        flow_wait(cnt + t.dst, t.count, tid);
+        flow_wait(cnt + t.dst, t.count, tid, err);
         // fold the block's products: wave w takes every eighth one (its loads independent), the waves' sums are added
         // in a fixed order
         double f0 = 0.0, f1 = 0.0, f2 = 0.0;
@@ -1338,8 +1347,9 @@ void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const do
                      int nt, hipStream_t s, const double* fold_b, double* fold_out) {
     if (n_tasks <= 0) return;
     (void)hipMemsetAsync(flags, 0, (size_t)2 * nt * sizeof(int), s);   // cnt[nt] | done[nt]
-    if (backward) hipLaunchKernelGGL(k_tri_bwd_flow, dim3(n_tasks), dim3(kBwdThreads), 0, s, tasks, in, out, part, flags, flags + nt);
-    else hipLaunchKernelGGL(k_tri_fwd_flow, dim3(n_tasks), dim3(kFwdThreads), 0, s, tasks, in, out, part, flags, flags + nt, fold_b, fold_out);
+    int* err = flags + 2 * nt;   // (not cleared here: sticky until the plan reads it)
+    if (backward) hipLaunchKernelGGL(k_tri_bwd_flow, dim3(n_tasks), dim3(kBwdThreads), 0, s, tasks, in, out, part, flags, flags + nt, err);
+    else hipLaunchKernelGGL(k_tri_fwd_flow, dim3(n_tasks), dim3(kFwdThreads), 0, s, tasks, in, out, part, flags, flags + nt, err, fold_b, fold_out);
 }
 void launch_sym_tile_products(const SymTile* list, int n, const double* tiles, const double* x, double* part, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_sym_tile_products, dim3(n), dim3(256), 0, s, list, tiles, x, part);

@@ -92,6 +92,7 @@ class TilePlan {
     void enable_graphs(bool on) { use_graphs_ = on; }
     void enable_overlap(bool on) { overlap_ = on; }  // before the first factor()
     void set_overlap_min(int n) { overlap_min_ = n; }
+    hipError_t read_flags(int* failed_at);   // pivot flag + error word of the dataflow sweeps (hipErrorLaunchTimeOut)
     void enable_tri_flow(bool on);   // triangular sweeps as one dataflow launch each (default) or level by level
 
     hipError_t zero_tiles();                             // async on the plan's stream

@@ -504,8 +504,8 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     TP_TRY(upload(&flow_bwd_, bt));
     TP_TRY(alloc_zero(&flow_part_, (size_t)std::max(n_flow_parts_, 1) * kNB));
     if (flow_flags_) { (void)hipFree(flow_flags_); flow_flags_ = nullptr; }
-    TP_TRY(dev_alloc(&flow_flags_, (size_t)2 * nt_));
-    TP_TRY(hipMemset(flow_flags_, 0, (size_t)2 * nt_ * sizeof(int)));
+    TP_TRY(dev_alloc(&flow_flags_, (size_t)2 * nt_ + 1));   // cnt[nt] | done[nt] | error word of the dataflow sweeps
+    TP_TRY(hipMemset(flow_flags_, 0, ((size_t)2 * nt_ + 1) * sizeof(int)));
     TP_TRY(upload(&potrf_tasks_, potrf));
     TP_TRY(upload(&trsm_tasks_, trsm));
     TP_TRY(upload(&upd_tasks_, upd));
@@ -728,22 +728,26 @@ hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
             if (rg[i].second > 0 && !comm_.sum(tiles_ + (size_t)rg[i].first * te, (size_t)rg[i].second * te, stream_)) return hipErrorUnknown;
         factor_phase(1);
         if (!comm_.max_int(flag_, 1, stream_)) return hipErrorUnknown;  // a failed pivot anywhere fails the factorisation everywhere
-        int f = 0;
-        hipError_t e = hipMemcpyAsync(&f, flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
-        if (e != hipSuccess) return e;
-        e = hipStreamSynchronize(stream_);
-        *failed_at = f;
-        return e;
+        return read_flags(failed_at);
     }
     if (!fuse_forward_) { rhs = nullptr; work = nullptr; }
     if (!run_graph(0, rhs, nullptr, work)) enqueue_factor(rhs, work, 0, n_levels_);
     fwd_rhs_ = rhs; fwd_work_ = work;  // the forward sweep for this right-hand side is part of the factorisation
-    int f = 0;
-    hipError_t e = hipMemcpyAsync(&f, flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
+    return read_flags(failed_at);
+}
+
+// The pivot flag of this factorisation and, with the same synchronisation, the error word of the dataflow sweeps (a wait
+// that gave up: reported with the next factorisation, i.e. one solve late).
+hipError_t TilePlan::read_flags(int* failed_at) {
+    int f[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(&f[0], flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
+    if (e == hipSuccess && flow_flags_) e = hipMemcpyAsync(&f[1], flow_flags_ + 2 * (size_t)nt_, sizeof(int), hipMemcpyDeviceToHost, stream_);
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(stream_);
-    *failed_at = f;
-    return e;
+    *failed_at = f[0];
+    if (e != hipSuccess || f[1] == 0) return e;
+    (void)hipMemsetAsync(flow_flags_ + 2 * (size_t)nt_, 0, sizeof(int), stream_);
+    return hipErrorLaunchTimeOut;
 }
 
 hipError_t TilePlan::solve(const double* rhs, double* x, double* work) {
