@@ -983,86 +983,90 @@ __global__ __launch_bounds__(kBwdThreads) void k_tri_bwd_flow(const FlowTask* __
     flow_publish(t.src >= 0 ? cnt + t.dst : done + t.dst, tid);
 }
 
-// forward (plain products): 8 waves x 18 rows; a lane holds columns lane, lane + 64, lane + 128 of its wave's rows
-// (coalesced 8-byte loads); the row sums are folded over the lanes
-constexpr int kFwdThreads = 64 * (NB / kFlowRows);   // 8 waves, 512 threads
+// Sum over the 16 lanes of a DPP row on the VALU (result in lane 15 of the row).  The generic __shfl_xor butterfly goes
+// through the LDS crossbar (two ds_bpermute per double and step); with one row sum per lane and matrix row it was a
+// third of the forward sweep.
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum_lane15(double v) {
+    v = dpp_add<0x111>(v);   // row_shr:1
+    v = dpp_add<0x112>(v);   // row_shr:2
+    v = dpp_add<0x114>(v);   // row_shr:4
+    v = dpp_add<0x118>(v);   // row_shr:8
+    return v;
+}
+
+// forward (plain products): 9 waves x 16 matrix rows; lane = (row group rg, column lane cl): rows 16 w + 4 rg + 0..3,
+// columns cl, cl + 16, ..., cl + 128.  A load instruction covers four 128-byte row segments; a row sum is folded over the
+// 16 lanes of a DPP row only (four shifts), four sums per lane.
+constexpr int kFwdThreads = 576, kFwdRows = 4, kFwdCols = NB / 16;   // 9 columns per lane
 
 __global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowTask* __restrict__ tasks, const double* __restrict__ b,
                                                              double* __restrict__ y, double* __restrict__ part,
                                                              int* __restrict__ cnt, int* __restrict__ done, int* __restrict__ err,
                                                              const double* __restrict__ fold_b, double* __restrict__ fold_out) {
-    __shared__ double sfold[NB / kFlowRows][192];
+    __shared__ double sx[NB];
+    __shared__ double spart[4][NB];
     const FlowTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r0 = w * kFlowRows;
-    const bool third = lane < NB - 128;
-    double m[kFlowRows][3];
+    const int rg = lane >> 4, cl = lane & 15;
+    const int row0 = 16 * w + kFwdRows * rg;
+    double m[kFwdRows][kFwdCols];
     {
-        const double* __restrict__ M = t.mat + (size_t)r0 * NB + lane;
+        const double* __restrict__ M = t.mat + (size_t)row0 * NB + cl;   // L resp. Linv is final: in flight during the wait
 #pragma unroll
-        for (int r = 0; r < kFlowRows; ++r) {
-            const double* row = M + (size_t)r * NB;
-            m[r][0] = row[0]; m[r][1] = row[64]; m[r][2] = third ? row[128] : 0.0;
-        }
+        for (int rr = 0; rr < kFwdRows; ++rr)
+#pragma unroll
+            for (int k = 0; k < kFwdCols; ++k) m[rr][k] = M[(size_t)rr * NB + 16 * k];
     }
-    double v0, v1, v2 = 0.0;
     if (t.src >= 0) {
         flow_wait(done + t.src, 1, tid, err);
-        const double* __restrict__ ys = y + (size_t)t.src * NB + lane;
-        v0 = flow_ld(ys); v1 = flow_ld(ys + 64);
-        if (third) v2 = flow_ld(ys + 128);
+        if (tid < NB) sx[tid] = flow_ld(y + (size_t)t.src * NB + tid);
     } else {
         flow_wait(cnt + t.dst, t.count, tid, err);
-        // fold the block's products: wave w takes every eighth one (its loads independent), the waves' sums are added
-        // in a fixed order
-        double f0 = 0.0, f1 = 0.0, f2 = 0.0;
-        const double* __restrict__ pp = part + (size_t)t.part * NB + lane;
-        int q = w;
-        for (; q + 8 < t.count; q += 16) {
-            const double* pa = pp + (size_t)q * NB;
-            const double* pb = pa + (size_t)8 * NB;
-            const double a0 = flow_ld(pa), a1 = flow_ld(pa + 64), b0 = flow_ld(pb), b1 = flow_ld(pb + 64);
-            double a2 = 0.0, b2 = 0.0;
-            if (third) { a2 = flow_ld(pa + 128); b2 = flow_ld(pb + 128); }
-            f0 += a0 + b0; f1 += a1 + b1; f2 += a2 + b2;
-        }
-        for (; q < t.count; q += 8) {
-            const double* pa = pp + (size_t)q * NB;
-            f0 += flow_ld(pa); f1 += flow_ld(pa + 64);
-            if (third) f2 += flow_ld(pa + 128);
-        }
-        sfold[w][lane] = f0; sfold[w][lane + 64] = f1; sfold[w][lane + 128] = f2;
-        __syncthreads();
-        const double* __restrict__ bsrc = t.src == -2 ? fold_b : b;
-        v0 = 0.0; v1 = 0.0;
-        if (bsrc) {
-            const double* __restrict__ bs = bsrc + (size_t)t.dst * NB + lane;
-            v0 = bs[0]; v1 = bs[64];
-            if (third) v2 = bs[128];
-        }
-#pragma unroll
-        for (int u = 0; u < NB / kFlowRows; ++u) { v0 -= sfold[u][lane]; v1 -= sfold[u][lane + 64]; v2 -= sfold[u][lane + 128]; }
-        if (t.src == -2) {   // fold only: this rank's share of a shared top block of the right-hand side, no solve, no flag
-            if (w == 0) {
-                double* __restrict__ o = fold_out + (size_t)t.dst * NB + lane;
-                o[0] = v0; o[64] = v1;
-                if (third) o[128] = v2;
+        // fold the block's products: four groups of 144 threads take every fourth one (all loads of a thread
+        // independent), then the groups are added in a fixed order
+        const int g = tid / NB, c = tid - g * NB;
+        double v = 0.0;
+        {
+            const double* __restrict__ pp = part + (size_t)t.part * NB + c;
+            int q = g;
+            for (; q + 12 < t.count; q += 16) {
+                const double p0 = flow_ld(pp + (size_t)q * NB), p1 = flow_ld(pp + (size_t)(q + 4) * NB);
+                const double p2 = flow_ld(pp + (size_t)(q + 8) * NB), p3 = flow_ld(pp + (size_t)(q + 12) * NB);
+                v += (p0 + p1) + (p2 + p3);
             }
-            return;
+            for (; q < t.count; q += 4) v += flow_ld(pp + (size_t)q * NB);
         }
+        spart[g][c] = v;
+        __syncthreads();
+        if (tid < NB) {
+            const double* __restrict__ bsrc = t.src == -2 ? fold_b : b;
+            const double rhs = bsrc ? bsrc[(size_t)t.dst * NB + tid] : 0.0;
+            const double val = rhs - ((spart[0][tid] + spart[1][tid]) + (spart[2][tid] + spart[3][tid]));
+            if (t.src == -2) fold_out[(size_t)t.dst * NB + tid] = val;   // fold only: this rank's share of a shared top
+            else sx[tid] = val;                                         // block of the right-hand side (no solve, no flag)
+        }
+        if (t.src == -2) return;
     }
-    double acc[kFlowRows];
+    __syncthreads();
+    double acc[kFwdRows] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = 0; r < kFlowRows; ++r) acc[r] = fma(m[r][2], v2, fma(m[r][1], v1, m[r][0] * v0));
+    for (int k = 0; k < kFwdCols; ++k) {
+        const double xv = sx[cl + 16 * k];
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1)
+        for (int rr = 0; rr < kFwdRows; ++rr) acc[rr] = fma(m[rr][k], xv, acc[rr]);
+    }
 #pragma unroll
-        for (int r = 0; r < kFlowRows; ++r) acc[r] += __shfl_xor(acc[r], s, 64);
-    double mine = 0.0;
+    for (int rr = 0; rr < kFwdRows; ++rr) acc[rr] = row16_sum_lane15(acc[rr]);
+    if (cl == 15) {
+        double* __restrict__ o = (t.src >= 0 ? part + (size_t)t.part * NB : y + (size_t)t.dst * NB) + row0;
 #pragma unroll
-    for (int r = 0; r < kFlowRows; ++r) mine = lane == r ? acc[r] : mine;
-    if (lane < kFlowRows) {
-        flow_st(t.src >= 0 ? part + (size_t)t.part * NB + r0 + lane : y + (size_t)t.dst * NB + r0 + lane, mine);
+        for (int rr = 0; rr < kFwdRows; ++rr) flow_st(o + rr, acc[rr]);
     }
     flow_publish(t.src >= 0 ? cnt + t.dst : done + t.dst, tid);
 }
