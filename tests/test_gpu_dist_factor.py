@@ -143,3 +143,37 @@ def test_distributed_schedule_on_one_rank_equals_the_plain_schedule(world):
     assert rel(s.solve_augmented_equation(lam), step) < 1e-9
     for x in (s, s1):
         x.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_lockstep_on_a_forest_with_a_partial_last_tile(world):
+    """Two disconnected captures (the elimination tree is a forest) and 9 n_cam not a multiple of 144: the last tile column
+    is a subtree root below the shared top, owned by some rank q; the identity on its padding rows must sit on rank q's
+    copy -- the only one that is ever factorised (with the identity on rank 0 only, rank q met zero pivots)."""
+    a = pkg.synthetic.make_problem(1408, 24000, 3, 7, config_id=321)           # 88 whole tiles
+    b = pkg.synthetic.make_problem(41, 800, 3, 7, config_id=322, window=16)    # a second, small capture: tiles 88 .. 90
+    d = pkg.synthetic.BAProblemData(
+        poses=np.concatenate([a.poses, b.poses]), intr=np.concatenate([a.intr, b.intr]), points=np.concatenate([a.points, b.points]),
+        cam_idx=np.concatenate([a.cam_idx, b.cam_idx + a.n_cam]), pt_idx=np.concatenate([a.pt_idx, b.pt_idx + a.n_pt]),
+        obs_uv=np.concatenate([a.obs_uv, b.obs_uv]), truth_poses=np.concatenate([a.truth_poses, b.truth_poses]),
+        truth_intr=np.concatenate([a.truth_intr, b.truth_intr]), truth_points=np.concatenate([a.truth_points, b.truth_points]),
+        name="two-captures")
+    assert (9 * d.n_cam) % 144 != 0
+    hs = pkg.capi.host_structure(d.n_cam, d.n_pt, d.cam_idx, d.pt_idx, rank=0, world=world)
+    assert hs["tile_owner"][-1] > 0, "the last tile column must belong to a rank other than 0 for this test to bite"
+    lam = 1e-3
+    prob, s1, step1, gred = single_rank_reference(d, "selfcal", lam)
+    ranks = lockstep(d, "selfcal", world, lam)
+    infos = [s.info() for s in ranks]
+    print("world", world, "top columns", infos[0]["dist_top_columns"], "local fractions", [round(i["dist_local_fraction"], 3) for i in infos],
+          "tree sharded", [i["tree_sharded"] for i in infos])
+    nc = prob.layout.cam_dof
+    steps = [s.export_step()[0] for s in ranks]
+    for r in range(1, world):
+        assert np.array_equal(steps[r][:nc], steps[0][:nc])
+    Sx, _ = s1.schur_matvec(lam, steps[0][:nc], implicit=False)
+    r_dist = np.linalg.norm(Sx - gred) / np.linalg.norm(gred)
+    print("residual", r_dist, "step difference", rel(steps[0][:nc], step1[:nc]))
+    assert r_dist < 1e-12 and rel(steps[0][:nc], step1[:nc]) < 1e-7
+    for s in ranks + [s1]:
+        s.close()

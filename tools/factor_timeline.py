@@ -6,7 +6,7 @@ ev = []
 for r in rows:
     n = r["Kernel_Name"]
     short = ("potrf" if "potrf" in n else "gemm_small_strip" if "small_strip" in n else "gemm_small" if "gemm_nt_small" in n else
-             "gemm" if "tile_gemm_nt" in n else "rows" if "schur_rows" in n else "tri" if "tri_step" in n else None)
+             "gemm" if "tile_gemm_nt" in n else "rows" if ("schur_rows" in n or "schur_pairs" in n) else "tri" if ("tri_step" in n or "tri_fwd_flow" in n) else None)
     if short:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short, int(r["Queue_Id"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)))
 ev.sort()
