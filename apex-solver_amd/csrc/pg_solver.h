@@ -52,6 +52,7 @@ class PoseGraphSolver : public LmBackend {
     void enable_graphs(bool on) { tp_.enable_graphs(on); }
     void enable_overlap(bool on) { tp_.enable_overlap(on); }
     void enable_tri_flow(bool on) { tp_.enable_tri_flow(on); }
+    void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }

@@ -92,6 +92,7 @@ class TilePlan {
     void enable_graphs(bool on) { use_graphs_ = on; }
     void enable_overlap(bool on) { overlap_ = on; }  // before the first factor()
     void set_overlap_min(int n) { overlap_min_ = n; }
+    void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
     hipError_t read_flags(int* failed_at);   // pivot flag + error word of the dataflow sweeps (hipErrorLaunchTimeOut)
     void enable_tri_flow(bool on);   // triangular sweeps as one dataflow launch each (default) or level by level
 
@@ -138,11 +139,14 @@ class TilePlan {
     int64_t n_potrf_ = 0, n_trsm_ = 0, n_upd_ = 0;
     hipStream_t stream_ = nullptr;
     std::vector<int> slot_h_, diag_slot_h_;
-    std::vector<int> lv_potrf_, lv_trsm_, lv_fwd_, lv_bwd_, lv_upd_round_, lv_upd_split_;
+    std::vector<int> lv_potrf_, lv_trsm_, lv_fwd_, lv_bwd_, lv_upd_round_, lv_upd_split_, lv_upd_splitd_;
     std::vector<std::vector<int>> fwd_cut_;  // per group: first forward task of each column that gets its own launch
     hipStream_t side_ = nullptr;  // trailing updates that the next level does not need (enqueue_factor)
-    std::vector<hipEvent_t> ev_t_, ev_u2_;
-    std::vector<bool> u2_pending_;
+    hipStream_t so_ = nullptr;    // U1o: updates of the next level's off-diagonal tiles, beside its potrf
+    std::vector<hipEvent_t> ev_t_, ev_u2_, ev_o_;
+    std::vector<bool> u2_pending_, o_pending_;
+    bool split_u1_ = true;
+    int split_u1_min_ = 24;
     bool overlap_ = true;
     int overlap_min_ = 2;   // U2 batches smaller than this stay on the main stream (swept 1..1024: flat up to 64)
     std::vector<std::pair<int64_t, int64_t>> upd_rounds_;

@@ -112,12 +112,14 @@ void TilePlan::release() {
     if (ev_fwd_) { (void)hipEventDestroy(ev_fwd_); ev_fwd_ = nullptr; }
     for (hipEvent_t e : ev_t_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_u2_) (void)hipEventDestroy(e);
-    ev_t_.clear(); ev_u2_.clear();
+    for (hipEvent_t e : ev_o_) (void)hipEventDestroy(e);
+    ev_t_.clear(); ev_u2_.clear(); ev_o_.clear();
 }
 
 TilePlan::~TilePlan() {
     release();
     if (side_) (void)hipStreamDestroy(side_);
+    if (so_) { (void)hipStreamDestroy(so_); so_ = nullptr; }
     if (fwd_) (void)hipStreamDestroy(fwd_);
 }
 
@@ -351,6 +353,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     fwd_cut_.assign(n_levels_, std::vector<int>());
     lv_upd_round_.assign(n_levels_ + 1, 0);
     lv_upd_split_.assign(n_levels_ + 1, 0);
+    lv_upd_splitd_.assign(n_levels_ + 1, 0);
     upd_rounds_.clear();
     upd.reserve(n_upd);
     for (int lv = 0; lv < n_levels_; ++lv) {
@@ -375,14 +378,17 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
                     us.push_back({(int64_t)rows[a] * nt_ + rows[b], K, {tile_ptr(rows[a], rows[b]), tile_ptr(rows[a], K), tile_ptr(rows[b], K)}});
         }
         std::stable_sort(us.begin(), us.end(), [](const U& x, const U& y) { return x.key < y.key; });
-        // U1: targets in a column of the NEXT level (needed by its potrf / panel solves right away);
+        // U1d: targets = DIAGONAL tiles of the next level's columns (what its potrf needs);
+        // U1o: the other tiles of the next level's columns (what its panel solves need) -- on a third stream, beside the
+        //      next potrf;
         // U2: targets further up the tree -- these run on the side stream, overlapped with the next
         // level's potrf and panel solves (see enqueue_factor)
-        for (int part = 0; part < 2; ++part) {
+        for (int part = 0; part < 3; ++part) {
             std::vector<const U*> mine;
             for (const U& u : us) {
-                const int tcol = (int)(u.key % nt_);
-                if ((group_of[tcol] == lv + 1) == (part == 0)) mine.push_back(&u);
+                const int tcol = (int)(u.key % nt_), trow = (int)(u.key / nt_);
+                const int cls = group_of[tcol] == lv + 1 ? (trow == tcol ? 0 : 1) : 2;
+                if (cls == part) mine.push_back(&u);
             }
             std::vector<int> round(mine.size(), 0);
             int n_rounds = 0;
@@ -400,7 +406,8 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
                 for (const U* u : sel) upd.push_back(u->t);
                 upd_rounds_.push_back({off, (int64_t)upd.size() - off});
             }
-            if (part == 0) lv_upd_split_[lv] = (int)upd_rounds_.size();
+            if (part == 0) lv_upd_splitd_[lv] = (int)upd_rounds_.size();
+            if (part == 1) lv_upd_split_[lv] = (int)upd_rounds_.size();
         }
         lv_potrf_[lv + 1] = (int)potrf.size();
         lv_trsm_[lv + 1] = (int)trsm.size();
@@ -516,13 +523,16 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     // (a lowest-priority side stream was tried: no gain without graphs, +2.7 ms with them)
     // (and so was a CU-masked one that leaves 1 CU in 8 / 4 / 2 to the critical path: the same, either way)
     if (!side_) TP_TRY(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    if (!so_) TP_TRY(hipStreamCreateWithFlags(&so_, hipStreamNonBlocking));
     if (!fwd_) TP_TRY(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
     TP_TRY(hipEventCreateWithFlags(&ev_fwd_, hipEventDisableTiming));
-    ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_);
+    ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_); ev_o_.resize(n_levels_);
     u2_pending_.assign(n_levels_, false);
+    o_pending_.assign(n_levels_, false);
     for (int i = 0; i < n_levels_; ++i) {
         TP_TRY(hipEventCreateWithFlags(&ev_t_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_u2_[i], hipEventDisableTiming));
+        TP_TRY(hipEventCreateWithFlags(&ev_o_[i], hipEventDisableTiming));
     }
     TP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on the stream
 #undef TP_TRY
@@ -561,12 +571,14 @@ void TilePlan::launch_fwd_group(int lv, double* bvec, double* yvec, hipStream_t 
 // they are captured once into hipGraphs (a few hundred dependent launches would otherwise be paced by
 // host launch overhead) and replayed every iteration.
 void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
-    // Two streams.  Main: potrf(lv), panel solves(lv), U1(lv) = the updates the next level needs.
-    // Side: U2(lv) = every other update of level lv, overlapped with potrf / panel solves of level lv+1
-    // (one workgroup resp. a few dozen: they leave the chip nearly empty).  Ordering that keeps every
-    // tile's read-modify-write sequence race free:
-    //   U2(lv) after the panel solves of lv;  U1(lv) after U2(lv-1) (both may hit columns of level lv+1);
-    //   potrf(lv) after U1(lv-1) [stream order] and U2(<= lv-2) [main already waited for it before U1(lv-1)].
+    // Three streams.  Main: potrf(lv), panel solves(lv), U1d(lv) = the updates of the next level's DIAGONAL tiles (all
+    // its potrf needs).  Third: U1o(lv) = the updates of the other tiles of the next level's columns, beside that
+    // potrf; the next panel solves wait for them.  Side: U2(lv) = every other update of level lv, overlapped with
+    // potrf / panel solves of level lv+1 (one workgroup resp. a few dozen: they leave the chip nearly empty).
+    // Ordering that keeps every tile's read-modify-write sequence race free:
+    //   U2(lv) after the panel solves of lv;  U1d(lv), U1o(lv) after U2(lv-1) (all may hit columns of level lv+1);
+    //   potrf(lv) after U1d(lv-1) [stream order] and U2(<= lv-2) [main already waited for it before U1d(lv-1)];
+    //   panel(lv) after U1o(lv-1) [event];  U1o(lv) and U2(lv) hit different columns (level lv+1 / above).
     const bool two = overlap_ && side_ != nullptr && n_levels_ > 2;
     // Forward substitution L y = rhs fused into the factorisation (when the right-hand side is known now): the
     // step of level lv needs only that level's L^-1 and panel tiles, which are final after its panel solves, so it
@@ -578,27 +590,41 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     if (fwd) (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
     for (int lv = g0; lv < g1; ++lv) {
         launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flag_, stream_);
+        // the panel solves work on the off-diagonal tiles of this level's columns: U1o of the level below must be in
+        if (lv > g0 && o_pending_[lv - 1]) (void)hipStreamWaitEvent(stream_, ev_o_[lv - 1], 0);
         launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_);
-        const int r0 = lv_upd_round_[lv], rs = lv_upd_split_[lv], r1 = lv_upd_round_[lv + 1];
-        int64_t n_u2 = 0;
+        const int r0 = lv_upd_round_[lv], rd = lv_upd_splitd_[lv], rs = lv_upd_split_[lv], r1 = lv_upd_round_[lv + 1];
+        int64_t n_u2 = 0, n_o = 0;
         for (int r = rs; r < r1; ++r) n_u2 += upd_rounds_[r].second;
-        // a cross-stream edge costs a few microseconds in the graph: only worth it when U2 is a real batch
+        for (int r = rd; r < rs; ++r) n_o += upd_rounds_[r].second;
+        // a cross-stream edge costs a few microseconds in the graph: only worth it when the batch is a real one
         const bool has_u2 = two && n_u2 >= overlap_min_;
-        if (has_u2 || fwd) (void)hipEventRecord(ev_t_[lv], stream_);
+        const bool has_o = two && so_ != nullptr && split_u1_ && n_o >= split_u1_min_;
+        if (has_u2 || fwd || has_o) (void)hipEventRecord(ev_t_[lv], stream_);
         if (has_u2) (void)hipStreamWaitEvent(side_, ev_t_[lv], 0);
+        if (has_o) (void)hipStreamWaitEvent(so_, ev_t_[lv], 0);
         if (fwd) {
             (void)hipStreamWaitEvent(fwd_, ev_t_[lv], 0);
             launch_fwd_group(lv, bvec, yvec, fwd_);
         }
-        if (two && lv > g0 && u2_pending_[lv - 1]) (void)hipStreamWaitEvent(stream_, ev_u2_[lv - 1], 0);
-        for (int r = r0; r < rs; ++r)
+        if (two && lv > g0 && u2_pending_[lv - 1]) {
+            (void)hipStreamWaitEvent(stream_, ev_u2_[lv - 1], 0);
+            if (has_o) (void)hipStreamWaitEvent(so_, ev_u2_[lv - 1], 0);
+        }
+        for (int r = r0; r < rd; ++r)   // U1d: what the next potrf needs
             launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, stream_);
+        hipStream_t s1 = has_o ? so_ : stream_;
+        for (int r = rd; r < rs; ++r)   // U1o: what the next panel solves need, beside the next potrf
+            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s1);
+        o_pending_[lv] = has_o;
+        if (has_o) (void)hipEventRecord(ev_o_[lv], so_);
         hipStream_t s2 = has_u2 ? side_ : stream_;
         for (int r = rs; r < r1; ++r)
             launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s2);
         u2_pending_[lv] = has_u2;
         if (has_u2) (void)hipEventRecord(ev_u2_[lv], side_);
     }
+    if (g1 > g0 && o_pending_[g1 - 1]) (void)hipStreamWaitEvent(stream_, ev_o_[g1 - 1], 0);
     if (two)  // join: the last side-stream work precedes whatever follows on the main stream
         for (int lv = g1 - 1; lv >= g0; --lv)
             if (u2_pending_[lv]) { (void)hipStreamWaitEvent(stream_, ev_u2_[lv], 0); break; }

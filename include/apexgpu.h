@@ -212,7 +212,7 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
 
 /* Implementation switches (defaults in parentheses), for A/B tests and profiling:
  * Switches that shape what apexgpu_set_structure builds or what the captured hipGraphs hold ("schur_rows",
- * "potrf_lookahead", "update_overlap", "fused_forward", "nested_dissection", "dist_factor", "tree_sharding",
+ * "potrf_lookahead", "update_overlap", "split_u1", "fused_forward", "nested_dissection", "dist_factor", "tree_sharding",
  * "dist_selftest") return APEXGPU_ERR_INVALID_STATE once the structure is set.
  *   "schur_rows" (3)  form of the Schur reduction (alias "schur_form"); set before set_structure:
  *                     3 = every camera pair of a landmark in a list sorted by the block S(ci, cj) it adds to, one pair per
@@ -224,6 +224,9 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
  *   "update_overlap" (1)  run the trailing updates the next elimination level does not need on a second
  *                     stream, overlapped with that level's potrf / panel solves (before the first solve)
+ *   "split_u1" (24)   the updates a level sends into the NEXT level's columns are split: those of its diagonal tiles stay on
+ *                     the main stream (the next potrf needs nothing else), the others run on a third stream beside that
+ *                     potrf when they are at least this many tasks; 0 = one batch on the main stream (before set_structure)
  *   "potrf_lookahead" (8)  diagonal-tile Cholesky + inverse: 8 / 6 / 1 = look-ahead schedule with 8 / 6 / 4 waves
  *                     per workgroup, 0 = the schedule without look-ahead
  *   "fused_forward" (0)  run the forward triangular sweep inside the factorisation graph on a third stream
