@@ -48,7 +48,7 @@ constexpr double kMaskAll = 7.0;
 // slightly non-unit after a compose); normalised twice like from_translation_quaternion.
 APEX_HD void quat_to_rot(const double q[4], double R[9]);
 
-APEX_HD void load_cam(const double* __restrict__ pose7, const double* __restrict__ intr3, Cam& c) {
+APEX_HD void load_cam(const double* __restrict__ pose7, const double* __restrict__ intr3, Cam& c, double* qn_out = nullptr) {
     c.t[0] = pose7[0]; c.t[1] = pose7[1]; c.t[2] = pose7[2];
     double w = pose7[3], x = pose7[4], y = pose7[5], z = pose7[6];
 #pragma unroll
@@ -59,6 +59,25 @@ APEX_HD void load_cam(const double* __restrict__ pose7, const double* __restrict
     const double q[4] = {w, x, y, z};
     quat_to_rot(q, c.R);
     c.f = intr3[0]; c.k1 = intr3[1]; c.k2 = intr3[2];
+    if (qn_out) { qn_out[0] = w; qn_out[1] = x; qn_out[2] = y; qn_out[3] = z; }
+}
+
+// The compact form of a prepared camera for the kernels that gather one camera PER LANE (the landmark-major ones):
+// normalised quaternion (4) t (3) f k1 k2 = 80 bytes = five 16-byte loads instead of eight.  Those kernels are bound by
+// the bytes their lanes pull through the L1 (128 of the ~150-220 bytes per observation were the camera); rebuilding R
+// from the stored quaternion is the same quat_to_rot call on the same numbers as k_prepare_cams makes.
+constexpr int kCamQStride = 10;
+APEX_HD void store_cam_q(const double qn[4], const Cam& c, double* __restrict__ o) {
+    o[0] = qn[0]; o[1] = qn[1]; o[2] = qn[2]; o[3] = qn[3];
+    o[4] = c.t[0]; o[5] = c.t[1]; o[6] = c.t[2];
+    o[7] = c.f; o[8] = c.k1; o[9] = c.k2;
+}
+APEX_HD void load_cam_q(const double* __restrict__ p, int mask_code, Cam& c) {
+    const double q[4] = {p[0], p[1], p[2], p[3]};
+    quat_to_rot(q, c.R);
+    c.t[0] = p[4]; c.t[1] = p[5]; c.t[2] = p[6];
+    c.f = p[7]; c.k1 = p[8]; c.k2 = p[9];
+    c.m_pose = (mask_code & 4) ? 1.0 : 0.0; c.m_lm = (mask_code & 2) ? 1.0 : 0.0; c.m_intr = (mask_code & 1) ? 1.0 : 0.0;
 }
 
 APEX_HD void store_cam_prepared(const Cam& c, double* __restrict__ o) {
@@ -104,6 +123,12 @@ APEX_HD void quat_rotate(const double q[4], const double v[3], double o[3]) {
 }
 
 APEX_HD void quat_to_rot(const double q[4], double R[9]) {
+    // No FMA contraction here: k_prepare_cams and the kernels that rebuild R from the compact camera (load_cam_q) must
+    // produce the SAME bits -- a last-bit difference between the R behind g_l and the R behind W is amplified by
+    // cond(S) in the step (measured: 5e-8 -> 6e-7 against the oracle).
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     double w = q[0], i = q[1], j = q[2], k = q[3];
     double ww = w * w, ii = i * i, jj = j * j, kk = k * k;
     double ij = i * j * 2.0, wk = w * k * 2.0, wj = w * j * 2.0;

@@ -13,6 +13,7 @@ constexpr int kScatterBlk = 64;   // block size used to split landmarks with mor
 struct BAView {
     int64_t n_cam, n_pt, n_obs;
     const double* camp;    // [n_cam][16] prepared cameras (R t f k1 k2), see k_prepare_cams
+    const double* camq;    // [n_cam][10] the same cameras as (unit quaternion, t, f k1 k2): per-lane gathers (ba_device.hpp)
     const double* pts;     // [n_pt][3]
     const uint32_t* o_cam; // [n_obs] landmark-major
     const uint32_t* o_pt;  // [n_obs]

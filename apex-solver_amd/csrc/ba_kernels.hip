@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
             const uint32_t c = v.o_cam[i];
             const double2 uv = v.o_uv[i];
             Cam cam;
-            load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
+            load_cam_q(v.camq + kCamQStride * (size_t)c, v.mask_code, cam);
             double r[2], Jc[2][DC], Jl[2][3];
             linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
             h[0] += Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0];
@@ -377,9 +377,11 @@ __global__ __launch_bounds__(256) void k_prepare_cams(int64_t n_cam, const doubl
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= n_cam) return;
     Cam cam;
-    load_cam(poses + 7 * c, intr + 3 * c, cam);
+    double qn[4];
+    load_cam(poses + 7 * c, intr + 3 * c, cam, qn);
     cam.m_pose = (mask_code & 4) ? 1.0 : 0.0; cam.m_lm = (mask_code & 2) ? 1.0 : 0.0; cam.m_intr = (mask_code & 1) ? 1.0 : 0.0;
     store_cam_prepared(cam, camp + kCamStride * c);
+    store_cam_q(qn, cam, camp + kCamStride * n_cam + kCamQStride * c);   // the compact copy follows the 16-double records
 }
 
 // ------------------------------------------------------------------------------------------
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(256) void k_back_substitute(BAView v, const double*
             const uint32_t c = v.o_cam[i];
             const double2 uv = v.o_uv[i];
             Cam cam;
-            load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
+            load_cam_q(v.camq + kCamQStride * (size_t)c, v.mask_code, cam);
             double r[2], Jc[2][DC], Jl[2][3];
             linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
             double s0 = 0.0, s1 = 0.0;
@@ -920,7 +922,7 @@ __global__ __launch_bounds__(256) void k_cost_partial(BAView v, double* __restri
         const uint32_t c = v.o_cam[i], l = v.o_pt[i];
         const double2 uv = v.o_uv[i];
         Cam cam;
-        load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
+        load_cam_q(v.camq + kCamQStride * (size_t)c, v.mask_code, cam);
         const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
         double r[2];
         residual_obs(cam, pw, uv.x, uv.y, v.huber_delta, r);

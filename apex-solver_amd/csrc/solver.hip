@@ -76,7 +76,7 @@ int Solver::check_hip(hipError_t e, const char* what) {
 BAView Solver::view(int which) const {
     BAView v;
     v.n_cam = n_cam_; v.n_pt = n_pt_; v.n_obs = (int64_t)o_orig_h_.size();
-    v.camp = camp_[which]; v.pts = pts_[which];
+    v.camp = camp_[which]; v.camq = camp_[which] + (size_t)kCamStride * n_cam_; v.pts = pts_[which];
     v.o_cam = o_cam_; v.o_pt = o_pt_; v.o_uv = o_uv_; v.pt_ptr = pt_ptr_;
     v.huber_delta = huber_delta_;
     v.mask_code = mode_mask(mode_);
@@ -286,7 +286,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         HIP_TRY(alloc(&poses_[w], 7 * n_cam_));
         HIP_TRY(alloc(&intr_[w], 3 * n_cam_));
         HIP_TRY(alloc(&pts_[w], 3 * n_pt_));
-        HIP_TRY(alloc(&camp_[w], (size_t)kCamStride * n_cam_));
+        HIP_TRY(alloc(&camp_[w], (size_t)(kCamStride + kCamQStride) * n_cam_));   // [n_cam][16] records | [n_cam][10] compact form
     }
     HIP_TRY(alloc(&g_c_, n_c_pad_));
     HIP_TRY(alloc(&g_red_, n_c_pad_));
