@@ -99,10 +99,21 @@ APEX_HD void load_cam_prepared(const double* __restrict__ p, Cam& c) {
 
 // p_cam = R p_w + t  (SE3::act, se3.rs:322-328; the reference rotates with the quaternion, this is
 // the same rotation through its matrix)
+// The per-observation arithmetic below is written with EXPLICIT fma and compiled without further contraction: every
+// kernel that linearises an observation must produce the SAME bits for r and J.  Left to the compiler, which of
+// a*b + c*d becomes the fma depends on the surrounding code, g_l (k_landmark_reduce) and W (k_cam_reduce) then come from
+// Jacobians that differ in the last bit, and cond(S) ~ 1e9 turns that into 1e-7 in the step (seen twice while
+// restructuring kernels: the step moved from 5e-8 to 2e-7 against the oracle with bit-identical inputs).
+#if defined(__clang__)
+#define APEX_FP_EXACT _Pragma("clang fp contract(off)")
+#else
+#define APEX_FP_EXACT
+#endif
 APEX_HD void cam_transform(const Cam& c, const double pw[3], double pc[3]) {
-    pc[0] = c.R[0] * pw[0] + c.R[1] * pw[1] + c.R[2] * pw[2] + c.t[0];
-    pc[1] = c.R[3] * pw[0] + c.R[4] * pw[1] + c.R[5] * pw[2] + c.t[1];
-    pc[2] = c.R[6] * pw[0] + c.R[7] * pw[1] + c.R[8] * pw[2] + c.t[2];
+    APEX_FP_EXACT
+    pc[0] = fma(c.R[0], pw[0], fma(c.R[1], pw[1], fma(c.R[2], pw[2], c.t[0])));
+    pc[1] = fma(c.R[3], pw[0], fma(c.R[4], pw[1], fma(c.R[5], pw[2], c.t[1])));
+    pc[2] = fma(c.R[6], pw[0], fma(c.R[7], pw[1], fma(c.R[8], pw[2], c.t[2])));
 }
 
 APEX_HD void cross3(const double a[3], const double b[3], double o[3]) {
@@ -186,16 +197,17 @@ APEX_HD double huber_sqrt_rho1(double delta, double s) {
 // Residual only (A16).  Returns validity; r is the CORRECTED residual.
 APEX_HD bool residual_obs(const Cam& c, const double pw[3], double u_obs, double v_obs,
                           double huber_delta, double r[2]) {
+    APEX_FP_EXACT
     double pc[3];
     cam_transform(c, pw, pc);
     if (!(pc[2] < -kMinDepth)) { r[0] = 0.0; r[1] = 0.0; return false; }
     double inz = -apex_rcp(pc[2]);
     double xn = pc[0] * inz, yn = pc[1] * inz;
-    double r2 = xn * xn + yn * yn, r4 = r2 * r2;
-    double d = 1.0 + c.k1 * r2 + c.k2 * r4;
-    double r0 = c.f * (xn * d) - u_obs;
-    double r1 = c.f * (yn * d) - v_obs;
-    double w = huber_sqrt_rho1(huber_delta, r0 * r0 + r1 * r1);
+    double r2 = fma(xn, xn, yn * yn), r4 = r2 * r2;
+    double d = fma(c.k2, r4, fma(c.k1, r2, 1.0));
+    double r0 = fma(c.f, xn * d, -u_obs);
+    double r1 = fma(c.f, yn * d, -v_obs);
+    double w = huber_sqrt_rho1(huber_delta, fma(r0, r0, r1 * r1));
     r[0] = r0 * w; r[1] = r1 * w;
     return true;
 }
@@ -208,6 +220,7 @@ APEX_HD bool residual_obs(const Cam& c, const double pw[3], double u_obs, double
 template <int DC, bool MASKED = true>
 APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, double v_obs,
                            double huber_delta, double r[2], double Jc[2][DC], double Jl[2][3]) {
+    APEX_FP_EXACT
     double pc[3];
     cam_transform(c, pw, pc);
     if (!(pc[2] < -kMinDepth)) {
@@ -221,39 +234,40 @@ APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, doubl
     const double f = c.f, k1 = c.k1, k2 = c.k2;
     double inz = -apex_rcp(pc[2]);
     double xn = pc[0] * inz, yn = pc[1] * inz;
-    double r2 = xn * xn + yn * yn, r4 = r2 * r2;
-    double dist = 1.0 + k1 * r2 + k2 * r4;
-    double r0 = f * (xn * dist) - u_obs;
-    double r1 = f * (yn * dist) - v_obs;
+    double r2 = fma(xn, xn, yn * yn), r4 = r2 * r2;
+    double dist = fma(k2, r4, fma(k1, r2, 1.0));
+    double r0 = fma(f, xn * dist, -u_obs);
+    double r1 = fma(f, yn * dist, -v_obs);
     // d(u,v)/d p_cam  (bal_pinhole.rs:400-435)
-    double dd = k1 + 2.0 * k2 * r2;
+    double dd = fma(2.0 * k2, r2, k1);
     double dxn_dz = xn * inz, dyn_dz = yn * inz;
-    double dxd_dxn = dist + xn * dd * 2.0 * xn;
-    double dxd_dyn = xn * dd * 2.0 * yn;
-    double dyd_dxn = yn * dd * 2.0 * xn;
-    double dyd_dyn = dist + yn * dd * 2.0 * yn;
+    const double tx = (xn * dd) * 2.0, ty = (yn * dd) * 2.0;
+    double dxd_dxn = fma(tx, xn, dist);
+    double dxd_dyn = tx * yn;
+    double dyd_dxn = ty * xn;
+    double dyd_dyn = fma(ty, yn, dist);
     double Jp[2][3];
     Jp[0][0] = f * (dxd_dxn * inz);
     Jp[0][1] = f * (dxd_dyn * inz);
-    Jp[0][2] = f * (dxd_dxn * dxn_dz + dxd_dyn * dyn_dz);
+    Jp[0][2] = f * fma(dxd_dxn, dxn_dz, dxd_dyn * dyn_dz);
     Jp[1][0] = f * (dyd_dxn * inz);
     Jp[1][1] = f * (dyd_dyn * inz);
-    Jp[1][2] = f * (dyd_dxn * dxn_dz + dyd_dyn * dyn_dz);
+    Jp[1][2] = f * fma(dyd_dxn, dxn_dz, dyd_dyn * dyn_dz);
     const double* R = c.R;
-    double w = huber_sqrt_rho1(huber_delta, r0 * r0 + r1 * r1);
+    double w = huber_sqrt_rho1(huber_delta, fma(r0, r0, r1 * r1));
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         // landmark block = Jp R ; pose block = [Jp R | -(Jp R)[p_w]x]  (bal_pinhole.rs:528-556:
         // d p_cam/d delta = [R | -R [p_w]x], right perturbation delta = [rho; theta])
-        double a0 = Jp[rr][0] * R[0] + Jp[rr][1] * R[3] + Jp[rr][2] * R[6];
-        double a1 = Jp[rr][0] * R[1] + Jp[rr][1] * R[4] + Jp[rr][2] * R[7];
-        double a2 = Jp[rr][0] * R[2] + Jp[rr][1] * R[5] + Jp[rr][2] * R[8];
+        double a0 = fma(Jp[rr][0], R[0], fma(Jp[rr][1], R[3], Jp[rr][2] * R[6]));
+        double a1 = fma(Jp[rr][0], R[1], fma(Jp[rr][1], R[4], Jp[rr][2] * R[7]));
+        double a2 = fma(Jp[rr][0], R[2], fma(Jp[rr][1], R[5], Jp[rr][2] * R[8]));
         const double wl = MASKED ? w * c.m_lm : w, wp = MASKED ? w * c.m_pose : w;
         Jl[rr][0] = a0 * wl; Jl[rr][1] = a1 * wl; Jl[rr][2] = a2 * wl;
         Jc[rr][0] = a0 * wp; Jc[rr][1] = a1 * wp; Jc[rr][2] = a2 * wp;
-        Jc[rr][3] = -(a1 * pw[2] - a2 * pw[1]) * wp;
-        Jc[rr][4] = -(a2 * pw[0] - a0 * pw[2]) * wp;
-        Jc[rr][5] = -(a0 * pw[1] - a1 * pw[0]) * wp;
+        Jc[rr][3] = fma(a2, pw[1], -(a1 * pw[2])) * wp;
+        Jc[rr][4] = fma(a0, pw[2], -(a2 * pw[0])) * wp;
+        Jc[rr][5] = fma(a1, pw[0], -(a0 * pw[1])) * wp;
     }
     if (DC == 9) {
         // d(u,v)/d(f,k1,k2)  (bal_pinhole.rs:649-672)

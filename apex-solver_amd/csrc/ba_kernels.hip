@@ -913,20 +913,74 @@ __global__ __launch_bounds__(256) void k_retract_points(int64_t n3, const double
 }
 
 // ------------------------------------------------------------------------------------------
-// A16 cost: per-block partial sums of |r~|^2 (grid-stride, fixed geometry -> reproducible).
+// A16 cost: per-block partial sums of |r~|^2 (fixed geometry -> reproducible).
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Per-wave camera cache in LDS (k_cost_partial).  A wave walks a CONTIGUOUS range of observations (landmark-major: its
+// cameras stay inside a capture window), keeps the compact cameras it has seen in a direct-mapped table of
+// kCamCacheSlots entries and gathers hits from LDS -- the per-lane gathers are bound by the bytes they pull through the
+// L1, and the LDS is a second, wider path (cost 0.33 -> 0.25 ms on final-13682).  In k_landmark_reduce and
+// k_back_substitute the same cache cost a wave of occupancy and gained nothing (0.71 / 0.69 -> 0.73 / 0.72 ms).
+constexpr int kCamCacheSlots = 64;
+struct CamCache {
+    uint32_t tag[kCamCacheSlots];
+    double2 data[kCamCacheSlots][kCamQStride / 2];
+};
+__device__ __forceinline__ void cam_cache_reset(CamCache& cc, int lane) {
+    for (int s = lane; s < kCamCacheSlots; s += 64) cc.tag[s] = 0xFFFFFFFFu;
+    __builtin_amdgcn_wave_barrier();
+}
+// Wave-synchronous: the LDS executes a wave's instructions in order, so the hits of a step are read before its misses
+// replace entries; when several missing lanes map to one slot they all write the same sequence of instructions to the
+// same addresses and the same (last) lane wins every one of them, tag included -- the entry is always one whole camera.
+__device__ __forceinline__ void cam_cache_get(CamCache& cc, const double* __restrict__ camq, uint32_t c, bool active, double q[kCamQStride]) {
+    const uint32_t slot = c & (kCamCacheSlots - 1);
+    const bool hit = active && cc.tag[slot] == c;
+    double2 t[kCamQStride / 2];
+    if (hit) {
+#pragma unroll
+        for (int k = 0; k < kCamQStride / 2; ++k) t[k] = cc.data[slot][k];
+    } else if (active) {
+        const double2* src = reinterpret_cast<const double2*>(camq + kCamQStride * (size_t)c);
+#pragma unroll
+        for (int k = 0; k < kCamQStride / 2; ++k) t[k] = src[k];
+    }
+    __builtin_amdgcn_wave_barrier();   // (compiler only) no entry is replaced before the hits are read
+    if (active && !hit) {
+#pragma unroll
+        for (int k = 0; k < kCamQStride / 2; ++k) cc.data[slot][k] = t[k];
+        cc.tag[slot] = c;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < kCamQStride / 2; ++k) { q[2 * k] = t[k].x; q[2 * k + 1] = t[k].y; }
+}
+
 __global__ __launch_bounds__(256) void k_cost_partial(BAView v, double* __restrict__ partial) {
     __shared__ double scratch[4];
+    __shared__ CamCache cache[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    CamCache& cc = cache[w];
+    cam_cache_reset(cc, lane);
+    // contiguous range of this wave: whole 64-observation steps
+    const int64_t n_waves = (int64_t)gridDim.x * 4, wave = (int64_t)blockIdx.x * 4 + w;
+    const int64_t steps = (v.n_obs + 63) / 64, per = (steps + n_waves - 1) / n_waves;
+    const int64_t s0 = wave * per, s1 = min(steps, s0 + per);
     double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < v.n_obs; i += (int64_t)gridDim.x * 256) {
-        const uint32_t c = v.o_cam[i], l = v.o_pt[i];
-        const double2 uv = v.o_uv[i];
+    for (int64_t st = s0; st < s1; ++st) {
+        const int64_t i = st * 64 + lane;
+        const bool active = i < v.n_obs;
+        const int64_t ii = active ? i : 0;
+        const uint32_t c = v.o_cam[ii], l = v.o_pt[ii];
+        const double2 uv = v.o_uv[ii];
+        double q[kCamQStride];
+        cam_cache_get(cc, v.camq, c, active, q);
         Cam cam;
-        load_cam_q(v.camq + kCamQStride * (size_t)c, v.mask_code, cam);
+        load_cam_q(q, v.mask_code, cam);
         const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
         double r[2];
         residual_obs(cam, pw, uv.x, uv.y, v.huber_delta, r);
-        s += r[0] * r[0] + r[1] * r[1];
+        s += active ? r[0] * r[0] + r[1] * r[1] : 0.0;
     }
     s = block_sum_256(s, scratch);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
