@@ -146,7 +146,7 @@ class TilePlan {
     std::vector<hipEvent_t> ev_t_, ev_u2_, ev_o_;
     std::vector<bool> u2_pending_, o_pending_;
     bool split_u1_ = true;
-    int split_u1_min_ = 24;
+    int split_u1_min_ = 4;
     bool overlap_ = true;
     int overlap_min_ = 2;   // U2 batches smaller than this stay on the main stream (swept 1..1024: flat up to 64)
     std::vector<std::pair<int64_t, int64_t>> upd_rounds_;

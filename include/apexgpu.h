@@ -224,7 +224,7 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
  *   "update_overlap" (1)  run the trailing updates the next elimination level does not need on a second
  *                     stream, overlapped with that level's potrf / panel solves (before the first solve)
- *   "split_u1" (24)   the updates a level sends into the NEXT level's columns are split: those of its diagonal tiles stay on
+ *   "split_u1" (4)    the updates a level sends into the NEXT level's columns are split: those of its diagonal tiles stay on
  *                     the main stream (the next potrf needs nothing else), the others run on a third stream beside that
  *                     potrf when they are at least this many tasks; 0 = one batch on the main stream (before set_structure)
  *   "potrf_lookahead" (8)  diagonal-tile Cholesky + inverse: 8 / 6 / 1 = look-ahead schedule with 8 / 6 / 4 waves
