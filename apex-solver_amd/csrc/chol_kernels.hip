@@ -260,8 +260,9 @@ __global__ __launch_bounds__(256) void k_potrf_inv(const PotrfTask* __restrict__
 //             P2  panel A(i,kb) <- A(i,kb) D_kb^-T (i > kb);  row kb of L goes to global memory and becomes
 //                 L~(kb,k) = D_kb^-1 L(kb,k) in place (k < kb)
 //             --  barrier
-//             P3  look-ahead: column kb+1 receives the rank-16 update of step kb (the only part of the trailing
-//                 update the next potrf16 and panel need)
+//                 look-ahead: wave 0, which solved the panel block (kb+1, kb) itself, gives the next DIAGONAL block this
+//                 step's update right away (all the next potrf16 needs); the rest of column kb+1 is updated by the
+//                 other waves at the start of the next P1, beside that potrf16 (round 2: one barrier per step less)
 //             --  barrier
 // with  L^-1(r,j) = - sum_{k=j}^{r-1} L~(r,k) L^-1(k,j),  L^-1(k,k) = D_k^-1  (row-oriented dtrtri).
 // Row r of L is dead once step r has used it, so its blocks are reused for L~ and then L^-1: no extra LDS.
@@ -412,7 +413,15 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_inv_la(const PotrfTask* __res
         } else {
             if (kb >= 1) {
                 const int ks = kb - 1;
-                // rest of the trailing update of step ks: targets (i, j) with kb < j <= i
+                // column kb below its diagonal block first (the panel solves of this step need it; the diagonal block
+                // itself got its update from wave 0 at the end of the previous step) ...
+                for (int i = kb + w; i < NBK; i += NW - 1) {
+                    double* Cb = sA + bidx(i, kb) * BSZ;
+                    double4_t acc = blk_load_cd(Cb, lr, lk);
+                    acc = blk_mma_nt(sA + bidx(i, ks) * BSZ, sA + bidx(kb, ks) * BSZ, acc, lr, lk, -1.0);
+                    blk_store_cd(Cb, acc, lr, lk, 1.0);
+                }
+                // ... then the rest of the trailing update of step ks: targets (i, j) with kb < j <= i
                 const int m = NBK - 1 - kb;
                 const int n_upd = m * (m + 1) / 2;
                 for (int t = w - 1; t < n_upd; t += NW - 1) {
@@ -465,16 +474,14 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_inv_la(const PotrfTask* __res
                 }
             }
             if (w == NW - 1) blk_to_global(sA + bidx(kb, kb) * BSZ, A, kb, kb, lane, 64);  // the diagonal block of L
-        }
-        __syncthreads();
-        POTRF_STAMP();
-        // ---------------- P3: look-ahead update of column kb+1 ---------------------------------------------------
-        if (kb + 1 < NBK) {
-            const int jc = kb + 1;
-            for (int i = jc + w; i < NBK; i += NW) {
-                double* Cb = sA + bidx(i, jc) * BSZ;
+            // ---------------- look-ahead: only what the next potrf16 needs, by the wave that runs it -----------------
+            // wave 0 solved the panel block (kb+1, kb) itself (task 0 above): the next diagonal block gets this step's
+            // update right away; the rest of column kb+1 is updated by the other waves while wave 0 factorises it.
+            if (w == 0 && kb + 1 < NBK) {
+                const int jc = kb + 1;
+                double* Cb = sA + bidx(jc, jc) * BSZ;
                 double4_t acc = blk_load_cd(Cb, lr, lk);
-                acc = blk_mma_nt(sA + bidx(i, kb) * BSZ, sA + bidx(jc, kb) * BSZ, acc, lr, lk, -1.0);
+                acc = blk_mma_nt(sA + bidx(jc, kb) * BSZ, sA + bidx(jc, kb) * BSZ, acc, lr, lk, -1.0);
                 blk_store_cd(Cb, acc, lr, lk, 1.0);
             }
         }
