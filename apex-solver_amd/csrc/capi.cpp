@@ -241,6 +241,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "schur_form") h->s->use_row_schur(value);   /* alias of "schur_rows": 3 sorted pair list (default), 2 / 1 LDS rows, 0 global atomics */
     else if (n == "rows_debug") h->s->set_rows_debug(value);
     else if (n == "pairs_ablation") apex::set_pairs_ablation(value);   /* timing experiments only */
+    else if (n == "pairs_variant") apex::set_pairs_variant(value);
     else if (n == "hubs_last") h->s->set_hubs_last(value != 0);
     else if (n == "pair_task_slots") h->s->set_pair_task_slots(value);
     else if (n == "dist_factor") h->s->set_dist_factor(value != 0);

@@ -6,8 +6,9 @@
 //     -W_i Hll^-1 W_j^T = (Jc_i^T M_ij) Jc_j = U_ij V_j ,   U (d_c x 2), V (2 x d_c),
 // so a block S(ci, cj) is the product of a d_c x 2P and a 2P x d_c matrix, P = pairs of the block: a tiny GEMM whose K
 // dimension runs over the pairs.  All pairs of the problem are sorted by block once per structure; a wave takes 64
-// consecutive pair slots, one pair per lane computes U and V (both observations re-linearised from the 24-byte records)
-// and parks them in LDS; then lane (g, bi, bj) owns the 3 x 3 sub-block (bi, bj) of the running block and adds the pairs
+// consecutive pair slots, computes U and V of every pair (both observations re-linearised from the 24-byte records: one
+// observation per lane, two lanes per pair, 32 pairs per step -- k_schur_pairs_h, the default; or one pair per lane --
+// k_schur_pairs) and parks them in LDS; then lane (g, bi, bj) owns the 3 x 3 sub-block (bi, bj) of the running block and adds the pairs
 // g, g + NG, ... of the segment (18 FMA per pair), the NG groups are folded with shuffles at a block boundary.  A block
 // is owned by one wave and stored ONCE with plain stores: no atomics, no LDS accumulators, no neighbour chunking.
 // (v_mfma_f64_16x16x4_f64 was the first design: it occupies the fp64 datapath for 64 cycles whatever the tile holds,
@@ -63,6 +64,7 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
                       int task_slots = 0 /* 0: default */);
 
+void set_pairs_variant(int v);     // 0: one pair per lane, 1: one observation per lane (two lanes per pair)
 void set_pairs_ablation(int bits);   // timing experiments only: results are wrong when != 0
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
                         const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s);

@@ -521,13 +521,215 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
     if (cur >= 0) pairs_flush<DC>(tiles, cur_dst, cur_flags, acc, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Variant H ("half-pair lanes"): one OBSERVATION per lane, two lanes per pair, 32 pair slots per step.
+// Lane 2p linearises observation i of pair p, lane 2p+1 observation j; the odd lane forms Q = Hll^-1 Jl_j^T (3 x 2) and hands it
+// to its neighbour (DPP quad_perm), the even lane forms M = -Jl_i Q and U = Jc_i^T M, the odd lane's V is its Jc_j.  One
+// linearisation's temporaries instead of two and half the U / V staging per wave (10 KB of LDS): three waves per SIMD
+// instead of two.  Same lists, same product phase (lane = (group, sub-block)), over the two 32-slot halves of a chunk.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dpp_swap1(double x) {   // value of lane ^ 1
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+struct HalfData {     // what a lane needs for its observation, fetched one half-chunk ahead
+    double2 uv;
+    double2 lm[6];
+};
+__device__ __forceinline__ void half_issue_loads(const BAView& v, const double* __restrict__ lmrec, const uint4 rr, int side, HalfData& d) {
+    const bool valid = rr.x != kPairPad;
+    const uint32_t o = valid ? (side ? rr.y : rr.x) : 0u, l = valid ? rr.z : 0u;
+    d.uv = v.o_uv[o];
+    const double2* q = reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)l);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d.lm[k] = q[k];
+}
+
+template <int DC>
+__global__ __launch_bounds__(256, 3) void k_schur_pairs_h(BAView v, double* __restrict__ tiles, const PairTask* __restrict__ tasks,
+                                                          int n_tasks, const PairChunk* __restrict__ chunks,
+                                                          const PairBlock* __restrict__ blocks, const PairRec* __restrict__ recs,
+                                                          const double* __restrict__ lmrec) {
+    constexpr int UV = 2 * DC;
+    constexpr int NB3 = DC / 3;
+    constexpr int GL = NB3 * NB3;
+    constexpr int NG = (DC == 9) ? 7 : 16;
+    constexpr int WAVE_LDS = 2 * 32 * UV + 8 * kCamStride;   // U[32][UV] | V[32][UV] | 8 cameras staged by LDS-DMA
+    __shared__ double lds_all[4 * WAVE_LDS];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    const int t = wg * 4 + w;
+    if (t >= n_tasks) return;
+    double* U = lds_all + w * WAVE_LDS;
+    double* V = U + 32 * UV;
+    double* CAMS = V + 32 * UV;
+    const PairTask task = tasks[t];
+    const int g = lane / GL, sub = lane - g * GL, bi = sub / NB3, bj = sub - bi * NB3;
+    const bool worker = g < NG;
+    const int side = lane & 1, pl = lane >> 1;     // this lane's observation of pair slot pl of the half
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    int cur = -1;
+    int64_t cur_dst = 0;
+    uint32_t cur_flags = 0;
+
+    const int ch_end = task.chunk0 + task.nchunks;
+    int ch = task.chunk0;
+    PairChunk ck = chunks[ch];
+    const uint4* rec4 = reinterpret_cast<const uint4*>(recs);
+    uint4 rr = rec4[(size_t)ch * 64 + pl];
+    HalfData dat;
+    half_issue_loads(v, lmrec, rr, side, dat);
+    bool dma = 1 + __popc(ck.mask & ~1u) <= kPairDmaBlocks;
+    if (dma) pairs_dma_issue(v, pairs_dma_cam(blocks, ck, lane), lane, CAMS);
+    // one half ahead: the record; one chunk ahead: the descriptor and the camera this lane stages
+    uint4 rr_next = rec4[(size_t)ch * 64 + 32 + pl];
+    PairChunk ck_next = ck;
+    uint32_t cam_next = 0;
+    if (ch + 1 < ch_end) { ck_next = chunks[ch + 1]; cam_next = pairs_dma_cam(blocks, ck_next, lane); }
+
+    for (; ch < ch_end; ++ch) {
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const bool valid = rr.x != kPairPad;
+            const uint32_t blk = valid ? rr.w : 0u;
+            // ---- B: one observation per lane ---------------------------------------------------------------------------
+            double cv[16];
+            if (dma) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA writes LDS behind the VM counter
+                __builtin_amdgcn_wave_barrier();
+                const double2* c2 = reinterpret_cast<const double2*>(CAMS + (2 * blk + side) * kCamStride);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const double2 tq = c2[k]; cv[2 * k] = tq.x; cv[2 * k + 1] = tq.y; }
+            } else {   // many tiny blocks in this chunk: the camera comes straight from memory
+                const PairBlock* pb = blocks + ck.first_block + blk;
+                const uint32_t cam = side ? pb->cj : pb->ci;
+                const double2* c2 = reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)cam);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const double2 tq = c2[k]; cv[2 * k] = tq.x; cv[2 * k + 1] = tq.y; }
+            }
+            double Hi[9], pw[3];
+            Hi[0] = dat.lm[0].x; Hi[1] = dat.lm[0].y; Hi[2] = dat.lm[1].x; Hi[3] = dat.lm[1].y; Hi[4] = dat.lm[2].x; Hi[5] = dat.lm[2].y;
+            Hi[6] = dat.lm[3].x; Hi[7] = dat.lm[3].y; Hi[8] = dat.lm[4].x; pw[0] = dat.lm[4].y; pw[1] = dat.lm[5].x; pw[2] = dat.lm[5].y;
+            double Jc[2][DC], Jl[2][3];
+            linearize_pairside<DC>(cv, pw, dat.uv.x, dat.uv.y, v.huber_delta, Jc, Jl);
+            // odd lane: Q = Hll^-1 Jl_j^T (3 x 2); every lane forms it, the even lane takes its neighbour's
+            double Q[3][2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) Q[a][m] = Hi[3 * a] * Jl[m][0] + Hi[3 * a + 1] * Jl[m][1] + Hi[3 * a + 2] * Jl[m][2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) Q[a][m] = dpp_swap1(Q[a][m]);
+            double out[UV];
+            if (side == 0) {
+                const double sgn = valid ? -1.0 : 0.0;     // a padding slot contributes U = 0
+                double M[2][2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) M[n][m] = sgn * (Jl[n][0] * Q[0][m] + Jl[n][1] * Q[1][m] + Jl[n][2] * Q[2][m]);
+#pragma unroll
+                for (int e = 0; e < UV; ++e) {   // U[m][3 bi + c] in the order [bi][m][3]
+                    const int s0 = e / 6, m = (e % 6) / 3, c = e % 3;
+                    out[e] = Jc[0][3 * s0 + c] * M[0][m] + Jc[1][3 * s0 + c] * M[1][m];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < UV; ++e) {   // V[m][3 bj + c] in the order [bj][m][3]
+                    const int s0 = e / 6, m = (e % 6) / 3, c = e % 3;
+                    out[e] = Jc[m][3 * s0 + c];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // the previous half's products are done with U / V (one wave: program order)
+            {
+                double2* po = reinterpret_cast<double2*>((side ? V : U) + pl * UV);
+#pragma unroll
+                for (int k = 0; k < UV / 2; ++k) po[k] = make_double2(out[2 * k], out[2 * k + 1]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- D: the next half's gathers go out now and land during the product phase ----------------------------------
+            const PairChunk ck_cur = ck;
+            const uint32_t hmask = (ck_cur.mask >> (16 * half)) & 0xFFFFu;
+            const bool more = half == 0 || ch + 1 < ch_end;
+            if (more) {
+                rr = rr_next;
+                half_issue_loads(v, lmrec, rr, side, dat);
+                if (half == 1) {
+                    // (every lane read its cameras of this chunk above: the camera area is free)
+                    ck = ck_next;
+                    dma = 1 + __popc(ck.mask & ~1u) <= kPairDmaBlocks;
+                    if (dma) pairs_dma_issue(v, cam_next, lane, CAMS);
+                    rr_next = rec4[(size_t)(ch + 1) * 64 + 32 + pl];
+                    if (ch + 2 < ch_end) { ck_next = chunks[ch + 2]; cam_next = pairs_dma_cam(blocks, ck_next, lane); }
+                } else {
+                    if (ch + 1 < ch_end) rr_next = rec4[(size_t)(ch + 1) * 64 + pl];
+                }
+            }
+            // ---- E: block products over the 32 slots of the half -------------------------------------------------------------
+            uint32_t mask = hmask;
+            int seg0 = 0;
+            if (mask & 1u) {
+                if (cur >= 0) pairs_flush<DC>(tiles, cur_dst, cur_flags, acc, lane);
+                cur = cur < 0 ? ck_cur.first_block : cur + 1;
+                cur_dst = blocks[cur].dst; cur_flags = blocks[cur].flags;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+            }
+            mask &= ~1u;
+            for (;;) {
+                const int seg1 = mask ? 2 * (__ffs(mask) - 1) : 32;      // wave-uniform
+                for (int p = seg0 + g; p < seg1; p += NG) {
+                    if (worker) {
+                        const double2* qu = reinterpret_cast<const double2*>(U + p * UV + bi * 6);
+                        const double2* qv = reinterpret_cast<const double2*>(V + p * UV + bj * 6);
+                        const double2 u0 = qu[0], u1 = qu[1], u2 = qu[2], v0 = qv[0], v1 = qv[1], v2 = qv[2];
+                        const double um0[3] = {u0.x, u0.y, u1.x}, um1[3] = {u1.y, u2.x, u2.y};
+                        const double vm0[3] = {v0.x, v0.y, v1.x}, vm1[3] = {v1.y, v2.x, v2.y};
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) acc[3 * r + c] = fma(um1[r], vm1[c], fma(um0[r], vm0[c], acc[3 * r + c]));
+                    }
+                }
+                if (!mask) break;
+                pairs_flush<DC>(tiles, cur_dst, cur_flags, acc, lane);
+                ++cur;
+                cur_dst = blocks[cur].dst; cur_flags = blocks[cur].flags;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+                seg0 = seg1;
+                mask &= mask - 1;
+            }
+        }
+    }
+    if (cur >= 0) pairs_flush<DC>(tiles, cur_dst, cur_flags, acc, lane);
+}
+
 static int g_pairs_ablation = 0;   // timing experiments only (tools/schur_bench.py --abl)
 void set_pairs_ablation(int bits) { g_pairs_ablation = bits; }
+static int g_pairs_variant = 1;    // 1 (default): one observation per lane (k_schur_pairs_h); 0: one pair per lane (k_schur_pairs)
+void set_pairs_variant(int vv) { g_pairs_variant = vv; }
 
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
                         const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s) {
     if (n_tasks == 0) return;
     const unsigned grid = (unsigned)((n_tasks + 3) / 4);
+    if (g_pairs_variant == 1 && g_pairs_ablation == 0) {
+        if (dc == 9) hipLaunchKernelGGL((k_schur_pairs_h<9>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec);
+        else hipLaunchKernelGGL((k_schur_pairs_h<6>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec);
+        return;
+    }
 #define PAIRS_LAUNCH(DCV, A) hipLaunchKernelGGL((k_schur_pairs<DCV, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec)
     if (dc == 9) {
         switch (g_pairs_ablation) {

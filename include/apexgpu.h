@@ -221,6 +221,8 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     2 = LDS row form, one lane per observation, block rows walked in a per-lane rotated order
  *                     (k_schur_rows2); 1 = LDS row form, one lane per camera pair (k_schur_rows);
  *                     0 = the landmark-major global-atomics form (k_schur_scatter)
+ *   "pairs_variant" (1)  schur form 3 only, process-wide: 1 = one observation per lane, two lanes per pair (three waves per
+ *                     SIMD), 0 = one pair per lane (two waves per SIMD); same lists, same results up to rounding
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
  *   "update_overlap" (1)  run the trailing updates the next elimination level does not need on a second
  *                     stream, overlapped with that level's potrf / panel solves (before the first solve)
