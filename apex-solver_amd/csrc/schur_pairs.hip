@@ -556,7 +556,10 @@ __global__ __launch_bounds__(256, 3) void k_schur_pairs_h(BAView v, double* __re
     constexpr int NB3 = DC / 3;
     constexpr int GL = NB3 * NB3;
     constexpr int NG = (DC == 9) ? 7 : 16;
-    constexpr int WAVE_LDS = 2 * 32 * UV + 8 * kCamStride;   // U[32][UV] | V[32][UV] | 8 cameras staged by LDS-DMA
+    // U[32][UV] | skew | V[32][UV] | skew | 8 cameras staged by LDS-DMA.  The skew between U and V: lanes 2p and 2p+1 store
+    // U[p] and V[p] in the same instruction, and 32 * UV doubles apart they would hit the same banks
+    constexpr int kSkew = 8;   // ds_write_b128: groups of 8 lanes, bank = dword address mod 32 -> V sixteen banks away from U
+    constexpr int WAVE_LDS = 2 * (32 * UV + kSkew) + 8 * kCamStride;
     __shared__ double lds_all[4 * WAVE_LDS];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -568,8 +571,8 @@ __global__ __launch_bounds__(256, 3) void k_schur_pairs_h(BAView v, double* __re
     const int t = wg * 4 + w;
     if (t >= n_tasks) return;
     double* U = lds_all + w * WAVE_LDS;
-    double* V = U + 32 * UV;
-    double* CAMS = V + 32 * UV;
+    double* V = U + 32 * UV + kSkew;
+    double* CAMS = V + 32 * UV + kSkew;
     const PairTask task = tasks[t];
     const int g = lane / GL, sub = lane - g * GL, bi = sub / NB3, bj = sub - bi * NB3;
     const bool worker = g < NG;
