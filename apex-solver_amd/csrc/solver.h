@@ -183,7 +183,7 @@ class Solver : public LmBackend {
     PairRec* precs_ = nullptr;
     int n_ptasks_ = 0;
     int64_t n_pair_blocks_ = 0, n_pair_slots_ = 0;
-    int rows_form_ = 3;              // 3 (default): sorted pair list reduced on the fp64 matrix cores (k_schur_pairs: every
+    int rows_form_ = 3;              // 3 (default): sorted pair list reduced over the lanes of a wave (k_schur_pairs_h / k_schur_pairs: every
                                      // block S(ci, cj) stored once by one wave, no atomics, no LDS accumulators);
                                      // 2: one lane per observation (k_schur_rows2, default: every lane walks the rows of
                                      // a neighbour block in its own rotated order, which takes the same-address

@@ -327,7 +327,7 @@ def main():
     # ---- roofline of the graded Schur-reduction kernel, per launch -------------------------------------------------------
     dc = 9 if args.mode == "selfcal" else 6
     form = info.get("schur_form", 3)
-    kernel = {3: "k_schur_pairs", 2: "k_schur_rows2", 1: "k_schur_rows", 0: "k_schur_scatter"}[form]
+    kernel = {3: "k_schur_pairs_h", 2: "k_schur_rows2", 1: "k_schur_rows", 0: "k_schur_scatter"}[form]
     n_obs_local = info["local_obs"]
     tile_bytes = 144 * 144 * 8
     # SURVEY §8(d), fused form (J never stored): each input read once, each output written once

@@ -332,7 +332,7 @@ def test_ragged_landmarks(oracle, mode):
 
 @pytest.mark.parametrize("mode", ["selfcal", "ba"])
 def test_row_and_atomic_schur_forms_agree(mode):
-    """The four implementations of the Schur reduction (sorted pair list reduced on the matrix cores -- the default --,
+    """The implementations of the Schur reduction (sorted pair list, two lanes per pair -- the default -- or one pair per lane,
     LDS row form with one lane per camera pair, with one lane per observation, global-atomics form) build the same
     S, g_red and gradient -- also on landmarks with more than 64 partners per observation (split entries), more
     neighbours than one LDS chunk, and camera pairs with more common landmarks than one chunk of the pair list."""
