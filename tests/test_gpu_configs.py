@@ -294,3 +294,23 @@ def test_hub_shape_vs_oracle(oracle, mode):
         print("hubs_last", hubs_last, {k: f"{v:.1e}" for k, v in errs.items()}, f"backward {bwd:.1e}")
         assert errs["S"] < 1e-12 and errs["gred"] < 1e-10 and errs["grad"] < 1e-12
         assert bwd < 1e-13 and errs["step"] < 1e-7
+
+
+def test_hub_full_size_properties():
+    """final-13682-hub at full size (29 M observations, ~600 border cameras, a 39-tile dense border): the size-independent
+    properties -- S dc = g_red through the explicit tiles and through the matrix-free operator (backward error), S
+    symmetric positive on probes, one LM iteration reduces the cost -- with the border ordering and the dataflow sweeps
+    on a factor of 41 K tiles."""
+    d = pkg.synthetic.make_named("final-13682-hub")
+    lam = 1e-3
+    prob, s = make(d, "selfcal")
+    info = dict(s.info(), border_cameras=s.setup_times()["hub_cameras"])
+    print("final-13682-hub:", {k: info[k] for k in ("tile_rows", "tiles", "touched_tiles", "etree_levels", "border_cameras")})
+    assert info["border_cameras"] > 0
+    probe_symmetry(s, prob, lam)
+    step = s.solve_augmented_equation(lam)
+    bwd_e, bwd_i = camera_step_checks(s, prob, lam, step, "final-13682-hub")
+    assert bwd_e < 1e-13 and bwd_i < 1e-12
+    s.solve_augmented_equation(lam, want_step=False)
+    one_lm_iteration_behaves(s, lam)
+    s.close()
