@@ -127,7 +127,7 @@ class Solver : public LmBackend {
     // for_factor: the result feeds tp_.factor() (a distributed plan then leaves the top tiles to the factorisation's
     // own exchange); otherwise S is complete on every rank (PCG, exports, the ladder's diagonal read)
     int assemble(double lambda, double diag_extra, bool for_factor = false);
-    int assemble_local(double lambda, double diag_extra);
+    int assemble_local(double lambda, double diag_extra, bool for_factor = false);
     int assemble_finish();
     int assemble_implicit(double lambda);
     int implicit_pcg_solve(double lambda);

@@ -412,7 +412,7 @@ int Solver::cost(double* out) {
 // assembly of S, g_red, Hll^-1, g (A6-A11) at the current parameters
 // ---------------------------------------------------------------------------------------------
 int Solver::assemble(double lambda, double diag_extra, bool for_factor) {
-    int rc = assemble_local(lambda, diag_extra);
+    int rc = assemble_local(lambda, diag_extra, for_factor);
     if (rc != kOk) return rc;
 #ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1) {
@@ -445,11 +445,13 @@ int Solver::assemble(double lambda, double diag_extra, bool for_factor) {
 }
 
 // this rank's part of S, g_red, g_c (its landmarks), before any exchange
-int Solver::assemble_local(double lambda, double diag_extra) {
+int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     const BAView v = view(cur_);
     const TileMap tm = tilemap();
     stage_begin(kStAssembleCam);
-    HIP_TRY(tp_.zero_tiles());
+    // (a tree-sharded rank that assembles for its distributed factorisation adds to its own and the top tiles only; every
+    // other use of S -- PCG, exports, the ladder's diagonal -- all-reduces every touched tile and needs them all cleared)
+    HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor));
     HIP_TRY(hipMemsetAsync(g_red_, 0, n_c_pad_ * sizeof(double), stream_));
     HIP_TRY(hipMemsetAsync(g_c_, 0, n_c_pad_ * sizeof(double), stream_));
     HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
@@ -712,7 +714,7 @@ int Solver::dist_phase(int phase, double lambda) {
     if (!tp_.distributed()) return fail(kInvalidState, "the plan is not distributed (set_shard with world > 1, dist_factor on)");
     HIP_TRY(hipSetDevice(device_));
     switch (phase) {
-        case 0: have_step_ = false; last_lambda_ = lambda; return assemble_local(lambda, 0.0);
+        case 0: have_step_ = false; last_lambda_ = lambda; return assemble_local(lambda, 0.0, true);
         case 1: {
             int rc = assemble_finish();
             if (rc != kOk) return rc;

@@ -96,7 +96,9 @@ class TilePlan {
     hipError_t read_flags(int* failed_at);   // pivot flag + error word of the dataflow sweeps (hipErrorLaunchTimeOut)
     void enable_tri_flow(bool on);   // triangular sweeps as one dataflow launch each (default) or level by level
 
-    hipError_t zero_tiles();                             // async on the plan's stream
+    // async on the plan's stream.  own_touched_only: (distributed plans) this rank adds to the tiles of its own columns and
+    // of the shared top only -- tree-sharded landmarks; the other ranks' tiles are then left alone
+    hipError_t zero_tiles(bool own_touched_only = false);
     void add_diag(int n_valid, double add_valid, double pad_value);  // diagonal += / padding rows := value
     void diag(double* out) const;                        // out[n_pad] = diagonal
     void scale_sym(const double* scale);                 // A := D A D on the unfactored tiles, D = diag(scale[n_pad])
@@ -131,6 +133,7 @@ class TilePlan {
     std::vector<int> cls_h_;      // per tile column: 0 another rank's, 1 this rank's, 2 top (shared)
     std::vector<int> owner_h_;    // per tile column: owning rank, -1 top
     std::vector<std::pair<int64_t, int64_t>> own_range_;  // per rank: slots of the touched tiles of its columns
+    std::vector<std::pair<int64_t, int64_t>> own_fill_;   // per rank: slots of the fill tiles of its columns
     int* cls_ = nullptr;
     double* exch_ = nullptr;
     Comm comm_;

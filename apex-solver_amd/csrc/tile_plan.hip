@@ -261,13 +261,17 @@ std::vector<std::vector<int>> TilePlan::symbolic_slots(const std::vector<uint8_t
         if (pass == n_owner - 1) n_t_nt_ = n_slots_;
     }
     n_touched_ = n_slots_;
-    for (int pass = 0; pass < 2; ++pass) {
+    own_fill_.assign(n_owner, {0, 0});
+    for (int pass = 0; pass <= n_owner; ++pass) {   // the fill tiles in the same order: owner by owner, then the top
+        const int64_t first = n_slots_;
         for (int K = 0; K < nt_; ++K) {
-            if ((cls_h_[K] == 2) != (pass == 1)) continue;
+            const bool is_top = cls_h_[K] == 2;
+            if (pass < n_owner ? (is_top || (n_top_cols_ > 0 && owner_h_[K] != pass)) : !is_top) continue;
             for (int I : col_rows[K])
                 if (!present[(size_t)I * nt_ + K]) slot_h_[(size_t)I * nt_ + K] = (int)n_slots_++;
         }
-        if (pass == 0) n_f_nt_ = n_slots_;
+        if (pass < n_owner) own_fill_[pass] = {first, n_slots_ - first};
+        if (pass == n_owner - 1) n_f_nt_ = n_slots_;
     }
     n_potrf_ = nt_; n_trsm_ = 0; n_upd_ = 0;
     for (int K = 0; K < nt_; ++K) {
@@ -539,9 +543,23 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     return "";
 }
 
-hipError_t TilePlan::zero_tiles() {
+hipError_t TilePlan::zero_tiles(bool own_touched_only) {
     fwd_rhs_ = nullptr;
-    hipError_t e = hipMemsetAsync(tiles_, 0, (size_t)n_slots_ * kNB * kNB * sizeof(double), stream_);
+    const size_t te = (size_t)kNB * kNB * sizeof(double);
+    hipError_t e = hipSuccess;
+    auto clear = [&](int64_t first, int64_t count) {
+        if (e == hipSuccess && count > 0) e = hipMemsetAsync(tiles_ + (size_t)first * kNB * kNB, 0, (size_t)count * te, stream_);
+    };
+    if (distributed() && !own_all_ && part_rank_ < (int)own_range_.size()) {
+        // a rank of a distributed plan factorises its own columns and the shared top: the fill tiles of the other ranks'
+        // columns are never touched; their touched tiles only when this rank's landmarks may add to them (range sharding)
+        if (own_touched_only) { clear(own_range_[part_rank_].first, own_range_[part_rank_].second); clear(n_t_nt_, n_touched_ - n_t_nt_); }
+        else clear(0, n_touched_);
+        clear(own_fill_[part_rank_].first, own_fill_[part_rank_].second);
+        clear(n_f_nt_, n_slots_ - n_f_nt_);
+    } else {
+        clear(0, n_slots_);
+    }
     if (e != hipSuccess) return e;
     return hipMemsetAsync(flag_, 0, 4 * sizeof(int), stream_);
 }
