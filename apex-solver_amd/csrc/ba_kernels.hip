@@ -931,11 +931,14 @@ __device__ __forceinline__ void cam_cache_reset(CamCache& cc, int lane) {
     __builtin_amdgcn_wave_barrier();
 }
 // Wave-synchronous: the LDS executes a wave's instructions in order, so the hits of a step are read before its misses
-// replace entries; when several missing lanes map to one slot they all write the same sequence of instructions to the
-// same addresses and the same (last) lane wins every one of them, tag included -- the entry is always one whole camera.
+// replace entries.  When several missing lanes map to one slot they first all store their camera index to the tag; the
+// re-read tells each whether it won (which of the colliding stores lands last is the hardware's choice, and need not be
+// the same for a 4-byte and a 16-byte store): only the winner fills the entry.  The tag accesses are volatile so that
+// the compiler does not forward a lane's own store to its re-read.
 __device__ __forceinline__ void cam_cache_get(CamCache& cc, const double* __restrict__ camq, uint32_t c, bool active, double q[kCamQStride]) {
     const uint32_t slot = c & (kCamCacheSlots - 1);
-    const bool hit = active && cc.tag[slot] == c;
+    volatile uint32_t* tag = cc.tag + slot;
+    const bool hit = active && *tag == c;
     double2 t[kCamQStride / 2];
     if (hit) {
 #pragma unroll
@@ -946,10 +949,12 @@ __device__ __forceinline__ void cam_cache_get(CamCache& cc, const double* __rest
         for (int k = 0; k < kCamQStride / 2; ++k) t[k] = src[k];
     }
     __builtin_amdgcn_wave_barrier();   // (compiler only) no entry is replaced before the hits are read
-    if (active && !hit) {
+    const bool miss = active && !hit;
+    if (miss) *tag = c;
+    __builtin_amdgcn_wave_barrier();
+    if (miss && *tag == c) {
 #pragma unroll
         for (int k = 0; k < kCamQStride / 2; ++k) cc.data[slot][k] = t[k];
-        cc.tag[slot] = c;
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
