@@ -937,16 +937,20 @@ __device__ __forceinline__ void cam_cache_reset(CamCache& cc, int lane) {
 // the compiler does not forward a lane's own store to its re-read.
 __device__ __forceinline__ void cam_cache_get(CamCache& cc, const double* __restrict__ camq, uint32_t c, bool active, double q[kCamQStride]) {
     const uint32_t slot = c & (kCamCacheSlots - 1);
-    volatile uint32_t* tag = cc.tag + slot;
+    volatile __attribute__((address_space(3))) uint32_t* tag = (volatile __attribute__((address_space(3))) uint32_t*)&cc.tag[slot];
     const bool hit = active && *tag == c;
     double2 t[kCamQStride / 2];
+    // (typed address spaces: left to itself the compiler selects between the two ADDRESSES and issues flat loads, which
+    // take the LDS hits through the vector-memory path)
+    typedef double __attribute__((ext_vector_type(2))) f64x2;
     if (hit) {
+        const __attribute__((address_space(3))) f64x2* lsrc = (const __attribute__((address_space(3))) f64x2*)&cc.data[slot][0];
 #pragma unroll
-        for (int k = 0; k < kCamQStride / 2; ++k) t[k] = cc.data[slot][k];
+        for (int k = 0; k < kCamQStride / 2; ++k) { const f64x2 v2 = lsrc[k]; t[k] = make_double2(v2.x, v2.y); }
     } else if (active) {
-        const double2* src = reinterpret_cast<const double2*>(camq + kCamQStride * (size_t)c);
+        const __attribute__((address_space(1))) f64x2* gsrc = (const __attribute__((address_space(1))) f64x2*)(camq + kCamQStride * (size_t)c);
 #pragma unroll
-        for (int k = 0; k < kCamQStride / 2; ++k) t[k] = src[k];
+        for (int k = 0; k < kCamQStride / 2; ++k) { const f64x2 v2 = gsrc[k]; t[k] = make_double2(v2.x, v2.y); }
     }
     __builtin_amdgcn_wave_barrier();   // (compiler only) no entry is replaced before the hits are read
     const bool miss = active && !hit;
