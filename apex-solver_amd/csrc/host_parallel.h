@@ -12,6 +12,7 @@
 #include <functional>
 #include <mutex>
 #include <cstdio>
+#include <exception>
 #include <memory>
 #include <new>
 #include <thread>
@@ -32,24 +33,39 @@ inline unsigned host_threads() {
 class HostPool {
    public:
     static HostPool& get() { static HostPool p; return p; }
-    // run job(worker) on `use` workers (including the caller) and wait
+    // run job(worker) on `use` workers (including the caller) and wait.  Exception-safe: a throw in ANY participant
+    // (the bodies allocate: std::bad_alloc) is caught where it happens, the first one is kept, every worker is still
+    // waited for -- `job` and the caller's loop state live on this stack frame -- and the exception is rethrown on the
+    // calling thread, where capi.cpp's guarded() turns it into a status code.  Nothing ever escapes a worker thread
+    // (that would be std::terminate in the host process).
     template <typename J>
     void run(unsigned use, J&& job) {
         std::lock_guard<std::mutex> serial(run_mu_);
         if (use <= 1) { job(); return; }
-        ensure(use - 1);
+        ensure(use - 1);     // (may throw std::system_error before anything is published: nothing to undo)
         {
             std::lock_guard<std::mutex> lk(mu_);
             fn_ = [&job]() { job(); };
             want_ = use - 1; started_ = 0; pending_ = use - 1;
+            error_ = nullptr;
             ++epoch_;
         }
         cv_.notify_all();
-        job();
-        std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [&] { return pending_ == 0; });
-        fn_ = nullptr;
+        std::exception_ptr mine;
+        try { job(); } catch (...) { mine = std::current_exception(); }
+        std::exception_ptr first;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            done_cv_.wait(lk, [&] { return pending_ == 0; });
+            fn_ = nullptr;
+            first = error_ ? error_ : mine;
+            error_ = nullptr;
+        }
+        if (first) std::rethrow_exception(first);
     }
+    // one flag per thread for ALL loop instantiations: a loop started from inside any other loop must run serially
+    // (run_mu_ is not recursive, and a worker that waits for the pool waits for itself)
+    static bool& inside_loop() { static thread_local bool inside = false; return inside; }
 
    private:
     HostPool() = default;
@@ -73,9 +89,12 @@ class HostPool {
                 ++started_;
                 fn = fn_;
             }
-            fn();
+            std::exception_ptr err;
+            try { fn(); } catch (...) { err = std::current_exception(); }
+            fn = nullptr;    // (drop the reference to the caller's frame before reporting completion)
             {
                 std::lock_guard<std::mutex> lk(mu_);
+                if (err && !error_) error_ = err;
                 if (--pending_ == 0) done_cv_.notify_all();
             }
         }
@@ -84,6 +103,7 @@ class HostPool {
     std::condition_variable cv_, done_cv_;
     std::vector<std::thread> th_;
     std::function<void()> fn_;
+    std::exception_ptr error_;
     unsigned want_ = 0, started_ = 0, pending_ = 0;
     uint64_t epoch_ = 0;
     bool stop_ = false;
@@ -93,18 +113,24 @@ class HostPool {
 template <typename F>
 void parallel_ranges(int64_t n, int64_t grain, F&& f) {
     const unsigned nt = host_threads();
-    static thread_local bool inside = false;   // a loop started from inside a loop runs serially
+    bool& inside = HostPool::inside_loop();   // a loop started from inside a loop (of any instantiation) runs serially
     if (n <= grain || nt == 1 || inside) { if (n > 0) f((int64_t)0, n); return; }
     std::atomic<int64_t> next(0);
     const unsigned use = (unsigned)std::min<int64_t>(nt, (n + grain - 1) / grain);
     HostPool::get().run(use, [&] {
-        inside = true;
+        bool& in = HostPool::inside_loop();
+        struct Reset { bool& b; ~Reset() { b = false; } } reset{in};   // also on the exceptional path
+        in = true;
         for (;;) {
             const int64_t b = next.fetch_add(grain);
             if (b >= n) break;
-            f(b, std::min<int64_t>(n, b + grain));
+            try {
+                f(b, std::min<int64_t>(n, b + grain));
+            } catch (...) {
+                next.store(n);     // the other participants stop at their next chunk
+                throw;
+            }
         }
-        inside = false;
     });
 }
 

@@ -1339,3 +1339,209 @@ int ora_lm_optimize(ora_problem *p, ora_lm_config *cfg, double *hist, int hist_r
     free(step); free(grad);
     return status;
 }
+
+/* ------------------------------------------------------------------------- */
+/* REFEREE: the exact step of the last linearisation, in __float128            */
+/* ------------------------------------------------------------------------- */
+/* NOT a restatement of reference code.  The reference solves S dc = g_red in fp64
+ * (solve_with_cholesky, explicit_schur.rs:539-634); on bundle adjustment the gauge is only damped,
+ * cond(S) is 1e9..1e10, and two correct fp64 solvers differ by eps*cond.  "The device step matches the
+ * reference" can then only mean: the device step is as close to the EXACT solution of the reference's
+ * equations as the reference's own fp64 path is.  This function supplies that exact solution:
+ *
+ *   inputs   the fp64 residuals and Jacobian blocks of the last ora_linearize / ora_set_linearization
+ *            (scaled by the Jacobi column scaling in fp64 when one is set, exactly as the fp64 path does)
+ *   exact    H = J^T J, g = J^T r, Hll + lambda I (+ the eigenvalue gate's regularisation, DECIDED in fp64
+ *            exactly as ora_invert_landmark_blocks decides it, explicit_schur.rs:377-442), its inverse,
+ *            S = Hcc + lambda I - sum W Hll^-1 W^T, g_red, all accumulated in __float128 (113-bit
+ *            significand: products of two doubles are exact, sums lose ~1e-34 relative)
+ *   solve    fp64 Cholesky of the rounded S as the preconditioner of an iterative refinement whose residual
+ *            g_red - S x is formed in __float128, run until it stalls below 1e-28 |g_red|
+ *   output   dc and the back-substituted dl, rounded to fp64 once at the end, reference global column order.
+ *
+ * No regularisation ladder: the referee is defined only where the undamped-ladder factorisation succeeds
+ * (every parity case); otherwise ORA_ERR_FACTORIZATION.  info (optional, 4 doubles): refinement sweeps,
+ * final |residual| / |g_red|, first-sweep |correction| / |x| (= the forward error of the plain fp64 solve of
+ * the rounded S), number of landmark blocks the gate regularised. */
+typedef __float128 q128;
+
+static int q_inv3(const q128 m[9], q128 o[9]) {
+    q128 c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    q128 det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    if (det == 0) return 0;
+    o[0] = c00 / det; o[1] = (m[2] * m[7] - m[1] * m[8]) / det; o[2] = (m[1] * m[5] - m[2] * m[4]) / det;
+    o[3] = c01 / det; o[4] = (m[0] * m[8] - m[2] * m[6]) / det; o[5] = (m[2] * m[3] - m[0] * m[5]) / det;
+    o[6] = c02 / det; o[7] = (m[1] * m[6] - m[0] * m[7]) / det; o[8] = (m[0] * m[4] - m[1] * m[3]) / det;
+    return 1;
+}
+
+/* replace the stored linearisation (e.g. by the blocks a device exported): the referee then judges a solver on ITS
+ * OWN equations.  Row order = observation order; Jpose n_obs x 2 x 6, Jpt / Jintr n_obs x 2 x 3, r n_obs x 2. */
+void ora_set_linearization(ora_problem *p, const double *r, const double *Jpose, const double *Jpt, const double *Jintr) {
+    memcpy(p->r, r, (size_t)p->n_obs * 16);
+    memcpy(p->Jpose, Jpose, (size_t)p->n_obs * 96);
+    memcpy(p->Jpt, Jpt, (size_t)p->n_obs * 48);
+    if (Jintr) memcpy(p->Jintr, Jintr, (size_t)p->n_obs * 48); else memset(p->Jintr, 0, (size_t)p->n_obs * 48);
+}
+
+int ora_solve_augmented_quad(ora_problem *p, double lambda, double *step_out, double *info) {
+    const int64_t nc = p->cam_dof, npt = p->n_pt, nobs = p->n_obs, land0 = nc;
+    const int has_intr = ora_mode_mask(p->mode) & 1;
+    if (nc > 6000 || nobs > 4000000) return ORA_ERR_INPUT;   /* dense quad S: 16 nc^2 bytes */
+    /* per observation: the 9 camera-side columns (global column, 2 values) and the 3 landmark columns, scaled in fp64 */
+    double *Jc = (double *)malloc((size_t)nobs * 18 * 8 + 8), *Jl = (double *)malloc((size_t)nobs * 6 * 8 + 8);
+    int64_t *col = (int64_t *)malloc((size_t)nobs * 9 * 8 + 8);
+    for (int64_t i = 0; i < nobs; ++i) {
+        uint32_t c = p->cam_idx[i], l = p->pt_idx[i];
+        for (int a = 0; a < 9; ++a) {
+            int64_t cc = (a < 6) ? p->pose_col[c] + a : p->intr_col[c] + (a - 6);
+            double s = p->scaling ? p->scaling[cc] : 1.0;
+            for (int rr = 0; rr < 2; ++rr) {
+                double v = (a < 6) ? p->Jpose[12 * i + 6 * rr + a] : (has_intr ? p->Jintr[6 * i + 3 * rr + (a - 6)] : 0.0);
+                Jc[18 * i + 2 * a + rr] = p->scaling ? v * s : v;
+            }
+            col[9 * i + a] = cc;
+        }
+        for (int a = 0; a < 3; ++a) {
+            double s = p->scaling ? p->scaling[p->pt_col[l] + a] : 1.0;
+            for (int rr = 0; rr < 2; ++rr) Jl[6 * i + 2 * a + rr] = p->scaling ? p->Jpt[6 * i + 3 * rr + a] * s : p->Jpt[6 * i + 3 * rr + a];
+        }
+    }
+    q128 *S = (q128 *)calloc((size_t)nc * (size_t)nc, sizeof(q128));
+    q128 *gc = (q128 *)calloc((size_t)nc, sizeof(q128));        /* -g_c, then g_red */
+    q128 *Hinv = (q128 *)malloc((size_t)npt * 9 * sizeof(q128));
+    q128 *gl = (q128 *)calloc((size_t)npt * 3, sizeof(q128));    /* -g_l */
+    q128 *W = (q128 *)malloc((size_t)nobs * 27 * sizeof(q128) + 16);
+    double *A = (double *)malloc((size_t)nc * (size_t)nc * 8);
+    int rc = ORA_OK;
+    int64_t n_reg = 0;
+    if (!S || !gc || !Hinv || !gl || !W || !A) rc = ORA_ERR_INPUT;
+    if (rc == ORA_OK) {
+        /* Hcc, g_c, W_i = Jc_i^T Jl_i (9 x 3), exact products, quad sums */
+        for (int64_t i = 0; i < nobs; ++i) {
+            const double *jc = Jc + 18 * i, *jl = Jl + 6 * i, *r = p->r + 2 * i;
+            const int64_t *cl = col + 9 * i;
+            for (int a = 0; a < 9; ++a) {
+                for (int b = 0; b < 9; ++b)
+                    S[cl[a] * nc + cl[b]] += (q128)jc[2 * a] * jc[2 * b] + (q128)jc[2 * a + 1] * jc[2 * b + 1];
+                gc[cl[a]] -= (q128)jc[2 * a] * r[0] + (q128)jc[2 * a + 1] * r[1];
+                for (int b = 0; b < 3; ++b)
+                    W[27 * i + 3 * a + b] = (q128)jc[2 * a] * jl[2 * b] + (q128)jc[2 * a + 1] * jl[2 * b + 1];
+            }
+        }
+        for (int64_t i = 0; i < nc; ++i) S[i * nc + i] += lambda;
+        /* landmark blocks: exact Hll + lambda, the gate decided on the fp64 block the fp64 path builds */
+        for (int64_t l = 0; l < npt && rc == ORA_OK; ++l) {
+            q128 H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int64_t k = p->pt_ptr[l]; k < p->pt_ptr[l + 1]; ++k) {
+                int64_t i = p->pt_obs[k];
+                const double *jl = Jl + 6 * i, *r = p->r + 2 * i;
+                for (int a = 0; a < 3; ++a) {
+                    for (int b = 0; b < 3; ++b) {
+                        H[3 * a + b] += (q128)jl[2 * a] * jl[2 * b] + (q128)jl[2 * a + 1] * jl[2 * b + 1];
+                        B[3 * a + b] += jl[2 * a] * jl[2 * b] + jl[2 * a + 1] * jl[2 * b + 1];
+                    }
+                    gl[3 * l + a] -= (q128)jl[2 * a] * r[0] + (q128)jl[2 * a + 1] * r[1];
+                }
+            }
+            B[0] += lambda; B[4] += lambda; B[8] += lambda;
+            H[0] += lambda; H[4] += lambda; H[8] += lambda;
+            double ev[3];
+            sym3_eigenvalues(B, ev);
+            double mn = fmin(ev[0], fmin(ev[1], ev[2])), mx = fmax(ev[0], fmax(ev[1], ev[2]));
+            double reg = 0.0;
+            if (mn < 1e-12) reg = 1e-6 + mx * 1e-6;
+            else if (mx / mn > 1e10) reg = mx * 1e-6;
+            if (reg != 0.0) { H[0] += reg; H[4] += reg; H[8] += reg; ++n_reg; }
+            if (!q_inv3(H, Hinv + 9 * l)) rc = ORA_ERR_SINGULAR;
+        }
+    }
+    if (rc == ORA_OK) {
+        /* S -= W_i Hinv W_j^T over all ordered pairs of a landmark's observations (i == j included), g_red.
+         * Parallel over landmarks would race on S: parallel over the ROW observation's camera instead -- every thread
+         * owns the S rows of a residue class of cameras. */
+#pragma omp parallel
+        {
+            int nth = 1, tid = 0;
+#ifdef _OPENMP
+            extern int omp_get_num_threads(void); extern int omp_get_thread_num(void);
+            nth = omp_get_num_threads(); tid = omp_get_thread_num();
+#endif
+            for (int64_t l = 0; l < npt; ++l) {
+                const q128 *Hi = Hinv + 9 * l;
+                for (int64_t k = p->pt_ptr[l]; k < p->pt_ptr[l + 1]; ++k) {
+                    const int64_t i = p->pt_obs[k];
+                    if ((int)(p->cam_idx[i] % (uint32_t)nth) != tid) continue;
+                    q128 Y[27];   /* W_i Hinv */
+                    for (int a = 0; a < 9; ++a)
+                        for (int b = 0; b < 3; ++b)
+                            Y[3 * a + b] = W[27 * i + 3 * a] * Hi[b] + W[27 * i + 3 * a + 1] * Hi[3 + b] + W[27 * i + 3 * a + 2] * Hi[6 + b];
+                    for (int a = 0; a < 9; ++a)
+                        gc[col[9 * i + a]] -= Y[3 * a] * gl[3 * l] + Y[3 * a + 1] * gl[3 * l + 1] + Y[3 * a + 2] * gl[3 * l + 2];
+                    for (int64_t k2 = p->pt_ptr[l]; k2 < p->pt_ptr[l + 1]; ++k2) {
+                        const int64_t j = p->pt_obs[k2];
+                        for (int a = 0; a < 9; ++a) {
+                            q128 *Srow = S + col[9 * i + a] * nc;
+                            for (int b = 0; b < 9; ++b)
+                                Srow[col[9 * j + b]] -= Y[3 * a] * W[27 * j + 3 * b] + Y[3 * a + 1] * W[27 * j + 3 * b + 1] + Y[3 * a + 2] * W[27 * j + 3 * b + 2];
+                        }
+                    }
+                }
+            }
+        }
+        for (int64_t i = 0; i < nc * nc; ++i) A[i] = (double)S[i];
+        if (dense_llt(nc, A) != 0) rc = ORA_ERR_FACTORIZATION;
+    }
+    double sweeps = 0.0, rel_res = 0.0, first_corr = 0.0;
+    if (rc == ORA_OK) {
+        q128 *x = (q128 *)calloc((size_t)nc, sizeof(q128)), *res = (q128 *)malloc((size_t)nc * sizeof(q128));
+        double *d = (double *)malloc((size_t)nc * 8);
+        double gn = 0.0;
+        for (int64_t i = 0; i < nc; ++i) { res[i] = gc[i]; gn += (double)gc[i] * (double)gc[i]; }
+        gn = sqrt(gn);
+        double prev = 1e300;
+        for (int it = 0; it < 40; ++it) {
+            /* scale the residual so that its fp64 image keeps full relative precision however small it has become */
+            double rn = 0.0;
+            for (int64_t i = 0; i < nc; ++i) rn = fmax(rn, fabs((double)res[i]));
+            if (rn == 0.0) break;
+            for (int64_t i = 0; i < nc; ++i) d[i] = (double)(res[i] / rn);
+            dense_llt_solve(nc, A, d);
+            double dn = 0.0, xn = 0.0;
+            for (int64_t i = 0; i < nc; ++i) { x[i] += (q128)d[i] * rn; dn += d[i] * d[i] * rn * rn; xn += (double)x[i] * (double)x[i]; }
+            if (it == 1) first_corr = sqrt(dn) / fmax(sqrt(xn), 1e-300);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < nc; ++i) {
+                q128 s = gc[i];
+                const q128 *Si = S + i * nc;
+                for (int64_t j = 0; j < nc; ++j) s -= Si[j] * x[j];
+                res[i] = s;
+            }
+            double r2 = 0.0;
+            for (int64_t i = 0; i < nc; ++i) r2 += (double)res[i] * (double)res[i];
+            rel_res = sqrt(r2) / fmax(gn, 1e-300);
+            sweeps = it + 1;
+            if (rel_res < 1e-28 || rel_res > 0.5 * prev) break;
+            prev = rel_res;
+        }
+        /* back-substitution (explicit_schur.rs:980-1029) in quad; output rounded once */
+        for (int64_t i = 0; i < nc; ++i) step_out[i] = (double)x[i];
+        for (int64_t l = 0; l < npt; ++l) {
+            q128 rhs[3] = {gl[3 * l], gl[3 * l + 1], gl[3 * l + 2]};
+            for (int64_t k = p->pt_ptr[l]; k < p->pt_ptr[l + 1]; ++k) {
+                const int64_t i = p->pt_obs[k];
+                for (int a = 0; a < 9; ++a)
+                    for (int b = 0; b < 3; ++b) rhs[b] -= W[27 * i + 3 * a + b] * x[col[9 * i + a]];
+            }
+            const q128 *Hi = Hinv + 9 * l;
+            const int64_t lc = p->pt_col[l];
+            for (int a = 0; a < 3; ++a) step_out[lc + a] = (double)(Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2]);
+        }
+        (void)land0;
+        free(x); free(res); free(d);
+    }
+    if (info) { info[0] = sweeps; info[1] = rel_res; info[2] = first_corr; info[3] = (double)n_reg; }
+    free(Jc); free(Jl); free(col); free(S); free(gc); free(Hinv); free(gl); free(W); free(A);
+    return rc;
+}

@@ -125,6 +125,9 @@ def lib(native: bool = False):
     L.ora_linearize.restype = C.c_double
     L.ora_solve_augmented.argtypes = [vp, C.c_double, C.c_int, _f64p, _f64p, vp, vp]
     L.ora_solve_augmented.restype = C.c_int
+    L.ora_solve_augmented_quad.argtypes = [vp, C.c_double, _f64p, _OptF64]
+    L.ora_solve_augmented_quad.restype = C.c_int
+    L.ora_set_linearization.argtypes = [vp, _f64p, _f64p, _f64p, _OptF64]
     L.ora_column_norms.argtypes = [vp, _f64p]
     L.ora_column_norms.restype = C.c_int
     L.ora_set_column_scaling.argtypes = [vp, _OptF64]
@@ -249,6 +252,23 @@ class OracleProblem:
         if rc != 0:
             raise RuntimeError(f"oracle solve_augmented failed: {rc}")
         return (step, grad, S, gred) if want_schur else (step, grad)
+
+    def solve_augmented_quad(self, lam: float):
+        """REFEREE (ba_oracle.c, ora_solve_augmented_quad): the exact step of the last linearisation's damped normal
+        equations -- H, Hll^-1, S, g_red accumulated in __float128, the solve refined with __float128 residuals -- rounded
+        to fp64 once.  Returns (step, info) with info = dict(sweeps, residual, fp64_forward_error, regularised_blocks)."""
+        step = np.zeros(self.total_dof); info = np.zeros(4)
+        rc = self._L.ora_solve_augmented_quad(self._h, float(lam), step, info)
+        if rc != 0:
+            raise RuntimeError(f"oracle referee failed: {rc}")
+        return step, dict(sweeps=int(info[0]), residual=float(info[1]), fp64_forward_error=float(info[2]),
+                          regularised_blocks=int(info[3]))
+
+    def set_linearization(self, r, Jpose, Jpt, Jintr=None):
+        """Replace the stored linearisation (e.g. by the blocks a device exported): the referee then judges a solver on
+        its own equations.  Shapes: r (n_obs, 2), Jpose (n_obs, 2, 6), Jpt / Jintr (n_obs, 2, 3)."""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self._L.ora_set_linearization(self._h, f(r), f(Jpose), f(Jpt), None if Jintr is None else f(Jintr))
 
     def column_norms(self) -> np.ndarray:
         """compute_column_norms of the last linearisation (linearizer/mod.rs:229-239)."""

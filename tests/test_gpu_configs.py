@@ -19,6 +19,7 @@ import pytest
 
 import apex_solver_amd as pkg
 import np_ref
+import referee
 from apex_solver_amd.solver import GpuSchurComplementSolver, OptimizationType, Problem, SchurVariant
 
 pytestmark = pytest.mark.gpu
@@ -111,6 +112,7 @@ def oracle_sample_check(oracle, shape, scale, mode, variant=0, cg=None):
         print(f"{d.name} vs oracle:", {k: f"{v:.1e}" for k, v in errs.items()}, f"backward {bwd:.1e}")
         assert errs["grad"] < 1e-12 and errs["S"] < 1e-12 and errs["gred"] < 1e-10
         assert bwd < 1e-13 and errs["step"] < 1e-7
+        referee.check_step(o, s, step, ostep, lam, 9 if mode == "selfcal" else 6, label=d.name)
     else:
         istep, _ = o.solve_augmented(lam, 2)
         it_g, it_o = s.info()["pcg_iterations"], o.last_pcg_iters
@@ -294,6 +296,12 @@ def test_hub_shape_vs_oracle(oracle, mode):
         print("hubs_last", hubs_last, {k: f"{v:.1e}" for k, v in errs.items()}, f"backward {bwd:.1e}")
         assert errs["S"] < 1e-12 and errs["gred"] < 1e-10 and errs["grad"] < 1e-12
         assert bwd < 1e-13 and errs["step"] < 1e-7
+        if hubs_last == 1:
+            exact, qinfo = o.solve_augmented_quad(lam)
+            e_gpu, e_64 = rel(step, exact), rel(ostep, exact)
+            print(f"referee hub {mode}: |gpu - exact| {e_gpu:.2e}  |fp64 oracle - exact| {e_64:.2e}")
+            referee.RECORD.append((f"hub {mode}", e_gpu, e_64))
+            assert qinfo["residual"] < 1e-26 and e_gpu <= referee.FP64_ENVELOPE, (e_gpu, e_64)
 
 
 def test_hub_full_size_properties():

@@ -10,6 +10,7 @@ import pytest
 
 import apex_solver_amd as pkg
 import np_ref
+import referee
 from apex_solver_amd.solver import (GpuSchurComplementSolver, LevenbergMarquardt, LevenbergMarquardtConfig,
                                     OptimizationStatus, OptimizationType, Problem, SchurVariant)
 
@@ -80,11 +81,23 @@ def test_golden_fixture_iterations(path):
         assert rel(jp, g[f"it{it}_Jpose"]) < 1e-12 and rel(jl, g[f"it{it}_Jpt"]) < 1e-12
         if dc == 9:
             assert rel(ji, g[f"it{it}_Jintr"]) < 1e-12
+        # well-conditioned regime first (lambda = 1e4, cond(S) <= 1e5, fixtures' it*_wc_*): the north star's 1e-10 directly
+        wstep = s.solve_augmented_equation(float(g[f"it{it}_wc_lambda"]))
+        wS, wgred = s.get_schur()
+        werr = dict(S=rel(wS, g[f"it{it}_wc_S"]), gred=rel(wgred, g[f"it{it}_wc_gred"]), step=rel(wstep, g[f"it{it}_wc_step"]),
+                    step_exact=rel(wstep, g[f"it{it}_wc_step_exact"]))
+        print(os.path.basename(path), "iter", it, "lambda 1e4:", {k: f"{v:.1e}" for k, v in werr.items()})
+        assert werr["S"] < 1e-12 and werr["gred"] < 1e-11 and werr["step"] < referee.NORTH_STAR and werr["step_exact"] < referee.NORTH_STAR
         step = s.solve_augmented_equation(lam)
         grad = s.get_gradient()
         S, gred = s.get_schur()
         errs = dict(grad=rel(grad, g[f"it{it}_grad"]), S=rel(S, g[f"it{it}_S"]), gred=rel(gred, g[f"it{it}_gred"]),
                     step=rel(step, g[f"it{it}_step"]))
+        # the referee: the device against the EXACT step of the fixture's linearisation, next to the fp64 oracle's error
+        e_gpu, e_64 = rel(step, g[f"it{it}_step_exact"]), rel(g[f"it{it}_step"], g[f"it{it}_step_exact"])
+        print(os.path.basename(path), "iter", it, f"referee: |gpu - exact| {e_gpu:.2e}  |fp64 oracle - exact| {e_64:.2e}")
+        referee.RECORD.append((f"{os.path.basename(path)[:-4]} it{it}", e_gpu, e_64))
+        assert e_gpu <= referee.FP64_ENVELOPE, (e_gpu, e_64)
         print(os.path.basename(path), "iter", it, {k: f"{v:.1e}" for k, v in errs.items()})
         assert errs["grad"] < 1e-12 and errs["S"] < 1e-12 and errs["gred"] < 1e-11
         # The step is held to (i) a normwise backward error of 1e-13 on S dc = g_red and (ii) a FIXED forward bound of
@@ -151,9 +164,16 @@ def test_one_iteration_vs_oracle(oracle, mode, shape):
     # ... and the step agrees with the oracle's within the fixed forward bound (north star: 1e-10 where cond(S) allows)
     print("step vs oracle", errs["step"], "cond(S)", np.linalg.cond(oS), "meets 1e-10:", errs["step"] < 1e-10)
     assert errs["step"] < STEP_FORWARD_BOUND, errs["step"]
+    # ... and, the actual pass/fail line: as close to the EXACT step as the fp64 oracle is (tests/referee.py)
+    dc = 9 if mode == "selfcal" else 6
+    referee.check_step(o, s, step, ostep, lam, dc, label=f"{mode} {shape}")
     # trial point
     o.apply_step(ostep, 1.0)
     assert s.eval_step() == pytest.approx(o.residuals()[0], rel=1e-9)
+    s.discard_step()
+    o.apply_step(ostep, -1.0); o.linearize()
+    # well-conditioned regime: 1e-10 against the fp64 oracle outright
+    referee.check_well_conditioned(o, s, dc, label=f"{mode} {shape}")
     s.close()
 
 
@@ -327,6 +347,9 @@ def test_ragged_landmarks(oracle, mode):
     nc = prob.layout.cam_dof
     bwd = np.linalg.norm(oS @ step[:nc] - ogred) / (np.linalg.norm(oS, 2) * np.linalg.norm(step[:nc]) + np.linalg.norm(ogred))
     assert bwd < 1e-13 and errs["step"] < STEP_FORWARD_BOUND, (bwd, errs["step"])
+    dc = 9 if mode == "selfcal" else 6
+    referee.check_step(o, s, step, ostep, 1e-3, dc, label=f"ragged {mode}")
+    referee.check_well_conditioned(o, s, dc, label=f"ragged {mode}")
     s.close()
 
 
@@ -418,6 +441,10 @@ def test_cheirality_and_no_loss(oracle):
         hinv, gl = s.get_landmark_blocks()
         assert np.isfinite(S).all() and np.isfinite(step).all()
         assert np.abs(S - oS).max() / scale < 1e-6
+        # the step itself: against the exact step of this linearisation, next to the fp64 oracle's error, and at
+        # lambda = 1e4 against the fp64 oracle outright
+        referee.check_step(o, s, step, ostep, 1e-3, 9, label=f"cheirality huber={huber}")
+        referee.check_well_conditioned(o, s, 9, label=f"cheirality huber={huber}")
         s.close()
 
 
@@ -582,6 +609,9 @@ def test_jacobi_scaling_one_iteration_vs_oracle(oracle, mode):
     nc = prob.layout.cam_dof
     bwd = np.linalg.norm(oS @ y[:nc] - ogred) / (np.linalg.norm(oS, 2) * np.linalg.norm(y[:nc]) + np.linalg.norm(ogred))
     assert bwd < 1e-13 and errs["step"] < tol, (bwd, errs["step"], tol)
+    # referee on the SCALED system (the oracle scales its blocks in fp64 exactly as apply_column_scaling does; the device's
+    # exported blocks are unscaled, so only the oracle's linearisation is refereed here)
+    referee.check_step(o, s, y, oy, lam, 9 if mode == "selfcal" else 6, label=f"jacobi scaling {mode}", own=False)
     # compute_step_generic (levenberg_marquardt.rs:746-760): |scaled gradient|, |unscaled step|,
     # predicted reduction from the unscaled step and the scaled gradient
     ostep = oy * scal
