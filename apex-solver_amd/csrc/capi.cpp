@@ -240,8 +240,13 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "schur_form") h->s->use_row_schur(value);   /* alias of "schur_rows": 3 sorted pair list (default), 2 / 1 LDS rows, 0 global atomics */
     else if (n == "rows_debug") h->s->set_rows_debug(value);
-    else if (n == "pairs_ablation") apex::set_pairs_ablation(value);   /* timing experiments only */
-    else if (n == "pairs_variant") apex::set_pairs_variant(value);
+    else if (n == "pairs_ablation") {   /* timing experiments only: the results are WRONG when != 0, so the switch exists only */
+        if (value != 0 && !getenv("APEX_ALLOW_ABLATION")) return APEXGPU_ERR_INVALID_INPUT;   /* for a process that asks for it */
+        h->s->set_pairs_ablation(value);
+    }
+    else if (n == "pairs_variant") h->s->set_pairs_variant(value);
+    else if (n == "debug_poison_sweep") h->s->debug_poison_next_solve(value);   /* tests: 1 / 2 = the next solve's forward / backward dataflow sweep times out */
+    else if (n == "debug_occupy_cus") return h->s->debug_occupy_cus(value, 40000);   /* tests: block `value` CUs for 40 ms, starting now */
     else if (n == "hubs_last") h->s->set_hubs_last(value != 0);
     else if (n == "pair_task_slots") h->s->set_pair_task_slots(value);
     else if (n == "dist_factor") h->s->set_dist_factor(value != 0);
@@ -277,6 +282,13 @@ int apexgpu_info(apexgpu_solver* h, double info[16]) {
     info[12] = h->s->dist_top_columns(); info[13] = h->s->dist_local_fraction();
     info[14] = h->s->tree_sharded() ? 1.0 : 0.0;
     info[15] = h->s->schur_form();
+    return APEXGPU_OK;
+}
+
+int apexgpu_counters(apexgpu_solver* h, int64_t out[4]) {
+    H_OR_FAIL;
+    if (!out) return APEXGPU_ERR_INVALID_INPUT;
+    out[0] = h->s->sweep_timeouts(); out[1] = h->s->plan().tri_flow() ? 1 : 0; out[2] = 0; out[3] = 0;
     return APEXGPU_OK;
 }
 
@@ -502,6 +514,7 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);
+    else if (n == "debug_poison_sweep") h->s->debug_poison_next_solve(value);
     else return APEXGPU_ERR_INVALID_INPUT;
     return APEXGPU_OK;
 }
@@ -510,6 +523,12 @@ int apexgpu_pg_reset_stage_times(apexgpu_pg_solver* h) { PG_OR_FAIL; h->s->reset
 int apexgpu_pg_stage_times(apexgpu_pg_solver* h, double ms[APEXGPU_PG_NUM_STAGES], int64_t calls[APEXGPU_PG_NUM_STAGES]) {
     PG_OR_FAIL;
     h->s->stage_times(ms, calls);
+    return APEXGPU_OK;
+}
+int apexgpu_pg_counters(apexgpu_pg_solver* h, int64_t out[4]) {
+    PG_OR_FAIL;
+    if (!out) return APEXGPU_ERR_INVALID_INPUT;
+    out[0] = h->s->sweep_timeouts(); out[1] = h->s->plan().tri_flow() ? 1 : 0; out[2] = 0; out[3] = 0;
     return APEXGPU_OK;
 }
 int apexgpu_pg_info(apexgpu_pg_solver* h, double info[8]) {

@@ -54,8 +54,13 @@ void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s);
 void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 1 / 6 / 8 k_potrf_inv_la with 4 / 6 / 8 waves (default 8)
 // batches of <= 56 tasks use the latency kernels, larger ones the 3 x 3-wave strip kernel
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s);
+// poison_block >= 0 (tests only): that block's counter is made unreachable after the flags are cleared, so the task that
+// waits for it runs into the spin limit -- the time-out path (error word raised, wrong result) on demand
 void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const double* in, double* out, double* part, int* flags,
-                     int nt, hipStream_t s, const double* fold_b, double* fold_out);
+                     int nt, hipStream_t s, const double* fold_b, double* fold_out, int poison_block = -1);
+// tests only: n workgroups that each take a whole CU's LDS (nothing else that needs LDS fits beside them) and spin for
+// `micros`; *started (host-visible) counts the workgroups that are resident
+void launch_occupy_cus(int n, int micros, int* started, hipStream_t s);
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s);
 void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double* diag, hipStream_t s);
 void launch_tile_add_diag(double* tiles, const int* diag_slot, int n_valid, int n_total, double add_valid,

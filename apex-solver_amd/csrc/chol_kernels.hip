@@ -910,8 +910,9 @@ __global__ __launch_bounds__(256) void k_tri_step(const TriTask* __restrict__ ta
 __device__ __forceinline__ double flow_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void flow_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // A wait is bounded: the scheme rests on workgroups being dispatched in blockIdx order; should that ever fail, a workgroup
-// gives up after ~2 s of polling, raises the error word (read back with the next factorisation's pivot flag) and lets the
-// launch end with a wrong result instead of hanging the device.
+// gives up after ~2 s of polling, raises the error word and lets the launch end with a wrong result instead of hanging the
+// device.  TilePlan::solve posts the error word to the host behind the sweeps and the caller reads it at its next
+// synchronisation (sweep_timed_out()): the solve the time-out belongs to is repeated with the level-by-level sweeps.
 constexpr int kFlowSpinLimit = 1 << 21;
 __device__ __forceinline__ void flow_wait(const int* flag, int want, int tid, int* err) {
     if (tid == 0) {
@@ -1354,11 +1355,28 @@ void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, dou
     if (trans) hipLaunchKernelGGL(k_tri_step<true>, dim3(grid), dim3(256), 0, s, tasks, n, vwork, vout);
     else hipLaunchKernelGGL(k_tri_step<false>, dim3(grid), dim3(256), 0, s, tasks, n, vwork, vout);
 }
+__global__ __launch_bounds__(256) void k_occupy_cu(long long ticks_100mhz, int* started) {
+    __shared__ char hog[156 * 1024];   // the CU's LDS: no workgroup that needs more than 4 KB fits beside this one
+    if (threadIdx.x == 0) {
+        hog[blockIdx.x & 1023] = 1;
+        __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+        while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(32);
+        if (hog[(blockIdx.x + 7) & 1023] == 77) started[1] = 1;   // (keeps the array alive)
+    }
+    __syncthreads();
+}
+void launch_occupy_cus(int n, int micros, int* started, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_occupy_cu, dim3(n), dim3(256), 0, s, (long long)micros * 100, started);
+}
+
 void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const double* in, double* out, double* part, int* flags,
-                     int nt, hipStream_t s, const double* fold_b, double* fold_out) {
+                     int nt, hipStream_t s, const double* fold_b, double* fold_out, int poison_block) {
     if (n_tasks <= 0) return;
     (void)hipMemsetAsync(flags, 0, (size_t)2 * nt * sizeof(int), s);   // cnt[nt] | done[nt]
-    int* err = flags + 2 * nt;   // (not cleared here: sticky until the plan reads it)
+    if (poison_block >= 0 && poison_block < nt)   // tests: INT_MIN never reaches the count the block's solve task waits for
+        (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flags + poison_block), (int)0x80000000, 1, s);
+    int* err = flags + 2 * nt;   // (not cleared here: sticky until the plan posts it to the host, TilePlan::solve)
     if (backward) hipLaunchKernelGGL(k_tri_bwd_flow, dim3(n_tasks), dim3(kBwdThreads), 0, s, tasks, in, out, part, flags, flags + nt, err);
     else hipLaunchKernelGGL(k_tri_fwd_flow, dim3(n_tasks), dim3(kFwdThreads), 0, s, tasks, in, out, part, flags, flags + nt, err, fold_b, fold_out);
 }

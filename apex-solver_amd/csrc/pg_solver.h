@@ -52,6 +52,8 @@ class PoseGraphSolver : public LmBackend {
     void enable_graphs(bool on) { tp_.enable_graphs(on); }
     void enable_overlap(bool on) { tp_.enable_overlap(on); }
     void enable_tri_flow(bool on) { tp_.enable_tri_flow(on); }
+    int sweep_timeouts() const { return tp_.sweep_timeouts(); }
+    void debug_poison_next_solve(int which) { tp_.debug_poison_next_solve(which); }
     void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }

@@ -195,27 +195,33 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
     HIP_TRY(tp_.factor(&failed, rhs_, work_));  // the forward sweep rides along
     timer_.end(kPgFactor, stream_);
     if (failed) return fail(kSingularMatrix, "Cholesky factorization failed (matrix may be singular)");
-    timer_.begin(kPgTriSolve, stream_);
-    HIP_TRY(tp_.solve(rhs_, d_, work_));
-    if (scaled_) launch_vec_mul(n_pad_, d_, scale_, d_, stream_);  // apply_inverse_scaling: step = D y
-    timer_.end(kPgTriSolve, stream_);
-    have_step_ = true;
-    if (step_out || grad_out) {
-        std::vector<double> h(n_);
-        for (int pass = 0; pass < 2; ++pass) {
-            double* out = pass == 0 ? step_out : grad_out;
-            if (!out) continue;
-            HIP_TRY(hipMemcpyAsync(h.data(), pass == 0 ? d_ : g_, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    for (int attempt = 0;; ++attempt) {
+        timer_.begin(kPgTriSolve, stream_);
+        HIP_TRY(tp_.solve(rhs_, d_, work_));
+        if (scaled_) launch_vec_mul(n_pad_, d_, scale_, d_, stream_);  // apply_inverse_scaling: step = D y
+        timer_.end(kPgTriSolve, stream_);
+        have_step_ = true;
+        if (step_out || grad_out) {
+            std::vector<double> h(n_);
+            for (int pass = 0; pass < 2; ++pass) {
+                double* out = pass == 0 ? step_out : grad_out;
+                if (!out) continue;
+                HIP_TRY(hipMemcpyAsync(h.data(), pass == 0 ? d_ : g_, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(hipStreamSynchronize(stream_));
+                if (scaled_)  // the caller's variables are the scaled ones: y = step / s, gradient = s g
+                    for (int64_t i = 0; i < n_; ++i) h[i] = pass == 0 ? h[i] / scale_h_[i] : h[i] * scale_h_[i];
+                for (int64_t v = 0; v < n_v_; ++v)
+                    for (int a = 0; a < 6; ++a) out[pose_col_[v] + a] = h[6 * (size_t)vmap_[v] + a];
+            }
+        } else {
             HIP_TRY(hipStreamSynchronize(stream_));
-            if (scaled_)  // the caller's variables are the scaled ones: y = step / s, gradient = s g
-                for (int64_t i = 0; i < n_; ++i) h[i] = pass == 0 ? h[i] / scale_h_[i] : h[i] * scale_h_[i];
-            for (int64_t v = 0; v < n_v_; ++v)
-                for (int a = 0; a < 6; ++a) out[pose_col_[v] + a] = h[6 * (size_t)vmap_[v] + a];
         }
-    } else {
-        HIP_TRY(hipStreamSynchronize(stream_));
+        if (!tp_.sweep_timed_out()) return kOk;
+        // a dataflow sweep of this solve gave up (chol_kernels.hip, flow_wait): repeat it level by level (Solver::solve_augmented)
+        have_step_ = false;
+        if (attempt > 0 || !tp_.tri_flow()) return fail(kDeviceError, "triangular sweep timed out");
+        tp_.enable_tri_flow(false);
     }
-    return kOk;
 }
 
 int PoseGraphSolver::step_stats(double out3[3]) {

@@ -64,9 +64,10 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
                       int task_slots = 0 /* 0: default */);
 
-void set_pairs_variant(int v);     // 0: one pair per lane, 1: one observation per lane (two lanes per pair)
-void set_pairs_ablation(int bits);   // timing experiments only: results are wrong when != 0
+// variant 0: one pair per lane, 1: one observation per lane (two lanes per pair, default); ablation: timing experiments
+// only (results are wrong when != 0)
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
-                        const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s);
+                        const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, int variant = 1,
+                        int ablation = 0);
 
 }  // namespace apex

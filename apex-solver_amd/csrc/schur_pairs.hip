@@ -433,11 +433,10 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
                     for (int a = 0; a < 3; ++a) { Jl[0][a] = pw[a]; Jl[1][a] = cv[a]; }
                 } else
                 linearize_pairside<DC>(cv, pw, dat.uvj.x, dat.uvj.y, v.huber_delta, Jcj, Jl);
-                const double sgn = valid ? -1.0 : 0.0;     // a padding slot contributes U = 0
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) M[n][m] = sgn * (N[n][0] * Jl[m][0] + N[n][1] * Jl[m][1] + N[n][2] * Jl[m][2]);
+                    for (int m = 0; m < 2; ++m) M[n][m] = -(N[n][0] * Jl[m][0] + N[n][1] * Jl[m][1] + N[n][2] * Jl[m][2]);
                 // V goes to its own LDS region straight away (it never overlaps the staged cameras); element order
                 // [sub-column bj][m][3]: V[m][3 bj + c]
                 double2* pv = reinterpret_cast<double2*>(V + lane * UV);
@@ -445,14 +444,16 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BAView v, double* __restric
                 for (int k = 0; k < DC; ++k) {
                     const int e0 = 2 * k, e1 = 2 * k + 1;
                     const int s0 = e0 / 6, m0 = (e0 % 6) / 3, c0 = e0 % 3, s1 = e1 / 6, m1 = (e1 % 6) / 3, c1 = e1 % 3;
-                    if (!(ABL & 16) || k == 0) pv[k] = make_double2(Jcj[m0][3 * s0 + c0], Jcj[m1][3 * s1 + c1]);
+                    // (a padding slot contributes exact zeros on both sides, by selection: see k_schur_pairs_h)
+                    if (!(ABL & 16) || k == 0) pv[k] = make_double2(valid ? Jcj[m0][3 * s0 + c0] : 0.0, valid ? Jcj[m1][3 * s1 + c1] : 0.0);
                     else asm volatile("" ::"v"(Jcj[m0][3 * s0 + c0]), "v"(Jcj[m1][3 * s1 + c1]));
                 }
             }
 #pragma unroll
             for (int e = 0; e < UV; ++e) {   // U[m][3 bi + c] in the order [bi][m][3]
                 const int s0 = e / 6, m = (e % 6) / 3, c = e % 3;
-                u[e] = Jci[0][3 * s0 + c] * M[0][m] + Jci[1][3 * s0 + c] * M[1][m];
+                const double uv = Jci[0][3 * s0 + c] * M[0][m] + Jci[1][3 * s0 + c] * M[1][m];
+                u[e] = valid ? uv : 0.0;
             }
         }
         // every lane has read its cameras (program order, one wave): U may now overwrite the staging area
@@ -635,23 +636,25 @@ __global__ __launch_bounds__(256, 3) void k_schur_pairs_h(BAView v, double* __re
 #pragma unroll
                 for (int m = 0; m < 2; ++m) Q[a][m] = dpp_swap1(Q[a][m]);
             double out[UV];
+            // A padding slot (and the filler slot of an odd block) contributes EXACT zeros on both sides, by selection: its
+            // lanes linearised element 0 against an unrelated camera, and 0 * (a non-finite value) would poison the block.
             if (side == 0) {
-                const double sgn = valid ? -1.0 : 0.0;     // a padding slot contributes U = 0
                 double M[2][2];
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) M[n][m] = sgn * (Jl[n][0] * Q[0][m] + Jl[n][1] * Q[1][m] + Jl[n][2] * Q[2][m]);
+                    for (int m = 0; m < 2; ++m) M[n][m] = -(Jl[n][0] * Q[0][m] + Jl[n][1] * Q[1][m] + Jl[n][2] * Q[2][m]);
 #pragma unroll
                 for (int e = 0; e < UV; ++e) {   // U[m][3 bi + c] in the order [bi][m][3]
                     const int s0 = e / 6, m = (e % 6) / 3, c = e % 3;
-                    out[e] = Jc[0][3 * s0 + c] * M[0][m] + Jc[1][3 * s0 + c] * M[1][m];
+                    const double uv = Jc[0][3 * s0 + c] * M[0][m] + Jc[1][3 * s0 + c] * M[1][m];
+                    out[e] = valid ? uv : 0.0;
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < UV; ++e) {   // V[m][3 bj + c] in the order [bj][m][3]
                     const int s0 = e / 6, m = (e % 6) / 3, c = e % 3;
-                    out[e] = Jc[m][3 * s0 + c];
+                    out[e] = valid ? Jc[m][3 * s0 + c] : 0.0;
                 }
             }
             __builtin_amdgcn_wave_barrier();   // the previous half's products are done with U / V (one wave: program order)
@@ -719,15 +722,14 @@ __global__ __launch_bounds__(256, 3) void k_schur_pairs_h(BAView v, double* __re
     if (cur >= 0) pairs_flush<DC>(tiles, cur_dst, cur_flags, acc, lane);
 }
 
-static int g_pairs_ablation = 0;   // timing experiments only (tools/schur_bench.py --abl)
-void set_pairs_ablation(int bits) { g_pairs_ablation = bits; }
-static int g_pairs_variant = 1;    // 1 (default): one observation per lane (k_schur_pairs_h); 0: one pair per lane (k_schur_pairs)
-void set_pairs_variant(int vv) { g_pairs_variant = vv; }
-
+// variant: 1 (default) one observation per lane (k_schur_pairs_h); 0: one pair per lane (k_schur_pairs).
+// ablation: timing experiments only (tools/schur_bench.py --abl; results are WRONG when != 0).  Both are per-solver
+// state handed in by the caller: nothing process-wide that one handle could leave behind for the next.
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
-                        const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s) {
+                        const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, int variant, int ablation) {
     if (n_tasks == 0) return;
     const unsigned grid = (unsigned)((n_tasks + 3) / 4);
+    const int g_pairs_variant = variant, g_pairs_ablation = ablation;
     if (g_pairs_variant == 1 && g_pairs_ablation == 0) {
         if (dc == 9) hipLaunchKernelGGL((k_schur_pairs_h<9>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec);
         else hipLaunchKernelGGL((k_schur_pairs_h<6>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec);

@@ -86,6 +86,11 @@ class Solver : public LmBackend {
     void enable_graphs(bool on) { use_graphs_ = on; tp_.enable_graphs(on); }
     void enable_overlap(bool on) { tp_.enable_overlap(on); }
     void enable_tri_flow(bool on) { tp_.enable_tri_flow(on); }
+    void set_pairs_variant(int v) { pairs_variant_ = v; }       // pair kernel: 1 two lanes per pair (default), 0 one pair per lane
+    void set_pairs_ablation(int bits) { pairs_ablation_ = bits; }   // timing experiments only (results are wrong when != 0)
+    int sweep_timeouts() const { return tp_.sweep_timeouts(); }   // dataflow sweeps that gave up and were repeated level by level
+    void debug_poison_next_solve(int which) { tp_.debug_poison_next_solve(which); }
+    int debug_occupy_cus(int n_cus, int micros) { return check_hip(tp_.debug_occupy_cus(n_cus, micros), "debug_occupy_cus"); }
     void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
@@ -193,6 +198,7 @@ class Solver : public LmBackend {
     int* nbr_ = nullptr;
     int n_rtasks_ = 0;
     int rows_dbg_ = 0;      // timing-only ablation switches of k_schur_rows (results are wrong when != 0)
+    int pairs_variant_ = 1, pairs_ablation_ = 0;   // k_schur_pairs: lane mapping; timing-only ablation bits (wrong results when != 0)
     bool use_rows_ = true;  // Schur reduction: LDS row form (default) or the global-atomics form
     uint32_t *o_cam_ = nullptr, *o_pt_ = nullptr, *co_pt_ = nullptr;
     double2* co_uv_ = nullptr;

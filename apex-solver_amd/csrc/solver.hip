@@ -468,7 +468,7 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     stage_end(kStAssembleCam);
     stage_begin(kStScatter);
     if (use_rows_ && rows_form_ == 3)
-        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_);
+        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, pairs_variant_, pairs_ablation_);
     else if (use_rows_ && rows_form_ == 2 && rows_dbg_ == 0)
         launch_schur_rows2(dc_, v, tm, rtasks2_, n_rtasks_, rchunks_, rentries_, nbr_, hinv_, stream_);
     else if (use_rows_)
@@ -664,13 +664,25 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     if (lm_err) return fail(kSingularMatrix, "Landmark block is singular");
     rc = (variant == 2) ? implicit_pcg_solve(lambda) : (variant == 1) ? pcg_solve() : factor_and_solve(lambda);
     if (rc != kOk) return rc;
-    stage_begin(kStBackSub);
-    if (scaled_) launch_vec_mul(n_c_, dcam_, cam_scale_, dcam_, stream_);  // apply_inverse_scaling: dc = D_c y
-    launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_);
-    stage_end(kStBackSub);
-    HIP_TRY(hipGetLastError());
-    have_step_ = true;
-    return export_step(step_out, grad_out);
+    for (int attempt = 0;; ++attempt) {
+        stage_begin(kStBackSub);
+        if (scaled_) launch_vec_mul(n_c_, dcam_, cam_scale_, dcam_, stream_);  // apply_inverse_scaling: dc = D_c y
+        launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_);
+        stage_end(kStBackSub);
+        HIP_TRY(hipGetLastError());
+        have_step_ = true;
+        rc = export_step(step_out, grad_out);   // (synchronises: the sweeps' error word is on the host now)
+        if (rc != kOk || variant != 0 || !tp_.sweep_timed_out()) return rc;
+        // A dataflow sweep of THIS solve ran into its spin limit (chol_kernels.hip, flow_wait): dcam_ is wrong.  The factor is
+        // intact, so the solve is repeated with the level-by-level sweeps -- for this call and for the rest of the plan's
+        // life (a device that starved a sweep once will do it again, and every time-out costs ~2 s).  In a distributed plan
+        // the word was max-reduced: every rank is here.
+        have_step_ = false;
+        if (attempt > 0 || !tp_.tri_flow()) return fail(kDeviceError, "triangular sweep timed out");
+        tp_.enable_tri_flow(false);
+        rc = tri_solve();
+        if (rc != kOk) return rc;
+    }
 }
 
 // the last step / gradient in the reference's global column order (syncs)

@@ -93,8 +93,20 @@ class TilePlan {
     void enable_overlap(bool on) { overlap_ = on; }  // before the first factor()
     void set_overlap_min(int n) { overlap_min_ = n; }
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
-    hipError_t read_flags(int* failed_at);   // pivot flag + error word of the dataflow sweeps (hipErrorLaunchTimeOut)
+    hipError_t read_flags(int* failed_at);   // pivot flag of the last factorisation (syncs)
     void enable_tri_flow(bool on);   // triangular sweeps as one dataflow launch each (default) or level by level
+    bool tri_flow() const { return tri_flow_; }
+    // The dataflow sweeps bound their waits (chol_kernels.hip, flow_wait): a sweep that gave up leaves a WRONG x and raises
+    // an error word, which solve() posts to pinned host memory behind the sweeps (in a distributed plan after a max over
+    // the ranks, so that every rank takes the same decision).  Valid once the plan's stream has been synchronised behind
+    // solve(); reading clears it.  The caller repeats that solve with enable_tri_flow(false).
+    bool sweep_timed_out();
+    int sweep_timeouts() const { return n_sweep_timeouts_; }
+    // tests only: the next solve()'s forward (1) / backward (2) dataflow sweep runs into its spin limit on purpose
+    void debug_poison_next_solve(int which) { poison_ = which; }
+    // tests only: block n_cus compute units (all of their LDS) for `micros`, starting now, on a stream of their own;
+    // returns once the blocking workgroups are resident (or after 200 ms)
+    hipError_t debug_occupy_cus(int n_cus, int micros);
 
     // async on the plan's stream.  own_touched_only: (distributed plans) this rank adds to the tiles of its own columns and
     // of the shared top only -- tree-sharded landmarks; the other ranks' tiles are then left alone
@@ -160,7 +172,12 @@ class TilePlan {
     TriTask *tri_fwd_ = nullptr, *tri_bwd_ = nullptr;
     FlowTask *flow_fwd_ = nullptr, *flow_bwd_ = nullptr;   // dataflow triangular sweeps (single-GPU plans)
     double* flow_part_ = nullptr;                          // one 144-vector per off-diagonal tile
-    int* flow_flags_ = nullptr;                            // cnt[nt] | done[nt]
+    int* flow_flags_ = nullptr;                            // cnt[nt] | done[nt] | error word
+    int* flow_err_host_ = nullptr;                         // pinned: [0] the error word behind the last solve(), [1..2] debug_occupy_cus
+    int n_sweep_timeouts_ = 0;
+    int poison_ = 0;
+    hipStream_t occ_stream_ = nullptr;
+    void post_sweep_status(bool reduce);
     int n_flow_tasks_ = 0, n_flow_bwd_ = 0, n_flow_parts_ = 0;
     int n_flow_local_ = 0;   // distributed plans: the forward tasks of phase 0 (the rest: the top columns, phase 1)
     bool tri_flow_ = true;

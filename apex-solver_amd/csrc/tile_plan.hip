@@ -1,6 +1,9 @@
 // tile_plan.hip -- see tile_plan.h
 #include "tile_plan.h"
 
+#include <chrono>
+#include <thread>
+
 #include <stdlib.h>
 
 #include <math.h>
@@ -109,6 +112,8 @@ void TilePlan::release() {
         graph_failed_[i] = false;
     }
     fwd_rhs_ = nullptr;
+    if (flow_err_host_) { (void)hipHostFree(flow_err_host_); flow_err_host_ = nullptr; }
+    if (occ_stream_) { (void)hipStreamSynchronize(occ_stream_); (void)hipStreamDestroy(occ_stream_); occ_stream_ = nullptr; }
     if (ev_fwd_) { (void)hipEventDestroy(ev_fwd_); ev_fwd_ = nullptr; }
     for (hipEvent_t e : ev_t_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_u2_) (void)hipEventDestroy(e);
@@ -517,6 +522,10 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     if (flow_flags_) { (void)hipFree(flow_flags_); flow_flags_ = nullptr; }
     TP_TRY(dev_alloc(&flow_flags_, (size_t)2 * nt_ + 1));   // cnt[nt] | done[nt] | error word of the dataflow sweeps
     TP_TRY(hipMemset(flow_flags_, 0, ((size_t)2 * nt_ + 1) * sizeof(int)));
+    if (!flow_err_host_) {
+        TP_TRY(hipHostMalloc(reinterpret_cast<void**>(&flow_err_host_), 4 * sizeof(int), hipHostMallocDefault));
+        flow_err_host_[0] = flow_err_host_[1] = flow_err_host_[2] = flow_err_host_[3] = 0;
+    }
     TP_TRY(upload(&potrf_tasks_, potrf));
     TP_TRY(upload(&trsm_tasks_, trsm));
     TP_TRY(upload(&upd_tasks_, upd));
@@ -659,7 +668,8 @@ void TilePlan::enqueue_solve(const double* rhs, double* x, double* work, bool ba
     const bool flow = tri_flow_ && n_flow_tasks_ > 0;
     if (!backward_only) {
         if (flow) {
-            launch_tri_flow(false, flow_fwd_, n_flow_tasks_, rhs, yvec, flow_part_, flow_flags_, nt_, stream_, nullptr, nullptr);
+            launch_tri_flow(false, flow_fwd_, n_flow_tasks_, rhs, yvec, flow_part_, flow_flags_, nt_, stream_, nullptr, nullptr,
+                            poison_ == 1 ? nt_ - 1 : -1);
         } else {
             (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
             for (int lv = 0; lv < n_levels_; ++lv)
@@ -667,7 +677,8 @@ void TilePlan::enqueue_solve(const double* rhs, double* x, double* work, bool ba
         }
     }
     if (flow) {
-        launch_tri_flow(true, flow_bwd_, n_flow_bwd_, yvec, x, flow_part_, flow_flags_, nt_, stream_, nullptr, nullptr);
+        launch_tri_flow(true, flow_bwd_, n_flow_bwd_, yvec, x, flow_part_, flow_flags_, nt_, stream_, nullptr, nullptr,
+                        poison_ == 2 ? nt_ - 1 : -1);
         return;
     }
     for (int s = 0; s < n_levels_; ++s)
@@ -780,18 +791,45 @@ hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
     return read_flags(failed_at);
 }
 
-// The pivot flag of this factorisation and, with the same synchronisation, the error word of the dataflow sweeps (a wait
-// that gave up: reported with the next factorisation, i.e. one solve late).
+// The pivot flag of this factorisation.  (The error word of the dataflow sweeps belongs to the SOLVE that ran them:
+// post_sweep_status / sweep_timed_out.)
 hipError_t TilePlan::read_flags(int* failed_at) {
-    int f[2] = {0, 0};
-    hipError_t e = hipMemcpyAsync(&f[0], flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
-    if (e == hipSuccess && flow_flags_) e = hipMemcpyAsync(&f[1], flow_flags_ + 2 * (size_t)nt_, sizeof(int), hipMemcpyDeviceToHost, stream_);
+    int f = 0;
+    hipError_t e = hipMemcpyAsync(&f, flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(stream_);
-    *failed_at = f[0];
-    if (e != hipSuccess || f[1] == 0) return e;
-    (void)hipMemsetAsync(flow_flags_ + 2 * (size_t)nt_, 0, sizeof(int), stream_);
-    return hipErrorLaunchTimeOut;
+    *failed_at = f;
+    return e;
+}
+
+// Behind the sweeps of a solve: the error word goes to pinned host memory (no synchronisation here: the caller's next
+// one covers it) and is cleared for the next solve.  Distributed plans take the max over the ranks first -- a rank whose
+// sweep gave up must not be the only one that repeats the solve, the others would be waiting in its collectives.
+void TilePlan::post_sweep_status(bool reduce) {
+    if (!flow_flags_ || !flow_err_host_) return;
+    int* err = flow_flags_ + 2 * (size_t)nt_;
+    if (reduce && comm_.max_int) (void)comm_.max_int(err, 1, stream_);
+    (void)hipMemcpyAsync(flow_err_host_, err, sizeof(int), hipMemcpyDeviceToHost, stream_);
+    (void)hipMemsetAsync(err, 0, sizeof(int), stream_);
+}
+
+bool TilePlan::sweep_timed_out() {
+    if (!flow_err_host_ || flow_err_host_[0] == 0) return false;
+    flow_err_host_[0] = 0;
+    ++n_sweep_timeouts_;
+    return true;
+}
+
+hipError_t TilePlan::debug_occupy_cus(int n_cus, int micros) {
+    if (!flow_err_host_) return hipErrorNotInitialized;
+    if (!occ_stream_) { const hipError_t e = hipStreamCreateWithFlags(&occ_stream_, hipStreamNonBlocking); if (e != hipSuccess) return e; }
+    volatile int* started = flow_err_host_ + 1;
+    started[0] = 0; started[1] = 0;
+    launch_occupy_cus(n_cus, micros, flow_err_host_ + 1, occ_stream_);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    for (int spin = 0; spin < 2000 && started[0] < n_cus; ++spin) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    return started[0] >= n_cus ? hipSuccess : hipErrorNotReady;
 }
 
 hipError_t TilePlan::solve(const double* rhs, double* x, double* work) {
@@ -802,11 +840,16 @@ hipError_t TilePlan::solve(const double* rhs, double* x, double* work) {
         solve_phase(1, rhs, x, work);
         if (!comm_.sum(exch_, (size_t)n_pad(), stream_)) return hipErrorUnknown;
         solve_phase(2, rhs, x, work);
+        if (tri_flow_ && n_flow_local_ > 0) post_sweep_status(true);
         return hipGetLastError();
     }
     const bool backward_only = fwd_rhs_ != nullptr && rhs == fwd_rhs_ && work == fwd_work_;
     fwd_rhs_ = nullptr;  // one solve per fused sweep: the backward sweep consumes yvec's partner bvec
-    if (!run_graph(backward_only ? 2 : 1, rhs, x, work)) enqueue_solve(rhs, x, work, backward_only);
+    if (poison_ != 0) {   // (tests: the poisoned launch is not part of the captured graphs)
+        enqueue_solve(rhs, x, work, backward_only);
+        poison_ = 0;
+    } else if (!run_graph(backward_only ? 2 : 1, rhs, x, work)) enqueue_solve(rhs, x, work, backward_only);
+    if (tri_flow_ && n_flow_tasks_ > 0) post_sweep_status(false);
     return hipGetLastError();
 }
 

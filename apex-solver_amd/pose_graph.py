@@ -282,6 +282,14 @@ class GpuSparseCholeskySolver:
         return {"tile_rows": int(a[0]), "tiles": int(a[1]), "touched_tiles": int(a[2]), "etree_levels": int(a[3]),
                 "total_dof": int(a[4]), "n_potrf": int(a[5]), "n_trsm": int(a[6]), "n_update": int(a[7])}
 
+    def set_option(self, name: str, value: int):
+        h = self._need(); h.check(h.L.apexgpu_pg_set_option(h.h, name.encode(), int(value)))
+
+    def counters(self) -> dict:
+        h = self._need(); out = (C.c_int64 * 4)()
+        h.check(h.L.apexgpu_pg_counters(h.h, C.byref(out)))
+        return dict(sweep_timeouts=int(out[0]), tri_dataflow=bool(out[1]))
+
     def enable_stage_timing(self, on=True): h = self._need(); h.check(h.L.apexgpu_pg_enable_stage_timing(h.h, int(on)))
     def reset_stage_times(self): h = self._need(); h.check(h.L.apexgpu_pg_reset_stage_times(h.h))
 

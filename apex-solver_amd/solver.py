@@ -394,6 +394,12 @@ class GpuSchurComplementSolver:
                     n_potrf=int(out[9]), n_trsm=int(out[10]), n_update=int(out[11]),
                     dist_top_columns=int(out[12]), dist_local_fraction=float(out[13]), tree_sharded=bool(out[14]), schur_form=int(out[15]))
 
+    def counters(self) -> dict:
+        """Events of this handle's life: dataflow triangular sweeps that timed out and were repeated level by level."""
+        h = self._need(); out = (C.c_int64 * 4)()
+        h.check(h.L.apexgpu_counters(h.h, C.byref(out)))
+        return dict(sweep_timeouts=int(out[0]), tri_dataflow=bool(out[1]))
+
     def setup_times(self) -> dict:
         """Wall time of initialize_structure by phase (seconds) and the counts that go with it."""
         h = self._need(); sec = (C.c_double * 6)(); cnt = (C.c_double * 4)()

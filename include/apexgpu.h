@@ -221,8 +221,10 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     2 = LDS row form, one lane per observation, block rows walked in a per-lane rotated order
  *                     (k_schur_rows2); 1 = LDS row form, one lane per camera pair (k_schur_rows);
  *                     0 = the landmark-major global-atomics form (k_schur_scatter)
- *   "pairs_variant" (1)  schur form 3 only, process-wide: 1 = one observation per lane, two lanes per pair (three waves per
+ *   "pairs_variant" (1)  schur form 3 only, per handle: 1 = one observation per lane, two lanes per pair (three waves per
  *                     SIMD), 0 = one pair per lane (two waves per SIMD); same lists, same results up to rounding
+ *   "pairs_ablation" (0)  per handle, TIMING EXPERIMENTS ONLY (the results are wrong when != 0): refused with
+ *                     APEXGPU_ERR_INVALID_INPUT unless the process runs with APEX_ALLOW_ABLATION set
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
  *   "update_overlap" (1)  run the trailing updates the next elimination level does not need on a second
  *                     stream, overlapped with that level's potrf / panel solves (before the first solve)
@@ -233,7 +235,12 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     per workgroup, 0 = the schedule without look-ahead
  *   "fused_forward" (0)  run the forward triangular sweep inside the factorisation graph on a third stream
  *   "tri_dataflow" (1)  triangular sweeps of a single-GPU plan as ONE launch each: one workgroup per tile, dependencies
- *                     through per-block flags (k_tri_fwd_flow / k_tri_bwd_flow); 0 = one launch per elimination-tree level
+ *                     through per-block flags (k_tri_fwd_flow / k_tri_bwd_flow); 0 = one launch per elimination-tree level.
+ *                     The flag waits are bounded (~2 s): a sweep that gives up is detected IN THE SAME apexgpu_solve_augmented
+ *                     (error word posted to the host behind the sweeps, max-reduced over the ranks), the solve is repeated
+ *                     with the level sweeps and the handle stays on them; apexgpu_counters()[0] counts these events
+ *   "debug_poison_sweep", "debug_occupy_cus"  tests only: the next solve's forward (1) / backward (2) dataflow sweep runs
+ *                     into its spin limit on purpose; block that many compute units for 40 ms starting now
  *   "nested_dissection" (1)  order camera tiles by nested dissection (call before set_structure);
  *                     0 keeps the caller's camera order, a value > 1 sets the leaf size in tiles
  *   "hubs_last" (1)   order a vertex cover of the camera pairs that share landmarks across tiles more than two strong
@@ -261,6 +268,9 @@ int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_
  * operations below them (1 when not distributed), [14] = 1 when the landmarks are sharded by the elimination tree,
  * [15] = form of the Schur reduction in use ("schur_rows") */
 int apexgpu_info(apexgpu_solver* h, double info[16]);
+/* out[0] = dataflow triangular sweeps that timed out and were repeated level by level (see "tri_dataflow"),
+ * out[1] = 1 while the handle still uses the dataflow sweeps, out[2..3] reserved (0) */
+int apexgpu_counters(apexgpu_solver* h, int64_t out[4]);
 /* Wall time of the last apexgpu_set_structure by phase, seconds[6] = {camera order + tile structure, landmark sharding +
  * observation lists, tile plan (symbolic fill, task lists, allocation), lists of the Schur reduction, uploads, total};
  * counts[4] (may be NULL) = {hub cameras ordered last, camera-pair blocks, pair slots incl. padding, Schur form}. */
@@ -411,6 +421,7 @@ int apexgpu_pg_stage_times(apexgpu_pg_solver* h, double ms[APEXGPU_PG_NUM_STAGES
 /* info[0] tile rows, [1] tiles incl. fill, [2] tiles of H itself, [3] elimination-tree levels, [4] total dof,
  * [5..7] tile operations per factorisation: potrf, panel products, trailing updates */
 int apexgpu_pg_info(apexgpu_pg_solver* h, double info[8]);
+int apexgpu_pg_counters(apexgpu_pg_solver* h, int64_t out[4]);   /* as apexgpu_counters */
 
 /* ---- input path (host only): G2O files ------------------------------------------------------------
  * G2oLoader::load (crates/apex-io/src/g2o.rs:140-620): VERTEX_SE3:QUAT id x y z qx qy qz qw (norm checked to

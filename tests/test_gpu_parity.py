@@ -366,7 +366,7 @@ def test_row_and_atomic_schur_forms_agree(mode):
     wide = _custom(150, len(lists), lists)
     for d in (base, wide):
         out = []
-        for rows in (30, 3, 1, 2, 0):   # 30: form 3 with one pair per lane ("pairs_variant" 0, process-wide; the later ones set the default, 1, again)
+        for rows in (30, 3, 1, 2, 0):   # 30: form 3 with one pair per lane ("pairs_variant" 0, a per-handle switch)
             ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
             prob = Problem.bundle_adjustment(d, ot, 1.0)
             s = GpuSchurComplementSolver(0).with_option("schur_rows", 3 if rows == 30 else rows)

@@ -48,3 +48,66 @@ def test_pose_graph_dataflow_sweeps_match_level_sweeps():
     # (H is assembled with fp64 atomics here: two solves differ by last bits times cond(H) whatever the sweeps do)
     assert rel(steps[1][0], steps[1][1]) < 1e-9
     assert rel(steps[1][0], steps[0][0]) < 1e-9
+
+
+# ---- a sweep that gives up fails (and is repaired inside) the solve it belongs to ------------------------------------------
+@pytest.mark.parametrize("which", [1, 2], ids=["forward", "backward"])
+def test_sweep_timeout_is_caught_in_the_same_solve_and_repaired(which):
+    """"debug_poison_sweep": one block's counter is made unreachable, so the dataflow sweep runs into its spin limit, raises
+    the error word and leaves a wrong x.  The SAME solve_augmented must notice (error word posted to the host behind the
+    sweeps), repeat the triangular solve level by level and return the right step; the event is counted and the handle
+    stays on the level sweeps."""
+    d = pkg.synthetic.make_problem(400, 12000, 3, 8, config_id=84)
+    prob = Problem.bundle_adjustment(d, OptimizationType.SelfCalibration, 1.0)
+    ref = GpuSchurComplementSolver(0).with_option("tri_dataflow", 0).initialize_structure(prob)
+    ref.set_parameters(d.poses, d.intr, d.points)
+    want = ref.solve_augmented_equation(1e-3).copy()
+    ref.close()
+    s = GpuSchurComplementSolver(0).initialize_structure(prob)
+    s.set_parameters(d.poses, d.intr, d.points)
+    good = s.solve_augmented_equation(1e-3).copy()
+    assert s.counters() == dict(sweep_timeouts=0, tri_dataflow=True)
+    s.set_option("debug_poison_sweep", which)
+    got = s.solve_augmented_equation(1e-3).copy()          # ~2 s: the poisoned wait runs to its limit
+    c = s.counters()
+    print("sweep", which, "counters after the poisoned solve:", c, "vs level sweeps", rel(got, want), "vs dataflow", rel(got, good))
+    assert c == dict(sweep_timeouts=1, tri_dataflow=False)
+    assert np.array_equal(got, want), "the repaired solve is the level-sweep solve, bit for bit"
+    # the step, the statistics and the trial cost of that call are the repaired ones
+    gn, sn, pred = s.step_stats()
+    assert np.isfinite([gn, sn, pred]).all() and pred > 0
+    again = s.solve_augmented_equation(1e-3).copy()         # the handle stays on the level sweeps
+    assert np.array_equal(again, want) and s.counters()["sweep_timeouts"] == 1
+    s.close()
+
+
+def test_pose_graph_sweep_timeout_is_repaired():
+    d = pkg.synthetic.make_sphere(30, 40)
+    s = GpuSparseCholeskySolver(0).initialize_structure(PoseGraphProblem.pose_graph(d))
+    s.set_parameters(d.poses)
+    good = s.solve_augmented_equation(1e-3).copy()
+    s.set_option("debug_poison_sweep", 1)
+    got = s.solve_augmented_equation(1e-3).copy()
+    assert s.counters() == dict(sweep_timeouts=1, tri_dataflow=False)
+    assert rel(got, good) < 1e-9 and np.all(np.isfinite(got))
+    s.close()
+
+
+@pytest.mark.parametrize("busy", [224, 248])
+def test_dataflow_sweeps_make_progress_while_most_cus_are_blocked(busy):
+    """Forward progress under contention: `busy` of the 256 compute units are taken by workgroups of another stream that hold
+    all of their LDS for 40 ms ("debug_occupy_cus").  The sweeps' one-workgroup-per-tile launches then run on the remaining
+    CUs only -- far fewer resident workgroups than tasks, every wait must still be for an EARLIER workgroup.  No time-out,
+    same bits as on the idle chip."""
+    d = pkg.synthetic.make_problem(1200, 40000, 3, 8, config_id=83)
+    prob = Problem.bundle_adjustment(d, OptimizationType.SelfCalibration, 1.0)
+    s = GpuSchurComplementSolver(0).initialize_structure(prob)
+    s.set_parameters(d.poses, d.intr, d.points)
+    idle = s.solve_augmented_equation(1e-3).copy()
+    for rep in range(3):
+        s.set_option("debug_occupy_cus", busy)              # returns once the blocking workgroups are resident
+        got = s.solve_augmented_equation(1e-3).copy()
+        assert s.counters() == dict(sweep_timeouts=0, tri_dataflow=True)
+        # (S is assembled deterministically on this shape and the sweeps fold in list order: bitwise equal)
+        assert np.array_equal(got, idle)
+    s.close()

@@ -9,6 +9,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("APEX_SYNTH_CACHE", "/tmp/apex_synth_cache")
+os.environ.setdefault("APEX_ALLOW_ABLATION", "1")   # "pairs_ablation" (wrong results, timing only) is refused without it
 
 import numpy as np  # noqa: E402
 
