@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--cg", default="", help="max_iter,tol of the PCG variants (default: the reference's 200,1e-6 / implicit 500,1e-9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="implementation switch name=value (apexgpu_set_option), repeatable")
-    ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0: choose for ~10-30 s of CPU work")
+    ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0: full size when the reference's dense S fits (<= 2300 cameras), else a ~1000-camera sample")
     return ap.parse_args()
 
 
@@ -71,13 +71,32 @@ def lm_step(s, state):
     state["hist"].append((state["cost"], rho))
 
 
+def usable_cores():
+    """Hardware threads this process may actually run on: the affinity mask, cut by the cgroup CPU quota (a container on a
+    256-thread host may be allowed far fewer: 256 OpenMP threads spinning on 32 CPUs' worth of quota is how a baseline
+    gets SLOWER with "more cores")."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline_worker(workload, shape_scale, mode):
     """Runs in a child process (OMP_NUM_THREADS / OMP_PROC_BIND set by the parent): 2 LM iterations of the oracle."""
     import apex_solver_amd as pkg
     from oracle import oracle as ora
 
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    d = pkg.synthetic.make_named(workload, shape_scale)
+    d = pkg.datasets.load_named(workload, shape_scale)[0]
     lay = pkg.layout.reference_column_layout(d.n_cam, d.n_pt)
     o = ora.from_data(d, lay, mode=mode, native=True)
     cost = o.residuals()[0]
@@ -105,20 +124,23 @@ def cpu_baseline_worker(workload, shape_scale, mode):
     }
 
 
-def cpu_baseline(args, shape_scale, mode):
-    """The oracle (kind "port": C restatement of the reference CPU path, OpenMP, pinned threads) timed on this box's host
-    cores on bounded samples of the same workload.  Measured on the GPU box (tools/cpu_baseline_sweep.sh): the restated
-    path scales to ~32 threads (its explicit Schur formation is serial like the reference's, explicit_schur.rs:801-898)
-    and collapses when all 256 hardware threads are used, so the headline `value` is taken at min(cores, 32) threads on
-    the ~1000-camera sample (the reference forms S densely: 9000^2), and ONE thread and ALL cores (SURVEY §8d asks for
-    both) are reported on a third of it.  Each run is its own child process so that the OpenMP runtime starts with the
-    wanted thread count and binding."""
+def cpu_baseline(args, shape_scale, mode, full_size):
+    """The oracle (kind "port": C restatement of the reference CPU path, OpenMP) timed on this box's host cores.
+
+    full_size: the workload's dense S fits (ladybug-1723, venice-1778: ~2 GB) -- the oracle runs the SAME problem the GPU
+    line is quoted on.  Otherwise (final-13682: the reference forms S as a dense n_c x n_c matrix, explicit_schur.rs:782,
+    = 121 GB at 9 DOF per camera) a bounded sample of the same generator, and the line says so.
+    Threads: `value` at min(usable, 32) (the restated path's Schur formation is serial like the reference's,
+    explicit_schur.rs:801-898, so it stops scaling there), plus ONE thread and ALL usable cores (SURVEY §8d asks for both)
+    on a third of the sample.  usable = affinity mask cut by the cgroup quota (usable_cores()); threads sleep at barriers
+    (OMP_WAIT_POLICY=passive) instead of spinning.  Each run is its own child process so that the OpenMP runtime starts
+    with the wanted thread count."""
     import subprocess
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
 
     def run(threads, sc):
-        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false", OMP_WAIT_POLICY="passive", OMP_DYNAMIC="false")
         code = (f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; "
                 f"print('CPUBASE ' + json.dumps(bench.cpu_baseline_worker({args.workload!r}, {sc!r}, {mode!r})))")
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
@@ -128,10 +150,18 @@ def cpu_baseline(args, shape_scale, mode):
         return json.loads(line[0][8:])
 
     out = run(min(cores, 32), shape_scale)
+    out["usable_cores"] = cores
+    out["hardware_threads"] = os.cpu_count() or 1
+    if full_size:
+        out["sample"] = "FULL SIZE, the GPU line's own problem -- " + out["sample"]
+    else:
+        out["sample"] += (f"; a SAMPLE of the same generator: {args.workload} itself is beyond the reference's CPU path, which forms S as a"
+                          " dense n_c x n_c matrix (explicit_schur.rs:782) -- 121 GB at 13,682 cameras x 9 DOF")
     keep = ("value", "unit", "cores", "sample", "obs_per_s")
-    out["one_thread"] = {k: v for k, v in run(1, shape_scale / 3.0).items() if k in keep}
+    third = shape_scale / 3.0 if not full_size else shape_scale / 6.0
+    out["one_thread"] = {k: v for k, v in run(1, third).items() if k in keep}
     if cores > 32:
-        out["all_cores"] = {k: v for k, v in run(cores, shape_scale / 3.0).items() if k in keep}
+        out["all_cores"] = {k: v for k, v in run(cores, third).items() if k in keep}
     return out
 
 
@@ -153,7 +183,10 @@ def bench_pose_graph(args):
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     side = max(2, int(round(50 * args.scale ** 0.5)))
-    d = pkg.synthetic.make_sphere(side, side)
+    if args.scale == 1.0:
+        d, data_kind, data_src = pkg.datasets.load_pose_graph(args.workload, side, side)   # data/odometry/3d/sphere2500.g2o when present
+    else:
+        d, data_kind, data_src = pkg.synthetic.make_sphere(side, side), "synthetic", None
     prob = PoseGraphProblem.pose_graph(d)
     s = GpuSparseCholeskySolver(local_rank).initialize_structure(prob)
     s.set_parameters(d.poses)
@@ -201,8 +234,8 @@ def bench_pose_graph(args):
     ach = flops / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
     out = {"metric": "ms per LM iter (Jacobian+JtJ+Cholesky)", "value": ms, "unit": "ms", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"{d.name} synthetic SE3 pose graph ({d.n_v} vertices / {d.n_e} edges)", "tile_rows": info["tile_rows"],
+           "dtype": "f64", "data": data_kind,
+           "config": {"workload": f"{d.name} {data_kind} SE3 pose graph ({d.n_v} vertices / {d.n_e} edges)" + (f" from {data_src}" if data_src else ""), "tile_rows": info["tile_rows"],
                       "tiles": info["tiles"], "etree_levels": info["etree_levels"], "parallelism": f"replicas x{world}"},
            "roofline": {"bound": "mfma", "kernel": "tile Cholesky (k_potrf_inv_la + k_tile_gemm_nt)", "achieved": ach, "peak": 78.6,
                         "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None, "flops_per_factorisation": flops,
@@ -268,7 +301,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
 
-    d = pkg.synthetic.make_named(args.workload, args.scale)
+    d, data_kind, data_src = pkg.datasets.load_named(args.workload, args.scale)   # real BAL file when data/... holds it
     ot = OptimizationType.SelfCalibration if args.mode == "selfcal" else OptimizationType.BundleAdjustment
     prob = Problem.bundle_adjustment(d, ot, 1.0)
     s = GpuSchurComplementSolver(local_rank)
@@ -378,8 +411,8 @@ def main():
     out = {
         "metric": "ms per LM iter (Jacobian+Schur+solve)", "value": ms_per_step, "unit": "ms", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{d.name} synthetic ({d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations)",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": data_kind,
+        "config": {"workload": f"{d.name} {data_kind} ({d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations)" + (f" from {data_src}" if data_src else ""),
                    "optimization_type": args.mode, "camera_dof": dc, "schur_variant": args.variant, "huber": 1.0,
                    "s_tile_rows": info["tile_rows"], "s_tiles": info["tiles"], "s_tiles_touched": info["touched_tiles"],
                    "etree_levels": info["etree_levels"], "border_cameras": st["hub_cameras"], "schur_form": form, "parallelism": f"landmark-shard x{world}" + (f", landmarks and Cholesky distributed by elimination subtree ({info['dist_top_columns']} shared top tile columns, tree_sharded={info.get('tree_sharded')})" if info.get("dist_top_columns") else "")},
@@ -395,10 +428,13 @@ def main():
         out["pcg_iterations_per_step"] = state["pcg"][args.warmup:]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sc = args.cpu_sample_scale
-        if sc <= 0.0:  # ~1000 cameras (dense S of 9000^2, as the reference forms it): 10-30 s of CPU work
-            sc = min(1.0, 1000.0 / max(d.n_cam, 1))
+        # the reference's dense S (explicit_schur.rs:782) of ladybug-1723 / venice-1778 is ~2 GB: the oracle runs those at
+        # FULL size; beyond ~2,300 cameras (8 (9 n_cam)^2 > ~3.5 GB, and a Cholesky of minutes) a ~1000-camera sample
+        full = sc <= 0.0 and d.n_cam <= 2300
+        if sc <= 0.0:
+            sc = 1.0 if full else min(1.0, 1000.0 / max(d.n_cam, 1))
         try:
-            out["cpu_baseline"] = cpu_baseline(args, sc * args.scale, args.mode)
+            out["cpu_baseline"] = cpu_baseline(args, sc * args.scale, args.mode, full)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
             out["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:

@@ -72,12 +72,14 @@ def test_sweep_timeout_is_caught_in_the_same_solve_and_repaired(which):
     c = s.counters()
     print("sweep", which, "counters after the poisoned solve:", c, "vs level sweeps", rel(got, want), "vs dataflow", rel(got, good))
     assert c == dict(sweep_timeouts=1, tri_dataflow=False)
-    assert np.array_equal(got, want), "the repaired solve is the level-sweep solve, bit for bit"
+    # the repaired solve is a level-sweep solve of the same factor (its forward sweep adds into shared ancestor blocks
+    # with atomics, so two of them agree to rounding times cond(S), not bit for bit); the poisoned sweep's x was garbage
+    assert rel(got, want) < 1e-9 and rel(got, good) < 1e-9
     # the step, the statistics and the trial cost of that call are the repaired ones
     gn, sn, pred = s.step_stats()
     assert np.isfinite([gn, sn, pred]).all() and pred > 0
     again = s.solve_augmented_equation(1e-3).copy()         # the handle stays on the level sweeps
-    assert np.array_equal(again, want) and s.counters()["sweep_timeouts"] == 1
+    assert rel(again, want) < 1e-9 and s.counters()["sweep_timeouts"] == 1
     s.close()
 
 
