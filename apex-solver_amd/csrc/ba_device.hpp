@@ -217,13 +217,17 @@ APEX_HD bool residual_obs(const Cam& c, const double pw[3], double u_obs, double
 // Jc is 2 x DC (row-major [row][col]), Jl is 2 x 3; both CORRECTED (scaled by sqrt(rho')).
 // MASKED = false: every block the factor has columns for is optimised (SelfCalibration; BundleAdjustment at DC = 6) -- the
 // column masks are all ones and are not read (the register-critical kernels instantiate this form for those modes).
+// rec4 (optional): the observation's PROJECTION RECORD (xn, yn, -1/z, sqrt(rho')) -- everything the Jacobian needs besides
+// the camera (R, f, k1, k2) and the point; the record form of the Schur pair kernel (schur_pairs.hip, jac_from_rec)
+// rebuilds J from it instead of re-linearising the observation once per pair.  A point behind the camera: weight 0.
 template <int DC, bool MASKED = true>
 APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, double v_obs,
-                           double huber_delta, double r[2], double Jc[2][DC], double Jl[2][3]) {
+                           double huber_delta, double r[2], double Jc[2][DC], double Jl[2][3], double* rec4 = nullptr) {
     APEX_FP_EXACT
     double pc[3];
     cam_transform(c, pw, pc);
     if (!(pc[2] < -kMinDepth)) {
+        if (rec4) { rec4[0] = 0.0; rec4[1] = 0.0; rec4[2] = 1.0; rec4[3] = 0.0; }
         r[0] = 0.0; r[1] = 0.0;
 #pragma unroll
         for (int a = 0; a < DC; ++a) { Jc[0][a] = 0.0; Jc[1][a] = 0.0; }
@@ -255,6 +259,7 @@ APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, doubl
     Jp[1][2] = f * fma(dyd_dxn, dxn_dz, dyd_dyn * dyn_dz);
     const double* R = c.R;
     double w = huber_sqrt_rho1(huber_delta, fma(r0, r0, r1 * r1));
+    if (rec4) { rec4[0] = xn; rec4[1] = yn; rec4[2] = inz; rec4[3] = w; }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         // landmark block = Jp R ; pose block = [Jp R | -(Jp R)[p_w]x]  (bal_pinhole.rs:528-556:

@@ -87,8 +87,10 @@ struct ScatterTask {
 void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* cam_ptr, const int* cam_obs,
                        double lambda, int add_lambda, const double* hinv, const double* g_l, int with_self, double* g_c,
                        double* g_red, hipStream_t s);
+// orec (may be NULL): [n_obs][4] projection records (xn, yn, -1/z, sqrt(rho')), landmark-major, for the record form of
+// the Schur pair kernel (schur_pairs.hip)
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag,
-                            double* lmu /* may be NULL */, hipStream_t s);
+                            double* lmu /* may be NULL */, hipStream_t s, double* orec = nullptr);
 // A18 (implicit_schur.rs): y = S x matrix-free, the Schur-Jacobi preconditioner blocks and their application
 void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
                             double lambda, double* y, hipStream_t s);

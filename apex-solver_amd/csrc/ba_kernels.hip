@@ -172,7 +172,7 @@ constexpr int kLmLanes = 4;   // lanes per landmark in the landmark-major kernel
 template <int DC>
 __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda, double* __restrict__ hinv,
                                                            double* __restrict__ g_l, int* __restrict__ err_flag,
-                                                           double* __restrict__ lmu) {
+                                                           double* __restrict__ lmu, double* __restrict__ orec) {
     const int g = threadIdx.x & (kLmLanes - 1);
     const int64_t l = (int64_t)blockIdx.x * (256 / kLmLanes) + threadIdx.x / kLmLanes;
     const bool active = l < v.n_pt;
@@ -186,7 +186,14 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
             Cam cam;
             load_cam_q(v.camq + kCamQStride * (size_t)c, v.mask_code, cam);
             double r[2], Jc[2][DC], Jl[2][3];
-            linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
+            if (orec) {   // record form of the pair kernel: the observation's projection record, 32 bytes, landmark-major
+                double rec[4];
+                linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl, rec);
+                double2* q = reinterpret_cast<double2*>(orec + 4 * (size_t)i);
+                q[0] = make_double2(rec[0], rec[1]); q[1] = make_double2(rec[2], rec[3]);
+            } else {
+                linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
+            }
             h[0] += Jl[0][0] * Jl[0][0] + Jl[1][0] * Jl[1][0];
             h[1] += Jl[0][1] * Jl[0][0] + Jl[1][1] * Jl[1][0];
             h[2] += Jl[0][1] * Jl[0][1] + Jl[1][1] * Jl[1][1];
@@ -1134,11 +1141,11 @@ void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* ca
 }
 
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag, double* lmu,
-                            hipStream_t s) {
+                            hipStream_t s, double* orec) {
     if (v.n_pt == 0) return;
     const int grid = grid_for(v.n_pt, 256 / kLmLanes, 0);
-    if (dc == 9) hipLaunchKernelGGL(k_landmark_reduce<9>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag, lmu);
-    else hipLaunchKernelGGL(k_landmark_reduce<6>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag, lmu);
+    if (dc == 9) hipLaunchKernelGGL(k_landmark_reduce<9>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag, lmu, orec);
+    else hipLaunchKernelGGL(k_landmark_reduce<6>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag, lmu, orec);
 }
 
 void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const ScatterTask* tasks, int n_tasks,

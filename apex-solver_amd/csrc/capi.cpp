@@ -285,6 +285,13 @@ int apexgpu_info(apexgpu_solver* h, double info[16]) {
     return APEXGPU_OK;
 }
 
+int apexgpu_debug_pair_phases(int64_t out[8], int reset) {
+    if (!out) return APEXGPU_ERR_INVALID_INPUT;
+    unsigned long long v[8];
+    apex::pairs_phase_cycles(v, reset != 0);
+    for (int k = 0; k < 8; ++k) out[k] = (int64_t)v[k];
+    return APEXGPU_OK;
+}
 int apexgpu_counters(apexgpu_solver* h, int64_t out[4]) {
     H_OR_FAIL;
     if (!out) return APEXGPU_ERR_INVALID_INPUT;

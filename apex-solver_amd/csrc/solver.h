@@ -86,7 +86,7 @@ class Solver : public LmBackend {
     void enable_graphs(bool on) { use_graphs_ = on; tp_.enable_graphs(on); }
     void enable_overlap(bool on) { tp_.enable_overlap(on); }
     void enable_tri_flow(bool on) { tp_.enable_tri_flow(on); }
-    void set_pairs_variant(int v) { pairs_variant_ = v; }       // pair kernel: 1 two lanes per pair (default), 0 one pair per lane
+    void set_pairs_variant(int v) { pairs_variant_ = v; }       // pair kernel: 2 record form; fused forms: 1 two lanes per pair, 0 one pair per lane
     void set_pairs_ablation(int bits) { pairs_ablation_ = bits; }   // timing experiments only (results are wrong when != 0)
     int sweep_timeouts() const { return tp_.sweep_timeouts(); }   // dataflow sweeps that gave up and were repeated level by level
     void debug_poison_next_solve(int which) { tp_.debug_poison_next_solve(which); }
@@ -186,6 +186,7 @@ class Solver : public LmBackend {
     PairChunk* pchunks_ = nullptr;
     PairBlock* pblocks_ = nullptr;
     PairRec* precs_ = nullptr;
+    double* orec_ = nullptr;   // [local observations][4] projection records written by k_landmark_reduce (pair kernel, record form)
     int n_ptasks_ = 0;
     int64_t n_pair_blocks_ = 0, n_pair_slots_ = 0;
     int rows_form_ = 3;              // 3 (default): sorted pair list reduced over the lanes of a wave (k_schur_pairs_h / k_schur_pairs: every
@@ -198,7 +199,7 @@ class Solver : public LmBackend {
     int* nbr_ = nullptr;
     int n_rtasks_ = 0;
     int rows_dbg_ = 0;      // timing-only ablation switches of k_schur_rows (results are wrong when != 0)
-    int pairs_variant_ = 1, pairs_ablation_ = 0;   // k_schur_pairs: lane mapping; timing-only ablation bits (wrong results when != 0)
+    int pairs_variant_ = 2, pairs_ablation_ = 0;   // k_schur_pairs: 2 record form (default), 3 record form two lanes per pair, 1 / 0 fused forms; timing-only ablation bits
     bool use_rows_ = true;  // Schur reduction: LDS row form (default) or the global-atomics form
     uint32_t *o_cam_ = nullptr, *o_pt_ = nullptr, *co_pt_ = nullptr;
     double2* co_uv_ = nullptr;

@@ -52,7 +52,7 @@ Solver::~Solver() {
     if (free_thread_.joinable()) free_thread_.join();
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
+    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, orec_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_, lam_mask_};
     for (void* p : ptrs)
@@ -292,6 +292,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(alloc(&g_red_, n_c_pad_));
     HIP_TRY(alloc(&dcam_, n_c_pad_));
     HIP_TRY(alloc(&hinv_, (size_t)kLmStride * n_pt_));  // landmark records: Hll^-1 | g_l | point
+    // projection records of the local observations (xn, yn, -1/z, sqrt(rho')): the record form of the pair kernel
+    if (use_rows_ && rows_form_ == 3) HIP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
     HIP_TRY(alloc(&g_l_, 3 * n_pt_));
     HIP_TRY(alloc(&dl_, 3 * n_pt_));
     HIP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
@@ -460,7 +462,8 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     tp_.add_diag((int)n_c_, 0.0, rank_ == pad_rank_ ? 1.0 : 0.0);
     stage_end(kStAssembleCam);
     stage_begin(kStAssembleLm);
-    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_);
+    const bool rec_form = use_rows_ && rows_form_ == 3 && pairs_variant_ >= 2 && orec_ != nullptr;
+    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_, rec_form ? orec_ : nullptr);
     stage_end(kStAssembleLm);
     stage_begin(kStAssembleCam);
     launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, hinv_, g_l_, use_rows_ ? 1 : 0,
@@ -468,7 +471,8 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     stage_end(kStAssembleCam);
     stage_begin(kStScatter);
     if (use_rows_ && rows_form_ == 3)
-        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, pairs_variant_, pairs_ablation_);
+        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, pairs_variant_, pairs_ablation_,
+                           rec_form ? orec_ : nullptr);
     else if (use_rows_ && rows_form_ == 2 && rows_dbg_ == 0)
         launch_schur_rows2(dc_, v, tm, rtasks2_, n_rtasks_, rchunks_, rentries_, nbr_, hinv_, stream_);
     else if (use_rows_)

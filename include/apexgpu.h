@@ -271,6 +271,10 @@ int apexgpu_info(apexgpu_solver* h, double info[16]);
 /* out[0] = dataflow triangular sweeps that timed out and were repeated level by level (see "tri_dataflow"),
  * out[1] = 1 while the handle still uses the dataflow sweeps, out[2..3] reserved (0) */
 int apexgpu_counters(apexgpu_solver* h, int64_t out[4]);
+/* Profiling aid of the Schur pair kernel (record form run with "pairs_ablation" 64: results stay right): shader cycles summed
+ * over all waves since the last reset, out[0..4] = wait for the gathers, un-staging, Jacobians + U / V stores, issue of the next
+ * chunk's loads, block products + flushes; out[5] chunks, out[6] cycles inside flushes, out[7] flushes. */
+int apexgpu_debug_pair_phases(int64_t out[8], int reset);
 /* Wall time of the last apexgpu_set_structure by phase, seconds[6] = {camera order + tile structure, landmark sharding +
  * observation lists, tile plan (symbolic fill, task lists, allocation), lists of the Schur reduction, uploads, total};
  * counts[4] (may be NULL) = {hub cameras ordered last, camera-pair blocks, pair slots incl. padding, Schur form}. */

@@ -366,17 +366,17 @@ def test_row_and_atomic_schur_forms_agree(mode):
     wide = _custom(150, len(lists), lists)
     for d in (base, wide):
         out = []
-        for rows in (30, 3, 1, 2, 0):   # 30: form 3 with one pair per lane ("pairs_variant" 0, a per-handle switch)
+        for rows in (30, 3, 1, 2, 0, 32, 33):   # 30 / 3 / 32 / 33: form 3 with "pairs_variant" 0 / 1 / 2 / 3 (fused one pair per lane, fused two lanes per pair, record form one pair per lane, record form two lanes per pair)
             ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
             prob = Problem.bundle_adjustment(d, ot, 1.0)
-            s = GpuSchurComplementSolver(0).with_option("schur_rows", 3 if rows == 30 else rows)
-            s.with_option("pairs_variant", 0 if rows == 30 else 1).initialize_structure(prob)
+            s = GpuSchurComplementSolver(0).with_option("schur_rows", 3 if rows >= 30 else rows)
+            s.with_option("pairs_variant", {30: 0, 32: 2, 33: 3}.get(rows, 1)).initialize_structure(prob)
             s.set_parameters(d.poses, d.intr, d.points)
             step = s.solve_augmented_equation(1e-3)
             S, gred = s.get_schur()
             out.append((S, gred, s.get_gradient(), step))
             s.close()
-        for k in (1, 2, 3, 4):
+        for k in (1, 2, 3, 4, 5, 6):
             assert rel(out[0][0], out[k][0]) < 1e-13 and rel(out[0][1], out[k][1]) < 1e-12
             assert rel(out[0][2], out[k][2]) < 1e-13
 

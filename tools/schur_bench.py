@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--task-slots", default="0", help="comma list of pair_task_slots values to try with form 3")
     ap.add_argument("--abl", default="0", help="comma list of ablation bit sets for the pair kernel (timing only)")
     ap.add_argument("--check", action="store_true", help="compare S x of every form with the first one's")
+    ap.add_argument("--variants", default="", help="comma list of pairs_variant values to try with form 3 (0 / 1 fused, 2 record form)")
     a = ap.parse_args()
     t = time.time()
     d = pkg.synthetic.make_named(a.workload, a.scale)
@@ -35,9 +36,13 @@ def main():
     prob = Problem.bundle_adjustment(d, ot, 1.0)
     ref = None
     x = np.random.default_rng(0).normal(size=prob.layout.cam_dof)
-    runs = [(int(f), int(ts)) for f in a.forms.split(",") for ts in (a.task_slots.split(",") if int(f) == 3 else ["0"])]
-    for form, ts in runs:
+    variants = [int(x) for x in a.variants.split(",")] if a.variants else [None]
+    runs = [(int(f), int(ts), pv) for f in a.forms.split(",") for ts in (a.task_slots.split(",") if int(f) == 3 else ["0"])
+            for pv in (variants if int(f) == 3 else [None])]
+    for form, ts, pv in runs:
         s = GpuSchurComplementSolver(0).with_option("schur_rows", form).with_option("pair_task_slots", ts)
+        if pv is not None:
+            s.with_option("pairs_variant", pv)
         t = time.time()
         s.initialize_structure(prob)
         s.set_parameters(d.poses, d.intr, d.points)
@@ -52,7 +57,14 @@ def main():
                 s.assemble(1e-3)
             st = s.stage_times()
             line = {k: round(v[0] / max(v[1], 1), 3) for k, v in st.items() if v[1] > 0}
-            print(f"form {form} task_slots {ts} abl {abl}: {line}", flush=True)
+            print(f"form {form} variant {pv} task_slots {ts} abl {abl}: {line}", flush=True)
+            if abl == 64:
+                import ctypes as C
+                out = (C.c_int64 * 8)()
+                pkg.capi.load().apexgpu_debug_pair_phases(C.byref(out), 1)
+                n = max(out[5], 1)
+                print("   cycles per chunk and wave: wait %.0f  unstage %.0f  jacobians+stores %.0f  issue %.0f  products+flush %.0f  (flush %.0f per flush, %.2f flushes per chunk)  total %.0f" %
+                      (out[0] / n, out[1] / n, out[2] / n, out[3] / n, out[4] / n, out[6] / max(out[7], 1), out[7] / n, sum(out[:5]) / n), flush=True)
         s.set_option("pairs_ablation", 0)
         print(f"   setup {setup:.2f} s  {s.setup_times()}", flush=True)
         if a.check:
