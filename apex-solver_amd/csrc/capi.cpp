@@ -313,7 +313,13 @@ int apexgpu_get_unique_id(void* out128) {
 }
 int apexgpu_comm_init(apexgpu_solver* h, int world, int rank, const void* unique_id128) {
     H_OR_FAIL;
-    return h->s->comm_init(world, rank, unique_id128);
+    if (!unique_id128) return APEXGPU_ERR_INVALID_INPUT;
+    return guarded([&] { return h->s->comm_init(world, rank, unique_id128); });
+}
+int apexgpu_comm_init_shm(apexgpu_solver* h, int world, int rank, const char* name) {
+    H_OR_FAIL;
+    if (!name) return APEXGPU_ERR_INVALID_INPUT;
+    return guarded([&] { return h->s->comm_init_shm(world, rank, name); });
 }
 int apexgpu_shard_range(int64_t n_pt, int64_t n_obs, const uint32_t* pt_idx, int rank, int world, int64_t* lo, int64_t* hi) {
     if (!pt_idx || !lo || !hi || world < 1 || rank < 0 || rank >= world || n_pt <= 0) return APEXGPU_ERR_INVALID_INPUT;

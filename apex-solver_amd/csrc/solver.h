@@ -17,9 +17,9 @@
 #include "lm_loop.h"
 #include "schur_pairs.h"
 #include "stage_timer.h"
+#include "comm.h"
 #include "tile_plan.h"
 
-struct ncclComm;  // RCCL communicator (optional)
 
 namespace apex {
 
@@ -117,7 +117,8 @@ class Solver : public LmBackend {
     double local_obs() const { return (double)o_orig_h_.size(); }
 
     // multi-GPU (one process per GPU; landmarks sharded, S and g_red all-reduced over RCCL)
-    int comm_init(int world, int rank, const void* unique_id128);
+    int comm_init(int world, int rank, const void* unique_id128);          // RCCL over xGMI (production)
+    int comm_init_shm(int world, int rank, const char* name);              // host shared memory (bring-up / tests, comm.h)
     int set_shard(int rank, int world);  // without RCCL: assemble only this rank's landmark range
 
     const char* last_error() const override { return err_.c_str(); }
@@ -165,7 +166,8 @@ class Solver : public LmBackend {
     int pad_rank_ = 0;          // rank that writes the identity on the padding rows of the last tile (assemble_local)
     std::string comm_err_;      // text of the last failed collective inside TilePlan's hooks
     int64_t lm_lo_ = 0, lm_hi_ = 0;  // landmark range owned by this rank
-    ncclComm* comm_ = nullptr;
+    std::unique_ptr<Communicator> comm_;
+    int adopt_comm(std::unique_ptr<Communicator> c, const std::string& err);
 
     // host copies
     std::vector<int64_t> intr_col_, pose_col_, pt_col_;

@@ -10,10 +10,6 @@
 #include <chrono>
 #include <numeric>
 
-#ifdef APEX_WITH_RCCL
-#include <rccl/rccl.h>
-#endif
-
 namespace apex {
 
 #define HIP_TRY(expr)                                         \
@@ -22,14 +18,11 @@ namespace apex {
         if (_rc != kOk) return _rc;                           \
     } while (0)
 
-#ifdef APEX_WITH_RCCL
-// every collective's return code is surfaced as APEXGPU_ERR_DEVICE with RCCL's own text
-#define NCCL_TRY(expr)                                                                                      \
-    do {                                                                                                    \
-        ncclResult_t _r = (expr);                                                                           \
-        if (_r != ncclSuccess) return fail(kDeviceError, std::string("RCCL error in " #expr ": ") + ncclGetErrorString(_r)); \
+// every collective's result is surfaced as APEXGPU_ERR_DEVICE with the transport's own text (comm.h)
+#define COMM_TRY(expr)                                                                  \
+    do {                                                                                \
+        if (!(expr)) return fail(kDeviceError, comm_->error());                         \
     } while (0)
-#endif
 
 template <typename T>
 static hipError_t dev_alloc(T** p, size_t n) {
@@ -57,9 +50,7 @@ Solver::~Solver() {
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_, lam_mask_};
     for (void* p : ptrs)
         if (p) hipFree(p);
-#ifdef APEX_WITH_RCCL
-    if (comm_) ncclCommDestroy(reinterpret_cast<ncclComm_t>(comm_));
-#endif
+    comm_.reset();
     if (stream_) hipStreamDestroy(stream_);
 }
 
@@ -101,31 +92,33 @@ int Solver::set_shard(int rank, int world) {
     return kOk;
 }
 
+int Solver::adopt_comm(std::unique_ptr<Communicator> c, const std::string& err) {
+    if (!c) return fail(kDeviceError, err);
+    comm_ = std::move(c);
+    Communicator* cp = comm_.get();
+    TilePlan::Comm tc;
+    auto note = [this, cp](bool ok) { if (!ok) comm_err_ = cp->error(); return ok; };
+    tc.sum = [cp, note](double* buf, size_t n, hipStream_t st) { return note(cp->all_reduce_sum(buf, n, st)); };
+    tc.max_int = [cp, note](int* buf, size_t n, hipStream_t st) { return note(cp->all_reduce_max(buf, n, st)); };
+    tp_.set_comm(std::move(tc));
+    return kOk;
+}
+
 int Solver::comm_init(int world, int rank, const void* unique_id128) {
-#ifdef APEX_WITH_RCCL
     int rc = set_shard(rank, world);
     if (rc != kOk) return rc;
     HIP_TRY(hipSetDevice(device_));
-    ncclUniqueId id;
-    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
-    memcpy(&id, unique_id128, sizeof id);
-    ncclComm_t c;
-    ncclResult_t r = ncclCommInitRank(&c, world, id, rank);
-    if (r != ncclSuccess) return fail(kDeviceError, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
-    comm_ = reinterpret_cast<ncclComm*>(c);
-    TilePlan::Comm tc;
-    auto note = [this](ncclResult_t r, const char* what) {
-        if (r != ncclSuccess) comm_err_ = std::string("RCCL error in ") + what + ": " + ncclGetErrorString(r);
-        return r == ncclSuccess;
-    };
-    tc.sum = [c, note](double* buf, size_t n, hipStream_t st) { return note(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, c, st), "all-reduce (sum)"); };
-    tc.max_int = [c, note](int* buf, size_t n, hipStream_t st) { return note(ncclAllReduce(buf, buf, n, ncclInt, ncclMax, c, st), "all-reduce (max)"); };
-    tp_.set_comm(std::move(tc));
-    return kOk;
-#else
-    (void)world; (void)rank; (void)unique_id128;
-    return fail(kInvalidState, "library built without RCCL");
-#endif
+    std::string err;
+    return adopt_comm(make_rccl_comm(world, rank, unique_id128, &err), err);
+}
+
+// The same multi-rank schedule over the host shared-memory transport (comm.h): ranks = processes of one node.
+int Solver::comm_init_shm(int world, int rank, const char* name) {
+    int rc = set_shard(rank, world);
+    if (rc != kOk) return rc;
+    HIP_TRY(hipSetDevice(device_));
+    std::string err;
+    return adopt_comm(make_shm_comm(world, rank, name, &err), err);
 }
 
 // Landmark range [lo,hi) of `rank`: contiguous, balanced by observation count.  ptr[l] = number of
@@ -348,7 +341,6 @@ int Solver::set_params(const double* poses, const double* intr, const double* po
 int Solver::get_params(double* poses, double* intr, double* points) {
     if (!have_params_) return fail(kInvalidState, "no parameters set");
     HIP_TRY(hipSetDevice(device_));
-#ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1) {
         // every rank owns a contiguous landmark range: gather the owners' points everywhere
         // (ranges differ in size, so one broadcast per owner)
@@ -358,17 +350,15 @@ int Solver::get_params(double* poses, double* intr, double* points) {
         int64_t mine[2] = {lm_lo_, lm_hi_};
         int64_t* d_rng = reinterpret_cast<int64_t*>(scal_ + 8);
         HIP_TRY(hipMemcpyAsync(d_rng + 2 * rank_, mine, sizeof mine, hipMemcpyHostToDevice, stream_));
-        NCCL_TRY(ncclAllGather(d_rng + 2 * rank_, d_rng, 2 * sizeof(int64_t), ncclChar, reinterpret_cast<ncclComm_t>(comm_), stream_));
+        COMM_TRY(comm_->all_gather(d_rng + 2 * rank_, d_rng, 2 * sizeof(int64_t), stream_));
         std::vector<int64_t> rng(2 * world_);
         HIP_TRY(hipMemcpyAsync(rng.data(), d_rng, rng.size() * 8, hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         for (int r = 0; r < world_; ++r) {
             const int64_t a = rng[2 * r], b = rng[2 * r + 1];
-            if (b > a) NCCL_TRY(ncclBroadcast(pts_[cur_] + 3 * a, pts_[cur_] + 3 * a, 3 * (b - a), ncclDouble, r,
-                                              reinterpret_cast<ncclComm_t>(comm_), stream_));
+            if (b > a) COMM_TRY(comm_->broadcast(pts_[cur_] + 3 * a, 3 * (b - a), r, stream_));
         }
     }
-#endif
     std::vector<double> hp(7 * n_cam_), hi(3 * n_cam_);
     HIP_TRY(hipMemcpyAsync(hp.data(), poses_[cur_], 7 * n_cam_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipMemcpyAsync(hi.data(), intr_[cur_], 3 * n_cam_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -390,10 +380,8 @@ int Solver::get_params(double* poses, double* intr, double* points) {
 int Solver::cost_of(int which, double* out) {
     stage_begin(kStCost);
     launch_cost(view(which), partial_, n_partial_, scal_, stream_);
-#ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1)
-        NCCL_TRY(ncclAllReduce(scal_, scal_, 1, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_));
-#endif
+        COMM_TRY(comm_->all_reduce_sum(scal_, 1, stream_));
     stage_end(kStCost);
     HIP_TRY(hipGetLastError());
     double ss = 0.0;
@@ -416,33 +404,29 @@ int Solver::cost(double* out) {
 int Solver::assemble(double lambda, double diag_extra, bool for_factor) {
     int rc = assemble_local(lambda, diag_extra, for_factor);
     if (rc != kOk) return rc;
-#ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1) {
         stage_begin(kStAllReduce);
-        ncclComm_t c = reinterpret_cast<ncclComm_t>(comm_);
         // A distributed factorisation sums the shared top tiles itself, after the local levels, and a rank's local
         // levels read its own columns only: every column's tiles are reduced to their owner (tile_plan.h).
         const size_t te = (size_t)kNB * kNB;
-        NCCL_TRY(ncclGroupStart());
+        COMM_TRY(comm_->group_start());
         if (for_factor && tp_.distributed() && tree_shard_) {
             // tree sharding: a rank's landmarks are exactly those that touch its columns -- its tiles are complete
         } else if (for_factor && tp_.distributed()) {
             for (int o = 0; o < tp_.part_world(); ++o) {
                 const std::pair<int64_t, int64_t> rg = tp_.owner_slot_range(o);
                 if (rg.second > 0)
-                    NCCL_TRY(ncclReduce(tp_.tiles() + (size_t)rg.first * te, tp_.tiles() + (size_t)rg.first * te, (size_t)rg.second * te,
-                                        ncclDouble, ncclSum, o, c, stream_));
+                    COMM_TRY(comm_->reduce_sum(tp_.tiles() + (size_t)rg.first * te, (size_t)rg.second * te, o, stream_));
             }
         } else {
-            NCCL_TRY(ncclAllReduce(tp_.tiles(), tp_.tiles(), (size_t)tp_.n_touched_slots() * te, ncclDouble, ncclSum, c, stream_));
+            COMM_TRY(comm_->all_reduce_sum(tp_.tiles(), (size_t)tp_.n_touched_slots() * te, stream_));
         }
-        NCCL_TRY(ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_));
-        NCCL_TRY(ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_));
-        NCCL_TRY(ncclAllReduce(flags_, flags_, 1, ncclInt, ncclMax, c, stream_));  // a singular landmark block anywhere fails the solve on every rank
-        NCCL_TRY(ncclGroupEnd());
+        COMM_TRY(comm_->all_reduce_sum(g_red_, (size_t)n_c_pad_, stream_));
+        COMM_TRY(comm_->all_reduce_sum(g_c_, (size_t)n_c_pad_, stream_));
+        COMM_TRY(comm_->all_reduce_max(flags_, 1, stream_));  // a singular landmark block anywhere fails the solve on every rank
+        COMM_TRY(comm_->group_end());
         stage_end(kStAllReduce);
     }
-#endif
     return assemble_finish();
 }
 
@@ -572,19 +556,16 @@ int Solver::assemble_implicit(double lambda) {
     launch_cam_reduce(dc_, v, tilemap(), cam_ptr_, cam_obs_, lambda, rank_ == 0 ? 1 : 0, hinv_, g_l_, 1, g_c_, g_red_, stream_);
     launch_extract_diag_blocks(dc_, n_cam_, tilemap(), sd_, stream_);
     stage_end(kStAssembleCam);
-#ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1) {
         stage_begin(kStAllReduce);
-        ncclComm_t c = reinterpret_cast<ncclComm_t>(comm_);
-        NCCL_TRY(ncclGroupStart());
-        NCCL_TRY(ncclAllReduce(sd_, sd_, (size_t)n_cam_ * dc_ * dc_, ncclDouble, ncclSum, c, stream_));
-        NCCL_TRY(ncclAllReduce(g_red_, g_red_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_));
-        NCCL_TRY(ncclAllReduce(g_c_, g_c_, (size_t)n_c_pad_, ncclDouble, ncclSum, c, stream_));
-        NCCL_TRY(ncclAllReduce(flags_, flags_, 1, ncclInt, ncclMax, c, stream_));  // a singular landmark block anywhere fails the solve on every rank
-        NCCL_TRY(ncclGroupEnd());
+        COMM_TRY(comm_->group_start());
+        COMM_TRY(comm_->all_reduce_sum(sd_, (size_t)n_cam_ * dc_ * dc_, stream_));
+        COMM_TRY(comm_->all_reduce_sum(g_red_, (size_t)n_c_pad_, stream_));
+        COMM_TRY(comm_->all_reduce_sum(g_c_, (size_t)n_c_pad_, stream_));
+        COMM_TRY(comm_->all_reduce_max(flags_, 1, stream_));  // a singular landmark block anywhere fails the solve on every rank
+        COMM_TRY(comm_->group_end());
         stage_end(kStAllReduce);
     }
-#endif
     stage_begin(kStAssembleCam);
     if (scaled_) {
         launch_scale_diag_blocks(dc_, n_cam_, cam_scale_, sd_, stream_);
@@ -605,10 +586,8 @@ int Solver::implicit_matvec(const double* x, double lam_local, double* y, bool r
         xin = t;
     }
     launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xin, lam_local, y, stream_);
-#ifdef APEX_WITH_RCCL
     if (reduce && comm_ && world_ > 1)
-        NCCL_TRY(ncclAllReduce(y, y, (size_t)n_c_, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_));
-#endif
+        COMM_TRY(comm_->all_reduce_sum(y, (size_t)n_c_, stream_));
     if (scaled_) launch_vec_mul(n_c_, y, cam_scale_, y, stream_);
     return check_hip(hipGetLastError(), "implicit_matvec");
 }
@@ -814,10 +793,8 @@ int Solver::step_stats(double out3[3]) {
     stage_begin(kStStats);
     launch_step_stats(n_c_, g_c_, dcam_, last_lambda_, scaled_ ? cam_scale_ : nullptr, partial_, n_partial_, scal_, stream_);
     launch_step_stats(3 * n_pt_, g_l_, dl_, last_lambda_, scaled_ ? pt_scale_ : nullptr, partial_, n_partial_, scal_ + 3, stream_);
-#ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1)  // landmark part is sharded, camera part replicated
-        NCCL_TRY(ncclAllReduce(scal_ + 3, scal_ + 3, 3, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_));
-#endif
+        COMM_TRY(comm_->all_reduce_sum(scal_ + 3, 3, stream_));
     stage_end(kStStats);
     double h[6];
     HIP_TRY(hipMemcpyAsync(h, scal_, sizeof h, hipMemcpyDeviceToHost, stream_));
@@ -871,10 +848,8 @@ int Solver::parameter_norm(double* out) {
     launch_sumsq(3 * n_cam_, intr_[cur_], partial_, n_partial_, scal_ + 10, stream_);
     // points: in a sharded run only the owned range is current on this rank
     launch_sumsq(3 * (lm_hi_ - lm_lo_), pts_[cur_] + 3 * lm_lo_, partial_, n_partial_, scal_ + 11, stream_);
-#ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1)
-        NCCL_TRY(ncclAllReduce(scal_ + 11, scal_ + 11, 1, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_));
-#endif
+        COMM_TRY(comm_->all_reduce_sum(scal_ + 11, 1, stream_));
     double h[3];
     HIP_TRY(hipMemcpyAsync(h, scal_ + 9, sizeof h, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -903,10 +878,8 @@ int Solver::column_norms_sq_device() {
     HIP_TRY(hipMemsetAsync(cam_scale_, 0, n_c_pad_ * sizeof(double), stream_));
     HIP_TRY(hipMemsetAsync(pt_scale_, 0, std::max<int64_t>(3 * n_pt_, 1) * sizeof(double), stream_));
     launch_column_norms_sq(dc_, v, cam_scale_, pt_scale_, stream_);
-#ifdef APEX_WITH_RCCL
     if (comm_ && world_ > 1)  // every rank sees all cameras but only its own landmarks
-        NCCL_TRY(ncclAllReduce(cam_scale_, cam_scale_, (size_t)n_c_, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm_), stream_));
-#endif
+        COMM_TRY(comm_->all_reduce_sum(cam_scale_, (size_t)n_c_, stream_));
     return kOk;
 }
 

@@ -233,6 +233,9 @@ class GpuSchurComplementSolver:
 
     def with_shard(self, rank: int, world: int): self._shard = (rank, world); return self
     def with_communicator(self, world: int, rank: int, unique_id: bytes): self._comm = (world, rank, unique_id); return self
+    def with_shm_communicator(self, world: int, rank: int, name: str):
+        """The multi-rank schedule over host shared memory (bring-up / tests: csrc/comm.h) instead of RCCL."""
+        self._comm = (world, rank, name); return self
 
     # StructureAware::initialize_structure
     def initialize_structure(self, problem: Problem):
@@ -242,8 +245,11 @@ class GpuSchurComplementSolver:
         h = self._h
         if self._comm is not None:
             world, rank, uid = self._comm
-            buf = (C.c_char * 128).from_buffer_copy(uid)
-            h.check(h.L.apexgpu_comm_init(h.h, world, rank, C.cast(buf, C.c_void_p)))
+            if isinstance(uid, str):    # host shared-memory transport
+                h.check(h.L.apexgpu_comm_init_shm(h.h, world, rank, uid.encode()))
+            else:
+                buf = (C.c_char * 128).from_buffer_copy(uid)
+                h.check(h.L.apexgpu_comm_init(h.h, world, rank, C.cast(buf, C.c_void_p)))
         elif self._shard is not None:
             h.check(h.L.apexgpu_set_shard(h.h, *self._shard))
         for k, v in self._pre_options.items():

@@ -360,10 +360,15 @@ def main():
     # ---- roofline of the graded Schur-reduction kernel, per launch -------------------------------------------------------
     dc = 9 if args.mode == "selfcal" else 6
     form = info.get("schur_form", 3)
-    kernel = {3: "k_schur_pairs_h", 2: "k_schur_rows2", 1: "k_schur_rows", 0: "k_schur_scatter"}[form]
+    pv = next((int(o.split("=")[1]) for o in args.opt if o.split("=")[0] == "pairs_variant"), 2)
+    kernel = {3: {2: "k_schur_pairs_r", 3: "k_schur_pairs_r2", 1: "k_schur_pairs_h", 0: "k_schur_pairs"}.get(pv, "k_schur_pairs_r"),
+              2: "k_schur_rows2", 1: "k_schur_rows", 0: "k_schur_scatter"}[form]
+    record_form = form == 3 and pv >= 2
     n_obs_local = info["local_obs"]
     tile_bytes = 144 * 144 * 8
-    # SURVEY §8(d), fused form (J never stored): each input read once, each output written once
+    # SURVEY §8(d), fused form (J never stored): each input read once, each output written once.  The record form (the
+    # default pair kernel) reads a 32-byte projection record per observation instead of the 24-byte observation record;
+    # the figure below stays the survey's fused-form one (the smaller of the two), so `frac` is comparable across rounds.
     alg_bytes = (24.0 * n_obs_local            # observation stream: cam idx, landmark idx, (u,v)
                  + 80.0 * d.n_cam + 24.0 * d.n_pt  # poses + intrinsics, points (each read once)
                  + 96.0 * d.n_pt                # Hll^-1 and g_l per landmark
@@ -378,14 +383,17 @@ def main():
     # observation linearised once (~125 fp64 operations); the kernel re-linearises both observations of every pair
     off_pairs = info["pair_blocks"] - n_obs_local      # pair contributions without the self pairs
     useful_flop = 2.0 * (12 + 4 * dc + 2 * dc * dc) * off_pairs + 250.0 * n_obs_local
-    executed_flop = (2.0 * (12 + 4 * dc + 2 * dc * dc) + 2 * 250.0 + 36.0) * off_pairs
+    executed_flop = ((2.0 * (12 + 4 * dc + 2 * dc * dc) + 2 * 120.0 + 36.0) if record_form else (2.0 * (12 + 4 * dc + 2 * dc * dc) + 2 * 250.0 + 36.0)) * off_pairs
     stage_ms = sum(stages[k][0] / max(stages[k][1], 1) * (2 if k == "cam_reduce" else 1) for k in ("landmark_reduce", "cam_reduce", "schur_scatter"))
     stage_ms = (stages["landmark_reduce"][0] + stages["cam_reduce"][0] + stages["schur_scatter"][0]) / max(sc_n, 1)
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
                 "pair_list_bytes": pair_list_bytes if form == 3 else 0.0,
                 "avg_launch_ms": sc_avg, "launches": sc_n,
-                "actual_bound": "fp64 vector unit + LDS (the fused form moves 2 GB but executes ~60 GFLOP: DESIGN.md §4)",
+                "actual_bound": ("L2-miss line rate of the per-pair gathers: ~1.5e8 64-byte lines per launch at ~8 clocks per line and CU "
+                                 "(tools/vmem_issue_bench.hip, profiles/r03_vmem_issue_bench.txt; DESIGN.md section 4)") if record_form else
+                                "fp64 vector unit + LDS (the fused form moves 2 GB but executes ~60 GFLOP: DESIGN.md section 4)",
+                "projection_record_bytes": 32.0 * n_obs_local if record_form else 0.0,
                 "pair_contributions_per_launch": off_pairs,
                 "fp64_useful_gflops": useful_flop / (sc_avg * 1e-3) / 1e9 if sc_avg > 0 else 0.0,
                 "fp64_executed_gflops": executed_flop / (sc_avg * 1e-3) / 1e9 if sc_avg > 0 else 0.0,
@@ -398,13 +406,14 @@ def main():
     # HBM traffic of the same kernel from the committed PMC pass (rocprofv3 cannot run inside this
     # process); only attached when the committed profile is of this very workload and kernel
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_final13682_pmc_summary.json")))
+        pm_path = next(p for p in (os.path.join(ROOT, "profiles", f"r0{r}_final13682_pmc_summary.json") for r in (3, 2)) if os.path.exists(p))
+        pm = json.load(open(pm_path))
         if world == 1 and args.workload == "final-13682" and args.scale == 1.0 and args.mode == "selfcal":
             k = [v for n, v in pm["kernels"].items() if kernel in n]
             if k:
                 roofline["traffic"] = k[0]["hbm_bytes_per_launch_corrected"]
                 roofline["traffic_raw"] = k[0].get("hbm_bytes_per_launch_raw")
-                roofline["traffic_source"] = "profiles/r02_final13682_pmc_summary.json"
+                roofline["traffic_source"] = os.path.relpath(pm_path, ROOT)
     except Exception:
         pass
 

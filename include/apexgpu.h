@@ -292,6 +292,12 @@ int apexgpu_setup_times(apexgpu_solver* h, double seconds[6], double counts[4]);
  * by every rank, and the triangular sweeps exchange two n-vectors (csrc/tile_plan.h). */
 int apexgpu_get_unique_id(void* out128);
 int apexgpu_comm_init(apexgpu_solver* h, int world, int rank, const void* unique_id128);
+/* The same multi-rank schedule over HOST SHARED MEMORY instead of RCCL (csrc/comm.h): the ranks are processes of one node --
+ * they may share one GPU -- and every collective is staged through a POSIX shared-memory segment named after `name`
+ * (a string common to the ranks of ONE run and to no other), summed in rank order.  For bring-up and tests: every
+ * world > 1 branch of the library runs with the real kernels on a single-GPU box, where RCCL cannot be initialised with
+ * two ranks.  Same call order and error convention as apexgpu_comm_init (before apexgpu_set_structure). */
+int apexgpu_comm_init_shm(apexgpu_solver* h, int world, int rank, const char* name);
 int apexgpu_set_shard(apexgpu_solver* h, int rank, int world);
 /* Test entry for the distributed solve without a communicator: hs[0..n) are the ranks of ONE sharded problem
  * (apexgpu_set_shard(r, n), same structure and parameters) living in this process on one GPU; one Cholesky solve of
