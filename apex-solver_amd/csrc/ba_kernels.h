@@ -32,7 +32,17 @@ struct BAView {
     // which rank adds lambda to a camera's diagonal block: NULL = rank 0 for every camera (all partial S are summed);
     // tree sharding: the owner of the camera's tile column (its tiles are never summed), rank 0 for the shared top
     const uint8_t* lam_mask;  // [n_cam]
+    // Camera staging of the landmark-major kernels (k_landmark_reduce, k_back_substitute; NULL = off): a workgroup handles
+    // kLmWg consecutive landmarks, whose observations see a few dozen DISTINCT cameras; the host lists them per workgroup
+    // (wg_cam_list[w][0 .. wg_cam_n[w]), first-appearance order) and gives every observation its camera's slot in that list
+    // (o_slot[i], 255 = not staged: the list is capped at kCamStageCap).  The workgroup copies those cameras to LDS once
+    // -- a few hundred line accesses instead of ten scattered 16-byte loads per observation and lane.
+    const uint8_t* o_slot;        // [n_obs]
+    const uint8_t* wg_cam_n;      // [workgroups]
+    const uint32_t* wg_cam_list;  // [workgroups][kCamStageCap]
 };
+constexpr int kLmWg = 64;           // landmarks per workgroup of the landmark-major kernels (256 threads / 4 lanes per landmark)
+constexpr int kCamStageCap = 128;   // distinct cameras staged per workgroup (slot 255 = gather from memory)
 
 // Per-landmark record written by k_landmark_reduce and read by the camera-major kernels: everything a
 // camera-major gather needs from a landmark sits in ONE 128-byte line instead of three arrays.

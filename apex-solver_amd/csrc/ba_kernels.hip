@@ -166,6 +166,29 @@ __global__ __launch_bounds__(kCamThreads, 2) void k_cam_reduce(BAView v, TileMap
 // K2a: landmark-major reduction, 8 lanes per landmark (32 landmarks per 256-thread block).
 // H_ll = sum Jl^T Jl + lambda I, g_l = sum Jl^T r, eigen-gated inverse.
 // ------------------------------------------------------------------------------------------
+// Camera staging (BAView::o_slot): the workgroup's distinct cameras, compact form (+ EXTRA doubles each, e.g. the camera
+// step), copied to LDS by all 256 threads; returns after the barrier.  STR doubles per slot (even: 16-byte pieces).
+template <int STR, int EXTRA>
+__device__ __forceinline__ void stage_cams(const BAView& v, const double* __restrict__ extra, double* __restrict__ sCam) {
+    static_assert(STR % 2 == 0 && STR >= kCamQStride + EXTRA, "slot pitch");
+    if (v.o_slot) {
+        const int n = v.wg_cam_n[blockIdx.x];
+        const uint32_t* __restrict__ list = v.wg_cam_list + (size_t)blockIdx.x * kCamStageCap;
+        constexpr int PQ = kCamQStride / 2;
+        for (int idx = threadIdx.x; idx < n * PQ; idx += 256) {
+            const int k = idx / PQ, p = idx - PQ * k;
+            reinterpret_cast<double2*>(sCam + k * STR)[p] = reinterpret_cast<const double2*>(v.camq + kCamQStride * (size_t)list[k])[p];
+        }
+        if (EXTRA > 0) {
+            for (int idx = threadIdx.x; idx < n * EXTRA; idx += 256) {
+                const int k = idx / EXTRA, a = idx - EXTRA * k;
+                sCam[k * STR + kCamQStride + a] = extra[(size_t)list[k] * EXTRA + a];
+            }
+        }
+    }
+    __syncthreads();
+}
+
 constexpr int kLmLanes = 4;   // lanes per landmark in the landmark-major kernels.  final-13682 (3..9 observations per landmark): 8 lanes
                               // 1.05 + 0.97 ms (k_landmark_reduce + k_back_substitute), 4 lanes 0.87 + 0.77, 2 lanes 0.74 + 0.68, 1 lane
                               // 0.75 + 0.73; 4 keeps the tail of a landmark with a thousand observations at a few hundred microseconds
@@ -173,6 +196,9 @@ template <int DC>
 __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda, double* __restrict__ hinv,
                                                            double* __restrict__ g_l, int* __restrict__ err_flag,
                                                            double* __restrict__ lmu, double* __restrict__ orec) {
+    static_assert(256 / kLmLanes == kLmWg, "camera staging lists are built per kLmWg landmarks");
+    __shared__ double sCam[kCamStageCap * kCamQStride];
+    stage_cams<kCamQStride, 0>(v, nullptr, sCam);
     const int g = threadIdx.x & (kLmLanes - 1);
     const int64_t l = (int64_t)blockIdx.x * (256 / kLmLanes) + threadIdx.x / kLmLanes;
     const bool active = l < v.n_pt;
@@ -181,10 +207,11 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
         const int b = v.pt_ptr[l], e = v.pt_ptr[l + 1];
         pw[0] = v.pts[3 * l]; pw[1] = v.pts[3 * l + 1]; pw[2] = v.pts[3 * l + 2];
         for (int i = b + g; i < e; i += kLmLanes) {
-            const uint32_t c = v.o_cam[i];
             const double2 uv = v.o_uv[i];
             Cam cam;
-            load_cam_q(v.camq + kCamQStride * (size_t)c, v.mask_code, cam);
+            const int sl = v.o_slot ? (int)v.o_slot[i] : 255;
+            if (sl != 255) load_cam_q(sCam + sl * kCamQStride, v.mask_code, cam);
+            else load_cam_q(v.camq + kCamQStride * (size_t)v.o_cam[i], v.mask_code, cam);
             double r[2], Jc[2][DC], Jl[2][3];
             if (orec) {   // record form of the pair kernel: the observation's projection record, 32 bytes, landmark-major
                 double rec[4];
@@ -704,6 +731,9 @@ __global__ __launch_bounds__(256) void k_back_substitute(BAView v, const double*
                                                            const double* __restrict__ g_l,
                                                            const double* __restrict__ dc,
                                                            double* __restrict__ dl) {
+    constexpr int STR = kCamQStride + DC + ((kCamQStride + DC) & 1);   // camera | its step, 16-byte pieces
+    __shared__ double sCam[kCamStageCap * STR];
+    stage_cams<STR, DC>(v, dc, sCam);
     const int g = threadIdx.x & (kLmLanes - 1);
     const int64_t l = (int64_t)blockIdx.x * (256 / kLmLanes) + threadIdx.x / kLmLanes;
     const bool active = l < v.n_pt;
@@ -712,16 +742,26 @@ __global__ __launch_bounds__(256) void k_back_substitute(BAView v, const double*
         const int b = v.pt_ptr[l], e = v.pt_ptr[l + 1];
         const double pw[3] = {v.pts[3 * l], v.pts[3 * l + 1], v.pts[3 * l + 2]};
         for (int i = b + g; i < e; i += kLmLanes) {
-            const uint32_t c = v.o_cam[i];
             const double2 uv = v.o_uv[i];
             Cam cam;
-            load_cam_q(v.camq + kCamQStride * (size_t)c, v.mask_code, cam);
+            double dcv[DC];
+            const int sl = v.o_slot ? (int)v.o_slot[i] : 255;
+            if (sl != 255) {
+                load_cam_q(sCam + sl * STR, v.mask_code, cam);
+#pragma unroll
+                for (int a = 0; a < DC; ++a) dcv[a] = sCam[sl * STR + kCamQStride + a];
+            } else {
+                const uint32_t c = v.o_cam[i];
+                load_cam_q(v.camq + kCamQStride * (size_t)c, v.mask_code, cam);
+#pragma unroll
+                for (int a = 0; a < DC; ++a) dcv[a] = dc[(size_t)c * DC + a];
+            }
             double r[2], Jc[2][DC], Jl[2][3];
             linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int a = 0; a < DC; ++a) {
-                const double d = dc[(size_t)c * DC + a];
+                const double d = dcv[a];
                 s0 += Jc[0][a] * d; s1 += Jc[1][a] * d;
             }
 #pragma unroll

