@@ -800,8 +800,9 @@ __device__ __noinline__ void pairs_flush_slow(double* __restrict__ dst, const ui
 // dependent round trips through the LDS crossbar (ds_bpermute): sub-blocks 0..7 own one aligned OCTET of lanes each
 // (lane = 8 sub + g, g = 0..6) and sub-block 8 takes the octets' eighth lanes (lane = 8 g + 7; lane 63 idles and ends up
 // holding sub-block 8's total).
-template <int DC>
+template <int DC, bool LEGACY = false>
 __device__ __forceinline__ void pairs_lane_map(int lane, int& g, int& sub) {
+    if (DC == 9 && LEGACY) { g = lane / 9; sub = lane - 9 * g; return; }   // lane = 9 g + sub, fold by ds_bpermute (A/B)
     if (DC == 9) {
         const bool eighth = (lane & 7) == 7;
         sub = eighth ? 8 : lane >> 3;
@@ -816,15 +817,15 @@ __device__ __forceinline__ double dpp_add_masked(double x) {   // x + (x moved b
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, BANK_MASK, true);
     return x + __hiloint2double(hi, lo);
 }
-template <int DC>
+template <int DC, bool LEGACY = false>
 __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const int64_t pb_dst, const uint32_t pb_flags,
                                              double acc[9], int lane) {
     constexpr int NB3 = DC / 3, GL = NB3 * NB3;
     constexpr int NG = (DC == 9) ? 7 : 16, P2 = (DC == 9) ? 8 : 16;
     int g, sub;
-    pairs_lane_map<DC>(lane, g, sub);
+    pairs_lane_map<DC, LEGACY>(lane, g, sub);
     bool storer;
-    if (DC == 9) {
+    if (DC == 9 && !LEGACY) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             // sub-blocks 0..7: sum over the octet's lanes 0..6 into lane 6 (row_shr 4, 2, 1 into the upper half-octets only)
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     double* Z = V + 64 * UV;
     if (lane < UV) Z[lane] = 0.0;
     int g, sub;
-    pairs_lane_map<DC>(lane, g, sub);
+    pairs_lane_map<DC, (ABL & 256) != 0>(lane, g, sub);
     const int bi = sub / NB3, bj = sub - bi * NB3;
     const bool worker = g < NG;
     double acc[9];
@@ -1170,7 +1171,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         };
         auto flush = [&]() {
             const unsigned long long f0 = stamp();
-            if (!(ABL & 8)) pairs_flush2<DC>(tiles, cur_dst, cur_flags, acc, lane);
+            if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0>(tiles, cur_dst, cur_flags, acc, lane);
             else if (acc[0] == 1.2345e300) tiles[0] = acc[1];
             if (ABL & 64) { ph[6] += stamp() - f0; ph[7] += 1; }
         };
@@ -1237,7 +1238,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         for (int k = 0; k < 8; ++k) atomicAdd(&g_pair_phase[k], ph[k]);
     }
     if (cur >= 0) {
-        if (!(ABL & 8)) pairs_flush2<DC>(tiles, cur_dst, cur_flags, acc, lane);
+        if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0>(tiles, cur_dst, cur_flags, acc, lane);
         else if (acc[0] == 1.2345e300) tiles[0] = acc[1];
     }
 }
@@ -1511,7 +1512,7 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
     const int g_pairs_variant = variant, g_pairs_ablation = ablation;
     if (variant >= 2 && orec && ablation != 0 && dc == 9) {   // timing experiments on the record form (SelfCalibration only)
 #define PAIRS_RA(A) case A: hipLaunchKernelGGL((k_schur_pairs_r<9, false, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec); break
-        switch (ablation) { PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3); default: break; }
+        switch (ablation) { PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3); default: break; }
 #undef PAIRS_RA
         return;
     }
