@@ -284,6 +284,38 @@ APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, doubl
     return true;
 }
 
+// ---- the Jacobian of one observation from its projection record (device code only) ---------------------------------
+// J follows from the record and the camera without the projection:
+//     Jl = a = (f w inz) [dxx dxy .; dxy dyy .] R      (2 x 3, corrected)
+//     Jc = [ a | -a [p_w]x | (xn w, yn w)^T (dist, f r2, f r4) ]                                    (2 x 9)
+#if defined(__HIPCC__)
+struct RecJac {          // what one observation contributes to a pair: a (= Jl), the intrinsics factors
+    double a[2][3];
+    double xw, yw;        // xn w, yn w
+    double t[3];          // dist, f r2, f r4
+};
+// cv: the staged camera (R row-major at 0..8, f k1 k2 at 12..14)
+__device__ __forceinline__ void jac_from_rec(const double* __restrict__ cv, const double2 r01, const double2 r23, RecJac& o) {
+    const double xn = r01.x, yn = r01.y, inz = r23.x, w = r23.y;
+    const double f = cv[12], k1 = cv[13], k2 = cv[14];
+    const double r2 = fma(yn, yn, xn * xn), r4 = r2 * r2;
+    const double dist = fma(k2, r4, fma(k1, r2, 1.0));
+    const double t2 = fma(4.0 * k2, r2, 2.0 * k1);            // 2 d(dist)/d(r2)
+    const double txn = t2 * xn;
+    const double dxx = fma(txn, xn, dist), dxy = txn * yn, dyy = fma(t2 * yn, yn, dist);
+    const double s = (f * w) * inz;
+    const double J00 = s * dxx, J01 = s * dxy, J11 = s * dyy;
+    const double J02 = fma(xn, J00, yn * J01), J12 = fma(xn, J01, yn * J11);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o.a[0][c] = fma(J00, cv[c], fma(J01, cv[3 + c], J02 * cv[6 + c]));
+        o.a[1][c] = fma(J01, cv[c], fma(J11, cv[3 + c], J12 * cv[6 + c]));
+    }
+    o.xw = xn * w; o.yw = yn * w;
+    o.t[0] = dist; o.t[1] = f * r2; o.t[2] = f * r4;
+}
+#endif
+
 // ---- 3x3 symmetric block: eigenvalue gate + inverse (A9) ---------------------------------
 // B (symmetric, row-major 9) -> Binv.  Returns false iff the (regularised) matrix has a zero
 // determinant (LinAlgError::SingularMatrix in the reference).

@@ -103,7 +103,7 @@ void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv
                             double* lmu /* may be NULL */, hipStream_t s, double* orec = nullptr);
 // A18 (implicit_schur.rs): y = S x matrix-free, the Schur-Jacobi preconditioner blocks and their application
 void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
-                            double lambda, double* y, hipStream_t s);
+                            double lambda, double* y, hipStream_t s, const double* orec = nullptr);
 void launch_extract_diag_blocks(int dc, int64_t n_cam, const TileMap& tm, double* sd, hipStream_t s);
 void launch_precond_blocks(int dc, int64_t n_cam, const double* sd, double* minv, hipStream_t s);
 void launch_precond_apply(int dc, int64_t n_cam, const double* minv, const double* r, double* z, hipStream_t s);
@@ -116,8 +116,9 @@ void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask
                        const double* hinv, int dbg, hipStream_t s);
 void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
                         const RowChunk* chunks, const RowEntry* entries, const int* nbr, const double* hinv, hipStream_t s);
+// orec: the projection records of the same linearisation (k_landmark_reduce) or NULL -- the record form of the kernel
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
-                            double* dl, hipStream_t s);
+                            double* dl, hipStream_t s, const double* orec = nullptr);
 void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, const double* intr, const double* pts,
                     const double* dcam, const double* dl, double sign, const uint8_t* fix_pose,
                     const uint8_t* fix_intr, const uint8_t* fix_pt, double* poses_out, double* intr_out,

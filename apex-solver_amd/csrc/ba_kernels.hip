@@ -189,6 +189,47 @@ __device__ __forceinline__ void stage_cams(const BAView& v, const double* __rest
     __syncthreads();
 }
 
+// The same staging in three steps, so that a kernel can put its own loads between them: the landmark-major kernels are
+// bound by the latency of their dependent loads (workgroup list -> cameras -> barrier, then pt_ptr -> observations), and
+// interleaved the two chains cost two round trips instead of four.  Every load is unconditional on a clamped index
+// (straight-line code: nothing keeps the compiler from issuing the caller's loads in between); only the LDS stores are
+// predicated.  Item q of camera k: q < 5 the q-th 16-byte piece of the compact camera, else extra[cam][q - 5].
+// CAMD: doubles per camera in the source array (kCamQStride: the compact form, kCamStride: the prepared records).
+template <int STR, int EXTRA, int CAMD = kCamQStride>
+struct CamStager {
+    static constexpr int PQ = CAMD / 2, IT = PQ + EXTRA, NJ = (kCamStageCap * IT + 255) / 256;
+    static_assert(STR % 2 == 0 && CAMD % 2 == 0 && STR >= CAMD + EXTRA, "slot pitch");
+    uint32_t ci[NJ];
+    double2 d[NJ];
+    int n;
+    __device__ __forceinline__ void issue_indices(const BAView& v) {
+        // (the list is zero-padded to kCamStageCap entries: no need to wait for n before reading it)
+        n = v.o_slot ? v.wg_cam_n[blockIdx.x] : 0;
+        const uint32_t* __restrict__ list = v.wg_cam_list + (size_t)blockIdx.x * kCamStageCap;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ci[j] = list[min(((int)threadIdx.x + 256 * j) / IT, kCamStageCap - 1)];
+    }
+    __device__ __forceinline__ void issue_data(const double* __restrict__ cams, const double* __restrict__ extra) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int idx = (int)threadIdx.x + 256 * j, q = idx % IT;
+            if (EXTRA == 0 || q < PQ) d[j] = reinterpret_cast<const double2*>(cams + CAMD * (size_t)ci[j])[q];
+            else d[j] = make_double2(extra[(size_t)ci[j] * EXTRA + (q - PQ)], 0.0);
+        }
+    }
+    __device__ __forceinline__ void store(double* __restrict__ sCam) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int idx = (int)threadIdx.x + 256 * j, k = idx / IT, q = idx - IT * k;
+            if (k < n) {
+                if (EXTRA == 0 || q < PQ) reinterpret_cast<double2*>(sCam + k * STR)[q] = d[j];
+                else sCam[k * STR + CAMD + (q - PQ)] = d[j].x;
+            }
+        }
+        __syncthreads();
+    }
+};
+
 constexpr int kLmLanes = 4;   // lanes per landmark in the landmark-major kernels.  final-13682 (3..9 observations per landmark): 8 lanes
                               // 1.05 + 0.97 ms (k_landmark_reduce + k_back_substitute), 4 lanes 0.87 + 0.77, 2 lanes 0.74 + 0.68, 1 lane
                               // 0.75 + 0.73; 4 keeps the tail of a landmark with a thousand observations at a few hundred microseconds
@@ -198,18 +239,30 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
                                                            double* __restrict__ lmu, double* __restrict__ orec) {
     static_assert(256 / kLmLanes == kLmWg, "camera staging lists are built per kLmWg landmarks");
     __shared__ double sCam[kCamStageCap * kCamQStride];
-    stage_cams<kCamQStride, 0>(v, nullptr, sCam);
     const int g = threadIdx.x & (kLmLanes - 1);
     const int64_t l = (int64_t)blockIdx.x * (256 / kLmLanes) + threadIdx.x / kLmLanes;
     const bool active = l < v.n_pt;
     double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0}, pw[3] = {0, 0, 0};
+    // two round trips to memory before the arithmetic starts: (list, pt_ptr), then (cameras, point, first observation)
+    CamStager<kCamQStride, 0> stager;
+    stager.issue_indices(v);
+    const int64_t lc = active ? l : 0;
+    const int b = v.pt_ptr[lc], e = active ? v.pt_ptr[lc + 1] : b;
+    stager.issue_data(v.camq, nullptr);
+    pw[0] = v.pts[3 * lc]; pw[1] = v.pts[3 * lc + 1]; pw[2] = v.pts[3 * lc + 2];
+    const int i_first = max(min(b + g, (int)v.n_obs - 1), 0);   // (clamped: the load is unconditional, the use is not)
+    double2 uv_next = v.o_uv[i_first];
+    int sl_next = v.o_slot ? (int)v.o_slot[i_first] : 255;
+    stager.store(sCam);
     if (active) {
-        const int b = v.pt_ptr[l], e = v.pt_ptr[l + 1];
-        pw[0] = v.pts[3 * l]; pw[1] = v.pts[3 * l + 1]; pw[2] = v.pts[3 * l + 2];
         for (int i = b + g; i < e; i += kLmLanes) {
-            const double2 uv = v.o_uv[i];
+            const double2 uv = uv_next;
+            const int sl = sl_next;
+            if (i + kLmLanes < e) {   // the next observation's record is in flight while this one is linearised
+                uv_next = v.o_uv[i + kLmLanes];
+                sl_next = v.o_slot ? (int)v.o_slot[i + kLmLanes] : 255;
+            }
             Cam cam;
-            const int sl = v.o_slot ? (int)v.o_slot[i] : 255;
             if (sl != 255) load_cam_q(sCam + sl * kCamQStride, v.mask_code, cam);
             else load_cam_q(v.camq + kCamQStride * (size_t)v.o_cam[i], v.mask_code, cam);
             double r[2], Jc[2][DC], Jl[2][3];
@@ -726,26 +779,82 @@ __global__ __launch_bounds__(kRow2Threads) void k_schur_rows2(BAView v, TileMap 
 // ------------------------------------------------------------------------------------------
 // MATVEC = true is the landmark half of the matrix-free Schur operator (A18, implicit_schur.rs:186-226):
 // u_l = Hll^-1 (H_cl^T x), written next to the point into the 64-byte record lmu[l] = {pt, -, u, -}.
-template <int DC, bool MATVEC>
-__global__ __launch_bounds__(256) void k_back_substitute(BAView v, const double* __restrict__ hinv,
+// (4 waves per SIMD: 129 -> 128 VGPRs buys the fourth workgroup per CU, 0.70 -> 0.65 ms; the kernel is bound by the
+// latency of its dependent loads, not by bytes or arithmetic)
+// REC = true: J comes from the observation's projection record (written by k_landmark_reduce of the same linearisation,
+// orec, landmark-major like the observations) and the prepared camera instead of a second linearisation:
+//     Jc_i dc = a (dt + dtheta x p_w) + (xn w, yn w)^T (t . dk),   H_cl^T dc += a^T (Jc_i dc)
+// ~110 instead of ~500 fp64 instructions per observation (the kernel was bound by exactly those once its loads were
+// interleaved); only for the modes that optimise every column group the factor has (no masks in the record form).
+template <int DC, bool MATVEC, bool REC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_back_substitute(BAView v, const double* __restrict__ hinv,
                                                            const double* __restrict__ g_l,
                                                            const double* __restrict__ dc,
-                                                           double* __restrict__ dl) {
-    constexpr int STR = kCamQStride + DC + ((kCamQStride + DC) & 1);   // camera | its step, 16-byte pieces
+                                                           double* __restrict__ dl,
+                                                           const double* __restrict__ orec) {
+    constexpr int CAMD = REC ? kCamStride : kCamQStride;
+    constexpr int STR = CAMD + DC + ((CAMD + DC) & 1);   // camera | its step, 16-byte pieces
     __shared__ double sCam[kCamStageCap * STR];
-    stage_cams<STR, DC>(v, dc, sCam);
     const int g = threadIdx.x & (kLmLanes - 1);
     const int64_t l = (int64_t)blockIdx.x * (256 / kLmLanes) + threadIdx.x / kLmLanes;
     const bool active = l < v.n_pt;
     double acc[3] = {0, 0, 0};
+    CamStager<STR, DC, CAMD> stager;   // (see k_landmark_reduce: the staging chain and the landmark's own chain interleaved)
+    stager.issue_indices(v);
+    const int64_t lc = active ? l : 0;
+    const int b = v.pt_ptr[lc], e = active ? v.pt_ptr[lc + 1] : b;
+    stager.issue_data(REC ? v.camp : v.camq, dc);
+    const double pw[3] = {v.pts[3 * lc], v.pts[3 * lc + 1], v.pts[3 * lc + 2]};
+    const int i_first = max(min(b + g, (int)v.n_obs - 1), 0);
+    const double2* __restrict__ rec2 = reinterpret_cast<const double2*>(orec);
+    double2 uv_next = REC ? rec2[2 * (size_t)i_first] : v.o_uv[i_first];   // REC: (xn, yn) | (-1/z, w)
+    double2 rw_next = REC ? rec2[2 * (size_t)i_first + 1] : make_double2(0.0, 0.0);
+    int sl_next = v.o_slot ? (int)v.o_slot[i_first] : 255;
+    stager.store(sCam);
     if (active) {
-        const int b = v.pt_ptr[l], e = v.pt_ptr[l + 1];
-        const double pw[3] = {v.pts[3 * l], v.pts[3 * l + 1], v.pts[3 * l + 2]};
         for (int i = b + g; i < e; i += kLmLanes) {
-            const double2 uv = v.o_uv[i];
-            Cam cam;
+            const double2 uv = uv_next, rw = rw_next;
+            const int sl = sl_next;
+            if (i + kLmLanes < e) {
+                uv_next = REC ? rec2[2 * (size_t)(i + kLmLanes)] : v.o_uv[i + kLmLanes];
+                if (REC) rw_next = rec2[2 * (size_t)(i + kLmLanes) + 1];
+                sl_next = v.o_slot ? (int)v.o_slot[i + kLmLanes] : 255;
+            }
             double dcv[DC];
-            const int sl = v.o_slot ? (int)v.o_slot[i] : 255;
+            if (REC) {
+                double cv[kCamStride];
+                if (sl != 255) {
+#pragma unroll
+                    for (int a = 0; a < kCamStride; a += 2) {
+                        const double2 t = *reinterpret_cast<const double2*>(sCam + sl * STR + a);
+                        cv[a] = t.x; cv[a + 1] = t.y;
+                    }
+#pragma unroll
+                    for (int a = 0; a < DC; ++a) dcv[a] = sCam[sl * STR + kCamStride + a];
+                } else {
+                    const uint32_t c = v.o_cam[i];
+#pragma unroll
+                    for (int a = 0; a < kCamStride; a += 2) {
+                        const double2 t = *reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)c + a);
+                        cv[a] = t.x; cv[a + 1] = t.y;
+                    }
+#pragma unroll
+                    for (int a = 0; a < DC; ++a) dcv[a] = dc[(size_t)c * DC + a];
+                }
+                RecJac J;
+                jac_from_rec(cv, uv, rw, J);
+                const double q0 = dcv[0] + (dcv[4] * pw[2] - dcv[5] * pw[1]);   // dt + dtheta x p_w
+                const double q1 = dcv[1] + (dcv[5] * pw[0] - dcv[3] * pw[2]);
+                const double q2 = dcv[2] + (dcv[3] * pw[1] - dcv[4] * pw[0]);
+                double tk = 0.0;
+                if (DC == 9) tk = J.t[0] * dcv[DC - 3] + J.t[1] * dcv[DC - 2] + J.t[2] * dcv[DC - 1];
+                const double s0 = J.a[0][0] * q0 + J.a[0][1] * q1 + J.a[0][2] * q2 + J.xw * tk;
+                const double s1 = J.a[1][0] * q0 + J.a[1][1] * q1 + J.a[1][2] * q2 + J.yw * tk;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc[a] += J.a[0][a] * s0 + J.a[1][a] * s1;
+                continue;
+            }
+            Cam cam;
             if (sl != 255) {
                 load_cam_q(sCam + sl * STR, v.mask_code, cam);
 #pragma unroll
@@ -1218,12 +1327,19 @@ void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTas
     else hipLaunchKernelGGL((k_schur_rows2<6, kRowCap6>), dim3(n_tasks), dim3(kRow2Threads), 0, s, v, tm, tasks, chunks, entries, nbr, hinv);
 }
 
+// orec != nullptr: the record form (the records of THIS linearisation, k_landmark_reduce); ignored in the masked modes
+static bool rec_form_ok(int dc, const BAView& v, const double* orec) { return orec != nullptr && v.mask_code == (dc == 9 ? 7 : 6); }
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
-                            double* dl, hipStream_t s) {
+                            double* dl, hipStream_t s, const double* orec) {
     if (v.n_pt == 0) return;
     const int grid = grid_for(v.n_pt, 256 / kLmLanes, 0);
-    if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl);
-    else hipLaunchKernelGGL((k_back_substitute<6, false>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl);
+    if (rec_form_ok(dc, v, orec)) {
+        if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false, true>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl, orec);
+        else hipLaunchKernelGGL((k_back_substitute<6, false, true>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl, orec);
+        return;
+    }
+    if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false, false>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl, nullptr);
+    else hipLaunchKernelGGL((k_back_substitute<6, false, false>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl, nullptr);
 }
 
 void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, const double* intr, const double* pts,
@@ -1279,11 +1395,16 @@ void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, do
 
 // y = S x without S: landmark half (u_l into lmu), then camera half
 void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
-                            double lambda, double* y, hipStream_t s) {
+                            double lambda, double* y, hipStream_t s, const double* orec) {
     if (v.n_pt > 0) {
         const int grid = (int)((v.n_pt + 256 / kLmLanes - 1) / (256 / kLmLanes));
-        if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu);
-        else hipLaunchKernelGGL((k_back_substitute<6, true>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu);
+        if (rec_form_ok(dc, v, orec)) {
+            if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, true>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu, orec);
+            else hipLaunchKernelGGL((k_back_substitute<6, true, true>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu, orec);
+        } else {
+            if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, false>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu, nullptr);
+            else hipLaunchKernelGGL((k_back_substitute<6, true, false>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu, nullptr);
+        }
     }
     if (dc == 9) hipLaunchKernelGGL(k_implicit_cam<9>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, lmu, x, lambda, y);
     else hipLaunchKernelGGL(k_implicit_cam<6>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, lmu, x, lambda, y);

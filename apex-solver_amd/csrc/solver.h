@@ -86,6 +86,7 @@ class Solver : public LmBackend {
     void enable_graphs(bool on) { use_graphs_ = on; tp_.enable_graphs(on); }
     void enable_overlap(bool on) { tp_.enable_overlap(on); }
     void enable_tri_flow(bool on) { tp_.enable_tri_flow(on); }
+    void set_rec_backsub(bool on) { rec_backsub_ = on; }        // before set_structure: back-substitution / matrix-free operator from the projection records
     void set_cam_staging(bool on) { cam_staging_ = on; }        // landmark-major kernels: the workgroup's cameras staged in LDS
     void set_pairs_variant(int v) { pairs_variant_ = v; }       // pair kernel: 2 record form; fused forms: 1 two lanes per pair, 0 one pair per lane
     void set_pairs_ablation(int bits) { pairs_ablation_ = bits; }   // timing experiments only (results are wrong when != 0)
@@ -192,6 +193,9 @@ class Solver : public LmBackend {
     uint8_t *o_slot_ = nullptr, *wg_cam_n_ = nullptr;   // camera staging lists of the landmark-major kernels (BAView::o_slot)
     uint32_t* wg_cam_list_ = nullptr;
     bool cam_staging_ = true;
+    bool rec_backsub_ = true;
+    bool orec_fresh_ = false;   // orec_ holds the records of the current parameters' last linearisation
+    const double* backsub_records() const { return rec_backsub_ && orec_fresh_ ? orec_ : nullptr; }
     double* orec_ = nullptr;   // [local observations][4] projection records written by k_landmark_reduce (pair kernel, record form)
     int n_ptasks_ = 0;
     int64_t n_pair_blocks_ = 0, n_pair_slots_ = 0;

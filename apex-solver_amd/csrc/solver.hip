@@ -312,7 +312,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(alloc(&dcam_, n_c_pad_));
     HIP_TRY(alloc(&hinv_, (size_t)kLmStride * n_pt_));  // landmark records: Hll^-1 | g_l | point
     // projection records of the local observations (xn, yn, -1/z, sqrt(rho')): the record form of the pair kernel
-    if (use_rows_ && rows_form_ == 3) HIP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
+    if ((use_rows_ && rows_form_ == 3) || rec_backsub_) HIP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
     HIP_TRY(alloc(&g_l_, 3 * n_pt_));
     HIP_TRY(alloc(&dl_, 3 * n_pt_));
     HIP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
@@ -360,7 +360,7 @@ int Solver::set_params(const double* poses, const double* intr, const double* po
     HIP_TRY(hipMemcpyAsync(pts_[cur_], src_pts, 3 * n_pt_ * sizeof(double), hipMemcpyHostToDevice, stream_));
     launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], mode_mask(mode_), stream_);
     HIP_TRY(hipStreamSynchronize(stream_));
-    have_params_ = true; have_step_ = have_trial_ = false;
+    have_params_ = true; have_step_ = have_trial_ = false; orec_fresh_ = false;
     return kOk;
 }
 
@@ -473,7 +473,9 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     stage_end(kStAssembleCam);
     stage_begin(kStAssembleLm);
     const bool rec_form = use_rows_ && rows_form_ == 3 && pairs_variant_ >= 2 && orec_ != nullptr;
-    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_, rec_form ? orec_ : nullptr);
+    const bool want_rec = rec_form || (rec_backsub_ && orec_ != nullptr);
+    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_, want_rec ? orec_ : nullptr);
+    orec_fresh_ = want_rec;
     stage_end(kStAssembleLm);
     stage_begin(kStAssembleCam);
     launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, hinv_, g_l_, use_rows_ ? 1 : 0,
@@ -576,7 +578,9 @@ int Solver::assemble_implicit(double lambda) {
     const BAView v = view(cur_);
     stage_begin(kStAssembleLm);
     HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
-    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, lmu_, stream_);
+    const bool want_rec = rec_backsub_ && orec_ != nullptr;
+    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, lmu_, stream_, want_rec ? orec_ : nullptr);
+    orec_fresh_ = want_rec;
     stage_end(kStAssembleLm);
     stage_begin(kStAssembleCam);
     launch_cam_reduce(dc_, v, tilemap(), cam_ptr_, cam_obs_, lambda, rank_ == 0 ? 1 : 0, hinv_, g_l_, 1, g_c_, g_red_, stream_);
@@ -611,7 +615,7 @@ int Solver::implicit_matvec(const double* x, double lam_local, double* y, bool r
         launch_vec_mul(n_c_, x, cam_scale_, t, stream_);
         xin = t;
     }
-    launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xin, lam_local, y, stream_);
+    launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xin, lam_local, y, stream_, backsub_records());
     if (reduce && comm_ && world_ > 1)
         COMM_TRY(comm_->all_reduce_sum(y, (size_t)n_c_, stream_));
     if (scaled_) launch_vec_mul(n_c_, y, cam_scale_, y, stream_);
@@ -676,7 +680,7 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     for (int attempt = 0;; ++attempt) {
         stage_begin(kStBackSub);
         if (scaled_) launch_vec_mul(n_c_, dcam_, cam_scale_, dcam_, stream_);  // apply_inverse_scaling: dc = D_c y
-        launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_);
+        launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_, backsub_records());
         stage_end(kStBackSub);
         HIP_TRY(hipGetLastError());
         have_step_ = true;
@@ -769,7 +773,7 @@ int Solver::dist_phase(int phase, double lambda) {
         case 5:
             tp_.solve_phase(2, g_red_, dcam_, pcg_buf_);
             if (scaled_) launch_vec_mul(n_c_, dcam_, cam_scale_, dcam_, stream_);
-            launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_);
+            launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_, backsub_records());
             HIP_TRY(hipStreamSynchronize(stream_));
             have_step_ = true;
             return kOk;
@@ -847,7 +851,7 @@ int Solver::eval_step(double* trial_cost) {
 int Solver::commit_step() {
     if (!have_trial_) return fail(kInvalidState, "no trial point");
     cur_ ^= 1;
-    have_trial_ = false; have_step_ = false;
+    have_trial_ = false; have_step_ = false; orec_fresh_ = false;
     return kOk;
 }
 
@@ -863,7 +867,7 @@ int Solver::discard_step() {
     launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], mode_mask(mode_), stream_);
     stage_end(kStRetract);
     HIP_TRY(hipStreamSynchronize(stream_));
-    have_trial_ = false; have_step_ = false;
+    have_trial_ = false; have_step_ = false; orec_fresh_ = false;
     return kOk;
 }
 

@@ -713,3 +713,34 @@ def test_get_hessian_matches_jtj_of_the_exported_blocks(mode):
         for c in range(d.n_cam):
             assert H[:, lay.intr_col[c]:lay.intr_col[c] + 3].nnz == 0
     s.close()
+
+
+@pytest.mark.parametrize("mode", ["selfcal", "ba"])
+def test_record_form_of_the_back_substitution(oracle, mode):
+    """k_back_substitute<.., REC>: the landmark steps from the projection records k_landmark_reduce wrote for the same
+    linearisation ("rec_backsub", default on) against the form that linearises every observation again; explicit and
+    matrix-free Schur variants (the matrix-free operator's landmark half is the same kernel).  The two forms differ in
+    the rounding of J (1e-16 per entry); the landmark step is well conditioned given the camera step."""
+    d = pkg.synthetic.make_problem(14, 900, 3, 8, config_id=33)
+    for variant in (SchurVariant.Sparse, SchurVariant.Iterative):
+        steps = {}
+        for rec in (0, 1):
+            ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
+            prob = Problem.bundle_adjustment(d, ot, 1.0)
+            s = GpuSchurComplementSolver(0).with_variant(variant).with_option("rec_backsub", rec)
+            s.initialize_structure(prob)
+            s.set_parameters(d.poses, d.intr, d.points)
+            steps[rec] = s.solve_augmented_equation(1e-3)
+            s.eval_step(); s.commit_step()
+            # the records must be those of the NEW parameters: the same solve on a fresh handle at these parameters
+            after = s.solve_augmented_equation(1e-3)
+            params = s.get_parameters()
+            s.close()
+            s = GpuSchurComplementSolver(0).with_variant(variant).with_option("rec_backsub", rec)
+            s.initialize_structure(prob)
+            s.set_parameters(*params)
+            # (not bitwise: blocks of S shared by several waves are summed with atomics; stale records would be off by ~1e-3)
+            assert rel(after, s.solve_augmented_equation(1e-3)) < 1e-7
+            s.close()
+        tol = 1e-11 if variant == SchurVariant.Sparse else 1e-6       # (PCG: the operator's rounding moves the iterates)
+        assert rel(steps[1], steps[0]) < tol, (variant, rel(steps[1], steps[0]))
