@@ -35,6 +35,7 @@ SYMBOLS = (
     "apexgpu_pg_set_column_scaling", "apexgpu_pg_lm_optimize",
     "apexgpu_pg_get_residual", "apexgpu_pg_get_jacobian_blocks", "apexgpu_pg_get_hessian", "apexgpu_pg_set_option",
     "apexgpu_pg_enable_stage_timing", "apexgpu_pg_reset_stage_times", "apexgpu_pg_stage_times", "apexgpu_pg_info", "apexgpu_pg_counters",
+    "apexgpu_pg_set_priors", "apexgpu_pg_get_prior_residual",
     "apexgpu_g2o_open", "apexgpu_g2o_close", "apexgpu_g2o_last_error", "apexgpu_g2o_sizes", "apexgpu_g2o_raw",
     "apexgpu_g2o_problem", "apexgpu_pose_graph_columns",
 )
@@ -159,6 +160,8 @@ def load() -> C.CDLL:
     L.apexgpu_pg_last_error.restype = C.c_char_p
     L.apexgpu_pg_set_structure.argtypes = [vp, vp, vp, vp, vp, vp, dbl]
     L.apexgpu_pg_set_params.argtypes = [vp, vp]
+    L.apexgpu_pg_set_priors.argtypes = [vp, C.c_int64, vp, vp, vp]
+    L.apexgpu_pg_get_prior_residual.argtypes = [vp, vp]
     L.apexgpu_pg_get_params.argtypes = [vp, vp]
     L.apexgpu_pg_cost.argtypes = [vp, C.POINTER(dbl)]
     L.apexgpu_pg_solve_augmented.argtypes = [vp, dbl, vp, vp]

@@ -515,6 +515,15 @@ int apexgpu_pg_lm_optimize(apexgpu_pg_solver* h, apexgpu_lm_config* cfg, apexgpu
 }
 int apexgpu_pg_get_residual(apexgpu_pg_solver* h, double* r_out) { PG_OR_FAIL; return h->s->get_residual(r_out); }
 int apexgpu_pg_get_jacobian_blocks(apexgpu_pg_solver* h, double* j_out) { PG_OR_FAIL; return h->s->get_jacobian_blocks(j_out); }
+int apexgpu_pg_set_priors(apexgpu_pg_solver* h, int64_t n, const uint32_t* vertex, const double* data7, const double* huber_delta) {
+    PG_OR_FAIL;
+    if (n > 0 && (!vertex || !data7)) return APEXGPU_ERR_INVALID_INPUT;
+    return h->s->set_priors(n, vertex, data7, huber_delta);
+}
+int apexgpu_pg_get_prior_residual(apexgpu_pg_solver* h, double* r7_out) {
+    PG_OR_FAIL;
+    return h->s->get_prior_residual(r7_out);
+}
 int apexgpu_pg_get_hessian(apexgpu_pg_solver* h, double lambda, double* H_out, double* g_out) {
     PG_OR_FAIL;
     return h->s->get_hessian(lambda, H_out, g_out);

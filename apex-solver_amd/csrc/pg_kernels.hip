@@ -118,9 +118,52 @@ __global__ __launch_bounds__(256) void k_pg_edges(PGView v, TileMap tm, double* 
     for (int i = 0; i < 6; ++i) unsafeAtomicAdd(g + (size_t)b * 6 + i, gv[i]);
 }
 
+// One prior block: the corrected residual (7 rows) and sqrt(rho') -- the variable as the factor sees it is the prepared
+// pose (SE3::from(DVector).to_vector(), unit quaternion).
+__device__ __forceinline__ double prior_eval(const PGView& v, int k, double r[7]) {
+    double x[7], d[7];
+    load_pose8(v.posep, v.prior_v[k], x);
+    load_pose8(v.prior_data, k, d);
+    const double delta = v.prior_data[kPoseStride * (size_t)k + 7];
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < 7; ++a) { r[a] = x[a] - d[a]; s += r[a] * r[a]; }
+    const double sc = pg_huber_scale(delta, s);
+#pragma unroll
+    for (int a = 0; a < 7; ++a) r[a] *= sc;
+    return sc;
+}
+__global__ __launch_bounds__(64) void k_pg_priors(PGView v, TileMap tm, double* __restrict__ g) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= v.n_prior) return;
+    double r[7];
+    const double sc = prior_eval(v, k, r);
+    const uint32_t a = v.prior_v[k];
+    double* blk = h_block_ptr(tm, a, a);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {   // J~ = sc [I6; 0]: J~^T J~ = sc^2 I6, J~^T r~ = sc r~[0..5]
+        unsafeAtomicAdd(blk + i * kNB + i, sc * sc);
+        unsafeAtomicAdd(g + (size_t)a * 6 + i, sc * r[i]);
+    }
+}
+__global__ __launch_bounds__(64) void k_pg_prior_export(PGView v, double* __restrict__ r7_out) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= v.n_prior) return;
+    double r[7];
+    (void)prior_eval(v, k, r);
+    for (int a = 0; a < 7; ++a) r7_out[7 * k + a] = r[a];
+}
+
 __global__ __launch_bounds__(256) void k_pg_cost_partial(PGView v, double* __restrict__ partial) {
     __shared__ double scratch[4];
     double acc = 0.0;
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < v.n_prior; k += 256) {
+            double r[7];
+            (void)prior_eval(v, k, r);
+#pragma unroll
+            for (int a = 0; a < 7; ++a) acc += r[a] * r[a];
+        }
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < v.n_e; e += (int64_t)gridDim.x * 256) {
         double k0[7], k1[7], m[7], r[6], tA[3], qA[4], D[9];
         load_pose8(v.posep, v.e_from[e], k0);
@@ -186,6 +229,12 @@ void launch_pg_prepare(int64_t n, const double* poses7, double* posep, hipStream
 }
 void launch_pg_edges(const PGView& v, const TileMap& tm, double* g, hipStream_t s) {
     if (v.n_e > 0) hipLaunchKernelGGL(k_pg_edges, dim3(grid256(v.n_e)), dim3(256), 0, s, v, tm, g);
+}
+void launch_pg_priors(const PGView& v, const TileMap& tm, double* g, hipStream_t s) {
+    if (v.n_prior > 0) hipLaunchKernelGGL(k_pg_priors, dim3((v.n_prior + 63) / 64), dim3(64), 0, s, v, tm, g);
+}
+void launch_pg_prior_export(const PGView& v, double* r7_out, hipStream_t s) {
+    if (v.n_prior > 0) hipLaunchKernelGGL(k_pg_prior_export, dim3((v.n_prior + 63) / 64), dim3(64), 0, s, v, r7_out);
 }
 void launch_pg_cost(const PGView& v, double* partial, int n_partial, double* out_sumsq, hipStream_t s) {
     hipLaunchKernelGGL(k_pg_cost_partial, dim3(n_partial), dim3(256), 0, s, v, partial);

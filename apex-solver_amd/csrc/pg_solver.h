@@ -29,6 +29,8 @@ class PoseGraphSolver : public LmBackend {
     int set_structure(const uint32_t* e_from, const uint32_t* e_to, const double* meas7, const int64_t* pose_col,
                       const uint8_t* fix6, double huber_delta);
     int set_params(const double* poses7);
+    int set_priors(int64_t n, const uint32_t* vertex, const double* data7, const double* huber_delta);   // PriorFactor blocks
+    int get_prior_residual(double* r7_out);
     int get_params(double* poses7);
 
     int cost(double* out) override;
@@ -92,6 +94,9 @@ class PoseGraphSolver : public LmBackend {
     TilePlan tp_;
     double *poses_[2] = {nullptr, nullptr}, *posep_[2] = {nullptr, nullptr};
     uint32_t *e_from_ = nullptr, *e_to_ = nullptr;
+    int n_prior_ = 0;
+    uint32_t* prior_v_ = nullptr;
+    double* prior_data_ = nullptr;
     double* meas_ = nullptr;
     uint8_t* fix_ = nullptr;
     double *g_ = nullptr, *rhs_ = nullptr, *d_ = nullptr, *work_ = nullptr, *partial_ = nullptr, *scal_ = nullptr;

@@ -56,7 +56,49 @@ PGView PoseGraphSolver::view(int which) const {
     v.n_v = n_v_; v.n_e = n_e_;
     v.posep = posep_[which]; v.e_from = e_from_; v.e_to = e_to_; v.meas = meas_;
     v.huber_delta = huber_delta_;
+    v.n_prior = n_prior_; v.prior_v = prior_v_; v.prior_data = prior_data_;
     return v;
+}
+
+// PriorFactor blocks (prior_factor.rs:96-108); replaces the set.  data7 in to_vector order [t, w, i, j, k].
+int PoseGraphSolver::set_priors(int64_t n, const uint32_t* vertex, const double* data7, const double* huber_delta) {
+    if (!have_structure_) return fail(kInvalidState, "Block structure not built. Call set_structure() first.");
+    if (n < 0 || n > (1 << 24)) return fail(kInvalidInput, "prior count out of range");
+    for (int64_t k = 0; k < n; ++k)
+        if ((int64_t)vertex[k] >= n_v_) return fail(kInvalidInput, "prior on a vertex that does not exist");
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    if (prior_v_) { (void)hipFree(prior_v_); prior_v_ = nullptr; }
+    if (prior_data_) { (void)hipFree(prior_data_); prior_data_ = nullptr; }
+    n_prior_ = (int)n;
+    have_step_ = have_trial_ = false;
+    if (n == 0) return kOk;
+    std::vector<uint32_t> hv((size_t)n);
+    std::vector<double> hd((size_t)n * kPoseStride, 0.0);
+    for (int64_t k = 0; k < n; ++k) {
+        hv[k] = (uint32_t)vmap_[vertex[k]];
+        memcpy(hd.data() + (size_t)k * kPoseStride, data7 + 7 * k, 7 * sizeof(double));
+        hd[(size_t)k * kPoseStride + 7] = huber_delta ? huber_delta[k] : -1.0;
+    }
+    HIP_TRY(hipMalloc(&prior_v_, hv.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&prior_data_, hd.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(prior_v_, hv.data(), hv.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(prior_data_, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice));
+    return kOk;
+}
+
+int PoseGraphSolver::get_prior_residual(double* r7_out) {
+    if (!have_params_) return fail(kInvalidState, "no parameters set");
+    if (n_prior_ == 0) return kOk;
+    HIP_TRY(hipSetDevice(device_));
+    double* d = nullptr;
+    HIP_TRY(hipMalloc(&d, (size_t)n_prior_ * 7 * sizeof(double)));
+    launch_pg_prior_export(view(cur_), d, stream_);
+    hipError_t e = hipMemcpyAsync(r7_out, d, (size_t)n_prior_ * 7 * sizeof(double), hipMemcpyDeviceToHost, stream_);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+    (void)hipFree(d);
+    HIP_TRY(e);
+    return kOk;
 }
 
 int PoseGraphSolver::set_structure(const uint32_t* e_from, const uint32_t* e_to, const double* meas7,
@@ -171,6 +213,7 @@ int PoseGraphSolver::assemble(double lambda) {
     HIP_TRY(hipMemsetAsync(g_, 0, n_pad_ * sizeof(double), stream_));
     tp_.add_diag((int)n_, scaled_ ? 0.0 : lambda, 1.0);  // lambda on the real rows, identity on the padding rows
     launch_pg_edges(view(cur_), tp_.tilemap(), g_, stream_);
+    launch_pg_priors(view(cur_), tp_.tilemap(), g_, stream_);
     if (scaled_) {  // Jacobi scaling: H := D H D, then the damping of the scaled system
         tp_.scale_sym(scale_);
         tp_.add_diag((int)n_, lambda, 1.0);

@@ -110,6 +110,16 @@ def pose_graph_columns(ids: np.ndarray) -> np.ndarray:
     return out
 
 
+def se3_as_vector(pose7) -> np.ndarray:
+    """SE3::from(DVector).to_vector(): [t, w, i, j, k] with the quaternion normalised (se3.rs:200-206, 107-113)."""
+    p = np.asarray(pose7, dtype=np.float64).reshape(7).copy()
+    q = p[3:7]
+    q = q / np.sqrt(np.dot(q, q))
+    q = q / np.sqrt(np.dot(q, q))
+    p[3:7] = q
+    return p
+
+
 @dataclass
 class PoseGraphProblem:
     """The factor graph bin/pose_graph_g2o.rs:748-830 builds: variables `x{id}` (SE3), one
@@ -118,11 +128,27 @@ class PoseGraphProblem:
     data: PoseGraphData
     huber_delta: float | None = None
     fix: np.ndarray = field(default=None)
+    priors: list = field(default_factory=list)   # (vertex index, data[7], huber delta or None) per PriorFactor block
 
     def __post_init__(self):
         if self.fix is None:
             self.fix = np.zeros((self.data.n_v, 6), dtype=np.uint8)
         self.pose_col = pose_graph_columns(self.data.ids)
+
+    def add_prior(self, name: str, data=None, huber_delta: float | None = None):
+        """`problem.add_residual_block(&[name], PriorFactor { data }, loss)` (src/factors/prior_factor.rs:53-113): the
+        gauge of the reference's pose-graph integration test (tests/integration_tests.rs:98-118, Huber(1.0), data = the
+        variable's initial value).  r = to_vector(x) - data, seven rows; the linearizer keeps the first six columns of the
+        7 x 7 identity Jacobian (src/linearizer/cpu/sparse.rs:201-204)."""
+        if not name.startswith("x"):
+            raise KeyError(name)
+        hit = np.nonzero(self.data.ids == int(name[1:]))[0]
+        if hit.size == 0:
+            raise KeyError(name)
+        v = int(hit[0])
+        x = se3_as_vector(self.data.poses[v]) if data is None else np.asarray(data, dtype=np.float64).reshape(7)
+        self.priors.append((v, x, huber_delta))
+        return self
 
     @classmethod
     def pose_graph(cls, data: PoseGraphData, huber_delta: float | None = None) -> "PoseGraphProblem":
@@ -147,7 +173,7 @@ class PoseGraphProblem:
 
     @property
     def num_residual_blocks(self) -> int:
-        return self.data.n_e
+        return self.data.n_e + len(self.priors)
 
 
 class GpuSparseCholeskySolver:
@@ -178,7 +204,25 @@ class GpuSparseCholeskySolver:
         delta = -1.0 if problem.huber_delta is None else float(problem.huber_delta)
         h.check(h.L.apexgpu_pg_set_structure(h.h, capi.ptr(ef), capi.ptr(et), capi.ptr(meas), capi.ptr(col), capi.ptr(fix), delta))
         self._h, self.problem = h, problem
+        if problem.priors:
+            self.set_priors(problem.priors)
         return self
+
+    def set_priors(self, priors):
+        """PriorFactor blocks: (vertex index, data[7], huber delta or None) each; replaces the set."""
+        h = self._need()
+        v = np.ascontiguousarray([q[0] for q in priors], dtype=np.uint32)
+        x = np.ascontiguousarray([q[1] for q in priors], dtype=np.float64).reshape(-1, 7)
+        dl = np.ascontiguousarray([-1.0 if q[2] is None else float(q[2]) for q in priors], dtype=np.float64)
+        h.check(h.L.apexgpu_pg_set_priors(h.h, len(v), capi.ptr(v), capi.ptr(x), capi.ptr(dl)))
+
+    def get_prior_residual(self) -> np.ndarray:
+        """Corrected residuals of the prior blocks at the current parameters: [n_prior][7]."""
+        h = self._need()
+        n = len(self.problem.priors)
+        r = np.zeros((n, 7))
+        if n: h.check(h.L.apexgpu_pg_get_prior_residual(h.h, capi.ptr(r)))
+        return r
 
     def _need(self) -> capi.PgHandle:
         if self._h is None:

@@ -239,9 +239,11 @@ class GpuSchurComplementSolver:
 
     # StructureAware::initialize_structure
     def initialize_structure(self, problem: Problem):
+        import time
+        t0 = time.perf_counter()
         d = problem.data
         mode = problem.optimization_type.value
-        self._h = capi.Handle(d.n_cam, d.n_pt, d.n_obs, mode, self.device)
+        self._h = capi.Handle(d.n_cam, d.n_pt, d.n_obs, mode, self.device)   # the process's first HIP call: runtime start-up
         h = self._h
         if self._comm is not None:
             world, rank, uid = self._comm
@@ -254,14 +256,19 @@ class GpuSchurComplementSolver:
             h.check(h.L.apexgpu_set_shard(h.h, *self._shard))
         for k, v in self._pre_options.items():
             h.check(h.L.apexgpu_set_option(h.h, k.encode(), v))
+        t1 = time.perf_counter()
         lay = problem.layout
         self._keep = [np.ascontiguousarray(a) for a in (
             d.cam_idx.astype(np.uint32, copy=False), d.pt_idx.astype(np.uint32, copy=False), d.obs_uv.astype(np.float64, copy=False),
             lay.intr_col, lay.pose_col, lay.pt_col, problem.fix_pose, problem.fix_intr, problem.fix_pt)]
         hd = -1.0 if problem.huber_delta is None else float(problem.huber_delta)
+        t2 = time.perf_counter()
         h.check(h.L.apexgpu_set_structure(h.h, *[capi.ptr(a) for a in self._keep], hd))
+        t3 = time.perf_counter()
         h.check(h.L.apexgpu_set_cg_params(h.h, self.cg_max_iterations, self.cg_tolerance))
         self._problem = problem
+        # wall time of this call by piece (seconds): handle + communicator, host-side argument arrays, apexgpu_set_structure
+        self.setup_wall = dict(create_handle=t1 - t0, host_arrays=t2 - t1, set_structure=t3 - t2)
         return self
 
     def _need(self) -> capi.Handle:
@@ -270,9 +277,12 @@ class GpuSchurComplementSolver:
         return self._h
 
     def set_parameters(self, poses, intr, points):
+        import time
+        t0 = time.perf_counter()
         h = self._need()
         a = [np.ascontiguousarray(x, dtype=np.float64) for x in (poses, intr, points)]
         h.check(h.L.apexgpu_set_params(h.h, *[capi.ptr(x) for x in a]))
+        if hasattr(self, "setup_wall"): self.setup_wall["set_parameters"] = time.perf_counter() - t0
 
     def get_parameters(self):
         h = self._need()

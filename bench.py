@@ -429,6 +429,9 @@ def main():
         "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
         "stage_launches": {k: int(v[1]) for k, v in stages.items()},
         "setup_s": setup_s, "setup_by_phase_s": {k: st[k] for k in ("order", "lists", "tile_plan", "schur_lists", "uploads", "total")},
+        # the whole of setup_s by piece: handle creation (the process's first HIP call = runtime start-up), the host-side
+        # argument arrays, apexgpu_set_structure (= setup_by_phase_s.total + its argument checks), the parameter upload
+        "setup_wall_s": dict(getattr(s, "setup_wall", {})),
         "initial_cost": initial_cost, "final_cost": state["cost"], "accepted_steps": state["accepted"] - accepted_before,
         "accepted_steps_incl_warmup": state["accepted"],
         "obs_per_s": d.n_obs / (ms_per_step * 1e-3),

@@ -390,6 +390,13 @@ const char* apexgpu_pg_last_error(const apexgpu_pg_solver* h);
 int apexgpu_pg_set_structure(apexgpu_pg_solver* h, const uint32_t* e_from, const uint32_t* e_to, const double* meas7,
                              const int64_t* pose_col, const uint8_t* fix6, double huber_delta);
 /* Problem::initialize_variables (src/core/problem.rs:686-808): poses7[v] = [t, qw,qx,qy,qz] */
+/* PriorFactor blocks on SE3 variables (reference: src/factors/prior_factor.rs:96-108; the gauge of
+ * tests/integration_tests.rs:98-118): r = to_vector(x_vertex) - data7 (seven rows, [t, w, i, j, k]); the Jacobian is the 7 x 7
+ * identity of which the linearizer keeps the variable's six tangent columns (src/linearizer/cpu/sparse.rs:201-204);
+ * huber_delta[k] <= 0 (or huber_delta == NULL): no loss on block k.  Replaces the set; after apexgpu_pg_set_structure.
+ * apexgpu_pg_get_prior_residual: the corrected residuals [n][7] at the current parameters. */
+int apexgpu_pg_set_priors(apexgpu_pg_solver* h, int64_t n, const uint32_t* vertex, const double* data7, const double* huber_delta);
+int apexgpu_pg_get_prior_residual(apexgpu_pg_solver* h, double* r7_out);
 int apexgpu_pg_set_params(apexgpu_pg_solver* h, const double* poses7);
 int apexgpu_pg_get_params(apexgpu_pg_solver* h, double* poses7);
 

@@ -377,6 +377,16 @@ typedef struct {
     double huber_delta;
     double *r, *J; /* last linearisation: [n_e][6], [n_e][72] */
     double *scaling; /* Jacobi column scaling (optimizer/mod.rs:749-763), caller's column order; NULL = off */
+    /* PriorFactor blocks on SE3 variables (src/factors/prior_factor.rs:96-108; the gauge of the reference's pose-graph
+     * integration test, tests/integration_tests.rs:98-118): r = to_vector(x) - data (7 rows), J = the 7 x 7 identity of
+     * which the linearizer keeps the variable's 6 tangent columns (src/linearizer/cpu/sparse.rs:201-204), i.e. rows 0..5
+     * are e_0..e_5 and row 6 (the quaternion's k component) has no Jacobian; each block has its own Huber loss. */
+    int64_t n_prior;
+    int64_t *prior_v;
+    double *prior_data;  /* [n_prior][7] */
+    double *prior_delta; /* [n_prior], <= 0: no loss */
+    double *prior_r;     /* last evaluation, corrected: [n_prior][7] */
+    double *prior_sc;    /* sqrt(rho') of the last evaluation */
 } pgo_problem;
 
 static void *dupmem(const void *src, size_t bytes) {
@@ -403,8 +413,39 @@ void pgo_destroy(pgo_problem *p) {
     if (!p) return;
     free(p->from); free(p->to); free(p->pose_col); free(p->meas); free(p->poses); free(p->fix); free(p->r); free(p->J);
     free(p->scaling);
+    free(p->prior_v); free(p->prior_data); free(p->prior_delta); free(p->prior_r); free(p->prior_sc);
     free(p);
 }
+/* replaces the set of prior blocks (n = 0: none) */
+void pgo_set_priors(pgo_problem *p, int64_t n, const int64_t *vertex, const double *data7, const double *huber_delta) {
+    free(p->prior_v); free(p->prior_data); free(p->prior_delta); free(p->prior_r); free(p->prior_sc);
+    p->n_prior = n;
+    p->prior_v = (int64_t *)dupmem(vertex, (size_t)n * 8);
+    p->prior_data = (double *)dupmem(data7, (size_t)n * 56);
+    p->prior_delta = (double *)dupmem(huber_delta, (size_t)n * 8);
+    p->prior_r = (double *)dupmem(NULL, (size_t)n * 56);
+    p->prior_sc = (double *)dupmem(NULL, (size_t)n * 8);
+}
+/* the variable as the factors see it: SE3::from(DVector) normalises the quaternion, to_vector returns [t, w, i, j, k] */
+static void pose_as_vector(const double *pose7, double out[7]) {
+    double t[3], q[4];
+    pgo_se3_from_vec(pose7, t, q);
+    out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; out[3] = q[0]; out[4] = q[1]; out[5] = q[2]; out[6] = q[3];
+}
+/* evaluates every prior block (corrected residual kept in prior_r, scale in prior_sc); returns sum |r~|^2 */
+static double eval_priors(pgo_problem *p) {
+    double ss = 0.0;
+    for (int64_t k = 0; k < p->n_prior; ++k) {
+        double x[7], *r = p->prior_r + 7 * k, s = 0.0;
+        pose_as_vector(p->poses + 7 * p->prior_v[k], x);
+        for (int a = 0; a < 7; ++a) { r[a] = x[a] - p->prior_data[7 * k + a]; s += r[a] * r[a]; }
+        const double sc = huber_scale(p->prior_delta[k], s);
+        p->prior_sc[k] = sc;
+        for (int a = 0; a < 7; ++a) { r[a] *= sc; ss += r[a] * r[a]; }
+    }
+    return ss;
+}
+void pgo_prior_residuals(const pgo_problem *p, double *r7_out) { memcpy(r7_out, p->prior_r, (size_t)p->n_prior * 56); }
 void pgo_set_params(pgo_problem *p, const double *poses) { memcpy(p->poses, poses, (size_t)p->n_v * 56); }
 void pgo_get_params(const pgo_problem *p, double *poses) { memcpy(poses, p->poses, (size_t)p->n_v * 56); }
 
@@ -424,6 +465,7 @@ double pgo_residuals(pgo_problem *p, double *r_out) {
             if (r_out) r_out[6 * e + a] = r[a];
         }
     }
+    ss += eval_priors(p);
     double nrm = sqrt(ss);
     return 0.5 * nrm * nrm;
 }
@@ -445,6 +487,7 @@ double pgo_linearize(pgo_problem *p, double *r_out, double *J_out) {
     }
     if (r_out) memcpy(r_out, p->r, (size_t)p->n_e * 48);
     if (J_out) memcpy(J_out, p->J, (size_t)p->n_e * 576);
+    ss += eval_priors(p);
     double nrm = sqrt(ss);
     return 0.5 * nrm * nrm;
 }
@@ -471,6 +514,14 @@ void pgo_normal_equations(const pgo_problem *p, double *H /* may be NULL */, dou
             }
         }
     }
+    for (int64_t k = 0; k < p->n_prior; ++k) {   /* J~ = sc [I6; 0], r~ = sc r */
+        const int64_t c0 = p->pose_col[p->prior_v[k]];
+        const double sc = p->prior_sc[k];
+        for (int a = 0; a < 6; ++a) {
+            g[c0 + a] += sc * p->prior_r[7 * k + a];
+            if (H) H[(c0 + a) * n + c0 + a] += sc * sc;
+        }
+    }
 }
 
 /* compute_column_norms (linearizer/mod.rs:229-239) of the last linearisation, caller's column order */
@@ -482,6 +533,8 @@ void pgo_column_norms(const pgo_problem *p, double *norms_out) {
         for (int a = 0; a < 12; ++a)
             for (int k = 0; k < 6; ++k) norms_out[col[a / 6] + a % 6] += J[12 * k + a] * J[12 * k + a];
     }
+    for (int64_t k = 0; k < p->n_prior; ++k)
+        for (int a = 0; a < 6; ++a) norms_out[p->pose_col[p->prior_v[k]] + a] += p->prior_sc[k] * p->prior_sc[k];
     for (int64_t i = 0; i < p->total_dof; ++i) norms_out[i] = sqrt(norms_out[i]);
 }
 
@@ -535,6 +588,14 @@ int pgo_solve_augmented(pgo_problem *p, double lambda, double *step_out, double 
                 for (int k = 0; k < 6; ++k) h += J[12 * k + a] * J[12 * k + b];
                 ENV(ia, ib) += h;
             }
+        }
+    }
+    for (int64_t k = 0; k < p->n_prior; ++k) {
+        const int64_t v = p->prior_v[k];
+        for (int a = 0; a < 6; ++a) {
+            const double cs = p->scaling ? p->scaling[p->pose_col[v] + a] : 1.0, j = p->prior_sc[k] * cs;
+            g[6 * v + a] += j * p->prior_r[7 * k + a];
+            ENV(6 * v + a, 6 * v + a) += j * j;
         }
     }
     for (int64_t i = 0; i < n; ++i) ENV(i, i) += lambda;

@@ -68,6 +68,10 @@ def lib() -> C.CDLL:
     L.pgo_lm_optimize.argtypes = [C.c_void_p, _f64, _Opt, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), _Opt]
     L.pgo_lm_optimize.restype = C.c_int
+    L.pgo_set_priors.argtypes = [C.c_void_p, C.c_int64, _i64, _f64, _f64]
+    L.pgo_set_priors.restype = None
+    L.pgo_prior_residuals.argtypes = [C.c_void_p, _f64]
+    L.pgo_prior_residuals.restype = None
     _lib = L
     return L
 
@@ -123,7 +127,25 @@ class PgOracle:
     @classmethod
     def from_problem(cls, problem):
         d = problem.data
-        return cls(d.e_from, d.e_to, d.meas, problem.pose_col, problem.fix, problem.huber_delta, d.poses)
+        o = cls(d.e_from, d.e_to, d.meas, problem.pose_col, problem.fix, problem.huber_delta, d.poses)
+        if getattr(problem, "priors", None):
+            o.set_priors([v for v, _, _ in problem.priors], [x for _, x, _ in problem.priors], [dl for _, _, dl in problem.priors])
+        return o
+
+    def set_priors(self, vertex, data7, huber_delta):
+        """PriorFactor blocks (prior_factor.rs:96-108) on SE3 variables; huber_delta <= 0 / None: no loss."""
+        v = np.ascontiguousarray(vertex, dtype=np.int64).reshape(-1)
+        x = np.ascontiguousarray(data7, dtype=np.float64).reshape(-1, 7)
+        dl = np.ascontiguousarray([-1.0 if q is None else float(q) for q in huber_delta], dtype=np.float64)
+        assert len(v) == len(x) == len(dl)
+        self.n_prior = len(v)
+        self.L.pgo_set_priors(self.p, len(v), v, x, dl)
+
+    def prior_residuals(self):
+        """Corrected residuals of the prior blocks at the last residuals() / linearize(): [n_prior][7]."""
+        r = np.zeros((getattr(self, "n_prior", 0), 7))
+        if len(r): self.L.pgo_prior_residuals(self.p, r)
+        return r
 
     def __del__(self):
         if getattr(self, "p", None):

@@ -57,6 +57,13 @@ extern "C" {
     pub fn apexgpu_commit_step(h: *mut ApexGpuSolver) -> c_int;
     pub fn apexgpu_discard_step(h: *mut ApexGpuSolver) -> c_int;
     pub fn apexgpu_get_params(h: *mut ApexGpuSolver, poses: *mut f64, intr: *mut f64, points: *mut f64) -> c_int;
+    // multi-rank: RCCL, or N processes on one device over host shared memory (bring-up)
+    pub fn apexgpu_get_unique_id(out128: *mut core::ffi::c_void) -> c_int;
+    pub fn apexgpu_comm_init(h: *mut ApexGpuSolver, world: c_int, rank: c_int, unique_id128: *const core::ffi::c_void) -> c_int;
+    pub fn apexgpu_comm_init_shm(h: *mut ApexGpuSolver, world: c_int, rank: c_int, name: *const c_char) -> c_int;
+    // [0] dataflow sweeps that timed out and were repeated level by level inside the same solve, [1] dataflow sweeps still on
+    pub fn apexgpu_counters(h: *mut ApexGpuSolver, out4: *mut i64) -> c_int;
+    pub fn apexgpu_set_option(h: *mut ApexGpuSolver, name: *const c_char, value: c_int) -> c_int;
 }
 
 /// Status code -> `LinAlgError` (the codes ARE the variants, src/linalg/mod.rs:76-101).

@@ -299,3 +299,55 @@ def test_jacobi_scaling_lm_history_vs_oracle():
     assert np.allclose(res.history[:, 0], H[:, 0], rtol=1e-7) and np.allclose(res.history[:, 4], H[:, 4], rtol=1e-6)
     assert np.allclose(res.history[:, 1], H[:, 1], rtol=1e-4)
     assert res.final_cost < 0.05 * res.initial_cost
+
+
+@pytest.mark.parametrize("delta", [None, 1.0, 0.05])
+def test_prior_factor_blocks_vs_oracle(delta):
+    """PriorFactor blocks (prior_factor.rs:96-108; the gauge of tests/integration_tests.rs:98-118) through
+    apexgpu_pg_set_priors: cost, prior residuals, J^T J, J^T r and the step against the oracle (which
+    tests/test_pg_prior_factor.py pins against a dense restatement), nothing fixed, loss active and inactive."""
+    from apex_solver_amd.pose_graph import se3_as_vector
+
+    d = pkg.synthetic.make_sphere(12, 20, id_stride=2)
+    rng = np.random.default_rng(4)
+    prob = PoseGraphProblem(d, huber_delta=0.7)
+    x0 = se3_as_vector(d.poses[0]); x0[:3] += 0.2 * rng.standard_normal(3); x0[3:] += 0.05 * rng.standard_normal(4)
+    prob.add_prior(f"x{int(d.ids[0])}", data=x0, huber_delta=delta)
+    prob.add_prior(f"x{int(d.ids[77])}", huber_delta=delta)
+    o = po.PgOracle.from_problem(prob)
+    s = GpuSparseCholeskySolver().initialize_structure(prob)
+    s.set_parameters(d.poses)
+    c, r, J = o.linearize()
+    assert abs(s.compute_cost() - c) <= 1e-12 * c
+    assert rel(s.get_prior_residual(), o.prior_residuals()) < 1e-13
+    assert rel(s.get_residual(), r) < 1e-12
+    lam = 1e-4
+    H, g = s.get_hessian(lam)
+    Ho, go = o.normal_equations()
+    Ho += lam * np.eye(Ho.shape[0])
+    assert rel(H, Ho) < 1e-12 and rel(g, go) < 1e-12
+    assert rel(s.compute_column_norms(), o.column_norms()) < 1e-12
+    step = s.solve_augmented_equation(lam)
+    rc, so, _ = o.solve_augmented(lam)
+    assert rc == 0 and rel(step, so) < 1e-9, rel(step, so)
+    # trial cost includes the priors at the trial point
+    nc = s.eval_step()
+    o.apply_step(so, 1.0)
+    assert abs(nc - o.residuals()[0]) <= 1e-8 * nc
+    s.discard_step()
+    # without damping the priors alone must hold the gauge
+    assert np.all(np.isfinite(s.solve_augmented_equation(0.0)))
+    s.close()
+
+
+def test_lm_with_prior_gauge_matches_the_oracle_loop():
+    d = pkg.synthetic.make_sphere(10, 12, config_id=9)
+    prob = PoseGraphProblem(d).add_prior(f"x{int(d.ids[0])}", huber_delta=1.0)
+    o = po.PgOracle.from_problem(prob)
+    ref = o.lm_optimize(po.lm_config(max_iterations=30))
+    cfg = LevenbergMarquardtConfig.new().with_max_iterations(30).with_linear_solver_type(LinearSolverType.SparseCholesky)
+    res = LevenbergMarquardt.with_config(cfg).optimize(prob)
+    assert res.iterations == ref["iterations"]
+    assert abs(res.initial_cost - ref["initial_cost"]) <= 1e-12 * ref["initial_cost"]
+    assert abs(res.final_cost - ref["final_cost"]) <= 1e-7 * ref["final_cost"]
+    assert res.final_cost < 0.5 * res.initial_cost
