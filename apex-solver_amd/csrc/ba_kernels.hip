@@ -93,6 +93,8 @@ __global__ __launch_bounds__(kCamThreads, 2) void k_cam_reduce(BAView v, TileMap
     Cam cam;
     load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
     const int b = cam_ptr[c], e = cam_ptr[c + 1];
+    // (prefetching the next observation's landmark index and measurement was tried: three more live registers on a kernel that
+    // sits at 256 VGPRs spill, 1.14 -> 1.29 ms)
     for (int k = b + (int)threadIdx.x; k < e; k += kCamThreads) {
         const uint32_t l = v.co_pt[k];   // camera-major copies: coalesced
         const double2 uv = v.co_uv[k];
@@ -804,7 +806,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int64_t lc = active ? l : 0;
     const int b = v.pt_ptr[lc], e = active ? v.pt_ptr[lc + 1] : b;
     stager.issue_data(REC ? v.camp : v.camq, dc);
-    const double pw[3] = {v.pts[3 * lc], v.pts[3 * lc + 1], v.pts[3 * lc + 2]};
+    // REC: the landmark's whole record now (Hll^-1 | point | g_l, one 128-byte line, the four lanes of a landmark read the
+    // same address) -- the point comes with it and the epilogue has no load left to wait for
+    double lrec[REC ? kLmStride : 1];
+    if (REC) load_lm_record(hinv, (size_t)lc, lrec);
+    const double pw[3] = {REC ? lrec[REC ? kLmPt : 0] : v.pts[3 * lc], REC ? lrec[REC ? kLmPt + 1 : 0] : v.pts[3 * lc + 1],
+                          REC ? lrec[REC ? kLmPt + 2 : 0] : v.pts[3 * lc + 2]};
     const int i_first = max(min(b + g, (int)v.n_obs - 1), 0);
     const double2* __restrict__ rec2 = reinterpret_cast<const double2*>(orec);
     double2 uv_next = REC ? rec2[2 * (size_t)i_first] : v.o_uv[i_first];   // REC: (xn, yn) | (-1/z, w)
@@ -882,7 +889,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int i = 0; i < 3; ++i) acc[i] += __shfl_xor(acc[i], m, kLmLanes);
     if (active && g == 0) {
-        const double* Hi = hinv + kLmStride * l;
+        double Hi[kLmStride];
+        if (REC) {
+#pragma unroll
+            for (int a = 0; a < kLmStride; ++a) Hi[a] = lrec[REC ? a : 0];
+        } else {
+#pragma unroll
+            for (int a = 0; a < kLmStride; ++a) Hi[a] = hinv[kLmStride * l + a];
+        }
         if (MATVEC) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) dl[kLmuStride * l + 4 + a] = Hi[3 * a] * acc[0] + Hi[3 * a + 1] * acc[1] + Hi[3 * a + 2] * acc[2];
@@ -1132,12 +1146,23 @@ __global__ __launch_bounds__(256) void k_cost_partial(BAView v, double* __restri
     const int64_t steps = (v.n_obs + 63) / 64, per = (steps + n_waves - 1) / n_waves;
     const int64_t s0 = wave * per, s1 = min(steps, s0 + per);
     double s = 0.0;
+    // software-pipelined: the next step's observation record (camera, landmark, measurement) is in flight while this step's
+    // camera and point are gathered and projected
+    uint32_t c_next = 0, l_next = 0;
+    double2 uv_next = make_double2(0.0, 0.0);
+    if (s0 < s1) {
+        const int64_t i0 = min(s0 * 64 + lane, v.n_obs - 1);
+        c_next = v.o_cam[i0]; l_next = v.o_pt[i0]; uv_next = v.o_uv[i0];
+    }
     for (int64_t st = s0; st < s1; ++st) {
         const int64_t i = st * 64 + lane;
         const bool active = i < v.n_obs;
-        const int64_t ii = active ? i : 0;
-        const uint32_t c = v.o_cam[ii], l = v.o_pt[ii];
-        const double2 uv = v.o_uv[ii];
+        const uint32_t c = c_next, l = l_next;
+        const double2 uv = uv_next;
+        if (st + 1 < s1) {
+            const int64_t in = min(i + 64, v.n_obs - 1);
+            c_next = v.o_cam[in]; l_next = v.o_pt[in]; uv_next = v.o_uv[in];
+        }
         double q[kCamQStride];
         cam_cache_get(cc, v.camq, c, active, q);
         Cam cam;
