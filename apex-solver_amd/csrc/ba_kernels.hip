@@ -168,30 +168,9 @@ __global__ __launch_bounds__(kCamThreads, 2) void k_cam_reduce(BAView v, TileMap
 // K2a: landmark-major reduction, 8 lanes per landmark (32 landmarks per 256-thread block).
 // H_ll = sum Jl^T Jl + lambda I, g_l = sum Jl^T r, eigen-gated inverse.
 // ------------------------------------------------------------------------------------------
-// Camera staging (BAView::o_slot): the workgroup's distinct cameras, compact form (+ EXTRA doubles each, e.g. the camera
-// step), copied to LDS by all 256 threads; returns after the barrier.  STR doubles per slot (even: 16-byte pieces).
-template <int STR, int EXTRA>
-__device__ __forceinline__ void stage_cams(const BAView& v, const double* __restrict__ extra, double* __restrict__ sCam) {
-    static_assert(STR % 2 == 0 && STR >= kCamQStride + EXTRA, "slot pitch");
-    if (v.o_slot) {
-        const int n = v.wg_cam_n[blockIdx.x];
-        const uint32_t* __restrict__ list = v.wg_cam_list + (size_t)blockIdx.x * kCamStageCap;
-        constexpr int PQ = kCamQStride / 2;
-        for (int idx = threadIdx.x; idx < n * PQ; idx += 256) {
-            const int k = idx / PQ, p = idx - PQ * k;
-            reinterpret_cast<double2*>(sCam + k * STR)[p] = reinterpret_cast<const double2*>(v.camq + kCamQStride * (size_t)list[k])[p];
-        }
-        if (EXTRA > 0) {
-            for (int idx = threadIdx.x; idx < n * EXTRA; idx += 256) {
-                const int k = idx / EXTRA, a = idx - EXTRA * k;
-                sCam[k * STR + kCamQStride + a] = extra[(size_t)list[k] * EXTRA + a];
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// The same staging in three steps, so that a kernel can put its own loads between them: the landmark-major kernels are
+// Camera staging (BAView::o_slot): the workgroup's distinct cameras (+ EXTRA doubles each, e.g. the camera step) copied to
+// LDS by all 256 threads, STR doubles per slot (even: 16-byte pieces) -- in three steps, so that a kernel can put its own
+// loads between them: the landmark-major kernels are
 // bound by the latency of their dependent loads (workgroup list -> cameras -> barrier, then pt_ptr -> observations), and
 // interleaved the two chains cost two round trips instead of four.  Every load is unconditional on a clamped index
 // (straight-line code: nothing keeps the compiler from issuing the caller's loads in between); only the LDS stores are
