@@ -50,7 +50,8 @@ void launch_pcg_step1(int n, int nt, const double* scal, const double* row_dot, 
                       const double* pre, double* x, double* r, double* blk_part, double* out_pap, hipStream_t s);
 void launch_pcg_step2(int n, double* scal, const double* blk_part, const double* pre, const double* r, double* p,
                       double* out2, hipStream_t s);
-void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s);
+void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s, int* arrived = nullptr);
+void launch_gate(const int* arrived, int expected, int max_micros, hipStream_t s);
 void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 1 / 6 / 8 k_potrf_inv_la with 4 / 6 / 8 waves (default 8)
 // batches of <= 56 tasks use the latency kernels, larger ones the 3 x 3-wave strip kernel
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s);

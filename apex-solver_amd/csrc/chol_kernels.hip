@@ -287,8 +287,11 @@ __device__ unsigned long long g_potrf_trace[64];
 __device__ int g_potrf_trace_n;
 #endif
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_potrf_inv_la(const PotrfTask* __restrict__ tasks, int* __restrict__ fail) {
+__global__ __launch_bounds__(64 * NW) void k_potrf_inv_la(const PotrfTask* __restrict__ tasks, int* __restrict__ fail,
+                                                          int* __restrict__ arrived) {
     constexpr int NT = 64 * NW;
+    // (scheduling hint for k_gate: this workgroup has its CU; nothing depends on the counter for correctness)
+    if (arrived != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef APEX_POTRF_TRACE   // tools/potrf_bench.hip: wall-clock stamps of workgroup 0 at the phase boundaries
 #define POTRF_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_potrf_trace[g_potrf_trace_n++] = wall_clock64(); } while (0)
 #else
@@ -1332,11 +1335,24 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const 
 // ------------------------------------------------------------------------------------------
 static int g_potrf_lookahead = 8;   // 0: k_potrf_inv; 1: look-ahead kernel with 4 waves; 6 / 8 (default): with 6 / 8 waves
 void set_potrf_lookahead(int mode) { g_potrf_lookahead = mode; }
-void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s) {
+// The flood gate (TilePlan::enqueue_factor): one lane that ends when `expected` potrf workgroups have announced themselves
+// in *arrived, or after max_ticks of the 100 MHz clock -- a scheduling hint in front of the bulk updates of a level, so
+// that they do not take the CUs the next level's potrf is about to need.  Never waited for: a gate that times out only
+// costs the time it waited.
+__global__ __launch_bounds__(64) void k_gate(const int* __restrict__ arrived, int expected, long long max_ticks) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected && wall_clock64() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(16);
+}
+void launch_gate(const int* arrived, int expected, int max_micros, hipStream_t s) {
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, arrived, expected, (long long)max_micros * 100);
+}
+void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s, int* arrived) {
     if (n <= 0) return;
-    if (g_potrf_lookahead == 1) hipLaunchKernelGGL(k_potrf_inv_la<4>, dim3(n), dim3(256), 0, s, tasks, fail);
-    else if (g_potrf_lookahead == 6) hipLaunchKernelGGL(k_potrf_inv_la<6>, dim3(n), dim3(384), 0, s, tasks, fail);
-    else if (g_potrf_lookahead) hipLaunchKernelGGL(k_potrf_inv_la<8>, dim3(n), dim3(512), 0, s, tasks, fail);
+    if (g_potrf_lookahead == 1) hipLaunchKernelGGL(k_potrf_inv_la<4>, dim3(n), dim3(256), 0, s, tasks, fail, arrived);
+    else if (g_potrf_lookahead == 6) hipLaunchKernelGGL(k_potrf_inv_la<6>, dim3(n), dim3(384), 0, s, tasks, fail, arrived);
+    else if (g_potrf_lookahead) hipLaunchKernelGGL(k_potrf_inv_la<8>, dim3(n), dim3(512), 0, s, tasks, fail, arrived);
     else hipLaunchKernelGGL(k_potrf_inv, dim3(n), dim3(256), 0, s, tasks, fail);
 }
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s) {

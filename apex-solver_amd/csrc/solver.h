@@ -95,6 +95,7 @@ class Solver : public LmBackend {
     int debug_occupy_cus(int n_cus, int micros) { return check_hip(tp_.debug_occupy_cus(n_cus, micros), "debug_occupy_cus"); }
     void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
+    void set_gate_min(int n) { tp_.set_gate_min(n); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void use_row_schur(int v) { use_rows_ = v != 0; if (v) rows_form_ = v; }
     bool has_structure() const { return have_structure_; }

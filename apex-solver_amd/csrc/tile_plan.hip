@@ -99,7 +99,7 @@ std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool 
 
 void TilePlan::release() {
     void* ptrs[] = {tiles_, linv_, slot_, diag_slot_, flag_, potrf_tasks_, trsm_tasks_, upd_tasks_, tri_fwd_, tri_bwd_,
-                    flow_fwd_, flow_bwd_, flow_part_, flow_flags_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_};
+                    flow_fwd_, flow_bwd_, flow_part_, flow_flags_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_, gate_cnt_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = exch_ = nullptr;
@@ -107,6 +107,7 @@ void TilePlan::release() {
     potrf_tasks_ = nullptr; trsm_tasks_ = upd_tasks_ = nullptr; tri_fwd_ = tri_bwd_ = nullptr;
     flow_fwd_ = flow_bwd_ = nullptr; flow_part_ = nullptr; flow_flags_ = nullptr; n_flow_tasks_ = 0;
     sym_tiles_ = nullptr; sym_entries_ = nullptr;
+    gate_cnt_ = nullptr;
     for (int i = 0; i < kGraphs; ++i) {
         if (graph_exec_[i]) { (void)hipGraphExecDestroy(graph_exec_[i]); graph_exec_[i] = nullptr; }
         graph_failed_[i] = false;
@@ -547,6 +548,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         TP_TRY(hipEventCreateWithFlags(&ev_u2_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_o_[i], hipEventDisableTiming));
     }
+    TP_TRY(hipMalloc(&gate_cnt_, (size_t)(n_levels_ + 1) * sizeof(int)));
     TP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on the stream
 #undef TP_TRY
     return "";
@@ -615,8 +617,10 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     double* bvec = work;
     double* yvec = work ? work + n_pad() : nullptr;
     if (fwd) (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
+    if (gate_min_ > 0 && gate_cnt_) (void)hipMemsetAsync(gate_cnt_, 0, (size_t)(n_levels_ + 1) * sizeof(int), stream_);
     for (int lv = g0; lv < g1; ++lv) {
-        launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flag_, stream_);
+        launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flag_, stream_,
+                         gate_min_ > 0 && gate_cnt_ ? gate_cnt_ + lv : nullptr);
         // the panel solves work on the off-diagonal tiles of this level's columns: U1o of the level below must be in
         if (lv > g0 && o_pending_[lv - 1]) (void)hipStreamWaitEvent(stream_, ev_o_[lv - 1], 0);
         launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_);
@@ -646,6 +650,11 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         o_pending_[lv] = has_o;
         if (has_o) (void)hipEventRecord(ev_o_[lv], so_);
         hipStream_t s2 = has_u2 ? side_ : stream_;
+        // flood gate: the bulk updates of a big level start when the next level's potrf workgroups sit on their CUs (they
+        // follow U1d on the main stream) -- otherwise the update's grid takes every CU first and the potrf, 124 KB of LDS per
+        // workgroup, waits for it to drain
+        if (has_u2 && gate_min_ > 0 && gate_cnt_ && n_u2 >= gate_min_ && lv + 1 < g1)
+            launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);
         for (int r = rs; r < r1; ++r)
             launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s2);
         u2_pending_[lv] = has_u2;
