@@ -155,11 +155,11 @@ class TilePlan {
     int64_t n_potrf_ = 0, n_trsm_ = 0, n_upd_ = 0;
     hipStream_t stream_ = nullptr;
     std::vector<int> slot_h_, diag_slot_h_;
-    std::vector<int> lv_potrf_, lv_trsm_, lv_fwd_, lv_bwd_, lv_upd_round_, lv_upd_split_, lv_upd_splitd_;
+    std::vector<int> lv_potrf_, lv_trsm_, lv_fwd_, lv_bwd_, lv_upd_round_, lv_upd_split_, lv_upd_splitd_, lv_upd_splita_;
     std::vector<std::vector<int>> fwd_cut_;  // per group: first forward task of each column that gets its own launch
     hipStream_t side_ = nullptr;  // trailing updates that the next level does not need (enqueue_factor)
     hipStream_t so_ = nullptr;    // U1o: updates of the next level's off-diagonal tiles, beside its potrf
-    std::vector<hipEvent_t> ev_t_, ev_u2_, ev_o_;
+    std::vector<hipEvent_t> ev_t_, ev_u2_, ev_o_, ev_b_;   // ev_u2_: after U2a of the level; ev_b_: after its U2b
     std::vector<bool> u2_pending_, o_pending_;
     bool split_u1_ = true;
     int split_u1_min_ = 4;

@@ -119,7 +119,8 @@ void TilePlan::release() {
     for (hipEvent_t e : ev_t_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_u2_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_o_) (void)hipEventDestroy(e);
-    ev_t_.clear(); ev_u2_.clear(); ev_o_.clear();
+    for (hipEvent_t e : ev_b_) (void)hipEventDestroy(e);
+    ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear();
 }
 
 TilePlan::~TilePlan() {
@@ -363,6 +364,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     fwd_cut_.assign(n_levels_, std::vector<int>());
     lv_upd_round_.assign(n_levels_ + 1, 0);
     lv_upd_split_.assign(n_levels_ + 1, 0);
+    lv_upd_splita_.assign(n_levels_ + 1, 0);
     lv_upd_splitd_.assign(n_levels_ + 1, 0);
     upd_rounds_.clear();
     upd.reserve(n_upd);
@@ -393,11 +395,13 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         //      next potrf;
         // U2: targets further up the tree -- these run on the side stream, overlapped with the next
         // level's potrf and panel solves (see enqueue_factor)
-        for (int part = 0; part < 3; ++part) {
+        // U2 itself in two parts: U2a = targets in the columns of level lv+2 -- the only ones the NEXT level's U1 updates also
+        // write, so U1(lv+1) waits for U2a(lv) alone -- and U2b = everything higher, which then runs beside them.
+        for (int part = 0; part < 4; ++part) {
             std::vector<const U*> mine;
             for (const U& u : us) {
                 const int tcol = (int)(u.key % nt_), trow = (int)(u.key / nt_);
-                const int cls = group_of[tcol] == lv + 1 ? (trow == tcol ? 0 : 1) : 2;
+                const int cls = group_of[tcol] == lv + 1 ? (trow == tcol ? 0 : 1) : (group_of[tcol] == lv + 2 ? 2 : 3);
                 if (cls == part) mine.push_back(&u);
             }
             std::vector<int> round(mine.size(), 0);
@@ -418,6 +422,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             }
             if (part == 0) lv_upd_splitd_[lv] = (int)upd_rounds_.size();
             if (part == 1) lv_upd_split_[lv] = (int)upd_rounds_.size();
+            if (part == 2) lv_upd_splita_[lv] = (int)upd_rounds_.size();
         }
         lv_potrf_[lv + 1] = (int)potrf.size();
         lv_trsm_[lv + 1] = (int)trsm.size();
@@ -540,13 +545,14 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     if (!so_) TP_TRY(hipStreamCreateWithFlags(&so_, hipStreamNonBlocking));
     if (!fwd_) TP_TRY(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
     TP_TRY(hipEventCreateWithFlags(&ev_fwd_, hipEventDisableTiming));
-    ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_); ev_o_.resize(n_levels_);
+    ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_); ev_o_.resize(n_levels_); ev_b_.resize(n_levels_);
     u2_pending_.assign(n_levels_, false);
     o_pending_.assign(n_levels_, false);
     for (int i = 0; i < n_levels_; ++i) {
         TP_TRY(hipEventCreateWithFlags(&ev_t_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_u2_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_o_[i], hipEventDisableTiming));
+        TP_TRY(hipEventCreateWithFlags(&ev_b_[i], hipEventDisableTiming));
     }
     TP_TRY(hipMalloc(&gate_cnt_, (size_t)(n_levels_ + 1) * sizeof(int)));
     TP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on the stream
@@ -605,9 +611,13 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     // potrf; the next panel solves wait for them.  Side: U2(lv) = every other update of level lv, overlapped with
     // potrf / panel solves of level lv+1 (one workgroup resp. a few dozen: they leave the chip nearly empty).
     // Ordering that keeps every tile's read-modify-write sequence race free:
-    //   U2(lv) after the panel solves of lv;  U1d(lv), U1o(lv) after U2(lv-1) (all may hit columns of level lv+1);
-    //   potrf(lv) after U1d(lv-1) [stream order] and U2(<= lv-2) [main already waited for it before U1d(lv-1)];
-    //   panel(lv) after U1o(lv-1) [event];  U1o(lv) and U2(lv) hit different columns (level lv+1 / above).
+    //   U2(lv) after the panel solves of lv;  U1d(lv), U1o(lv) after U2a(lv-1) -- the part of U2(lv-1) whose targets lie in
+    //   the columns of level lv+1, and with it (side-stream order) every older side-stream update; U2b(lv-1), targets in
+    //   level lv+2 and above, runs on beside them (round 3: the wait for the whole of U2(lv-1) had become the critical chain
+    //   once the flood gate let the potrf start on time);
+    //   potrf(lv) after U1d(lv-1) [stream order] and whatever U1d(lv-1) waited for;
+    //   panel(lv) after U1o(lv-1) [event];  U1o(lv) and U2(lv) hit different columns (level lv+1 / above);
+    //   a U2 too small for the side stream runs on the main stream after the side stream's last U2b [ev_b_].
     const bool two = overlap_ && side_ != nullptr && n_levels_ > 2;
     // Forward substitution L y = rhs fused into the factorisation (when the right-hand side is known now): the
     // step of level lv needs only that level's L^-1 and panel tiles, which are final after its panel solves, so it
@@ -618,6 +628,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     double* yvec = work ? work + n_pad() : nullptr;
     if (fwd) (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
     if (gate_min_ > 0 && gate_cnt_) (void)hipMemsetAsync(gate_cnt_, 0, (size_t)(n_levels_ + 1) * sizeof(int), stream_);
+    int last_side = -1;   // last level whose U2b went to the side stream and has not been waited for on the main stream
     for (int lv = g0; lv < g1; ++lv) {
         launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flag_, stream_,
                          gate_min_ > 0 && gate_cnt_ ? gate_cnt_ + lv : nullptr);
@@ -655,15 +666,20 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         // workgroup, waits for it to drain
         if (has_u2 && gate_min_ > 0 && gate_cnt_ && n_u2 >= gate_min_ && lv + 1 < g1)
             launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);
-        for (int r = rs; r < r1; ++r)
+        // a small U2 stays on the main stream: an earlier level's U2b may still be at work on the same targets over there
+        if (!has_u2 && last_side >= 0 && r1 > rs) { (void)hipStreamWaitEvent(stream_, ev_b_[last_side], 0); last_side = -1; }
+        const int ra = lv_upd_splita_[lv];
+        for (int r = rs; r < ra; ++r)   // U2a: targets in the columns of level lv+2 (U1 of the next level writes them too)
             launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s2);
         u2_pending_[lv] = has_u2;
-        if (has_u2) (void)hipEventRecord(ev_u2_[lv], side_);
+        if (has_u2) (void)hipEventRecord(ev_u2_[lv], side_);   // ... and, in stream order, every earlier side-stream update
+        for (int r = ra; r < r1; ++r)   // U2b: targets higher up, beside the next level
+            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s2);
+        if (has_u2) { (void)hipEventRecord(ev_b_[lv], side_); last_side = lv; }
     }
     if (g1 > g0 && o_pending_[g1 - 1]) (void)hipStreamWaitEvent(stream_, ev_o_[g1 - 1], 0);
-    if (two)  // join: the last side-stream work precedes whatever follows on the main stream
-        for (int lv = g1 - 1; lv >= g0; --lv)
-            if (u2_pending_[lv]) { (void)hipStreamWaitEvent(stream_, ev_u2_[lv], 0); break; }
+    if (last_side >= 0)  // join: the last side-stream work (a U2b) precedes whatever follows on the main stream
+        (void)hipStreamWaitEvent(stream_, ev_b_[last_side], 0);
     if (fwd) {
         (void)hipEventRecord(ev_fwd_, fwd_);
         (void)hipStreamWaitEvent(stream_, ev_fwd_, 0);
