@@ -92,6 +92,7 @@ class TilePlan {
     void enable_graphs(bool on) { use_graphs_ = on; }
     void enable_overlap(bool on) { overlap_ = on; }  // before the first factor()
     void set_overlap_min(int n) { overlap_min_ = n; }
+    void set_gate_pos(int p) { gate_pos_ = p; }   // 0: in front of U2a, 1: between U2a and U2b
     void set_gate_min(int n) { gate_min_ = n; }   // flood gate in front of U2 batches of at least n tasks (0: off); before the first factor()
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
     hipError_t read_flags(int* failed_at);   // pivot flag of the last factorisation (syncs)
@@ -164,7 +165,10 @@ class TilePlan {
     bool split_u1_ = true;
     int split_u1_min_ = 4;
     bool overlap_ = true;
-    int gate_min_ = 50;   // swept 2 .. 1500 on final-13682: 7.9 ms for 2 .. 100, 8.2 at 1000, 8.3 without (gating U1o as well: no difference)
+    int gate_pos_ = 0;
+    int gate_min_ = 256;  // U2 batches of at least this many tasks get the flood gate.  Before U2 was split into U2a / U2b the gate was worth 0.3-0.4 ms on
+                          // final-13682 (8.3 -> 7.9, any threshold 2 .. 250); after the split it is neutral there (7.6-7.7 either way), +2-3 % on the
+                          // dense fronts of ladybug / venice, -2 % on sphere2500's small batches: kept for the large batches only
     int* gate_cnt_ = nullptr;   // [levels + 1] potrf workgroups that have started, per level
     int overlap_min_ = 2;   // U2 batches smaller than this stay on the main stream (swept 1..1024: flat up to 64)
     std::vector<std::pair<int64_t, int64_t>> upd_rounds_;

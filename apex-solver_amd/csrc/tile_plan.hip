@@ -664,8 +664,8 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         // flood gate: the bulk updates of a big level start when the next level's potrf workgroups sit on their CUs (they
         // follow U1d on the main stream) -- otherwise the update's grid takes every CU first and the potrf, 124 KB of LDS per
         // workgroup, waits for it to drain
-        if (has_u2 && gate_min_ > 0 && gate_cnt_ && n_u2 >= gate_min_ && lv + 1 < g1)
-            launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);
+        const bool gated = has_u2 && gate_min_ > 0 && gate_cnt_ && n_u2 >= gate_min_ && lv + 1 < g1;
+        if (gated && gate_pos_ == 0) launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);
         // a small U2 stays on the main stream: an earlier level's U2b may still be at work on the same targets over there
         if (!has_u2 && last_side >= 0 && r1 > rs) { (void)hipStreamWaitEvent(stream_, ev_b_[last_side], 0); last_side = -1; }
         const int ra = lv_upd_splita_[lv];
@@ -673,6 +673,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
             launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s2);
         u2_pending_[lv] = has_u2;
         if (has_u2) (void)hipEventRecord(ev_u2_[lv], side_);   // ... and, in stream order, every earlier side-stream update
+        if (gated && gate_pos_ == 1) launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);
         for (int r = ra; r < r1; ++r)   // U2b: targets higher up, beside the next level
             launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s2);
         if (has_u2) { (void)hipEventRecord(ev_b_[lv], side_); last_side = lv; }
