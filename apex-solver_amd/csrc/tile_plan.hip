@@ -120,7 +120,8 @@ void TilePlan::release() {
     for (hipEvent_t e : ev_u2_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_o_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_b_) (void)hipEventDestroy(e);
-    ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear();
+    for (hipEvent_t e : ev_b2_) (void)hipEventDestroy(e);
+    ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear(); ev_b2_.clear();
 }
 
 TilePlan::~TilePlan() {
@@ -365,6 +366,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     lv_upd_round_.assign(n_levels_ + 1, 0);
     lv_upd_split_.assign(n_levels_ + 1, 0);
     lv_upd_splita_.assign(n_levels_ + 1, 0);
+    lv_upd_splitb_.assign(n_levels_ + 1, 0);
     lv_upd_splitd_.assign(n_levels_ + 1, 0);
     upd_rounds_.clear();
     upd.reserve(n_upd);
@@ -397,11 +399,14 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         // level's potrf and panel solves (see enqueue_factor)
         // U2 itself in two parts: U2a = targets in the columns of level lv+2 -- the only ones the NEXT level's U1 updates also
         // write, so U1(lv+1) waits for U2a(lv) alone -- and U2b = everything higher, which then runs beside them.
-        for (int part = 0; part < 4; ++part) {
+        // ... and U2b in two: U2b1 = targets in level lv+3 (all that U2a of the NEXT level collides with), which stays on U2a's
+        // stream, and U2b2 = level lv+4 and above, the bulk, on a stream of its own (enqueue_factor).
+        for (int part = 0; part < 5; ++part) {
             std::vector<const U*> mine;
             for (const U& u : us) {
                 const int tcol = (int)(u.key % nt_), trow = (int)(u.key / nt_);
-                const int cls = group_of[tcol] == lv + 1 ? (trow == tcol ? 0 : 1) : (group_of[tcol] == lv + 2 ? 2 : 3);
+                const int d = group_of[tcol] - lv;
+                const int cls = d == 1 ? (trow == tcol ? 0 : 1) : (d == 2 ? 2 : (d == 3 ? 3 : 4));
                 if (cls == part) mine.push_back(&u);
             }
             std::vector<int> round(mine.size(), 0);
@@ -423,6 +428,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             if (part == 0) lv_upd_splitd_[lv] = (int)upd_rounds_.size();
             if (part == 1) lv_upd_split_[lv] = (int)upd_rounds_.size();
             if (part == 2) lv_upd_splita_[lv] = (int)upd_rounds_.size();
+            if (part == 3) lv_upd_splitb_[lv] = (int)upd_rounds_.size();
         }
         lv_potrf_[lv + 1] = (int)potrf.size();
         lv_trsm_[lv + 1] = (int)trsm.size();
@@ -543,9 +549,10 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     // (and so was a CU-masked one that leaves 1 CU in 8 / 4 / 2 to the critical path: the same, either way)
     if (!side_) TP_TRY(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
     if (!so_) TP_TRY(hipStreamCreateWithFlags(&so_, hipStreamNonBlocking));
+    if (!side2_) TP_TRY(hipStreamCreateWithFlags(&side2_, hipStreamNonBlocking));
     if (!fwd_) TP_TRY(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
     TP_TRY(hipEventCreateWithFlags(&ev_fwd_, hipEventDisableTiming));
-    ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_); ev_o_.resize(n_levels_); ev_b_.resize(n_levels_);
+    ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_); ev_o_.resize(n_levels_); ev_b_.resize(n_levels_); ev_b2_.resize(n_levels_);
     u2_pending_.assign(n_levels_, false);
     o_pending_.assign(n_levels_, false);
     for (int i = 0; i < n_levels_; ++i) {
@@ -553,6 +560,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         TP_TRY(hipEventCreateWithFlags(&ev_u2_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_o_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_b_[i], hipEventDisableTiming));
+        TP_TRY(hipEventCreateWithFlags(&ev_b2_[i], hipEventDisableTiming));
     }
     TP_TRY(hipMalloc(&gate_cnt_, (size_t)(n_levels_ + 1) * sizeof(int)));
     TP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on the stream
@@ -628,7 +636,12 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     double* yvec = work ? work + n_pad() : nullptr;
     if (fwd) (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
     if (gate_min_ > 0 && gate_cnt_) (void)hipMemsetAsync(gate_cnt_, 0, (size_t)(n_levels_ + 1) * sizeof(int), stream_);
-    int last_side = -1;   // last level whose U2b went to the side stream and has not been waited for on the main stream
+    int last_a = -1, last_b = -1;   // last levels with work on the side streams A / B that the main stream has not waited for
+    std::vector<int> lastb((size_t)std::max(g1 - g0, 1), -1);   // lastb[lv - g0]: the last level <= lv with U2b2 work on stream B
+    int b2_pending = -1, a_waited = -1;
+    auto a_wait_upto = [&](int lvb) {   // stream A waits for stream B up to level lvb's U2b2 (B runs in order)
+        if (lvb > a_waited) { (void)hipStreamWaitEvent(side_, ev_b2_[lvb], 0); a_waited = lvb; }
+    };
     for (int lv = g0; lv < g1; ++lv) {
         launch_potrf_inv(potrf_tasks_ + lv_potrf_[lv], lv_potrf_[lv + 1] - lv_potrf_[lv], flag_, stream_,
                          gate_min_ > 0 && gate_cnt_ ? gate_cnt_ + lv : nullptr);
@@ -660,27 +673,49 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
             launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s1);
         o_pending_[lv] = has_o;
         if (has_o) (void)hipEventRecord(ev_o_[lv], so_);
-        hipStream_t s2 = has_u2 ? side_ : stream_;
+        // U2 on two streams of its own.  A (side_): U2a(lv) [targets in level lv+2: what U1(lv+1) waits for], then U2b1(lv)
+        // [level lv+3].  B (side2_): U2b2(lv) [level lv+4 and above: the bulk].  Writers of one target level t, in time:
+        // U2b2(<= t-4) -> U2b1(t-3) -> U2a(t-2) -> U1(t-1); B orders the first among themselves, U2b1(lv) waits for
+        // U2b2(lv-1) [ev_b2_], the rest is stream order on A and ev_u2_.  U2a(lv+1) thus waits for U2b1(lv) only, not for the
+        // bulk of level lv (on one stream it did, and through it U1d(lv+2) and the potrf behind it).
+        const bool b2_side = has_u2 && side2_ != nullptr && two_side_;
         // flood gate: the bulk updates of a big level start when the next level's potrf workgroups sit on their CUs (they
         // follow U1d on the main stream) -- otherwise the update's grid takes every CU first and the potrf, 124 KB of LDS per
         // workgroup, waits for it to drain
         const bool gated = has_u2 && gate_min_ > 0 && gate_cnt_ && n_u2 >= gate_min_ && lv + 1 < g1;
         if (gated && gate_pos_ == 0) launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);
-        // a small U2 stays on the main stream: an earlier level's U2b may still be at work on the same targets over there
-        if (!has_u2 && last_side >= 0 && r1 > rs) { (void)hipStreamWaitEvent(stream_, ev_b_[last_side], 0); last_side = -1; }
-        const int ra = lv_upd_splita_[lv];
-        for (int r = rs; r < ra; ++r)   // U2a: targets in the columns of level lv+2 (U1 of the next level writes them too)
-            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s2);
+        // a small U2 stays on the main stream: earlier levels' U2b may still be at work on the same targets over there
+        if (!has_u2 && r1 > rs) {
+            if (last_a >= 0) { (void)hipStreamWaitEvent(stream_, ev_b_[last_a], 0); last_a = -1; }
+            if (last_b >= 0) { (void)hipStreamWaitEvent(stream_, ev_b2_[last_b], 0); last_b = -1; }
+        }
+        const int ra = lv_upd_splita_[lv], rb = lv_upd_splitb_[lv];
+        hipStream_t sa = has_u2 ? side_ : stream_, sb = b2_side ? side2_ : sa;
+        // U2a(lv) [level lv+2] follows every U2b2 of levels <= lv-2 [their targets start at level lv+2] ...
+        if (has_u2 && lv - 2 >= g0) a_wait_upto(lastb[lv - 2 - g0]);
+        for (int r = rs; r < ra; ++r)   // U2a
+            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, sa);
         u2_pending_[lv] = has_u2;
-        if (has_u2) (void)hipEventRecord(ev_u2_[lv], side_);   // ... and, in stream order, every earlier side-stream update
-        if (gated && gate_pos_ == 1) launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);
-        for (int r = ra; r < r1; ++r)   // U2b: targets higher up, beside the next level
-            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, s2);
-        if (has_u2) { (void)hipEventRecord(ev_b_[lv], side_); last_side = lv; }
+        if (has_u2) (void)hipEventRecord(ev_u2_[lv], side_);   // ... and, in stream order, every earlier update on A
+        if (b2_side) {
+            (void)hipStreamWaitEvent(side2_, ev_t_[lv], 0);
+            if (gated) launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side2_);
+        } else if (gated && gate_pos_ == 1) {
+            launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);
+        }
+        if (has_u2 && lv - 1 >= g0) a_wait_upto(lastb[lv - 1 - g0]);   // ... and U2b1(lv) [level lv+3] every U2b2 of levels <= lv-1
+        for (int r = ra; r < rb; ++r)   // U2b1
+            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, sa);
+        for (int r = rb; r < r1; ++r)   // U2b2
+            launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, sb);
+        if (has_u2) { (void)hipEventRecord(ev_b_[lv], side_); last_a = lv; }
+        if (b2_side && r1 > rb) { (void)hipEventRecord(ev_b2_[lv], side2_); last_b = lv; }
+        lastb[lv - g0] = b2_pending = (b2_side && r1 > rb) ? lv : b2_pending;
     }
     if (g1 > g0 && o_pending_[g1 - 1]) (void)hipStreamWaitEvent(stream_, ev_o_[g1 - 1], 0);
-    if (last_side >= 0)  // join: the last side-stream work (a U2b) precedes whatever follows on the main stream
-        (void)hipStreamWaitEvent(stream_, ev_b_[last_side], 0);
+    // join: the last side-stream work precedes whatever follows on the main stream
+    if (last_a >= 0) (void)hipStreamWaitEvent(stream_, ev_b_[last_a], 0);
+    if (last_b >= 0) (void)hipStreamWaitEvent(stream_, ev_b2_[last_b], 0);
     if (fwd) {
         (void)hipEventRecord(ev_fwd_, fwd_);
         (void)hipStreamWaitEvent(stream_, ev_fwd_, 0);
