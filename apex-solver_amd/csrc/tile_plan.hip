@@ -520,6 +520,11 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             if (J == I || present[(size_t)I * nt_ + J]) symt.push_back({slot_h_[(size_t)I * nt_ + J], I, J});
     }
     n_potrf_ = (int64_t)potrf.size(); n_trsm_ = (int64_t)trsm.size(); n_upd_ = (int64_t)upd.size();
+    // The second side stream (enqueue_factor), for the whole plan or not at all: it pays where a level carries a bulk worth
+    // overlapping (final-13682: ~1,000 tile products per level, 7.95 -> 7.5 ms; synthetic-10k 6.4 -> 6.1) and costs where the
+    // levels are small and the factorisation is its launch chain (the ladybug / venice shapes, ~100 products per level: one
+    // more stream is one more edge per level, 3.1 -> 3.5 ms).
+    two_side_plan_ = two_side_ && n_upd_ >= 256 * (int64_t)n_levels_;
     n_sym_tiles_ = (int)symt.size();
     TP_TRY(upload(&sym_tiles_, symt));
     TP_TRY(alloc_zero(&sym_part_, (size_t)n_slots_ * 2 * kNB));
@@ -678,7 +683,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         // U2b2(<= t-4) -> U2b1(t-3) -> U2a(t-2) -> U1(t-1); B orders the first among themselves, U2b1(lv) waits for
         // U2b2(lv-1) [ev_b2_], the rest is stream order on A and ev_u2_.  U2a(lv+1) thus waits for U2b1(lv) only, not for the
         // bulk of level lv (on one stream it did, and through it U1d(lv+2) and the potrf behind it).
-        const bool b2_side = has_u2 && side2_ != nullptr && two_side_;
+        const bool b2_side = has_u2 && side2_ != nullptr && two_side_plan_;
         // flood gate: the bulk updates of a big level start when the next level's potrf workgroups sit on their CUs (they
         // follow U1d on the main stream) -- otherwise the update's grid takes every CU first and the potrf, 124 KB of LDS per
         // workgroup, waits for it to drain
