@@ -238,7 +238,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "split_u1") h->s->set_split_u1(value);
     else if (n == "flood_gate") h->s->set_gate_min(value);
     else if (n == "flood_gate_pos") h->s->set_gate_pos(value);
-    else if (n == "two_side") h->s->set_two_side(value != 0);
+    else if (n == "two_side") h->s->set_two_side(value);
     else if (n == "rec_backsub") h->s->set_rec_backsub(value != 0);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
@@ -537,7 +537,7 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     if (n == "graphs") h->s->enable_graphs(value != 0);
     else if (n == "update_overlap") { h->s->enable_overlap(value != 0); if (value > 1) h->s->set_overlap_min(value); }
     else if (n == "tri_dataflow") h->s->enable_tri_flow(value != 0);
-    else if (n == "two_side") h->s->set_two_side(value != 0);
+    else if (n == "two_side") h->s->set_two_side(value);
     else if (n == "flood_gate") h->s->set_gate_min(value);
     else if (n == "split_u1") h->s->set_split_u1(value);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);

@@ -59,7 +59,7 @@ class PoseGraphSolver : public LmBackend {
     void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
-    void set_two_side(bool on) { tp_.set_two_side(on); }
+    void set_two_side(int mode) { tp_.set_two_side(mode); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void enable_stage_timing(bool on) { timer_.enable(on); }

@@ -97,7 +97,7 @@ class Solver : public LmBackend {
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
     void set_gate_pos(int p) { tp_.set_gate_pos(p); }
-    void set_two_side(bool on) { tp_.set_two_side(on); }
+    void set_two_side(int mode) { tp_.set_two_side(mode); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void use_row_schur(int v) { use_rows_ = v != 0; if (v) rows_form_ = v; }
     bool has_structure() const { return have_structure_; }

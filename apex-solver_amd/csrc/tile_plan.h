@@ -92,7 +92,7 @@ class TilePlan {
     void enable_graphs(bool on) { use_graphs_ = on; }
     void enable_overlap(bool on) { overlap_ = on; }  // before the first factor()
     void set_overlap_min(int n) { overlap_min_ = n; }
-    void set_two_side(bool on) { two_side_ = on; }   // before build()
+    void set_two_side(int mode) { two_side_ = mode; }   // 0 off, 1 by plan size (default), 2 always (tests); before build()
     void set_gate_pos(int p) { gate_pos_ = p; }   // 0: in front of U2a, 1: between U2a and U2b
     void set_gate_min(int n) { gate_min_ = n; }   // flood gate in front of U2 batches of at least n tasks (0: off); before the first factor()
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
@@ -161,7 +161,7 @@ class TilePlan {
     std::vector<std::vector<int>> fwd_cut_;  // per group: first forward task of each column that gets its own launch
     hipStream_t side_ = nullptr;  // trailing updates that the next level does not need (enqueue_factor)
     hipStream_t side2_ = nullptr; // U2b2: the bulk of U2 (targets four levels up and more)
-    bool two_side_ = true;        // option; two_side_plan_: what build() decided for this plan
+    int two_side_ = 1;            // option; two_side_plan_: what build() decided for this plan
     bool two_side_plan_ = false;
     hipStream_t so_ = nullptr;    // U1o: updates of the next level's off-diagonal tiles, beside its potrf
     std::vector<hipEvent_t> ev_t_, ev_u2_, ev_o_, ev_b_, ev_b2_;   // ev_u2_: after U2a of the level; ev_b_: after its U2b

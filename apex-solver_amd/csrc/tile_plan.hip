@@ -127,6 +127,7 @@ void TilePlan::release() {
 TilePlan::~TilePlan() {
     release();
     if (side_) (void)hipStreamDestroy(side_);
+    if (side2_) { (void)hipStreamDestroy(side2_); side2_ = nullptr; }
     if (so_) { (void)hipStreamDestroy(so_); so_ = nullptr; }
     if (fwd_) (void)hipStreamDestroy(fwd_);
 }
@@ -524,7 +525,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     // overlapping (final-13682: ~1,000 tile products per level, 7.95 -> 7.5 ms; synthetic-10k 6.4 -> 6.1) and costs where the
     // levels are small and the factorisation is its launch chain (the ladybug / venice shapes, ~100 products per level: one
     // more stream is one more edge per level, 3.1 -> 3.5 ms).
-    two_side_plan_ = two_side_ && n_upd_ >= 256 * (int64_t)n_levels_;
+    two_side_plan_ = two_side_ == 2 || (two_side_ == 1 && n_upd_ >= 256 * (int64_t)n_levels_);
     n_sym_tiles_ = (int)symt.size();
     TP_TRY(upload(&sym_tiles_, symt));
     TP_TRY(alloc_zero(&sym_part_, (size_t)n_slots_ * 2 * kNB));
@@ -683,7 +684,8 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         // U2b2(<= t-4) -> U2b1(t-3) -> U2a(t-2) -> U1(t-1); B orders the first among themselves, U2b1(lv) waits for
         // U2b2(lv-1) [ev_b2_], the rest is stream order on A and ev_u2_.  U2a(lv+1) thus waits for U2b1(lv) only, not for the
         // bulk of level lv (on one stream it did, and through it U1d(lv+2) and the potrf behind it).
-        const bool b2_side = has_u2 && side2_ != nullptr && two_side_plan_;
+        // (only when there is such work: a stream that joins the capture must come back to it with an event)
+        const bool b2_side = has_u2 && side2_ != nullptr && two_side_plan_ && r1 > lv_upd_splitb_[lv];
         // flood gate: the bulk updates of a big level start when the next level's potrf workgroups sit on their CUs (they
         // follow U1d on the main stream) -- otherwise the update's grid takes every CU first and the potrf, 124 KB of LDS per
         // workgroup, waits for it to drain
@@ -714,8 +716,8 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         for (int r = rb; r < r1; ++r)   // U2b2
             launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, sb);
         if (has_u2) { (void)hipEventRecord(ev_b_[lv], side_); last_a = lv; }
-        if (b2_side && r1 > rb) { (void)hipEventRecord(ev_b2_[lv], side2_); last_b = lv; }
-        lastb[lv - g0] = b2_pending = (b2_side && r1 > rb) ? lv : b2_pending;
+        if (b2_side) { (void)hipEventRecord(ev_b2_[lv], side2_); last_b = lv; }
+        lastb[lv - g0] = b2_pending = b2_side ? lv : b2_pending;
     }
     if (g1 > g0 && o_pending_[g1 - 1]) (void)hipStreamWaitEvent(stream_, ev_o_[g1 - 1], 0);
     // join: the last side-stream work precedes whatever follows on the main stream
