@@ -74,11 +74,11 @@ __device__ __forceinline__ double* s_block_ptr(const TileMap& tm, uint32_t row_c
 // (+lambda on the diagonal when add_lambda), g_c and g_red := -g_c.
 // ------------------------------------------------------------------------------------------
 constexpr int kCamThreads = 64;  // one wave per camera: ~30 observations per lane amortise the 63-value reduction
-template <int DC, bool MASKED>
+template <int DC, bool MASKED, bool WITH_SELF>
 __global__ __launch_bounds__(kCamThreads, 2) void k_cam_reduce(BAView v, TileMap tm, const int* __restrict__ cam_ptr,
                                                       const int* __restrict__ cam_obs, double lambda,
                                                       int add_lambda, const double* __restrict__ hinv,
-                                                      const double* __restrict__ g_l, int with_self,
+                                                      const double* __restrict__ g_l,
                                                       double* __restrict__ g_c, double* __restrict__ g_red) {
     // with_self (row form of the Schur reduction): the block also receives the camera's own Schur
     // terms -sum_i Y_i W_i^T and g_red is completed with +sum_i Y_i g_l, so that k_schur_rows only
@@ -93,41 +93,55 @@ __global__ __launch_bounds__(kCamThreads, 2) void k_cam_reduce(BAView v, TileMap
     Cam cam;
     load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
     const int b = cam_ptr[c], e = cam_ptr[c + 1];
-    // (prefetching the next observation's landmark index and measurement was tried: three more live registers on a kernel that
-    // sits at 256 VGPRs spill, 1.14 -> 1.29 ms)
+    // the next observation's landmark index and measurement are in flight while this one is reduced: the record gather of an
+    // iteration starts at once instead of after a round trip for its address (affordable since the self term goes through the
+    // 2 x 2 matrix P: at 256 VGPRs the three extra live registers spilled, 1.14 -> 1.29 ms)
+    const int k_first = max(min(b + (int)threadIdx.x, e - 1), 0);
+    uint32_t l_next = v.co_pt[k_first];
+    double2 uv_next = v.co_uv[k_first];
     for (int k = b + (int)threadIdx.x; k < e; k += kCamThreads) {
-        const uint32_t l = v.co_pt[k];   // camera-major copies: coalesced
-        const double2 uv = v.co_uv[k];
+        const uint32_t l = l_next;   // camera-major copies: coalesced
+        const double2 uv = uv_next;
+        if (k + kCamThreads < e) { l_next = v.co_pt[k + kCamThreads]; uv_next = v.co_uv[k + kCamThreads]; }
         double rec[kLmStride];
         load_lm_record(hinv, l, rec);     // Hll^-1, g_l and the point: one 128-byte line
         const double pw[3] = {rec[kLmPt], rec[kLmPt + 1], rec[kLmPt + 2]};
         double r[2], Jc[2][DC], Jl[2][3];
         linearize_obs<DC, MASKED>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
-        int idx = 0;
-#pragma unroll
-        for (int a = 0; a < DC; ++a)
-#pragma unroll
-            for (int bb = 0; bb <= a; ++bb) acc[idx++] += Jc[0][a] * Jc[0][bb] + Jc[1][a] * Jc[1][bb];
 #pragma unroll
         for (int a = 0; a < DC; ++a) acc[NH + a] += Jc[0][a] * r[0] + Jc[1][a] * r[1];
-        if (with_self) {
-            // row a of Y = W Hll^-1 is used as soon as it exists (the self term only needs W(bb), bb <= a): no Y array,
-            // which keeps the kernel under 256 VGPRs = 2 waves per SIMD (it was 300 = 1 wave, nothing to hide a gather)
-            double W[DC][3];
+        if (WITH_SELF) {
+            // The camera's own Schur term folded into the block through the observation's 2 x 2 matrix
+            //     P = I - Jl Hll^-1 Jl^T :   Jc^T Jc - (Jc^T Jl) Hll^-1 (Jl^T Jc) = Jc^T P Jc,
+            // and W Hll^-1 g_l = Jc^T (Jl (Hll^-1 g_l)): 2-vectors and a 2 x 2 instead of the 9 x 3 matrices W and Y = W Hll^-1 --
+            // ~200 instead of ~400 multiply-adds per observation, 54 registers fewer, and no difference of two large sums.
             const double* Hi = rec;
             const double gl0 = rec[kLmG], gl1 = rec[kLmG + 1], gl2 = rec[kLmG + 2];
-            int idx2 = 0;
+            double T[2][3];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) T[rr][q] = Jl[rr][0] * Hi[q] + Jl[rr][1] * Hi[3 + q] + Jl[rr][2] * Hi[6 + q];
+            const double p00 = 1.0 - (T[0][0] * Jl[0][0] + T[0][1] * Jl[0][1] + T[0][2] * Jl[0][2]);
+            const double p01 = -(T[0][0] * Jl[1][0] + T[0][1] * Jl[1][1] + T[0][2] * Jl[1][2]);
+            const double p11 = 1.0 - (T[1][0] * Jl[1][0] + T[1][1] * Jl[1][1] + T[1][2] * Jl[1][2]);
+            const double v0 = Hi[0] * gl0 + Hi[1] * gl1 + Hi[2] * gl2, v1 = Hi[3] * gl0 + Hi[4] * gl1 + Hi[5] * gl2,
+                         v2 = Hi[6] * gl0 + Hi[7] * gl1 + Hi[8] * gl2;
+            const double w0 = Jl[0][0] * v0 + Jl[0][1] * v1 + Jl[0][2] * v2, w1 = Jl[1][0] * v0 + Jl[1][1] * v1 + Jl[1][2] * v2;
+            int idx = 0;
 #pragma unroll
             for (int a = 0; a < DC; ++a) {
+                const double q0 = p00 * Jc[0][a] + p01 * Jc[1][a], q1 = p01 * Jc[0][a] + p11 * Jc[1][a];
+                acc[NH + DC + a] += Jc[0][a] * w0 + Jc[1][a] * w1;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) W[a][q] = Jc[0][a] * Jl[0][q] + Jc[1][a] * Jl[1][q];
-                double Ya[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) Ya[q] = W[a][0] * Hi[q] + W[a][1] * Hi[3 + q] + W[a][2] * Hi[6 + q];
-                acc[NH + DC + a] += Ya[0] * gl0 + Ya[1] * gl1 + Ya[2] * gl2;
-#pragma unroll
-                for (int bb = 0; bb <= a; ++bb) acc[idx2++] -= Ya[0] * W[bb][0] + Ya[1] * W[bb][1] + Ya[2] * W[bb][2];
+                for (int bb = 0; bb <= a; ++bb) acc[idx++] += q0 * Jc[0][bb] + q1 * Jc[1][bb];
             }
+        } else {
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < DC; ++a)
+#pragma unroll
+                for (int bb = 0; bb <= a; ++bb) acc[idx++] += Jc[0][a] * Jc[0][bb] + Jc[1][a] * Jc[1][bb];
         }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1287,10 +1301,15 @@ void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* ca
                        double* g_red, hipStream_t s) {
     if (v.n_cam == 0) return;
     const bool masked = !(v.mask_code == 7 || (dc == 6 && v.mask_code == 6));   // (the masked form costs a wave per SIMD at d_c = 9)
-    if (dc == 9 && !masked) hipLaunchKernelGGL((k_cam_reduce<9, false>), dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
-    else if (dc == 9) hipLaunchKernelGGL((k_cam_reduce<9, true>), dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
-    else if (!masked) hipLaunchKernelGGL((k_cam_reduce<6, false>), dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
-    else hipLaunchKernelGGL((k_cam_reduce<6, true>), dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, with_self, g_c, g_red);
+#define CAM_REDUCE(DCV, MK, WS) hipLaunchKernelGGL((k_cam_reduce<DCV, MK, WS>), dim3((unsigned)v.n_cam), dim3(kCamThreads), 0, s, v, tm, cam_ptr, cam_obs, lambda, add_lambda, hinv, g_l, g_c, g_red)
+    if (with_self) {
+        if (dc == 9 && !masked) CAM_REDUCE(9, false, true); else if (dc == 9) CAM_REDUCE(9, true, true);
+        else if (!masked) CAM_REDUCE(6, false, true); else CAM_REDUCE(6, true, true);
+    } else {
+        if (dc == 9 && !masked) CAM_REDUCE(9, false, false); else if (dc == 9) CAM_REDUCE(9, true, false);
+        else if (!masked) CAM_REDUCE(6, false, false); else CAM_REDUCE(6, true, false);
+    }
+#undef CAM_REDUCE
 }
 
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag, double* lmu,
