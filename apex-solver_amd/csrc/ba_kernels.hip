@@ -99,12 +99,19 @@ __global__ __launch_bounds__(kCamThreads, 2) void k_cam_reduce(BAView v, TileMap
     const int k_first = max(min(b + (int)threadIdx.x, e - 1), 0);
     uint32_t l_next = v.co_pt[k_first];
     double2 uv_next = v.co_uv[k_first];
+    double rec_next[kLmStride];
+    load_lm_record(hinv, l_next, rec_next);
+    if (k_first + kCamThreads < e) l_next = v.co_pt[k_first + kCamThreads];
     for (int k = b + (int)threadIdx.x; k < e; k += kCamThreads) {
-        const uint32_t l = l_next;   // camera-major copies: coalesced
         const double2 uv = uv_next;
-        if (k + kCamThreads < e) { l_next = v.co_pt[k + kCamThreads]; uv_next = v.co_uv[k + kCamThreads]; }
         double rec[kLmStride];
-        load_lm_record(hinv, l, rec);     // Hll^-1, g_l and the point: one 128-byte line
+#pragma unroll
+        for (int q = 0; q < kLmStride; ++q) rec[q] = rec_next[q];
+        if (k + kCamThreads < e) {   // the next observation's record and measurement, the index of the one after
+            uv_next = v.co_uv[k + kCamThreads];
+            load_lm_record(hinv, l_next, rec_next);
+            if (k + 2 * kCamThreads < e) l_next = v.co_pt[k + 2 * kCamThreads];
+        }
         const double pw[3] = {rec[kLmPt], rec[kLmPt + 1], rec[kLmPt + 2]};
         double r[2], Jc[2][DC], Jl[2][3];
         linearize_obs<DC, MASKED>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
