@@ -1,4 +1,4 @@
-# tools/gate_other_workloads.sh <option> <v1> <v2>: A/B of an implementation switch on the other workloads
+# tools/ab_other_workloads.sh <option> <v1> <v2>: A/B of an implementation switch on the other workloads
 O=${1:-flood_gate}; A=${2:-50}; B=${3:-0}
 for w in sphere2500 ladybug-1723 venice-1778 synthetic-10k; do for g in $A $B $A $B; do
 timeout 300 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --opt $O=$g 2>/dev/null | python3 -c "
