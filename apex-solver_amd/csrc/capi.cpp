@@ -227,7 +227,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
     // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
     static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "dist_factor", "tree_sharding", "dist_selftest",
-                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side"};
+                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows"};
     if (h->s->has_structure())
         for (const char* k : structural)
             if (n == k) return APEXGPU_ERR_INVALID_STATE;
@@ -239,6 +239,8 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "flood_gate") h->s->set_gate_min(value);
     else if (n == "flood_gate_pos") h->s->set_gate_pos(value);
     else if (n == "two_side") h->s->set_two_side(value);
+    else if (n == "factor_flow") h->s->set_factor_flow(value, 0);          // max columns per level group inside the dataflow launch (0: off)
+    else if (n == "factor_flow_rows") h->s->set_factor_flow(h->s->plan().factor_flow_cols(), value);
     else if (n == "rec_backsub") h->s->set_rec_backsub(value != 0);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
@@ -300,7 +302,7 @@ int apexgpu_debug_pair_phases(int64_t out[8], int reset) {
 int apexgpu_counters(apexgpu_solver* h, int64_t out[4]) {
     H_OR_FAIL;
     if (!out) return APEXGPU_ERR_INVALID_INPUT;
-    out[0] = h->s->sweep_timeouts(); out[1] = h->s->plan().tri_flow() ? 1 : 0; out[2] = 0; out[3] = 0;
+    out[0] = h->s->sweep_timeouts(); out[1] = h->s->plan().tri_flow() ? 1 : 0; out[2] = h->s->factor_flow_timeouts(); out[3] = h->s->plan().factor_flow_groups();
     return APEXGPU_OK;
 }
 
@@ -538,6 +540,8 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     else if (n == "update_overlap") { h->s->enable_overlap(value != 0); if (value > 1) h->s->set_overlap_min(value); }
     else if (n == "tri_dataflow") h->s->enable_tri_flow(value != 0);
     else if (n == "two_side") h->s->set_two_side(value);
+    else if (n == "factor_flow") h->s->set_factor_flow(value, 0);
+    else if (n == "factor_flow_rows") h->s->set_factor_flow(h->s->plan().factor_flow_cols(), value);
     else if (n == "flood_gate") h->s->set_gate_min(value);
     else if (n == "split_u1") h->s->set_split_u1(value);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
@@ -557,7 +561,7 @@ int apexgpu_pg_stage_times(apexgpu_pg_solver* h, double ms[APEXGPU_PG_NUM_STAGES
 int apexgpu_pg_counters(apexgpu_pg_solver* h, int64_t out[4]) {
     PG_OR_FAIL;
     if (!out) return APEXGPU_ERR_INVALID_INPUT;
-    out[0] = h->s->sweep_timeouts(); out[1] = h->s->plan().tri_flow() ? 1 : 0; out[2] = 0; out[3] = 0;
+    out[0] = h->s->sweep_timeouts(); out[1] = h->s->plan().tri_flow() ? 1 : 0; out[2] = h->s->factor_flow_timeouts(); out[3] = h->s->plan().factor_flow_groups();
     return APEXGPU_OK;
 }
 int apexgpu_pg_info(apexgpu_pg_solver* h, double info[8]) {

@@ -282,9 +282,12 @@ __device__ __forceinline__ void blk_to_global(const double* __restrict__ src, do
 // NW waves per workgroup: wave 0 factorises the 16 x 16 diagonal block in registers while the other NW-1 waves do
 // the previous step's trailing update and one row of L^-1 -- with 4 waves those three take ~3 us per block step
 // against wave 0's ~1.2 us and are the critical path of the tile; 8 waves balance the two.
-#ifdef APEX_POTRF_TRACE
+#ifdef APEX_POTRF_TRACE   // tools/potrf_bench.hip: wall-clock stamps of workgroup 0 at the phase boundaries
 __device__ unsigned long long g_potrf_trace[64];
 __device__ int g_potrf_trace_n;
+#define POTRF_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_potrf_trace[g_potrf_trace_n++] = wall_clock64(); } while (0)
+#else
+#define POTRF_STAMP() do {} while (0)
 #endif
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_potrf_inv_la(const PotrfTask* __restrict__ tasks, int* __restrict__ fail,
@@ -292,11 +295,6 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_inv_la(const PotrfTask* __res
     constexpr int NT = 64 * NW;
     // (scheduling hint for k_gate: this workgroup has its CU; nothing depends on the counter for correctness)
     if (arrived != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef APEX_POTRF_TRACE   // tools/potrf_bench.hip: wall-clock stamps of workgroup 0 at the phase boundaries
-#define POTRF_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_potrf_trace[g_potrf_trace_n++] = wall_clock64(); } while (0)
-#else
-#define POTRF_STAMP() do {} while (0)
-#endif
     POTRF_STAMP();
     const PotrfTask pt = tasks[blockIdx.x];
     double* __restrict__ A = pt.A;
@@ -522,8 +520,307 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_inv_la(const PotrfTask* __res
     }
     if (tid == 0 && bad) atomicCAS(fail, 0, K + 1);
     POTRF_STAMP();
-#undef POTRF_STAMP
 }
+
+// ------------------------------------------------------------------------------------------
+// potrf + inverse, round 4 (default, "potrf_lookahead" 9): the same blocked schedule as k_potrf_inv_la with the serial part
+// -- wave 0's 16 x 16 Cholesky and the inverse of its factor -- rewritten for the matrix pipe.  The look-ahead kernel
+// spent 4.1 of its 5.4 us per block step there: lane r owned row r, so every one of the 16 pivots broadcast its column
+// through ~30 v_readlane (SGPR round trips) for the rank-1 update, and the inverse was a second pass of 16 steps.
+// Here the diagonal block lives in wave 0 as ONE MFMA accumulator (16 x 16 fp64 = 4 doubles per lane, element
+// [lk + 4 i][lr] in register i of lane (lr, lk)), kept SYMMETRIC, and a pivot step is
+//     d = D[j][j]                              one v_readlane pair (lane and register known at compile time)
+//     1/sqrt(d), sqrt(d)                       rsq + two Newton steps, wave-uniform
+//     row j of D scaled = column j of L        register j/4 of the lanes with lk == j%4 -- already where the MFMA wants
+//                                              operand column k = j%4 of A (rows) AND row k of B (columns): no lane moves
+//     D -= l l^T                               one v_mfma_f64_16x16x4 with the other three k-slices zero
+//     X -= l (row j of X)                      a second one: X = L^-1 by forward substitution rides along (X starts as I),
+// i.e. two matrix instructions and ~10 vector instructions per pivot instead of ~60; rows <= j see a zero operand and
+// keep their values, so D ends as L^T in its upper triangle.  Wave 0 then solves the panel block below the diagonal
+// block itself, TRANSPOSED (X N^T = L_(kb+1,kb)^T, whose accumulator registers are exactly the operand registers of
+// L L^T), and gives the next diagonal block this step's update in registers: between two block factorisations wave 0
+// touches LDS only to fetch N and the next D and to publish L / X for the other waves.
+// ------------------------------------------------------------------------------------------
+// Coherent tile accesses for the dataflow kernels: data produced by another workgroup of the SAME launch may sit in another
+// XCD's L2, so it is read and written at agent scope -- the sc1 bit, exactly what a relaxed agent-scope atomic compiles to
+// (flow_ld / flow_st below) -- but 16 bytes at a time, which the atomics cannot do: raw buffer loads / stores through a
+// descriptor of the tile (bounds = the tile, so a stray offset reads zero instead of faulting), cache policy sc1.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x2_t __attribute__((ext_vector_type(2)));
+constexpr int kCohAux = 16;   // gfx940+: bit 4 of the buffer instructions' cache-policy operand = sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t coh_rsrc(const void* tile) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tile), 0, NB * NB * (int)sizeof(double), 0x00020000);
+}
+template <bool COH>
+__device__ __forceinline__ double2 tile_ld2(const double* tile, __amdgpu_buffer_rsrc_t r, int off) {   // off: in doubles, even
+    if constexpr (COH) {
+        const i32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(r, off * 8, 0, kCohAux);
+        double2 v; v.x = __hiloint2double(q[1], q[0]); v.y = __hiloint2double(q[3], q[2]);
+        return v;
+    } else {
+        return *reinterpret_cast<const double2*>(tile + off);
+    }
+}
+template <bool COH>
+__device__ __forceinline__ void tile_st2(double* tile, __amdgpu_buffer_rsrc_t r, int off, double2 v) {
+    if constexpr (COH) {
+        i32x4_t q;
+        q[0] = __double2loint(v.x); q[1] = __double2hiint(v.x); q[2] = __double2loint(v.y); q[3] = __double2hiint(v.y);
+        __builtin_amdgcn_raw_buffer_store_b128(q, r, off * 8, 0, kCohAux);
+    } else {
+        *reinterpret_cast<double2*>(tile + off) = v;
+    }
+}
+__device__ __forceinline__ double coh_ld1(__amdgpu_buffer_rsrc_t r, int off) {
+    const i32x2_t q = __builtin_amdgcn_raw_buffer_load_b64(r, off * 8, 0, kCohAux);
+    return __hiloint2double(q[1], q[0]);
+}
+__device__ __forceinline__ void coh_st1(__amdgpu_buffer_rsrc_t r, int off, double v) {
+    i32x2_t q; q[0] = __double2loint(v); q[1] = __double2hiint(v);
+    __builtin_amdgcn_raw_buffer_store_b64(q, r, off * 8, 0, kCohAux);
+}
+template <bool COH>
+__device__ __forceinline__ void blk_to_tile(const double* __restrict__ src, double* __restrict__ dst_tile, __amdgpu_buffer_rsrc_t r,
+                                            int bi, int bj, int t, int nthreads) {
+    for (int idx = t; idx < 128; idx += nthreads) {   // 16 rows x 8 double2 per block
+        const int rr = idx >> 3, c2 = idx & 7;
+        double2 v; v.x = src[rr * BP + 2 * c2]; v.y = src[rr * BP + 2 * c2 + 1];
+        tile_st2<COH>(dst_tile, r, (16 * bi + rr) * NB + 16 * bj + 2 * c2, v);
+    }
+}
+
+__device__ __forceinline__ double4_t blk_load_cd_sym(const double* C, int lr, int lk) {   // lower triangle mirrored
+    double4_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = lk + 4 * r;
+        v[r] = row >= lr ? C[row * BP + lr] : C[lr * BP + row];
+    }
+    return v;
+}
+
+template <int NW, bool COH>
+__device__ __forceinline__ void potrf_tile_mf(double* __restrict__ A, double* __restrict__ Linv, int K, int* __restrict__ fail,
+                                              double* sA, double* sD, int* bad) {
+    constexpr int NT = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rA = coh_rsrc(A), rL = coh_rsrc(Linv);
+    if (tid == 0) *bad = 0;
+    {
+        constexpr int NREG = (128 * 45 + NT - 1) / NT + NBK;
+        double2 reg[NREG];
+        int n = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBK; ++bi) {
+            const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
+#pragma unroll
+            for (int it = 0; it < (16 * 8 * (bi + 1) + NT - 1) / NT; ++it, ++n) {
+                const int idx = tid + NT * it;
+                if (idx < cnt) {
+                    const int rr = idx / per_row, c2 = idx - rr * per_row;
+                    reg[n] = tile_ld2<COH>(A, rA, (16 * bi + rr) * NB + 2 * c2);
+                }
+            }
+        }
+        n = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBK; ++bi) {
+            const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
+#pragma unroll
+            for (int it = 0; it < (16 * 8 * (bi + 1) + NT - 1) / NT; ++it, ++n) {
+                const int idx = tid + NT * it;
+                if (idx < cnt) {
+                    const int rr = idx / per_row, c2 = idx - rr * per_row;
+                    double* dst = sA + bidx(bi, c2 >> 3) * BSZ + rr * BP + 2 * (c2 & 7);
+                    dst[0] = reg[n].x; dst[1] = reg[n].y;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    POTRF_STAMP();
+
+    double4_t Dm = (double4_t){0.0, 0.0, 0.0, 0.0};   // wave 0: the current diagonal block, symmetric, carried across the steps
+    if (w == 0) Dm = blk_load_cd_sym(sA, lr, lk);
+    for (int kb = 0; kb < NBK; ++kb) {
+        // ---------------- P1 ------------------------------------------------------------------------------
+        double4_t T[(NBK - 1 + NW - 2) / (NW - 1)];   // row kb-1 of L^-1: blocks j = (w-1), (w-1)+(NW-1), ... of waves 1..NW-1
+        if (w == 0) {
+            double4_t Xm;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xm[r] = (lk + 4 * r == lr) ? 1.0 : 0.0;
+            int isbad = 0;
+            double dnext = readlane_f64(Dm[0], 0);
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+                const int jr = j >> 2, jq = j & 3;
+                const double djj = dnext;
+                if (!(djj > 0.0)) isbad = 1;
+                const double dj = djj > 0.0 ? djj : 1.0;
+                double isj = __builtin_amdgcn_rsq(dj);
+                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
+                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
+                double sj = dj * isj;
+                sj = fma(0.5 * isj, fma(-sj, sj, dj), sj);
+                const bool row = lk == jq;
+                const double l = Dm[jr] * isj;                     // lanes of row j: L[lr][j]
+                if (j + 1 < BS) {
+                    // the NEXT pivot ahead of the update that produces it: D[j+1][j+1] - L[j+1][j]^2, so that its
+                    // 1/sqrt chain runs in the shadow of this step's matrix instructions instead of behind them
+                    const double dd = readlane_f64(Dm[(j + 1) >> 2], 16 * ((j + 1) & 3) + j + 1);
+                    const double lj1 = readlane_f64(l, 16 * jq + j + 1);
+                    dnext = fma(-lj1, lj1, dd);
+                }
+                const double a = (row && lr > j) ? l : 0.0;
+                const double xs = Xm[jr] * isj;                    // lanes of row j: X[j][lr] / L[j][j]
+                const double bx = row ? xs : 0.0;
+                Dm[jr] = row ? (lr > j ? l : (lr == j ? sj : Dm[jr])) : Dm[jr];
+                Xm[jr] = row ? xs : Xm[jr];
+                if (j + 1 < BS) {
+                    Dm = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, a, Dm, 0, 0, 0);
+                    Xm = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, bx, Xm, 0, 0, 0);
+                }
+            }
+            // Dm holds L^T on and above its diagonal: register i of lane (lr, lk) is L[lr][lk + 4 i]
+            double* D = sA + bidx(kb, kb) * BSZ;
+            double* Xs = sD + kb * BSZ;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = lk + 4 * r;
+                D[lr * BP + c] = lr >= c ? Dm[r] : 0.0;
+                Xs[c * BP + lr] = Xm[r];
+            }
+            if (isbad) *bad = 1;
+            POTRF_STAMP();
+        } else {
+            if (kb >= 1) {
+                const int ks = kb - 1;
+                // column kb below its diagonal block first (wave 0 reads block (kb+1, kb) right behind the barrier) ...
+                for (int i = kb + w; i < NBK; i += NW - 1) {
+                    double* Cb = sA + bidx(i, kb) * BSZ;
+                    double4_t acc = blk_load_cd(Cb, lr, lk);
+                    acc = blk_mma_nt(sA + bidx(i, ks) * BSZ, sA + bidx(kb, ks) * BSZ, acc, lr, lk, -1.0);
+                    blk_store_cd(Cb, acc, lr, lk, 1.0);
+                }
+                // ... then the rest of the trailing update of step ks: targets (i, j) with kb < j <= i
+                const int m = NBK - 1 - kb;
+                const int n_upd = m * (m + 1) / 2;
+                for (int t = w - 1; t < n_upd; t += NW - 1) {
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+                    const int jj = t - ii * (ii + 1) / 2;
+                    const int i = kb + 1 + ii, j = kb + 1 + jj;
+                    double* Cb = sA + bidx(i, j) * BSZ;
+                    double4_t acc = blk_load_cd(Cb, lr, lk);
+                    acc = blk_mma_nt(sA + bidx(i, ks) * BSZ, sA + bidx(j, ks) * BSZ, acc, lr, lk, -1.0);
+                    blk_store_cd(Cb, acc, lr, lk, 1.0);
+                }
+                // row r = ks of L^-1 from L~(r,.) and the rows above (kept in registers until the barrier)
+                const int r = ks;
+                int nt = 0;
+                for (int j = w - 1; j < r; j += NW - 1, ++nt) {
+                    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+                    for (int k = j; k < r; ++k) {
+                        const double* Y = (k == j) ? (sD + j * BSZ) : (sA + bidx(k, j) * BSZ);
+                        acc = blk_mma_nn(sA + bidx(r, k) * BSZ, Y, acc, lr, lk);
+                    }
+                    T[nt] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        POTRF_STAMP();
+        if (w > 0 && kb >= 1) {
+            const int r = kb - 1;
+            int nt = 0;
+            for (int j = w - 1; j < r; j += NW - 1, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
+        }
+        // ---------------- P2 ------------------------------------------------------------------------------
+        // tasks 0 .. m-1: panel blocks (kb+1+t, kb); tasks m .. m+kb-1: row block (kb, t-m) -> global, then L~.
+        // Wave 0 takes the panel block right below the diagonal (task 0) and nothing else; the other waves share the rest.
+        {
+            const int m = NBK - 1 - kb;
+            if (w == 0) {
+                if (m > 0) {
+                    // L_(kb+1,kb)^T = X N^T, so that register i of lane (lr, lk) is L[lr][lk + 4 i]: the operand of L L^T
+                    double* N = sA + bidx(kb + 1, kb) * BSZ;
+                    double4_t Lt = (double4_t){0.0, 0.0, 0.0, 0.0};
+                    Lt = blk_mma_nt(sD + kb * BSZ, N, Lt, lr, lk, 1.0);
+                    Dm = blk_load_cd_sym(sA + bidx(kb + 1, kb + 1) * BSZ, lr, lk);   // through step kb-1: the other waves' P1
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) N[lr * BP + lk + 4 * r] = Lt[r];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Dm = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lt[r], Lt[r], Dm, 0, 0, 0);
+                }
+            } else {
+                const int t0 = m > 0 ? 1 : 0;
+                for (int t = t0 + w - 1; t < m + kb; t += NW - 1) {
+                    if (t < m) {
+                        double* P = sA + bidx(kb + 1 + t, kb) * BSZ;
+                        double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+                        acc = blk_mma_nt(P, sD + kb * BSZ, acc, lr, lk, 1.0);
+                        blk_store_cd(P, acc, lr, lk, 1.0);
+                    } else {
+                        const int k = t - m;
+                        double* Bk = sA + bidx(kb, k) * BSZ;
+                        blk_to_tile<COH>(Bk, A, rA, kb, k, lane, 64);
+                        double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+                        acc = blk_mma_nn(sD + kb * BSZ, Bk, acc, lr, lk);
+                        blk_store_cd(Bk, acc, lr, lk, 1.0);  // same wave read it: LDS accesses of one wave stay in order
+                    }
+                }
+                if (w == NW - 1) blk_to_tile<COH>(sA + bidx(kb, kb) * BSZ, A, rA, kb, kb, lane, 64);  // the diagonal block of L
+            }
+        }
+        __syncthreads();
+        POTRF_STAMP();
+    }
+    // last row of L^-1 (r = NBK-1), all waves
+    {
+        const int r = NBK - 1;
+        double4_t T[(NBK - 1 + NW - 1) / NW];
+        int nt = 0;
+        for (int j = w; j < r; j += NW, ++nt) {
+            double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+            for (int k = j; k < r; ++k) {
+                const double* Y = (k == j) ? (sD + j * BSZ) : (sA + bidx(k, j) * BSZ);
+                acc = blk_mma_nn(sA + bidx(r, k) * BSZ, Y, acc, lr, lk);
+            }
+            T[nt] = acc;
+        }
+        __syncthreads();
+        nt = 0;
+        for (int j = w; j < r; j += NW, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int bi = 0; bi < NBK; ++bi) {
+        const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
+        for (int idx = tid; idx < cnt; idx += NT) {
+            const int rr = idx / per_row, c2 = idx - rr * per_row;
+            const int bj = c2 >> 3;
+            const double* src = ((bj == bi) ? (sD + bi * BSZ) : (sA + bidx(bi, bj) * BSZ)) + rr * BP + 2 * (c2 & 7);
+            double2 v; v.x = src[0]; v.y = src[1];
+            tile_st2<COH>(Linv, rL, (16 * bi + rr) * NB + 2 * c2, v);
+        }
+    }
+    if (tid == 0 && *bad) atomicCAS(fail, 0, K + 1);
+    POTRF_STAMP();
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_potrf_inv_mf(const PotrfTask* __restrict__ tasks, int* __restrict__ fail,
+                                                          int* __restrict__ arrived) {
+    if (arrived != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    POTRF_STAMP();
+    __shared__ double sA[NLB * BSZ];
+    __shared__ double sD[NBK * BSZ];
+    __shared__ int bad;
+    const PotrfTask pt = tasks[blockIdx.x];
+    potrf_tile_mf<NW, false>(pt.A, pt.Linv, pt.K, fail, sA, sD, &bad);
+}
+#undef POTRF_STAMP
 
 // ------------------------------------------------------------------------------------------
 // Batched 144^3 tile GEMM, NT form:  C = beta*C + alpha * A * B^T   (all row-major tiles).
@@ -1083,6 +1380,117 @@ __global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowTask* __
 }
 
 // ------------------------------------------------------------------------------------------
+// The TOP of the elimination tree as ONE dataflow launch (round 4; TilePlan::build_flow_units / enqueue_factor).
+// Up there a level is one or a few tile columns: potrf -> panel solves -> updates -> next potrf is a chain of dependent
+// launches (three per level plus their gaps: ~95 us per level for ~30 us of dependent work on final-13682, and the WHOLE
+// factorisation of the dense BAL shapes and of sphere2500).  Here every potrf, every 48-row strip of a panel solve and
+// of an update is one workgroup of a single launch; a workgroup waits for its inputs on per-tile version counters
+// (ver[slot] += 1 per finished strip, += 3 by a potrf; the n-th writer of a tile waits for 3 n) and publishes its own.
+// Units are listed in LEFT-LOOKING order -- per tile column: the updates into it (per target in source order, the same
+// summation order as the level launches: results are bit-identical), its potrf, its panel solves -- so a unit waits only
+// for units EARLIER in the list; workgroups are dispatched in blockIdx order, hence no deadlock whatever the residency
+// (the argument of the dataflow sweeps above), and the columns ahead of the critical one are already resident and take
+// whatever updates their sources allow: look-ahead for free.  One 576-thread workgroup per CU (the potrf's 124 KB of LDS).
+// Everything a unit reads was written inside this launch, possibly through another XCD's L2: tile_ld2 / coh_* (sc1).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flow_wait_ge(const int* ver, int flag, int want, int tid, int* err) {
+    if (flag >= 0) flow_wait(ver + flag, want, tid, err);   // (wave-uniform branch: the unit record)
+}
+
+__device__ __forceinline__ void flow_gemm_unit(const FactorUnit& u, double* __restrict__ sA, double* __restrict__ sB,
+                                               int* __restrict__ ver, int* __restrict__ err) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int wr = w / 3, wc = w % 3;   // wave: rows 16 wr .. of the strip, columns 48 wc .. (three 16-wide accumulators)
+    const bool solve = u.kind == 1;
+    const __amdgpu_buffer_rsrc_t rC = coh_rsrc(u.C), rA = coh_rsrc(u.A), rB = coh_rsrc(u.B);
+    const int row0 = 48 * u.strip;
+    // (1) the previous writer of the target: the old values of the strip are requested first and consumed last
+    flow_wait_ge(ver, u.wait_flag[0], u.wait_val[0], tid, err);
+    double cv[3][4];
+    if (!solve) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[j][r] = coh_ld1(rC, (row0 + 16 * wr + lk + 4 * r) * NB + 48 * wc + 16 * j + lr);
+    }
+    // (2) the operands are final: ALL of K requested at once (one round trip instead of three), staged chunk by chunk
+    flow_wait_ge(ver, u.wait_flag[1], u.wait_val[1], tid, err);
+    flow_wait_ge(ver, u.wait_flag[2], u.wait_val[2], tid, err);
+    constexpr int C2 = KS / 2, NCH = NB / KS, NRA = 48 * C2 / 576, NRB = NB * C2 / 576;   // per chunk: 2 and 6 double2 per thread
+    static_assert(48 * C2 % 576 == 0 && NB * C2 % 576 == 0 && NB % KS == 0, "staging loops assume whole rounds");
+    double2 ra[NCH][NRA], rb[NCH][NRB];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            ra[c][i] = tile_ld2<true>(u.A, rA, (row0 + row) * NB + KS * c + 2 * c2);
+        }
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            rb[c][i] = tile_ld2<true>(u.B, rB, row * NB + KS * c + 2 * c2);
+        }
+    }
+    double4_t acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            sA[row * PS + 2 * c2] = ra[c][i].x; sA[row * PS + 2 * c2 + 1] = ra[c][i].y;
+        }
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            sB[row * PS + 2 * c2] = rb[c][i].x; sB[row * PS + 2 * c2 + 1] = rb[c][i].y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KS; kk += 4) {
+            const double a = sA[(16 * wr + lr) * PS + kk + lk];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double b = sB[(48 * wc + 16 * j + lr) * PS + kk + lk];
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // (the panel solve is in place: every read of the strip's rows happened above, and the other strips' rows are not ours)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = solve ? acc[j][r] : -1.0 * acc[j][r] + 1.0 * cv[j][r];
+            coh_st1(rC, (row0 + 16 * wr + lk + 4 * r) * NB + 48 * wc + 16 * j + lr, v);
+        }
+    flow_publish(ver + u.pub, tid);
+}
+
+constexpr int kFlowFactorThreads = 576;
+__global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const FactorUnit* __restrict__ units, int* __restrict__ ver,
+                                                                     int* __restrict__ fail, int* __restrict__ err) {
+    __shared__ double smem[(NLB + NBK) * BSZ];   // potrf: the tile's 45 lower blocks + 9 inverted diagonal blocks; product: sA | sB
+    __shared__ int bad;
+    static_assert((48 + NB) * PS <= (NLB + NBK) * BSZ, "the product's staging area fits in the potrf's");
+    const FactorUnit u = units[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (u.kind == 0) {
+        flow_wait_ge(ver, u.wait_flag[0], u.wait_val[0], tid, err);
+        potrf_tile_mf<kFlowFactorThreads / 64, true>(u.C, const_cast<double*>(u.A), u.strip, fail, smem, smem + NLB * BSZ, &bad);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ver + u.pub, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        flow_gemm_unit(u, smem, smem + 48 * PS, ver, err);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Symmetric tile matvec for the PCG variant, two deterministic passes (no atomics):
 //   k_sym_tile_products: one workgroup per STRUCTURALLY NON-ZERO tile (I,J) of S reads the tile ONCE
 //       (two 72-row halves through LDS) and writes u = A x_J and, off the diagonal, v = A^T x_I
@@ -1333,7 +1741,7 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const 
 }
 
 // ------------------------------------------------------------------------------------------
-static int g_potrf_lookahead = 8;   // 0: k_potrf_inv; 1: look-ahead kernel with 4 waves; 6 / 8 (default): with 6 / 8 waves
+static int g_potrf_lookahead = 9;   // 0: k_potrf_inv; 1 / 6 / 8: look-ahead kernel (round 3) with 4 / 6 / 8 waves; 9 (default): matrix-pipe form, 8 waves
 void set_potrf_lookahead(int mode) { g_potrf_lookahead = mode; }
 // The flood gate (TilePlan::enqueue_factor): one lane that ends when `expected` potrf workgroups have announced themselves
 // in *arrived, or after max_ticks of the 100 MHz clock -- a scheduling hint in front of the bulk updates of a level, so
@@ -1348,9 +1756,14 @@ __global__ __launch_bounds__(64) void k_gate(const int* __restrict__ arrived, in
 void launch_gate(const int* arrived, int expected, int max_micros, hipStream_t s) {
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, arrived, expected, (long long)max_micros * 100);
 }
+void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, hipStream_t s) {
+    if (n_units <= 0) return;
+    hipLaunchKernelGGL(k_factor_flow, dim3(n_units), dim3(kFlowFactorThreads), 0, s, units, ver, fail, err);
+}
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s, int* arrived) {
     if (n <= 0) return;
-    if (g_potrf_lookahead == 1) hipLaunchKernelGGL(k_potrf_inv_la<4>, dim3(n), dim3(256), 0, s, tasks, fail, arrived);
+    if (g_potrf_lookahead == 9) hipLaunchKernelGGL(k_potrf_inv_mf<8>, dim3(n), dim3(512), 0, s, tasks, fail, arrived);
+    else if (g_potrf_lookahead == 1) hipLaunchKernelGGL(k_potrf_inv_la<4>, dim3(n), dim3(256), 0, s, tasks, fail, arrived);
     else if (g_potrf_lookahead == 6) hipLaunchKernelGGL(k_potrf_inv_la<6>, dim3(n), dim3(384), 0, s, tasks, fail, arrived);
     else if (g_potrf_lookahead) hipLaunchKernelGGL(k_potrf_inv_la<8>, dim3(n), dim3(512), 0, s, tasks, fail, arrived);
     else hipLaunchKernelGGL(k_potrf_inv, dim3(n), dim3(256), 0, s, tasks, fail);

@@ -60,6 +60,8 @@ class PoseGraphSolver : public LmBackend {
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
     void set_two_side(int mode) { tp_.set_two_side(mode); }
+    void set_factor_flow(int max_cols, int max_rows) { tp_.set_factor_flow(max_cols, max_rows); }
+    int factor_flow_timeouts() const { return n_factor_flow_timeouts_; }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void enable_stage_timing(bool on) { timer_.enable(on); }
@@ -97,6 +99,7 @@ class PoseGraphSolver : public LmBackend {
     double *poses_[2] = {nullptr, nullptr}, *posep_[2] = {nullptr, nullptr};
     uint32_t *e_from_ = nullptr, *e_to_ = nullptr;
     int n_prior_ = 0;
+    int n_factor_flow_timeouts_ = 0;
     uint32_t* prior_v_ = nullptr;
     double* prior_data_ = nullptr;
     double* meas_ = nullptr;

@@ -236,6 +236,16 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
     timer_.begin(kPgFactor, stream_);
     int failed = 0;
     HIP_TRY(tp_.factor(&failed, rhs_, work_));  // the forward sweep rides along
+    if (tp_.factor_flow_gave_up()) {
+        // the dataflow launch of the top groups timed out (the plan is back on the level launches): H is half updated
+        timer_.end(kPgFactor, stream_);
+        ++n_factor_flow_timeouts_;
+        rc = assemble(lambda);
+        if (rc != kOk) return rc;
+        timer_.begin(kPgFactor, stream_);
+        HIP_TRY(tp_.factor(&failed, rhs_, work_));
+        if (tp_.factor_flow_gave_up()) return fail(kDeviceError, "dataflow factorisation timed out twice");
+    }
     timer_.end(kPgFactor, stream_);
     if (failed) return fail(kSingularMatrix, "Cholesky factorization failed (matrix may be singular)");
     for (int attempt = 0;; ++attempt) {

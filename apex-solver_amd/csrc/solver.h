@@ -98,6 +98,8 @@ class Solver : public LmBackend {
     void set_gate_min(int n) { tp_.set_gate_min(n); }
     void set_gate_pos(int p) { tp_.set_gate_pos(p); }
     void set_two_side(int mode) { tp_.set_two_side(mode); }
+    void set_factor_flow(int max_cols, int max_rows) { tp_.set_factor_flow(max_cols, max_rows); }
+    int factor_flow_timeouts() const { return n_factor_flow_timeouts_; }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void use_row_schur(int v) { use_rows_ = v != 0; if (v) rows_form_ = v; }
     bool has_structure() const { return have_structure_; }
@@ -147,6 +149,8 @@ class Solver : public LmBackend {
     int column_norms_sq_device();   // -> n2 in cam_scale_ / pt_scale_ (camera part all-reduced over the shards)
     int factor_and_solve(double lambda);
     int cholesky_attempt(int* failed_at);
+    int cholesky_on_fresh_s(double lambda, double reg, int* failed_at);
+    int n_factor_flow_timeouts_ = 0;
     int tri_solve();
     int pcg_solve();
     int cost_of(int which, double* out);

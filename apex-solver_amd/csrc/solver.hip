@@ -516,6 +516,20 @@ int Solver::cholesky_attempt(int* failed_at) {
     return kOk;
 }
 
+// cholesky_attempt on the S that assemble(lambda, reg, true) has just built.  Should the dataflow launch of the top groups
+// time out (TilePlan::factor_flow_gave_up: the tiles are half updated and the plan has gone back to the level launches, in a
+// distributed plan on every rank alike), S is built again and factorised once more.
+int Solver::cholesky_on_fresh_s(double lambda, double reg, int* failed_at) {
+    int rc = cholesky_attempt(failed_at);
+    if (rc != kOk || !tp_.factor_flow_gave_up()) return rc;
+    ++n_factor_flow_timeouts_;
+    rc = assemble(lambda, reg, true);
+    if (rc != kOk) return rc;
+    rc = cholesky_attempt(failed_at);
+    if (rc == kOk && tp_.factor_flow_gave_up()) return fail(kDeviceError, "dataflow factorisation timed out twice");
+    return rc;
+}
+
 int Solver::tri_solve() {
     stage_begin(kStTriSolve);
     const hipError_t se = tp_.solve(g_red_, dcam_, pcg_buf_);
@@ -529,7 +543,7 @@ int Solver::tri_solve() {
 int Solver::factor_and_solve(double lambda) {
     int failed = 0;
     last_reg_ = 0.0;
-    int rc = cholesky_attempt(&failed);
+    int rc = cholesky_on_fresh_s(lambda, 0.0, &failed);
     if (rc != kOk) return rc;
     if (!failed) return tri_solve();
     // the factorisation overwrote S: re-assemble it to read trace and max |diag| (:563-579)
@@ -551,7 +565,7 @@ int Solver::factor_and_solve(double lambda) {
         const double reg = base * pow(10.0, (double)(attempt - 4));
         rc = assemble(lambda, reg, true);
         if (rc != kOk) return rc;
-        rc = cholesky_attempt(&failed);
+        rc = cholesky_on_fresh_s(lambda, reg, &failed);
         if (rc != kOk) return rc;
         if (!failed) { last_reg_ = reg; return tri_solve(); }
     }

@@ -95,6 +95,16 @@ class TilePlan {
     void set_two_side(int mode) { two_side_ = mode; }   // 0 off, 1 by plan size (default), 2 always (tests); before build()
     void set_gate_pos(int p) { gate_pos_ = p; }   // 0: in front of U2a, 1: between U2a and U2b
     void set_gate_min(int n) { gate_min_ = n; }   // flood gate in front of U2 batches of at least n tasks (0: off); before the first factor()
+    // The top of the elimination tree as one dataflow launch (k_factor_flow): the trailing level groups of a phase whose
+    // groups have at most max_cols columns each, every column with at most max_rows off-diagonal tiles.  0 columns: off.
+    // Before build().
+    void set_factor_flow(int max_cols, int max_rows) { flow_cols_ = max_cols; if (max_rows > 0) flow_rows_ = max_rows; }
+    int factor_flow_groups() const { return (flow_g1_[0] - flow_g0_[0]) + (flow_g1_[1] - flow_g0_[1]); }   // level groups inside the dataflow launches
+    int factor_flow_cols() const { return flow_cols_; }
+    int factor_flow_units() const { return flow_n_[0] + flow_n_[1]; }
+    // A dataflow factorisation whose waits ran into their spin limit leaves the tiles half updated: factor() reports it here
+    // (once) and the plan goes back to the level launches for good; the caller re-assembles and factorises again.
+    bool factor_flow_gave_up() { const bool g = flow_gave_up_; flow_gave_up_ = false; return g; }
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
     hipError_t read_flags(int* failed_at);   // pivot flag of the last factorisation (syncs)
     void enable_tri_flow(bool on);   // triangular sweeps as one dataflow launch each (default) or level by level
@@ -189,6 +199,12 @@ class TilePlan {
     int poison_ = 0;
     hipStream_t occ_stream_ = nullptr;
     void post_sweep_status(bool reduce);
+    FactorUnit* flow_units_ = nullptr;   // dataflow factorisation of the top groups: [phase 0 units | phase 1 units]
+    int* flow_ver_ = nullptr;            // per tile slot: finished strips of in-launch writers
+    int flow_cols_ = 6, flow_rows_ = 24;
+    int flow_g0_[2] = {0, 0}, flow_g1_[2] = {0, 0};   // per phase (local groups / top groups): the groups inside the launch
+    int flow_first_[2] = {0, 0}, flow_n_[2] = {0, 0};
+    bool flow_on_ = true, flow_gave_up_ = false;
     int n_flow_tasks_ = 0, n_flow_bwd_ = 0, n_flow_parts_ = 0;
     int n_flow_local_ = 0;   // distributed plans: the forward tasks of phase 0 (the rest: the top columns, phase 1)
     bool tri_flow_ = true;

@@ -99,13 +99,14 @@ std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool 
 
 void TilePlan::release() {
     void* ptrs[] = {tiles_, linv_, slot_, diag_slot_, flag_, potrf_tasks_, trsm_tasks_, upd_tasks_, tri_fwd_, tri_bwd_,
-                    flow_fwd_, flow_bwd_, flow_part_, flow_flags_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_, gate_cnt_};
+                    flow_fwd_, flow_bwd_, flow_part_, flow_flags_, flow_units_, flow_ver_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_, gate_cnt_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = exch_ = nullptr;
     slot_ = diag_slot_ = flag_ = sym_row_ptr_ = cls_ = nullptr;
     potrf_tasks_ = nullptr; trsm_tasks_ = upd_tasks_ = nullptr; tri_fwd_ = tri_bwd_ = nullptr;
     flow_fwd_ = flow_bwd_ = nullptr; flow_part_ = nullptr; flow_flags_ = nullptr; n_flow_tasks_ = 0;
+    flow_units_ = nullptr; flow_ver_ = nullptr; flow_n_[0] = flow_n_[1] = 0; flow_on_ = true; flow_gave_up_ = false;
     sym_tiles_ = nullptr; sym_entries_ = nullptr;
     gate_cnt_ = nullptr;
     for (int i = 0; i < kGraphs; ++i) {
@@ -526,6 +527,80 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     // levels are small and the factorisation is its launch chain (the ladybug / venice shapes, ~100 products per level: one
     // more stream is one more edge per level, 3.1 -> 3.5 ms).
     two_side_plan_ = two_side_ == 2 || (two_side_ == 1 && n_upd_ >= 256 * (int64_t)n_levels_);
+    // ---- the trailing level groups of each phase as ONE dataflow launch (k_factor_flow, chol_kernels.hip) ----------------
+    // Units in left-looking order: per column of the region the updates into its tiles (per target in source order = the
+    // order of the level launches), its potrf, its panel solves; last the updates into tiles whose column is outside
+    // the launch (the local phase of a distributed plan adding to the shared top).  `running` replays the version
+    // counters: a unit may only wait for what EARLIER units publish (the no-deadlock argument), checked here.
+    std::vector<FactorUnit> funits;
+    for (int ph = 0; ph < 2; ++ph) {
+        const int g0 = ph == 0 ? 0 : n_local_groups_, g1 = ph == 0 ? n_local_groups_ : n_levels_;
+        flow_g0_[ph] = flow_g1_[ph] = g1; flow_first_[ph] = (int)funits.size(); flow_n_[ph] = 0;
+        if (flow_cols_ <= 0 || g1 <= g0) continue;
+        int gf = g1;
+        while (gf > g0) {
+            const std::vector<int>& cols = level_cols[gf - 1];
+            bool ok = (int)cols.size() <= flow_cols_;
+            for (int K : cols) ok = ok && (int)col_rows[K].size() <= flow_rows_;
+            if (!ok) break;
+            --gf;
+        }
+        if (g1 - gf < 2) continue;   // a single group has nothing to chain
+        std::vector<int> cols;
+        std::vector<char> in_reg(nt_, 0);
+        for (int g = gf; g < g1; ++g)
+            for (int K : level_cols[g]) { cols.push_back(K); in_reg[K] = 1; }
+        auto slot_of = [&](int I, int J) { return slot_h_[(size_t)I * nt_ + J]; };
+        std::vector<std::vector<int>> src_of((size_t)n_slots_);
+        std::vector<std::pair<int, int>> outside;   // (J, I) of targets whose column is not in the launch
+        for (int K : cols) {
+            const auto& rows = col_rows[K];
+            for (size_t a = 0; a < rows.size(); ++a)
+                for (size_t b = 0; b <= a; ++b) {
+                    std::vector<int>& v = src_of[(size_t)slot_of(rows[a], rows[b])];
+                    if (v.empty() && !in_reg[rows[b]]) outside.push_back({rows[b], rows[a]});
+                    v.push_back(K);
+                }
+        }
+        std::sort(outside.begin(), outside.end());
+        std::vector<int> running((size_t)n_slots_, 0);
+        bool order_ok = true;
+        auto emit = [&](FactorUnit u, int inc) {
+            for (int q = 0; q < 3; ++q)
+                if (u.wait_flag[q] >= 0 && running[(size_t)u.wait_flag[q]] < u.wait_val[q]) order_ok = false;
+            funits.push_back(u);
+            running[(size_t)u.pub] += inc;
+        };
+        auto n_upd_of = [&](int st) { return (int)src_of[(size_t)st].size(); };
+        auto emit_updates = [&](int I, int J) {
+            const int st = slot_of(I, J);
+            for (int n = 0; n < n_upd_of(st); ++n) {
+                const int K = src_of[(size_t)st][n], sa = slot_of(I, K), sb = slot_of(J, K);
+                for (int sp = 0; sp < 3; ++sp)
+                    emit(FactorUnit{tile_ptr(I, J), tile_ptr(I, K), tile_ptr(J, K), {n > 0 ? st : -1, sa, sb},
+                                    {3 * n, 3 * (n_upd_of(sa) + 1), 3 * (n_upd_of(sb) + 1)}, st, 2, sp, 0}, 1);
+            }
+        };
+        for (int J : cols) {
+            const int sd = slot_of(J, J), nd = n_upd_of(sd);
+            emit_updates(J, J);
+            for (int I : col_rows[J]) emit_updates(I, J);
+            emit(FactorUnit{tile_ptr(J, J), linv_ptr(J), nullptr, {nd > 0 ? sd : -1, -1, -1}, {3 * nd, 0, 0}, sd, 0, J, 0}, 3);
+            for (int I : col_rows[J]) {
+                const int st = slot_of(I, J), n = n_upd_of(st);
+                for (int sp = 0; sp < 3; ++sp)
+                    emit(FactorUnit{tile_ptr(I, J), tile_ptr(I, J), linv_ptr(J), {n > 0 ? st : -1, -1, sd}, {3 * n, 0, 3 * (nd + 1)}, st, 1, sp, 0}, 1);
+            }
+        }
+        for (const auto& t : outside) emit_updates(t.second, t.first);
+        if (!order_ok) return "internal error: a dataflow factorisation unit waits for a later one";
+        flow_g0_[ph] = gf;
+        flow_n_[ph] = (int)funits.size() - flow_first_[ph];
+    }
+    TP_TRY(upload(&flow_units_, funits));
+    if (flow_ver_) { (void)hipFree(flow_ver_); flow_ver_ = nullptr; }
+    TP_TRY(dev_alloc(&flow_ver_, (size_t)n_slots_));
+    TP_TRY(hipMemset(flow_ver_, 0, (size_t)std::max<int64_t>(n_slots_, 1) * sizeof(int)));
     n_sym_tiles_ = (int)symt.size();
     TP_TRY(upload(&sym_tiles_, symt));
     TP_TRY(alloc_zero(&sym_part_, (size_t)n_slots_ * 2 * kNB));
@@ -638,6 +713,10 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     // runs on a third stream beside the trailing updates -- a chain of tiny latency-bound launches that costs
     // nothing there.  solve() then starts at the backward sweep.
     const bool fwd = rhs != nullptr && work != nullptr && fwd_ != nullptr && !distributed();
+    // the trailing groups [gf, g1) of this phase run as one dataflow launch behind the level launches (build())
+    const int ph = (g0 == n_local_groups_ && g1 == n_levels_ && n_local_groups_ < n_levels_) ? 1 : 0;
+    const int g_end = g1;
+    if (flow_on_ && !fwd && flow_n_[ph] > 0 && flow_g0_[ph] >= g0 && flow_g1_[ph] == g1) g1 = flow_g0_[ph];
     double* bvec = work;
     double* yvec = work ? work + n_pad() : nullptr;
     if (fwd) (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
@@ -671,6 +750,21 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         if (two && lv > g0 && u2_pending_[lv - 1]) {
             (void)hipStreamWaitEvent(stream_, ev_u2_[lv - 1], 0);
             if (has_o) (void)hipStreamWaitEvent(so_, ev_u2_[lv - 1], 0);
+        } else if (two && lv > g0) {
+            // Level lv-1 put nothing on the side streams, so there is no ev_u2_[lv-1] to carry "every older side-stream update
+            // precedes U1(lv)": U2b1(lv-2) [targets in level lv+1, stream A] and the U2b2 of levels <= lv-3 [stream B] may
+            // still be at work on the tiles U1(lv) is about to update (and that potrf(lv+1) then reads).  Levels are assigned
+            // by height, so a chain can pass through such a level.  Wait for both side streams outright.
+            if (last_a >= 0) {
+                (void)hipStreamWaitEvent(stream_, ev_b_[last_a], 0);
+                if (has_o) (void)hipStreamWaitEvent(so_, ev_b_[last_a], 0);
+                last_a = -1;
+            }
+            if (last_b >= 0) {
+                (void)hipStreamWaitEvent(stream_, ev_b2_[last_b], 0);
+                if (has_o) (void)hipStreamWaitEvent(so_, ev_b2_[last_b], 0);
+                last_b = -1;
+            }
         }
         for (int r = r0; r < rd; ++r)   // U1d: what the next potrf needs
             launch_tile_gemm_nt(upd_tasks_ + upd_rounds_[r].first, (int)upd_rounds_[r].second, -1.0, 1.0, stream_);
@@ -726,6 +820,10 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     if (fwd) {
         (void)hipEventRecord(ev_fwd_, fwd_);
         (void)hipStreamWaitEvent(stream_, ev_fwd_, 0);
+    }
+    if (g1 < g_end) {   // every update the level launches add to the region's tiles is in: the joins above
+        (void)hipMemsetAsync(flow_ver_, 0, (size_t)n_slots_ * sizeof(int), stream_);
+        launch_factor_flow(flow_units_ + flow_first_[ph], flow_n_[ph], flow_ver_, flag_, flag_ + 1, stream_);
     }
 }
 
@@ -850,7 +948,7 @@ hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
         for (int i = 0; i < 2; ++i)
             if (rg[i].second > 0 && !comm_.sum(tiles_ + (size_t)rg[i].first * te, (size_t)rg[i].second * te, stream_)) return hipErrorUnknown;
         factor_phase(1);
-        if (!comm_.max_int(flag_, 1, stream_)) return hipErrorUnknown;  // a failed pivot anywhere fails the factorisation everywhere
+        if (!comm_.max_int(flag_, 2, stream_)) return hipErrorUnknown;  // a failed pivot (or a dataflow time-out) anywhere fails the factorisation everywhere
         return read_flags(failed_at);
     }
     if (!fuse_forward_) { rhs = nullptr; work = nullptr; }
@@ -862,11 +960,20 @@ hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
 // The pivot flag of this factorisation.  (The error word of the dataflow sweeps belongs to the SOLVE that ran them:
 // post_sweep_status / sweep_timed_out.)
 hipError_t TilePlan::read_flags(int* failed_at) {
-    int f = 0;
-    hipError_t e = hipMemcpyAsync(&f, flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
+    int f[2] = {0, 0};   // [0] first failed tile column + 1, [1] error word of the dataflow factorisation (k_factor_flow)
+    hipError_t e = hipMemcpyAsync(f, flag_, sizeof f, hipMemcpyDeviceToHost, stream_);
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(stream_);
-    *failed_at = f;
+    *failed_at = f[0];
+    if (e == hipSuccess && f[1] != 0) {
+        // a unit gave up waiting (flow_wait's spin limit): the tiles are half updated.  Back to the level launches for the
+        // rest of the plan's life; the caller re-assembles and factorises again (factor_flow_gave_up()).
+        flow_gave_up_ = true;
+        flow_on_ = false;
+        for (int which : {0, 3})
+            if (graph_exec_[which]) { (void)hipGraphExecDestroy(graph_exec_[which]); graph_exec_[which] = nullptr; }
+        (void)hipMemsetAsync(flag_ + 1, 0, sizeof(int), stream_);
+    }
     return e;
 }
 

@@ -332,7 +332,7 @@ class GpuSparseCholeskySolver:
     def counters(self) -> dict:
         h = self._need(); out = (C.c_int64 * 4)()
         h.check(h.L.apexgpu_pg_counters(h.h, C.byref(out)))
-        return dict(sweep_timeouts=int(out[0]), tri_dataflow=bool(out[1]))
+        return dict(sweep_timeouts=int(out[0]), tri_dataflow=bool(out[1]), factor_flow_timeouts=int(out[2]), factor_flow_groups=int(out[3]))
 
     def enable_stage_timing(self, on=True): h = self._need(); h.check(h.L.apexgpu_pg_enable_stage_timing(h.h, int(on)))
     def reset_stage_times(self): h = self._need(); h.check(h.L.apexgpu_pg_reset_stage_times(h.h))

@@ -414,7 +414,7 @@ class GpuSchurComplementSolver:
         """Events of this handle's life: dataflow triangular sweeps that timed out and were repeated level by level."""
         h = self._need(); out = (C.c_int64 * 4)()
         h.check(h.L.apexgpu_counters(h.h, C.byref(out)))
-        return dict(sweep_timeouts=int(out[0]), tri_dataflow=bool(out[1]))
+        return dict(sweep_timeouts=int(out[0]), tri_dataflow=bool(out[1]), factor_flow_timeouts=int(out[2]), factor_flow_groups=int(out[3]))
 
     def setup_times(self) -> dict:
         """Wall time of initialize_structure by phase (seconds) and the counts that go with it."""

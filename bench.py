@@ -90,8 +90,11 @@ def usable_cores():
     return n
 
 
-def cpu_baseline_worker(workload, shape_scale, mode):
-    """Runs in a child process (OMP_NUM_THREADS / OMP_PROC_BIND set by the parent): 2 LM iterations of the oracle."""
+def cpu_baseline_worker(workload, shape_scale, mode, dense_too=True):
+    """Runs in a child process (OMP_NUM_THREADS / OMP_PROC_BIND set by the parent): 2 LM iterations of the oracle with the
+    SPARSE solve -- S sparsified at 1e-12 and factorised inside the envelope of a fill-reducing order, the reference's
+    solve_with_cholesky contract (explicit_schur.rs:913-921, 544-550) -- and, beside it, one iteration with the dense LL^T
+    that round 1-3 timed (it overstated the reference's cost on banded shapes)."""
     import apex_solver_amd as pkg
     from oracle import oracle as ora
 
@@ -99,29 +102,43 @@ def cpu_baseline_worker(workload, shape_scale, mode):
     d = pkg.datasets.load_named(workload, shape_scale)[0]
     lay = pkg.layout.reference_column_layout(d.n_cam, d.n_pt)
     o = ora.from_data(d, lay, mode=mode, native=True)
-    cost = o.residuals()[0]
-    t0 = time.perf_counter()
-    n_it = 0
-    lam = 1e-3
-    while n_it < 2:
-        o.linearize()
-        step, grad = o.solve_augmented(lam, 0)
-        o.apply_step(step, 1.0)
-        new_cost = o.residuals()[0]
-        if new_cost < cost:
-            cost = new_cost
-            lam = max(lam / 3.0, 1e-12)
-        else:
-            o.apply_step(step, -1.0)
-            lam *= 2.0
-        n_it += 1
-    ms = (time.perf_counter() - t0) * 1e3 / n_it
-    return {
-        "value": ms, "unit": "ms per LM iter on the sample", "cores": cores, "kind": "port",
+
+    def iterate(variant, n_iter):
+        cost = o.residuals()[0]
+        lam, t_solve = 1e-3, 0.0
+        t0 = time.perf_counter()
+        for _ in range(n_iter):
+            o.linearize()
+            t1 = time.perf_counter()
+            step, grad = o.solve_augmented(lam, variant)
+            t_solve += time.perf_counter() - t1
+            o.apply_step(step, 1.0)
+            new_cost = o.residuals()[0]
+            if new_cost < cost:
+                cost = new_cost
+                lam = max(lam / 3.0, 1e-12)
+            else:
+                o.apply_step(step, -1.0)
+                lam *= 2.0
+        return (time.perf_counter() - t0) * 1e3 / n_iter, t_solve * 1e3 / n_iter
+
+    p0 = o.get_params()
+    ms, ms_solve = iterate(3, 2)
+    stats = o.last_sparse_stats()
+    out = {
+        "value": ms, "unit": "ms per LM iter on the sample", "cores": cores, "kind": "port", "solve": "sparse",
         "sample": f"{d.name}: {d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations, "
-                  f"{2} LM iterations of oracle/ba_oracle.c (linearise + explicit dense Schur + dense Cholesky + trial cost)",
+                  f"{2} LM iterations of oracle/ba_oracle.c (linearise + explicit Schur into a dense S + sparsify at 1e-12 + "
+                  f"envelope Cholesky in reverse Cuthill-McKee order + trial cost)",
         "obs_per_s": d.n_obs / (ms * 1e-3),
+        "solve_ms": ms_solve,   # H = J^T J, Schur complement, factorisation, back-substitution
+        "sparse_s": dict(stats, n=o.cam_dof),
     }
+    if dense_too:
+        o.set_params(*p0)
+        dms, dsolve = iterate(0, 1)
+        out["dense_solve"] = {"value": dms, "solve_ms": dsolve, "note": "the same iteration with a DENSE LL^T of S (rounds 1-3's baseline)"}
+    return out
 
 
 def cpu_baseline(args, shape_scale, mode, full_size):
@@ -139,17 +156,17 @@ def cpu_baseline(args, shape_scale, mode, full_size):
 
     cores = usable_cores()
 
-    def run(threads, sc):
+    def run(threads, sc, dense_too=False):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false", OMP_WAIT_POLICY="passive", OMP_DYNAMIC="false")
         code = (f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; "
-                f"print('CPUBASE ' + json.dumps(bench.cpu_baseline_worker({args.workload!r}, {sc!r}, {mode!r})))")
+                f"print('CPUBASE ' + json.dumps(bench.cpu_baseline_worker({args.workload!r}, {sc!r}, {mode!r}, {dense_too!r})))")
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
         line = [l for l in p.stdout.splitlines() if l.startswith("CPUBASE ")]
         if not line:
             raise RuntimeError(p.stderr[-500:])
         return json.loads(line[0][8:])
 
-    out = run(min(cores, 32), shape_scale)
+    out = run(min(cores, 32), shape_scale, True)
     out["usable_cores"] = cores
     out["hardware_threads"] = os.cpu_count() or 1
     if full_size:
@@ -157,7 +174,7 @@ def cpu_baseline(args, shape_scale, mode, full_size):
     else:
         out["sample"] += (f"; a SAMPLE of the same generator: {args.workload} itself is beyond the reference's CPU path, which forms S as a"
                           " dense n_c x n_c matrix (explicit_schur.rs:782) -- 121 GB at 13,682 cameras x 9 DOF")
-    keep = ("value", "unit", "cores", "sample", "obs_per_s")
+    keep = ("value", "unit", "cores", "sample", "obs_per_s", "solve", "solve_ms")
     third = shape_scale / 3.0 if not full_size else shape_scale / 6.0
     out["one_thread"] = {k: v for k, v in run(1, third).items() if k in keep}
     if cores > 32:

@@ -231,8 +231,16 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "split_u1" (4)    the updates a level sends into the NEXT level's columns are split: those of its diagonal tiles stay on
  *                     the main stream (the next potrf needs nothing else), the others run on a third stream beside that
  *                     potrf when they are at least this many tasks; 0 = one batch on the main stream (before set_structure)
- *   "potrf_lookahead" (8)  diagonal-tile Cholesky + inverse: 8 / 6 / 1 = look-ahead schedule with 8 / 6 / 4 waves
- *                     per workgroup, 0 = the schedule without look-ahead
+ *   "potrf_lookahead" (9)  diagonal-tile Cholesky + inverse: 9 = the 16 x 16 pivot blocks on the matrix pipe (round 4),
+ *                     8 / 6 / 1 = look-ahead schedule of round 3 with 8 / 6 / 4 waves per workgroup, 0 = without look-ahead
+ *   "factor_flow" (6), "factor_flow_rows" (24)  the TOP of the elimination tree -- the trailing level groups with at most
+ *                     that many tile columns each, every column with at most "factor_flow_rows" off-diagonal tiles -- is
+ *                     factorised by ONE dataflow launch (k_factor_flow: a workgroup per potrf / per 48-row strip of a
+ *                     panel solve or update, per-tile version counters) instead of three dependent launches per level;
+ *                     same summation order, bit-identical factor.  0 = level launches everywhere.  Its waits are bounded
+ *                     like the sweeps': a launch that gives up is detected in the same apexgpu_solve_augmented, S is
+ *                     assembled again and factorised by the level launches, which the handle then keeps
+ *                     (apexgpu_counters()[2]); before set_structure
  *   "fused_forward" (0)  run the forward triangular sweep inside the factorisation graph on a third stream
  *   "tri_dataflow" (1)  triangular sweeps of a single-GPU plan as ONE launch each: one workgroup per tile, dependencies
  *                     through per-block flags (k_tri_fwd_flow / k_tri_bwd_flow); 0 = one launch per elimination-tree level.
@@ -269,7 +277,8 @@ int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_
  * [15] = form of the Schur reduction in use ("schur_rows") */
 int apexgpu_info(apexgpu_solver* h, double info[16]);
 /* out[0] = dataflow triangular sweeps that timed out and were repeated level by level (see "tri_dataflow"),
- * out[1] = 1 while the handle still uses the dataflow sweeps, out[2..3] reserved (0) */
+ * out[1] = 1 while the handle still uses the dataflow sweeps, out[2] = dataflow factorisations that timed out and were
+ * repeated by the level launches (see "factor_flow"), out[3] = level groups inside the dataflow launches of this plan */
 int apexgpu_counters(apexgpu_solver* h, int64_t out[4]);
 /* Profiling aid of the Schur pair kernel (record form run with "pairs_ablation" 64: results stay right): shader cycles summed
  * over all waves since the last reset, out[0..4] = wait for the gathers, un-staging, Jacobians + U / V stores, issue of the next

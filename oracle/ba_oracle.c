@@ -581,6 +581,219 @@ int ora_solve_cholesky(int64_t n, const double *S, const double *b, double *x, d
     return ORA_ERR_SINGULAR;
 }
 
+/* ---- the SPARSE form of solve_with_cholesky --------------------------------------------------
+ * The reference does not factorise S densely: compute_schur_complement returns S as a sparse
+ * matrix with every |v| <= 1e-12 dropped (explicit_schur.rs:913-921) and solve_with_cholesky hands
+ * it to faer's sparse LL^T (SymbolicLlt::try_new + Llt::try_new_with_symbolic, :544-550), i.e. a
+ * fill-reducing ordering and a factor that lives inside the pattern's fill.  faer is not in the
+ * reference tree; what is restated here is that contract with the textbook tools: the pattern
+ * of the sparsified S at block granularity (`blk` = the camera block, the unit every non-zero
+ * of S comes in), a reverse Cuthill-McKee order of that graph, and a blocked Cholesky confined
+ * to the ENVELOPE of the permuted matrix (the fill of an envelope stays inside it).  The numbers
+ * differ from ora_solve_cholesky's only by the order of the sums (tests/test_oracle_kat.py holds
+ * the two together); the work is n * band^2 instead of n^3 / 3.  This is the solve bench.py's
+ * cpu_baseline times ("solve": "sparse"); parity keeps using the dense one, whose summation
+ * order does not depend on an ordering heuristic.  Regularisation ladder as above. */
+static void rcm_order(int64_t nb, const int64_t *ptr, const int64_t *adj, int64_t *perm /* new -> old */) {
+    int64_t *deg = (int64_t *)malloc((size_t)nb * 8), *q = (int64_t *)malloc((size_t)nb * 8);
+    int64_t *lvl = (int64_t *)malloc((size_t)nb * 8);
+    char *seen = (char *)calloc((size_t)nb, 1);
+    for (int64_t v = 0; v < nb; ++v) deg[v] = ptr[v + 1] - ptr[v];
+    int64_t n_out = 0;
+    for (int64_t s0 = 0; s0 < nb; ++s0) {
+        if (seen[s0]) continue;
+        /* pseudo-peripheral start of this component: repeat BFS from the last, lowest-degree node of the deepest level */
+        int64_t start = s0;
+        for (int round = 0; round < 4; ++round) {
+            int64_t h = 0, t = 0, depth = 0;
+            for (int64_t v = 0; v < nb; ++v) lvl[v] = -1;
+            q[t++] = start; lvl[start] = 0;
+            while (h < t) {
+                const int64_t v = q[h++];
+                for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e) {
+                    const int64_t w = adj[e];
+                    if (!seen[w] && lvl[w] < 0) { lvl[w] = lvl[v] + 1; if (lvl[w] > depth) depth = lvl[w]; q[t++] = w; }
+                }
+            }
+            int64_t best = start;
+            for (int64_t i = 0; i < t; ++i)
+                if (lvl[q[i]] == depth && (best == start || deg[q[i]] < deg[best])) best = q[i];
+            if (best == start) break;
+            start = best;
+        }
+        /* Cuthill-McKee: BFS, neighbours by increasing degree */
+        int64_t h = n_out, t = n_out;
+        perm[t++] = start; seen[start] = 1;
+        while (h < t) {
+            const int64_t v = perm[h++];
+            const int64_t t0 = t;
+            for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e) {
+                const int64_t w = adj[e];
+                if (!seen[w]) { seen[w] = 1; perm[t++] = w; }
+            }
+            for (int64_t i = t0 + 1; i < t; ++i) {   /* insertion sort of the new nodes by degree */
+                const int64_t w = perm[i];
+                int64_t j = i;
+                while (j > t0 && deg[perm[j - 1]] > deg[w]) { perm[j] = perm[j - 1]; --j; }
+                perm[j] = w;
+            }
+        }
+        n_out = t;
+    }
+    for (int64_t i = 0; i < nb / 2; ++i) { const int64_t a = perm[i]; perm[i] = perm[nb - 1 - i]; perm[nb - 1 - i] = a; }
+    free(deg); free(q); free(lvl); free(seen);
+}
+
+/* Cholesky of a dense-stored matrix whose lower triangle lives in the envelope first[i] <= j <= i
+ * (first[] per row; last[j] = the last row whose envelope reaches column j, non-decreasing): the
+ * blocked right-looking algorithm of dense_llt with every loop cut to the rows a block column can touch. */
+static int envelope_llt(int64_t n, double *A, const int64_t *last) {
+    const int64_t NB = 64;
+    for (int64_t k0 = 0; k0 < n; k0 += NB) {
+        const int64_t kb = (k0 + NB < n) ? NB : n - k0;
+        const int64_t rend = last[k0 + kb - 1] + 1;   /* rows >= rend have zeros in columns < k0 + kb */
+        for (int64_t j = k0; j < k0 + kb; ++j) {
+            double d = A[j * n + j];
+            for (int64_t p = k0; p < j; ++p) d -= A[j * n + p] * A[j * n + p];
+            if (!(d > 0.0)) return 1;
+            d = sqrt(d);
+            A[j * n + j] = d;
+            for (int64_t i = j + 1; i < k0 + kb; ++i) {
+                double s = A[i * n + j];
+                for (int64_t p = k0; p < j; ++p) s -= A[i * n + p] * A[j * n + p];
+                A[i * n + j] = s / d;
+            }
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t i = k0 + kb; i < rend; ++i) {
+            for (int64_t j = k0; j < k0 + kb; ++j) {
+                double s = A[i * n + j];
+                for (int64_t p = k0; p < j; ++p) s -= A[i * n + p] * A[j * n + p];
+                A[i * n + j] = s / A[j * n + j];
+            }
+        }
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int64_t i = k0 + kb; i < rend; ++i) {
+            const double *Li = A + i * n + k0;
+            for (int64_t j = k0 + kb; j <= i; ++j) {
+                const double *Lj = A + j * n + k0;
+                double s = 0.0;
+                for (int64_t p = 0; p < kb; ++p) s += Li[p] * Lj[p];
+                A[i * n + j] -= s;
+            }
+        }
+    }
+    return 0;
+}
+
+/* S dense row-major symmetric (as compute_schur_complement builds it); blk: block size of the pattern
+ * (n % blk == 0, else 1 is used).  stats (may be NULL): [0] non-zero blocks of the sparsified S (lower, incl.
+ * diagonal), [1] scalar entries inside the envelope, [2] half bandwidth (scalars) after the ordering. */
+int ora_solve_cholesky_sparse(int64_t n, int64_t blk, const double *S, const double *b, double *x, double *reg_used,
+                              double *stats) {
+    if (blk < 1 || n % blk != 0) blk = 1;
+    const int64_t nb = n / blk;
+    if (reg_used) *reg_used = 0.0;
+    /* pattern of the sparsified S (:913-921: |v| > 1e-12 kept), symmetric, block granularity */
+    char *nz = (char *)calloc((size_t)nb * (size_t)nb, 1);
+#pragma omp parallel for schedule(static)
+    for (int64_t bi = 0; bi < nb; ++bi)
+        for (int64_t bj = 0; bj <= bi; ++bj) {
+            char any = 0;
+            for (int64_t r = 0; r < blk && !any; ++r)
+                for (int64_t c = 0; c < blk; ++c) {
+                    const double v = 0.5 * (S[(bi * blk + r) * n + bj * blk + c] + S[(bj * blk + c) * n + bi * blk + r]);
+                    if (fabs(v) > 1e-12) { any = 1; break; }
+                }
+            nz[bi * nb + bj] = any;
+        }
+    int64_t *ptr = (int64_t *)calloc((size_t)nb + 1, 8);
+    int64_t n_blocks = 0;
+    for (int64_t bi = 0; bi < nb; ++bi)
+        for (int64_t bj = 0; bj < bi; ++bj)
+            if (nz[bi * nb + bj]) { ++ptr[bi + 1]; ++ptr[bj + 1]; ++n_blocks; }
+    for (int64_t v = 0; v < nb; ++v) ptr[v + 1] += ptr[v];
+    int64_t *adj = (int64_t *)malloc((size_t)(ptr[nb] ? ptr[nb] : 1) * 8), *fill = (int64_t *)calloc((size_t)nb, 8);
+    for (int64_t bi = 0; bi < nb; ++bi)
+        for (int64_t bj = 0; bj < bi; ++bj)
+            if (nz[bi * nb + bj]) { adj[ptr[bi] + fill[bi]++] = bj; adj[ptr[bj] + fill[bj]++] = bi; }
+    int64_t *perm = (int64_t *)malloc((size_t)nb * 8), *inv = (int64_t *)malloc((size_t)nb * 8);
+    rcm_order(nb, ptr, adj, perm);
+    for (int64_t i = 0; i < nb; ++i) inv[perm[i]] = i;
+    /* envelope of the permuted pattern */
+    int64_t *firstb = (int64_t *)malloc((size_t)nb * 8), *last = (int64_t *)malloc((size_t)n * 8);
+    for (int64_t i = 0; i < nb; ++i) {
+        int64_t f = i;
+        const int64_t v = perm[i];
+        for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e) if (inv[adj[e]] < f) f = inv[adj[e]];
+        firstb[i] = f;
+    }
+    {
+        int64_t *lastb = (int64_t *)malloc((size_t)nb * 8);
+        for (int64_t j = 0; j < nb; ++j) lastb[j] = j;
+        for (int64_t i = 0; i < nb; ++i)
+            for (int64_t j = firstb[i]; j <= i; ++j) if (lastb[j] < i) lastb[j] = i;
+        for (int64_t j = 1; j < nb; ++j) if (lastb[j] < lastb[j - 1]) lastb[j] = lastb[j - 1];
+        for (int64_t j = 0; j < n; ++j) last[j] = lastb[j / blk] * blk + blk - 1;
+        free(lastb);
+    }
+    double env = 0.0, band = 0.0;
+    for (int64_t i = 0; i < nb; ++i) {
+        env += (double)(i - firstb[i] + 1) * (double)(blk * blk);
+        if ((double)(i - firstb[i]) * (double)blk > band) band = (double)(i - firstb[i]) * (double)blk;
+    }
+    if (stats) { stats[0] = (double)(n_blocks + nb); stats[1] = env; stats[2] = band; }
+    /* P S P^T (lower envelope only), the permuted right-hand side */
+    double *A = (double *)calloc((size_t)n * (size_t)n, 8), *L = (double *)calloc((size_t)n * (size_t)n, 8);   /* zero outside the envelope, and they stay zero */
+    double *pb = (double *)malloc((size_t)n * 8);
+    if (!A || !L) { free(A); free(L); free(pb); free(nz); free(ptr); free(adj); free(fill); free(perm); free(inv); free(firstb); free(last); return ORA_ERR_INPUT; }
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t i = 0; i < nb; ++i)
+        for (int64_t j = firstb[i]; j <= i; ++j) {
+            const int64_t oi = perm[i], oj = perm[j];
+            if (!nz[oi > oj ? oi * nb + oj : oj * nb + oi]) continue;
+            for (int64_t r = 0; r < blk; ++r)
+                for (int64_t c = 0; c < blk; ++c) {
+                    /* symmetrised as :903-911; entries at or below the drop threshold inside a kept block are dropped too */
+                    const double v = 0.5 * (S[(oi * blk + r) * n + oj * blk + c] + S[(oj * blk + c) * n + oi * blk + r]);
+                    A[(i * blk + r) * n + j * blk + c] = fabs(v) > 1e-12 ? v : 0.0;
+                }
+        }
+    for (int64_t i = 0; i < nb; ++i)
+        for (int64_t r = 0; r < blk; ++r) pb[i * blk + r] = b[perm[i] * blk + r];
+    int rc = ORA_ERR_SINGULAR;
+    double trace = 0.0, max_diag = 0.0;
+    for (int64_t i = 0; i < n; ++i) { trace += A[i * n + i]; max_diag = fmax(max_diag, fabs(A[i * n + i])); }
+    const double base = fmax(fmax(trace / (double)n, max_diag), 1.0);
+    for (int attempt = -1; attempt < 5 && rc != ORA_OK; ++attempt) {
+        const double reg = attempt < 0 ? 0.0 : base * pow(10.0, (double)(attempt - 4));
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t f = firstb[i / blk] * blk;
+            memcpy(L + i * n + f, A + i * n + f, (size_t)(i - f + 1) * 8);
+            L[i * n + i] += reg;
+        }
+        if (envelope_llt(n, L, last) != 0) continue;
+        double *y = (double *)malloc((size_t)n * 8);
+        for (int64_t i = 0; i < n; ++i) {
+            double s = pb[i];
+            for (int64_t p = firstb[i / blk] * blk; p < i; ++p) s -= L[i * n + p] * y[p];
+            y[i] = s / L[i * n + i];
+        }
+        for (int64_t i = n - 1; i >= 0; --i) {
+            y[i] /= L[i * n + i];
+            for (int64_t p = firstb[i / blk] * blk; p < i; ++p) y[p] -= L[i * n + p] * y[i];
+        }
+        for (int64_t i = 0; i < nb; ++i)
+            for (int64_t r = 0; r < blk; ++r) x[perm[i] * blk + r] = y[i * blk + r];
+        free(y);
+        if (reg_used) *reg_used = reg;
+        rc = ORA_OK;
+    }
+    free(A); free(L); free(pb); free(nz); free(ptr); free(adj); free(fill); free(perm); free(inv); free(firstb); free(last);
+    return rc;
+}
+
 /* solve_with_pcg (explicit_schur.rs:639-756): Jacobi-preconditioned CG on the
  * explicit S.  Returns the number of iterations performed in *iters. */
 int ora_solve_pcg(int64_t n, const double *S, const double *b, int64_t max_iter, double tol,
@@ -829,6 +1042,7 @@ int ora_schur_solve_dense_jacobian(int64_t n_rows, int64_t cam_dof, int64_t n_pt
                                         step_out, &its);
             free(bs); free(bz);
         } else if (variant == 1) rc = ora_solve_pcg(cam_dof, S, gred, cg_max_iter, cg_tol, step_out, &its);
+        else if (variant == 3) rc = ora_solve_cholesky_sparse(cam_dof, 1, S, gred, step_out, NULL, NULL);
         else rc = ora_solve_cholesky(cam_dof, S, gred, step_out, NULL);
     }
     if (rc == ORA_OK) ora_back_substitute(n_pt, step_out, g_p, row_ptr, cam_rows, hcl, Hinv, step_out + cam_dof);
@@ -859,6 +1073,7 @@ typedef struct {
     double *grad; /* +J^T r, global column order (get_gradient, :1240-1242) */
     int cg_max_iter; double cg_tol; int64_t last_pcg_iters; double last_reg;
     double *scaling; /* Jacobi column scaling (optimizer/mod.rs:749-763), total_dof; NULL = off */
+    double sparse_stats[3]; /* of the last variant-3 solve: blocks of the sparsified S, envelope entries, half bandwidth */
 } ora_problem;
 
 void ora_problem_destroy(ora_problem *p) {
@@ -984,7 +1199,8 @@ static int cmp_i64(const void *a, const void *b) {
 
 /* A6-A13: SparseSchurComplementSolver::solve_augmented_equation
  * (explicit_schur.rs:1129-1234) on the last linearisation.
- * variant 0 = Sparse (Cholesky), 1 = Iterative (Jacobi-PCG on explicit S),
+ * variant 0 = Sparse (Cholesky; dense LL^T here), 3 = the same through ora_solve_cholesky_sparse (the timed CPU baseline),
+ * 1 = Iterative (Jacobi-PCG on explicit S),
  * 2 = IterativeSchurSolver semantics (matrix-free PCG, Schur-Jacobi preconditioner; implicit_schur.rs).
  * step_out / grad_out: total_dof, reference global column order.
  * S_out (cam_dof^2, row-major, camera-side columns in reference order) and
@@ -1132,6 +1348,7 @@ int ora_solve_augmented(ora_problem *p, double lambda, int variant, double *step
                                         dc, &p->last_pcg_iters);
             free(bs); free(bz);
         } else if (variant == 1) rc = ora_solve_pcg(nc, S, gred, p->cg_max_iter, p->cg_tol, dc, &p->last_pcg_iters);
+        else if (variant == 3) rc = ora_solve_cholesky_sparse(nc, 3, S, gred, dc, &p->last_reg, p->sparse_stats);   /* columns: intr_* (3 each), then pose_* (6 = 2 x 3 each) */
         else rc = ora_solve_cholesky(nc, S, gred, dc, &p->last_reg);
     }
     if (rc == ORA_OK) {
@@ -1174,6 +1391,7 @@ int ora_set_column_scaling(ora_problem *p, const double *scaling) {
 
 int64_t ora_last_pcg_iters(const ora_problem *p) { return p->last_pcg_iters; }
 double ora_last_reg(const ora_problem *p) { return p->last_reg; }
+void ora_last_sparse_stats(const ora_problem *p, double out[3]) { for (int k = 0; k < 3; ++k) out[k] = p->sparse_stats[k]; }
 
 /* A15: apply_parameter_step (optimizer/mod.rs:309-331) with sign = +1, or
  * apply_negative_parameter_step (:343-356) with sign = -1.  Fixed DOF are zeroed in

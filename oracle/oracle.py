@@ -136,6 +136,10 @@ def lib(native: bool = False):
     L.ora_last_pcg_iters.restype = C.c_int64
     L.ora_last_reg.argtypes = [vp]
     L.ora_last_reg.restype = C.c_double
+    L.ora_last_sparse_stats.argtypes = [vp, _f64p]
+    L.ora_last_sparse_stats.restype = None
+    L.ora_solve_cholesky_sparse.argtypes = [C.c_int64, C.c_int64, _f64p, _f64p, _f64p, vp, vp]
+    L.ora_solve_cholesky_sparse.restype = C.c_int
     L.ora_apply_step.argtypes = [vp, _f64p, C.c_double]
     L.ora_apply_step.restype = C.c_double
     L.ora_parameter_norm.argtypes = [vp]
@@ -294,6 +298,11 @@ class OracleProblem:
     @property
     def last_reg(self) -> float:
         return float(self._L.ora_last_reg(self._h))
+
+    def last_sparse_stats(self) -> dict:
+        """Of the last variant-3 solve (ora_solve_cholesky_sparse): the sparsified S and its envelope after the ordering."""
+        o = np.zeros(3); self._L.ora_last_sparse_stats(self._h, o)
+        return dict(nonzero_blocks=int(o[0]), envelope_entries=float(o[1]), half_bandwidth=int(o[2]))
 
     def optimize(self, cfg: LMConfig, keep_steps: bool = False) -> LMResult:
         rows = cfg.max_iterations + 2

@@ -358,3 +358,83 @@ def test_se3_plus_small_and_large_angle_agree_with_rodrigues(oracle):
         tn = pose[:3] + R @ (np_ref.so3_V(d[None, 3:])[0] @ d[:3])
         assert np.allclose(np_ref.quat_to_R(out[None, 3:])[0], Rn, atol=1e-12)
         assert np.allclose(out[:3], tn, atol=1e-12)
+
+
+# --- the sparse form of solve_with_cholesky (the timed CPU baseline) against the dense one ---------
+def test_sparse_cholesky_agrees_with_dense(oracle):
+    """explicit_schur.rs:913-921 (entries |v| <= 1e-12 dropped) + :544-550 (sparse LL^T in a fill-reducing order):
+    ora_solve_cholesky_sparse restates that contract with reverse Cuthill-McKee + an envelope Cholesky; parity uses the
+    dense ora_solve_cholesky.  The two differ by the order of the sums only -- on a block-banded system with a wrapped
+    corner (the ring shape of the synthetic BAL generators), an arrow (hub) system, and a dense one; the ordering must
+    find the band, and a matrix that needs the regularisation ladder must walk it to the same rung."""
+    L = oracle.lib()
+    rng = np.random.default_rng(7)
+
+    def solve_both(S, blk):
+        n = S.shape[0]
+        b = rng.standard_normal(n)
+        x0 = np.empty(n); x1 = np.empty(n)
+        r0 = C.c_double(0.0); r1 = C.c_double(0.0); st = (C.c_double * 3)()
+        assert L.ora_solve_cholesky(n, S, b, x0, C.byref(r0)) == 0
+        assert L.ora_solve_cholesky_sparse(n, blk, S, b, x1, C.byref(r1), C.byref(st)) == 0
+        return x0, x1, r0.value, r1.value, [st[0], st[1], st[2]], b
+
+    # (a) ring of 40 blocks of 6, half bandwidth 3 blocks, wrapped
+    nb, blk = 40, 6
+    n = nb * blk
+    A = np.zeros((n, n))
+    for i in range(nb):
+        for d in range(-3, 4):
+            j = (i + d) % nb
+            A[i * blk:(i + 1) * blk, j * blk:(j + 1) * blk] = rng.standard_normal((blk, blk))
+    S = A @ A.T + 50.0 * np.eye(n)
+    S[np.abs(S) < 1e-9] = 0.0
+    x0, x1, r0, r1, st, b = solve_both(np.ascontiguousarray(S), blk)
+    assert r0 == 0.0 and r1 == 0.0
+    assert np.linalg.norm(x1 - x0) <= 1e-12 * np.linalg.norm(x0)
+    assert np.linalg.norm(S @ x1 - b) <= 1e-12 * np.linalg.norm(b)
+    assert st[2] <= 2 * 2 * 6 * blk + blk, st      # RCM on a ring: at most twice the ring's own band (here 6 blocks each side)
+    assert st[1] < 0.45 * n * n                     # ... so the envelope is a fraction of the dense triangle pair
+
+    # (b) arrow: 30 independent blocks + one hub block coupled to all of them
+    nb, blk = 31, 3
+    n = nb * blk
+    S = np.zeros((n, n))
+    for i in range(nb):
+        M = rng.standard_normal((blk, blk)); S[i * blk:(i + 1) * blk, i * blk:(i + 1) * blk] = M @ M.T + 4.0 * np.eye(blk)
+    for i in range(nb - 1):
+        Cb = 0.3 * rng.standard_normal((blk, blk))
+        S[(nb - 1) * blk:, i * blk:(i + 1) * blk] = Cb; S[i * blk:(i + 1) * blk, (nb - 1) * blk:] = Cb.T
+    S[(nb - 1) * blk:, (nb - 1) * blk:] += 30.0 * np.eye(blk)
+    x0, x1, r0, r1, st, b = solve_both(np.ascontiguousarray(S), blk)
+    assert np.linalg.norm(x1 - x0) <= 1e-12 * np.linalg.norm(x0) and st[0] == 2 * nb - 1
+
+    # (c) dense, and a block size that does not divide n (falls back to scalar granularity)
+    M = rng.standard_normal((37, 37)); S = np.ascontiguousarray(M @ M.T + 37.0 * np.eye(37))
+    x0, x1, r0, r1, st, b = solve_both(S, 5)
+    assert np.linalg.norm(x1 - x0) <= 1e-12 * np.linalg.norm(x0) and st[1] == 37 * 38 / 2
+
+    # (d) the regularisation ladder (:559-634): a rank-deficient S takes the same rung in both
+    v = rng.standard_normal((24, 5)); S = np.ascontiguousarray(v @ v.T)
+    x0, x1, r0, r1, st, b = solve_both(S, 3)
+    assert r0 > 0.0 and r1 == r0
+    assert np.linalg.norm(x1 - x0) <= 1e-6 * np.linalg.norm(x0)
+
+
+def test_sparse_cholesky_step_on_a_ba_problem(oracle):
+    """variant 3 of ora_solve_augmented (what bench.py's cpu_baseline times) against variant 0 on a synthetic BA problem:
+    the same step to the conditioning of S, and an envelope well below the dense triangle on the ring shape."""
+    import apex_solver_amd as pkg
+
+    d = pkg.synthetic.make_problem(150, 3000, 3, 7, config_id=11, window=12)
+    lay = pkg.layout.reference_column_layout(d.n_cam, d.n_pt)
+    o = oracle.from_data(d, lay, mode="selfcal")
+    o.residuals(); o.linearize()
+    for lam, tol in ((1e4, 1e-12), (1e-3, 1e-7)):
+        s0, g0 = o.solve_augmented(lam, 0)
+        s3, g3 = o.solve_augmented(lam, 3)
+        assert np.array_equal(g0, g3)
+        assert np.linalg.norm(s3 - s0) <= tol * np.linalg.norm(s0), (lam, np.linalg.norm(s3 - s0) / np.linalg.norm(s0))
+    st = o.last_sparse_stats()
+    n = o.cam_dof
+    assert st["envelope_entries"] < 0.5 * n * (n + 1) / 2 and st["half_bandwidth"] < n // 2, st

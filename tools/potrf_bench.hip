@@ -3,6 +3,7 @@
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAPEX_POTRF_TRACE -I apex-solver_amd/csrc tools/potrf_bench.hip -o tools/potrf_bench
 #include "../apex-solver_amd/csrc/chol_kernels.hip"
 #include <stdio.h>
+#include <math.h>
 #include <vector>
 using namespace apex;
 int main() {
@@ -10,7 +11,7 @@ int main() {
     const int nb = 64;
     std::vector<double> h(te);
     for (int i = 0; i < kNB; ++i)
-        for (int j = 0; j < kNB; ++j) h[(size_t)i * kNB + j] = (i == j ? 200.0 : 0.0) + 1.0 / (1.0 + abs(i - j));
+        for (int j = 0; j < kNB; ++j) h[(size_t)i * kNB + j] = (i == j ? 6.0 : 0.0) + 1.0 / (1.0 + abs(i - j)) + 0.3 * cos(0.37 * i * j + i + j);
     double *src, *A, *Li; int* fail; PotrfTask* d;
     hipMalloc(&src, te * 8); hipMalloc(&A, nb * te * 8); hipMalloc(&Li, nb * te * 8); hipMalloc(&fail, 16); hipMalloc(&d, nb * sizeof(PotrfTask));
     hipMemcpy(src, h.data(), te * 8, hipMemcpyHostToDevice);
@@ -19,7 +20,7 @@ int main() {
     for (int i = 0; i < nb; ++i) t[i] = {A + i * te, Li + i * te, i};
     hipMemcpy(d, t.data(), nb * sizeof(PotrfTask), hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode : {1, 6, 8}) {
+    for (int mode : {1, 6, 8, 9}) {
         set_potrf_lookahead(mode);
         for (int n : {1, 64}) {
             float best = 1e9f;
@@ -31,6 +32,34 @@ int main() {
                 float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
             }
             printf("waves mode %d, %2d tiles: %.1f us\n", mode, n, best * 1e3);
+            if (n == 1) {   // numerics against a host Cholesky of the same tile: L (lower) and L^-1
+                std::vector<double> L(h), gl(te), gi(te), Li0(te, 0.0);
+                for (int j = 0; j < kNB; ++j) {
+                    double d = L[(size_t)j * kNB + j];
+                    for (int k = 0; k < j; ++k) d -= L[(size_t)j * kNB + k] * L[(size_t)j * kNB + k];
+                    d = sqrt(d); L[(size_t)j * kNB + j] = d;
+                    for (int i = j + 1; i < kNB; ++i) {
+                        double v = L[(size_t)i * kNB + j];
+                        for (int k = 0; k < j; ++k) v -= L[(size_t)i * kNB + k] * L[(size_t)j * kNB + k];
+                        L[(size_t)i * kNB + j] = v / d;
+                    }
+                }
+                for (int c = 0; c < kNB; ++c)
+                    for (int i = c; i < kNB; ++i) {
+                        double v = i == c ? 1.0 : 0.0;
+                        for (int k = c; k < i; ++k) v -= L[(size_t)i * kNB + k] * Li0[(size_t)k * kNB + c];
+                        Li0[(size_t)i * kNB + c] = v / L[(size_t)i * kNB + i];
+                    }
+                hipMemcpy(gl.data(), A, te * 8, hipMemcpyDeviceToHost); hipMemcpy(gi.data(), Li, te * 8, hipMemcpyDeviceToHost);
+                double eL = 0, eI = 0, nL = 0, nI = 0;
+                for (int i = 0; i < kNB; ++i)
+                    for (int j = 0; j <= i; ++j) {
+                        const size_t q = (size_t)i * kNB + j;
+                        eL = fmax(eL, fabs(gl[q] - L[q])); nL = fmax(nL, fabs(L[q]));
+                        eI = fmax(eI, fabs(gi[q] - Li0[q])); nI = fmax(nI, fabs(Li0[q]));
+                    }
+                printf("   vs host: max|L - L0| / max|L0| = %.2e, max|Linv - Linv0| / max|Linv0| = %.2e\n", eL / nL, eI / nI);
+            }
             if (n == 1) {
                 unsigned long long tr[64]; int cnt = 0;
                 hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_potrf_trace), sizeof tr); hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_potrf_trace_n), sizeof cnt);
