@@ -19,15 +19,16 @@ struct PotrfTask {  // one diagonal tile: factor in place, inverse of the factor
     int K;
 };
 
+constexpr int kFlowUnitsPerTile = 9;   // units per panel solve / update; the weight of a potrf in the version counters
 struct FactorUnit {   // one workgroup of the dataflow factorisation of the top of the elimination tree (k_factor_flow)
     double* C;            // potrf: the diagonal tile (factorised in place); product: the target tile
     const double* A;      // potrf: L^-1 of the tile (written); product: left operand tile (panel solve: == C, in place)
     const double* B;      // product: right operand tile (panel solve: L^-1 of the column's diagonal tile)
     int wait_flag[3];     // indices into the version array, -1 = none: [0] the target's previous writer, [1] A final, [2] B final
     int wait_val[3];      // ... proceed when ver[flag] >= val
-    int pub;              // index into the version array: += 1 per finished 48-row strip, += 3 by a potrf
-    int kind;             // 0 potrf + inverse, 1 panel solve C = A B^T, 2 update C -= A B^T
-    int strip;            // product: 48-row strip 0..2 of C; potrf: tile column (for the pivot-failure flag)
+    int pub;              // index into the version array: += 1 per finished unit (kFlowUnitsPerTile per tile and writer), += 9 by a potrf
+    int kind;             // 0 potrf + inverse, 1 panel solve C = A B^T (in place), 2 update C -= A B^T
+    int strip;            // panel solve: 16-row strip 0..8 of C; update: 48 x 48 block 3 bi + bj of C; potrf: tile column (for the failure flag)
     int pad;
 };
 
@@ -65,7 +66,8 @@ void launch_pcg_step2(int n, double* scal, const double* blk_part, const double*
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s, int* arrived = nullptr);
 void launch_gate(const int* arrived, int expected, int max_micros, hipStream_t s);
 // the dataflow factorisation: one workgroup per unit, dispatched in list order; ver[] must be zero; err: error word (time-out)
-void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, hipStream_t s);
+void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, hipStream_t s,
+                        unsigned long long* trace = nullptr);   // trace (tools only): 3 stamps of the 100 MHz clock per unit
 void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 1 / 6 / 8 k_potrf_inv_la with 4 / 6 / 8 waves, 9 k_potrf_inv_mf (default)
 // batches of <= 56 tasks use the latency kernels, larger ones the 3 x 3-wave strip kernel
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s);

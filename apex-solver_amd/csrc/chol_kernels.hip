@@ -283,9 +283,9 @@ __device__ __forceinline__ void blk_to_global(const double* __restrict__ src, do
 // the previous step's trailing update and one row of L^-1 -- with 4 waves those three take ~3 us per block step
 // against wave 0's ~1.2 us and are the critical path of the tile; 8 waves balance the two.
 #ifdef APEX_POTRF_TRACE   // tools/potrf_bench.hip: wall-clock stamps of workgroup 0 at the phase boundaries
-__device__ unsigned long long g_potrf_trace[64];
+__device__ unsigned long long g_potrf_trace[64], g_potrf_cycles[64];   // 100 MHz stamps and shader-clock stamps (s_memtime)
 __device__ int g_potrf_trace_n;
-#define POTRF_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_potrf_trace[g_potrf_trace_n++] = wall_clock64(); } while (0)
+#define POTRF_STAMP() do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_potrf_cycles[g_potrf_trace_n] = __builtin_amdgcn_s_memtime(); g_potrf_trace[g_potrf_trace_n++] = wall_clock64(); } } while (0)
 #else
 #define POTRF_STAMP() do {} while (0)
 #endif
@@ -605,6 +605,13 @@ __device__ __forceinline__ void potrf_tile_mf(double* __restrict__ A, double* __
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
+    // Wave 0's pivot loop lives on ONE SIMD's matrix pipe: two dependent v_mfma_f64 per pivot, 161 cycles per pivot when it has
+    // the pipe to itself (tools/lat_bench.hip) -- and twice that when another wave of the workgroup feeds the same pipe with
+    // block products (measured: 360).  A workgroup's waves go to the four SIMDs cyclically, so waves 4 (and 8) share wave 0's:
+    // they sit out the block products; the helpers are the waves with w % 4 != 0.
+    constexpr int NH = NW - (NW + 3) / 4;
+    const bool helper = (w & 3) != 0;
+    const int hid = w - 1 - (w >> 2);   // 1,2,3,5,6,7 -> 0..5
     const __amdgpu_buffer_rsrc_t rA = coh_rsrc(A), rL = coh_rsrc(Linv);
     if (tid == 0) *bad = 0;
     {
@@ -645,59 +652,80 @@ __device__ __forceinline__ void potrf_tile_mf(double* __restrict__ A, double* __
     if (w == 0) Dm = blk_load_cd_sym(sA, lr, lk);
     for (int kb = 0; kb < NBK; ++kb) {
         // ---------------- P1 ------------------------------------------------------------------------------
-        double4_t T[(NBK - 1 + NW - 2) / (NW - 1)];   // row kb-1 of L^-1: blocks j = (w-1), (w-1)+(NW-1), ... of waves 1..NW-1
+        double4_t T[(NBK - 1 + NH - 1) / NH];   // row kb-1 of L^-1: blocks j = hid, hid + NH, ... of the helpers
         if (w == 0) {
-            double4_t Xm;
+            double4_t Xm, Ls = (double4_t){0.0, 0.0, 0.0, 0.0}, Xs = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int r = 0; r < 4; ++r) Xm[r] = (lk + 4 * r == lr) ? 1.0 : 0.0;
+            // Nothing protects the rows and columns <= j from the later updates (a masked operand costs two v_cndmask per
+            // double, and the 16 steps are bound by their instruction count): row j of L^T and of X are SAVED the moment they
+            // are final -- the scaled row is non-zero on the lanes of row j only, so "save" is one add -- and what the
+            // updates then do to the dead rows / columns of Dm and Xm never reaches a live element (an update of element
+            // (r, c) uses column entries r and c of the pivot row only, and for r, c > j those are clean).
+            // TWO pivots per matrix instruction: fp64 MFMA and fp64 VALU share one datapath (an MFMA holds it for 64 cycles,
+            // tools/lat_bench.hip), so the loop costs the SUM of its instructions and the MFMAs are the largest item.  Pivots
+            // j (even) and j + 1 sit in adjacent 16-lane rows of the same accumulator register: row j, scaled, is copied next
+            // door (v_permlane16_swap), row j + 1 takes pivot j's update there as one FMA and is scaled in turn, and the two
+            // scaled rows -- disjoint lanes of one operand register -- go through ONE rank-2 update.  The inverse likewise.
+            double rmask[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rmask[q] = lk == q ? 1.0 : 0.0;
+            auto rsq_newton = [](double d) {
+                double r = __builtin_amdgcn_rsq(d);
+                r = r * fma(-0.5 * d * r, r, 1.5);
+                r = r * fma(-0.5 * d * r, r, 1.5);
+                return r;
+            };
+            auto even_rows_to_odd = [](double x) {   // 16-lane rows 1, 3 <- rows 0, 2 (rows 0, 2 keep their values)
+                const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+                return __hiloint2double(hi[0], lo[0]);
+            };
             int isbad = 0;
             double dnext = readlane_f64(Dm[0], 0);
 #pragma unroll
-            for (int j = 0; j < BS; ++j) {
-                const int jr = j >> 2, jq = j & 3;
-                const double djj = dnext;
-                if (!(djj > 0.0)) isbad = 1;
-                const double dj = djj > 0.0 ? djj : 1.0;
-                double isj = __builtin_amdgcn_rsq(dj);
-                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
-                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
-                double sj = dj * isj;
-                sj = fma(0.5 * isj, fma(-sj, sj, dj), sj);
-                const bool row = lk == jq;
-                const double l = Dm[jr] * isj;                     // lanes of row j: L[lr][j]
-                if (j + 1 < BS) {
-                    // the NEXT pivot ahead of the update that produces it: D[j+1][j+1] - L[j+1][j]^2, so that its
-                    // 1/sqrt chain runs in the shadow of this step's matrix instructions instead of behind them
-                    const double dd = readlane_f64(Dm[(j + 1) >> 2], 16 * ((j + 1) & 3) + j + 1);
-                    const double lj1 = readlane_f64(l, 16 * jq + j + 1);
-                    dnext = fma(-lj1, lj1, dd);
-                }
-                const double a = (row && lr > j) ? l : 0.0;
-                const double xs = Xm[jr] * isj;                    // lanes of row j: X[j][lr] / L[j][j]
-                const double bx = row ? xs : 0.0;
-                Dm[jr] = row ? (lr > j ? l : (lr == j ? sj : Dm[jr])) : Dm[jr];
-                Xm[jr] = row ? xs : Xm[jr];
-                if (j + 1 < BS) {
-                    Dm = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, a, Dm, 0, 0, 0);
-                    Xm = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, bx, Xm, 0, 0, 0);
+            for (int j = 0; j < BS; j += 2) {
+                const int jr = j >> 2, q0 = j & 3, q1 = q0 + 1;
+                const double d0 = dnext;
+                if (!(d0 > 0.0)) isbad = 1;      // (a non-positive pivot poisons what follows with NaN; the tile is reported failed)
+                const double s0 = rsq_newton(d0) * rmask[q0];
+                const double l0 = Dm[jr] * s0;                      // lanes of row j: L[lr][j] (lr == j: sqrt(d) = d / sqrt(d)); 0 elsewhere
+                const double x0 = Xm[jr] * s0;                      // lanes of row j: X[j][lr] / L[j][j], final
+                const double u = readlane_f64(l0, 16 * q0 + j + 1);               // L[j+1][j]
+                const double r1 = fma(-u, even_rows_to_odd(l0), Dm[jr]);          // lanes of row j+1: that row after pivot j's update
+                const double d1 = readlane_f64(r1, 16 * q1 + j + 1);
+                if (!(d1 > 0.0)) isbad = 1;
+                const double s1 = rsq_newton(d1) * rmask[q1];
+                const double l1 = r1 * s1;                                         // lanes of row j+1: L[lr][j+1]
+                const double x1 = fma(-u, even_rows_to_odd(x0), Xm[jr]) * s1;      // lanes of row j+1: X[j+1][lr], final
+                const double la = l0 + l1, xb = x0 + x1;
+                Ls[jr] += la;
+                Xs[jr] += xb;
+                if (j + 2 < BS) {
+                    // the NEXT pivot ahead of the update that produces it, so that its 1/sqrt chain does not wait for the matrix pipe
+                    const double dd = readlane_f64(Dm[(j + 2) >> 2], 16 * ((j + 2) & 3) + j + 2);
+                    const double a0 = readlane_f64(l0, 16 * q0 + j + 2), a1 = readlane_f64(l1, 16 * q1 + j + 2);
+                    dnext = fma(-a1, a1, fma(-a0, a0, dd));
+                    Dm = __builtin_amdgcn_mfma_f64_16x16x4f64(-la, la, Dm, 0, 0, 0);
+                    Xm = __builtin_amdgcn_mfma_f64_16x16x4f64(-la, xb, Xm, 0, 0, 0);
                 }
             }
-            // Dm holds L^T on and above its diagonal: register i of lane (lr, lk) is L[lr][lk + 4 i]
+            // Ls holds L^T on and above its diagonal: register i of lane (lr, lk) is L[lr][lk + 4 i]; Xs holds X = L^-1
             double* D = sA + bidx(kb, kb) * BSZ;
-            double* Xs = sD + kb * BSZ;
+            double* Xd = sD + kb * BSZ;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = lk + 4 * r;
-                D[lr * BP + c] = lr >= c ? Dm[r] : 0.0;
-                Xs[c * BP + lr] = Xm[r];
+                D[lr * BP + c] = lr >= c ? Ls[r] : 0.0;
+                Xd[c * BP + lr] = Xs[r];
             }
             if (isbad) *bad = 1;
             POTRF_STAMP();
-        } else {
+        } else if (helper) {
             if (kb >= 1) {
                 const int ks = kb - 1;
                 // column kb below its diagonal block first (wave 0 reads block (kb+1, kb) right behind the barrier) ...
-                for (int i = kb + w; i < NBK; i += NW - 1) {
+                for (int i = kb + 1 + hid; i < NBK; i += NH) {
                     double* Cb = sA + bidx(i, kb) * BSZ;
                     double4_t acc = blk_load_cd(Cb, lr, lk);
                     acc = blk_mma_nt(sA + bidx(i, ks) * BSZ, sA + bidx(kb, ks) * BSZ, acc, lr, lk, -1.0);
@@ -706,7 +734,7 @@ __device__ __forceinline__ void potrf_tile_mf(double* __restrict__ A, double* __
                 // ... then the rest of the trailing update of step ks: targets (i, j) with kb < j <= i
                 const int m = NBK - 1 - kb;
                 const int n_upd = m * (m + 1) / 2;
-                for (int t = w - 1; t < n_upd; t += NW - 1) {
+                for (int t = hid; t < n_upd; t += NH) {
                     int ii = 0;
                     while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
                     const int jj = t - ii * (ii + 1) / 2;
@@ -719,7 +747,7 @@ __device__ __forceinline__ void potrf_tile_mf(double* __restrict__ A, double* __
                 // row r = ks of L^-1 from L~(r,.) and the rows above (kept in registers until the barrier)
                 const int r = ks;
                 int nt = 0;
-                for (int j = w - 1; j < r; j += NW - 1, ++nt) {
+                for (int j = hid; j < r; j += NH, ++nt) {
                     double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
                     for (int k = j; k < r; ++k) {
                         const double* Y = (k == j) ? (sD + j * BSZ) : (sA + bidx(k, j) * BSZ);
@@ -731,10 +759,10 @@ __device__ __forceinline__ void potrf_tile_mf(double* __restrict__ A, double* __
         }
         __syncthreads();
         POTRF_STAMP();
-        if (w > 0 && kb >= 1) {
+        if (helper && kb >= 1) {
             const int r = kb - 1;
             int nt = 0;
-            for (int j = w - 1; j < r; j += NW - 1, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
+            for (int j = hid; j < r; j += NH, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
         }
         // ---------------- P2 ------------------------------------------------------------------------------
         // tasks 0 .. m-1: panel blocks (kb+1+t, kb); tasks m .. m+kb-1: row block (kb, t-m) -> global, then L~.
@@ -753,9 +781,9 @@ __device__ __forceinline__ void potrf_tile_mf(double* __restrict__ A, double* __
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Dm = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lt[r], Lt[r], Dm, 0, 0, 0);
                 }
-            } else {
+            } else if (helper) {
                 const int t0 = m > 0 ? 1 : 0;
-                for (int t = t0 + w - 1; t < m + kb; t += NW - 1) {
+                for (int t = t0 + hid; t < m + kb; t += NH) {
                     if (t < m) {
                         double* P = sA + bidx(kb + 1 + t, kb) * BSZ;
                         double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -770,7 +798,7 @@ __device__ __forceinline__ void potrf_tile_mf(double* __restrict__ A, double* __
                         blk_store_cd(Bk, acc, lr, lk, 1.0);  // same wave read it: LDS accesses of one wave stay in order
                     }
                 }
-                if (w == NW - 1) blk_to_tile<COH>(sA + bidx(kb, kb) * BSZ, A, rA, kb, kb, lane, 64);  // the diagonal block of L
+                if (hid == NH - 1) blk_to_tile<COH>(sA + bidx(kb, kb) * BSZ, A, rA, kb, kb, lane, 64);  // the diagonal block of L
             }
         }
         __syncthreads();
@@ -1385,7 +1413,8 @@ __global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowTask* __
 // launches (three per level plus their gaps: ~95 us per level for ~30 us of dependent work on final-13682, and the WHOLE
 // factorisation of the dense BAL shapes and of sphere2500).  Here every potrf, every 48-row strip of a panel solve and
 // of an update is one workgroup of a single launch; a workgroup waits for its inputs on per-tile version counters
-// (ver[slot] += 1 per finished strip, += 3 by a potrf; the n-th writer of a tile waits for 3 n) and publishes its own.
+// (ver[slot] += 1 per finished unit, nine units per tile and writer, += 9 by a potrf; the n-th writer of a tile waits for 9 n)
+// and publishes its own.
 // Units are listed in LEFT-LOOKING order -- per tile column: the updates into it (per target in source order, the same
 // summation order as the level launches: results are bit-identical), its potrf, its panel solves -- so a unit waits only
 // for units EARLIER in the list; workgroups are dispatched in blockIdx order, hence no deadlock whatever the residency
@@ -1396,54 +1425,95 @@ __global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowTask* __
 __device__ __forceinline__ void flow_wait_ge(const int* ver, int flag, int want, int tid, int* err) {
     if (flag >= 0) flow_wait(ver + flag, want, tid, err);   // (wave-uniform branch: the unit record)
 }
+// all of a unit's conditions in ONE polling loop -- lanes 0..2 of the first wave poll one counter each and vote: a poll is a
+// round trip to memory (~2 us), and three waits in a row cost three of them after the last counter moves
+__device__ __forceinline__ void flow_wait_unit(const int* ver, const FactorUnit& u, int tid, int* err) {
+    if (tid < 64) {
+        const int f = tid == 0 ? u.wait_flag[0] : (tid == 1 ? u.wait_flag[1] : (tid == 2 ? u.wait_flag[2] : -1));
+        const int want = tid == 0 ? u.wait_val[0] : (tid == 1 ? u.wait_val[1] : u.wait_val[2]);
+        int spins = 0;
+        for (;;) {
+            const bool ok = f < 0 || __hip_atomic_load(ver + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kFlowSpinLimit) { if (tid == 0) atomicOr(err, 1); break; }
+        }
+    }
+    __syncthreads();
+}
 
-__device__ __forceinline__ void flow_gemm_unit(const FactorUnit& u, double* __restrict__ sA, double* __restrict__ sB,
-                                               int* __restrict__ ver, int* __restrict__ err) {
+// An UPDATE unit: one 48 x 48 block (bi, bj) of C -= A B^T.  Nine waves, one 16 x 16 accumulator each; the two 48 x 144 operand
+// strips are requested in one go (12 16-byte loads per lane, one round trip) and staged whole -- no K loop, one barrier.
+// 36 MFMAs per wave, summed over k in the order of the level kernels (k ascending, four per instruction): same bits.
+constexpr int kFlowPK = NB + 2;   // LDS pitch of a full-K operand row: 292 dwords = 36 mod 64 -> conflict-free b64 operand reads
+__device__ __forceinline__ void flow_update_unit(const FactorUnit& u, double* __restrict__ sA, double* __restrict__ sB,
+                                                 int* __restrict__ ver, int* __restrict__ err, unsigned long long* __restrict__ trace) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
-    const int wr = w / 3, wc = w % 3;   // wave: rows 16 wr .. of the strip, columns 48 wc .. (three 16-wide accumulators)
-    const bool solve = u.kind == 1;
+    const int wr = w / 3, wc = w % 3;
+    const int bi = u.strip / 3, bj = u.strip % 3;
     const __amdgpu_buffer_rsrc_t rC = coh_rsrc(u.C), rA = coh_rsrc(u.A), rB = coh_rsrc(u.B);
-    const int row0 = 48 * u.strip;
-    // (1) the previous writer of the target: the old values of the strip are requested first and consumed last
-    flow_wait_ge(ver, u.wait_flag[0], u.wait_val[0], tid, err);
-    double cv[3][4];
-    if (!solve) {
+    flow_wait_unit(ver, u, tid, err);   // the previous writer of the target is done, both operands are final
+    if (trace && tid == 0) trace[1] = wall_clock64();
+    double cv[4];   // the old values of the block: requested with the operands, consumed last
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+    for (int r = 0; r < 4; ++r) cv[r] = coh_ld1(rC, (48 * bi + 16 * wr + lk + 4 * r) * NB + 48 * bj + 16 * wc + lr);
+    constexpr int C2 = NB / 2, NR = 48 * C2 / 576;   // 72 double2 per row, 6 per thread and operand
+    static_assert(48 * C2 % 576 == 0, "staging loops assume whole rounds");
+    double2 ra[NR], rb[NR];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cv[j][r] = coh_ld1(rC, (row0 + 16 * wr + lk + 4 * r) * NB + 48 * wc + 16 * j + lr);
+    for (int i = 0; i < NR; ++i) {
+        const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+        ra[i] = tile_ld2<true>(u.A, rA, (48 * bi + row) * NB + 2 * c2);
+        rb[i] = tile_ld2<true>(u.B, rB, (48 * bj + row) * NB + 2 * c2);
     }
-    // (2) the operands are final: ALL of K requested at once (one round trip instead of three), staged chunk by chunk
-    flow_wait_ge(ver, u.wait_flag[1], u.wait_val[1], tid, err);
-    flow_wait_ge(ver, u.wait_flag[2], u.wait_val[2], tid, err);
-    constexpr int C2 = KS / 2, NCH = NB / KS, NRA = 48 * C2 / 576, NRB = NB * C2 / 576;   // per chunk: 2 and 6 double2 per thread
-    static_assert(48 * C2 % 576 == 0 && NB * C2 % 576 == 0 && NB % KS == 0, "staging loops assume whole rounds");
-    double2 ra[NCH][NRA], rb[NCH][NRB];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int i = 0; i < NR; ++i) {
+        const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+        sA[row * kFlowPK + 2 * c2] = ra[i].x; sA[row * kFlowPK + 2 * c2 + 1] = ra[i].y;
+        sB[row * kFlowPK + 2 * c2] = rb[i].x; sB[row * kFlowPK + 2 * c2 + 1] = rb[i].y;
+    }
+    __syncthreads();
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const double* pa = sA + (16 * wr + lr) * kFlowPK + lk;
+    const double* pb = sB + (16 * wc + lr) * kFlowPK + lk;
 #pragma unroll
-        for (int i = 0; i < NRA; ++i) {
-            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
-            ra[c][i] = tile_ld2<true>(u.A, rA, (row0 + row) * NB + KS * c + 2 * c2);
-        }
+    for (int kk = 0; kk < NB; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kk], pb[kk], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        coh_st1(rC, (48 * bi + 16 * wr + lk + 4 * r) * NB + 48 * bj + 16 * wc + lr, -1.0 * acc[r] + 1.0 * cv[r]);
+    flow_publish(ver + u.pub, tid);
+}
+
+// A PANEL-SOLVE unit: rows 16 s .. 16 s + 15 of C = A Linv^T IN PLACE (C aliases A): a unit reads only the rows it
+// writes, all of them before its first store, so the nine units of a tile do not race.  Wave w owns the 16 x 16 block of
+// columns 16 w; Linv comes whole (18 16-byte loads per lane in flight at once) and is staged in three 48-wide K chunks.
+__device__ __forceinline__ void flow_solve_unit(const FactorUnit& u, double* __restrict__ sA, double* __restrict__ sB,
+                                                int* __restrict__ ver, int* __restrict__ err, unsigned long long* __restrict__ trace) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int row0 = 16 * u.strip;
+    const __amdgpu_buffer_rsrc_t rC = coh_rsrc(u.C), rB = coh_rsrc(u.B);
+    constexpr int C2 = KS / 2, NCH = NB / KS, NRB = NB * C2 / 576;   // per chunk: 16 x 24 double2 of A (lanes < 384), 6 per thread of B
+    static_assert(NB * C2 % 576 == 0 && 16 * C2 <= 576, "staging loops assume whole rounds");
+    flow_wait_unit(ver, u, tid, err);   // the tile carries all its updates, L^-1 of the column's diagonal tile is there
+    if (trace && tid == 0) trace[1] = wall_clock64();
+    double2 ra[NCH], rb[NCH][NRB];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (tid < 16 * C2) ra[c] = tile_ld2<true>(u.C, rC, (row0 + tid / C2) * NB + KS * c + 2 * (tid % C2));
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int i = 0; i < NRB; ++i) {
             const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
             rb[c][i] = tile_ld2<true>(u.B, rB, row * NB + KS * c + 2 * c2);
         }
-    }
-    double4_t acc[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NRA; ++i) {
-            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
-            sA[row * PS + 2 * c2] = ra[c][i].x; sA[row * PS + 2 * c2 + 1] = ra[c][i].y;
-        }
+        if (tid < 16 * C2) { const int row = tid / C2, c2 = tid % C2; sA[row * PS + 2 * c2] = ra[c].x; sA[row * PS + 2 * c2 + 1] = ra[c].y; }
 #pragma unroll
         for (int i = 0; i < NRB; ++i) {
             const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
@@ -1451,43 +1521,40 @@ __device__ __forceinline__ void flow_gemm_unit(const FactorUnit& u, double* __re
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < KS; kk += 4) {
-            const double a = sA[(16 * wr + lr) * PS + kk + lk];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const double b = sB[(48 * wc + 16 * j + lr) * PS + kk + lk];
-                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
-            }
-        }
+        for (int kk = 0; kk < KS; kk += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[lr * PS + kk + lk], sB[(16 * w + lr) * PS + kk + lk], acc, 0, 0, 0);
     }
-    // (the panel solve is in place: every read of the strip's rows happened above, and the other strips' rows are not ours)
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double v = solve ? acc[j][r] : -1.0 * acc[j][r] + 1.0 * cv[j][r];
-            coh_st1(rC, (row0 + 16 * wr + lk + 4 * r) * NB + 48 * wc + 16 * j + lr, v);
-        }
+    for (int r = 0; r < 4; ++r) coh_st1(rC, (row0 + lk + 4 * r) * NB + 16 * w + lr, acc[r]);
     flow_publish(ver + u.pub, tid);
 }
 
 constexpr int kFlowFactorThreads = 576;
 __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const FactorUnit* __restrict__ units, int* __restrict__ ver,
-                                                                     int* __restrict__ fail, int* __restrict__ err) {
+                                                                     int* __restrict__ fail, int* __restrict__ err,
+                                                                     unsigned long long* __restrict__ trace) {
     __shared__ double smem[(NLB + NBK) * BSZ];   // potrf: the tile's 45 lower blocks + 9 inverted diagonal blocks; product: sA | sB
     __shared__ int bad;
-    static_assert((48 + NB) * PS <= (NLB + NBK) * BSZ, "the product's staging area fits in the potrf's");
+    static_assert((16 + NB) * PS <= (NLB + NBK) * BSZ && 2 * 48 * kFlowPK <= (NLB + NBK) * BSZ, "the products' staging areas fit in the potrf's");
     const FactorUnit u = units[blockIdx.x];
     const int tid = threadIdx.x;
+    if (trace) {   // (tools/flow_bench: 100 MHz stamps per unit -- dispatched, inputs ready, done)
+        trace += 3 * (size_t)blockIdx.x;
+        if (tid == 0) trace[0] = wall_clock64();
+    }
     if (u.kind == 0) {
         flow_wait_ge(ver, u.wait_flag[0], u.wait_val[0], tid, err);
+        if (trace && tid == 0) trace[1] = wall_clock64();
         potrf_tile_mf<kFlowFactorThreads / 64, true>(u.C, const_cast<double*>(u.A), u.strip, fail, smem, smem + NLB * BSZ, &bad);
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ver + u.pub, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(ver + u.pub, kFlowUnitsPerTile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (u.kind == 1) {
+        flow_solve_unit(u, smem, smem + 16 * PS, ver, err, trace);
     } else {
-        flow_gemm_unit(u, smem, smem + 48 * PS, ver, err);
+        flow_update_unit(u, smem, smem + 48 * kFlowPK, ver, err, trace);
     }
+    if (trace && tid == 0) trace[2] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1756,9 +1823,9 @@ __global__ __launch_bounds__(64) void k_gate(const int* __restrict__ arrived, in
 void launch_gate(const int* arrived, int expected, int max_micros, hipStream_t s) {
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, arrived, expected, (long long)max_micros * 100);
 }
-void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, hipStream_t s) {
+void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, hipStream_t s, unsigned long long* trace) {
     if (n_units <= 0) return;
-    hipLaunchKernelGGL(k_factor_flow, dim3(n_units), dim3(kFlowFactorThreads), 0, s, units, ver, fail, err);
+    hipLaunchKernelGGL(k_factor_flow, dim3(n_units), dim3(kFlowFactorThreads), 0, s, units, ver, fail, err, trace);
 }
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s, int* arrived) {
     if (n <= 0) return;

@@ -12,7 +12,11 @@
 //                                                   kernels -- where RCCL cannot even be initialised with two ranks.
 // All calls are collective, issued in the same order on every rank, and enqueue on / synchronise with `stream`.
 #pragma once
+#ifdef APEX_COMM_HOST_ONLY   // tests/comm_host_harness.cpp: the shm transport on HOST buffers, built with g++ (no HIP, no GPU)
+typedef void* hipStream_t;
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stddef.h>
 
 #include <memory>

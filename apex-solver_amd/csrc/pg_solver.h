@@ -102,6 +102,7 @@ class PoseGraphSolver : public LmBackend {
     int n_factor_flow_timeouts_ = 0;
     uint32_t* prior_v_ = nullptr;
     double* prior_data_ = nullptr;
+    double* prior_res_ = nullptr;   // staging of get_prior_residual
     double* meas_ = nullptr;
     uint8_t* fix_ = nullptr;
     double *g_ = nullptr, *rhs_ = nullptr, *d_ = nullptr, *work_ = nullptr, *partial_ = nullptr, *scal_ = nullptr;

@@ -40,7 +40,7 @@ PoseGraphSolver::PoseGraphSolver(int64_t n_v, int64_t n_e, int device) : n_v_(n_
 PoseGraphSolver::~PoseGraphSolver() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], posep_[0], posep_[1], e_from_, e_to_, meas_, fix_, g_, rhs_, d_, work_, partial_, scal_, scale_};
+    void* ptrs[] = {poses_[0], poses_[1], posep_[0], posep_[1], e_from_, e_to_, meas_, fix_, g_, rhs_, d_, work_, partial_, scal_, scale_, prior_v_, prior_data_, prior_res_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -70,6 +70,7 @@ int PoseGraphSolver::set_priors(int64_t n, const uint32_t* vertex, const double*
     HIP_TRY(hipStreamSynchronize(stream_));
     if (prior_v_) { (void)hipFree(prior_v_); prior_v_ = nullptr; }
     if (prior_data_) { (void)hipFree(prior_data_); prior_data_ = nullptr; }
+    if (prior_res_) { (void)hipFree(prior_res_); prior_res_ = nullptr; }
     n_prior_ = (int)n;
     have_step_ = have_trial_ = false;
     if (n == 0) return kOk;
@@ -91,13 +92,10 @@ int PoseGraphSolver::get_prior_residual(double* r7_out) {
     if (!have_params_) return fail(kInvalidState, "no parameters set");
     if (n_prior_ == 0) return kOk;
     HIP_TRY(hipSetDevice(device_));
-    double* d = nullptr;
-    HIP_TRY(hipMalloc(&d, (size_t)n_prior_ * 7 * sizeof(double)));
-    launch_pg_prior_export(view(cur_), d, stream_);
-    hipError_t e = hipMemcpyAsync(r7_out, d, (size_t)n_prior_ * 7 * sizeof(double), hipMemcpyDeviceToHost, stream_);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream_);
-    (void)hipFree(d);
-    HIP_TRY(e);
+    if (!prior_res_) HIP_TRY(hipMalloc(&prior_res_, (size_t)n_prior_ * 7 * sizeof(double)));   // kept with the priors (set_priors frees it)
+    launch_pg_prior_export(view(cur_), prior_res_, stream_);
+    HIP_TRY(hipMemcpyAsync(r7_out, prior_res_, (size_t)n_prior_ * 7 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
     return kOk;
 }
 

@@ -101,9 +101,13 @@ class TilePlan {
     void set_factor_flow(int max_cols, int max_rows) { flow_cols_ = max_cols; if (max_rows > 0) flow_rows_ = max_rows; }
     int factor_flow_groups() const { return (flow_g1_[0] - flow_g0_[0]) + (flow_g1_[1] - flow_g0_[1]); }   // level groups inside the dataflow launches
     int factor_flow_cols() const { return flow_cols_; }
+    double factor_flow_sim_us() const { return flow_sim_us_[0] + flow_sim_us_[1]; }
     int factor_flow_units() const { return flow_n_[0] + flow_n_[1]; }
     // A dataflow factorisation whose waits ran into their spin limit leaves the tiles half updated: factor() reports it here
     // (once) and the plan goes back to the level launches for good; the caller re-assembles and factorises again.
+    // tools/flow_bench: per-unit stamps of the next factorisations (dispatched, inputs ready, done; 100 MHz) + the unit list
+    hipError_t enable_flow_trace();
+    hipError_t read_flow_trace(std::vector<FactorUnit>* units, std::vector<unsigned long long>* stamps);
     bool factor_flow_gave_up() { const bool g = flow_gave_up_; flow_gave_up_ = false; return g; }
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
     hipError_t read_flags(int* failed_at);   // pivot flag of the last factorisation (syncs)
@@ -201,9 +205,11 @@ class TilePlan {
     void post_sweep_status(bool reduce);
     FactorUnit* flow_units_ = nullptr;   // dataflow factorisation of the top groups: [phase 0 units | phase 1 units]
     int* flow_ver_ = nullptr;            // per tile slot: finished strips of in-launch writers
+    unsigned long long* flow_trace_ = nullptr;
     int flow_cols_ = 6, flow_rows_ = 24;
     int flow_g0_[2] = {0, 0}, flow_g1_[2] = {0, 0};   // per phase (local groups / top groups): the groups inside the launch
     int flow_first_[2] = {0, 0}, flow_n_[2] = {0, 0};
+    double flow_sim_us_[2] = {0.0, 0.0};   // makespan of the list schedule that ordered the units (build())
     bool flow_on_ = true, flow_gave_up_ = false;
     int n_flow_tasks_ = 0, n_flow_bwd_ = 0, n_flow_parts_ = 0;
     int n_flow_local_ = 0;   // distributed plans: the forward tasks of phase 0 (the rest: the top columns, phase 1)

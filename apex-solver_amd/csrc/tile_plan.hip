@@ -99,14 +99,14 @@ std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool 
 
 void TilePlan::release() {
     void* ptrs[] = {tiles_, linv_, slot_, diag_slot_, flag_, potrf_tasks_, trsm_tasks_, upd_tasks_, tri_fwd_, tri_bwd_,
-                    flow_fwd_, flow_bwd_, flow_part_, flow_flags_, flow_units_, flow_ver_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_, gate_cnt_};
+                    flow_fwd_, flow_bwd_, flow_part_, flow_flags_, flow_units_, flow_ver_, flow_trace_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_, gate_cnt_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = exch_ = nullptr;
     slot_ = diag_slot_ = flag_ = sym_row_ptr_ = cls_ = nullptr;
     potrf_tasks_ = nullptr; trsm_tasks_ = upd_tasks_ = nullptr; tri_fwd_ = tri_bwd_ = nullptr;
     flow_fwd_ = flow_bwd_ = nullptr; flow_part_ = nullptr; flow_flags_ = nullptr; n_flow_tasks_ = 0;
-    flow_units_ = nullptr; flow_ver_ = nullptr; flow_n_[0] = flow_n_[1] = 0; flow_on_ = true; flow_gave_up_ = false;
+    flow_units_ = nullptr; flow_ver_ = nullptr; flow_trace_ = nullptr; flow_n_[0] = flow_n_[1] = 0; flow_on_ = true; flow_gave_up_ = false;
     sym_tiles_ = nullptr; sym_entries_ = nullptr;
     gate_cnt_ = nullptr;
     for (int i = 0; i < kGraphs; ++i) {
@@ -563,6 +563,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
                 }
         }
         std::sort(outside.begin(), outside.end());
+        constexpr int W = kFlowUnitsPerTile;
         std::vector<int> running((size_t)n_slots_, 0);
         bool order_ok = true;
         auto emit = [&](FactorUnit u, int inc) {
@@ -576,26 +577,108 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             const int st = slot_of(I, J);
             for (int n = 0; n < n_upd_of(st); ++n) {
                 const int K = src_of[(size_t)st][n], sa = slot_of(I, K), sb = slot_of(J, K);
-                for (int sp = 0; sp < 3; ++sp)
+                for (int sp = 0; sp < W; ++sp)
                     emit(FactorUnit{tile_ptr(I, J), tile_ptr(I, K), tile_ptr(J, K), {n > 0 ? st : -1, sa, sb},
-                                    {3 * n, 3 * (n_upd_of(sa) + 1), 3 * (n_upd_of(sb) + 1)}, st, 2, sp, 0}, 1);
+                                    {W * n, W * (n_upd_of(sa) + 1), W * (n_upd_of(sb) + 1)}, st, 2, sp, 0}, 1);
             }
         };
         for (int J : cols) {
             const int sd = slot_of(J, J), nd = n_upd_of(sd);
             emit_updates(J, J);
             for (int I : col_rows[J]) emit_updates(I, J);
-            emit(FactorUnit{tile_ptr(J, J), linv_ptr(J), nullptr, {nd > 0 ? sd : -1, -1, -1}, {3 * nd, 0, 0}, sd, 0, J, 0}, 3);
+            emit(FactorUnit{tile_ptr(J, J), linv_ptr(J), nullptr, {nd > 0 ? sd : -1, -1, -1}, {W * nd, 0, 0}, sd, 0, J, 0}, W);
             for (int I : col_rows[J]) {
                 const int st = slot_of(I, J), n = n_upd_of(st);
-                for (int sp = 0; sp < 3; ++sp)
-                    emit(FactorUnit{tile_ptr(I, J), tile_ptr(I, J), linv_ptr(J), {n > 0 ? st : -1, -1, sd}, {3 * n, 0, 3 * (nd + 1)}, st, 1, sp, 0}, 1);
+                for (int sp = 0; sp < W; ++sp)
+                    emit(FactorUnit{tile_ptr(I, J), tile_ptr(I, J), linv_ptr(J), {n > 0 ? st : -1, -1, sd}, {W * n, 0, W * (nd + 1)}, st, 1, sp, 0}, 1);
             }
         }
         for (const auto& t : outside) emit_updates(t.second, t.first);
         if (!order_ok) return "internal error: a dataflow factorisation unit waits for a later one";
         flow_g0_[ph] = gf;
         flow_n_[ph] = (int)funits.size() - flow_first_[ph];
+        // ---- dispatch order = the start order of a simulated list schedule -------------------------------------------------
+        // Workgroups are dispatched in list order, one per CU: the launch works through a WINDOW of ~256 consecutive units.
+        // In plain left-looking order that window fills up with units that wait for the current column while units further
+        // down the list -- updates whose sources were finished long ago -- cannot start: the bulk ends up serialised behind
+        // the critical chain, and the chain then waits for the bulk (measured: tools/flow_bench).  So the units are listed in
+        // the order in which a 240-processor list schedule STARTS them (a unit becomes ready when the versions it waits for
+        // are reached; among ready units the one with the longest remaining chain goes first).  A unit starts after its
+        // producers finish, hence after they started: still a topological order, re-checked below.
+        {
+            const int base = flow_first_[ph], n = flow_n_[ph];
+            auto cost_of = [](const FactorUnit& u) { return u.kind == 0 ? 34.0 : (u.kind == 1 ? 10.0 : 8.0); };   // us, with the hop
+            auto inc_of = [](const FactorUnit& u) { return u.kind == 0 ? W : 1; };
+            std::vector<int> writer(n);           // which writer of its tile a unit belongs to
+            {
+                std::vector<int> cnt((size_t)n_slots_, 0);
+                for (int x = 0; x < n; ++x) { const FactorUnit& u = funits[base + x]; writer[x] = cnt[(size_t)u.pub] / W; cnt[(size_t)u.pub] += inc_of(u); }
+            }
+            // remaining chain (bottom level) through the tile-version nodes (slot, writer)
+            std::vector<int> node0((size_t)n_slots_ + 1, 0);
+            for (int sl = 0; sl < n_slots_; ++sl) node0[(size_t)sl + 1] = node0[(size_t)sl] + n_upd_of(sl) + 1;
+            std::vector<double> node_bl((size_t)node0[(size_t)n_slots_], 0.0), bl(n, 0.0);
+            for (int x = n - 1; x >= 0; --x) {
+                const FactorUnit& u = funits[base + x];
+                bl[x] = cost_of(u) + node_bl[(size_t)node0[(size_t)u.pub] + writer[x]];
+                for (int q = 0; q < 3; ++q)
+                    if (u.wait_flag[q] >= 0) {
+                        double& nb = node_bl[(size_t)node0[(size_t)u.wait_flag[q]] + u.wait_val[q] / W - 1];
+                        nb = std::max(nb, bl[x]);
+                    }
+            }
+            // event simulation
+            std::vector<std::vector<std::pair<int, int>>> waiters((size_t)n_slots_);   // per flag: (value, unit)
+            std::vector<int> pending(n, 0), ver_sim((size_t)n_slots_, 0), order;
+            order.reserve(n);
+            for (int x = 0; x < n; ++x) {
+                const FactorUnit& u = funits[base + x];
+                for (int q = 0; q < 3; ++q)
+                    if (u.wait_flag[q] >= 0) { waiters[(size_t)u.wait_flag[q]].push_back({u.wait_val[q], x}); ++pending[x]; }
+            }
+            std::vector<size_t> woke((size_t)n_slots_, 0);
+            for (auto& wl : waiters) std::sort(wl.begin(), wl.end());
+            auto worse = [&](int a, int b) { return bl[a] != bl[b] ? bl[a] < bl[b] : a > b; };   // heap top = longest chain, then list order
+            std::vector<int> ready;
+            for (int x = 0; x < n; ++x) if (pending[x] == 0) ready.push_back(x);
+            std::make_heap(ready.begin(), ready.end(), worse);
+            std::vector<std::pair<double, int>> running_ev;   // min-heap of (finish time, unit)
+            auto later = [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a > b; };
+            int free_p = 240;
+            double now = 0.0;
+            while ((int)order.size() < n) {
+                while (free_p > 0 && !ready.empty()) {
+                    std::pop_heap(ready.begin(), ready.end(), worse);
+                    const int x = ready.back(); ready.pop_back();
+                    order.push_back(x); --free_p;
+                    running_ev.push_back({now + cost_of(funits[base + x]), x});
+                    std::push_heap(running_ev.begin(), running_ev.end(), later);
+                }
+                if (running_ev.empty()) return "internal error: the dataflow units do not form a schedule";
+                std::pop_heap(running_ev.begin(), running_ev.end(), later);
+                const std::pair<double, int> ev = running_ev.back(); running_ev.pop_back();
+                now = ev.first; ++free_p;
+                const FactorUnit& u = funits[base + ev.second];
+                const size_t f = (size_t)u.pub;
+                ver_sim[f] += inc_of(u);
+                while (woke[f] < waiters[f].size() && waiters[f][woke[f]].first <= ver_sim[f]) {
+                    const int x = waiters[f][woke[f]++].second;
+                    if (--pending[x] == 0) { ready.push_back(x); std::push_heap(ready.begin(), ready.end(), worse); }
+                }
+            }
+            flow_sim_us_[ph] = now;
+            std::vector<FactorUnit> sorted(n);
+            for (int i = 0; i < n; ++i) sorted[i] = funits[base + order[i]];
+            std::fill(running.begin(), running.end(), 0);
+            for (int i = 0; i < n; ++i) {
+                const FactorUnit& u = sorted[i];
+                for (int q = 0; q < 3; ++q)
+                    if (u.wait_flag[q] >= 0 && running[(size_t)u.wait_flag[q]] < u.wait_val[q]) order_ok = false;
+                running[(size_t)u.pub] += inc_of(u);
+                funits[base + i] = u;
+            }
+            if (!order_ok) return "internal error: the scheduled dataflow order is not topological";
+        }
     }
     TP_TRY(upload(&flow_units_, funits));
     if (flow_ver_) { (void)hipFree(flow_ver_); flow_ver_ = nullptr; }
@@ -823,7 +906,8 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     }
     if (g1 < g_end) {   // every update the level launches add to the region's tiles is in: the joins above
         (void)hipMemsetAsync(flow_ver_, 0, (size_t)n_slots_ * sizeof(int), stream_);
-        launch_factor_flow(flow_units_ + flow_first_[ph], flow_n_[ph], flow_ver_, flag_, flag_ + 1, stream_);
+        launch_factor_flow(flow_units_ + flow_first_[ph], flow_n_[ph], flow_ver_, flag_, flag_ + 1, stream_,
+                           flow_trace_ ? flow_trace_ + 3 * (size_t)flow_first_[ph] : nullptr);
     }
 }
 
@@ -921,6 +1005,25 @@ void TilePlan::enable_tri_flow(bool on) {
     tri_flow_ = on;
     for (int which : {1, 2, 4, 5})   // the captured sweeps change
         if (graph_exec_[which]) { (void)hipGraphExecDestroy(graph_exec_[which]); graph_exec_[which] = nullptr; }
+}
+
+hipError_t TilePlan::enable_flow_trace() {
+    if (flow_trace_) return hipSuccess;
+    const size_t n = 3 * (size_t)std::max(flow_n_[0] + flow_n_[1], 1);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&flow_trace_), n * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    for (int which : {0, 3})   // the captured launches hold the old (null) pointer
+        if (graph_exec_[which]) { (void)hipGraphExecDestroy(graph_exec_[which]); graph_exec_[which] = nullptr; }
+    return hipMemset(flow_trace_, 0, n * sizeof(unsigned long long));
+}
+
+hipError_t TilePlan::read_flow_trace(std::vector<FactorUnit>* units, std::vector<unsigned long long>* stamps) {
+    const size_t n = (size_t)(flow_n_[0] + flow_n_[1]);
+    units->resize(n); stamps->resize(3 * n);
+    if (n == 0 || !flow_trace_) return hipErrorNotInitialized;
+    hipError_t e = hipMemcpy(units->data(), flow_units_, n * sizeof(FactorUnit), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(stamps->data(), flow_trace_, 3 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
 
 void TilePlan::top_slot_ranges(std::pair<int64_t, int64_t> out[2]) const {
