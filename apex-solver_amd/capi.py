@@ -25,7 +25,7 @@ SYMBOLS = (
     "apexgpu_parameter_norm", "apexgpu_column_norms", "apexgpu_set_column_scaling", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
     "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_get_hessian_csc", "apexgpu_debug_invert_blocks", "apexgpu_debug_pair_lists", "apexgpu_debug_host_structure", "apexgpu_setup_times", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
     "apexgpu_stage_times", "apexgpu_info", "apexgpu_counters", "apexgpu_debug_pair_phases", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_comm_init_shm", "apexgpu_set_shard", "apexgpu_shard_range",
-    "apexgpu_debug_lockstep_solve", "apexgpu_export_step", "apexgpu_owned_landmarks", "apexgpu_debug_partition",
+    "apexgpu_debug_lockstep_solve", "apexgpu_export_step", "apexgpu_owned_landmarks", "apexgpu_debug_partition", "apexgpu_debug_check_schedule",
     "apexgpu_bal_open", "apexgpu_bal_close", "apexgpu_bal_last_error", "apexgpu_bal_sizes", "apexgpu_bal_raw",
     "apexgpu_bal_variables", "apexgpu_reference_columns",
     # SE3 pose-graph backend
@@ -121,6 +121,7 @@ def load() -> C.CDLL:
     L.apexgpu_export_step.argtypes = [vp, vp, vp]
     L.apexgpu_owned_landmarks.argtypes = [vp, vp]
     L.apexgpu_debug_partition.argtypes = [C.c_int, vp, C.c_int, vp]
+    L.apexgpu_debug_check_schedule.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_char_p, C.c_int]
     L.apexgpu_set_column_scaling.argtypes = [vp, vp]
     L.apexgpu_lm_optimize.argtypes = [vp, C.POINTER(LmConfigC), C.POINTER(LmResultC), vp, C.c_int]
     L.apexgpu_get_residual.argtypes = [vp, vp]
@@ -209,6 +210,24 @@ def tile_partition(present: np.ndarray, world: int):
     if n_top < 0:
         raise LinAlgError(n_top, "apexgpu_debug_partition")
     return owner, n_top
+
+
+def check_schedule(present: np.ndarray, world: int = 1, rank: int = 0, two_side: int = 1, overlap: int = 1, split_u1: int = 4,
+                   flood_gate: int = 256, factor_flow: int = -1, factor_flow_rows: int = 24, old_idle_level_bug: bool = False,
+                   drop_wait: int = -1) -> dict:
+    """Host-only race check of the factorisation's launch sequence for one tile structure (apexgpu_debug_check_schedule)."""
+    L = load()
+    pr = np.ascontiguousarray(present, dtype=np.uint8)
+    nt = pr.shape[0]
+    opts = np.array([two_side, overlap, split_u1, flood_gate, factor_flow, factor_flow_rows, int(old_idle_level_bug), drop_wait], dtype=np.int32)
+    out = np.zeros(8, dtype=np.int64)
+    msg = C.create_string_buffer(512)
+    rc = L.apexgpu_debug_check_schedule(nt, pr.ctypes.data_as(C.c_void_p), int(world), int(rank), opts.ctypes.data_as(C.c_void_p),
+                                        out.ctypes.data_as(C.c_void_p), msg, 512)
+    if rc < 0:
+        raise LinAlgError(rc, "apexgpu_debug_check_schedule: " + msg.value.decode())
+    return dict(levels=rc, calls=int(out[0]), launches=int(out[1]), violations=int(out[2]) + int(out[3]), violations_top=int(out[3]),
+                flow_units=int(out[4]), flow_groups=int(out[5]), waits=int(out[6]), dropped=bool(out[7]), first=msg.value.decode())
 
 
 HOST_STRUCTURE_STATS = ("tile_rows", "hub_cameras", "border_tiles", "touched_tiles", "tiles", "etree_levels", "top_columns",

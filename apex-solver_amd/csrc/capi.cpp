@@ -213,6 +213,42 @@ int apexgpu_debug_partition(int nt, const uint8_t* present, int world, int* owne
     });
 }
 
+int apexgpu_debug_check_schedule(int nt, const uint8_t* present, int world, int rank, const int opts[8], int64_t out[8], char* msg, int msg_len) {
+    if (nt <= 0 || !present || !opts || !out || world < 1 || rank < 0 || rank >= world) return APEXGPU_ERR_INVALID_INPUT;
+    return guarded([&]() -> int {
+    apex::TilePlan tp;
+    if (world > 1) tp.set_partition(rank, world);
+    tp.set_two_side(opts[0]);
+    tp.enable_overlap(opts[1] != 0); if (opts[1] > 1) tp.set_overlap_min(opts[1]);
+    tp.set_split_u1(opts[2]);
+    tp.set_gate_min(opts[3]);
+    tp.set_factor_flow(opts[4], opts[5]);
+    tp.debug_skip_idle_level_wait(opts[6] != 0);
+    const std::vector<uint8_t> pr(present, present + (size_t)nt * nt);
+    const std::string e = tp.build_host_only(nt, pr);
+    std::string first;
+    if (!e.empty()) { if (msg && msg_len > 0) snprintf(msg, (size_t)msg_len, "%s", e.c_str()); return APEXGPU_ERR_INVALID_STATE; }
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int ph = 0; ph < 2; ++ph) {
+        std::vector<apex::SchedOp> ops = tp.schedule_trace(ph);
+        if (opts[7] >= 0 && ph == 0) {   // drop the opts[7]-th stream wait of the sequence: the checker must notice when it mattered
+            int seen = 0;
+            for (size_t i = 0; i < ops.size(); ++i)
+                if (ops[i].op == 2 && seen++ == opts[7]) { ops.erase(ops.begin() + (long)i); out[7] = 1; break; }
+        }
+        std::string why;
+        const int bad = tp.check_schedule(ops, &why);
+        out[0] += (int64_t)ops.size();
+        for (const apex::SchedOp& o : ops) { out[1] += o.op == 0; out[6] += o.op == 2; }
+        out[2 + ph] = bad;
+        if (bad && first.empty()) first = why;
+    }
+    out[4] = tp.factor_flow_units(); out[5] = tp.factor_flow_groups();
+    if (msg && msg_len > 0) snprintf(msg, (size_t)msg_len, "%s", first.c_str());
+    return tp.n_levels();
+    });
+}
+
 int apexgpu_owned_landmarks(apexgpu_solver* h, uint8_t* mask) {
     H_OR_FAIL;
     if (!mask) return APEXGPU_ERR_INVALID_INPUT;

@@ -28,6 +28,16 @@
 
 namespace apex {
 
+// One call of the factorisation's launch sequence, as TilePlan::schedule_trace records it instead of issuing it.
+struct SchedOp {
+    int op;             // 0 launch, 1 event record, 2 stream waits for event
+    uintptr_t stream;   // the stream the call goes to
+    uintptr_t event;    // record / wait: the event
+    int list;           // launch: 0 potrf, 1 panel solves, 2 updates, 3 the dataflow launch
+    int64_t first;      // launch: first task (unit) of its list
+    int count;          // ... and how many
+};
+
 class TilePlan {
    public:
     TilePlan() = default;
@@ -43,6 +53,18 @@ class TilePlan {
     // present: lower-triangular nt x nt 0/1 structure (I >= J) in the FINAL order.
     // Returns "" on success or an error message.
     std::string build(int nt, const std::vector<uint8_t>& present, hipStream_t stream);
+    // build() without a device (tests): the same lists and decisions on made-up addresses; inspect with schedule_trace /
+    // check_schedule / flow_units_host.  Nothing on such a plan may be launched.
+    std::string build_host_only(int nt, const std::vector<uint8_t>& present);
+    // The launch sequence of one factorisation phase (0: the local level groups / everything, 1: the shared top of a
+    // distributed plan) exactly as enqueue_factor issues it, recorded instead of issued.
+    std::vector<SchedOp> schedule_trace(int phase);
+    // Proves a recorded sequence race free: stream order + event edges give a happens-before relation; every two launches
+    // that touch one tile, at least one of them writing it, must be ordered by it, and no two tasks of one launch may write
+    // one tile (or one read what another writes).  Returns the number of violations (0 = proven) and describes the first.
+    int check_schedule(const std::vector<SchedOp>& ops, std::string* first_violation) const;
+    const std::vector<FactorUnit>& flow_units_host() const { return flow_units_h_; }
+    void debug_skip_idle_level_wait(bool on) { debug_skip_idle_wait_ = on; }
     // The host half of build() alone: symbolic fill, partition, slot map, level count (slot_host(), n_slots(),
     // n_touched_slots(), n_levels(), op_counts() are valid afterwards; nothing is allocated on a device).
     void build_symbolic(int nt, const std::vector<uint8_t>& present);
@@ -96,8 +118,8 @@ class TilePlan {
     void set_gate_pos(int p) { gate_pos_ = p; }   // 0: in front of U2a, 1: between U2a and U2b
     void set_gate_min(int n) { gate_min_ = n; }   // flood gate in front of U2 batches of at least n tasks (0: off); before the first factor()
     // The top of the elimination tree as one dataflow launch (k_factor_flow): the trailing level groups of a phase whose
-    // groups have at most max_cols columns each, every column with at most max_rows off-diagonal tiles.  0 columns: off.
-    // Before build().
+    // groups have at most max_cols columns each, every column with at most max_rows off-diagonal tiles.  0 columns: off;
+    // < 0 (default): where the launch starts is chosen by a cost model.  Before build().
     void set_factor_flow(int max_cols, int max_rows) { flow_cols_ = max_cols; if (max_rows > 0) flow_rows_ = max_rows; }
     int factor_flow_groups() const { return (flow_g1_[0] - flow_g0_[0]) + (flow_g1_[1] - flow_g0_[1]); }   // level groups inside the dataflow launches
     int factor_flow_cols() const { return flow_cols_; }
@@ -203,10 +225,16 @@ class TilePlan {
     int poison_ = 0;
     hipStream_t occ_stream_ = nullptr;
     void post_sweep_status(bool reduce);
+    bool dry_run_ = false;
+    bool debug_skip_idle_wait_ = false;   // tests only: bring back the round-3 schedule bug (no wait after a level without side-stream work)
+    std::vector<SchedOp>* sched_trace_ = nullptr;
+    std::vector<PotrfTask> potrf_h_;
+    std::vector<GemmTask> trsm_h_, upd_h_;
+    std::vector<FactorUnit> flow_units_h_;
     FactorUnit* flow_units_ = nullptr;   // dataflow factorisation of the top groups: [phase 0 units | phase 1 units]
     int* flow_ver_ = nullptr;            // per tile slot: finished strips of in-launch writers
     unsigned long long* flow_trace_ = nullptr;
-    int flow_cols_ = 6, flow_rows_ = 24;
+    int flow_cols_ = -1, flow_rows_ = 24;   // -1: the start of the launch is chosen by a cost model (build())
     int flow_g0_[2] = {0, 0}, flow_g1_[2] = {0, 0};   // per phase (local groups / top groups): the groups inside the launch
     int flow_first_[2] = {0, 0}, flow_n_[2] = {0, 0};
     double flow_sim_us_[2] = {0.0, 0.0};   // makespan of the list schedule that ordered the units (build())

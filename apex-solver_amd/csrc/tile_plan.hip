@@ -98,6 +98,12 @@ std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool 
 }
 
 void TilePlan::release() {
+    if (dry_run_) {   // a host-only plan owns no device memory, streams or events
+        tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = exch_ = nullptr; flag_ = nullptr; gate_cnt_ = nullptr;
+        side_ = side2_ = so_ = fwd_ = nullptr; ev_fwd_ = nullptr;
+        ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear(); ev_b2_.clear();
+        return;
+    }
     void* ptrs[] = {tiles_, linv_, slot_, diag_slot_, flag_, potrf_tasks_, trsm_tasks_, upd_tasks_, tri_fwd_, tri_bwd_,
                     flow_fwd_, flow_bwd_, flow_part_, flow_flags_, flow_units_, flow_ver_, flow_trace_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_, gate_cnt_};
     for (void* p : ptrs)
@@ -301,13 +307,23 @@ void TilePlan::build_symbolic(int nt, const std::vector<uint8_t>& present) {
     n_local_groups_ = n_levels_;
 }
 
+// Host-only twin of build() (tests: no device is touched): the same symbolic work, task lists, dataflow units and schedule
+// decisions, with made-up tile addresses and stream / event handles.  The plan it leaves behind can only be inspected
+// (schedule_trace, check_schedule, flow units): factor() / solve() on it are undefined.
+std::string TilePlan::build_host_only(int nt, const std::vector<uint8_t>& present) {
+    dry_run_ = true;
+    const std::string e = build(nt, present, reinterpret_cast<hipStream_t>(uintptr_t(0x51)));
+    return e;
+}
+
 std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStream_t stream) {
+    if (dry_run_) { tiles_ = linv_ = nullptr; }   // (fake addresses: never freed)
     release();
     nt_ = nt;
     stream_ = stream;
     const size_t tile_elems = (size_t)kNB * kNB;
     std::vector<std::vector<int>> col_rows = symbolic_slots(present);
-    {
+    if (!dry_run_) {
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const double need = (double)(n_slots_ + nt_) * tile_elems * 8.0;
@@ -318,12 +334,16 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     for (int K = 0; K < nt_; ++K) n_upd += (int64_t)col_rows[K].size() * (col_rows[K].size() + 1) / 2;
     if (n_upd > 80000000LL) return "tile update list too large (" + std::to_string(n_upd) + ")";
 
-#define TP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return std::string("HIP error in " #expr ": ") + hipGetErrorString(_e); } while (0)
+#define TP_TRY(expr) do { if (!dry_run_) { hipError_t _e = (expr); if (_e != hipSuccess) return std::string("HIP error in " #expr ": ") + hipGetErrorString(_e); } } while (0)
     TP_TRY(alloc_zero(&tiles_, (size_t)n_slots_ * tile_elems));
     TP_TRY(alloc_zero(&linv_, (size_t)nt_ * tile_elems));
+    if (dry_run_) {   // addresses that identify tiles, nothing more
+        tiles_ = reinterpret_cast<double*>(uintptr_t(1) << 44);
+        linv_ = reinterpret_cast<double*>(uintptr_t(1) << 45);
+    }
     TP_TRY(upload(&slot_, slot_h_));
     TP_TRY(upload(&diag_slot_, diag_slot_h_));
-    if (flag_) (void)hipFree(flag_);
+    if (flag_ && !dry_run_) (void)hipFree(flag_);
     TP_TRY(dev_alloc(&flag_, 4));
     TP_TRY(hipMemset(flag_, 0, 4 * sizeof(int)));
 
@@ -532,20 +552,8 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     // order of the level launches), its potrf, its panel solves; last the updates into tiles whose column is outside
     // the launch (the local phase of a distributed plan adding to the shared top).  `running` replays the version
     // counters: a unit may only wait for what EARLIER units publish (the no-deadlock argument), checked here.
-    std::vector<FactorUnit> funits;
-    for (int ph = 0; ph < 2; ++ph) {
-        const int g0 = ph == 0 ? 0 : n_local_groups_, g1 = ph == 0 ? n_local_groups_ : n_levels_;
-        flow_g0_[ph] = flow_g1_[ph] = g1; flow_first_[ph] = (int)funits.size(); flow_n_[ph] = 0;
-        if (flow_cols_ <= 0 || g1 <= g0) continue;
-        int gf = g1;
-        while (gf > g0) {
-            const std::vector<int>& cols = level_cols[gf - 1];
-            bool ok = (int)cols.size() <= flow_cols_;
-            for (int K : cols) ok = ok && (int)col_rows[K].size() <= flow_rows_;
-            if (!ok) break;
-            --gf;
-        }
-        if (g1 - gf < 2) continue;   // a single group has nothing to chain
+    auto make_flow_units = [&](int gf, int g1, std::vector<FactorUnit>& funits, double* sim_us) -> std::string {
+        funits.clear();
         std::vector<int> cols;
         std::vector<char> in_reg(nt_, 0);
         for (int g = gf; g < g1; ++g)
@@ -595,8 +603,6 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         }
         for (const auto& t : outside) emit_updates(t.second, t.first);
         if (!order_ok) return "internal error: a dataflow factorisation unit waits for a later one";
-        flow_g0_[ph] = gf;
-        flow_n_[ph] = (int)funits.size() - flow_first_[ph];
         // ---- dispatch order = the start order of a simulated list schedule -------------------------------------------------
         // Workgroups are dispatched in list order, one per CU: the launch works through a WINDOW of ~256 consecutive units.
         // In plain left-looking order that window fills up with units that wait for the current column while units further
@@ -606,7 +612,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         // are reached; among ready units the one with the longest remaining chain goes first).  A unit starts after its
         // producers finish, hence after they started: still a topological order, re-checked below.
         {
-            const int base = flow_first_[ph], n = flow_n_[ph];
+            const int base = 0, n = (int)funits.size();
             auto cost_of = [](const FactorUnit& u) { return u.kind == 0 ? 34.0 : (u.kind == 1 ? 10.0 : 8.0); };   // us, with the hop
             auto inc_of = [](const FactorUnit& u) { return u.kind == 0 ? W : 1; };
             std::vector<int> writer(n);           // which writer of its tile a unit belongs to
@@ -666,7 +672,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
                     if (--pending[x] == 0) { ready.push_back(x); std::push_heap(ready.begin(), ready.end(), worse); }
                 }
             }
-            flow_sim_us_[ph] = now;
+            *sim_us = now;
             std::vector<FactorUnit> sorted(n);
             for (int i = 0; i < n; ++i) sorted[i] = funits[base + order[i]];
             std::fill(running.begin(), running.end(), 0);
@@ -679,9 +685,71 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             }
             if (!order_ok) return "internal error: the scheduled dataflow order is not topological";
         }
+        return "";
+    };
+    // Where the launch starts.  "factor_flow" > 0: the trailing groups with at most that many columns (and "factor_flow_rows"
+    // off-diagonal tiles per column).  < 0 (default): by a model -- the level launches cost max(80 us of launch chain,
+    // 0.14 us per tile product) per group, the dataflow launch what its list schedule says (it runs a tile product on one
+    // CU at a time and reads every operand past the L2: ~0.22 us per product with all CUs busy, but a level costs it ~55 us
+    // of chain instead of 80); the start with the smallest sum wins, no launch if none beats the level launches.
+    std::vector<FactorUnit> funits;
+    for (int ph = 0; ph < 2; ++ph) {
+        const int g0 = ph == 0 ? 0 : n_local_groups_, g1 = ph == 0 ? n_local_groups_ : n_levels_;
+        flow_g0_[ph] = flow_g1_[ph] = g1; flow_first_[ph] = (int)funits.size(); flow_n_[ph] = 0; flow_sim_us_[ph] = 0.0;
+        if (flow_cols_ == 0 || g1 - g0 < 2) continue;
+        std::vector<FactorUnit> best_units;
+        double best_sim = 0.0;
+        int best_gf = g1;
+        if (flow_cols_ > 0) {
+            int gf = g1;
+            while (gf > g0) {
+                const std::vector<int>& cols = level_cols[gf - 1];
+                bool ok = (int)cols.size() <= flow_cols_;
+                for (int K : cols) ok = ok && (int)col_rows[K].size() <= flow_rows_;
+                if (!ok) break;
+                --gf;
+            }
+            if (g1 - gf < 2) continue;   // a single group has nothing to chain
+            const std::string e = make_flow_units(gf, g1, best_units, &best_sim);
+            if (!e.empty()) return e;
+            best_gf = gf;
+        } else {
+            auto level_us = [&](int g) {
+                double prod = 0.0;
+                for (int K : level_cols[g]) { const double m = (double)col_rows[K].size(); prod += m + 0.5 * m * (m + 1.0); }
+                return std::max(80.0, 0.14 * prod);
+            };
+            double level_tail = 0.0, best_total = 0.0;   // cost of the groups [gf, g1) by level launches; best (level head dropped: common)
+            int64_t units = 0;
+            std::vector<FactorUnit> cand;
+            for (int gf = g1 - 1; gf >= g0; --gf) {
+                bool ok = (int)level_cols[gf].size() <= 64;
+                for (int K : level_cols[gf]) {
+                    const int64_t m = (int64_t)col_rows[K].size();
+                    ok = ok && m <= 96;
+                    units += 1 + kFlowUnitsPerTile * (m + m * (m + 1) / 2);
+                }
+                if (!ok || units > 120000) break;   // (the model is evaluated per candidate start: keep plan building in the milliseconds)
+                level_tail += level_us(gf);
+                if (g1 - gf < 2) continue;
+                double sim = 0.0;
+                const std::string e = make_flow_units(gf, g1, cand, &sim);
+                if (!e.empty()) return e;
+                // gain of starting the launch at gf = what the level launches would have cost from there - the launch
+                const double gain = level_tail - (sim + 15.0);
+                if (gain > best_total) { best_total = gain; best_gf = gf; best_sim = sim; best_units.swap(cand); }
+                else if (gain < best_total - 300.0) break;   // past the optimum: the launch is swallowing throughput-bound levels
+            }
+            if (best_gf == g1) continue;
+        }
+        flow_g0_[ph] = best_gf;
+        flow_n_[ph] = (int)best_units.size();
+        flow_sim_us_[ph] = best_sim;
+        funits.insert(funits.end(), best_units.begin(), best_units.end());
     }
+    potrf_h_ = potrf; trsm_h_ = trsm; upd_h_ = upd; flow_units_h_ = funits;   // (kept for check_schedule / the tools: small)
     TP_TRY(upload(&flow_units_, funits));
-    if (flow_ver_) { (void)hipFree(flow_ver_); flow_ver_ = nullptr; }
+    if (flow_ver_ && !dry_run_) { (void)hipFree(flow_ver_); flow_ver_ = nullptr; }
     TP_TRY(dev_alloc(&flow_ver_, (size_t)n_slots_));
     TP_TRY(hipMemset(flow_ver_, 0, (size_t)std::max<int64_t>(n_slots_, 1) * sizeof(int)));
     n_sym_tiles_ = (int)symt.size();
@@ -695,10 +763,10 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     TP_TRY(upload(&flow_fwd_, ft));
     TP_TRY(upload(&flow_bwd_, bt));
     TP_TRY(alloc_zero(&flow_part_, (size_t)std::max(n_flow_parts_, 1) * kNB));
-    if (flow_flags_) { (void)hipFree(flow_flags_); flow_flags_ = nullptr; }
+    if (flow_flags_ && !dry_run_) { (void)hipFree(flow_flags_); flow_flags_ = nullptr; }
     TP_TRY(dev_alloc(&flow_flags_, (size_t)2 * nt_ + 1));   // cnt[nt] | done[nt] | error word of the dataflow sweeps
     TP_TRY(hipMemset(flow_flags_, 0, ((size_t)2 * nt_ + 1) * sizeof(int)));
-    if (!flow_err_host_) {
+    if (!flow_err_host_ && !dry_run_) {
         TP_TRY(hipHostMalloc(reinterpret_cast<void**>(&flow_err_host_), 4 * sizeof(int), hipHostMallocDefault));
         flow_err_host_[0] = flow_err_host_[1] = flow_err_host_[2] = flow_err_host_[3] = 0;
     }
@@ -717,9 +785,20 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     if (!fwd_) TP_TRY(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
     TP_TRY(hipEventCreateWithFlags(&ev_fwd_, hipEventDisableTiming));
     ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_); ev_o_.resize(n_levels_); ev_b_.resize(n_levels_); ev_b2_.resize(n_levels_);
+    if (dry_run_) {   // handles that identify streams and events in a schedule trace
+        side_ = reinterpret_cast<hipStream_t>(uintptr_t(0x52)); side2_ = reinterpret_cast<hipStream_t>(uintptr_t(0x53));
+        so_ = reinterpret_cast<hipStream_t>(uintptr_t(0x54)); fwd_ = reinterpret_cast<hipStream_t>(uintptr_t(0x55));
+        ev_fwd_ = reinterpret_cast<hipEvent_t>(uintptr_t(0x1000));
+        for (int i = 0; i < n_levels_; ++i) {
+            ev_t_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10000 + 8 * i)); ev_u2_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10001 + 8 * i));
+            ev_o_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10002 + 8 * i)); ev_b_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10003 + 8 * i));
+            ev_b2_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10004 + 8 * i));
+        }
+        gate_cnt_ = reinterpret_cast<int*>(uintptr_t(1) << 46);
+    }
     u2_pending_.assign(n_levels_, false);
     o_pending_.assign(n_levels_, false);
-    for (int i = 0; i < n_levels_; ++i) {
+    for (int i = 0; i < n_levels_ && !dry_run_; ++i) {
         TP_TRY(hipEventCreateWithFlags(&ev_t_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_u2_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_o_[i], hipEventDisableTiming));
@@ -790,6 +869,29 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     //   potrf(lv) after U1d(lv-1) [stream order] and whatever U1d(lv-1) waited for;
     //   panel(lv) after U1o(lv-1) [event];  U1o(lv) and U2(lv) hit different columns (level lv+1 / above);
     //   a U2 too small for the side stream runs on the main stream after the side stream's last U2b [ev_b_].
+    // Every call below goes through these shadows: with a trace attached (schedule_trace: tests, host-only plans) the call
+    // is recorded instead of issued -- what check_schedule() then proves is this very sequence.
+    std::vector<SchedOp>* const tr = sched_trace_;
+    auto hipStreamWaitEvent = [&](hipStream_t s, hipEvent_t e, unsigned) { if (tr) { tr->push_back({2, (uintptr_t)s, (uintptr_t)e, -1, 0, 0}); return hipSuccess; } return ::hipStreamWaitEvent(s, e, 0); };
+    auto hipEventRecord = [&](hipEvent_t e, hipStream_t s) { if (tr) { tr->push_back({1, (uintptr_t)s, (uintptr_t)e, -1, 0, 0}); return hipSuccess; } return ::hipEventRecord(e, s); };
+    auto launch_potrf_inv = [&](const PotrfTask* t, int n, int* fail, hipStream_t s, int* arrived) {
+        if (tr) { if (n > 0) tr->push_back({0, (uintptr_t)s, 0, 0, (int64_t)(t - potrf_tasks_), n}); return; }
+        apex::launch_potrf_inv(t, n, fail, s, arrived);
+    };
+    auto launch_tile_gemm_nt = [&](const GemmTask* t, int n, double alpha, double beta, hipStream_t s) {
+        if (tr) {
+            const bool panel = beta == 0.0;
+            if (n > 0) tr->push_back({0, (uintptr_t)s, 0, panel ? 1 : 2, (int64_t)(t - (panel ? trsm_tasks_ : upd_tasks_)), n});
+            return;
+        }
+        apex::launch_tile_gemm_nt(t, n, alpha, beta, s);
+    };
+    auto launch_gate = [&](const int* a, int expected, int us, hipStream_t s) { if (!tr) apex::launch_gate(a, expected, us, s); };
+    auto hipMemsetAsync = [&](void* p, int v, size_t n, hipStream_t s) { if (tr) return hipSuccess; return ::hipMemsetAsync(p, v, n, s); };
+    auto launch_factor_flow = [&](const FactorUnit* u, int n, int* ver, int* fail, int* err, hipStream_t s, unsigned long long* trace) {
+        if (tr) { tr->push_back({0, (uintptr_t)s, 0, 3, (int64_t)(u - flow_units_), n}); return; }
+        apex::launch_factor_flow(u, n, ver, fail, err, s, trace);
+    };
     const bool two = overlap_ && side_ != nullptr && n_levels_ > 2;
     // Forward substitution L y = rhs fused into the factorisation (when the right-hand side is known now): the
     // step of level lv needs only that level's L^-1 and panel tiles, which are final after its panel solves, so it
@@ -833,7 +935,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         if (two && lv > g0 && u2_pending_[lv - 1]) {
             (void)hipStreamWaitEvent(stream_, ev_u2_[lv - 1], 0);
             if (has_o) (void)hipStreamWaitEvent(so_, ev_u2_[lv - 1], 0);
-        } else if (two && lv > g0) {
+        } else if (two && lv > g0 && !debug_skip_idle_wait_) {
             // Level lv-1 put nothing on the side streams, so there is no ev_u2_[lv-1] to carry "every older side-stream update
             // precedes U1(lv)": U2b1(lv-2) [targets in level lv+1, stream A] and the U2b2 of levels <= lv-3 [stream B] may
             // still be at work on the tiles U1(lv) is about to update (and that potrf(lv+1) then reads).  Levels are assigned
@@ -1024,6 +1126,92 @@ hipError_t TilePlan::read_flow_trace(std::vector<FactorUnit>* units, std::vector
     hipError_t e = hipMemcpy(units->data(), flow_units_, n * sizeof(FactorUnit), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return e;
     return hipMemcpy(stamps->data(), flow_trace_, 3 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+
+std::vector<SchedOp> TilePlan::schedule_trace(int phase) {
+    std::vector<SchedOp> ops;
+    sched_trace_ = &ops;
+    if (phase == 0) enqueue_factor(nullptr, nullptr, 0, n_local_groups_);
+    else enqueue_factor(nullptr, nullptr, n_local_groups_, n_levels_);
+    sched_trace_ = nullptr;
+    return ops;
+}
+
+int TilePlan::check_schedule(const std::vector<SchedOp>& ops, std::string* first_violation) const {
+    // vector clocks over the streams that appear: clock[s] = how many launches of stream s happen before this point
+    std::vector<uintptr_t> streams;
+    auto sid = [&](uintptr_t s) { for (size_t i = 0; i < streams.size(); ++i) if (streams[i] == s) return (int)i; streams.push_back(s); return (int)streams.size() - 1; };
+    for (const SchedOp& o : ops) (void)sid(o.stream);
+    const int S = (int)streams.size();
+    typedef std::vector<int> Clock;
+    std::vector<Clock> now((size_t)S, Clock((size_t)S, 0));     // per stream: what precedes its next call
+    std::vector<std::pair<uintptr_t, Clock>> events;             // last record of each event
+    struct Access { int launch; bool write; };
+    struct Launch { int stream, pos; Clock before; const SchedOp* op; };
+    std::vector<Launch> launches;
+    std::vector<std::pair<const double*, Access>> acc;
+    int bad = 0;
+    auto complain = [&](const std::string& m) { if (bad++ == 0 && first_violation) *first_violation = m; };
+    auto describe = [&](const Launch& l) {
+        static const char* const names[] = {"potrf", "panel solves", "updates", "dataflow launch"};
+        return std::string(names[l.op->list]) + " [" + std::to_string(l.op->first) + ", +" + std::to_string(l.op->count) + ") on stream " + std::to_string(l.stream);
+    };
+    for (const SchedOp& o : ops) {
+        const int s = sid(o.stream);
+        if (o.op == 1) {
+            bool found = false;
+            for (auto& e : events) if (e.first == o.event) { e.second = now[(size_t)s]; found = true; }
+            if (!found) events.push_back({o.event, now[(size_t)s]});
+        } else if (o.op == 2) {
+            bool found = false;
+            for (const auto& e : events)
+                if (e.first == o.event) { for (int k = 0; k < S; ++k) now[(size_t)s][(size_t)k] = std::max(now[(size_t)s][(size_t)k], e.second[(size_t)k]); found = true; }
+            if (!found) complain("a stream waits for an event that was never recorded");
+        } else {
+            const int li = (int)launches.size();
+            launches.push_back({s, now[(size_t)s][(size_t)s] + 1, now[(size_t)s], &o});
+            now[(size_t)s][(size_t)s] += 1;
+            // the tiles the launch touches; inside one launch no tile may be written twice or read and written by two tasks
+            std::vector<std::pair<const double*, int>> local;   // (tile, +1 write / 0 read) of this launch
+            auto touch = [&](const double* t, bool w) { acc.push_back({t, {li, w}}); local.push_back({t, w ? 1 : 0}); };
+            for (int64_t q = o.first; q < o.first + o.count; ++q) {
+                if (o.list == 0) { touch(potrf_h_[(size_t)q].A, true); touch(potrf_h_[(size_t)q].Linv, true); }
+                else if (o.list == 1) { touch(trsm_h_[(size_t)q].C, true); touch(trsm_h_[(size_t)q].B, false); }
+                else if (o.list == 2) { touch(upd_h_[(size_t)q].C, true); touch(upd_h_[(size_t)q].A, false); touch(upd_h_[(size_t)q].B, false); }
+                else {   // the dataflow launch orders its own units (version counters): one writer of everything it touches
+                    const FactorUnit& u = flow_units_h_[(size_t)q];
+                    touch(u.C, true);
+                    if (u.kind == 0) touch(u.A, true);
+                }
+            }
+            if (o.list != 3) {
+                std::sort(local.begin(), local.end());
+                for (size_t i = 0; i < local.size();) {
+                    size_t j = i; int writes = 0;
+                    while (j < local.size() && local[j].first == local[i].first) writes += local[j++].second;
+                    if (writes >= 1 && j - i >= 2) { complain("two tasks of one launch touch a tile that one of them writes: " + describe(launches.back())); break; }
+                    i = j;
+                }
+            }
+        }
+    }
+    // every pair of launches on one tile with a writer among them must be ordered
+    std::sort(acc.begin(), acc.end(), [](const std::pair<const double*, Access>& a, const std::pair<const double*, Access>& b) {
+        return a.first != b.first ? a.first < b.first : a.second.launch < b.second.launch; });
+    for (size_t i = 0; i < acc.size();) {
+        size_t j = i;
+        while (j < acc.size() && acc[j].first == acc[i].first) ++j;
+        for (size_t a = i; a < j; ++a)
+            for (size_t b = a + 1; b < j; ++b) {
+                const Access &x = acc[a].second, &y = acc[b].second;
+                if (x.launch == y.launch || (!x.write && !y.write)) continue;
+                const Launch &lx = launches[(size_t)x.launch], &ly = launches[(size_t)y.launch];   // lx was issued first
+                if (ly.before[(size_t)lx.stream] < lx.pos)
+                    complain("unordered accesses to one tile: " + describe(lx) + " and " + describe(ly));
+            }
+        i = j;
+    }
+    return bad;
 }
 
 void TilePlan::top_slot_ranges(std::pair<int64_t, int64_t> out[2]) const {
