@@ -289,6 +289,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "pairs_variant") h->s->set_pairs_variant(value);
     else if (n == "cam_staging") h->s->set_cam_staging(value != 0);
     else if (n == "debug_poison_sweep") h->s->debug_poison_next_solve(value);   /* tests: 1 / 2 = the next solve's forward / backward dataflow sweep times out */
+    else if (n == "debug_poison_factor") h->s->debug_poison_next_factor();       /* tests: the next factorisation's dataflow launch times out */
     else if (n == "debug_occupy_cus") return h->s->debug_occupy_cus(value, 40000);   /* tests: block `value` CUs for 40 ms, starting now */
     else if (n == "hubs_last") h->s->set_hubs_last(value != 0);
     else if (n == "pair_task_slots") h->s->set_pair_task_slots(value);
@@ -584,6 +585,7 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);
     else if (n == "debug_poison_sweep") h->s->debug_poison_next_solve(value);
+    else if (n == "debug_poison_factor") h->s->debug_poison_next_factor();
     else return APEXGPU_ERR_INVALID_INPUT;
     return APEXGPU_OK;
 }

@@ -601,7 +601,7 @@ __device__ __forceinline__ double4_t blk_load_cd_sym(const double* C, int lr, in
 
 template <int NW, bool COH>
 __device__ __forceinline__ void potrf_tile_mf(double* __restrict__ A, double* __restrict__ Linv, int K, int* __restrict__ fail,
-                                              double* sA, double* sD, int* bad) {
+                                              double* sA, double* sD, int* bad, int* sync_cnt) {
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -611,9 +611,9 @@ __device__ __forceinline__ void potrf_tile_mf(double* __restrict__ A, double* __
     // they sit out the block products; the helpers are the waves with w % 4 != 0.
     constexpr int NH = NW - (NW + 3) / 4;
     const bool helper = (w & 3) != 0;
-    const int hid = w - 1 - (w >> 2);   // 1,2,3,5,6,7 -> 0..5
+    const int hid = w - 1 - (w >> 2);   // 1,2,3,5,6,7,(9,10,11) -> 0..5,(6,7,8)
     const __amdgpu_buffer_rsrc_t rA = coh_rsrc(A), rL = coh_rsrc(Linv);
-    if (tid == 0) *bad = 0;
+    if (tid == 0) { *bad = 0; *sync_cnt = 0; }
     {
         constexpr int NREG = (128 * 45 + NT - 1) / NT + NBK;
         double2 reg[NREG];
@@ -801,9 +801,23 @@ __device__ __forceinline__ void potrf_tile_mf(double* __restrict__ A, double* __
                 if (hid == NH - 1) blk_to_tile<COH>(sA + bidx(kb, kb) * BSZ, A, rA, kb, kb, lane, 64);  // the diagonal block of L
             }
         }
-        __syncthreads();
+        // P2 -> P1 WITHOUT a workgroup barrier: wave 0 needs nothing from the other waves' P2 -- its next block is in its
+        // registers -- and goes straight to the next 16 pivots; the helpers' next job (the trailing update of this step) needs
+        // the whole panel, theirs and wave 0's block: everyone who wrote a piece counts itself in, the helpers wait for the
+        // count (an LDS counter: the LDS executes a wave's operations in order, the release / acquire fences are waitcnts).
+        // One barrier per block step is left, behind P1, where wave 0 picks up the helpers' updates of its next block.
+        if (w == 0 || helper) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (helper) {
+            const int target = (kb + 1) * (NH + 1);
+            while (__hip_atomic_load(sync_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         POTRF_STAMP();
     }
+    __syncthreads();   // (the last step's row blocks are in: the last row of L^-1 reads them)
     // last row of L^-1 (r = NBK-1), all waves
     {
         const int r = NBK - 1;
@@ -844,9 +858,9 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_inv_mf(const PotrfTask* __res
     POTRF_STAMP();
     __shared__ double sA[NLB * BSZ];
     __shared__ double sD[NBK * BSZ];
-    __shared__ int bad;
+    __shared__ int bad, sync_cnt;
     const PotrfTask pt = tasks[blockIdx.x];
-    potrf_tile_mf<NW, false>(pt.A, pt.Linv, pt.K, fail, sA, sD, &bad);
+    potrf_tile_mf<NW, false>(pt.A, pt.Linv, pt.K, fail, sA, sD, &bad, &sync_cnt);
 }
 #undef POTRF_STAMP
 
@@ -1428,13 +1442,19 @@ __device__ __forceinline__ void flow_wait_ge(const int* ver, int flag, int want,
 // all of a unit's conditions in ONE polling loop -- lanes 0..2 of the first wave poll one counter each and vote: a poll is a
 // round trip to memory (~2 us), and three waits in a row cost three of them after the last counter moves
 __device__ __forceinline__ void flow_wait_unit(const int* ver, const FactorUnit& u, int tid, int* err) {
+    // (the six words by value: indexing the record with the lane id would put it in scratch memory)
+    const int f0 = u.wait_flag[0], f1 = u.wait_flag[1], f2 = u.wait_flag[2], w0 = u.wait_val[0], w1 = u.wait_val[1], w2 = u.wait_val[2];
     if (tid < 64) {
-        const int f = tid == 0 ? u.wait_flag[0] : (tid == 1 ? u.wait_flag[1] : (tid == 2 ? u.wait_flag[2] : -1));
-        const int want = tid == 0 ? u.wait_val[0] : (tid == 1 ? u.wait_val[1] : u.wait_val[2]);
+        const int f = tid == 0 ? f0 : (tid == 1 ? f1 : (tid == 2 ? f2 : -1));
+        const int want = tid == 0 ? w0 : (tid == 1 ? w1 : w2);
         int spins = 0;
         for (;;) {
             const bool ok = f < 0 || __hip_atomic_load(ver + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
             if (__all(ok)) break;
+            // a unit that gave up raises the error word; whoever waits downstream of it leaves at once instead of running into
+            // its own limit (lane 3 watches the word: the launch ends in one time-out, not in one per dependent unit)
+            const bool dead = tid == 3 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (__any(dead)) break;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > kFlowSpinLimit) { if (tid == 0) atomicOr(err, 1); break; }
         }
@@ -1455,33 +1475,40 @@ __device__ __forceinline__ void flow_update_unit(const FactorUnit& u, double* __
     const __amdgpu_buffer_rsrc_t rC = coh_rsrc(u.C), rA = coh_rsrc(u.A), rB = coh_rsrc(u.B);
     flow_wait_unit(ver, u, tid, err);   // the previous writer of the target is done, both operands are final
     if (trace && tid == 0) trace[1] = wall_clock64();
-    double cv[4];   // the old values of the block: requested with the operands, consumed last
+    const bool act = tid < 576;   // (the workgroup has 12 waves for the potrf units' sake: nine of them work here)
+    double cv[4] = {0.0, 0.0, 0.0, 0.0};   // the old values of the block: requested with the operands, consumed last
+    if (act) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cv[r] = coh_ld1(rC, (48 * bi + 16 * wr + lk + 4 * r) * NB + 48 * bj + 16 * wc + lr);
+        for (int r = 0; r < 4; ++r) cv[r] = coh_ld1(rC, (48 * bi + 16 * wr + lk + 4 * r) * NB + 48 * bj + 16 * wc + lr);
+    }
     constexpr int C2 = NB / 2, NR = 48 * C2 / 576;   // 72 double2 per row, 6 per thread and operand
     static_assert(48 * C2 % 576 == 0, "staging loops assume whole rounds");
-    double2 ra[NR], rb[NR];
+    if (act) {
+        double2 ra[NR], rb[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
-        ra[i] = tile_ld2<true>(u.A, rA, (48 * bi + row) * NB + 2 * c2);
-        rb[i] = tile_ld2<true>(u.B, rB, (48 * bj + row) * NB + 2 * c2);
-    }
+        for (int i = 0; i < NR; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            ra[i] = tile_ld2<true>(u.A, rA, (48 * bi + row) * NB + 2 * c2);
+            rb[i] = tile_ld2<true>(u.B, rB, (48 * bj + row) * NB + 2 * c2);
+        }
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
-        sA[row * kFlowPK + 2 * c2] = ra[i].x; sA[row * kFlowPK + 2 * c2 + 1] = ra[i].y;
-        sB[row * kFlowPK + 2 * c2] = rb[i].x; sB[row * kFlowPK + 2 * c2 + 1] = rb[i].y;
+        for (int i = 0; i < NR; ++i) {
+            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+            sA[row * kFlowPK + 2 * c2] = ra[i].x; sA[row * kFlowPK + 2 * c2 + 1] = ra[i].y;
+            sB[row * kFlowPK + 2 * c2] = rb[i].x; sB[row * kFlowPK + 2 * c2 + 1] = rb[i].y;
+        }
     }
     __syncthreads();
-    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-    const double* pa = sA + (16 * wr + lr) * kFlowPK + lk;
-    const double* pb = sB + (16 * wc + lr) * kFlowPK + lk;
+    if (act) {
+        double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+        const double* pa = sA + (16 * wr + lr) * kFlowPK + lk;
+        const double* pb = sB + (16 * wc + lr) * kFlowPK + lk;
 #pragma unroll
-    for (int kk = 0; kk < NB; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kk], pb[kk], acc, 0, 0, 0);
+        for (int kk = 0; kk < NB; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kk], pb[kk], acc, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        coh_st1(rC, (48 * bi + 16 * wr + lk + 4 * r) * NB + 48 * bj + 16 * wc + lr, -1.0 * acc[r] + 1.0 * cv[r]);
+        for (int r = 0; r < 4; ++r)
+            coh_st1(rC, (48 * bi + 16 * wr + lk + 4 * r) * NB + 48 * bj + 16 * wc + lr, -1.0 * acc[r] + 1.0 * cv[r]);
+    }
     flow_publish(ver + u.pub, tid);
 }
 
@@ -1498,43 +1525,52 @@ __device__ __forceinline__ void flow_solve_unit(const FactorUnit& u, double* __r
     static_assert(NB * C2 % 576 == 0 && 16 * C2 <= 576, "staging loops assume whole rounds");
     flow_wait_unit(ver, u, tid, err);   // the tile carries all its updates, L^-1 of the column's diagonal tile is there
     if (trace && tid == 0) trace[1] = wall_clock64();
+    const bool act = tid < 576;   // (nine of the workgroup's twelve waves work here)
     double2 ra[NCH], rb[NCH][NRB];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
         if (tid < 16 * C2) ra[c] = tile_ld2<true>(u.C, rC, (row0 + tid / C2) * NB + KS * c + 2 * (tid % C2));
+    if (act) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+        for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int i = 0; i < NRB; ++i) {
-            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
-            rb[c][i] = tile_ld2<true>(u.B, rB, row * NB + KS * c + 2 * c2);
-        }
+            for (int i = 0; i < NRB; ++i) {
+                const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+                rb[c][i] = tile_ld2<true>(u.B, rB, row * NB + KS * c + 2 * c2);
+            }
+    }
     double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         __syncthreads();
         if (tid < 16 * C2) { const int row = tid / C2, c2 = tid % C2; sA[row * PS + 2 * c2] = ra[c].x; sA[row * PS + 2 * c2 + 1] = ra[c].y; }
+        if (act) {
 #pragma unroll
-        for (int i = 0; i < NRB; ++i) {
-            const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
-            sB[row * PS + 2 * c2] = rb[c][i].x; sB[row * PS + 2 * c2 + 1] = rb[c][i].y;
+            for (int i = 0; i < NRB; ++i) {
+                const int idx = tid + 576 * i, row = idx / C2, c2 = idx % C2;
+                sB[row * PS + 2 * c2] = rb[c][i].x; sB[row * PS + 2 * c2 + 1] = rb[c][i].y;
+            }
         }
         __syncthreads();
+        if (act) {
 #pragma unroll
-        for (int kk = 0; kk < KS; kk += 4)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[lr * PS + kk + lk], sB[(16 * w + lr) * PS + kk + lk], acc, 0, 0, 0);
+            for (int kk = 0; kk < KS; kk += 4)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[lr * PS + kk + lk], sB[(16 * w + lr) * PS + kk + lk], acc, 0, 0, 0);
+        }
     }
+    if (act) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) coh_st1(rC, (row0 + lk + 4 * r) * NB + 16 * w + lr, acc[r]);
+        for (int r = 0; r < 4; ++r) coh_st1(rC, (row0 + lk + 4 * r) * NB + 16 * w + lr, acc[r]);
+    }
     flow_publish(ver + u.pub, tid);
 }
 
-constexpr int kFlowFactorThreads = 576;
+constexpr int kFlowFactorThreads = 768;   // 12 waves: the potrf units' 9 helper waves (+ wave 0 and two idle ones on its SIMD); products use 9
 __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const FactorUnit* __restrict__ units, int* __restrict__ ver,
                                                                      int* __restrict__ fail, int* __restrict__ err,
                                                                      unsigned long long* __restrict__ trace) {
     __shared__ double smem[(NLB + NBK) * BSZ];   // potrf: the tile's 45 lower blocks + 9 inverted diagonal blocks; product: sA | sB
-    __shared__ int bad;
+    __shared__ int bad, sync_cnt;
     static_assert((16 + NB) * PS <= (NLB + NBK) * BSZ && 2 * 48 * kFlowPK <= (NLB + NBK) * BSZ, "the products' staging areas fit in the potrf's");
     const FactorUnit u = units[blockIdx.x];
     const int tid = threadIdx.x;
@@ -1543,9 +1579,9 @@ __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const Factor
         if (tid == 0) trace[0] = wall_clock64();
     }
     if (u.kind == 0) {
-        flow_wait_ge(ver, u.wait_flag[0], u.wait_val[0], tid, err);
+        flow_wait_unit(ver, u, tid, err);
         if (trace && tid == 0) trace[1] = wall_clock64();
-        potrf_tile_mf<kFlowFactorThreads / 64, true>(u.C, const_cast<double*>(u.A), u.strip, fail, smem, smem + NLB * BSZ, &bad);
+        potrf_tile_mf<kFlowFactorThreads / 64, true>(u.C, const_cast<double*>(u.A), u.strip, fail, smem, smem + NLB * BSZ, &bad, &sync_cnt);
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ver + u.pub, kFlowUnitsPerTile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1808,7 +1844,7 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const 
 }
 
 // ------------------------------------------------------------------------------------------
-static int g_potrf_lookahead = 9;   // 0: k_potrf_inv; 1 / 6 / 8: look-ahead kernel (round 3) with 4 / 6 / 8 waves; 9 (default): matrix-pipe form, 8 waves
+static int g_potrf_lookahead = 12;   // 0: k_potrf_inv; 1 / 6 / 8: look-ahead kernel (round 3) with 4 / 6 / 8 waves; 9 / 12 (default): matrix-pipe form, 8 / 12 waves
 void set_potrf_lookahead(int mode) { g_potrf_lookahead = mode; }
 // The flood gate (TilePlan::enqueue_factor): one lane that ends when `expected` potrf workgroups have announced themselves
 // in *arrived, or after max_ticks of the 100 MHz clock -- a scheduling hint in front of the bulk updates of a level, so
@@ -1830,6 +1866,7 @@ void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fai
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s, int* arrived) {
     if (n <= 0) return;
     if (g_potrf_lookahead == 9) hipLaunchKernelGGL(k_potrf_inv_mf<8>, dim3(n), dim3(512), 0, s, tasks, fail, arrived);
+    else if (g_potrf_lookahead == 12) hipLaunchKernelGGL(k_potrf_inv_mf<12>, dim3(n), dim3(768), 0, s, tasks, fail, arrived);
     else if (g_potrf_lookahead == 1) hipLaunchKernelGGL(k_potrf_inv_la<4>, dim3(n), dim3(256), 0, s, tasks, fail, arrived);
     else if (g_potrf_lookahead == 6) hipLaunchKernelGGL(k_potrf_inv_la<6>, dim3(n), dim3(384), 0, s, tasks, fail, arrived);
     else if (g_potrf_lookahead) hipLaunchKernelGGL(k_potrf_inv_la<8>, dim3(n), dim3(512), 0, s, tasks, fail, arrived);

@@ -62,6 +62,7 @@ class PoseGraphSolver : public LmBackend {
     void set_two_side(int mode) { tp_.set_two_side(mode); }
     void set_factor_flow(int max_cols, int max_rows) { tp_.set_factor_flow(max_cols, max_rows); }
     int factor_flow_timeouts() const { return n_factor_flow_timeouts_; }
+    void debug_poison_next_factor() { tp_.debug_poison_next_factor(); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void enable_stage_timing(bool on) { timer_.enable(on); }

@@ -143,6 +143,8 @@ class TilePlan {
     int sweep_timeouts() const { return n_sweep_timeouts_; }
     // tests only: the next solve()'s forward (1) / backward (2) dataflow sweep runs into its spin limit on purpose
     void debug_poison_next_solve(int which) { poison_ = which; }
+    // tests only: the next factorisation's dataflow launch cannot finish (one version counter is made unreachable)
+    void debug_poison_next_factor() { poison_factor_ = true; }
     // tests only: block n_cus compute units (all of their LDS) for `micros`, starting now, on a stream of their own;
     // returns once the blocking workgroups are resident (or after 200 ms)
     hipError_t debug_occupy_cus(int n_cus, int micros);
@@ -223,8 +225,9 @@ class TilePlan {
     int* flow_err_host_ = nullptr;                         // pinned: [0] the error word behind the last solve(), [1..2] debug_occupy_cus
     int n_sweep_timeouts_ = 0;
     int poison_ = 0;
+    bool poison_factor_ = false;
     hipStream_t occ_stream_ = nullptr;
-    void post_sweep_status(bool reduce);
+    bool post_sweep_status(bool reduce);   // false: the max-reduction over the ranks failed
     bool dry_run_ = false;
     bool debug_skip_idle_wait_ = false;   // tests only: bring back the round-3 schedule bug (no wait after a level without side-stream work)
     std::vector<SchedOp>* sched_trace_ = nullptr;

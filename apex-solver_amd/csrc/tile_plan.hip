@@ -1008,6 +1008,8 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     }
     if (g1 < g_end) {   // every update the level launches add to the region's tiles is in: the joins above
         (void)hipMemsetAsync(flow_ver_, 0, (size_t)n_slots_ * sizeof(int), stream_);
+        if (poison_factor_ && !tr)   // (tests: the version of the first unit's tile starts hugely negative and is never reached)
+            (void)hipMemsetAsync(flow_ver_ + flow_units_h_[(size_t)flow_first_[ph]].pub, 0x80, sizeof(int), stream_);
         launch_factor_flow(flow_units_ + flow_first_[ph], flow_n_[ph], flow_ver_, flag_, flag_ + 1, stream_,
                            flow_trace_ ? flow_trace_ + 3 * (size_t)flow_first_[ph] : nullptr);
     }
@@ -1243,7 +1245,10 @@ hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
         return read_flags(failed_at);
     }
     if (!fuse_forward_) { rhs = nullptr; work = nullptr; }
-    if (!run_graph(0, rhs, nullptr, work)) enqueue_factor(rhs, work, 0, n_levels_);
+    if (poison_factor_) {   // (tests: the poisoned launch is not part of the captured graphs)
+        enqueue_factor(rhs, work, 0, n_levels_);
+        poison_factor_ = false;
+    } else if (!run_graph(0, rhs, nullptr, work)) enqueue_factor(rhs, work, 0, n_levels_);
     fwd_rhs_ = rhs; fwd_work_ = work;  // the forward sweep for this right-hand side is part of the factorisation
     return read_flags(failed_at);
 }
@@ -1271,12 +1276,13 @@ hipError_t TilePlan::read_flags(int* failed_at) {
 // Behind the sweeps of a solve: the error word goes to pinned host memory (no synchronisation here: the caller's next
 // one covers it) and is cleared for the next solve.  Distributed plans take the max over the ranks first -- a rank whose
 // sweep gave up must not be the only one that repeats the solve, the others would be waiting in its collectives.
-void TilePlan::post_sweep_status(bool reduce) {
-    if (!flow_flags_ || !flow_err_host_) return;
+bool TilePlan::post_sweep_status(bool reduce) {
+    if (!flow_flags_ || !flow_err_host_) return true;
     int* err = flow_flags_ + 2 * (size_t)nt_;
-    if (reduce && comm_.max_int) (void)comm_.max_int(err, 1, stream_);
+    if (reduce && comm_.max_int && !comm_.max_int(err, 1, stream_)) return false;   // (the communicator keeps its message)
     (void)hipMemcpyAsync(flow_err_host_, err, sizeof(int), hipMemcpyDeviceToHost, stream_);
     (void)hipMemsetAsync(err, 0, sizeof(int), stream_);
+    return true;
 }
 
 bool TilePlan::sweep_timed_out() {
@@ -1306,7 +1312,9 @@ hipError_t TilePlan::solve(const double* rhs, double* x, double* work) {
         solve_phase(1, rhs, x, work);
         if (!comm_.sum(exch_, (size_t)n_pad(), stream_)) return hipErrorUnknown;
         solve_phase(2, rhs, x, work);
-        if (tri_flow_ && n_flow_local_ > 0) post_sweep_status(true);
+        // (the collective is entered by every rank or by none: tri_flow_ is a plan-wide setting, and a distributed plan has
+        // dataflow tasks on every rank -- at least the fold tasks of the shared top columns)
+        if (tri_flow_ && !post_sweep_status(true)) return hipErrorUnknown;
         return hipGetLastError();
     }
     const bool backward_only = fwd_rhs_ != nullptr && rhs == fwd_rhs_ && work == fwd_work_;
@@ -1315,7 +1323,7 @@ hipError_t TilePlan::solve(const double* rhs, double* x, double* work) {
         enqueue_solve(rhs, x, work, backward_only);
         poison_ = 0;
     } else if (!run_graph(backward_only ? 2 : 1, rhs, x, work)) enqueue_solve(rhs, x, work, backward_only);
-    if (tri_flow_ && n_flow_tasks_ > 0) post_sweep_status(false);
+    if (tri_flow_ && n_flow_tasks_ > 0) (void)post_sweep_status(false);
     return hipGetLastError();
 }
 

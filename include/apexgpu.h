@@ -247,6 +247,7 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     The flag waits are bounded (~2 s): a sweep that gives up is detected IN THE SAME apexgpu_solve_augmented
  *                     (error word posted to the host behind the sweeps, max-reduced over the ranks), the solve is repeated
  *                     with the level sweeps and the handle stays on them; apexgpu_counters()[0] counts these events
+ *   "debug_poison_factor"  tests only: the next factorisation's dataflow launch ("factor_flow") cannot finish and times out
  *   "debug_poison_sweep", "debug_occupy_cus"  tests only: the next solve's forward (1) / backward (2) dataflow sweep runs
  *                     into its spin limit on purpose; block that many compute units for 40 ms starting now
  *   "nested_dissection" (1)  order camera tiles by nested dissection (call before set_structure);

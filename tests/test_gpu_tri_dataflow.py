@@ -66,12 +66,13 @@ def test_sweep_timeout_is_caught_in_the_same_solve_and_repaired(which):
     s = GpuSchurComplementSolver(0).initialize_structure(prob)
     s.set_parameters(d.poses, d.intr, d.points)
     good = s.solve_augmented_equation(1e-3).copy()
-    assert s.counters() == dict(sweep_timeouts=0, tri_dataflow=True)
+    c0 = s.counters()
+    assert (c0["sweep_timeouts"], c0["tri_dataflow"], c0["factor_flow_timeouts"]) == (0, True, 0)
     s.set_option("debug_poison_sweep", which)
     got = s.solve_augmented_equation(1e-3).copy()          # ~2 s: the poisoned wait runs to its limit
     c = s.counters()
     print("sweep", which, "counters after the poisoned solve:", c, "vs level sweeps", rel(got, want), "vs dataflow", rel(got, good))
-    assert c == dict(sweep_timeouts=1, tri_dataflow=False)
+    assert (c["sweep_timeouts"], c["tri_dataflow"], c["factor_flow_timeouts"]) == (1, False, 0)
     # the repaired solve is a level-sweep solve of the same factor (its forward sweep adds into shared ancestor blocks
     # with atomics, so two of them agree to rounding times cond(S), not bit for bit); the poisoned sweep's x was garbage
     assert rel(got, want) < 1e-9 and rel(got, good) < 1e-9
@@ -90,7 +91,8 @@ def test_pose_graph_sweep_timeout_is_repaired():
     good = s.solve_augmented_equation(1e-3).copy()
     s.set_option("debug_poison_sweep", 1)
     got = s.solve_augmented_equation(1e-3).copy()
-    assert s.counters() == dict(sweep_timeouts=1, tri_dataflow=False)
+    c = s.counters()
+    assert (c["sweep_timeouts"], c["tri_dataflow"], c["factor_flow_timeouts"]) == (1, False, 0)
     assert rel(got, good) < 1e-9 and np.all(np.isfinite(got))
     s.close()
 
@@ -109,7 +111,38 @@ def test_dataflow_sweeps_make_progress_while_most_cus_are_blocked(busy):
     for rep in range(3):
         s.set_option("debug_occupy_cus", busy)              # returns once the blocking workgroups are resident
         got = s.solve_augmented_equation(1e-3).copy()
-        assert s.counters() == dict(sweep_timeouts=0, tri_dataflow=True)
+        c0 = s.counters()
+        assert (c0["sweep_timeouts"], c0["tri_dataflow"], c0["factor_flow_timeouts"]) == (0, True, 0)
         # (S is assembled deterministically on this shape and the sweeps fold in list order: bitwise equal)
         assert np.array_equal(got, idle)
+    s.close()
+
+
+# ---- the dataflow launch of the factorisation's top groups: a launch that gives up is repaired inside the same solve ---------
+def test_factor_flow_timeout_is_caught_in_the_same_solve_and_repaired():
+    """"debug_poison_factor": one version counter of k_factor_flow is made unreachable, the units downstream run into the spin
+    limit (one time-out, the rest leave at once through the error word) and the tiles are left half updated.  The SAME
+    solve_augmented must notice (flag word read with the pivot flag), assemble S again, factorise it with the level launches
+    and return the right step; the event is counted and the handle stays on the level launches."""
+    d = pkg.datasets.load_named("ladybug-1723", 0.25)[0]
+    prob = Problem.bundle_adjustment(d, OptimizationType.SelfCalibration, 1.0)
+    ref = GpuSchurComplementSolver(0).with_option("factor_flow", 0).initialize_structure(prob)
+    ref.set_parameters(d.poses, d.intr, d.points)
+    want = ref.solve_augmented_equation(1e-3).copy()
+    assert ref.counters()["factor_flow_groups"] == 0
+    ref.close()
+    s = GpuSchurComplementSolver(0).with_option("factor_flow", 8).initialize_structure(prob)
+    s.set_parameters(d.poses, d.intr, d.points)
+    good = s.solve_augmented_equation(1e-3).copy()
+    c0 = s.counters()
+    assert c0["factor_flow_groups"] >= 2 and c0["factor_flow_timeouts"] == 0, c0
+    # (S is assembled with atomics on a few shared blocks: two factorisations agree to rounding times cond(S))
+    assert rel(good, want) < 1e-7
+    s.set_option("debug_poison_factor", 1)
+    got = s.solve_augmented_equation(1e-3).copy()          # a few seconds: the poisoned wait runs to its limit
+    c = s.counters()
+    print("counters after the poisoned factorisation:", c, "vs level launches", rel(got, want))
+    assert c["factor_flow_timeouts"] == 1 and np.all(np.isfinite(got)) and rel(got, want) < 1e-7
+    again = s.solve_augmented_equation(1e-3).copy()         # the handle stays on the level launches
+    assert rel(again, want) < 1e-7 and s.counters()["factor_flow_timeouts"] == 1
     s.close()

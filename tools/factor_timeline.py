@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = []
 for r in rows:
     n = r["Kernel_Name"]
-    short = ("potrf" if "potrf" in n else "gemm_small_strip" if "small_strip" in n else "gemm_small" if "gemm_nt_small" in n else
+    short = ("flow" if "factor_flow" in n else "potrf" if "potrf" in n else "gemm_small_strip" if "small_strip" in n else "gemm_small" if "gemm_nt_small" in n else
              "gemm" if "tile_gemm_nt" in n else "rows" if ("schur_rows" in n or "schur_pairs" in n) else "tri" if ("tri_step" in n or "tri_fwd_flow" in n) else None)
     if short:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short, int(r["Queue_Id"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)))
@@ -30,6 +30,8 @@ tot = {}
 for s, e, k, q, g in f: tot[k] = tot.get(k, 0) + (e - s)
 print("busy per kernel kind (ms):", {k: round(v / 1e6, 2) for k, v in tot.items()})
 # critical path view: potrf launches and what happens between consecutive potrfs
+for x in f:
+    if x[2] == "flow": print("dataflow launch of the top groups: start %.1f us, duration %.1f us, %d workgroups" % ((x[0] - t0) / 1e3, (x[1] - x[0]) / 1e3, x[4]))
 pot = [x for x in f if x[2] == "potrf"]
 print("potrf launches", len(pot), "sum %.2f ms" % (sum(e - s for s, e, *_ in pot) / 1e6))
 print("%4s %8s %8s %8s  | between this potrf's end and the next potrf's start: main-queue kernels" % ("lv", "start", "dur", "wgs"))
