@@ -793,7 +793,7 @@ __device__ __forceinline__ double dpp_add_masked(double x) {   // x + (x moved b
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, BANK_MASK, true);
     return x + __hiloint2double(hi, lo);
 }
-template <int DC, bool LEGACY = false>
+template <int DC, bool LEGACY = false, int FABL = 0>   // FABL (timing experiments): 1 no fold over the groups, 2 no stores
 __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const int64_t pb_dst, const uint32_t pb_flags,
                                              double acc[9], int lane) {
     constexpr int NB3 = DC / 3, GL = NB3 * NB3;
@@ -801,7 +801,10 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
     int g, sub;
     pairs_lane_map<DC, LEGACY>(lane, g, sub);
     bool storer;
-    if (DC == 9 && !LEGACY) {
+    if (FABL & 1) {
+        storer = DC == 9 ? (lane == 63 || (lane & 7) == 6) : lane < GL;
+        if (DC == 9) sub = lane == 63 ? 8 : lane >> 3;
+    } else if (DC == 9 && !LEGACY) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             // sub-blocks 0..7: sum over the octet's lanes 0..6 into lane 6 (row_shr 4, 2, 1 into the upper half-octets only)
@@ -831,6 +834,7 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
         }
         storer = lane < GL;
     }
+    if ((FABL & 2) && acc[0] != 1.2345e300) return;
     if (storer) {
         double* dst = tiles + pb_dst;
         if (pb_flags == 0) {
@@ -847,7 +851,9 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
 }
 
 // ABL (timing experiments only, results wrong when != 0): 1 no per-pair gathers, 2 no block products, 4 no U / V stores,
-// 8 no flush (fold + store of the finished block), 16 no camera reads, 32 no Jacobian arithmetic; 64 (results RIGHT): phase
+// 8 no flush (fold + store of the finished block) -- NOTE: with the flush gone seven of the nine accumulators are dead and the
+// compiler drops their FMAs, so 8 measures "no flush and 7/9 of the products", not the flush (round 4: 512 / 1024 below do) --,
+// 512 no fold over the groups, 1024 no stores of the finished block, 16 no camera reads, 32 no Jacobian arithmetic; 64 (results RIGHT): phase
 // stamps -- every wave adds the shader cycles it spent in each phase of its chunks to g_pair_phase (read with
 // pairs_phase_cycles): 0 wait for the gathers, 1 unstage, 2 cameras + both Jacobians + U / V stores, 3 issue, 4 products and
 // flushes, 5 chunks, 6 flushes alone, 7 number of flushes
@@ -1147,7 +1153,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         };
         auto flush = [&]() {
             const unsigned long long f0 = stamp();
-            if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0>(tiles, cur_dst, cur_flags, acc, lane);
+            if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0, (ABL >> 9) & 3>(tiles, cur_dst, cur_flags, acc, lane);
             else if (acc[0] == 1.2345e300) tiles[0] = acc[1];
             if (ABL & 64) { ph[6] += stamp() - f0; ph[7] += 1; }
         };
@@ -1488,9 +1494,9 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
     const int g_pairs_variant = variant, g_pairs_ablation = ablation;
     if (variant >= 2 && orec && ablation != 0 && dc == 9) {   // timing experiments on the record form (SelfCalibration only)
 #define PAIRS_RA(A) case A: hipLaunchKernelGGL((k_schur_pairs_r<9, false, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec); break
-        switch (ablation) { PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3); default: break; }
+        switch (ablation) { PAIRS_RA(512); PAIRS_RA(1024); PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3); default: ablation = 0; break; }   // (an unlisted value: the plain kernel below, never a missing launch)
 #undef PAIRS_RA
-        return;
+        if (ablation != 0) return;
     }
     if (variant >= 2 && orec && ablation == 0) {   // record form (needs k_landmark_reduce's projection records)
         const bool masked = v.mask_code != (dc == 9 ? 7 : 6);
