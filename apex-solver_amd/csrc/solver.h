@@ -187,6 +187,10 @@ class Solver : public LmBackend {
 
     // device
     hipStream_t stream_ = nullptr;
+    // host -> device copies of caller (pageable) memory through two pinned chunks: the DMA of one overlaps the memcpy into the other
+    int upload_staged(void* dst_dev, const void* src_host, size_t bytes);
+    void* pin_[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev_[2] = {nullptr, nullptr};
     double *poses_[2] = {nullptr, nullptr}, *intr_[2] = {nullptr, nullptr}, *pts_[2] = {nullptr, nullptr};
     double* camp_[2] = {nullptr, nullptr};  // prepared cameras of the two parameter sets
     RowTask* rtasks_ = nullptr;

@@ -78,7 +78,7 @@ def _open_maybe_bz2(path: str, loader):
 def load_named(shape: str, scale: float = 1.0):
     """-> (BAProblemData, "real" | "synthetic", source path or None).  A real file is used at scale 1 only (the scaled
     shapes are parity-test sizes of the generator)."""
-    if scale == 1.0 and not shape.endswith("-hub"):
+    if scale == 1.0 and not shape.endswith("-hub") and "-mix:" not in shape:
         p = bal_path(shape)
         if p:
             from .bal import BalLoader

@@ -162,12 +162,19 @@ def make_problem(
     hub_frac: float = 0.0,
     hub_obs_prob: float = 0.25,
     long_range_prob: float = 0.0001,
+    mix_frac: float = 0.0,
 ) -> BAProblemData:
     """Generate a synthetic BA problem (see module docstring).
 
     `behind_frac` > 0 moves that fraction of the landmarks behind a camera's
     image plane so that the cheirality branch (zero residual and Jacobian,
     projection_factor.rs:227-238) is exercised.
+
+    `mix_frac` > 0 is the structure sweep between "banded" and "hubs" ("<shape>-mix:<p>"): that fraction of the landmarks
+    ignores the capture window and draws each of its cameras from a global POPULARITY law over all cameras -- rank r with
+    probability ~ 1 / (r + 1), ranks dealt to cameras by a fixed pseudo-random permutation -- the co-visibility of an
+    internet photo collection (crates/apex-io/datasets.toml:155-156: final-13682 is one) rather than of a capture
+    sequence.  A landmark may draw a camera twice (duplicate observations are legal input: tests/test_gpu_parity.py).
 
     `hub_frac` > 0 is the NON-BANDED stress variant ("<shape>-hub"): that fraction of the cameras (evenly spread over
     the ring) are hubs; a landmark anywhere on the ring swaps one of its window cameras for a random hub with
@@ -210,6 +217,15 @@ def make_problem(
     stratum = W // kk
     off = slot * stratum + np.floor(rng.uniform(41, n_obs) * stratum).astype(np.int64)
     cam_idx = (centre[pt_idx] - W // 2 + off) % n_cam
+    if mix_frac > 0.0:
+        mixed = rng.uniform(46, n_pt) < mix_frac
+        # popularity ranks by the inverse of P(rank <= r) = ln(r + 1) / ln(n + 1); the slot index is added so that one
+        # landmark rarely draws a rank twice
+        u = rng.uniform(47, n_obs)
+        rank = np.minimum(np.floor(np.exp(u * np.log(n_cam + 1.0))).astype(np.int64) - 1 + slot, n_cam - 1)
+        order = np.argsort(rng.uniform(48, n_cam), kind="stable")      # rank -> camera
+        sel = mixed[pt_idx]
+        cam_idx = np.where(sel, order[rank], cam_idx)
     if hub_frac > 0.0:
         n_hub = max(1, int(round(hub_frac * n_cam)))
         hubs = (np.arange(n_hub, dtype=np.int64) * n_cam) // n_hub + (n_cam // (2 * n_hub))
@@ -299,7 +315,12 @@ def make_named(shape: str, scale: float = 1.0) -> BAProblemData:
     """One of the BASELINE.json shapes; `scale` < 1 shrinks cameras and landmarks
     proportionally (same generator, same per-landmark statistics)."""
     hub = shape.endswith("-hub")
-    cid, n_cam, n_pt, k_lo, k_hi = SHAPES[shape[:-4] if hub else shape]
+    mix = 0.0
+    base = shape[:-4] if hub else shape
+    if "-mix:" in base:
+        base, frac = base.split("-mix:")
+        mix = float(frac)
+    cid, n_cam, n_pt, k_lo, k_hi = SHAPES[base]
     if scale != 1.0:
         n_cam = max(8, int(round(n_cam * scale)))
         n_pt = max(16, int(round(n_pt * scale)))
@@ -312,7 +333,7 @@ def make_named(shape: str, scale: float = 1.0) -> BAProblemData:
     if path and os.path.exists(path):
         z = np.load(path)
         return BAProblemData(**{k: z[k] for k in z.files}, name=nm)
-    d = _make_named_uncached(shape, scale, nm, hub, cid, n_cam, n_pt, k_lo, k_hi)
+    d = _make_named_uncached(shape, scale, nm, hub, cid, n_cam, n_pt, k_lo, k_hi, mix)
     if path:
         os.makedirs(cache, exist_ok=True)
         tmp = path + f".{os.getpid()}.tmp.npz"
@@ -322,8 +343,8 @@ def make_named(shape: str, scale: float = 1.0) -> BAProblemData:
     return d
 
 
-def _make_named_uncached(shape, scale, nm, hub, cid, n_cam, n_pt, k_lo, k_hi) -> BAProblemData:
-    return make_problem(n_cam, n_pt, k_lo, k_hi, config_id=cid, name=nm, hub_frac=0.015 if hub else 0.0)
+def _make_named_uncached(shape, scale, nm, hub, cid, n_cam, n_pt, k_lo, k_hi, mix=0.0) -> BAProblemData:
+    return make_problem(n_cam, n_pt, k_lo, k_hi, config_id=cid, name=nm, hub_frac=0.015 if hub else 0.0, mix_frac=mix)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--variant", default="sparse", choices=["sparse", "iterative", "implicit"])
     ap.add_argument("--cg", default="", help="max_iter,tol of the PCG variants (default: the reference's 200,1e-6 / implicit 500,1e-9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-variants", action="store_true", help="skip the Iterative / matrix-free runs that follow the timed region of a Sparse run")
     ap.add_argument("--opt", action="append", default=[], help="implementation switch name=value (apexgpu_set_option), repeatable")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0: full size when the reference's dense S fits (<= 2300 cameras), else a ~1000-camera sample")
     return ap.parse_args()
@@ -455,6 +456,30 @@ def main():
     }
     if args.variant != "sparse":
         out["pcg_iterations_per_step"] = state["pcg"][args.warmup:]
+    elif world == 1 and not args.no_other_variants:
+        # OUTSIDE the timed region, same handle, same problem, the optimisation simply goes on: the reference's BA default
+        # (SchurVariant::Iterative, 200 Jacobi-PCG iterations at 1e-6 on the explicit S: levenberg_marquardt.rs:519-530 -- what
+        # every BASELINE.md row was published with) and the matrix-free IterativeSchurSolver at ITS defaults (500 / 1e-9,
+        # implicit_schur.rs:94-95), whose cost does not depend on the fill of S: the structure-independent bound of an LM
+        # iteration on this problem.
+        other = {}
+        for key, var, cg in (("iterative_ms", SchurVariant.Iterative, (200, 1e-6)), ("fallback_ms_implicit", SchurVariant.Implicit, (500, 1e-9))):
+            try:
+                s.with_variant(var).with_cg_params(*cg)
+                lm_step(s, state)
+                torch.cuda.synchronize()
+                n0 = len(state["pcg"])
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    lm_step(s, state)
+                torch.cuda.synchronize()
+                out[key] = (time.perf_counter() - t1) * 1e3 / 2
+                other[key] = {"ms_per_lm_iter": out[key], "cg_max_iter": cg[0], "cg_tol": cg[1], "pcg_iterations": state["pcg"][n0:],
+                              "steps": 2, "cost_after": state["cost"]}
+            except Exception as e:
+                other[key] = {"error": repr(e)}
+        s.with_variant(SchurVariant.Sparse).with_cg_params(200, 1e-6)
+        out["other_variants"] = other
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sc = args.cpu_sample_scale
         # the reference's dense S (explicit_schur.rs:782) of ladybug-1723 / venice-1778 is ~2 GB: the oracle runs those at

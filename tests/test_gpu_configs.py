@@ -322,3 +322,44 @@ def test_hub_full_size_properties():
     s.solve_augmented_equation(lam, want_step=False)
     one_lm_iteration_behaves(s, lam)
     s.close()
+
+
+# ---- the structure sweep between "banded" and "hubs": a fraction of the landmarks drawn from a global camera popularity ------
+def test_mix_shape_vs_oracle(oracle):
+    """final-13682-mix:0.05 at 1/10 of the named size (1,368 cameras): 5 % of the landmarks ignore the capture window and take
+    their cameras from a power-law popularity over all cameras (an internet photo collection rather than a capture sequence:
+    crates/apex-io/datasets.toml:155-156).  S, g_red, the gradient and the step against the oracle's dense path; the
+    border ordering and the fill this structure causes are invisible at the boundary.  Both solvers of the headline JSON:
+    the Cholesky variant and the matrix-free fallback (its step against the Cholesky step of the same S)."""
+    d = pkg.synthetic.make_named("final-13682-mix:0.05", 0.1)
+    lam = 1e-3
+    prob, s = make(d, "selfcal")
+    info = dict(s.info(), border_cameras=s.setup_times()["hub_cameras"])
+    banded = pkg.synthetic.make_named("final-13682", 0.1)
+    pb, sb = make(banded, "selfcal")
+    ib = sb.info(); sb.close()
+    print("mix 0.05:", {k: info[k] for k in ("tile_rows", "tiles", "touched_tiles", "etree_levels", "border_cameras")},
+          "| banded:", {k: ib[k] for k in ("tiles", "touched_tiles", "etree_levels")})
+    assert info["touched_tiles"] > 2 * ib["touched_tiles"]          # the popular cameras couple far-apart tiles
+    o = oracle.from_data(d, prob.layout, mode="selfcal", huber_delta=1.0)
+    assert s.compute_cost() == pytest.approx(o.residuals()[0], rel=1e-13)
+    o.linearize()
+    ostep, ograd, oS, ogred = o.solve_augmented(lam, 0, want_schur=True)
+    step = s.solve_augmented_equation(lam)
+    S, gred = s.get_schur()
+    nc = prob.layout.cam_dof
+    bwd = np.linalg.norm(oS @ step[:nc] - ogred) / (np.linalg.norm(oS, 2) * np.linalg.norm(step[:nc]) + np.linalg.norm(ogred))
+    errs = dict(S=rel(S, oS), gred=rel(gred, ogred), grad=rel(s.get_gradient(), ograd), step=rel(step, ostep))
+    print("mix 0.05 vs oracle:", {k: f"{v:.1e}" for k, v in errs.items()}, f"backward {bwd:.1e}")
+    assert errs["S"] < 1e-12 and errs["gred"] < 1e-10 and errs["grad"] < 1e-12
+    assert bwd < 1e-13 and errs["step"] < 1e-6
+    one_lm_iteration_behaves(s, lam)
+    chol4 = s.solve_augmented_equation(1e4).copy()   # (the device Cholesky at cond(S) <= 1e5: 1e-10 of the oracle's in every parity case)
+    s.close()
+    # the matrix-free fallback on the same structure, at lambda = 1e4 where its iteration determines the step
+    prob, s = make(d, "selfcal", variant=SchurVariant.Implicit)
+    s.with_cg_params(500, 1e-12)
+    istep = s.solve_augmented_equation(1e4)
+    print("mix 0.05 matrix-free at lambda 1e4:", s.info()["pcg_iterations"], "iterations, step vs the Cholesky variant", rel(istep, chol4))
+    assert rel(istep, chol4) < 1e-8
+    s.close()

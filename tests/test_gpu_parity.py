@@ -191,6 +191,18 @@ def test_pcg_variant_vs_oracle(oracle, mode):
     assert abs(s.info()["pcg_iterations"] - o.last_pcg_iters) <= 2
     r_gpu = np.linalg.norm(oS @ step[:nc] - ogred); r_ora = np.linalg.norm(oS @ ostep[:nc] - ogred)
     assert r_gpu < 10 * max(r_ora, 1e-6 * max(np.linalg.norm(ogred), 1.0))
+    # the SOLUTION, not only the iteration count: both iterations run to 1e-13 (a few hundred to ~1,500 steps on this size) and
+    # the two steps must agree -- to 1e-8 at lambda = 1e-3 (cond(S) ~ 1e9; the oracle's own PCG lands 2e-10 from its Cholesky
+    # there) and to 1e-10 at lambda = 1e4
+    s.with_cg_params(5000, 1e-13); o.set_cg_params(5000, 1e-13)
+    for lam, tol in ((1e-3, 1e-8), (1e4, 1e-10)):
+        s.discard_step()
+        ostep, _ = o.solve_augmented(lam, 1)
+        ochol, _ = o.solve_augmented(lam, 0)
+        step = s.solve_augmented_equation(lam)
+        print(f"lambda {lam:g}: pcg iterations gpu/oracle {s.info()['pcg_iterations']}/{o.last_pcg_iters}  step gpu vs oracle pcg {rel(step, ostep):.2e}"
+              f"  vs oracle Cholesky {rel(step, ochol):.2e}")
+        assert rel(step, ostep) < tol and rel(step, ochol) < 10 * tol
     s.close()
 
 
@@ -221,6 +233,15 @@ def test_implicit_schur_pcg_vs_oracle(oracle, mode):
     nc_cost = s.eval_step()
     assert nc_cost < s.compute_cost() or pred > 0
     s.discard_step()
+    # the SOLUTION of the matrix-free iteration, run to 1e-13 on both sides, where it determines the step: lambda = 1e4
+    # (at 1e-3 its stopping rule, relative to max(|b|, 1), leaves 1e-6 in the oracle itself)
+    s.with_cg_params(5000, 1e-13); o.set_cg_params(5000, 1e-13)
+    istep, _ = o.solve_augmented(1e4, 2)
+    ochol, _ = o.solve_augmented(1e4, 0)
+    step = s.solve_augmented_equation(1e4)
+    print(f"lambda 1e4: implicit pcg iterations gpu/oracle {s.info()['pcg_iterations']}/{o.last_pcg_iters}  step vs oracle implicit {rel(step, istep):.2e}"
+          f"  vs oracle Cholesky {rel(step, ochol):.2e}")
+    assert rel(step, istep) < 1e-9 and rel(step, ochol) < 1e-9
     s.close()
 
 
@@ -429,7 +450,7 @@ def test_cheirality_and_no_loss(oracle):
         assert np.sum((r.reshape(-1, 2) == 0).all(1)) > 0
         assert s.compute_cost() == pytest.approx(c, rel=1e-13)
         assert rel(s.get_residual(), r) < 1e-12
-        o.linearize()
+        _, _, oJp, _, oJi = o.linearize()
         ostep, ograd, oS, ogred = o.solve_augmented(1e-3, 0, want_schur=True)
         step = s.solve_augmented_equation(1e-3)
         S, gred = s.get_schur()
@@ -441,6 +462,23 @@ def test_cheirality_and_no_loss(oracle):
         hinv, gl = s.get_landmark_blocks()
         assert np.isfinite(S).all() and np.isfinite(step).all()
         assert np.abs(S - oS).max() / scale < 1e-6
+        # ... and block by block, against what is cancelled IN THAT BLOCK: S_ij = Hcc_ij - E_ij with E_ij = sum_l W_il Hll^-1 W_jl^T;
+        # the rounding of a difference is relative to max(|Hcc_ij|, |E_ij|), which the oracle's undamped H and S give
+        # (E = Hcc + lambda I - S).  A block whose terms are ~1 must then match to ~1e-13 however large the near-singular
+        # landmark makes the blocks next to it -- the global bound above would let it be wrong by 1e-6 * 1e12.
+        lay = prob.layout
+        Hcc = np.zeros((lay.cam_dof, lay.cam_dof))
+        for k, c in enumerate(d.cam_idx):   # Hcc = sum over the factors of Jc^T Jc, reference column order [intr | pose]
+            cols = np.r_[lay.intr_col[c] + np.arange(3), lay.pose_col[c] + np.arange(6)]
+            Jc = np.hstack([oJi.reshape(-1, 2, 3)[k], oJp.reshape(-1, 2, 6)[k]])
+            Hcc[np.ix_(cols, cols)] += Jc.T @ Jc
+        E = Hcc + 1e-3 * np.eye(Hcc.shape[0]) - oS
+        nb = Hcc.shape[0] // 3
+        mag = np.maximum(np.abs(Hcc), np.abs(E)).reshape(nb, 3, nb, 3).max(axis=(1, 3))
+        err = np.abs(S - oS).reshape(nb, 3, nb, 3).max(axis=(1, 3))
+        worst = float((err / np.maximum(mag, 1e-300)).max())
+        print("huber", huber, "worst block error relative to the block's cancelled magnitude", worst, "block magnitudes", float(mag[mag > 0].min()), float(mag.max()))
+        assert worst < 1e-11
         # the step itself: against the exact step of this linearisation, next to the fp64 oracle's error, and at
         # lambda = 1e4 against the fp64 oracle outright
         referee.check_step(o, s, step, ostep, 1e-3, 9, label=f"cheirality huber={huber}")

@@ -27,9 +27,17 @@ def test_rccl_ranks_match_single_rank(world):
         pytest.skip(f"needs {world} GPUs on this node")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the first multi-GPU record of this path should be diagnosable from its log alone: RCCL reports the topology it found,
+    # the rings / trees / channels it built and the transport of every connection (xGMI = P2P/direct pointer) at init
+    env.setdefault("NCCL_DEBUG", "INFO"); env.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,ENV")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "rccl_worker.py")],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    topo = [l for l in (p.stdout + p.stderr).splitlines()
+            if "NCCL INFO" in l and any(k in l for k in ("Channel", "Ring", "Tree", "comm 0x", "via P2P", "via SHM", "via NET", "XGMI", "nRanks", "Connected all"))]
+    print(f"RCCL topology lines ({len(topo)}):")
+    for l in topo[:80]:
+        print("   ", l[-200:])
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RCCL_RESULT ")]
     assert line, p.stdout[-2000:]

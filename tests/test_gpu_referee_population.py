@@ -10,8 +10,10 @@ explains why), so the assertions are on the distribution:
     >= 70 % of the cases within 2 x   ... and rarely much worse
     every e_gpu <= 1e-7, worst ratio <= 64
 
-The problems are small, so the device's Schur reduction and factorisation are deterministic (no split blocks, conflict-free
-update rounds): the numbers below do not move from run to run.
+The 32 small problems make the device's Schur reduction and factorisation deterministic (no split blocks, conflict-free
+update rounds): their numbers do not move from run to run.  Round 4 adds two members per mode with 320 and 420 cameras
+(three tile rows and more: split blocks with the atomic flush, nested-dissection levels, the dataflow launch of the top
+groups), which the small ones never reach; their last bits depend on the order of a few atomic adds.
 """
 import numpy as np
 import pytest
@@ -23,6 +25,7 @@ from apex_solver_amd.solver import GpuSchurComplementSolver, OptimizationType, P
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(12, 500), (24, 1200), (40, 2000), (60, 3000)]
+LARGE = [(320, 9000), (420, 12000)]
 
 
 def test_device_step_is_as_accurate_as_fp64_on_a_population(oracle):
@@ -30,8 +33,8 @@ def test_device_step_is_as_accurate_as_fp64_on_a_population(oracle):
     rows = []
     for mode in ("selfcal", "ba"):
         ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
-        for k in range(16):
-            n_cam, n_pt = SHAPES[k % 4]
+        for k in range(16 + len(LARGE)):
+            n_cam, n_pt = SHAPES[k % 4] if k < 16 else LARGE[k - 16]
             d = pkg.synthetic.make_problem(n_cam, n_pt, 3, 7, config_id=300 + k)
             prob = Problem.bundle_adjustment(d, ot, 1.0)
             s = GpuSchurComplementSolver(0).initialize_structure(prob)
