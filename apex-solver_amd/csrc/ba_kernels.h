@@ -57,23 +57,14 @@ struct TileMap {
     int nt;
 };
 
-constexpr int kRowThreads = 256;  // k_schur_rows workgroup size (512 threads need <= 128 VGPRs per lane to keep two
-                                 // workgroups per CU: that spills to scratch -> +10 GB of HBM writes per launch, same time)
-constexpr int kRowBatch = kRowThreads;  // (i,j) pairs one k_schur_rows workgroup handles per sweep
 constexpr int kRowCap9 = 96;    // neighbour cameras whose 9x9 blocks one workgroup keeps in LDS (62 KB: 2 workgroups per CU)
 constexpr int kRowCap6 = 160;   // same for 6x6 blocks (46 KB)
 
-struct RowTask {   // one workgroup of k_schur_rows: camera `cam`, neighbours nbr[nbr0 .. nbr0+nnbr)
+struct RowTask {   // one workgroup of k_schur_rows2: camera `cam`, neighbours nbr[nbr0 .. nbr0+nnbr)
     int cam;
     int nbr0, nnbr;
     int diag;            // this chunk holds the camera's own diagonal block (and its g sums)
-    int batch0, nbatch;  // the camera's batches
-};
-
-struct RowBatch {  // <= kRowBatch pairs: camera-major observations [first, first+count)
-    int first, count;
-    int jj0, njj;        // njj != 0: one observation with more partners than a batch; partners [jj0, jj0+njj)
-    int total;           // pairs in the batch
+    int batch0, nbatch;  // the camera's chunks (RowChunk)
 };
 
 // k_schur_rows2: one lane per observation i of the row camera, looping over its partner observations.
@@ -89,11 +80,6 @@ struct RowChunk {  // <= 64 entries with (nearly) equal partner counts: the work
 };
 constexpr int kRowMaxPartners = 64;  // an observation with more partners is split into several entries
 
-struct ScatterTask {
-    int i0, ni;  // first block of observations (landmark-major indices)
-    int j0, nj;  // second block (nj == 0: diagonal task)
-};
-
 void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* cam_ptr, const int* cam_obs,
                        double lambda, int add_lambda, const double* hinv, const double* g_l, int with_self, double* g_c,
                        double* g_red, hipStream_t s);
@@ -107,13 +93,8 @@ void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const d
 void launch_extract_diag_blocks(int dc, int64_t n_cam, const TileMap& tm, double* sd, hipStream_t s);
 void launch_precond_blocks(int dc, int64_t n_cam, const double* sd, double* minv, hipStream_t s);
 void launch_precond_apply(int dc, int64_t n_cam, const double* minv, const double* r, double* z, hipStream_t s);
-void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const ScatterTask* tasks, int n_tasks,
-                          const double* hinv, const double* g_l, double* g_red, hipStream_t s);
 // mask_code = 4 POSE + 2 LANDMARK + INTRINSIC: which blocks of the factors' Jacobians exist (OptimizeParams, src/factors/mod.rs:66-101)
 void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, int mask_code, hipStream_t s);
-void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
-                       const RowBatch* batches, const int* cam_obs, const uint16_t* cam_obs_off, const int* nbr,
-                       const double* hinv, int dbg, hipStream_t s);
 void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
                         const RowChunk* chunks, const RowEntry* entries, const int* nbr, const double* hinv, hipStream_t s);
 // orec: the projection records of the same linearisation (k_landmark_reduce) or NULL -- the record form of the kernel

@@ -15,7 +15,7 @@
 // record instead of streaming a 216-byte Jacobian row through HBM):
 //   k_cam_reduce       camera-major   H_cc diagonal blocks (+lambda), g_c, g_red := -g_c     (A6-A8)
 //   k_landmark_reduce  landmark-major H_ll, g_l, eigen-gated 3x3 inverse                     (A6, A8, A9)
-//   k_schur_scatter    landmark-major S -= (W Hll^-1) W^T, g_red += W Hll^-1 g_l             (A10, A11)
+//   k_schur_rows2      camera-major   S -= (W Hll^-1) W^T in LDS row blocks (the A/B of the pair list, schur_pairs.hip) (A10)
 //   k_back_substitute  landmark-major dl = Hll^-1 (-g_l - W^T dc)                            (A11)
 //   k_retract_*        x (+) d with the fixed-DOF mask                                       (A15)
 //   k_cost_partial     1/2 |r~|^2 on a (trial) parameter set                                 (A16)
@@ -327,137 +327,6 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
 }
 
 // ------------------------------------------------------------------------------------------
-// K2b: the Schur reduction.  One 256-thread workgroup per TASK.
-//   diagonal task  : observations [i0, i0+ni) (<= 128, whole landmarks or one block of a big
-//                    landmark); pairs (i <= j) inside the same landmark.
-//   off-diag task  : two disjoint blocks [i0,i0+ni), [j0,j0+nj) of ONE big landmark (<= 64 each);
-//                    all ni*nj pairs.
-// Phase 1: one lane per observation recomputes the Jacobian blocks, forms W = Jc^T Jl (DC x 3) and
-//          Y = W Hll^-1, parks both in LDS, and (diagonal tasks) adds Y g_l into g_red.
-// Phase 2: the DC*DC elements of each pair's block are spread over consecutive lanes, so one wave
-//          atomic instruction covers 64 consecutive elements (DC-long contiguous row segments of
-//          one S block) instead of 64 different blocks.
-// ------------------------------------------------------------------------------------------
-template <int DC>
-__global__ __launch_bounds__(256) void k_schur_scatter(BAView v, TileMap tm, const ScatterTask* __restrict__ tasks,
-                                                         const double* __restrict__ hinv,
-                                                         const double* __restrict__ g_l,
-                                                         double* __restrict__ g_red) {
-    constexpr int WY = DC * 3;
-    constexpr int E = DC * DC;
-    constexpr int PP = 256 / E;  // pairs per sweep
-    __shared__ double sW[kScatterCap * WY];
-    __shared__ double sY[kScatterCap * WY];
-    __shared__ uint32_t sCam[kScatterCap];
-    __shared__ int sEnd[kScatterCap];      // local index one past the last obs of this obs' landmark
-    __shared__ int sScan[kScatterCap + 1]; // pair offsets (diagonal tasks)
-    const ScatterTask t = tasks[blockIdx.x];
-    const int n = t.ni + t.nj;
-    const int tid = threadIdx.x;
-
-    if (tid < n) {
-        const int i = (tid < t.ni) ? t.i0 + tid : t.j0 + (tid - t.ni);
-        const uint32_t c = v.o_cam[i];
-        const uint32_t l = v.o_pt[i];
-        const double2 uv = v.o_uv[i];
-        Cam cam;
-        load_cam_prepared(v.camp + kCamStride * (size_t)c, cam);
-        const double pw[3] = {v.pts[3 * (size_t)l], v.pts[3 * (size_t)l + 1], v.pts[3 * (size_t)l + 2]};
-        double r[2], Jc[2][DC], Jl[2][3];
-        linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
-        double Hi[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Hi[k] = hinv[kLmStride * (size_t)l + k];
-        double yg[DC];
-#pragma unroll
-        for (int a = 0; a < DC; ++a) {
-            const double w0 = Jc[0][a] * Jl[0][0] + Jc[1][a] * Jl[1][0];
-            const double w1 = Jc[0][a] * Jl[0][1] + Jc[1][a] * Jl[1][1];
-            const double w2 = Jc[0][a] * Jl[0][2] + Jc[1][a] * Jl[1][2];
-            const double y0 = w0 * Hi[0] + w1 * Hi[3] + w2 * Hi[6];
-            const double y1 = w0 * Hi[1] + w1 * Hi[4] + w2 * Hi[7];
-            const double y2 = w0 * Hi[2] + w1 * Hi[5] + w2 * Hi[8];
-            sW[tid * WY + 3 * a + 0] = w0; sW[tid * WY + 3 * a + 1] = w1; sW[tid * WY + 3 * a + 2] = w2;
-            sY[tid * WY + 3 * a + 0] = y0; sY[tid * WY + 3 * a + 1] = y1; sY[tid * WY + 3 * a + 2] = y2;
-            yg[a] = y0 * hinv[kLmStride * (size_t)l + kLmG] + y1 * hinv[kLmStride * (size_t)l + kLmG + 1] + y2 * hinv[kLmStride * (size_t)l + kLmG + 2];
-        }
-        sCam[tid] = c;
-        if (t.nj == 0) {
-            // g_red = -g_c + W Hll^-1 g_l   (explicit_schur.rs:928-977 with the signs folded)
-#pragma unroll
-            for (int a = 0; a < DC; ++a) unsafeAtomicAdd(&g_red[(size_t)c * DC + a], yg[a]);
-            int e = v.pt_ptr[l + 1] - t.i0;  // local end of this landmark, clipped to the task
-            sEnd[tid] = e < t.ni ? e : t.ni;
-        }
-    }
-    __syncthreads();
-
-    int n_pairs;
-    if (t.nj == 0) {
-        // exclusive scan of (end - i) over the task's observations (<= 128 values)
-        if (tid < kScatterCap) sScan[tid] = (tid < t.ni) ? (sEnd[tid] - tid) : 0;
-        __syncthreads();
-        for (int off = 1; off < kScatterCap; off <<= 1) {
-            int x = 0;
-            if (tid < kScatterCap && tid >= off) x = sScan[tid - off];
-            __syncthreads();
-            if (tid < kScatterCap) sScan[tid] += x;
-            __syncthreads();
-        }
-        n_pairs = sScan[kScatterCap - 1];  // inclusive total
-    } else {
-        n_pairs = t.ni * t.nj;
-    }
-
-    const int grp = tid / E, e = tid - grp * E;
-    if (grp < PP) {
-        const int a = e / DC, b = e - a * DC;
-        for (int p = grp; p < n_pairs; p += PP) {
-            int i, j;
-            if (t.nj == 0) {
-                // find i with excl(i) <= p < incl(i): binary search over inclusive sums
-                int lo = 0, hi = t.ni - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sScan[mid] > p) hi = mid; else lo = mid + 1;
-                }
-                i = lo;
-                const int excl = (i == 0) ? 0 : sScan[i - 1];
-                j = i + (p - excl);
-            } else {
-                i = p / t.nj;
-                j = t.ni + (p - i * t.nj);
-            }
-            const uint32_t ci = sCam[i], cj = sCam[j];
-            const double* Yi = sY + i * WY + 3 * a;
-            const double* Wj = sW + j * WY + 3 * b;
-            if (i == j) {
-                if (a >= b) {
-                    const double val = Yi[0] * Wj[0] + Yi[1] * Wj[1] + Yi[2] * Wj[2];
-                    unsafeAtomicAdd(s_block_ptr<DC>(tm, ci, ci) + a * kNB + b, -val);
-                }
-            } else if (ci == cj) {
-                if (a >= b) {
-                    const double* Yj = sY + j * WY + 3 * a;
-                    const double* Wi = sW + i * WY + 3 * b;
-                    const double val = (Yi[0] * Wj[0] + Yi[1] * Wj[1] + Yi[2] * Wj[2]) +
-                                       (Yj[0] * Wi[0] + Yj[1] * Wi[1] + Yj[2] * Wi[2]);
-                    unsafeAtomicAdd(s_block_ptr<DC>(tm, ci, ci) + a * kNB + b, -val);
-                }
-            } else if (ci > cj) {
-                const double val = Yi[0] * Wj[0] + Yi[1] * Wj[1] + Yi[2] * Wj[2];
-                unsafeAtomicAdd(s_block_ptr<DC>(tm, ci, cj) + a * kNB + b, -val);
-            } else {
-                const double* Yj = sY + j * WY + 3 * a;
-                const double* Wi = sW + i * WY + 3 * b;
-                const double val = Yj[0] * Wi[0] + Yj[1] * Wi[1] + Yj[2] * Wi[2];
-                unsafeAtomicAdd(s_block_ptr<DC>(tm, cj, ci) + a * kNB + b, -val);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Prepared cameras: normalise the stored quaternion twice (SE3::from, se3.rs:200-206, 107-113), turn it
 // into R once, and park [R t f k1 k2] in 16 doubles per camera for every per-observation kernel.
 // ------------------------------------------------------------------------------------------
@@ -499,134 +368,6 @@ __device__ __forceinline__ int hash_slot(const int* hkey, const int* hval, int k
         h = (h + 1) & (kHashSize - 1);
     }
     return -1;
-}
-
-template <int DC, int CAP, bool DBG>
-__global__ __launch_bounds__(kRowThreads) void k_schur_rows(BAView v, TileMap tm, const RowTask* __restrict__ tasks,
-                                                      const RowBatch* __restrict__ batches,
-                                                      const int* __restrict__ cam_obs,
-                                                      const uint16_t* __restrict__ cam_obs_off,
-                                                      const int* __restrict__ nbr, const double* __restrict__ hinv,
-                                                      int dbg) {
-    constexpr int E = DC * DC;
-    __shared__ double acc[CAP * E];
-    __shared__ double scam[CAP * kCamPitch];
-    __shared__ int hkey[kHashSize], hval[kHashSize];
-    __shared__ int s_i[kRowBatch], s_j[kRowBatch];
-    const RowTask t = tasks[blockIdx.x];
-    const int tid = threadIdx.x;
-    const uint32_t ci = (uint32_t)t.cam;
-    for (int idx = tid; idx < CAP * E; idx += kRowThreads) acc[idx] = 0.0;
-    for (int idx = tid; idx < kHashSize; idx += kRowThreads) hkey[idx] = -1;
-    __syncthreads();
-    if (tid < t.nnbr) {
-        const int key = nbr[t.nbr0 + tid];
-        unsigned h = ((unsigned)key * 2654435761u) >> 24;
-        while (atomicCAS(&hkey[h], -1, key) != -1) h = (h + 1) & (kHashSize - 1);
-        hval[h] = tid;
-    }
-    // the prepared cameras of all neighbours, staged once: a pair lane then reads its partner camera
-    // from LDS instead of gathering 128 bytes per pair through the vector cache
-    for (int idx = tid; idx < t.nnbr * kCamStride; idx += kRowThreads) {
-        const int sl = idx / kCamStride, k = idx - sl * kCamStride;
-        scam[sl * kCamPitch + k] = v.camp[(size_t)nbr[t.nbr0 + sl] * kCamStride + k];
-    }
-    __syncthreads();
-    Cam cam_i;
-    load_cam_prepared(v.camp + kCamStride * (size_t)ci, cam_i);
-
-    for (int b = t.batch0; b < t.batch0 + t.nbatch; ++b) {
-        const RowBatch bt = batches[b];
-        if (tid < bt.count) {
-            const int e = bt.first + tid;
-            const int i_s = cam_obs[e];
-            const int base = i_s - v.co_rank[e];  // first observation of the landmark (no pt_ptr / o_pt gathers)
-            int off, n, j0;
-            if (bt.njj) { off = 0; n = bt.njj; j0 = base + bt.jj0; }
-            else { off = cam_obs_off[e]; n = i_s - base; j0 = base; }  // partners: the observations BEFORE i
-            for (int q = 0; q < n; ++q) { s_i[off + q] = i_s; s_j[off + q] = j0 + q; }
-        }
-        __syncthreads();
-        if (tid < bt.total && !(DBG && (dbg & 4))) {
-            const int i_s = s_i[tid], j_s = s_j[tid];
-            const uint32_t cj = v.o_cam[j_s];
-            const int slot = hash_slot(hkey, hval, (int)cj);
-            if (slot >= 0) {
-                const uint32_t l = v.o_pt[i_s];
-                double Hi[9], pw[3];
-                {   // Hll^-1 and the point from the landmark record: aligned 16-byte loads of one line
-                    const double2* q = reinterpret_cast<const double2*>(hinv + kLmStride * (size_t)l);
-                    const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
-                    Hi[0] = a0.x; Hi[1] = a0.y; Hi[2] = a1.x; Hi[3] = a1.y; Hi[4] = a2.x; Hi[5] = a2.y; Hi[6] = a3.x; Hi[7] = a3.y;
-                    Hi[8] = a4.x; pw[0] = a4.y; pw[1] = a5.x; pw[2] = a5.y;
-                }
-                const double2 uvi = v.o_uv[i_s];
-                double r[2], Jc[2][DC], Jl[2][3];
-                linearize_obs<DC>(cam_i, pw, uvi.x, uvi.y, v.huber_delta, r, Jc, Jl);
-                double Y[DC][3];  // -Y_i: the sign of the Schur term is folded in here
-#pragma unroll
-                for (int a = 0; a < DC; ++a) {
-                    const double w0 = -(Jc[0][a] * Jl[0][0] + Jc[1][a] * Jl[1][0]);
-                    const double w1 = -(Jc[0][a] * Jl[0][1] + Jc[1][a] * Jl[1][1]);
-                    const double w2 = -(Jc[0][a] * Jl[0][2] + Jc[1][a] * Jl[1][2]);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) Y[a][c] = w0 * Hi[c] + w1 * Hi[3 + c] + w2 * Hi[6 + c];
-                }
-                double* blk = acc + slot * E;
-                Cam cam_j;
-                double rj[2], Jcj[2][DC], Jlj[2][3];
-                if (!(DBG && (dbg & 2))) {
-                    load_cam_prepared(scam + slot * kCamPitch, cam_j);
-                    const double2 uvj = v.o_uv[j_s];
-                    linearize_obs<DC>(cam_j, pw, uvj.x, uvj.y, v.huber_delta, rj, Jcj, Jlj);
-                } else {
-#pragma unroll
-                    for (int a = 0; a < DC; ++a) { Jcj[0][a] = Jc[0][a]; Jcj[1][a] = Jc[1][a]; }
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) { Jlj[0][a] = Jl[0][a]; Jlj[1][a] = Jl[1][a]; }
-                }
-                const bool dup = (cj == ci);  // the same camera sees the landmark twice (practically never)
-                if (DBG || dup) {
-#pragma unroll
-                    for (int bb = 0; bb < DC; ++bb) {
-                        const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
-                        const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
-                        const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
-#pragma unroll
-                        for (int a = 0; a < DC; ++a) {
-                            const double val = Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2;
-                            if (DBG && (dbg & 1)) { if (val == 1.2345e300) blk[0] = val; }
-                            else if (!dup) unsafeAtomicAdd(&blk[a * DC + bb], val);
-                            else {  // B + B^T on the diagonal block, kept in its lower triangle
-                                if (a >= bb) unsafeAtomicAdd(&blk[a * DC + bb], val);
-                                if (bb >= a) unsafeAtomicAdd(&blk[bb * DC + a], val);
-                            }
-                        }
-                    }
-                } else {  // straight-line: 243 FMA + 81 ds_add_f64, no per-element control flow
-#pragma unroll
-                    for (int bb = 0; bb < DC; ++bb) {
-                        const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
-                        const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
-                        const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
-#pragma unroll
-                        for (int a = 0; a < DC; ++a)
-                            unsafeAtomicAdd(&blk[a * DC + bb], Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- store the row block once; the diagonal block already holds H_cc + lambda I - sum Y_i W_i^T
-    // from k_cam_reduce and only receives the (rare) duplicate-observation cross terms ---------------------
-    for (int idx = tid; idx < t.nnbr * E; idx += kRowThreads) {
-        const int s = idx / E, e = idx - s * E, a = e / DC, bb = e - a * DC;
-        const uint32_t cj = (uint32_t)nbr[t.nbr0 + s];
-        double* dst = s_block_ptr<DC>(tm, ci, cj) + a * kNB + bb;
-        if (cj == ci) { if (bb <= a && acc[idx] != 0.0) *dst += acc[idx]; }
-        else *dst = acc[idx];
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1327,27 +1068,8 @@ void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv
     else hipLaunchKernelGGL(k_landmark_reduce<6>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag, lmu, orec);
 }
 
-void launch_schur_scatter(int dc, const BAView& v, const TileMap& tm, const ScatterTask* tasks, int n_tasks,
-                          const double* hinv, const double* g_l, double* g_red, hipStream_t s) {
-    if (n_tasks == 0) return;
-    if (dc == 9) hipLaunchKernelGGL(k_schur_scatter<9>, dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, hinv, g_l, g_red);
-    else hipLaunchKernelGGL(k_schur_scatter<6>, dim3(n_tasks), dim3(256), 0, s, v, tm, tasks, hinv, g_l, g_red);
-}
-
 void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, int mask_code, hipStream_t s) {
     if (n_cam > 0) hipLaunchKernelGGL(k_prepare_cams, dim3(grid_for(n_cam, 256, 0)), dim3(256), 0, s, n_cam, poses, intr, camp, mask_code);
-}
-
-void launch_schur_rows(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
-                       const RowBatch* batches, const int* cam_obs, const uint16_t* cam_obs_off, const int* nbr,
-                       const double* hinv, int dbg, hipStream_t s) {
-    if (n_tasks == 0) return;
-    const unsigned dyn = (unsigned)(dbg >> 8) * 1024u;  // ablation: extra dynamic LDS lowers the occupancy
-    // dbg != 0 selects the instrumented build of the kernel (timing ablations only)
-    if (dc == 9 && dbg == 0) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9, false>), dim3(n_tasks), dim3(kRowThreads), dyn, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
-    else if (dc == 9) hipLaunchKernelGGL((k_schur_rows<9, kRowCap9, true>), dim3(n_tasks), dim3(kRowThreads), dyn, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
-    else if (dbg == 0) hipLaunchKernelGGL((k_schur_rows<6, kRowCap6, false>), dim3(n_tasks), dim3(kRowThreads), dyn, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
-    else hipLaunchKernelGGL((k_schur_rows<6, kRowCap6, true>), dim3(n_tasks), dim3(kRowThreads), dyn, s, v, tm, tasks, batches, cam_obs, cam_obs_off, nbr, hinv, dbg);
 }
 
 void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,

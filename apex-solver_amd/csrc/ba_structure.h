@@ -27,7 +27,7 @@ struct BaStructOptions {
     int rank = 0, world = 1;
     bool dist_factor = true, tree_sharding = true;
     int dist_selftest = 0;
-    int schur_form = 3;        // 3 sorted pair list, 2 / 1 LDS rows, 0 global atomics
+    int schur_form = 3;        // 3 sorted pair list (default), 2 LDS rows (k_schur_rows2, the A/B)
     int pair_task_slots = 0;   // pair slots per wave task of the pair list (0: default)
 };
 
@@ -53,11 +53,8 @@ struct BaHostStructure {
     raw_vector<int> co_rank;
     int64_t n_pairs = 0, n_present = 0;
     // Schur task lists (only the selected form is built)
-    std::vector<ScatterTask> tasks;
     std::vector<int> nbr;
-    std::vector<RowBatch> rbatches;
-    std::vector<RowTask> rtasks, rtasks2;
-    std::vector<uint16_t> cam_obs_off;
+    std::vector<RowTask> rtasks2;
     std::vector<RowEntry> rentries;
     std::vector<RowChunk> rchunks;
     PairLists pl;

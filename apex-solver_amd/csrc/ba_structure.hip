@@ -342,44 +342,17 @@ void BaHostStructure::release_scratch() {
 
 void BaHostStructure::build_schur_lists(const BaStructOptions& o, const int* slot_host) {
     const double t0 = now_s();
-    tasks.clear(); nbr.clear(); rbatches.clear(); rtasks.clear(); rtasks2.clear(); cam_obs_off.clear(); rentries.clear(); rchunks.clear();
+    nbr.clear(); rtasks2.clear(); rentries.clear(); rchunks.clear();
     pl = PairLists();
-    const int64_t n_loc = (int64_t)o_cam.size();
-    if (o.schur_form == 3) {
+    if (o.schur_form < 0) {
+        // a matrix-free-only handle: S is never reduced, no lists
+    } else if (o.schur_form == 3) {
         // every camera pair (i, j) of a landmark, sorted by the block S(cam_i, cam_j) it adds to
         build_pair_lists(dc, nt, slot_host, n_cam, cinv.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(),
                          cam_obs.data(), &pl, o.pair_task_slots);
-    } else if (o.schur_form == 0) {
-        // ---- Schur-scatter tasks over the local landmarks (global-atomics form) --------------------------------------
-        int cur0 = -1, curn = 0;
-        auto flush = [&]() {
-            if (curn > 0) tasks.push_back({cur0, curn, 0, 0});
-            cur0 = -1; curn = 0;
-        };
-        for (int64_t l = lm_lo; l < lm_hi; ++l) {
-            const int b = pt_ptr[l], e = pt_ptr[l + 1], k = e - b;
-            if (k == 0) continue;
-            if (k > kScatterBlk) {
-                flush();
-                const int nb = (k + kScatterBlk - 1) / kScatterBlk;
-                for (int bi = 0; bi < nb; ++bi) {
-                    const int i0 = b + bi * kScatterBlk, ni = std::min(kScatterBlk, e - i0);
-                    tasks.push_back({i0, ni, 0, 0});
-                    for (int bj = bi + 1; bj < nb; ++bj) {
-                        const int j0 = b + bj * kScatterBlk, nj = std::min(kScatterBlk, e - j0);
-                        tasks.push_back({i0, ni, j0, nj});
-                    }
-                }
-                continue;
-            }
-            if (curn + k > kScatterCap) flush();
-            if (curn == 0) cur0 = b;
-            curn += k;
-        }
-        flush();
     } else {
-        // ---- k_schur_rows / k_schur_rows2: neighbour lists (cameras cj <= ci sharing a landmark with ci, from the FULL
-        // problem so that every rank writes the same blocks), per-camera pair batches, row tasks ------------------------
+        // ---- k_schur_rows2 (the LDS row form, kept as the A/B of the pair list): neighbour lists (cameras cj <= ci sharing a
+        // landmark with ci, from the FULL problem so that every rank writes the same blocks), row entries, row tasks --------
         std::vector<int> nbr_ptr(n_cam + 1, 0);
         {
             std::vector<std::vector<int>> lists(n_cam);
@@ -411,37 +384,7 @@ void BaHostStructure::build_schur_lists(const BaStructOptions& o, const int* slo
             for (auto& L : lists) nbr.insert(nbr.end(), L.begin(), L.end());
         }
         const int cap = (dc == 9) ? kRowCap9 : kRowCap6;
-        if (o.schur_form == 1) {
-            cam_obs_off.assign(n_loc, 0);
-            for (int64_t c = 0; c < n_cam; ++c) {
-                const int b0 = (int)rbatches.size();
-                RowBatch cur{-1, 0, 0, 0, 0};
-                auto flushb = [&]() { if (cur.count > 0 && cur.total > 0) rbatches.push_back(cur); cur = RowBatch{-1, 0, 0, 0, 0}; };
-                for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
-                    const int i_s = cam_obs[e];
-                    const int np = i_s - pt_ptr[o_pt[i_s]];  // partners: observations of the landmark before i (cam_j <= cam_i)
-                    if (np > kRowBatch) {
-                        flushb();
-                        for (int j0 = 0; j0 < np; j0 += kRowBatch) {
-                            const int n = std::min(kRowBatch, np - j0);
-                            rbatches.push_back(RowBatch{e, 1, j0, n, n});
-                        }
-                        continue;
-                    }
-                    if (cur.total + np > kRowBatch || cur.count == kRowThreads) flushb();  // one lane expands one observation
-                    if (cur.count == 0) cur.first = e;
-                    cam_obs_off[e] = (uint16_t)cur.total;
-                    cur.count++; cur.total += np;
-                }
-                flushb();
-                const int nb = (int)rbatches.size() - b0;
-                const int n0 = nbr_ptr[c], nn = nbr_ptr[c + 1] - nbr_ptr[c];
-                for (int s0 = 0; s0 < nn; s0 += cap) {
-                    const int cnt = std::min(cap, nn - s0);
-                    rtasks.push_back(RowTask{(int)c, n0 + s0, cnt, (s0 + cnt == nn) ? 1 : 0, b0, nb});
-                }
-            }
-        } else {
+        {
             // k_schur_rows2: one entry per observation of a camera (split at kRowMaxPartners partners), sorted by partner
             // count so that the 64 lanes of a wave loop the same number of times; chunks of <= 64 entries, largest first
             std::vector<RowEntry> ce;

@@ -263,11 +263,14 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
     // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
     static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "dist_factor", "tree_sharding", "dist_selftest",
-                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows"};
+                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "matrix_free_only"};
     if (h->s->has_structure())
         for (const char* k : structural)
             if (n == k) return APEXGPU_ERR_INVALID_STATE;
-    if (n == "schur_rows") h->s->use_row_schur(value);
+    if (n == "schur_rows" || n == "schur_form") {   // 3 sorted pair list (default), 2 LDS rows; the forms 0 / 1 of rounds 1-3 are gone
+        if (value != 3 && value != 2) return APEXGPU_ERR_INVALID_INPUT;
+        h->s->use_row_schur(value);
+    }
     else if (n == "graphs") h->s->enable_graphs(value != 0);
     else if (n == "update_overlap") { h->s->enable_overlap(value != 0); if (value > 1) h->s->set_overlap_min(value); }
     else if (n == "tri_dataflow") h->s->enable_tri_flow(value != 0);
@@ -275,18 +278,17 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "flood_gate") h->s->set_gate_min(value);
     else if (n == "flood_gate_pos") h->s->set_gate_pos(value);
     else if (n == "two_side") h->s->set_two_side(value);
+    else if (n == "matrix_free_only") h->s->set_matrix_free_only(value != 0);
     else if (n == "factor_flow") h->s->set_factor_flow(value, 0);          // max columns per level group inside the dataflow launch (0: off)
     else if (n == "factor_flow_rows") h->s->set_factor_flow(h->s->plan().factor_flow_cols(), value);
     else if (n == "rec_backsub") h->s->set_rec_backsub(value != 0);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
-    else if (n == "schur_form") h->s->use_row_schur(value);   /* alias of "schur_rows": 3 sorted pair list (default), 2 / 1 LDS rows, 0 global atomics */
-    else if (n == "rows_debug") h->s->set_rows_debug(value);
     else if (n == "pairs_ablation") {   /* timing experiments only: the results are WRONG when != 0, so the switch exists only */
         if (value != 0 && !getenv("APEX_ALLOW_ABLATION")) return APEXGPU_ERR_INVALID_INPUT;   /* for a process that asks for it */
         h->s->set_pairs_ablation(value);
     }
-    else if (n == "pairs_variant") h->s->set_pairs_variant(value);
+    else if (n == "pairs_variant") { if (value != 2) return APEXGPU_ERR_INVALID_INPUT; }   /* one pair kernel is left: the record form (2) */
     else if (n == "cam_staging") h->s->set_cam_staging(value != 0);
     else if (n == "debug_poison_sweep") h->s->debug_poison_next_solve(value);   /* tests: 1 / 2 = the next solve's forward / backward dataflow sweep times out */
     else if (n == "debug_poison_factor") h->s->debug_poison_next_factor();       /* tests: the next factorisation's dataflow launch times out */

@@ -64,13 +64,12 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
                       int task_slots = 0 /* 0: default */);
 
-// variant 0: fused form, one pair per lane; 1: fused form, one observation per lane (two lanes per pair); 2: RECORD form, one
-// pair per lane -- J rebuilt from the 32-byte projection records k_landmark_reduce writes (orec) instead of re-linearising
-// both observations of every pair.  ablation: timing experiments only (results are wrong when != 0)
+// The pair kernel (record form: J rebuilt from the 32-byte projection records k_landmark_reduce writes, orec).
+// ablation: timing experiments only (results are wrong when != 0)
 // ablation 64 (record form): per-phase shader cycles summed over all waves since the last reset (see k_schur_pairs_r)
 void pairs_phase_cycles(unsigned long long out[8], bool reset);
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
-                        const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, int variant = 1,
-                        int ablation = 0, const double* orec = nullptr);
+                        const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, int ablation,
+                        const double* orec);
 
 }  // namespace apex

@@ -88,7 +88,6 @@ class Solver : public LmBackend {
     void enable_tri_flow(bool on) { tp_.enable_tri_flow(on); }
     void set_rec_backsub(bool on) { rec_backsub_ = on; }        // before set_structure: back-substitution / matrix-free operator from the projection records
     void set_cam_staging(bool on) { cam_staging_ = on; }        // landmark-major kernels: the workgroup's cameras staged in LDS
-    void set_pairs_variant(int v) { pairs_variant_ = v; }       // pair kernel: 2 record form; fused forms: 1 two lanes per pair, 0 one pair per lane
     void set_pairs_ablation(int bits) { pairs_ablation_ = bits; }   // timing experiments only (results are wrong when != 0)
     int sweep_timeouts() const { return tp_.sweep_timeouts(); }   // dataflow sweeps that gave up and were repeated level by level
     void debug_poison_next_solve(int which) { tp_.debug_poison_next_solve(which); }
@@ -97,14 +96,17 @@ class Solver : public LmBackend {
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
     void set_gate_pos(int p) { tp_.set_gate_pos(p); }
+    // before set_structure: the handle will only run the matrix-free variant (2, IterativeSchurSolver).  S is never formed, so
+    // neither is its tile structure beyond the diagonal blocks the Schur-Jacobi preconditioner needs, nor the pair list: the
+    // set-up and the LM iteration no longer depend on the fill of S (a photo collection whose S is dense: tools/structure_sweep.py)
+    void set_matrix_free_only(bool on) { matrix_free_only_ = on; }
     void set_two_side(int mode) { tp_.set_two_side(mode); }
     void set_factor_flow(int max_cols, int max_rows) { tp_.set_factor_flow(max_cols, max_rows); }
     int factor_flow_timeouts() const { return n_factor_flow_timeouts_; }
     void debug_poison_next_factor() { tp_.debug_poison_next_factor(); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
-    void use_row_schur(int v) { use_rows_ = v != 0; if (v) rows_form_ = v; }
+    void use_row_schur(int v) { rows_form_ = v == 2 ? 2 : 3; }   // 3 sorted pair list (default), 2 LDS rows (the A/B)
     bool has_structure() const { return have_structure_; }
-    void set_rows_debug(int v) { rows_dbg_ = v; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void set_hubs_last(bool on) { hubs_last_ = on; }
     void set_pair_task_slots(int n) { pair_task_slots_ = n; }
@@ -119,7 +121,7 @@ class Solver : public LmBackend {
     double schur_scatter_pairs() const { return (double)n_pairs_; }
     double pair_blocks() const { return (double)n_pair_blocks_; }
     double pair_slots() const { return (double)n_pair_slots_; }
-    int schur_form() const { return use_rows_ ? rows_form_ : 0; }
+    int schur_form() const { return rows_form_; }
     const double* setup_seconds() const { return setup_s_; }
     double touched_tiles() const { return (double)n_present_; }
     double local_obs() const { return (double)o_orig_h_.size(); }
@@ -193,8 +195,6 @@ class Solver : public LmBackend {
     hipEvent_t pin_ev_[2] = {nullptr, nullptr};
     double *poses_[2] = {nullptr, nullptr}, *intr_[2] = {nullptr, nullptr}, *pts_[2] = {nullptr, nullptr};
     double* camp_[2] = {nullptr, nullptr};  // prepared cameras of the two parameter sets
-    RowTask* rtasks_ = nullptr;
-    RowBatch* rbatches_ = nullptr;
     RowTask* rtasks2_ = nullptr;     // k_schur_rows2: the same row tasks over chunks of entries
     RowChunk* rchunks_ = nullptr;
     RowEntry* rentries_ = nullptr;
@@ -205,24 +205,21 @@ class Solver : public LmBackend {
     uint8_t *o_slot_ = nullptr, *wg_cam_n_ = nullptr;   // camera staging lists of the landmark-major kernels (BAView::o_slot)
     uint32_t* wg_cam_list_ = nullptr;
     bool cam_staging_ = true;
+    bool matrix_free_only_ = false;
     bool rec_backsub_ = true;
     bool orec_fresh_ = false;   // orec_ holds the records of the current parameters' last linearisation
     const double* backsub_records() const { return rec_backsub_ && orec_fresh_ ? orec_ : nullptr; }
     double* orec_ = nullptr;   // [local observations][4] projection records written by k_landmark_reduce (pair kernel, record form)
     int n_ptasks_ = 0;
     int64_t n_pair_blocks_ = 0, n_pair_slots_ = 0;
-    int rows_form_ = 3;              // 3 (default): sorted pair list reduced over the lanes of a wave (k_schur_pairs_h / k_schur_pairs: every
-                                     // block S(ci, cj) stored once by one wave, no atomics, no LDS accumulators);
-                                     // 2: one lane per observation (k_schur_rows2, default: every lane walks the rows of
-                                     // a neighbour block in its own rotated order, which takes the same-address
-                                     // conflicts out of the LDS atomics: 9.7 -> 6.1 ms on final-13682); 1: one lane
-                                     // per pair (k_schur_rows).  Select before set_structure.
-    uint16_t* cam_obs_off_ = nullptr;
+    int rows_form_ = 3;              // 3 (default): sorted pair list reduced over the lanes of a wave (k_schur_pairs_r: every block
+                                     // S(ci, cj) stored once by one wave, no atomics, no LDS accumulators); 2: the LDS row form,
+                                     // one lane per observation (k_schur_rows2: 6.0 ms against 3.6-3.8 on final-13682), kept
+                                     // as the A/B.  Select before set_structure.  (Rounds 1-3 also carried a global-atomics
+                                     // form, 135 ms, and a one-lane-per-pair row form, 9.7 ms: deleted in round 4.)
     int* nbr_ = nullptr;
     int n_rtasks_ = 0;
-    int rows_dbg_ = 0;      // timing-only ablation switches of k_schur_rows (results are wrong when != 0)
-    int pairs_variant_ = 2, pairs_ablation_ = 0;   // k_schur_pairs: 2 record form (default), 3 record form two lanes per pair, 1 / 0 fused forms; timing-only ablation bits
-    bool use_rows_ = true;  // Schur reduction: LDS row form (default) or the global-atomics form
+    int pairs_ablation_ = 0;   // k_schur_pairs_r: timing-only ablation bits
     uint32_t *o_cam_ = nullptr, *o_pt_ = nullptr, *co_pt_ = nullptr;
     double2* co_uv_ = nullptr;
     int* co_rank_ = nullptr;
@@ -233,8 +230,6 @@ class Solver : public LmBackend {
     double *g_c_ = nullptr, *g_red_ = nullptr, *dcam_ = nullptr, *hinv_ = nullptr, *g_l_ = nullptr, *dl_ = nullptr;
     double *partial_ = nullptr, *scal_ = nullptr;  // reduction scratch, scalar outputs
     int* flags_ = nullptr;                          // [0] landmark inversion error
-    ScatterTask* tasks_ = nullptr;
-    int n_tasks_ = 0;
     std::vector<int> cmap_, cinv_;   // external camera -> internal camera and back
     bool use_nd_ = true;
     int pair_task_slots_ = 0;

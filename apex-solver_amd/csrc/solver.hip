@@ -45,9 +45,9 @@ Solver::~Solver() {
     if (free_thread_.joinable()) free_thread_.join();
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks_, rbatches_, rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, orec_, o_slot_, wg_cam_n_, wg_cam_list_, cam_obs_off_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
+    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, orec_, o_slot_, wg_cam_n_, wg_cam_list_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
-                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, tasks_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_, lam_mask_};
+                    dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_, lam_mask_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     comm_.reset();
@@ -204,7 +204,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     BaStructOptions so;
     so.dc = dc_; so.use_nd = use_nd_; so.nd_leaf = nd_leaf_; so.hubs_last = hubs_last_;
     so.rank = rank_; so.world = world_; so.dist_factor = dist_factor_; so.tree_sharding = tree_sharding_;
-    so.dist_selftest = dist_selftest_; so.schur_form = use_rows_ ? rows_form_ : 0; so.pair_task_slots = pair_task_slots_;
+    so.dist_selftest = dist_selftest_; so.schur_form = rows_form_; so.pair_task_slots = pair_task_slots_;
     std::unique_ptr<BaHostStructure> hs_owner(new BaHostStructure);
     BaHostStructure& hs = *hs_owner;
     {
@@ -224,6 +224,11 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     }
     // ---- symbolic Cholesky fill, slot map and task lists of the tile plan -------------
     const auto t_plan = std::chrono::steady_clock::now();
+    if (matrix_free_only_) {   // S is never formed: keep the diagonal tiles (Schur-Jacobi blocks are read from them), nothing else
+        std::fill(hs.present.begin(), hs.present.end(), (uint8_t)0);
+        for (int I = 0; I < nt_; ++I) hs.present[(size_t)I * nt_ + I] = 1;
+        so.schur_form = -1;
+    }
     tp_.enable_graphs(use_graphs_);
     {
         const std::string e = tp_.build(nt_, hs.present, stream_);
@@ -233,8 +238,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     // ---- task lists of the selected form of the Schur reduction (they need the slot map) ------------------------------
     hs.build_schur_lists(so, tp_.slot_host());
     hs.release_scratch();
-    n_tasks_ = (int)hs.tasks.size();
-    n_rtasks_ = (int)(so.schur_form == 2 ? hs.rtasks2.size() : hs.rtasks.size());
+    n_rtasks_ = (int)hs.rtasks2.size();
     n_ptasks_ = (int)hs.pl.tasks.size();
     n_pair_blocks_ = hs.pl.n_blocks; n_pair_slots_ = (int64_t)hs.pl.recs.size();
     const int64_t n_loc = (int64_t)hs.o_cam.size();
@@ -244,12 +248,9 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     const auto &pt_ptr = hs.pt_ptr, &cam_ptr = hs.cam_ptr;
     const auto &cam_obs = hs.cam_obs, &co_rank = hs.co_rank;
     const auto& nbr = hs.nbr;
-    const std::vector<ScatterTask>& tasks = hs.tasks;
-    const std::vector<RowTask>&rtasks = hs.rtasks, &rtasks2 = hs.rtasks2;
-    const std::vector<RowBatch>& rbatches = hs.rbatches;
+    const std::vector<RowTask>& rtasks2 = hs.rtasks2;
     const std::vector<RowChunk>& rchunks = hs.rchunks;
     const std::vector<RowEntry>& rentries = hs.rentries;
-    const std::vector<uint16_t>& cam_obs_off = hs.cam_obs_off;
     const PairLists& pl = hs.pl;
     (void)n_loc;
 
@@ -297,13 +298,9 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(up(&co_pt_, co_pt));
     HIP_TRY(up(&co_rank_, co_rank));
     HIP_TRY(up(reinterpret_cast<double**>(&co_uv_), co_uv));
-    HIP_TRY(up(&tasks_, tasks));
-    HIP_TRY(up(&rtasks_, rtasks));
-    HIP_TRY(up(&rbatches_, rbatches));
     HIP_TRY(up(&rtasks2_, rtasks2));
     HIP_TRY(up(&rchunks_, rchunks));
     HIP_TRY(up(&rentries_, rentries));
-    HIP_TRY(up(&cam_obs_off_, cam_obs_off));
     HIP_TRY(up(&ptasks_, pl.tasks));
     HIP_TRY(up(&pchunks_, pl.chunks));
     HIP_TRY(up(&pblocks_, pl.blocks));
@@ -338,7 +335,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(alloc(&dcam_, n_c_pad_));
     HIP_TRY(alloc(&hinv_, (size_t)kLmStride * n_pt_));  // landmark records: Hll^-1 | g_l | point
     // projection records of the local observations (xn, yn, -1/z, sqrt(rho')): the record form of the pair kernel
-    if ((use_rows_ && rows_form_ == 3) || rec_backsub_) HIP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
+    if (rows_form_ == 3 || rec_backsub_) HIP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
     HIP_TRY(alloc(&g_l_, 3 * n_pt_));
     HIP_TRY(alloc(&dl_, 3 * n_pt_));
     HIP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
@@ -454,6 +451,7 @@ int Solver::cost(double* out) {
 // assembly of S, g_red, Hll^-1, g (A6-A11) at the current parameters
 // ---------------------------------------------------------------------------------------------
 int Solver::assemble(double lambda, double diag_extra, bool for_factor) {
+    if (matrix_free_only_) return fail(kInvalidState, "this handle was built matrix-free only (\"matrix_free_only\"): the explicit S does not exist");
     int rc = assemble_local(lambda, diag_extra, for_factor);
     if (rc != kOk) return rc;
     if (comm_ && world_ > 1) {
@@ -498,25 +496,20 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     tp_.add_diag((int)n_c_, 0.0, rank_ == pad_rank_ ? 1.0 : 0.0);
     stage_end(kStAssembleCam);
     stage_begin(kStAssembleLm);
-    const bool rec_form = use_rows_ && rows_form_ == 3 && pairs_variant_ >= 2 && orec_ != nullptr;
+    const bool rec_form = rows_form_ == 3;   // the pair kernel reads the projection records (allocated with the form: set_structure)
     const bool want_rec = rec_form || (rec_backsub_ && orec_ != nullptr);
     launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_, want_rec ? orec_ : nullptr);
     orec_fresh_ = want_rec;
     stage_end(kStAssembleLm);
     stage_begin(kStAssembleCam);
-    launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, hinv_, g_l_, use_rows_ ? 1 : 0,
+    launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, hinv_, g_l_, 1,
                       g_c_, g_red_, stream_);
     stage_end(kStAssembleCam);
     stage_begin(kStScatter);
-    if (use_rows_ && rows_form_ == 3)
-        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, pairs_variant_, pairs_ablation_,
-                           rec_form ? orec_ : nullptr);
-    else if (use_rows_ && rows_form_ == 2 && rows_dbg_ == 0)
-        launch_schur_rows2(dc_, v, tm, rtasks2_, n_rtasks_, rchunks_, rentries_, nbr_, hinv_, stream_);
-    else if (use_rows_)
-        launch_schur_rows(dc_, v, tm, rtasks_, n_rtasks_, rbatches_, cam_obs_, cam_obs_off_, nbr_, hinv_, rows_dbg_, stream_);
+    if (rows_form_ == 3)
+        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, pairs_ablation_, orec_);
     else
-        launch_schur_scatter(dc_, v, tm, tasks_, n_tasks_, hinv_, g_l_, g_red_, stream_);
+        launch_schur_rows2(dc_, v, tm, rtasks2_, n_rtasks_, rchunks_, rentries_, nbr_, hinv_, stream_);
     stage_end(kStScatter);
     return check_hip(hipGetLastError(), "assembly kernels");
 }

@@ -541,6 +541,9 @@ class LevenbergMarquardt:
         s = solver or GpuSchurComplementSolver(self.device)
         s.with_variant(self.config.schur_variant).with_preconditioner(self.config.schur_preconditioner)
         if s._h is None:
+            if self.config.schur_variant == SchurVariant.Implicit and solver is None:
+                # IterativeSchurSolver never forms S (implicit_schur.rs:163-251): neither does a handle made for it
+                s.with_option("matrix_free_only", 1)
             s.initialize_structure(problem)
         poses, intr, pts = initial_values if initial_values is not None else (d.poses, d.intr, d.points)
         s.set_parameters(poses, intr, pts)

@@ -328,6 +328,8 @@ def main():
         s.with_cg_params(int(args.cg.split(",")[0]), float(args.cg.split(",")[1]))
     elif args.variant == "implicit":
         s.with_cg_params(500, 1e-9)  # IterativeSchurSolver::new (implicit_schur.rs:94-95)
+    if args.variant == "implicit":
+        s.with_option("matrix_free_only", 1)   # S is never formed: no tile structure beyond the diagonal, no pair list
     for o in args.opt:
         s.with_option(o.split("=")[0], int(o.split("=")[1]))
     if world > 1:
@@ -378,10 +380,8 @@ def main():
     # ---- roofline of the graded Schur-reduction kernel, per launch -------------------------------------------------------
     dc = 9 if args.mode == "selfcal" else 6
     form = info.get("schur_form", 3)
-    pv = next((int(o.split("=")[1]) for o in args.opt if o.split("=")[0] == "pairs_variant"), 2)
-    kernel = {3: {2: "k_schur_pairs_r", 3: "k_schur_pairs_r2", 1: "k_schur_pairs_h", 0: "k_schur_pairs"}.get(pv, "k_schur_pairs_r"),
-              2: "k_schur_rows2", 1: "k_schur_rows", 0: "k_schur_scatter"}[form]
-    record_form = form == 3 and pv >= 2
+    kernel = {3: "k_schur_pairs_r", 2: "k_schur_rows2"}[form]
+    record_form = form == 3
     n_obs_local = info["local_obs"]
     tile_bytes = 144 * 144 * 8
     # SURVEY §8(d), fused form (J never stored): each input read once, each output written once.  The record form (the

@@ -216,13 +216,13 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  * "dist_selftest") return APEXGPU_ERR_INVALID_STATE once the structure is set.
  *   "schur_rows" (3)  form of the Schur reduction (alias "schur_form"); set before set_structure:
  *                     3 = every camera pair of a landmark in a list sorted by the block S(ci, cj) it adds to, one pair per
- *                     lane as a rank-2 update U V parked in LDS, the block sums taken over the lanes as 3 x 3 sub-block
- *                     products on the vector unit, every block stored once (k_schur_pairs, csrc/schur_pairs.h);
+ *                     lane as a rank-2 update U V parked in LDS (J rebuilt from the projection records k_landmark_reduce
+ *                     writes), the block sums taken over the lanes as 3 x 3 sub-block products on the vector unit, every
+ *                     block stored once (k_schur_pairs_r, csrc/schur_pairs.h);
  *                     2 = LDS row form, one lane per observation, block rows walked in a per-lane rotated order
- *                     (k_schur_rows2); 1 = LDS row form, one lane per camera pair (k_schur_rows);
- *                     0 = the landmark-major global-atomics form (k_schur_scatter)
- *   "pairs_variant" (1)  schur form 3 only, per handle: 1 = one observation per lane, two lanes per pair (three waves per
- *                     SIMD), 0 = one pair per lane (two waves per SIMD); same lists, same results up to rounding
+ *                     (k_schur_rows2), kept as the A/B.  The forms 1 / 0 of rounds 1-3 (one lane per camera pair;
+ *                     landmark-major global atomics) and the three other pair kernels ("pairs_variant" 0 / 1 / 3) were
+ *                     deleted in round 4: those values answer APEXGPU_ERR_INVALID_INPUT
  *   "pairs_ablation" (0)  per handle, TIMING EXPERIMENTS ONLY (the results are wrong when != 0): refused with
  *                     APEXGPU_ERR_INVALID_INPUT unless the process runs with APEX_ALLOW_ABLATION set
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
@@ -233,9 +233,14 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     potrf when they are at least this many tasks; 0 = one batch on the main stream (before set_structure)
  *   "potrf_lookahead" (9)  diagonal-tile Cholesky + inverse: 9 = the 16 x 16 pivot blocks on the matrix pipe (round 4),
  *                     8 / 6 / 1 = look-ahead schedule of round 3 with 8 / 6 / 4 waves per workgroup, 0 = without look-ahead
- *   "factor_flow" (6), "factor_flow_rows" (24)  the TOP of the elimination tree -- the trailing level groups with at most
+ *   "matrix_free_only" (0)  before set_structure: the handle will only be asked for variant 2 (IterativeSchurSolver semantics):
+ *                     S is never formed, so only its diagonal tiles are allocated and no pair list is built -- set-up and LM
+ *                     iteration are then independent of the fill of S (an input whose S is dense costs what a banded one
+ *                     does); variants 0 / 1 and the exports of S answer APEXGPU_ERR_INVALID_STATE on such a handle
+ *   "factor_flow" (-1), "factor_flow_rows" (24)  the TOP of the elimination tree -- the trailing level groups with at most
  *                     that many tile columns each, every column with at most "factor_flow_rows" off-diagonal tiles -- is
- *                     factorised by ONE dataflow launch (k_factor_flow: a workgroup per potrf / per 48-row strip of a
+ *                     factorised by ONE dataflow launch (-1, the default: where the launch starts is chosen by a cost
+ *                     model of both schedules) (k_factor_flow: a workgroup per potrf / per 48-row strip of a
  *                     panel solve or update, per-tile version counters) instead of three dependent launches per level;
  *                     same summation order, bit-identical factor.  0 = level launches everywhere.  Its waits are bounded
  *                     like the sweeps': a launch that gives up is detected in the same apexgpu_solve_augmented, S is

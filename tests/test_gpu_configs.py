@@ -357,9 +357,19 @@ def test_mix_shape_vs_oracle(oracle):
     chol4 = s.solve_augmented_equation(1e4).copy()   # (the device Cholesky at cond(S) <= 1e5: 1e-10 of the oracle's in every parity case)
     s.close()
     # the matrix-free fallback on the same structure, at lambda = 1e4 where its iteration determines the step
-    prob, s = make(d, "selfcal", variant=SchurVariant.Implicit)
-    s.with_cg_params(500, 1e-12)
-    istep = s.solve_augmented_equation(1e4)
-    print("mix 0.05 matrix-free at lambda 1e4:", s.info()["pcg_iterations"], "iterations, step vs the Cholesky variant", rel(istep, chol4))
-    assert rel(istep, chol4) < 1e-8
-    s.close()
+    # ... on a handle built MATRIX-FREE ONLY ("matrix_free_only": S never formed, diagonal tiles and no pair list -- what makes
+    # the fallback independent of the fill of S) and on an ordinary one: the same iteration, the same step
+    steps = {}
+    for mfo in (1, 0):
+        prob, s = make(d, "selfcal", variant=SchurVariant.Implicit, opts=(("matrix_free_only", mfo),))
+        s.with_cg_params(500, 1e-12)
+        steps[mfo] = s.solve_augmented_equation(1e4).copy()
+        print(f"mix 0.05 matrix-free at lambda 1e4 (matrix_free_only={mfo}):", s.info()["pcg_iterations"], "iterations, tiles", s.info()["tiles"],
+              "step vs the Cholesky variant", rel(steps[mfo], chol4))
+        assert rel(steps[mfo], chol4) < 1e-8
+        if mfo:
+            assert s.info()["tiles"] == s.info()["tile_rows"]      # the diagonal tiles, nothing else
+            with pytest.raises(pkg.capi.LinAlgError):              # the explicit S does not exist on such a handle
+                s.get_schur()
+        s.close()
+    assert rel(steps[1], steps[0]) < 1e-12

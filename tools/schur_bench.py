@@ -27,7 +27,6 @@ def main():
     ap.add_argument("--task-slots", default="0", help="comma list of pair_task_slots values to try with form 3")
     ap.add_argument("--abl", default="0", help="comma list of ablation bit sets for the pair kernel (timing only)")
     ap.add_argument("--check", action="store_true", help="compare S x of every form with the first one's")
-    ap.add_argument("--variants", default="", help="comma list of pairs_variant values to try with form 3 (0 / 1 fused, 2 record form)")
     a = ap.parse_args()
     t = time.time()
     d = pkg.synthetic.make_named(a.workload, a.scale)
@@ -36,13 +35,9 @@ def main():
     prob = Problem.bundle_adjustment(d, ot, 1.0)
     ref = None
     x = np.random.default_rng(0).normal(size=prob.layout.cam_dof)
-    variants = [int(x) for x in a.variants.split(",")] if a.variants else [None]
-    runs = [(int(f), int(ts), pv) for f in a.forms.split(",") for ts in (a.task_slots.split(",") if int(f) == 3 else ["0"])
-            for pv in (variants if int(f) == 3 else [None])]
+    runs = [(int(f), int(ts), None) for f in a.forms.split(",") for ts in (a.task_slots.split(",") if int(f) == 3 else ["0"])]
     for form, ts, pv in runs:
         s = GpuSchurComplementSolver(0).with_option("schur_rows", form).with_option("pair_task_slots", ts)
-        if pv is not None:
-            s.with_option("pairs_variant", pv)
         t = time.time()
         s.initialize_structure(prob)
         s.set_parameters(d.poses, d.intr, d.points)
