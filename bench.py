@@ -402,14 +402,14 @@ def main():
     off_pairs = info["pair_blocks"] - n_obs_local      # pair contributions without the self pairs
     useful_flop = 2.0 * (12 + 4 * dc + 2 * dc * dc) * off_pairs + 250.0 * n_obs_local
     executed_flop = ((2.0 * (12 + 4 * dc + 2 * dc * dc) + 2 * 120.0 + 36.0) if record_form else (2.0 * (12 + 4 * dc + 2 * dc * dc) + 2 * 250.0 + 36.0)) * off_pairs
-    stage_ms = sum(stages[k][0] / max(stages[k][1], 1) * (2 if k == "cam_reduce" else 1) for k in ("landmark_reduce", "cam_reduce", "schur_scatter"))
     stage_ms = (stages["landmark_reduce"][0] + stages["cam_reduce"][0] + stages["schur_scatter"][0]) / max(sc_n, 1)
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
                 "pair_list_bytes": pair_list_bytes if form == 3 else 0.0,
                 "avg_launch_ms": sc_avg, "launches": sc_n,
-                "actual_bound": ("L2-miss line rate of the per-pair gathers: ~1.5e8 64-byte lines per launch at ~8 clocks per line and CU "
-                                 "(tools/vmem_issue_bench.hip, profiles/r03_vmem_issue_bench.txt; DESIGN.md section 4)") if record_form else
+                "actual_bound": ("L2-miss line rate of the per-pair gathers: ~1.5e8 64-byte lines per launch at ~8 clocks per line and CU = 91 % of the "
+                                 "kernel's time per chunk (tools/vmem_issue_bench.hip, profiles/r03_vmem_issue_bench.txt, profiles/r04_pairs_ablation.txt; "
+                                 "DESIGN.md section 4, round 4)") if record_form else
                                 "fp64 vector unit + LDS (the fused form moves 2 GB but executes ~60 GFLOP: DESIGN.md section 4)",
                 "projection_record_bytes": 32.0 * n_obs_local if record_form else 0.0,
                 "pair_contributions_per_launch": off_pairs,
@@ -424,7 +424,7 @@ def main():
     # HBM traffic of the same kernel from the committed PMC pass (rocprofv3 cannot run inside this
     # process); only attached when the committed profile is of this very workload and kernel
     try:
-        pm_path = next(p for p in (os.path.join(ROOT, "profiles", f"r0{r}_final13682_pmc_summary.json") for r in (3, 2)) if os.path.exists(p))
+        pm_path = next(p for p in (os.path.join(ROOT, "profiles", f"r0{r}_final13682_pmc_summary.json") for r in (4, 3, 2)) if os.path.exists(p))
         pm = json.load(open(pm_path))
         if world == 1 and args.workload == "final-13682" and args.scale == 1.0 and args.mode == "selfcal":
             k = [v for n, v in pm["kernels"].items() if kernel in n]

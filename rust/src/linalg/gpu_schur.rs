@@ -7,7 +7,7 @@
 #![cfg(feature = "gpu")]
 
 use std::collections::HashMap;
-use std::os::raw::c_int;
+use std::os::raw::{c_char, c_int};
 use std::sync::Arc;
 
 use apex_manifolds::ManifoldType;
@@ -135,6 +135,11 @@ impl GpuSchurComplementSolver {
             pts: self.pt_vars.iter().map(|v| v.0.clone()).collect(),
             fixed_intr, lock: std::sync::Mutex::new(()),
         });
+        if self.implicit {
+            // IterativeSchurSolver never forms S (implicit_schur.rs:163-251); neither does a handle made for it: only the diagonal
+            // tiles exist and no pair list is built, so set-up and iteration do not depend on the fill of S (round 4)
+            check(h, unsafe { apexgpu_set_option(h, b"matrix_free_only\0".as_ptr() as *const c_char, 1) })?;
+        }
         check(h, unsafe { apexgpu_set_structure(h, cam_idx.as_ptr(), pt_idx.as_ptr(), uv.as_ptr(), intr_col.as_ptr(), pose_col.as_ptr(),
                                                  pt_col.as_ptr(), fix_pose.as_ptr(), fix_intr.as_ptr(), fix_pt.as_ptr(), huber.unwrap_or(-1.0)) })?;
         check(h, unsafe { apexgpu_set_cg_params(h, self.cg.0, self.cg.1) })?;

@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nb; ++i) t[i] = {A + i * te, Li + i * te, i};
     hipMemcpy(d, t.data(), nb * sizeof(PotrfTask), hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode : {8, 9, 12}) {
+    for (int mode : {8, 9, 12}) {   // round-3 look-ahead kernel, matrix-pipe form with 8 and with 12 waves
         set_potrf_lookahead(mode);
         for (int n : {1, 64}) {
             float best = 1e9f;
