@@ -407,9 +407,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
                 "pair_list_bytes": pair_list_bytes if form == 3 else 0.0,
                 "avg_launch_ms": sc_avg, "launches": sc_n,
-                "actual_bound": ("L2-miss line rate of the per-pair gathers: ~1.5e8 64-byte lines per launch at ~8 clocks per line and CU = 91 % of the "
-                                 "kernel's time per chunk (tools/vmem_issue_bench.hip, profiles/r03_vmem_issue_bench.txt, profiles/r04_pairs_ablation.txt; "
-                                 "DESIGN.md section 4, round 4)") if record_form else
+                "actual_bound": ("latency at two waves per SIMD (211 VGPRs, 18.4 KB of LDS per wave): no unit saturated -- vector unit 49 %, LDS 70 %, "
+                                 "gathers worth 0.5 ms of 3.7 by ablation (profiles/r04_pairs_ablation.txt; DESIGN.md section 4, round 4)") if record_form else
                                 "fp64 vector unit + LDS (the fused form moves 2 GB but executes ~60 GFLOP: DESIGN.md section 4)",
                 "projection_record_bytes": 32.0 * n_obs_local if record_form else 0.0,
                 "pair_contributions_per_launch": off_pairs,

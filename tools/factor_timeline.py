@@ -17,7 +17,7 @@ while i < len(ev):
     if ev[i][2] == "rows":
         j = i + 1
         while j < len(ev) and ev[j][2] != "tri" and ev[j][2] != "rows": j += 1
-        spans.append((i + 1, j))
+        if any(x[2] in ("potrf", "flow") for x in ev[i + 1:j]): spans.append((i + 1, j))   # (a cost-only pass has no factorisation)
         i = j
     else:
         i += 1
