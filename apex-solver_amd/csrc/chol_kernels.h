@@ -70,7 +70,9 @@ void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fai
                         unsigned long long* trace = nullptr);   // trace (tools only): 3 stamps of the 100 MHz clock per unit
 void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 1 / 6 / 8 k_potrf_inv_la with 4 / 6 / 8 waves, 9 k_potrf_inv_mf (default)
 // batches of <= 56 tasks use the latency kernels, larger ones the 3 x 3-wave strip kernel
-void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s);
+// tri_b: every B is a lower-triangular inverse written by launch_potrf_inv (zero 16 x 16 blocks right of the diagonal): the
+// large-batch kernel then skips the 36 of 81 block products that multiply by them.
+void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, bool tri_b = false);
 // poison_block >= 0 (tests only): that block's counter is made unreachable after the flags are cleared, so the task that
 // waits for it runs into the spin limit -- the time-out path (error word raised, wrong result) on demand
 void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const double* in, double* out, double* part, int* flags,

@@ -887,6 +887,11 @@ typedef const double __attribute__((address_space(1)))* GlobalCF64;
 typedef double f64x2_t __attribute__((ext_vector_type(2)));
 typedef const f64x2_t __attribute__((address_space(1)))* GlobalCF64x2;
 
+// TRI: B is a lower-triangular inverse (the panel solve L_IK = S_IK Linv_KK^T): its 16 x 16 blocks right of the diagonal are
+// never written (zero), so column block cb of C needs the K chunks 0 .. cb only -- 45 of the 81 block products.  The column
+// blocks are then dealt to the waves round-robin (wave w: w, w + 3, w + 6: 12 / 15 / 18 chunk products instead of 27 each)
+// rather than in runs of three (6 / 15 / 24).  Skipping a product with an exact-zero factor changes no finite value.
+template <bool TRI>
 __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restrict__ tasks, int n_units, double alpha,
                                                         double beta) {
     __shared__ double sA[STRIP * PITCH];
@@ -909,6 +914,9 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     GlobalCF64 Ag = t.A + (size_t)strip * STRIP * NB;
+    int cb[3];   // first column of this wave's three 16-wide column blocks
+#pragma unroll
+    for (int j = 0; j < 3; ++j) cb[j] = TRI ? 16 * (w + 3 * j) : 48 * w + 16 * j;
     double4_t acc[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -948,15 +956,18 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
             // wave w owns the 48 x 48 block of columns 48w..: 3 a-reads and 3 b-reads feed 9 MFMAs (a 16 x 144
             // row per wave needs 1 + 9 reads for the same 9 MFMAs and makes the LDS, not the MFMA pipe, the limit)
             double av[3], bv[3];
+            if (TRI && k0 > cb[2]) continue;   // (wave-uniform) nothing of this wave's columns left in this chunk
 #pragma unroll
             for (int i = 0; i < 3; ++i) av[i] = sA[(16 * i + lr) * PITCH + kk + lk];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) bv[j] = sB[(48 * w + 16 * j + lr) * PITCH + kk + lk];
+            for (int j = 0; j < 3; ++j) bv[j] = sB[(cb[j] + lr) * PITCH + kk + lk];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                if (TRI && k0 > cb[j]) continue;
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
+                for (int i = 0; i < 3; ++i)
                     acc[3 * i + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[3 * i + j], 0, 0, 0);
+            }
         }
     }
     // epilogue: per 16-column block, the 4 loads of C are issued before the 4 stores.  (A
@@ -968,25 +979,25 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
 #pragma unroll
         for (int j = 0; j < 9; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) C[(size_t)(16 * (j / 3) + lk + 4 * r) * NB + 48 * w + 16 * (j % 3) + lr] = alpha * acc[j][r];
+            for (int r = 0; r < 4; ++r) C[(size_t)(16 * (j / 3) + lk + 4 * r) * NB + cb[j % 3] + lr] = alpha * acc[j][r];
         return;
     }
     // software-pipelined read-modify-write: the loads of column block j+2 are in flight while block j
     // is stored (three 4-value buffers), so the 9 blocks cost ~3 memory round trips instead of 9
     double cv[3][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cv[0][r] = C[(size_t)(lk + 4 * r) * NB + 48 * w + lr];
+    for (int r = 0; r < 4; ++r) cv[0][r] = C[(size_t)(lk + 4 * r) * NB + cb[0] + lr];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cv[1][r] = C[(size_t)(lk + 4 * r) * NB + 48 * w + 16 + lr];
+    for (int r = 0; r < 4; ++r) cv[1][r] = C[(size_t)(lk + 4 * r) * NB + cb[1] + lr];
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         if (j + 2 < 9) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cv[(j + 2) % 3][r] = C[(size_t)(16 * ((j + 2) / 3) + lk + 4 * r) * NB + 48 * w + 16 * ((j + 2) % 3) + lr];
+            for (int r = 0; r < 4; ++r) cv[(j + 2) % 3][r] = C[(size_t)(16 * ((j + 2) / 3) + lk + 4 * r) * NB + cb[(j + 2) % 3] + lr];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            C[(size_t)(16 * (j / 3) + lk + 4 * r) * NB + 48 * w + 16 * (j % 3) + lr] = alpha * acc[j][r] + beta * cv[j % 3][r];
+            C[(size_t)(16 * (j / 3) + lk + 4 * r) * NB + cb[j % 3] + lr] = alpha * acc[j][r] + beta * cv[j % 3][r];
     }
 }
 
@@ -1872,7 +1883,7 @@ void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s, i
     else if (g_potrf_lookahead) hipLaunchKernelGGL(k_potrf_inv_la<8>, dim3(n), dim3(512), 0, s, tasks, fail, arrived);
     else hipLaunchKernelGGL(k_potrf_inv, dim3(n), dim3(256), 0, s, tasks, fail);
 }
-void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s) {
+void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, bool tri_b) {
     if (n <= 0) return;
     if (n <= kGemmSmallMax) {  // latency kernels; the 9-workgroup form never for the in-place panel solves (C aliases A)
         if (beta != 0.0) hipLaunchKernelGGL(k_tile_gemm_nt_small, dim3(9 * n), dim3(192), 0, s, tasks, 9 * n, alpha, beta);
@@ -1880,7 +1891,8 @@ void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta
         return;
     }
     const int units = n * NSTRIP, per_xcd = (units + 7) / 8;
-    hipLaunchKernelGGL(k_tile_gemm_nt, dim3(8 * per_xcd), dim3(192), 0, s, tasks, units, alpha, beta);
+    if (tri_b) hipLaunchKernelGGL(k_tile_gemm_nt<true>, dim3(8 * per_xcd), dim3(192), 0, s, tasks, units, alpha, beta);
+    else hipLaunchKernelGGL(k_tile_gemm_nt<false>, dim3(8 * per_xcd), dim3(192), 0, s, tasks, units, alpha, beta);
 }
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s) {
     if (n <= 0) return;
