@@ -262,7 +262,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     // Switches that shape what set_structure builds (task lists, tile order, partition) or what the captured hipGraphs
     // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
     // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
-    static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "dist_factor", "tree_sharding", "dist_selftest",
+    static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "panel_tri", "dist_factor", "tree_sharding", "dist_selftest",
                                              "nested_dissection", "update_overlap", "fused_forward", "split_u1", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "matrix_free_only"};
     if (h->s->has_structure())
         for (const char* k : structural)
@@ -283,6 +283,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "factor_flow_rows") h->s->set_factor_flow(h->s->plan().factor_flow_cols(), value);
     else if (n == "rec_backsub") h->s->set_rec_backsub(value != 0);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
+    else if (n == "panel_tri") apex::set_panel_tri(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "pairs_ablation") {   /* timing experiments only: the results are WRONG when != 0, so the switch exists only */
         if (value != 0 && !getenv("APEX_ALLOW_ABLATION")) return APEXGPU_ERR_INVALID_INPUT;   /* for a process that asks for it */
@@ -584,6 +585,7 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     else if (n == "flood_gate") h->s->set_gate_min(value);
     else if (n == "split_u1") h->s->set_split_u1(value);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
+    else if (n == "panel_tri") apex::set_panel_tri(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);
     else if (n == "debug_poison_sweep") h->s->debug_poison_next_solve(value);

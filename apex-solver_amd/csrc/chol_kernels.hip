@@ -1857,6 +1857,8 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const 
 // ------------------------------------------------------------------------------------------
 static int g_potrf_lookahead = 12;   // 0: k_potrf_inv; 1 / 6 / 8: look-ahead kernel (round 3) with 4 / 6 / 8 waves; 9 / 12 (default): matrix-pipe form, 8 / 12 waves
 void set_potrf_lookahead(int mode) { g_potrf_lookahead = mode; }
+static int g_panel_tri = 1;   // 1: the panel solves skip the zero blocks of Linv (k_tile_gemm_nt<true>); 0: full products (A/B)
+void set_panel_tri(int on) { g_panel_tri = on; }
 // The flood gate (TilePlan::enqueue_factor): one lane that ends when `expected` potrf workgroups have announced themselves
 // in *arrived, or after max_ticks of the 100 MHz clock -- a scheduling hint in front of the bulk updates of a level, so
 // that they do not take the CUs the next level's potrf is about to need.  Never waited for: a gate that times out only
@@ -1868,6 +1870,7 @@ __global__ __launch_bounds__(64) void k_gate(const int* __restrict__ arrived, in
         __builtin_amdgcn_s_sleep(16);
 }
 void launch_gate(const int* arrived, int expected, int max_micros, hipStream_t s) {
+    if (g_potrf_lookahead == 0) return;   // k_potrf_inv does not count its workgroups in: the gate would spin to its limit
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, arrived, expected, (long long)max_micros * 100);
 }
 void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, hipStream_t s, unsigned long long* trace) {
@@ -1891,7 +1894,7 @@ void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta
         return;
     }
     const int units = n * NSTRIP, per_xcd = (units + 7) / 8;
-    if (tri_b) hipLaunchKernelGGL(k_tile_gemm_nt<true>, dim3(8 * per_xcd), dim3(192), 0, s, tasks, units, alpha, beta);
+    if (tri_b && g_panel_tri) hipLaunchKernelGGL(k_tile_gemm_nt<true>, dim3(8 * per_xcd), dim3(192), 0, s, tasks, units, alpha, beta);
     else hipLaunchKernelGGL(k_tile_gemm_nt<false>, dim3(8 * per_xcd), dim3(192), 0, s, tasks, units, alpha, beta);
 }
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s) {

@@ -812,11 +812,12 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
 }
 
 hipError_t TilePlan::zero_tiles(bool own_touched_only) {
+    const hipStream_t zs = stream_;
     fwd_rhs_ = nullptr;
     const size_t te = (size_t)kNB * kNB * sizeof(double);
     hipError_t e = hipSuccess;
     auto clear = [&](int64_t first, int64_t count) {
-        if (e == hipSuccess && count > 0) e = hipMemsetAsync(tiles_ + (size_t)first * kNB * kNB, 0, (size_t)count * te, stream_);
+        if (e == hipSuccess && count > 0) e = hipMemsetAsync(tiles_ + (size_t)first * kNB * kNB, 0, (size_t)count * te, zs);
     };
     if (distributed() && !own_all_ && part_rank_ < (int)own_range_.size()) {
         // a rank of a distributed plan factorises its own columns and the shared top: the fill tiles of the other ranks'
@@ -829,7 +830,7 @@ hipError_t TilePlan::zero_tiles(bool own_touched_only) {
         clear(0, n_slots_);
     }
     if (e != hipSuccess) return e;
-    return hipMemsetAsync(flag_, 0, 4 * sizeof(int), stream_);
+    return hipMemsetAsync(flag_, 0, 4 * sizeof(int), zs);
 }
 
 void TilePlan::add_diag(int n_valid, double add_valid, double pad_value) {
@@ -884,7 +885,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
             if (n > 0) tr->push_back({0, (uintptr_t)s, 0, panel ? 1 : 2, (int64_t)(t - (panel ? trsm_tasks_ : upd_tasks_)), n});
             return;
         }
-        apex::launch_tile_gemm_nt(t, n, alpha, beta, s);
+        apex::launch_tile_gemm_nt(t, n, alpha, beta, s, /*tri_b=*/beta == 0.0);   // the panel solves multiply by Linv
     };
     auto launch_gate = [&](const int* a, int expected, int us, hipStream_t s) { if (!tr) apex::launch_gate(a, expected, us, s); };
     auto hipMemsetAsync = [&](void* p, int v, size_t n, hipStream_t s) { if (tr) return hipSuccess; return ::hipMemsetAsync(p, v, n, s); };

@@ -233,6 +233,8 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     potrf when they are at least this many tasks; 0 = one batch on the main stream (before set_structure)
  *   "potrf_lookahead" (9)  diagonal-tile Cholesky + inverse: 9 = the 16 x 16 pivot blocks on the matrix pipe (round 4),
  *                     8 / 6 / 1 = look-ahead schedule of round 3 with 8 / 6 / 4 waves per workgroup, 0 = without look-ahead
+ *   "panel_tri" (1)   the panel solves L_IK = S_IK Linv_KK^T skip the 36 of 81 16 x 16 block products that multiply by the zero
+ *                     blocks of the triangular inverse (process-wide, before set_structure; 0 = full products, for A/B)
  *   "matrix_free_only" (0)  before set_structure: the handle will only be asked for variant 2 (IterativeSchurSolver semantics):
  *                     S is never formed, so only its diagonal tiles are allocated and no pair list is built -- set-up and LM
  *                     iteration are then independent of the fill of S (an input whose S is dense costs what a banded one
