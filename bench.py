@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cg", default="", help="max_iter,tol of the PCG variants (default: the reference's 200,1e-6 / implicit 500,1e-9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-variants", action="store_true", help="skip the Iterative / matrix-free runs that follow the timed region of a Sparse run")
+    ap.add_argument("--comm", choices=("auto", "rccl", "shm"), default="auto", help="N > 1: the library's transport (auto: RCCL, host shared memory if RCCL cannot be initialised)")
     ap.add_argument("--opt", action="append", default=[], help="implementation switch name=value (apexgpu_set_option), repeatable")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0: full size when the reference's dense S fits (<= 2300 cameras), else a ~1000-camera sample")
     return ap.parse_args()
@@ -196,17 +197,18 @@ def bench_pose_graph(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    dev, pg_dev = torch.cuda.current_device(), "cuda"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dev, pg_dev = process_group(torch, local_rank)
     side = max(2, int(round(50 * args.scale ** 0.5)))
     if args.scale == 1.0:
         d, data_kind, data_src = pkg.datasets.load_pose_graph(args.workload, side, side)   # data/odometry/3d/sphere2500.g2o when present
     else:
         d, data_kind, data_src = pkg.synthetic.make_sphere(side, side), "synthetic", None
     prob = PoseGraphProblem.pose_graph(d)
-    s = GpuSparseCholeskySolver(local_rank).initialize_structure(prob)
+    s = GpuSparseCholeskySolver(dev).initialize_structure(prob)
     s.set_parameters(d.poses)
     info = s.info()
     st8 = dict(lam=1e-3, nu=2.0, cost=s.compute_cost(), accepted=0)
@@ -242,7 +244,7 @@ def bench_pose_graph(args):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=pg_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stages = s.stage_times()
@@ -255,7 +257,7 @@ def bench_pose_graph(args):
            "dtype": "f64", "data": data_kind,
            "config": {"workload": f"{d.name} {data_kind} SE3 pose graph ({d.n_v} vertices / {d.n_e} edges)" + (f" from {data_src}" if data_src else ""), "tile_rows": info["tile_rows"],
                       "tiles": info["tiles"], "etree_levels": info["etree_levels"], "parallelism": f"replicas x{world}"},
-           "roofline": {"bound": "mfma", "kernel": "tile Cholesky (k_potrf_inv_la + k_tile_gemm_nt)", "achieved": ach, "peak": 78.6,
+           "roofline": {"bound": "mfma", "kernel": "tile Cholesky (k_potrf_inv_mf + k_tile_gemm_nt + k_factor_flow)", "achieved": ach, "peak": 78.6,
                         "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None, "flops_per_factorisation": flops,
                         "avg_factor_ms": f_ms, "note": "17-68 dependent levels: latency-bound at this size"},
            "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
@@ -277,6 +279,22 @@ def bench_pose_graph(args):
         dist.destroy_process_group()
 
 
+def process_group(torch, local_rank):
+    """torch.distributed for the barrier / max-over-ranks of the contract: RCCL, one rank per GPU.  Bring-up on a box with
+    fewer GPUs than ranks (APEX_BENCH_PG=gloo): the ranks share the devices round-robin and the group runs over gloo with
+    host tensors -- the library's own RCCL communicator then cannot be built and the shared-memory transport takes over,
+    which is how the fall-back of main() is exercised on one GPU.  Returns (device index, device for group tensors)."""
+    import torch.distributed as dist
+    if os.environ.get("APEX_BENCH_PG", "nccl") == "gloo":
+        dev = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend="gloo")
+        return dev, "cpu"
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    return local_rank, "cuda"
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: run N ranks of this very command under torch.distributed.run as a
     CHILD process (never an exec: this process may not replace itself once a GPU runtime is loaded, and it has not
@@ -287,7 +305,7 @@ def spawn_ranks(n):
     import torch
 
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get("APEX_BENCH_PG", "nccl") != "gloo":   # (gloo bring-up: the ranks share the devices)
         raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s)")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ)
@@ -317,12 +335,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    dev, pg_dev = torch.cuda.current_device(), "cuda"
+    if world > 1:
+        dev, pg_dev = process_group(torch, local_rank)
 
     d, data_kind, data_src = pkg.datasets.load_named(args.workload, args.scale)   # real BAL file when data/... holds it
     ot = OptimizationType.SelfCalibration if args.mode == "selfcal" else OptimizationType.BundleAdjustment
     prob = Problem.bundle_adjustment(d, ot, 1.0)
-    s = GpuSchurComplementSolver(local_rank)
+    s = GpuSchurComplementSolver(dev)
     s.with_variant({"sparse": SchurVariant.Sparse, "iterative": SchurVariant.Iterative, "implicit": SchurVariant.Implicit}[args.variant])
     if args.cg:
         s.with_cg_params(int(args.cg.split(",")[0]), float(args.cg.split(",")[1]))
@@ -332,18 +353,45 @@ def main():
         s.with_option("matrix_free_only", 1)   # S is never formed: no tile structure beyond the diagonal, no pair list
     for o in args.opt:
         s.with_option(o.split("=")[0], int(o.split("=")[1]))
+    comm_kind = "none"
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         import ctypes as C
 
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            buf = (C.c_char * 128)()
-            rc = pkg.capi.load().apexgpu_get_unique_id(C.cast(buf, C.c_void_p))
-            assert rc == 0
-            uid = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).cuda()
-        dist.broadcast(uid, 0)
-        s.with_communicator(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        def fresh_unique_id():
+            uid = torch.zeros(128, dtype=torch.uint8, device=pg_dev)
+            if rank == 0:
+                buf = (C.c_char * 128)()
+                rc = pkg.capi.load().apexgpu_get_unique_id(C.cast(buf, C.c_void_p))
+                assert rc == 0
+                uid = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).to(pg_dev)
+            dist.broadcast(uid, 0)
+            return bytes(uid.cpu().numpy().tobytes())
+
+        # The library's own RCCL communicator (csrc/comm.cpp) is probed on a throw-away handle first: if any rank cannot
+        # join it, every rank takes the host shared-memory transport instead (one node: csrc/comm.h) and the line says so --
+        # slower exchanges, same schedule, and a record instead of a dead run.  --comm rccl / shm force one or the other.
+        ok, why = 1, ""
+        if args.comm != "shm":
+            try:
+                probe = pkg.capi.Handle(1, 1, 1, 0, dev)
+                buf = (C.c_char * 128).from_buffer_copy(fresh_unique_id())
+                probe.check(probe.L.apexgpu_comm_init(probe.h, world, rank, C.cast(buf, C.c_void_p)))
+                probe.close()
+            except Exception as e:   # noqa: BLE001 -- whatever it is, the vote below decides
+                ok, why = 0, repr(e)[:200]
+        else:
+            ok = 0
+        vote = torch.tensor([ok], dtype=torch.int32, device=pg_dev)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+        if int(vote.item()) == 1:
+            s.with_communicator(world, rank, fresh_unique_id()); comm_kind = "rccl"
+        elif args.comm == "rccl":
+            raise SystemExit(f"rank {rank}: the RCCL communicator could not be built ({why or 'another rank failed'})")
+        else:
+            tag = torch.tensor([os.getpid()], dtype=torch.int64, device=pg_dev)
+            dist.broadcast(tag, 0)
+            s.with_shm_communicator(world, rank, f"bench-{int(tag.item())}")
+            comm_kind = "shm" if args.comm == "shm" else "shm (RCCL communicator failed: " + (why or "on another rank") + ")"
     t_setup = time.perf_counter()
     s.initialize_structure(prob)
     s.set_parameters(d.poses, d.intr, d.points)
@@ -371,7 +419,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=pg_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stages = s.stage_times()
@@ -441,7 +489,7 @@ def main():
         "config": {"workload": f"{d.name} {data_kind} ({d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations)" + (f" from {data_src}" if data_src else ""),
                    "optimization_type": args.mode, "camera_dof": dc, "schur_variant": args.variant, "huber": 1.0,
                    "s_tile_rows": info["tile_rows"], "s_tiles": info["tiles"], "s_tiles_touched": info["touched_tiles"],
-                   "etree_levels": info["etree_levels"], "border_cameras": st["hub_cameras"], "schur_form": form, "parallelism": f"landmark-shard x{world}" + (f", landmarks and Cholesky distributed by elimination subtree ({info['dist_top_columns']} shared top tile columns, tree_sharded={info.get('tree_sharded')})" if info.get("dist_top_columns") else "")},
+                   "etree_levels": info["etree_levels"], "border_cameras": st["hub_cameras"], "schur_form": form, **({"transport": comm_kind} if world > 1 else {}), "parallelism": f"landmark-shard x{world}" + (f", landmarks and Cholesky distributed by elimination subtree ({info['dist_top_columns']} shared top tile columns, tree_sharded={info.get('tree_sharded')})" if info.get("dist_top_columns") else "")},
         "roofline": roofline,
         "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
         "stage_launches": {k: int(v[1]) for k, v in stages.items()},
