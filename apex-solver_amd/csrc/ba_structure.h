@@ -27,7 +27,7 @@ struct BaStructOptions {
     int rank = 0, world = 1;
     bool dist_factor = true, tree_sharding = true;
     int dist_selftest = 0;
-    int schur_form = 3;        // 3 sorted pair list (default), 2 LDS rows (k_schur_rows2, the A/B)
+    int schur_form = 3;        // 3 sorted pair list, 4 the same pairs in the queued layout (d_c = 9; schur_pairs.h), 2 LDS rows (k_schur_rows2, the A/B)
     int pair_task_slots = 0;   // pair slots per wave task of the pair list (0: default)
 };
 

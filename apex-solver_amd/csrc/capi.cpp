@@ -268,7 +268,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
         for (const char* k : structural)
             if (n == k) return APEXGPU_ERR_INVALID_STATE;
     if (n == "schur_rows" || n == "schur_form") {   // 3 sorted pair list (default), 2 LDS rows; the forms 0 / 1 of rounds 1-3 are gone
-        if (value != 3 && value != 2) return APEXGPU_ERR_INVALID_INPUT;
+        if (value != 3 && value != 2 && value != 4) return APEXGPU_ERR_INVALID_INPUT;
         h->s->use_row_schur(value);
     }
     else if (n == "graphs") h->s->enable_graphs(value != 0);
@@ -286,7 +286,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "panel_tri") apex::set_panel_tri(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "pairs_ablation") {   /* timing experiments only: the results are WRONG when != 0, so the switch exists only */
-        if (value != 0 && !getenv("APEX_ALLOW_ABLATION")) return APEXGPU_ERR_INVALID_INPUT;   /* for a process that asks for it */
+        if (value != 0 && value != 2048 && !getenv("APEX_ALLOW_ABLATION")) return APEXGPU_ERR_INVALID_INPUT;   /* (2048: strip mapping, results right) */   /* for a process that asks for it */
         h->s->set_pairs_ablation(value);
     }
     else if (n == "pairs_variant") { if (value != 2) return APEXGPU_ERR_INVALID_INPUT; }   /* one pair kernel is left: the record form (2) */
@@ -388,9 +388,9 @@ int apexgpu_set_shard(apexgpu_solver* h, int rank, int world) { H_OR_FAIL; retur
 // I >= J, = I (I + 1) / 2 + J).  Two-call pattern: with every output NULL the sizes come back in counts[4] = {slots,
 // chunks, blocks, tasks}; o_index_out[n_obs] receives the landmark-major position -> caller's observation index map that
 // the records' i / j refer to.  Lets CPU tests replay the kernel's bookkeeping (block boundaries, padding, flush points).
-int apexgpu_debug_pair_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc, const uint32_t* cam_idx, const uint32_t* pt_idx,
-                             int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
-                             int32_t* tasks2_out, int32_t* o_index_out) {
+static int debug_pair_lists_impl(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc, const uint32_t* cam_idx, const uint32_t* pt_idx,
+                                 int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
+                                 int32_t* tasks2_out, int32_t* o_index_out, bool queued, int64_t* qdesc3_out) {
     if (n_cam <= 0 || n_pt <= 0 || n_obs < 0 || (dc != 6 && dc != 9) || !cam_idx || !pt_idx || !counts) return APEXGPU_ERR_INVALID_INPUT;
     return guarded([&]() -> int {
         for (int64_t i = 0; i < n_obs; ++i)
@@ -413,7 +413,7 @@ int apexgpu_debug_pair_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc,
         std::vector<int> ext(n_cam);
         for (int64_t c = 0; c < n_cam; ++c) ext[c] = (int)c;
         apex::PairLists pl;
-        apex::build_pair_lists(dc, nt, slot.data(), n_cam, ext.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(), cam_obs.data(), &pl);
+        apex::build_pair_lists(dc, nt, slot.data(), n_cam, ext.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(), cam_obs.data(), &pl, 0, queued);
         counts[0] = (int64_t)pl.recs.size(); counts[1] = (int64_t)pl.chunks.size(); counts[2] = (int64_t)pl.blocks.size(); counts[3] = (int64_t)pl.tasks.size();
         if (recs4_out) memcpy(recs4_out, pl.recs.data(), pl.recs.size() * sizeof(apex::PairRec));
         if (chunks2_out) memcpy(chunks2_out, pl.chunks.data(), pl.chunks.size() * sizeof(apex::PairChunk));
@@ -424,8 +424,22 @@ int apexgpu_debug_pair_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc,
             }
         if (tasks2_out) memcpy(tasks2_out, pl.tasks.data(), pl.tasks.size() * sizeof(apex::PairTask));
         if (o_index_out) for (int64_t k = 0; k < n_obs; ++k) o_index_out[k] = order[k];
+        if (qdesc3_out)
+            for (size_t q = 0; q < pl.qdesc.size(); ++q) { qdesc3_out[3 * q] = pl.qdesc[q].dst; qdesc3_out[3 * q + 1] = pl.qdesc[q].cj; qdesc3_out[3 * q + 2] = pl.qdesc[q].flags; }
         return APEXGPU_OK;
     });
+}
+int apexgpu_debug_pair_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc, const uint32_t* cam_idx, const uint32_t* pt_idx,
+                             int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
+                             int32_t* tasks2_out, int32_t* o_index_out) {
+    return debug_pair_lists_impl(n_cam, n_pt, n_obs, dc, cam_idx, pt_idx, counts, recs4_out, chunks2_out, blocks4_out, tasks2_out, o_index_out, false, nullptr);
+}
+// The same in the QUEUED layout ("schur_form" 4, d_c = 9; csrc/schur_pairs.h): qdesc3_out[8 * chunks][3] = {dst, cj, flags} of
+// every (chunk, queue) -- entry 7 of a chunk: cj = the row's camera --, chunks2_out[.][0] = the chunk's flush bits.
+int apexgpu_debug_pair_lists_queued(int64_t n_cam, int64_t n_pt, int64_t n_obs, const uint32_t* cam_idx, const uint32_t* pt_idx,
+                                    int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
+                                    int32_t* tasks2_out, int32_t* o_index_out, int64_t* qdesc3_out) {
+    return debug_pair_lists_impl(n_cam, n_pt, n_obs, 9, cam_idx, pt_idx, counts, recs4_out, chunks2_out, blocks4_out, tasks2_out, o_index_out, true, qdesc3_out);
 }
 
 // Host arithmetic only: everything apexgpu_set_structure derives from the observation list before it touches the device

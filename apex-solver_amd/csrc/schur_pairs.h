@@ -46,12 +46,32 @@ struct PairBlock {
 struct PairTask {     // the work of one wave: whole blocks, a whole number of chunks
     int32_t chunk0, nchunks;
 };
+// QUEUED layout (round 4, "schur_form" 4).  The seven lane groups of the product phase each own a block of their own instead
+// of a seventh of the pairs of one block: a finished block is complete in the nine lanes of its group and is stored without a
+// fold over the groups.  A task is the blocks of (part of) ONE row ci, each padded to whole NONETS of nine slots; the task's
+// nonets, in block order, are cut into seven contiguous queues of `nchunks` nonets, and chunk q holds nonet q of every queue:
+// slot g + 7 t of the chunk is pair t of queue g's nonet, slot 63 is padding.  Inside a chunk a queue therefore has exactly one
+// block -- one descriptor per (chunk, queue), flush decisions per chunk, 1 + 7 cameras per chunk.
+struct PairQDesc {    // queue g < 7 of a chunk: the block its nonet belongs to; entry 7: cj = the row's camera ci
+    int64_t dst;      // as PairBlock::dst
+    uint32_t cj;      // the block's partner camera (a valid camera index also in an empty queue)
+    uint32_t flags;   // kPairBlock* | kPairQFlush: the block (piece) ends with this nonet -- store / add it after this chunk
+};
+constexpr uint32_t kPairQFlush = 4;
+// A block cut between the tail of queue g and the head of queue g + 1 (the same wave) is still stored once: the head part is
+// CARRIED in registers from the chunk it ends in to the end of the task, where queue g JOINS it to its tail part.
+constexpr uint32_t kPairQCarry = 8;     // this flush keeps the sum in the lanes (head part of a cut block)
+constexpr uint32_t kPairQJoin = 16;     // this flush (last chunk of the task) adds the next queue's carried sum first
+constexpr int kPairQPiecePairs = 576;   // a block with more pairs is cut into pieces of 64 nonets (atomic flush); a task has at
+                                        // most 64 chunks >= its longest piece, so a piece spans at most two queues
 
 struct PairLists {
     raw_vector<PairRec> recs;     // written once, in parallel (1.5 GB on final-13682)
     std::vector<PairChunk> chunks;
     std::vector<PairBlock> blocks;
     std::vector<PairTask> tasks;
+    std::vector<PairQDesc> qdesc; // queued layout only: 8 per chunk (PairChunk::mask then holds the flush bits of its queues)
+    bool queued = false;
     int64_t n_pairs = 0;      // real pairs (without padding)
     int64_t n_blocks = 0;     // camera-pair blocks that receive contributions
 };
@@ -62,7 +82,7 @@ struct PairLists {
 // slot: tile slot map (nt x nt, lower).
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
-                      int task_slots = 0 /* 0: default */);
+                      int task_slots = 0 /* 0: default */, bool queued = false);
 
 // The pair kernel (record form: J rebuilt from the 32-byte projection records k_landmark_reduce writes, orec).
 // ablation: timing experiments only (results are wrong when != 0)
@@ -70,6 +90,6 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
 void pairs_phase_cycles(unsigned long long out[8], bool reset);
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
                         const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, int ablation,
-                        const double* orec);
+                        const double* orec, const PairQDesc* qdesc = nullptr /* the queued layout's descriptors */);
 
 }  // namespace apex

@@ -12,6 +12,9 @@ namespace apex {
 
 constexpr int kPairTaskSlots = 1536;     // a wave's task is closed once it holds this many slots (24 chunks: the pipeline's
                                          // prologue -- three dependent loads -- is paid once per task)
+constexpr int kPairQTaskSlots = 2016;    // queued layout: slots of a task (224 nonets = 7 queues x 32 chunks: the longest block of the
+                                         // headline shape is 32 nonets, and a task has at least as many chunks as its longest piece;
+                                         // 2016 / 2592 / 4032: 3.18 / 3.24 / 3.36 ms, smaller tasks pad their queues: 1152 3.66 ms)
 constexpr int kPairMaxBlockSlots = 4096; // a block with more slots is split over several waves (atomic flush).  With 2 kTask <= 4096
                                          // a task never has more than 64 chunks: the record kernel keeps a task's chunk descriptors
                                          // one per lane (k_schur_pairs_r)
@@ -20,12 +23,12 @@ constexpr int kPairMaxBlockSlots = 4096; // a block with more slots is split ove
 // host: the sorted pair list
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
-
+struct Run { uint32_t cj; int len; int piece0; };   // the pairs of one row with one partner camera = one block of S
 }  // namespace
 
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
-                      int task_slots) {
+                      int task_slots, bool queued) {
     SetupTrace tr;
     const int cpt = kNB / dc;
     const int kTask = std::min(task_slots > 0 ? (task_slots + 63) / 64 * 64 : kPairTaskSlots, kPairMaxBlockSlots / 2);
@@ -46,7 +49,6 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
     tr.mark("pairs: count");
     // Pass A, per row: its blocks = the partner cameras it has pairs with (sorted) and how many.  A counting pass over
     // the partner lists; no pair is stored yet.
-    struct Run { uint32_t cj; int len; int piece0; };
     std::vector<std::vector<Run>> row_runs(n_cam);
     parallel_ranges(n_cam, 16, [&](int64_t rb, int64_t re) {
         std::vector<int> cnt(n_cam, 0), touched;
@@ -67,8 +69,119 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
         }
     });
     tr.mark("pairs: blocks of every row");
+    out->blocks.clear(); out->chunks.clear(); out->tasks.clear(); out->qdesc.clear(); out->queued = false;
+    if (queued) {
+        // ---- QUEUED layout (schur_pairs.h): tasks inside one row, blocks padded to nonets, seven queues per task -----------
+        // nonets per task: 7 x 64 at most (a task's chunk descriptors sit one per lane); fewer = more tasks per row = fewer rows
+        // in flight per XCD, whose L2 then sees a row's landmark records again before they are evicted ("pair_task_slots")
+        const int kMaxNonets = std::min(7 * 64, std::max(63, (task_slots > 0 ? task_slots : kPairQTaskSlots) / 9));
+        struct QPiece { int task; int nonet0; int len; int block; };
+        struct QTask { int chunk0, nchunks, nonets, ci, piece0, piece1; };
+        std::vector<QPiece> pieces;
+        std::vector<QTask> qtasks;
+        int64_t n_blocks = 0;
+        for (int64_t r = 0; r < n_cam; ++r) n_blocks += (int64_t)row_runs[r].size();
+        pieces.reserve(n_blocks + 16);
+        out->blocks.reserve(n_blocks + 16);
+        out->queued = true;
+        int64_t total_chunks = 0;
+        for (int64_t r = 0; r < n_cam; ++r) {
+            const int ci = rows[r];
+            int64_t row_nonets = 0;
+            for (const Run& run : row_runs[r])
+                for (int len = run.len; len > 0; len -= kPairQPiecePairs) row_nonets += (std::min(len, kPairQPiecePairs) + 8) / 9;
+            if (row_nonets == 0) continue;
+            const int n_row_tasks = (int)((row_nonets + kMaxNonets - 1) / kMaxNonets);
+            const int target = (int)((row_nonets + n_row_tasks - 1) / n_row_tasks);   // even tasks, cut at block boundaries
+            int task_nonets = 0, task_piece0 = (int)pieces.size(), max_nn = 0;
+            auto close_task = [&]() {
+                if (task_nonets == 0) return;
+                const int nchunks = std::max((task_nonets + 6) / 7, max_nn);   // >= the longest piece: a piece spans <= 2 queues
+                qtasks.push_back(QTask{(int)total_chunks, nchunks, task_nonets, ci, task_piece0, (int)pieces.size()});
+                out->tasks.push_back(PairTask{(int32_t)total_chunks, (int32_t)nchunks});
+                total_chunks += nchunks;
+                task_nonets = 0; max_nn = 0; task_piece0 = (int)pieces.size();
+            };
+            for (Run& run : row_runs[r]) {
+                const uint32_t cj = run.cj;
+                const int I = ci / cpt, J = (int)cj / cpt;
+                const int sl = slot[(size_t)I * nt + J];
+                const int64_t dst = (int64_t)sl * kNB * kNB + (int64_t)((ci % cpt) * dc) * kNB + ((int)cj % cpt) * dc;
+                const uint32_t diag = ((int)cj == ci) ? kPairBlockDiag : 0u;
+                const bool split = run.len > kPairQPiecePairs;
+                run.piece0 = (int)pieces.size();
+                for (int len = run.len; len > 0; len -= kPairQPiecePairs) {
+                    const int take = std::min(len, kPairQPiecePairs), nn = (take + 8) / 9;
+                    if (task_nonets > 0 && (task_nonets + nn > kMaxNonets || task_nonets >= target)) close_task();
+                    const int bi = (int)out->blocks.size();
+                    out->blocks.push_back(PairBlock{dst, (uint32_t)ci, cj, diag | ((split || diag) ? kPairBlockAtomic : 0u), 0u});
+                    pieces.push_back(QPiece{(int)qtasks.size(), task_nonets, take, bi});
+                    task_nonets += nn; max_nn = std::max(max_nn, nn);
+                }
+            }
+            close_task();
+        }
+        if (total_chunks * 64 > (int64_t)0x7fffffff * 64) { out->tasks.clear(); return; }
+        out->chunks.assign((size_t)total_chunks, PairChunk{0u, 0});
+        out->qdesc.assign((size_t)total_chunks * 8, PairQDesc{0, 0u, 0u});
+        out->recs.resize((size_t)total_chunks * 64);
+        tr.mark("pairs: blocks, tasks");
+        // descriptors and padding, task by task; a nonet's slot t is (chunk0 + idx % nchunks) * 64 + idx / nchunks + 7 t
+        parallel_rows((int64_t)qtasks.size(), [&](int64_t ti) {
+            const QTask& tk = qtasks[ti];
+            auto slot_of = [&](int idx, int t) { return ((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + idx / tk.nchunks + 7 * t; };
+            for (int q = 0; q < tk.nchunks; ++q) {
+                PairQDesc* qd = out->qdesc.data() + ((size_t)tk.chunk0 + q) * 8;
+                for (int g = 0; g < 8; ++g) qd[g] = PairQDesc{0, (uint32_t)tk.ci, 0u};
+                out->recs[((size_t)tk.chunk0 + q) * 64 + 63] = PairRec{kPairPad, 0u, 0u, 0u};
+            }
+            for (int pi = tk.piece0; pi < tk.piece1; ++pi) {
+                const QPiece& pc = pieces[pi];
+                const PairBlock& pb = out->blocks[pc.block];
+                const int nn = (pc.len + 8) / 9;
+                const bool two_queues = pc.nonet0 / tk.nchunks != (pc.nonet0 + nn - 1) / tk.nchunks;
+                for (int n = 0; n < nn; ++n) {
+                    const int idx = pc.nonet0 + n, g = idx / tk.nchunks, q = idx % tk.nchunks;
+                    const bool last = n == nn - 1 || q == tk.nchunks - 1;   // the piece ends, or its queue does
+                    PairQDesc& d = out->qdesc[((size_t)tk.chunk0 + q) * 8 + g];
+                    d.dst = pb.dst; d.cj = pb.cj;
+                    d.flags = pb.flags | (last ? kPairQFlush : 0u);
+                    if (two_queues && last) d.flags |= (n == nn - 1) ? kPairQCarry : kPairQJoin;   // the head part ends the piece, the tail part its queue
+                    if (last) out->chunks[(size_t)tk.chunk0 + q].mask |= 1u << g;
+                    for (int t = (n == nn - 1 ? pc.len - 9 * n : 9); t < 9; ++t) out->recs[slot_of(idx, t)] = PairRec{kPairPad, 0u, 0u, (uint32_t)g};
+                }
+            }
+            for (int idx = tk.nonets; idx < 7 * tk.nchunks; ++idx)   // the empty tail of the last queues
+                for (int t = 0; t < 9; ++t) out->recs[slot_of(idx, t)] = PairRec{kPairPad, 0u, 0u, (uint32_t)(idx / tk.nchunks)};
+        }, 64);
+        // records: the k-th pair of a row with one partner goes to pair k % 576 of piece k / 576 of that block
+        parallel_ranges(n_cam, 16, [&](int64_t rb, int64_t re) {
+            std::vector<int> pos(n_cam, 0), ridx(n_cam, 0);
+            for (int64_t r = rb; r < re; ++r) {
+                const int c = rows[r];
+                const auto& runs = row_runs[r];
+                for (size_t q = 0; q < runs.size(); ++q) { ridx[runs[q].cj] = (int)q; pos[runs[q].cj] = 0; }
+                for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
+                    const int i = cam_obs[e];
+                    const uint32_t l = o_pt[i];
+                    for (int j = pt_ptr[l]; j < i; ++j) {
+                        const uint32_t cj = o_cam[j];
+                        const Run& run = runs[ridx[cj]];
+                        const int k = pos[cj]++;
+                        const QPiece& pc = pieces[run.piece0 + k / kPairQPiecePairs];
+                        const QTask& tk = qtasks[pc.task];
+                        const int kk = k % kPairQPiecePairs, idx = pc.nonet0 + kk / 9, g = idx / tk.nchunks;
+                        out->recs[((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + g + 7 * (kk % 9)] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
+                    }
+                }
+            }
+        });
+        tr.mark("pairs: records");
+        out->n_pairs = n_pairs;
+        out->n_blocks = n_blocks;
+        return;
+    }
     // ---- serial pass over the BLOCKS (not the pairs): slot offsets, block table, chunk descriptors, tasks ------------
-    out->blocks.clear(); out->chunks.clear(); out->tasks.clear();
     struct Piece { int64_t slot0; int len; };   // a block (or a piece of a split block) -> its slots
     std::vector<Piece> pieces;
     int64_t n_blocks = 0;
@@ -220,6 +333,21 @@ __device__ __noinline__ void pairs_flush_slow(double* __restrict__ dst, const ui
             }
         }
 }
+// ... the same for a lane that holds COLUMN col of the finished block (queued layout: av.a0 .. a8 = rows 0 .. 8)
+template <int DC>
+__device__ __noinline__ void pairs_flush_slow_col(double* __restrict__ dst, const uint32_t flags, const Acc9 av, int col) {
+    const double acc[9] = {av.a0, av.a1, av.a2, av.a3, av.a4, av.a5, av.a6, av.a7, av.a8};
+#pragma unroll
+    for (int row = 0; row < 9; ++row) {
+        const double val = acc[row];
+        if (flags & kPairBlockDiag) {
+            if (row >= col) unsafeAtomicAdd(&dst[row * kNB + col], val);
+            if (col >= row) unsafeAtomicAdd(&dst[col * kNB + row], val);
+        } else {
+            unsafeAtomicAdd(&dst[row * kNB + col], val);
+        }
+    }
+}
 // Lane mapping of the record kernel's product phase.  DC = 6: lane = 4 g + sub (16 groups x 4 sub-blocks).  DC = 9: the 9
 // sub-blocks x 7 groups are laid out so that the fold over the groups is DPP arithmetic on the vector unit instead of three
 // dependent round trips through the LDS crossbar (ds_bpermute): sub-blocks 0..7 own one aligned OCTET of lanes each
@@ -299,6 +427,47 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
     }
 }
 
+// STRIP mapping of the product phase (d_c = 9, round 4): a lane owns a 3 x 9 ROW STRIP of the running block -- lane = 16 bi + g,
+// strip bi = 0..2 in the first three 16-lane rows, sixteen groups g that split the pairs; the fourth row idles.  Per pair a lane
+// reads U's three rows (6 doubles) and ALL of V (18) for 54 FMA: 0.44 doubles per FMA instead of 0.67, twelve ds_read_b128 per
+// 64-lane step of sixteen pairs instead of six per step of seven -- 48 instead of 60 LDS instructions and 37 instead of 60 KB
+// read per chunk, and the sixteen V rows of a step sit in sixteen different 16-byte bank groups (row pitch 144 B = 9 groups).
+// The fold is a sum over the 16 lanes of a DPP row: four row_shr adds per value, total in lane 15 of each row.
+template <int FABL = 0>
+__device__ __forceinline__ void pairs_flush_strip(double* __restrict__ tiles, const int64_t pb_dst, const uint32_t pb_flags,
+                                                  double acc[27], int lane) {
+    if (!(FABL & 1)) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            double a = acc[k];
+            a = dpp_add_masked<0x118, 0xF, 0xF>(a);
+            a = dpp_add_masked<0x114, 0xF, 0xF>(a);
+            a = dpp_add_masked<0x112, 0xF, 0xF>(a);
+            a = dpp_add_masked<0x111, 0xF, 0xF>(a);
+            acc[k] = a;
+        }
+    }
+    if ((FABL & 2) && acc[0] != 1.2345e300) return;
+    if ((lane & 15) == 15 && lane < 48) {
+        const int bi = lane >> 4;
+        double* dst = tiles + pb_dst;
+        if (pb_flags == 0) {
+            double* d0 = dst + (3 * bi) * kNB;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int bj = 0; bj < 3; ++bj)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) d0[r * kNB + 3 * bj + c] = acc[9 * bj + 3 * r + c];
+        } else {
+#pragma unroll
+            for (int bj = 0; bj < 3; ++bj)
+                pairs_flush_slow<9>(dst, pb_flags, Acc9{acc[9 * bj], acc[9 * bj + 1], acc[9 * bj + 2], acc[9 * bj + 3], acc[9 * bj + 4], acc[9 * bj + 5],
+                                                        acc[9 * bj + 6], acc[9 * bj + 7], acc[9 * bj + 8]}, 3 * bi + bj);
+        }
+    }
+}
+
 // ABL (timing experiments only, results wrong when != 0): 1 no per-pair gathers, 2 no block products, 4 no U / V stores,
 // 8 no flush (fold + store of the finished block) -- NOTE: with the flush gone seven of the nine accumulators are dead and the
 // compiler drops their FMAs, so 8 measures "no flush and 7/9 of the products", not the flush (round 4: 512 / 1024 below do) --,
@@ -312,15 +481,21 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
 // version of this kernel stalled ~1 us per chunk on its own chunk descriptor).  The task's chunk descriptors are loaded
 // once, one per lane, and read with v_readlane; a chunk's block descriptors (destination, flags) come one chunk ahead as
 // a vector load by the first lanes and are read the same way.
-template <int DC, bool MASKED, int ABL = 0>
+// QL: the QUEUED layout (schur_pairs.h): every lane group owns a block of its own -- nine product steps per chunk without
+// segment bookkeeping, no fold over the groups, one descriptor per (chunk, queue) fetched by the lanes that store.
+template <int DC, bool MASKED, int ABL = 0, bool QL = false>
 __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __restrict__ tiles, const PairTask* __restrict__ tasks,
                                                           int n_tasks, const PairChunk* __restrict__ chunks,
                                                           const PairBlock* __restrict__ blocks, const PairRec* __restrict__ recs,
-                                                          const double* __restrict__ lmrec, const double* __restrict__ orec) {
+                                                          const double* __restrict__ lmrec, const double* __restrict__ orec,
+                                                          const PairQDesc* __restrict__ qdesc) {
+    static_assert(!QL || DC == 9, "the queued layout is built for d_c = 9 (seven groups of nine lanes)");
     constexpr int UV = 2 * DC;
     constexpr int NB3 = DC / 3;
     constexpr int GL = NB3 * NB3;
-    constexpr int NG = (DC == 9) ? 7 : 16;
+    constexpr bool STRIP = DC == 9 && (ABL & 2048) != 0;   // a lane owns a 3 x 9 row strip (pairs_flush_strip)
+    constexpr int NG = STRIP ? 16 : (DC == 9) ? 7 : 16;
+    constexpr int NACC = STRIP ? 27 : 9;
     constexpr int WAVE_LDS = 2 * 64 * UV + UV;   // U[64][UV] | V[64][UV] | zeros[UV]
     __shared__ double lds_all[4 * WAVE_LDS];
     // The chunk's <= 8 cameras are staged through REGISTERS (one 16-byte load per lane a chunk ahead, one ds_write at the top
@@ -347,14 +522,37 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     if (lane < UV) Z[lane] = 0.0;
     int g, sub;
     pairs_lane_map<DC, (ABL & 256) != 0>(lane, g, sub);
+    if (STRIP) { g = lane & 15; sub = 3 * (lane >> 4); }
+    if (QL) { g = lane == 63 ? 0 : lane / 9; sub = lane == 63 ? 0 : lane - 9 * g; }   // (lane 63 shadows lane 0 and never stores)
     const int bi = sub / NB3, bj = sub - bi * NB3;
-    const bool worker = g < NG;
-    double acc[9];
+    const bool worker = STRIP ? lane < 48 : g < NG;
+    double acc[NACC];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
     int cur = -1;
     int64_t cur_dst = 0;
     uint32_t cur_flags = 0;
+    double pend[QL ? 9 : 1];          // queued layout: a finished block on its way to memory (stored a chunk later)
+    double carry[QL ? 9 : 1];         // ... and the head part of a block cut between two queues (see kPairQCarry)
+#pragma unroll
+    for (int k = 0; k < (QL ? 9 : 1); ++k) carry[k] = 0.0;
+    int2 pend_dst = make_int2(0, 0);
+    uint32_t pend_fl = 0;
+    bool pend_on = false;
+    auto store_pending = [&]() {   // pend[r] = element (r, sub) of the block: store instruction r writes one whole 72-byte row per group
+        if (QL && pend_on && !(ABL & 1024)) {
+            double* dst = tiles + (((int64_t)pend_dst.y << 32) | (uint32_t)pend_dst.x);
+            const uint32_t fl = pend_fl & (kPairBlockAtomic | kPairBlockDiag);
+            if (fl == 0) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) dst[r * kNB + sub] = pend[r % (QL ? 9 : 1)];
+            } else {
+                pairs_flush_slow_col<DC>(dst, fl, Acc9{pend[0], pend[1 % (QL ? 9 : 1)], pend[2 % (QL ? 9 : 1)], pend[3 % (QL ? 9 : 1)], pend[4 % (QL ? 9 : 1)], pend[5 % (QL ? 9 : 1)],
+                                                       pend[6 % (QL ? 9 : 1)], pend[7 % (QL ? 9 : 1)], pend[8 % (QL ? 9 : 1)]}, sub);
+            }
+        }
+        pend_on = false;
+    };
     const double mp = MASKED ? ((v.mask_code & 4) ? 1.0 : 0.0) : 1.0, ml = MASKED ? ((v.mask_code & 2) ? 1.0 : 0.0) : 1.0,
                  mi = MASKED ? ((v.mask_code & 1) ? 1.0 : 0.0) : 1.0;
 
@@ -440,11 +638,21 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     };
     // block descriptors of a chunk: lane b < nblk holds block first_block + b (destination offset, flags)
     struct BlockDesc { int2 dst; uint32_t flags; };
-    auto load_blocks = [&](const PairChunk c, BlockDesc& b) {
+    auto load_blocks = [&](const PairChunk c, BlockDesc& b, int qrel) {
+        if (QL) {   // the descriptor of this lane's queue in chunk chunk0 + qrel: what it stores to after that chunk
+            const uint4 d = *reinterpret_cast<const uint4*>(qdesc + 8 * (size_t)(chunk0 + qrel) + g);
+            b.dst = make_int2((int)d.x, (int)d.y); b.flags = d.w;
+            return;
+        }
         const int nblk = 1 + __popc(c.mask & ~1u);
         const PairBlock* pb = blocks + c.first_block + min(lane, nblk - 1);
         b.dst = *reinterpret_cast<const int2*>(&pb->dst);
         b.flags = pb->flags;
+    };
+    // the chunk's cameras, eight lanes each: queued layout = the row's camera (entry 7) and the seven queues' partners
+    auto chunk_cam = [&](const PairChunk c, int qrel) -> uint32_t {
+        if (QL) { const int cc = lane >> 3; return qdesc[8 * (size_t)(chunk0 + qrel) + (cc == 0 ? 7 : cc - 1)].cj; }
+        return pairs_dma_cam(blocks, c, lane);
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ckv
     const uint4* rec4 = reinterpret_cast<const uint4*>(recs);
@@ -455,22 +663,22 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     Coop coop;
     issue(rr, coop);
     BlockDesc bd, bd_next;
-    load_blocks(ck, bd);
+    load_blocks(ck, bd, 0);
     bd_next = bd;
-    bool dma = 1 + __popc(ck.mask & ~1u) <= kPairDmaBlocks;
+    bool dma = QL || 1 + __popc(ck.mask & ~1u) <= kPairDmaBlocks;
     auto cam_piece = [&](uint32_t cam) {   // lanes 8 c .. 8 c + 7 fetch the 128-byte prepared camera c of the chunk
         return *reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)cam + 2 * (lane & 7));
     };
-    double2 cam_stage = cam_piece(pairs_dma_cam(blocks, ck, lane));
+    double2 cam_stage = cam_piece(chunk_cam(ck, 0));
     PairChunk ck_next = chunk_desc(min(1, nchunks - 1));
     uint4 rr_next = rec4[(size_t)(chunk0 + min(1, nchunks - 1)) * 64 + lane];
-    uint32_t cam_next = pairs_dma_cam(blocks, ck_next, lane);
+    uint32_t cam_next = chunk_cam(ck_next, min(1, nchunks - 1));
 
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto stamp = [&]() -> unsigned long long { return (ABL & 64) ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull; };
     for (; q < nchunks; ++q) {
         const bool valid = rr.x != kPairPad;
-        const uint32_t blk = valid ? rr.w : 0u;
+        const uint32_t blk = valid ? rr.w : 0u;   // (queued layout: the slot's queue)
         const unsigned long long t0 = stamp();
         // ---- cameras of this lane's pair: LDS (DMA issued a chunk ago) or, in a chunk of many tiny blocks, memory ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // gathers, block descriptors, and the LDS-DMA (it writes LDS behind the VM counter)
@@ -487,8 +695,8 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             for (int k = 0; k < 16; ++k) { cvi[k] = dat.lm[k % 6].x + k; cvj[k] = dat.lm[k % 6].y - k; }
         } else {
             if (dma) {
-                const double2* ci = reinterpret_cast<const double2*>(CAMS + (2 * blk) * kCamStride);
-                const double2* cj = reinterpret_cast<const double2*>(CAMS + (2 * blk + 1) * kCamStride);
+                const double2* ci = reinterpret_cast<const double2*>(CAMS + (QL ? 0 : 2 * blk) * kCamStride);
+                const double2* cj = reinterpret_cast<const double2*>(CAMS + (QL ? 1 + blk : 2 * blk + 1) * kCamStride);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 a = ci[k], b = cj[k]; cvi[2 * k] = a.x; cvi[2 * k + 1] = a.y; cvj[2 * k] = b.x; cvj[2 * k + 1] = b.y; }
             } else {   // a chunk of many tiny blocks: the cameras come straight from memory
@@ -581,28 +789,99 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             // every outstanding load (s_waitcnt vmcnt(0)) to do it, i.e. for the gathers issued three lines earlier.
             ck = ck_next; rr = rr_next;
             if (!(ABL & 1)) issue(rr, coop);
-            load_blocks(ck, bd_next);
-            dma = 1 + __popc(ck.mask & ~1u) <= kPairDmaBlocks;
+            load_blocks(ck, bd_next, min(q + 1, nchunks - 1));
+            dma = QL || 1 + __popc(ck.mask & ~1u) <= kPairDmaBlocks;
             cam_stage = cam_piece(cam_next);
             const int q2 = min(q + 2, nchunks - 1);
             ck_next = chunk_desc(q2);
             rr_next = rec4[(size_t)(chunk0 + q2) * 64 + lane];
-            cam_next = pairs_dma_cam(blocks, ck_next, lane);
+            cam_next = chunk_cam(ck_next, q2);
         }
+        // The block finished by the PREVIOUS chunk goes to memory here, behind this chunk's gathers: the vector-memory counter
+        // counts stores too and in issue order, so stores issued before loads that the code waits for (the compiler puts its own
+        // s_waitcnt vmcnt(small) in front of the first use of a prefetched descriptor) stall the wave until they are ACKNOWLEDGED --
+        // 0.5 ms of the kernel when they sat at the top of the chunk.  Here the next wait for memory is a whole product phase away.
+        if constexpr (QL) store_pending();
         const unsigned long long t4 = stamp();
         // ---- block products over the 64 slots.  Uniform loop, two pairs per trip with all twelve operand reads issued up
         // front; a lane whose pair lies beyond the segment (and the idle 64th lane) reads the zero row instead.
+        if constexpr (QL) {
+            // nine steps, pair g + 7 t of the chunk in step t; ping-pong operand registers as below
+            if (!(ABL & 2)) {
+                auto ld = [&](int t, double2& u0, double2& u1, double2& u2, double2& v0, double2& v1, double2& v2) {
+                    const double2* qu = reinterpret_cast<const double2*>(U + (g + 7 * t) * UV + bi * 6);
+                    const double2* qv = reinterpret_cast<const double2*>(V + (g + 7 * t) * UV + bj * 6);
+                    u0 = qu[0]; u1 = qu[1]; u2 = qu[2]; v0 = qv[0]; v1 = qv[1]; v2 = qv[2];
+                };
+                auto mac = [&](const double2 u0, const double2 u1, const double2 u2, const double2 v0, const double2 v1, const double2 v2) {
+                    const double um0[3] = {u0.x, u0.y, u1.x}, um1[3] = {u1.y, u2.x, u2.y};
+                    const double vm0[3] = {v0.x, v0.y, v1.x}, vm1[3] = {v1.y, v2.x, v2.y};
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) acc[3 * r + c] = fma(um1[r], vm1[c], fma(um0[r], vm0[c], acc[3 * r + c]));
+                };
+                double2 a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5;
+                ld(0, a0, a1, a2, a3, a4, a5);
+#pragma unroll
+                for (int t = 0; t < 8; t += 2) {
+                    ld(t + 1, b0, b1, b2, b3, b4, b5);
+                    mac(a0, a1, a2, a3, a4, a5);
+                    ld(t + 2, a0, a1, a2, a3, a4, a5);
+                    mac(b0, b1, b2, b3, b4, b5);
+                }
+                mac(a0, a1, a2, a3, a4, a5);
+            }
+            // a queue whose block (piece) ends with this chunk: its nine lanes hold the finished 3 x 3 sub-blocks.  They are
+            // parked and stored at the top of the NEXT chunk, behind its wait for the gathers: stored here they would be the
+            // youngest entries of the memory counter that wait drains, i.e. a store round trip on every chunk's critical path
+            const unsigned long long f0 = stamp();
+            // (a block cut between queue g's tail and queue g + 1's head: the head's sum waits in `carry` for the last chunk)
+            if (q == nchunks - 1) {   // wave-uniform: the tails that join a carried head (kPairQJoin only occurs here)
+                const bool join = ((ck_cur.mask >> g) & 1u) && (bd_cur.flags & kPairQJoin);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { const double o = __shfl_down(carry[k], 9, 64); acc[k] += join ? o : 0.0; }
+            }
+            if (ck_cur.mask & 0x7fu) {   // wave-uniform: some queue's block (piece) ends with this chunk
+                // The nine lanes of a group hold the block as 3 x 3 sub-blocks; stored like that, one store instruction touches
+                // six 64-byte lines per block (three rows, each 72-byte row astride two lines) and a block costs 54 line
+                // writes -- 0.77 ms of the kernel went there.  Turned through the (now free) U area into one COLUMN per lane,
+                // store instruction r writes row r of every finished block as nine adjacent lanes: 18 line writes per block.
+                const bool mine = (ck_cur.mask >> g) & 1u;
+                const bool keep = mine && (bd_cur.flags & kPairQCarry) != 0;
+                double* T = U + 81 * g;
+                if (mine && !keep && lane < 63 && !(ABL & 4096)) {   // (lane 63 shadows lane 0 except in a join: it must not write)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) T[(3 * bj + c) * 9 + 3 * bi + r] = acc[3 * r + c];
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (mine) {
+                    if (!keep) {
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) pend[r] = (ABL & 4096) ? acc[r] : T[9 * sub + r];   // (4096: timing only, no transposition)
+                        pend_dst = bd_cur.dst; pend_fl = bd_cur.flags; pend_on = lane < 63;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) { carry[k] = keep ? acc[k] : carry[k]; acc[k] = 0.0; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (ABL & 64) { ph[6] += stamp() - f0; ph[7] += 1; }
+        } else {
         uint32_t mask = ck_cur.mask;
         int seg0 = 0, lb = 0;                 // lb: index of the running block inside this chunk's descriptors
         auto start_block = [&]() {
             cur_dst = ((int64_t)__builtin_amdgcn_readlane(bd_cur.dst.y, lb) << 32) | (uint32_t)__builtin_amdgcn_readlane(bd_cur.dst.x, lb);
             cur_flags = (uint32_t)__builtin_amdgcn_readlane((int)bd_cur.flags, lb);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+            for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
         };
         auto flush = [&]() {
             const unsigned long long f0 = stamp();
-            if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0, (ABL >> 9) & 3>(tiles, cur_dst, cur_flags, acc, lane);
+            if constexpr (STRIP) pairs_flush_strip<(ABL >> 9) & 3>(tiles, cur_dst, cur_flags, acc, lane);
+            else if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0, (ABL >> 9) & 3>(tiles, cur_dst, cur_flags, acc, lane);
             else if (acc[0] == 1.2345e300) tiles[0] = acc[1];
             if (ABL & 64) { ph[6] += stamp() - f0; ph[7] += 1; }
         };
@@ -617,7 +896,37 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         mask &= ~1u;
         for (;;) {
             const int seg1 = mask ? 2 * (__ffs(mask) - 1) : 64;      // wave-uniform
-            if (!(ABL & 2)) {
+            if constexpr (STRIP && !(ABL & 2)) {
+                // strip mapping: sixteen pairs per step; U's three rows and all of V per lane, ping-pong operand registers
+                int p = seg0 + g;
+                struct Ops { double2 u0, u1, u2, v[9]; };
+                auto ld = [&](int pp, Ops& o) {
+                    const bool ok = worker && pp < seg1;
+                    const double2* qu = reinterpret_cast<const double2*>(ok ? U + pp * UV + bi * 6 : Z);
+                    const double2* qv = reinterpret_cast<const double2*>(ok ? V + pp * UV : Z);
+                    o.u0 = qu[0]; o.u1 = qu[1]; o.u2 = qu[2];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) o.v[k] = qv[k];
+                };
+                auto mac = [&](const Ops& o) {
+                    const double um0[3] = {o.u0.x, o.u0.y, o.u1.x}, um1[3] = {o.u1.y, o.u2.x, o.u2.y};
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const double2 v0 = o.v[3 * b], v1 = o.v[3 * b + 1], v2 = o.v[3 * b + 2];
+                        const double vm0[3] = {v0.x, v0.y, v1.x}, vm1[3] = {v1.y, v2.x, v2.y};
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) acc[9 * b + 3 * r + c] = fma(um1[r], vm1[c], fma(um0[r], vm0[c], acc[9 * b + 3 * r + c]));
+                    }
+                };
+                // (one operand set: a second one for ping-pong, 48 more VGPRs, spills 61 registers at the 256-register limit)
+                Ops a;
+                for (int it = seg0; it < seg1; it += NG, p += NG) {
+                    ld(p, a);
+                    mac(a);
+                }
+            } else if (!(ABL & 2)) {
                 // One pair per step and lane, ping-pong operand registers: the six reads of the NEXT pair are in flight while
                 // the 18 FMA of this one run.  Uniform control flow; a lane whose pair lies beyond the segment (and the idle
                 // lane) reads the zero row.
@@ -657,6 +966,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             seg0 = seg1;
             mask &= mask - 1;
         }
+        }
         __builtin_amdgcn_wave_barrier();
         bd = bd_next;
         if (ABL & 64) {
@@ -668,8 +978,10 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
 #pragma unroll
         for (int k = 0; k < 8; ++k) atomicAdd(&g_pair_phase[k], ph[k]);
     }
-    if (cur >= 0) {
-        if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0>(tiles, cur_dst, cur_flags, acc, lane);
+    if constexpr (QL) store_pending();
+    if (!QL && cur >= 0) {
+        if constexpr (STRIP) pairs_flush_strip<0>(tiles, cur_dst, cur_flags, acc, lane);
+        else if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0>(tiles, cur_dst, cur_flags, acc, lane);
         else if (acc[0] == 1.2345e300) tiles[0] = acc[1];
     }
 }
@@ -681,18 +993,34 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
 // profiles/r03_pairs_ablation.txt); they were deleted in round 4.
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
                         const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, int ablation,
-                        const double* orec) {
+                        const double* orec, const PairQDesc* qdesc) {
     if (n_tasks == 0) return;
     const unsigned grid = (unsigned)((n_tasks + 3) / 4);
+    if (qdesc) {   // the queued layout (SelfCalibration's nine columns per camera only: set_structure builds it for nothing else)
+#define PAIRS_Q(MK, A) hipLaunchKernelGGL((k_schur_pairs_r<9, MK, A, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, qdesc)
+        if (v.mask_code != 7) PAIRS_Q(true, 0);
+        else if (ablation == 64) PAIRS_Q(false, 64);
+        else if (ablation == 1) PAIRS_Q(false, 1);
+        else if (ablation == 2) PAIRS_Q(false, 2);
+        else if (ablation == 1024) PAIRS_Q(false, 1024);
+        else if (ablation == 4096) PAIRS_Q(false, 4096);
+        else if (ablation == 64 + 1024) PAIRS_Q(false, 64 + 1024);
+        else if (ablation == 64 + 4096) PAIRS_Q(false, 64 + 4096);
+        else if (ablation == 64 + 5120) PAIRS_Q(false, 64 + 5120);
+        else if (ablation == 4096 + 1024) PAIRS_Q(false, 4096 + 1024);
+        else PAIRS_Q(false, 0);
+#undef PAIRS_Q
+        return;
+    }
     if (ablation != 0 && dc == 9) {   // timing experiments (SelfCalibration only)
-#define PAIRS_RA(A) case A: hipLaunchKernelGGL((k_schur_pairs_r<9, false, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec); return
-        switch (ablation) { PAIRS_RA(512); PAIRS_RA(1024); PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3);
+#define PAIRS_RA(A) case A: hipLaunchKernelGGL((k_schur_pairs_r<9, false, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, nullptr); return
+        switch (ablation) { PAIRS_RA(2048); PAIRS_RA(2048 + 64); PAIRS_RA(2048 + 512); PAIRS_RA(2048 + 1024); PAIRS_RA(2048 + 2); PAIRS_RA(512); PAIRS_RA(1024); PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3);
             default: break;   // an unlisted value: the plain kernel below, never a missing launch
         }
 #undef PAIRS_RA
     }
     const bool masked = v.mask_code != (dc == 9 ? 7 : 6);
-#define PAIRS_R(DCV, MK) hipLaunchKernelGGL((k_schur_pairs_r<DCV, MK>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec)
+#define PAIRS_R(DCV, MK) hipLaunchKernelGGL((k_schur_pairs_r<DCV, MK>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, nullptr)
     if (dc == 9) { if (masked) PAIRS_R(9, true); else PAIRS_R(9, false); }
     else { if (masked) PAIRS_R(6, true); else PAIRS_R(6, false); }
 #undef PAIRS_R

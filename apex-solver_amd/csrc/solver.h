@@ -105,7 +105,7 @@ class Solver : public LmBackend {
     int factor_flow_timeouts() const { return n_factor_flow_timeouts_; }
     void debug_poison_next_factor() { tp_.debug_poison_next_factor(); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
-    void use_row_schur(int v) { rows_form_ = v == 2 ? 2 : 3; }   // 3 sorted pair list (default), 2 LDS rows (the A/B)
+    void use_row_schur(int v) { rows_form_ = v == 2 ? 2 : (v == 4 ? 4 : 3); }   // 3 sorted pair list (default), 2 LDS rows (the A/B)
     bool has_structure() const { return have_structure_; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void set_hubs_last(bool on) { hubs_last_ = on; }
@@ -202,6 +202,7 @@ class Solver : public LmBackend {
     PairChunk* pchunks_ = nullptr;
     PairBlock* pblocks_ = nullptr;
     PairRec* precs_ = nullptr;
+    PairQDesc* pqdesc_ = nullptr;    // rows_form_ 4 (and d_c = 9): the queued layout's descriptors, else null
     uint8_t *o_slot_ = nullptr, *wg_cam_n_ = nullptr;   // camera staging lists of the landmark-major kernels (BAView::o_slot)
     uint32_t* wg_cam_list_ = nullptr;
     bool cam_staging_ = true;
@@ -212,7 +213,7 @@ class Solver : public LmBackend {
     double* orec_ = nullptr;   // [local observations][4] projection records written by k_landmark_reduce (pair kernel, record form)
     int n_ptasks_ = 0;
     int64_t n_pair_blocks_ = 0, n_pair_slots_ = 0;
-    int rows_form_ = 3;              // 3 (default): sorted pair list reduced over the lanes of a wave (k_schur_pairs_r: every block
+    int rows_form_ = 4;              // 3 (default): sorted pair list reduced over the lanes of a wave (k_schur_pairs_r: every block
                                      // S(ci, cj) stored once by one wave, no atomics, no LDS accumulators); 2: the LDS row form,
                                      // one lane per observation (k_schur_rows2: 6.0 ms against 3.6-3.8 on final-13682), kept
                                      // as the A/B.  Select before set_structure.  (Rounds 1-3 also carried a global-atomics

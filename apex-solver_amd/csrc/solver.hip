@@ -45,7 +45,7 @@ Solver::~Solver() {
     if (free_thread_.joinable()) free_thread_.join();
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, orec_, o_slot_, wg_cam_n_, wg_cam_list_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
+    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, pqdesc_, orec_, o_slot_, wg_cam_n_, wg_cam_list_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_, lam_mask_};
     for (void* p : ptrs)
@@ -305,6 +305,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(up(&pchunks_, pl.chunks));
     HIP_TRY(up(&pblocks_, pl.blocks));
     HIP_TRY(up(&precs_, pl.recs));
+    if (pqdesc_) { hipFree(pqdesc_); pqdesc_ = nullptr; }
+    if (pl.queued) HIP_TRY(up(&pqdesc_, pl.qdesc));
     HIP_TRY(up(&nbr_, nbr));
     {
         std::vector<uint8_t> fp(6 * n_cam_, 0), fi(3 * n_cam_, 0), fl(3 * n_pt_, 0);
@@ -335,7 +337,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(alloc(&dcam_, n_c_pad_));
     HIP_TRY(alloc(&hinv_, (size_t)kLmStride * n_pt_));  // landmark records: Hll^-1 | g_l | point
     // projection records of the local observations (xn, yn, -1/z, sqrt(rho')): the record form of the pair kernel
-    if (rows_form_ == 3 || rec_backsub_) HIP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
+    if (rows_form_ == 3 || rows_form_ == 4 || rec_backsub_) HIP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
     HIP_TRY(alloc(&g_l_, 3 * n_pt_));
     HIP_TRY(alloc(&dl_, 3 * n_pt_));
     HIP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
@@ -496,7 +498,7 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     tp_.add_diag((int)n_c_, 0.0, rank_ == pad_rank_ ? 1.0 : 0.0);
     stage_end(kStAssembleCam);
     stage_begin(kStAssembleLm);
-    const bool rec_form = rows_form_ == 3;   // the pair kernel reads the projection records (allocated with the form: set_structure)
+    const bool rec_form = rows_form_ == 3 || rows_form_ == 4;   // the pair kernel reads the projection records (allocated with the form: set_structure)
     const bool want_rec = rec_form || (rec_backsub_ && orec_ != nullptr);
     launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_, want_rec ? orec_ : nullptr);
     orec_fresh_ = want_rec;
@@ -506,8 +508,8 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
                       g_c_, g_red_, stream_);
     stage_end(kStAssembleCam);
     stage_begin(kStScatter);
-    if (rows_form_ == 3)
-        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, pairs_ablation_, orec_);
+    if (rec_form)
+        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, pairs_ablation_, orec_, pqdesc_);
     else
         launch_schur_rows2(dc_, v, tm, rtasks2_, n_rtasks_, rchunks_, rentries_, nbr_, hinv_, stream_);
     stage_end(kStScatter);

@@ -360,6 +360,11 @@ int apexgpu_debug_host_structure(int64_t n_cam, int64_t n_pt, int64_t n_obs, int
 int apexgpu_debug_pair_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc, const uint32_t* cam_idx, const uint32_t* pt_idx,
                              int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
                              int32_t* tasks2_out, int32_t* o_index_out);
+/* ... and in the QUEUED layout ("schur_form" 4, nine columns per camera; csrc/schur_pairs.h): qdesc3_out[8 * chunks][3] =
+ * {dst, cj, flags} of every (chunk, queue), entry 7 of a chunk carrying the row's camera; chunks2_out[.][0] = flush bits. */
+int apexgpu_debug_pair_lists_queued(int64_t n_cam, int64_t n_pt, int64_t n_obs, const uint32_t* cam_idx, const uint32_t* pt_idx,
+                                    int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
+                                    int32_t* tasks2_out, int32_t* o_index_out, int64_t* qdesc3_out);
 int apexgpu_export_step(apexgpu_solver* h, double* step_out, double* grad_out);
 /* The landmark range [lo,hi) rank `rank` of `world` owns (contiguous, balanced by observation count).
  * Host arithmetic only -- no device is touched -- so schedulers and tests can call it anywhere. */

@@ -40,3 +40,17 @@ def test_pose_graph_line():
     for k in REQUIRED:
         assert k in out, k
     assert out["roofline"]["bound"] == "mfma" and out["scaling"] == "weak" and out["final_cost"] < out["initial_cost"]
+
+
+def test_two_ranks_fall_back_to_shared_memory_when_rccl_refuses():
+    """`--gpus 2` with both ranks on the one GPU of the box (gloo bring-up mode): RCCL refuses the duplicate device, the ranks
+    vote, and the run completes over the shared-memory transport -- the line says which transport carried it."""
+    env = dict(os.environ, APEX_BENCH_PG="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "ladybug-1723", "--scale", "0.25", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-other-variants"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["final_cost"] < out["initial_cost"]
+    assert out["config"]["transport"].startswith("shm (RCCL communicator failed"), out["config"]["transport"]

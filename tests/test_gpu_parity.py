@@ -375,8 +375,9 @@ def test_ragged_landmarks(oracle, mode):
 
 @pytest.mark.parametrize("mode", ["selfcal", "ba"])
 def test_row_and_atomic_schur_forms_agree(mode):
-    """The two implementations of the Schur reduction that are left after round 4 -- the sorted pair list (record form,
-    the default) and the LDS row form with one lane per observation (the A/B) -- build the same S, g_red and gradient, also
+    """The implementations of the Schur reduction that are left after round 4 -- the sorted pair list in its queued layout
+    (4, the default with nine columns per camera: every lane group owns a block), in its first layout (3: seven groups share a
+    block and fold; what six-column cameras use) and the LDS row form with one lane per observation (2, the A/B) -- build the same S, g_red and gradient, also
     on landmarks with more than 64 partners per observation (split entries), more neighbours than one LDS chunk, and camera
     pairs with more common landmarks than one chunk of the pair list.  (The fused pair kernels, the one-lane-per-pair row
     form and the global-atomics form of rounds 1-3 are deleted; their switch values are refused.)"""
@@ -387,7 +388,7 @@ def test_row_and_atomic_schur_forms_agree(mode):
     wide = _custom(150, len(lists), lists)
     for d in (base, wide):
         out = []
-        for rows in (3, 2):
+        for rows in (4, 3, 2):
             ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
             prob = Problem.bundle_adjustment(d, ot, 1.0)
             s = GpuSchurComplementSolver(0).with_option("schur_rows", rows).initialize_structure(prob)
@@ -396,7 +397,7 @@ def test_row_and_atomic_schur_forms_agree(mode):
             S, gred = s.get_schur()
             out.append((S, gred, s.get_gradient(), step))
             s.close()
-        for k in (1,):
+        for k in (1, 2):
             assert rel(out[0][0], out[k][0]) < 1e-13 and rel(out[0][1], out[k][1]) < 1e-12
             assert rel(out[0][2], out[k][2]) < 1e-13
 

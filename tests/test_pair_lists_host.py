@@ -115,3 +115,106 @@ def test_empty_and_single_observation_landmarks():
     assert sum(len(v) for v in flushed.values()) == 1 and len(pl["tasks"]) == 1
     pl0 = capi.pair_lists(4, 7, 6, np.array([2], dtype=np.uint32), np.array([1], dtype=np.uint32))
     assert len(pl0["tasks"]) == 0 and len(pl0["recs"]) == 0
+
+
+# ---- the queued layout ("schur_form" 4): every lane group owns a block of its own ------------------------------------------
+def replay_queued(pl):
+    """What k_schur_pairs_r<.., QL = true> does with the lists, minus the arithmetic: group g of a wave adds the pairs
+    g, g + 7, ..., g + 56 of every chunk of its task and, where the chunk's flush bit g is set, hands what it has gathered
+    to the destination of ITS descriptor of that chunk.  Returns [(dst, cj, flags, [(i, j, l), ...]), ...] per flush."""
+    recs, chunks, tasks, qd = pl["recs"], pl["chunks"], pl["tasks"], pl["qdesc"]
+    out = []
+    seen = np.zeros(len(chunks), dtype=int)
+    for c0, n in tasks:
+        assert 1 <= n <= 64, "a task's chunk descriptors are held one per lane"
+        acc = [[] for _ in range(7)]
+        carry = [None] * 8
+        ci = int(qd[c0, 7, 1])
+        for ch in range(c0, c0 + n):
+            seen[ch] += 1
+            assert int(qd[ch, 7, 1]) == ci, "one row camera per task (1 + 7 cameras staged per chunk)"
+            assert int(recs[64 * ch + 63, 0]) == PAD
+            fm = int(np.uint32(chunks[ch, 0]))
+            for g in range(7):
+                dst, cj, flags = (int(x) for x in qd[ch, g])
+                assert ((flags & 4) != 0) == (((fm >> g) & 1) != 0), "the flush bit of the mask and of the descriptor agree"
+                for t in range(9):
+                    i, j, l, q = (int(x) for x in recs[64 * ch + g + 7 * t])
+                    if i != PAD:
+                        assert q == g
+                        acc[g].append((i, j, l, dst, cj))
+                if (fm >> g) & 1:
+                    assert all(a[3] == dst and a[4] == cj for a in acc[g]), "a queue holds one block between two flushes"
+                    if flags & 8:      # head part of a block cut between queue g - 1 and g: carried to the end of the task
+                        assert g > 0 and carry[g] is None and ch < c0 + n - 1
+                        carry[g] = (dst, cj, acc[g])
+                    else:
+                        pairs = [a[:3] for a in acc[g]]
+                        if flags & 16:     # tail part: joined with the next queue's carried head, stored once
+                            assert ch == c0 + n - 1 and carry[g + 1] is not None and carry[g + 1][:2] == (dst, cj)
+                            pairs += [a[:3] for a in carry[g + 1][2]]
+                            carry[g + 1] = None
+                        out.append((dst, ci, cj, flags & 3, pairs))
+                    acc[g] = []
+        assert all(not a for a in acc), "every queue ends its task flushed"
+        assert all(c is None for c in carry), "every carried head was joined"
+    assert (seen == 1).all()
+    return out
+
+
+def check_queued(d_cam_idx, d_pt_idx, n_cam, n_pt, pl):
+    o_index = pl["o_index"]
+    cpt = NB // 9
+    got = {}
+    per_block = {}
+    for dst, ci, cj, flags, pairs in replay_queued(pl):
+        I, J = ci // cpt, cj // cpt
+        assert dst == (I * (I + 1) // 2 + J) * NB * NB + (ci % cpt) * 9 * NB + (cj % cpt) * 9
+        assert cj <= ci and ((flags & 2) != 0) == (ci == cj)
+        per_block.setdefault((ci, cj), []).append(flags)
+        for i, j, l in pairs:
+            oi, oj = o_index[i], o_index[j]
+            assert d_cam_idx[oi] == ci and d_cam_idx[oj] == cj and d_pt_idx[oi] == l and d_pt_idx[oj] == l
+            key = (min(oi, oj), max(oi, oj))
+            assert key not in got
+            got[key] = (ci, cj)
+    k = np.bincount(d_pt_idx, minlength=n_pt).astype(np.int64)
+    assert len(got) == int((k * (k - 1) // 2).sum())
+    # a block flushed more than once (cut between two queues, or longer than a piece) adds atomically every time
+    for key, fl in per_block.items():
+        if len(fl) > 1:
+            assert all(f & 1 for f in fl), key
+    return per_block
+
+
+@pytest.mark.parametrize("shuffled", [False, True], ids=["grouped", "shuffled"])
+@pytest.mark.parametrize("shape", [(40, 1500, 3, 7), (300, 9000, 2, 9)])
+def test_queued_layout_delivers_every_pair_once(shape, shuffled):
+    n_cam, n_pt, klo, khi = shape
+    d = pkg.synthetic.make_problem(n_cam, n_pt, klo, khi, config_id=400 + n_cam)
+    if shuffled:
+        perm = np.random.default_rng(7).permutation(d.n_obs)
+        d.cam_idx, d.pt_idx, d.obs_uv = d.cam_idx[perm], d.pt_idx[perm], d.obs_uv[perm]
+    pl = capi.pair_lists_queued(d.n_cam, d.n_pt, d.cam_idx, d.pt_idx)
+    per_block = check_queued(d.cam_idx, d.pt_idx, d.n_cam, d.n_pt, pl)
+    # every block of these shapes (none longer than a piece, no camera sees a landmark twice) is stored exactly once with
+    # plain stores -- also the blocks cut between two queues of a task (carried head + tail)
+    assert all(fl == [0] for fl in per_block.values())
+    joins = int(((pl["qdesc"][:, :7, 2] & 16) != 0).sum())
+    assert 0 < joins <= 6 * len(pl["tasks"])
+
+
+def test_queued_layout_hub_block_pieces_and_diagonal():
+    n_cam, n_pt = 12, 20000
+    rng = np.random.default_rng(0)
+    cam_idx, pt_idx = [], []
+    for l in range(n_pt):
+        cams = [3, 7] + ([int(rng.integers(8, 12))] if l % 5 == 0 else [])
+        if l == 17:
+            cams = [5, 5, 9]
+        cam_idx += cams; pt_idx += [l] * len(cams)
+    cam_idx = np.asarray(cam_idx, dtype=np.uint32); pt_idx = np.asarray(pt_idx, dtype=np.uint32)
+    pl = capi.pair_lists_queued(n_cam, n_pt, cam_idx, pt_idx)
+    per_block = check_queued(cam_idx, pt_idx, n_cam, n_pt, pl)
+    assert len(per_block[(7, 3)]) >= (n_pt - 1) // 576 and all(f & 1 for f in per_block[(7, 3)])
+    assert per_block[(5, 5)] and all(f & 2 for f in per_block[(5, 5)])

@@ -35,7 +35,7 @@ def main():
     prob = Problem.bundle_adjustment(d, ot, 1.0)
     ref = None
     x = np.random.default_rng(0).normal(size=prob.layout.cam_dof)
-    runs = [(int(f), int(ts), None) for f in a.forms.split(",") for ts in (a.task_slots.split(",") if int(f) == 3 else ["0"])]
+    runs = [(int(f), int(ts), None) for f in a.forms.split(",") for ts in (a.task_slots.split(",") if int(f) in (3, 4) else ["0"])]
     for form, ts, pv in runs:
         s = GpuSchurComplementSolver(0).with_option("schur_rows", form).with_option("pair_task_slots", ts)
         t = time.time()
@@ -53,7 +53,11 @@ def main():
             st = s.stage_times()
             line = {k: round(v[0] / max(v[1], 1), 3) for k, v in st.items() if v[1] > 0}
             print(f"form {form} variant {pv} task_slots {ts} abl {abl}: {line}", flush=True)
-            if abl == 64:
+            if a.check and abl in (0, 2048):   # (the strip mapping's results are right: held against the default's)
+                y, _ = s.schur_matvec(1e-3, x, implicit=False)
+                if abl == 0: y_abl0 = y
+                else: print(f"   S x with abl {abl} vs abl 0: {np.linalg.norm(y - y_abl0) / np.linalg.norm(y_abl0):.2e}", flush=True)
+            if abl & 64:
                 import ctypes as C
                 out = (C.c_int64 * 8)()
                 pkg.capi.load().apexgpu_debug_pair_phases(C.byref(out), 1)
