@@ -428,8 +428,8 @@ def main():
     # ---- roofline of the graded Schur-reduction kernel, per launch -------------------------------------------------------
     dc = 9 if args.mode == "selfcal" else 6
     form = info.get("schur_form", 3)
-    kernel = {3: "k_schur_pairs_r", 2: "k_schur_rows2"}[form]
-    record_form = form == 3
+    kernel = {4: "k_schur_pairs_r", 3: "k_schur_pairs_r", 2: "k_schur_rows2"}[form]   # (4: the queued layout of the pair list)
+    record_form = form in (3, 4)
     n_obs_local = info["local_obs"]
     tile_bytes = 144 * 144 * 8
     # SURVEY §8(d), fused form (J never stored): each input read once, each output written once.  The record form (the
@@ -453,10 +453,11 @@ def main():
     stage_ms = (stages["landmark_reduce"][0] + stages["cam_reduce"][0] + stages["schur_scatter"][0]) / max(sc_n, 1)
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
-                "pair_list_bytes": pair_list_bytes if form == 3 else 0.0,
+                "pair_list_bytes": pair_list_bytes if record_form else 0.0,
                 "avg_launch_ms": sc_avg, "launches": sc_n,
-                "actual_bound": ("latency at two waves per SIMD (211 VGPRs, 18.4 KB of LDS per wave): no unit saturated -- vector unit 49 %, LDS 70 %, "
-                                 "gathers worth 0.5 ms of 3.7 by ablation (profiles/r04_pairs_ablation.txt; DESIGN.md section 4, round 4)") if record_form else
+                "actual_bound": ("vector-memory path: the gathers of a 64-pair chunk (4 x 64-byte lines per pair, ~2/3 of them L2 misses) take a third of a "
+                                 "wave's time to ISSUE; products and flush are no longer co-critical in the queued layout "
+                                 "(profiles/r04_pairs_queued_*.txt; DESIGN.md section 4, round 4)") if record_form else
                                 "fp64 vector unit + LDS (the fused form moves 2 GB but executes ~60 GFLOP: DESIGN.md section 4)",
                 "projection_record_bytes": 32.0 * n_obs_local if record_form else 0.0,
                 "pair_contributions_per_launch": off_pairs,
