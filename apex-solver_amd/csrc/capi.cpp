@@ -286,7 +286,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "panel_tri") apex::set_panel_tri(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "pairs_ablation") {   /* timing experiments only: the results are WRONG when != 0, so the switch exists only */
-        if (value != 0 && value != 2048 && !getenv("APEX_ALLOW_ABLATION")) return APEXGPU_ERR_INVALID_INPUT;   /* (2048: strip mapping, results right) */   /* for a process that asks for it */
+        if (value != 0 && !getenv("APEX_ALLOW_ABLATION")) return APEXGPU_ERR_INVALID_INPUT;   /* for a process that asks for it */
         h->s->set_pairs_ablation(value);
     }
     else if (n == "pairs_variant") { if (value != 2) return APEXGPU_ERR_INVALID_INPUT; }   /* one pair kernel is left: the record form (2) */

@@ -177,6 +177,12 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
             }
         });
         tr.mark("pairs: records");
+        // A workgroup is four consecutive tasks and lives as long as its longest one (its LDS is released as a whole): within
+        // windows of 32 tasks (~10 rows: the XCD-contiguous dealing keeps its locality) the tasks are sorted by length, so that
+        // the four of a workgroup are alike -- 96 % -> 99 % of the wave slots busy on final-13682.
+        for (size_t a = 0; a < out->tasks.size(); a += 32)
+            std::stable_sort(out->tasks.begin() + a, out->tasks.begin() + std::min(a + 32, out->tasks.size()),
+                             [](const PairTask& x, const PairTask& y) { return x.nchunks > y.nchunks; });
         out->n_pairs = n_pairs;
         out->n_blocks = n_blocks;
         return;
@@ -427,47 +433,6 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
     }
 }
 
-// STRIP mapping of the product phase (d_c = 9, round 4): a lane owns a 3 x 9 ROW STRIP of the running block -- lane = 16 bi + g,
-// strip bi = 0..2 in the first three 16-lane rows, sixteen groups g that split the pairs; the fourth row idles.  Per pair a lane
-// reads U's three rows (6 doubles) and ALL of V (18) for 54 FMA: 0.44 doubles per FMA instead of 0.67, twelve ds_read_b128 per
-// 64-lane step of sixteen pairs instead of six per step of seven -- 48 instead of 60 LDS instructions and 37 instead of 60 KB
-// read per chunk, and the sixteen V rows of a step sit in sixteen different 16-byte bank groups (row pitch 144 B = 9 groups).
-// The fold is a sum over the 16 lanes of a DPP row: four row_shr adds per value, total in lane 15 of each row.
-template <int FABL = 0>
-__device__ __forceinline__ void pairs_flush_strip(double* __restrict__ tiles, const int64_t pb_dst, const uint32_t pb_flags,
-                                                  double acc[27], int lane) {
-    if (!(FABL & 1)) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            double a = acc[k];
-            a = dpp_add_masked<0x118, 0xF, 0xF>(a);
-            a = dpp_add_masked<0x114, 0xF, 0xF>(a);
-            a = dpp_add_masked<0x112, 0xF, 0xF>(a);
-            a = dpp_add_masked<0x111, 0xF, 0xF>(a);
-            acc[k] = a;
-        }
-    }
-    if ((FABL & 2) && acc[0] != 1.2345e300) return;
-    if ((lane & 15) == 15 && lane < 48) {
-        const int bi = lane >> 4;
-        double* dst = tiles + pb_dst;
-        if (pb_flags == 0) {
-            double* d0 = dst + (3 * bi) * kNB;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int bj = 0; bj < 3; ++bj)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) d0[r * kNB + 3 * bj + c] = acc[9 * bj + 3 * r + c];
-        } else {
-#pragma unroll
-            for (int bj = 0; bj < 3; ++bj)
-                pairs_flush_slow<9>(dst, pb_flags, Acc9{acc[9 * bj], acc[9 * bj + 1], acc[9 * bj + 2], acc[9 * bj + 3], acc[9 * bj + 4], acc[9 * bj + 5],
-                                                        acc[9 * bj + 6], acc[9 * bj + 7], acc[9 * bj + 8]}, 3 * bi + bj);
-        }
-    }
-}
-
 // ABL (timing experiments only, results wrong when != 0): 1 no per-pair gathers, 2 no block products, 4 no U / V stores,
 // 8 no flush (fold + store of the finished block) -- NOTE: with the flush gone seven of the nine accumulators are dead and the
 // compiler drops their FMAs, so 8 measures "no flush and 7/9 of the products", not the flush (round 4: 512 / 1024 below do) --,
@@ -493,9 +458,8 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     constexpr int UV = 2 * DC;
     constexpr int NB3 = DC / 3;
     constexpr int GL = NB3 * NB3;
-    constexpr bool STRIP = DC == 9 && (ABL & 2048) != 0;   // a lane owns a 3 x 9 row strip (pairs_flush_strip)
-    constexpr int NG = STRIP ? 16 : (DC == 9) ? 7 : 16;
-    constexpr int NACC = STRIP ? 27 : 9;
+    constexpr int NG = (DC == 9) ? 7 : 16;
+    constexpr int NACC = 9;
     constexpr int WAVE_LDS = 2 * 64 * UV + UV;   // U[64][UV] | V[64][UV] | zeros[UV]
     __shared__ double lds_all[4 * WAVE_LDS];
     // The chunk's <= 8 cameras are staged through REGISTERS (one 16-byte load per lane a chunk ahead, one ds_write at the top
@@ -522,10 +486,9 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     if (lane < UV) Z[lane] = 0.0;
     int g, sub;
     pairs_lane_map<DC, (ABL & 256) != 0>(lane, g, sub);
-    if (STRIP) { g = lane & 15; sub = 3 * (lane >> 4); }
     if (QL) { g = lane == 63 ? 0 : lane / 9; sub = lane == 63 ? 0 : lane - 9 * g; }   // (lane 63 shadows lane 0 and never stores)
     const int bi = sub / NB3, bj = sub - bi * NB3;
-    const bool worker = STRIP ? lane < 48 : g < NG;
+    const bool worker = g < NG;
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
@@ -880,8 +843,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         };
         auto flush = [&]() {
             const unsigned long long f0 = stamp();
-            if constexpr (STRIP) pairs_flush_strip<(ABL >> 9) & 3>(tiles, cur_dst, cur_flags, acc, lane);
-            else if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0, (ABL >> 9) & 3>(tiles, cur_dst, cur_flags, acc, lane);
+            if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0, (ABL >> 9) & 3>(tiles, cur_dst, cur_flags, acc, lane);
             else if (acc[0] == 1.2345e300) tiles[0] = acc[1];
             if (ABL & 64) { ph[6] += stamp() - f0; ph[7] += 1; }
         };
@@ -896,37 +858,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         mask &= ~1u;
         for (;;) {
             const int seg1 = mask ? 2 * (__ffs(mask) - 1) : 64;      // wave-uniform
-            if constexpr (STRIP && !(ABL & 2)) {
-                // strip mapping: sixteen pairs per step; U's three rows and all of V per lane, ping-pong operand registers
-                int p = seg0 + g;
-                struct Ops { double2 u0, u1, u2, v[9]; };
-                auto ld = [&](int pp, Ops& o) {
-                    const bool ok = worker && pp < seg1;
-                    const double2* qu = reinterpret_cast<const double2*>(ok ? U + pp * UV + bi * 6 : Z);
-                    const double2* qv = reinterpret_cast<const double2*>(ok ? V + pp * UV : Z);
-                    o.u0 = qu[0]; o.u1 = qu[1]; o.u2 = qu[2];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) o.v[k] = qv[k];
-                };
-                auto mac = [&](const Ops& o) {
-                    const double um0[3] = {o.u0.x, o.u0.y, o.u1.x}, um1[3] = {o.u1.y, o.u2.x, o.u2.y};
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) {
-                        const double2 v0 = o.v[3 * b], v1 = o.v[3 * b + 1], v2 = o.v[3 * b + 2];
-                        const double vm0[3] = {v0.x, v0.y, v1.x}, vm1[3] = {v1.y, v2.x, v2.y};
-#pragma unroll
-                        for (int r = 0; r < 3; ++r)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) acc[9 * b + 3 * r + c] = fma(um1[r], vm1[c], fma(um0[r], vm0[c], acc[9 * b + 3 * r + c]));
-                    }
-                };
-                // (one operand set: a second one for ping-pong, 48 more VGPRs, spills 61 registers at the 256-register limit)
-                Ops a;
-                for (int it = seg0; it < seg1; it += NG, p += NG) {
-                    ld(p, a);
-                    mac(a);
-                }
-            } else if (!(ABL & 2)) {
+            if (!(ABL & 2)) {
                 // One pair per step and lane, ping-pong operand registers: the six reads of the NEXT pair are in flight while
                 // the 18 FMA of this one run.  Uniform control flow; a lane whose pair lies beyond the segment (and the idle
                 // lane) reads the zero row.
@@ -980,8 +912,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     }
     if constexpr (QL) store_pending();
     if (!QL && cur >= 0) {
-        if constexpr (STRIP) pairs_flush_strip<0>(tiles, cur_dst, cur_flags, acc, lane);
-        else if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0>(tiles, cur_dst, cur_flags, acc, lane);
+        if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0>(tiles, cur_dst, cur_flags, acc, lane);
         else if (acc[0] == 1.2345e300) tiles[0] = acc[1];
     }
 }
@@ -1014,7 +945,7 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
     }
     if (ablation != 0 && dc == 9) {   // timing experiments (SelfCalibration only)
 #define PAIRS_RA(A) case A: hipLaunchKernelGGL((k_schur_pairs_r<9, false, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, nullptr); return
-        switch (ablation) { PAIRS_RA(2048); PAIRS_RA(2048 + 64); PAIRS_RA(2048 + 512); PAIRS_RA(2048 + 1024); PAIRS_RA(2048 + 2); PAIRS_RA(512); PAIRS_RA(1024); PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3);
+        switch (ablation) { PAIRS_RA(512); PAIRS_RA(1024); PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3);
             default: break;   // an unlisted value: the plain kernel below, never a missing launch
         }
 #undef PAIRS_RA

@@ -53,10 +53,6 @@ def main():
             st = s.stage_times()
             line = {k: round(v[0] / max(v[1], 1), 3) for k, v in st.items() if v[1] > 0}
             print(f"form {form} variant {pv} task_slots {ts} abl {abl}: {line}", flush=True)
-            if a.check and abl in (0, 2048):   # (the strip mapping's results are right: held against the default's)
-                y, _ = s.schur_matvec(1e-3, x, implicit=False)
-                if abl == 0: y_abl0 = y
-                else: print(f"   S x with abl {abl} vs abl 0: {np.linalg.norm(y - y_abl0) / np.linalg.norm(y_abl0):.2e}", flush=True)
             if abl & 64:
                 import ctypes as C
                 out = (C.c_int64 * 8)()
