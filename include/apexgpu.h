@@ -214,7 +214,12 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  * Switches that shape what apexgpu_set_structure builds or what the captured hipGraphs hold ("schur_rows",
  * "potrf_lookahead", "update_overlap", "split_u1", "fused_forward", "nested_dissection", "dist_factor", "tree_sharding",
  * "dist_selftest") return APEXGPU_ERR_INVALID_STATE once the structure is set.
- *   "schur_rows" (3)  form of the Schur reduction (alias "schur_form"); set before set_structure:
+ *   "schur_rows" (4)  form of the Schur reduction (alias "schur_form"); set before set_structure:
+ *                     4 = the pair list of form 3 in the QUEUED layout (round 4; nine columns per camera, six-column
+ *                     cameras get form 3's lists): a task is the blocks of one row padded to nonets of nine slots and cut
+ *                     into seven queues, every lane group of the product phase owns a block of its own -- nine fixed
+ *                     steps per chunk, no fold over the groups, a block cut between two queues carried in registers and
+ *                     stored once (k_schur_pairs_r<.., QL>, csrc/schur_pairs.h);
  *                     3 = every camera pair of a landmark in a list sorted by the block S(ci, cj) it adds to, one pair per
  *                     lane as a rank-2 update U V parked in LDS (J rebuilt from the projection records k_landmark_reduce
  *                     writes), the block sums taken over the lanes as 3 x 3 sub-block products on the vector unit, every

@@ -5,7 +5,8 @@
 #include <vector>
 using namespace apex;
 int main(int argc, char** argv) {
-    const int n_tiles = 1500, n_tasks = argc > 1 ? atoi(argv[1]) : 4096;
+    // third = tiles per operand class (default 500: 250 MB in all, inside the 256 MB Infinity Cache; 4000 = 2 GB streams from HBM)
+    const int third = argc > 2 ? atoi(argv[2]) : 500, n_tiles = 3 * third, n_tasks = argc > 1 ? atoi(argv[1]) : 4096;
     const size_t te = (size_t)kNB * kNB;
     double* tiles; hipMalloc(&tiles, n_tiles * te * 8);
     std::vector<double> h(n_tiles * te);
@@ -14,10 +15,10 @@ int main(int argc, char** argv) {
     for (int mode = 0; mode < 4; ++mode) {   // 0: scattered operands, 1: column-like sharing (9 operand tiles per 45 tasks)
         std::vector<GemmTask> t(n_tasks);
         for (int i = 0; i < n_tasks; ++i) {
-            if (mode == 0) t[i] = {tiles + (size_t)(i % 500) * te, tiles + (size_t)(500 + (i * 7) % 500) * te, tiles + (size_t)(1000 + (i * 13) % 500) * te};
-            else if (mode == 2) t[i] = {tiles + (size_t)(i % 8) * te, tiles + (size_t)(500 + i % 4) * te, tiles + (size_t)(1000 + i % 4) * te};  // cache-resident
-            else if (mode == 3) t[i] = {tiles + (size_t)(i % 500) * te, tiles + (size_t)(500 + i % 4) * te, tiles + (size_t)(1000 + i % 4) * te};  // only C streams
-            else { int col = i / 45, r = i % 45, a = r % 9, b = r / 5; t[i] = {tiles + (size_t)(i % 500) * te, tiles + (size_t)(500 + (col * 9 + a) % 500) * te, tiles + (size_t)(500 + (col * 9 + b) % 500) * te}; }
+            if (mode == 0) t[i] = {tiles + (size_t)(i % third) * te, tiles + (size_t)(third + (i * 7) % third) * te, tiles + (size_t)(2 * third + (i * 13) % third) * te};
+            else if (mode == 2) t[i] = {tiles + (size_t)(i % 8) * te, tiles + (size_t)(third + i % 4) * te, tiles + (size_t)(2 * third + i % 4) * te};  // cache-resident
+            else if (mode == 3) t[i] = {tiles + (size_t)(i % third) * te, tiles + (size_t)(third + i % 4) * te, tiles + (size_t)(2 * third + i % 4) * te};  // only C streams
+            else { int col = i / 45, r = i % 45, a = r % 9, b = r / 5; t[i] = {tiles + (size_t)(i % third) * te, tiles + (size_t)(third + (col * 9 + a) % third) * te, tiles + (size_t)(third + (col * 9 + b) % third) * te}; }
         }
         GemmTask* d; hipMalloc(&d, n_tasks * sizeof(GemmTask)); hipMemcpy(d, t.data(), n_tasks * sizeof(GemmTask), hipMemcpyHostToDevice);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
