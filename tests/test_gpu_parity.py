@@ -386,7 +386,12 @@ def test_row_and_atomic_schur_forms_agree(mode):
     lists = [sorted(rng.choice(150, size=int(k), replace=False).tolist()) for k in rng.integers(2, 9, size=500)]
     lists += [list(range(150)), list(range(0, 150, 2)), list(range(140))]       # 150 / 75 / 140 observations
     wide = _custom(150, len(lists), lists)
-    for d in (base, wide):
+    # two cameras that share 2,600 landmarks (a block of more than four 576-pair pieces in the queued layout: atomic adds),
+    # with a third camera on a quarter of them, a camera that sees a landmark twice, and rows of one or two pairs
+    heavy_lists = [[3, 7] + ([int(rng.integers(8, 20))] if l % 4 == 0 else []) for l in range(2600)]
+    heavy_lists += [[5, 5, 9], [0, 1], [1, 2, 19]]
+    heavy = _custom(20, len(heavy_lists), heavy_lists, seed=8)
+    for d in (base, wide, heavy):
         out = []
         for rows in (4, 3, 2):
             ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment

@@ -218,3 +218,37 @@ def test_queued_layout_hub_block_pieces_and_diagonal():
     per_block = check_queued(cam_idx, pt_idx, n_cam, n_pt, pl)
     assert len(per_block[(7, 3)]) >= (n_pt - 1) // 576 and all(f & 1 for f in per_block[(7, 3)])
     assert per_block[(5, 5)] and all(f & 2 for f in per_block[(5, 5)])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_queued_layout_on_random_structures(seed):
+    """Random co-visibility: a few cameras that share hundreds to thousands of landmarks (blocks longer than a piece, rows of
+    several tasks, queues cut inside blocks), many that share a handful (tasks of a single chunk, empty queues), a camera that
+    sees some landmarks twice.  Every pair must arrive once, carried heads must be joined, pieces must add atomically."""
+    rng = np.random.default_rng(1000 + seed)
+    n_cam = int(rng.integers(4, 40))
+    n_pt = int(rng.integers(30, 4000))
+    popular = rng.choice(n_cam, size=min(n_cam, int(rng.integers(2, 5))), replace=False)
+    cam_idx, pt_idx = [], []
+    for l in range(n_pt):
+        cams = set(int(c) for c in popular if rng.random() < 0.8)
+        for _ in range(int(rng.integers(0, 4))):
+            cams.add(int(rng.integers(0, n_cam)))
+        cams = sorted(cams)
+        if len(cams) < 2:
+            cams = sorted({int(popular[0]), int((popular[0] + 1) % n_cam)})
+        if rng.random() < 0.01:
+            cams.append(cams[0])           # one camera sees the landmark twice: a pair on the diagonal block
+        cam_idx += cams; pt_idx += [l] * len(cams)
+    cam_idx = np.asarray(cam_idx, dtype=np.uint32); pt_idx = np.asarray(pt_idx, dtype=np.uint32)
+    perm = rng.permutation(len(cam_idx))
+    cam_idx, pt_idx = cam_idx[perm], pt_idx[perm]
+    pl = capi.pair_lists_queued(n_cam, n_pt, cam_idx, pt_idx)
+    per_block = check_queued(cam_idx, pt_idx, n_cam, n_pt, pl)
+    assert per_block
+    # and the first layout delivers the same pairs to the same blocks
+    pl3 = capi.pair_lists(n_cam, n_pt, 9, cam_idx, pt_idx)
+    flushed = replay(pl3, cam_idx, 9)
+    n3 = sum(len(v) for v in flushed.values())
+    k = np.bincount(pt_idx, minlength=n_pt).astype(np.int64)
+    assert n3 == int((k * (k - 1) // 2).sum())
