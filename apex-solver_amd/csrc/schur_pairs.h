@@ -6,11 +6,13 @@
 //     -W_i Hll^-1 W_j^T = (Jc_i^T M_ij) Jc_j = U_ij V_j ,   U (d_c x 2), V (2 x d_c),
 // so a block S(ci, cj) is the product of a d_c x 2P and a 2P x d_c matrix, P = pairs of the block: a tiny GEMM whose K
 // dimension runs over the pairs.  All pairs of the problem are sorted by block once per structure; a wave takes 64
-// consecutive pair slots, computes U and V of every pair (both observations re-linearised from the 24-byte records: one
-// observation per lane, two lanes per pair, 32 pairs per step -- k_schur_pairs_h, the default; or one pair per lane --
-// k_schur_pairs) and parks them in LDS; then lane (g, bi, bj) owns the 3 x 3 sub-block (bi, bj) of the running block and adds the pairs
-// g, g + NG, ... of the segment (18 FMA per pair), the NG groups are folded with shuffles at a block boundary.  A block
-// is owned by one wave and stored ONCE with plain stores: no atomics, no LDS accumulators, no neighbour chunking.
+// consecutive pair slots, one pair per lane, rebuilds both Jacobians from the 32-byte projection records k_landmark_reduce
+// writes and the staged cameras, and parks U and V in LDS; then the lanes turn into block owners: lane (g, bi, bj) keeps the
+// 3 x 3 sub-block (bi, bj) of a block and adds 18 FMA per pair.  Two layouts of the list decide WHICH block:
+//   form 3  the lane groups split the pairs of ONE running block (g, g + NG, ...) and are folded at a block boundary;
+//   form 4  (round 4, default for nine-column cameras) every lane group owns a block of its own -- see PairQDesc below.
+// A block is owned by one wave and stored ONCE with plain stores: no atomics, no LDS accumulators, no neighbour chunking
+// (blocks longer than a piece and pairs on the diagonal of S add atomically).
 // (v_mfma_f64_16x16x4_f64 was the first design: it occupies the fp64 datapath for 64 cycles whatever the tile holds,
 // a 9 x 9 block fills 32 % of it, and it cannot overlap the linearisation's vector work: DESIGN.md section 4.)
 #pragma once
