@@ -177,12 +177,9 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
             }
         });
         tr.mark("pairs: records");
-        // A workgroup is four consecutive tasks and lives as long as its longest one (its LDS is released as a whole): within
-        // windows of 32 tasks (~10 rows: the XCD-contiguous dealing keeps its locality) the tasks are sorted by length, so that
-        // the four of a workgroup are alike -- 96 % -> 99 % of the wave slots busy on final-13682.
-        for (size_t a = 0; a < out->tasks.size(); a += 32)
-            std::stable_sort(out->tasks.begin() + a, out->tasks.begin() + std::min(a + 32, out->tasks.size()),
-                             [](const PairTask& x, const PairTask& y) { return x.nchunks > y.nchunks; });
+        // (A workgroup is four consecutive tasks and lives as long as its longest one; sorting the tasks by length inside
+        // windows of 8 / 32 evens the four out -- 96 % -> 99 % of the wave slots busy -- and LOSES 0.07 / 0.1 ms: consecutive
+        // tasks are the same row, and four waves of a CU on one row share its landmark lines in the L1.  Row order kept.)
         out->n_pairs = n_pairs;
         out->n_blocks = n_blocks;
         return;
