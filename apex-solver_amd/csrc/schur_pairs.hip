@@ -436,7 +436,9 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
 // 512 no fold over the groups, 1024 no stores of the finished block, 16 no camera reads, 32 no Jacobian arithmetic; 64 (results RIGHT): phase
 // stamps -- every wave adds the shader cycles it spent in each phase of its chunks to g_pair_phase (read with
 // pairs_phase_cycles): 0 wait for the gathers, 1 unstage, 2 cameras + both Jacobians + U / V stores, 3 issue, 4 products and
-// flushes, 5 chunks, 6 flushes alone, 7 number of flushes
+// flushes, 5 chunks, 6 flushes alone, 7 number of flushes.  Queued layout only: 4096 no transposition of the finished block
+// through LDS (its elements land in the wrong places), 8192 the landmark record's second line is not fetched; 1024 together
+// with 4096 leaves the accumulators without a use and removes the PRODUCT PHASE as well (it does not measure the stores).
 //
 // Nothing in the loop goes through the scalar memory path: s_load shares the lgkm counter with the LDS and returns out of
 // order, so one descriptor load in flight turns every LDS wait of the product loop into a wait for memory (the first
