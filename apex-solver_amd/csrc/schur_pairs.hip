@@ -437,7 +437,9 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
 // stamps -- every wave adds the shader cycles it spent in each phase of its chunks to g_pair_phase (read with
 // pairs_phase_cycles): 0 wait for the gathers, 1 unstage, 2 cameras + both Jacobians + U / V stores, 3 issue, 4 products and
 // flushes, 5 chunks, 6 flushes alone, 7 number of flushes.  Queued layout only: 4096 no transposition of the finished block
-// through LDS (its elements land in the wrong places), 8192 the landmark record's second line is not fetched; 1024 together
+// through LDS (its elements land in the wrong places), 8192 the landmark record's second line is not fetched, 16384 the
+// gathered pieces are used where they landed (no un-staging through LDS: 3.05 -> 2.85 ms, the bound of what a register
+// transpose could gain; without the camera reads, 16: 2.93); 1024 together
 // with 4096 leaves the accumulators without a use and removes the PRODUCT PHASE as well (it does not measure the stores).
 //
 // Nothing in the loop goes through the scalar memory path: s_load shares the lgkm counter with the LDS and returns out of
@@ -648,7 +650,10 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         __builtin_amdgcn_wave_barrier();
         const unsigned long long t1 = stamp();
         Gather dat;
-        unstage(coop, dat);
+        if (ABL & 16384) {   // (timing only: the gathered pieces are used where they landed, no trip through LDS)
+            dat.lm[0] = coop.a0; dat.lm[1] = coop.a1; dat.lm[2] = coop.a2; dat.lm[3] = coop.a3; dat.lm[4] = coop.b0; dat.lm[5] = coop.b1;
+            dat.ri0 = coop.i0; dat.ri1 = coop.i1; dat.rj0 = coop.j0; dat.rj1 = coop.j1;
+        } else unstage(coop, dat);
         if (ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long t2 = stamp();
         double cvi[16], cvj[16];
@@ -935,6 +940,9 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
         else if (ablation == 1024) PAIRS_Q(false, 1024);
         else if (ablation == 4096) PAIRS_Q(false, 4096);
         else if (ablation == 8192) PAIRS_Q(false, 8192);
+        else if (ablation == 16384) PAIRS_Q(false, 16384);
+        else if (ablation == 16) PAIRS_Q(false, 16);
+        else if (ablation == 16384 + 16) PAIRS_Q(false, 16384 + 16);
         else if (ablation == 64 + 1024) PAIRS_Q(false, 64 + 1024);
         else if (ablation == 64 + 4096) PAIRS_Q(false, 64 + 4096);
         else if (ablation == 64 + 5120) PAIRS_Q(false, 64 + 5120);
