@@ -600,6 +600,36 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         o.ri0 = me[6]; o.ri1 = me[7]; o.rj0 = me[8]; o.rj1 = me[9];
         __builtin_amdgcn_wave_barrier();   // (the LDS executes a wave's operations in order: the U / V stores below come after these reads)
     };
+    // The same redistribution in registers (round 4, second half): the pieces form a 4 x 4 matrix per quad (lane q holds quarter q
+    // of the quad's pair k in a_k) and 2 x 2 matrices per lane pair (half h of pair k in b_k / i_k / j_k); a lane wants the
+    // row of its own pair.  A butterfly transpose -- exchange with the lane one away, then two away, each a DPP quad_perm
+    // move folded into a select -- instead of ten LDS writes, ten LDS reads and their round trip.
+    auto unstage_dpp = [&](const Coop& d, Gather& o) {
+        const bool odd = (lane & 1) != 0, hi2 = (lane & 2) != 0;
+        constexpr int X1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);   // quad_perm:[1,0,3,2]
+        constexpr int X2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);   // quad_perm:[2,3,0,1]
+        auto xch = [&](const bool take, const double2 own, const double2 other, auto ctrl) -> double2 {   // take ? other[partner lane] : own
+            constexpr int C = decltype(ctrl)::value;
+            const double v[2] = {other.x, other.y};
+            double r[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v[k]), C, 0xf, 0xf, true);
+                const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v[k]), C, 0xf, 0xf, true);
+                r[k] = __hiloint2double(hi, lo);
+            }
+            return make_double2(take ? r[0] : own.x, take ? r[1] : own.y);
+        };
+        const std::integral_constant<int, X1> c1{};
+        const std::integral_constant<int, X2> c2{};
+        const double2 b0 = xch(odd, d.a0, d.a1, c1), b1 = xch(!odd, d.a1, d.a0, c1);
+        const double2 b2 = xch(odd, d.a2, d.a3, c1), b3 = xch(!odd, d.a3, d.a2, c1);
+        o.lm[0] = xch(hi2, b0, b2, c2); o.lm[2] = xch(!hi2, b2, b0, c2);
+        o.lm[1] = xch(hi2, b1, b3, c2); o.lm[3] = xch(!hi2, b3, b1, c2);
+        o.lm[4] = xch(odd, d.b0, d.b1, c1); o.lm[5] = xch(!odd, d.b1, d.b0, c1);
+        o.ri0 = xch(odd, d.i0, d.i1, c1); o.ri1 = xch(!odd, d.i1, d.i0, c1);
+        o.rj0 = xch(odd, d.j0, d.j1, c1); o.rj1 = xch(!odd, d.j1, d.j0, c1);
+    };
     // block descriptors of a chunk: lane b < nblk holds block first_block + b (destination offset, flags)
     struct BlockDesc { int2 dst; uint32_t flags; };
     auto load_blocks = [&](const PairChunk c, BlockDesc& b, int qrel) {
@@ -638,6 +668,14 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     uint4 rr_next = rec4[(size_t)(chunk0 + min(1, nchunks - 1)) * 64 + lane];
     uint32_t cam_next = chunk_cam(ck_next, min(1, nchunks - 1));
 
+    // queued layout: the row's camera is the same for every pair of the task -- it stays in registers (the same address in
+    // every lane: one request per load), and only the seven partners are read from the staged copy chunk by chunk
+    double cvi_task[QL ? 16 : 1];
+    if constexpr (QL) {
+        const double2* pc = reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)qdesc[8 * (size_t)chunk0 + 7].cj);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const double2 a = pc[k]; cvi_task[2 * k] = a.x; cvi_task[2 * k + 1] = a.y; }
+    }
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto stamp = [&]() -> unsigned long long { return (ABL & 64) ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull; };
     for (; q < nchunks; ++q) {
@@ -653,7 +691,8 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         if (ABL & 16384) {   // (timing only: the gathered pieces are used where they landed, no trip through LDS)
             dat.lm[0] = coop.a0; dat.lm[1] = coop.a1; dat.lm[2] = coop.a2; dat.lm[3] = coop.a3; dat.lm[4] = coop.b0; dat.lm[5] = coop.b1;
             dat.ri0 = coop.i0; dat.ri1 = coop.i1; dat.rj0 = coop.j0; dat.rj1 = coop.j1;
-        } else unstage(coop, dat);
+        } else if (!(ABL & 32768)) unstage_dpp(coop, dat);   // (32768: the trip through LDS, for the A/B)
+        else unstage(coop, dat);
         if (ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long t2 = stamp();
         double cvi[16], cvj[16];
@@ -661,9 +700,15 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
 #pragma unroll
             for (int k = 0; k < 16; ++k) { cvi[k] = dat.lm[k % 6].x + k; cvj[k] = dat.lm[k % 6].y - k; }
         } else {
-            if (dma) {
-                const double2* ci = reinterpret_cast<const double2*>(CAMS + (QL ? 0 : 2 * blk) * kCamStride);
-                const double2* cj = reinterpret_cast<const double2*>(CAMS + (QL ? 1 + blk : 2 * blk + 1) * kCamStride);
+            if (QL) {
+                const double2* cj = reinterpret_cast<const double2*>(CAMS + (1 + blk) * kCamStride);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const double2 b = cj[k]; cvj[2 * k] = b.x; cvj[2 * k + 1] = b.y; }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) cvi[k] = cvi_task[QL ? k : 0];
+            } else if (dma) {
+                const double2* ci = reinterpret_cast<const double2*>(CAMS + (2 * blk) * kCamStride);
+                const double2* cj = reinterpret_cast<const double2*>(CAMS + (2 * blk + 1) * kCamStride);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 a = ci[k], b = cj[k]; cvi[2 * k] = a.x; cvi[2 * k + 1] = a.y; cvj[2 * k] = b.x; cvj[2 * k + 1] = b.y; }
             } else {   // a chunk of many tiny blocks: the cameras come straight from memory
@@ -941,6 +986,7 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
         else if (ablation == 4096) PAIRS_Q(false, 4096);
         else if (ablation == 8192) PAIRS_Q(false, 8192);
         else if (ablation == 16384) PAIRS_Q(false, 16384);
+        else if (ablation == 32768) PAIRS_Q(false, 32768);
         else if (ablation == 16) PAIRS_Q(false, 16);
         else if (ablation == 16384 + 16) PAIRS_Q(false, 16384 + 16);
         else if (ablation == 64 + 1024) PAIRS_Q(false, 64 + 1024);
@@ -953,7 +999,7 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
     }
     if (ablation != 0 && dc == 9) {   // timing experiments (SelfCalibration only)
 #define PAIRS_RA(A) case A: hipLaunchKernelGGL((k_schur_pairs_r<9, false, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, nullptr); return
-        switch (ablation) { PAIRS_RA(512); PAIRS_RA(1024); PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3);
+        switch (ablation) { PAIRS_RA(32768); PAIRS_RA(512); PAIRS_RA(1024); PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3);
             default: break;   // an unlisted value: the plain kernel below, never a missing launch
         }
 #undef PAIRS_RA
