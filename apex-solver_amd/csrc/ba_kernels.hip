@@ -293,10 +293,7 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
 #pragma unroll
         for (int i = 0; i < 3; ++i) gl[i] += __shfl_xor(gl[i], m, kLmLanes);
     }
-    if (active) {
-        // Every lane of the landmark holds the folded sums (butterfly above) and inverts the block itself: the 128-byte record
-        // then leaves as four adjacent 32-byte pieces, one per lane (two 16-byte stores each: 2 line writes per landmark and
-        // instruction), instead of fifteen 8-byte stores by lane 0 (16 scattered lines per instruction, fifteen times).
+    if (active && g == 0) {
         // With Jacobi scaling the reference inverts the block of the SCALED system, D Hll D + lambda I (eigenvalue
         // gate included); D (.)^-1 D is then the inverse of Hll + lambda D^-2 that the unscaled kernels need.
         double sc[3] = {1.0, 1.0, 1.0};
@@ -306,7 +303,7 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
                        sc[2] * sc[0] * h[3], sc[2] * sc[1] * h[4], sc[2] * sc[2] * h[5] + lambda};
         double Bi[9];
         if (!invert_landmark_block(B, Bi)) {
-            if (g == 0) atomicExch(err_flag, 1);
+            atomicExch(err_flag, 1);
 #pragma unroll
             for (int i = 0; i < 9; ++i) Bi[i] = 0.0;
         }
@@ -316,20 +313,15 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
 #pragma unroll
                 for (int b = 0; b < 3; ++b) Bi[3 * a + b] *= sc[a] * sc[b];
         }
-        static_assert(kLmLanes == 4 && kLmStride == 16 && kLmPt == 9 && kLmG == 12, "the record is written as four 32-byte quarters");
-        const double rec[16] = {Bi[0], Bi[1], Bi[2], Bi[3], Bi[4], Bi[5], Bi[6], Bi[7], Bi[8], pw[0], pw[1], pw[2], gl[0], gl[1], gl[2], 0.0};
-        double q4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) q4[k] = g == 0 ? rec[k] : g == 1 ? rec[4 + k] : g == 2 ? rec[8 + k] : rec[12 + k];
-        double2* out = reinterpret_cast<double2*>(hinv + kLmStride * l + 4 * g);
-        out[0] = make_double2(q4[0], q4[1]); out[1] = make_double2(q4[2], q4[3]);
-        if (g == 0) {
+        for (int i = 0; i < 9; ++i) hinv[kLmStride * l + i] = Bi[i];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) g_l[3 * l + i] = gl[i];
-            if (lmu) {  // matrix-free variant: the point travels with u_l in a 64-byte record
+        for (int i = 0; i < 3; ++i) { hinv[kLmStride * l + kLmG + i] = gl[i]; hinv[kLmStride * l + kLmPt + i] = pw[i]; }
 #pragma unroll
-                for (int i = 0; i < 3; ++i) lmu[kLmuStride * l + i] = pw[i];
-            }
+        for (int i = 0; i < 3; ++i) g_l[3 * l + i] = gl[i];
+        if (lmu) {  // matrix-free variant: the point travels with u_l in a 64-byte record
+#pragma unroll
+            for (int i = 0; i < 3; ++i) lmu[kLmuStride * l + i] = pw[i];
         }
     }
 }
