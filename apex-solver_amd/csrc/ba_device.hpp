@@ -217,8 +217,11 @@ APEX_HD bool residual_obs(const Cam& c, const double pw[3], double u_obs, double
 // Jc is 2 x DC (row-major [row][col]), Jl is 2 x 3; both CORRECTED (scaled by sqrt(rho')).
 // MASKED = false: every block the factor has columns for is optimised (SelfCalibration; BundleAdjustment at DC = 6) -- the
 // column masks are all ones and are not read (the register-critical kernels instantiate this form for those modes).
-// rec4 (optional): the observation's PROJECTION RECORD (xn, yn, -1/z, sqrt(rho')) -- everything the Jacobian needs besides
-// the camera (R, f, k1, k2) and the point; the record form of the Schur pair kernel (schur_pairs.hip, jac_from_rec)
+// rec4 (optional): the observation's PROJECTION RECORD (xn, yn, p_w.z, sqrt(rho')) -- with -1/z, which jac_from_rec rebuilds
+// bit for bit from the point and the camera by this function's own operations, everything the Jacobian needs besides
+// the camera (R, t, f, k1, k2) and the point.  (Rounds 3-4a stored -1/z in slot 2; the point's third component rides there
+// now so that the pair kernel finds what it needs of a landmark -- six entries of Hll^-1 and p_w.x, p_w.y -- in ONE 64-byte line.)
+// the the record form of the Schur pair kernel (schur_pairs.hip, jac_from_rec)
 // rebuilds J from it instead of re-linearising the observation once per pair.  A point behind the camera: weight 0.
 template <int DC, bool MASKED = true>
 APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, double v_obs,
@@ -227,7 +230,7 @@ APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, doubl
     double pc[3];
     cam_transform(c, pw, pc);
     if (!(pc[2] < -kMinDepth)) {
-        if (rec4) { rec4[0] = 0.0; rec4[1] = 0.0; rec4[2] = 1.0; rec4[3] = 0.0; }
+        if (rec4) { rec4[0] = 0.0; rec4[1] = 0.0; rec4[2] = pw[2]; rec4[3] = 0.0; }
         r[0] = 0.0; r[1] = 0.0;
 #pragma unroll
         for (int a = 0; a < DC; ++a) { Jc[0][a] = 0.0; Jc[1][a] = 0.0; }
@@ -259,7 +262,7 @@ APEX_HD bool linearize_obs(const Cam& c, const double pw[3], double u_obs, doubl
     Jp[1][2] = f * fma(dyd_dxn, dxn_dz, dyd_dyn * dyn_dz);
     const double* R = c.R;
     double w = huber_sqrt_rho1(huber_delta, fma(r0, r0, r1 * r1));
-    if (rec4) { rec4[0] = xn; rec4[1] = yn; rec4[2] = inz; rec4[3] = w; }
+    if (rec4) { rec4[0] = xn; rec4[1] = yn; rec4[2] = pw[2]; rec4[3] = w; }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         // landmark block = Jp R ; pose block = [Jp R | -(Jp R)[p_w]x]  (bal_pinhole.rs:528-556:
@@ -294,9 +297,17 @@ struct RecJac {          // what one observation contributes to a pair: a (= Jl)
     double xw, yw;        // xn w, yn w
     double t[3];          // dist, f r2, f r4
 };
-// cv: the staged camera (R row-major at 0..8, f k1 k2 at 12..14)
-__device__ __forceinline__ void jac_from_rec(const double* __restrict__ cv, const double2 r01, const double2 r23, RecJac& o) {
-    const double xn = r01.x, yn = r01.y, inz = r23.x, w = r23.y;
+// cv: the staged camera (R row-major at 0..8, t at 9..11, f k1 k2 at 12..14); pw: the landmark (pw[2] == r23.x).
+// -1/z is linearize_obs' own: the third row of cam_transform, then -apex_rcp -- same operations, same operands, same bits.  A
+// point behind the camera has weight 0 in its record and any finite -1/z gives the zero Jacobian.
+APEX_HD double rec_inz(const double* __restrict__ cv, const double pw[3], double w) {
+    APEX_FP_EXACT
+    const double pc2 = fma(cv[6], pw[0], fma(cv[7], pw[1], fma(cv[8], pw[2], cv[11])));
+    return w == 0.0 ? 1.0 : -apex_rcp(pc2);
+}
+__device__ __forceinline__ void jac_from_rec(const double* __restrict__ cv, const double2 r01, const double2 r23, const double pw[3], RecJac& o) {
+    const double xn = r01.x, yn = r01.y, w = r23.y;
+    const double inz = rec_inz(cv, pw, w);
     const double f = cv[12], k1 = cv[13], k2 = cv[14];
     const double r2 = fma(yn, yn, xn * xn), r4 = r2 * r2;
     const double dist = fma(k2, r4, fma(k1, r2, 1.0));

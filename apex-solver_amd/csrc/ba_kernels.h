@@ -46,8 +46,11 @@ constexpr int kCamStageCap = 128;   // distinct cameras staged per workgroup (sl
 
 // Per-landmark record written by k_landmark_reduce and read by the camera-major kernels: everything a
 // camera-major gather needs from a landmark sits in ONE 128-byte line instead of three arrays.
-constexpr int kLmStride = 16;  // doubles: Hll^-1 (9, row-major) | point (3) | g_l (3) | pad -- what the pair kernels need
-constexpr int kLmPt = 9, kLmG = 12;  // (Hll^-1 and the point) is the first 96 bytes: six 16-byte loads
+// In MEMORY (round 4): Hll^-1 -- bitwise symmetric -- as (00, 01, 02, 11, 12, 22) | p_w.x, p_w.y || p_w.z | g_l (3) | pad: the first
+// 64-byte line is all the pair kernel needs of a landmark (p_w.z rides in the projection records), the first 96 bytes all
+// anybody needs.  In REGISTERS (load_lm_record, ba_kernels.hip) the kernels keep the layout of rounds 1-3:
+constexpr int kLmStride = 16;  // doubles: Hll^-1 (9, row-major) | point (3) | g_l (3) | pad
+constexpr int kLmPt = 9, kLmG = 12;
 constexpr int kLmuStride = 8;  // matrix-free Schur operator: {point(3), -, u_l(3), -} per landmark, 64 bytes
 
 // Lower-triangular tile map of the reduced camera matrix S.
@@ -83,8 +86,8 @@ constexpr int kRowMaxPartners = 64;  // an observation with more partners is spl
 void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* cam_ptr, const int* cam_obs,
                        double lambda, int add_lambda, const double* hinv, const double* g_l, int with_self, double* g_c,
                        double* g_red, hipStream_t s);
-// orec (may be NULL): [n_obs][4] projection records (xn, yn, -1/z, sqrt(rho')), landmark-major, for the record form of
-// the Schur pair kernel (schur_pairs.hip)
+// orec (may be NULL): [n_obs][4] projection records (xn, yn, p_w.z, sqrt(rho')), landmark-major, for the record form of
+// the Schur pair kernel (schur_pairs.hip) and of the back-substitution
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag,
                             double* lmu /* may be NULL */, hipStream_t s, double* orec = nullptr);
 // A18 (implicit_schur.rs): y = S x matrix-free, the Schur-Jacobi preconditioner blocks and their application

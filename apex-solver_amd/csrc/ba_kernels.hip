@@ -51,11 +51,13 @@ __device__ __forceinline__ double block_sum_256(double v, double* scratch) {
     return r;
 }
 
-// one landmark record = eight aligned 16-byte loads
+// (memory layout -> register layout, see ba_kernels.h: six 16-byte loads, the expansion is register moves)
 __device__ __forceinline__ void load_lm_record(const double* __restrict__ rec, size_t l, double out[kLmStride]) {
     const double2* q = reinterpret_cast<const double2*>(rec + kLmStride * l);
-#pragma unroll
-    for (int i = 0; i < kLmStride / 2; ++i) { const double2 t = q[i]; out[2 * i] = t.x; out[2 * i + 1] = t.y; }
+    const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
+    out[0] = a0.x; out[1] = a0.y; out[2] = a1.x; out[3] = a0.y; out[4] = a1.y; out[5] = a2.x; out[6] = a1.x; out[7] = a2.x; out[8] = a2.y;
+    out[kLmPt] = a3.x; out[kLmPt + 1] = a3.y; out[kLmPt + 2] = a4.x;
+    out[kLmG] = a4.y; out[kLmG + 1] = a5.x; out[kLmG + 2] = a5.y; out[15] = 0.0;
 }
 
 template <int DC>
@@ -313,10 +315,11 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
 #pragma unroll
                 for (int b = 0; b < 3; ++b) Bi[3 * a + b] *= sc[a] * sc[b];
         }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) hinv[kLmStride * l + i] = Bi[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { hinv[kLmStride * l + kLmG + i] = gl[i]; hinv[kLmStride * l + kLmPt + i] = pw[i]; }
+        {   // the record's memory layout (ba_kernels.h); mat3_try_inverse of a symmetric block is symmetric bit for bit
+            double2* q = reinterpret_cast<double2*>(hinv + kLmStride * l);
+            q[0] = make_double2(Bi[0], Bi[1]); q[1] = make_double2(Bi[2], Bi[4]); q[2] = make_double2(Bi[5], Bi[8]);
+            q[3] = make_double2(pw[0], pw[1]); q[4] = make_double2(pw[2], gl[0]); q[5] = make_double2(gl[1], gl[2]);
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) g_l[3 * l + i] = gl[i];
         if (lmu) {  // matrix-free variant: the point travels with u_l in a 64-byte record
@@ -432,10 +435,11 @@ __global__ __launch_bounds__(kRow2Threads) void k_schur_rows2(BAView v, TileMap 
             const double2 uvi = v.co_uv[en.x];
             double Hi[9];
             {
-                const double2* q = reinterpret_cast<const double2*>(hinv + kLmStride * (size_t)l);
-                const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
-                Hi[0] = a0.x; Hi[1] = a0.y; Hi[2] = a1.x; Hi[3] = a1.y; Hi[4] = a2.x; Hi[5] = a2.y; Hi[6] = a3.x; Hi[7] = a3.y;
-                Hi[8] = a4.x; pw[0] = a4.y; pw[1] = a5.x; pw[2] = a5.y;
+                double lr[kLmStride];
+                load_lm_record(hinv, (size_t)l, lr);
+#pragma unroll
+                for (int a = 0; a < 9; ++a) Hi[a] = lr[a];
+                pw[0] = lr[kLmPt]; pw[1] = lr[kLmPt + 1]; pw[2] = lr[kLmPt + 2];
             }
             double r[2], Jc[2][DC], Jl[2][3];
             linearize_obs<DC>(cam_i, pw, uvi.x, uvi.y, v.huber_delta, r, Jc, Jl);
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     for (int a = 0; a < DC; ++a) dcv[a] = dc[(size_t)c * DC + a];
                 }
                 RecJac J;
-                jac_from_rec(cv, uv, rw, J);
+                jac_from_rec(cv, uv, rw, pw, J);
                 const double q0 = dcv[0] + (dcv[4] * pw[2] - dcv[5] * pw[1]);   // dt + dtheta x p_w
                 const double q1 = dcv[1] + (dcv[5] * pw[0] - dcv[3] * pw[2]);
                 const double q2 = dcv[2] + (dcv[3] * pw[1] - dcv[4] * pw[0]);
@@ -635,8 +639,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int a = 0; a < kLmStride; ++a) Hi[a] = lrec[REC ? a : 0];
         } else {
-#pragma unroll
-            for (int a = 0; a < kLmStride; ++a) Hi[a] = hinv[kLmStride * l + a];
+            load_lm_record(hinv, (size_t)l, Hi);
         }
         if (MATVEC) {
 #pragma unroll

@@ -437,9 +437,7 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
 // stamps -- every wave adds the shader cycles it spent in each phase of its chunks to g_pair_phase (read with
 // pairs_phase_cycles): 0 wait for the gathers, 1 unstage, 2 cameras + both Jacobians + U / V stores, 3 issue, 4 products and
 // flushes, 5 chunks, 6 flushes alone, 7 number of flushes.  Queued layout only: 4096 no transposition of the finished block
-// through LDS (its elements land in the wrong places), 8192 the landmark record's second line is not fetched, 16384 the
-// gathered pieces are used where they landed (no un-staging through LDS: 3.05 -> 2.85 ms, the bound of what a register
-// transpose could gain; without the camera reads, 16: 2.93); 1024 together
+// through LDS (its elements land in the wrong places); 1024 together
 // with 4096 leaves the accumulators without a use and removes the PRODUCT PHASE as well (it does not measure the stores).
 //
 // Nothing in the loop goes through the scalar memory path: s_load shares the lgkm counter with the LDS and returns out of
@@ -537,16 +535,14 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         c.first_block = __builtin_amdgcn_readlane((int)ckv.y, q);
         return c;
     };
-    // The per-pair gathers (landmark record 96 B, the two projection records 32 B each) are COOPERATIVE: the L1 serves one
+    // The per-pair gathers (the first 64-byte line of the landmark record, the two projection records 32 B each) are COOPERATIVE: the L1 serves one
     // 64-byte line per clock whatever the lanes take from it, and a lane that fetches its own 160 bytes as ten 16-byte loads
     // costs ten line accesses per pair -- 1.6 ms of pure tag-lookup time per launch, the largest single item of the first
     // record kernel (profiles/r03_pairs_ablation.txt).  Here four lanes share a 64-byte line in ONE instruction (two lanes a
-    // 32-byte record): four line accesses per pair.  The pieces land in the registers of the lanes that fetched them and go
-    // to the lanes that need them through the LDS area U / V leave free between two product phases (stage / unstage).
-    struct Coop { double2 a0, a1, a2, a3, b0, b1, i0, i1, j0, j1; };   // what a lane fetches for OTHER lanes' pairs (scalars: arrays in a loop-carried struct went to scratch memory)
-    struct Gather { double2 ri0, ri1, rj0, rj1; double2 lm[6]; };  // a lane's own pair
-    constexpr int kStage = 176;   // bytes per pair in the staging image: 160 of data; 44 dwords = 4 x odd keeps the b128 reads conflict-free
-    static_assert(64 * kStage <= 2 * 64 * UV * 8, "the staging image must fit the U / V area");
+    // 32-byte record): three line accesses per pair, eight gather instructions per chunk.  The pieces land in the registers of
+    // the lanes that fetched them and reach the lanes that need them by a register transpose (unstage_dpp).
+    struct Coop { double2 a0, a1, a2, a3, i0, i1, j0, j1; };   // what a lane fetches for OTHER lanes' pairs (scalars: arrays in a loop-carried struct went to scratch memory)
+    struct Gather { double2 ri0, ri1, rj0, rj1; double2 lm[4]; };  // a lane's own pair
     // Which lane fetches what: the four lanes of a quad fetch the four quarters of the landmark line of the quad's k-th pair
     // (k = 0..3: four instructions, 16 lines each), the two lanes of a lane pair the two halves of a 32-byte piece of the
     // lane pair's k-th pair (k = 0, 1).  The indices therefore come from a lane of the same quad: one DPP quad_perm move each,
@@ -568,42 +564,20 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         d.a2 = lm0(std::integral_constant<int, 2>{}); d.a3 = lm0(std::integral_constant<int, 3>{});
         {
             const std::integral_constant<int, 0> k{};
-            d.b0 = (ABL & 8192) ? d.a0 : *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)pair_bcast(l, k) + 8 + 2 * h);   // (8192: timing only, the landmark record's second line not fetched)
             d.i0 = *reinterpret_cast<const double2*>(orec + 4 * (size_t)pair_bcast(i, k) + 2 * h);
             d.j0 = *reinterpret_cast<const double2*>(orec + 4 * (size_t)pair_bcast(j, k) + 2 * h);
         }
         {
             const std::integral_constant<int, 1> k{};
-            d.b1 = (ABL & 8192) ? d.a1 : *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)pair_bcast(l, k) + 8 + 2 * h);
             d.i1 = *reinterpret_cast<const double2*>(orec + 4 * (size_t)pair_bcast(i, k) + 2 * h);
             d.j1 = *reinterpret_cast<const double2*>(orec + 4 * (size_t)pair_bcast(j, k) + 2 * h);
         }
     };
-    auto unstage = [&](const Coop& d, Gather& o) {   // the U / V area is free: no product phase is running
-        char* T = reinterpret_cast<char*>(U);
-        char* A = T + kStage * (lane & ~3) + 16 * (lane & 3);      // pair (lane & ~3) + k, quarter lane & 3
-        *reinterpret_cast<double2*>(A) = d.a0;
-        *reinterpret_cast<double2*>(A + kStage) = d.a1;
-        *reinterpret_cast<double2*>(A + 2 * kStage) = d.a2;
-        *reinterpret_cast<double2*>(A + 3 * kStage) = d.a3;
-        char* R = T + kStage * (lane & ~1) + 16 * (lane & 1);      // pair (lane & ~1) + k, half lane & 1
-        *reinterpret_cast<double2*>(R + 64) = d.b0;
-        *reinterpret_cast<double2*>(R + 96) = d.i0;
-        *reinterpret_cast<double2*>(R + 128) = d.j0;
-        *reinterpret_cast<double2*>(R + kStage + 64) = d.b1;
-        *reinterpret_cast<double2*>(R + kStage + 96) = d.i1;
-        *reinterpret_cast<double2*>(R + kStage + 128) = d.j1;
-        __builtin_amdgcn_wave_barrier();
-        const double2* me = reinterpret_cast<const double2*>(T + kStage * lane);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o.lm[k] = me[k];
-        o.ri0 = me[6]; o.ri1 = me[7]; o.rj0 = me[8]; o.rj1 = me[9];
-        __builtin_amdgcn_wave_barrier();   // (the LDS executes a wave's operations in order: the U / V stores below come after these reads)
-    };
-    // The same redistribution in registers (round 4, second half): the pieces form a 4 x 4 matrix per quad (lane q holds quarter q
-    // of the quad's pair k in a_k) and 2 x 2 matrices per lane pair (half h of pair k in b_k / i_k / j_k); a lane wants the
-    // row of its own pair.  A butterfly transpose -- exchange with the lane one away, then two away, each a DPP quad_perm
-    // move folded into a select -- instead of ten LDS writes, ten LDS reads and their round trip.
+    // From the lanes that fetched the pieces to the lanes that need them, in registers (round 4; through LDS before: ten
+    // writes, ten reads and their round trip, 0.14 ms): the pieces form a 4 x 4 matrix per quad (lane q holds quarter q of the
+    // quad's pair k in a_k) and 2 x 2 matrices per lane pair (half h of pair k in i_k / j_k); a lane wants the row of its own
+    // pair.  A butterfly transpose -- exchange with the lane one away, then two away, each a DPP quad_perm move folded into a
+    // select.
     auto unstage_dpp = [&](const Coop& d, Gather& o) {
         const bool odd = (lane & 1) != 0, hi2 = (lane & 2) != 0;
         constexpr int X1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);   // quad_perm:[1,0,3,2]
@@ -626,7 +600,6 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         const double2 b2 = xch(odd, d.a2, d.a3, c1), b3 = xch(!odd, d.a3, d.a2, c1);
         o.lm[0] = xch(hi2, b0, b2, c2); o.lm[2] = xch(!hi2, b2, b0, c2);
         o.lm[1] = xch(hi2, b1, b3, c2); o.lm[3] = xch(!hi2, b3, b1, c2);
-        o.lm[4] = xch(odd, d.b0, d.b1, c1); o.lm[5] = xch(!odd, d.b1, d.b0, c1);
         o.ri0 = xch(odd, d.i0, d.i1, c1); o.ri1 = xch(!odd, d.i1, d.i0, c1);
         o.rj0 = xch(odd, d.j0, d.j1, c1); o.rj1 = xch(!odd, d.j1, d.j0, c1);
     };
@@ -688,17 +661,13 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         __builtin_amdgcn_wave_barrier();
         const unsigned long long t1 = stamp();
         Gather dat;
-        if (ABL & 16384) {   // (timing only: the gathered pieces are used where they landed, no trip through LDS)
-            dat.lm[0] = coop.a0; dat.lm[1] = coop.a1; dat.lm[2] = coop.a2; dat.lm[3] = coop.a3; dat.lm[4] = coop.b0; dat.lm[5] = coop.b1;
-            dat.ri0 = coop.i0; dat.ri1 = coop.i1; dat.rj0 = coop.j0; dat.rj1 = coop.j1;
-        } else if (!(ABL & 32768)) unstage_dpp(coop, dat);   // (32768: the trip through LDS, for the A/B)
-        else unstage(coop, dat);
+        unstage_dpp(coop, dat);
         if (ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long t2 = stamp();
         double cvi[16], cvj[16];
         if (ABL & 16) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { cvi[k] = dat.lm[k % 6].x + k; cvj[k] = dat.lm[k % 6].y - k; }
+            for (int k = 0; k < 16; ++k) { cvi[k] = dat.lm[k % 4].x + k; cvj[k] = dat.lm[k % 4].y - k; }
         } else {
             if (QL) {
                 const double2* cj = reinterpret_cast<const double2*>(CAMS + (1 + blk) * kCamStride);
@@ -720,8 +689,11 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             }
         }
         double Hi[9], pw[3];
-        Hi[0] = dat.lm[0].x; Hi[1] = dat.lm[0].y; Hi[2] = dat.lm[1].x; Hi[3] = dat.lm[1].y; Hi[4] = dat.lm[2].x; Hi[5] = dat.lm[2].y;
-        Hi[6] = dat.lm[3].x; Hi[7] = dat.lm[3].y; Hi[8] = dat.lm[4].x; pw[0] = dat.lm[4].y; pw[1] = dat.lm[5].x; pw[2] = dat.lm[5].y;
+        // the landmark record's first line: Hll^-1 (bitwise symmetric) as (00, 01, 02, 11, 12, 22) | p_w.x, p_w.y; p_w.z rides in
+        // slot 2 of the projection records (both carry the same landmark's)
+        Hi[0] = dat.lm[0].x; Hi[1] = dat.lm[0].y; Hi[2] = dat.lm[1].x; Hi[4] = dat.lm[1].y; Hi[5] = dat.lm[2].x; Hi[8] = dat.lm[2].y;
+        Hi[3] = Hi[1]; Hi[6] = Hi[2]; Hi[7] = Hi[5];
+        pw[0] = dat.lm[3].x; pw[1] = dat.lm[3].y; pw[2] = dat.ri1.x;
         // A padding slot (and the filler slot of an odd block) contributes exact zeros: its lanes carry element 0's records
         // with the Huber weight forced to 0, which zeroes a, (xn w, yn w) and with them V, M and U.
         const double2 rj1 = make_double2(dat.rj1.x, valid ? dat.rj1.y : 0.0), ri1 = make_double2(dat.ri1.x, valid ? dat.ri1.y : 0.0);
@@ -730,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         {
             RecJac J;
             if (ABL & 32) { J.a[0][0] = dat.rj0.x; J.a[0][1] = dat.rj0.y; J.a[0][2] = rj1.x; J.a[1][0] = rj1.y; J.a[1][1] = cvj[0]; J.a[1][2] = cvj[1]; J.xw = cvj[2]; J.yw = cvj[3]; J.t[0] = cvj[4]; J.t[1] = cvj[5]; J.t[2] = cvj[6]; }
-            else jac_from_rec(cvj, dat.rj0, rj1, J);
+            else jac_from_rec(cvj, dat.rj0, rj1, pw, J);
             double Jc[2][DC];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -761,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         {
             RecJac J;
             if (ABL & 32) { J.a[0][0] = dat.ri0.x; J.a[0][1] = dat.ri0.y; J.a[0][2] = ri1.x; J.a[1][0] = ri1.y; J.a[1][1] = cvi[0]; J.a[1][2] = cvi[1]; J.xw = cvi[2]; J.yw = cvi[3]; J.t[0] = cvi[4]; J.t[1] = cvi[5]; J.t[2] = cvi[6]; }
-            else jac_from_rec(cvi, dat.ri0, ri1, J);
+            else jac_from_rec(cvi, dat.ri0, ri1, pw, J);
             double M[2][2];
 #pragma unroll
             for (int n = 0; n < 2; ++n)
@@ -984,11 +956,7 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
         else if (ablation == 2) PAIRS_Q(false, 2);
         else if (ablation == 1024) PAIRS_Q(false, 1024);
         else if (ablation == 4096) PAIRS_Q(false, 4096);
-        else if (ablation == 8192) PAIRS_Q(false, 8192);
-        else if (ablation == 16384) PAIRS_Q(false, 16384);
-        else if (ablation == 32768) PAIRS_Q(false, 32768);
         else if (ablation == 16) PAIRS_Q(false, 16);
-        else if (ablation == 16384 + 16) PAIRS_Q(false, 16384 + 16);
         else if (ablation == 64 + 1024) PAIRS_Q(false, 64 + 1024);
         else if (ablation == 64 + 4096) PAIRS_Q(false, 64 + 4096);
         else if (ablation == 64 + 5120) PAIRS_Q(false, 64 + 5120);
@@ -999,7 +967,7 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
     }
     if (ablation != 0 && dc == 9) {   // timing experiments (SelfCalibration only)
 #define PAIRS_RA(A) case A: hipLaunchKernelGGL((k_schur_pairs_r<9, false, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, nullptr); return
-        switch (ablation) { PAIRS_RA(32768); PAIRS_RA(512); PAIRS_RA(1024); PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3);
+        switch (ablation) { PAIRS_RA(512); PAIRS_RA(1024); PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3);
             default: break;   // an unlisted value: the plain kernel below, never a missing launch
         }
 #undef PAIRS_RA

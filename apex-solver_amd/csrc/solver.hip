@@ -1244,11 +1244,17 @@ int Solver::owned_landmarks(uint8_t* mask) const {
 int Solver::get_landmark_blocks(double* hinv_out, double* gl_out) {
     if (!have_params_) return fail(kInvalidState, "no parameters set");
     HIP_TRY(hipSetDevice(device_));
-    if (hinv_out)
-        HIP_TRY(hipMemcpy2DAsync(hinv_out, 9 * sizeof(double), hinv_, kLmStride * sizeof(double), 9 * sizeof(double), (size_t)n_pt_,
+    if (hinv_out)   // the record's first six doubles: Hll^-1 as (00, 01, 02, 11, 12, 22) (ba_kernels.h); expanded below
+        HIP_TRY(hipMemcpy2DAsync(hinv_out, 9 * sizeof(double), hinv_, kLmStride * sizeof(double), 6 * sizeof(double), (size_t)n_pt_,
                                  hipMemcpyDeviceToHost, stream_));
     if (gl_out) HIP_TRY(hipMemcpyAsync(gl_out, g_l_, 3 * n_pt_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
+    if (hinv_out)
+        for (int64_t l = 0; l < n_pt_; ++l) {
+            double* h = hinv_out + 9 * l;
+            const double s[6] = {h[0], h[1], h[2], h[3], h[4], h[5]};
+            h[0] = s[0]; h[1] = s[1]; h[2] = s[2]; h[3] = s[1]; h[4] = s[3]; h[5] = s[4]; h[6] = s[2]; h[7] = s[4]; h[8] = s[5];
+        }
     if (tree_shard_) {  // back to the caller's landmark order
         std::vector<double> t;
         if (hinv_out) { t.assign(hinv_out, hinv_out + 9 * n_pt_); for (int64_t l = 0; l < n_pt_; ++l) memcpy(hinv_out + 9 * l, t.data() + 9 * (size_t)lmap_[l], 9 * sizeof(double)); }
