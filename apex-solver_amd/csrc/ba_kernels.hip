@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                           REC ? lrec[REC ? kLmPt + 2 : 0] : v.pts[3 * lc + 2]};
     const int i_first = max(min(b + g, (int)v.n_obs - 1), 0);
     const double2* __restrict__ rec2 = reinterpret_cast<const double2*>(orec);
-    double2 uv_next = REC ? rec2[2 * (size_t)i_first] : v.o_uv[i_first];   // REC: (xn, yn) | (-1/z, w)
+    double2 uv_next = REC ? rec2[2 * (size_t)i_first] : v.o_uv[i_first];   // REC: (xn, yn) | (p_w.z, w)
     double2 rw_next = REC ? rec2[2 * (size_t)i_first + 1] : make_double2(0.0, 0.0);
     int sl_next = v.o_slot ? (int)v.o_slot[i_first] : 255;
     stager.store(sCam);

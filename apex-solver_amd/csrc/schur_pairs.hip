@@ -295,10 +295,10 @@ __device__ __forceinline__ uint32_t pairs_dma_cam(const PairBlock* __restrict__ 
 // RECORD FORM (round 3).  The fused kernels above re-linearise both observations of every pair from the 24-byte
 // observation records: ~140 fp64 instructions per observation, k - 1 = 5.5 times per observation and iteration -- 40 % of
 // the kernel's vector instructions, and it is bound by exactly those.  k_landmark_reduce linearises
-// every observation once anyway; it now also writes the observation's PROJECTION RECORD (xn, yn, -1/z, sqrt(rho')), 32
+// every observation once anyway; it now also writes the observation's PROJECTION RECORD (xn, yn, p_w.z, sqrt(rho'); -1/z until the end of round 4), 32
 // bytes, in place of which the pair kernel used to gather the 16-byte measurement.  From the record and the camera
-// (R, f, k1, k2: staged in LDS as before) the Jacobian is ~60 instructions with no reciprocal, no square root and no
-// dependent chain longer than six:
+// (R, t, f, k1, k2: staged in LDS as before) and the point the Jacobian is ~70 instructions, one reciprocal (-1/z, rebuilt
+// with linearize_obs' own operations: rec_inz), no square root:
 //     a = d(u,v)/d p_w = w f (-1/z) [dxx dxy xn dxx + yn dxy ; dxy dyy xn dxy + yn dyy] R          (2 x 3, = Jl)
 //     Jc = [ a | -a [p_w]x | (xn w, yn w)^T (dist, f r2, f r4) ]                                    (2 x 9)
 // and the row side never forms Jc at all: U = Jc_i^T M = [ G ; p_w x G ; t (s M) ] with G = a_i^T M  (34 instead of 66).

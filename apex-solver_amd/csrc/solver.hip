@@ -336,7 +336,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(alloc(&g_red_, n_c_pad_));
     HIP_TRY(alloc(&dcam_, n_c_pad_));
     HIP_TRY(alloc(&hinv_, (size_t)kLmStride * n_pt_));  // landmark records: Hll^-1 | g_l | point
-    // projection records of the local observations (xn, yn, -1/z, sqrt(rho')): the record form of the pair kernel
+    // projection records of the local observations (xn, yn, p_w.z, sqrt(rho')): the record form of the pair kernel
     if (rows_form_ == 3 || rows_form_ == 4 || rec_backsub_) HIP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
     HIP_TRY(alloc(&g_l_, 3 * n_pt_));
     HIP_TRY(alloc(&dl_, 3 * n_pt_));
