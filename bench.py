@@ -455,7 +455,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
                 "pair_list_bytes": pair_list_bytes if record_form else 0.0,
                 "avg_launch_ms": sc_avg, "launches": sc_n,
-                "actual_bound": ("vector-memory path: the gathers of a 64-pair chunk (4 x 64-byte lines per pair, ~2/3 of them L2 misses) take a third of a "
+                "actual_bound": ("vector-memory path: the gathers of a 64-pair chunk (3 x 64-byte lines per pair, ~2/3 of them L2 misses) take more than a third of a "
                                  "wave's time to ISSUE; products and flush are no longer co-critical in the queued layout "
                                  "(profiles/r04_pairs_queued_*.txt; DESIGN.md section 4, round 4)") if record_form else
                                 "fp64 vector unit + LDS (the fused form moves 2 GB but executes ~60 GFLOP: DESIGN.md section 4)",

@@ -45,7 +45,7 @@ if has lockstep; then timeout 1500 python3 tools/dist_lockstep_times.py final-13
 if has pairs; then   # the queued layout (form 4, the default); the form-3 evidence of the first half of the round stays as r04_k_schur_pairs_counters / r04_pairs_ablation
   timeout 900 tools/profile_pairs.sh ${T}_queued > /dev/null 2>&1; mv $O/${T}_queued_k_schur_pairs_counters.txt $O/${T}_pairs_queued_counters.txt
   grep -E "SQ_LDS_BANK|TCC_MISS|SQ_INSTS_VALU |SQ_INSTS_LDS|SQ_INSTS_SALU|^form" $O/${T}_pairs_queued_counters.txt
-  { python3 tools/schur_bench.py --forms 4,3,2 --iters 10 --abl 0,1,2,1024,8192,64 2>&1 | grep -E "^form|cycles per chunk"
+  { python3 tools/schur_bench.py --forms 4,3,2 --iters 10 --abl 0,1,2,1024,64 2>&1 | grep -E "^form|cycles per chunk"
     python3 tools/schur_bench.py --forms 4 --task-slots 4032,2592,2016,1152 --iters 10 2>&1 | grep -E "^form"; } > $O/${T}_pairs_queued_ablation.txt; cat $O/${T}_pairs_queued_ablation.txt
 fi
 if has micro; then
