@@ -1612,63 +1612,82 @@ __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const Factor
 //   k_sym_tile_gather: one workgroup per block row adds its partials in list order and also emits
 //       the block's share of p.Ap.
 // ------------------------------------------------------------------------------------------
+// (round 4: the tile no longer goes through LDS.  The first version staged two 72-row halves in 84 KB of LDS -- one workgroup
+// per CU, 144 of its 256 threads doing 72-step dot products out of LDS between two barriers: 198 us for the 710 MB of
+// final-13682's touched tiles, 3.6 TB/s.  Now a wave streams 36 rows straight into registers, a lane owning the column pair
+// (2 l, 2 l + 1) and, lanes 0..7, (128 + 2 l, 129 + 2 l): v = A^T x_I accumulates in the lane, u = A x_J is one DPP wave
+// reduction per row; 4.7 KB of LDS for the vectors and the four waves' column sums, eight workgroups per CU.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double sym_dpp_add(double x) {   // x + (x moved by CTRL); lanes outside the row mask, and lanes the move has nothing for, add 0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xF, true);
+    return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sym_wave_sum(double x) {   // the sum over the 64 lanes, valid in lane 63
+    x = sym_dpp_add<0x118, 0xF>(x);   // row_shr:8
+    x = sym_dpp_add<0x114, 0xF>(x);   // row_shr:4
+    x = sym_dpp_add<0x112, 0xF>(x);   // row_shr:2
+    x = sym_dpp_add<0x111, 0xF>(x);   // row_shr:1   -> lane 15 of every row of 16 holds the row's sum
+    x = sym_dpp_add<0x142, 0xA>(x);   // row_bcast:15 into rows 1 and 3
+    x = sym_dpp_add<0x143, 0xC>(x);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
 __global__ __launch_bounds__(256) void k_sym_tile_products(const SymTile* __restrict__ list,
                                                              const double* __restrict__ tiles,
                                                              const double* __restrict__ x, double* __restrict__ part) {
-    __shared__ double sT[HROWS * TP];
-    __shared__ double sxJ[NB], sxI[NB], sp[NB];
+    constexpr int RW = NB / 4;   // 36 rows per wave
+    constexpr int RB = 6;        // rows in flight per wave (12 loads of 16 bytes per lane)
+    __shared__ double sxI[NB], su[NB], sv[4][NB];
     const SymTile st = list[blockIdx.x];
     const double* __restrict__ M = tiles + (size_t)st.slot * (NB * NB);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool diag = (st.I == st.J);
-    if (tid < NB) { sxJ[tid] = x[(size_t)st.J * NB + tid]; sxI[tid] = x[(size_t)st.I * NB + tid]; }
-    double accT = 0.0;
-    double* pu = part + (size_t)st.slot * (2 * NB);
-    for (int h = 0; h < 2; ++h) {
-        double2 reg[21];
+    if (tid < NB) sxI[tid] = x[(size_t)st.I * NB + tid];
+    const bool ext = lane < 8;   // the lanes that also own columns 128 + 2 l, 129 + 2 l
+    const int c0 = 2 * lane, c1 = 128 + 2 * lane;
+    const double2 xj = *reinterpret_cast<const double2*>(x + (size_t)st.J * NB + c0);
+    const double2 xje = ext ? *reinterpret_cast<const double2*>(x + (size_t)st.J * NB + c1) : make_double2(0.0, 0.0);
+    double v0 = 0.0, v1 = 0.0, ve0 = 0.0, ve1 = 0.0;
+    __syncthreads();
+    for (int rb = 0; rb < RW; rb += RB) {
+        double2 m[RB], me[RB];
 #pragma unroll
-        for (int i = 0; i < 21; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < HROWS * (NB / 2)) {
-                const int row = idx / (NB / 2), c2 = idx - row * (NB / 2);
-                reg[i] = *reinterpret_cast<const double2*>(M + (size_t)(HROWS * h + row) * NB + 2 * c2);
-            }
+        for (int k = 0; k < RB; ++k) {
+            const double* row = M + (size_t)(RW * w + rb + k) * NB;
+            m[k] = *reinterpret_cast<const double2*>(row + c0);
+            me[k] = ext ? *reinterpret_cast<const double2*>(row + c1) : make_double2(0.0, 0.0);
         }
-        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 21; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < HROWS * (NB / 2)) {
-                const int row = idx / (NB / 2), c2 = idx - row * (NB / 2);
-                const int gr = HROWS * h + row;
-                double vx = reg[i].x, vy = reg[i].y;
-                if (diag) {  // only the lower triangle of a diagonal tile is valid
-                    if (2 * c2 > gr) vx = 0.0;
-                    if (2 * c2 + 1 > gr) vy = 0.0;
-                }
-                sT[row * TP + 2 * c2] = vx; sT[row * TP + 2 * c2 + 1] = vy;
+        for (int k = 0; k < RB; ++k) {
+            const int r = RW * w + rb + k;
+            double a0 = m[k].x, a1 = m[k].y, b0 = me[k].x, b1 = me[k].y;
+            if (diag) {   // only the lower triangle of a diagonal tile is valid: u takes it with the diagonal ...
+                if (c0 > r) a0 = 0.0;
+                if (c0 + 1 > r) a1 = 0.0;
+                if (c1 > r) b0 = 0.0;
+                if (c1 + 1 > r) b1 = 0.0;
             }
-        }
-        __syncthreads();
-        if (tid < NB) {  // u = M x_J, rows of this half; two column halves per row
-            const int row = tid % HROWS, ch = tid / HROWS;
-            double a = 0.0;
-#pragma unroll 8
-            for (int c = 0; c < HROWS; ++c) a += sT[row * TP + ch * HROWS + c] * sxJ[ch * HROWS + c];
-            sp[ch * HROWS + row] = a;
-        }
-        __syncthreads();
-        if (tid < HROWS) pu[HROWS * h + tid] = sp[tid] + sp[HROWS + tid];
-        if (tid < NB) {  // v = M^T x_I (for a diagonal tile: the strictly-upper part of sym(M) x)
-#pragma unroll 8
-            for (int r = 0; r < HROWS; ++r) {
-                const int gr = HROWS * h + r;
-                const double m = sT[r * TP + tid];
-                accT += ((diag && gr == tid) ? 0.0 : m) * sxI[gr];
+            const double pr = fma(a0, xj.x, fma(a1, xj.y, fma(b0, xje.x, b1 * xje.y)));
+            const double tot = sym_wave_sum(pr);
+            if (lane == 63) su[r] = tot;
+            if (diag) {   // ... and v = (strictly lower part)^T x_I completes sym(A) x
+                if (c0 == r) a0 = 0.0;
+                if (c0 + 1 == r) a1 = 0.0;
+                if (c1 == r) b0 = 0.0;
+                if (c1 + 1 == r) b1 = 0.0;
             }
+            const double xi = sxI[r];
+            v0 = fma(a0, xi, v0); v1 = fma(a1, xi, v1); ve0 = fma(b0, xi, ve0); ve1 = fma(b1, xi, ve1);
         }
     }
-    if (tid < NB) pu[NB + tid] = accT;
+    sv[w][c0] = v0; sv[w][c0 + 1] = v1;
+    if (ext) { sv[w][c1] = ve0; sv[w][c1 + 1] = ve1; }
+    __syncthreads();
+    double* pu = part + (size_t)st.slot * (2 * NB);
+    if (tid < NB) {
+        pu[tid] = su[tid];
+        pu[NB + tid] = (sv[0][tid] + sv[1][tid]) + (sv[2][tid] + sv[3][tid]);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sym_tile_gather(const int* __restrict__ row_ptr,
