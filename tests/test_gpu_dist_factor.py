@@ -205,7 +205,10 @@ def test_factorisation_schedule_switches_agree():
     assert info["etree_levels"] >= 8
     nrm = np.linalg.norm(ref)
     for opts in ({"two_side": 2}, {"two_side": 2, "flood_gate": 2}, {"two_side": 0, "flood_gate": 2}, {"two_side": 2, "flood_gate": 0},
-                 {"two_side": 2, "split_u1": 0}, {"two_side": 2, "flood_gate": 2, "flood_gate_pos": 1}):
+                 {"two_side": 2, "split_u1": 0}, {"two_side": 2, "flood_gate": 2, "flood_gate_pos": 1},
+                 # round 4: the top of the tree by level launches only / as one dataflow launch down to wide groups (the default
+                 # lets a cost model choose), and the panel solves with and without the triangular skip (process-wide switch)
+                 {"factor_flow": 0}, {"factor_flow": 64}, {"factor_flow": 0, "panel_tri": 0}, {"panel_tri": 1}):
         (a, b), _ = step(opts)
         # (S itself is assembled with atomics on a few shared blocks: 1e-16 differences, amplified by cond(S) ~ 1e9)
         assert np.linalg.norm(a - ref) < 1e-7 * nrm and np.linalg.norm(b - a) < 1e-7 * nrm, (opts, np.linalg.norm(a - ref) / nrm)
