@@ -196,7 +196,7 @@ def test_factorisation_schedule_switches_agree():
             s.with_option(k, v)
         s.initialize_structure(prob)
         s.set_parameters(d.poses, d.intr, d.points)
-        out = [s.solve_augmented_equation(1e-3), s.solve_augmented_equation(1e-3)]
+        out = [s.solve_augmented_equation(1e-3).copy(), s.solve_augmented_equation(1e-3).copy()]
         info = s.info()
         s.close()
         return out, info
@@ -210,5 +210,7 @@ def test_factorisation_schedule_switches_agree():
                  # lets a cost model choose), and the panel solves with and without the triangular skip (process-wide switch)
                  {"factor_flow": 0}, {"factor_flow": 64}, {"factor_flow": 0, "panel_tri": 0}, {"panel_tri": 1}):
         (a, b), _ = step(opts)
-        # (S itself is assembled with atomics on a few shared blocks: 1e-16 differences, amplified by cond(S) ~ 1e9)
-        assert np.linalg.norm(a - ref) < 1e-7 * nrm and np.linalg.norm(b - a) < 1e-7 * nrm, (opts, np.linalg.norm(a - ref) / nrm)
+        # Bit for bit (round 4): with the queued pair layout S is assembled without atomics on this shape (no block longer than
+        # a piece, no camera that sees a landmark twice), every schedule adds a tile's updates in the same order, the dataflow
+        # launch and the triangular panel skip change no finite value, and the dataflow sweeps fold in list order.
+        assert np.array_equal(a, ref) and np.array_equal(b, a), (opts, np.linalg.norm(a - ref) / nrm)
