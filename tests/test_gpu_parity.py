@@ -803,3 +803,25 @@ def test_record_form_of_the_back_substitution(oracle, mode):
             s.close()
         tol = 1e-11 if variant == SchurVariant.Sparse else 1e-6       # (PCG: the operator's rounding moves the iterates)
         assert rel(steps[1], steps[0]) < tol, (variant, rel(steps[1], steps[0]))
+
+
+def test_schur_assembly_is_reproducible_bit_for_bit():
+    """With the queued pair layout every block of S is summed by one lane group in list order and stored once (a block cut
+    between two queues of a task is joined in registers, in a fixed order); the camera and landmark passes fold in fixed
+    orders too.  Two assemblies of the same linearisation are therefore the same bits -- on a shape with several tile rows,
+    split tasks and nested-dissection levels, but no block beyond 576 pairs and no camera that sees a landmark twice (those
+    add atomically)."""
+    d = pkg.synthetic.make_problem(420, 12000, 3, 8, config_id=91)
+    prob = Problem.bundle_adjustment(d, OptimizationType.SelfCalibration, 1.0)
+    s = GpuSchurComplementSolver(0).initialize_structure(prob)
+    s.set_parameters(d.poses, d.intr, d.points)
+    s.assemble(1e-3)
+    S1, g1 = s.get_schur()
+    S1, g1 = S1.copy(), g1.copy()
+    s.assemble(1e-3)
+    S2, g2 = s.get_schur()
+    assert np.array_equal(S1, S2) and np.array_equal(g1, g2)
+    a = s.solve_augmented_equation(1e-3).copy()
+    b = s.solve_augmented_equation(1e-3).copy()
+    assert np.array_equal(a, b)
+    s.close()
