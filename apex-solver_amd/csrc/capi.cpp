@@ -263,7 +263,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
     // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
     static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "panel_tri", "dist_factor", "tree_sharding", "dist_selftest",
-                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "matrix_free_only"};
+                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "matrix_free_only", "auto_variant", "max_tile_updates"};
     if (h->s->has_structure())
         for (const char* k : structural)
             if (n == k) return APEXGPU_ERR_INVALID_STATE;
@@ -279,6 +279,8 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "flood_gate_pos") h->s->set_gate_pos(value);
     else if (n == "two_side") h->s->set_two_side(value);
     else if (n == "matrix_free_only") h->s->set_matrix_free_only(value != 0);
+    else if (n == "auto_variant") h->s->set_auto_variant(value != 0);
+    else if (n == "max_tile_updates") h->s->set_max_tile_updates(value);
     else if (n == "factor_flow") h->s->set_factor_flow(value, 0);          // max columns per level group inside the dataflow launch (0: off)
     else if (n == "factor_flow_rows") h->s->set_factor_flow(h->s->plan().factor_flow_cols(), value);
     else if (n == "rec_backsub") h->s->set_rec_backsub(value != 0);
@@ -329,6 +331,20 @@ int apexgpu_info(apexgpu_solver* h, double info[16]) {
     info[12] = h->s->dist_top_columns(); info[13] = h->s->dist_local_fraction();
     info[14] = h->s->tree_sharded() ? 1.0 : 0.0;
     info[15] = h->s->schur_form();
+    return APEXGPU_OK;
+}
+
+int apexgpu_variant_info(apexgpu_solver* h, int asked_variant, int* used_variant, char* reason, int reason_len) {
+    H_OR_FAIL;
+    if (asked_variant != APEXGPU_VARIANT_SPARSE && asked_variant != APEXGPU_VARIANT_ITERATIVE && asked_variant != APEXGPU_VARIANT_IMPLICIT)
+        return APEXGPU_ERR_INVALID_INPUT;
+    if (used_variant) *used_variant = h->s->variant_used(asked_variant);
+    if (reason && reason_len > 0) {
+        const std::string& r = h->s->variant_reason();
+        const size_t n = std::min<size_t>(r.size(), (size_t)reason_len - 1);
+        memcpy(reason, r.data(), n);
+        reason[n] = 0;
+    }
     return APEXGPU_OK;
 }
 

@@ -69,7 +69,7 @@ void launch_gate(const int* arrived, int expected, int max_micros, hipStream_t s
 void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, hipStream_t s,
                         unsigned long long* trace = nullptr);   // trace (tools only): 3 stamps of the 100 MHz clock per unit
 void set_panel_tri(int on);          // process-wide A/B switch: 1 (default) the panel solves skip the zero blocks of Linv
-void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 1 / 6 / 8 k_potrf_inv_la with 4 / 6 / 8 waves, 9 k_potrf_inv_mf (default)
+void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 1 / 6 / 8 k_potrf_inv_la with 4 / 6 / 8 waves, 9 / 12 k_potrf_inv_mf with 8 / 12 waves (12: default)
 // batches of <= 56 tasks use the latency kernels, larger ones the 3 x 3-wave strip kernel
 // tri_b: every B is a lower-triangular inverse written by launch_potrf_inv (zero 16 x 16 blocks right of the diagonal): the
 // large-batch kernel then skips the 36 of 81 block products that multiply by them.

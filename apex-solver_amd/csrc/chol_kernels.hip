@@ -22,7 +22,12 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int NB = kNB;
 // ------------------------------------------------------------------------------------------
 // potrf + triangular inverse of one diagonal tile: the latency-critical link of the tile Cholesky
-// (every column K waits for it).  One 256-thread workgroup; the tile lives in LDS as the 45 lower
+// (every column K waits for it).  THIS first kernel (k_potrf_inv, "potrf_lookahead" 0) is the round-1 form, kept as the
+// A/B and as the plain statement of the algorithm; the default since round 4 is k_potrf_inv_mf<12> further down (768
+// threads: wave 0 keeps the 16 x 16 pivot block and its inverse as two MFMA accumulators, two pivots per matrix
+// instruction, nine helper waves for the trailing update; 37 us per tile against this kernel's ~64), k_potrf_inv_la the
+// round-3 look-ahead form in between.  All three share the LDS layout below.
+// One 256-thread workgroup; the tile lives in LDS as the 45 lower
 // 16x16 blocks (pitch 18 doubles -> conflict-free MFMA operand reads), 101 KB, plus the 9 inverted
 // diagonal blocks, 20 KB.  Blocked right-looking factorisation:
 //   per block column kb:  wave 0 factors the 16x16 diagonal block in registers (shuffles, no
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_inv_la(const PotrfTask* __res
 }
 
 // ------------------------------------------------------------------------------------------
-// potrf + inverse, round 4 (default, "potrf_lookahead" 9): the same blocked schedule as k_potrf_inv_la with the serial part
+// potrf + inverse, round 4 (default, "potrf_lookahead" 12 = twelve waves; 9 = eight waves): the same blocked schedule as k_potrf_inv_la with the serial part
 // -- wave 0's 16 x 16 Cholesky and the inverse of its factor -- rewritten for the matrix pipe.  The look-ahead kernel
 // spent 4.1 of its 5.4 us per block step there: lane r owned row r, so every one of the 16 pivots broadcast its column
 // through ~30 v_readlane (SGPR round trips) for the rank-1 update, and the inverse was a second pass of 16 steps.

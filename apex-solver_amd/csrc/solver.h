@@ -100,6 +100,17 @@ class Solver : public LmBackend {
     // neither is its tile structure beyond the diagonal blocks the Schur-Jacobi preconditioner needs, nor the pair list: the
     // set-up and the LM iteration no longer depend on the fill of S (a photo collection whose S is dense: tools/structure_sweep.py)
     void set_matrix_free_only(bool on) { matrix_free_only_ = on; }
+    // Automatic variant selection (round 5; the LM dispatch of levenberg_marquardt.rs:1039-1082 never fails on the fill of S,
+    // so a drop-in backend may not either): when the tile plan of S is refused at set_structure -- its update list beyond
+    // TilePlan's limit, or (single rank) its tiles beyond the free HBM -- the handle is built matrix-free only by itself and
+    // variants 0 / 1 are answered by the matrix-free PCG (IterativeSchurSolver semantics, implicit_schur.rs:835-946): variant 0
+    // at that solver's own defaults (500 iterations, 1e-9: implicit_schur.rs:94-95), variant 1 at the caller's cg parameters.
+    // "auto_variant" 0 restores the refusal.  variant_used() / variant_reason() say what happened (apexgpu_variant_info).
+    void set_auto_variant(bool on) { auto_variant_ = on; }
+    void set_max_tile_updates(int64_t n) { tp_.set_max_updates(n); }   // tests: force the refusal on a small problem
+    int variant_used(int asked) const { return (auto_fallback_ && asked != 2) ? 2 : asked; }
+    bool auto_fallback() const { return auto_fallback_; }
+    const std::string& variant_reason() const { return fallback_reason_; }
     void set_two_side(int mode) { tp_.set_two_side(mode); }
     void set_factor_flow(int max_cols, int max_rows) { tp_.set_factor_flow(max_cols, max_rows); }
     int factor_flow_timeouts() const { return n_factor_flow_timeouts_; }
@@ -121,7 +132,8 @@ class Solver : public LmBackend {
     double schur_scatter_pairs() const { return (double)n_pairs_; }
     double pair_blocks() const { return (double)n_pair_blocks_; }
     double pair_slots() const { return (double)n_pair_slots_; }
-    int schur_form() const { return rows_form_; }
+    // the form that RUNS: the queued layout (4) exists for nine-column cameras only, six-column cameras run form 3's lists and kernels
+    int schur_form() const { return (rows_form_ == 4 && !pair_queued_) ? 3 : rows_form_; }
     const double* setup_seconds() const { return setup_s_; }
     double touched_tiles() const { return (double)n_present_; }
     double local_obs() const { return (double)o_orig_h_.size(); }
@@ -146,7 +158,7 @@ class Solver : public LmBackend {
     int assemble_local(double lambda, double diag_extra, bool for_factor = false);
     int assemble_finish();
     int assemble_implicit(double lambda);
-    int implicit_pcg_solve(double lambda);
+    int implicit_pcg_solve(double lambda, int max_iter, double tol);
     int implicit_matvec(const double* x, double lam_local, double* y, bool reduce);
     int ensure_scale_buffers();
     int column_norms_sq_device();   // -> n2 in cam_scale_ / pt_scale_ (camera part all-reduced over the shards)
@@ -193,6 +205,7 @@ class Solver : public LmBackend {
     int upload_staged(void* dst_dev, const void* src_host, size_t bytes);
     void* pin_[2] = {nullptr, nullptr};
     hipEvent_t pin_ev_[2] = {nullptr, nullptr};
+    bool pin_busy_[2] = {false, false};   // pin_ev_[b] has been recorded behind a DMA out of pin_[b] and not waited for yet
     double *poses_[2] = {nullptr, nullptr}, *intr_[2] = {nullptr, nullptr}, *pts_[2] = {nullptr, nullptr};
     double* camp_[2] = {nullptr, nullptr};  // prepared cameras of the two parameter sets
     RowTask* rtasks2_ = nullptr;     // k_schur_rows2: the same row tasks over chunks of entries
@@ -207,13 +220,17 @@ class Solver : public LmBackend {
     uint32_t* wg_cam_list_ = nullptr;
     bool cam_staging_ = true;
     bool matrix_free_only_ = false;
+    bool auto_variant_ = true, auto_fallback_ = false;   // see set_auto_variant
+    std::string fallback_reason_;
     bool rec_backsub_ = true;
     bool orec_fresh_ = false;   // orec_ holds the records of the current parameters' last linearisation
     const double* backsub_records() const { return rec_backsub_ && orec_fresh_ ? orec_ : nullptr; }
     double* orec_ = nullptr;   // [local observations][4] projection records written by k_landmark_reduce (pair kernel, record form)
     int n_ptasks_ = 0;
     int64_t n_pair_blocks_ = 0, n_pair_slots_ = 0;
-    int rows_form_ = 4;              // 3 (default): sorted pair list reduced over the lanes of a wave (k_schur_pairs_r: every block
+    bool pair_queued_ = false;       // what build_pair_lists arrived at (PairLists::queued)
+    int rows_form_ = 4;              // 4 (default): the sorted pair list in the QUEUED layout (every lane group owns a block, no fold:
+                                     // schur_pairs.h); 3: the same list reduced over the lanes of a wave (k_schur_pairs_r: every block
                                      // S(ci, cj) stored once by one wave, no atomics, no LDS accumulators); 2: the LDS row form,
                                      // one lane per observation (k_schur_rows2: 6.0 ms against 3.6-3.8 on final-13682), kept
                                      // as the A/B.  Select before set_structure.  (Rounds 1-3 also carried a global-atomics

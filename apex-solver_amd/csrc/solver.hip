@@ -72,10 +72,13 @@ int Solver::upload_staged(void* dst_dev, const void* src_host, size_t bytes) {
     for (size_t off = 0; off < bytes; off += kChunk, ++i) {
         const int b = (int)(i & 1);
         const size_t n = std::min(kChunk, bytes - off);
-        if (i >= 2) HIP_TRY(hipEventSynchronize(pin_ev_[b]));
+        // a pinned chunk is rewritten only when the DMA that last read it has finished -- also the one a PREVIOUS call (or a
+        // call that returned early on an error) left in flight
+        if (pin_busy_[b]) { HIP_TRY(hipEventSynchronize(pin_ev_[b])); pin_busy_[b] = false; }
         memcpy(pin_[b], static_cast<const char*>(src_host) + off, n);
         HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst_dev) + off, pin_[b], n, hipMemcpyHostToDevice, stream_));
         HIP_TRY(hipEventRecord(pin_ev_[b], stream_));
+        pin_busy_[b] = true;
     }
     return kOk;
 }
@@ -230,8 +233,22 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         so.schur_form = -1;
     }
     tp_.enable_graphs(use_graphs_);
+    auto_fallback_ = false; fallback_reason_.clear();
     {
-        const std::string e = tp_.build(nt_, hs.present, stream_);
+        std::string e = tp_.build(nt_, hs.present, stream_);
+        // A structure whose direct factorisation is out of reach (a photo collection: S dense at tile granularity) is not an
+        // error of the caller's: the reference's LM never fails on the fill of S.  The handle becomes matrix-free only by itself
+        // and answers every variant with the matrix-free PCG (set_auto_variant).  The update-list rule is pure host arithmetic
+        // on the replicated structure (every rank decides alike); the memory rule depends on the device and is single-rank only.
+        const bool refused_size = tp_.refused_too_large(), refused_mem = tp_.refused_no_memory() && world_ == 1;
+        if (!e.empty() && auto_variant_ && !matrix_free_only_ && (refused_size || refused_mem)) {
+            auto_fallback_ = true; matrix_free_only_ = true;
+            fallback_reason_ = "the direct factorisation of S was refused (" + e + "): matrix-free PCG (IterativeSchurSolver semantics) selected";
+            std::fill(hs.present.begin(), hs.present.end(), (uint8_t)0);
+            for (int I = 0; I < nt_; ++I) hs.present[(size_t)I * nt_ + I] = 1;
+            so.schur_form = -1;
+            e = tp_.build(nt_, hs.present, stream_);
+        }
         if (!e.empty()) return fail(kInvalidInput, "reduced camera matrix: " + e);
     }
     hs.seconds[2] = since(t_plan);
@@ -240,7 +257,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     hs.release_scratch();
     n_rtasks_ = (int)hs.rtasks2.size();
     n_ptasks_ = (int)hs.pl.tasks.size();
-    n_pair_blocks_ = hs.pl.n_blocks; n_pair_slots_ = (int64_t)hs.pl.recs.size();
+    n_pair_blocks_ = hs.pl.n_blocks; n_pair_slots_ = (int64_t)hs.pl.recs.size(); pair_queued_ = hs.pl.queued;
     const int64_t n_loc = (int64_t)hs.o_cam.size();
     const auto t_up = std::chrono::steady_clock::now();
     const auto &o_cam = hs.o_cam, &o_pt = hs.o_pt, &co_pt = hs.co_pt;
@@ -657,7 +674,7 @@ int Solver::implicit_matvec(const double* x, double lam_local, double* y, bool r
     return check_hip(hipGetLastError(), "implicit_matvec");
 }
 
-int Solver::implicit_pcg_solve(double lambda) {
+int Solver::implicit_pcg_solve(double lambda, int max_iter, double tol) {
     stage_begin(kStFactor);
     const int n = (int)n_c_;
     double *x = dcam_, *r = pcg_buf_, *z = pcg_buf_ + n_c_pad_, *p = pcg_buf_ + 2 * n_c_pad_, *ap = pcg_buf_ + 3 * n_c_pad_;
@@ -671,10 +688,10 @@ int Solver::implicit_pcg_solve(double lambda) {
     HIP_TRY(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     double rz_old = h[0];
-    const double abs_tol = cg_tol_ * std::max(sqrt(h[1]), 1.0);
+    const double abs_tol = tol * std::max(sqrt(h[1]), 1.0);
     const double lam_local = (rank_ == 0) ? lambda : 0.0;  // the all-reduce sums the ranks' partial S p
     int it = 0;
-    for (; it < cg_max_iter_; ++it) {
+    for (; it < max_iter; ++it) {
         const int mrc = implicit_matvec(p, lam_local, ap, true);
         if (mrc != kOk) return mrc;
         launch_dot2(n, p, ap, p, ap, partial_, n_partial_, sc, stream_);
@@ -704,13 +721,19 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     HIP_TRY(hipSetDevice(device_));
     have_step_ = false;
     last_lambda_ = lambda;
+    int pcg_max = cg_max_iter_;
+    double pcg_tol = cg_tol_;
+    if (auto_fallback_ && variant != 2) {   // set_structure selected the matrix-free variant for this handle (set_auto_variant)
+        if (variant == 0) { pcg_max = 500; pcg_tol = 1e-9; }   // IterativeSchurSolver::new (implicit_schur.rs:94-95)
+        variant = 2;
+    }
     int rc = (variant == 2) ? assemble_implicit(lambda) : assemble(lambda, 0.0, variant == 0);
     if (rc != kOk) return rc;
     int lm_err = 0;
     HIP_TRY(hipMemcpyAsync(&lm_err, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     if (lm_err) return fail(kSingularMatrix, "Landmark block is singular");
-    rc = (variant == 2) ? implicit_pcg_solve(lambda) : (variant == 1) ? pcg_solve() : factor_and_solve(lambda);
+    rc = (variant == 2) ? implicit_pcg_solve(lambda, pcg_max, pcg_tol) : (variant == 1) ? pcg_solve() : factor_and_solve(lambda);
     if (rc != kOk) return rc;
     for (int attempt = 0;; ++attempt) {
         stage_begin(kStBackSub);
@@ -772,6 +795,7 @@ int Solver::export_step(double* step_out, double* grad_out) {
 int Solver::dist_phase(int phase, double lambda) {
     if (!have_params_) return fail(kInvalidState, "no parameters set");
     if (!tp_.distributed()) return fail(kInvalidState, "the plan is not distributed (set_shard with world > 1, dist_factor on)");
+    if (matrix_free_only_) return fail(kInvalidState, "this handle was built matrix-free only (\"matrix_free_only\"): the explicit S does not exist");
     HIP_TRY(hipSetDevice(device_));
     switch (phase) {
         case 0: have_step_ = false; last_lambda_ = lambda; return assemble_local(lambda, 0.0, true);

@@ -121,7 +121,9 @@ class TilePlan {
     // groups have at most max_cols columns each, every column with at most max_rows off-diagonal tiles.  0 columns: off;
     // < 0 (default): where the launch starts is chosen by a cost model.  Before build().
     void set_factor_flow(int max_cols, int max_rows) { flow_cols_ = max_cols; if (max_rows > 0) flow_rows_ = max_rows; }
-    int factor_flow_groups() const { return (flow_g1_[0] - flow_g0_[0]) + (flow_g1_[1] - flow_g0_[1]); }   // level groups inside the dataflow launches
+    // level groups inside the dataflow launches THAT RUN: none once a launch has timed out (flow_on_) or while the forward
+    // sweep rides inside the factorisation graph ("fused_forward": enqueue_factor then keeps the level launches)
+    int factor_flow_groups() const { return (!flow_on_ || fuse_forward_) ? 0 : (flow_g1_[0] - flow_g0_[0]) + (flow_g1_[1] - flow_g0_[1]); }
     int factor_flow_cols() const { return flow_cols_; }
     double factor_flow_sim_us() const { return flow_sim_us_[0] + flow_sim_us_[1]; }
     int factor_flow_units() const { return flow_n_[0] + flow_n_[1]; }
@@ -130,6 +132,9 @@ class TilePlan {
     // tools/flow_bench: per-unit stamps of the next factorisations (dispatched, inputs ready, done; 100 MHz) + the unit list
     hipError_t enable_flow_trace();
     hipError_t read_flow_trace(std::vector<FactorUnit>* units, std::vector<unsigned long long>* stamps);
+    bool refused_too_large() const { return refused_ == 1; }
+    bool refused_no_memory() const { return refused_ == 2; }
+    void set_max_updates(int64_t n) { max_updates_ = n > 0 ? n : 80000000LL; }   // (tests lower it to force the refusal on a small problem)
     bool factor_flow_gave_up() { const bool g = flow_gave_up_; flow_gave_up_ = false; return g; }
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
     hipError_t read_flags(int* failed_at);   // pivot flag of the last factorisation (syncs)
@@ -229,6 +234,8 @@ class TilePlan {
     hipStream_t occ_stream_ = nullptr;
     bool post_sweep_status(bool reduce);   // false: the max-reduction over the ranks failed
     bool dry_run_ = false;
+    int refused_ = 0;                       // why the last build() gave up: 1 update list beyond max_updates_, 2 tiles beyond the free memory
+    int64_t max_updates_ = 80000000LL;      // tile products per factorisation a plan may hold (12.7 s at 45 TF/s)
     bool debug_skip_idle_wait_ = false;   // tests only: bring back the round-3 schedule bug (no wait after a level without side-stream work)
     std::vector<SchedOp>* sched_trace_ = nullptr;
     std::vector<PotrfTask> potrf_h_;

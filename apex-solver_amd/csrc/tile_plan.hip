@@ -322,17 +322,21 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     nt_ = nt;
     stream_ = stream;
     const size_t tile_elems = (size_t)kNB * kNB;
+    refused_ = 0;
     std::vector<std::vector<int>> col_rows = symbolic_slots(present);
+    int64_t n_upd = 0;
+    for (int K = 0; K < nt_; ++K) n_upd += (int64_t)col_rows[K].size() * (col_rows[K].size() + 1) / 2;
+    // (the size rule first: it is host arithmetic on the structure, so every rank of a distributed plan decides alike)
+    if (n_upd > max_updates_) { refused_ = 1; return "tile update list too large (" + std::to_string(n_upd) + " tile products per factorisation, limit " + std::to_string(max_updates_) + ")"; }
     if (!dry_run_) {
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const double need = (double)(n_slots_ + nt_) * tile_elems * 8.0;
-        if (need > 0.9 * (double)free_b)
+        if (need > 0.9 * (double)free_b) {
+            refused_ = 2;
             return "the tile matrix needs " + std::to_string(need / 1e9) + " GB; only " + std::to_string(free_b / 1e9) + " GB free";
+        }
     }
-    int64_t n_upd = 0;
-    for (int K = 0; K < nt_; ++K) n_upd += (int64_t)col_rows[K].size() * (col_rows[K].size() + 1) / 2;
-    if (n_upd > 80000000LL) return "tile update list too large (" + std::to_string(n_upd) + ")";
 
 #define TP_TRY(expr) do { if (!dry_run_) { hipError_t _e = (expr); if (_e != hipSuccess) return std::string("HIP error in " #expr ": ") + hipGetErrorString(_e); } } while (0)
     TP_TRY(alloc_zero(&tiles_, (size_t)n_slots_ * tile_elems));

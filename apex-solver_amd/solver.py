@@ -410,6 +410,16 @@ class GpuSchurComplementSolver:
                     n_potrf=int(out[9]), n_trsm=int(out[10]), n_update=int(out[11]),
                     dist_top_columns=int(out[12]), dist_local_fraction=float(out[13]), tree_sharded=bool(out[14]), schur_form=int(out[15]))
 
+    def variant_info(self, asked: "SchurVariant | None" = None) -> dict:
+        """Which variant a solve of `asked` (default: this solver's variant) really runs on this handle, and why: after the
+        automatic selection at initialize_structure (a structure whose direct factorisation was refused) every variant is
+        answered by the matrix-free PCG."""
+        h = self._need()
+        asked = self.variant if asked is None else asked
+        used = C.c_int(0); buf = C.create_string_buffer(512)
+        h.check(h.L.apexgpu_variant_info(h.h, asked.value, C.byref(used), buf, 512))
+        return dict(variant_asked=asked.name, variant_used=SchurVariant(used.value).name, reason=buf.value.decode())
+
     def counters(self) -> dict:
         """Events of this handle's life: dataflow triangular sweeps that timed out and were repeated level by level."""
         h = self._need(); out = (C.c_int64 * 4)()

@@ -236,14 +236,23 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "split_u1" (4)    the updates a level sends into the NEXT level's columns are split: those of its diagonal tiles stay on
  *                     the main stream (the next potrf needs nothing else), the others run on a third stream beside that
  *                     potrf when they are at least this many tasks; 0 = one batch on the main stream (before set_structure)
- *   "potrf_lookahead" (9)  diagonal-tile Cholesky + inverse: 9 = the 16 x 16 pivot blocks on the matrix pipe (round 4),
- *                     8 / 6 / 1 = look-ahead schedule of round 3 with 8 / 6 / 4 waves per workgroup, 0 = without look-ahead
+ *   "potrf_lookahead" (12)  diagonal-tile Cholesky + inverse: 12 (default) / 9 = the 16 x 16 pivot blocks on the matrix pipe
+ *                     (k_potrf_inv_mf, round 4) with twelve / eight waves per workgroup (768 / 512 threads; twelve = nine helper
+ *                     waves for the trailing update, 37 against 40 us per tile), 8 / 6 / 1 = look-ahead schedule of round 3
+ *                     (k_potrf_inv_la) with 8 / 6 / 4 waves per workgroup, 0 = without look-ahead (k_potrf_inv)
  *   "panel_tri" (1)   the panel solves L_IK = S_IK Linv_KK^T skip the 36 of 81 16 x 16 block products that multiply by the zero
  *                     blocks of the triangular inverse (process-wide, before set_structure; 0 = full products, for A/B)
  *   "matrix_free_only" (0)  before set_structure: the handle will only be asked for variant 2 (IterativeSchurSolver semantics):
  *                     S is never formed, so only its diagonal tiles are allocated and no pair list is built -- set-up and LM
  *                     iteration are then independent of the fill of S (an input whose S is dense costs what a banded one
  *                     does); variants 0 / 1 and the exports of S answer APEXGPU_ERR_INVALID_STATE on such a handle
+ *   "auto_variant" (1)  before set_structure: a structure whose direct factorisation is refused -- more than 8e7 tile products
+ *                     per factorisation (S dense at tile granularity: a photo collection), or, on a single rank, tiles beyond
+ *                     the free HBM -- does NOT fail apexgpu_set_structure: the handle is built matrix-free only by itself and
+ *                     apexgpu_solve_augmented / apexgpu_lm_optimize answer variants 0 and 1 with the matrix-free PCG (variant 2;
+ *                     for variant 0 at IterativeSchurSolver's defaults, 500 iterations / 1e-9, for variant 1 at the caller's
+ *                     cg parameters).  apexgpu_variant_info tells.  0: the refusal is APEXGPU_ERR_INVALID_INPUT as before
+ *   "max_tile_updates" (80000000)  tests: the limit of tile products per factorisation above which the plan is refused
  *   "factor_flow" (-1), "factor_flow_rows" (24)  the TOP of the elimination tree -- the trailing level groups with at most
  *                     that many tile columns each, every column with at most "factor_flow_rows" off-diagonal tiles -- is
  *                     factorised by ONE dataflow launch (-1, the default: where the launch starts is chosen by a cost
@@ -289,6 +298,11 @@ int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_
  * operations below them (1 when not distributed), [14] = 1 when the landmarks are sharded by the elimination tree,
  * [15] = form of the Schur reduction in use ("schur_rows") */
 int apexgpu_info(apexgpu_solver* h, double info[16]);
+/* Which variant a solve asked with `asked_variant` runs on this handle (*used_variant; differs only after the automatic
+ * selection of "auto_variant") and why (reason: NUL-terminated, cut to reason_len; empty when nothing was overridden).
+ * The reference never needs it: its LM dispatch (src/optimizer/levenberg_marquardt.rs:1039-1082) does not depend on the
+ * fill of S, and IterativeSchurSolver (src/linalg/sparse/implicit_schur.rs:835-946) is the solver the fall-back restates. */
+int apexgpu_variant_info(apexgpu_solver* h, int asked_variant, int* used_variant, char* reason, int reason_len);
 /* out[0] = dataflow triangular sweeps that timed out and were repeated level by level (see "tri_dataflow"),
  * out[1] = 1 while the handle still uses the dataflow sweeps, out[2] = dataflow factorisations that timed out and were
  * repeated by the level launches (see "factor_flow"), out[3] = level groups inside the dataflow launches of this plan */

@@ -33,6 +33,14 @@ def test_ba_line():
     c = out["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert out["final_cost"] < out["initial_cost"]
+    # round 5: the factorisation against ITS roof, the variant that really ran, and the fall-back figure that does not depend
+    # on the state of the handle (one PCG iteration x the reference's cap) next to the observed one
+    f = out["factor"]
+    assert f["bound"] == "mfma" and f["peak"] == 78.6 and f["frac"] == pytest.approx(f["achieved"] / 78.6) and f["flops_per_factorisation"] > 0
+    assert out["config"]["variant_used"] == "Sparse" and out["config"]["reason"] == ""
+    fb = out["fallback_implicit"]
+    assert fb["cap"] == 500 and fb["ms_per_pcg_iter"] > 0 and fb["bound_ms"] >= fb["ms_per_pcg_iter"] * 500 and len(fb["observed_iterations"]) == 2
+    assert "other_workloads" not in out          # only the headline line carries them
 
 
 def test_pose_graph_line():

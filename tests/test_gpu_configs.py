@@ -373,3 +373,60 @@ def test_mix_shape_vs_oracle(oracle):
                 s.get_schur()
         s.close()
     assert rel(steps[1], steps[0]) < 1e-12
+
+
+# ---- automatic variant selection: a structure whose direct factorisation is refused must not fail the caller (round 5) ----------
+def test_refused_plan_selects_the_matrix_free_variant_by_itself(oracle):
+    """final-13682-mix:0.05 at 1/10 of the named size, through the PLAIN surface (SchurVariant::Sparse, LevenbergMarquardt
+    .optimize), with the plan limit lowered so that this small S is refused the way the full-size one is (8e7 tile products:
+    tile_plan.hip): initialize_structure succeeds, the handle says which variant it runs and why, a solve is the oracle's
+    matrix-free PCG (IterativeSchurSolver at its defaults, implicit_schur.rs:94-95, 835-946) and the LM loop behaves.
+    With "auto_variant" 0 the refusal is the error it used to be (the CPU path would not have returned one:
+    levenberg_marquardt.rs:1039-1082)."""
+    from apex_solver_amd.solver import LevenbergMarquardt, LevenbergMarquardtConfig
+
+    d = pkg.synthetic.make_named("final-13682-mix:0.05", 0.1)
+    with pytest.raises(pkg.capi.LinAlgError, match="tile update list too large"):
+        make(d, "selfcal", opts=(("max_tile_updates", 1000), ("auto_variant", 0)))
+    prob, s = make(d, "selfcal", opts=(("max_tile_updates", 1000),))
+    vi = s.variant_info()
+    print("auto variant:", vi, "tiles", s.info()["tiles"], "of", s.info()["tile_rows"], "rows")
+    assert vi["variant_asked"] == "Sparse" and vi["variant_used"] == "Implicit" and "refused" in vi["reason"] and "tile update list" in vi["reason"]
+    assert s.variant_info(SchurVariant.Iterative)["variant_used"] == "Implicit"
+    assert s.info()["tiles"] == s.info()["tile_rows"]          # the diagonal tiles, nothing else: no fill, no pair list
+    assert s.setup_times()["pair_slots"] == 0
+    lam = 1e-3
+    o = oracle.from_data(d, prob.layout, mode="selfcal", huber_delta=1.0)
+    assert s.compute_cost() == pytest.approx(o.residuals()[0], rel=1e-13)
+    o.linearize()
+    o.set_cg_params(500, 1e-9)
+    istep, ograd = o.solve_augmented(lam, 2)
+    ostep, _, oS, ogred = o.solve_augmented(lam, 0, want_schur=True)
+    step = s.solve_augmented_equation(lam)                       # asked: variant 0
+    nc = prob.layout.cam_dof
+    it_gpu, it_ora = s.info()["pcg_iterations"], o.last_pcg_iters
+    r_gpu = np.linalg.norm(oS @ step[:nc] - ogred); r_ora = np.linalg.norm(oS @ istep[:nc] - ogred)
+    print(f"auto variant solve: pcg iterations gpu / oracle {it_gpu} / {it_ora}, residual {r_gpu:.2e} / {r_ora:.2e}, "
+          f"step vs the oracle's matrix-free step {rel(step, istep):.1e}, vs its Cholesky step {rel(step, ostep):.1e}")
+    assert it_gpu > 0 and abs(it_gpu - it_ora) <= max(3, it_ora // 20)
+    assert rel(s.get_gradient(), ograd) < 1e-12
+    assert r_gpu < 10 * max(r_ora, 1e-9 * max(np.linalg.norm(ogred), 1.0))
+    one_lm_iteration_behaves(s, lam)
+    # where the iteration determines the step (lambda = 1e4) the fall-back IS the direct solve to the PCG tolerance
+    w = s.solve_augmented_equation(1e4)
+    wchol, _ = o.solve_augmented(1e4, 0)
+    print(f"auto variant at lambda 1e4: {s.info()['pcg_iterations']} iterations, step vs the oracle's Cholesky step {rel(w, wchol):.1e}")
+    assert rel(w, wchol) < 1e-7
+    with pytest.raises(pkg.capi.LinAlgError):                    # the explicit S does not exist on such a handle
+        s.get_schur()
+    s.close()
+    # the LM surface: same config a caller of the reference would pass; costs against the oracle's LM with the matrix-free variant
+    _, s2 = make(d, "selfcal", opts=(("max_tile_updates", 1000),))
+    res = LevenbergMarquardt.with_config(LevenbergMarquardtConfig().with_max_iterations(4)).optimize(prob, solver=s2)
+    o2 = oracle.from_data(d, prob.layout, mode="selfcal", huber_delta=1.0)
+    o2.set_cg_params(500, 1e-9)
+    ores = o2.optimize(oracle.LMConfig.default(max_iterations=4, variant=2))
+    print("auto variant LM:", res.status.name, res.iterations, res.initial_cost, "->", res.final_cost, "| oracle (matrix-free):", ores.status, ores.final_cost)
+    assert res.final_cost < 0.5 * res.initial_cost
+    assert res.iterations == ores.iterations and res.final_cost == pytest.approx(ores.final_cost, rel=1e-6)
+    s2.close()
