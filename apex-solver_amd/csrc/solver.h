@@ -197,7 +197,6 @@ class Solver : public LmBackend {
     std::vector<int64_t> intr_col_, pose_col_, pt_col_;
     std::vector<int> o_orig_h_;
     std::thread free_thread_;   // unmaps the set-up's host lists off the caller's path
-    raw_vector<uint32_t> cam_idx_h_, pt_idx_h_;    // the caller's factor list (kept for the Hessian export)
 
     // device
     hipStream_t stream_ = nullptr;

@@ -193,12 +193,9 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     intr_col_.assign(intr_col, intr_col + n_cam_);
     pose_col_.assign(pose_col, pose_col + n_cam_);
     pt_col_.assign(pt_col, pt_col + n_pt_);
-    cam_idx_h_.resize(n_obs_); pt_idx_h_.resize(n_obs_);   // kept for get_hessian_csc
-    parallel_ranges(n_obs_, 1 << 18, [&](int64_t b, int64_t e) {
-        memcpy(cam_idx_h_.data() + b, cam_idx + b, (size_t)(e - b) * sizeof(uint32_t));
-        memcpy(pt_idx_h_.data() + b, pt_idx + b, (size_t)(e - b) * sizeof(uint32_t));
-    });
-    tr.mark("validate, keep the index lists");
+    // (the caller's factor list is NOT kept: get_hessian_csc, the one reader, rebuilds it from the device's observation
+    // lists on demand -- 0.1 s of set-up on final-13682 for an export the LM loop never calls)
+    tr.mark("validate the index lists");
 
     // ---- everything derived from the observation list on the host (ba_structure.h): internal camera order (hub
     // cameras last, nested dissection of the tile graph), tile structure, landmark sharding, observation lists ------
@@ -225,6 +222,114 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         HIP_TRY(dev_alloc(&lam_mask_, hs.lam_mask.size()));
         HIP_TRY(hipMemcpy(lam_mask_, hs.lam_mask.data(), hs.lam_mask.size(), hipMemcpyHostToDevice));
     }
+    // ---- uploads of everything that does not depend on the tile plan, on a thread of their own: the observation lists
+    // (1.7 GB on final-13682), the camera staging lists, the masks and the work arrays go to the device while this thread
+    // builds the tile plan and the pair list (round 5: 0.09 s of copies under 0.27 s of host work) -------------------------
+    const auto t_up = std::chrono::steady_clock::now();
+    double up_seconds = 0.0;
+    const auto &o_cam = hs.o_cam, &o_pt = hs.o_pt, &co_pt = hs.co_pt;
+    const auto &o_uv = hs.o_uv, &co_uv = hs.co_uv;
+    const auto &pt_ptr = hs.pt_ptr, &cam_ptr = hs.cam_ptr;
+    const auto &cam_obs = hs.cam_obs, &co_rank = hs.co_rank;
+    auto up = [&](auto** dptr, const auto& hv) -> hipError_t {
+        using T = typename std::remove_reference<decltype(hv)>::type::value_type;
+        if (*dptr) { hipFree(*dptr); *dptr = nullptr; }
+        hipError_t e = dev_alloc(reinterpret_cast<T**>(dptr), hv.size());
+        if (e != hipSuccess) return e;
+        if (hv.empty()) return hipSuccess;
+        return hipMemcpy(*dptr, hv.data(), hv.size() * sizeof(T), hipMemcpyHostToDevice);
+    };
+    auto alloc = [&](double** p, size_t n) -> hipError_t {
+        if (*p) { hipFree(*p); *p = nullptr; }
+        hipError_t e = dev_alloc(p, n);
+        if (e != hipSuccess) return e;
+        return hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(double));
+    };
+    const bool want_orec = rows_form_ == 3 || rows_form_ == 4 || rec_backsub_;
+    auto upload_lists = [&]() -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        HIP_TRY(hipSetDevice(device_));
+        {   // camera staging lists of the landmark-major kernels (ba_kernels.h, BAView::o_slot)
+            const int64_t n_wg = (n_pt_ + kLmWg - 1) / kLmWg;
+            raw_vector<uint8_t> slot(o_cam.size());
+            std::vector<uint8_t> wn((size_t)std::max<int64_t>(n_wg, 1), 0);
+            raw_vector<uint32_t> wlist((size_t)std::max<int64_t>(n_wg, 1) * kCamStageCap);
+            parallel_ranges(n_wg, 64, [&](int64_t wb, int64_t we) {
+                std::vector<int> where(n_cam_, -1), stamp(n_cam_, -1);
+                for (int64_t w = wb; w < we; ++w) {
+                    const int64_t l0 = w * kLmWg, l1 = std::min<int64_t>(n_pt_, l0 + kLmWg);
+                    int n = 0;
+                    uint32_t* list = wlist.data() + (size_t)w * kCamStageCap;
+                    for (int64_t i = pt_ptr[l0]; i < pt_ptr[l1]; ++i) {
+                        const uint32_t c = o_cam[i];
+                        if (stamp[c] != (int)w) { stamp[c] = (int)w; where[c] = n < kCamStageCap ? n : 255; if (n < kCamStageCap) list[n++] = c; }
+                        slot[i] = (uint8_t)where[c];
+                    }
+                    for (int k = n; k < kCamStageCap; ++k) list[k] = 0;
+                    wn[w] = (uint8_t)n;
+                }
+            });
+            static_assert(kCamStageCap <= 254, "slot 255 means not staged");
+            HIP_TRY(up(&o_slot_, slot));
+            HIP_TRY(up(&wg_cam_n_, wn));
+            HIP_TRY(up(&wg_cam_list_, wlist));
+        }
+        HIP_TRY(up(&o_cam_, o_cam));
+        HIP_TRY(up(&o_pt_, o_pt));
+        HIP_TRY(up(reinterpret_cast<double**>(&o_uv_), o_uv));
+        HIP_TRY(up(&o_orig_, o_orig_h_));
+        HIP_TRY(up(&pt_ptr_, pt_ptr));
+        HIP_TRY(up(&cam_ptr_, cam_ptr));
+        HIP_TRY(up(&cam_obs_, cam_obs));
+        HIP_TRY(up(&co_pt_, co_pt));
+        HIP_TRY(up(&co_rank_, co_rank));
+        HIP_TRY(up(reinterpret_cast<double**>(&co_uv_), co_uv));
+        {
+            std::vector<uint8_t> fp(6 * n_cam_, 0), fi(3 * n_cam_, 0), fl(3 * n_pt_, 0);
+            for (int64_t c = 0; c < n_cam_; ++c) {
+                if (fix_pose) memcpy(fp.data() + 6 * (size_t)cmap_[c], fix_pose + 6 * c, 6);
+                if (fix_intr) memcpy(fi.data() + 3 * (size_t)cmap_[c], fix_intr + 3 * c, 3);
+            }
+            if (fix_pt)
+                for (int64_t l = 0; l < n_pt_; ++l) memcpy(fl.data() + 3 * (size_t)lmap_[l], fix_pt + 3 * l, 3);
+            HIP_TRY(up(&fix_pose_, fp));
+            HIP_TRY(up(&fix_intr_, fi));
+            HIP_TRY(up(&fix_pt_, fl));
+        }
+        for (int w = 0; w < 2; ++w) {
+            HIP_TRY(alloc(&poses_[w], 7 * n_cam_));
+            HIP_TRY(alloc(&intr_[w], 3 * n_cam_));
+            HIP_TRY(alloc(&pts_[w], 3 * n_pt_));
+            HIP_TRY(alloc(&camp_[w], (size_t)(kCamStride + kCamQStride) * n_cam_));   // [n_cam][16] records | [n_cam][10] compact form
+        }
+        HIP_TRY(alloc(&g_c_, n_c_pad_));
+        HIP_TRY(alloc(&g_red_, n_c_pad_));
+        HIP_TRY(alloc(&dcam_, n_c_pad_));
+        HIP_TRY(alloc(&hinv_, (size_t)kLmStride * n_pt_));  // landmark records: Hll^-1 | g_l | point
+        // projection records of the local observations (xn, yn, p_w.z, sqrt(rho')): the record form of the pair kernel
+        if (want_orec) HIP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
+        HIP_TRY(alloc(&g_l_, 3 * n_pt_));
+        HIP_TRY(alloc(&dl_, 3 * n_pt_));
+        HIP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
+        HIP_TRY(alloc(&scal_, 32));
+        HIP_TRY(alloc(&pcg_buf_, 7 * (size_t)n_c_pad_));
+        HIP_TRY(alloc(&lmu_, (size_t)kLmuStride * n_pt_));
+        HIP_TRY(alloc(&sd_, (size_t)n_cam_ * dc_ * dc_));
+        HIP_TRY(alloc(&minv_, (size_t)n_cam_ * dc_ * dc_));
+        if (flags_) hipFree(flags_);
+        HIP_TRY(dev_alloc(&flags_, 4));
+        HIP_TRY(hipMemset(flags_, 0, 4 * sizeof(int)));
+        up_seconds = since(t0);
+        return kOk;
+    };
+    int up_rc = kOk;
+    std::string up_err;
+    std::thread uploader([&] {   // (nothing may escape a thread: an allocation failure becomes this call's status)
+        try { up_rc = upload_lists(); if (up_rc != kOk) up_err = err_; }
+        catch (const std::exception& ex) { up_rc = kDeviceError; up_err = std::string("set_structure uploads: ") + ex.what(); }
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
+
     // ---- symbolic Cholesky fill, slot map and task lists of the tile plan -------------
     const auto t_plan = std::chrono::steady_clock::now();
     if (matrix_free_only_) {   // S is never formed: keep the diagonal tiles (Schur-Jacobi blocks are read from them), nothing else
@@ -234,6 +339,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     }
     tp_.enable_graphs(use_graphs_);
     auto_fallback_ = false; fallback_reason_.clear();
+    std::string plan_err;
     {
         std::string e = tp_.build(nt_, hs.present, stream_);
         // A structure whose direct factorisation is out of reach (a photo collection: S dense at tile granularity) is not an
@@ -249,72 +355,25 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
             so.schur_form = -1;
             e = tp_.build(nt_, hs.present, stream_);
         }
-        if (!e.empty()) return fail(kInvalidInput, "reduced camera matrix: " + e);
+        plan_err = e;
     }
+    if (!plan_err.empty()) { uploader.join(); return fail(kInvalidInput, "reduced camera matrix: " + plan_err); }
     hs.seconds[2] = since(t_plan);
     // ---- task lists of the selected form of the Schur reduction (they need the slot map) ------------------------------
     hs.build_schur_lists(so, tp_.slot_host());
-    hs.release_scratch();
     n_rtasks_ = (int)hs.rtasks2.size();
     n_ptasks_ = (int)hs.pl.tasks.size();
     n_pair_blocks_ = hs.pl.n_blocks; n_pair_slots_ = (int64_t)hs.pl.recs.size(); pair_queued_ = hs.pl.queued;
-    const int64_t n_loc = (int64_t)hs.o_cam.size();
-    const auto t_up = std::chrono::steady_clock::now();
-    const auto &o_cam = hs.o_cam, &o_pt = hs.o_pt, &co_pt = hs.co_pt;
-    const auto &o_uv = hs.o_uv, &co_uv = hs.co_uv;
-    const auto &pt_ptr = hs.pt_ptr, &cam_ptr = hs.cam_ptr;
-    const auto &cam_obs = hs.cam_obs, &co_rank = hs.co_rank;
     const auto& nbr = hs.nbr;
     const std::vector<RowTask>& rtasks2 = hs.rtasks2;
     const std::vector<RowChunk>& rchunks = hs.rchunks;
     const std::vector<RowEntry>& rentries = hs.rentries;
     const PairLists& pl = hs.pl;
-    (void)n_loc;
-
-    // ---- uploads ------------------------------------------------------------------------------------
-    auto up = [&](auto** dptr, const auto& hv) -> hipError_t {
-        using T = typename std::remove_reference<decltype(hv)>::type::value_type;
-        if (*dptr) { hipFree(*dptr); *dptr = nullptr; }
-        hipError_t e = dev_alloc(reinterpret_cast<T**>(dptr), hv.size());
-        if (e != hipSuccess) return e;
-        if (hv.empty()) return hipSuccess;
-        return hipMemcpy(*dptr, hv.data(), hv.size() * sizeof(T), hipMemcpyHostToDevice);
-    };
-    {   // camera staging lists of the landmark-major kernels (ba_kernels.h, BAView::o_slot)
-        const int64_t n_wg = (n_pt_ + kLmWg - 1) / kLmWg;
-        raw_vector<uint8_t> slot(o_cam.size());
-        std::vector<uint8_t> wn((size_t)std::max<int64_t>(n_wg, 1), 0);
-        raw_vector<uint32_t> wlist((size_t)std::max<int64_t>(n_wg, 1) * kCamStageCap);
-        parallel_ranges(n_wg, 64, [&](int64_t wb, int64_t we) {
-            std::vector<int> where(n_cam_, -1), stamp(n_cam_, -1);
-            for (int64_t w = wb; w < we; ++w) {
-                const int64_t l0 = w * kLmWg, l1 = std::min<int64_t>(n_pt_, l0 + kLmWg);
-                int n = 0;
-                uint32_t* list = wlist.data() + (size_t)w * kCamStageCap;
-                for (int64_t i = pt_ptr[l0]; i < pt_ptr[l1]; ++i) {
-                    const uint32_t c = o_cam[i];
-                    if (stamp[c] != (int)w) { stamp[c] = (int)w; where[c] = n < kCamStageCap ? n : 255; if (n < kCamStageCap) list[n++] = c; }
-                    slot[i] = (uint8_t)where[c];
-                }
-                for (int k = n; k < kCamStageCap; ++k) list[k] = 0;
-                wn[w] = (uint8_t)n;
-            }
-        });
-        static_assert(kCamStageCap <= 254, "slot 255 means not staged");
-        HIP_TRY(up(&o_slot_, slot));
-        HIP_TRY(up(&wg_cam_n_, wn));
-        HIP_TRY(up(&wg_cam_list_, wlist));
-    }
-    HIP_TRY(up(&o_cam_, o_cam));
-    HIP_TRY(up(&o_pt_, o_pt));
-    HIP_TRY(up(reinterpret_cast<double**>(&o_uv_), o_uv));
-    HIP_TRY(up(&o_orig_, o_orig_h_));
-    HIP_TRY(up(&pt_ptr_, pt_ptr));
-    HIP_TRY(up(&cam_ptr_, cam_ptr));
-    HIP_TRY(up(&cam_obs_, cam_obs));
-    HIP_TRY(up(&co_pt_, co_pt));
-    HIP_TRY(up(&co_rank_, co_rank));
-    HIP_TRY(up(reinterpret_cast<double**>(&co_uv_), co_uv));
+    uploader.join();
+    if (up_rc != kOk) return fail(up_rc, up_err);
+    hs.release_scratch();
+    tr.mark("plan + Schur lists (observation lists uploading beside them)");
+    const auto t_up2 = std::chrono::steady_clock::now();
     HIP_TRY(up(&rtasks2_, rtasks2));
     HIP_TRY(up(&rchunks_, rchunks));
     HIP_TRY(up(&rentries_, rentries));
@@ -325,56 +384,23 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     if (pqdesc_) { hipFree(pqdesc_); pqdesc_ = nullptr; }
     if (pl.queued) HIP_TRY(up(&pqdesc_, pl.qdesc));
     HIP_TRY(up(&nbr_, nbr));
-    {
-        std::vector<uint8_t> fp(6 * n_cam_, 0), fi(3 * n_cam_, 0), fl(3 * n_pt_, 0);
-        for (int64_t c = 0; c < n_cam_; ++c) {
-            if (fix_pose) memcpy(fp.data() + 6 * (size_t)cmap_[c], fix_pose + 6 * c, 6);
-            if (fix_intr) memcpy(fi.data() + 3 * (size_t)cmap_[c], fix_intr + 3 * c, 3);
-        }
-        if (fix_pt)
-            for (int64_t l = 0; l < n_pt_; ++l) memcpy(fl.data() + 3 * (size_t)lmap_[l], fix_pt + 3 * l, 3);
-        HIP_TRY(up(&fix_pose_, fp));
-        HIP_TRY(up(&fix_intr_, fi));
-        HIP_TRY(up(&fix_pt_, fl));
-    }
-    auto alloc = [&](double** p, size_t n) -> hipError_t {
-        if (*p) { hipFree(*p); *p = nullptr; }
-        hipError_t e = dev_alloc(p, n);
-        if (e != hipSuccess) return e;
-        return hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(double));
-    };
-    for (int w = 0; w < 2; ++w) {
-        HIP_TRY(alloc(&poses_[w], 7 * n_cam_));
-        HIP_TRY(alloc(&intr_[w], 3 * n_cam_));
-        HIP_TRY(alloc(&pts_[w], 3 * n_pt_));
-        HIP_TRY(alloc(&camp_[w], (size_t)(kCamStride + kCamQStride) * n_cam_));   // [n_cam][16] records | [n_cam][10] compact form
-    }
-    HIP_TRY(alloc(&g_c_, n_c_pad_));
-    HIP_TRY(alloc(&g_red_, n_c_pad_));
-    HIP_TRY(alloc(&dcam_, n_c_pad_));
-    HIP_TRY(alloc(&hinv_, (size_t)kLmStride * n_pt_));  // landmark records: Hll^-1 | g_l | point
-    // projection records of the local observations (xn, yn, p_w.z, sqrt(rho')): the record form of the pair kernel
-    if (rows_form_ == 3 || rows_form_ == 4 || rec_backsub_) HIP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
-    HIP_TRY(alloc(&g_l_, 3 * n_pt_));
-    HIP_TRY(alloc(&dl_, 3 * n_pt_));
-    HIP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
-    HIP_TRY(alloc(&scal_, 32));
-    HIP_TRY(alloc(&pcg_buf_, 7 * (size_t)n_c_pad_));
-    HIP_TRY(alloc(&lmu_, (size_t)kLmuStride * n_pt_));
-    HIP_TRY(alloc(&sd_, (size_t)n_cam_ * dc_ * dc_));
-    HIP_TRY(alloc(&minv_, (size_t)n_cam_ * dc_ * dc_));
-    if (flags_) hipFree(flags_);
-    HIP_TRY(dev_alloc(&flags_, 4));
-    HIP_TRY(hipMemset(flags_, 0, 4 * sizeof(int)));
+    up_seconds += since(t_up2);
+    (void)t_up;
 
     HIP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on stream_
-    hs.seconds[4] = since(t_up);
+    hs.seconds[4] = up_seconds;   // (copy time; the first part of it ran beside the plan and the pair list)
     hs.seconds[5] = since(t_begin);
     for (int k = 0; k < 6; ++k) setup_s_[k] = hs.seconds[k];
     tr.mark("set_structure body");
     // the host lists (3.7 GB on final-13682) are unmapped off the caller's path: 0.2 s
     if (free_thread_.joinable()) free_thread_.join();
-    free_thread_ = std::thread([p = hs_owner.release()] { delete p; });
+    {
+        const char* fm = getenv("APEX_SETUP_FREE");   // experiment switch: "sync" frees on the caller's path, "leak" never
+        if (fm && !strcmp(fm, "sync")) hs_owner.reset();
+        else if (fm && !strcmp(fm, "leak")) (void)hs_owner.release();
+        else free_thread_ = std::thread([p = hs_owner.release()] { delete p; });
+    }
+    tr.mark("host lists handed to the free thread");
 
     have_structure_ = true;
     have_params_ = have_step_ = have_trial_ = false;
@@ -1179,6 +1205,24 @@ int Solver::get_hessian_csc(int64_t* nnz_out, int64_t* colptr, int64_t* rowidx, 
     if (world_ > 1) return fail(kInvalidState, "the Hessian export is single-rank");
     if (!nnz_out) return fail(kInvalidInput, "nnz_out is NULL");
     const int64_t total = 9 * n_cam_ + 3 * n_pt_;
+    // the caller's factor list, rebuilt from the device's landmark-major lists (single rank: they hold every observation):
+    // observation k of the device is the caller's o_orig[k], its camera / landmark the internal ones mapped back
+    std::vector<uint32_t> cam_idx_h_(n_obs_), pt_idx_h_(n_obs_);
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if ((int64_t)o_orig_h_.size() != n_obs_) return fail(kInvalidState, "the Hessian export needs every observation on this rank");
+        std::vector<uint32_t> oc(n_obs_), op(n_obs_);
+        HIP_TRY(hipMemcpyAsync(oc.data(), o_cam_, n_obs_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipMemcpyAsync(op.data(), o_pt_, n_obs_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        std::vector<int> linv(n_pt_);
+        for (int64_t l = 0; l < n_pt_; ++l) linv[lmap_[l]] = (int)l;
+        for (int64_t k = 0; k < n_obs_; ++k) {
+            const int64_t i = o_orig_h_[k];
+            cam_idx_h_[i] = (uint32_t)cinv_[oc[k]];
+            pt_idx_h_[i] = (uint32_t)linv[op[k]];
+        }
+    }
     // unique (camera, landmark) couplings and the variables that carry entries
     std::vector<int64_t> order(n_obs_);
     std::iota(order.begin(), order.end(), 0);
