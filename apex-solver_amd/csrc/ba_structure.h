@@ -64,11 +64,20 @@ struct BaHostStructure {
     // (host calls only).  Returns "" or an error message.
     std::string build_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, const uint32_t* cam_idx, const uint32_t* pt_idx,
                             const double* obs_uv, const BaStructOptions& o, TilePlan& tp);
+    // Step 1 in its two halves (round 5): build_order leaves the camera order and the tile structure (`present`) -- all the tile
+    // plan needs, so TilePlan::build may run on another thread beside build_obs_lists, which reads `present` only through
+    // tp.preview_owners and only when needs_owner_preview() (a distributed plan with tree sharding: no overlap then).
+    void build_order(int64_t n_cam, int64_t n_pt, int64_t n_obs, const uint32_t* cam_idx, const uint32_t* pt_idx,
+                     const BaStructOptions& o, TilePlan& tp);
+    std::string build_obs_lists(const uint32_t* cam_idx, const uint32_t* pt_idx, const double* obs_uv, const BaStructOptions& o, TilePlan& tp);
+    static bool needs_owner_preview(const BaStructOptions& o) { return o.world > 1 && o.dist_factor && o.tree_sharding; }
     // Step 2, after tp.build() / tp.build_symbolic(): the task lists of the selected Schur form
     void build_schur_lists(const BaStructOptions& o, const int* slot_host);
     void release_scratch();   // the full-problem lists step 2 needed
 
    private:
+    std::vector<int64_t> lp_;                    // landmark buckets of the caller's list (build_order -> build_obs_lists)
+    raw_vector<int> lobs_;
     raw_vector<uint32_t> cam_i_, pt_i_;          // internal camera / landmark of every observation (caller's order)
     std::vector<int64_t> full_ptr_;
     raw_vector<int> full_obs_;

@@ -22,6 +22,12 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t n_obs_, const uint32_t* cam_idx,
                                          const uint32_t* pt_idx, const double* obs_uv, const BaStructOptions& o, TilePlan& tp) {
+    build_order(n_cam_, n_pt_, n_obs_, cam_idx, pt_idx, o, tp);
+    return build_obs_lists(cam_idx, pt_idx, obs_uv, o, tp);
+}
+
+void BaHostStructure::build_order(int64_t n_cam_, int64_t n_pt_, int64_t n_obs_, const uint32_t* cam_idx,
+                                  const uint32_t* pt_idx, const BaStructOptions& o, TilePlan& tp) {
     const double t_begin = now_s();
     SetupTrace tr;
     n_cam = n_cam_; n_pt = n_pt_; n_obs = n_obs_; dc = o.dc;
@@ -32,8 +38,8 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
     const int rank = o.rank, world = o.world;
 
     // ---- landmark-major view of the full problem in the caller's numbering (counting sort) ------------------------------
-    std::vector<int64_t> lp;
-    raw_vector<int> lobs;
+    std::vector<int64_t>& lp = lp_;
+    raw_vector<int>& lobs = lobs_;
     parallel_bucket_large(n_obs, n_pt, pt_idx, lp, lobs);
     tr.mark("order: landmark buckets");
 
@@ -207,15 +213,10 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
     { std::vector<uint8_t>().swap(adjm); std::vector<uint32_t>().swap(acnt); }
     cam_i_.resize(n_obs);
     parallel_ranges(n_obs, 1 << 16, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) cam_i_[i] = (uint32_t)cmap[cam_idx[i]]; });
-    seconds[0] = now_s() - t_begin;
+    n_present = 0;
+    for (uint8_t b : present) n_present += b;
     tr.mark("order: maps");
-
-    // ---- partition of the elimination tree, landmark sharding ----------------------------------------------------------------
-    const double t1 = now_s();
-    lmap.resize(n_pt);
-    std::iota(lmap.begin(), lmap.end(), 0);
-    tree_shard = false;
-    lm_lo = 0; lm_hi = n_pt;
+    // ---- the plan's partition settings (host calls only) ------------------------------------------------------------------
     tp.set_partition(rank, (o.dist_factor && world > 1) ? world : 1);
     tp.set_own_all(false);
     if (o.dist_selftest > 1 && world == 1) {  // self-test: the distributed schedule for that many ranks, all played by this one
@@ -226,6 +227,24 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
         tc.max_int = [](int*, size_t, hipStream_t) { return true; };
         tp.set_comm(std::move(tc));
     }
+    seconds[0] = now_s() - t_begin;
+}
+
+std::string BaHostStructure::build_obs_lists(const uint32_t* cam_idx, const uint32_t* pt_idx, const double* obs_uv,
+                                             const BaStructOptions& o, TilePlan& tp) {
+    SetupTrace tr;
+    const int cpt = kNB / dc;
+    const int rank = o.rank, world = o.world;
+    std::vector<int64_t>& lp = lp_;
+    raw_vector<int>& lobs = lobs_;
+    (void)cam_idx;
+    // ---- landmark sharding along the partition of the elimination tree ---------------------------------------------------------
+    const double t1 = now_s();
+    lmap.resize(n_pt);
+    std::iota(lmap.begin(), lmap.end(), 0);
+    tree_shard = false;
+    lm_lo = 0; lm_hi = n_pt;
+    if (false) tp.set_partition(rank, (o.dist_factor && world > 1) ? world : 1);
     pad_rank = 0;
     lam_mask.clear();
     // Tree sharding (distributed Cholesky, no communicator-less test shards): a landmark's cameras form a clique of
@@ -234,7 +253,7 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
     // no reduce of S at all, only the top tiles are summed (which the distributed factorisation does anyway).
     // Landmarks seen by top cameras only go to the least loaded rank.  Landmarks are renumbered so that every
     // rank's set is one contiguous internal range.
-    const std::vector<int> owner = (world > 1 && o.dist_factor && o.tree_sharding) ? tp.preview_owners(nt, present) : std::vector<int>();
+    const std::vector<int> owner = needs_owner_preview(o) ? tp.preview_owners(nt, present) : std::vector<int>();
     if (!owner.empty()) {
         std::vector<int> lm_owner(n_pt, -1);
         std::vector<int64_t> load(world, 0);
@@ -329,8 +348,6 @@ std::string BaHostStructure::build_lists(int64_t n_cam_, int64_t n_pt_, int64_t 
     n_pairs = 0;
     for (int64_t l = lm_lo; l < lm_hi; ++l) { const int64_t k = pt_ptr[l + 1] - pt_ptr[l]; n_pairs += k * (k + 1) / 2; }   // 4 M adds
     tr.mark("lists: camera-major");
-    n_present = 0;
-    for (uint8_t b : present) n_present += b;
     seconds[1] = now_s() - t1;
     return "";
 }

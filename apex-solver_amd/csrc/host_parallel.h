@@ -174,7 +174,20 @@ struct NoInitAlloc : std::allocator<T> {
         if (!p) throw std::bad_alloc();
         return static_cast<T*>(p);
     }
-    void deallocate(T* p, size_t) { free(p); }
+    // Big blocks give their pages back with MADV_DONTNEED first, 64 MB at a time: zapping the pages of the set-up's 3.7 GB of
+    // lists is 0.2 s wherever it happens, and inside munmap it happens under the address space's WRITE lock -- the caller's
+    // next mmap / page fault (apexgpu_set_params right behind apexgpu_set_structure: its pinned chunks, numpy's buffers) then
+    // waits for the whole of it although the lists are freed on a background thread.  MADV_DONTNEED takes the lock shared
+    // and in short pieces; the munmap that follows finds nothing left to zap (round 5, tools/setup_probe.py).
+    void deallocate(T* p, size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= (size_t)32 << 20) {
+            constexpr size_t kPiece = (size_t)64 << 20;
+            char* c = reinterpret_cast<char*>(p);
+            for (size_t off = 0; off < bytes; off += kPiece) (void)madvise(c + off, std::min(kPiece, bytes - off), MADV_DONTNEED);
+        }
+        free(p);
+    }
     template <typename U> void construct(U* p) { ::new (static_cast<void*>(p)) U; }
     template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
 };

@@ -69,10 +69,10 @@ constexpr int kPairQPiecePairs = 576;   // a block with more pairs is cut into p
 
 struct PairLists {
     raw_vector<PairRec> recs;     // written once, in parallel (1.5 GB on final-13682)
-    std::vector<PairChunk> chunks;
+    raw_vector<PairChunk> chunks; // (raw: 12 MB / 190 MB on final-13682, initialised by the parallel passes that fill them)
     std::vector<PairBlock> blocks;
     std::vector<PairTask> tasks;
-    std::vector<PairQDesc> qdesc; // queued layout only: 8 per chunk (PairChunk::mask then holds the flush bits of its queues)
+    raw_vector<PairQDesc> qdesc;  // queued layout only: 8 per chunk (PairChunk::mask then holds the flush bits of its queues)
     bool queued = false;
     int64_t n_pairs = 0;      // real pairs (without padding)
     int64_t n_blocks = 0;     // camera-pair blocks that receive contributions

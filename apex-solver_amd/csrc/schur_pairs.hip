@@ -122,8 +122,8 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
             close_task();
         }
         if (total_chunks * 64 > (int64_t)0x7fffffff * 64) { out->tasks.clear(); return; }
-        out->chunks.assign((size_t)total_chunks, PairChunk{0u, 0});
-        out->qdesc.assign((size_t)total_chunks * 8, PairQDesc{0, 0u, 0u});
+        out->chunks.resize((size_t)total_chunks);        // every chunk belongs to one task: initialised in the loop over the tasks
+        out->qdesc.resize((size_t)total_chunks * 8);
         out->recs.resize((size_t)total_chunks * 64);
         tr.mark("pairs: blocks, tasks");
         // descriptors and padding, task by task; a nonet's slot t is (chunk0 + idx % nchunks) * 64 + idx / nchunks + 7 t
@@ -132,6 +132,7 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
             auto slot_of = [&](int idx, int t) { return ((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + idx / tk.nchunks + 7 * t; };
             for (int q = 0; q < tk.nchunks; ++q) {
                 PairQDesc* qd = out->qdesc.data() + ((size_t)tk.chunk0 + q) * 8;
+                out->chunks[(size_t)tk.chunk0 + q] = PairChunk{0u, 0};
                 for (int g = 0; g < 8; ++g) qd[g] = PairQDesc{0, (uint32_t)tk.ci, 0u};
                 out->recs[((size_t)tk.chunk0 + q) * 64 + 63] = PairRec{kPairPad, 0u, 0u, 0u};
             }

@@ -207,8 +207,47 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     so.dist_selftest = dist_selftest_; so.schur_form = rows_form_; so.pair_task_slots = pair_task_slots_;
     std::unique_ptr<BaHostStructure> hs_owner(new BaHostStructure);
     BaHostStructure& hs = *hs_owner;
+    // Camera order and tile structure first; then the tile plan (symbolic fill, task lists, 1.4 GB of device allocations: 0.06-
+    // 0.1 s, mostly serial) is built on a thread of its own BESIDE the observation lists (0.1 s), which do not need it (round 5).
+    // A distributed plan with tree sharding previews the partition inside the list phase on the same TilePlan: no overlap then.
+    hs.build_order(n_cam_, n_pt_, n_obs_, cam_idx, pt_idx, so, tp_);
+    nt_ = hs.nt;
+    std::vector<uint8_t> present_plan = hs.present;   // (the plan's own copy: a matrix-free handle keeps the diagonal only)
+    std::string plan_err;
+    double plan_seconds = 0.0;
+    auto build_plan = [&]() {
+        const auto t_plan = std::chrono::steady_clock::now();
+        (void)hipSetDevice(device_);
+        if (matrix_free_only_) {   // S is never formed: keep the diagonal tiles (Schur-Jacobi blocks are read from them), nothing else
+            std::fill(present_plan.begin(), present_plan.end(), (uint8_t)0);
+            for (int I = 0; I < nt_; ++I) present_plan[(size_t)I * nt_ + I] = 1;
+        }
+        tp_.enable_graphs(use_graphs_);
+        auto_fallback_ = false; fallback_reason_.clear();
+        std::string e = tp_.build(nt_, present_plan, stream_);
+        // A structure whose direct factorisation is out of reach (a photo collection: S dense at tile granularity) is not an
+        // error of the caller's: the reference's LM never fails on the fill of S.  The handle becomes matrix-free only by itself
+        // and answers every variant with the matrix-free PCG (set_auto_variant).  The update-list rule is pure host arithmetic
+        // on the replicated structure (every rank decides alike); the memory rule depends on the device and is single-rank only.
+        const bool refused_size = tp_.refused_too_large(), refused_mem = tp_.refused_no_memory() && world_ == 1;
+        if (!e.empty() && auto_variant_ && !matrix_free_only_ && (refused_size || refused_mem)) {
+            auto_fallback_ = true; matrix_free_only_ = true;
+            fallback_reason_ = "the direct factorisation of S was refused (" + e + "): matrix-free PCG (IterativeSchurSolver semantics) selected";
+            std::fill(present_plan.begin(), present_plan.end(), (uint8_t)0);
+            for (int I = 0; I < nt_; ++I) present_plan[(size_t)I * nt_ + I] = 1;
+            e = tp_.build(nt_, present_plan, stream_);
+        }
+        plan_err = e;
+        plan_seconds = since(t_plan);
+    };
+    if (!stream_) HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    std::thread planner;
+    struct PJoiner { std::thread& t; ~PJoiner() { if (t.joinable()) t.join(); } } pjoiner{planner};
+    const bool plan_beside_lists = !BaHostStructure::needs_owner_preview(so);
+    if (plan_beside_lists)
+        planner = std::thread([&] { try { build_plan(); } catch (const std::exception& ex) { plan_err = std::string("tile plan: ") + ex.what(); } });
     {
-        const std::string e = hs.build_lists(n_cam_, n_pt_, n_obs_, cam_idx, pt_idx, obs_uv, so, tp_);
+        const std::string e = hs.build_obs_lists(cam_idx, pt_idx, obs_uv, so, tp_);
         if (!e.empty()) return fail(kInvalidInput, e);
     }
     n_c_ = hs.n_c; nt_ = hs.nt; n_c_pad_ = hs.n_c_pad;
@@ -319,6 +358,10 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         if (flags_) hipFree(flags_);
         HIP_TRY(dev_alloc(&flags_, 4));
         HIP_TRY(hipMemset(flags_, 0, 4 * sizeof(int)));
+        for (int b = 0; b < 2; ++b) {   // the pinned chunks of upload_staged: mapped here, not in the caller's first set_params
+            if (!pin_[b]) HIP_TRY(hipHostMalloc(&pin_[b], (size_t)16 << 20, hipHostMallocDefault));
+            if (!pin_ev_[b]) HIP_TRY(hipEventCreateWithFlags(&pin_ev_[b], hipEventDisableTiming));
+        }
         up_seconds = since(t0);
         return kOk;
     };
@@ -330,35 +373,11 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
 
-    // ---- symbolic Cholesky fill, slot map and task lists of the tile plan -------------
-    const auto t_plan = std::chrono::steady_clock::now();
-    if (matrix_free_only_) {   // S is never formed: keep the diagonal tiles (Schur-Jacobi blocks are read from them), nothing else
-        std::fill(hs.present.begin(), hs.present.end(), (uint8_t)0);
-        for (int I = 0; I < nt_; ++I) hs.present[(size_t)I * nt_ + I] = 1;
-        so.schur_form = -1;
-    }
-    tp_.enable_graphs(use_graphs_);
-    auto_fallback_ = false; fallback_reason_.clear();
-    std::string plan_err;
-    {
-        std::string e = tp_.build(nt_, hs.present, stream_);
-        // A structure whose direct factorisation is out of reach (a photo collection: S dense at tile granularity) is not an
-        // error of the caller's: the reference's LM never fails on the fill of S.  The handle becomes matrix-free only by itself
-        // and answers every variant with the matrix-free PCG (set_auto_variant).  The update-list rule is pure host arithmetic
-        // on the replicated structure (every rank decides alike); the memory rule depends on the device and is single-rank only.
-        const bool refused_size = tp_.refused_too_large(), refused_mem = tp_.refused_no_memory() && world_ == 1;
-        if (!e.empty() && auto_variant_ && !matrix_free_only_ && (refused_size || refused_mem)) {
-            auto_fallback_ = true; matrix_free_only_ = true;
-            fallback_reason_ = "the direct factorisation of S was refused (" + e + "): matrix-free PCG (IterativeSchurSolver semantics) selected";
-            std::fill(hs.present.begin(), hs.present.end(), (uint8_t)0);
-            for (int I = 0; I < nt_; ++I) hs.present[(size_t)I * nt_ + I] = 1;
-            so.schur_form = -1;
-            e = tp_.build(nt_, hs.present, stream_);
-        }
-        plan_err = e;
-    }
+    // ---- the tile plan: built beside the lists above, or here (distributed plans with tree sharding) -------------
+    if (plan_beside_lists) planner.join(); else build_plan();
+    if (matrix_free_only_) so.schur_form = -1;
     if (!plan_err.empty()) { uploader.join(); return fail(kInvalidInput, "reduced camera matrix: " + plan_err); }
-    hs.seconds[2] = since(t_plan);
+    hs.seconds[2] = plan_seconds;
     // ---- task lists of the selected form of the Schur reduction (they need the slot map) ------------------------------
     hs.build_schur_lists(so, tp_.slot_host());
     n_rtasks_ = (int)hs.rtasks2.size();

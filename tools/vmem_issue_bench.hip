@@ -7,6 +7,9 @@
 //   2 pair-contiguous   lane pairs read 32 contiguous bytes at random places  (32 lines)
 //   3 scattered         every lane its own random 16 B                        (64 lines)
 //   4 scattered 8 B, 5 scattered 4 B
+//   6 octet-contiguous  eight lanes read 128 contiguous, 128-byte aligned bytes at random places (16 x 64 B = 8 L2 lines)
+//   7 16-lane-contiguous  sixteen lanes read 256 contiguous bytes at random places               (16 x 64 B = 4 x 256 B)
+//   (round 5: does an L2 miss cost per 64-byte request or per 128-byte L2 line?  -- what a landmark BUNDLE would buy)
 // Reported: clocks per wave-instruction at the CU level (wall clocks x CUs-worth of waves / instructions issued on a CU).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -27,8 +30,10 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ tab, const uin
             if (SHAPE == 0) off = ((r >> 8) * 0 + ((t * 8 + k) * 1024 + wave * 8192) % (table_bytes - 1024)) & ~1023u, off += 16 * lane;
             else if (SHAPE == 1) { const uint32_t q = __shfl(r, lane & ~3, 64); off = ((q >> 4) % (table_bytes / 64)) * 64 + 16 * (lane & 3); }
             else if (SHAPE == 2) { const uint32_t q = __shfl(r, lane & ~1, 64); off = ((q >> 4) % (table_bytes / 32)) * 32 + 16 * (lane & 1); }
+            else if (SHAPE == 6) { const uint32_t q = __shfl(r, lane & ~7, 64); off = ((q >> 4) % (table_bytes / 128)) * 128 + 16 * (lane & 7); }
+            else if (SHAPE == 7) { const uint32_t q = __shfl(r, lane & ~15, 64); off = ((q >> 4) % (table_bytes / 256)) * 256 + 16 * (lane & 15); }
             else off = ((r >> 4) % (table_bytes / 16)) * 16;
-            if (SHAPE <= 3) { const double2 v = *reinterpret_cast<const double2*>(tab + off); acc += v.x + v.y; }
+            if (SHAPE <= 3 || SHAPE >= 6) { const double2 v = *reinterpret_cast<const double2*>(tab + off); acc += v.x + v.y; }
             else if (SHAPE == 4) { acc += *reinterpret_cast<const double*>(tab + off); }
             else { acc += *reinterpret_cast<const float*>(tab + off); }
         }
@@ -45,11 +50,11 @@ int main(int argc, char** argv) {
     hipMalloc(&idx, h.size() * 4); hipMemcpy(idx, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMalloc(&out, 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const char* names[6] = {"contiguous 16 B", "quad-contiguous 64 B", "pair-contiguous 32 B", "scattered 16 B", "scattered 8 B", "scattered 4 B"};
+    const char* names[8] = {"contiguous 16 B", "quad-contiguous 64 B", "pair-contiguous 32 B", "scattered 16 B", "scattered 8 B", "scattered 4 B", "octet-contiguous 128 B", "16-lane-contiguous 256 B"};
     for (int wgs_per_cu : {1, 2, 4}) {
         const int grid = 256 * wgs_per_cu;
         printf("table %d KB, %d workgroups (of 4 waves) per CU:\n", table_bytes / 1024, wgs_per_cu);
-        for (int s = 0; s < 6; ++s) {
+        for (int s = 0; s < 8; ++s) {
             float best = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
@@ -59,6 +64,8 @@ int main(int argc, char** argv) {
                     case 2: hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, tab, idx, table_bytes, trips, out); break;
                     case 3: hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), 0, 0, tab, idx, table_bytes, trips, out); break;
                     case 4: hipLaunchKernelGGL(k<4>, dim3(grid), dim3(256), 0, 0, tab, idx, table_bytes, trips, out); break;
+                    case 6: hipLaunchKernelGGL(k<6>, dim3(grid), dim3(256), 0, 0, tab, idx, table_bytes, trips, out); break;
+                    case 7: hipLaunchKernelGGL(k<7>, dim3(grid), dim3(256), 0, 0, tab, idx, table_bytes, trips, out); break;
                     default: hipLaunchKernelGGL(k<5>, dim3(grid), dim3(256), 0, 0, tab, idx, table_bytes, trips, out); break;
                 }
                 hipEventRecord(e1); hipEventSynchronize(e1);
