@@ -334,6 +334,11 @@ int apexgpu_info(apexgpu_solver* h, double info[16]) {
     return APEXGPU_OK;
 }
 
+int apexgpu_trim_host_cache(int64_t* released_bytes) {
+    const size_t n = apex::HostBlockCache::get().trim();
+    if (released_bytes) *released_bytes = (int64_t)n;
+    return APEXGPU_OK;
+}
 int apexgpu_variant_info(apexgpu_solver* h, int asked_variant, int* used_variant, char* reason, int reason_len) {
     H_OR_FAIL;
     if (asked_variant != APEXGPU_VARIANT_SPARSE && asked_variant != APEXGPU_VARIANT_ITERATIVE && asked_variant != APEXGPU_VARIANT_IMPLICIT)

@@ -153,6 +153,65 @@ struct SetupTrace {
     }
 };
 
+// The big blocks of the structure set-up (observation lists, the pair list: 3.7 GB on final-13682) come from a process-wide
+// CACHE and go back to it (round 5).  Returning them to the system costs 0.2 s of page zapping wherever it is done -- and done on
+// a background thread it still stalls the caller: while the pages of buffers the GPU driver has seen (hipMemcpy from pageable
+// memory registers them) are unmapped, the caller's next apexgpu_set_params took 0.2-0.39 s instead of 0.012
+// (tools/setup_probe.py, APEX_SETUP_FREE=bg / sync / leak).  A block handed back is kept (up to kKeepBytes in all) and serves the
+// next handle's set-up, which then also skips the first-touch page faults of fresh memory; apexgpu_trim_host_cache() (or
+// APEX_HOST_CACHE=0) returns everything to the system.
+class HostBlockCache {
+   public:
+    static HostBlockCache& get() { static HostBlockCache c; return c; }
+    void* take(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            int best = -1;   // the smallest kept block that fits and is not more than twice the request
+            for (int i = 0; i < (int)kept_.size(); ++i)
+                if (kept_[i].bytes >= bytes && kept_[i].bytes <= 2 * bytes && (best < 0 || kept_[i].bytes < kept_[best].bytes)) best = i;
+            if (best >= 0) {
+                void* p = kept_[best].p;
+                kept_bytes_ -= kept_[best].bytes;
+                live_.push_back(kept_[best]);
+                kept_.erase(kept_.begin() + best);
+                return p;
+            }
+        }
+        void* p = nullptr;
+        if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0 || !p) throw std::bad_alloc();
+        (void)madvise(p, bytes, MADV_HUGEPAGE);
+        std::lock_guard<std::mutex> lk(mu_);
+        live_.push_back(Block{p, bytes});
+        return p;
+    }
+    void give(void* p, size_t) {
+        std::lock_guard<std::mutex> lk(mu_);
+        size_t bytes = 0;
+        for (size_t i = 0; i < live_.size(); ++i)
+            if (live_[i].p == p) { bytes = live_[i].bytes; live_.erase(live_.begin() + i); break; }
+        if (bytes == 0 || !enabled_ || kept_bytes_ + bytes > kKeepBytes) { free(p); return; }
+        kept_.push_back(Block{p, bytes});
+        kept_bytes_ += bytes;
+    }
+    size_t trim() {   // everything kept goes back to the system; returns the bytes released
+        std::vector<Block> drop;
+        size_t n = 0;
+        { std::lock_guard<std::mutex> lk(mu_); drop.swap(kept_); n = kept_bytes_; kept_bytes_ = 0; }
+        for (const Block& b : drop) free(b.p);
+        return n;
+    }
+    size_t kept_bytes() { std::lock_guard<std::mutex> lk(mu_); return kept_bytes_; }
+
+   private:
+    struct Block { void* p; size_t bytes; };
+    HostBlockCache() { const char* e = getenv("APEX_HOST_CACHE"); enabled_ = !(e && e[0] == '0'); }
+    static constexpr size_t kKeepBytes = (size_t)8 << 30;
+    std::mutex mu_;
+    std::vector<Block> kept_, live_;
+    size_t kept_bytes_ = 0;
+    bool enabled_ = true;
+};
+
 // A vector whose resize() leaves trivially constructible elements UNINITIALISED: the set-up fills hundreds of megabytes
 // of lists from parallel loops, and a value-initialising resize would first touch (and page in) all of it from one thread.
 template <typename T>
@@ -164,29 +223,14 @@ struct NoInitAlloc : std::allocator<T> {
     // 400 K page faults)
     T* allocate(size_t n) {
         const size_t bytes = n * sizeof(T);
-        if (bytes >= (size_t)32 << 20) {
-            void* p = nullptr;
-            if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0 || !p) throw std::bad_alloc();
-            (void)madvise(p, bytes, MADV_HUGEPAGE);
-            return static_cast<T*>(p);
-        }
+        if (bytes >= (size_t)32 << 20) return static_cast<T*>(HostBlockCache::get().take(bytes));
         void* p = malloc(bytes ? bytes : 1);
         if (!p) throw std::bad_alloc();
         return static_cast<T*>(p);
     }
-    // Big blocks give their pages back with MADV_DONTNEED first, 64 MB at a time: zapping the pages of the set-up's 3.7 GB of
-    // lists is 0.2 s wherever it happens, and inside munmap it happens under the address space's WRITE lock -- the caller's
-    // next mmap / page fault (apexgpu_set_params right behind apexgpu_set_structure: its pinned chunks, numpy's buffers) then
-    // waits for the whole of it although the lists are freed on a background thread.  MADV_DONTNEED takes the lock shared
-    // and in short pieces; the munmap that follows finds nothing left to zap (round 5, tools/setup_probe.py).
     void deallocate(T* p, size_t n) {
-        const size_t bytes = n * sizeof(T);
-        if (bytes >= (size_t)32 << 20) {
-            constexpr size_t kPiece = (size_t)64 << 20;
-            char* c = reinterpret_cast<char*>(p);
-            for (size_t off = 0; off < bytes; off += kPiece) (void)madvise(c + off, std::min(kPiece, bytes - off), MADV_DONTNEED);
-        }
-        free(p);
+        if (n * sizeof(T) >= (size_t)32 << 20) HostBlockCache::get().give(p, n * sizeof(T));
+        else free(p);
     }
     template <typename U> void construct(U* p) { ::new (static_cast<void*>(p)) U; }
     template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }

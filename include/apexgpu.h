@@ -72,6 +72,13 @@ int apexgpu_create(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int dev
 void apexgpu_destroy(apexgpu_solver* h);
 const char* apexgpu_last_error(const apexgpu_solver* h);
 const char* apexgpu_version(void);
+/* The structure set-up builds its lists (3.7 GB on BAL final-13682) in host blocks that are KEPT by the process, up to 8 GB,
+ * when a handle lets go of them, and serve the next apexgpu_set_structure: handing them back to the system costs 0.2 s of page
+ * zapping that stalls the caller's next GPU calls even from a background thread (tools/setup_probe.py).  This call returns
+ * everything kept to the system (*released_bytes, may be NULL); the environment variable APEX_HOST_CACHE=0 switches the
+ * cache off (blocks are then freed where they are released).  No counterpart in the reference: its symbolic structures
+ * live and die with the solver (src/linearizer/cpu/sparse.rs:54-105). */
+int apexgpu_trim_host_cache(int64_t* released_bytes);
 
 /* ---- structure -------------------------------------------------------------------------------
  * Replaces StructureAware::initialize_structure (src/linalg/mod.rs:116-123; explicit_schur.rs:

@@ -57,3 +57,16 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f == "ba_device.hpp", os.path.join(dp, f)
+
+
+def test_host_block_cache_trims():
+    """apexgpu_trim_host_cache answers without a GPU (nothing kept in a fresh process: 0 bytes) -- the set-up's host blocks
+    are kept by the process for the next handle and this call hands them back."""
+    import ctypes as C
+
+    from apex_solver_amd import capi
+
+    L = capi.load()
+    n = C.c_int64(-1)
+    assert L.apexgpu_trim_host_cache(C.byref(n)) == 0 and n.value >= 0
+    assert L.apexgpu_trim_host_cache(None) == 0
