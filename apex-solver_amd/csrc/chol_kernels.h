@@ -27,7 +27,7 @@ struct FactorUnit {   // one workgroup of the dataflow factorisation of the top 
     int wait_flag[3];     // indices into the version array, -1 = none: [0] the target's previous writer, [1] A final, [2] B final
     int wait_val[3];      // ... proceed when ver[flag] >= val
     int pub;              // index into the version array: += 1 per finished unit (kFlowUnitsPerTile per tile and writer), += 9 by a potrf
-    int kind;             // 0 potrf + inverse, 1 panel solve C = A B^T (in place), 2 update C -= A B^T
+    int kind;             // 0 potrf + inverse, 1 panel solve C = A B^T (in place), 2 update C -= A B^T (one 48 x 48 block), 3 update, the whole tile (publishes 9)
     int strip;            // panel solve: 16-row strip 0..8 of C; update: 48 x 48 block 3 bi + bj of C; potrf: tile column (for the failure flag)
     int pad;
 };

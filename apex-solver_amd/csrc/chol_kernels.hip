@@ -1478,6 +1478,7 @@ __device__ __forceinline__ void flow_wait_unit(const int* ver, const FactorUnit&
     __syncthreads();
 }
 
+constexpr int kFlowFactorThreadsC = 768;   // (= kFlowFactorThreads, needed by the whole-tile unit before its definition)
 // An UPDATE unit: one 48 x 48 block (bi, bj) of C -= A B^T.  Nine waves, one 16 x 16 accumulator each; the two 48 x 144 operand
 // strips are requested in one go (12 16-byte loads per lane, one round trip) and staged whole -- no K loop, one barrier.
 // 36 MFMAs per wave, summed over k in the order of the level kernels (k ascending, four per instruction): same bits.
@@ -1581,13 +1582,95 @@ __device__ __forceinline__ void flow_solve_unit(const FactorUnit& u, double* __r
     flow_publish(ver + u.pub, tid);
 }
 
+
+// A WHOLE-TILE UPDATE unit (round 5, kind 3): all of C -= A B^T in ONE workgroup.  The 48 x 48 units above are made for the
+// critical chain -- nine CUs finish a product in ~6 us, at 1 us of matrix work each: 0.22 us per product with every CU busy,
+// which is why the dataflow launch lost wherever the BULK of a level was inside it (DESIGN_HISTORY, round 4).  The updates
+// that are not on the chain (targets two level groups or more ahead) take this form: twelve waves, the 81 16 x 16 blocks of the
+// target dealt 7 / 6 per wave (21 / 20 / 20 / 20 per SIMD), K in three 48-wide chunks staged through LDS with the next
+// chunk's 16-byte loads in flight under the current chunk's MFMAs, the old values of the target requested under the last
+// chunk.  ~20 us of matrix work per unit and CU = the level kernels' rate, without their launch chain.  Same MFMA sequence per
+// block (k ascending, four per instruction) and the same epilogue expression as the 48 x 48 units and the level kernels: the
+// factor is bit-identical.  Publishes all nine counts of a writer at once.
+__device__ __forceinline__ void flow_update_tile_unit(const FactorUnit& u, double* __restrict__ sA, double* __restrict__ sB,
+                                                      int* __restrict__ ver, int* __restrict__ err, unsigned long long* __restrict__ trace) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rC = coh_rsrc(u.C), rA = coh_rsrc(u.A), rB = coh_rsrc(u.B);
+    flow_wait_unit(ver, u, tid, err);   // the previous writer of the target is done, both operands are final
+    if (trace && tid == 0) trace[1] = wall_clock64();
+    constexpr int NBW = 7;                                     // blocks per wave (waves 9..11: six)
+    const int nb = w < 9 ? 7 : 6, b0 = w < 9 ? 7 * w : 63 + 6 * (w - 9);
+    constexpr int C2 = KS / 2, NCH = NB / KS;                  // 24 double2 per row and chunk, 3 chunks
+    constexpr int NLD = (NB * C2 + kFlowFactorThreadsC - 1) / kFlowFactorThreadsC;   // 3456 double2 per operand and chunk over 768 threads: 5 rounds, the last half empty
+    double2 ra[NLD], rb[NLD];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + kFlowFactorThreadsC * i, row = min(idx / C2, NB - 1), c2 = idx % C2;   // (clamped: a stray lane re-reads the last row)
+            ra[i] = tile_ld2<true>(u.A, rA, row * NB + KS * c + 2 * c2);
+            rb[i] = tile_ld2<true>(u.B, rB, row * NB + KS * c + 2 * c2);
+        }
+    };
+    load_chunk(0);
+    double4_t acc[NBW];
+#pragma unroll
+    for (int q = 0; q < NBW; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double cv[NBW][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        __syncthreads();   // the previous chunk's operand reads are done
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + kFlowFactorThreadsC * i, row = idx / C2, c2 = idx % C2;
+            if (idx < NB * C2) {
+                sA[row * PS + 2 * c2] = ra[i].x; sA[row * PS + 2 * c2 + 1] = ra[i].y;
+                sB[row * PS + 2 * c2] = rb[i].x; sB[row * PS + 2 * c2 + 1] = rb[i].y;
+            }
+        }
+        if (c + 1 < NCH) {
+            load_chunk(c + 1);
+        } else {   // the old values of the target: requested now, consumed behind the last MFMAs
+#pragma unroll
+            for (int q = 0; q < NBW; ++q) {
+                const int b = min(b0 + q, 80), br = b / 9, bc = b - 9 * br;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cv[q][r] = coh_ld1(rC, (16 * br + lk + 4 * r) * NB + 16 * bc + lr);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NBW; ++q) {
+            if (q < nb) {
+                const int b = b0 + q, br = b / 9, bc = b - 9 * br;
+                const double* pa = sA + (16 * br + lr) * PS + lk;
+                const double* pb = sB + (16 * bc + lr) * PS + lk;
+#pragma unroll
+                for (int kk = 0; kk < KS; kk += 4) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kk], pb[kk], acc[q], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NBW; ++q) {
+        if (q < nb) {
+            const int b = b0 + q, br = b / 9, bc = b - 9 * br;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) coh_st1(rC, (16 * br + lk + 4 * r) * NB + 16 * bc + lr, -1.0 * acc[q][r] + 1.0 * cv[q][r]);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(ver + u.pub, kFlowUnitsPerTile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr int kFlowFactorThreads = 768;   // 12 waves: the potrf units' 9 helper waves (+ wave 0 and two idle ones on its SIMD); products use 9
 __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const FactorUnit* __restrict__ units, int* __restrict__ ver,
                                                                      int* __restrict__ fail, int* __restrict__ err,
                                                                      unsigned long long* __restrict__ trace) {
     __shared__ double smem[(NLB + NBK) * BSZ];   // potrf: the tile's 45 lower blocks + 9 inverted diagonal blocks; product: sA | sB
     __shared__ int bad, sync_cnt;
-    static_assert((16 + NB) * PS <= (NLB + NBK) * BSZ && 2 * 48 * kFlowPK <= (NLB + NBK) * BSZ, "the products' staging areas fit in the potrf's");
+    static_assert((16 + NB) * PS <= (NLB + NBK) * BSZ && 2 * 48 * kFlowPK <= (NLB + NBK) * BSZ && 2 * NB * PS <= (NLB + NBK) * BSZ, "the products' staging areas fit in the potrf's");
+    static_assert(kFlowFactorThreadsC == kFlowFactorThreads, "one constant");
     const FactorUnit u = units[blockIdx.x];
     const int tid = threadIdx.x;
     if (trace) {   // (tools/flow_bench: 100 MHz stamps per unit -- dispatched, inputs ready, done)
@@ -1603,6 +1686,8 @@ __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const Factor
         if (tid == 0) __hip_atomic_fetch_add(ver + u.pub, kFlowUnitsPerTile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (u.kind == 1) {
         flow_solve_unit(u, smem, smem + 16 * PS, ver, err, trace);
+    } else if (u.kind == 3) {
+        flow_update_tile_unit(u, smem, smem + NB * PS, ver, err, trace);
     } else {
         flow_update_unit(u, smem, smem + 48 * kFlowPK, ver, err, trace);
     }

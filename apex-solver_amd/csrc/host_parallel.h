@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
+#include <sched.h>
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -21,10 +22,33 @@
 
 namespace apex {
 
+// Threads of the set-up's loops: the CPUs this process may really use -- the affinity mask cut by the cgroup CPU quota --, not
+// the hardware threads the machine shows (a GPU box of this pool shows 256 and grants 16: 128 pooled threads took 0.17 s to
+// start and were throttled by the quota for the rest of the set-up; round 5).  APEX_HOST_THREADS overrides.
 inline unsigned host_threads() {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 4;
-    return std::min<unsigned>(nt, 128);
+    static const unsigned n = [] {
+        if (const char* e = getenv("APEX_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)std::min(v, 256); }
+        unsigned nt = std::thread::hardware_concurrency();
+        if (nt == 0) nt = 4;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) nt = std::min<unsigned>(nt, (unsigned)c); }
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+            char q[64]; long long period = 0;
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && q[0] != 'm' && period > 0) {
+                const long long quota = atoll(q);
+                if (quota > 0) nt = std::min<unsigned>(nt, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+            }
+            fclose(f);
+        } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+            long long quota = -1, period = 0;
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 0; fclose(h); }
+            if (quota > 0 && period > 0) nt = std::min<unsigned>(nt, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+        }
+        return std::min<unsigned>(std::max<unsigned>(nt, 1), 128);
+    }();
+    return n;
 }
 
 // A persistent pool: the set-up runs some thirty parallel loops and creating 128 threads for each costs more than most of

@@ -563,6 +563,16 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         auto lm0 = [&](auto sel) { return *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)quad_bcast(l, sel) + 2 * qq); };
         d.a0 = lm0(std::integral_constant<int, 0>{}); d.a1 = lm0(std::integral_constant<int, 1>{});
         d.a2 = lm0(std::integral_constant<int, 2>{}); d.a3 = lm0(std::integral_constant<int, 3>{});
+        if (ABL & 8192) {   // timing only (round 5): both projection records read from the landmark record's own 128-byte line --
+            // what a bundle [header | records] would cost if every pair's three pieces shared ONE L2 line (its best case)
+            const std::integral_constant<int, 0> k0{};
+            const std::integral_constant<int, 1> k1{};
+            d.i0 = *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)pair_bcast(l, k0) + 8 + 2 * h);
+            d.j0 = *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)pair_bcast(l, k0) + 12 + 2 * h);
+            d.i1 = *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)pair_bcast(l, k1) + 8 + 2 * h);
+            d.j1 = *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)pair_bcast(l, k1) + 12 + 2 * h);
+            return;
+        }
         {
             const std::integral_constant<int, 0> k{};
             d.i0 = *reinterpret_cast<const double2*>(orec + 4 * (size_t)pair_bcast(i, k) + 2 * h);
@@ -962,6 +972,7 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
         else if (ablation == 64 + 4096) PAIRS_Q(false, 64 + 4096);
         else if (ablation == 64 + 5120) PAIRS_Q(false, 64 + 5120);
         else if (ablation == 4096 + 1024) PAIRS_Q(false, 4096 + 1024);
+        else if (ablation == 8192) PAIRS_Q(false, 8192);
         else PAIRS_Q(false, 0);
 #undef PAIRS_Q
         return;

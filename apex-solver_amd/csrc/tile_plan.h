@@ -134,6 +134,7 @@ class TilePlan {
     hipError_t read_flow_trace(std::vector<FactorUnit>* units, std::vector<unsigned long long>* stamps);
     bool refused_too_large() const { return refused_ == 1; }
     bool refused_no_memory() const { return refused_ == 2; }
+    void set_flow_tile_units(bool on) { flow_tile_units_ = on; }   // before build()
     void set_max_updates(int64_t n) { max_updates_ = n > 0 ? n : 80000000LL; }   // (tests lower it to force the refusal on a small problem)
     bool factor_flow_gave_up() { const bool g = flow_gave_up_; flow_gave_up_ = false; return g; }
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
@@ -249,6 +250,7 @@ class TilePlan {
     int flow_first_[2] = {0, 0}, flow_n_[2] = {0, 0};
     double flow_sim_us_[2] = {0.0, 0.0};   // makespan of the list schedule that ordered the units (build())
     bool flow_on_ = true, flow_gave_up_ = false;
+    bool flow_tile_units_ = true;   // off-chain updates of the dataflow launch as whole-tile units (k_factor_flow kind 3)
     int n_flow_tasks_ = 0, n_flow_bwd_ = 0, n_flow_parts_ = 0;
     int n_flow_local_ = 0;   // distributed plans: the forward tasks of phase 0 (the rest: the top columns, phase 1)
     bool tri_flow_ = true;

@@ -585,10 +585,19 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             running[(size_t)u.pub] += inc;
         };
         auto n_upd_of = [&](int st) { return (int)src_of[(size_t)st].size(); };
+        // An update whose target column lies TWO level groups or more above its source column is not on the chain
+        // potrf -> panel solves -> updates of the next group's tiles -> potrf: it runs as ONE whole-tile unit (kind 3, the level
+        // kernels' rate per CU) instead of nine 48 x 48 units made for latency (round 5; "factor_flow_tile" 0: nine everywhere).
         auto emit_updates = [&](int I, int J) {
             const int st = slot_of(I, J);
             for (int n = 0; n < n_upd_of(st); ++n) {
                 const int K = src_of[(size_t)st][n], sa = slot_of(I, K), sb = slot_of(J, K);
+                const bool whole = flow_tile_units_ && group_of[J] > group_of[K] + 1;
+                if (whole) {
+                    emit(FactorUnit{tile_ptr(I, J), tile_ptr(I, K), tile_ptr(J, K), {n > 0 ? st : -1, sa, sb},
+                                    {W * n, W * (n_upd_of(sa) + 1), W * (n_upd_of(sb) + 1)}, st, 3, 0, 0}, W);
+                    continue;
+                }
                 for (int sp = 0; sp < W; ++sp)
                     emit(FactorUnit{tile_ptr(I, J), tile_ptr(I, K), tile_ptr(J, K), {n > 0 ? st : -1, sa, sb},
                                     {W * n, W * (n_upd_of(sa) + 1), W * (n_upd_of(sb) + 1)}, st, 2, sp, 0}, 1);
@@ -617,8 +626,8 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         // producers finish, hence after they started: still a topological order, re-checked below.
         {
             const int base = 0, n = (int)funits.size();
-            auto cost_of = [](const FactorUnit& u) { return u.kind == 0 ? 34.0 : (u.kind == 1 ? 10.0 : 8.0); };   // us, with the hop
-            auto inc_of = [](const FactorUnit& u) { return u.kind == 0 ? W : 1; };
+            auto cost_of = [](const FactorUnit& u) { return u.kind == 0 ? 34.0 : (u.kind == 1 ? 10.0 : (u.kind == 3 ? 30.0 : 8.0)); };   // us, with the hop
+            auto inc_of = [](const FactorUnit& u) { return (u.kind == 0 || u.kind == 3) ? W : 1; };
             std::vector<int> writer(n);           // which writer of its tile a unit belongs to
             {
                 std::vector<int> cnt((size_t)n_slots_, 0);
@@ -733,7 +742,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
                     ok = ok && m <= 96;
                     units += 1 + kFlowUnitsPerTile * (m + m * (m + 1) / 2);
                 }
-                if (!ok || units > 120000) break;   // (the model is evaluated per candidate start: keep plan building in the milliseconds)
+                if (!ok || units > (flow_tile_units_ ? 400000 : 120000)) break;   // (the model is evaluated per candidate start: keep plan building in the milliseconds)
                 level_tail += level_us(gf);
                 if (g1 - gf < 2) continue;
                 double sim = 0.0;

@@ -269,6 +269,10 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     like the sweeps': a launch that gives up is detected in the same apexgpu_solve_augmented, S is
  *                     assembled again and factorised by the level launches, which the handle then keeps
  *                     (apexgpu_counters()[2]); before set_structure
+ *   "factor_flow_tile" (1)  inside that launch an update whose target column lies two level groups or more above its source
+ *                     column runs as ONE whole-tile unit (the level kernels' rate per CU) instead of nine 48 x 48 units built
+ *                     for latency, which lets the cost model hand the launch the throughput-bound MIDDLE levels as well
+ *                     (round 5); 0 = nine units everywhere (round 4); before set_structure
  *   "fused_forward" (0)  run the forward triangular sweep inside the factorisation graph on a third stream
  *   "tri_dataflow" (1)  triangular sweeps of a single-GPU plan as ONE launch each: one workgroup per tile, dependencies
  *                     through per-block flags (k_tri_fwd_flow / k_tri_bwd_flow); 0 = one launch per elimination-tree level.

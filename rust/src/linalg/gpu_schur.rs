@@ -143,6 +143,18 @@ impl GpuSchurComplementSolver {
         check(h, unsafe { apexgpu_set_structure(h, cam_idx.as_ptr(), pt_idx.as_ptr(), uv.as_ptr(), intr_col.as_ptr(), pose_col.as_ptr(),
                                                  pt_col.as_ptr(), fix_pose.as_ptr(), fix_intr.as_ptr(), fix_pt.as_ptr(), huber.unwrap_or(-1.0)) })?;
         check(h, unsafe { apexgpu_set_cg_params(h, self.cg.0, self.cg.1) })?;
+        {
+            // A structure whose direct factorisation the backend refuses (S dense at tile granularity) does not fail: the handle
+            // answers with the matrix-free PCG (IterativeSchurSolver semantics, implicit_schur.rs:835-946).  Say so once.
+            let mut used: c_int = 0;
+            let mut why = [0 as c_char; 512];
+            let asked: c_int = if self.implicit { 2 } else if matches!(self.variant, SchurVariant::Iterative) { 1 } else { 0 };
+            check(h, unsafe { apexgpu_variant_info(h, asked, &mut used, why.as_mut_ptr(), why.len() as c_int) })?;
+            if used != asked {
+                let msg = unsafe { std::ffi::CStr::from_ptr(why.as_ptr()) }.to_string_lossy().into_owned();
+                tracing::warn!("GpuSchurComplementSolver: variant {asked} requested, variant {used} runs: {msg}");
+            }
+        }
         let key = problem as *const Problem as usize;
         registry().lock().map_err(|_| LinAlgError::InvalidState("GPU context registry poisoned".into()))?.insert(key, ctx.clone());
         self.ctx = Some(ctx);

@@ -46,6 +46,11 @@ extern "C" {
         pose_col: *const i64, pt_col: *const i64, fix_pose: *const u8, fix_intr: *const u8, fix_pt: *const u8, huber_delta: f64,
     ) -> c_int;
     pub fn apexgpu_set_cg_params(h: *mut ApexGpuSolver, max_iterations: c_int, tolerance: f64) -> c_int;
+    /// which variant a solve asked with `asked_variant` runs on this handle, and why (round 5: automatic selection of the
+    /// matrix-free PCG when the tile plan of S is refused -- the CPU path never fails on the fill of S)
+    pub fn apexgpu_variant_info(h: *mut ApexGpuSolver, asked_variant: c_int, used_variant: *mut c_int, reason: *mut c_char, reason_len: c_int) -> c_int;
+    /// hand the set-up's cached host blocks back to the system (a long-lived host between two optimize() calls)
+    pub fn apexgpu_trim_host_cache(released_bytes: *mut i64) -> c_int;
     pub fn apexgpu_set_params(h: *mut ApexGpuSolver, poses: *const f64, intr: *const f64, points: *const f64) -> c_int;
     pub fn apexgpu_solve_augmented(h: *mut ApexGpuSolver, lambda: f64, variant: c_int, step_out: *mut f64, grad_out: *mut f64) -> c_int;
     pub fn apexgpu_column_norms(h: *mut ApexGpuSolver, norms_out: *mut f64) -> c_int;
