@@ -92,7 +92,9 @@ def test_distributed_cuts_are_race_free_in_both_phases():
 def test_dataflow_launch_takes_the_top_of_a_dense_block():
     p = lower(18, [(i, j) for i in range(18) for j in range(i)])
     r = chk(p, factor_flow=64, factor_flow_rows=1000)
-    # 18 potrf + 9 units per panel solve (153) and per update (969 = sum of m (m + 1) / 2, m = 1..17): the whole factorisation
-    assert r["violations"] == 0 and r["flow_groups"] == 18 and r["flow_units"] == 18 + 9 * (153 + 969), r
+    # 18 potrf + 9 units per panel solve (153); of the 969 updates (sum of m (m + 1) / 2, m = 1..17) the 153 into the NEXT column
+    # (the critical chain) keep nine 48 x 48 units each, the 816 = C(18, 3) whose target lies two columns or more ahead are one
+    # whole-tile unit each (round 5): the whole factorisation
+    assert r["violations"] == 0 and r["flow_groups"] == 18 and r["flow_units"] == 18 + 9 * (153 + 153) + 816, r
     auto = chk(p)
     assert auto["violations"] == 0 and auto["flow_groups"] >= 10, auto
