@@ -1483,6 +1483,7 @@ constexpr int kFlowFactorThreadsC = 768;   // (= kFlowFactorThreads, needed by t
 // strips are requested in one go (12 16-byte loads per lane, one round trip) and staged whole -- no K loop, one barrier.
 // 36 MFMAs per wave, summed over k in the order of the level kernels (k ascending, four per instruction): same bits.
 constexpr int kFlowPK = NB + 2;   // LDS pitch of a full-K operand row: 292 dwords = 36 mod 64 -> conflict-free b64 operand reads
+template <bool DYN>
 __device__ __forceinline__ void flow_update_unit(const FactorUnit& u, double* __restrict__ sA, double* __restrict__ sB,
                                                  int* __restrict__ ver, int* __restrict__ err, unsigned long long* __restrict__ trace) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1490,7 +1491,7 @@ __device__ __forceinline__ void flow_update_unit(const FactorUnit& u, double* __
     const int wr = w / 3, wc = w % 3;
     const int bi = u.strip / 3, bj = u.strip % 3;
     const __amdgpu_buffer_rsrc_t rC = coh_rsrc(u.C), rA = coh_rsrc(u.A), rB = coh_rsrc(u.B);
-    flow_wait_unit(ver, u, tid, err);   // the previous writer of the target is done, both operands are final
+    if (!DYN) flow_wait_unit(ver, u, tid, err);   // the previous writer of the target is done, both operands are final
     if (trace && tid == 0) trace[1] = wall_clock64();
     const bool act = tid < 576;   // (the workgroup has 12 waves for the potrf units' sake: nine of them work here)
     double cv[4] = {0.0, 0.0, 0.0, 0.0};   // the old values of the block: requested with the operands, consumed last
@@ -1526,12 +1527,13 @@ __device__ __forceinline__ void flow_update_unit(const FactorUnit& u, double* __
         for (int r = 0; r < 4; ++r)
             coh_st1(rC, (48 * bi + 16 * wr + lk + 4 * r) * NB + 48 * bj + 16 * wc + lr, -1.0 * acc[r] + 1.0 * cv[r]);
     }
-    flow_publish(ver + u.pub, tid);
+    if (!DYN) flow_publish(ver + u.pub, tid);
 }
 
 // A PANEL-SOLVE unit: rows 16 s .. 16 s + 15 of C = A Linv^T IN PLACE (C aliases A): a unit reads only the rows it
 // writes, all of them before its first store, so the nine units of a tile do not race.  Wave w owns the 16 x 16 block of
 // columns 16 w; Linv comes whole (18 16-byte loads per lane in flight at once) and is staged in three 48-wide K chunks.
+template <bool DYN>
 __device__ __forceinline__ void flow_solve_unit(const FactorUnit& u, double* __restrict__ sA, double* __restrict__ sB,
                                                 int* __restrict__ ver, int* __restrict__ err, unsigned long long* __restrict__ trace) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1540,7 +1542,7 @@ __device__ __forceinline__ void flow_solve_unit(const FactorUnit& u, double* __r
     const __amdgpu_buffer_rsrc_t rC = coh_rsrc(u.C), rB = coh_rsrc(u.B);
     constexpr int C2 = KS / 2, NCH = NB / KS, NRB = NB * C2 / 576;   // per chunk: 16 x 24 double2 of A (lanes < 384), 6 per thread of B
     static_assert(NB * C2 % 576 == 0 && 16 * C2 <= 576, "staging loops assume whole rounds");
-    flow_wait_unit(ver, u, tid, err);   // the tile carries all its updates, L^-1 of the column's diagonal tile is there
+    if (!DYN) flow_wait_unit(ver, u, tid, err);   // the tile carries all its updates, L^-1 of the column's diagonal tile is there
     if (trace && tid == 0) trace[1] = wall_clock64();
     const bool act = tid < 576;   // (nine of the workgroup's twelve waves work here)
     double2 ra[NCH], rb[NCH][NRB];
@@ -1579,7 +1581,7 @@ __device__ __forceinline__ void flow_solve_unit(const FactorUnit& u, double* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r) coh_st1(rC, (row0 + lk + 4 * r) * NB + 16 * w + lr, acc[r]);
     }
-    flow_publish(ver + u.pub, tid);
+    if (!DYN) flow_publish(ver + u.pub, tid);
 }
 
 
@@ -1592,12 +1594,13 @@ __device__ __forceinline__ void flow_solve_unit(const FactorUnit& u, double* __r
 // chunk.  ~20 us of matrix work per unit and CU = the level kernels' rate, without their launch chain.  Same MFMA sequence per
 // block (k ascending, four per instruction) and the same epilogue expression as the 48 x 48 units and the level kernels: the
 // factor is bit-identical.  Publishes all nine counts of a writer at once.
+template <bool DYN>
 __device__ __forceinline__ void flow_update_tile_unit(const FactorUnit& u, double* __restrict__ sA, double* __restrict__ sB,
                                                       int* __restrict__ ver, int* __restrict__ err, unsigned long long* __restrict__ trace) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     const __amdgpu_buffer_rsrc_t rC = coh_rsrc(u.C), rA = coh_rsrc(u.A), rB = coh_rsrc(u.B);
-    flow_wait_unit(ver, u, tid, err);   // the previous writer of the target is done, both operands are final
+    if (!DYN) flow_wait_unit(ver, u, tid, err);   // the previous writer of the target is done, both operands are final
     if (trace && tid == 0) trace[1] = wall_clock64();
     constexpr int NBW = 7;                                     // blocks per wave (waves 9..11: six)
     const int nb = w < 9 ? 7 : 6, b0 = w < 9 ? 7 * w : 63 + 6 * (w - 9);
@@ -1658,6 +1661,7 @@ __device__ __forceinline__ void flow_update_tile_unit(const FactorUnit& u, doubl
             for (int r = 0; r < 4; ++r) coh_st1(rC, (16 * br + lk + 4 * r) * NB + 16 * bc + lr, -1.0 * acc[q][r] + 1.0 * cv[q][r]);
         }
     }
+    if (DYN) return;
     __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(ver + u.pub, kFlowUnitsPerTile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1685,13 +1689,99 @@ __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const Factor
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ver + u.pub, kFlowUnitsPerTile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (u.kind == 1) {
-        flow_solve_unit(u, smem, smem + 16 * PS, ver, err, trace);
+        flow_solve_unit<false>(u, smem, smem + 16 * PS, ver, err, trace);
     } else if (u.kind == 3) {
-        flow_update_tile_unit(u, smem, smem + NB * PS, ver, err, trace);
+        flow_update_tile_unit<false>(u, smem, smem + NB * PS, ver, err, trace);
     } else {
-        flow_update_unit(u, smem, smem + 48 * kFlowPK, ver, err, trace);
+        flow_update_unit<false>(u, smem, smem + 48 * kFlowPK, ver, err, trace);
     }
     if (trace && tid == 0) trace[2] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------
+// The same units, DYNAMICALLY scheduled (round 5; "factor_flow_dyn", default).  k_factor_flow above gives every unit a
+// workgroup of its own, dispatched in list order, and a unit whose inputs are not there yet holds its CU while it polls: by
+// the launch's own stamps 40 % of the CU time of a dense 32 x 32-tile block is such waiting (tools/flow_bench), more where
+// the real durations drift from the simulated ones the order was made from -- which is what lost the throughput-bound middle
+// levels of final-13682 to the level launches.  Here one persistent workgroup per CU takes READY units from a queue:
+//   pop      slot = head++ (one atomic); wait until q[slot] holds a unit index (only when nothing is ready)
+//   run      the unit, no polling: everything it reads is final
+//   finish   stores acknowledged, barrier; ver[pub] += inc; the unit whose add completes a writer (the count reaches a
+//            multiple of nine) WAKES the units registered for that (tile, writer) node: pending[x] -= 1, and whoever takes
+//            it to zero appends x to the queue (q[tail++] = x).
+// Units, version counters and per-tile writer order are those of the static launch: the factor is bit-identical.  No unit
+// is pushed before its producers' stores were acknowledged, every unit is pushed exactly once, and the units form a DAG:
+// the earliest unfinished unit is always ready or running, so the queue cannot stall whatever the number of resident
+// workgroups.  A workgroup that polls an empty slot for ~2 s raises the error word (as the static launch does); the others
+// watch it and leave.
+// ------------------------------------------------------------------------------------------
+struct FlowDyn {
+    int* pending;            // [n_units] unfinished inputs of every unit (reset from the plan's image before the launch)
+    int* q;                  // [n_units] the ready queue: unit indices in push order, -1 = not yet pushed
+    int* ctr;                // [0] head (next slot to pop), [1] tail (next slot to push)
+    const int* wl_ptr;       // [nodes + 1] waiters of node (tile, writer m): FactorUnit::pad + m - 1
+    const int* wl;           // unit indices
+};
+__global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow_dyn(const FactorUnit* __restrict__ units, int n_units, int* __restrict__ ver,
+                                                                         int* __restrict__ fail, int* __restrict__ err, FlowDyn d,
+                                                                         unsigned long long* __restrict__ trace0) {
+    __shared__ double smem[(NLB + NBK) * BSZ];
+    __shared__ int bad, sync_cnt, s_idx, s_node;
+    const int tid = threadIdx.x;
+    for (;;) {
+        if (tid < 64) {   // wave 0 pops: lane 0 owns the slot, lane 1 watches the error word
+            int idx = -2;
+            int slot = 0;
+            if (tid == 0) slot = __hip_atomic_fetch_add(d.ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (slot < n_units) {
+                int spins = 0;
+                for (;;) {
+                    const int v = tid == 0 ? __hip_atomic_load(d.q + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+                    const bool dead = tid == 1 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    idx = __builtin_amdgcn_readfirstlane(v);
+                    if (idx >= 0) break;
+                    if (__any(dead)) { idx = -2; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kFlowSpinLimit) { if (tid == 0) atomicOr(err, 1); idx = -2; break; }
+                }
+            }
+            if (tid == 0) s_idx = idx;
+        }
+        __syncthreads();
+        const int idx = s_idx;
+        if (idx < 0) return;
+        const FactorUnit u = units[idx];
+        unsigned long long* trace = trace0 ? trace0 + 3 * (size_t)idx : nullptr;
+        if (trace && tid == 0) { trace[0] = wall_clock64(); trace[1] = trace[0]; }
+        if (u.kind == 0) potrf_tile_mf<kFlowFactorThreads / 64, true>(u.C, const_cast<double*>(u.A), u.strip, fail, smem, smem + NLB * BSZ, &bad, &sync_cnt);
+        else if (u.kind == 1) flow_solve_unit<true>(u, smem, smem + 16 * PS, ver, err, trace);
+        else if (u.kind == 3) flow_update_tile_unit<true>(u, smem, smem + NB * PS, ver, err, trace);
+        else flow_update_unit<true>(u, smem, smem + 48 * kFlowPK, ver, err, trace);
+        // ---- finish: publish, and wake whoever waited for the writer this unit completes --------------------------------------
+        __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
+        __syncthreads();                 // ... every wave's; also: all reads of smem and s_idx are done
+        if (tid == 0) {
+            const int inc = (u.kind == 0 || u.kind == 3) ? kFlowUnitsPerTile : 1;
+            const int old = __hip_atomic_fetch_add(ver + u.pub, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int m = (old + inc) / kFlowUnitsPerTile;
+            s_node = (old >= 0 && m > old / kFlowUnitsPerTile) ? u.pad + m - 1 : -1;
+            if (trace) trace[2] = wall_clock64();
+        }
+        __syncthreads();
+        const int node = s_node;
+        if (node >= 0) {
+            const int w0 = d.wl_ptr[node], w1 = d.wl_ptr[node + 1];
+            for (int k = w0 + tid; k < w1; k += kFlowFactorThreads) {
+                const int x = d.wl[k];
+                if (__hip_atomic_fetch_add(d.pending + x, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) {
+                    const int sl = __hip_atomic_fetch_add(d.ctr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(d.q + sl, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __syncthreads();   // (s_node / s_idx are rewritten by the next trip)
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1985,6 +2075,12 @@ void launch_gate(const int* arrived, int expected, int max_micros, hipStream_t s
 void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, hipStream_t s, unsigned long long* trace) {
     if (n_units <= 0) return;
     hipLaunchKernelGGL(k_factor_flow, dim3(n_units), dim3(kFlowFactorThreads), 0, s, units, ver, fail, err, trace);
+}
+void launch_factor_flow_dyn(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, int* pending, int* q, int* ctr,
+                            const int* wl_ptr, const int* wl, int n_workgroups, hipStream_t s, unsigned long long* trace) {
+    if (n_units <= 0) return;
+    FlowDyn d{pending, q, ctr, wl_ptr, wl};
+    hipLaunchKernelGGL(k_factor_flow_dyn, dim3(std::min(n_units, n_workgroups)), dim3(kFlowFactorThreads), 0, s, units, n_units, ver, fail, err, d, trace);
 }
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s, int* arrived) {
     if (n <= 0) return;

@@ -62,6 +62,7 @@ class PoseGraphSolver : public LmBackend {
     void set_two_side(int mode) { tp_.set_two_side(mode); }
     void set_factor_flow(int max_cols, int max_rows) { tp_.set_factor_flow(max_cols, max_rows); }
     void set_factor_flow_tile(bool on) { tp_.set_flow_tile_units(on); }
+    void set_factor_flow_dyn(bool on) { tp_.set_flow_dyn(on); }
     int factor_flow_timeouts() const { return n_factor_flow_timeouts_; }
     void debug_poison_next_factor() { tp_.debug_poison_next_factor(); }
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }

@@ -135,6 +135,8 @@ class TilePlan {
     bool refused_too_large() const { return refused_ == 1; }
     bool refused_no_memory() const { return refused_ == 2; }
     void set_flow_tile_units(bool on) { flow_tile_units_ = on; }   // before build()
+    void set_flow_dyn(bool on) { flow_dyn_ = on; }                 // before build()
+    bool flow_dyn() const { return flow_dyn_; }
     void set_max_updates(int64_t n) { max_updates_ = n > 0 ? n : 80000000LL; }   // (tests lower it to force the refusal on a small problem)
     bool factor_flow_gave_up() { const bool g = flow_gave_up_; flow_gave_up_ = false; return g; }
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
@@ -251,6 +253,17 @@ class TilePlan {
     double flow_sim_us_[2] = {0.0, 0.0};   // makespan of the list schedule that ordered the units (build())
     bool flow_on_ = true, flow_gave_up_ = false;
     bool flow_tile_units_ = true;   // off-chain updates of the dataflow launch as whole-tile units (k_factor_flow kind 3)
+    // dynamic scheduling of the dataflow launch (k_factor_flow_dyn): one image per plan, both phases back to back --
+    // [pending | queue] initial values (copied over the live arrays before every launch), waiter lists, {head, tail} per phase
+    bool flow_dyn_ = true;
+    int* flow_dyn_init_ = nullptr;   // [2 * units]: pending of every unit, then the queue (ready units first, -1 behind)
+    int* flow_dyn_live_ = nullptr;   // the same, live
+    int* flow_wl_ptr_ = nullptr;     // waiter lists of the (tile, writer) nodes, the phases' node numbers back to back
+    int* flow_wl_ = nullptr;
+    int* flow_ctr_init_ = nullptr;   // [4]: {0, ready units of phase 0, 0, ready units of phase 1}
+    int* flow_ctr_ = nullptr;
+    int flow_node_first_[2] = {0, 0};
+    int flow_cus_ = 256;
     int n_flow_tasks_ = 0, n_flow_bwd_ = 0, n_flow_parts_ = 0;
     int n_flow_local_ = 0;   // distributed plans: the forward tasks of phase 0 (the rest: the top columns, phase 1)
     bool tri_flow_ = true;

@@ -105,7 +105,7 @@ void TilePlan::release() {
         return;
     }
     void* ptrs[] = {tiles_, linv_, slot_, diag_slot_, flag_, potrf_tasks_, trsm_tasks_, upd_tasks_, tri_fwd_, tri_bwd_,
-                    flow_fwd_, flow_bwd_, flow_part_, flow_flags_, flow_units_, flow_ver_, flow_trace_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_, gate_cnt_};
+                    flow_fwd_, flow_bwd_, flow_part_, flow_flags_, flow_units_, flow_ver_, flow_trace_, flow_dyn_init_, flow_dyn_live_, flow_wl_ptr_, flow_wl_, flow_ctr_init_, flow_ctr_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_, gate_cnt_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = exch_ = nullptr;
@@ -113,6 +113,7 @@ void TilePlan::release() {
     potrf_tasks_ = nullptr; trsm_tasks_ = upd_tasks_ = nullptr; tri_fwd_ = tri_bwd_ = nullptr;
     flow_fwd_ = flow_bwd_ = nullptr; flow_part_ = nullptr; flow_flags_ = nullptr; n_flow_tasks_ = 0;
     flow_units_ = nullptr; flow_ver_ = nullptr; flow_trace_ = nullptr; flow_n_[0] = flow_n_[1] = 0; flow_on_ = true; flow_gave_up_ = false;
+    flow_dyn_init_ = flow_dyn_live_ = flow_wl_ptr_ = flow_wl_ = flow_ctr_init_ = flow_ctr_ = nullptr;
     sym_tiles_ = nullptr; sym_entries_ = nullptr;
     gate_cnt_ = nullptr;
     for (int i = 0; i < kGraphs; ++i) {
@@ -760,6 +761,55 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         flow_sim_us_[ph] = best_sim;
         funits.insert(funits.end(), best_units.begin(), best_units.end());
     }
+    // ---- dynamic scheduling of the launches (k_factor_flow_dyn): per unit its number of unfinished inputs, per (tile, writer)
+    // node the units that wait for it, the initially ready units at the head of the queue.  Unit and node numbers are local
+    // to a phase; FactorUnit::pad = first node of the unit's target tile.
+    {
+        constexpr int W = kFlowUnitsPerTile;
+        const int n_all = (int)funits.size();
+        std::vector<int> image((size_t)2 * std::max(n_all, 1), -1), wl_ptr(1, 0), wl, ctr(4, 0);
+        for (int ph = 0; ph < 2; ++ph) {
+            const int first = flow_first_[ph], n = flow_n_[ph];
+            flow_node_first_[ph] = (int)wl_ptr.size() - 1;
+            if (n == 0) continue;
+            std::vector<int> total((size_t)n_slots_, 0), node0((size_t)n_slots_ + 1, 0);
+            for (int x = 0; x < n; ++x) { const FactorUnit& u = funits[(size_t)first + x]; total[(size_t)u.pub] += (u.kind == 0 || u.kind == 3) ? W : 1; }
+            for (int sl = 0; sl < n_slots_; ++sl) node0[(size_t)sl + 1] = node0[(size_t)sl] + total[(size_t)sl] / W;
+            const int n_nodes = node0[(size_t)n_slots_];
+            std::vector<std::vector<int>> lists((size_t)n_nodes);
+            int* pending = image.data() + 2 * (size_t)first;          // [n] pending, then [n] queue
+            int* queue = pending + n;
+            int n_ready = 0;
+            for (int x = 0; x < n; ++x) {
+                FactorUnit& u = funits[(size_t)first + x];
+                u.pad = node0[(size_t)u.pub];
+                int cnt = 0;
+                for (int q = 0; q < 3; ++q)
+                    if (u.wait_flag[q] >= 0) {
+                        const int m = u.wait_val[q] / W;
+                        if (u.wait_val[q] % W != 0 || m < 1 || m > total[(size_t)u.wait_flag[q]] / W) return "internal error: a dataflow unit waits for a version nobody publishes";
+                        lists[(size_t)node0[(size_t)u.wait_flag[q]] + m - 1].push_back(x);
+                        ++cnt;
+                    }
+                pending[x] = cnt;
+                if (cnt == 0) queue[n_ready++] = x;
+            }
+            if (n_ready == 0) return "internal error: the dataflow launch has no ready unit";
+            ctr[2 * ph] = 0; ctr[2 * ph + 1] = n_ready;
+            for (int nd = 0; nd < n_nodes; ++nd) {
+                wl.insert(wl.end(), lists[(size_t)nd].begin(), lists[(size_t)nd].end());
+                wl_ptr.push_back((int)wl.size());
+            }
+        }
+        if (wl.empty()) wl.push_back(0);
+        TP_TRY(upload(&flow_dyn_init_, image));
+        TP_TRY(upload(&flow_dyn_live_, image));
+        TP_TRY(upload(&flow_wl_ptr_, wl_ptr));
+        TP_TRY(upload(&flow_wl_, wl));
+        TP_TRY(upload(&flow_ctr_init_, ctr));
+        TP_TRY(upload(&flow_ctr_, ctr));
+        if (!dry_run_) { int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) flow_cus_ = cus; }
+    }
     potrf_h_ = potrf; trsm_h_ = trsm; upd_h_ = upd; flow_units_h_ = funits;   // (kept for check_schedule / the tools: small)
     TP_TRY(upload(&flow_units_, funits));
     if (flow_ver_ && !dry_run_) { (void)hipFree(flow_ver_); flow_ver_ = nullptr; }
@@ -1024,6 +1074,16 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         (void)hipMemsetAsync(flow_ver_, 0, (size_t)n_slots_ * sizeof(int), stream_);
         if (poison_factor_ && !tr)   // (tests: the version of the first unit's tile starts hugely negative and is never reached)
             (void)hipMemsetAsync(flow_ver_ + flow_units_h_[(size_t)flow_first_[ph]].pub, 0x80, sizeof(int), stream_);
+        if (flow_dyn_ && !tr) {
+            const size_t first = (size_t)flow_first_[ph], n = (size_t)flow_n_[ph];
+            (void)hipMemcpyAsync(flow_dyn_live_ + 2 * first, flow_dyn_init_ + 2 * first, 2 * n * sizeof(int), hipMemcpyDeviceToDevice, stream_);
+            (void)hipMemcpyAsync(flow_ctr_ + 2 * ph, flow_ctr_init_ + 2 * ph, 2 * sizeof(int), hipMemcpyDeviceToDevice, stream_);
+            if (poison_factor_)   // (tests: the first ready unit is never found in the queue -- its slot stays empty)
+                (void)hipMemsetAsync(flow_dyn_live_ + 2 * first + n, 0xFF, sizeof(int), stream_);
+            launch_factor_flow_dyn(flow_units_ + first, (int)n, flow_ver_, flag_, flag_ + 1, flow_dyn_live_ + 2 * first, flow_dyn_live_ + 2 * first + n,
+                                   flow_ctr_ + 2 * ph, flow_wl_ptr_ + flow_node_first_[ph], flow_wl_, flow_cus_, stream_,
+                                   flow_trace_ ? flow_trace_ + 3 * first : nullptr);
+        } else
         launch_factor_flow(flow_units_ + flow_first_[ph], flow_n_[ph], flow_ver_, flag_, flag_ + 1, stream_,
                            flow_trace_ ? flow_trace_ + 3 * (size_t)flow_first_[ph] : nullptr);
     }

@@ -16,6 +16,8 @@ using namespace apex;
 
 int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 18, reps = argc > 2 ? atoi(argv[2]) : 5;
+    const bool tile_units = argc > 3 ? atoi(argv[3]) != 0 : true;   // whole-tile update units off the chain (round 5)
+    const bool dyn = argc > 4 ? atoi(argv[4]) != 0 : true;          // dynamic scheduling of the units (round 5)
     const size_t te = (size_t)kNB * kNB;
     std::vector<uint8_t> present((size_t)T * T, 0);
     for (int i = 0; i < T; ++i) for (int j = 0; j <= i; ++j) present[(size_t)i * T + j] = 1;
@@ -27,6 +29,8 @@ int main(int argc, char** argv) {
     for (int mode = 0; mode < 2; ++mode) {   // 0: level launches, 1: dataflow
         TilePlan tp;
         tp.set_factor_flow(mode ? 64 : 0, 1000);
+        tp.set_flow_tile_units(tile_units);
+        tp.set_flow_dyn(dyn);
         const std::string err = tp.build(T, present, st);
         if (!err.empty()) { printf("build: %s\n", err.c_str()); return 1; }
         for (int I = 0; I < T; ++I)
@@ -78,10 +82,10 @@ int main(int argc, char** argv) {
             printf("launch span by the stamps: %.1f us\n", (t1 - t0) * 0.01);
             auto us = [&](unsigned long long t) { return (t - t0) * 0.01; };
             // per kind: how long units wait after dispatch, how long they work
-            double w[3] = {0, 0, 0}, d[3] = {0, 0, 0}; int n[3] = {0, 0, 0};
+            double w[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0}; int n[4] = {0, 0, 0, 0};
             for (size_t i = 0; i < u.size(); ++i) { const int k = u[i].kind; w[k] += (s[3 * i + 1] - s[3 * i]) * 0.01; d[k] += (s[3 * i + 2] - s[3 * i + 1]) * 0.01; ++n[k]; }
-            for (int k = 0; k < 3; ++k)
-                if (n[k]) printf("  kind %d (%s): %5d units, mean wait after dispatch %.1f us, mean work %.1f us\n", k, k == 0 ? "potrf" : k == 1 ? "panel" : "update", n[k], w[k] / n[k], d[k] / n[k]);
+            for (int k = 0; k < 4; ++k)
+                if (n[k]) printf("  kind %d (%s): %5d units, mean wait after dispatch %.1f us, mean work %.1f us\n", k, k == 0 ? "potrf" : k == 1 ? "panel" : k == 2 ? "update 48x48" : "update, whole tile", n[k], w[k] / n[k], d[k] / n[k]);
             // the chain: potrf K -> the nine panel units of the tile below the diagonal -> the nine units of the last update of
             // the next diagonal tile -> potrf K+1.  Per group of nine: last dispatch | first ready .. last ready | last done
             printf("  potrf: dispatched ready done | panel (K+1,K): disp<= ready[first..last] done<= | update (K+1,K+1)<-K: disp<= ready[first..last] done<=\n");
