@@ -1699,7 +1699,7 @@ __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const Factor
 }
 
 // ------------------------------------------------------------------------------------------
-// The same units, DYNAMICALLY scheduled (round 5; "factor_flow_dyn", default).  k_factor_flow above gives every unit a
+// The same units, DYNAMICALLY scheduled (round 5; "factor_flow_dyn" 1 -- NOT the default: measured below).  k_factor_flow above gives every unit a
 // workgroup of its own, dispatched in list order, and a unit whose inputs are not there yet holds its CU while it polls: by
 // the launch's own stamps 40 % of the CU time of a dense 32 x 32-tile block is such waiting (tools/flow_bench), more where
 // the real durations drift from the simulated ones the order was made from -- which is what lost the throughput-bound middle
@@ -1714,7 +1714,27 @@ __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const Factor
 // the earliest unfinished unit is always ready or running, so the queue cannot stall whatever the number of resident
 // workgroups.  A workgroup that polls an empty slot for ~2 s raises the error word (as the static launch does); the others
 // watch it and leave.
+// MEASURED (profiles/r05_flow_bench_dyn.txt, r05_flow_dyn_sweep.txt): bit-identical, no CU ever waits with a unit in hand --
+// and slower: dense 18 x 18 tiles 1,017 us against 947 static, 32 x 32 2,216 against 1,823, final-13682 6.85 against 6.58 ms.
+// These launches are bound by their dependency CHAIN, and a chain hop through finish -> wake -> push -> pop -> descriptor
+// load costs ~4 us more than a waiting workgroup's polled flag; the CU time the static launch wastes on waiting (40 % on the
+// 32 x 32 block) was idle capacity, not lost throughput.  Kept as the A/B.
 // ------------------------------------------------------------------------------------------
+// (the four unit bodies as real functions: inlined into one loop the register allocator keeps pieces of all of them alive around
+// the back edge and spills 134 VGPRs -- every unit then ran 30-40 % longer than in the static launch)
+__device__ __noinline__ void dyn_unit_potrf(const FactorUnit* up, int* fail, double* smem, int* bad, int* sync_cnt) {
+    const FactorUnit u = *up;
+    potrf_tile_mf<kFlowFactorThreadsC / 64, true>(u.C, const_cast<double*>(u.A), u.strip, fail, smem, smem + NLB * BSZ, bad, sync_cnt);
+}
+__device__ __noinline__ void dyn_unit_solve(const FactorUnit* up, double* smem, unsigned long long* trace) {
+    flow_solve_unit<true>(*up, smem, smem + 16 * PS, nullptr, nullptr, trace);
+}
+__device__ __noinline__ void dyn_unit_update(const FactorUnit* up, double* smem, unsigned long long* trace) {
+    flow_update_unit<true>(*up, smem, smem + 48 * kFlowPK, nullptr, nullptr, trace);
+}
+__device__ __noinline__ void dyn_unit_update_tile(const FactorUnit* up, double* smem, unsigned long long* trace) {
+    flow_update_tile_unit<true>(*up, smem, smem + NB * PS, nullptr, nullptr, trace);
+}
 struct FlowDyn {
     int* pending;            // [n_units] unfinished inputs of every unit (reset from the plan's image before the launch)
     int* q;                  // [n_units] the ready queue: unit indices in push order, -1 = not yet pushed
@@ -1754,10 +1774,10 @@ __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow_dyn(const Fa
         const FactorUnit u = units[idx];
         unsigned long long* trace = trace0 ? trace0 + 3 * (size_t)idx : nullptr;
         if (trace && tid == 0) { trace[0] = wall_clock64(); trace[1] = trace[0]; }
-        if (u.kind == 0) potrf_tile_mf<kFlowFactorThreads / 64, true>(u.C, const_cast<double*>(u.A), u.strip, fail, smem, smem + NLB * BSZ, &bad, &sync_cnt);
-        else if (u.kind == 1) flow_solve_unit<true>(u, smem, smem + 16 * PS, ver, err, trace);
-        else if (u.kind == 3) flow_update_tile_unit<true>(u, smem, smem + NB * PS, ver, err, trace);
-        else flow_update_unit<true>(u, smem, smem + 48 * kFlowPK, ver, err, trace);
+        if (u.kind == 0) dyn_unit_potrf(units + idx, fail, smem, &bad, &sync_cnt);
+        else if (u.kind == 1) dyn_unit_solve(units + idx, smem, trace);
+        else if (u.kind == 3) dyn_unit_update_tile(units + idx, smem, trace);
+        else dyn_unit_update(units + idx, smem, trace);
         // ---- finish: publish, and wake whoever waited for the writer this unit completes --------------------------------------
         __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
         __syncthreads();                 // ... every wave's; also: all reads of smem and s_idx are done

@@ -255,7 +255,7 @@ class TilePlan {
     bool flow_tile_units_ = true;   // off-chain updates of the dataflow launch as whole-tile units (k_factor_flow kind 3)
     // dynamic scheduling of the dataflow launch (k_factor_flow_dyn): one image per plan, both phases back to back --
     // [pending | queue] initial values (copied over the live arrays before every launch), waiter lists, {head, tail} per phase
-    bool flow_dyn_ = true;
+    bool flow_dyn_ = false;          // measured slower than the static launch wherever it was tried (chol_kernels.hip, k_factor_flow_dyn): the A/B
     int* flow_dyn_init_ = nullptr;   // [2 * units]: pending of every unit, then the queue (ready units first, -1 behind)
     int* flow_dyn_live_ = nullptr;   // the same, live
     int* flow_wl_ptr_ = nullptr;     // waiter lists of the (tile, writer) nodes, the phases' node numbers back to back

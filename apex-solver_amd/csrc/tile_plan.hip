@@ -731,6 +731,9 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             auto level_us = [&](int g) {
                 double prod = 0.0;
                 for (int K : level_cols[g]) { const double m = (double)col_rows[K].size(); prod += m + 0.5 * m * (m + 1.0); }
+                // (round 5: by the timeline a middle level of final-13682 really takes 140-250 us, ~90 + 0.11 prod -- but the launch's
+                // own simulated time is as optimistic there, and the starts this pair of models picks ARE the measured optima:
+                // profiles/r05_flow_dyn_sweep.txt.  Both left as they are.)
                 return std::max(80.0, 0.14 * prod);
             };
             double level_tail = 0.0, best_total = 0.0;   // cost of the groups [gf, g1) by level launches; best (level head dropped: common)

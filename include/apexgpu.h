@@ -273,11 +273,12 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     column runs as ONE whole-tile unit (the level kernels' rate per CU) instead of nine 48 x 48 units built
  *                     for latency, which lets the cost model hand the launch the throughput-bound MIDDLE levels as well
  *                     (round 5); 0 = nine units everywhere (round 4); before set_structure
- *   "factor_flow_dyn" (1)  the units of that launch are scheduled DYNAMICALLY: one persistent workgroup per CU takes ready units
- *                     from a queue, and the unit that completes a writer of a tile wakes the units that waited for it
- *                     (k_factor_flow_dyn, round 5) -- no CU is held by a unit that polls for its inputs; 0 = one workgroup per
- *                     unit dispatched in list order (round 4).  Same units, same order of writers per tile: same bits.
- *                     Before set_structure
+ *   "factor_flow_dyn" (0)  1: the units of that launch are scheduled DYNAMICALLY -- one persistent workgroup per CU takes ready
+ *                     units from a queue, and the unit that completes a writer of a tile wakes the units that waited for it
+ *                     (k_factor_flow_dyn, round 5): no CU is held by a unit that polls for its inputs.  Same units, same order
+ *                     of writers per tile, same bits -- and SLOWER wherever measured (a hop through the queue costs ~4 us more
+ *                     than a polled flag, and the launches are chain-bound: profiles/r05_flow_bench_dyn.txt), hence off: the
+ *                     A/B of the static launch (one workgroup per unit, dispatched in list order).  Before set_structure
  *   "fused_forward" (0)  run the forward triangular sweep inside the factorisation graph on a third stream
  *   "tri_dataflow" (1)  triangular sweeps of a single-GPU plan as ONE launch each: one workgroup per tile, dependencies
  *                     through per-block flags (k_tri_fwd_flow / k_tri_bwd_flow); 0 = one launch per elimination-tree level.
