@@ -24,7 +24,7 @@ SYMBOLS = (
     "apexgpu_step_stats", "apexgpu_eval_step", "apexgpu_commit_step", "apexgpu_discard_step",
     "apexgpu_parameter_norm", "apexgpu_column_norms", "apexgpu_set_column_scaling", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
     "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_get_hessian_csc", "apexgpu_debug_invert_blocks", "apexgpu_debug_pair_lists", "apexgpu_debug_pair_lists_queued", "apexgpu_debug_host_structure", "apexgpu_setup_times", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
-    "apexgpu_stage_times", "apexgpu_info", "apexgpu_variant_info", "apexgpu_trim_host_cache", "apexgpu_counters", "apexgpu_debug_pair_phases", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_comm_init_shm", "apexgpu_set_shard", "apexgpu_shard_range",
+    "apexgpu_stage_times", "apexgpu_info", "apexgpu_variant_info", "apexgpu_trim_host_cache", "apexgpu_counters", "apexgpu_debug_pair_phases", "apexgpu_debug_get_pair_records", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_comm_init_shm", "apexgpu_set_shard", "apexgpu_shard_range",
     "apexgpu_debug_lockstep_solve", "apexgpu_export_step", "apexgpu_owned_landmarks", "apexgpu_debug_partition", "apexgpu_debug_check_schedule",
     "apexgpu_bal_open", "apexgpu_bal_close", "apexgpu_bal_last_error", "apexgpu_bal_sizes", "apexgpu_bal_raw",
     "apexgpu_bal_variables", "apexgpu_reference_columns",
@@ -141,6 +141,7 @@ def load() -> C.CDLL:
     L.apexgpu_stage_times.argtypes = [vp, C.POINTER(dbl * NUM_STAGES), C.POINTER(i64 * NUM_STAGES)]
     L.apexgpu_info.argtypes = [vp, C.POINTER(dbl * 16)]
     L.apexgpu_trim_host_cache.argtypes = [C.POINTER(C.c_int64)]
+    L.apexgpu_debug_get_pair_records.argtypes = [vp, vp, i64]
     L.apexgpu_variant_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_int]
     L.apexgpu_counters.argtypes = [vp, C.POINTER(i64 * 4)]
     L.apexgpu_debug_pair_phases.argtypes = [C.POINTER(i64 * 8), C.c_int]

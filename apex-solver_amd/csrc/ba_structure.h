@@ -72,7 +72,8 @@ struct BaHostStructure {
     std::string build_obs_lists(const uint32_t* cam_idx, const uint32_t* pt_idx, const double* obs_uv, const BaStructOptions& o, TilePlan& tp);
     static bool needs_owner_preview(const BaStructOptions& o) { return o.world > 1 && o.dist_factor && o.tree_sharding; }
     // Step 2, after tp.build() / tp.build_symbolic(): the task lists of the selected Schur form
-    void build_schur_lists(const BaStructOptions& o, const int* slot_host);
+    // dev_tables != NULL (queued layout only): the pair RECORDS are left to the device (PairDeviceTables, schur_pairs.h)
+    void build_schur_lists(const BaStructOptions& o, const int* slot_host, PairDeviceTables* dev_tables = nullptr);
     void release_scratch();   // the full-problem lists step 2 needed
 
    private:

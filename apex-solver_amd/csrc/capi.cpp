@@ -263,7 +263,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
     // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
     static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "panel_tri", "dist_factor", "tree_sharding", "dist_selftest",
-                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "factor_flow_tile", "factor_flow_dyn", "matrix_free_only", "auto_variant", "max_tile_updates"};
+                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "factor_flow_tile", "factor_flow_dyn", "device_pair_list", "matrix_free_only", "auto_variant", "max_tile_updates"};
     if (h->s->has_structure())
         for (const char* k : structural)
             if (n == k) return APEXGPU_ERR_INVALID_STATE;
@@ -280,6 +280,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "two_side") h->s->set_two_side(value);
     else if (n == "matrix_free_only") h->s->set_matrix_free_only(value != 0);
     else if (n == "auto_variant") h->s->set_auto_variant(value != 0);
+    else if (n == "device_pair_list") h->s->set_device_pair_recs(value != 0);
     else if (n == "max_tile_updates") h->s->set_max_tile_updates(value);
     else if (n == "factor_flow") h->s->set_factor_flow(value, 0);          // max columns per level group inside the dataflow launch (0: off)
     else if (n == "factor_flow_tile") h->s->set_factor_flow_tile(value != 0);
@@ -336,6 +337,11 @@ int apexgpu_info(apexgpu_solver* h, double info[16]) {
     return APEXGPU_OK;
 }
 
+int apexgpu_debug_get_pair_records(apexgpu_solver* h, uint32_t* recs4_out, int64_t cap_slots) {
+    H_OR_FAIL;
+    if (!recs4_out) return APEXGPU_ERR_INVALID_INPUT;
+    return guarded([&] { return h->s->get_pair_records(recs4_out, cap_slots); });
+}
 int apexgpu_trim_host_cache(int64_t* released_bytes) {
     const size_t n = apex::HostBlockCache::get().trim();
     if (released_bytes) *released_bytes = (int64_t)n;

@@ -78,13 +78,34 @@ struct PairLists {
     int64_t n_blocks = 0;     // camera-pair blocks that receive contributions
 };
 
+// Round 5: the RECORDS of the queued layout (97 M slots = 1.56 GB on final-13682: 0.1-0.18 s of host time plus 35 ms of upload,
+// the largest single piece of apexgpu_set_structure) can be written by the DEVICE instead: the host keeps what is small and
+// serial -- the blocks of every row, pieces, tasks, descriptors -- and hands over these tables; k_build_pair_recs_q walks the
+// observation lists that are on the device anyway.  Order inside a block: by the row camera's observation, as on the host
+// (a camera that sees one landmark twice may order that block's pairs differently from the host builder: both orders are
+// fixed functions of the lists, the sums they give differ in the last bits only, and no test mixes the two).
+struct PairDeviceTables {
+    std::vector<int> rows;          // [n_cam] internal camera of row r (rows in the caller's camera order)
+    std::vector<int> run_ptr;       // [n_cam + 1] the row's runs (= blocks of S with this row camera)
+    std::vector<uint32_t> run_cj;   // partner camera, ascending inside a row
+    std::vector<int> run_piece0;    // first piece of the run (a run longer than kPairQPiecePairs has several, consecutive)
+    std::vector<int2> piece;        // (task, first nonet inside the task)
+    std::vector<int2> task;         // (first chunk, chunks)
+    int64_t n_slots = 0;
+};
+
 // Host, once per structure.  o_cam / o_pt / pt_ptr: the LOCAL landmark-major observation arrays (observations of one
 // landmark sorted by internal camera index); cam_ptr / cam_obs: their camera-major view; cam_ext[ci]: the caller's index
 // of internal camera ci (rows are processed in the caller's order: consecutive rows then share landmarks);
 // slot: tile slot map (nt x nt, lower).
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
-                      int task_slots = 0 /* 0: default */, bool queued = false);
+                      int task_slots = 0 /* 0: default */, bool queued = false,
+                      PairDeviceTables* dev_tables = nullptr /* queued only: leave out->recs empty and fill these instead */);
+// the records of the queued layout from those tables (all pointers device memory; recs is cleared to padding first)
+hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* run_ptr, const uint32_t* run_cj, const int* run_piece0,
+                                    const int2* piece, const int2* task, const int* cam_ptr, const int* cam_obs, const uint32_t* o_pt,
+                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s);
 
 // The pair kernel (record form: J rebuilt from the 32-byte projection records k_landmark_reduce writes, orec).
 // ablation: timing experiments only (results are wrong when != 0)

@@ -28,7 +28,7 @@ struct Run { uint32_t cj; int len; int piece0; };   // the pairs of one row with
 
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
-                      int task_slots, bool queued) {
+                      int task_slots, bool queued, PairDeviceTables* dev_tables) {
     SetupTrace tr;
     const int cpt = kNB / dc;
     const int kTask = std::min(task_slots > 0 ? (task_slots + 63) / 64 * 64 : kPairTaskSlots, kPairMaxBlockSlots / 2);
@@ -124,7 +124,8 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
         if (total_chunks * 64 > (int64_t)0x7fffffff * 64) { out->tasks.clear(); return; }
         out->chunks.resize((size_t)total_chunks);        // every chunk belongs to one task: initialised in the loop over the tasks
         out->qdesc.resize((size_t)total_chunks * 8);
-        out->recs.resize((size_t)total_chunks * 64);
+        const bool host_recs = dev_tables == nullptr;     // (else the device writes the records: launch_build_pair_recs_q)
+        if (host_recs) out->recs.resize((size_t)total_chunks * 64);
         tr.mark("pairs: blocks, tasks");
         // descriptors and padding, task by task; a nonet's slot t is (chunk0 + idx % nchunks) * 64 + idx / nchunks + 7 t
         parallel_rows((int64_t)qtasks.size(), [&](int64_t ti) {
@@ -134,7 +135,7 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                 PairQDesc* qd = out->qdesc.data() + ((size_t)tk.chunk0 + q) * 8;
                 out->chunks[(size_t)tk.chunk0 + q] = PairChunk{0u, 0};
                 for (int g = 0; g < 8; ++g) qd[g] = PairQDesc{0, (uint32_t)tk.ci, 0u};
-                out->recs[((size_t)tk.chunk0 + q) * 64 + 63] = PairRec{kPairPad, 0u, 0u, 0u};
+                if (host_recs) out->recs[((size_t)tk.chunk0 + q) * 64 + 63] = PairRec{kPairPad, 0u, 0u, 0u};
             }
             for (int pi = tk.piece0; pi < tk.piece1; ++pi) {
                 const QPiece& pc = pieces[pi];
@@ -149,12 +150,34 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                     d.flags = pb.flags | (last ? kPairQFlush : 0u);
                     if (two_queues && last) d.flags |= (n == nn - 1) ? kPairQCarry : kPairQJoin;   // the head part ends the piece, the tail part its queue
                     if (last) out->chunks[(size_t)tk.chunk0 + q].mask |= 1u << g;
-                    for (int t = (n == nn - 1 ? pc.len - 9 * n : 9); t < 9; ++t) out->recs[slot_of(idx, t)] = PairRec{kPairPad, 0u, 0u, (uint32_t)g};
+                    if (host_recs)
+                        for (int t = (n == nn - 1 ? pc.len - 9 * n : 9); t < 9; ++t) out->recs[slot_of(idx, t)] = PairRec{kPairPad, 0u, 0u, (uint32_t)g};
                 }
             }
-            for (int idx = tk.nonets; idx < 7 * tk.nchunks; ++idx)   // the empty tail of the last queues
-                for (int t = 0; t < 9; ++t) out->recs[slot_of(idx, t)] = PairRec{kPairPad, 0u, 0u, (uint32_t)(idx / tk.nchunks)};
+            if (host_recs)
+                for (int idx = tk.nonets; idx < 7 * tk.nchunks; ++idx)   // the empty tail of the last queues
+                    for (int t = 0; t < 9; ++t) out->recs[slot_of(idx, t)] = PairRec{kPairPad, 0u, 0u, (uint32_t)(idx / tk.nchunks)};
         }, 64);
+        if (!host_recs) {
+            PairDeviceTables& dt = *dev_tables;
+            dt.rows = rows;
+            dt.run_ptr.assign(n_cam + 1, 0);
+            for (int64_t r = 0; r < n_cam; ++r) dt.run_ptr[r + 1] = dt.run_ptr[r] + (int)row_runs[r].size();
+            dt.run_cj.resize((size_t)dt.run_ptr[n_cam]); dt.run_piece0.resize((size_t)dt.run_ptr[n_cam]);
+            parallel_rows(n_cam, [&](int64_t r) {
+                int k = dt.run_ptr[r];
+                for (const Run& run : row_runs[r]) { dt.run_cj[k] = run.cj; dt.run_piece0[k] = run.piece0; ++k; }
+            });
+            dt.piece.resize(pieces.size());
+            for (size_t i = 0; i < pieces.size(); ++i) dt.piece[i] = make_int2(pieces[i].task, pieces[i].nonet0);
+            dt.task.resize(qtasks.size());
+            for (size_t i = 0; i < qtasks.size(); ++i) dt.task[i] = make_int2(qtasks[i].chunk0, qtasks[i].nchunks);
+            dt.n_slots = total_chunks * 64;
+            tr.mark("pairs: descriptors, device tables");
+            out->n_pairs = n_pairs;
+            out->n_blocks = n_blocks;
+            return;
+        }
         // records: the k-th pair of a row with one partner goes to pair k % 576 of piece k / 576 of that block
         parallel_ranges(n_cam, 16, [&](int64_t rb, int64_t re) {
             std::vector<int> pos(n_cam, 0), ridx(n_cam, 0);
@@ -281,6 +304,106 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
 // ------------------------------------------------------------------------------------------------------------------
 // device
 // ------------------------------------------------------------------------------------------------------------------
+// The records of the queued layout written by the device (round 5; PairDeviceTables).  One WAVE per row of S: it walks the row
+// camera's observations 64 at a time, in order; an observation i pairs with the observations j < i of its landmark, pair s of
+// every lane in turn.  The k-th pair of the row with partner cj goes to pair k % 576 of piece k / 576 of that block: k is a
+// running count per partner (LDS; rows with more partners than kRecsLdsPartners count in their piece of a global scratch array,
+// cleared by the host), advanced in LANE order inside a step -- the lanes that meet the same partner are found with ballots --,
+// so the list is a fixed function of the observation lists, the same at every build.
+constexpr int kRecsLdsPartners = 2048;
+__global__ __launch_bounds__(64) void k_build_pair_recs_q(int64_t n_rows, const int* __restrict__ rows, const int* __restrict__ run_ptr,
+                                                           const uint32_t* __restrict__ run_cj, const int* __restrict__ run_piece0,
+                                                           const int2* __restrict__ piece, const int2* __restrict__ task,
+                                                           const int* __restrict__ cam_ptr, const int* __restrict__ cam_obs,
+                                                           const uint32_t* __restrict__ o_pt, const int* __restrict__ pt_ptr,
+                                                           const uint32_t* __restrict__ o_cam, int* __restrict__ cnt_global,
+                                                           PairRec* __restrict__ recs) {
+    __shared__ int cnt_lds[kRecsLdsPartners];
+    const int64_t r = blockIdx.x;
+    if (r >= n_rows) return;
+    const int lane = threadIdx.x;
+    const int c = rows[r], r0 = run_ptr[r], P = run_ptr[r + 1] - r0;
+    if (P == 0) return;
+    const bool in_lds = P <= kRecsLdsPartners;
+    int* cnt = in_lds ? cnt_lds : cnt_global + r0;
+    if (in_lds) for (int p = lane; p < P; p += 64) cnt_lds[p] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t* cjs = run_cj + r0;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int e0 = cam_ptr[c]; e0 < cam_ptr[c + 1]; e0 += 64) {
+        const int e = e0 + lane;
+        const bool act = e < cam_ptr[c + 1];
+        const int i = act ? cam_obs[e] : 0;
+        const uint32_t l = act ? o_pt[i] : 0u;
+        const int b = act ? pt_ptr[l] : 0;
+        const int np = act ? i - b : 0;
+        int maxnp = np;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) maxnp = max(maxnp, __shfl_xor(maxnp, off, 64));
+        for (int s = 0; s < maxnp; ++s) {
+            const bool has = s < np;
+            const int j = b + (has ? s : 0);
+            const uint32_t cj = has ? o_cam[j] : 0u;
+            int p = 0;
+            if (has) {   // the partner's run: cj is in the list (binary search over the row's ascending partners)
+                int lo = 0, hi = P - 1;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (cjs[mid] < cj) lo = mid + 1; else hi = mid; }
+                p = lo;
+            }
+            int k = 0;
+            unsigned long long todo = __ballot(has);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int pl = __builtin_amdgcn_readlane(p, leader);
+                const unsigned long long same = __ballot(has && p == pl) & todo;
+                // (the global counters of a row with very many partners are read and written past the L1: a plain load behind
+                // another lane's store of an earlier step could hit a stale line)
+                const int base = in_lds ? cnt[pl] : __hip_atomic_load(cnt + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (has && p == pl) k = base + __popcll(same & lt_mask);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == leader) {
+                    if (in_lds) cnt[pl] = base + __popcll(same);
+                    else __hip_atomic_store(cnt + pl, base + __popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_wave_barrier();
+                todo &= ~same;
+            }
+            if (has) {
+                const int2 pc = piece[run_piece0[r0 + p] + k / kPairQPiecePairs];
+                const int2 tk = task[pc.x];
+                const int kk = k % kPairQPiecePairs, idx = pc.y + kk / 9, g = idx / tk.y;
+                recs[((int64_t)tk.x + idx % tk.y) * 64 + g + 7 * (kk % 9)] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
+            }
+        }
+    }
+}
+hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* run_ptr, const uint32_t* run_cj, const int* run_piece0,
+                                    const int2* piece, const int2* task, const int* cam_ptr, const int* cam_obs, const uint32_t* o_pt,
+                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s) {
+    if (n_rows <= 0 || n_slots <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(recs, 0xFF, (size_t)n_slots * sizeof(PairRec), s);   // i = kPairPad everywhere: padding unless written below
+    if (e != hipSuccess) return e;
+    // rows with more partners than the LDS counters hold count in global memory; their number is known only on the device side
+    // of the tables, so the scratch covers every run (4 bytes each: 3.4 MB on final-13682) and lives for this call
+    int n_runs = 0;
+    e = hipMemcpyAsync(&n_runs, run_ptr + n_rows, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    int* scratch = nullptr;
+    e = hipMalloc(reinterpret_cast<void**>(&scratch), (size_t)std::max(n_runs, 1) * sizeof(int));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(scratch, 0, (size_t)std::max(n_runs, 1) * sizeof(int), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_build_pair_recs_q, dim3((unsigned)n_rows), dim3(64), 0, s, n_rows, rows, run_ptr, run_cj, run_piece0, piece, task,
+                           cam_ptr, cam_obs, o_pt, pt_ptr, o_cam, scratch, recs);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(scratch);
+    return e;
+}
+
 constexpr int kPairDmaBlocks = 4;   // a chunk with at most this many blocks stages its <= 8 cameras in LDS (one 16-byte piece per lane)
 
 // Camera staging: the 8 lanes t = 8 c .. 8 c + 7 fetch the 128-byte prepared camera c of the chunk (camera c & 1 of block

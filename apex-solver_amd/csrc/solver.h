@@ -106,6 +106,8 @@ class Solver : public LmBackend {
     // variants 0 / 1 are answered by the matrix-free PCG (IterativeSchurSolver semantics, implicit_schur.rs:835-946): variant 0
     // at that solver's own defaults (500 iterations, 1e-9: implicit_schur.rs:94-95), variant 1 at the caller's cg parameters.
     // "auto_variant" 0 restores the refusal.  variant_used() / variant_reason() say what happened (apexgpu_variant_info).
+    void set_device_pair_recs(bool on) { device_pair_recs_ = on; }   // before set_structure ("device_pair_list")
+    int get_pair_records(uint32_t* recs4_out, int64_t cap_slots);     // tests: the pair records as they sit on the device
     void set_auto_variant(bool on) { auto_variant_ = on; }
     void set_max_tile_updates(int64_t n) { tp_.set_max_updates(n); }   // tests: force the refusal on a small problem
     int variant_used(int asked) const { return (auto_fallback_ && asked != 2) ? 2 : asked; }
@@ -221,6 +223,7 @@ class Solver : public LmBackend {
     uint32_t* wg_cam_list_ = nullptr;
     bool cam_staging_ = true;
     bool matrix_free_only_ = false;
+    bool device_pair_recs_ = true;   // queued layout: the pair records are written by the device (k_build_pair_recs_q), not built on the host and copied
     bool auto_variant_ = true, auto_fallback_ = false;   // see set_auto_variant
     std::string fallback_reason_;
     bool rec_backsub_ = true;

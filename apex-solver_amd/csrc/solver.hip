@@ -379,10 +379,13 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     if (!plan_err.empty()) { uploader.join(); return fail(kInvalidInput, "reduced camera matrix: " + plan_err); }
     hs.seconds[2] = plan_seconds;
     // ---- task lists of the selected form of the Schur reduction (they need the slot map) ------------------------------
-    hs.build_schur_lists(so, tp_.slot_host());
+    PairDeviceTables dtab;
+    const bool recs_on_device = device_pair_recs_ && so.schur_form == 4 && dc_ == 9;
+    hs.build_schur_lists(so, tp_.slot_host(), recs_on_device ? &dtab : nullptr);
     n_rtasks_ = (int)hs.rtasks2.size();
     n_ptasks_ = (int)hs.pl.tasks.size();
-    n_pair_blocks_ = hs.pl.n_blocks; n_pair_slots_ = (int64_t)hs.pl.recs.size(); pair_queued_ = hs.pl.queued;
+    n_pair_blocks_ = hs.pl.n_blocks; pair_queued_ = hs.pl.queued;
+    n_pair_slots_ = (recs_on_device && hs.pl.queued) ? dtab.n_slots : (int64_t)hs.pl.recs.size();
     const auto& nbr = hs.nbr;
     const std::vector<RowTask>& rtasks2 = hs.rtasks2;
     const std::vector<RowChunk>& rchunks = hs.rchunks;
@@ -399,7 +402,29 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     HIP_TRY(up(&ptasks_, pl.tasks));
     HIP_TRY(up(&pchunks_, pl.chunks));
     HIP_TRY(up(&pblocks_, pl.blocks));
-    HIP_TRY(up(&precs_, pl.recs));
+    if (recs_on_device && pl.queued) {
+        // the records of the queued layout are written by the device from the observation lists the uploader put there
+        // (schur_pairs.h, PairDeviceTables): 17 MB of tables up instead of 1.56 GB of records built and copied
+        int *d_rows = nullptr, *d_run_ptr = nullptr, *d_run_piece0 = nullptr;
+        uint32_t* d_run_cj = nullptr;
+        int2 *d_piece = nullptr, *d_task = nullptr;
+        if (precs_) { hipFree(precs_); precs_ = nullptr; }
+        hipError_t e = dev_alloc(&precs_, (size_t)dtab.n_slots);
+        if (e == hipSuccess) e = up(&d_rows, dtab.rows);
+        if (e == hipSuccess) e = up(&d_run_ptr, dtab.run_ptr);
+        if (e == hipSuccess) e = up(&d_run_cj, dtab.run_cj);
+        if (e == hipSuccess) e = up(&d_run_piece0, dtab.run_piece0);
+        if (e == hipSuccess) e = up(&d_piece, dtab.piece);
+        if (e == hipSuccess) e = up(&d_task, dtab.task);
+        if (e == hipSuccess)
+            e = launch_build_pair_recs_q(n_cam_, d_rows, d_run_ptr, d_run_cj, d_run_piece0, d_piece, d_task, cam_ptr_, cam_obs_, o_pt_, pt_ptr_, o_cam_,
+                                         precs_, dtab.n_slots, stream_);
+        for (void* q : {(void*)d_rows, (void*)d_run_ptr, (void*)d_run_cj, (void*)d_run_piece0, (void*)d_piece, (void*)d_task})
+            if (q) (void)hipFree(q);
+        HIP_TRY(e);
+    } else {
+        HIP_TRY(up(&precs_, pl.recs));
+    }
     if (pqdesc_) { hipFree(pqdesc_); pqdesc_ = nullptr; }
     if (pl.queued) HIP_TRY(up(&pqdesc_, pl.qdesc));
     HIP_TRY(up(&nbr_, nbr));
@@ -1319,6 +1344,15 @@ int Solver::get_hessian_csc(int64_t* nnz_out, int64_t* colptr, int64_t* rowidx, 
     for (const Trip& e : t) colptr[e.col + 1]++;
     for (int64_t j = 0; j < total; ++j) colptr[j + 1] += colptr[j];
     for (int64_t k = 0; k < nnz; ++k) { rowidx[k] = t[k].row; values[k] = t[k].v; }
+    return kOk;
+}
+
+// tests: the pair records of the default Schur form as they sit on the device (host-built and copied, or written by the device)
+int Solver::get_pair_records(uint32_t* recs4_out, int64_t cap_slots) {
+    if (!have_structure_) return fail(kInvalidState, "Block structure not built");
+    if (!precs_ || cap_slots < n_pair_slots_) return fail(kInvalidInput, "pair records: none on this handle, or the buffer is too small");
+    HIP_TRY(hipSetDevice(device_));
+    HIP_TRY(hipMemcpy(recs4_out, precs_, (size_t)n_pair_slots_ * sizeof(PairRec), hipMemcpyDeviceToHost));
     return kOk;
 }
 

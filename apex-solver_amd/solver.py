@@ -436,6 +436,14 @@ class GpuSchurComplementSolver:
     def set_option(self, name: str, value: int):
         h = self._need(); h.check(h.L.apexgpu_set_option(h.h, name.encode(), int(value)))
 
+    def pair_records(self) -> np.ndarray:
+        """Tests: the records of the sorted pair list as they sit on the device, (slots, 4) uint32 = (i, j, landmark, queue)."""
+        h = self._need()
+        n = self.setup_times()["pair_slots"]
+        out = np.zeros((n, 4), dtype=np.uint32)
+        h.check(h.L.apexgpu_debug_get_pair_records(h.h, capi.ptr(out), n))
+        return out
+
     def owned_landmarks(self) -> np.ndarray:
         """Boolean mask (caller's landmark numbering) of the landmarks this rank assembles and back-substitutes."""
         h = self._need()

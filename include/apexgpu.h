@@ -253,6 +253,11 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     S is never formed, so only its diagonal tiles are allocated and no pair list is built -- set-up and LM
  *                     iteration are then independent of the fill of S (an input whose S is dense costs what a banded one
  *                     does); variants 0 / 1 and the exports of S answer APEXGPU_ERR_INVALID_STATE on such a handle
+ *   "device_pair_list" (1)  before set_structure: the RECORDS of the sorted pair list (queued layout, nine-column cameras: 1.56 GB
+ *                     on final-13682) are written by the device from the observation lists (k_build_pair_recs_q: the host keeps
+ *                     the small, serial part -- blocks, tasks, descriptors); 0 = built on the host and copied (rounds 2-4):
+ *                     0.1-0.18 s + 35 ms of upload of every apexgpu_set_structure.  Same list unless a camera sees one landmark
+ *                     twice (that block's pairs may then come in another, equally fixed order)
  *   "auto_variant" (1)  before set_structure: a structure whose direct factorisation is refused -- more than 8e7 tile products
  *                     per factorisation (S dense at tile granularity: a photo collection), or, on a single rank, tiles beyond
  *                     the free HBM -- does NOT fail apexgpu_set_structure: the handle is built matrix-free only by itself and
@@ -328,6 +333,9 @@ int apexgpu_counters(apexgpu_solver* h, int64_t out[4]);
  * over all waves since the last reset, out[0..4] = wait for the gathers, un-staging, Jacobians + U / V stores, issue of the next
  * chunk's loads, block products + flushes; out[5] chunks, out[6] cycles inside flushes, out[7] flushes. */
 int apexgpu_debug_pair_phases(int64_t out[8], int reset);
+/* Tests: the records of the sorted pair list as they sit on the device, recs4_out[slots][4] = {i, j, landmark, queue}
+ * (i = 0xFFFFFFFF: padding; slots = counts[2] of apexgpu_setup_times). */
+int apexgpu_debug_get_pair_records(apexgpu_solver* h, uint32_t* recs4_out, int64_t cap_slots);
 /* Wall time of the last apexgpu_set_structure by phase, seconds[6] = {camera order + tile structure, landmark sharding +
  * observation lists, tile plan (symbolic fill, task lists, allocation), lists of the Schur reduction, uploads, total};
  * counts[4] (may be NULL) = {hub cameras ordered last, camera-pair blocks, pair slots incl. padding, Schur form}. */

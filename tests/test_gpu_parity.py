@@ -825,3 +825,51 @@ def test_schur_assembly_is_reproducible_bit_for_bit():
     b = s.solve_augmented_equation(1e-3).copy()
     assert np.array_equal(a, b)
     s.close()
+
+
+# ---- round 5: the records of the pair list written by the device ---------------------------------------------------------------
+def test_device_built_pair_list_is_the_host_list():
+    """The records of the queued pair list are written by the device from the observation lists ("device_pair_list", default;
+    k_build_pair_recs_q) instead of being built on the host and copied.  On a banded problem the two lists are the same slot for
+    slot and S the same bit for bit; with cameras that see a landmark twice, landmarks of 64..300 observations (split blocks,
+    pieces) the same pairs reach the same (chunk, queue) -- the order inside such a block may differ -- and S agrees to rounding."""
+    PAD = np.uint32(0xFFFFFFFF)
+
+    def build(d, dev):
+        prob = Problem.bundle_adjustment(d, OptimizationType.SelfCalibration, 1.0)
+        s = GpuSchurComplementSolver(0).with_option("device_pair_list", dev)
+        s.initialize_structure(prob)
+        s.set_parameters(d.poses, d.intr, d.points)
+        recs = s.pair_records()
+        s.assemble(1e-3)
+        S, g = s.get_schur()
+        s.close()
+        return recs, S, g
+
+    d = pkg.synthetic.make_problem(130, 4000, 3, 9, config_id=515)
+    rh, Sh, gh = build(d, 0)
+    rd, Sd, gd = build(d, 1)
+    assert rh.shape == rd.shape and rh.shape[0] % 64 == 0
+    real_h, real_d = rh[:, 0] != PAD, rd[:, 0] != PAD
+    assert np.array_equal(real_h, real_d) and real_h.sum() > 10000
+    assert np.array_equal(rh[real_h], rd[real_d])
+    assert np.array_equal(Sh, Sd) and np.array_equal(gh, gd)
+
+    n_cam = 320
+    rng = np.random.default_rng(9)
+    lists = [[], [3], [5, 5, 9], list(range(64)), list(range(65)), list(range(40, 169)), list(range(200)),
+             [7, 8, 7, 8, 100], list(range(300)), [319, 0, 319]]
+    lists += [sorted(rng.choice(n_cam, size=int(rng.integers(2, 12)), replace=False).tolist()) for _ in range(300)]
+    d = _custom(n_cam, len(lists), lists)
+    rh, Sh, gh = build(d, 0)
+    rd, Sd, gd = build(d, 1)
+    real_h, real_d = rh[:, 0] != PAD, rd[:, 0] != PAD
+    assert rh.shape == rd.shape and real_h.sum() == real_d.sum()
+
+    def keyed(r, real):   # (chunk, queue, i, j, landmark) of every real slot, sorted
+        slot = np.nonzero(real)[0]
+        k = np.stack([slot // 64, r[real, 3].astype(np.int64), r[real, 0].astype(np.int64), r[real, 1].astype(np.int64), r[real, 2].astype(np.int64)], axis=1)
+        return k[np.lexsort(k.T[::-1])]
+
+    assert np.array_equal(keyed(rh, real_h), keyed(rd, real_d))
+    assert rel(Sd, Sh) < 1e-13 and rel(gd, gh) < 1e-13
