@@ -23,7 +23,7 @@ SYMBOLS = (
     "apexgpu_set_cg_params", "apexgpu_set_params", "apexgpu_get_params", "apexgpu_cost", "apexgpu_assemble", "apexgpu_solve_augmented",
     "apexgpu_step_stats", "apexgpu_eval_step", "apexgpu_commit_step", "apexgpu_discard_step",
     "apexgpu_parameter_norm", "apexgpu_column_norms", "apexgpu_set_column_scaling", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
-    "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_get_hessian_csc", "apexgpu_debug_invert_blocks", "apexgpu_debug_pair_lists", "apexgpu_debug_pair_lists_queued", "apexgpu_debug_host_structure", "apexgpu_setup_times", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
+    "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_get_hessian_csc", "apexgpu_debug_invert_blocks", "apexgpu_debug_pair_lists", "apexgpu_debug_pair_lists_queued", "apexgpu_debug_pair_lists_queued_dc", "apexgpu_debug_host_structure", "apexgpu_setup_times", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
     "apexgpu_stage_times", "apexgpu_info", "apexgpu_variant_info", "apexgpu_trim_host_cache", "apexgpu_counters", "apexgpu_debug_pair_phases", "apexgpu_debug_get_pair_records", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_comm_init_shm", "apexgpu_set_shard", "apexgpu_shard_range",
     "apexgpu_debug_lockstep_solve", "apexgpu_export_step", "apexgpu_owned_landmarks", "apexgpu_debug_partition", "apexgpu_debug_check_schedule",
     "apexgpu_bal_open", "apexgpu_bal_close", "apexgpu_bal_last_error", "apexgpu_bal_sizes", "apexgpu_bal_raw",
@@ -274,22 +274,24 @@ def pair_lists(n_cam: int, n_pt: int, dc: int, cam_idx: np.ndarray, pt_idx: np.n
     return dict(recs=recs, chunks=chunks, blocks=blocks, tasks=tasks, o_index=o_index)
 
 
-def pair_lists_queued(n_cam: int, n_pt: int, cam_idx: np.ndarray, pt_idx: np.ndarray):
-    """Host only: the same pairs in the queued layout ("schur_form" 4, nine columns per camera; apexgpu_debug_pair_lists_queued)."""
+def pair_lists_queued(n_cam: int, n_pt: int, cam_idx: np.ndarray, pt_idx: np.ndarray, dc: int = 9):
+    """Host only: the same pairs in the queued layout ("schur_form" 4; apexgpu_debug_pair_lists_queued_dc): nine columns per
+    camera = seven queues of nine pairs per chunk, six columns = sixteen queues of four."""
     ci = np.ascontiguousarray(cam_idx, dtype=np.uint32); pi = np.ascontiguousarray(pt_idx, dtype=np.uint32)
     counts = np.zeros(4, dtype=np.int64)
     L = load()
-    rc = L.apexgpu_debug_pair_lists_queued(n_cam, n_pt, len(ci), ptr(ci), ptr(pi), ptr(counts), None, None, None, None, None, None)
+    nd = 8 if dc == 9 else 17
+    rc = L.apexgpu_debug_pair_lists_queued_dc(n_cam, n_pt, len(ci), dc, ptr(ci), ptr(pi), ptr(counts), None, None, None, None, None, None)
     if rc != 0:
-        raise LinAlgError(rc, "apexgpu_debug_pair_lists_queued failed")
+        raise LinAlgError(rc, "apexgpu_debug_pair_lists_queued_dc failed")
     recs = np.zeros((counts[0], 4), dtype=np.uint32); chunks = np.zeros((counts[1], 2), dtype=np.int32)
     blocks = np.zeros((counts[2], 4), dtype=np.int64); tasks = np.zeros((counts[3], 2), dtype=np.int32)
-    o_index = np.zeros(len(ci), dtype=np.int32); qdesc = np.zeros((counts[1] * 8, 3), dtype=np.int64)
-    rc = L.apexgpu_debug_pair_lists_queued(n_cam, n_pt, len(ci), ptr(ci), ptr(pi), ptr(counts), ptr(recs), ptr(chunks), ptr(blocks),
-                                           ptr(tasks), ptr(o_index), ptr(qdesc))
+    o_index = np.zeros(len(ci), dtype=np.int32); qdesc = np.zeros((counts[1] * nd, 3), dtype=np.int64)
+    rc = L.apexgpu_debug_pair_lists_queued_dc(n_cam, n_pt, len(ci), dc, ptr(ci), ptr(pi), ptr(counts), ptr(recs), ptr(chunks), ptr(blocks),
+                                              ptr(tasks), ptr(o_index), ptr(qdesc))
     if rc != 0:
-        raise LinAlgError(rc, "apexgpu_debug_pair_lists_queued failed")
-    return dict(recs=recs, chunks=chunks, blocks=blocks, tasks=tasks, o_index=o_index, qdesc=qdesc.reshape(-1, 8, 3))
+        raise LinAlgError(rc, "apexgpu_debug_pair_lists_queued_dc failed")
+    return dict(recs=recs, chunks=chunks, blocks=blocks, tasks=tasks, o_index=o_index, qdesc=qdesc.reshape(-1, nd, 3), dc=dc)
 
 
 def invert_blocks_on_device(blocks: np.ndarray, device: int = 0):

@@ -470,6 +470,13 @@ int apexgpu_debug_pair_lists_queued(int64_t n_cam, int64_t n_pt, int64_t n_obs, 
                                     int32_t* tasks2_out, int32_t* o_index_out, int64_t* qdesc3_out) {
     return debug_pair_lists_impl(n_cam, n_pt, n_obs, 9, cam_idx, pt_idx, counts, recs4_out, chunks2_out, blocks4_out, tasks2_out, o_index_out, true, qdesc3_out);
 }
+// ... and for either camera width (round 5): dc = 9 as above; dc = 6: sixteen queues of four pairs per chunk, qdesc3_out[17 * chunks][3],
+// entry 16 of a chunk = the row's camera
+int apexgpu_debug_pair_lists_queued_dc(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc, const uint32_t* cam_idx, const uint32_t* pt_idx,
+                                       int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
+                                       int32_t* tasks2_out, int32_t* o_index_out, int64_t* qdesc3_out) {
+    return debug_pair_lists_impl(n_cam, n_pt, n_obs, dc, cam_idx, pt_idx, counts, recs4_out, chunks2_out, blocks4_out, tasks2_out, o_index_out, true, qdesc3_out);
+}
 
 // Host arithmetic only: everything apexgpu_set_structure derives from the observation list before it touches the device
 // (csrc/ba_structure.h) -- camera order with hub cameras last and nested dissection of the tile graph, symbolic fill,

@@ -59,6 +59,11 @@ struct PairQDesc {    // queue g < 7 of a chunk: the block its nonet belongs to;
     uint32_t cj;      // the block's partner camera (a valid camera index also in an empty queue)
     uint32_t flags;   // kPairBlock* | kPairQFlush: the block (piece) ends with this nonet -- store / add it after this chunk
 };
+// (round 5) the same layout for SIX-column cameras (BundleAdjustment mode): a 6 x 6 block is four 3 x 3 sub-blocks, a lane group four
+// lanes -- SIXTEEN queues of QUARTETS (slot g + 16 t of a chunk is pair t < 4 of queue g, no idle slot), 16 + 1 descriptors and
+// 1 + 16 cameras per chunk, pieces of 256 pairs.  pair_queue_len / pair_queues give (9, 7) or (4, 16).
+constexpr int pair_queue_len(int dc) { return dc == 9 ? 9 : 4; }
+constexpr int pair_queues(int dc) { return dc == 9 ? 7 : 16; }
 constexpr uint32_t kPairQFlush = 4;
 // A block cut between the tail of queue g and the head of queue g + 1 (the same wave) is still stored once: the head part is
 // CARRIED in registers from the chunk it ends in to the end of the task, where queue g JOINS it to its tail part.
@@ -105,7 +110,7 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
 // the records of the queued layout from those tables (all pointers device memory; recs is cleared to padding first)
 hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* run_ptr, const uint32_t* run_cj, const int* run_piece0,
                                     const int2* piece, const int2* task, const int* cam_ptr, const int* cam_obs, const uint32_t* o_pt,
-                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s);
+                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s, int dc = 9);
 
 // The pair kernel (record form: J rebuilt from the 32-byte projection records k_landmark_reduce writes, orec).
 // ablation: timing experiments only (results are wrong when != 0)

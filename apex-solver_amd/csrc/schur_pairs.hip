@@ -74,7 +74,10 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
         // ---- QUEUED layout (schur_pairs.h): tasks inside one row, blocks padded to nonets, seven queues per task -----------
         // nonets per task: 7 x 64 at most (a task's chunk descriptors sit one per lane); fewer = more tasks per row = fewer rows
         // in flight per XCD, whose L2 then sees a row's landmark records again before they are evicted ("pair_task_slots")
-        const int kMaxNonets = std::min(7 * 64, std::max(63, (task_slots > 0 ? task_slots : kPairQTaskSlots) / 9));
+        // (round 5) nine-column cameras: seven queues of NONETS (the lanes of a group hold the 9 x 9 block as nine 3 x 3 sub-blocks);
+        // six-column cameras: sixteen queues of QUARTETS (four lanes, four sub-blocks).  QL = slots of a queue per chunk, NQ = queues.
+        const int QL = pair_queue_len(dc), NQ = pair_queues(dc), ND = NQ + 1, kPiecePairs = 64 * QL;
+        const int kMaxNonets = std::min(NQ * 64, std::max(63, (task_slots > 0 ? task_slots : (dc == 9 ? kPairQTaskSlots : 2048)) / QL));
         struct QPiece { int task; int nonet0; int len; int block; };
         struct QTask { int chunk0, nchunks, nonets, ci, piece0, piece1; };
         std::vector<QPiece> pieces;
@@ -89,14 +92,14 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
             const int ci = rows[r];
             int64_t row_nonets = 0;
             for (const Run& run : row_runs[r])
-                for (int len = run.len; len > 0; len -= kPairQPiecePairs) row_nonets += (std::min(len, kPairQPiecePairs) + 8) / 9;
+                for (int len = run.len; len > 0; len -= kPiecePairs) row_nonets += (std::min(len, kPiecePairs) + QL - 1) / QL;
             if (row_nonets == 0) continue;
             const int n_row_tasks = (int)((row_nonets + kMaxNonets - 1) / kMaxNonets);
             const int target = (int)((row_nonets + n_row_tasks - 1) / n_row_tasks);   // even tasks, cut at block boundaries
             int task_nonets = 0, task_piece0 = (int)pieces.size(), max_nn = 0;
             auto close_task = [&]() {
                 if (task_nonets == 0) return;
-                const int nchunks = std::max((task_nonets + 6) / 7, max_nn);   // >= the longest piece: a piece spans <= 2 queues
+                const int nchunks = std::max((task_nonets + NQ - 1) / NQ, max_nn);   // >= the longest piece: a piece spans <= 2 queues
                 qtasks.push_back(QTask{(int)total_chunks, nchunks, task_nonets, ci, task_piece0, (int)pieces.size()});
                 out->tasks.push_back(PairTask{(int32_t)total_chunks, (int32_t)nchunks});
                 total_chunks += nchunks;
@@ -108,10 +111,10 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                 const int sl = slot[(size_t)I * nt + J];
                 const int64_t dst = (int64_t)sl * kNB * kNB + (int64_t)((ci % cpt) * dc) * kNB + ((int)cj % cpt) * dc;
                 const uint32_t diag = ((int)cj == ci) ? kPairBlockDiag : 0u;
-                const bool split = run.len > kPairQPiecePairs;
+                const bool split = run.len > kPiecePairs;
                 run.piece0 = (int)pieces.size();
-                for (int len = run.len; len > 0; len -= kPairQPiecePairs) {
-                    const int take = std::min(len, kPairQPiecePairs), nn = (take + 8) / 9;
+                for (int len = run.len; len > 0; len -= kPiecePairs) {
+                    const int take = std::min(len, kPiecePairs), nn = (take + QL - 1) / QL;
                     if (task_nonets > 0 && (task_nonets + nn > kMaxNonets || task_nonets >= target)) close_task();
                     const int bi = (int)out->blocks.size();
                     out->blocks.push_back(PairBlock{dst, (uint32_t)ci, cj, diag | ((split || diag) ? kPairBlockAtomic : 0u), 0u});
@@ -123,40 +126,41 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
         }
         if (total_chunks * 64 > (int64_t)0x7fffffff * 64) { out->tasks.clear(); return; }
         out->chunks.resize((size_t)total_chunks);        // every chunk belongs to one task: initialised in the loop over the tasks
-        out->qdesc.resize((size_t)total_chunks * 8);
+        out->qdesc.resize((size_t)total_chunks * ND);
         const bool host_recs = dev_tables == nullptr;     // (else the device writes the records: launch_build_pair_recs_q)
         if (host_recs) out->recs.resize((size_t)total_chunks * 64);
         tr.mark("pairs: blocks, tasks");
-        // descriptors and padding, task by task; a nonet's slot t is (chunk0 + idx % nchunks) * 64 + idx / nchunks + 7 t
+        // descriptors and padding, task by task; a nonet's slot t is (chunk0 + idx % nchunks) * 64 + idx / nchunks + NQ t
         parallel_rows((int64_t)qtasks.size(), [&](int64_t ti) {
             const QTask& tk = qtasks[ti];
-            auto slot_of = [&](int idx, int t) { return ((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + idx / tk.nchunks + 7 * t; };
+            auto slot_of = [&](int idx, int t) { return ((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + idx / tk.nchunks + NQ * t; };
             for (int q = 0; q < tk.nchunks; ++q) {
-                PairQDesc* qd = out->qdesc.data() + ((size_t)tk.chunk0 + q) * 8;
+                PairQDesc* qd = out->qdesc.data() + ((size_t)tk.chunk0 + q) * ND;
                 out->chunks[(size_t)tk.chunk0 + q] = PairChunk{0u, 0};
-                for (int g = 0; g < 8; ++g) qd[g] = PairQDesc{0, (uint32_t)tk.ci, 0u};
-                if (host_recs) out->recs[((size_t)tk.chunk0 + q) * 64 + 63] = PairRec{kPairPad, 0u, 0u, 0u};
+                for (int g = 0; g < ND; ++g) qd[g] = PairQDesc{0, (uint32_t)tk.ci, 0u};
+                if (host_recs)
+                    for (int sl = NQ * QL; sl < 64; ++sl) out->recs[((size_t)tk.chunk0 + q) * 64 + sl] = PairRec{kPairPad, 0u, 0u, 0u};   // (d_c = 9: slot 63)
             }
             for (int pi = tk.piece0; pi < tk.piece1; ++pi) {
                 const QPiece& pc = pieces[pi];
                 const PairBlock& pb = out->blocks[pc.block];
-                const int nn = (pc.len + 8) / 9;
+                const int nn = (pc.len + QL - 1) / QL;
                 const bool two_queues = pc.nonet0 / tk.nchunks != (pc.nonet0 + nn - 1) / tk.nchunks;
                 for (int n = 0; n < nn; ++n) {
                     const int idx = pc.nonet0 + n, g = idx / tk.nchunks, q = idx % tk.nchunks;
                     const bool last = n == nn - 1 || q == tk.nchunks - 1;   // the piece ends, or its queue does
-                    PairQDesc& d = out->qdesc[((size_t)tk.chunk0 + q) * 8 + g];
+                    PairQDesc& d = out->qdesc[((size_t)tk.chunk0 + q) * ND + g];
                     d.dst = pb.dst; d.cj = pb.cj;
                     d.flags = pb.flags | (last ? kPairQFlush : 0u);
                     if (two_queues && last) d.flags |= (n == nn - 1) ? kPairQCarry : kPairQJoin;   // the head part ends the piece, the tail part its queue
                     if (last) out->chunks[(size_t)tk.chunk0 + q].mask |= 1u << g;
                     if (host_recs)
-                        for (int t = (n == nn - 1 ? pc.len - 9 * n : 9); t < 9; ++t) out->recs[slot_of(idx, t)] = PairRec{kPairPad, 0u, 0u, (uint32_t)g};
+                        for (int t = (n == nn - 1 ? pc.len - QL * n : QL); t < QL; ++t) out->recs[slot_of(idx, t)] = PairRec{kPairPad, 0u, 0u, (uint32_t)g};
                 }
             }
             if (host_recs)
-                for (int idx = tk.nonets; idx < 7 * tk.nchunks; ++idx)   // the empty tail of the last queues
-                    for (int t = 0; t < 9; ++t) out->recs[slot_of(idx, t)] = PairRec{kPairPad, 0u, 0u, (uint32_t)(idx / tk.nchunks)};
+                for (int idx = tk.nonets; idx < NQ * tk.nchunks; ++idx)   // the empty tail of the last queues
+                    for (int t = 0; t < QL; ++t) out->recs[slot_of(idx, t)] = PairRec{kPairPad, 0u, 0u, (uint32_t)(idx / tk.nchunks)};
         }, 64);
         if (!host_recs) {
             PairDeviceTables& dt = *dev_tables;
@@ -178,7 +182,7 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
             out->n_blocks = n_blocks;
             return;
         }
-        // records: the k-th pair of a row with one partner goes to pair k % 576 of piece k / 576 of that block
+        // records: the k-th pair of a row with one partner goes to pair k % (64 QL) of piece k / (64 QL) of that block
         parallel_ranges(n_cam, 16, [&](int64_t rb, int64_t re) {
             std::vector<int> pos(n_cam, 0), ridx(n_cam, 0);
             for (int64_t r = rb; r < re; ++r) {
@@ -192,10 +196,10 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                         const uint32_t cj = o_cam[j];
                         const Run& run = runs[ridx[cj]];
                         const int k = pos[cj]++;
-                        const QPiece& pc = pieces[run.piece0 + k / kPairQPiecePairs];
+                        const QPiece& pc = pieces[run.piece0 + k / kPiecePairs];
                         const QTask& tk = qtasks[pc.task];
-                        const int kk = k % kPairQPiecePairs, idx = pc.nonet0 + kk / 9, g = idx / tk.nchunks;
-                        out->recs[((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + g + 7 * (kk % 9)] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
+                        const int kk = k % kPiecePairs, idx = pc.nonet0 + kk / QL, g = idx / tk.nchunks;
+                        out->recs[((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + g + NQ * (kk % QL)] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
                     }
                 }
             }
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(64) void k_build_pair_recs_q(int64_t n_rows, const 
                                                            const int* __restrict__ cam_ptr, const int* __restrict__ cam_obs,
                                                            const uint32_t* __restrict__ o_pt, const int* __restrict__ pt_ptr,
                                                            const uint32_t* __restrict__ o_cam, int* __restrict__ cnt_global,
-                                                           PairRec* __restrict__ recs) {
+                                                           PairRec* __restrict__ recs, int QL, int NQ) {
     __shared__ int cnt_lds[kRecsLdsPartners];
     const int64_t r = blockIdx.x;
     if (r >= n_rows) return;
@@ -369,17 +373,18 @@ __global__ __launch_bounds__(64) void k_build_pair_recs_q(int64_t n_rows, const 
                 todo &= ~same;
             }
             if (has) {
-                const int2 pc = piece[run_piece0[r0 + p] + k / kPairQPiecePairs];
+                const int piece_pairs = 64 * QL;
+                const int2 pc = piece[run_piece0[r0 + p] + k / piece_pairs];
                 const int2 tk = task[pc.x];
-                const int kk = k % kPairQPiecePairs, idx = pc.y + kk / 9, g = idx / tk.y;
-                recs[((int64_t)tk.x + idx % tk.y) * 64 + g + 7 * (kk % 9)] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
+                const int kk = k % piece_pairs, idx = pc.y + kk / QL, g = idx / tk.y;
+                recs[((int64_t)tk.x + idx % tk.y) * 64 + g + NQ * (kk % QL)] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
             }
         }
     }
 }
 hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* run_ptr, const uint32_t* run_cj, const int* run_piece0,
                                     const int2* piece, const int2* task, const int* cam_ptr, const int* cam_obs, const uint32_t* o_pt,
-                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s) {
+                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s, int dc) {
     if (n_rows <= 0 || n_slots <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(recs, 0xFF, (size_t)n_slots * sizeof(PairRec), s);   // i = kPairPad everywhere: padding unless written below
     if (e != hipSuccess) return e;
@@ -396,7 +401,7 @@ hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* 
     e = hipMemsetAsync(scratch, 0, (size_t)std::max(n_runs, 1) * sizeof(int), s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_build_pair_recs_q, dim3((unsigned)n_rows), dim3(64), 0, s, n_rows, rows, run_ptr, run_cj, run_piece0, piece, task,
-                           cam_ptr, cam_obs, o_pt, pt_ptr, o_cam, scratch, recs);
+                           cam_ptr, cam_obs, o_pt, pt_ptr, o_cam, scratch, recs, pair_queue_len(dc), pair_queues(dc));
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     }

@@ -409,6 +409,11 @@ int apexgpu_debug_pair_lists(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc,
 int apexgpu_debug_pair_lists_queued(int64_t n_cam, int64_t n_pt, int64_t n_obs, const uint32_t* cam_idx, const uint32_t* pt_idx,
                                     int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
                                     int32_t* tasks2_out, int32_t* o_index_out, int64_t* qdesc3_out);
+/* The same for either camera width (round 5): dc = 9 as above; dc = 6 (BundleAdjustment mode): sixteen queues of four pairs per
+ * chunk -- slot g + 16 t = pair t of queue g --, qdesc3_out[17 * chunks][3], entry 16 of a chunk = the row's camera. */
+int apexgpu_debug_pair_lists_queued_dc(int64_t n_cam, int64_t n_pt, int64_t n_obs, int dc, const uint32_t* cam_idx, const uint32_t* pt_idx,
+                                       int64_t counts[4], uint32_t* recs4_out, int32_t* chunks2_out, int64_t* blocks4_out,
+                                       int32_t* tasks2_out, int32_t* o_index_out, int64_t* qdesc3_out);
 int apexgpu_export_step(apexgpu_solver* h, double* step_out, double* grad_out);
 /* The landmark range [lo,hi) rank `rank` of `world` owns (contiguous, balanced by observation count).
  * Host arithmetic only -- no device is touched -- so schedulers and tests can call it anywhere. */

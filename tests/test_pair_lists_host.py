@@ -123,23 +123,25 @@ def replay_queued(pl):
     g, g + 7, ..., g + 56 of every chunk of its task and, where the chunk's flush bit g is set, hands what it has gathered
     to the destination of ITS descriptor of that chunk.  Returns [(dst, cj, flags, [(i, j, l), ...]), ...] per flush."""
     recs, chunks, tasks, qd = pl["recs"], pl["chunks"], pl["tasks"], pl["qdesc"]
+    NQ, QLEN = (7, 9) if pl.get("dc", 9) == 9 else (16, 4)   # queues per chunk, pairs of a queue per chunk (round 5: six-column cameras)
     out = []
     seen = np.zeros(len(chunks), dtype=int)
     for c0, n in tasks:
         assert 1 <= n <= 64, "a task's chunk descriptors are held one per lane"
-        acc = [[] for _ in range(7)]
-        carry = [None] * 8
-        ci = int(qd[c0, 7, 1])
+        acc = [[] for _ in range(NQ)]
+        carry = [None] * (NQ + 1)
+        ci = int(qd[c0, NQ, 1])
         for ch in range(c0, c0 + n):
             seen[ch] += 1
-            assert int(qd[ch, 7, 1]) == ci, "one row camera per task (1 + 7 cameras staged per chunk)"
-            assert int(recs[64 * ch + 63, 0]) == PAD
+            assert int(qd[ch, NQ, 1]) == ci, "one row camera per task (1 + NQ cameras staged per chunk)"
+            for sl in range(NQ * QLEN, 64):
+                assert int(recs[64 * ch + sl, 0]) == PAD
             fm = int(np.uint32(chunks[ch, 0]))
-            for g in range(7):
+            for g in range(NQ):
                 dst, cj, flags = (int(x) for x in qd[ch, g])
                 assert ((flags & 4) != 0) == (((fm >> g) & 1) != 0), "the flush bit of the mask and of the descriptor agree"
-                for t in range(9):
-                    i, j, l, q = (int(x) for x in recs[64 * ch + g + 7 * t])
+                for t in range(QLEN):
+                    i, j, l, q = (int(x) for x in recs[64 * ch + g + NQ * t])
                     if i != PAD:
                         assert q == g
                         acc[g].append((i, j, l, dst, cj))
@@ -164,12 +166,13 @@ def replay_queued(pl):
 
 def check_queued(d_cam_idx, d_pt_idx, n_cam, n_pt, pl):
     o_index = pl["o_index"]
-    cpt = NB // 9
+    dc = pl.get("dc", 9)
+    cpt = NB // dc
     got = {}
     per_block = {}
     for dst, ci, cj, flags, pairs in replay_queued(pl):
         I, J = ci // cpt, cj // cpt
-        assert dst == (I * (I + 1) // 2 + J) * NB * NB + (ci % cpt) * 9 * NB + (cj % cpt) * 9
+        assert dst == (I * (I + 1) // 2 + J) * NB * NB + (ci % cpt) * dc * NB + (cj % cpt) * dc
         assert cj <= ci and ((flags & 2) != 0) == (ci == cj)
         per_block.setdefault((ci, cj), []).append(flags)
         for i, j, l in pairs:
@@ -187,21 +190,23 @@ def check_queued(d_cam_idx, d_pt_idx, n_cam, n_pt, pl):
     return per_block
 
 
+@pytest.mark.parametrize("dc", [9, 6])
 @pytest.mark.parametrize("shuffled", [False, True], ids=["grouped", "shuffled"])
 @pytest.mark.parametrize("shape", [(40, 1500, 3, 7), (300, 9000, 2, 9)])
-def test_queued_layout_delivers_every_pair_once(shape, shuffled):
+def test_queued_layout_delivers_every_pair_once(shape, shuffled, dc):
     n_cam, n_pt, klo, khi = shape
     d = pkg.synthetic.make_problem(n_cam, n_pt, klo, khi, config_id=400 + n_cam)
     if shuffled:
         perm = np.random.default_rng(7).permutation(d.n_obs)
         d.cam_idx, d.pt_idx, d.obs_uv = d.cam_idx[perm], d.pt_idx[perm], d.obs_uv[perm]
-    pl = capi.pair_lists_queued(d.n_cam, d.n_pt, d.cam_idx, d.pt_idx)
+    pl = capi.pair_lists_queued(d.n_cam, d.n_pt, d.cam_idx, d.pt_idx, dc)
     per_block = check_queued(d.cam_idx, d.pt_idx, d.n_cam, d.n_pt, pl)
     # every block of these shapes (none longer than a piece, no camera sees a landmark twice) is stored exactly once with
     # plain stores -- also the blocks cut between two queues of a task (carried head + tail)
     assert all(fl == [0] for fl in per_block.values())
-    joins = int(((pl["qdesc"][:, :7, 2] & 16) != 0).sum())
-    assert 0 < joins <= 6 * len(pl["tasks"])
+    nq = 7 if dc == 9 else 16
+    joins = int(((pl["qdesc"][:, :nq, 2] & 16) != 0).sum())
+    assert 0 < joins <= (nq - 1) * len(pl["tasks"])
 
 
 def test_queued_layout_hub_block_pieces_and_diagonal():
@@ -214,10 +219,11 @@ def test_queued_layout_hub_block_pieces_and_diagonal():
             cams = [5, 5, 9]
         cam_idx += cams; pt_idx += [l] * len(cams)
     cam_idx = np.asarray(cam_idx, dtype=np.uint32); pt_idx = np.asarray(pt_idx, dtype=np.uint32)
-    pl = capi.pair_lists_queued(n_cam, n_pt, cam_idx, pt_idx)
-    per_block = check_queued(cam_idx, pt_idx, n_cam, n_pt, pl)
-    assert len(per_block[(7, 3)]) >= (n_pt - 1) // 576 and all(f & 1 for f in per_block[(7, 3)])
-    assert per_block[(5, 5)] and all(f & 2 for f in per_block[(5, 5)])
+    for dc, piece in ((9, 576), (6, 256)):
+        pl = capi.pair_lists_queued(n_cam, n_pt, cam_idx, pt_idx, dc)
+        per_block = check_queued(cam_idx, pt_idx, n_cam, n_pt, pl)
+        assert len(per_block[(7, 3)]) >= (n_pt - 1) // piece and all(f & 1 for f in per_block[(7, 3)])
+        assert per_block[(5, 5)] and all(f & 2 for f in per_block[(5, 5)])
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -243,7 +249,7 @@ def test_queued_layout_on_random_structures(seed):
     cam_idx = np.asarray(cam_idx, dtype=np.uint32); pt_idx = np.asarray(pt_idx, dtype=np.uint32)
     perm = rng.permutation(len(cam_idx))
     cam_idx, pt_idx = cam_idx[perm], pt_idx[perm]
-    pl = capi.pair_lists_queued(n_cam, n_pt, cam_idx, pt_idx)
+    pl = capi.pair_lists_queued(n_cam, n_pt, cam_idx, pt_idx, 9 if seed % 2 == 0 else 6)
     per_block = check_queued(cam_idx, pt_idx, n_cam, n_pt, pl)
     assert per_block
     # and the first layout delivers the same pairs to the same blocks
