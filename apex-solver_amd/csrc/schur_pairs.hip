@@ -582,7 +582,9 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
                                                           const PairBlock* __restrict__ blocks, const PairRec* __restrict__ recs,
                                                           const double* __restrict__ lmrec, const double* __restrict__ orec,
                                                           const PairQDesc* __restrict__ qdesc) {
-    static_assert(!QL || DC == 9, "the queued layout is built for d_c = 9 (seven groups of nine lanes)");
+    // the queued layout: d_c = 9 seven groups of nine lanes, nonets; d_c = 6 (round 5) sixteen groups of four lanes, quartets
+    constexpr int QLEN = pair_queue_len(DC), NQ = pair_queues(DC), ND = NQ + 1;
+    constexpr int NCAMS = (QL && DC == 6) ? 16 : 8;   // cameras staged per chunk: d_c = 6 the sixteen partners (two rounds of 64 pieces)
     constexpr int UV = 2 * DC;
     constexpr int NB3 = DC / 3;
     constexpr int GL = NB3 * NB3;
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     // counter, the compiler cannot tell its destination from U / V and puts s_waitcnt vmcnt(0) in front of every LDS read of
     // the product loop -- which then waits for the very gathers that were issued to overlap with it (the fused kernels have
     // exactly this: their prefetch never overlapped their products).
-    __shared__ double lds_cams[4 * 8 * kCamStride];
+    __shared__ double lds_cams[4 * NCAMS * kCamStride];
     __shared__ double lds_occ[(ABL & 128) ? 6000 : 1];   // ABL 128: +47 KB of LDS = ONE workgroup per CU (occupancy experiment)
     if ((ABL & 128) && n_tasks == -12345) { lds_occ[threadIdx.x * 23] = 1.0; __syncthreads(); tiles[0] = lds_occ[threadIdx.x * 7 + 1]; }
     const int lane = threadIdx.x & 63;
@@ -609,12 +611,13 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     if (t >= n_tasks) return;
     double* U = lds_all + w * WAVE_LDS;
     double* V = U + 64 * UV;
-    double* CAMS = lds_cams + w * 8 * kCamStride;
+    double* CAMS = lds_cams + w * NCAMS * kCamStride;
     double* Z = V + 64 * UV;
     if (lane < UV) Z[lane] = 0.0;
     int g, sub;
     pairs_lane_map<DC, (ABL & 256) != 0>(lane, g, sub);
-    if (QL) { g = lane == 63 ? 0 : lane / 9; sub = lane == 63 ? 0 : lane - 9 * g; }   // (lane 63 shadows lane 0 and never stores)
+    if (QL && DC == 9) { g = lane == 63 ? 0 : lane / 9; sub = lane == 63 ? 0 : lane - 9 * g; }   // (lane 63 shadows lane 0 and never stores)
+    // (QL, d_c = 6: pairs_lane_map's lane = 4 g + sub is the queue / sub-block mapping as it stands; every lane works)
     const int bi = sub / NB3, bj = sub - bi * NB3;
     const bool worker = g < NG;
     double acc[NACC];
@@ -634,12 +637,25 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         if (QL && pend_on && !(ABL & 1024)) {
             double* dst = tiles + (((int64_t)pend_dst.y << 32) | (uint32_t)pend_dst.x);
             const uint32_t fl = pend_fl & (kPairBlockAtomic | kPairBlockDiag);
-            if (fl == 0) {
+            const Acc9 pv{pend[0], pend[1 % (QL ? 9 : 1)], pend[2 % (QL ? 9 : 1)], pend[3 % (QL ? 9 : 1)], pend[4 % (QL ? 9 : 1)], pend[5 % (QL ? 9 : 1)],
+                          pend[6 % (QL ? 9 : 1)], pend[7 % (QL ? 9 : 1)], pend[8 % (QL ? 9 : 1)]};
+            if (DC == 9) {   // pend[r] = element (r, sub): one column per lane
+                if (fl == 0) {
 #pragma unroll
-                for (int r = 0; r < 9; ++r) dst[r * kNB + sub] = pend[r % (QL ? 9 : 1)];
-            } else {
-                pairs_flush_slow_col<DC>(dst, fl, Acc9{pend[0], pend[1 % (QL ? 9 : 1)], pend[2 % (QL ? 9 : 1)], pend[3 % (QL ? 9 : 1)], pend[4 % (QL ? 9 : 1)], pend[5 % (QL ? 9 : 1)],
-                                                       pend[6 % (QL ? 9 : 1)], pend[7 % (QL ? 9 : 1)], pend[8 % (QL ? 9 : 1)]}, sub);
+                    for (int r = 0; r < 9; ++r) dst[r * kNB + sub] = pend[r % (QL ? 9 : 1)];
+                } else {
+                    pairs_flush_slow_col<DC>(dst, fl, pv, sub);
+                }
+            } else {         // d_c = 6: pend = the lane's 3 x 3 sub-block (bi, bj): a 48-byte row of the block is two adjacent lanes' stores
+                if (fl == 0) {
+                    double* d0 = dst + (3 * bi) * kNB + 3 * bj;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) d0[r * kNB + c] = pend[(3 * r + c) % (QL ? 9 : 1)];
+                } else {
+                    pairs_flush_slow<DC>(dst, fl, pv, sub);
+                }
             }
         }
         pend_on = false;
@@ -746,7 +762,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     struct BlockDesc { int2 dst; uint32_t flags; };
     auto load_blocks = [&](const PairChunk c, BlockDesc& b, int qrel) {
         if (QL) {   // the descriptor of this lane's queue in chunk chunk0 + qrel: what it stores to after that chunk
-            const uint4 d = *reinterpret_cast<const uint4*>(qdesc + 8 * (size_t)(chunk0 + qrel) + g);
+            const uint4 d = *reinterpret_cast<const uint4*>(qdesc + ND * (size_t)(chunk0 + qrel) + g);
             b.dst = make_int2((int)d.x, (int)d.y); b.flags = d.w;
             return;
         }
@@ -757,8 +773,12 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     };
     // the chunk's cameras, eight lanes each: queued layout = the row's camera (entry 7) and the seven queues' partners
     auto chunk_cam = [&](const PairChunk c, int qrel) -> uint32_t {
-        if (QL) { const int cc = lane >> 3; return qdesc[8 * (size_t)(chunk0 + qrel) + (cc == 0 ? 7 : cc - 1)].cj; }
+        if (QL && DC == 6) return qdesc[ND * (size_t)(chunk0 + qrel) + (lane >> 3)].cj;   // partners of queues 0..7 (chunk_cam2: 8..15)
+        if (QL) { const int cc = lane >> 3; return qdesc[ND * (size_t)(chunk0 + qrel) + (cc == 0 ? NQ : cc - 1)].cj; }
         return pairs_dma_cam(blocks, c, lane);
+    };
+    auto chunk_cam2 = [&](int qrel) -> uint32_t {   // (d_c = 6, queued: the second round of camera pieces)
+        return (QL && DC == 6) ? qdesc[ND * (size_t)(chunk0 + qrel) + 8 + (lane >> 3)].cj : 0u;
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ckv
     const uint4* rec4 = reinterpret_cast<const uint4*>(recs);
@@ -776,15 +796,17 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         return *reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)cam + 2 * (lane & 7));
     };
     double2 cam_stage = cam_piece(chunk_cam(ck, 0));
+    double2 cam_stage2 = (QL && DC == 6) ? cam_piece(chunk_cam2(0)) : make_double2(0.0, 0.0);
     PairChunk ck_next = chunk_desc(min(1, nchunks - 1));
     uint4 rr_next = rec4[(size_t)(chunk0 + min(1, nchunks - 1)) * 64 + lane];
     uint32_t cam_next = chunk_cam(ck_next, min(1, nchunks - 1));
+    uint32_t cam_next2 = chunk_cam2(min(1, nchunks - 1));
 
     // queued layout: the row's camera is the same for every pair of the task -- it stays in registers (the same address in
     // every lane: one request per load), and only the seven partners are read from the staged copy chunk by chunk
     double cvi_task[QL ? 16 : 1];
     if constexpr (QL) {
-        const double2* pc = reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)qdesc[8 * (size_t)chunk0 + 7].cj);
+        const double2* pc = reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)qdesc[ND * (size_t)chunk0 + NQ].cj);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { const double2 a = pc[k]; cvi_task[2 * k] = a.x; cvi_task[2 * k + 1] = a.y; }
     }
@@ -797,6 +819,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         // ---- cameras of this lane's pair: LDS (DMA issued a chunk ago) or, in a chunk of many tiny blocks, memory ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // gathers, block descriptors, and the LDS-DMA (it writes LDS behind the VM counter)
         reinterpret_cast<double2*>(CAMS)[lane] = cam_stage;   // (the previous chunk's camera reads are long done)
+        if constexpr (QL && DC == 6) reinterpret_cast<double2*>(CAMS)[64 + lane] = cam_stage2;
         __builtin_amdgcn_wave_barrier();
         const unsigned long long t1 = stamp();
         Gather dat;
@@ -809,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             for (int k = 0; k < 16; ++k) { cvi[k] = dat.lm[k % 4].x + k; cvj[k] = dat.lm[k % 4].y - k; }
         } else {
             if (QL) {
-                const double2* cj = reinterpret_cast<const double2*>(CAMS + (1 + blk) * kCamStride);
+                const double2* cj = reinterpret_cast<const double2*>(CAMS + ((DC == 9 ? 1 : 0) + blk) * kCamStride);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 b = cj[k]; cvj[2 * k] = b.x; cvj[2 * k + 1] = b.y; }
 #pragma unroll
@@ -915,10 +938,12 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             load_blocks(ck, bd_next, min(q + 1, nchunks - 1));
             dma = QL || 1 + __popc(ck.mask & ~1u) <= kPairDmaBlocks;
             cam_stage = cam_piece(cam_next);
+            if constexpr (QL && DC == 6) cam_stage2 = cam_piece(cam_next2);
             const int q2 = min(q + 2, nchunks - 1);
             ck_next = chunk_desc(q2);
             rr_next = rec4[(size_t)(chunk0 + q2) * 64 + lane];
             cam_next = chunk_cam(ck_next, q2);
+            cam_next2 = chunk_cam2(q2);
         }
         // The block finished by the PREVIOUS chunk goes to memory here, behind this chunk's gathers: the vector-memory counter
         // counts stores too and in issue order, so stores issued before loads that the code waits for (the compiler puts its own
@@ -932,8 +957,8 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             // nine steps, pair g + 7 t of the chunk in step t; ping-pong operand registers as below
             if (!(ABL & 2)) {
                 auto ld = [&](int t, double2& u0, double2& u1, double2& u2, double2& v0, double2& v1, double2& v2) {
-                    const double2* qu = reinterpret_cast<const double2*>(U + (g + 7 * t) * UV + bi * 6);
-                    const double2* qv = reinterpret_cast<const double2*>(V + (g + 7 * t) * UV + bj * 6);
+                    const double2* qu = reinterpret_cast<const double2*>(U + (g + NQ * t) * UV + bi * 6);
+                    const double2* qv = reinterpret_cast<const double2*>(V + (g + NQ * t) * UV + bj * 6);
                     u0 = qu[0]; u1 = qu[1]; u2 = qu[2]; v0 = qv[0]; v1 = qv[1]; v2 = qv[2];
                 };
                 auto mac = [&](const double2 u0, const double2 u1, const double2 u2, const double2 v0, const double2 v1, const double2 v2) {
@@ -946,14 +971,24 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
                 };
                 double2 a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5;
                 ld(0, a0, a1, a2, a3, a4, a5);
+                if constexpr (QLEN == 9) {
 #pragma unroll
-                for (int t = 0; t < 8; t += 2) {
-                    ld(t + 1, b0, b1, b2, b3, b4, b5);
+                    for (int t = 0; t < 8; t += 2) {
+                        ld(t + 1, b0, b1, b2, b3, b4, b5);
+                        mac(a0, a1, a2, a3, a4, a5);
+                        ld(t + 2, a0, a1, a2, a3, a4, a5);
+                        mac(b0, b1, b2, b3, b4, b5);
+                    }
                     mac(a0, a1, a2, a3, a4, a5);
-                    ld(t + 2, a0, a1, a2, a3, a4, a5);
+                } else {   // four steps
+                    ld(1, b0, b1, b2, b3, b4, b5);
+                    mac(a0, a1, a2, a3, a4, a5);
+                    ld(2, a0, a1, a2, a3, a4, a5);
+                    mac(b0, b1, b2, b3, b4, b5);
+                    ld(3, b0, b1, b2, b3, b4, b5);
+                    mac(a0, a1, a2, a3, a4, a5);
                     mac(b0, b1, b2, b3, b4, b5);
                 }
-                mac(a0, a1, a2, a3, a4, a5);
             }
             // a queue whose block (piece) ends with this chunk: its nine lanes hold the finished 3 x 3 sub-blocks.  They are
             // parked and stored at the top of the NEXT chunk, behind its wait for the gathers: stored here they would be the
@@ -963,9 +998,9 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             if (q == nchunks - 1) {   // wave-uniform: the tails that join a carried head (kPairQJoin only occurs here)
                 const bool join = ((ck_cur.mask >> g) & 1u) && (bd_cur.flags & kPairQJoin);
 #pragma unroll
-                for (int k = 0; k < 9; ++k) { const double o = __shfl_down(carry[k], 9, 64); acc[k] += join ? o : 0.0; }
+                for (int k = 0; k < 9; ++k) { const double o = __shfl_down(carry[k], GL, 64); acc[k] += join ? o : 0.0; }
             }
-            if (ck_cur.mask & 0x7fu) {   // wave-uniform: some queue's block (piece) ends with this chunk
+            if (ck_cur.mask & ((1u << NQ) - 1u)) {   // wave-uniform: some queue's block (piece) ends with this chunk
                 // The nine lanes of a group hold the block as 3 x 3 sub-blocks; stored like that, one store instruction touches
                 // six 64-byte lines per block (three rows, each 72-byte row astride two lines) and a block costs 54 line
                 // writes -- 0.77 ms of the kernel went there.  Turned through the (now free) U area into one COLUMN per lane,
@@ -973,7 +1008,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
                 const bool mine = (ck_cur.mask >> g) & 1u;
                 const bool keep = mine && (bd_cur.flags & kPairQCarry) != 0;
                 double* T = U + 81 * g;
-                if (mine && !keep && lane < 63 && !(ABL & 4096)) {   // (lane 63 shadows lane 0 except in a join: it must not write)
+                if (DC == 9 && mine && !keep && lane < 63 && !(ABL & 4096)) {   // (lane 63 shadows lane 0 except in a join: it must not write)
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -983,8 +1018,8 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
                 if (mine) {
                     if (!keep) {
 #pragma unroll
-                        for (int r = 0; r < 9; ++r) pend[r] = (ABL & 4096) ? acc[r] : T[9 * sub + r];   // (4096: timing only, no transposition)
-                        pend_dst = bd_cur.dst; pend_fl = bd_cur.flags; pend_on = lane < 63;
+                        for (int r = 0; r < 9; ++r) pend[r] = ((ABL & 4096) || DC == 6) ? acc[r] : T[9 * sub + r];   // (4096: timing only, no transposition; d_c = 6: the sub-block as it stands)
+                        pend_dst = bd_cur.dst; pend_fl = bd_cur.flags; pend_on = DC == 6 || lane < 63;
                     }
 #pragma unroll
                     for (int k = 0; k < 9; ++k) { carry[k] = keep ? acc[k] : carry[k]; acc[k] = 0.0; }
@@ -1087,7 +1122,12 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
                         const double* orec, const PairQDesc* qdesc) {
     if (n_tasks == 0) return;
     const unsigned grid = (unsigned)((n_tasks + 3) / 4);
-    if (qdesc) {   // the queued layout (SelfCalibration's nine columns per camera only: set_structure builds it for nothing else)
+    if (qdesc && dc == 6) {   // the queued layout for six-column cameras (round 5): sixteen queues of four pairs
+        if (v.mask_code != 6) hipLaunchKernelGGL((k_schur_pairs_r<6, true, 0, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, qdesc);
+        else hipLaunchKernelGGL((k_schur_pairs_r<6, false, 0, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, qdesc);
+        return;
+    }
+    if (qdesc) {   // the queued layout, nine columns per camera
 #define PAIRS_Q(MK, A) hipLaunchKernelGGL((k_schur_pairs_r<9, MK, A, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, qdesc)
         if (v.mask_code != 7) PAIRS_Q(true, 0);
         else if (ablation == 64) PAIRS_Q(false, 64);

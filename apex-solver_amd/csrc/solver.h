@@ -136,7 +136,7 @@ class Solver : public LmBackend {
     double schur_scatter_pairs() const { return (double)n_pairs_; }
     double pair_blocks() const { return (double)n_pair_blocks_; }
     double pair_slots() const { return (double)n_pair_slots_; }
-    // the form that RUNS: the queued layout (4) exists for nine-column cameras only, six-column cameras run form 3's lists and kernels
+    // the form that RUNS (4 = the queued layout, either camera width since round 5)
     int schur_form() const { return (rows_form_ == 4 && !pair_queued_) ? 3 : rows_form_; }
     const double* setup_seconds() const { return setup_s_; }
     double touched_tiles() const { return (double)n_present_; }

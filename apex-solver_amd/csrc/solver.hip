@@ -380,7 +380,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     hs.seconds[2] = plan_seconds;
     // ---- task lists of the selected form of the Schur reduction (they need the slot map) ------------------------------
     PairDeviceTables dtab;
-    const bool recs_on_device = device_pair_recs_ && so.schur_form == 4 && dc_ == 9;
+    const bool recs_on_device = device_pair_recs_ && so.schur_form == 4;
     hs.build_schur_lists(so, tp_.slot_host(), recs_on_device ? &dtab : nullptr);
     n_rtasks_ = (int)hs.rtasks2.size();
     n_ptasks_ = (int)hs.pl.tasks.size();
@@ -418,7 +418,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         if (e == hipSuccess) e = up(&d_task, dtab.task);
         if (e == hipSuccess)
             e = launch_build_pair_recs_q(n_cam_, d_rows, d_run_ptr, d_run_cj, d_run_piece0, d_piece, d_task, cam_ptr_, cam_obs_, o_pt_, pt_ptr_, o_cam_,
-                                         precs_, dtab.n_slots, stream_);
+                                         precs_, dtab.n_slots, stream_, dc_);
         for (void* q : {(void*)d_rows, (void*)d_run_ptr, (void*)d_run_cj, (void*)d_run_piece0, (void*)d_piece, (void*)d_task})
             if (q) (void)hipFree(q);
         HIP_TRY(e);
