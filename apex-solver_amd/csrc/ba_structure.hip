@@ -366,8 +366,8 @@ void BaHostStructure::build_schur_lists(const BaStructOptions& o, const int* slo
     } else if (o.schur_form == 3 || o.schur_form == 4) {
         // every camera pair (i, j) of a landmark, sorted by the block S(cam_i, cam_j) it adds to
         build_pair_lists(dc, nt, slot_host, n_cam, cinv.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(),
-                         cam_obs.data(), &pl, o.pair_task_slots, /*queued=*/o.schur_form == 4,
-                         o.schur_form == 4 ? dev_tables : nullptr);
+                         cam_obs.data(), &pl, o.pair_task_slots, /*queued=*/o.schur_form == 4 && (dc == 9 || o.queued6),
+                         (o.schur_form == 4 && (dc == 9 || o.queued6)) ? dev_tables : nullptr);
     } else {
         // ---- k_schur_rows2 (the LDS row form, kept as the A/B of the pair list): neighbour lists (cameras cj <= ci sharing a
         // landmark with ci, from the FULL problem so that every rank writes the same blocks), row entries, row tasks --------

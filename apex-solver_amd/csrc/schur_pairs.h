@@ -86,9 +86,8 @@ struct PairLists {
 // Round 5: the RECORDS of the queued layout (97 M slots = 1.56 GB on final-13682: 0.1-0.18 s of host time plus 35 ms of upload,
 // the largest single piece of apexgpu_set_structure) can be written by the DEVICE instead: the host keeps what is small and
 // serial -- the blocks of every row, pieces, tasks, descriptors -- and hands over these tables; k_build_pair_recs_q walks the
-// observation lists that are on the device anyway.  Order inside a block: by the row camera's observation, as on the host
-// (a camera that sees one landmark twice may order that block's pairs differently from the host builder: both orders are
-// fixed functions of the lists, the sums they give differ in the last bits only, and no test mixes the two).
+// observation lists that are on the device anyway.  The order of a block's pairs is defined by that kernel (64 observations of
+// the row camera at a time, their partner slots in lockstep) and the host builder follows it: the two lists are the same list.
 struct PairDeviceTables {
     std::vector<int> rows;          // [n_cam] internal camera of row r (rows in the caller's camera order)
     std::vector<int> run_ptr;       // [n_cam + 1] the row's runs (= blocks of S with this row camera)

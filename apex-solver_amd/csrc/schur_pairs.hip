@@ -189,18 +189,28 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                 const int c = rows[r];
                 const auto& runs = row_runs[r];
                 for (size_t q = 0; q < runs.size(); ++q) { ridx[runs[q].cj] = (int)q; pos[runs[q].cj] = 0; }
-                for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
-                    const int i = cam_obs[e];
-                    const uint32_t l = o_pt[i];
-                    for (int j = pt_ptr[l]; j < i; ++j) {
-                        const uint32_t cj = o_cam[j];
-                        const Run& run = runs[ridx[cj]];
-                        const int k = pos[cj]++;
-                        const QPiece& pc = pieces[run.piece0 + k / kPiecePairs];
-                        const QTask& tk = qtasks[pc.task];
-                        const int kk = k % kPiecePairs, idx = pc.nonet0 + kk / QL, g = idx / tk.nchunks;
-                        out->recs[((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + g + NQ * (kk % QL)] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
-                    }
+                // The order of a block's pairs is the DEVICE builder's (k_build_pair_recs_q: a wave takes 64 observations of the row
+                // camera at a time and walks their partner slots s = 0, 1, ... in lockstep, lanes in order inside a step), so that a
+                // list built here and a list built there are the same list, slot for slot (round 5).
+                for (int e0 = cam_ptr[c]; e0 < cam_ptr[c + 1]; e0 += 64) {
+                    const int e1 = std::min(e0 + 64, cam_ptr[c + 1]);
+                    int maxnp = 0;
+                    for (int e = e0; e < e1; ++e) { const int i = cam_obs[e]; maxnp = std::max(maxnp, i - pt_ptr[o_pt[i]]); }
+                    for (int sp = 0; sp < maxnp; ++sp)
+                        for (int e = e0; e < e1; ++e) {
+                            const int i = cam_obs[e];
+                            const uint32_t l = o_pt[i];
+                            const int b = pt_ptr[l];
+                            if (sp >= i - b) continue;
+                            const int j = b + sp;
+                            const uint32_t cj = o_cam[j];
+                            const Run& run = runs[ridx[cj]];
+                            const int k = pos[cj]++;
+                            const QPiece& pc = pieces[run.piece0 + k / kPiecePairs];
+                            const QTask& tk = qtasks[pc.task];
+                            const int kk = k % kPiecePairs, idx = pc.nonet0 + kk / QL, g = idx / tk.nchunks;
+                            out->recs[((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + g + NQ * (kk % QL)] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
+                        }
                 }
             }
         });
@@ -637,14 +647,14 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         if (QL && pend_on && !(ABL & 1024)) {
             double* dst = tiles + (((int64_t)pend_dst.y << 32) | (uint32_t)pend_dst.x);
             const uint32_t fl = pend_fl & (kPairBlockAtomic | kPairBlockDiag);
-            const Acc9 pv{pend[0], pend[1 % (QL ? 9 : 1)], pend[2 % (QL ? 9 : 1)], pend[3 % (QL ? 9 : 1)], pend[4 % (QL ? 9 : 1)], pend[5 % (QL ? 9 : 1)],
-                          pend[6 % (QL ? 9 : 1)], pend[7 % (QL ? 9 : 1)], pend[8 % (QL ? 9 : 1)]};
-            if (DC == 9) {   // pend[r] = element (r, sub): one column per lane
+#define PEND_ACC9 Acc9{pend[0], pend[1 % (QL ? 9 : 1)], pend[2 % (QL ? 9 : 1)], pend[3 % (QL ? 9 : 1)], pend[4 % (QL ? 9 : 1)], pend[5 % (QL ? 9 : 1)], \
+                      pend[6 % (QL ? 9 : 1)], pend[7 % (QL ? 9 : 1)], pend[8 % (QL ? 9 : 1)]}
+            if constexpr (DC == 9) {   // pend[r] = element (r, sub): one column per lane
                 if (fl == 0) {
 #pragma unroll
                     for (int r = 0; r < 9; ++r) dst[r * kNB + sub] = pend[r % (QL ? 9 : 1)];
                 } else {
-                    pairs_flush_slow_col<DC>(dst, fl, pv, sub);
+                    pairs_flush_slow_col<DC>(dst, fl, PEND_ACC9, sub);
                 }
             } else {         // d_c = 6: pend = the lane's 3 x 3 sub-block (bi, bj): a 48-byte row of the block is two adjacent lanes' stores
                 if (fl == 0) {
@@ -654,9 +664,10 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
 #pragma unroll
                         for (int c = 0; c < 3; ++c) d0[r * kNB + c] = pend[(3 * r + c) % (QL ? 9 : 1)];
                 } else {
-                    pairs_flush_slow<DC>(dst, fl, pv, sub);
+                    pairs_flush_slow<DC>(dst, fl, PEND_ACC9, sub);
                 }
             }
+#undef PEND_ACC9
         }
         pend_on = false;
     };

@@ -106,6 +106,7 @@ class Solver : public LmBackend {
     // variants 0 / 1 are answered by the matrix-free PCG (IterativeSchurSolver semantics, implicit_schur.rs:835-946): variant 0
     // at that solver's own defaults (500 iterations, 1e-9: implicit_schur.rs:94-95), variant 1 at the caller's cg parameters.
     // "auto_variant" 0 restores the refusal.  variant_used() / variant_reason() say what happened (apexgpu_variant_info).
+    void set_queued6(bool on) { queued6_ = on; }
     void set_device_pair_recs(bool on) { device_pair_recs_ = on; }   // before set_structure ("device_pair_list")
     int get_pair_records(uint32_t* recs4_out, int64_t cap_slots);     // tests: the pair records as they sit on the device
     void set_auto_variant(bool on) { auto_variant_ = on; }
@@ -136,7 +137,7 @@ class Solver : public LmBackend {
     double schur_scatter_pairs() const { return (double)n_pairs_; }
     double pair_blocks() const { return (double)n_pair_blocks_; }
     double pair_slots() const { return (double)n_pair_slots_; }
-    // the form that RUNS (4 = the queued layout, either camera width since round 5)
+    // the form that RUNS (4 = the queued layout: nine-column cameras, and six-column ones with "pairs_queued6")
     int schur_form() const { return (rows_form_ == 4 && !pair_queued_) ? 3 : rows_form_; }
     const double* setup_seconds() const { return setup_s_; }
     double touched_tiles() const { return (double)n_present_; }
@@ -223,6 +224,7 @@ class Solver : public LmBackend {
     uint32_t* wg_cam_list_ = nullptr;
     bool cam_staging_ = true;
     bool matrix_free_only_ = false;
+    bool queued6_ = false;           // "pairs_queued6": the queued layout for six-column cameras too (measured slower: ba_structure.h)
     bool device_pair_recs_ = true;   // queued layout: the pair records are written by the device (k_build_pair_recs_q), not built on the host and copied
     bool auto_variant_ = true, auto_fallback_ = false;   // see set_auto_variant
     std::string fallback_reason_;

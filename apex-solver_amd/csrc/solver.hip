@@ -204,7 +204,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     BaStructOptions so;
     so.dc = dc_; so.use_nd = use_nd_; so.nd_leaf = nd_leaf_; so.hubs_last = hubs_last_;
     so.rank = rank_; so.world = world_; so.dist_factor = dist_factor_; so.tree_sharding = tree_sharding_;
-    so.dist_selftest = dist_selftest_; so.schur_form = rows_form_; so.pair_task_slots = pair_task_slots_;
+    so.dist_selftest = dist_selftest_; so.schur_form = rows_form_; so.pair_task_slots = pair_task_slots_; so.queued6 = queued6_;
     std::unique_ptr<BaHostStructure> hs_owner(new BaHostStructure);
     BaHostStructure& hs = *hs_owner;
     // Camera order and tile structure first; then the tile plan (symbolic fill, task lists, 1.4 GB of device allocations: 0.06-
@@ -380,7 +380,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     hs.seconds[2] = plan_seconds;
     // ---- task lists of the selected form of the Schur reduction (they need the slot map) ------------------------------
     PairDeviceTables dtab;
-    const bool recs_on_device = device_pair_recs_ && so.schur_form == 4;
+    const bool recs_on_device = device_pair_recs_ && so.schur_form == 4 && (dc_ == 9 || queued6_);
     hs.build_schur_lists(so, tp_.slot_host(), recs_on_device ? &dtab : nullptr);
     n_rtasks_ = (int)hs.rtasks2.size();
     n_ptasks_ = (int)hs.pl.tasks.size();

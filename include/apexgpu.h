@@ -253,11 +253,13 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     S is never formed, so only its diagonal tiles are allocated and no pair list is built -- set-up and LM
  *                     iteration are then independent of the fill of S (an input whose S is dense costs what a banded one
  *                     does); variants 0 / 1 and the exports of S answer APEXGPU_ERR_INVALID_STATE on such a handle
+ *   "pairs_queued6" (0)  before set_structure: the queued layout of the pair list ("schur_form" 4) also for SIX-column cameras
+ *                     (BundleAdjustment mode): sixteen queues of four pairs per chunk.  Built and measured in round 5: slower than
+ *                     form 3 there (3.52 against 2.90 ms on final-13682), so six-column cameras keep form 3 unless this is set
  *   "device_pair_list" (1)  before set_structure: the RECORDS of the sorted pair list (queued layout, nine-column cameras: 1.56 GB
  *                     on final-13682) are written by the device from the observation lists (k_build_pair_recs_q: the host keeps
  *                     the small, serial part -- blocks, tasks, descriptors); 0 = built on the host and copied (rounds 2-4):
- *                     0.1-0.18 s + 35 ms of upload of every apexgpu_set_structure.  Same list unless a camera sees one landmark
- *                     twice (that block's pairs may then come in another, equally fixed order)
+ *                     0.1-0.18 s + 35 ms of upload of every apexgpu_set_structure.  The same list, slot for slot
  *   "auto_variant" (1)  before set_structure: a structure whose direct factorisation is refused -- more than 8e7 tile products
  *                     per factorisation (S dense at tile granularity: a photo collection), or, on a single rank, tiles beyond
  *                     the free HBM -- does NOT fail apexgpu_set_structure: the handle is built matrix-free only by itself and
