@@ -1233,4 +1233,9 @@ void launch_export_linearization(int dc, const BAView& v, const int* o_orig, dou
     else hipLaunchKernelGGL(k_export_linearization<6>, dim3(grid), dim3(256), 0, s, v, o_orig, r_out, jc_out, jl_out);
 }
 
+// (set-up: the first launch of a kernel of this translation unit loads its code object -- tens of milliseconds for the big
+// ones; Solver::set_structure pays that on a background thread while the host builds its lists: warm_device_code)
+__global__ void k_warm_ba_kernels() {}
+void warm_ba_kernels(hipStream_t s) { hipLaunchKernelGGL(k_warm_ba_kernels, dim3(1), dim3(64), 0, s); }
+
 }  // namespace apex

@@ -2200,4 +2200,9 @@ void launch_pcg_update_p(int n, double beta, const double* z, double* p, hipStre
     hipLaunchKernelGGL(k_pcg_update_p, dim3((n + 255) / 256), dim3(256), 0, s, n, beta, z, p);
 }
 
+// (set-up: the first launch of a kernel of this translation unit loads its code object -- tens of milliseconds for the big
+// ones; Solver::set_structure pays that on a background thread while the host builds its lists: warm_device_code)
+__global__ void k_warm_chol_kernels() {}
+void warm_chol_kernels(hipStream_t s) { hipLaunchKernelGGL(k_warm_chol_kernels, dim3(1), dim3(64), 0, s); }
+
 }  // namespace apex

@@ -1170,4 +1170,9 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
 #undef PAIRS_R
 }
 
+// (set-up: the first launch of a kernel of this translation unit loads its code object -- tens of milliseconds for the big
+// ones; Solver::set_structure pays that on a background thread while the host builds its lists: warm_device_code)
+__global__ void k_warm_schur_pairs() {}
+void warm_schur_pairs(hipStream_t s) { hipLaunchKernelGGL(k_warm_schur_pairs, dim3(1), dim3(64), 0, s); }
+
 }  // namespace apex

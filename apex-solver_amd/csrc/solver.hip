@@ -12,6 +12,10 @@
 
 namespace apex {
 
+void warm_ba_kernels(hipStream_t s);
+void warm_schur_pairs(hipStream_t s);
+void warm_chol_kernels(hipStream_t s);
+
 #define HIP_TRY(expr)                                         \
     do {                                                      \
         int _rc = check_hip((expr), #expr);                   \
@@ -174,6 +178,19 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
                           double huber_delta) {
     if (n_cam_ <= 0 || n_pt_ <= 0) return fail(kInvalidInput, n_cam_ <= 0 ? "No camera variables found" : "No landmark variables found");
     if (n_obs_ < 0 || n_obs_ > 2000000000LL) return fail(kInvalidInput, "observation count out of range");
+    HIP_TRY(hipSetDevice(device_));
+    if (!stream_) HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    // the code objects of the three kernel files are loaded by their first launch (~0.1 s in all on a cold process): done here,
+    // on a thread, beside the host's list building instead of in front of the first kernels that matter
+    std::thread warmer([this] {
+        if (hipSetDevice(device_) != hipSuccess) return;
+        hipStream_t ws = nullptr;
+        if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) return;
+        warm_ba_kernels(ws); warm_schur_pairs(ws); warm_chol_kernels(ws);
+        (void)hipStreamSynchronize(ws);
+        (void)hipStreamDestroy(ws);
+    });
+    struct WJoiner { std::thread& t; ~WJoiner() { if (t.joinable()) t.join(); } } wjoiner{warmer};
     SetupTrace tr;
     {
         std::atomic<int64_t> bad(n_obs_);   // first observation that references a missing variable
@@ -187,8 +204,6 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         });
         if (bad.load() < n_obs_) return fail(kInvalidInput, "observation " + std::to_string(bad.load()) + " references a missing variable");
     }
-    HIP_TRY(hipSetDevice(device_));
-    if (!stream_) HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     huber_delta_ = huber_delta;
     intr_col_.assign(intr_col, intr_col + n_cam_);
     pose_col_.assign(pose_col, pose_col + n_cam_);

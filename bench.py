@@ -556,7 +556,7 @@ def main():
     # HBM traffic of the same kernel from the committed PMC pass (rocprofv3 cannot run inside this
     # process); only attached when the committed profile is of this very workload and kernel
     try:
-        pm_path = next(p for p in (os.path.join(ROOT, "profiles", f"r0{r}_final13682_pmc_summary.json") for r in (4, 3, 2)) if os.path.exists(p))
+        pm_path = next(p for p in (os.path.join(ROOT, "profiles", f"r0{r}_final13682_pmc_summary.json") for r in (5, 4, 3, 2)) if os.path.exists(p))
         pm = json.load(open(pm_path))
         if world == 1 and args.workload == "final-13682" and args.scale == 1.0 and args.mode == "selfcal":
             k = [v for n, v in pm["kernels"].items() if kernel in n]
