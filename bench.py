@@ -425,6 +425,13 @@ def main():
         s.with_cg_params(500, 1e-9)  # IterativeSchurSolver::new (implicit_schur.rs:94-95)
     if args.variant == "implicit":
         s.with_option("matrix_free_only", 1)   # S is never formed: no tile structure beyond the diagonal, no pair list
+    shared_gpu = world > 1 and os.environ.get("APEX_BENCH_PG", "nccl") == "gloo" and world > torch.cuda.device_count()
+    if shared_gpu:
+        # Bring-up mode only (several ranks on ONE GPU): two processes time-slice the device, and a launch whose workgroups wait
+        # for each other's flags (the dataflow sweeps, the dataflow top of the factorisation) can then starve until its bounded
+        # wait gives up -- handled (the solve is repeated by level launches, the handle stays on them), but each time-out costs
+        # ~1 s and a second one fails the solve.  One rank per GPU, the production layout, keeps the dataflow launches.
+        s.with_option("tri_dataflow", 0).with_option("factor_flow", 0)
     for o in args.opt:
         s.with_option(o.split("=")[0], int(o.split("=")[1]))
     comm_kind = "none"
@@ -476,6 +483,8 @@ def main():
             dist.broadcast(tag, 0)
             s.with_shm_communicator(world, rank, f"bench-{int(tag.item())}")
             comm_kind = "shm" if args.comm == "shm" else "shm (RCCL communicator failed: " + (why or "on another rank") + ")"
+        if shared_gpu:
+            comm_kind += "; ranks share a GPU: level launches instead of the dataflow launches"
     t_setup = time.perf_counter()
     s.initialize_structure(prob)
     s.set_parameters(d.poses, d.intr, d.points)
