@@ -814,12 +814,31 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     }
     int rc = (variant == 2) ? assemble_implicit(lambda) : assemble(lambda, 0.0, variant == 0);
     if (rc != kOk) return rc;
+    // ONE host wait per Cholesky solve (round 5).  Until round 4 the host waited three times inside this call -- for the
+    // landmark-inversion flag behind the assembly, for the pivot flag behind the factorisation, for the step at the end -- and
+    // the GPU idled through a synchronisation plus a graph launch each time.  On a single rank the factorisation, the sweeps and
+    // the back-substitution are now enqueued back to back and the two flags are read at the final wait; a singular landmark
+    // block, a failed pivot or a dataflow time-out then takes the old path from the top (re-assembly, ladder), results unchanged.
+    const bool one_wait = variant == 0 && !(comm_ && world_ > 1) && !tp_.distributed();
+    bool speculative = false;
+    if (one_wait) {
+        int failed = 0;
+        last_reg_ = 0.0;
+        stage_begin(kStFactor);
+        const hipError_t fe = tp_.factor(&failed, g_red_, pcg_buf_, /*defer_flags=*/true);
+        HIP_TRY(fe);
+        stage_end(kStFactor);
+        rc = tri_solve();
+        if (rc != kOk) return rc;
+        speculative = true;
+    } else {
     int lm_err = 0;
     HIP_TRY(hipMemcpyAsync(&lm_err, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
     if (lm_err) return fail(kSingularMatrix, "Landmark block is singular");
     rc = (variant == 2) ? implicit_pcg_solve(lambda, pcg_max, pcg_tol) : (variant == 1) ? pcg_solve() : factor_and_solve(lambda);
     if (rc != kOk) return rc;
+    }
     for (int attempt = 0;; ++attempt) {
         stage_begin(kStBackSub);
         if (scaled_) launch_vec_mul(n_c_, dcam_, cam_scale_, dcam_, stream_);  // apply_inverse_scaling: dc = D_c y
@@ -828,6 +847,26 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
         HIP_TRY(hipGetLastError());
         have_step_ = true;
         rc = export_step(step_out, grad_out);   // (synchronises: the sweeps' error word is on the host now)
+        if (rc == kOk && speculative) {   // the flags the old path read before going on
+            speculative = false;
+            int lm_err = 0, failed = 0;
+            HIP_TRY(hipMemcpyAsync(&lm_err, flags_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(tp_.read_flags(&failed));   // (synchronises; raises factor_flow_gave_up() on a dataflow time-out)
+            if (lm_err) { have_step_ = false; return fail(kSingularMatrix, "Landmark block is singular"); }
+            const bool gave_up = tp_.factor_flow_gave_up();
+            if (failed || gave_up) {
+                // what was enqueued behind the failed factorisation is void: S again, then the old path (ladder included)
+                have_step_ = false;
+                (void)tp_.sweep_timed_out();   // (clears the word a sweep over a broken factor may have raised)
+                if (gave_up) ++n_factor_flow_timeouts_;
+                rc = assemble(lambda, 0.0, true);
+                if (rc != kOk) return rc;
+                rc = factor_and_solve(lambda);
+                if (rc != kOk) return rc;
+                attempt = -1;   // (the loop's counter is for the sweep time-outs of the solve that follows)
+                continue;       // back-substitution and export once more
+            }
+        }
         if (rc != kOk || variant != 0 || !tp_.sweep_timed_out()) return rc;
         // A dataflow sweep of THIS solve ran into its spin limit (chol_kernels.hip, flow_wait): dcam_ is wrong.  The factor is
         // intact, so the solve is repeated with the level-by-level sweeps -- for this call and for the rest of the plan's

@@ -166,7 +166,9 @@ class TilePlan {
     // Cholesky in place; *failed_at = 0 or (tile column + 1) of the first non-positive pivot.  Syncs.
     // With rhs/work (2*n_pad doubles) the forward sweep L y = rhs rides along on a third stream; the next
     // solve(rhs, x, work) with the same pointers then only runs the backward sweep.
-    hipError_t factor(int* failed_at, const double* rhs = nullptr, double* work = nullptr);
+    // defer_flags: do not wait for the pivot flag (single-rank plans only): the caller enqueues the sweeps behind the
+    // factorisation and calls read_flags() at its own synchronisation point (Solver::solve_augmented: one host wait per solve)
+    hipError_t factor(int* failed_at, const double* rhs = nullptr, double* work = nullptr, bool defer_flags = false);
     void enable_fused_forward(bool on) { fuse_forward_ = on; }
     // x = (L L^T)^-1 rhs ; work: 2*n_pad doubles ; all on the plan's stream, no sync.  hipErrorUnknown: a collective of
     // the distributed sweeps failed (the communicator's own message is with the caller)

@@ -1307,7 +1307,7 @@ void TilePlan::solve_phase(int phase, const double* rhs, double* x, double* work
     if (phase == 2 || !run_graph(4 + phase, rhs, x, work)) enqueue_dist_solve(phase, rhs, x, work);
 }
 
-hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
+hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work, bool defer_flags) {
     if (distributed()) {
         if (!comm_.sum || !comm_.max_int) return hipErrorNotInitialized;  // a distributed plan needs its communicator
         fwd_rhs_ = nullptr;
@@ -1327,6 +1327,7 @@ hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work) {
         poison_factor_ = false;
     } else if (!run_graph(0, rhs, nullptr, work)) enqueue_factor(rhs, work, 0, n_levels_);
     fwd_rhs_ = rhs; fwd_work_ = work;  // the forward sweep for this right-hand side is part of the factorisation
+    if (defer_flags) { *failed_at = 0; return hipGetLastError(); }
     return read_flags(failed_at);
 }
 

@@ -93,7 +93,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline_worker(workload, shape_scale, mode, dense_too=True):
+def cpu_baseline_worker(workload, shape_scale, mode, dense_too=True, n_iter=2):
     """Runs in a child process (OMP_NUM_THREADS / OMP_PROC_BIND set by the parent): 2 LM iterations of the oracle with the
     SPARSE solve -- S sparsified at 1e-12 and factorised inside the envelope of a fill-reducing order, the reference's
     solve_with_cholesky contract (explicit_schur.rs:913-921, 544-550) -- and, beside it, one iteration with the dense LL^T
@@ -126,12 +126,12 @@ def cpu_baseline_worker(workload, shape_scale, mode, dense_too=True):
         return (time.perf_counter() - t0) * 1e3 / n_iter, t_solve * 1e3 / n_iter
 
     p0 = o.get_params()
-    ms, ms_solve = iterate(3, 2)
+    ms, ms_solve = iterate(3, n_iter)
     stats = o.last_sparse_stats()
     out = {
         "value": ms, "unit": "ms per LM iter on the sample", "cores": cores, "kind": "port", "solve": "sparse",
         "sample": f"{d.name}: {d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations, "
-                  f"{2} LM iterations of oracle/ba_oracle.c (linearise + explicit Schur into a dense S + sparsify at 1e-12 + "
+                  f"{n_iter} LM iteration(s) of oracle/ba_oracle.c (linearise + explicit Schur into a dense S + sparsify at 1e-12 + "
                   f"envelope Cholesky in reverse Cuthill-McKee order + trial cost)",
         "obs_per_s": d.n_obs / (ms * 1e-3),
         "solve_ms": ms_solve,   # H = J^T J, Schur complement, factorisation, back-substitution
@@ -159,10 +159,10 @@ def cpu_baseline(args, shape_scale, mode, full_size):
 
     cores = usable_cores()
 
-    def run(threads, sc, dense_too=False):
+    def run(threads, sc, dense_too=False, n_iter=2):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false", OMP_WAIT_POLICY="passive", OMP_DYNAMIC="false")
         code = (f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; "
-                f"print('CPUBASE ' + json.dumps(bench.cpu_baseline_worker({args.workload!r}, {sc!r}, {mode!r}, {dense_too!r})))")
+                f"print('CPUBASE ' + json.dumps(bench.cpu_baseline_worker({args.workload!r}, {sc!r}, {mode!r}, {dense_too!r}, {n_iter!r})))")
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
         line = [l for l in p.stdout.splitlines() if l.startswith("CPUBASE ")]
         if not line:
@@ -178,10 +178,13 @@ def cpu_baseline(args, shape_scale, mode, full_size):
         out["sample"] += (f"; a SAMPLE of the same generator: {args.workload} itself is beyond the reference's CPU path, which forms S as a"
                           " dense n_c x n_c matrix (explicit_schur.rs:782) -- 121 GB at 13,682 cameras x 9 DOF")
     keep = ("value", "unit", "cores", "sample", "obs_per_s", "solve", "solve_ms")
-    third = shape_scale / 3.0 if not full_size else shape_scale / 6.0
-    out["one_thread"] = {k: v for k, v in run(1, third).items() if k in keep}
+    # ONE thread on the SAME sample as `value` where that sample is the bounded one (round 5: a third of it until then, which made
+    # the two figures incomparable), one LM iteration; the full-size configurations keep a sixth (their one-thread run would
+    # take minutes)
+    third = shape_scale if not full_size else shape_scale / 6.0
+    out["one_thread"] = {k: v for k, v in run(1, third, False, 1 if not full_size else 2).items() if k in keep}
     if cores > 32:
-        out["all_cores"] = {k: v for k, v in run(cores, third).items() if k in keep}
+        out["all_cores"] = {k: v for k, v in run(cores, shape_scale / 3.0 if not full_size else shape_scale / 6.0).items() if k in keep}
     return out
 
 
