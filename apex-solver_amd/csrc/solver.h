@@ -107,6 +107,8 @@ class Solver : public LmBackend {
     // at that solver's own defaults (500 iterations, 1e-9: implicit_schur.rs:94-95), variant 1 at the caller's cg parameters.
     // "auto_variant" 0 restores the refusal.  variant_used() / variant_reason() say what happened (apexgpu_variant_info).
     void set_queued6(bool on) { queued6_ = on; }
+    void set_prezero(bool on) { prezero_ = on; }
+    void set_one_wait(bool on) { one_wait_ = on; }
     void set_device_pair_recs(bool on) { device_pair_recs_ = on; }   // before set_structure ("device_pair_list")
     int get_pair_records(uint32_t* recs4_out, int64_t cap_slots);     // tests: the pair records as they sit on the device
     void set_auto_variant(bool on) { auto_variant_ = on; }
@@ -224,6 +226,13 @@ class Solver : public LmBackend {
     uint32_t* wg_cam_list_ = nullptr;
     bool cam_staging_ = true;
     bool matrix_free_only_ = false;
+    // The 1.34 GB of S tiles are cleared for the NEXT assembly on a side stream right behind a finished Cholesky solve -- beside
+    // the step statistics, the retraction and the trial cost, which leave the memory system mostly idle -- instead of at the
+    // head of the assembly (0.19 ms of every iteration, round 5; single rank; "prezero_tiles" 0: as before)
+    bool one_wait_ = true;   // "one_wait": one host wait per Cholesky solve (solve_augmented); 0 = three, as in rounds 1-4
+    bool prezero_ = true, tiles_prezeroed_ = false;
+    hipStream_t zero_stream_ = nullptr;
+    hipEvent_t zero_ev_ = nullptr;
     bool queued6_ = false;           // "pairs_queued6": the queued layout for six-column cameras too (measured slower: ba_structure.h)
     bool device_pair_recs_ = true;   // queued layout: the pair records are written by the device (k_build_pair_recs_q), not built on the host and copied
     bool auto_variant_ = true, auto_fallback_ = false;   // see set_auto_variant

@@ -55,6 +55,8 @@ Solver::~Solver() {
     for (void* p : ptrs)
         if (p) hipFree(p);
     comm_.reset();
+    if (zero_stream_) { (void)hipStreamSynchronize(zero_stream_); (void)hipStreamDestroy(zero_stream_); }
+    if (zero_ev_) (void)hipEventDestroy(zero_ev_);
     for (int b = 0; b < 2; ++b) {
         if (pin_[b]) (void)hipHostFree(pin_[b]);
         if (pin_ev_[b]) (void)hipEventDestroy(pin_ev_[b]);
@@ -591,7 +593,12 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     stage_begin(kStAssembleCam);
     // (a tree-sharded rank that assembles for its distributed factorisation adds to its own and the top tiles only; every
     // other use of S -- PCG, exports, the ladder's diagonal -- all-reduces every touched tile and needs them all cleared)
-    HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor));
+    if (tiles_prezeroed_) {   // cleared on the side stream behind the previous solve (solve_augmented)
+        tiles_prezeroed_ = false;
+        HIP_TRY(hipStreamWaitEvent(stream_, zero_ev_, 0));
+    } else {
+        HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor));
+    }
     HIP_TRY(hipMemsetAsync(g_red_, 0, n_c_pad_ * sizeof(double), stream_));
     HIP_TRY(hipMemsetAsync(g_c_, 0, n_c_pad_ * sizeof(double), stream_));
     HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
@@ -712,6 +719,10 @@ int Solver::pcg_solve() {
 // Sharded: g_red, g_c and the diagonal blocks are all-reduced once, every S p once per iteration.
 // ---------------------------------------------------------------------------------------------
 int Solver::assemble_implicit(double lambda) {
+    if (tiles_prezeroed_) {   // the side stream may still be clearing the tiles this pass stores its diagonal blocks into
+        tiles_prezeroed_ = false;
+        HIP_TRY(hipStreamWaitEvent(stream_, zero_ev_, 0));
+    }
     const BAView v = view(cur_);
     stage_begin(kStAssembleLm);
     HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
@@ -819,7 +830,7 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     // the GPU idled through a synchronisation plus a graph launch each time.  On a single rank the factorisation, the sweeps and
     // the back-substitution are now enqueued back to back and the two flags are read at the final wait; a singular landmark
     // block, a failed pivot or a dataflow time-out then takes the old path from the top (re-assembly, ladder), results unchanged.
-    const bool one_wait = variant == 0 && !(comm_ && world_ > 1) && !tp_.distributed();
+    const bool one_wait = one_wait_ && variant == 0 && !(comm_ && world_ > 1) && !tp_.distributed();
     bool speculative = false;
     if (one_wait) {
         int failed = 0;
@@ -866,6 +877,14 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
                 attempt = -1;   // (the loop's counter is for the sweep time-outs of the solve that follows)
                 continue;       // back-substitution and export once more
             }
+        }
+        if (rc == kOk && variant == 0 && one_wait && prezero_ && !tp_.sweep_timed_out_peek()) {
+            // the factor is used up (the step is out): clear the tiles for the next assembly beside what the caller does next
+            if (!zero_stream_) HIP_TRY(hipStreamCreateWithFlags(&zero_stream_, hipStreamNonBlocking));
+            if (!zero_ev_) HIP_TRY(hipEventCreateWithFlags(&zero_ev_, hipEventDisableTiming));
+            HIP_TRY(tp_.zero_tiles(false, zero_stream_));
+            HIP_TRY(hipEventRecord(zero_ev_, zero_stream_));
+            tiles_prezeroed_ = true;
         }
         if (rc != kOk || variant != 0 || !tp_.sweep_timed_out()) return rc;
         // A dataflow sweep of THIS solve ran into its spin limit (chol_kernels.hip, flow_wait): dcam_ is wrong.  The factor is

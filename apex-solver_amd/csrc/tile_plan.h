@@ -148,6 +148,7 @@ class TilePlan {
     // the ranks, so that every rank takes the same decision).  Valid once the plan's stream has been synchronised behind
     // solve(); reading clears it.  The caller repeats that solve with enable_tri_flow(false).
     bool sweep_timed_out();
+    bool sweep_timed_out_peek() const { return flow_err_host_ && flow_err_host_[0] != 0; }   // the same word, not cleared
     int sweep_timeouts() const { return n_sweep_timeouts_; }
     // tests only: the next solve()'s forward (1) / backward (2) dataflow sweep runs into its spin limit on purpose
     void debug_poison_next_solve(int which) { poison_ = which; }
@@ -159,7 +160,7 @@ class TilePlan {
 
     // async on the plan's stream.  own_touched_only: (distributed plans) this rank adds to the tiles of its own columns and
     // of the shared top only -- tree-sharded landmarks; the other ranks' tiles are then left alone
-    hipError_t zero_tiles(bool own_touched_only = false);
+    hipError_t zero_tiles(bool own_touched_only = false, hipStream_t on = nullptr /* nullptr: the plan's stream */);
     void add_diag(int n_valid, double add_valid, double pad_value);  // diagonal += / padding rows := value
     void diag(double* out) const;                        // out[n_pad] = diagonal
     void scale_sym(const double* scale);                 // A := D A D on the unfactored tiles, D = diag(scale[n_pad])

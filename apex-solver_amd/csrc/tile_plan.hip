@@ -877,8 +877,8 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     return "";
 }
 
-hipError_t TilePlan::zero_tiles(bool own_touched_only) {
-    const hipStream_t zs = stream_;
+hipError_t TilePlan::zero_tiles(bool own_touched_only, hipStream_t on) {
+    const hipStream_t zs = on ? on : stream_;
     fwd_rhs_ = nullptr;
     const size_t te = (size_t)kNB * kNB * sizeof(double);
     hipError_t e = hipSuccess;
