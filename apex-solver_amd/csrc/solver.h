@@ -226,11 +226,12 @@ class Solver : public LmBackend {
     uint32_t* wg_cam_list_ = nullptr;
     bool cam_staging_ = true;
     bool matrix_free_only_ = false;
-    // The 1.34 GB of S tiles are cleared for the NEXT assembly on a side stream right behind a finished Cholesky solve -- beside
-    // the step statistics, the retraction and the trial cost, which leave the memory system mostly idle -- instead of at the
-    // head of the assembly (0.19 ms of every iteration, round 5; single rank; "prezero_tiles" 0: as before)
+    // "prezero_tiles": the 1.34 GB of S tiles cleared for the NEXT assembly on a side stream right behind a finished Cholesky
+    // solve -- beside the step statistics, the retraction and the trial cost -- instead of at the head of the assembly (0.19 ms).
+    // Measured (round 5, profiles/r05_ab_one_wait_prezero.txt): the clear is not hidden, it moves -- the camera stage loses 0.17
+    // ms and k_step_stats / k_retract_points, which stream the same HBM, gain 0.18: 12.77 against 12.78 ms.  Off.
     bool one_wait_ = true;   // "one_wait": one host wait per Cholesky solve (solve_augmented); 0 = three, as in rounds 1-4
-    bool prezero_ = true, tiles_prezeroed_ = false;
+    bool prezero_ = false, tiles_prezeroed_ = false;
     hipStream_t zero_stream_ = nullptr;
     hipEvent_t zero_ev_ = nullptr;
     bool queued6_ = false;           // "pairs_queued6": the queued layout for six-column cameras too (measured slower: ba_structure.h)

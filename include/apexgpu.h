@@ -256,9 +256,9 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "one_wait" (1)    single rank, Cholesky variant: apexgpu_solve_augmented enqueues factorisation, sweeps and back-substitution
  *                     back to back and waits for the device ONCE (the landmark-inversion and pivot flags are read at that
  *                     wait; a failure repeats the solve on the old path, ladder included); 0: three waits as in rounds 1-4
- *   "prezero_tiles" (1)  single rank, Cholesky variant: the tiles of S are cleared for the next assembly on a side stream right
+ *   "prezero_tiles" (0)  single rank, Cholesky variant; 1: the tiles of S are cleared for the next assembly on a side stream right
  *                     behind a finished solve (beside the caller's step statistics / trial cost) instead of at the head of the
- *                     assembly; 0: at the head of the assembly as in rounds 1-4
+ *                     assembly.  Measured neutral (the clear moves into the statistics / retraction kernels' time): off
  *   "pairs_queued6" (0)  before set_structure: the queued layout of the pair list ("schur_form" 4) also for SIX-column cameras
  *                     (BundleAdjustment mode): sixteen queues of four pairs per chunk.  Built and measured in round 5: slower than
  *                     form 3 there (3.52 against 2.90 ms on final-13682), so six-column cameras keep form 3 unless this is set
