@@ -37,6 +37,11 @@ struct BAView {
     // (wg_cam_list[w][0 .. wg_cam_n[w]), first-appearance order) and gives every observation its camera's slot in that list
     // (o_slot[i], 255 = not staged: the list is capped at kCamStageCap).  The workgroup copies those cameras to LDS once
     // -- a few hundred line accesses instead of ten scattered 16-byte loads per observation and lane.
+    // Landmark BUNDLES (round 5; NULL = the records are indexed by observation): the projection records of landmark l sit right
+    // behind a 64-byte copy of its record's first line -- [Hll^-1 (6) p.x p.y | rec 0 | rec 1 | ...], 128-byte aligned, 32-byte
+    // units: header at unit bun_ptr[l], record of the landmark's r-th observation at bun_ptr[l] + 2 + r.  An L2 miss costs per
+    // 128-byte line (profiles/r05_vmem_issue_bench_32MB_table.txt): a pair of the Schur kernel then touches 2.1 lines, not 2.6.
+    const int* bun_ptr;           // [n_pt]
     const uint8_t* o_slot;        // [n_obs]
     const uint8_t* wg_cam_n;      // [workgroups]
     const uint32_t* wg_cam_list;  // [workgroups][kCamStageCap]

@@ -252,6 +252,8 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
     stager.issue_indices(v);
     const int64_t lc = active ? l : 0;
     const int b = v.pt_ptr[lc], e = active ? v.pt_ptr[lc + 1] : b;
+    const int bun = v.bun_ptr ? v.bun_ptr[lc] : 0;                        // the landmark's bundle (32-byte units)
+    const int64_t rbase = v.bun_ptr ? (int64_t)bun + 2 - b : 0;            // record of observation i: unit rbase + i
     stager.issue_data(v.camq, nullptr);
     pw[0] = v.pts[3 * lc]; pw[1] = v.pts[3 * lc + 1]; pw[2] = v.pts[3 * lc + 2];
     const int i_first = max(min(b + g, (int)v.n_obs - 1), 0);   // (clamped: the load is unconditional, the use is not)
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
             if (orec) {   // record form of the pair kernel: the observation's projection record, 32 bytes, landmark-major
                 double rec[4];
                 linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl, rec);
-                double2* q = reinterpret_cast<double2*>(orec + 4 * (size_t)i);
+                double2* q = reinterpret_cast<double2*>(orec + 4 * (size_t)(rbase + i));
                 q[0] = make_double2(rec[0], rec[1]); q[1] = make_double2(rec[2], rec[3]);
             } else {
                 linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
@@ -319,6 +321,10 @@ __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda
             double2* q = reinterpret_cast<double2*>(hinv + kLmStride * l);
             q[0] = make_double2(Bi[0], Bi[1]); q[1] = make_double2(Bi[2], Bi[4]); q[2] = make_double2(Bi[5], Bi[8]);
             q[3] = make_double2(pw[0], pw[1]); q[4] = make_double2(pw[2], gl[0]); q[5] = make_double2(gl[1], gl[2]);
+            if (orec && v.bun_ptr && e > b) {   // (a landmark without local observations has no bundle) the bundle's header: the first line once more, in front of the landmark's projection records
+                double2* hq = reinterpret_cast<double2*>(orec + 4 * (size_t)bun);
+                hq[0] = q[0]; hq[1] = q[1]; hq[2] = q[2]; hq[3] = q[3];
+            }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) g_l[3 * l + i] = gl[i];
@@ -558,9 +564,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const double pw[3] = {REC ? lrec[REC ? kLmPt : 0] : v.pts[3 * lc], REC ? lrec[REC ? kLmPt + 1 : 0] : v.pts[3 * lc + 1],
                           REC ? lrec[REC ? kLmPt + 2 : 0] : v.pts[3 * lc + 2]};
     const int i_first = max(min(b + g, (int)v.n_obs - 1), 0);
+    const int64_t rbase = (REC && v.bun_ptr) ? (int64_t)v.bun_ptr[lc] + 2 - b : 0;   // bundles: the record of observation i is unit rbase + i
     const double2* __restrict__ rec2 = reinterpret_cast<const double2*>(orec);
-    double2 uv_next = REC ? rec2[2 * (size_t)i_first] : v.o_uv[i_first];   // REC: (xn, yn) | (p_w.z, w)
-    double2 rw_next = REC ? rec2[2 * (size_t)i_first + 1] : make_double2(0.0, 0.0);
+    double2 uv_next = REC ? rec2[2 * (size_t)(rbase + i_first)] : v.o_uv[i_first];   // REC: (xn, yn) | (p_w.z, w)
+    double2 rw_next = REC ? rec2[2 * (size_t)(rbase + i_first) + 1] : make_double2(0.0, 0.0);
     int sl_next = v.o_slot ? (int)v.o_slot[i_first] : 255;
     stager.store(sCam);
     if (active) {
@@ -568,8 +575,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const double2 uv = uv_next, rw = rw_next;
             const int sl = sl_next;
             if (i + kLmLanes < e) {
-                uv_next = REC ? rec2[2 * (size_t)(i + kLmLanes)] : v.o_uv[i + kLmLanes];
-                if (REC) rw_next = rec2[2 * (size_t)(i + kLmLanes) + 1];
+                uv_next = REC ? rec2[2 * (size_t)(rbase + i + kLmLanes)] : v.o_uv[i + kLmLanes];
+                if (REC) rw_next = rec2[2 * (size_t)(rbase + i + kLmLanes) + 1];
                 sl_next = v.o_slot ? (int)v.o_slot[i + kLmLanes] : 255;
             }
             double dcv[DC];

@@ -347,6 +347,23 @@ std::string BaHostStructure::build_obs_lists(const uint32_t* cam_idx, const uint
     });
     n_pairs = 0;
     for (int64_t l = lm_lo; l < lm_hi; ++l) { const int64_t k = pt_ptr[l + 1] - pt_ptr[l]; n_pairs += k * (k + 1) / 2; }   // 4 M adds
+    // landmark bundles: [64-byte header | 32-byte record per local observation], rounded up to 128 bytes (4 units)
+    bun_ptr.clear(); bun_units = 0; bun_pad_unit = bun_pad_header = 0;
+    if (o.bundles) {
+        bun_ptr.assign(n_pt, 0);
+        int64_t u = 0;
+        bool have_pad = false;
+        for (int64_t l = 0; l < n_pt; ++l) {
+            const int64_t k = pt_ptr[l + 1] - pt_ptr[l];
+            bun_ptr[l] = (int)u;
+            if (k > 0) {
+                if (!have_pad) { have_pad = true; bun_pad_header = (int)u; bun_pad_unit = (int)u + 2; }
+                u += (2 + k + 3) / 4 * 4;
+            }
+        }
+        if (u + 16 > 0x7fffffffLL) { bun_ptr.clear(); }   // (beyond 64 GB of bundles: fall back to plain records)
+        else bun_units = u + 16;
+    }
     tr.mark("lists: camera-major");
     seconds[1] = now_s() - t1;
     return "";
@@ -367,7 +384,7 @@ void BaHostStructure::build_schur_lists(const BaStructOptions& o, const int* slo
         // every camera pair (i, j) of a landmark, sorted by the block S(cam_i, cam_j) it adds to
         build_pair_lists(dc, nt, slot_host, n_cam, cinv.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(),
                          cam_obs.data(), &pl, o.pair_task_slots, /*queued=*/o.schur_form == 4 && (dc == 9 || o.queued6),
-                         (o.schur_form == 4 && (dc == 9 || o.queued6)) ? dev_tables : nullptr);
+                         (o.schur_form == 4 && (dc == 9 || o.queued6)) ? dev_tables : nullptr, bun_ptr.empty() ? nullptr : bun_ptr.data());
     } else {
         // ---- k_schur_rows2 (the LDS row form, kept as the A/B of the pair list): neighbour lists (cameras cj <= ci sharing a
         // landmark with ci, from the FULL problem so that every rank writes the same blocks), row entries, row tasks --------

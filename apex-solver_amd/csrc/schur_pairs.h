@@ -105,11 +105,14 @@ struct PairDeviceTables {
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
                       int task_slots = 0 /* 0: default */, bool queued = false,
-                      PairDeviceTables* dev_tables = nullptr /* queued only: leave out->recs empty and fill these instead */);
+                      PairDeviceTables* dev_tables = nullptr /* queued only: leave out->recs empty and fill these instead */,
+                      const int* bun_ptr = nullptr /* landmark bundles (BAView::bun_ptr): the records then hold 32-byte UNIT offsets --
+                                                      i, j = the two projection records, l = the bundle's header -- instead of indices */);
 // the records of the queued layout from those tables (all pointers device memory; recs is cleared to padding first)
 hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* run_ptr, const uint32_t* run_cj, const int* run_piece0,
                                     const int2* piece, const int2* task, const int* cam_ptr, const int* cam_obs, const uint32_t* o_pt,
-                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s, int dc = 9);
+                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s, int dc = 9,
+                                    const int* bun_ptr = nullptr);
 
 // The pair kernel (record form: J rebuilt from the 32-byte projection records k_landmark_reduce writes, orec).
 // ablation: timing experiments only (results are wrong when != 0)
@@ -117,6 +120,7 @@ hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* 
 void pairs_phase_cycles(unsigned long long out[8], bool reset);
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
                         const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, int ablation,
-                        const double* orec, const PairQDesc* qdesc = nullptr /* the queued layout's descriptors */);
+                        const double* orec, const PairQDesc* qdesc = nullptr /* the queued layout's descriptors */,
+                        int pad_unit = 0, int pad_header = 0 /* bundles (v.bun_ptr): what the padding slots read -- a real record and its header */);
 
 }  // namespace apex

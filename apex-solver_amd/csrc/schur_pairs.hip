@@ -28,8 +28,14 @@ struct Run { uint32_t cj; int len; int piece0; };   // the pairs of one row with
 
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
-                      int task_slots, bool queued, PairDeviceTables* dev_tables) {
+                      int task_slots, bool queued, PairDeviceTables* dev_tables, const int* bun_ptr) {
     SetupTrace tr;
+    // (landmark bundles: what a record names is a 32-byte unit of the bundle array -- header of l, records of i and j)
+    auto make_rec = [&](int i, int j, uint32_t l, uint32_t w) -> PairRec {
+        if (!bun_ptr) return PairRec{(uint32_t)i, (uint32_t)j, l, w};
+        const uint32_t ul = (uint32_t)bun_ptr[l], b = (uint32_t)pt_ptr[l];
+        return PairRec{ul + 2u + ((uint32_t)i - b), ul + 2u + ((uint32_t)j - b), ul, w};
+    };
     const int cpt = kNB / dc;
     const int kTask = std::min(task_slots > 0 ? (task_slots + 63) / 64 * 64 : kPairTaskSlots, kPairMaxBlockSlots / 2);
     // rows in the caller's camera order
@@ -209,7 +215,7 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                             const QPiece& pc = pieces[run.piece0 + k / kPiecePairs];
                             const QTask& tk = qtasks[pc.task];
                             const int kk = k % kPiecePairs, idx = pc.nonet0 + kk / QL, g = idx / tk.nchunks;
-                            out->recs[((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + g + NQ * (kk % QL)] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
+                            out->recs[((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + g + NQ * (kk % QL)] = make_rec(i, j, l, (uint32_t)g);
                         }
                 }
             }
@@ -294,7 +300,7 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                     const int k = pos[cj]++;
                     const int pi = run.piece0 + k / kPairMaxBlockSlots;   // (only a split block has more than one piece)
                     const int64_t s = pieces[pi].slot0 + k % kPairMaxBlockSlots;
-                    out->recs[s] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)(pi - out->chunks[s / 64].first_block)};
+                    out->recs[s] = make_rec(i, j, l, (uint32_t)(pi - out->chunks[s / 64].first_block));
                 }
             }
         }
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(64) void k_build_pair_recs_q(int64_t n_rows, const 
                                                            const int* __restrict__ cam_ptr, const int* __restrict__ cam_obs,
                                                            const uint32_t* __restrict__ o_pt, const int* __restrict__ pt_ptr,
                                                            const uint32_t* __restrict__ o_cam, int* __restrict__ cnt_global,
-                                                           PairRec* __restrict__ recs, int QL, int NQ) {
+                                                           PairRec* __restrict__ recs, int QL, int NQ, const int* __restrict__ bun_ptr) {
     __shared__ int cnt_lds[kRecsLdsPartners];
     const int64_t r = blockIdx.x;
     if (r >= n_rows) return;
@@ -387,14 +393,17 @@ __global__ __launch_bounds__(64) void k_build_pair_recs_q(int64_t n_rows, const 
                 const int2 pc = piece[run_piece0[r0 + p] + k / piece_pairs];
                 const int2 tk = task[pc.x];
                 const int kk = k % piece_pairs, idx = pc.y + kk / QL, g = idx / tk.y;
-                recs[((int64_t)tk.x + idx % tk.y) * 64 + g + NQ * (kk % QL)] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
+                PairRec rec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
+                if (bun_ptr) { const uint32_t ul = (uint32_t)bun_ptr[l]; rec.i = ul + 2u + (uint32_t)(i - b); rec.j = ul + 2u + (uint32_t)s; rec.l = ul; }
+                recs[((int64_t)tk.x + idx % tk.y) * 64 + g + NQ * (kk % QL)] = rec;
             }
         }
     }
 }
 hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* run_ptr, const uint32_t* run_cj, const int* run_piece0,
                                     const int2* piece, const int2* task, const int* cam_ptr, const int* cam_obs, const uint32_t* o_pt,
-                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s, int dc) {
+                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s, int dc,
+                                    const int* bun_ptr) {
     if (n_rows <= 0 || n_slots <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(recs, 0xFF, (size_t)n_slots * sizeof(PairRec), s);   // i = kPairPad everywhere: padding unless written below
     if (e != hipSuccess) return e;
@@ -411,7 +420,7 @@ hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* 
     e = hipMemsetAsync(scratch, 0, (size_t)std::max(n_runs, 1) * sizeof(int), s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_build_pair_recs_q, dim3((unsigned)n_rows), dim3(64), 0, s, n_rows, rows, run_ptr, run_cj, run_piece0, piece, task,
-                           cam_ptr, cam_obs, o_pt, pt_ptr, o_cam, scratch, recs, pair_queue_len(dc), pair_queues(dc));
+                           cam_ptr, cam_obs, o_pt, pt_ptr, o_cam, scratch, recs, pair_queue_len(dc), pair_queues(dc), bun_ptr);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
@@ -591,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
                                                           int n_tasks, const PairChunk* __restrict__ chunks,
                                                           const PairBlock* __restrict__ blocks, const PairRec* __restrict__ recs,
                                                           const double* __restrict__ lmrec, const double* __restrict__ orec,
-                                                          const PairQDesc* __restrict__ qdesc) {
+                                                          const PairQDesc* __restrict__ qdesc, int lm_stride, int pad_unit, int pad_header) {
     // the queued layout: d_c = 9 seven groups of nine lanes, nonets; d_c = 6 (round 5) sixteen groups of four lanes, quartets
     constexpr int QLEN = pair_queue_len(DC), NQ = pair_queues(DC), ND = NQ + 1;
     constexpr int NCAMS = (QL && DC == 6) ? 16 : 8;   // cameras staged per chunk: d_c = 6 the sixteen partners (two rounds of 64 pieces)
@@ -713,19 +722,21 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     };
     auto issue = [&](const uint4 rr, Coop& d) {
         const bool valid = rr.x != kPairPad;
-        const int i = valid ? (int)rr.x : 0, j = valid ? (int)rr.y : 0, l = valid ? (int)rr.z : 0;   // padding lanes read element 0
+        // padding lanes read element 0 (bundles: a real record and its header, handed in -- unit 0 is a header, not a record)
+        const int i = valid ? (int)rr.x : pad_unit, j = valid ? (int)rr.y : pad_unit, l = valid ? (int)rr.z : pad_header;
         const int qq = lane & 3, h = lane & 1;
-        auto lm0 = [&](auto sel) { return *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)quad_bcast(l, sel) + 2 * qq); };
+        // (lm_stride: 16 doubles = the landmark records; 4 = the bundle array, whose units the records then name: launch_schur_pairs)
+        auto lm0 = [&](auto sel) { return *reinterpret_cast<const double2*>(lmrec + (size_t)lm_stride * (size_t)quad_bcast(l, sel) + 2 * qq); };
         d.a0 = lm0(std::integral_constant<int, 0>{}); d.a1 = lm0(std::integral_constant<int, 1>{});
         d.a2 = lm0(std::integral_constant<int, 2>{}); d.a3 = lm0(std::integral_constant<int, 3>{});
         if (ABL & 8192) {   // timing only (round 5): both projection records read from the landmark record's own 128-byte line --
             // what a bundle [header | records] would cost if every pair's three pieces shared ONE L2 line (its best case)
             const std::integral_constant<int, 0> k0{};
             const std::integral_constant<int, 1> k1{};
-            d.i0 = *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)pair_bcast(l, k0) + 8 + 2 * h);
-            d.j0 = *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)pair_bcast(l, k0) + 12 + 2 * h);
-            d.i1 = *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)pair_bcast(l, k1) + 8 + 2 * h);
-            d.j1 = *reinterpret_cast<const double2*>(lmrec + kLmStride * (size_t)pair_bcast(l, k1) + 12 + 2 * h);
+            d.i0 = *reinterpret_cast<const double2*>(lmrec + (size_t)lm_stride * (size_t)pair_bcast(l, k0) + 8 + 2 * h);
+            d.j0 = *reinterpret_cast<const double2*>(lmrec + (size_t)lm_stride * (size_t)pair_bcast(l, k0) + 12 + 2 * h);
+            d.i1 = *reinterpret_cast<const double2*>(lmrec + (size_t)lm_stride * (size_t)pair_bcast(l, k1) + 8 + 2 * h);
+            d.j1 = *reinterpret_cast<const double2*>(lmrec + (size_t)lm_stride * (size_t)pair_bcast(l, k1) + 12 + 2 * h);
             return;
         }
         {
@@ -1130,16 +1141,20 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
 // profiles/r03_pairs_ablation.txt); they were deleted in round 4.
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
                         const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, int ablation,
-                        const double* orec, const PairQDesc* qdesc) {
+                        const double* orec, const PairQDesc* qdesc, int pad_unit, int pad_header) {
     if (n_tasks == 0) return;
     const unsigned grid = (unsigned)((n_tasks + 3) / 4);
+    // landmark bundles: the first line of a landmark's record is read from the bundle array (32-byte units), not from lmrec
+    const double* lmb = v.bun_ptr ? orec : lmrec;
+    const int lms = v.bun_ptr ? 4 : kLmStride;
+    if (!v.bun_ptr) { pad_unit = 0; pad_header = 0; }
     if (qdesc && dc == 6) {   // the queued layout for six-column cameras (round 5): sixteen queues of four pairs
-        if (v.mask_code != 6) hipLaunchKernelGGL((k_schur_pairs_r<6, true, 0, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, qdesc);
-        else hipLaunchKernelGGL((k_schur_pairs_r<6, false, 0, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, qdesc);
+        if (v.mask_code != 6) hipLaunchKernelGGL((k_schur_pairs_r<6, true, 0, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmb, orec, qdesc, lms, pad_unit, pad_header);
+        else hipLaunchKernelGGL((k_schur_pairs_r<6, false, 0, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmb, orec, qdesc, lms, pad_unit, pad_header);
         return;
     }
     if (qdesc) {   // the queued layout, nine columns per camera
-#define PAIRS_Q(MK, A) hipLaunchKernelGGL((k_schur_pairs_r<9, MK, A, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, qdesc)
+#define PAIRS_Q(MK, A) hipLaunchKernelGGL((k_schur_pairs_r<9, MK, A, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmb, orec, qdesc, lms, pad_unit, pad_header)
         if (v.mask_code != 7) PAIRS_Q(true, 0);
         else if (ablation == 64) PAIRS_Q(false, 64);
         else if (ablation == 1) PAIRS_Q(false, 1);
@@ -1157,14 +1172,14 @@ void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* 
         return;
     }
     if (ablation != 0 && dc == 9) {   // timing experiments (SelfCalibration only)
-#define PAIRS_RA(A) case A: hipLaunchKernelGGL((k_schur_pairs_r<9, false, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, nullptr); return
+#define PAIRS_RA(A) case A: hipLaunchKernelGGL((k_schur_pairs_r<9, false, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmb, orec, nullptr, lms, pad_unit, pad_header); return
         switch (ablation) { PAIRS_RA(512); PAIRS_RA(1024); PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3);
             default: break;   // an unlisted value: the plain kernel below, never a missing launch
         }
 #undef PAIRS_RA
     }
     const bool masked = v.mask_code != (dc == 9 ? 7 : 6);
-#define PAIRS_R(DCV, MK) hipLaunchKernelGGL((k_schur_pairs_r<DCV, MK>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, nullptr)
+#define PAIRS_R(DCV, MK) hipLaunchKernelGGL((k_schur_pairs_r<DCV, MK>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmb, orec, nullptr, lms, pad_unit, pad_header)
     if (dc == 9) { if (masked) PAIRS_R(9, true); else PAIRS_R(9, false); }
     else { if (masked) PAIRS_R(6, true); else PAIRS_R(6, false); }
 #undef PAIRS_R

@@ -107,6 +107,7 @@ class Solver : public LmBackend {
     // at that solver's own defaults (500 iterations, 1e-9: implicit_schur.rs:94-95), variant 1 at the caller's cg parameters.
     // "auto_variant" 0 restores the refusal.  variant_used() / variant_reason() say what happened (apexgpu_variant_info).
     void set_queued6(bool on) { queued6_ = on; }
+    void set_bundles(bool on) { bundles_ = on; }
     void set_prezero(bool on) { prezero_ = on; }
     void set_one_wait(bool on) { one_wait_ = on; }
     void set_device_pair_recs(bool on) { device_pair_recs_ = on; }   // before set_structure ("device_pair_list")
@@ -234,6 +235,9 @@ class Solver : public LmBackend {
     bool prezero_ = false, tiles_prezeroed_ = false;
     hipStream_t zero_stream_ = nullptr;
     hipEvent_t zero_ev_ = nullptr;
+    bool bundles_ = true;            // "landmark_bundles": BAView::bun_ptr (ba_kernels.h)
+    int* bun_ptr_ = nullptr;         // [n_pt] device copy
+    int bun_pad_unit_ = 0, bun_pad_header_ = 0;
     bool queued6_ = false;           // "pairs_queued6": the queued layout for six-column cameras too (measured slower: ba_structure.h)
     bool device_pair_recs_ = true;   // queued layout: the pair records are written by the device (k_build_pair_recs_q), not built on the host and copied
     bool auto_variant_ = true, auto_fallback_ = false;   // see set_auto_variant

@@ -49,7 +49,7 @@ Solver::~Solver() {
     if (free_thread_.joinable()) free_thread_.join();
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, pqdesc_, orec_, o_slot_, wg_cam_n_, wg_cam_list_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
+    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, pqdesc_, orec_, bun_ptr_, o_slot_, wg_cam_n_, wg_cam_list_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_, lam_mask_};
     for (void* p : ptrs)
@@ -111,6 +111,7 @@ BAView Solver::view(int which) const {
     v.pt_scale = scaled_ ? pt_scale_ : nullptr;
     v.lam_mask = tree_shard_ ? lam_mask_ : nullptr;
     v.o_slot = cam_staging_ ? o_slot_ : nullptr; v.wg_cam_n = wg_cam_n_; v.wg_cam_list = wg_cam_list_;
+    v.bun_ptr = bun_ptr_;
     return v;
 }
 
@@ -222,6 +223,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     so.dc = dc_; so.use_nd = use_nd_; so.nd_leaf = nd_leaf_; so.hubs_last = hubs_last_;
     so.rank = rank_; so.world = world_; so.dist_factor = dist_factor_; so.tree_sharding = tree_sharding_;
     so.dist_selftest = dist_selftest_; so.schur_form = rows_form_; so.pair_task_slots = pair_task_slots_; so.queued6 = queued6_;
+    so.bundles = bundles_ && (rows_form_ == 3 || rows_form_ == 4) && !matrix_free_only_;   // (the pair kernel's layout; a matrix-free handle keeps plain records)
     std::unique_ptr<BaHostStructure> hs_owner(new BaHostStructure);
     BaHostStructure& hs = *hs_owner;
     // Camera order and tile structure first; then the tile plan (symbolic fill, task lists, 1.4 GB of device allocations: 0.06-
@@ -362,8 +364,12 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         HIP_TRY(alloc(&g_red_, n_c_pad_));
         HIP_TRY(alloc(&dcam_, n_c_pad_));
         HIP_TRY(alloc(&hinv_, (size_t)kLmStride * n_pt_));  // landmark records: Hll^-1 | g_l | point
-        // projection records of the local observations (xn, yn, p_w.z, sqrt(rho')): the record form of the pair kernel
-        if (want_orec) HIP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
+        // projection records of the local observations (xn, yn, p_w.z, sqrt(rho')): the record form of the pair kernel --
+        // inside the landmark bundles when those are on (4 doubles per 32-byte unit)
+        if (want_orec) HIP_TRY(alloc(&orec_, 4 * (hs.bun_ptr.empty() ? (size_t)o_cam.size() : (size_t)hs.bun_units)));
+        if (bun_ptr_) { hipFree(bun_ptr_); bun_ptr_ = nullptr; }
+        if (!hs.bun_ptr.empty()) HIP_TRY(up(&bun_ptr_, hs.bun_ptr));
+        bun_pad_unit_ = hs.bun_pad_unit; bun_pad_header_ = hs.bun_pad_header;
         HIP_TRY(alloc(&g_l_, 3 * n_pt_));
         HIP_TRY(alloc(&dl_, 3 * n_pt_));
         HIP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
@@ -435,7 +441,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         if (e == hipSuccess) e = up(&d_task, dtab.task);
         if (e == hipSuccess)
             e = launch_build_pair_recs_q(n_cam_, d_rows, d_run_ptr, d_run_cj, d_run_piece0, d_piece, d_task, cam_ptr_, cam_obs_, o_pt_, pt_ptr_, o_cam_,
-                                         precs_, dtab.n_slots, stream_, dc_);
+                                         precs_, dtab.n_slots, stream_, dc_, bun_ptr_);
         for (void* q : {(void*)d_rows, (void*)d_run_ptr, (void*)d_run_cj, (void*)d_run_piece0, (void*)d_piece, (void*)d_task})
             if (q) (void)hipFree(q);
         HIP_TRY(e);
@@ -618,7 +624,8 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     stage_end(kStAssembleCam);
     stage_begin(kStScatter);
     if (rec_form)
-        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, pairs_ablation_, orec_, pqdesc_);
+        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, pairs_ablation_, orec_, pqdesc_,
+                           bun_pad_unit_, bun_pad_header_);
     else
         launch_schur_rows2(dc_, v, tm, rtasks2_, n_rtasks_, rchunks_, rentries_, nbr_, hinv_, stream_);
     stage_end(kStScatter);
