@@ -29,7 +29,7 @@ struct BaStructOptions {
     int dist_selftest = 0;
     int schur_form = 3;        // 3 sorted pair list, 4 the same pairs in the queued layout (d_c = 9; schur_pairs.h), 2 LDS rows (k_schur_rows2, the A/B)
     int pair_task_slots = 0;   // pair slots per wave task of the pair list (0: default)
-    bool bundles = true;       // landmark bundles (BAView::bun_ptr): the projection records behind a copy of the landmark record's first line
+    bool bundles = false;      // landmark bundles (BAView::bun_ptr): the projection records behind a copy of the landmark record's first line
     bool queued6 = false;      // the queued layout also for six-column cameras (sixteen queues of four pairs).  Built in round 5 and
                                // MEASURED SLOWER than form 3 there (final-13682, BundleAdjustment mode: 3.52 against 2.90 ms -- a 6 x 6
                                // block has nothing to gain from the fixed nine-step product loop, and a chunk stages sixteen partner

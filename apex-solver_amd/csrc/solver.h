@@ -235,7 +235,10 @@ class Solver : public LmBackend {
     bool prezero_ = false, tiles_prezeroed_ = false;
     hipStream_t zero_stream_ = nullptr;
     hipEvent_t zero_ev_ = nullptr;
-    bool bundles_ = true;            // "landmark_bundles": BAView::bun_ptr (ba_kernels.h)
+    bool bundles_ = false;           // "landmark_bundles": BAView::bun_ptr (ba_kernels.h).  Built and measured in round 5 (profiles/
+                                     // r05_ab_landmark_bundles.txt): the pair kernel gains 0.10 ms (2.90 against 3.00), k_landmark_reduce
+                                     // loses 0.33 (1.05 against 0.72: a header per landmark, records no longer one contiguous stream) and
+                                     // k_back_substitute 0.05 -- a net loss of 0.2-0.3 ms per LM iteration.  Off.
     int* bun_ptr_ = nullptr;         // [n_pt] device copy
     int bun_pad_unit_ = 0, bun_pad_header_ = 0;
     bool queued6_ = false;           // "pairs_queued6": the queued layout for six-column cameras too (measured slower: ba_structure.h)

@@ -259,10 +259,11 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "prezero_tiles" (0)  single rank, Cholesky variant; 1: the tiles of S are cleared for the next assembly on a side stream right
  *                     behind a finished solve (beside the caller's step statistics / trial cost) instead of at the head of the
  *                     assembly.  Measured neutral (the clear moves into the statistics / retraction kernels' time): off
- *   "landmark_bundles" (1)  before set_structure: the projection records of a landmark sit right behind a 64-byte copy of its
+ *   "landmark_bundles" (0)  before set_structure; 1: the projection records of a landmark sit right behind a 64-byte copy of its
  *                     record's first line ([Hll^-1 p.x p.y | record 0 | record 1 | ...], 128-byte aligned) and the pair list
  *                     names 32-byte units of that array: an L2 miss costs per 128-byte line, and a pair of the Schur kernel
- *                     then touches 2.1 lines instead of 2.6 (round 5); 0 = records indexed by observation as in rounds 3-4
+ *                     then touches 2.1 lines instead of 2.6.  Built and measured in round 5: the pair kernel gains 0.10 ms,
+ *                     k_landmark_reduce loses 0.33 -- off; 0 = records indexed by observation (rounds 3-5)
  *   "pairs_queued6" (0)  before set_structure: the queued layout of the pair list ("schur_form" 4) also for SIX-column cameras
  *                     (BundleAdjustment mode): sixteen queues of four pairs per chunk.  Built and measured in round 5: slower than
  *                     form 3 there (3.52 against 2.90 ms on final-13682), so six-column cameras keep form 3 unless this is set
