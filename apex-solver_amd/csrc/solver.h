@@ -109,6 +109,7 @@ class Solver : public LmBackend {
     void set_queued6(bool on) { queued6_ = on; }
     void set_bundles(bool on) { bundles_ = on; }
     void set_prezero(bool on) { prezero_ = on; }
+    void set_cam_beside_pairs(bool on) { cam_beside_ = on; }
     void set_one_wait(bool on) { one_wait_ = on; }
     void set_device_pair_recs(bool on) { device_pair_recs_ = on; }   // before set_structure ("device_pair_list")
     int get_pair_records(uint32_t* recs4_out, int64_t cap_slots);     // tests: the pair records as they sit on the device
@@ -235,6 +236,10 @@ class Solver : public LmBackend {
     bool prezero_ = false, tiles_prezeroed_ = false;
     hipStream_t zero_stream_ = nullptr;
     hipEvent_t zero_ev_ = nullptr;
+    // "cam_beside_pairs": k_cam_reduce (the diagonal blocks of S, g_c, g_red) on zero_stream_ beside the pair kernel (every other
+    // block of S): disjoint outputs, both read what k_landmark_reduce wrote
+    bool cam_beside_ = false;
+    hipEvent_t cam_ev_[2] = {nullptr, nullptr};
     bool bundles_ = false;           // "landmark_bundles": BAView::bun_ptr (ba_kernels.h).  Built and measured in round 5 (profiles/
                                      // r05_ab_landmark_bundles.txt): the pair kernel gains 0.10 ms (2.90 against 3.00), k_landmark_reduce
                                      // loses 0.33 (1.05 against 0.72: a header per landmark, records no longer one contiguous stream) and

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include <numeric>
 
 namespace apex {
@@ -57,6 +58,7 @@ Solver::~Solver() {
     comm_.reset();
     if (zero_stream_) { (void)hipStreamSynchronize(zero_stream_); (void)hipStreamDestroy(zero_stream_); }
     if (zero_ev_) (void)hipEventDestroy(zero_ev_);
+    for (hipEvent_t e : cam_ev_) if (e) (void)hipEventDestroy(e);
     for (int b = 0; b < 2; ++b) {
         if (pin_[b]) (void)hipHostFree(pin_[b]);
         if (pin_ev_[b]) (void)hipEventDestroy(pin_ev_[b]);
@@ -181,18 +183,30 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
                           double huber_delta) {
     if (n_cam_ <= 0 || n_pt_ <= 0) return fail(kInvalidInput, n_cam_ <= 0 ? "No camera variables found" : "No landmark variables found");
     if (n_obs_ < 0 || n_obs_ > 2000000000LL) return fail(kInvalidInput, "observation count out of range");
-    HIP_TRY(hipSetDevice(device_));
-    if (!stream_) HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    // the code objects of the three kernel files are loaded by their first launch (~0.1 s in all on a cold process): done here,
-    // on a thread, beside the host's list building instead of in front of the first kernels that matter
-    std::thread warmer([this] {
-        if (hipSetDevice(device_) != hipSuccess) return;
+    // The first stream this process creates costs 0.1-0.16 s (the runtime brings up its hardware queues; measured with
+    // APEX_SETUP_TRACE in bench.py, torch's context already there), the code objects of the three kernel files a few ms more:
+    // both on a thread, beside the argument checks and the camera order (host only), joined in front of the first device call
+    // below (device_ready) -- round 5.
+    std::promise<hipError_t> init_p;
+    std::shared_future<hipError_t> init_f = init_p.get_future().share();
+    std::thread warmer([this, &init_p] {
+        SetupTrace wt;
+        hipError_t e = hipSetDevice(device_);
+        if (e == hipSuccess && !stream_) e = hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
+        init_p.set_value(e);
+        wt.mark("device thread: device, stream");
+        if (e != hipSuccess) return;
         hipStream_t ws = nullptr;
         if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) return;
         warm_ba_kernels(ws); warm_schur_pairs(ws); warm_chol_kernels(ws);
         (void)hipStreamSynchronize(ws);
         (void)hipStreamDestroy(ws);
+        wt.mark("device thread: code objects");
     });
+    auto device_ready = [this, init_f]() -> hipError_t {   // (any thread: the calling thread's device is set as well)
+        const hipError_t e = init_f.get();
+        return e != hipSuccess ? e : hipSetDevice(device_);
+    };
     struct WJoiner { std::thread& t; ~WJoiner() { if (t.joinable()) t.join(); } } wjoiner{warmer};
     SetupTrace tr;
     {
@@ -259,16 +273,24 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         plan_err = e;
         plan_seconds = since(t_plan);
     };
-    if (!stream_) HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    tr.mark("camera order, tile structure");
     std::thread planner;
     struct PJoiner { std::thread& t; ~PJoiner() { if (t.joinable()) t.join(); } } pjoiner{planner};
     const bool plan_beside_lists = !BaHostStructure::needs_owner_preview(so);
     if (plan_beside_lists)
-        planner = std::thread([&] { try { build_plan(); } catch (const std::exception& ex) { plan_err = std::string("tile plan: ") + ex.what(); } });
+        planner = std::thread([&] {
+            try {
+                if (device_ready() != hipSuccess) { plan_err = "the device could not be initialised"; return; }
+                build_plan();
+            } catch (const std::exception& ex) { plan_err = std::string("tile plan: ") + ex.what(); }
+        });
     {
         const std::string e = hs.build_obs_lists(cam_idx, pt_idx, obs_uv, so, tp_);
         if (!e.empty()) return fail(kInvalidInput, e);
     }
+    tr.mark("observation lists");
+    HIP_TRY(device_ready());
+    tr.mark("waited for the device thread");
     n_c_ = hs.n_c; nt_ = hs.nt; n_c_pad_ = hs.n_c_pad;
     cmap_ = hs.cmap; cinv_ = hs.cinv; lmap_ = hs.lmap;
     lm_lo_ = hs.lm_lo; lm_hi_ = hs.lm_hi; tree_shard_ = hs.tree_shard; pad_rank_ = hs.pad_rank;
@@ -618,16 +640,27 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_, want_rec ? orec_ : nullptr);
     orec_fresh_ = want_rec;
     stage_end(kStAssembleLm);
-    stage_begin(kStAssembleCam);
+    const bool beside = cam_beside_ && rec_form && world_ == 1;
+    hipStream_t cam_stream = stream_;
+    if (beside) {
+        if (!zero_stream_) HIP_TRY(hipStreamCreateWithFlags(&zero_stream_, hipStreamNonBlocking));
+        for (hipEvent_t& e : cam_ev_) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(cam_ev_[0], stream_));
+        HIP_TRY(hipStreamWaitEvent(zero_stream_, cam_ev_[0], 0));
+        cam_stream = zero_stream_;
+    }
+    if (!beside) stage_begin(kStAssembleCam);
     launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, hinv_, g_l_, 1,
-                      g_c_, g_red_, stream_);
-    stage_end(kStAssembleCam);
+                      g_c_, g_red_, cam_stream);
+    if (!beside) stage_end(kStAssembleCam);
+    else HIP_TRY(hipEventRecord(cam_ev_[1], zero_stream_));
     stage_begin(kStScatter);
     if (rec_form)
         launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, pairs_ablation_, orec_, pqdesc_,
                            bun_pad_unit_, bun_pad_header_);
     else
         launch_schur_rows2(dc_, v, tm, rtasks2_, n_rtasks_, rchunks_, rentries_, nbr_, hinv_, stream_);
+    if (beside) HIP_TRY(hipStreamWaitEvent(stream_, cam_ev_[1], 0));
     stage_end(kStScatter);
     return check_hip(hipGetLastError(), "assembly kernels");
 }

@@ -8,6 +8,6 @@ for k in $(seq 1 $R); do
     python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-variants --no-other-workloads $O 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][0]); st=d['stages_ms_per_step']
-print('$v [$O]', round(d['value'],3), 'stage sum', round(sum(st.values()),3), {k:round(x,3) for k,x in st.items() if x>0})"
+print('$v [$O]', round(d['value'],3), 'final_cost', repr(d.get('final_cost')), 'stage sum', round(sum(st.values()),3), {k:round(x,3) for k,x in st.items() if x>0})"
   done
 done
