@@ -218,12 +218,12 @@ def tile_partition(present: np.ndarray, world: int):
 
 def check_schedule(present: np.ndarray, world: int = 1, rank: int = 0, two_side: int = 1, overlap: int = 1, split_u1: int = 4,
                    flood_gate: int = 256, factor_flow: int = -1, factor_flow_rows: int = 24, old_idle_level_bug: bool = False,
-                   drop_wait: int = -1) -> dict:
+                   drop_wait: int = -1, panel_split: int = 0) -> dict:
     """Host-only race check of the factorisation's launch sequence for one tile structure (apexgpu_debug_check_schedule)."""
     L = load()
     pr = np.ascontiguousarray(present, dtype=np.uint8)
     nt = pr.shape[0]
-    opts = np.array([two_side, overlap, split_u1, flood_gate, factor_flow, factor_flow_rows, int(old_idle_level_bug), drop_wait], dtype=np.int32)
+    opts = np.array([two_side, overlap, split_u1, flood_gate, factor_flow, factor_flow_rows, int(old_idle_level_bug), drop_wait, panel_split], dtype=np.int32)
     out = np.zeros(8, dtype=np.int64)
     msg = C.create_string_buffer(512)
     rc = L.apexgpu_debug_check_schedule(nt, pr.ctypes.data_as(C.c_void_p), int(world), int(rank), opts.ctypes.data_as(C.c_void_p),

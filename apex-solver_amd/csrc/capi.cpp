@@ -51,6 +51,29 @@ static int guarded(F&& f) noexcept {
     }
 }
 
+// APEX_SEGV_BACKTRACE=1 (debugging aid): the native stack of a crash on stderr (the GPU boxes have no debugger)
+#include <execinfo.h>
+#include <signal.h>
+namespace {
+void segv_backtrace(int sig) {
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    raise(sig);
+}
+void segv_hook() {   // (on an alternate stack: a stack overflow is a SIGSEGV too)
+    static const bool on = [] { const char* e = getenv("APEX_SEGV_BACKTRACE"); return e && e[0] == '1'; }();
+    if (!on) return;
+    static thread_local char alt[1 << 16];
+    stack_t ss; ss.ss_sp = alt; ss.ss_size = sizeof(alt); ss.ss_flags = 0;
+    (void)sigaltstack(&ss, nullptr);
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = segv_backtrace; sa.sa_flags = SA_ONSTACK | SA_RESETHAND;
+    (void)sigaction(SIGSEGV, &sa, nullptr);
+}
+}  // namespace
+
 extern "C" {
 
 const char* apexgpu_version(void) { return "apexgpu 0.1 (gfx950)"; }
@@ -104,6 +127,7 @@ int apexgpu_solve_augmented(apexgpu_solver* h, double lambda, int variant, doubl
     H_OR_FAIL;
     if (variant != APEXGPU_VARIANT_SPARSE && variant != APEXGPU_VARIANT_ITERATIVE && variant != APEXGPU_VARIANT_IMPLICIT)
         return APEXGPU_ERR_INVALID_INPUT;
+    segv_hook();
     return guarded([&] { return h->s->solve_augmented(lambda, variant, step_out, grad_out); });
 }
 int apexgpu_assemble(apexgpu_solver* h, double lambda) { H_OR_FAIL; return guarded([&] { return h->s->assemble_only(lambda); }); }
@@ -213,7 +237,7 @@ int apexgpu_debug_partition(int nt, const uint8_t* present, int world, int* owne
     });
 }
 
-int apexgpu_debug_check_schedule(int nt, const uint8_t* present, int world, int rank, const int opts[8], int64_t out[8], char* msg, int msg_len) {
+int apexgpu_debug_check_schedule(int nt, const uint8_t* present, int world, int rank, const int opts[9], int64_t out[8], char* msg, int msg_len) {
     if (nt <= 0 || !present || !opts || !out || world < 1 || rank < 0 || rank >= world) return APEXGPU_ERR_INVALID_INPUT;
     return guarded([&]() -> int {
     apex::TilePlan tp;
@@ -221,6 +245,7 @@ int apexgpu_debug_check_schedule(int nt, const uint8_t* present, int world, int 
     tp.set_two_side(opts[0]);
     tp.enable_overlap(opts[1] != 0); if (opts[1] > 1) tp.set_overlap_min(opts[1]);
     tp.set_split_u1(opts[2]);
+    tp.set_panel_split(opts[8]);
     tp.set_gate_min(opts[3]);
     tp.set_factor_flow(opts[4], opts[5]);
     tp.debug_skip_idle_level_wait(opts[6] != 0);
@@ -263,7 +288,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
     // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
     static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "panel_tri", "dist_factor", "tree_sharding", "dist_selftest",
-                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "factor_flow_tile", "factor_flow_dyn", "device_pair_list", "landmark_bundles", "pairs_queued6", "matrix_free_only", "auto_variant", "max_tile_updates"};
+                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "panel_split", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "factor_flow_tile", "factor_flow_dyn", "device_pair_list", "landmark_bundles", "pairs_queued6", "matrix_free_only", "auto_variant", "max_tile_updates"};
     if (h->s->has_structure())
         for (const char* k : structural)
             if (n == k) return APEXGPU_ERR_INVALID_STATE;
@@ -275,6 +300,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "update_overlap") { h->s->enable_overlap(value != 0); if (value > 1) h->s->set_overlap_min(value); }
     else if (n == "tri_dataflow") h->s->enable_tri_flow(value != 0);
     else if (n == "split_u1") h->s->set_split_u1(value);
+    else if (n == "panel_split") h->s->set_panel_split(value);
     else if (n == "flood_gate") h->s->set_gate_min(value);
     else if (n == "flood_gate_pos") h->s->set_gate_pos(value);
     else if (n == "two_side") h->s->set_two_side(value);
@@ -641,6 +667,7 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     else if (n == "factor_flow_rows") h->s->set_factor_flow(h->s->plan().factor_flow_cols(), value);
     else if (n == "flood_gate") h->s->set_gate_min(value);
     else if (n == "split_u1") h->s->set_split_u1(value);
+    else if (n == "panel_split") h->s->set_panel_split(value);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
     else if (n == "panel_tri") apex::set_panel_tri(value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);

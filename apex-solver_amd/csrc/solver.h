@@ -93,6 +93,7 @@ class Solver : public LmBackend {
     void debug_poison_next_solve(int which) { tp_.debug_poison_next_solve(which); }
     int debug_occupy_cus(int n_cus, int micros) { return check_hip(tp_.debug_occupy_cus(n_cus, micros), "debug_occupy_cus"); }
     void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
+    void set_panel_split(int min_rest) { tp_.set_panel_split(min_rest); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
     void set_gate_pos(int p) { tp_.set_gate_pos(p); }

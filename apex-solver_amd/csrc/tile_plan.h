@@ -139,6 +139,13 @@ class TilePlan {
     bool flow_dyn() const { return flow_dyn_; }
     void set_max_updates(int64_t n) { max_updates_ = n > 0 ? n : 80000000LL; }   // (tests lower it to force the refusal on a small problem)
     bool factor_flow_gave_up() { const bool g = flow_gave_up_; flow_gave_up_ = false; return g; }
+    // panel lookahead (round 5): the panel solves of a level in two launches -- the tiles whose rows belong to the NEXT level
+    // (all that U1d and the next potrf need) on the main stream, the rest on a stream of their own beside them; 0 = one launch.
+    // Built, race free (check_schedule), bit-identical -- and no gain: 6.60 against 6.53 ms on final-13682.  The timeline
+    // (profiles/r05_factor_timeline_panel_split.txt) shows U1d(lv) starting ~90 us after the critical panel tiles are done:
+    // it also follows U2a(lv-1) -- the updates of the same diagonal tiles from two levels below --, which follows ALL panel
+    // solves of level lv-1 and the U2 stream's older work; the period of a bulk level stays at ~360 us.  Off by default.
+    void set_panel_split(int min_rest) { panel_split_ = min_rest > 0; if (min_rest > 0) panel_split_min_ = min_rest; }   // before the first factor()
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
     hipError_t read_flags(int* failed_at);   // pivot flag of the last factorisation (syncs)
     void enable_tri_flow(bool on);   // triangular sweeps as one dataflow launch each (default) or level by level
@@ -213,6 +220,11 @@ class TilePlan {
     int two_side_ = 1;            // option; two_side_plan_: what build() decided for this plan
     bool two_side_plan_ = false;
     hipStream_t so_ = nullptr;    // U1o: updates of the next level's off-diagonal tiles, beside its potrf
+    hipStream_t sp_ = nullptr;    // panel lookahead: the non-critical panel solves of a level (waits for the main stream only -- see enqueue_factor)
+    std::vector<hipEvent_t> ev_p_, ev_pr_;   // panel lookahead: after the potrf of the level; after the rest of its panel solves
+    std::vector<int> lv_trsm_crit_;          // [level]: end of the level's critical panel tasks (rows in the next level) in trsm_tasks_
+    bool panel_split_ = false;
+    int panel_split_min_ = 96;
     std::vector<hipEvent_t> ev_t_, ev_u2_, ev_o_, ev_b_, ev_b2_;   // ev_u2_: after U2a of the level; ev_b_: after its U2b
     std::vector<bool> u2_pending_, o_pending_;
     bool split_u1_ = true;

@@ -100,8 +100,8 @@ std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool 
 void TilePlan::release() {
     if (dry_run_) {   // a host-only plan owns no device memory, streams or events
         tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = exch_ = nullptr; flag_ = nullptr; gate_cnt_ = nullptr;
-        side_ = side2_ = so_ = fwd_ = nullptr; ev_fwd_ = nullptr;
-        ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear(); ev_b2_.clear();
+        side_ = side2_ = so_ = sp_ = fwd_ = nullptr; ev_fwd_ = nullptr;
+        ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear(); ev_b2_.clear(); ev_p_.clear(); ev_pr_.clear();
         return;
     }
     void* ptrs[] = {tiles_, linv_, slot_, diag_slot_, flag_, potrf_tasks_, trsm_tasks_, upd_tasks_, tri_fwd_, tri_bwd_,
@@ -129,7 +129,9 @@ void TilePlan::release() {
     for (hipEvent_t e : ev_o_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_b_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_b2_) (void)hipEventDestroy(e);
-    ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear(); ev_b2_.clear();
+    for (hipEvent_t e : ev_p_) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_pr_) (void)hipEventDestroy(e);
+    ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear(); ev_b2_.clear(); ev_p_.clear(); ev_pr_.clear();
 }
 
 TilePlan::~TilePlan() {
@@ -137,6 +139,7 @@ TilePlan::~TilePlan() {
     if (side_) (void)hipStreamDestroy(side_);
     if (side2_) { (void)hipStreamDestroy(side2_); side2_ = nullptr; }
     if (so_) { (void)hipStreamDestroy(so_); so_ = nullptr; }
+    if (sp_) { (void)hipStreamDestroy(sp_); sp_ = nullptr; }
     if (fwd_) (void)hipStreamDestroy(fwd_);
 }
 
@@ -387,7 +390,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     std::vector<PotrfTask> potrf;
     std::vector<GemmTask> trsm, upd;
     std::vector<TriTask> tf, tb;
-    lv_potrf_.assign(n_levels_ + 1, 0); lv_trsm_.assign(n_levels_ + 1, 0);
+    lv_potrf_.assign(n_levels_ + 1, 0); lv_trsm_.assign(n_levels_ + 1, 0); lv_trsm_crit_.assign(n_levels_, 0);
     lv_fwd_.assign(n_levels_ + 1, 0); lv_bwd_.assign(n_levels_ + 1, 0);
     fwd_cut_.assign(n_levels_, std::vector<int>());
     lv_upd_round_.assign(n_levels_ + 1, 0);
@@ -411,13 +414,19 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             if (cls_h_[K] == 2) fwd_cut_[lv].push_back((int)tf.size());
             tf.push_back({linv_ptr(K), nullptr, K, -1});
             for (int I : rows) {
-                trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});
+                if (group_of[I] == lv + 1) trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});   // critical: see below
                 tf.push_back({linv_ptr(K), tile_ptr(I, K), K, I});
             }
             for (size_t a = 0; a < rows.size(); ++a)
                 for (size_t b = 0; b <= a; ++b)
                     us.push_back({(int64_t)rows[a] * nt_ + rows[b], K, {tile_ptr(rows[a], rows[b]), tile_ptr(rows[a], K), tile_ptr(rows[b], K)}});
         }
+        // the panel solves of the level: first the tiles whose ROW belongs to the next level -- all that U1d(lv) reads, hence all
+        // that the next potrf waits for (panel lookahead, enqueue_factor) --, then the others; by column inside each part
+        lv_trsm_crit_[lv] = (int)trsm.size();
+        for (int K : level_cols[lv])
+            for (int I : col_rows[K])
+                if (group_of[I] != lv + 1) trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});
         std::stable_sort(us.begin(), us.end(), [](const U& x, const U& y) { return x.key < y.key; });
         // U1d: targets = DIAGONAL tiles of the next level's columns (what its potrf needs);
         // U1o: the other tiles of the next level's columns (what its panel solves need) -- on a third stream, beside the
@@ -847,18 +856,22 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     // (and so was a CU-masked one that leaves 1 CU in 8 / 4 / 2 to the critical path: the same, either way)
     if (!side_) TP_TRY(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
     if (!so_) TP_TRY(hipStreamCreateWithFlags(&so_, hipStreamNonBlocking));
+    if (!sp_) TP_TRY(hipStreamCreateWithFlags(&sp_, hipStreamNonBlocking));
     if (!side2_) TP_TRY(hipStreamCreateWithFlags(&side2_, hipStreamNonBlocking));
     if (!fwd_) TP_TRY(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
     TP_TRY(hipEventCreateWithFlags(&ev_fwd_, hipEventDisableTiming));
     ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_); ev_o_.resize(n_levels_); ev_b_.resize(n_levels_); ev_b2_.resize(n_levels_);
+    ev_p_.resize(n_levels_); ev_pr_.resize(n_levels_);
     if (dry_run_) {   // handles that identify streams and events in a schedule trace
         side_ = reinterpret_cast<hipStream_t>(uintptr_t(0x52)); side2_ = reinterpret_cast<hipStream_t>(uintptr_t(0x53));
         so_ = reinterpret_cast<hipStream_t>(uintptr_t(0x54)); fwd_ = reinterpret_cast<hipStream_t>(uintptr_t(0x55));
+        sp_ = reinterpret_cast<hipStream_t>(uintptr_t(0x56));
         ev_fwd_ = reinterpret_cast<hipEvent_t>(uintptr_t(0x1000));
         for (int i = 0; i < n_levels_; ++i) {
             ev_t_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10000 + 8 * i)); ev_u2_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10001 + 8 * i));
             ev_o_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10002 + 8 * i)); ev_b_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10003 + 8 * i));
             ev_b2_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10004 + 8 * i));
+            ev_p_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10005 + 8 * i)); ev_pr_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10006 + 8 * i));
         }
         gate_cnt_ = reinterpret_cast<int*>(uintptr_t(1) << 46);
     }
@@ -870,6 +883,8 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         TP_TRY(hipEventCreateWithFlags(&ev_o_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_b_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_b2_[i], hipEventDisableTiming));
+        TP_TRY(hipEventCreateWithFlags(&ev_p_[i], hipEventDisableTiming));
+        TP_TRY(hipEventCreateWithFlags(&ev_pr_[i], hipEventDisableTiming));
     }
     TP_TRY(hipMalloc(&gate_cnt_, (size_t)(n_levels_ + 1) * sizeof(int)));
     TP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on the stream
@@ -984,7 +999,6 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
                          gate_min_ > 0 && gate_cnt_ ? gate_cnt_ + lv : nullptr);
         // the panel solves work on the off-diagonal tiles of this level's columns: U1o of the level below must be in
         if (lv > g0 && o_pending_[lv - 1]) (void)hipStreamWaitEvent(stream_, ev_o_[lv - 1], 0);
-        launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_);
         const int r0 = lv_upd_round_[lv], rd = lv_upd_splitd_[lv], rs = lv_upd_split_[lv], r1 = lv_upd_round_[lv + 1];
         int64_t n_u2 = 0, n_o = 0;
         for (int r = rs; r < r1; ++r) n_u2 += upd_rounds_[r].second;
@@ -992,9 +1006,31 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         // a cross-stream edge costs a few microseconds in the graph: only worth it when the batch is a real one
         const bool has_u2 = two && n_u2 >= overlap_min_;
         const bool has_o = two && so_ != nullptr && split_u1_ && n_o >= split_u1_min_;
+        // Panel lookahead (round 5).  In the bulk levels the period of a level WAS its dependency chain: potrf (100 us beside
+        // the updates) -> all panel solves (1,536 workgroups: 190 us) -> U1d (80 us) -> next potrf (profiles/
+        // r05_factor_timeline.txt) -- but U1d reads only the panel tiles whose rows belong to the next level.  Those go first,
+        // on the main stream; the others run on a stream of their own (sp_) behind the potrf, and every reader of theirs waits
+        // for them (ev_pr_): U1o(lv) on the third stream -- which is what the next level's panel solves wait for (ev_o_) -- and
+        // the U2 streams.  Same tasks, same order on every tile: bit-identical.
+        // (Why a FIFTH stream: sp_ waits for events of the main stream only.  On the third stream the rest made the U2 stream
+        // wait for an event of the third stream, which itself waits for events of the U2 stream -- and ending the capture then
+        // recursed for ever inside the runtime, which walks "streams that joined through me" without a visited set.)
+        const int t0 = lv_trsm_[lv], tc = lv_trsm_crit_[lv], t1 = lv_trsm_[lv + 1];
+        const bool psplit = panel_split_ && sp_ != nullptr && has_u2 && has_o && !fwd && !distributed() && tc > t0 && t1 - tc >= panel_split_min_;
+        if (psplit) {
+            (void)hipEventRecord(ev_p_[lv], stream_);   // after the potrf and everything the main stream has waited for
+            launch_tile_gemm_nt(trsm_tasks_ + t0, tc - t0, 1.0, 0.0, stream_);
+            (void)hipStreamWaitEvent(sp_, ev_p_[lv], 0);
+            launch_tile_gemm_nt(trsm_tasks_ + tc, t1 - tc, 1.0, 0.0, sp_);
+            (void)hipEventRecord(ev_pr_[lv], sp_);
+        } else {
+            launch_tile_gemm_nt(trsm_tasks_ + t0, t1 - t0, 1.0, 0.0, stream_);
+        }
         if (has_u2 || fwd || has_o) (void)hipEventRecord(ev_t_[lv], stream_);
         if (has_u2) (void)hipStreamWaitEvent(side_, ev_t_[lv], 0);
+        if (has_u2 && psplit) (void)hipStreamWaitEvent(side_, ev_pr_[lv], 0);
         if (has_o) (void)hipStreamWaitEvent(so_, ev_t_[lv], 0);
+        if (has_o && psplit) (void)hipStreamWaitEvent(so_, ev_pr_[lv], 0);
         if (fwd) {
             (void)hipStreamWaitEvent(fwd_, ev_t_[lv], 0);
             launch_fwd_group(lv, bvec, yvec, fwd_);
@@ -1052,6 +1088,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         if (has_u2) (void)hipEventRecord(ev_u2_[lv], side_);   // ... and, in stream order, every earlier update on A
         if (b2_side) {
             (void)hipStreamWaitEvent(side2_, ev_t_[lv], 0);
+            if (psplit) (void)hipStreamWaitEvent(side2_, ev_pr_[lv], 0);
             if (gated) launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side2_);
         } else if (gated && gate_pos_ == 1) {
             launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);

@@ -393,12 +393,13 @@ int apexgpu_debug_partition(int nt, const uint8_t* present, int world, int* owne
  * instead of issuing them, and every two launches that touch one tile with a writer among them must be ordered by stream
  * order + event edges; tasks of one launch must not share a written tile.  present: lower-triangular nt x nt structure in
  * the final tile order.  opts = {two_side, update_overlap (>1: minimum batch), split_u1, flood_gate, factor_flow,
- * factor_flow_rows, tests: bring back the round-3 idle-level bug, tests: drop that stream wait of phase 0 (-1: none)}.
+ * factor_flow_rows, tests: bring back the round-3 idle-level bug, tests: drop that stream wait of phase 0 (-1: none),
+ * panel_split (round 5: 0 off, > 0 the smallest rest that is split off)}.
  * out = {calls, launches, violations of phase 0 (local level groups / everything), violations of phase 1 (shared top of a
  * distributed plan), dataflow units, level groups inside dataflow launches, stream waits, 1 if a wait was dropped}.
  * Returns the number of level groups (>= 0) or an error; msg receives the first violation.  (round-3 advice: the U2 split
  * had dropped the edge behind a level without side-stream work; the checker finds it on the advisor's pattern.) */
-int apexgpu_debug_check_schedule(int nt, const uint8_t* present, int world, int rank, const int opts[8], int64_t out[8], char* msg, int msg_len);
+int apexgpu_debug_check_schedule(int nt, const uint8_t* present, int world, int rank, const int opts[9], int64_t out[8], char* msg, int msg_len);
 /* Host arithmetic only: the sorted camera-pair lists of the default Schur reduction for an observation list, with the
  * caller's camera order and a dense tile map (slot(I, J) = I (I + 1) / 2 + J).  counts[4] = {slots, chunks, blocks, tasks};
  * outputs may be NULL (size query): recs4 [slots][4] = {i, j, landmark, block local to the chunk} (i = 0xFFFFFFFF:

@@ -208,7 +208,9 @@ def test_factorisation_schedule_switches_agree():
                  {"two_side": 2, "split_u1": 0}, {"two_side": 2, "flood_gate": 2, "flood_gate_pos": 1},
                  # round 4: the top of the tree by level launches only / as one dataflow launch down to wide groups (the default
                  # lets a cost model choose), and the panel solves with and without the triangular skip (process-wide switch)
-                 {"factor_flow": 0}, {"factor_flow": 64}, {"factor_flow": 0, "panel_tri": 0}, {"panel_tri": 1}):
+                 {"factor_flow": 0}, {"factor_flow": 64}, {"factor_flow": 0, "panel_tri": 0}, {"panel_tri": 1},
+                 # round 5: the panel lookahead off / on every level that has both kinds of panel tiles (default: rest >= 96 tiles)
+                 {"panel_split": 0}, {"panel_split": 1}, {"panel_split": 1, "factor_flow": 0}):
         (a, b), _ = step(opts)
         # Bit for bit (round 4): with the queued pair layout S is assembled without atomics on this shape (no block longer than
         # a piece, no camera that sees a landmark twice), every schedule adds a tile's updates in the same order, the dataflow
