@@ -287,7 +287,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     // Switches that shape what set_structure builds (task lists, tile order, partition) or what the captured hipGraphs
     // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
     // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
-    static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "panel_tri", "dist_factor", "tree_sharding", "dist_selftest",
+    static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "panel_tri", "panel_small_max", "update_small_max", "dist_factor", "tree_sharding", "dist_selftest",
                                              "nested_dissection", "update_overlap", "fused_forward", "split_u1", "panel_split", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "factor_flow_tile", "factor_flow_dyn", "device_pair_list", "landmark_bundles", "pairs_queued6", "matrix_free_only", "auto_variant", "max_tile_updates"};
     if (h->s->has_structure())
         for (const char* k : structural)
@@ -320,6 +320,8 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "rec_backsub") h->s->set_rec_backsub(value != 0);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
     else if (n == "panel_tri") apex::set_panel_tri(value);
+    else if (n == "panel_small_max") apex::set_gemm_small_max(value, -1);
+    else if (n == "update_small_max") apex::set_gemm_small_max(-1, value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "pairs_ablation") {   /* timing experiments only: the results are WRONG when != 0, so the switch exists only */
         if (value != 0 && !getenv("APEX_ALLOW_ABLATION")) return APEXGPU_ERR_INVALID_INPUT;   /* for a process that asks for it */
@@ -670,6 +672,8 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     else if (n == "panel_split") h->s->set_panel_split(value);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
     else if (n == "panel_tri") apex::set_panel_tri(value);
+    else if (n == "panel_small_max") apex::set_gemm_small_max(value, -1);
+    else if (n == "update_small_max") apex::set_gemm_small_max(-1, value);
     else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);
     else if (n == "debug_poison_sweep") h->s->debug_poison_next_solve(value);

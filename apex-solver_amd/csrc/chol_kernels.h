@@ -71,6 +71,7 @@ void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fai
 // the same units scheduled dynamically (one persistent workgroup per CU, a queue of ready units): see k_factor_flow_dyn
 void launch_factor_flow_dyn(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, int* pending, int* q, int* ctr,
                             const int* wl_ptr, const int* wl, int n_workgroups, hipStream_t s, unsigned long long* trace);   // trace (tools only): 3 stamps of the 100 MHz clock per unit
+void set_gemm_small_max(int panel, int update);   // process-wide: largest batch that uses the latency kernels (-1: keep); default kGemmSmallMax = 56 for both
 void set_panel_tri(int on);          // process-wide A/B switch: 1 (default) the panel solves skip the zero blocks of Linv
 void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 1 / 6 / 8 k_potrf_inv_la with 4 / 6 / 8 waves, 9 / 12 k_potrf_inv_mf with 8 / 12 waves (12: default)
 // batches of <= 56 tasks use the latency kernels, larger ones the 3 x 3-wave strip kernel

@@ -2078,6 +2078,8 @@ static int g_potrf_lookahead = 12;   // 0: k_potrf_inv; 1 / 6 / 8: look-ahead ke
 void set_potrf_lookahead(int mode) { g_potrf_lookahead = mode; }
 static int g_panel_tri = 1;   // 1: the panel solves skip the zero blocks of Linv (k_tile_gemm_nt<true>); 0: full products (A/B)
 void set_panel_tri(int on) { g_panel_tri = on; }
+static int g_small_max_panel = kGemmSmallMax, g_small_max_update = kGemmSmallMax;
+void set_gemm_small_max(int panel, int update) { if (panel >= 0) g_small_max_panel = panel; if (update >= 0) g_small_max_update = update; }
 // The flood gate (TilePlan::enqueue_factor): one lane that ends when `expected` potrf workgroups have announced themselves
 // in *arrived, or after max_ticks of the 100 MHz clock -- a scheduling hint in front of the bulk updates of a level, so
 // that they do not take the CUs the next level's potrf is about to need.  Never waited for: a gate that times out only
@@ -2113,7 +2115,7 @@ void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s, i
 }
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, bool tri_b) {
     if (n <= 0) return;
-    if (n <= kGemmSmallMax) {  // latency kernels; the 9-workgroup form never for the in-place panel solves (C aliases A)
+    if (n <= (beta != 0.0 ? g_small_max_update : g_small_max_panel)) {  // latency kernels; the 9-workgroup form never for the in-place panel solves (C aliases A)
         if (beta != 0.0) hipLaunchKernelGGL(k_tile_gemm_nt_small, dim3(9 * n), dim3(192), 0, s, tasks, 9 * n, alpha, beta);
         else hipLaunchKernelGGL(k_tile_gemm_nt_small_strip, dim3(3 * n), dim3(576), 0, s, tasks, 3 * n, alpha, beta);
         return;
