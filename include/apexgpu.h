@@ -259,6 +259,12 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "prezero_tiles" (0)  single rank, Cholesky variant; 1: the tiles of S are cleared for the next assembly on a side stream right
  *                     behind a finished solve (beside the caller's step statistics / trial cost) instead of at the head of the
  *                     assembly.  Measured neutral (the clear moves into the statistics / retraction kernels' time): off
+ *   "panel_split" (0)  before set_structure; n > 0: panel lookahead -- the panel solves of a level in two launches when at least
+ *                     n tiles are not critical: those whose rows belong to the next level (all that its potrf waits for) first,
+ *                     the others on a stream of their own.  Race free, bit-identical, measured no gain (round 5): off
+ *   "cam_beside_pairs" (0)  single rank; 1: k_cam_reduce on a second stream beside the pair kernel (disjoint outputs).  Neutral: off
+ *   "panel_small_max" / "update_small_max" (56)  process-wide, before set_structure: the largest batch of panel solves / updates
+ *                     that uses the latency kernels instead of the throughput kernel (measured flat, round 5)
  *   "landmark_bundles" (0)  before set_structure; 1: the projection records of a landmark sit right behind a 64-byte copy of its
  *                     record's first line ([Hll^-1 p.x p.y | record 0 | record 1 | ...], 128-byte aligned) and the pair list
  *                     names 32-byte units of that array: an L2 miss costs per 128-byte line, and a pair of the Schur kernel
