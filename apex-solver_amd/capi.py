@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libapexgpu.so")
+LIB_PATH = os.environ.get("APEXGPU_LIB", LIB_PATH)   # (A/B of two builds on one box: tools only)
 
 NUM_STAGES = 10
 STAGE_NAMES = ("cam_reduce", "landmark_reduce", "schur_scatter", "all_reduce", "factor", "tri_solve",

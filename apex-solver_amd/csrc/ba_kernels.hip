@@ -237,6 +237,8 @@ struct CamStager {
 constexpr int kLmLanes = 4;   // lanes per landmark in the landmark-major kernels.  final-13682 (3..9 observations per landmark): 8 lanes
                               // 1.05 + 0.97 ms (k_landmark_reduce + k_back_substitute), 4 lanes 0.87 + 0.77, 2 lanes 0.74 + 0.68, 1 lane
                               // 0.75 + 0.73; 4 keeps the tail of a landmark with a thousand observations at a few hundred microseconds
+// (occupancy: 114 VGPRs = 4 waves per SIMD.  Forcing 5 / 6 with amdgpu_waves_per_eu spills 124 / 180 bytes per lane and the
+// kernel goes from 0.78 to 1.94 / 3.10 ms -- k_back_substitute likewise 0.48 -> 0.85 / 2.12: profiles/r05_ab_waves_per_eu.txt)
 template <int DC>
 __global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda, double* __restrict__ hinv,
                                                            double* __restrict__ g_l, int* __restrict__ err_flag,
