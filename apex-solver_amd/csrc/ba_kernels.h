@@ -97,7 +97,8 @@ void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv
                             double* lmu /* may be NULL */, hipStream_t s, double* orec = nullptr);
 // A18 (implicit_schur.rs): y = S x matrix-free, the Schur-Jacobi preconditioner blocks and their application
 void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
-                            double lambda, double* y, hipStream_t s, const double* orec = nullptr);
+                            double lambda, double* y, hipStream_t s, const double* orec = nullptr, const double* corec = nullptr);
+void launch_gather_records(int64_t n_obs, const int* cam_obs, const double* orec, double* corec, hipStream_t s);
 void launch_extract_diag_blocks(int dc, int64_t n_cam, const TileMap& tm, double* sd, hipStream_t s);
 void launch_precond_blocks(int dc, int64_t n_cam, const double* sd, double* minv, hipStream_t s);
 void launch_precond_apply(int dc, int64_t n_cam, const double* minv, const double* r, double* z, hipStream_t s);

@@ -1157,9 +1157,74 @@ void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, do
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n_partial, 1, out);
 }
 
+// The camera half from the projection records (round 5): the Jacobian of an observation follows from its record and the prepared
+// camera without the projection (jac_from_rec, ba_device.hpp) -- ~130 instead of ~500 fp64 instructions per observation, which
+// is what bounded k_implicit_cam.  corec: the records in CAMERA-major order (k_gather_records, once per linearisation; a PCG
+// solve reads them once per iteration).  With Jc = [a | -a [p]x | (xw, yw)^T t]:
+//     s   = a (x_rho + x_theta x p - u_l) + (xw, yw)^T (t . x_k)
+//     y_c = lambda x_c + sum_i [ a^T s | p x (a^T s) | t (xw s0 + yw s1) ]
+// Only for the modes that optimise every column group the factor has (rec_form_ok), like the landmark half.
+template <int DC>
+__global__ __launch_bounds__(64) void k_implicit_cam_rec(BAView v, const int* __restrict__ cam_ptr, const double2* __restrict__ corec,
+                                                           const double* __restrict__ lmu, const double* __restrict__ x,
+                                                           double lambda, double* __restrict__ y) {
+    const uint32_t c = blockIdx.x;
+    double cv[kCamStride];
+#pragma unroll
+    for (int a = 0; a < kCamStride; ++a) cv[a] = v.camp[kCamStride * (size_t)c + a];
+    double xc[DC], acc[DC];
+#pragma unroll
+    for (int a = 0; a < DC; ++a) { xc[a] = x[(size_t)c * DC + a]; acc[a] = 0.0; }
+    const int b = cam_ptr[c], e = cam_ptr[c + 1];
+    for (int k = b + (int)threadIdx.x; k < e; k += 64) {
+        const uint32_t l = v.co_pt[k];
+        const double2 r01 = corec[2 * (size_t)k], r23 = corec[2 * (size_t)k + 1];
+        const double2* q = reinterpret_cast<const double2*>(lmu + kLmuStride * (size_t)l);
+        const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        const double pw[3] = {q0.x, q0.y, q1.x}, u[3] = {q2.x, q2.y, q3.x};
+        RecJac j;
+        jac_from_rec(cv, r01, r23, pw, j);
+        const double w3[3] = {xc[0] + (xc[4] * pw[2] - xc[5] * pw[1]) - u[0], xc[1] + (xc[5] * pw[0] - xc[3] * pw[2]) - u[1],
+                              xc[2] + (xc[3] * pw[1] - xc[4] * pw[0]) - u[2]};
+        double s0 = j.a[0][0] * w3[0] + j.a[0][1] * w3[1] + j.a[0][2] * w3[2];
+        double s1 = j.a[1][0] * w3[0] + j.a[1][1] * w3[1] + j.a[1][2] * w3[2];
+        if (DC == 9) {
+            const double tk = j.t[0] * xc[6 % DC] + j.t[1] * xc[7 % DC] + j.t[2] * xc[8 % DC];
+            s0 += j.xw * tk; s1 += j.yw * tk;
+        }
+        const double g[3] = {j.a[0][0] * s0 + j.a[1][0] * s1, j.a[0][1] * s0 + j.a[1][1] * s1, j.a[0][2] * s0 + j.a[1][2] * s1};
+        acc[0] += g[0]; acc[1] += g[1]; acc[2] += g[2];
+        acc[3] += pw[1] * g[2] - pw[2] * g[1]; acc[4] += pw[2] * g[0] - pw[0] * g[2]; acc[5] += pw[0] * g[1] - pw[1] * g[0];
+        if (DC == 9) {
+            const double sk = j.xw * s0 + j.yw * s1;
+            acc[6 % DC] += j.t[0] * sk; acc[7 % DC] += j.t[1] * sk; acc[8 % DC] += j.t[2] * sk;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < DC; ++a) {
+        const double t = wave_sum(acc[a]);
+        double lam = lambda;
+        if (v.cam_scale) { const double sc = v.cam_scale[(size_t)c * DC + a]; lam = lambda / (sc * sc); }
+        if (threadIdx.x == 0) y[(size_t)c * DC + a] = t + lam * xc[a];
+    }
+}
+__global__ __launch_bounds__(256) void k_gather_records(int64_t n, const int* __restrict__ cam_obs, const double2* __restrict__ orec,
+                                                          double2* __restrict__ corec) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const size_t i = (size_t)cam_obs[k];
+    const double2 a = orec[2 * i], b2 = orec[2 * i + 1];
+    corec[2 * (size_t)k] = a; corec[2 * (size_t)k + 1] = b2;
+}
+// the projection records in camera-major order (the record form of the camera half of the matrix-free operator)
+void launch_gather_records(int64_t n_obs, const int* cam_obs, const double* orec, double* corec, hipStream_t s) {
+    if (n_obs > 0) hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((n_obs + 255) / 256)), dim3(256), 0, s, n_obs, cam_obs,
+                                      reinterpret_cast<const double2*>(orec), reinterpret_cast<double2*>(corec));
+}
+
 // y = S x without S: landmark half (u_l into lmu), then camera half
 void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
-                            double lambda, double* y, hipStream_t s, const double* orec) {
+                            double lambda, double* y, hipStream_t s, const double* orec, const double* corec) {
     if (v.n_pt > 0) {
         const int grid = (int)((v.n_pt + 256 / kLmLanes - 1) / (256 / kLmLanes));
         if (rec_form_ok(dc, v, orec)) {
@@ -1169,6 +1234,12 @@ void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const d
             if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, false>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu, nullptr);
             else hipLaunchKernelGGL((k_back_substitute<6, true, false>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu, nullptr);
         }
+    }
+    if (corec && rec_form_ok(dc, v, orec)) {
+        const double2* cr = reinterpret_cast<const double2*>(corec);
+        if (dc == 9) hipLaunchKernelGGL(k_implicit_cam_rec<9>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, cr, lmu, x, lambda, y);
+        else hipLaunchKernelGGL(k_implicit_cam_rec<6>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, cr, lmu, x, lambda, y);
+        return;
     }
     if (dc == 9) hipLaunchKernelGGL(k_implicit_cam<9>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, lmu, x, lambda, y);
     else hipLaunchKernelGGL(k_implicit_cam<6>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, lmu, x, lambda, y);

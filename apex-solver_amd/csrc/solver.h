@@ -110,6 +110,7 @@ class Solver : public LmBackend {
     void set_queued6(bool on) { queued6_ = on; }
     void set_bundles(bool on) { bundles_ = on; }
     void set_prezero(bool on) { prezero_ = on; }
+    void set_implicit_cam_records(bool on) { cam_records_ = on; }
     void set_cam_beside_pairs(bool on) { cam_beside_ = on; }
     void set_one_wait(bool on) { one_wait_ = on; }
     void set_device_pair_recs(bool on) { device_pair_recs_ = on; }   // before set_structure ("device_pair_list")
@@ -254,6 +255,13 @@ class Solver : public LmBackend {
     bool rec_backsub_ = true;
     bool orec_fresh_ = false;   // orec_ holds the records of the current parameters' last linearisation
     const double* backsub_records() const { return rec_backsub_ && orec_fresh_ ? orec_ : nullptr; }
+    // the same records in camera-major order for the camera half of the matrix-free operator ("implicit_cam_records"):
+    // allocated by the first matrix-free assembly, gathered once per linearisation (k_gather_records).  Built and measured in
+    // round 5: S x to 1e-12 of the oracle's, ~130 instead of ~500 fp64 instructions per observation -- and SLOWER, 0.547 against
+    // 0.518 ms per PCG iteration on synthetic-10k (profiles/r05_ab_implicit_cam_records.txt): the camera half is bound by its
+    // 64-byte landmark gathers, and the records add 32 bytes per observation to the stream.  Off.
+    double* corec_ = nullptr;
+    bool corec_fresh_ = false, cam_records_ = false;
     double* orec_ = nullptr;   // [local observations][4] projection records written by k_landmark_reduce (pair kernel, record form)
     int n_ptasks_ = 0;
     int64_t n_pair_blocks_ = 0, n_pair_slots_ = 0;

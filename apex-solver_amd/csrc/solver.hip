@@ -50,7 +50,7 @@ Solver::~Solver() {
     if (free_thread_.joinable()) free_thread_.join();
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, pqdesc_, orec_, bun_ptr_, o_slot_, wg_cam_n_, wg_cam_list_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
+    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, pqdesc_, orec_, corec_, bun_ptr_, o_slot_, wg_cam_n_, wg_cam_list_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_, lam_mask_};
     for (void* p : ptrs)
@@ -388,6 +388,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         HIP_TRY(alloc(&hinv_, (size_t)kLmStride * n_pt_));  // landmark records: Hll^-1 | g_l | point
         // projection records of the local observations (xn, yn, p_w.z, sqrt(rho')): the record form of the pair kernel --
         // inside the landmark bundles when those are on (4 doubles per 32-byte unit)
+        if (corec_) { (void)hipFree(corec_); corec_ = nullptr; corec_fresh_ = false; }   // (sized by the structure; re-made by the next matrix-free assembly)
         if (want_orec) HIP_TRY(alloc(&orec_, 4 * (hs.bun_ptr.empty() ? (size_t)o_cam.size() : (size_t)hs.bun_units)));
         if (bun_ptr_) { hipFree(bun_ptr_); bun_ptr_ = nullptr; }
         if (!hs.bun_ptr.empty()) HIP_TRY(up(&bun_ptr_, hs.bun_ptr));
@@ -517,7 +518,7 @@ int Solver::set_params(const double* poses, const double* intr, const double* po
     { const int rc = upload_staged(pts_[cur_], src_pts, 3 * (size_t)n_pt_ * sizeof(double)); if (rc != kOk) return rc; }
     launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], mode_mask(mode_), stream_);
     HIP_TRY(hipStreamSynchronize(stream_));
-    have_params_ = true; have_step_ = have_trial_ = false; orec_fresh_ = false;
+    have_params_ = true; have_step_ = have_trial_ = false; orec_fresh_ = false; corec_fresh_ = false;
     return kOk;
 }
 
@@ -638,7 +639,7 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     const bool rec_form = rows_form_ == 3 || rows_form_ == 4;   // the pair kernel reads the projection records (allocated with the form: set_structure)
     const bool want_rec = rec_form || (rec_backsub_ && orec_ != nullptr);
     launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_, want_rec ? orec_ : nullptr);
-    orec_fresh_ = want_rec;
+    orec_fresh_ = want_rec; corec_fresh_ = false;
     stage_end(kStAssembleLm);
     const bool beside = cam_beside_ && rec_form && world_ == 1;
     hipStream_t cam_stream = stream_;
@@ -769,6 +770,12 @@ int Solver::assemble_implicit(double lambda) {
     const bool want_rec = rec_backsub_ && orec_ != nullptr;
     launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, lmu_, stream_, want_rec ? orec_ : nullptr);
     orec_fresh_ = want_rec;
+    corec_fresh_ = false;
+    if (want_rec && cam_records_ && !bun_ptr_ && v.n_obs > 0) {   // (records indexed by observation: not the bundle layout)
+        if (!corec_) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&corec_), (size_t)v.n_obs * 4 * sizeof(double)));
+        launch_gather_records(v.n_obs, cam_obs_, orec_, corec_, stream_);
+        corec_fresh_ = true;
+    }
     stage_end(kStAssembleLm);
     stage_begin(kStAssembleCam);
     launch_cam_reduce(dc_, v, tilemap(), cam_ptr_, cam_obs_, lambda, rank_ == 0 ? 1 : 0, hinv_, g_l_, 1, g_c_, g_red_, stream_);
@@ -803,7 +810,8 @@ int Solver::implicit_matvec(const double* x, double lam_local, double* y, bool r
         launch_vec_mul(n_c_, x, cam_scale_, t, stream_);
         xin = t;
     }
-    launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xin, lam_local, y, stream_, backsub_records());
+    launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xin, lam_local, y, stream_, backsub_records(),
+                           corec_fresh_ && backsub_records() ? corec_ : nullptr);
     if (reduce && comm_ && world_ > 1)
         COMM_TRY(comm_->all_reduce_sum(y, (size_t)n_c_, stream_));
     if (scaled_) launch_vec_mul(n_c_, y, cam_scale_, y, stream_);
@@ -1093,7 +1101,7 @@ int Solver::eval_step(double* trial_cost) {
 int Solver::commit_step() {
     if (!have_trial_) return fail(kInvalidState, "no trial point");
     cur_ ^= 1;
-    have_trial_ = false; have_step_ = false; orec_fresh_ = false;
+    have_trial_ = false; have_step_ = false; orec_fresh_ = false; corec_fresh_ = false;
     return kOk;
 }
 
@@ -1109,7 +1117,7 @@ int Solver::discard_step() {
     launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], mode_mask(mode_), stream_);
     stage_end(kStRetract);
     HIP_TRY(hipStreamSynchronize(stream_));
-    have_trial_ = false; have_step_ = false; orec_fresh_ = false;
+    have_trial_ = false; have_step_ = false; orec_fresh_ = false; corec_fresh_ = false;
     return kOk;
 }
 

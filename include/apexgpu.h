@@ -265,6 +265,8 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "cam_beside_pairs" (0)  single rank; 1: k_cam_reduce on a second stream beside the pair kernel (disjoint outputs).  Neutral: off
  *   "panel_small_max" / "update_small_max" (56)  process-wide, before set_structure: the largest batch of panel solves / updates
  *                     that uses the latency kernels instead of the throughput kernel (measured flat, round 5)
+ *   "implicit_cam_records" (0)  1: the camera half of the matrix-free operator builds its Jacobians from camera-major projection
+ *                     records instead of re-linearising (fewer instructions, 32 more bytes per observation).  Measured slower: off
  *   "landmark_bundles" (0)  before set_structure; 1: the projection records of a landmark sit right behind a 64-byte copy of its
  *                     record's first line ([Hll^-1 p.x p.y | record 0 | record 1 | ...], 128-byte aligned) and the pair list
  *                     names 32-byte units of that array: an L2 miss costs per 128-byte line, and a pair of the Schur kernel
