@@ -97,6 +97,7 @@ void launch_pcg_init(int n, const double* diag, const double* b, double* pre, do
                      hipStream_t s);
 void launch_dot(int n, const double* a, const double* b, double* out, hipStream_t s);
 void launch_pcg_update_xr(int n, double alpha, const double* p, const double* ap, double* x, double* r, hipStream_t s);
+void launch_pcg_update_xr_dev(int n, double rz_old, const double* pap /* device */, const double* p, const double* ap, double* x, double* r, hipStream_t s);
 void launch_pcg_update_p(int n, double beta, const double* z, double* p, hipStream_t s);
 
 }  // namespace apex

@@ -2066,6 +2066,17 @@ __global__ __launch_bounds__(256) void k_pcg_update_xr(int n, double alpha, cons
     x[i] += alpha * p[i];
     r[i] -= alpha * ap[i];
 }
+// the same with alpha = rz_old / p.Ap taken from the device (p.Ap has just been reduced there: no host round trip in the middle of
+// the iteration); |p.Ap| < 1e-20: nothing is touched -- the host breaks on the same test when it reads the scalars
+__global__ __launch_bounds__(256) void k_pcg_update_xr_dev(int n, double rz_old, const double* __restrict__ pap_ptr, const double* __restrict__ p,
+                                                             const double* __restrict__ ap, double* __restrict__ x, double* __restrict__ r) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double pap = pap_ptr[0];
+    if (i >= n || fabs(pap) < 1e-20) return;
+    const double alpha = rz_old / pap;
+    x[i] += alpha * p[i];
+    r[i] -= alpha * ap[i];
+}
 // p = z + beta p
 __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const double* __restrict__ z,
                                                         double* __restrict__ p) {
@@ -2197,6 +2208,9 @@ void launch_dot(int n, const double* a, const double* b, double* out, hipStream_
 }
 void launch_pcg_update_xr(int n, double alpha, const double* p, const double* ap, double* x, double* r, hipStream_t s) {
     hipLaunchKernelGGL(k_pcg_update_xr, dim3((n + 255) / 256), dim3(256), 0, s, n, alpha, p, ap, x, r);
+}
+void launch_pcg_update_xr_dev(int n, double rz_old, const double* pap, const double* p, const double* ap, double* x, double* r, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_update_xr_dev, dim3((n + 255) / 256), dim3(256), 0, s, n, rz_old, pap, p, ap, x, r);
 }
 void launch_pcg_update_p(int n, double beta, const double* z, double* p, hipStream_t s) {
     hipLaunchKernelGGL(k_pcg_update_p, dim3((n + 255) / 256), dim3(256), 0, s, n, beta, z, p);

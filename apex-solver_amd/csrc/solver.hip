@@ -838,17 +838,18 @@ int Solver::implicit_pcg_solve(double lambda, int max_iter, double tol) {
     for (; it < max_iter; ++it) {
         const int mrc = implicit_matvec(p, lam_local, ap, true);
         if (mrc != kOk) return mrc;
-        launch_dot2(n, p, ap, p, ap, partial_, n_partial_, sc, stream_);
-        double pap = 0.0;
-        HIP_TRY(hipMemcpyAsync(&pap, sc, sizeof pap, hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
-        if (fabs(pap) < 1e-20) break;                          // :610-613
-        const double alpha = rz_old / pap;
-        launch_pcg_update_xr(n, alpha, p, ap, x, r, stream_);
+        // ONE host round trip per iteration (round 5; there were two): alpha = rz_old / p.Ap is formed on the device from the
+        // p.Ap it has just reduced (same division, same bits), x and r are left alone when |p.Ap| < 1e-20, and the host
+        // reads p.Ap together with the residual norms at the end of the iteration
+        launch_dot2(n, p, ap, p, ap, partial_, n_partial_, sc + 2, stream_);
+        launch_pcg_update_xr_dev(n, rz_old, sc + 2, p, ap, x, r, stream_);
         launch_precond_apply(dc_, n_cam_, minv_, r, z, stream_);  // used only when the test below does not stop
         launch_dot2(n, r, r, r, z, partial_, n_partial_, sc, stream_);
-        HIP_TRY(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_));
+        double h3[3];
+        HIP_TRY(hipMemcpyAsync(h3, sc, sizeof h3, hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
+        if (fabs(h3[2]) < 1e-20) break;                        // :610-613 (x, r untouched: k_pcg_update_xr_dev)
+        h[0] = h3[0]; h[1] = h3[1];
         if (sqrt(h[0]) < abs_tol) { ++it; break; }             // :634-641
         if (fabs(rz_old) < 1e-30) { ++it; break; }             // :652-654
         const double beta = h[1] / rz_old;
