@@ -257,7 +257,7 @@ class Solver : public LmBackend {
     const double* backsub_records() const { return rec_backsub_ && orec_fresh_ ? orec_ : nullptr; }
     // the same records in camera-major order for the camera half of the matrix-free operator ("implicit_cam_records"):
     // allocated by the first matrix-free assembly, gathered once per linearisation (k_gather_records).  Built and measured in
-    // round 5: S x to 1e-12 of the oracle's, ~130 instead of ~500 fp64 instructions per observation -- and SLOWER, 0.547 against
+    // round 5: S x to 1e-12 of the CPU restatement's, ~130 instead of ~500 fp64 instructions per observation -- and SLOWER, 0.547 against
     // 0.518 ms per PCG iteration on synthetic-10k (profiles/r05_ab_implicit_cam_records.txt): the camera half is bound by its
     // 64-byte landmark gathers, and the records add 32 bytes per observation to the stream.  Off.
     double* corec_ = nullptr;
