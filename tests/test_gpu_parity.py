@@ -30,12 +30,14 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
-def gpu_solver(d, mode, huber=1.0, variant=SchurVariant.Sparse, fix_first=True, shard=None):
+def gpu_solver(d, mode, huber=1.0, variant=SchurVariant.Sparse, fix_first=True, shard=None, options=None):
     ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
     prob = Problem.bundle_adjustment(d, ot, huber) if fix_first else Problem(d, ot, huber)
     s = GpuSchurComplementSolver(0).with_variant(variant)
     if shard:
         s.with_shard(*shard)
+    for k, v in (options or {}).items():
+        s.with_option(k, v)
     s.initialize_structure(prob)
     s.set_parameters(d.poses, d.intr, d.points)
     return prob, s
@@ -256,6 +258,32 @@ def test_schur_matvec_both_forms_vs_oracle(oracle, mode):
     ref = oS @ x
     assert rel(ye, ref) < 1e-12 and rel(yi, ref) < 1e-12
     s.close()
+
+
+@pytest.mark.parametrize("mode", ["selfcal", "ba"])
+def test_round5_switches_that_stayed_off_still_compute_the_same_system(oracle, mode):
+    """Options built and measured in round 5 and left off stay correct: the matrix-free operator's camera
+    half from camera-major projection records ("implicit_cam_records") gives S x to 1e-12 of the oracle's S, and the camera
+    reduce beside the pair kernel ("cam_beside_pairs") / the landmark bundles assemble the same S and solve to the same step."""
+    d = pkg.synthetic.make_problem(30, 1500, 3, 7, config_id=80)
+    prob, base = gpu_solver(d, mode)
+    o = oracle_problem(oracle, d, prob, mode)
+    o.linearize()
+    _, _, oS, _ = o.solve_augmented(1e-2, 0, want_schur=True)
+    x = np.random.default_rng(0).normal(size=prob.layout.cam_dof)
+    ref_step = base.solve_augmented_equation(1e-2).copy()
+    base.close()
+    _, s = gpu_solver(d, mode, options={"implicit_cam_records": 1})
+    ye, yi = s.schur_matvec(1e-2, x)
+    assert rel(ye, oS @ x) < 1e-12 and rel(yi, oS @ x) < 1e-12
+    s.close()
+    for opts in ({"cam_beside_pairs": 1}, {"landmark_bundles": 1}):
+        _, s = gpu_solver(d, mode, options=opts)
+        ye, _ = s.schur_matvec(1e-2, x)
+        assert rel(ye, oS @ x) < 1e-12, opts
+        step = s.solve_augmented_equation(1e-2)
+        assert rel(step, ref_step) < 1e-10, (opts, rel(step, ref_step))
+        s.close()
 
 
 def test_full_size_explicit_and_matrix_free_schur_agree():
