@@ -62,7 +62,7 @@ void launch_sym_tile_gather(int nt, const int* row_ptr, const SymEntry* entries,
 void launch_pcg_step1(int n, int nt, const double* scal, const double* row_dot, const double* p, const double* ap,
                       const double* pre, double* x, double* r, double* blk_part, double* out_pap, hipStream_t s);
 void launch_pcg_step2(int n, double* scal, const double* blk_part, const double* pre, const double* r, double* p,
-                      double* out2, hipStream_t s);
+                      double* out2, double abs_tol, hipStream_t s);
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s, int* arrived = nullptr);
 void launch_gate(const int* arrived, int expected, int max_micros, hipStream_t s);
 // the dataflow factorisation: one workgroup per unit, dispatched in list order; ver[] must be zero; err: error word (time-out)

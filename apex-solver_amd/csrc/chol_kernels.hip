@@ -1932,8 +1932,11 @@ __global__ __launch_bounds__(256) void k_pcg_step1(int n, int nt, const double* 
     __syncthreads();
     if (tid == 0) {
         const double tot = (sc[0] + sc[1]) + (sc[2] + sc[3]);
-        s_alpha = (fabs(tot) < 1e-30) ? 0.0 : scal[0] / tot;   // |pAp| < 1e-30: the host breaks (:703-705)
-        if (blockIdx.x == 0) out_pap[0] = tot;
+        // scal[4] != 0: the iteration BEFORE this one met a termination test (k_pcg_close_iteration) -- the host, which reads the
+        // scalars one iteration behind (TilePlan::pcg), has enqueued this one on speculation: it changes nothing
+        const bool frozen = scal[4] != 0.0;
+        s_alpha = (frozen || fabs(tot) < 1e-30) ? 0.0 : scal[0] / tot;   // |pAp| < 1e-30: the host breaks (:703-705)
+        if (blockIdx.x == 0 && !frozen) out_pap[0] = tot;
     }
     __syncthreads();
     const double alpha = s_alpha;
@@ -1975,12 +1978,22 @@ __global__ __launch_bounds__(256) void k_pcg_step2(int n, int n_blk, double* __r
     if ((tid & 63) == 0) sc[tid >> 6] = rz;
     __syncthreads();
     const double rz_t = (sc[0] + sc[1]) + (sc[2] + sc[3]);
-    if (tid == 0) s_beta = rz_t / scal[0];
+    __shared__ int s_frozen;
+    if (tid == 0) { s_beta = rz_t / scal[0]; s_frozen = scal[4] != 0.0; }
     __syncthreads();
+    if (s_frozen) return;   // (a speculative iteration behind a met termination test: p and the scalars stay)
     const double beta = s_beta;
     const int i = blockIdx.x * 256 + tid;
     if (i < n) p[i] = pre[i] * r[i] + beta * p[i];
     if (blockIdx.x == 0 && tid == 0) { out2[0] = rr_t; out2[1] = rz_t; }
+}
+// The end of a PCG iteration on the device (one thread): the reference's three termination tests on this iteration's scalars
+// (explicit_schur.rs:703-705, 726-728, 741-743) -- met: scal[4] = 1, everything later is frozen; else rz_old := r.z.
+// scal: [0] rz_old  [1] p.Ap  [2] r.r  [3] r.z  [4] frozen
+__global__ void k_pcg_close_iteration(double* __restrict__ scal, double abs_tol) {
+    if (scal[4] != 0.0) return;
+    if (fabs(scal[1]) < 1e-30 || sqrt(scal[2]) < abs_tol || fabs(scal[0]) < 1e-30) { scal[4] = 1.0; return; }
+    scal[0] = scal[3];
 }
 // scal[0] <- v[0]  (rz_old for the next iteration; separate tiny launch so that every block of
 // k_pcg_step2 has read the old value first)
@@ -2178,10 +2191,10 @@ void launch_pcg_step1(int n, int nt, const double* scal, const double* row_dot, 
     hipLaunchKernelGGL(k_pcg_step1, dim3((n + 255) / 256), dim3(256), 0, s, n, nt, scal, row_dot, p, ap, pre, x, r, blk_part, out_pap);
 }
 void launch_pcg_step2(int n, double* scal, const double* blk_part, const double* pre, const double* r, double* p,
-                      double* out2, hipStream_t s) {
+                      double* out2, double abs_tol, hipStream_t s) {
     const int nb = (n + 255) / 256;
     hipLaunchKernelGGL(k_pcg_step2, dim3(nb), dim3(256), 0, s, n, nb, scal, blk_part, pre, r, p, out2);
-    hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, s, scal, out2 + 1);
+    hipLaunchKernelGGL(k_pcg_close_iteration, dim3(1), dim3(1), 0, s, scal, abs_tol);
 }
 void launch_tile_diag(const double* tiles, const int* diag_slot, int nt, double* diag, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_diag, dim3((nt * NB + 255) / 256), dim3(256), 0, s, tiles, diag_slot, nt, diag);

@@ -122,6 +122,7 @@ void TilePlan::release() {
     }
     fwd_rhs_ = nullptr;
     if (flow_err_host_) { (void)hipHostFree(flow_err_host_); flow_err_host_ = nullptr; }
+    if (pcg_host_) { (void)hipHostFree(pcg_host_); pcg_host_ = nullptr; for (hipEvent_t& ev : pcg_ev_) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; } }
     if (occ_stream_) { (void)hipStreamSynchronize(occ_stream_); (void)hipStreamDestroy(occ_stream_); occ_stream_ = nullptr; }
     if (ev_fwd_) { (void)hipEventDestroy(ev_fwd_); ev_fwd_ = nullptr; }
     for (hipEvent_t e : ev_t_) (void)hipEventDestroy(e);
@@ -1450,37 +1451,49 @@ void TilePlan::sym_matvec(const double* x, double* y) {
 // solve_with_pcg (explicit_schur.rs:639-756).  Per iteration: one pass over the non-zero tiles
 // (k_sym_tile_products + k_sym_tile_gather, which also yields p.Ap), two fused vector kernels that keep
 // alpha/beta on the device, and ONE host read-back of {p.Ap, r.r, r.z} for the reference's three
-// termination tests.
+// termination tests -- read ONE ITERATION BEHIND (round 5): iteration k + 1 is enqueued before the host waits for the
+// scalars of iteration k, so the device never idles through a host round trip (25 us of a 185-us iteration).  The tests are
+// also made on the device (k_pcg_close_iteration): the speculative iteration behind a met test changes nothing, and x, the
+// iteration count and every scalar are those of the loop that waited every time.
 hipError_t TilePlan::pcg(const double* rhs, double* x, double* work, int max_iter, double tol, int* iters) {
     const int n = (int)n_pad();
     double *dg = work, *pre = work + n, *r = work + 2 * (size_t)n, *z = work + 3 * (size_t)n, *p = work + 4 * (size_t)n,
            *ap = work + 5 * (size_t)n;
-    double* sc = scal_;  // [0] rz_old  [1] p.Ap  [2] r.r  [3] r.z
+    double* sc = scal_;  // [0] rz_old  [1] p.Ap  [2] r.r  [3] r.z  [4] frozen
+    hipError_t e;
+    if (!pcg_host_) {
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&pcg_host_), 16 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return e;
+        for (hipEvent_t& ev : pcg_ev_) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+    }
     launch_tile_diag(tiles_, diag_slot_, nt_, dg, stream_);
     launch_pcg_init(n, dg, rhs, pre, x, r, z, p, stream_);
+    if ((e = hipMemsetAsync(sc, 0, 8 * sizeof(double), stream_)) != hipSuccess) return e;
     launch_dot(n, r, z, sc, stream_);
     launch_dot(n, r, r, sc + 2, stream_);
-    double h[4] = {0, 0, 0, 0};
-    hipError_t e = hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_);
-    if (e != hipSuccess) return e;
+    double* h = pcg_host_;
+    if ((e = hipMemcpyAsync(h, sc, 4 * sizeof(double), hipMemcpyDeviceToHost, stream_)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(stream_)) != hipSuccess) return e;
-    double rz_old = h[0];
     const double abs_tol = tol * std::max(sqrt(h[2]), 1.0);
-    int it = 0;
-    for (; it < max_iter; ++it) {
+    auto enqueue_iteration = [&](int slot) -> hipError_t {
         launch_sym_tile_products(sym_tiles_, n_sym_tiles_, tiles_, p, sym_part_, stream_);
         launch_sym_tile_gather(nt_, sym_row_ptr_, sym_entries_, sym_part_, p, ap, row_dot_, stream_);
         launch_pcg_step1(n, nt_, sc, row_dot_, p, ap, pre, x, r, blk_part_, sc + 1, stream_);
-        launch_pcg_step2(n, sc, blk_part_, pre, r, p, sc + 2, stream_);
-        if ((e = hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(stream_)) != hipSuccess) return e;
+        launch_pcg_step2(n, sc, blk_part_, pre, r, p, sc + 2, abs_tol, stream_);
+        const hipError_t ce = hipMemcpyAsync(pcg_host_ + 8 * slot, sc, 5 * sizeof(double), hipMemcpyDeviceToHost, stream_);
+        return ce != hipSuccess ? ce : hipEventRecord(pcg_ev_[slot], stream_);
+    };
+    int it = 0;
+    if (max_iter > 0 && (e = enqueue_iteration(0)) != hipSuccess) return e;
+    for (; it < max_iter; ++it) {
+        if (it + 1 < max_iter && (e = enqueue_iteration((it + 1) & 1)) != hipSuccess) return e;   // on speculation
+        if ((e = hipEventSynchronize(pcg_ev_[it & 1])) != hipSuccess) return e;
+        h = pcg_host_ + 8 * (it & 1);
+        // the device's verdict (h[4], k_pcg_close_iteration) decides -- the speculative iteration obeys the same word
         if (fabs(h[1]) < 1e-30) break;                       // p.Ap (:703-705); x was left untouched
-        if (sqrt(h[2]) < abs_tol) { ++it; break; }           // |r| (:726-728)
-        if (fabs(rz_old) < 1e-30) { ++it; break; }           // (:741-743)
-        rz_old = h[3];
+        if (h[4] != 0.0) { ++it; break; }                    // |r| < tol (:726-728) or rz_old ~ 0 (:741-743)
     }
     *iters = it;
-    return hipSuccess;
+    return hipStreamSynchronize(stream_);   // (the speculative iteration, if any, has drained: x is final)
 }
 
 }  // namespace apex
