@@ -99,5 +99,10 @@ void launch_dot(int n, const double* a, const double* b, double* out, hipStream_
 void launch_pcg_update_xr(int n, double alpha, const double* p, const double* ap, double* x, double* r, hipStream_t s);
 void launch_pcg_update_xr_dev(int n, double rz_old, const double* pap /* device */, const double* p, const double* ap, double* x, double* r, hipStream_t s);
 void launch_pcg_update_p(int n, double beta, const double* z, double* p, hipStream_t s);
+// the matrix-free PCG's scalars on the device (sc: [0] r.r [1] r.z [2] p.Ap [4] rz_old [5] frozen [6] beta): see k_pcg_implicit_close
+void launch_pcg_implicit_begin(double* sc, hipStream_t s);
+void launch_pcg_update_xr_sc(int n, const double* sc, const double* p, const double* ap, double* x, double* r, hipStream_t s);
+void launch_pcg_implicit_close(double* sc, double abs_tol, hipStream_t s);
+void launch_pcg_update_p_sc(int n, const double* sc, const double* z, double* p, hipStream_t s);
 
 }  // namespace apex

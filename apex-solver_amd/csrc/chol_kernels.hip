@@ -2090,6 +2090,29 @@ __global__ __launch_bounds__(256) void k_pcg_update_xr_dev(int n, double rz_old,
     x[i] += alpha * p[i];
     r[i] -= alpha * ap[i];
 }
+// ---- the matrix-free PCG with its scalars on the device (Solver::implicit_pcg_solve reads them one iteration behind) ----------
+// sc: [0] r.r  [1] r.z  [2] p.Ap  [3] -  [4] rz_old  [5] frozen  [6] beta
+__global__ void k_pcg_implicit_begin(double* __restrict__ sc) { sc[4] = sc[0]; sc[5] = 0.0; sc[6] = 0.0; }   // (sc[0] = r.z of the start)
+__global__ __launch_bounds__(256) void k_pcg_update_xr_sc(int n, const double* __restrict__ sc, const double* __restrict__ p,
+                                                            const double* __restrict__ ap, double* __restrict__ x, double* __restrict__ r) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double pap = sc[2];
+    if (i >= n || sc[5] != 0.0 || fabs(pap) < 1e-20) return;   // frozen, or the reference's break before the update (:610-613)
+    const double alpha = sc[4] / pap;
+    x[i] += alpha * p[i];
+    r[i] -= alpha * ap[i];
+}
+// the reference's tests at the end of an iteration (implicit_schur.rs:610-613, 634-641, 652-654), else beta and the new rz_old
+__global__ void k_pcg_implicit_close(double* __restrict__ sc, double abs_tol) {
+    if (sc[5] != 0.0) return;
+    if (fabs(sc[2]) < 1e-20 || sqrt(sc[0]) < abs_tol || fabs(sc[4]) < 1e-30) { sc[5] = 1.0; return; }
+    sc[6] = sc[1] / sc[4];
+    sc[4] = sc[1];
+}
+__global__ __launch_bounds__(256) void k_pcg_update_p_sc(int n, const double* __restrict__ sc, const double* __restrict__ z, double* __restrict__ p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && sc[5] == 0.0) p[i] = z[i] + sc[6] * p[i];
+}
 // p = z + beta p
 __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const double* __restrict__ z,
                                                         double* __restrict__ p) {
@@ -2224,6 +2247,14 @@ void launch_pcg_update_xr(int n, double alpha, const double* p, const double* ap
 }
 void launch_pcg_update_xr_dev(int n, double rz_old, const double* pap, const double* p, const double* ap, double* x, double* r, hipStream_t s) {
     hipLaunchKernelGGL(k_pcg_update_xr_dev, dim3((n + 255) / 256), dim3(256), 0, s, n, rz_old, pap, p, ap, x, r);
+}
+void launch_pcg_implicit_begin(double* sc, hipStream_t s) { hipLaunchKernelGGL(k_pcg_implicit_begin, dim3(1), dim3(1), 0, s, sc); }
+void launch_pcg_update_xr_sc(int n, const double* sc, const double* p, const double* ap, double* x, double* r, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_update_xr_sc, dim3((n + 255) / 256), dim3(256), 0, s, n, sc, p, ap, x, r);
+}
+void launch_pcg_implicit_close(double* sc, double abs_tol, hipStream_t s) { hipLaunchKernelGGL(k_pcg_implicit_close, dim3(1), dim3(1), 0, s, sc, abs_tol); }
+void launch_pcg_update_p_sc(int n, const double* sc, const double* z, double* p, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_update_p_sc, dim3((n + 255) / 256), dim3(256), 0, s, n, sc, z, p);
 }
 void launch_pcg_update_p(int n, double beta, const double* z, double* p, hipStream_t s) {
     hipLaunchKernelGGL(k_pcg_update_p, dim3((n + 255) / 256), dim3(256), 0, s, n, beta, z, p);

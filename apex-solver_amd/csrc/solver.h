@@ -242,6 +242,8 @@ class Solver : public LmBackend {
     // block of S): disjoint outputs, both read what k_landmark_reduce wrote
     bool cam_beside_ = false;
     hipEvent_t cam_ev_[2] = {nullptr, nullptr};
+    double* pcg_host_ = nullptr;                 // pinned: two slots of the matrix-free PCG's scalars (read one iteration behind)
+    hipEvent_t pcg_ev_[2] = {nullptr, nullptr};
     bool bundles_ = false;           // "landmark_bundles": BAView::bun_ptr (ba_kernels.h).  Built and measured in round 5 (profiles/
                                      // r05_ab_landmark_bundles.txt): the pair kernel gains 0.10 ms (2.90 against 3.00), k_landmark_reduce
                                      // loses 0.33 (1.05 against 0.72: a header per landmark, records no longer one contiguous stream) and

@@ -59,6 +59,8 @@ Solver::~Solver() {
     if (zero_stream_) { (void)hipStreamSynchronize(zero_stream_); (void)hipStreamDestroy(zero_stream_); }
     if (zero_ev_) (void)hipEventDestroy(zero_ev_);
     for (hipEvent_t e : cam_ev_) if (e) (void)hipEventDestroy(e);
+    if (pcg_host_) (void)hipHostFree(pcg_host_);
+    for (hipEvent_t e : pcg_ev_) if (e) (void)hipEventDestroy(e);
     for (int b = 0; b < 2; ++b) {
         if (pin_[b]) (void)hipHostFree(pin_[b]);
         if (pin_ev_[b]) (void)hipEventDestroy(pin_ev_[b]);
@@ -822,40 +824,50 @@ int Solver::implicit_pcg_solve(double lambda, int max_iter, double tol) {
     stage_begin(kStFactor);
     const int n = (int)n_c_;
     double *x = dcam_, *r = pcg_buf_, *z = pcg_buf_ + n_c_pad_, *p = pcg_buf_ + 2 * n_c_pad_, *ap = pcg_buf_ + 3 * n_c_pad_;
-    double* sc = scal_ + 16;
+    double* sc = scal_ + 16;   // [0] r.r  [1] r.z  [2] p.Ap  [4] rz_old  [5] frozen  [6] beta (chol_kernels.h)
+    if (!pcg_host_) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pcg_host_), 16 * sizeof(double), hipHostMallocDefault));
+        for (hipEvent_t& ev : pcg_ev_) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
     HIP_TRY(hipMemsetAsync(x, 0, n_c_pad_ * sizeof(double), stream_));
     HIP_TRY(hipMemcpyAsync(r, g_red_, n_c_pad_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     launch_precond_apply(dc_, n_cam_, minv_, r, z, stream_);
     HIP_TRY(hipMemcpyAsync(p, z, n_c_pad_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     launch_dot2(n, r, z, r, r, partial_, n_partial_, sc, stream_);
-    double h[2];
-    HIP_TRY(hipMemcpyAsync(h, sc, sizeof h, hipMemcpyDeviceToHost, stream_));
+    launch_pcg_implicit_begin(sc, stream_);   // rz_old := r.z, not frozen
+    double* h = pcg_host_;
+    HIP_TRY(hipMemcpyAsync(h, sc, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
-    double rz_old = h[0];
     const double abs_tol = tol * std::max(sqrt(h[1]), 1.0);
     const double lam_local = (rank_ == 0) ? lambda : 0.0;  // the all-reduce sums the ranks' partial S p
-    int it = 0;
-    for (; it < max_iter; ++it) {
+    // Every scalar of the iteration stays on the device (alpha, beta, the reference's three termination tests:
+    // k_pcg_implicit_close), and the host reads {r.r, r.z, p.Ap, frozen} ONE ITERATION BEHIND: iteration k + 1 is enqueued
+    // before the host waits for iteration k, so the device never idles through a host round trip (round 5; two round trips per
+    // iteration before).  An iteration enqueued behind a met test changes nothing: x, r, p and the iteration count are those of
+    // the loop that waited every time.  (Sharded: every rank reads the same scalars and enqueues the same iterations.)
+    auto enqueue_iteration = [&](int slot) -> int {
         const int mrc = implicit_matvec(p, lam_local, ap, true);
         if (mrc != kOk) return mrc;
-        // ONE host round trip per iteration (round 5; there were two): alpha = rz_old / p.Ap is formed on the device from the
-        // p.Ap it has just reduced (same division, same bits), x and r are left alone when |p.Ap| < 1e-20, and the host
-        // reads p.Ap together with the residual norms at the end of the iteration
         launch_dot2(n, p, ap, p, ap, partial_, n_partial_, sc + 2, stream_);
-        launch_pcg_update_xr_dev(n, rz_old, sc + 2, p, ap, x, r, stream_);
-        launch_precond_apply(dc_, n_cam_, minv_, r, z, stream_);  // used only when the test below does not stop
+        launch_pcg_update_xr_sc(n, sc, p, ap, x, r, stream_);        // alpha = rz_old / p.Ap; nothing when |p.Ap| < 1e-20 (:610-613)
+        launch_precond_apply(dc_, n_cam_, minv_, r, z, stream_);
         launch_dot2(n, r, r, r, z, partial_, n_partial_, sc, stream_);
-        double h3[3];
-        HIP_TRY(hipMemcpyAsync(h3, sc, sizeof h3, hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
-        if (fabs(h3[2]) < 1e-20) break;                        // :610-613 (x, r untouched: k_pcg_update_xr_dev)
-        h[0] = h3[0]; h[1] = h3[1];
-        if (sqrt(h[0]) < abs_tol) { ++it; break; }             // :634-641
-        if (fabs(rz_old) < 1e-30) { ++it; break; }             // :652-654
-        const double beta = h[1] / rz_old;
-        launch_pcg_update_p(n, beta, z, p, stream_);
-        rz_old = h[1];
+        launch_pcg_implicit_close(sc, abs_tol, stream_);               // :634-641, :652-654, else beta and rz_old
+        launch_pcg_update_p_sc(n, sc, z, p, stream_);
+        HIP_TRY(hipMemcpyAsync(pcg_host_ + 8 * slot, sc, 6 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipEventRecord(pcg_ev_[slot], stream_));
+        return kOk;
+    };
+    int it = 0;
+    if (max_iter > 0) { const int rc = enqueue_iteration(0); if (rc != kOk) return rc; }
+    for (; it < max_iter; ++it) {
+        if (it + 1 < max_iter) { const int rc = enqueue_iteration((it + 1) & 1); if (rc != kOk) return rc; }   // on speculation
+        HIP_TRY(hipEventSynchronize(pcg_ev_[it & 1]));
+        h = pcg_host_ + 8 * (it & 1);
+        if (fabs(h[2]) < 1e-20) break;           // :610-613 (x, r untouched)
+        if (h[5] != 0.0) { ++it; break; }        // the device's verdict: |r| < tol (:634-641) or rz_old ~ 0 (:652-654)
     }
+    HIP_TRY(hipStreamSynchronize(stream_));      // (the speculative iteration, if any, has drained)
     last_pcg_iters_ = it;
     stage_end(kStFactor);
     return kOk;
