@@ -81,7 +81,7 @@ void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta
 // poison_block >= 0 (tests only): that block's counter is made unreachable after the flags are cleared, so the task that
 // waits for it runs into the spin limit -- the time-out path (error word raised, wrong result) on demand
 void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const double* in, double* out, double* part, int* flags,
-                     int nt, hipStream_t s, const double* fold_b, double* fold_out, int poison_block = -1);
+                     int nt, hipStream_t s, const double* fold_b, double* fold_out, int poison_block = -1, bool keep_flags = false);   // keep_flags: the second part of a sweep launched in two (the counters of the first part stand)
 // tests only: n workgroups that each take a whole CU's LDS (nothing else that needs LDS fits beside them) and spin for
 // `micros`; *started (host-visible) counts the workgroups that are resident
 void launch_occupy_cus(int n, int micros, int* started, hipStream_t s);

@@ -2193,9 +2193,9 @@ void launch_occupy_cus(int n, int micros, int* started, hipStream_t s) {
 }
 
 void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const double* in, double* out, double* part, int* flags,
-                     int nt, hipStream_t s, const double* fold_b, double* fold_out, int poison_block) {
+                     int nt, hipStream_t s, const double* fold_b, double* fold_out, int poison_block, bool keep_flags) {
     if (n_tasks <= 0) return;
-    (void)hipMemsetAsync(flags, 0, (size_t)2 * nt * sizeof(int), s);   // cnt[nt] | done[nt]
+    if (!keep_flags) (void)hipMemsetAsync(flags, 0, (size_t)2 * nt * sizeof(int), s);   // cnt[nt] | done[nt]
     if (poison_block >= 0 && poison_block < nt)   // tests: INT_MIN never reaches the count the block's solve task waits for
         (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flags + poison_block), (int)0x80000000, 1, s);
     int* err = flags + 2 * nt;   // (not cleared here: sticky until the plan posts it to the host, TilePlan::solve)

@@ -58,6 +58,7 @@ class PoseGraphSolver : public LmBackend {
     void debug_poison_next_solve(int which) { tp_.debug_poison_next_solve(which); }
     void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
     void set_panel_split(int min_rest) { tp_.set_panel_split(min_rest); }
+    void set_fwd_beside_top(bool on) { tp_.set_fwd_beside_top(on); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
     void set_two_side(int mode) { tp_.set_two_side(mode); }

@@ -94,6 +94,7 @@ class Solver : public LmBackend {
     int debug_occupy_cus(int n_cus, int micros) { return check_hip(tp_.debug_occupy_cus(n_cus, micros), "debug_occupy_cus"); }
     void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
     void set_panel_split(int min_rest) { tp_.set_panel_split(min_rest); }
+    void set_fwd_beside_top(bool on) { tp_.set_fwd_beside_top(on); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
     void set_gate_pos(int p) { tp_.set_gate_pos(p); }

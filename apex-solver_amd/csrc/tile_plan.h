@@ -145,6 +145,7 @@ class TilePlan {
     // (profiles/r05_factor_timeline_panel_split.txt) shows U1d(lv) starting ~90 us after the critical panel tiles are done:
     // it also follows U2a(lv-1) -- the updates of the same diagonal tiles from two levels below --, which follows ALL panel
     // solves of level lv-1 and the U2 stream's older work; the period of a bulk level stays at ~360 us.  Off by default.
+    void set_fwd_beside_top(bool on) { fwd_beside_top_ = on; }   // before the first factor()
     void set_panel_split(int min_rest) { panel_split_ = min_rest > 0; if (min_rest > 0) panel_split_min_ = min_rest; }   // before the first factor()
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
     hipError_t read_flags(int* failed_at);   // pivot flag of the last factorisation (syncs)
@@ -189,7 +190,7 @@ class TilePlan {
    private:
     std::vector<std::vector<int>> symbolic_slots(const std::vector<uint8_t>& present);
     void enqueue_factor(const double* rhs, double* work, int g0, int g1);
-    void enqueue_solve(const double* rhs, double* x, double* work, bool backward_only);
+    void enqueue_solve(const double* rhs, double* x, double* work, bool backward_only, bool upper_only = false);
     void launch_fwd_group(int lv, double* bvec, double* yvec, hipStream_t s);
     void enqueue_dist_solve(int phase, const double* rhs, double* x, double* work);
     bool run_graph(int which, const double* rhs, double* x, double* work);
@@ -289,13 +290,25 @@ class TilePlan {
     int* sym_row_ptr_ = nullptr;
     SymEntry* sym_entries_ = nullptr;
     double *sym_part_ = nullptr, *row_dot_ = nullptr, *blk_part_ = nullptr, *scal_ = nullptr;
-    static constexpr int kGraphs = 6;  // 0 factor (local levels), 1 both sweeps, 2 backward sweep, 3 factor (top levels), 4/5 distributed solve phases
+    static constexpr int kGraphs = 7;  // 0 factor (local levels), 1 both sweeps, 2 backward sweep, 3 factor (top levels), 4/5 distributed solve phases, 6 upper forward + backward
     hipGraphExec_t graph_exec_[kGraphs] = {};
     const double* graph_rhs_[kGraphs] = {};
     double *graph_x_[kGraphs] = {}, *graph_work_[kGraphs] = {};
     bool graph_failed_[kGraphs] = {};
     hipStream_t fwd_ = nullptr;       // fused forward sweep
-    hipEvent_t ev_fwd_ = nullptr;
+    hipEvent_t ev_fwd_ = nullptr, ev_fwd2_ = nullptr;
+    // The forward sweep in two launches (round 5, "fwd_beside_top"): the part over the columns BELOW the dataflow launch of the
+    // factorisation's top runs on fwd_ beside that launch -- their L tiles are final at its start, the launch is a latency chain
+    // that leaves the chip nearly empty, the sweep part is bound by HBM --, the part over the top columns follows the
+    // factorisation (same tasks, same order, the counters of the first part stand: bit-identical).
+    // Measured (profiles/r05_ab_fwd_beside_top.txt): the sweeps go from 0.69 to 0.45 ms and the factorisation from 6.51 to 6.77 --
+    // the sweep part takes from the dataflow launch what it saves (its units read their operands past the L2, from the same
+    // HBM).  Zero sum: off.
+    bool fwd_beside_top_ = false, lower_fwd_now_ = false;
+    std::vector<int> lv_flow_fwd_;            // [level]: first forward dataflow task of the level (plans that are not distributed)
+    const double* fwd_lower_rhs_ = nullptr;   // right-hand side whose lower forward part the last factor() carried
+    double* fwd_lower_work_ = nullptr;
+    int fwd_lower_count_ = 0;
     const double* fwd_rhs_ = nullptr;  // right-hand side whose forward sweep the last factor() carried
     double* fwd_work_ = nullptr;
     bool fuse_forward_ = false;  // measured: the extra cross-stream edges cost the factorisation more than the sweep saves (+0.3 ms)

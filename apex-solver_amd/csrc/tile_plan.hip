@@ -100,7 +100,7 @@ std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool 
 void TilePlan::release() {
     if (dry_run_) {   // a host-only plan owns no device memory, streams or events
         tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = exch_ = nullptr; flag_ = nullptr; gate_cnt_ = nullptr;
-        side_ = side2_ = so_ = sp_ = fwd_ = nullptr; ev_fwd_ = nullptr;
+        side_ = side2_ = so_ = sp_ = fwd_ = nullptr; ev_fwd_ = nullptr; ev_fwd2_ = nullptr;
         ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear(); ev_b2_.clear(); ev_p_.clear(); ev_pr_.clear();
         return;
     }
@@ -125,6 +125,7 @@ void TilePlan::release() {
     if (pcg_host_) { (void)hipHostFree(pcg_host_); pcg_host_ = nullptr; for (hipEvent_t& ev : pcg_ev_) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; } }
     if (occ_stream_) { (void)hipStreamSynchronize(occ_stream_); (void)hipStreamDestroy(occ_stream_); occ_stream_ = nullptr; }
     if (ev_fwd_) { (void)hipEventDestroy(ev_fwd_); ev_fwd_ = nullptr; }
+    if (ev_fwd2_) { (void)hipEventDestroy(ev_fwd2_); ev_fwd2_ = nullptr; }
     for (hipEvent_t e : ev_t_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_u2_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_o_) (void)hipEventDestroy(e);
@@ -505,8 +506,10 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
                 ft.push_back({tile_ptr(I, K), K, I, first[I] + slot_of[I][pos], 0});
             }
         };
+        lv_flow_fwd_.assign(n_levels_ + 1, 0);
         if (!distributed()) {
             for (int lv = 0; lv < n_levels_; ++lv) {
+                lv_flow_fwd_[lv] = (int)ft.size();
                 for (int K : level_cols[lv]) ft.push_back({linv_ptr(K), -1, K, first[K], (int)row_cols[K].size()});
                 for (int K : level_cols[lv]) products_of(K);
             }
@@ -861,13 +864,14 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     if (!side2_) TP_TRY(hipStreamCreateWithFlags(&side2_, hipStreamNonBlocking));
     if (!fwd_) TP_TRY(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
     TP_TRY(hipEventCreateWithFlags(&ev_fwd_, hipEventDisableTiming));
+    TP_TRY(hipEventCreateWithFlags(&ev_fwd2_, hipEventDisableTiming));
     ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_); ev_o_.resize(n_levels_); ev_b_.resize(n_levels_); ev_b2_.resize(n_levels_);
     ev_p_.resize(n_levels_); ev_pr_.resize(n_levels_);
     if (dry_run_) {   // handles that identify streams and events in a schedule trace
         side_ = reinterpret_cast<hipStream_t>(uintptr_t(0x52)); side2_ = reinterpret_cast<hipStream_t>(uintptr_t(0x53));
         so_ = reinterpret_cast<hipStream_t>(uintptr_t(0x54)); fwd_ = reinterpret_cast<hipStream_t>(uintptr_t(0x55));
         sp_ = reinterpret_cast<hipStream_t>(uintptr_t(0x56));
-        ev_fwd_ = reinterpret_cast<hipEvent_t>(uintptr_t(0x1000));
+        ev_fwd_ = reinterpret_cast<hipEvent_t>(uintptr_t(0x1000)); ev_fwd2_ = reinterpret_cast<hipEvent_t>(uintptr_t(0x1001));
         for (int i = 0; i < n_levels_; ++i) {
             ev_t_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10000 + 8 * i)); ev_u2_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10001 + 8 * i));
             ev_o_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10002 + 8 * i)); ev_b_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10003 + 8 * i));
@@ -895,7 +899,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
 
 hipError_t TilePlan::zero_tiles(bool own_touched_only, hipStream_t on) {
     const hipStream_t zs = on ? on : stream_;
-    fwd_rhs_ = nullptr;
+    fwd_rhs_ = nullptr; fwd_lower_rhs_ = nullptr;
     const size_t te = (size_t)kNB * kNB * sizeof(double);
     hipError_t e = hipSuccess;
     auto clear = [&](int64_t first, int64_t count) {
@@ -980,7 +984,8 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     // step of level lv needs only that level's L^-1 and panel tiles, which are final after its panel solves, so it
     // runs on a third stream beside the trailing updates -- a chain of tiny latency-bound launches that costs
     // nothing there.  solve() then starts at the backward sweep.
-    const bool fwd = rhs != nullptr && work != nullptr && fwd_ != nullptr && !distributed();
+    const bool lower_fwd = lower_fwd_now_ && rhs != nullptr && work != nullptr && fwd_ != nullptr && !distributed() && !tr;
+    const bool fwd = !lower_fwd && rhs != nullptr && work != nullptr && fwd_ != nullptr && !distributed();
     // the trailing groups [gf, g1) of this phase run as one dataflow launch behind the level launches (build())
     const int ph = (g0 == n_local_groups_ && g1 == n_levels_ && n_local_groups_ < n_levels_) ? 1 : 0;
     const int g_end = g1;
@@ -1111,6 +1116,15 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         (void)hipEventRecord(ev_fwd_, fwd_);
         (void)hipStreamWaitEvent(stream_, ev_fwd_, 0);
     }
+    const bool lower_now = lower_fwd && g1 < g_end && ph == 0 && fwd_lower_count_ > 0;
+    if (lower_now) {
+        // the forward sweep over the columns below this launch, beside it (tile_plan.h, fwd_beside_top_): their L tiles and
+        // L^-1 are final here; the sweep's counters are cleared by this first part and stand for the second (TilePlan::solve)
+        (void)hipEventRecord(ev_fwd_, stream_);
+        (void)hipStreamWaitEvent(fwd_, ev_fwd_, 0);
+        apex::launch_tri_flow(false, flow_fwd_, fwd_lower_count_, rhs, yvec, flow_part_, flow_flags_, nt_, fwd_, nullptr, nullptr);
+        (void)hipEventRecord(ev_fwd2_, fwd_);
+    }
     if (g1 < g_end) {   // every update the level launches add to the region's tiles is in: the joins above
         (void)hipMemsetAsync(flow_ver_, 0, (size_t)n_slots_ * sizeof(int), stream_);
         if (poison_factor_ && !tr)   // (tests: the version of the first unit's tile starts hugely negative and is never reached)
@@ -1128,15 +1142,19 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         launch_factor_flow(flow_units_ + flow_first_[ph], flow_n_[ph], flow_ver_, flag_, flag_ + 1, stream_,
                            flow_trace_ ? flow_trace_ + 3 * (size_t)flow_first_[ph] : nullptr);
     }
+    if (lower_now) (void)hipStreamWaitEvent(stream_, ev_fwd2_, 0);   // (the side stream comes back to the capture)
 }
 
-void TilePlan::enqueue_solve(const double* rhs, double* x, double* work, bool backward_only) {
+void TilePlan::enqueue_solve(const double* rhs, double* x, double* work, bool backward_only, bool upper_only) {
     // L y = rhs (work vector bvec), then L^T x = y (work vector yvec); level by level
     double* bvec = work;
     double* yvec = work + n_pad();
     const bool flow = tri_flow_ && n_flow_tasks_ > 0;
     if (!backward_only) {
-        if (flow) {
+        if (flow && upper_only) {   // the part below the factorisation's dataflow launch ran beside it (enqueue_factor)
+            launch_tri_flow(false, flow_fwd_ + fwd_lower_count_, n_flow_tasks_ - fwd_lower_count_, rhs, yvec, flow_part_, flow_flags_, nt_, stream_,
+                            nullptr, nullptr, -1, /*keep_flags=*/true);
+        } else if (flow) {
             launch_tri_flow(false, flow_fwd_, n_flow_tasks_, rhs, yvec, flow_part_, flow_flags_, nt_, stream_, nullptr, nullptr,
                             poison_ == 1 ? nt_ - 1 : -1);
         } else {
@@ -1207,8 +1225,8 @@ bool TilePlan::run_graph(int which, const double* rhs, double* x, double* work) 
         if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_failed_[which] = true; return false; }
         if (which == 0) enqueue_factor(rhs, work, 0, n_local_groups_);
         else if (which == 3) enqueue_factor(nullptr, nullptr, n_local_groups_, n_levels_);
-        else if (which >= 4) enqueue_dist_solve(which - 4, rhs, x, work);
-        else enqueue_solve(rhs, x, work, which == 2);
+        else if (which == 4 || which == 5) enqueue_dist_solve(which - 4, rhs, x, work);
+        else enqueue_solve(rhs, x, work, which == 2, which == 6);
         if (hipStreamEndCapture(stream_, &g) != hipSuccess || !g) { graph_failed_[which] = true; (void)hipGetLastError(); return false; }
         hipGraphExec_t ex = nullptr;
         if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); graph_failed_[which] = true; (void)hipGetLastError(); return false; }
@@ -1359,11 +1377,21 @@ hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work, boo
         if (!comm_.max_int(flag_, 2, stream_)) return hipErrorUnknown;  // a failed pivot (or a dataflow time-out) anywhere fails the factorisation everywhere
         return read_flags(failed_at);
     }
-    if (!fuse_forward_) { rhs = nullptr; work = nullptr; }
+    // the lower part of the forward sweep beside the dataflow launch of the top (tile_plan.h): plans with such a launch only
+    const int lower_count = (flow_on_ && flow_n_[0] > 0 && flow_g1_[0] == n_levels_ && flow_g0_[0] > 0 && flow_g0_[0] < (int)lv_flow_fwd_.size())
+                                ? lv_flow_fwd_[(size_t)flow_g0_[0]] : 0;
+    const bool lower = !fuse_forward_ && fwd_beside_top_ && tri_flow_ && n_flow_tasks_ > 0 && rhs != nullptr && work != nullptr && fwd_ != nullptr &&
+                       !poison_factor_ && poison_ == 0 && !dry_run_ && lower_count > 0 && lower_count < n_flow_tasks_;
+    if (!fuse_forward_ && !lower) { rhs = nullptr; work = nullptr; }
+    lower_fwd_now_ = lower;
+    fwd_lower_count_ = lower ? lower_count : 0;
     if (poison_factor_) {   // (tests: the poisoned launch is not part of the captured graphs)
         enqueue_factor(rhs, work, 0, n_levels_);
         poison_factor_ = false;
     } else if (!run_graph(0, rhs, nullptr, work)) enqueue_factor(rhs, work, 0, n_levels_);
+    lower_fwd_now_ = false;
+    if (lower) { fwd_lower_rhs_ = rhs; fwd_lower_work_ = work; rhs = nullptr; work = nullptr; }
+    else fwd_lower_rhs_ = nullptr;
     fwd_rhs_ = rhs; fwd_work_ = work;  // the forward sweep for this right-hand side is part of the factorisation
     if (defer_flags) { *failed_at = 0; return hipGetLastError(); }
     return read_flags(failed_at);
@@ -1434,11 +1462,14 @@ hipError_t TilePlan::solve(const double* rhs, double* x, double* work) {
         return hipGetLastError();
     }
     const bool backward_only = fwd_rhs_ != nullptr && rhs == fwd_rhs_ && work == fwd_work_;
+    const bool upper_only = !backward_only && poison_ == 0 && tri_flow_ && fwd_lower_count_ > 0 && fwd_lower_rhs_ != nullptr && rhs == fwd_lower_rhs_ &&
+                            work == fwd_lower_work_;
     fwd_rhs_ = nullptr;  // one solve per fused sweep: the backward sweep consumes yvec's partner bvec
+    fwd_lower_rhs_ = nullptr;
     if (poison_ != 0) {   // (tests: the poisoned launch is not part of the captured graphs)
         enqueue_solve(rhs, x, work, backward_only);
         poison_ = 0;
-    } else if (!run_graph(backward_only ? 2 : 1, rhs, x, work)) enqueue_solve(rhs, x, work, backward_only);
+    } else if (!run_graph(upper_only ? 6 : (backward_only ? 2 : 1), rhs, x, work)) enqueue_solve(rhs, x, work, backward_only, upper_only);
     if (tri_flow_ && n_flow_tasks_ > 0) (void)post_sweep_status(false);
     return hipGetLastError();
 }

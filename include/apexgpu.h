@@ -262,6 +262,8 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "panel_split" (0)  before set_structure; n > 0: panel lookahead -- the panel solves of a level in two launches when at least
  *                     n tiles are not critical: those whose rows belong to the next level (all that its potrf waits for) first,
  *                     the others on a stream of their own.  Race free, bit-identical, measured no gain (round 5): off
+ *   "fwd_beside_top" (0)  before set_structure; 1: the forward sweep in two launches, the part over the columns below the
+ *                     factorisation's dataflow launch on a side stream beside that launch.  Bit-identical; zero sum (round 5): off
  *   "cam_beside_pairs" (0)  single rank; 1: k_cam_reduce on a second stream beside the pair kernel (disjoint outputs).  Neutral: off
  *   "panel_small_max" / "update_small_max" (56)  process-wide, before set_structure: the largest batch of panel solves / updates
  *                     that uses the latency kernels instead of the throughput kernel (measured flat, round 5)
