@@ -311,6 +311,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "pairs_queued6") h->s->set_queued6(value != 0);
     else if (n == "landmark_bundles") h->s->set_bundles(value != 0);
     else if (n == "prezero_tiles") h->s->set_prezero(value != 0);
+    else if (n == "eager_step_eval") h->s->set_eager_step_eval(value != 0);
     else if (n == "implicit_cam_records") h->s->set_implicit_cam_records(value != 0);
     else if (n == "cam_beside_pairs") h->s->set_cam_beside_pairs(value != 0);
     else if (n == "one_wait") h->s->set_one_wait(value != 0);

@@ -47,6 +47,8 @@ class Solver : public LmBackend {
     int assemble_only(double lambda);
     int step_stats(double out3[3]) override;                // |g|, |step|, predicted reduction
     int eval_step(double* trial_cost) override;             // x (+) step into the trial set, A16 there
+    int enqueue_step_stats();                               // (the kernels of the two calls above, without the read-back)
+    int enqueue_trial_point(double* sumsq_out);
     int commit_step() override;
     int discard_step() override;                            // reference semantics: trial (+) (-step)
     int parameter_norm(double* out) override;
@@ -111,6 +113,7 @@ class Solver : public LmBackend {
     void set_queued6(bool on) { queued6_ = on; }
     void set_bundles(bool on) { bundles_ = on; }
     void set_prezero(bool on) { prezero_ = on; }
+    void set_eager_step_eval(bool on) { eager_eval_ = on; }
     void set_implicit_cam_records(bool on) { cam_records_ = on; }
     void set_cam_beside_pairs(bool on) { cam_beside_ = on; }
     void set_one_wait(bool on) { one_wait_ = on; }
@@ -243,6 +246,13 @@ class Solver : public LmBackend {
     // block of S): disjoint outputs, both read what k_landmark_reduce wrote
     bool cam_beside_ = false;
     hipEvent_t cam_ev_[2] = {nullptr, nullptr};
+    // "eager_step_eval" (round 5): what the LM loop asks next of every solve -- the step statistics (apexgpu_step_stats) and the
+    // trial point with its cost (apexgpu_eval_step) -- is enqueued behind the back-substitution and read at the solve's own wait:
+    // the two calls then answer from the host, without a launch or a wait of their own (three device round trips per LM
+    // iteration become one).  The answers are those of this very solve (step_serial_); single rank.
+    bool eager_eval_ = true;
+    int64_t step_serial_ = 0, eager_serial_ = -1;
+    double* eager_host_ = nullptr;               // pinned: [0..5] step statistics, [6] sum of squares at the trial point
     double* pcg_host_ = nullptr;                 // pinned: two slots of the matrix-free PCG's scalars (read one iteration behind)
     hipEvent_t pcg_ev_[2] = {nullptr, nullptr};
     bool bundles_ = false;           // "landmark_bundles": BAView::bun_ptr (ba_kernels.h).  Built and measured in round 5 (profiles/

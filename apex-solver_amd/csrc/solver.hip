@@ -60,6 +60,7 @@ Solver::~Solver() {
     if (zero_ev_) (void)hipEventDestroy(zero_ev_);
     for (hipEvent_t e : cam_ev_) if (e) (void)hipEventDestroy(e);
     if (pcg_host_) (void)hipHostFree(pcg_host_);
+    if (eager_host_) (void)hipHostFree(eager_host_);
     for (hipEvent_t e : pcg_ev_) if (e) (void)hipEventDestroy(e);
     for (int b = 0; b < 2; ++b) {
         if (pin_[b]) (void)hipHostFree(pin_[b]);
@@ -877,6 +878,7 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     if (!have_params_) return fail(kInvalidState, "Block structure not built or parameters not set");
     HIP_TRY(hipSetDevice(device_));
     have_step_ = false;
+    ++step_serial_;
     last_lambda_ = lambda;
     int pcg_max = cg_max_iter_;
     double pcg_tol = cg_tol_;
@@ -918,6 +920,15 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
         stage_end(kStBackSub);
         HIP_TRY(hipGetLastError());
         have_step_ = true;
+        // what the LM loop asks next (step statistics, trial cost) rides on this solve's wait (solver.h, eager_eval_)
+        const bool eager = eager_eval_ && !(comm_ && world_ > 1);
+        if (eager) {
+            if (!eager_host_) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&eager_host_), 8 * sizeof(double), hipHostMallocDefault));
+            rc = enqueue_step_stats();
+            if (rc == kOk) rc = enqueue_trial_point(scal_ + 6);
+            if (rc != kOk) return rc;
+            HIP_TRY(hipMemcpyAsync(eager_host_, scal_, 7 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        }
         rc = export_step(step_out, grad_out);   // (synchronises: the sweeps' error word is on the host now)
         if (rc == kOk && speculative) {   // the flags the old path read before going on
             speculative = false;
@@ -947,7 +958,10 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
             HIP_TRY(hipEventRecord(zero_ev_, zero_stream_));
             tiles_prezeroed_ = true;
         }
-        if (rc != kOk || variant != 0 || !tp_.sweep_timed_out()) return rc;
+        if (rc != kOk || variant != 0 || !tp_.sweep_timed_out()) {
+            if (rc == kOk && eager) eager_serial_ = step_serial_;   // (the answers of THIS solve: step_stats / eval_step)
+            return rc;
+        }
         // A dataflow sweep of THIS solve ran into its spin limit (chol_kernels.hip, flow_wait): dcam_ is wrong.  The factor is
         // intact, so the solve is repeated with the level-by-level sweeps -- for this call and for the rest of the plan's
         // life (a device that starved a sweep once will do it again, and every time-out costs ~2 s).  In a distributed plan
@@ -1080,26 +1094,55 @@ int Solver::assemble_only(double lambda) {
     return kOk;
 }
 
-int Solver::step_stats(double out3[3]) {
-    if (!have_step_) return fail(kInvalidState, "no step computed");
-    HIP_TRY(hipSetDevice(device_));
+int Solver::enqueue_step_stats() {
     stage_begin(kStStats);
     launch_step_stats(n_c_, g_c_, dcam_, last_lambda_, scaled_ ? cam_scale_ : nullptr, partial_, n_partial_, scal_, stream_);
     launch_step_stats(3 * n_pt_, g_l_, dl_, last_lambda_, scaled_ ? pt_scale_ : nullptr, partial_, n_partial_, scal_ + 3, stream_);
     if (comm_ && world_ > 1)  // landmark part is sharded, camera part replicated
         COMM_TRY(comm_->all_reduce_sum(scal_ + 3, 3, stream_));
     stage_end(kStStats);
-    double h[6];
-    HIP_TRY(hipMemcpyAsync(h, scal_, sizeof h, hipMemcpyDeviceToHost, stream_));
-    HIP_TRY(hipStreamSynchronize(stream_));
+    return kOk;
+}
+static void stats_from_sums(const double h[6], double out3[3]) {
     out3[0] = sqrt(h[0] + h[3]);          // gradient.norm_l2()          (levenberg_marquardt.rs:746)
     out3[1] = sqrt(h[1] + h[4]);          // step.norm_l2()              (:890)
     out3[2] = 0.5 * (h[2] + h[5]);        // compute_predicted_reduction (:721-727)
+}
+int Solver::step_stats(double out3[3]) {
+    if (!have_step_) return fail(kInvalidState, "no step computed");
+    if (eager_serial_ == step_serial_ && eager_host_) { stats_from_sums(eager_host_, out3); return kOk; }   // read at the solve's wait
+    HIP_TRY(hipSetDevice(device_));
+    const int rc = enqueue_step_stats();
+    if (rc != kOk) return rc;
+    double h[6];
+    HIP_TRY(hipMemcpyAsync(h, scal_, sizeof h, hipMemcpyDeviceToHost, stream_));
+    HIP_TRY(hipStreamSynchronize(stream_));
+    stats_from_sums(h, out3);
     return kOk;
 }
-
+// the trial point x (+) step in the other parameter set and the sum of squared corrected residuals there (device scalar)
+int Solver::enqueue_trial_point(double* sumsq_out) {
+    const int t = cur_ ^ 1;
+    stage_begin(kStRetract);
+    launch_retract(dc_, n_cam_, n_pt_, poses_[cur_], intr_[cur_], pts_[cur_], dcam_, dl_, 1.0, fix_pose_, fix_intr_,
+                   fix_pt_, poses_[t], intr_[t], pts_[t], stream_);
+    launch_prepare_cams(n_cam_, poses_[t], intr_[t], camp_[t], mode_mask(mode_), stream_);
+    stage_end(kStRetract);
+    stage_begin(kStCost);
+    launch_cost(view(t), partial_, n_partial_, sumsq_out, stream_);
+    if (comm_ && world_ > 1)
+        COMM_TRY(comm_->all_reduce_sum(sumsq_out, 1, stream_));
+    stage_end(kStCost);
+    return kOk;
+}
 int Solver::eval_step(double* trial_cost) {
     if (!have_step_) return fail(kInvalidState, "no step computed");
+    if (eager_serial_ == step_serial_ && eager_host_) {   // the trial point is in place and its cost was read at the solve's wait
+        have_trial_ = true;
+        const double nrm = sqrt(eager_host_[6]);
+        *trial_cost = 0.5 * nrm * nrm;
+        return kOk;
+    }
     HIP_TRY(hipSetDevice(device_));
     const int t = cur_ ^ 1;
     stage_begin(kStRetract);
@@ -1110,7 +1153,6 @@ int Solver::eval_step(double* trial_cost) {
     have_trial_ = true;
     return cost_of(t, trial_cost);
 }
-
 int Solver::commit_step() {
     if (!have_trial_) return fail(kInvalidState, "no trial point");
     cur_ ^= 1;
