@@ -674,6 +674,8 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     else if (n == "split_u1") h->s->set_split_u1(value);
     else if (n == "panel_split") h->s->set_panel_split(value);
     else if (n == "fwd_beside_top") h->s->set_fwd_beside_top(value != 0);
+    else if (n == "one_wait") h->s->set_one_wait(value != 0);
+    else if (n == "eager_step_eval") h->s->set_eager_step_eval(value != 0);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
     else if (n == "panel_tri") apex::set_panel_tri(value);
     else if (n == "panel_small_max") apex::set_gemm_small_max(value, -1);

@@ -37,6 +37,8 @@ class PoseGraphSolver : public LmBackend {
     int solve_augmented(double lambda, int variant, double* step_out, double* grad_out) override;
     int step_stats(double out3[3]) override;
     int eval_step(double* trial_cost) override;
+    void enqueue_step_stats();                       // (the kernels of the two calls above, without the read-back)
+    void enqueue_trial_point(double* sumsq_out);
     int commit_step() override;
     int discard_step() override;
     int parameter_norm(double* out) override;
@@ -58,6 +60,8 @@ class PoseGraphSolver : public LmBackend {
     void debug_poison_next_solve(int which) { tp_.debug_poison_next_solve(which); }
     void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
     void set_panel_split(int min_rest) { tp_.set_panel_split(min_rest); }
+    void set_one_wait(bool on) { one_wait_ = on; }
+    void set_eager_step_eval(bool on) { eager_eval_ = on; }
     void set_fwd_beside_top(bool on) { tp_.set_fwd_beside_top(on); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
@@ -105,6 +109,11 @@ class PoseGraphSolver : public LmBackend {
     uint32_t *e_from_ = nullptr, *e_to_ = nullptr;
     int n_prior_ = 0;
     int n_factor_flow_timeouts_ = 0;
+    // one device round trip per LM iteration (round 5, as in Solver): the pivot flags are read at the solve's final wait, and the
+    // step statistics and the trial cost the LM loop asks next ride on that wait too ("one_wait", "eager_step_eval")
+    bool one_wait_ = true, eager_eval_ = true;
+    int64_t step_serial_ = 0, eager_serial_ = -1;
+    double* eager_host_ = nullptr;   // pinned: [0..2] step statistics, [3] sum of squares at the trial point
     uint32_t* prior_v_ = nullptr;
     double* prior_data_ = nullptr;
     double* prior_res_ = nullptr;   // staging of get_prior_residual

@@ -40,6 +40,7 @@ PoseGraphSolver::PoseGraphSolver(int64_t n_v, int64_t n_e, int device) : n_v_(n_
 PoseGraphSolver::~PoseGraphSolver() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (eager_host_) (void)hipHostFree(eager_host_);
     void* ptrs[] = {poses_[0], poses_[1], posep_[0], posep_[1], e_from_, e_to_, meas_, fix_, g_, rhs_, d_, work_, partial_, scal_, scale_, prior_v_, prior_data_, prior_res_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -226,6 +227,7 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
     if (variant != 0) return fail(kInvalidInput, "the pose-graph backend has the sparse Cholesky solver only");
     HIP_TRY(hipSetDevice(device_));
     have_step_ = false;
+    ++step_serial_;
     last_lambda_ = lambda;
     int rc = assemble(lambda);
     if (rc != kOk) return rc;
@@ -233,25 +235,40 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
     if (scaled_) launch_vec_mul(n_pad_, rhs_, scale_, rhs_, stream_);  // -D g
     timer_.begin(kPgFactor, stream_);
     int failed = 0;
-    HIP_TRY(tp_.factor(&failed, rhs_, work_));  // the forward sweep rides along
-    if (tp_.factor_flow_gave_up()) {
+    // (one_wait_: the pivot flags and the dataflow launch's time-out word are read at the final wait below; the sweeps over a
+    // failed factor are then void and the old path runs from the assembly on)
+    bool speculative = one_wait_;
+    HIP_TRY(tp_.factor(&failed, rhs_, work_, /*defer_flags=*/speculative));  // the forward sweep rides along
+    auto after_time_out = [&]() -> int {
         // the dataflow launch of the top groups timed out (the plan is back on the level launches): H is half updated
-        timer_.end(kPgFactor, stream_);
         ++n_factor_flow_timeouts_;
-        rc = assemble(lambda);
-        if (rc != kOk) return rc;
+        int r = assemble(lambda);
+        if (r != kOk) return r;
+        launch_pg_negate(n_pad_, g_, rhs_, stream_);
+        if (scaled_) launch_vec_mul(n_pad_, rhs_, scale_, rhs_, stream_);
         timer_.begin(kPgFactor, stream_);
         HIP_TRY(tp_.factor(&failed, rhs_, work_));
+        timer_.end(kPgFactor, stream_);
         if (tp_.factor_flow_gave_up()) return fail(kDeviceError, "dataflow factorisation timed out twice");
-    }
+        return kOk;
+    };
     timer_.end(kPgFactor, stream_);
-    if (failed) return fail(kSingularMatrix, "Cholesky factorization failed (matrix may be singular)");
+    if (!speculative) {
+        if (tp_.factor_flow_gave_up()) { rc = after_time_out(); if (rc != kOk) return rc; }
+        if (failed) return fail(kSingularMatrix, "Cholesky factorization failed (matrix may be singular)");
+    }
     for (int attempt = 0;; ++attempt) {
         timer_.begin(kPgTriSolve, stream_);
         HIP_TRY(tp_.solve(rhs_, d_, work_));
         if (scaled_) launch_vec_mul(n_pad_, d_, scale_, d_, stream_);  // apply_inverse_scaling: step = D y
         timer_.end(kPgTriSolve, stream_);
         have_step_ = true;
+        if (eager_eval_) {   // what the LM loop asks next rides on this solve's wait (step_stats, eval_step)
+            if (!eager_host_) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&eager_host_), 8 * sizeof(double), hipHostMallocDefault));
+            enqueue_step_stats();
+            enqueue_trial_point(scal_ + 4);
+            HIP_TRY(hipMemcpyAsync(eager_host_, scal_ + 1, 4 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        }
         if (step_out || grad_out) {
             std::vector<double> h(n_);
             for (int pass = 0; pass < 2; ++pass) {
@@ -267,7 +284,24 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
         } else {
             HIP_TRY(hipStreamSynchronize(stream_));
         }
-        if (!tp_.sweep_timed_out()) return kOk;
+        if (speculative) {   // the flags the old path read behind the factorisation
+            speculative = false;
+            HIP_TRY(tp_.read_flags(&failed));
+            if (tp_.factor_flow_gave_up()) {
+                have_step_ = false;
+                (void)tp_.sweep_timed_out();   // (clears the word a sweep over a broken factor may have raised)
+                rc = after_time_out();
+                if (rc != kOk) return rc;
+                if (failed) return fail(kSingularMatrix, "Cholesky factorization failed (matrix may be singular)");
+                attempt = -1;
+                continue;   // the sweeps once more, over the good factor
+            }
+            if (failed) { have_step_ = false; (void)tp_.sweep_timed_out(); return fail(kSingularMatrix, "Cholesky factorization failed (matrix may be singular)"); }
+        }
+        if (!tp_.sweep_timed_out()) {
+            if (eager_eval_) eager_serial_ = step_serial_;   // (the answers of THIS solve)
+            return kOk;
+        }
         // a dataflow sweep of this solve gave up (chol_kernels.hip, flow_wait): repeat it level by level (Solver::solve_augmented)
         have_step_ = false;
         if (attempt > 0 || !tp_.tri_flow()) return fail(kDeviceError, "triangular sweep timed out");
@@ -275,12 +309,30 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
     }
 }
 
-int PoseGraphSolver::step_stats(double out3[3]) {
-    if (!have_step_) return fail(kInvalidState, "no step computed");
-    HIP_TRY(hipSetDevice(device_));
+void PoseGraphSolver::enqueue_step_stats() {
     timer_.begin(kPgStats, stream_);
     launch_step_stats(n_, g_, d_, last_lambda_, scaled_ ? scale_ : nullptr, partial_, n_partial_, scal_ + 1, stream_);
     timer_.end(kPgStats, stream_);
+}
+void PoseGraphSolver::enqueue_trial_point(double* sumsq_out) {
+    const int t = cur_ ^ 1;
+    timer_.begin(kPgRetract, stream_);
+    launch_pg_retract(n_v_, poses_[cur_], d_, 1.0, fix_, poses_[t], stream_);
+    launch_pg_prepare(n_v_, poses_[t], posep_[t], stream_);
+    timer_.end(kPgRetract, stream_);
+    timer_.begin(kPgCost, stream_);
+    launch_pg_cost(view(t), partial_, n_partial_, sumsq_out, stream_);
+    timer_.end(kPgCost, stream_);
+}
+
+int PoseGraphSolver::step_stats(double out3[3]) {
+    if (!have_step_) return fail(kInvalidState, "no step computed");
+    if (eager_serial_ == step_serial_ && eager_host_) {   // read at the solve's wait
+        out3[0] = sqrt(eager_host_[0]); out3[1] = sqrt(eager_host_[1]); out3[2] = 0.5 * eager_host_[2];
+        return kOk;
+    }
+    HIP_TRY(hipSetDevice(device_));
+    enqueue_step_stats();
     double h[3];
     HIP_TRY(hipMemcpyAsync(h, scal_ + 1, sizeof h, hipMemcpyDeviceToHost, stream_));
     HIP_TRY(hipStreamSynchronize(stream_));
@@ -292,6 +344,12 @@ int PoseGraphSolver::step_stats(double out3[3]) {
 
 int PoseGraphSolver::eval_step(double* trial_cost) {
     if (!have_step_) return fail(kInvalidState, "no step computed");
+    if (eager_serial_ == step_serial_ && eager_host_) {   // the trial point is in place, its cost was read at the solve's wait
+        have_trial_ = true;
+        const double nrm = sqrt(eager_host_[3]);
+        *trial_cost = 0.5 * nrm * nrm;
+        return kOk;
+    }
     HIP_TRY(hipSetDevice(device_));
     const int t = cur_ ^ 1;
     timer_.begin(kPgRetract, stream_);

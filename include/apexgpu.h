@@ -256,6 +256,10 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "one_wait" (1)    single rank, Cholesky variant: apexgpu_solve_augmented enqueues factorisation, sweeps and back-substitution
  *                     back to back and waits for the device ONCE (the landmark-inversion and pivot flags are read at that
  *                     wait; a failure repeats the solve on the old path, ladder included); 0: three waits as in rounds 1-4
+ *   "eager_step_eval" (1)  single rank: the step statistics and the trial point with its cost -- what the LM loop asks next of
+ *                     every solve -- are enqueued behind the back-substitution and read at the solve's own wait; apexgpu_step_stats
+ *                     and apexgpu_eval_step then answer from the host (three device round trips per LM iteration become one).
+ *                     A caller that never asks (a level-1 binding that only takes the step) sets 0 and saves the kernels
  *   "prezero_tiles" (0)  single rank, Cholesky variant; 1: the tiles of S are cleared for the next assembly on a side stream right
  *                     behind a finished solve (beside the caller's step statistics / trial cost) instead of at the head of the
  *                     assembly.  Measured neutral (the clear moves into the statistics / retraction kernels' time): off
