@@ -344,7 +344,12 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else return APEXGPU_ERR_INVALID_INPUT;
     return APEXGPU_OK;
 }
-int apexgpu_enable_stage_timing(apexgpu_solver* h, int on) { H_OR_FAIL; h->s->enable_stage_timing(on != 0); return APEXGPU_OK; }
+int apexgpu_enable_stage_timing(apexgpu_solver* h, int on) {
+    H_OR_FAIL;
+    if (on > 1) h->s->enable_stage_timing_only((uint32_t)on >> 1);   // bit k + 1 of `on`: stage k alone is timed
+    else h->s->enable_stage_timing(on != 0);
+    return APEXGPU_OK;
+}
 int apexgpu_reset_stage_times(apexgpu_solver* h) { H_OR_FAIL; h->s->reset_stage_times(); return APEXGPU_OK; }
 int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_t calls[APEXGPU_NUM_STAGES]) {
     H_OR_FAIL;

@@ -85,6 +85,7 @@ class Solver : public LmBackend {
     int stage_times(double* ms, int64_t* launches);  // averaged HIP-event time per stage since reset
     void reset_stage_times();
     void enable_stage_timing(bool on) { timer_.enable(on); }
+    void enable_stage_timing_only(uint32_t stage_mask) { timer_.enable_only(stage_mask); }
     void enable_graphs(bool on) { use_graphs_ = on; tp_.enable_graphs(on); }
     void enable_overlap(bool on) { tp_.enable_overlap(on); }
     void enable_tri_flow(bool on) { tp_.enable_tri_flow(on); }

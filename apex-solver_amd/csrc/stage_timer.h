@@ -18,10 +18,11 @@ class StageTimer {
         resolve();
         for (hipEvent_t e : pool_) (void)hipEventDestroy(e);
     }
-    void enable(bool on) { on_ = on; }
+    void enable(bool on) { on_ = on; mask_ = ~0u; }
+    void enable_only(uint32_t stage_mask) { on_ = stage_mask != 0; mask_ = stage_mask; }   // bit k: stage k is timed
     bool enabled() const { return on_; }
     void begin(int st, hipStream_t s) {
-        if (!on_) return;
+        if (!on_ || !((mask_ >> st) & 1u)) return;
         hipEvent_t a = take(), b = take();
         (void)hipEventRecord(a, s);
         open_[st] = {a, b};
@@ -59,6 +60,7 @@ class StageTimer {
         pending_.clear();
     }
     bool on_ = false;
+    uint32_t mask_ = ~0u;
     std::vector<hipEvent_t> pool_;
     std::pair<hipEvent_t, hipEvent_t> open_[N] = {};
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_;

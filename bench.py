@@ -505,7 +505,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    s.enable_stage_timing(True)
+    # Inside the timed region only the graded kernel's stage is timed (HIP events on the solver's stream around
+    # k_schur_pairs_r: roofline.avg_launch_ms is measured live, over these very steps); the eighteen events per iteration of the
+    # full stage table cost the stream ~0.1 ms per iteration (round 5: 12.88 against 12.69 ms, three pairs of runs), so the other
+    # stages are timed over `stage_steps` further iterations right behind the timed region.
+    sc_stage = pkg.capi.STAGE_NAMES.index("schur_scatter")
+    s.enable_stage_timing(2 << sc_stage)
     s.reset_stage_times()
     accepted_before = state["accepted"]
     barrier()
@@ -518,8 +523,18 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=pg_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    stages = s.stage_times()
+    stages_timed = s.stage_times()
     ms_per_step = elapsed * 1e3 / args.steps
+    accepted_in_region = state["accepted"] - accepted_before
+    final_cost_region = state["cost"]
+    stage_steps = max(2, min(5, args.steps))
+    s.enable_stage_timing(True)
+    s.reset_stage_times()
+    for _ in range(stage_steps):
+        lm_step(s, state)
+    barrier()
+    stages = s.stage_times()
+    stages["schur_scatter"] = stages_timed["schur_scatter"]   # (the graded kernel: from the timed region itself)
 
     # ---- roofline of the graded Schur-reduction kernel, per launch -------------------------------------------------------
     dc = 9 if args.mode == "selfcal" else 6
@@ -546,7 +561,8 @@ def main():
     off_pairs = info["pair_blocks"] - n_obs_local      # pair contributions without the self pairs
     useful_flop = 2.0 * (12 + 4 * dc + 2 * dc * dc) * off_pairs + 250.0 * n_obs_local
     executed_flop = ((2.0 * (12 + 4 * dc + 2 * dc * dc) + 2 * 120.0 + 36.0) if record_form else (2.0 * (12 + 4 * dc + 2 * dc * dc) + 2 * 250.0 + 36.0)) * off_pairs
-    stage_ms = (stages["landmark_reduce"][0] + stages["cam_reduce"][0] + stages["schur_scatter"][0]) / max(sc_n, 1)
+    per_step = {k: v[0] / (args.steps if k == "schur_scatter" else stage_steps) for k, v in stages.items()}   # ms per LM iteration
+    stage_ms = per_step["landmark_reduce"] + per_step["cam_reduce"] + sc_avg
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
                 "pair_list_bytes": pair_list_bytes if record_form else 0.0,
@@ -592,18 +608,20 @@ def main():
         **({"factor": factor_roofline(info, stages["factor"][0] / max(stages["factor"][1], 1),
                                       "levels 0-8 at the tile GEMM's rate, the middle levels and the top latency-bound (profiles/r05_factor_timeline.txt)")}
            if args.variant == "sparse" and not s.variant_info()["reason"] else {}),
-        "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
+        "stages_ms_per_step": per_step,
         "stage_launches": {k: int(v[1]) for k, v in stages.items()},
+        "stages_measured": f"schur_scatter (the graded kernel): HIP events inside the timed region, {args.steps} iterations; the other stages: {stage_steps} "
+                           "further iterations right behind it with every stage event on (the full table costs the stream ~0.1 ms per iteration)",
         "setup_s": setup_s, "setup_by_phase_s": {k: st[k] for k in ("order", "lists", "tile_plan", "schur_lists", "uploads", "total")},
         # the whole of setup_s by piece: handle creation (the process's first HIP call = runtime start-up), the host-side
         # argument arrays, apexgpu_set_structure (= setup_by_phase_s.total + its argument checks), the parameter upload
         "setup_wall_s": dict(getattr(s, "setup_wall", {})),
-        "initial_cost": initial_cost, "final_cost": state["cost"], "accepted_steps": state["accepted"] - accepted_before,
+        "initial_cost": initial_cost, "final_cost": final_cost_region, "accepted_steps": accepted_in_region,
         "accepted_steps_incl_warmup": state["accepted"],
         "obs_per_s": d.n_obs / (ms_per_step * 1e-3),
     }
     if args.variant != "sparse":
-        out["pcg_iterations_per_step"] = state["pcg"][args.warmup:]
+        out["pcg_iterations_per_step"] = state["pcg"][args.warmup:args.warmup + args.steps]
     elif world == 1 and not args.no_other_variants:
         # OUTSIDE the timed region, same handle, same problem, the optimisation simply goes on: the reference's BA default
         # (SchurVariant::Iterative, 200 Jacobi-PCG iterations at 1e-6 on the explicit S: levenberg_marquardt.rs:519-530 -- what

@@ -335,6 +335,8 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value);
 #define APEXGPU_NUM_STAGES 10
 /* stage order: cam-reduce(+memset), landmark-reduce, schur-scatter, all-reduce, factor (or PCG),
  * triangular solves, back-substitute, step-stats, retract, cost */
+/* on: 0 off, 1 every stage, > 1: bit k + 1 set = stage k alone is timed (e.g. 2 << 2: the Schur kernel only -- what bench.py
+ * keeps inside its timed region; every stage event costs the stream a few microseconds) */
 int apexgpu_enable_stage_timing(apexgpu_solver* h, int on);
 int apexgpu_reset_stage_times(apexgpu_solver* h);
 int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_t calls[APEXGPU_NUM_STAGES]);
