@@ -692,7 +692,12 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     else return APEXGPU_ERR_INVALID_INPUT;
     return APEXGPU_OK;
 }
-int apexgpu_pg_enable_stage_timing(apexgpu_pg_solver* h, int on) { PG_OR_FAIL; h->s->enable_stage_timing(on != 0); return APEXGPU_OK; }
+int apexgpu_pg_enable_stage_timing(apexgpu_pg_solver* h, int on) {
+    PG_OR_FAIL;
+    if (on > 1) h->s->enable_stage_timing_only((uint32_t)on >> 1);   // bit k + 1 of `on`: stage k alone is timed
+    else h->s->enable_stage_timing(on != 0);
+    return APEXGPU_OK;
+}
 int apexgpu_pg_reset_stage_times(apexgpu_pg_solver* h) { PG_OR_FAIL; h->s->reset_stage_times(); return APEXGPU_OK; }
 int apexgpu_pg_stage_times(apexgpu_pg_solver* h, double ms[APEXGPU_PG_NUM_STAGES], int64_t calls[APEXGPU_PG_NUM_STAGES]) {
     PG_OR_FAIL;

@@ -74,6 +74,7 @@ class PoseGraphSolver : public LmBackend {
     void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void enable_stage_timing(bool on) { timer_.enable(on); }
+    void enable_stage_timing_only(uint32_t stage_mask) { timer_.enable_only(stage_mask); }
     void reset_stage_times() { timer_.reset(); }
     int stage_times(double* ms, int64_t* n) { return timer_.times(ms, n); }
     int64_t n_vertices() const { return n_v_; }
