@@ -46,6 +46,12 @@ struct FlowTask {     // one workgroup of a dataflow triangular sweep (k_tri_fwd
     int dst;              // product: the block the product belongs to; solve: the block solved
     int part;             // product: its slot in the partial array; solve: first slot of the block's products
     int count;            // solve: number of products to wait for and fold
+    // solve task, round 5 (single-GPU plans): the product of the block's LAST-ARRIVING source -- the link of the dependency chain --
+    // is formed by the solve task itself (tile mat2 times the solution of block src2, into slot `slot2` of the fold, same
+    // arithmetic, same place in the sum): one flag hop and one trip of the product through memory less per level.  src2 < 0: none
+    const double* mat2 = nullptr;
+    int src2 = -1;
+    int slot2 = -1;
 };
 
 struct SymEntry {  // one tile of block-row I of the symmetric tile matrix

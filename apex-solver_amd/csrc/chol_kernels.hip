@@ -1282,6 +1282,21 @@ __device__ __forceinline__ void flow_wait(const int* flag, int want, int tid, in
     }
     __syncthreads();
 }
+// two conditions in ONE polling loop (lanes 0 and 1 poll a counter each and vote): a poll is a round trip to memory
+__device__ __forceinline__ void flow_wait2(const int* flag_a, int want_a, const int* flag_b, int want_b, int tid, int* err) {
+    if (tid < 64) {
+        int spins = 0;
+        for (;;) {
+            int have = 0x7fffffff, want = 0;
+            if (tid == 0) { have = __hip_atomic_load(flag_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); want = want_a; }
+            if (tid == 1) { have = __hip_atomic_load(flag_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); want = want_b; }
+            if (__all(have >= want)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kFlowSpinLimit) { if (tid == 0) atomicOr(err, 1); break; }
+        }
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ void flow_publish(int* flag, int tid) {
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = expcnt = 0: this wave's stores are acknowledged
     __syncthreads();
@@ -1298,35 +1313,70 @@ __global__ __launch_bounds__(kBwdThreads) void k_tri_bwd_flow(const FlowTask* __
                                                              int* __restrict__ cnt, int* __restrict__ done, int* __restrict__ err) {
     __shared__ double sx[NB];
     __shared__ double spart[kBwdParts][NB];
+    __shared__ double sinl[NB];   // the inline product of a solve task (FlowTask::mat2)
     const FlowTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x;
     const int p = tid / (NB / 2), j2 = tid - p * (NB / 2);   // columns 2 j2, 2 j2 + 1; rows p * 18 ...
     const int r0 = p * kFlowRows;
-    double2 m[kFlowRows];
+    const bool inl = t.src < 0 && t.src2 >= 0;   // (workgroup-uniform)
+    double2 m[kFlowRows], m2[kFlowRows];
     {
         const double* __restrict__ M = t.mat + (size_t)r0 * NB + 2 * j2;   // L resp. Linv is final: in flight during the wait
 #pragma unroll
         for (int r = 0; r < kFlowRows; ++r) m[r] = *reinterpret_cast<const double2*>(M + (size_t)r * NB);
+        const double* __restrict__ M2 = (inl ? t.mat2 : t.mat) + (size_t)r0 * NB + 2 * j2;
+#pragma unroll
+        for (int r = 0; r < kFlowRows; ++r) m2[r] = inl ? *reinterpret_cast<const double2*>(M2 + (size_t)r * NB) : make_double2(0.0, 0.0);
     }
+    // M^T v over this thread's 18 rows and two columns, the eight row partitions added in a fixed order: the ONE matvec of
+    // product and solve tasks (and of a solve task's inline product: same arithmetic as the product task it replaces)
+    auto matvec_t = [&](const double2* mm, double* out_lds) {   // sx -> out_lds[0..NB) (valid after the trailing barrier)
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < kFlowRows; ++r) {
+            const double xv = sx[r0 + r];
+            a0 = fma(mm[r].x, xv, a0); a1 = fma(mm[r].y, xv, a1);
+        }
+        spart[p][2 * j2] = a0; spart[p][2 * j2 + 1] = a1;
+        __syncthreads();
+        if (tid < NB) {
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < kBwdParts; ++q) v += spart[q][tid];
+            out_lds[tid] = v;
+        }
+        __syncthreads();
+    };
     if (t.src >= 0) {
         flow_wait(done + t.src, 1, tid, err);
         if (tid < NB) sx[tid] = flow_ld(x + (size_t)t.src * NB + tid);
     } else {
-        flow_wait(cnt + t.dst, t.count, tid, err);
+        if (inl) {
+            flow_wait2(cnt + t.dst, t.count - 1, done + t.src2, 1, tid, err);
+            if (tid < NB) sx[tid] = flow_ld(x + (size_t)t.src2 * NB + tid);
+            __syncthreads();
+            matvec_t(m2, sinl);
+        } else {
+            flow_wait(cnt + t.dst, t.count, tid, err);
+        }
         // fold the block's products: four groups of 144 threads take every fourth one (all loads of a thread
         // independent), then the groups are added in a fixed order
         const int g = tid / NB, c = tid - g * NB;
+        const int s2 = inl ? t.slot2 : -1;
         double v = 0.0;
         {
             const double* __restrict__ pp = part + (size_t)t.part * NB + c;
+            const double own = inl ? sinl[c] : 0.0;
+            auto slot = [&](int q) { const double pv = flow_ld(pp + (size_t)q * NB); return q == s2 ? own : pv; };
             int q = g;
             for (; q + 12 < t.count; q += 16) {
-                const double p0 = flow_ld(pp + (size_t)q * NB), p1 = flow_ld(pp + (size_t)(q + 4) * NB);
-                const double p2 = flow_ld(pp + (size_t)(q + 8) * NB), p3 = flow_ld(pp + (size_t)(q + 12) * NB);
+                const double p0 = slot(q), p1 = slot(q + 4);
+                const double p2 = slot(q + 8), p3 = slot(q + 12);
                 v += (p0 + p1) + (p2 + p3);
             }
-            for (; q < t.count; q += 4) v += flow_ld(pp + (size_t)q * NB);
+            for (; q < t.count; q += 4) v += slot(q);
         }
+        __syncthreads();   // (spart was the matvec's scratch)
         spart[g][c] = v;
         __syncthreads();
         if (tid < NB) sx[tid] = y[(size_t)t.dst * NB + tid] - ((spart[0][tid] + spart[1][tid]) + (spart[2][tid] + spart[3][tid]));
@@ -1338,6 +1388,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_tri_bwd_flow(const FlowTask* __
         const double xv = sx[r0 + r];
         a0 = fma(m[r].x, xv, a0); a1 = fma(m[r].y, xv, a1);
     }
+    __syncthreads();   // (every thread has read its spart sums above)
     spart[p][2 * j2] = a0; spart[p][2 * j2 + 1] = a1;
     __syncthreads();
     if (tid < NB) {
@@ -1377,36 +1428,73 @@ __global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowTask* __
                                                              const double* __restrict__ fold_b, double* __restrict__ fold_out) {
     __shared__ double sx[NB];
     __shared__ double spart[4][NB];
+    __shared__ double sinl[NB];   // the inline product of a solve task (FlowTask::mat2)
     const FlowTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int rg = lane >> 4, cl = lane & 15;
     const int row0 = 16 * w + kFwdRows * rg;
-    double m[kFwdRows][kFwdCols];
+    const bool inl = t.src == -1 && t.src2 >= 0;   // (workgroup-uniform)
+    double m[kFwdRows][kFwdCols], m2[kFwdRows][kFwdCols];
     {
         const double* __restrict__ M = t.mat + (size_t)row0 * NB + cl;   // L resp. Linv is final: in flight during the wait
 #pragma unroll
         for (int rr = 0; rr < kFwdRows; ++rr)
 #pragma unroll
             for (int k = 0; k < kFwdCols; ++k) m[rr][k] = M[(size_t)rr * NB + 16 * k];
+        const double* __restrict__ M2 = (inl ? t.mat2 : t.mat) + (size_t)row0 * NB + cl;
+#pragma unroll
+        for (int rr = 0; rr < kFwdRows; ++rr)
+#pragma unroll
+            for (int k = 0; k < kFwdCols; ++k) m2[rr][k] = inl ? M2[(size_t)rr * NB + 16 * k] : 0.0;
     }
+    // M v for this lane's four rows (the sum over a DPP row of sixteen lanes lands in lane 15): the ONE matvec of product and
+    // solve tasks, and of a solve task's inline product (same arithmetic as the product task it replaces)
+    auto matvec = [&](const double (&mm)[kFwdRows][kFwdCols], double (&acc)[kFwdRows]) {
+#pragma unroll
+        for (int rr = 0; rr < kFwdRows; ++rr) acc[rr] = 0.0;
+#pragma unroll
+        for (int k = 0; k < kFwdCols; ++k) {
+            const double xv = sx[cl + 16 * k];
+#pragma unroll
+            for (int rr = 0; rr < kFwdRows; ++rr) acc[rr] = fma(mm[rr][k], xv, acc[rr]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < kFwdRows; ++rr) acc[rr] = row16_sum_lane15(acc[rr]);
+    };
     if (t.src >= 0) {
         flow_wait(done + t.src, 1, tid, err);
         if (tid < NB) sx[tid] = flow_ld(y + (size_t)t.src * NB + tid);
     } else {
-        flow_wait(cnt + t.dst, t.count, tid, err);
+        if (inl) {
+            flow_wait2(cnt + t.dst, t.count - 1, done + t.src2, 1, tid, err);
+            if (tid < NB) sx[tid] = flow_ld(y + (size_t)t.src2 * NB + tid);
+            __syncthreads();
+            double a2[kFwdRows];
+            matvec(m2, a2);
+            if (cl == 15) {
+#pragma unroll
+                for (int rr = 0; rr < kFwdRows; ++rr) sinl[row0 + rr] = a2[rr];
+            }
+            __syncthreads();
+        } else {
+            flow_wait(cnt + t.dst, t.count, tid, err);
+        }
         // fold the block's products: four groups of 144 threads take every fourth one (all loads of a thread
         // independent), then the groups are added in a fixed order
         const int g = tid / NB, c = tid - g * NB;
+        const int s2 = inl ? t.slot2 : -1;
         double v = 0.0;
         {
             const double* __restrict__ pp = part + (size_t)t.part * NB + c;
+            const double own = inl ? sinl[c] : 0.0;
+            auto slot = [&](int q) { const double pv = flow_ld(pp + (size_t)q * NB); return q == s2 ? own : pv; };
             int q = g;
             for (; q + 12 < t.count; q += 16) {
-                const double p0 = flow_ld(pp + (size_t)q * NB), p1 = flow_ld(pp + (size_t)(q + 4) * NB);
-                const double p2 = flow_ld(pp + (size_t)(q + 8) * NB), p3 = flow_ld(pp + (size_t)(q + 12) * NB);
+                const double p0 = slot(q), p1 = slot(q + 4);
+                const double p2 = slot(q + 8), p3 = slot(q + 12);
                 v += (p0 + p1) + (p2 + p3);
             }
-            for (; q < t.count; q += 4) v += flow_ld(pp + (size_t)q * NB);
+            for (; q < t.count; q += 4) v += slot(q);
         }
         spart[g][c] = v;
         __syncthreads();
@@ -1420,15 +1508,8 @@ __global__ __launch_bounds__(kFwdThreads) void k_tri_fwd_flow(const FlowTask* __
         if (t.src == -2) return;
     }
     __syncthreads();
-    double acc[kFwdRows] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < kFwdCols; ++k) {
-        const double xv = sx[cl + 16 * k];
-#pragma unroll
-        for (int rr = 0; rr < kFwdRows; ++rr) acc[rr] = fma(m[rr][k], xv, acc[rr]);
-    }
-#pragma unroll
-    for (int rr = 0; rr < kFwdRows; ++rr) acc[rr] = row16_sum_lane15(acc[rr]);
+    double acc[kFwdRows];
+    matvec(m, acc);
     if (cl == 15) {
         double* __restrict__ o = (t.src >= 0 ? part + (size_t)t.part * NB : y + (size_t)t.dst * NB) + row0;
 #pragma unroll

@@ -98,6 +98,7 @@ class Solver : public LmBackend {
     void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
     void set_panel_split(int min_rest) { tp_.set_panel_split(min_rest); }
     void set_fwd_beside_top(bool on) { tp_.set_fwd_beside_top(on); }
+    void set_tri_inline(int max_cols) { tp_.set_tri_inline(max_cols); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
     void set_gate_pos(int p) { tp_.set_gate_pos(p); }

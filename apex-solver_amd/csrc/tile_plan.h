@@ -146,6 +146,7 @@ class TilePlan {
     // it also follows U2a(lv-1) -- the updates of the same diagonal tiles from two levels below --, which follows ALL panel
     // solves of level lv-1 and the U2 stream's older work; the period of a bulk level stays at ~360 us.  Off by default.
     void set_fwd_beside_top(bool on) { fwd_beside_top_ = on; }   // before the first factor()
+    void set_tri_inline(int max_cols) { tri_inline_ = max_cols; }   // before build(): levels of at most that many columns (0: off)
     void set_panel_split(int min_rest) { panel_split_ = min_rest > 0; if (min_rest > 0) panel_split_min_ = min_rest; }   // before the first factor()
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
     hipError_t read_flags(int* failed_at);   // pivot flag of the last factorisation (syncs)
@@ -305,6 +306,7 @@ class TilePlan {
     // the sweep part takes from the dataflow launch what it saves (its units read their operands past the L2, from the same
     // HBM).  Zero sum: off.
     bool fwd_beside_top_ = false, lower_fwd_now_ = false;
+    int tri_inline_ = 8;       // (swept 0 / 4 / 8 / 16 / 32 / all: profiles/r05_sweep_tri_inline.txt) the dataflow sweeps: in levels of at most this many columns a block's solve task forms its last-arriving product itself (FlowTask::mat2)
     std::vector<int> lv_flow_fwd_;            // [level]: first forward dataflow task of the level (plans that are not distributed)
     const double* fwd_lower_rhs_ = nullptr;   // right-hand side whose lower forward part the last factor() carried
     double* fwd_lower_work_ = nullptr;

@@ -499,18 +499,42 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             slot_of[K].reserve(row_cols[K].size());
             for (int J : row_cols[K]) slot_of[K].push_back(cls_h_[J] == 1 ? a++ : b++);
         }
+        // Single-GPU plans (tri_inline_, round 5): the solve task of a block forms the product of its LAST-ARRIVING source itself
+        // (FlowTask::mat2 / src2 / slot2: the source solved latest, i.e. of the highest level forward, of the lowest backward) --
+        // the link of the dependency chain loses a flag hop and a trip through memory; that product task leaves the list.
+        // Only in the NARROW levels (at most tri_inline_ columns): where a level is wide the sweeps are bound by HBM and the
+        // second tile of a solve task only serialises two products (final-13682 with every block inlined: sweeps 0.71 -> 0.79 ms;
+        // ladybug-1723, narrow everywhere: 0.35 -> 0.28).
+        const bool inl = tri_inline_ > 0 && !distributed();
+        std::vector<int> fwd_inl(nt_, -1), bwd_inl(nt_, -1);
+        if (inl)
+            for (int K = 0; K < nt_; ++K) {
+                if ((int)level_cols[(size_t)group_of[K]].size() > tri_inline_) continue;
+                for (int J : row_cols[K]) if (fwd_inl[K] < 0 || group_of[J] >= group_of[fwd_inl[K]]) fwd_inl[K] = J;
+                for (int I : col_rows[K]) if (bwd_inl[K] < 0 || group_of[I] < group_of[bwd_inl[K]]) bwd_inl[K] = I;
+            }
         auto products_of = [&](int K) {
             for (int I : col_rows[K]) {
+                if (fwd_inl[I] == K) continue;   // (formed by the solve task of block I)
                 const auto& rc = row_cols[I];
                 const int pos = (int)(std::lower_bound(rc.begin(), rc.end(), K) - rc.begin());
                 ft.push_back({tile_ptr(I, K), K, I, first[I] + slot_of[I][pos], 0});
             }
         };
+        auto fwd_solve = [&](int K) {
+            FlowTask t{linv_ptr(K), -1, K, first[K], (int)row_cols[K].size()};
+            if (fwd_inl[K] >= 0) {
+                const auto& rc = row_cols[K];
+                const int pos = (int)(std::lower_bound(rc.begin(), rc.end(), fwd_inl[K]) - rc.begin());
+                t.mat2 = tile_ptr(K, fwd_inl[K]); t.src2 = fwd_inl[K]; t.slot2 = slot_of[K][pos];
+            }
+            return t;
+        };
         lv_flow_fwd_.assign(n_levels_ + 1, 0);
         if (!distributed()) {
             for (int lv = 0; lv < n_levels_; ++lv) {
                 lv_flow_fwd_[lv] = (int)ft.size();
-                for (int K : level_cols[lv]) ft.push_back({linv_ptr(K), -1, K, first[K], (int)row_cols[K].size()});
+                for (int K : level_cols[lv]) ft.push_back(fwd_solve(K));
                 for (int K : level_cols[lv]) products_of(K);
             }
         } else {
@@ -530,9 +554,18 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         if (!ft.empty()) {
             for (int K = 0; K < nt_; ++K) first[K + 1] = first[K] + (int)col_rows[K].size();      // backward: by block column
             for (int lv = n_levels_ - 1; lv >= 0; --lv) {
-                for (int I : level_cols[lv]) bt.push_back({linv_ptr(I), -1, I, first[I], (int)col_rows[I].size()});
+                for (int I : level_cols[lv]) {
+                    FlowTask t{linv_ptr(I), -1, I, first[I], (int)col_rows[I].size()};
+                    if (bwd_inl[I] >= 0) {
+                        const auto& cr = col_rows[I];
+                        t.mat2 = tile_ptr(bwd_inl[I], I); t.src2 = bwd_inl[I];
+                        t.slot2 = (int)(std::lower_bound(cr.begin(), cr.end(), bwd_inl[I]) - cr.begin());
+                    }
+                    bt.push_back(t);
+                }
                 for (int I : level_cols[lv])
                     for (int J : row_cols[I]) {
+                        if (bwd_inl[J] == I) continue;   // (formed by the solve task of block J)
                         const auto& cr = col_rows[J];
                         const int pos = (int)(std::lower_bound(cr.begin(), cr.end(), I) - cr.begin());
                         bt.push_back({tile_ptr(I, J), I, J, first[J] + pos, 0});

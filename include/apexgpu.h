@@ -266,6 +266,10 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "panel_split" (0)  before set_structure; n > 0: panel lookahead -- the panel solves of a level in two launches when at least
  *                     n tiles are not critical: those whose rows belong to the next level (all that its potrf waits for) first,
  *                     the others on a stream of their own.  Race free, bit-identical, measured no gain (round 5): off
+ *   "tri_inline" (8)  before set_structure: in the levels of at most this many tile columns the solve task of a block of the
+ *                     dataflow sweeps forms the product of its last-arriving source itself (the link of the dependency chain:
+ *                     one flag hop and one trip through memory less per level); 0 = every product is a task of its own.
+ *                     Bit-identical.  ladybug-1723: sweeps 0.35 -> 0.28 ms; wide levels lose (HBM-bound), hence the limit
  *   "fwd_beside_top" (0)  before set_structure; 1: the forward sweep in two launches, the part over the columns below the
  *                     factorisation's dataflow launch on a side stream beside that launch.  Bit-identical; zero sum (round 5): off
  *   "cam_beside_pairs" (0)  single rank; 1: k_cam_reduce on a second stream beside the pair kernel (disjoint outputs).  Neutral: off
