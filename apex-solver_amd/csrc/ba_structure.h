@@ -29,6 +29,8 @@ struct BaStructOptions {
     int dist_selftest = 0;
     int schur_form = 3;        // 3 sorted pair list, 4 the same pairs in the queued layout (d_c = 9; schur_pairs.h), 2 LDS rows (k_schur_rows2, the A/B)
     int pair_task_slots = 0;   // pair slots per wave task of the pair list (0: default)
+    bool device_gathers = false;   // the measurement lists (o_uv, co_uv) and co_pt are gathered on the device from the caller's array and the
+                                   // index lists (Solver::set_structure, single rank): the host does not build them
     bool bundles = false;      // landmark bundles (BAView::bun_ptr): the projection records behind a copy of the landmark record's first line
     bool queued6 = false;      // the queued layout also for six-column cameras (sixteen queues of four pairs).  Built in round 5 and
                                // MEASURED SLOWER than form 3 there (final-13682, BundleAdjustment mode: 3.52 against 2.90 ms -- a 6 x 6

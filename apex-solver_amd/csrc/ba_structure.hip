@@ -319,7 +319,8 @@ std::string BaHostStructure::build_obs_lists(const uint32_t* cam_idx, const uint
     const int64_t o_lo = full_ptr_[lm_lo], o_hi = full_ptr_[lm_hi];
     const int64_t n_loc = o_hi - o_lo;
     if (n_loc > 2000000000LL) return "too many observations on one rank";
-    o_cam.resize(n_loc); o_pt.resize(n_loc); o_uv.resize(2 * n_loc); o_orig.resize(n_loc);
+    const bool dev_gather = o.device_gathers && world == 1;
+    o_cam.resize(n_loc); o_pt.resize(n_loc); o_uv.resize(dev_gather ? 0 : 2 * n_loc); o_orig.resize(n_loc);
     pt_ptr.resize(n_pt + 1);
     for (int64_t l = 0; l <= n_pt; ++l) {
         int64_t p = full_ptr_[l];
@@ -331,17 +332,17 @@ std::string BaHostStructure::build_obs_lists(const uint32_t* cam_idx, const uint
             const int i = full_obs_[o_lo + k];
             o_orig[k] = i;
             o_cam[k] = cam_i_[i]; o_pt[k] = pt_i_[i];
-            o_uv[2 * k] = obs_uv[2 * (int64_t)i]; o_uv[2 * k + 1] = obs_uv[2 * (int64_t)i + 1];
+            if (!dev_gather) { o_uv[2 * k] = obs_uv[2 * (int64_t)i]; o_uv[2 * k + 1] = obs_uv[2 * (int64_t)i + 1]; }
         }
     });
     tr.mark("lists: landmark-major copies");
     // ---- camera-major lists over the local observations (+ copies of landmark and measurement) -----------------------------
     parallel_bucket_small(n_loc, n_cam, o_cam.data(), cam_ptr, cam_obs);
-    co_pt.resize(n_loc); co_uv.resize(2 * n_loc); co_rank.resize(n_loc);
+    co_pt.resize(dev_gather ? 0 : n_loc); co_uv.resize(dev_gather ? 0 : 2 * n_loc); co_rank.resize(n_loc);
     parallel_ranges(n_loc, 1 << 16, [&](int64_t b, int64_t e) {
         for (int64_t k = b; k < e; ++k) {
             const int i = cam_obs[k];
-            co_pt[k] = o_pt[i]; co_uv[2 * k] = o_uv[2 * (size_t)i]; co_uv[2 * k + 1] = o_uv[2 * (size_t)i + 1];
+            if (!dev_gather) { co_pt[k] = o_pt[i]; co_uv[2 * k] = o_uv[2 * (size_t)i]; co_uv[2 * k + 1] = o_uv[2 * (size_t)i + 1]; }
             co_rank[k] = i - pt_ptr[o_pt[i]];
         }
     });

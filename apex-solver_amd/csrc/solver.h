@@ -116,6 +116,7 @@ class Solver : public LmBackend {
     void set_bundles(bool on) { bundles_ = on; }
     void set_prezero(bool on) { prezero_ = on; }
     void set_eager_step_eval(bool on) { eager_eval_ = on; }
+    void set_device_gathers(bool on) { device_gathers_ = on; }
     void set_implicit_cam_records(bool on) { cam_records_ = on; }
     void set_cam_beside_pairs(bool on) { cam_beside_ = on; }
     void set_one_wait(bool on) { one_wait_ = on; }
@@ -252,6 +253,7 @@ class Solver : public LmBackend {
     // trial point with its cost (apexgpu_eval_step) -- is enqueued behind the back-substitution and read at the solve's own wait:
     // the two calls then answer from the host, without a launch or a wait of their own (three device round trips per LM
     // iteration become one).  The answers are those of this very solve (step_serial_); single rank.
+    bool device_gathers_ = true;   // "device_gathers": set-up, single rank: o_uv / co_uv / co_pt are permuted on the device (ba_structure.h)
     bool eager_eval_ = true;
     int64_t step_serial_ = 0, eager_serial_ = -1;
     double* eager_host_ = nullptr;               // pinned: [0..5] step statistics, [6] sum of squares at the trial point

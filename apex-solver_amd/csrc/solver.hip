@@ -190,15 +190,26 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     // APEX_SETUP_TRACE in bench.py, torch's context already there), the code objects of the three kernel files a few ms more:
     // both on a thread, beside the argument checks and the camera order (host only), joined in front of the first device call
     // below (device_ready) -- round 5.
+    double* raw_uv = nullptr;   // (device thread -> uploader thread, which joins the former through device_ready)
+    const bool raw_uv_wanted = device_gathers_ && world_ == 1 && !(comm_ && world_ > 1);
+    struct RawFree { double*& p; ~RawFree() { if (p) { (void)hipFree(p); p = nullptr; } } } raw_free{raw_uv};
     std::promise<hipError_t> init_p;
     std::shared_future<hipError_t> init_f = init_p.get_future().share();
-    std::thread warmer([this, &init_p] {
+    std::thread warmer([this, &init_p, &raw_uv, raw_uv_wanted, obs_uv] {
         SetupTrace wt;
         hipError_t e = hipSetDevice(device_);
         if (e == hipSuccess && !stream_) e = hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
         init_p.set_value(e);
         wt.mark("device thread: device, stream");
         if (e != hipSuccess) return;
+        if (raw_uv_wanted) {   // the caller's measurements as they are, beside the host's list building (device_gathers_)
+            if (hipMalloc(reinterpret_cast<void**>(&raw_uv), std::max<size_t>(2 * (size_t)n_obs_, 2) * sizeof(double)) != hipSuccess ||
+                hipMemcpy(raw_uv, obs_uv, 2 * (size_t)n_obs_ * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+                if (raw_uv) { (void)hipFree(raw_uv); raw_uv = nullptr; }
+                (void)hipGetLastError();
+            }
+            wt.mark("device thread: measurements up");
+        }
         hipStream_t ws = nullptr;
         if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) return;
         warm_ba_kernels(ws); warm_schur_pairs(ws); warm_chol_kernels(ws);
@@ -240,6 +251,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     so.dc = dc_; so.use_nd = use_nd_; so.nd_leaf = nd_leaf_; so.hubs_last = hubs_last_;
     so.rank = rank_; so.world = world_; so.dist_factor = dist_factor_; so.tree_sharding = tree_sharding_;
     so.dist_selftest = dist_selftest_; so.schur_form = rows_form_; so.pair_task_slots = pair_task_slots_; so.queued6 = queued6_;
+    so.device_gathers = device_gathers_ && world_ == 1;
     so.bundles = bundles_ && (rows_form_ == 3 || rows_form_ == 4) && !matrix_free_only_;   // (the pair kernel's layout; a matrix-free handle keeps plain records)
     std::unique_ptr<BaHostStructure> hs_owner(new BaHostStructure);
     BaHostStructure& hs = *hs_owner;
@@ -359,14 +371,39 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         }
         HIP_TRY(up(&o_cam_, o_cam));
         HIP_TRY(up(&o_pt_, o_pt));
-        HIP_TRY(up(reinterpret_cast<double**>(&o_uv_), o_uv));
         HIP_TRY(up(&o_orig_, o_orig_h_));
         HIP_TRY(up(&pt_ptr_, pt_ptr));
         HIP_TRY(up(&cam_ptr_, cam_ptr));
         HIP_TRY(up(&cam_obs_, cam_obs));
-        HIP_TRY(up(&co_pt_, co_pt));
         HIP_TRY(up(&co_rank_, co_rank));
-        HIP_TRY(up(reinterpret_cast<double**>(&co_uv_), co_uv));
+        if (so.device_gathers) {
+            // the caller's measurements go up as they are (one contiguous copy, no host gather), the three lists that are
+            // permutations of what is on the device already are made there
+            const size_t n_loc = o_cam.size();
+            if (warmer.joinable()) warmer.join();   // (the measurements went up on the device thread, beside the list building)
+            double* raw = raw_uv;
+            hipError_t ge = hipSuccess;
+            if (!raw) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&raw_uv), std::max<size_t>(2 * (size_t)n_obs_, 2) * sizeof(double)));
+                raw = raw_uv;
+                ge = hipMemcpy(raw, obs_uv, 2 * (size_t)n_obs_ * sizeof(double), hipMemcpyHostToDevice);
+            }
+            if (ge == hipSuccess) ge = alloc(reinterpret_cast<double**>(&o_uv_), 2 * n_loc);
+            if (ge == hipSuccess) ge = alloc(reinterpret_cast<double**>(&co_uv_), 2 * n_loc);
+            if (ge == hipSuccess) { if (co_pt_) { (void)hipFree(co_pt_); co_pt_ = nullptr; } ge = dev_alloc(&co_pt_, n_loc); }
+            if (ge == hipSuccess) {
+                launch_gather_uv((int64_t)n_loc, o_orig_, raw, reinterpret_cast<double*>(o_uv_), stream_);
+                launch_gather_uv((int64_t)n_loc, cam_obs_, reinterpret_cast<const double*>(o_uv_), reinterpret_cast<double*>(co_uv_), stream_);
+                launch_gather_u32((int64_t)n_loc, cam_obs_, o_pt_, co_pt_, stream_);
+                ge = hipStreamSynchronize(stream_);
+            }
+            (void)hipFree(raw_uv); raw_uv = nullptr;
+            HIP_TRY(ge);
+        } else {
+            HIP_TRY(up(reinterpret_cast<double**>(&o_uv_), o_uv));
+            HIP_TRY(up(&co_pt_, co_pt));
+            HIP_TRY(up(reinterpret_cast<double**>(&co_uv_), co_uv));
+        }
         {
             std::vector<uint8_t> fp(6 * n_cam_, 0), fi(3 * n_cam_, 0), fl(3 * n_pt_, 0);
             for (int64_t c = 0; c < n_cam_; ++c) {
