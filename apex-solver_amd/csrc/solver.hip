@@ -388,9 +388,16 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
                 raw = raw_uv;
                 ge = hipMemcpy(raw, obs_uv, 2 * (size_t)n_obs_ * sizeof(double), hipMemcpyHostToDevice);
             }
-            if (ge == hipSuccess) ge = alloc(reinterpret_cast<double**>(&o_uv_), 2 * n_loc);
-            if (ge == hipSuccess) ge = alloc(reinterpret_cast<double**>(&co_uv_), 2 * n_loc);
-            if (ge == hipSuccess) { if (co_pt_) { (void)hipFree(co_pt_); co_pt_ = nullptr; } ge = dev_alloc(&co_pt_, n_loc); }
+            // (plain allocations: every element is written by the gathers.  NOT the zero-filling alloc -- its hipMemset runs on the
+            // null stream, which stream_ (non-blocking) does not follow: the clear could land AFTER the gather had written the
+            // array; seen once in 36 problems of the population test as a step of garbage)
+            auto fresh = [](auto** pp, size_t n) -> hipError_t {
+                if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+                return hipMalloc(reinterpret_cast<void**>(pp), std::max<size_t>(n, 1) * sizeof(**pp));
+            };
+            if (ge == hipSuccess) ge = fresh(reinterpret_cast<double**>(&o_uv_), 2 * n_loc);
+            if (ge == hipSuccess) ge = fresh(reinterpret_cast<double**>(&co_uv_), 2 * n_loc);
+            if (ge == hipSuccess) ge = fresh(&co_pt_, n_loc);
             if (ge == hipSuccess) {
                 launch_gather_uv((int64_t)n_loc, o_orig_, raw, reinterpret_cast<double*>(o_uv_), stream_);
                 launch_gather_uv((int64_t)n_loc, cam_obs_, reinterpret_cast<const double*>(o_uv_), reinterpret_cast<double*>(co_uv_), stream_);
@@ -465,6 +472,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     if (!plan_err.empty()) { uploader.join(); return fail(kInvalidInput, "reduced camera matrix: " + plan_err); }
     hs.seconds[2] = plan_seconds;
     // ---- task lists of the selected form of the Schur reduction (they need the slot map) ------------------------------
+    // (tried in round 5: the pair list built from a host-only twin's slot map BEFORE the planner thread is done -- the host pool
+    // is shared, the three threads then slow one another down: set-up 0.26-0.28 s against 0.24)
     PairDeviceTables dtab;
     const bool recs_on_device = device_pair_recs_ && so.schur_form == 4 && (dc_ == 9 || queued6_);
     hs.build_schur_lists(so, tp_.slot_host(), recs_on_device ? &dtab : nullptr);

@@ -1,5 +1,6 @@
 // tile_plan.hip -- see tile_plan.h
 #include "tile_plan.h"
+#include "host_parallel.h"
 
 #include <chrono>
 #include <thread>
@@ -327,6 +328,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     release();
     nt_ = nt;
     stream_ = stream;
+    SetupTrace ptr_trace;
     const size_t tile_elems = (size_t)kNB * kNB;
     refused_ = 0;
     std::vector<std::vector<int>> col_rows = symbolic_slots(present);
@@ -345,8 +347,10 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     }
 
 #define TP_TRY(expr) do { if (!dry_run_) { hipError_t _e = (expr); if (_e != hipSuccess) return std::string("HIP error in " #expr ": ") + hipGetErrorString(_e); } } while (0)
+    ptr_trace.mark("plan: symbolic fill, slots");
     TP_TRY(alloc_zero(&tiles_, (size_t)n_slots_ * tile_elems));
     TP_TRY(alloc_zero(&linv_, (size_t)nt_ * tile_elems));
+    ptr_trace.mark("plan: tiles allocated, cleared");
     if (dry_run_) {   // addresses that identify tiles, nothing more
         tiles_ = reinterpret_cast<double*>(uintptr_t(1) << 44);
         linv_ = reinterpret_cast<double*>(uintptr_t(1) << 45);
@@ -784,7 +788,8 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             };
             double level_tail = 0.0, best_total = 0.0;   // cost of the groups [gf, g1) by level launches; best (level head dropped: common)
             int64_t units = 0;
-            std::vector<FactorUnit> cand;
+            // the candidate starts, from the top down, with what the level launches would cost from there
+            std::vector<std::pair<int, double>> cands;
             for (int gf = g1 - 1; gf >= g0; --gf) {
                 bool ok = (int)level_cols[gf].size() <= 64;
                 for (int K : level_cols[gf]) {
@@ -794,16 +799,34 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
                 }
                 if (!ok || units > (flow_tile_units_ ? 400000 : 120000)) break;   // (the model is evaluated per candidate start: keep plan building in the milliseconds)
                 level_tail += level_us(gf);
-                if (g1 - gf < 2) continue;
-                double sim = 0.0;
-                const std::string e = make_flow_units(gf, g1, cand, &sim);
-                if (!e.empty()) return e;
-                // gain of starting the launch at gf = what the level launches would have cost from there - the launch
-                const double gain = level_tail - (sim + 15.0);
-                if (gain > best_total) { best_total = gain; best_gf = gf; best_sim = sim; best_units.swap(cand); }
-                else if (gain < best_total - 300.0) break;   // past the optimum: the launch is swallowing throughput-bound levels
+                if (g1 - gf >= 2) cands.push_back({gf, level_tail});
             }
+            // The model of every candidate (its units in list-scheduled order, simulated) was half of the plan's build time on
+            // final-13682 -- 50 of 95 ms, evaluated one after the other.  They are independent: a batch at a time on the host
+            // pool, the choice replayed over the batch in the old order (same rule, same start), the winner's units built once
+            // more at the end (round 5).
+            const int batch = std::max(1, std::min<int>(8, (int)host_threads()));
+            bool past = false;
+            std::string err;
+            for (size_t c0 = 0; c0 < cands.size() && !past && err.empty(); c0 += (size_t)batch) {
+                const size_t c1 = std::min(cands.size(), c0 + (size_t)batch);
+                std::vector<double> sims(c1 - c0, 0.0);
+                std::vector<std::string> errs(c1 - c0);
+                parallel_rows((int64_t)(c1 - c0), [&](int64_t i) {
+                    std::vector<FactorUnit> scratch;
+                    errs[(size_t)i] = make_flow_units(cands[c0 + (size_t)i].first, g1, scratch, &sims[(size_t)i]);
+                }, 1);
+                for (size_t i = 0; i < c1 - c0 && !past; ++i) {
+                    if (!errs[i].empty()) { err = errs[i]; break; }
+                    // gain of starting the launch at gf = what the level launches would have cost from there - the launch
+                    const double gain = cands[c0 + i].second - (sims[i] + 15.0);
+                    if (gain > best_total) { best_total = gain; best_gf = cands[c0 + i].first; best_sim = sims[i]; }
+                    else if (gain < best_total - 300.0) past = true;   // past the optimum: the launch is swallowing throughput-bound levels
+                }
+            }
+            if (!err.empty()) return err;
             if (best_gf == g1) continue;
+            { double sim = 0.0; const std::string e = make_flow_units(best_gf, g1, best_units, &sim); if (!e.empty()) return e; }
         }
         flow_g0_[ph] = best_gf;
         flow_n_[ph] = (int)best_units.size();
@@ -859,6 +882,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         TP_TRY(upload(&flow_ctr_, ctr));
         if (!dry_run_) { int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) flow_cus_ = cus; }
     }
+    ptr_trace.mark("plan: task lists, dataflow units");
     potrf_h_ = potrf; trsm_h_ = trsm; upd_h_ = upd; flow_units_h_ = funits;   // (kept for check_schedule / the tools: small)
     TP_TRY(upload(&flow_units_, funits));
     if (flow_ver_ && !dry_run_) { (void)hipFree(flow_ver_); flow_ver_ = nullptr; }
@@ -926,6 +950,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     }
     TP_TRY(hipMalloc(&gate_cnt_, (size_t)(n_levels_ + 1) * sizeof(int)));
     TP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on the stream
+    ptr_trace.mark("plan: uploads, streams, events");
 #undef TP_TRY
     return "";
 }
