@@ -316,6 +316,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "device_gathers") h->s->set_device_gathers(value != 0);
     else if (n == "implicit_cam_records") h->s->set_implicit_cam_records(value != 0);
     else if (n == "cam_beside_pairs") h->s->set_cam_beside_pairs(value != 0);
+    else if (n == "zero_beside_lm") h->s->set_zero_beside_lm(value != 0);
     else if (n == "one_wait") h->s->set_one_wait(value != 0);
     else if (n == "max_tile_updates") h->s->set_max_tile_updates(value);
     else if (n == "factor_flow") h->s->set_factor_flow(value, 0);          // max columns per level group inside the dataflow launch (0: off)

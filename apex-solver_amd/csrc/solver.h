@@ -119,6 +119,7 @@ class Solver : public LmBackend {
     void set_device_gathers(bool on) { device_gathers_ = on; }
     void set_implicit_cam_records(bool on) { cam_records_ = on; }
     void set_cam_beside_pairs(bool on) { cam_beside_ = on; }
+    void set_zero_beside_lm(bool on) { zero_beside_lm_ = on; }
     void set_one_wait(bool on) { one_wait_ = on; }
     void set_device_pair_recs(bool on) { device_pair_recs_ = on; }   // before set_structure ("device_pair_list")
     int get_pair_records(uint32_t* recs4_out, int64_t cap_slots);     // tests: the pair records as they sit on the device
@@ -248,6 +249,7 @@ class Solver : public LmBackend {
     // "cam_beside_pairs": k_cam_reduce (the diagonal blocks of S, g_c, g_red) on zero_stream_ beside the pair kernel (every other
     // block of S): disjoint outputs, both read what k_landmark_reduce wrote
     bool cam_beside_ = false;
+    bool zero_beside_lm_ = false;   // "zero_beside_lm": the tile clears on the side stream beside k_landmark_reduce
     hipEvent_t cam_ev_[2] = {nullptr, nullptr};
     // "eager_step_eval" (round 5): what the LM loop asks next of every solve -- the step statistics (apexgpu_step_stats) and the
     // trial point with its cost (apexgpu_eval_step) -- is enqueued behind the back-substitution and read at the solve's own wait:

@@ -671,9 +671,20 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     stage_begin(kStAssembleCam);
     // (a tree-sharded rank that assembles for its distributed factorisation adds to its own and the top tiles only; every
     // other use of S -- PCG, exports, the ladder's diagonal -- all-reduces every touched tile and needs them all cleared)
+    // "zero_beside_lm" (round 5): the 1.34 GB of tile clears run on the side stream BESIDE k_landmark_reduce -- which touches no
+    // tile and is bound by the latency of its dependent loads (3 TB/s), not by HBM -- instead of in front of it
+    const bool zero_beside = zero_beside_lm_ && !tiles_prezeroed_ && world_ == 1;
     if (tiles_prezeroed_) {   // cleared on the side stream behind the previous solve (solve_augmented)
         tiles_prezeroed_ = false;
         HIP_TRY(hipStreamWaitEvent(stream_, zero_ev_, 0));
+    } else if (zero_beside) {
+        if (!zero_stream_) HIP_TRY(hipStreamCreateWithFlags(&zero_stream_, hipStreamNonBlocking));
+        if (!zero_ev_) HIP_TRY(hipEventCreateWithFlags(&zero_ev_, hipEventDisableTiming));
+        for (hipEvent_t& e : cam_ev_) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(cam_ev_[0], stream_));            // (whatever used the tiles before is behind this point)
+        HIP_TRY(hipStreamWaitEvent(zero_stream_, cam_ev_[0], 0));
+        HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor, zero_stream_));
+        HIP_TRY(hipEventRecord(zero_ev_, zero_stream_));
     } else {
         HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor));
     }
@@ -682,7 +693,7 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
     // identity on the padding rows of the last tile (rank 0 only: the all-reduce sums the ranks)
     // (tree sharding: by the owner of the last tile column, whose tiles are never summed -- pad_rank_)
-    tp_.add_diag((int)n_c_, 0.0, rank_ == pad_rank_ ? 1.0 : 0.0);
+    if (!zero_beside) tp_.add_diag((int)n_c_, 0.0, rank_ == pad_rank_ ? 1.0 : 0.0);
     stage_end(kStAssembleCam);
     stage_begin(kStAssembleLm);
     const bool rec_form = rows_form_ == 3 || rows_form_ == 4;   // the pair kernel reads the projection records (allocated with the form: set_structure)
@@ -690,6 +701,12 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_, want_rec ? orec_ : nullptr);
     orec_fresh_ = want_rec; corec_fresh_ = false;
     stage_end(kStAssembleLm);
+    if (zero_beside) {
+        stage_begin(kStAssembleCam);
+        HIP_TRY(hipStreamWaitEvent(stream_, zero_ev_, 0));
+        tp_.add_diag((int)n_c_, 0.0, rank_ == pad_rank_ ? 1.0 : 0.0);
+        stage_end(kStAssembleCam);
+    }
     const bool beside = cam_beside_ && rec_form && world_ == 1;
     hipStream_t cam_stream = stream_;
     if (beside) {
