@@ -140,6 +140,9 @@ impl GpuSchurComplementSolver {
             // tiles exist and no pair list is built, so set-up and iteration do not depend on the fill of S (round 4)
             check(h, unsafe { apexgpu_set_option(h, b"matrix_free_only\0".as_ptr() as *const c_char, 1) })?;
         }
+        // This binding is level 1: step statistics, retraction and trial cost stay with the reference's
+        // LM loop on the host, so the solve need not enqueue them (the backend does by default for its level-2 callers).
+        check(h, unsafe { apexgpu_set_option(h, b"eager_step_eval\0".as_ptr() as *const c_char, 0) })?;
         check(h, unsafe { apexgpu_set_structure(h, cam_idx.as_ptr(), pt_idx.as_ptr(), uv.as_ptr(), intr_col.as_ptr(), pose_col.as_ptr(),
                                                  pt_col.as_ptr(), fix_pose.as_ptr(), fix_intr.as_ptr(), fix_pt.as_ptr(), huber.unwrap_or(-1.0)) })?;
         check(h, unsafe { apexgpu_set_cg_params(h, self.cg.0, self.cg.1) })?;
