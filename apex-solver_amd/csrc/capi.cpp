@@ -288,7 +288,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
     // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
     static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "panel_tri", "panel_small_max", "update_small_max", "dist_factor", "tree_sharding", "dist_selftest",
-                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "panel_split", "fwd_beside_top", "tri_inline", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "factor_flow_tile", "factor_flow_dyn", "device_pair_list", "device_gathers", "landmark_bundles", "pairs_queued6", "matrix_free_only", "auto_variant", "max_tile_updates"};
+                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "panel_split", "fwd_beside_top", "tri_inline", "first_writer", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "factor_flow_tile", "factor_flow_dyn", "device_pair_list", "device_gathers", "landmark_bundles", "pairs_queued6", "matrix_free_only", "auto_variant", "max_tile_updates"};
     if (h->s->has_structure())
         for (const char* k : structural)
             if (n == k) return APEXGPU_ERR_INVALID_STATE;
@@ -303,6 +303,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "panel_split") h->s->set_panel_split(value);
     else if (n == "fwd_beside_top") h->s->set_fwd_beside_top(value != 0);
     else if (n == "tri_inline") h->s->set_tri_inline(value);
+    else if (n == "first_writer") h->s->set_first_writer(value != 0);
     else if (n == "flood_gate") h->s->set_gate_min(value);
     else if (n == "flood_gate_pos") h->s->set_gate_pos(value);
     else if (n == "two_side") h->s->set_two_side(value);
@@ -683,6 +684,7 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     else if (n == "panel_split") h->s->set_panel_split(value);
     else if (n == "fwd_beside_top") h->s->set_fwd_beside_top(value != 0);
     else if (n == "tri_inline") h->s->set_tri_inline(value);
+    else if (n == "first_writer") h->s->set_first_writer(value != 0);
     else if (n == "one_wait") h->s->set_one_wait(value != 0);
     else if (n == "eager_step_eval") h->s->set_eager_step_eval(value != 0);
     else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);

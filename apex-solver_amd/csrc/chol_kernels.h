@@ -19,6 +19,7 @@ struct PotrfTask {  // one diagonal tile: factor in place, inverse of the factor
     int K;
 };
 
+constexpr int kFlowFirstWriter = 16;   // FactorUnit::kind bit: the unit is the FIRST writer of a fill tile (nothing is read from the target)
 constexpr int kFlowUnitsPerTile = 9;   // units per panel solve / update; the weight of a potrf in the version counters
 struct FactorUnit {   // one workgroup of the dataflow factorisation of the top of the elimination tree (k_factor_flow)
     double* C;            // potrf: the diagonal tile (factorised in place); product: the target tile

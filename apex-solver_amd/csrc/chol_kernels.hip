@@ -909,7 +909,11 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
     const int per_xcd = (n_units + 7) >> 3;
     const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
-    const GemmTask tg = tasks[unit / NSTRIP];
+    GemmTask tg = tasks[unit / NSTRIP];
+    // Bit 0 of C (round 5, TilePlan::build): this task is the FIRST writer of a fill tile -- the tile holds nothing yet, it is
+    // not cleared before the factorisation and not read here (beta = 0; "+ 0.0" keeps the bits of the sum with a cleared tile)
+    const bool first = (reinterpret_cast<uintptr_t>(tg.C) & 1) != 0;
+    tg.C = reinterpret_cast<double*>(reinterpret_cast<uintptr_t>(tg.C) & ~uintptr_t(7));
     // The task's pointers are loaded from memory, so the compiler only knows them as generic (flat)
     // addresses; flat loads count on lgkmcnt as well as vmcnt, which makes every wait for an LDS read also
     // wait for the global prefetch of the next chunk.  Re-typed as global (address space 1) they become
@@ -980,11 +984,12 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
     // loads across possibly aliasing stores -- and holding all 36 values costs 72 VGPRs, i.e. a
     // wave per SIMD of occupancy; 4 at a time measured best: tools/gemm_var.hip.)
     GlobalF64 C = t.C + (size_t)strip * STRIP * NB;
-    if (beta == 0.0) {
+    if (beta == 0.0 || first) {
+        const double zero = first ? 0.0 : -0.0;   // (x + -0.0 == x bit for bit: the panel solves' stores are unchanged)
 #pragma unroll
         for (int j = 0; j < 9; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) C[(size_t)(16 * (j / 3) + lk + 4 * r) * NB + cb[j % 3] + lr] = alpha * acc[j][r];
+            for (int r = 0; r < 4; ++r) C[(size_t)(16 * (j / 3) + lk + 4 * r) * NB + cb[j % 3] + lr] = alpha * acc[j][r] + zero;
         return;
     }
     // software-pipelined read-modify-write: the loads of column block j+2 are in flight while block j
@@ -1022,7 +1027,10 @@ __global__ __launch_bounds__(192) void k_tile_gemm_nt_small(const GemmTask* __re
     __shared__ double sB[48 * PS];
     const int unit = blockIdx.x;
     if (unit >= n_units) return;
-    const GemmTask tg = tasks[unit / 9];
+    GemmTask tg = tasks[unit / 9];
+    const bool first = (reinterpret_cast<uintptr_t>(tg.C) & 1) != 0;   // first writer of a fill tile (k_tile_gemm_nt)
+    tg.C = reinterpret_cast<double*>(reinterpret_cast<uintptr_t>(tg.C) & ~uintptr_t(7));
+    if (first) beta = 0.0;
     const int blk = unit % 9, bi = blk / 3, bj = blk % 3;
     GlobalCF64 Ag = (GlobalCF64)tg.A + (size_t)bi * 48 * NB;
     GlobalCF64 Bg = (GlobalCF64)tg.B + (size_t)bj * 48 * NB;
@@ -1080,7 +1088,7 @@ __global__ __launch_bounds__(192) void k_tile_gemm_nt_small(const GemmTask* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double v = alpha * acc[j][r];
-            C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = (beta != 0.0) ? v + beta * cv[j][r] : v;
+            C[(size_t)(16 * w + lk + 4 * r) * NB + 16 * j + lr] = (beta != 0.0) ? v + beta * cv[j][r] : (first ? v + 0.0 : v);
         }
 }
 
@@ -1576,7 +1584,7 @@ __device__ __forceinline__ void flow_update_unit(const FactorUnit& u, double* __
     if (trace && tid == 0) trace[1] = wall_clock64();
     const bool act = tid < 576;   // (the workgroup has 12 waves for the potrf units' sake: nine of them work here)
     double cv[4] = {0.0, 0.0, 0.0, 0.0};   // the old values of the block: requested with the operands, consumed last
-    if (act) {
+    if (act && !(u.kind & kFlowFirstWriter)) {   // (the first writer of a fill tile: nothing there yet, nothing read)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cv[r] = coh_ld1(rC, (48 * bi + 16 * wr + lk + 4 * r) * NB + 48 * bj + 16 * wc + lr);
     }
@@ -1715,11 +1723,12 @@ __device__ __forceinline__ void flow_update_tile_unit(const FactorUnit& u, doubl
         if (c + 1 < NCH) {
             load_chunk(c + 1);
         } else {   // the old values of the target: requested now, consumed behind the last MFMAs
+            const bool first = (u.kind & kFlowFirstWriter) != 0;   // (the first writer of a fill tile: nothing there yet)
 #pragma unroll
             for (int q = 0; q < NBW; ++q) {
                 const int b = min(b0 + q, 80), br = b / 9, bc = b - 9 * br;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cv[q][r] = coh_ld1(rC, (16 * br + lk + 4 * r) * NB + 16 * bc + lr);
+                for (int r = 0; r < 4; ++r) cv[q][r] = first ? 0.0 : coh_ld1(rC, (16 * br + lk + 4 * r) * NB + 16 * bc + lr);
             }
         }
         __syncthreads();
@@ -1762,16 +1771,17 @@ __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const Factor
         trace += 3 * (size_t)blockIdx.x;
         if (tid == 0) trace[0] = wall_clock64();
     }
-    if (u.kind == 0) {
+    const int kind = u.kind & 15;
+    if (kind == 0) {
         flow_wait_unit(ver, u, tid, err);
         if (trace && tid == 0) trace[1] = wall_clock64();
         potrf_tile_mf<kFlowFactorThreads / 64, true>(u.C, const_cast<double*>(u.A), u.strip, fail, smem, smem + NLB * BSZ, &bad, &sync_cnt);
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ver + u.pub, kFlowUnitsPerTile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (u.kind == 1) {
+    } else if (kind == 1) {
         flow_solve_unit<false>(u, smem, smem + 16 * PS, ver, err, trace);
-    } else if (u.kind == 3) {
+    } else if (kind == 3) {
         flow_update_tile_unit<false>(u, smem, smem + NB * PS, ver, err, trace);
     } else {
         flow_update_unit<false>(u, smem, smem + 48 * kFlowPK, ver, err, trace);
@@ -1855,15 +1865,15 @@ __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow_dyn(const Fa
         const FactorUnit u = units[idx];
         unsigned long long* trace = trace0 ? trace0 + 3 * (size_t)idx : nullptr;
         if (trace && tid == 0) { trace[0] = wall_clock64(); trace[1] = trace[0]; }
-        if (u.kind == 0) dyn_unit_potrf(units + idx, fail, smem, &bad, &sync_cnt);
-        else if (u.kind == 1) dyn_unit_solve(units + idx, smem, trace);
-        else if (u.kind == 3) dyn_unit_update_tile(units + idx, smem, trace);
+        if ((u.kind & 15) == 0) dyn_unit_potrf(units + idx, fail, smem, &bad, &sync_cnt);
+        else if ((u.kind & 15) == 1) dyn_unit_solve(units + idx, smem, trace);
+        else if ((u.kind & 15) == 3) dyn_unit_update_tile(units + idx, smem, trace);
         else dyn_unit_update(units + idx, smem, trace);
         // ---- finish: publish, and wake whoever waited for the writer this unit completes --------------------------------------
         __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
         __syncthreads();                 // ... every wave's; also: all reads of smem and s_idx are done
         if (tid == 0) {
-            const int inc = (u.kind == 0 || u.kind == 3) ? kFlowUnitsPerTile : 1;
+            const int inc = ((u.kind & 15) == 0 || (u.kind & 15) == 3) ? kFlowUnitsPerTile : 1;
             const int old = __hip_atomic_fetch_add(ver + u.pub, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int m = (old + inc) / kFlowUnitsPerTile;
             s_node = (old >= 0 && m > old / kFlowUnitsPerTile) ? u.pad + m - 1 : -1;

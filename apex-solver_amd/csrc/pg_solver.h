@@ -64,6 +64,7 @@ class PoseGraphSolver : public LmBackend {
     void set_eager_step_eval(bool on) { eager_eval_ = on; }
     void set_fwd_beside_top(bool on) { tp_.set_fwd_beside_top(on); }
     void set_tri_inline(int max_cols) { tp_.set_tri_inline(max_cols); }
+    void set_first_writer(bool on) { tp_.set_first_writer(on); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
     void set_two_side(int mode) { tp_.set_two_side(mode); }

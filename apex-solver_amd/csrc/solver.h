@@ -99,6 +99,7 @@ class Solver : public LmBackend {
     void set_panel_split(int min_rest) { tp_.set_panel_split(min_rest); }
     void set_fwd_beside_top(bool on) { tp_.set_fwd_beside_top(on); }
     void set_tri_inline(int max_cols) { tp_.set_tri_inline(max_cols); }
+    void set_first_writer(bool on) { tp_.set_first_writer(on); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
     void set_gate_pos(int p) { tp_.set_gate_pos(p); }

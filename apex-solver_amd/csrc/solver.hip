@@ -683,10 +683,10 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
         for (hipEvent_t& e : cam_ev_) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(cam_ev_[0], stream_));            // (whatever used the tiles before is behind this point)
         HIP_TRY(hipStreamWaitEvent(zero_stream_, cam_ev_[0], 0));
-        HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor, zero_stream_));
+        HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor, zero_stream_, for_factor && world_ == 1));
         HIP_TRY(hipEventRecord(zero_ev_, zero_stream_));
     } else {
-        HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor));
+        HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor, nullptr, for_factor && world_ == 1));   // (the fill tiles stay as they are: tile_plan.h, first_writer_)
     }
     HIP_TRY(hipMemsetAsync(g_red_, 0, n_c_pad_ * sizeof(double), stream_));
     HIP_TRY(hipMemsetAsync(g_c_, 0, n_c_pad_ * sizeof(double), stream_));

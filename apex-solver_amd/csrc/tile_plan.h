@@ -169,7 +169,11 @@ class TilePlan {
 
     // async on the plan's stream.  own_touched_only: (distributed plans) this rank adds to the tiles of its own columns and
     // of the shared top only -- tree-sharded landmarks; the other ranks' tiles are then left alone
-    hipError_t zero_tiles(bool own_touched_only = false, hipStream_t on = nullptr /* nullptr: the plan's stream */);
+    // skip_fill (round 5): the assembly is for the Cholesky factorisation of a single-GPU plan whose first writers are flagged
+    // (first_writers_flagged()): the fill tiles are not cleared -- their first update does not read them
+    hipError_t zero_tiles(bool own_touched_only = false, hipStream_t on = nullptr /* nullptr: the plan's stream */, bool skip_fill = false);
+    bool first_writers_flagged() const { return first_ok_; }
+    void set_first_writer(bool on) { first_writer_ = on; }   // before build()
     void add_diag(int n_valid, double add_valid, double pad_value);  // diagonal += / padding rows := value
     void diag(double* out) const;                        // out[n_pad] = diagonal
     void scale_sym(const double* scale);                 // A := D A D on the unfactored tiles, D = diag(scale[n_pad])
@@ -306,6 +310,10 @@ class TilePlan {
     // the sweep part takes from the dataflow launch what it saves (its units read their operands past the L2, from the same
     // HBM).  Zero sum: off.
     bool fwd_beside_top_ = false, lower_fwd_now_ = false;
+    // The FIRST update of every fill tile (a tile of L that is structurally zero in S) is flagged -- bit 0 of GemmTask::C in the
+    // level lists, kFlowFirstWriter in the dataflow units -- and does not read its target (beta = 0): the 0.63 GB of fill tiles
+    // of final-13682 are then neither cleared before a factorisation nor read by those updates (round 5).
+    bool first_writer_ = true, first_ok_ = false;
     int tri_inline_ = 8;       // (swept 0 / 4 / 8 / 16 / 32 / all: profiles/r05_sweep_tri_inline.txt) the dataflow sweeps: in levels of at most this many columns a block's solve task forms its last-arriving product itself (FlowTask::mat2)
     std::vector<int> lv_flow_fwd_;            // [level]: first forward dataflow task of the level (plans that are not distributed)
     const double* fwd_lower_rhs_ = nullptr;   // right-hand side whose lower forward part the last factor() carried

@@ -882,6 +882,43 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         TP_TRY(upload(&flow_ctr_, ctr));
         if (!dry_run_) { int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) flow_cus_ = cus; }
     }
+    // ---- first writers of the fill tiles (tile_plan.h, first_writer_) ---------------------------------------------------------
+    // Two execution orders exist: the level launches alone (the lists of every level, in list order) and the level launches of
+    // the levels below a dataflow launch followed by its units (in unit order: the writers of a tile are chained in that order).
+    // A fill tile's first writer is flagged in both; touched tiles hold S and are never "first written".
+    first_ok_ = false;
+    if (first_writer_ && !distributed() && n_slots_ > n_touched_ && flow_n_[1] == 0) {
+        const size_t te = tile_elems;
+        auto slot_of_ptr = [&](const double* c) { return (int64_t)((c - tiles_) / (ptrdiff_t)te); };
+        std::vector<char> seen_a((size_t)n_slots_, 0);
+        for (int64_t sl = 0; sl < n_touched_; ++sl) seen_a[(size_t)sl] = 1;
+        std::vector<char> seen_b(seen_a);
+        int64_t upd_before_flow = (int64_t)upd.size();   // the level lists that run in front of the dataflow launch
+        if (flow_n_[0] > 0) {
+            const int r = lv_upd_round_[(size_t)flow_g0_[0]];
+            if (r < (int)upd_rounds_.size()) upd_before_flow = upd_rounds_[(size_t)r].first;
+        }
+        for (size_t q = 0; q < upd.size(); ++q) {
+            const int64_t sl = slot_of_ptr(upd[q].C);
+            if ((int64_t)q < upd_before_flow) seen_b[(size_t)sl] = 1;
+            if (!seen_a[(size_t)sl]) { seen_a[(size_t)sl] = 1; upd[q].C = reinterpret_cast<double*>(reinterpret_cast<uintptr_t>(upd[q].C) | 1); }
+        }
+        // the dataflow units: the first (tile, writer) of a tile not written below the launch; its nine block units share C, A, B
+        std::vector<const double*> first_a((size_t)n_slots_, nullptr), first_b((size_t)n_slots_, nullptr);
+        for (FactorUnit& u : funits) {
+            if (u.kind != 2 && u.kind != 3) continue;
+            const int64_t sl = slot_of_ptr(u.C);
+            if (!seen_b[(size_t)sl]) { seen_b[(size_t)sl] = 1; first_a[(size_t)sl] = u.A; first_b[(size_t)sl] = u.B; }
+            if (first_a[(size_t)sl] == u.A && first_b[(size_t)sl] == u.B && first_a[(size_t)sl] != nullptr) u.kind |= kFlowFirstWriter;
+        }
+        bool all = true;
+        for (int64_t sl = n_touched_; sl < n_slots_; ++sl) all = all && seen_a[(size_t)sl] && (flow_n_[0] == 0 || seen_b[(size_t)sl]);
+        if (all) first_ok_ = true;
+        else {   // (a fill tile without an update: cannot be -- take the flags back and clear everything as before)
+            for (GemmTask& t : upd) t.C = reinterpret_cast<double*>(reinterpret_cast<uintptr_t>(t.C) & ~uintptr_t(7));
+            for (FactorUnit& u : funits) u.kind &= 15;
+        }
+    }
     ptr_trace.mark("plan: task lists, dataflow units");
     potrf_h_ = potrf; trsm_h_ = trsm; upd_h_ = upd; flow_units_h_ = funits;   // (kept for check_schedule / the tools: small)
     TP_TRY(upload(&flow_units_, funits));
@@ -955,7 +992,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     return "";
 }
 
-hipError_t TilePlan::zero_tiles(bool own_touched_only, hipStream_t on) {
+hipError_t TilePlan::zero_tiles(bool own_touched_only, hipStream_t on, bool skip_fill) {
     const hipStream_t zs = on ? on : stream_;
     fwd_rhs_ = nullptr; fwd_lower_rhs_ = nullptr;
     const size_t te = (size_t)kNB * kNB * sizeof(double);
@@ -971,7 +1008,7 @@ hipError_t TilePlan::zero_tiles(bool own_touched_only, hipStream_t on) {
         clear(own_fill_[part_rank_].first, own_fill_[part_rank_].second);
         clear(n_f_nt_, n_slots_ - n_f_nt_);
     } else {
-        clear(0, n_slots_);
+        clear(0, (skip_fill && first_ok_) ? n_touched_ : n_slots_);
     }
     if (e != hipSuccess) return e;
     return hipMemsetAsync(flag_, 0, 4 * sizeof(int), zs);
@@ -1370,11 +1407,11 @@ int TilePlan::check_schedule(const std::vector<SchedOp>& ops, std::string* first
             for (int64_t q = o.first; q < o.first + o.count; ++q) {
                 if (o.list == 0) { touch(potrf_h_[(size_t)q].A, true); touch(potrf_h_[(size_t)q].Linv, true); }
                 else if (o.list == 1) { touch(trsm_h_[(size_t)q].C, true); touch(trsm_h_[(size_t)q].B, false); }
-                else if (o.list == 2) { touch(upd_h_[(size_t)q].C, true); touch(upd_h_[(size_t)q].A, false); touch(upd_h_[(size_t)q].B, false); }
+                else if (o.list == 2) { touch(reinterpret_cast<const double*>(reinterpret_cast<uintptr_t>(upd_h_[(size_t)q].C) & ~uintptr_t(7)), true); touch(upd_h_[(size_t)q].A, false); touch(upd_h_[(size_t)q].B, false); }
                 else {   // the dataflow launch orders its own units (version counters): one writer of everything it touches
                     const FactorUnit& u = flow_units_h_[(size_t)q];
                     touch(u.C, true);
-                    if (u.kind == 0) touch(u.A, true);
+                    if ((u.kind & 15) == 0) touch(u.A, true);
                 }
             }
             if (o.list != 3) {

@@ -266,6 +266,9 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "panel_split" (0)  before set_structure; n > 0: panel lookahead -- the panel solves of a level in two launches when at least
  *                     n tiles are not critical: those whose rows belong to the next level (all that its potrf waits for) first,
  *                     the others on a stream of their own.  Race free, bit-identical, measured no gain (round 5): off
+ *   "first_writer" (1)  before set_structure: the first update of every fill tile is flagged in the plan and does not read its
+ *                     target, and the fill tiles are not cleared before a factorisation (0: every tile cleared, every update
+ *                     reads its target, as until round 4).  Bit-identical; final-13682 -0.16 ms per LM iteration
  *   "tri_inline" (8)  before set_structure: in the levels of at most this many tile columns the solve task of a block of the
  *                     dataflow sweeps forms the product of its last-arriving source itself (the link of the dependency chain:
  *                     one flag hop and one trip through memory less per level); 0 = every product is a task of its own.

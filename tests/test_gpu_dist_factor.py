@@ -212,7 +212,10 @@ def test_factorisation_schedule_switches_agree():
                  # round 5: the panel lookahead off / on every level that has both kinds of panel tiles (default: rest >= 96 tiles)
                  {"panel_split": 0}, {"panel_split": 1}, {"panel_split": 1, "factor_flow": 0},
                  # the forward sweep as one launch behind the factorisation / its lower part beside the dataflow launch of the top
-                 {"fwd_beside_top": 0}, {"fwd_beside_top": 1, "factor_flow": 64}, {"fwd_beside_top": 1, "one_wait": 0}):
+                 {"fwd_beside_top": 0}, {"fwd_beside_top": 1, "factor_flow": 64}, {"fwd_beside_top": 1, "one_wait": 0},
+                 # the fill tiles cleared and read by their first update as until round 4 / neither (the default), by level launches
+                 # alone and with the dataflow launch of the top
+                 {"first_writer": 0}, {"first_writer": 0, "factor_flow": 0}, {"first_writer": 1, "factor_flow": 0}, {"first_writer": 1, "factor_flow": 64}):
         (a, b), _ = step(opts)
         # Bit for bit (round 4): with the queued pair layout S is assembled without atomics on this shape (no block longer than
         # a piece, no camera that sees a landmark twice), every schedule adds a tile's updates in the same order, the dataflow

@@ -90,18 +90,18 @@ int main(int argc, char** argv) {
             // the next diagonal tile -> potrf K+1.  Per group of nine: last dispatch | first ready .. last ready | last done
             printf("  potrf: dispatched ready done | panel (K+1,K): disp<= ready[first..last] done<= | update (K+1,K+1)<-K: disp<= ready[first..last] done<=\n");
             std::vector<size_t> potrfs;
-            for (size_t i = 0; i < u.size(); ++i) if (u[i].kind == 0) potrfs.push_back(i);
+            for (size_t i = 0; i < u.size(); ++i) if ((u[i].kind & 15) == 0) potrfs.push_back(i);
             for (size_t p = 0; p < potrfs.size(); ++p) {
                 const size_t i = potrfs[p];
                 double g[2][4] = {{-1, 1e18, -1, -1}, {-1, 1e18, -1, -1}};   // [panel | update][last dispatch, first ready, last ready, last done]
                 if (p + 1 < potrfs.size()) {
                     const size_t nx = potrfs[p + 1];
                     const double* below = nullptr;
-                    for (size_t q = i + 1; q < u.size() && !below; ++q) if (u[q].kind == 1) below = u[q].C;   // first panel tile of column K
+                    for (size_t q = i + 1; q < u.size() && !below; ++q) if ((u[q].kind & 15) == 1) below = u[q].C;   // first panel tile of column K
                     for (size_t q = 0; q < u.size(); ++q) {
                         int which = -1;
-                        if (u[q].kind == 1 && u[q].C == below) which = 0;
-                        if (u[q].kind == 2 && u[q].C == u[nx].C && u[q].A == below) which = 1;
+                        if ((u[q].kind & 15) == 1 && u[q].C == below) which = 0;
+                        if ((u[q].kind & 15) == 2 && u[q].C == u[nx].C && u[q].A == below) which = 1;
                         if (which < 0) continue;
                         g[which][0] = std::max(g[which][0], us(s[3 * q])); g[which][1] = std::min(g[which][1], us(s[3 * q + 1]));
                         g[which][2] = std::max(g[which][2], us(s[3 * q + 1])); g[which][3] = std::max(g[which][3], us(s[3 * q + 2]));
