@@ -98,6 +98,7 @@ void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv
 // A18 (implicit_schur.rs): y = S x matrix-free, the Schur-Jacobi preconditioner blocks and their application
 void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
                             double lambda, double* y, hipStream_t s, const double* orec = nullptr, const double* corec = nullptr);
+void launch_clear3(double* a, double* b, int64_t n, int* f, int nf, hipStream_t s);   // a[0..n) = b[0..n) = 0, f[0..nf) = 0: one launch
 void launch_gather_uv(int64_t n, const int* idx, const double* src, double* dst, hipStream_t s);          // dst[k] = src[idx[k]] (double2)
 void launch_gather_u32(int64_t n, const int* idx, const uint32_t* src, uint32_t* dst, hipStream_t s);
 void launch_gather_records(int64_t n_obs, const int* cam_obs, const double* orec, double* corec, hipStream_t s);

@@ -1216,6 +1216,14 @@ __global__ __launch_bounds__(256) void k_gather_records(int64_t n, const int* __
     const double2 a = orec[2 * i], b2 = orec[2 * i + 1];
     corec[2 * (size_t)k] = a; corec[2 * (size_t)k + 1] = b2;
 }
+// the three clears at the head of an assembly (g_red, g_c, the error flags) as one launch
+__global__ __launch_bounds__(256) void k_clear3(double* __restrict__ a, double* __restrict__ b, int64_t n, int* __restrict__ f, int nf) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { a[i] = 0.0; b[i] = 0.0; }
+    if (blockIdx.x == 0 && (int)threadIdx.x < nf) f[threadIdx.x] = 0;
+}
+void launch_clear3(double* a, double* b, int64_t n, int* f, int nf, hipStream_t s) {
+    hipLaunchKernelGGL(k_clear3, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (n + 1023) / 1024))), dim3(256), 0, s, a, b, n, f, nf);
+}
 // set-up (round 5): the measurement lists from the caller's array, on the device -- o_uv[i] = uv[o_orig[i]] (landmark-major),
 // then co_uv[k] = o_uv[cam_obs[k]], co_pt[k] = o_pt[cam_obs[k]] (camera-major): 0.6 GB less to build on the host and to upload
 __global__ __launch_bounds__(256) void k_gather_uv(int64_t n, const int* __restrict__ idx, const double2* __restrict__ src, double2* __restrict__ dst) {

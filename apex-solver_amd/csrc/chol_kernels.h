@@ -87,6 +87,8 @@ void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, bool tri_b = false);
 // poison_block >= 0 (tests only): that block's counter is made unreachable after the flags are cleared, so the task that
 // waits for it runs into the spin limit -- the time-out path (error word raised, wrong result) on demand
+void launch_clear_i32(int* p, int64_t n, hipStream_t s);                   // a small clear as ONE kernel (chol_kernels.hip)
+void launch_post_word(int* word, int* host_word_dev, hipStream_t s);       // *host = *word, *word = 0 when *word != 0
 void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const double* in, double* out, double* part, int* flags,
                      int nt, hipStream_t s, const double* fold_b, double* fold_out, int poison_block = -1, bool keep_flags = false);   // keep_flags: the second part of a sweep launched in two (the counters of the first part stand)
 // tests only: n workgroups that each take a whole CU's LDS (nothing else that needs LDS fits beside them) and spin for

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "chol_kernels.h"
+#include <algorithm>
 
 namespace apex {
 
@@ -2283,10 +2284,27 @@ void launch_occupy_cus(int n, int micros, int* started, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_occupy_cu, dim3(n), dim3(256), 0, s, (long long)micros * 100, started);
 }
 
+// Small clears as ONE kernel each (round 5): a hipMemsetAsync of a few hundred bytes becomes one or two fill kernels of 5-15 us
+// (12.6 + 14.6 us for the 168 bytes of gate counters in front of every factorisation, measured in the kernel trace); there were
+// fourteen of them per LM iteration, all on the critical path.
+__global__ __launch_bounds__(256) void k_clear_i32(int* __restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
+}
+void launch_clear_i32(int* p, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_clear_i32, dim3((unsigned)std::min<int64_t>(64, (n + 255) / 256)), dim3(256), 0, s, p, n);
+}
+// the sweeps' error word to pinned host memory (through its device address) and cleared, in one launch; nothing to do = no store
+__global__ void k_post_word(int* __restrict__ word, int* __restrict__ host_word) {
+    const int v = word[0];
+    if (v != 0) { host_word[0] = v; word[0] = 0; }
+}
+void launch_post_word(int* word, int* host_word_dev, hipStream_t s) { hipLaunchKernelGGL(k_post_word, dim3(1), dim3(1), 0, s, word, host_word_dev); }
+
 void launch_tri_flow(bool backward, const FlowTask* tasks, int n_tasks, const double* in, double* out, double* part, int* flags,
                      int nt, hipStream_t s, const double* fold_b, double* fold_out, int poison_block, bool keep_flags) {
     if (n_tasks <= 0) return;
-    if (!keep_flags) (void)hipMemsetAsync(flags, 0, (size_t)2 * nt * sizeof(int), s);   // cnt[nt] | done[nt]
+    if (!keep_flags) launch_clear_i32(flags, (int64_t)2 * nt, s);   // cnt[nt] | done[nt]
     if (poison_block >= 0 && poison_block < nt)   // tests: INT_MIN never reaches the count the block's solve task waits for
         (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flags + poison_block), (int)0x80000000, 1, s);
     int* err = flags + 2 * nt;   // (not cleared here: sticky until the plan posts it to the host, TilePlan::solve)

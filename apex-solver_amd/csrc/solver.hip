@@ -688,9 +688,7 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     } else {
         HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor, nullptr, for_factor && world_ == 1));   // (the fill tiles stay as they are: tile_plan.h, first_writer_)
     }
-    HIP_TRY(hipMemsetAsync(g_red_, 0, n_c_pad_ * sizeof(double), stream_));
-    HIP_TRY(hipMemsetAsync(g_c_, 0, n_c_pad_ * sizeof(double), stream_));
-    HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
+    launch_clear3(g_red_, g_c_, n_c_pad_, flags_, 4, stream_);   // (one launch instead of three fills)
     // identity on the padding rows of the last tile (rank 0 only: the all-reduce sums the ranks)
     // (tree sharding: by the owner of the last tile column, whose tiles are never summed -- pad_rank_)
     if (!zero_beside) tp_.add_diag((int)n_c_, 0.0, rank_ == pad_rank_ ? 1.0 : 0.0);

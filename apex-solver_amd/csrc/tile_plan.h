@@ -253,6 +253,7 @@ class TilePlan {
     int* flow_flags_ = nullptr;                            // cnt[nt] | done[nt] | error word
     double* pcg_host_ = nullptr;                           // pinned: two slots of PCG scalars (pcg(): read one iteration behind)
     hipEvent_t pcg_ev_[2] = {nullptr, nullptr};
+    int* flow_err_host_dev_ = nullptr;                     // the device address of flow_err_host_ (mapped pinned memory)
     int* flow_err_host_ = nullptr;                         // pinned: [0] the error word behind the last solve(), [1..2] debug_occupy_cus
     int n_sweep_timeouts_ = 0;
     int poison_ = 0;

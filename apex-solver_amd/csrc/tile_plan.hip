@@ -122,7 +122,7 @@ void TilePlan::release() {
         graph_failed_[i] = false;
     }
     fwd_rhs_ = nullptr;
-    if (flow_err_host_) { (void)hipHostFree(flow_err_host_); flow_err_host_ = nullptr; }
+    if (flow_err_host_) { (void)hipHostFree(flow_err_host_); flow_err_host_ = nullptr; flow_err_host_dev_ = nullptr; }
     if (pcg_host_) { (void)hipHostFree(pcg_host_); pcg_host_ = nullptr; for (hipEvent_t& ev : pcg_ev_) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; } }
     if (occ_stream_) { (void)hipStreamSynchronize(occ_stream_); (void)hipStreamDestroy(occ_stream_); occ_stream_ = nullptr; }
     if (ev_fwd_) { (void)hipEventDestroy(ev_fwd_); ev_fwd_ = nullptr; }
@@ -942,6 +942,9 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     if (!flow_err_host_ && !dry_run_) {
         TP_TRY(hipHostMalloc(reinterpret_cast<void**>(&flow_err_host_), 4 * sizeof(int), hipHostMallocDefault));
         flow_err_host_[0] = flow_err_host_[1] = flow_err_host_[2] = flow_err_host_[3] = 0;
+        void* dp = nullptr;   // (pinned host memory is mapped: the kernels that post a word write it through this address)
+        flow_err_host_dev_ = hipHostGetDevicePointer(&dp, flow_err_host_, 0) == hipSuccess ? static_cast<int*>(dp) : nullptr;
+        (void)hipGetLastError();
     }
     TP_TRY(upload(&potrf_tasks_, potrf));
     TP_TRY(upload(&trsm_tasks_, trsm));
@@ -1011,7 +1014,9 @@ hipError_t TilePlan::zero_tiles(bool own_touched_only, hipStream_t on, bool skip
         clear(0, (skip_fill && first_ok_) ? n_touched_ : n_slots_);
     }
     if (e != hipSuccess) return e;
-    return hipMemsetAsync(flag_, 0, 4 * sizeof(int), zs);
+    if (dry_run_) return hipSuccess;
+    launch_clear_i32(flag_, 4, zs);
+    return hipGetLastError();
 }
 
 void TilePlan::add_diag(int n_valid, double add_valid, double pad_value) {
@@ -1070,6 +1075,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     };
     auto launch_gate = [&](const int* a, int expected, int us, hipStream_t s) { if (!tr) apex::launch_gate(a, expected, us, s); };
     auto hipMemsetAsync = [&](void* p, int v, size_t n, hipStream_t s) { if (tr) return hipSuccess; return ::hipMemsetAsync(p, v, n, s); };
+    auto launch_clear_i32 = [&](int* p, int64_t n, hipStream_t s) { if (!tr) apex::launch_clear_i32(p, n, s); };
     auto launch_factor_flow = [&](const FactorUnit* u, int n, int* ver, int* fail, int* err, hipStream_t s, unsigned long long* trace) {
         if (tr) { tr->push_back({0, (uintptr_t)s, 0, 3, (int64_t)(u - flow_units_), n}); return; }
         apex::launch_factor_flow(u, n, ver, fail, err, s, trace);
@@ -1088,7 +1094,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     double* bvec = work;
     double* yvec = work ? work + n_pad() : nullptr;
     if (fwd) (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
-    if (gate_min_ > 0 && gate_cnt_) (void)hipMemsetAsync(gate_cnt_, 0, (size_t)(n_levels_ + 1) * sizeof(int), stream_);
+    if (gate_min_ > 0 && gate_cnt_) launch_clear_i32(gate_cnt_, n_levels_ + 1, stream_);
     int last_a = -1, last_b = -1;   // last levels with work on the side streams A / B that the main stream has not waited for
     std::vector<int> lastb((size_t)std::max(g1 - g0, 1), -1);   // lastb[lv - g0]: the last level <= lv with U2b2 work on stream B
     int b2_pending = -1, a_waited = -1;
@@ -1221,7 +1227,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         (void)hipEventRecord(ev_fwd2_, fwd_);
     }
     if (g1 < g_end) {   // every update the level launches add to the region's tiles is in: the joins above
-        (void)hipMemsetAsync(flow_ver_, 0, (size_t)n_slots_ * sizeof(int), stream_);
+        launch_clear_i32(flow_ver_, n_slots_, stream_);
         if (poison_factor_ && !tr)   // (tests: the version of the first unit's tile starts hugely negative and is never reached)
             (void)hipMemsetAsync(flow_ver_ + flow_units_h_[(size_t)flow_first_[ph]].pub, 0x80, sizeof(int), stream_);
         if (flow_dyn_ && !tr) {
@@ -1519,6 +1525,7 @@ bool TilePlan::post_sweep_status(bool reduce) {
     if (!flow_flags_ || !flow_err_host_) return true;
     int* err = flow_flags_ + 2 * (size_t)nt_;
     if (reduce && comm_.max_int && !comm_.max_int(err, 1, stream_)) return false;   // (the communicator keeps its message)
+    if (!reduce && flow_err_host_dev_) { launch_post_word(err, flow_err_host_dev_, stream_); return true; }   // (one launch, no copy engine)
     (void)hipMemcpyAsync(flow_err_host_, err, sizeof(int), hipMemcpyDeviceToHost, stream_);
     (void)hipMemsetAsync(err, 0, sizeof(int), stream_);
     return true;
