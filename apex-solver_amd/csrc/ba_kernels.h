@@ -46,7 +46,8 @@ struct BAView {
     const uint8_t* wg_cam_n;      // [workgroups]
     const uint32_t* wg_cam_list;  // [workgroups][kCamStageCap]
 };
-constexpr int kLmWg = 64;           // landmarks per workgroup of the landmark-major kernels (256 threads / 4 lanes per landmark)
+constexpr int kLmWg = 128;          // landmarks per workgroup of the landmark-major kernels (k_landmark_reduce: 4 lanes per landmark, 512 threads;
+                                    // k_back_substitute: 2 lanes, 256 threads) -- round 5; 64 until then
 constexpr int kCamStageCap = 128;   // distinct cameras staged per workgroup (slot 255 = gather from memory)
 
 // Per-landmark record written by k_landmark_reduce and read by the camera-major kernels: everything a

@@ -199,9 +199,9 @@ __global__ __launch_bounds__(kCamThreads, 2) void k_cam_reduce(BAView v, TileMap
 // (straight-line code: nothing keeps the compiler from issuing the caller's loads in between); only the LDS stores are
 // predicated.  Item q of camera k: q < 5 the q-th 16-byte piece of the compact camera, else extra[cam][q - 5].
 // CAMD: doubles per camera in the source array (kCamQStride: the compact form, kCamStride: the prepared records).
-template <int STR, int EXTRA, int CAMD = kCamQStride>
+template <int STR, int EXTRA, int CAMD = kCamQStride, int NT = 256>   // NT: threads of the workgroup (all of them copy)
 struct CamStager {
-    static constexpr int PQ = CAMD / 2, IT = PQ + EXTRA, NJ = (kCamStageCap * IT + 255) / 256;
+    static constexpr int PQ = CAMD / 2, IT = PQ + EXTRA, NJ = (kCamStageCap * IT + NT - 1) / NT;
     static_assert(STR % 2 == 0 && CAMD % 2 == 0 && STR >= CAMD + EXTRA, "slot pitch");
     uint32_t ci[NJ];
     double2 d[NJ];
@@ -211,12 +211,12 @@ struct CamStager {
         n = v.o_slot ? v.wg_cam_n[blockIdx.x] : 0;
         const uint32_t* __restrict__ list = v.wg_cam_list + (size_t)blockIdx.x * kCamStageCap;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) ci[j] = list[min(((int)threadIdx.x + 256 * j) / IT, kCamStageCap - 1)];
+        for (int j = 0; j < NJ; ++j) ci[j] = list[min(((int)threadIdx.x + NT * j) / IT, kCamStageCap - 1)];
     }
     __device__ __forceinline__ void issue_data(const double* __restrict__ cams, const double* __restrict__ extra) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int idx = (int)threadIdx.x + 256 * j, q = idx % IT;
+            const int idx = (int)threadIdx.x + NT * j, q = idx % IT;
             if (EXTRA == 0 || q < PQ) d[j] = reinterpret_cast<const double2*>(cams + CAMD * (size_t)ci[j])[q];
             else d[j] = make_double2(extra[(size_t)ci[j] * EXTRA + (q - PQ)], 0.0);
         }
@@ -224,7 +224,7 @@ struct CamStager {
     __device__ __forceinline__ void store(double* __restrict__ sCam) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int idx = (int)threadIdx.x + 256 * j, k = idx / IT, q = idx - IT * k;
+            const int idx = (int)threadIdx.x + NT * j, k = idx / IT, q = idx - IT * k;
             if (k < n) {
                 if (EXTRA == 0 || q < PQ) reinterpret_cast<double2*>(sCam + k * STR)[q] = d[j];
                 else sCam[k * STR + CAMD + (q - PQ)] = d[j].x;
@@ -234,23 +234,24 @@ struct CamStager {
     }
 };
 
+constexpr int kBsLanes = 2;   // lanes per landmark of k_back_substitute (see there)
 constexpr int kLmLanes = 4;   // lanes per landmark in the landmark-major kernels.  final-13682 (3..9 observations per landmark): 8 lanes
                               // 1.05 + 0.97 ms (k_landmark_reduce + k_back_substitute), 4 lanes 0.87 + 0.77, 2 lanes 0.74 + 0.68, 1 lane
                               // 0.75 + 0.73; 4 keeps the tail of a landmark with a thousand observations at a few hundred microseconds
 // (occupancy: 114 VGPRs = 4 waves per SIMD.  Forcing 5 / 6 with amdgpu_waves_per_eu spills 124 / 180 bytes per lane and the
 // kernel goes from 0.78 to 1.94 / 3.10 ms -- k_back_substitute likewise 0.48 -> 0.85 / 2.12: profiles/r05_ab_waves_per_eu.txt)
 template <int DC>
-__global__ __launch_bounds__(256) void k_landmark_reduce(BAView v, double lambda, double* __restrict__ hinv,
+__global__ __launch_bounds__(kLmWg * kLmLanes) void k_landmark_reduce(BAView v, double lambda, double* __restrict__ hinv,
                                                            double* __restrict__ g_l, int* __restrict__ err_flag,
                                                            double* __restrict__ lmu, double* __restrict__ orec) {
-    static_assert(256 / kLmLanes == kLmWg, "camera staging lists are built per kLmWg landmarks");
+    static_assert(kLmWg * kLmLanes <= 1024 && kLmWg * kBsLanes <= 1024, "a workgroup is kLmWg landmarks (the camera staging lists are built per kLmWg landmarks)");
     __shared__ double sCam[kCamStageCap * kCamQStride];
     const int g = threadIdx.x & (kLmLanes - 1);
-    const int64_t l = (int64_t)blockIdx.x * (256 / kLmLanes) + threadIdx.x / kLmLanes;
+    const int64_t l = (int64_t)blockIdx.x * kLmWg + threadIdx.x / kLmLanes;
     const bool active = l < v.n_pt;
     double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0}, pw[3] = {0, 0, 0};
     // two round trips to memory before the arithmetic starts: (list, pt_ptr), then (cameras, point, first observation)
-    CamStager<kCamQStride, 0> stager;
+    CamStager<kCamQStride, 0, kCamQStride, kLmWg * kLmLanes> stager;
     stager.issue_indices(v);
     const int64_t lc = active ? l : 0;
     const int b = v.pt_ptr[lc], e = active ? v.pt_ptr[lc + 1] : b;
@@ -541,8 +542,11 @@ __global__ __launch_bounds__(kRow2Threads) void k_schur_rows2(BAView v, TileMap 
 //     Jc_i dc = a (dt + dtheta x p_w) + (xn w, yn w)^T (t . dk),   H_cl^T dc += a^T (Jc_i dc)
 // ~110 instead of ~500 fp64 instructions per observation (the kernel was bound by exactly those once its loads were
 // interleaved); only for the modes that optimise every column group the factor has (no masks in the record form).
-template <int DC, bool MATVEC, bool REC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_back_substitute(BAView v, const double* __restrict__ hinv,
+// LANES per landmark (round 5): 2 here against k_landmark_reduce's 4 -- 0.39 against 0.48 ms on final-13682 (the A/B with every
+// landmark-major kernel at 2 lanes: this kernel -0.09, k_landmark_reduce +0.03); a workgroup is kLmWg landmarks either way (the
+// camera staging lists are built per kLmWg landmarks), i.e. 128 threads here.
+template <int DC, bool MATVEC, bool REC, int LANES = kBsLanes>
+__global__ __launch_bounds__(kLmWg * LANES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_back_substitute(BAView v, const double* __restrict__ hinv,
                                                            const double* __restrict__ g_l,
                                                            const double* __restrict__ dc,
                                                            double* __restrict__ dl,
@@ -550,11 +554,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     constexpr int CAMD = REC ? kCamStride : kCamQStride;
     constexpr int STR = CAMD + DC + ((CAMD + DC) & 1);   // camera | its step, 16-byte pieces
     __shared__ double sCam[kCamStageCap * STR];
-    const int g = threadIdx.x & (kLmLanes - 1);
-    const int64_t l = (int64_t)blockIdx.x * (256 / kLmLanes) + threadIdx.x / kLmLanes;
+    const int g = threadIdx.x & (LANES - 1);
+    const int64_t l = (int64_t)blockIdx.x * kLmWg + threadIdx.x / LANES;
     const bool active = l < v.n_pt;
     double acc[3] = {0, 0, 0};
-    CamStager<STR, DC, CAMD> stager;   // (see k_landmark_reduce: the staging chain and the landmark's own chain interleaved)
+    CamStager<STR, DC, CAMD, kLmWg * LANES> stager;   // (see k_landmark_reduce: the staging chain and the landmark's own chain interleaved)
     stager.issue_indices(v);
     const int64_t lc = active ? l : 0;
     const int b = v.pt_ptr[lc], e = active ? v.pt_ptr[lc + 1] : b;
@@ -573,13 +577,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int sl_next = v.o_slot ? (int)v.o_slot[i_first] : 255;
     stager.store(sCam);
     if (active) {
-        for (int i = b + g; i < e; i += kLmLanes) {
+        for (int i = b + g; i < e; i += LANES) {
             const double2 uv = uv_next, rw = rw_next;
             const int sl = sl_next;
-            if (i + kLmLanes < e) {
-                uv_next = REC ? rec2[2 * (size_t)(rbase + i + kLmLanes)] : v.o_uv[i + kLmLanes];
-                if (REC) rw_next = rec2[2 * (size_t)(rbase + i + kLmLanes) + 1];
-                sl_next = v.o_slot ? (int)v.o_slot[i + kLmLanes] : 255;
+            if (i + LANES < e) {
+                uv_next = REC ? rec2[2 * (size_t)(rbase + i + LANES)] : v.o_uv[i + LANES];
+                if (REC) rw_next = rec2[2 * (size_t)(rbase + i + LANES) + 1];
+                sl_next = v.o_slot ? (int)v.o_slot[i + LANES] : 255;
             }
             double dcv[DC];
             if (REC) {
@@ -639,9 +643,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
 #pragma unroll
-    for (int m = 1; m < kLmLanes; m <<= 1)
+    for (int m = 1; m < LANES; m <<= 1)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc[i] += __shfl_xor(acc[i], m, kLmLanes);
+        for (int i = 0; i < 3; ++i) acc[i] += __shfl_xor(acc[i], m, LANES);
     if (active && g == 0) {
         double Hi[kLmStride];
         if (REC) {
@@ -1075,9 +1079,9 @@ void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* ca
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag, double* lmu,
                             hipStream_t s, double* orec) {
     if (v.n_pt == 0) return;
-    const int grid = grid_for(v.n_pt, 256 / kLmLanes, 0);
-    if (dc == 9) hipLaunchKernelGGL(k_landmark_reduce<9>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag, lmu, orec);
-    else hipLaunchKernelGGL(k_landmark_reduce<6>, dim3(grid), dim3(256), 0, s, v, lambda, hinv, g_l, err_flag, lmu, orec);
+    const int grid = grid_for(v.n_pt, kLmWg, 0);
+    if (dc == 9) hipLaunchKernelGGL(k_landmark_reduce<9>, dim3(grid), dim3(kLmWg * kLmLanes), 0, s, v, lambda, hinv, g_l, err_flag, lmu, orec);
+    else hipLaunchKernelGGL(k_landmark_reduce<6>, dim3(grid), dim3(kLmWg * kLmLanes), 0, s, v, lambda, hinv, g_l, err_flag, lmu, orec);
 }
 
 void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, int mask_code, hipStream_t s) {
@@ -1096,14 +1100,14 @@ static bool rec_form_ok(int dc, const BAView& v, const double* orec) { return or
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
                             double* dl, hipStream_t s, const double* orec) {
     if (v.n_pt == 0) return;
-    const int grid = grid_for(v.n_pt, 256 / kLmLanes, 0);
+    const int grid = grid_for(v.n_pt, kLmWg, 0);
     if (rec_form_ok(dc, v, orec)) {
-        if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false, true>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl, orec);
-        else hipLaunchKernelGGL((k_back_substitute<6, false, true>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl, orec);
+        if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, orec);
+        else hipLaunchKernelGGL((k_back_substitute<6, false, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, orec);
         return;
     }
-    if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false, false>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl, nullptr);
-    else hipLaunchKernelGGL((k_back_substitute<6, false, false>), dim3(grid), dim3(256), 0, s, v, hinv, g_l, dcam, dl, nullptr);
+    if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, nullptr);
+    else hipLaunchKernelGGL((k_back_substitute<6, false, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, nullptr);
 }
 
 void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, const double* intr, const double* pts,
@@ -1250,13 +1254,13 @@ void launch_gather_records(int64_t n_obs, const int* cam_obs, const double* orec
 void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
                             double lambda, double* y, hipStream_t s, const double* orec, const double* corec) {
     if (v.n_pt > 0) {
-        const int grid = (int)((v.n_pt + 256 / kLmLanes - 1) / (256 / kLmLanes));
+        const int grid = (int)((v.n_pt + kLmWg - 1) / kLmWg);
         if (rec_form_ok(dc, v, orec)) {
-            if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, true>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu, orec);
-            else hipLaunchKernelGGL((k_back_substitute<6, true, true>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu, orec);
+            if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, orec);
+            else hipLaunchKernelGGL((k_back_substitute<6, true, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, orec);
         } else {
-            if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, false>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu, nullptr);
-            else hipLaunchKernelGGL((k_back_substitute<6, true, false>), dim3(grid), dim3(256), 0, s, v, hinv, nullptr, x, lmu, nullptr);
+            if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, nullptr);
+            else hipLaunchKernelGGL((k_back_substitute<6, true, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, nullptr);
         }
     }
     if (corec && rec_form_ok(dc, v, orec)) {
