@@ -680,11 +680,24 @@ __global__ __launch_bounds__(64) void k_implicit_cam(BAView v, const int* __rest
 #pragma unroll
     for (int a = 0; a < DC; ++a) { xc[a] = x[(size_t)c * DC + a]; acc[a] = 0.0; }
     const int b = cam_ptr[c], e = cam_ptr[c + 1];
+    // the next observation's landmark record and measurement are in flight while this one is linearised, the index of the one
+    // after too (as in k_cam_reduce): the gather of an iteration starts at once instead of behind a round trip for its address
+    // (round 5: the loop had two dependent round trips per observation and nothing to hide them but occupancy)
+    const int k_first = max(min(b + (int)threadIdx.x, e - 1), 0);
+    uint32_t l_next = v.co_pt[k_first];
+    double2 uv_next = v.co_uv[k_first];
+    double2 qn0, qn1, qn2, qn3;
+    { const double2* q = reinterpret_cast<const double2*>(lmu + kLmuStride * (size_t)l_next); qn0 = q[0]; qn1 = q[1]; qn2 = q[2]; qn3 = q[3]; }
+    if (k_first + 64 < e) l_next = v.co_pt[k_first + 64];
     for (int k = b + (int)threadIdx.x; k < e; k += 64) {
-        const uint32_t l = v.co_pt[k];
-        const double2 uv = v.co_uv[k];
-        const double2* q = reinterpret_cast<const double2*>(lmu + kLmuStride * (size_t)l);
-        const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        const double2 uv = uv_next;
+        const double2 q0 = qn0, q1 = qn1, q2 = qn2, q3 = qn3;
+        if (k + 64 < e) {
+            uv_next = v.co_uv[k + 64];
+            const double2* q = reinterpret_cast<const double2*>(lmu + kLmuStride * (size_t)l_next);
+            qn0 = q[0]; qn1 = q[1]; qn2 = q[2]; qn3 = q[3];
+            if (k + 128 < e) l_next = v.co_pt[k + 128];
+        }
         const double pw[3] = {q0.x, q0.y, q1.x}, u[3] = {q2.x, q2.y, q3.x};
         double r[2], Jc[2][DC], Jl[2][3];
         linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
