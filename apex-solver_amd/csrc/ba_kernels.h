@@ -112,7 +112,8 @@ void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTas
                         const RowChunk* chunks, const RowEntry* entries, const int* nbr, const double* hinv, hipStream_t s);
 // orec: the projection records of the same linearisation (k_landmark_reduce) or NULL -- the record form of the kernel
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
-                            double* dl, hipStream_t s, const double* orec = nullptr);
+                            double* dl, hipStream_t s, const double* orec = nullptr, const uint8_t* fix_pt = nullptr,
+                            double* pts_trial = nullptr /* with fix_pt: the trial points p (+) dl are written too */);
 void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, const double* intr, const double* pts,
                     const double* dcam, const double* dl, double sign, const uint8_t* fix_pose,
                     const uint8_t* fix_intr, const uint8_t* fix_pt, double* poses_out, double* intr_out,

@@ -550,7 +550,10 @@ __global__ __launch_bounds__(kLmWg * LANES) __attribute__((amdgpu_waves_per_eu(4
                                                            const double* __restrict__ g_l,
                                                            const double* __restrict__ dc,
                                                            double* __restrict__ dl,
-                                                           const double* __restrict__ orec) {
+                                                           const double* __restrict__ orec,
+                                                           const uint8_t* __restrict__ fix_pt, double* __restrict__ pts_trial) {
+    // pts_trial (may be NULL; back-substitution only): the trial point p (+) dl of the landmark is written with its step -- the
+    // retraction of the points (k_retract_points: a pass over 3 n_pt values) rides on this kernel (round 5, eager step evaluation)
     constexpr int CAMD = REC ? kCamStride : kCamQStride;
     constexpr int STR = CAMD + DC + ((CAMD + DC) & 1);   // camera | its step, 16-byte pieces
     __shared__ double sCam[kCamStageCap * STR];
@@ -660,7 +663,11 @@ __global__ __launch_bounds__(kLmWg * LANES) __attribute__((amdgpu_waves_per_eu(4
         } else {
             const double rhs[3] = {-Hi[kLmG] - acc[0], -Hi[kLmG + 1] - acc[1], -Hi[kLmG + 2] - acc[2]};
 #pragma unroll
-            for (int a = 0; a < 3; ++a) dl[3 * l + a] = Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2];
+            for (int a = 0; a < 3; ++a) {
+                const double d = Hi[3 * a] * rhs[0] + Hi[3 * a + 1] * rhs[1] + Hi[3 * a + 2] * rhs[2];
+                dl[3 * l + a] = d;
+                if (pts_trial) pts_trial[3 * l + a] = v.pts[3 * l + a] + (fix_pt[3 * l + a] ? 0.0 : 1.0 * d);   // (k_retract_points, sign = 1)
+            }
         }
     }
 }
@@ -1111,16 +1118,16 @@ void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTas
 // orec != nullptr: the record form (the records of THIS linearisation, k_landmark_reduce); ignored in the masked modes
 static bool rec_form_ok(int dc, const BAView& v, const double* orec) { return orec != nullptr && v.mask_code == (dc == 9 ? 7 : 6); }
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
-                            double* dl, hipStream_t s, const double* orec) {
+                            double* dl, hipStream_t s, const double* orec, const uint8_t* fix_pt, double* pts_trial) {
     if (v.n_pt == 0) return;
     const int grid = grid_for(v.n_pt, kLmWg, 0);
     if (rec_form_ok(dc, v, orec)) {
-        if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, orec);
-        else hipLaunchKernelGGL((k_back_substitute<6, false, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, orec);
+        if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, orec, fix_pt, pts_trial);
+        else hipLaunchKernelGGL((k_back_substitute<6, false, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, orec, fix_pt, pts_trial);
         return;
     }
-    if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, nullptr);
-    else hipLaunchKernelGGL((k_back_substitute<6, false, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, nullptr);
+    if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, nullptr, fix_pt, pts_trial);
+    else hipLaunchKernelGGL((k_back_substitute<6, false, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, nullptr, fix_pt, pts_trial);
 }
 
 void launch_retract(int dc, int64_t n_cam, int64_t n_pt, const double* poses, const double* intr, const double* pts,
@@ -1269,11 +1276,11 @@ void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const d
     if (v.n_pt > 0) {
         const int grid = (int)((v.n_pt + kLmWg - 1) / kLmWg);
         if (rec_form_ok(dc, v, orec)) {
-            if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, orec);
-            else hipLaunchKernelGGL((k_back_substitute<6, true, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, orec);
+            if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, orec, nullptr, nullptr);
+            else hipLaunchKernelGGL((k_back_substitute<6, true, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, orec, nullptr, nullptr);
         } else {
-            if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, nullptr);
-            else hipLaunchKernelGGL((k_back_substitute<6, true, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, nullptr);
+            if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, nullptr, nullptr, nullptr);
+            else hipLaunchKernelGGL((k_back_substitute<6, true, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, nullptr, nullptr, nullptr);
         }
     }
     if (corec && rec_form_ok(dc, v, orec)) {

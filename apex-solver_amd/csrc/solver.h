@@ -258,6 +258,7 @@ class Solver : public LmBackend {
     // iteration become one).  The answers are those of this very solve (step_serial_); single rank.
     bool device_gathers_ = true;   // "device_gathers": set-up, single rank: o_uv / co_uv / co_pt are permuted on the device (ba_structure.h)
     bool eager_eval_ = true;
+    bool trial_pts_written_ = false;   // the back-substitution of this solve has written the trial points (enqueue_trial_point skips them)
     int64_t step_serial_ = 0, eager_serial_ = -1;
     double* eager_host_ = nullptr;               // pinned: [0..5] step statistics, [6] sum of squares at the trial point
     double* pcg_host_ = nullptr;                 // pinned: two slots of the matrix-free PCG's scalars (read one iteration behind)

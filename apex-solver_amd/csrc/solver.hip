@@ -977,12 +977,15 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     for (int attempt = 0;; ++attempt) {
         stage_begin(kStBackSub);
         if (scaled_) launch_vec_mul(n_c_, dcam_, cam_scale_, dcam_, stream_);  // apply_inverse_scaling: dc = D_c y
-        launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_, backsub_records());
+        // what the LM loop asks next (step statistics, trial cost) rides on this solve's wait (solver.h, eager_eval_); the trial
+        // POINTS are written by the back-substitution itself
+        const bool eager = eager_eval_ && !(comm_ && world_ > 1);
+        trial_pts_written_ = eager && fix_pt_ != nullptr;
+        launch_back_substitute(dc_, view(cur_), hinv_, g_l_, dcam_, dl_, stream_, backsub_records(), trial_pts_written_ ? fix_pt_ : nullptr,
+                               trial_pts_written_ ? pts_[cur_ ^ 1] : nullptr);
         stage_end(kStBackSub);
         HIP_TRY(hipGetLastError());
         have_step_ = true;
-        // what the LM loop asks next (step statistics, trial cost) rides on this solve's wait (solver.h, eager_eval_)
-        const bool eager = eager_eval_ && !(comm_ && world_ > 1);
         if (eager) {
             if (!eager_host_) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&eager_host_), 8 * sizeof(double), hipHostMallocDefault));
             rc = enqueue_step_stats();
@@ -1185,8 +1188,9 @@ int Solver::step_stats(double out3[3]) {
 int Solver::enqueue_trial_point(double* sumsq_out) {
     const int t = cur_ ^ 1;
     stage_begin(kStRetract);
-    launch_retract(dc_, n_cam_, n_pt_, poses_[cur_], intr_[cur_], pts_[cur_], dcam_, dl_, 1.0, fix_pose_, fix_intr_,
-                   fix_pt_, poses_[t], intr_[t], pts_[t], stream_);
+    launch_retract(dc_, n_cam_, trial_pts_written_ ? 0 : n_pt_, poses_[cur_], intr_[cur_], pts_[cur_], dcam_, dl_, 1.0, fix_pose_, fix_intr_,
+                   fix_pt_, poses_[t], intr_[t], pts_[t], stream_);   // (the points: by k_back_substitute when trial_pts_written_)
+    trial_pts_written_ = false;
     launch_prepare_cams(n_cam_, poses_[t], intr_[t], camp_[t], mode_mask(mode_), stream_);
     stage_end(kStRetract);
     stage_begin(kStCost);
