@@ -81,7 +81,7 @@ void launch_factor_flow_dyn(const FactorUnit* units, int n_units, int* ver, int*
 void set_gemm_small_max(int panel, int update);   // process-wide: largest batch that uses the latency kernels (-1: keep); default kGemmSmallMax = 56 for both
 void set_panel_tri(int on);          // process-wide A/B switch: 1 (default) the panel solves skip the zero blocks of Linv
 void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 1 / 6 / 8 k_potrf_inv_la with 4 / 6 / 8 waves, 9 / 12 k_potrf_inv_mf with 8 / 12 waves (12: default)
-// batches of <= 56 tasks use the latency kernels, larger ones the 3 x 3-wave strip kernel
+// batches of <= 56 tasks use the latency kernels, larger ones the four-wave strip kernel (three workgroups per tile)
 // tri_b: every B is a lower-triangular inverse written by launch_potrf_inv (zero 16 x 16 blocks right of the diagonal): the
 // large-batch kernel then skips the 36 of 81 block products that multiply by them.
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, bool tri_b = false);

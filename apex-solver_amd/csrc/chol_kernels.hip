@@ -871,42 +871,49 @@ __global__ __launch_bounds__(64 * NW) void k_potrf_inv_mf(const PotrfTask* __res
 #undef POTRF_STAMP
 
 // ------------------------------------------------------------------------------------------
-// Batched 144^3 tile GEMM, NT form:  C = beta*C + alpha * A * B^T   (all row-major tiles).
-// Three 192-thread workgroups per task, one per 48-row strip of C; wave w of a workgroup owns the
-// 48x48 block at columns 48w and keeps 3x3 16x16 fp64 accumulators (v_mfma_f64_16x16x4_f64: lane l
-// supplies A[i=l&15][k=l>>4] and B^T[k=l>>4][j=l&15] = B[j][k]; result reg r of lane l is
-// C[(l>>4)+4r][l&15]), so 3 a-reads + 3 b-reads from LDS feed 9 MFMAs.
-// K is consumed in 16-wide chunks staged through LDS with an 18-double row pitch: the 16 rows x
-// 2 k-values read by each half-wave of a ds_read_b64 then hit 32 distinct bank pairs.
-// C may alias A (L_IK = S_IK L_KK^-T in place): every global read of A is staged into LDS before the
-// last barrier of the K loop and the epilogue stores come after it.
+// Batched 144^3 tile GEMM, NT form:  C = beta*C + alpha * A * B^T   (all row-major tiles), on v_mfma_f64_16x16x4_f64: lane l
+// supplies A[i=l&15][k=l>>4] and B^T[k=l>>4][j=l&15] = B[j][k]; result reg r of lane l is C[(l>>4)+4r][l&15].
+// K is consumed in 16-wide chunks staged through LDS with an 18-double row pitch: the 16 rows x 2 k-values read by each
+// half-wave of a ds_read_b64 then hit 32 distinct bank pairs.
+// C may alias A (L_IK = S_IK L_KK^-T in place): every global read of A is staged into LDS before the last barrier of the K loop
+// and the epilogue stores come after it.
 // ------------------------------------------------------------------------------------------
 constexpr int KC = 16;  // 24 (6 chunks) measured the same: the chunk size is not the limiter
-constexpr int PITCH = KC + 2;
-constexpr int STRIP = 48;          // output rows per workgroup (3 waves x 16)
+constexpr int STRIP = 48;          // output rows per workgroup
 constexpr int NSTRIP = NB / STRIP; // 3 workgroups per tile: 3x the parallelism of one per tile
 constexpr int kGemmSmallMax = 56;  // batches of at most this many tasks use the 9-workgroups-per-task latency kernel
-
 
 typedef double __attribute__((address_space(1)))* GlobalF64;
 typedef const double __attribute__((address_space(1)))* GlobalCF64;
 typedef double f64x2_t __attribute__((ext_vector_type(2)));
 typedef const f64x2_t __attribute__((address_space(1)))* GlobalCF64x2;
 
-// TRI: B is a lower-triangular inverse (the panel solve L_IK = S_IK Linv_KK^T): its 16 x 16 blocks right of the diagonal are
-// never written (zero), so column block cb of C needs the K chunks 0 .. cb only -- 45 of the 81 block products.  The column
-// blocks are then dealt to the waves round-robin (wave w: w, w + 3, w + 6: 12 / 15 / 18 chunk products instead of 27 each)
-// rather than in runs of three (6 / 15 / 24).  Skipping a product with an exact-zero factor changes no finite value.
+// The large-batch kernel (round 6).  Unit = a 48-row strip of C (all 144 columns) on FOUR waves -- one per SIMD of the CU whatever
+// the dispatcher does, so k resident workgroups are exactly k waves on every SIMD.  (Rounds 1-5 ran the strip on three waves of
+// 48 x 48: three-wave workgroups spread evenly over the four SIMDs only on average -- tools/wave_placement_bench.hip, 67.5
+// against 76.5 TF/s for a bare MFMA loop -- and each chunk's barrier makes the workgroup wait for its slowest wave: counters
+// 0.71 -> 0.75 of the matrix pipe, 55.9 -> 59.0 TF/s cache-resident, profiles/r06_gemm_forms*.txt.)  The 27 blocks of a strip
+// are dealt 7 / 7 / 7 / 6: wave w owns the block columns 2w, 2w + 1 (3 x 2 blocks) and, w < 3, block (w, 8).
+// A chunk of A (48 rows) and B (144 rows) is one 192-row image in LDS, 1,536 double2 = six per thread; 122 VGPRs = four
+// workgroups per CU.  Every element of C sums its k chunk by chunk, four k per instruction, the lane's k = kk + lane / 16 --
+// the order of the small-batch kernels and the dataflow units below: same bits in every schedule.
+// Tried beside it, same bits, all slower (profiles/r06_gemm_forms.txt): two LDS images with ONE barrier per chunk (52 KB = three
+// workgroups per CU: 55.8), persistent workgroups that request the next unit's first chunk before their epilogue (168 VGPRs =
+// three per CU: 54.0; two per CU 49.5) -- what pays in this kernel is resident waves per SIMD, not fewer barriers or prologues.
+// TRI (the panel solves): B is a lower-triangular inverse whose 16 x 16 blocks right of the diagonal are never written (zero),
+// so column block cb needs the K chunks 0 .. cb only -- 45 of the 81 block products; the columns are dealt by weight,
+// {8, 1} {7, 2} {6, 3} {5, 4, 0} = 11 / 11 / 11 / 12 chunk products per block row.  Skipping a product with an exact-zero factor
+// changes no finite value.
+// ------------------------------------------------------------------------------------------
 template <bool TRI>
-__global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restrict__ tasks, int n_units, double alpha,
-                                                        double beta) {
-    __shared__ double sA[STRIP * PITCH];
-    __shared__ double sB[NB * PITCH];
-    // XCD-aware unit order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each
-    // with its own L2.  Unit u = (task, strip) lists are sorted by source column, so giving every XCD
-    // one CONTIGUOUS eighth of the list makes the 3 strips of a task and the tasks of one column
-    // share their operand tiles in one L2 instead of fetching them 8 times from HBM.  (Placement
-    // is a speed assumption only: any mapping computes the same result.)
+__global__ __launch_bounds__(256, 3) void k_tile_gemm_nt(const GemmTask* __restrict__ tasks, int n_units, double alpha, double beta) {
+    constexpr int P4 = KC + 2;
+    constexpr int IMG = (NB + STRIP) * P4;
+    __shared__ double sm[IMG];
+    // XCD-aware unit order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  The unit
+    // lists are sorted by source column, so giving every XCD one CONTIGUOUS eighth of the list makes the 3 strips of a task and
+    // the tasks of one column share their operand tiles in one L2 instead of fetching them 8 times from HBM.  (Placement is a
+    // speed assumption only: any mapping computes the same result.)
     const int per_xcd = (n_units + 7) >> 3;
     const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
@@ -915,100 +922,128 @@ __global__ __launch_bounds__(192, 3) void k_tile_gemm_nt(const GemmTask* __restr
     // not cleared before the factorisation and not read here (beta = 0; "+ 0.0" keeps the bits of the sum with a cleared tile)
     const bool first = (reinterpret_cast<uintptr_t>(tg.C) & 1) != 0;
     tg.C = reinterpret_cast<double*>(reinterpret_cast<uintptr_t>(tg.C) & ~uintptr_t(7));
-    // The task's pointers are loaded from memory, so the compiler only knows them as generic (flat)
-    // addresses; flat loads count on lgkmcnt as well as vmcnt, which makes every wait for an LDS read also
-    // wait for the global prefetch of the next chunk.  Re-typed as global (address space 1) they become
-    // global_load / global_store and the prefetch stays asynchronous.
-    struct { GlobalF64 C; GlobalCF64 A; GlobalCF64 B; } t = {(GlobalF64)tg.C, (GlobalCF64)tg.A, (GlobalCF64)tg.B};
     const int strip = unit % NSTRIP;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // The task's pointers are loaded from memory, so the compiler only knows them as generic (flat) addresses; flat loads count
+    // on lgkmcnt as well as vmcnt, which makes every wait for an LDS read also wait for the global prefetch of the next chunk.
+    // Re-typed as global (address space 1) they become global_load / global_store and the prefetch stays asynchronous.
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
-    GlobalCF64 Ag = t.A + (size_t)strip * STRIP * NB;
-    int cb[3];   // first column of this wave's three 16-wide column blocks
+    GlobalCF64 Ag = (GlobalCF64)tg.A + (size_t)strip * STRIP * NB;
+    GlobalCF64 Bg = (GlobalCF64)tg.B;
+    constexpr int NACC = TRI ? 9 : 7;
+    int cb[3];
+    if (TRI) { cb[0] = 16 * (8 - w); cb[1] = 16 * (1 + w); cb[2] = w == 3 ? 0 : -16; }   // -16: no third column (every chunk skipped)
+    else { cb[0] = 32 * w; cb[1] = 32 * w + 16; cb[2] = 128; }
+    const bool extra = TRI ? (w == 3) : (w < 3);   // wave-uniform: the third column block (TRI) / the ninth column's block of row w
+    double4_t acc[NACC];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) cb[j] = TRI ? 16 * (w + 3 * j) : 48 * w + 16 * j;
-    double4_t acc[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    // staging: a KC-column chunk is KC/2 double2 per row; B: 144 rows, A strip: 48 rows
-    constexpr int C2 = KC / 2, NRB = NB * C2 / 192, NRA = STRIP * C2 / 192;
-    static_assert(NB * C2 % 192 == 0 && STRIP * C2 % 192 == 0 && NB % KC == 0 && KC % 4 == 0, "staging loops assume whole rounds");
-    double2 rb[NRB], ra[NRA];
+    for (int j = 0; j < NACC; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    constexpr int C2 = KC / 2, NR = (NB + STRIP) * C2 / 256, RPR = 256 / C2;   // six rounds of 32 rows x 8 double2
+    static_assert((NB + STRIP) * C2 % 256 == 0 && 256 % C2 == 0 && NR == 6 && RPR == 32, "staging loop assumes whole rounds");
+    // the staged rows of this thread: r0 + 32 i of the 192-row image = rows 0..143 of B, then the 48 rows of the A strip: rounds
+    // 0..3 are B, round 5 is A, round 4 is B for r0 < 16 and A behind it.  Uniform base + 32-bit offset: global_load with saddr
+    const int r0 = tid / C2, c2 = tid % C2;
+    const unsigned offB = r0 * NB + 2 * c2, offA = (r0 + 16) * NB + 2 * c2;
+    GlobalCF64 p4 = r0 < 16 ? Bg + (size_t)(r0 + 128) * NB + 2 * c2 : Ag + (size_t)(r0 - 16) * NB + 2 * c2;
+    const int dst0 = r0 * P4 + 2 * c2;
+    f64x2_t rg[NR];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < NRB; ++i) {
-            const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
-            { const f64x2_t q = *reinterpret_cast<GlobalCF64x2>(t.B + (size_t)row * NB + k0 + 2 * c2); rb[i].x = q.x; rb[i].y = q.y; }
-        }
+        for (int i = 0; i < 4; ++i) rg[i] = *reinterpret_cast<GlobalCF64x2>(Bg + (offB + (unsigned)(RPR * i * NB + k0)));
+        rg[4] = *reinterpret_cast<GlobalCF64x2>(p4 + k0);
+        rg[5] = *reinterpret_cast<GlobalCF64x2>(Ag + (offA + (unsigned)k0));
+    };
+    auto stage = [&](double* img) {
 #pragma unroll
-        for (int i = 0; i < NRA; ++i) {
-            const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
-            { const f64x2_t q = *reinterpret_cast<GlobalCF64x2>(Ag + (size_t)row * NB + k0 + 2 * c2); ra[i].x = q.x; ra[i].y = q.y; }
+        for (int i = 0; i < NR; ++i) { img[dst0 + RPR * i * P4] = rg[i].x; img[dst0 + RPR * i * P4 + 1] = rg[i].y; }
+    };
+    auto compute = [&](const double* img, int k0) {
+        const double* sB = img;
+        const double* sA = img + NB * P4;
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            if (TRI) {
+                if (k0 > cb[0]) continue;   // (wave-uniform; cb[0] is the wave's largest column)
+                double av[3], bv[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) av[i] = sA[(16 * i + lr) * P4 + kk + lk];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) bv[j] = sB[((cb[j] < 0 ? 0 : cb[j]) + lr) * P4 + kk + lk];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (k0 > cb[j]) continue;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        acc[3 * i + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[3 * i + j], 0, 0, 0);
+                }
+            } else {
+                double av[3], bv[2];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) av[i] = sA[(16 * i + lr) * P4 + kk + lk];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bv[j] = sB[(cb[j] + lr) * P4 + kk + lk];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[2 * i + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[2 * i + j], 0, 0, 0);
+                if (extra) {
+                    const double ax = sA[(16 * w + lr) * P4 + kk + lk], bx = sB[(128 + lr) * P4 + kk + lk];
+                    acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc[6], 0, 0, 0);
+                }
+            }
         }
     };
     gload(0);
     for (int k0 = 0; k0 < NB; k0 += KC) {
         __syncthreads();  // previous chunk fully consumed
-#pragma unroll
-        for (int i = 0; i < NRB; ++i) {
-            const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
-            sB[row * PITCH + 2 * c2] = rb[i].x; sB[row * PITCH + 2 * c2 + 1] = rb[i].y;
-        }
-#pragma unroll
-        for (int i = 0; i < NRA; ++i) {
-            const int idx = tid + 192 * i, row = idx / C2, c2 = idx % C2;
-            sA[row * PITCH + 2 * c2] = ra[i].x; sA[row * PITCH + 2 * c2 + 1] = ra[i].y;
-        }
+        stage(sm);
         __syncthreads();
         if (k0 + KC < NB) gload(k0 + KC);  // next chunk in flight while this one feeds the MFMAs
-#pragma unroll
-        for (int kk = 0; kk < KC; kk += 4) {
-            // wave w owns the 48 x 48 block of columns 48w..: 3 a-reads and 3 b-reads feed 9 MFMAs (a 16 x 144
-            // row per wave needs 1 + 9 reads for the same 9 MFMAs and makes the LDS, not the MFMA pipe, the limit)
-            double av[3], bv[3];
-            if (TRI && k0 > cb[2]) continue;   // (wave-uniform) nothing of this wave's columns left in this chunk
-#pragma unroll
-            for (int i = 0; i < 3; ++i) av[i] = sA[(16 * i + lr) * PITCH + kk + lk];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) bv[j] = sB[(cb[j] + lr) * PITCH + kk + lk];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (TRI && k0 > cb[j]) continue;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    acc[3 * i + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[3 * i + j], 0, 0, 0);
-            }
-        }
+        compute(sm, k0);
     }
-    // epilogue: per 16-column block, the 4 loads of C are issued before the 4 stores.  (A
-    // load-modify-store per element serialises 36 memory round trips -- the compiler cannot move
-    // loads across possibly aliasing stores -- and holding all 36 values costs 72 VGPRs, i.e. a
-    // wave per SIMD of occupancy; 4 at a time measured best: tools/gemm_var.hip.)
-    GlobalF64 C = t.C + (size_t)strip * STRIP * NB;
+    // epilogue: block n of this wave is at (brow(n), bcol(n)); read-modify-write software-pipelined, the loads of block n + 2 in
+    // flight while block n is stored (a load-modify-store per element serialises the round trips: tools/gemm_var.hip)
+    GlobalF64 C = (GlobalF64)tg.C + (size_t)strip * STRIP * NB;
+    auto brow = [&](int n) { return TRI ? 16 * (n / 3) : (n < 6 ? 16 * (n / 2) : 16 * w); };
+    auto bcol = [&](int n) { return TRI ? cb[n % 3] : (n < 6 ? cb[n % 2] : 128); };
     if (beta == 0.0 || first) {
         const double zero = first ? 0.0 : -0.0;   // (x + -0.0 == x bit for bit: the panel solves' stores are unchanged)
 #pragma unroll
-        for (int j = 0; j < 9; ++j)
+        for (int n = 0; n < NACC; ++n) {
+            if (TRI ? (n % 3 == 2 && !extra) : (n == 6 && !extra)) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) C[(size_t)(16 * (j / 3) + lk + 4 * r) * NB + cb[j % 3] + lr] = alpha * acc[j][r] + zero;
+            for (int r = 0; r < 4; ++r) C[(size_t)(brow(n) + lk + 4 * r) * NB + bcol(n) + lr] = alpha * acc[n][r] + zero;
+        }
         return;
     }
-    // software-pipelined read-modify-write: the loads of column block j+2 are in flight while block j
-    // is stored (three 4-value buffers), so the 9 blocks cost ~3 memory round trips instead of 9
+    if (TRI) {   // (the panel solves run with beta == 0; kept general)
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) {
+            if (n % 3 == 2 && !extra) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                GlobalF64 p = C + (size_t)(brow(n) + lk + 4 * r) * NB + bcol(n) + lr;
+                *p = alpha * acc[n][r] + beta * *p;
+            }
+        }
+        return;
+    }
     double cv[3][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cv[0][r] = C[(size_t)(lk + 4 * r) * NB + cb[0] + lr];
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cv[1][r] = C[(size_t)(lk + 4 * r) * NB + cb[1] + lr];
+        for (int r = 0; r < 4; ++r) cv[n][r] = C[(size_t)(brow(n) + lk + 4 * r) * NB + bcol(n) + lr];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        if (j + 2 < 9) {
+    for (int n = 0; n < NACC; ++n) {
+        if (n + 2 < NACC && (n + 2 < 6 || extra)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cv[(j + 2) % 3][r] = C[(size_t)(16 * ((j + 2) / 3) + lk + 4 * r) * NB + cb[(j + 2) % 3] + lr];
+            for (int r = 0; r < 4; ++r) cv[(n + 2) % 3][r] = C[(size_t)(brow(n + 2) + lk + 4 * r) * NB + bcol(n + 2) + lr];
         }
+        if (n == 6 && !extra) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            C[(size_t)(16 * (j / 3) + lk + 4 * r) * NB + cb[j % 3] + lr] = alpha * acc[j][r] + beta * cv[j % 3][r];
+            C[(size_t)(brow(n) + lk + 4 * r) * NB + bcol(n) + lr] = alpha * acc[n][r] + beta * cv[n % 3][r];
     }
 }
 
@@ -2260,8 +2295,8 @@ void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta
         return;
     }
     const int units = n * NSTRIP, per_xcd = (units + 7) / 8;
-    if (tri_b && g_panel_tri) hipLaunchKernelGGL(k_tile_gemm_nt<true>, dim3(8 * per_xcd), dim3(192), 0, s, tasks, units, alpha, beta);
-    else hipLaunchKernelGGL(k_tile_gemm_nt<false>, dim3(8 * per_xcd), dim3(192), 0, s, tasks, units, alpha, beta);
+    if (tri_b && g_panel_tri) hipLaunchKernelGGL(k_tile_gemm_nt<true>, dim3(8 * per_xcd), dim3(256), 0, s, tasks, units, alpha, beta);
+    else hipLaunchKernelGGL(k_tile_gemm_nt<false>, dim3(8 * per_xcd), dim3(256), 0, s, tasks, units, alpha, beta);
 }
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s) {
     if (n <= 0) return;

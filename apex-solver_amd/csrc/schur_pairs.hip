@@ -616,7 +616,11 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     // counter, the compiler cannot tell its destination from U / V and puts s_waitcnt vmcnt(0) in front of every LDS read of
     // the product loop -- which then waits for the very gathers that were issued to overlap with it (the fused kernels have
     // exactly this: their prefetch never overlapped their products).
-    __shared__ double lds_cams[4 * NCAMS * kCamStride];
+    // (round 6) a staged camera takes kCamLds = 18 doubles, not kCamStride = 16: the lanes of a chunk read the cameras of seven
+    // different queues, and at a stride of 32 dwords those addresses fall on two bank groups -- every ds_read_b128 of a camera took
+    // 16 LDS cycles instead of 4 (tools/lds_conflict_sim.py: 96 of a chunk's 556 LDS cycles)
+    constexpr int kCamLds = kCamStride + 2;
+    __shared__ double lds_cams[4 * NCAMS * kCamLds];
     __shared__ double lds_occ[(ABL & 128) ? 6000 : 1];   // ABL 128: +47 KB of LDS = ONE workgroup per CU (occupancy experiment)
     if ((ABL & 128) && n_tasks == -12345) { lds_occ[threadIdx.x * 23] = 1.0; __syncthreads(); tiles[0] = lds_occ[threadIdx.x * 7 + 1]; }
     const int lane = threadIdx.x & 63;
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     if (t >= n_tasks) return;
     double* U = lds_all + w * WAVE_LDS;
     double* V = U + 64 * UV;
-    double* CAMS = lds_cams + w * NCAMS * kCamStride;
+    double* CAMS = lds_cams + w * NCAMS * kCamLds;
     double* Z = V + 64 * UV;
     if (lane < UV) Z[lane] = 0.0;
     int g, sub;
@@ -840,8 +844,8 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         const unsigned long long t0 = stamp();
         // ---- cameras of this lane's pair: LDS (DMA issued a chunk ago) or, in a chunk of many tiny blocks, memory ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // gathers, block descriptors, and the LDS-DMA (it writes LDS behind the VM counter)
-        reinterpret_cast<double2*>(CAMS)[lane] = cam_stage;   // (the previous chunk's camera reads are long done)
-        if constexpr (QL && DC == 6) reinterpret_cast<double2*>(CAMS)[64 + lane] = cam_stage2;
+        *reinterpret_cast<double2*>(CAMS + (lane >> 3) * kCamLds + 2 * (lane & 7)) = cam_stage;   // (the previous chunk's camera reads are long done)
+        if constexpr (QL && DC == 6) *reinterpret_cast<double2*>(CAMS + (8 + (lane >> 3)) * kCamLds + 2 * (lane & 7)) = cam_stage2;
         __builtin_amdgcn_wave_barrier();
         const unsigned long long t1 = stamp();
         Gather dat;
@@ -854,14 +858,14 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             for (int k = 0; k < 16; ++k) { cvi[k] = dat.lm[k % 4].x + k; cvj[k] = dat.lm[k % 4].y - k; }
         } else {
             if (QL) {
-                const double2* cj = reinterpret_cast<const double2*>(CAMS + ((DC == 9 ? 1 : 0) + blk) * kCamStride);
+                const double2* cj = reinterpret_cast<const double2*>(CAMS + ((DC == 9 ? 1 : 0) + blk) * kCamLds);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 b = cj[k]; cvj[2 * k] = b.x; cvj[2 * k + 1] = b.y; }
 #pragma unroll
                 for (int k = 0; k < 16; ++k) cvi[k] = cvi_task[QL ? k : 0];
             } else if (dma) {
-                const double2* ci = reinterpret_cast<const double2*>(CAMS + (2 * blk) * kCamStride);
-                const double2* cj = reinterpret_cast<const double2*>(CAMS + (2 * blk + 1) * kCamStride);
+                const double2* ci = reinterpret_cast<const double2*>(CAMS + (2 * blk) * kCamLds);
+                const double2* cj = reinterpret_cast<const double2*>(CAMS + (2 * blk + 1) * kCamLds);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 a = ci[k], b = cj[k]; cvi[2 * k] = a.x; cvi[2 * k + 1] = a.y; cvj[2 * k] = b.x; cvj[2 * k + 1] = b.y; }
             } else {   // a chunk of many tiny blocks: the cameras come straight from memory
