@@ -25,7 +25,7 @@ SYMBOLS = (
     "apexgpu_step_stats", "apexgpu_eval_step", "apexgpu_commit_step", "apexgpu_discard_step",
     "apexgpu_parameter_norm", "apexgpu_column_norms", "apexgpu_set_column_scaling", "apexgpu_lm_optimize", "apexgpu_get_residual", "apexgpu_get_jacobian_blocks",
     "apexgpu_get_schur", "apexgpu_get_landmark_blocks", "apexgpu_get_hessian_csc", "apexgpu_debug_invert_blocks", "apexgpu_debug_pair_lists", "apexgpu_debug_pair_lists_queued", "apexgpu_debug_pair_lists_queued_dc", "apexgpu_debug_host_structure", "apexgpu_setup_times", "apexgpu_schur_matvec", "apexgpu_set_option", "apexgpu_enable_stage_timing", "apexgpu_reset_stage_times",
-    "apexgpu_stage_times", "apexgpu_info", "apexgpu_variant_info", "apexgpu_trim_host_cache", "apexgpu_counters", "apexgpu_debug_pair_phases", "apexgpu_debug_get_pair_records", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_comm_init_shm", "apexgpu_set_shard", "apexgpu_shard_range",
+    "apexgpu_stage_times", "apexgpu_info", "apexgpu_variant_info", "apexgpu_variant_costs", "apexgpu_trim_host_cache", "apexgpu_host_cache_bytes", "apexgpu_counters", "apexgpu_debug_get_pair_records", "apexgpu_get_unique_id", "apexgpu_comm_init", "apexgpu_comm_init_shm", "apexgpu_set_shard", "apexgpu_shard_range",
     "apexgpu_debug_lockstep_solve", "apexgpu_export_step", "apexgpu_owned_landmarks", "apexgpu_debug_partition", "apexgpu_debug_check_schedule",
     "apexgpu_bal_open", "apexgpu_bal_close", "apexgpu_bal_last_error", "apexgpu_bal_sizes", "apexgpu_bal_raw",
     "apexgpu_bal_variables", "apexgpu_reference_columns",
@@ -42,7 +42,7 @@ SYMBOLS = (
 )
 PG_NUM_STAGES = 6
 PG_STAGE_NAMES = ("assemble", "factor", "tri_solve", "step_stats", "retract", "cost")
-_NON_INT = ("apexgpu_destroy", "apexgpu_last_error", "apexgpu_version", "apexgpu_bal_close", "apexgpu_bal_last_error",
+_NON_INT = ("apexgpu_destroy", "apexgpu_last_error", "apexgpu_version", "apexgpu_host_cache_bytes", "apexgpu_bal_close", "apexgpu_bal_last_error",
             "apexgpu_pg_destroy", "apexgpu_pg_last_error", "apexgpu_g2o_close", "apexgpu_g2o_last_error")
 
 ERROR_NAMES = {
@@ -142,10 +142,12 @@ def load() -> C.CDLL:
     L.apexgpu_stage_times.argtypes = [vp, C.POINTER(dbl * NUM_STAGES), C.POINTER(i64 * NUM_STAGES)]
     L.apexgpu_info.argtypes = [vp, C.POINTER(dbl * 16)]
     L.apexgpu_trim_host_cache.argtypes = [C.POINTER(C.c_int64)]
+    L.apexgpu_host_cache_bytes.argtypes = []
+    L.apexgpu_host_cache_bytes.restype = C.c_int64
     L.apexgpu_debug_get_pair_records.argtypes = [vp, vp, i64]
     L.apexgpu_variant_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    L.apexgpu_variant_costs.argtypes = [vp, C.POINTER(dbl * 4)]
     L.apexgpu_counters.argtypes = [vp, C.POINTER(i64 * 4)]
-    L.apexgpu_debug_pair_phases.argtypes = [C.POINTER(i64 * 8), C.c_int]
     L.apexgpu_get_unique_id.argtypes = [vp]
     L.apexgpu_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.apexgpu_comm_init_shm.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
@@ -219,12 +221,12 @@ def tile_partition(present: np.ndarray, world: int):
 
 def check_schedule(present: np.ndarray, world: int = 1, rank: int = 0, two_side: int = 1, overlap: int = 1, split_u1: int = 4,
                    flood_gate: int = 256, factor_flow: int = -1, factor_flow_rows: int = 24, old_idle_level_bug: bool = False,
-                   drop_wait: int = -1, panel_split: int = 0) -> dict:
+                   drop_wait: int = -1) -> dict:
     """Host-only race check of the factorisation's launch sequence for one tile structure (apexgpu_debug_check_schedule)."""
     L = load()
     pr = np.ascontiguousarray(present, dtype=np.uint8)
     nt = pr.shape[0]
-    opts = np.array([two_side, overlap, split_u1, flood_gate, factor_flow, factor_flow_rows, int(old_idle_level_bug), drop_wait, panel_split], dtype=np.int32)
+    opts = np.array([two_side, overlap, split_u1, flood_gate, factor_flow, factor_flow_rows, int(old_idle_level_bug), drop_wait], dtype=np.int32)
     out = np.zeros(8, dtype=np.int64)
     msg = C.create_string_buffer(512)
     rc = L.apexgpu_debug_check_schedule(nt, pr.ctypes.data_as(C.c_void_p), int(world), int(rank), opts.ctypes.data_as(C.c_void_p),

@@ -37,11 +37,6 @@ struct BAView {
     // (wg_cam_list[w][0 .. wg_cam_n[w]), first-appearance order) and gives every observation its camera's slot in that list
     // (o_slot[i], 255 = not staged: the list is capped at kCamStageCap).  The workgroup copies those cameras to LDS once
     // -- a few hundred line accesses instead of ten scattered 16-byte loads per observation and lane.
-    // Landmark BUNDLES (round 5; NULL = the records are indexed by observation): the projection records of landmark l sit right
-    // behind a 64-byte copy of its record's first line -- [Hll^-1 (6) p.x p.y | rec 0 | rec 1 | ...], 128-byte aligned, 32-byte
-    // units: header at unit bun_ptr[l], record of the landmark's r-th observation at bun_ptr[l] + 2 + r.  An L2 miss costs per
-    // 128-byte line (profiles/r05_vmem_issue_bench_32MB_table.txt): a pair of the Schur kernel then touches 2.1 lines, not 2.6.
-    const int* bun_ptr;           // [n_pt]
     const uint8_t* o_slot;        // [n_obs]
     const uint8_t* wg_cam_n;      // [workgroups]
     const uint32_t* wg_cam_list;  // [workgroups][kCamStageCap]
@@ -66,29 +61,6 @@ struct TileMap {
     int nt;
 };
 
-constexpr int kRowCap9 = 96;    // neighbour cameras whose 9x9 blocks one workgroup keeps in LDS (62 KB: 2 workgroups per CU)
-constexpr int kRowCap6 = 160;   // same for 6x6 blocks (46 KB)
-
-struct RowTask {   // one workgroup of k_schur_rows2: camera `cam`, neighbours nbr[nbr0 .. nbr0+nnbr)
-    int cam;
-    int nbr0, nnbr;
-    int diag;            // this chunk holds the camera's own diagonal block (and its g sums)
-    int batch0, nbatch;  // the camera's chunks (RowChunk)
-};
-
-// k_schur_rows2: one lane per observation i of the row camera, looping over its partner observations.
-struct RowEntry {  // (a piece of) one observation of the row camera
-    int k;         // camera-major index (co_pt / co_uv)
-    int j0;        // landmark-major index of the first partner handled by this entry
-    int n;         // partners handled: observations j0 .. j0+n-1 (all BEFORE i in the landmark's list), 1..kRowMaxPartners
-    int pad;
-};
-struct RowChunk {  // <= 64 entries with (nearly) equal partner counts: the work of one wave
-    int first, count;
-    int nmax;      // largest n in the chunk = trip count of the wave's partner loop
-};
-constexpr int kRowMaxPartners = 64;  // an observation with more partners is split into several entries
-
 void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* cam_ptr, const int* cam_obs,
                        double lambda, int add_lambda, const double* hinv, const double* g_l, int with_self, double* g_c,
                        double* g_red, hipStream_t s);
@@ -98,18 +70,15 @@ void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv
                             double* lmu /* may be NULL */, hipStream_t s, double* orec = nullptr);
 // A18 (implicit_schur.rs): y = S x matrix-free, the Schur-Jacobi preconditioner blocks and their application
 void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
-                            double lambda, double* y, hipStream_t s, const double* orec = nullptr, const double* corec = nullptr);
+                            double lambda, double* y, hipStream_t s, const double* orec = nullptr);
 void launch_clear3(double* a, double* b, int64_t n, int* f, int nf, hipStream_t s);   // a[0..n) = b[0..n) = 0, f[0..nf) = 0: one launch
 void launch_gather_uv(int64_t n, const int* idx, const double* src, double* dst, hipStream_t s);          // dst[k] = src[idx[k]] (double2)
 void launch_gather_u32(int64_t n, const int* idx, const uint32_t* src, uint32_t* dst, hipStream_t s);
-void launch_gather_records(int64_t n_obs, const int* cam_obs, const double* orec, double* corec, hipStream_t s);
 void launch_extract_diag_blocks(int dc, int64_t n_cam, const TileMap& tm, double* sd, hipStream_t s);
 void launch_precond_blocks(int dc, int64_t n_cam, const double* sd, double* minv, hipStream_t s);
 void launch_precond_apply(int dc, int64_t n_cam, const double* minv, const double* r, double* z, hipStream_t s);
 // mask_code = 4 POSE + 2 LANDMARK + INTRINSIC: which blocks of the factors' Jacobians exist (OptimizeParams, src/factors/mod.rs:66-101)
 void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr, double* camp, int mask_code, hipStream_t s);
-void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
-                        const RowChunk* chunks, const RowEntry* entries, const int* nbr, const double* hinv, hipStream_t s);
 // orec: the projection records of the same linearisation (k_landmark_reduce) or NULL -- the record form of the kernel
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
                             double* dl, hipStream_t s, const double* orec = nullptr, const uint8_t* fix_pt = nullptr,

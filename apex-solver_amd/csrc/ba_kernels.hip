@@ -15,7 +15,6 @@
 // record instead of streaming a 216-byte Jacobian row through HBM):
 //   k_cam_reduce       camera-major   H_cc diagonal blocks (+lambda), g_c, g_red := -g_c     (A6-A8)
 //   k_landmark_reduce  landmark-major H_ll, g_l, eigen-gated 3x3 inverse                     (A6, A8, A9)
-//   k_schur_rows2      camera-major   S -= (W Hll^-1) W^T in LDS row blocks (the A/B of the pair list, schur_pairs.hip) (A10)
 //   k_back_substitute  landmark-major dl = Hll^-1 (-g_l - W^T dc)                            (A11)
 //   k_retract_*        x (+) d with the fixed-DOF mask                                       (A15)
 //   k_cost_partial     1/2 |r~|^2 on a (trial) parameter set                                 (A16)
@@ -255,8 +254,6 @@ __global__ __launch_bounds__(kLmWg * kLmLanes) void k_landmark_reduce(BAView v, 
     stager.issue_indices(v);
     const int64_t lc = active ? l : 0;
     const int b = v.pt_ptr[lc], e = active ? v.pt_ptr[lc + 1] : b;
-    const int bun = v.bun_ptr ? v.bun_ptr[lc] : 0;                        // the landmark's bundle (32-byte units)
-    const int64_t rbase = v.bun_ptr ? (int64_t)bun + 2 - b : 0;            // record of observation i: unit rbase + i
     stager.issue_data(v.camq, nullptr);
     pw[0] = v.pts[3 * lc]; pw[1] = v.pts[3 * lc + 1]; pw[2] = v.pts[3 * lc + 2];
     const int i_first = max(min(b + g, (int)v.n_obs - 1), 0);   // (clamped: the load is unconditional, the use is not)
@@ -278,7 +275,7 @@ __global__ __launch_bounds__(kLmWg * kLmLanes) void k_landmark_reduce(BAView v, 
             if (orec) {   // record form of the pair kernel: the observation's projection record, 32 bytes, landmark-major
                 double rec[4];
                 linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl, rec);
-                double2* q = reinterpret_cast<double2*>(orec + 4 * (size_t)(rbase + i));
+                double2* q = reinterpret_cast<double2*>(orec + 4 * (size_t)i);
                 q[0] = make_double2(rec[0], rec[1]); q[1] = make_double2(rec[2], rec[3]);
             } else {
                 linearize_obs<DC>(cam, pw, uv.x, uv.y, v.huber_delta, r, Jc, Jl);
@@ -324,10 +321,6 @@ __global__ __launch_bounds__(kLmWg * kLmLanes) void k_landmark_reduce(BAView v, 
             double2* q = reinterpret_cast<double2*>(hinv + kLmStride * l);
             q[0] = make_double2(Bi[0], Bi[1]); q[1] = make_double2(Bi[2], Bi[4]); q[2] = make_double2(Bi[5], Bi[8]);
             q[3] = make_double2(pw[0], pw[1]); q[4] = make_double2(pw[2], gl[0]); q[5] = make_double2(gl[1], gl[2]);
-            if (orec && v.bun_ptr && e > b) {   // (a landmark without local observations has no bundle) the bundle's header: the first line once more, in front of the landmark's projection records
-                double2* hq = reinterpret_cast<double2*>(orec + 4 * (size_t)bun);
-                hq[0] = q[0]; hq[1] = q[1]; hq[2] = q[2]; hq[3] = q[3];
-            }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) g_l[3 * l + i] = gl[i];
@@ -352,181 +345,6 @@ __global__ __launch_bounds__(256) void k_prepare_cams(int64_t n_cam, const doubl
     cam.m_pose = (mask_code & 4) ? 1.0 : 0.0; cam.m_lm = (mask_code & 2) ? 1.0 : 0.0; cam.m_intr = (mask_code & 1) ? 1.0 : 0.0;
     store_cam_prepared(cam, camp + kCamStride * c);
     store_cam_q(qn, cam, camp + kCamStride * n_cam + kCamQStride * c);   // the compact copy follows the 16-double records
-}
-
-// ------------------------------------------------------------------------------------------
-// K2c: the Schur reduction WITHOUT global atomics ("row" form).  One workgroup owns the row block
-// of S that belongs to one camera ci (or a <=CAP-neighbour chunk of it), keeps it in LDS, walks
-// the camera's observations, and for every observation i of landmark l visits the observations j of
-// l with cam_j <= cam_i (a prefix of l's list: observations are sorted by camera inside a landmark).
-// One lane per (i,j) pair recomputes both Jacobian blocks from the 24-byte observation records
-// (~0.5 kflop, cheaper than moving a DC x DC block through memory), forms Y_i = W_i Hll^-1 and adds
-// -Y_i W_j^T into the LDS block of camera pair (ci,cj) with ds_add_f64.  The self pair (j == i) also
-// folds in Jc^T Jc, Jc^T r and Y_i g_l, so H_cc, g_c and g_red need no separate pass.  At the end the
-// row block is stored once with plain stores: S = H_cc + lambda I - sum (W Hll^-1) W^T
-// (compute_schur_complement, explicit_schur.rs:771-925) and g_red = -g_c + W Hll^-1 g_l (:928-977).
-// HBM traffic is the observation stream times the mean track length plus S once; the atomics form
-// (k_schur_scatter) moves DC^2 doubles of atomic traffic per pair instead.
-// ------------------------------------------------------------------------------------------
-constexpr int kHashSize = 256;   // >= 1.6 x the largest CAP
-constexpr int kCamPitch = 17;    // doubles per neighbour camera in LDS: odd pitch spreads the lanes over the banks
-
-__device__ __forceinline__ int hash_slot(const int* hkey, const int* hval, int key) {
-    unsigned h = ((unsigned)key * 2654435761u) >> 24;  // 8 bits
-    for (int probe = 0; probe < kHashSize; ++probe) {
-        const int k = hkey[h];
-        if (k == key) return hval[h];
-        if (k < 0) return -1;
-        h = (h + 1) & (kHashSize - 1);
-    }
-    return -1;
-}
-
-// ------------------------------------------------------------------------------------------
-// K2d: the row form again, one lane per OBSERVATION.  k_schur_rows gives every (i, j) pair its own lane, so
-// the ~3 lanes that share an observation i repeat its linearisation and Y_i = W_i Hll^-1, and every batch of
-// pairs needs an expansion phase with two workgroup barriers.  Here a lane owns an observation i of the row
-// camera: it linearises i once, keeps -Y_i in registers and walks its partner observations j (the ones before
-// i in the landmark's list) in a loop; entries are sorted by partner count on the host, so the 64 lanes of a
-// wave run the same number of trips.  No pair expansion, no LDS index arrays, no barrier between the initial
-// staging and the final store: the four waves of a workgroup drift apart and hide each other's gathers.
-// Same arithmetic and the same LDS accumulation (81 ds_add_f64 per pair) as k_schur_rows.
-// ------------------------------------------------------------------------------------------
-// 256 threads: 218 VGPRs and 77 KB of LDS give 2 workgroups = 8 waves per CU; 384 / 512-thread variants forced to 3 / 4
-// waves per SIMD spill and run at 9.1 / 8.5 ms instead of 6.1.
-constexpr int kRow2Threads = 256;
-template <int DC, int CAP>
-__global__ __launch_bounds__(kRow2Threads) void k_schur_rows2(BAView v, TileMap tm, const RowTask* __restrict__ tasks,
-                                                       const RowChunk* __restrict__ chunks,
-                                                       const RowEntry* __restrict__ entries,
-                                                       const int* __restrict__ nbr, const double* __restrict__ hinv) {
-    constexpr int E = DC * DC;
-    __shared__ double acc[CAP * E];
-    __shared__ double scam[CAP * kCamPitch];
-    __shared__ int hkey[kHashSize], hval[kHashSize];
-    const RowTask t = tasks[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t ci = (uint32_t)t.cam;
-    for (int idx = tid; idx < CAP * E; idx += kRow2Threads) acc[idx] = 0.0;
-    for (int idx = tid; idx < kHashSize; idx += kRow2Threads) hkey[idx] = -1;
-    __syncthreads();
-    if (tid < t.nnbr) {
-        const int key = nbr[t.nbr0 + tid];
-        unsigned h = ((unsigned)key * 2654435761u) >> 24;
-        while (atomicCAS(&hkey[h], -1, key) != -1) h = (h + 1) & (kHashSize - 1);
-        hval[h] = tid;
-    }
-    for (int idx = tid; idx < t.nnbr * kCamStride; idx += kRow2Threads) {
-        const int sl = idx / kCamStride, k = idx - sl * kCamStride;
-        scam[sl * kCamPitch + k] = v.camp[(size_t)nbr[t.nbr0 + sl] * kCamStride + k];
-    }
-    __syncthreads();
-    Cam cam_i;
-    load_cam_prepared(v.camp + kCamStride * (size_t)ci, cam_i);
-
-    for (int ch = t.batch0 + w; ch < t.batch0 + t.nbatch; ch += kRow2Threads / 64) {
-        const RowChunk ck = chunks[ch];
-        const bool act = lane < ck.count;
-        int j0 = 0, n = 0;
-        double Y[DC][3], pw[3] = {0.0, 0.0, 0.0};
-        // Lanes that hit the same neighbour block in the same step would add to the same 81 addresses in the same order
-        // (adjacent observations of a camera see nearly the same cameras): the LDS atomic unit serialises them.  Every
-        // lane therefore walks the block rows in its own cyclic order: its copy of -Y_i is rotated by rot = lane % DC rows
-        // once per observation, and register row a goes to block row (a + rot) % DC.
-        const int rot = lane % DC;
-        int roff[DC];
-#pragma unroll
-        for (int a = 0; a < DC; ++a) { const int ra = a + rot; roff[a] = (ra >= DC ? ra - DC : ra) * DC; }
-        if (act) {
-            const int4 en = *reinterpret_cast<const int4*>(entries + ck.first + lane);
-            j0 = en.y; n = en.z;
-            const uint32_t l = v.co_pt[en.x];
-            const double2 uvi = v.co_uv[en.x];
-            double Hi[9];
-            {
-                double lr[kLmStride];
-                load_lm_record(hinv, (size_t)l, lr);
-#pragma unroll
-                for (int a = 0; a < 9; ++a) Hi[a] = lr[a];
-                pw[0] = lr[kLmPt]; pw[1] = lr[kLmPt + 1]; pw[2] = lr[kLmPt + 2];
-            }
-            double r[2], Jc[2][DC], Jl[2][3];
-            linearize_obs<DC>(cam_i, pw, uvi.x, uvi.y, v.huber_delta, r, Jc, Jl);
-#pragma unroll
-            for (int a = 0; a < DC; ++a) {  // -Y_i: the sign of the Schur term is folded in here
-                const double w0 = -(Jc[0][a] * Jl[0][0] + Jc[1][a] * Jl[1][0]);
-                const double w1 = -(Jc[0][a] * Jl[0][1] + Jc[1][a] * Jl[1][1]);
-                const double w2 = -(Jc[0][a] * Jl[0][2] + Jc[1][a] * Jl[1][2]);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Y[a][c] = w0 * Hi[c] + w1 * Hi[3 + c] + w2 * Hi[6 + c];
-            }
-            // barrel rotation: Y[a] <- Y[(a + rot) % DC]
-#pragma unroll
-            for (int sh = 1; sh < DC; sh <<= 1) {
-                const bool on = (rot & sh) != 0;
-                double T[DC][3];
-#pragma unroll
-                for (int a = 0; a < DC; ++a)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) T[a][c] = on ? Y[(a + sh) % DC][c] : Y[a][c];
-#pragma unroll
-                for (int a = 0; a < DC; ++a)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) Y[a][c] = T[a][c];
-            }
-        }
-        // the partner's camera index and measurement are fetched one trip ahead: a trip is ~500 dependent VALU
-        // instructions, about as long as the gather it would otherwise wait for at 2 waves per SIMD
-        uint32_t cj_next = 0;
-        double2 uv_next = make_double2(0.0, 0.0);
-        if (act && n > 0) { cj_next = v.o_cam[j0]; uv_next = v.o_uv[j0]; }
-        for (int q = 0; q < ck.nmax; ++q) {
-            const uint32_t cj = cj_next;
-            const double2 uvj = uv_next;
-            if (act && q + 1 < n) { cj_next = v.o_cam[j0 + q + 1]; uv_next = v.o_uv[j0 + q + 1]; }
-            if (!(act && q < n)) continue;
-            const int slot = hash_slot(hkey, hval, (int)cj);
-            if (slot < 0) continue;  // partner camera belongs to another chunk of this row
-            Cam cam_j;
-            load_cam_prepared(scam + slot * kCamPitch, cam_j);
-            double rj[2], Jcj[2][DC], Jlj[2][3];
-            linearize_obs<DC>(cam_j, pw, uvj.x, uvj.y, v.huber_delta, rj, Jcj, Jlj);
-            double* blk = acc + slot * E;
-            if (cj == ci) {  // the same camera sees the landmark twice: B + B^T, kept in the lower triangle
-#pragma unroll
-                for (int bb = 0; bb < DC; ++bb) {
-                    const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
-                    const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
-                    const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
-#pragma unroll
-                    for (int a = 0; a < DC; ++a) {
-                        const double val = Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2;
-                        const int ra = roff[a] / DC;   // the block row this register row stands for
-                        if (ra >= bb) unsafeAtomicAdd(&blk[ra * DC + bb], val);
-                        if (bb >= ra) unsafeAtomicAdd(&blk[bb * DC + ra], val);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int bb = 0; bb < DC; ++bb) {
-                    const double w0 = Jcj[0][bb] * Jlj[0][0] + Jcj[1][bb] * Jlj[1][0];
-                    const double w1 = Jcj[0][bb] * Jlj[0][1] + Jcj[1][bb] * Jlj[1][1];
-                    const double w2 = Jcj[0][bb] * Jlj[0][2] + Jcj[1][bb] * Jlj[1][2];
-#pragma unroll
-                    for (int a = 0; a < DC; ++a)
-                        unsafeAtomicAdd(&blk[roff[a] + bb], Y[a][0] * w0 + Y[a][1] * w1 + Y[a][2] * w2);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < t.nnbr * E; idx += kRow2Threads) {
-        const int s = idx / E, e = idx - s * E, a = e / DC, bb = e - a * DC;
-        const uint32_t cj = (uint32_t)nbr[t.nbr0 + s];
-        double* dst = s_block_ptr<DC>(tm, ci, cj) + a * kNB + bb;
-        if (cj == ci) { if (bb <= a && acc[idx] != 0.0) *dst += acc[idx]; }
-        else *dst = acc[idx];
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -573,10 +391,9 @@ __global__ __launch_bounds__(kLmWg * LANES) __attribute__((amdgpu_waves_per_eu(4
     const double pw[3] = {REC ? lrec[REC ? kLmPt : 0] : v.pts[3 * lc], REC ? lrec[REC ? kLmPt + 1 : 0] : v.pts[3 * lc + 1],
                           REC ? lrec[REC ? kLmPt + 2 : 0] : v.pts[3 * lc + 2]};
     const int i_first = max(min(b + g, (int)v.n_obs - 1), 0);
-    const int64_t rbase = (REC && v.bun_ptr) ? (int64_t)v.bun_ptr[lc] + 2 - b : 0;   // bundles: the record of observation i is unit rbase + i
     const double2* __restrict__ rec2 = reinterpret_cast<const double2*>(orec);
-    double2 uv_next = REC ? rec2[2 * (size_t)(rbase + i_first)] : v.o_uv[i_first];   // REC: (xn, yn) | (p_w.z, w)
-    double2 rw_next = REC ? rec2[2 * (size_t)(rbase + i_first) + 1] : make_double2(0.0, 0.0);
+    double2 uv_next = REC ? rec2[2 * (size_t)i_first] : v.o_uv[i_first];   // REC: (xn, yn) | (p_w.z, w)
+    double2 rw_next = REC ? rec2[2 * (size_t)i_first + 1] : make_double2(0.0, 0.0);
     int sl_next = v.o_slot ? (int)v.o_slot[i_first] : 255;
     stager.store(sCam);
     if (active) {
@@ -584,8 +401,8 @@ __global__ __launch_bounds__(kLmWg * LANES) __attribute__((amdgpu_waves_per_eu(4
             const double2 uv = uv_next, rw = rw_next;
             const int sl = sl_next;
             if (i + LANES < e) {
-                uv_next = REC ? rec2[2 * (size_t)(rbase + i + LANES)] : v.o_uv[i + LANES];
-                if (REC) rw_next = rec2[2 * (size_t)(rbase + i + LANES) + 1];
+                uv_next = REC ? rec2[2 * (size_t)(i + LANES)] : v.o_uv[i + LANES];
+                if (REC) rw_next = rec2[2 * (size_t)(i + LANES) + 1];
                 sl_next = v.o_slot ? (int)v.o_slot[i + LANES] : 255;
             }
             double dcv[DC];
@@ -1108,12 +925,6 @@ void launch_prepare_cams(int64_t n_cam, const double* poses, const double* intr,
     if (n_cam > 0) hipLaunchKernelGGL(k_prepare_cams, dim3(grid_for(n_cam, 256, 0)), dim3(256), 0, s, n_cam, poses, intr, camp, mask_code);
 }
 
-void launch_schur_rows2(int dc, const BAView& v, const TileMap& tm, const RowTask* tasks, int n_tasks,
-                        const RowChunk* chunks, const RowEntry* entries, const int* nbr, const double* hinv, hipStream_t s) {
-    if (n_tasks == 0) return;
-    if (dc == 9) hipLaunchKernelGGL((k_schur_rows2<9, kRowCap9>), dim3(n_tasks), dim3(kRow2Threads), 0, s, v, tm, tasks, chunks, entries, nbr, hinv);
-    else hipLaunchKernelGGL((k_schur_rows2<6, kRowCap6>), dim3(n_tasks), dim3(kRow2Threads), 0, s, v, tm, tasks, chunks, entries, nbr, hinv);
-}
 
 // orec != nullptr: the record form (the records of THIS linearisation, k_landmark_reduce); ignored in the masked modes
 static bool rec_form_ok(int dc, const BAView& v, const double* orec) { return orec != nullptr && v.mask_code == (dc == 9 ? 7 : 6); }
@@ -1181,65 +992,6 @@ void launch_sumsq(int64_t n, const double* x, double* partial, int n_partial, do
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n_partial, 1, out);
 }
 
-// The camera half from the projection records (round 5): the Jacobian of an observation follows from its record and the prepared
-// camera without the projection (jac_from_rec, ba_device.hpp) -- ~130 instead of ~500 fp64 instructions per observation, which
-// is what bounded k_implicit_cam.  corec: the records in CAMERA-major order (k_gather_records, once per linearisation; a PCG
-// solve reads them once per iteration).  With Jc = [a | -a [p]x | (xw, yw)^T t]:
-//     s   = a (x_rho + x_theta x p - u_l) + (xw, yw)^T (t . x_k)
-//     y_c = lambda x_c + sum_i [ a^T s | p x (a^T s) | t (xw s0 + yw s1) ]
-// Only for the modes that optimise every column group the factor has (rec_form_ok), like the landmark half.
-template <int DC>
-__global__ __launch_bounds__(64) void k_implicit_cam_rec(BAView v, const int* __restrict__ cam_ptr, const double2* __restrict__ corec,
-                                                           const double* __restrict__ lmu, const double* __restrict__ x,
-                                                           double lambda, double* __restrict__ y) {
-    const uint32_t c = blockIdx.x;
-    double cv[kCamStride];
-#pragma unroll
-    for (int a = 0; a < kCamStride; ++a) cv[a] = v.camp[kCamStride * (size_t)c + a];
-    double xc[DC], acc[DC];
-#pragma unroll
-    for (int a = 0; a < DC; ++a) { xc[a] = x[(size_t)c * DC + a]; acc[a] = 0.0; }
-    const int b = cam_ptr[c], e = cam_ptr[c + 1];
-    for (int k = b + (int)threadIdx.x; k < e; k += 64) {
-        const uint32_t l = v.co_pt[k];
-        const double2 r01 = corec[2 * (size_t)k], r23 = corec[2 * (size_t)k + 1];
-        const double2* q = reinterpret_cast<const double2*>(lmu + kLmuStride * (size_t)l);
-        const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-        const double pw[3] = {q0.x, q0.y, q1.x}, u[3] = {q2.x, q2.y, q3.x};
-        RecJac j;
-        jac_from_rec(cv, r01, r23, pw, j);
-        const double w3[3] = {xc[0] + (xc[4] * pw[2] - xc[5] * pw[1]) - u[0], xc[1] + (xc[5] * pw[0] - xc[3] * pw[2]) - u[1],
-                              xc[2] + (xc[3] * pw[1] - xc[4] * pw[0]) - u[2]};
-        double s0 = j.a[0][0] * w3[0] + j.a[0][1] * w3[1] + j.a[0][2] * w3[2];
-        double s1 = j.a[1][0] * w3[0] + j.a[1][1] * w3[1] + j.a[1][2] * w3[2];
-        if (DC == 9) {
-            const double tk = j.t[0] * xc[6 % DC] + j.t[1] * xc[7 % DC] + j.t[2] * xc[8 % DC];
-            s0 += j.xw * tk; s1 += j.yw * tk;
-        }
-        const double g[3] = {j.a[0][0] * s0 + j.a[1][0] * s1, j.a[0][1] * s0 + j.a[1][1] * s1, j.a[0][2] * s0 + j.a[1][2] * s1};
-        acc[0] += g[0]; acc[1] += g[1]; acc[2] += g[2];
-        acc[3] += pw[1] * g[2] - pw[2] * g[1]; acc[4] += pw[2] * g[0] - pw[0] * g[2]; acc[5] += pw[0] * g[1] - pw[1] * g[0];
-        if (DC == 9) {
-            const double sk = j.xw * s0 + j.yw * s1;
-            acc[6 % DC] += j.t[0] * sk; acc[7 % DC] += j.t[1] * sk; acc[8 % DC] += j.t[2] * sk;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < DC; ++a) {
-        const double t = wave_sum(acc[a]);
-        double lam = lambda;
-        if (v.cam_scale) { const double sc = v.cam_scale[(size_t)c * DC + a]; lam = lambda / (sc * sc); }
-        if (threadIdx.x == 0) y[(size_t)c * DC + a] = t + lam * xc[a];
-    }
-}
-__global__ __launch_bounds__(256) void k_gather_records(int64_t n, const int* __restrict__ cam_obs, const double2* __restrict__ orec,
-                                                          double2* __restrict__ corec) {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k >= n) return;
-    const size_t i = (size_t)cam_obs[k];
-    const double2 a = orec[2 * i], b2 = orec[2 * i + 1];
-    corec[2 * (size_t)k] = a; corec[2 * (size_t)k + 1] = b2;
-}
 // the three clears at the head of an assembly (g_red, g_c, the error flags) as one launch
 __global__ __launch_bounds__(256) void k_clear3(double* __restrict__ a, double* __restrict__ b, int64_t n, int* __restrict__ f, int nf) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { a[i] = 0.0; b[i] = 0.0; }
@@ -1264,15 +1016,9 @@ void launch_gather_uv(int64_t n, const int* idx, const double* src, double* dst,
 void launch_gather_u32(int64_t n, const int* idx, const uint32_t* src, uint32_t* dst, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_gather_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, idx, src, dst);
 }
-// the projection records in camera-major order (the record form of the camera half of the matrix-free operator)
-void launch_gather_records(int64_t n_obs, const int* cam_obs, const double* orec, double* corec, hipStream_t s) {
-    if (n_obs > 0) hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((n_obs + 255) / 256)), dim3(256), 0, s, n_obs, cam_obs,
-                                      reinterpret_cast<const double2*>(orec), reinterpret_cast<double2*>(corec));
-}
-
 // y = S x without S: landmark half (u_l into lmu), then camera half
 void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
-                            double lambda, double* y, hipStream_t s, const double* orec, const double* corec) {
+                            double lambda, double* y, hipStream_t s, const double* orec) {
     if (v.n_pt > 0) {
         const int grid = (int)((v.n_pt + kLmWg - 1) / kLmWg);
         if (rec_form_ok(dc, v, orec)) {
@@ -1282,12 +1028,6 @@ void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const d
             if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, nullptr, nullptr, nullptr);
             else hipLaunchKernelGGL((k_back_substitute<6, true, false>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, nullptr, nullptr, nullptr);
         }
-    }
-    if (corec && rec_form_ok(dc, v, orec)) {
-        const double2* cr = reinterpret_cast<const double2*>(corec);
-        if (dc == 9) hipLaunchKernelGGL(k_implicit_cam_rec<9>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, cr, lmu, x, lambda, y);
-        else hipLaunchKernelGGL(k_implicit_cam_rec<6>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, cr, lmu, x, lambda, y);
-        return;
     }
     if (dc == 9) hipLaunchKernelGGL(k_implicit_cam<9>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, lmu, x, lambda, y);
     else hipLaunchKernelGGL(k_implicit_cam<6>, dim3((unsigned)v.n_cam), dim3(64), 0, s, v, cam_ptr, lmu, x, lambda, y);

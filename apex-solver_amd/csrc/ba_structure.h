@@ -27,15 +27,10 @@ struct BaStructOptions {
     int rank = 0, world = 1;
     bool dist_factor = true, tree_sharding = true;
     int dist_selftest = 0;
-    int schur_form = 3;        // 3 sorted pair list, 4 the same pairs in the queued layout (d_c = 9; schur_pairs.h), 2 LDS rows (k_schur_rows2, the A/B)
+    int schur_form = 3;        // 3 sorted pair list, 4 the same pairs in the queued layout (d_c = 9; schur_pairs.h); < 0: none (matrix-free only)
     int pair_task_slots = 0;   // pair slots per wave task of the pair list (0: default)
     bool device_gathers = false;   // the measurement lists (o_uv, co_uv) and co_pt are gathered on the device from the caller's array and the
                                    // index lists (Solver::set_structure, single rank): the host does not build them
-    bool bundles = false;      // landmark bundles (BAView::bun_ptr): the projection records behind a copy of the landmark record's first line
-    bool queued6 = false;      // the queued layout also for six-column cameras (sixteen queues of four pairs).  Built in round 5 and
-                               // MEASURED SLOWER than form 3 there (final-13682, BundleAdjustment mode: 3.52 against 2.90 ms -- a 6 x 6
-                               // block has nothing to gain from the fixed nine-step product loop, and a chunk stages sixteen partner
-                               // cameras and seventeen descriptors instead of eight and four): the A/B, off by default
 };
 
 struct BaHostStructure {
@@ -55,19 +50,11 @@ struct BaHostStructure {
     raw_vector<double> o_uv;
     raw_vector<int> o_orig, cam_obs;
     std::vector<int> pt_ptr, cam_ptr;
-    std::vector<int> bun_ptr;          // [n_pt] landmark bundles: header unit of every landmark with local observations (BAView::bun_ptr)
-    int64_t bun_units = 0;             // 32-byte units of the bundle array (+ slack for the kernels' clamped prefetches)
-    int bun_pad_unit = 0, bun_pad_header = 0;   // a real record and its header, for the pair list's padding slots
     raw_vector<uint32_t> co_pt;
     raw_vector<double> co_uv;
     raw_vector<int> co_rank;
     int64_t n_pairs = 0, n_present = 0;
-    // Schur task lists (only the selected form is built)
-    std::vector<int> nbr;
-    std::vector<RowTask> rtasks2;
-    std::vector<RowEntry> rentries;
-    std::vector<RowChunk> rchunks;
-    PairLists pl;
+    PairLists pl;                      // the Schur reduction's task lists (schur_pairs.h)
     double seconds[6] = {0, 0, 0, 0, 0, 0};  // order + tile structure | sharding + lists | tile plan | Schur lists | uploads | total
 
     // Step 1: camera order, tile structure, sharding, observation lists.  Applies the partition settings to `tp`

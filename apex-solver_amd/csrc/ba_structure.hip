@@ -384,23 +384,6 @@ std::string BaHostStructure::build_obs_lists(const uint32_t* cam_idx, const uint
     });
     n_pairs = 0;
     for (int64_t l = lm_lo; l < lm_hi; ++l) { const int64_t k = pt_ptr[l + 1] - pt_ptr[l]; n_pairs += k * (k + 1) / 2; }   // 4 M adds
-    // landmark bundles: [64-byte header | 32-byte record per local observation], rounded up to 128 bytes (4 units)
-    bun_ptr.clear(); bun_units = 0; bun_pad_unit = bun_pad_header = 0;
-    if (o.bundles) {
-        bun_ptr.assign(n_pt, 0);
-        int64_t u = 0;
-        bool have_pad = false;
-        for (int64_t l = 0; l < n_pt; ++l) {
-            const int64_t k = pt_ptr[l + 1] - pt_ptr[l];
-            bun_ptr[l] = (int)u;
-            if (k > 0) {
-                if (!have_pad) { have_pad = true; bun_pad_header = (int)u; bun_pad_unit = (int)u + 2; }
-                u += (2 + k + 3) / 4 * 4;
-            }
-        }
-        if (u + 16 > 0x7fffffffLL) { bun_ptr.clear(); }   // (beyond 64 GB of bundles: fall back to plain records)
-        else bun_units = u + 16;
-    }
     tr.mark("lists: camera-major");
     seconds[1] = now_s() - t1;
     return "";
@@ -413,77 +396,13 @@ void BaHostStructure::release_scratch() {
 
 void BaHostStructure::build_schur_lists(const BaStructOptions& o, const int* slot_host, PairDeviceTables* dev_tables) {
     const double t0 = now_s();
-    nbr.clear(); rtasks2.clear(); rentries.clear(); rchunks.clear();
     pl = PairLists();
-    if (o.schur_form < 0) {
-        // a matrix-free-only handle: S is never reduced, no lists
-    } else if (o.schur_form == 3 || o.schur_form == 4) {
-        // every camera pair (i, j) of a landmark, sorted by the block S(cam_i, cam_j) it adds to
+    if (o.schur_form >= 0)   // (< 0: a matrix-free-only handle -- S is never reduced, no lists)
+        // every camera pair (i, j) of a landmark, sorted by the block S(cam_i, cam_j) it adds to; nine-column cameras in the
+        // queued layout (form 4), whose records the device can write itself (dev_tables)
         build_pair_lists(dc, nt, slot_host, n_cam, cinv.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(),
-                         cam_obs.data(), &pl, o.pair_task_slots, /*queued=*/o.schur_form == 4 && (dc == 9 || o.queued6),
-                         (o.schur_form == 4 && (dc == 9 || o.queued6)) ? dev_tables : nullptr, bun_ptr.empty() ? nullptr : bun_ptr.data());
-    } else {
-        // ---- k_schur_rows2 (the LDS row form, kept as the A/B of the pair list): neighbour lists (cameras cj <= ci sharing a
-        // landmark with ci, from the FULL problem so that every rank writes the same blocks), row entries, row tasks --------
-        std::vector<int> nbr_ptr(n_cam + 1, 0);
-        {
-            std::vector<std::vector<int>> lists(n_cam);
-            std::vector<int64_t> fcp(n_cam + 1, 0);
-            for (int64_t i = 0; i < n_obs; ++i) fcp[cam_i_[i] + 1]++;
-            for (int64_t c = 0; c < n_cam; ++c) fcp[c + 1] += fcp[c];
-            std::vector<int> fco(n_obs);
-            {
-                std::vector<int64_t> fill(fcp.begin(), fcp.end() - 1);
-                for (int64_t i = 0; i < n_obs; ++i) fco[fill[cam_i_[i]]++] = (int)i;
-            }
-            parallel_ranges(n_cam, 16, [&](int64_t cb, int64_t ce) {
-                std::vector<int> stamp(n_cam, -1);
-                for (int64_t c = cb; c < ce; ++c) {
-                    auto& L = lists[c];
-                    for (int64_t e = fcp[c]; e < fcp[c + 1]; ++e) {
-                        const uint32_t l = pt_i_[fco[e]];
-                        for (int64_t k = full_ptr_[l]; k < full_ptr_[l + 1]; ++k) {
-                            const int cj = (int)cam_i_[full_obs_[k]];
-                            if (cj < c && stamp[cj] != (int)c) { stamp[cj] = (int)c; L.push_back(cj); }
-                        }
-                    }
-                    std::sort(L.begin(), L.end());
-                    L.push_back((int)c);  // the camera itself closes its list
-                }
-            });
-            for (int64_t c = 0; c < n_cam; ++c) nbr_ptr[c + 1] = nbr_ptr[c] + (int)lists[c].size();
-            nbr.reserve(nbr_ptr[n_cam]);
-            for (auto& L : lists) nbr.insert(nbr.end(), L.begin(), L.end());
-        }
-        const int cap = (dc == 9) ? kRowCap9 : kRowCap6;
-        {
-            // k_schur_rows2: one entry per observation of a camera (split at kRowMaxPartners partners), sorted by partner
-            // count so that the 64 lanes of a wave loop the same number of times; chunks of <= 64 entries, largest first
-            std::vector<RowEntry> ce;
-            for (int64_t c = 0; c < n_cam; ++c) {
-                ce.clear();
-                for (int e = cam_ptr[c]; e < cam_ptr[c + 1]; ++e) {
-                    const int i_s = cam_obs[e];
-                    const int base = pt_ptr[o_pt[i_s]], np = i_s - base;
-                    for (int q0 = 0; q0 < np; q0 += kRowMaxPartners)
-                        ce.push_back(RowEntry{e, base + q0, std::min(kRowMaxPartners, np - q0), 0});
-                }
-                std::stable_sort(ce.begin(), ce.end(), [](const RowEntry& a, const RowEntry& b) { return a.n > b.n; });
-                const int c0 = (int)rchunks.size();
-                for (size_t f = 0; f < ce.size(); f += 64) {
-                    const int cnt = (int)std::min<size_t>(64, ce.size() - f);
-                    rchunks.push_back(RowChunk{(int)(rentries.size() + f), cnt, ce[f].n});
-                }
-                rentries.insert(rentries.end(), ce.begin(), ce.end());
-                const int nc2 = (int)rchunks.size() - c0;
-                const int n0 = nbr_ptr[c], nn = nbr_ptr[c + 1] - nbr_ptr[c];
-                for (int s0 = 0; s0 < nn; s0 += cap) {
-                    const int cnt = std::min(cap, nn - s0);
-                    rtasks2.push_back(RowTask{(int)c, n0 + s0, cnt, (s0 + cnt == nn) ? 1 : 0, c0, nc2});
-                }
-            }
-        }
-    }
+                         cam_obs.data(), &pl, o.pair_task_slots, /*queued=*/o.schur_form == 4 && dc == 9,
+                         (o.schur_form == 4 && dc == 9) ? dev_tables : nullptr);
     seconds[3] = now_s() - t0;
 }
 

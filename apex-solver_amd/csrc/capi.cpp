@@ -237,7 +237,7 @@ int apexgpu_debug_partition(int nt, const uint8_t* present, int world, int* owne
     });
 }
 
-int apexgpu_debug_check_schedule(int nt, const uint8_t* present, int world, int rank, const int opts[9], int64_t out[8], char* msg, int msg_len) {
+int apexgpu_debug_check_schedule(int nt, const uint8_t* present, int world, int rank, const int opts[8], int64_t out[8], char* msg, int msg_len) {
     if (nt <= 0 || !present || !opts || !out || world < 1 || rank < 0 || rank >= world) return APEXGPU_ERR_INVALID_INPUT;
     return guarded([&]() -> int {
     apex::TilePlan tp;
@@ -245,7 +245,6 @@ int apexgpu_debug_check_schedule(int nt, const uint8_t* present, int world, int 
     tp.set_two_side(opts[0]);
     tp.enable_overlap(opts[1] != 0); if (opts[1] > 1) tp.set_overlap_min(opts[1]);
     tp.set_split_u1(opts[2]);
-    tp.set_panel_split(opts[8]);
     tp.set_gate_min(opts[3]);
     tp.set_factor_flow(opts[4], opts[5]);
     tp.debug_skip_idle_level_wait(opts[6] != 0);
@@ -285,62 +284,36 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     H_OR_FAIL;
     const std::string n = name ? name : "";
     // Switches that shape what set_structure builds (task lists, tile order, partition) or what the captured hipGraphs
-    // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never
-    // built.  ("potrf_lookahead" is process-wide; it must precede every handle's set_structure.)
-    static const char* const structural[] = {"schur_rows", "schur_form", "hubs_last", "pair_task_slots", "potrf_lookahead", "panel_tri", "panel_small_max", "update_small_max", "dist_factor", "tree_sharding", "dist_selftest",
-                                             "nested_dissection", "update_overlap", "fused_forward", "split_u1", "panel_split", "fwd_beside_top", "tri_inline", "first_writer", "rec_backsub", "flood_gate", "flood_gate_pos", "two_side", "factor_flow", "factor_flow_rows", "factor_flow_tile", "factor_flow_dyn", "device_pair_list", "device_gathers", "landmark_bundles", "pairs_queued6", "matrix_free_only", "auto_variant", "max_tile_updates"};
+    // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never built.
+    static const char* const structural[] = {"schur_form", "hubs_last", "dist_factor", "tree_sharding", "dist_selftest", "nested_dissection", "update_overlap",
+                                             "split_u1", "flood_gate", "two_side", "factor_flow", "factor_flow_rows", "device_pair_list", "matrix_free_only",
+                                             "auto_variant", "variant_cost_percent", "max_tile_updates"};
     if (h->s->has_structure())
         for (const char* k : structural)
             if (n == k) return APEXGPU_ERR_INVALID_STATE;
-    if (n == "schur_rows" || n == "schur_form") {   // 3 sorted pair list (default), 2 LDS rows; the forms 0 / 1 of rounds 1-3 are gone
-        if (value != 3 && value != 2 && value != 4) return APEXGPU_ERR_INVALID_INPUT;
-        h->s->use_row_schur(value);
+    if (n == "schur_form") {   // 4 the queued pair list (default; nine-column cameras), 3 the pair list with one running block per wave
+        if (value != 3 && value != 4) return APEXGPU_ERR_INVALID_INPUT;
+        h->s->set_schur_form(value);
     }
     else if (n == "graphs") h->s->enable_graphs(value != 0);
     else if (n == "update_overlap") { h->s->enable_overlap(value != 0); if (value > 1) h->s->set_overlap_min(value); }
     else if (n == "tri_dataflow") h->s->enable_tri_flow(value != 0);
     else if (n == "split_u1") h->s->set_split_u1(value);
-    else if (n == "panel_split") h->s->set_panel_split(value);
-    else if (n == "fwd_beside_top") h->s->set_fwd_beside_top(value != 0);
-    else if (n == "tri_inline") h->s->set_tri_inline(value);
-    else if (n == "first_writer") h->s->set_first_writer(value != 0);
     else if (n == "flood_gate") h->s->set_gate_min(value);
-    else if (n == "flood_gate_pos") h->s->set_gate_pos(value);
     else if (n == "two_side") h->s->set_two_side(value);
     else if (n == "matrix_free_only") h->s->set_matrix_free_only(value != 0);
     else if (n == "auto_variant") h->s->set_auto_variant(value != 0);
+    else if (n == "variant_cost_percent") h->s->set_variant_cost_percent(value);
     else if (n == "device_pair_list") h->s->set_device_pair_recs(value != 0);
-    else if (n == "pairs_queued6") h->s->set_queued6(value != 0);
-    else if (n == "landmark_bundles") h->s->set_bundles(value != 0);
-    else if (n == "prezero_tiles") h->s->set_prezero(value != 0);
     else if (n == "eager_step_eval") h->s->set_eager_step_eval(value != 0);
-    else if (n == "device_gathers") h->s->set_device_gathers(value != 0);
-    else if (n == "implicit_cam_records") h->s->set_implicit_cam_records(value != 0);
-    else if (n == "cam_beside_pairs") h->s->set_cam_beside_pairs(value != 0);
-    else if (n == "zero_beside_lm") h->s->set_zero_beside_lm(value != 0);
     else if (n == "one_wait") h->s->set_one_wait(value != 0);
     else if (n == "max_tile_updates") h->s->set_max_tile_updates(value);
     else if (n == "factor_flow") h->s->set_factor_flow(value, 0);          // max columns per level group inside the dataflow launch (0: off)
-    else if (n == "factor_flow_tile") h->s->set_factor_flow_tile(value != 0);
-    else if (n == "factor_flow_dyn") h->s->set_factor_flow_dyn(value != 0);
     else if (n == "factor_flow_rows") h->s->set_factor_flow(h->s->plan().factor_flow_cols(), value);
-    else if (n == "rec_backsub") h->s->set_rec_backsub(value != 0);
-    else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
-    else if (n == "panel_tri") apex::set_panel_tri(value);
-    else if (n == "panel_small_max") apex::set_gemm_small_max(value, -1);
-    else if (n == "update_small_max") apex::set_gemm_small_max(-1, value);
-    else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
-    else if (n == "pairs_ablation") {   /* timing experiments only: the results are WRONG when != 0, so the switch exists only */
-        if (value != 0 && !getenv("APEX_ALLOW_ABLATION")) return APEXGPU_ERR_INVALID_INPUT;   /* for a process that asks for it */
-        h->s->set_pairs_ablation(value);
-    }
-    else if (n == "pairs_variant") { if (value != 2) return APEXGPU_ERR_INVALID_INPUT; }   /* one pair kernel is left: the record form (2) */
-    else if (n == "cam_staging") h->s->set_cam_staging(value != 0);
     else if (n == "debug_poison_sweep") h->s->debug_poison_next_solve(value);   /* tests: 1 / 2 = the next solve's forward / backward dataflow sweep times out */
     else if (n == "debug_poison_factor") h->s->debug_poison_next_factor();       /* tests: the next factorisation's dataflow launch times out */
     else if (n == "debug_occupy_cus") return h->s->debug_occupy_cus(value, 40000);   /* tests: block `value` CUs for 40 ms, starting now */
     else if (n == "hubs_last") h->s->set_hubs_last(value != 0);
-    else if (n == "pair_task_slots") h->s->set_pair_task_slots(value);
     else if (n == "dist_factor") h->s->set_dist_factor(value != 0);
     else if (n == "tree_sharding") h->s->set_tree_sharding(value != 0);
     else if (n == "dist_selftest") h->s->set_dist_selftest(value);
@@ -392,6 +365,13 @@ int apexgpu_trim_host_cache(int64_t* released_bytes) {
     if (released_bytes) *released_bytes = (int64_t)n;
     return APEXGPU_OK;
 }
+int apexgpu_variant_costs(apexgpu_solver* h, double out[4]) {
+    H_OR_FAIL;
+    if (!out) return APEXGPU_ERR_INVALID_INPUT;
+    h->s->variant_costs(out);
+    return APEXGPU_OK;
+}
+int64_t apexgpu_host_cache_bytes(void) { return (int64_t)apex::HostBlockCache::get().kept_bytes(); }
 int apexgpu_variant_info(apexgpu_solver* h, int asked_variant, int* used_variant, char* reason, int reason_len) {
     H_OR_FAIL;
     if (asked_variant != APEXGPU_VARIANT_SPARSE && asked_variant != APEXGPU_VARIANT_ITERATIVE && asked_variant != APEXGPU_VARIANT_IMPLICIT)
@@ -406,13 +386,6 @@ int apexgpu_variant_info(apexgpu_solver* h, int asked_variant, int* used_variant
     return APEXGPU_OK;
 }
 
-int apexgpu_debug_pair_phases(int64_t out[8], int reset) {
-    if (!out) return APEXGPU_ERR_INVALID_INPUT;
-    unsigned long long v[8];
-    apex::pairs_phase_cycles(v, reset != 0);
-    for (int k = 0; k < 8; ++k) out[k] = (int64_t)v[k];
-    return APEXGPU_OK;
-}
 int apexgpu_counters(apexgpu_solver* h, int64_t out[4]) {
     H_OR_FAIL;
     if (!out) return APEXGPU_ERR_INVALID_INPUT;
@@ -676,22 +649,11 @@ int apexgpu_pg_set_option(apexgpu_pg_solver* h, const char* name, int value) {
     else if (n == "tri_dataflow") h->s->enable_tri_flow(value != 0);
     else if (n == "two_side") h->s->set_two_side(value);
     else if (n == "factor_flow") h->s->set_factor_flow(value, 0);
-    else if (n == "factor_flow_tile") h->s->set_factor_flow_tile(value != 0);
-    else if (n == "factor_flow_dyn") h->s->set_factor_flow_dyn(value != 0);
     else if (n == "factor_flow_rows") h->s->set_factor_flow(h->s->plan().factor_flow_cols(), value);
     else if (n == "flood_gate") h->s->set_gate_min(value);
     else if (n == "split_u1") h->s->set_split_u1(value);
-    else if (n == "panel_split") h->s->set_panel_split(value);
-    else if (n == "fwd_beside_top") h->s->set_fwd_beside_top(value != 0);
-    else if (n == "tri_inline") h->s->set_tri_inline(value);
-    else if (n == "first_writer") h->s->set_first_writer(value != 0);
     else if (n == "one_wait") h->s->set_one_wait(value != 0);
     else if (n == "eager_step_eval") h->s->set_eager_step_eval(value != 0);
-    else if (n == "potrf_lookahead") apex::set_potrf_lookahead(value);
-    else if (n == "panel_tri") apex::set_panel_tri(value);
-    else if (n == "panel_small_max") apex::set_gemm_small_max(value, -1);
-    else if (n == "update_small_max") apex::set_gemm_small_max(-1, value);
-    else if (n == "fused_forward") h->s->enable_fused_forward(value != 0);
     else if (n == "nested_dissection") h->s->set_nd(value != 0, value > 1 ? value : 0);
     else if (n == "debug_poison_sweep") h->s->debug_poison_next_solve(value);
     else if (n == "debug_poison_factor") h->s->debug_poison_next_factor();

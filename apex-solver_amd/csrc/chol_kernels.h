@@ -30,7 +30,7 @@ struct FactorUnit {   // one workgroup of the dataflow factorisation of the top 
     int pub;              // index into the version array: += 1 per finished unit (kFlowUnitsPerTile per tile and writer), += 9 by a potrf
     int kind;             // 0 potrf + inverse, 1 panel solve C = A B^T (in place), 2 update C -= A B^T (one 48 x 48 block), 3 update, the whole tile (publishes 9)
     int strip;            // panel solve: 16-row strip 0..8 of C; update: 48 x 48 block 3 bi + bj of C; potrf: tile column (for the failure flag)
-    int pad;              // dynamic scheduling (k_factor_flow_dyn): index of this unit's tile's first (tile, writer) node in the waiter lists
+    int pad;
 };
 
 struct TriTask {   // one workgroup of a triangular-solve step (k_tri_step)
@@ -75,12 +75,6 @@ void launch_gate(const int* arrived, int expected, int max_micros, hipStream_t s
 // the dataflow factorisation: one workgroup per unit, dispatched in list order; ver[] must be zero; err: error word (time-out)
 void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, hipStream_t s,
                         unsigned long long* trace = nullptr);
-// the same units scheduled dynamically (one persistent workgroup per CU, a queue of ready units): see k_factor_flow_dyn
-void launch_factor_flow_dyn(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, int* pending, int* q, int* ctr,
-                            const int* wl_ptr, const int* wl, int n_workgroups, hipStream_t s, unsigned long long* trace);   // trace (tools only): 3 stamps of the 100 MHz clock per unit
-void set_gemm_small_max(int panel, int update);   // process-wide: largest batch that uses the latency kernels (-1: keep); default kGemmSmallMax = 56 for both
-void set_panel_tri(int on);          // process-wide A/B switch: 1 (default) the panel solves skip the zero blocks of Linv
-void set_potrf_lookahead(int mode);  // process-wide A/B switch: 0 k_potrf_inv, 1 / 6 / 8 k_potrf_inv_la with 4 / 6 / 8 waves, 9 / 12 k_potrf_inv_mf with 8 / 12 waves (12: default)
 // batches of <= 56 tasks use the latency kernels, larger ones the four-wave strip kernel (three workgroups per tile)
 // tri_b: every B is a lower-triangular inverse written by launch_potrf_inv (zero 16 x 16 blocks right of the diagonal): the
 // large-batch kernel then skips the 36 of 81 block products that multiply by them.

@@ -4,7 +4,7 @@
 // right-looking tile algorithm; only tiles that are structurally non-zero after symbolic fill
 // (computed once on the host, tile granularity) exist, so a banded S costs O(n b^2) and a dense
 // one runs the classic dense schedule:
-//     for K:   L_KK, L_KK^-1  <- potrf_inv(S_KK)                    k_potrf_inv   (1 workgroup)
+//     for K:   L_KK, L_KK^-1  <- potrf_inv(S_KK)                    k_potrf_inv_mf (1 workgroup)
 //              L_IK  <- S_IK L_KK^-T            for I > K           k_tile_gemm   (NT GEMM with L_KK^-1)
 //              S_IJ -= L_IK L_JK^T              for I >= J > K      k_tile_gemm   (fp64 MFMA 16x16x4)
 // The trailing update is >99 % of the flops and runs on v_mfma_f64_16x16x4_f64.
@@ -22,21 +22,18 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int NB = kNB;
 // ------------------------------------------------------------------------------------------
-// potrf + triangular inverse of one diagonal tile: the latency-critical link of the tile Cholesky
-// (every column K waits for it).  THIS first kernel (k_potrf_inv, "potrf_lookahead" 0) is the round-1 form, kept as the
-// A/B and as the plain statement of the algorithm; the default since round 4 is k_potrf_inv_mf<12> further down (768
-// threads: wave 0 keeps the 16 x 16 pivot block and its inverse as two MFMA accumulators, two pivots per matrix
-// instruction, nine helper waves for the trailing update; 37 us per tile against this kernel's ~64), k_potrf_inv_la the
-// round-3 look-ahead form in between.  All three share the LDS layout below.
-// One 256-thread workgroup; the tile lives in LDS as the 45 lower
-// 16x16 blocks (pitch 18 doubles -> conflict-free MFMA operand reads), 101 KB, plus the 9 inverted
-// diagonal blocks, 20 KB.  Blocked right-looking factorisation:
-//   per block column kb:  wave 0 factors the 16x16 diagonal block in registers (shuffles, no
-//   barriers) and inverts it by forward substitution; the panel solve X = A L_kk^-T and the rank-16
-//   trailing update run on v_mfma_f64_16x16x4_f64, blocks dealt round-robin to the 4 waves.
-// Then L is written out and inverted in place block-column by block-column (LAPACK dtrtri, lower):
-//   Linv(i,j) = -(sum_{k=j+1..i} Linv(i,k) L(k,j)) Linv(j,j).
-// fail[0] is set to K+1 if a pivot is not positive (faer's Llt: NonPositivePivot).
+// potrf + triangular inverse of one diagonal tile: the latency-critical link of the tile Cholesky (every column K waits for
+// it).  One workgroup per tile; the tile lives in LDS as the 45 lower 16 x 16 blocks (pitch 18 doubles -> conflict-free MFMA
+// operand reads), 101 KB, plus the 9 inverted diagonal blocks, 20 KB.  Blocked right-looking factorisation with look-ahead:
+//   step kb:  P1  wave 0: the 16 x 16 diagonal block D_kb and its inverse  | the other waves: trailing update of step kb-1 for
+//                                                                         | the columns > kb; row kb-1 of L^-1 (into registers)
+//             P2  panel A(i,kb) <- A(i,kb) D_kb^-T (i > kb);  row kb of L goes to global memory and becomes
+//                 L~(kb,k) = D_kb^-1 L(kb,k) in place (k < kb);  look-ahead: wave 0, which solved the panel block (kb+1, kb)
+//                 itself, gives the next diagonal block this step's update right away
+// with  L^-1(r,j) = - sum_{k=j}^{r-1} L~(r,k) L^-1(k,j),  L^-1(k,k) = D_k^-1  (row-oriented dtrtri): row r of L is dead once
+// step r has used it, so its blocks are reused for L~ and then L^-1.  fail[0] is set to K+1 if a pivot is not positive
+// (faer's Llt: NonPositivePivot).  (Rounds 1-3 ran this on the vector unit -- k_potrf_inv 85 us per tile, k_potrf_inv_la with
+// the look-ahead above 58-65 us -- both deleted in round 6; k_potrf_inv_mf below, round 4, 37 us, is the one that runs.)
 // ------------------------------------------------------------------------------------------
 constexpr int BS = 16;            // block edge
 constexpr int NBK = NB / BS;      // 9 blocks per tile edge
@@ -83,211 +80,6 @@ __device__ __forceinline__ void blk_store_cd(double* C, double4_t v, int lr, int
     for (int r = 0; r < 4; ++r) C[(lk + 4 * r) * BP + lr] = sgn * v[r];
 }
 
-__global__ __launch_bounds__(256) void k_potrf_inv(const PotrfTask* __restrict__ tasks, int* __restrict__ fail) {
-    const PotrfTask pt = tasks[blockIdx.x];
-    double* __restrict__ A = pt.A;
-    double* __restrict__ Linv = pt.Linv;
-    const int K = pt.K;
-    __shared__ double sA[NLB * BSZ];
-    __shared__ double sD[NBK * BSZ];
-    __shared__ int bad;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int lr = lane & 15, lk = lane >> 4;
-    if (tid == 0) bad = 0;
-    // lower blocks only, as 16-byte loads all issued before the first LDS store: block-row bi holds
-    // 16 rows x 8(bi+1) double2; 25 loads per lane cover the 5760 double2 of the lower blocks
-    {
-        double2 reg[25];
-        int n = 0;
-#pragma unroll
-        for (int bi = 0; bi < NBK; ++bi) {
-            const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
-#pragma unroll
-            for (int it = 0; it < (16 * 8 * (bi + 1) + 255) / 256; ++it, ++n) {
-                const int idx = tid + 256 * it;
-                if (idx < cnt) {
-                    const int rr = idx / per_row, c2 = idx - rr * per_row;
-                    reg[n] = *reinterpret_cast<const double2*>(A + (size_t)(16 * bi + rr) * NB + 2 * c2);
-                }
-            }
-        }
-        n = 0;
-#pragma unroll
-        for (int bi = 0; bi < NBK; ++bi) {
-            const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
-#pragma unroll
-            for (int it = 0; it < (16 * 8 * (bi + 1) + 255) / 256; ++it, ++n) {
-                const int idx = tid + 256 * it;
-                if (idx < cnt) {
-                    const int rr = idx / per_row, c2 = idx - rr * per_row;
-                    double* dst = sA + bidx(bi, c2 >> 3) * BSZ + rr * BP + 2 * (c2 & 7);
-                    dst[0] = reg[n].x; dst[1] = reg[n].y;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    for (int kb = 0; kb < NBK; ++kb) {
-        double* D = sA + bidx(kb, kb) * BSZ;
-        if (w == 0) {
-            // ---- 16x16 Cholesky + inverse in registers: lane r (= lane & 15) owns row r; every
-            // cross-lane operand has a compile-time lane index, so it is a v_readlane (SGPR
-            // broadcast), not an LDS permute.
-            double a[BS], invd[BS];
-#pragma unroll
-            for (int c = 0; c < BS; ++c) a[c] = D[lr * BP + c];
-            int isbad = 0;
-#pragma unroll
-            for (int j = 0; j < BS; ++j) {
-                const double djj = readlane_f64(a[j], j);
-                if (!(djj > 0.0)) isbad = 1;
-                // 1/sqrt(d) from the hardware estimate + two Newton steps (to the last bit or two), then
-                // sqrt(d) = d * (1/sqrt(d)) with one correction: no v_sqrt_f64 fix-up and no division on
-                // the critical path of the 16 dependent pivot steps
-                const double dj = djj > 0.0 ? djj : 1.0;
-                double isj = __builtin_amdgcn_rsq(dj);
-                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
-                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
-                double sj = dj * isj;
-                sj = fma(0.5 * isj, fma(-sj, sj, dj), sj);
-                invd[j] = isj;
-                const double lrj = a[j] * isj;  // L[r][j] for r > j
-#pragma unroll
-                for (int c = j + 1; c < BS; ++c) {
-                    const double lcj = readlane_f64(lrj, c);
-                    if (lr >= c) a[c] -= lrj * lcj;
-                }
-                a[j] = (lr > j) ? lrj : ((lr == j) ? sj : a[j]);
-            }
-            // inverse: lane c solves L x = e_c ; L[i][k] = row i's a[k]
-            double x[BS];
-#pragma unroll
-            for (int i = 0; i < BS; ++i) {
-                double acc = (i == lr) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < i; ++k) acc -= readlane_f64(a[k], i) * x[k];
-                x[i] = acc * invd[i];
-            }
-            if (lk == 0) {
-#pragma unroll
-                for (int c = 0; c < BS; ++c) D[lr * BP + c] = a[c];
-#pragma unroll
-                for (int i = 0; i < BS; ++i) sD[kb * BSZ + i * BP + lr] = x[i];
-            }
-            if (isbad) bad = 1;
-        }
-        __syncthreads();
-        // ---- panel: A(i,kb) <- A(i,kb) * L_kk^-T ------------------------------------------------------
-        for (int i = kb + 1 + w; i < NBK; i += 4) {
-            double* P = sA + bidx(i, kb) * BSZ;
-            double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-            acc = blk_mma_nt(P, sD + kb * BSZ, acc, lr, lk, 1.0);
-            blk_store_cd(P, acc, lr, lk, 1.0);
-        }
-        __syncthreads();
-        // ---- trailing update: A(i,j) -= A(i,kb) A(j,kb)^T, kb < j <= i -------------------------------------
-        {
-            const int m = NBK - 1 - kb;
-            const int n_upd = m * (m + 1) / 2;
-            for (int t = w; t < n_upd; t += 4) {
-                int ii = 0;
-                while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-                const int jj = t - ii * (ii + 1) / 2;
-                const int i = kb + 1 + ii, j = kb + 1 + jj;
-                double* Cb = sA + bidx(i, j) * BSZ;
-                double4_t acc = blk_load_cd(Cb, lr, lk);
-                acc = blk_mma_nt(sA + bidx(i, kb) * BSZ, sA + bidx(j, kb) * BSZ, acc, lr, lk, -1.0);
-                blk_store_cd(Cb, acc, lr, lk, 1.0);
-            }
-        }
-        __syncthreads();
-    }
-    // ---- write L (lower blocks; entries above the diagonal inside a diagonal block are never read) -----
-#pragma unroll
-    for (int bi = 0; bi < NBK; ++bi) {
-        const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
-        for (int idx = tid; idx < cnt; idx += 256) {
-            const int rr = idx / per_row, c2 = idx - rr * per_row;
-            const double* src = sA + bidx(bi, c2 >> 3) * BSZ + rr * BP + 2 * (c2 & 7);
-            double2 v; v.x = src[0]; v.y = src[1];
-            *reinterpret_cast<double2*>(A + (size_t)(16 * bi + rr) * NB + 2 * c2) = v;
-        }
-    }
-    __syncthreads();
-    // ---- in-place block inverse, block columns from last to first ------------------------------------------
-    for (int j = NBK - 2; j >= 0; --j) {
-        double4_t T[2];
-        int nt = 0;
-        for (int i = j + 1 + w; i < NBK; i += 4, ++nt) {
-            double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-            for (int k = j + 1; k <= i; ++k) {
-                const double* X = (k == i) ? (sD + i * BSZ) : (sA + bidx(i, k) * BSZ);
-                acc = blk_mma_nn(X, sA + bidx(k, j) * BSZ, acc, lr, lk);
-            }
-            T[nt] = acc;
-        }
-        __syncthreads();  // every wave is done reading the old block column j
-        nt = 0;
-        for (int i = j + 1 + w; i < NBK; i += 4, ++nt) blk_store_cd(sA + bidx(i, j) * BSZ, T[nt], lr, lk, 1.0);
-        __syncthreads();
-        for (int i = j + 1 + w; i < NBK; i += 4) {
-            double* Bk = sA + bidx(i, j) * BSZ;
-            double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-            acc = blk_mma_nn(Bk, sD + j * BSZ, acc, lr, lk);
-            blk_store_cd(Bk, acc, lr, lk, -1.0);
-        }
-        __syncthreads();
-    }
-    // Linv: lower blocks only (the buffer is zero-initialised once and nothing else writes it; the
-    // inverted diagonal blocks carry explicit zeros above their diagonal)
-#pragma unroll
-    for (int bi = 0; bi < NBK; ++bi) {
-        const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
-        for (int idx = tid; idx < cnt; idx += 256) {
-            const int rr = idx / per_row, c2 = idx - rr * per_row;
-            const int bj = c2 >> 3;
-            const double* src = ((bj == bi) ? (sD + bi * BSZ) : (sA + bidx(bi, bj) * BSZ)) + rr * BP + 2 * (c2 & 7);
-            double2 v; v.x = src[0]; v.y = src[1];
-            *reinterpret_cast<double2*>(Linv + (size_t)(16 * bi + rr) * NB + 2 * c2) = v;
-        }
-    }
-    if (tid == 0 && bad) atomicCAS(fail, 0, K + 1);
-}
-
-// ------------------------------------------------------------------------------------------
-// potrf + inverse with look-ahead (default).  Same blocked algorithm and the same LDS layout as
-// k_potrf_inv, rescheduled so that the serial part -- the 16x16 register Cholesky of the next diagonal
-// block on wave 0 -- runs while waves 1-3 do the bulk of the previous step's trailing update and turn one
-// more row of L into a row of L^-1:
-//   step kb:  P1  wave 0: potrf16 + inverse of D_kb            | waves 1-3: trailing update of step kb-1 for the
-//                                                               | columns > kb; row kb-1 of L^-1 (into registers)
-//             --  barrier; waves 1-3 put row kb-1 of L^-1 in place of row kb-1 of L~
-//             P2  panel A(i,kb) <- A(i,kb) D_kb^-T (i > kb);  row kb of L goes to global memory and becomes
-//                 L~(kb,k) = D_kb^-1 L(kb,k) in place (k < kb)
-//             --  barrier
-//                 look-ahead: wave 0, which solved the panel block (kb+1, kb) itself, gives the next DIAGONAL block this
-//                 step's update right away (all the next potrf16 needs); the rest of column kb+1 is updated by the
-//                 other waves at the start of the next P1, beside that potrf16 (round 2: one barrier per step less)
-//             --  barrier
-// with  L^-1(r,j) = - sum_{k=j}^{r-1} L~(r,k) L^-1(k,j),  L^-1(k,k) = D_k^-1  (row-oriented dtrtri).
-// Row r of L is dead once step r has used it, so its blocks are reused for L~ and then L^-1: no extra LDS.
-// The 8 x 3 barriers of the separate inversion phase of k_potrf_inv are gone and the trailing update is off
-// the critical path: 85 -> 65 us per tile with 4 waves, 58 us with 8 (one launch per elimination-tree level).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void blk_to_global(const double* __restrict__ src, double* __restrict__ dst_tile, int bi, int bj,
-                                              int t, int nthreads) {
-    // 16 rows x 8 double2 per block
-    for (int idx = t; idx < 128; idx += nthreads) {
-        const int rr = idx >> 3, c2 = idx & 7;
-        double2 v; v.x = src[rr * BP + 2 * c2]; v.y = src[rr * BP + 2 * c2 + 1];
-        *reinterpret_cast<double2*>(dst_tile + (size_t)(16 * bi + rr) * NB + 16 * bj + 2 * c2) = v;
-    }
-}
-
-// NW waves per workgroup: wave 0 factorises the 16 x 16 diagonal block in registers while the other NW-1 waves do
-// the previous step's trailing update and one row of L^-1 -- with 4 waves those three take ~3 us per block step
-// against wave 0's ~1.2 us and are the critical path of the tile; 8 waves balance the two.
 #ifdef APEX_POTRF_TRACE   // tools/potrf_bench.hip: wall-clock stamps of workgroup 0 at the phase boundaries
 __device__ unsigned long long g_potrf_trace[64], g_potrf_cycles[64];   // 100 MHz stamps and shader-clock stamps (s_memtime)
 __device__ int g_potrf_trace_n;
@@ -295,241 +87,8 @@ __device__ int g_potrf_trace_n;
 #else
 #define POTRF_STAMP() do {} while (0)
 #endif
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_potrf_inv_la(const PotrfTask* __restrict__ tasks, int* __restrict__ fail,
-                                                          int* __restrict__ arrived) {
-    constexpr int NT = 64 * NW;
-    // (scheduling hint for k_gate: this workgroup has its CU; nothing depends on the counter for correctness)
-    if (arrived != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    POTRF_STAMP();
-    const PotrfTask pt = tasks[blockIdx.x];
-    double* __restrict__ A = pt.A;
-    double* __restrict__ Linv = pt.Linv;
-    const int K = pt.K;
-    __shared__ double sA[NLB * BSZ];
-    __shared__ double sD[NBK * BSZ];
-    __shared__ int bad;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int lr = lane & 15, lk = lane >> 4;
-    if (tid == 0) bad = 0;
-    {
-        constexpr int NREG = (128 * 45 + NT - 1) / NT + NBK;
-        double2 reg[NREG];
-        int n = 0;
-#pragma unroll
-        for (int bi = 0; bi < NBK; ++bi) {
-            const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
-#pragma unroll
-            for (int it = 0; it < (16 * 8 * (bi + 1) + NT - 1) / NT; ++it, ++n) {
-                const int idx = tid + NT * it;
-                if (idx < cnt) {
-                    const int rr = idx / per_row, c2 = idx - rr * per_row;
-                    reg[n] = *reinterpret_cast<const double2*>(A + (size_t)(16 * bi + rr) * NB + 2 * c2);
-                }
-            }
-        }
-        n = 0;
-#pragma unroll
-        for (int bi = 0; bi < NBK; ++bi) {
-            const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
-#pragma unroll
-            for (int it = 0; it < (16 * 8 * (bi + 1) + NT - 1) / NT; ++it, ++n) {
-                const int idx = tid + NT * it;
-                if (idx < cnt) {
-                    const int rr = idx / per_row, c2 = idx - rr * per_row;
-                    double* dst = sA + bidx(bi, c2 >> 3) * BSZ + rr * BP + 2 * (c2 & 7);
-                    dst[0] = reg[n].x; dst[1] = reg[n].y;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    POTRF_STAMP();
-
-    for (int kb = 0; kb < NBK; ++kb) {
-        // ---------------- P1 ------------------------------------------------------------------------------
-        double4_t T[(NBK - 1 + NW - 2) / (NW - 1)];   // row kb-1 of L^-1: blocks j = (w-1), (w-1)+(NW-1), ... of waves 1..NW-1
-        if (w == 0) {
-            double* D = sA + bidx(kb, kb) * BSZ;
-            double a[BS], invd[BS];
-#pragma unroll
-            for (int c = 0; c < BS; ++c) a[c] = D[lr * BP + c];
-            int isbad = 0;
-#pragma unroll
-            for (int j = 0; j < BS; ++j) {
-                const double djj = readlane_f64(a[j], j);
-                if (!(djj > 0.0)) isbad = 1;
-                const double dj = djj > 0.0 ? djj : 1.0;
-                double isj = __builtin_amdgcn_rsq(dj);
-                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
-                isj = isj * fma(-0.5 * dj * isj, isj, 1.5);
-                double sj = dj * isj;
-                sj = fma(0.5 * isj, fma(-sj, sj, dj), sj);
-                invd[j] = isj;
-                const double lrj = a[j] * isj;
-#pragma unroll
-                for (int c = j + 1; c < BS; ++c) {
-                    // rows above the diagonal (lr < c) pick up garbage here: nothing below reads it and it is masked at
-                    // the store (a predicate per update costs 0.5 us per block step on this serial path)
-                    const double lcj = readlane_f64(lrj, c);
-                    a[c] -= lrj * lcj;
-                }
-                a[j] = (lr > j) ? lrj : ((lr == j) ? sj : a[j]);
-            }
-            // L of the block goes to LDS, and its transpose into the (still unused) slot of the inverse: the inverse
-            // below then takes column k of L as broadcast 16-byte LDS reads of one contiguous row of L^T (one address
-            // for the whole wave), fetched one step ahead, instead of two v_readlane per multiplier.
-            double* Lt = sD + kb * BSZ;
-            if (lk == 0) {
-#pragma unroll
-                for (int c = 0; c < BS; ++c) {
-                    D[lr * BP + c] = (lr >= c) ? a[c] : 0.0;
-                    Lt[c * BP + lr] = a[c];      // entries with lr < c are never read
-                }
-            }
-            // inverse: lane c solves L x = e_c, column-oriented so that the 16 steps form a chain of only two
-            // dependent operations each (the updates of the rows below k are independent of one another)
-            double x[BS], cur[BS], nxt[BS];
-#pragma unroll
-            for (int i = 0; i < BS; ++i) x[i] = (i == lr) ? 1.0 : 0.0;
-#pragma unroll
-            for (int i = 0; i < BS; i += 2) {
-                const double2 v = *reinterpret_cast<const double2*>(Lt + i);
-                cur[i] = v.x; cur[i + 1] = v.y;
-            }
-#pragma unroll
-            for (int k = 0; k < BS; ++k) {
-                if (k + 1 < BS) {
-#pragma unroll
-                    for (int i = (k + 2) & ~1; i < BS; i += 2) {
-                        const double2 v = *reinterpret_cast<const double2*>(Lt + (k + 1) * BP + i);
-                        nxt[i] = v.x; nxt[i + 1] = v.y;
-                    }
-                }
-                x[k] *= invd[k];
-#pragma unroll
-                for (int i = k + 1; i < BS; ++i) x[i] -= cur[i] * x[k];
-#pragma unroll
-                for (int i = 0; i < BS; ++i) cur[i] = nxt[i];
-            }
-            if (lk == 0) {
-#pragma unroll
-                for (int i = 0; i < BS; ++i) sD[kb * BSZ + i * BP + lr] = x[i];
-            }
-            if (isbad) bad = 1;
-        } else {
-            if (kb >= 1) {
-                const int ks = kb - 1;
-                // column kb below its diagonal block first (the panel solves of this step need it; the diagonal block
-                // itself got its update from wave 0 at the end of the previous step) ...
-                for (int i = kb + w; i < NBK; i += NW - 1) {
-                    double* Cb = sA + bidx(i, kb) * BSZ;
-                    double4_t acc = blk_load_cd(Cb, lr, lk);
-                    acc = blk_mma_nt(sA + bidx(i, ks) * BSZ, sA + bidx(kb, ks) * BSZ, acc, lr, lk, -1.0);
-                    blk_store_cd(Cb, acc, lr, lk, 1.0);
-                }
-                // ... then the rest of the trailing update of step ks: targets (i, j) with kb < j <= i
-                const int m = NBK - 1 - kb;
-                const int n_upd = m * (m + 1) / 2;
-                for (int t = w - 1; t < n_upd; t += NW - 1) {
-                    int ii = 0;
-                    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-                    const int jj = t - ii * (ii + 1) / 2;
-                    const int i = kb + 1 + ii, j = kb + 1 + jj;
-                    double* Cb = sA + bidx(i, j) * BSZ;
-                    double4_t acc = blk_load_cd(Cb, lr, lk);
-                    acc = blk_mma_nt(sA + bidx(i, ks) * BSZ, sA + bidx(j, ks) * BSZ, acc, lr, lk, -1.0);
-                    blk_store_cd(Cb, acc, lr, lk, 1.0);
-                }
-                // row r = ks of L^-1 from L~(r,.) and the rows above (kept in registers until the barrier)
-                const int r = ks;
-                int nt = 0;
-                for (int j = w - 1; j < r; j += NW - 1, ++nt) {
-                    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-                    for (int k = j; k < r; ++k) {
-                        const double* Y = (k == j) ? (sD + j * BSZ) : (sA + bidx(k, j) * BSZ);
-                        acc = blk_mma_nn(sA + bidx(r, k) * BSZ, Y, acc, lr, lk);
-                    }
-                    T[nt] = acc;
-                }
-            }
-        }
-        __syncthreads();
-        POTRF_STAMP();
-        if (w > 0 && kb >= 1) {
-            const int r = kb - 1;
-            int nt = 0;
-            for (int j = w - 1; j < r; j += NW - 1, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
-        }
-        // ---------------- P2 ------------------------------------------------------------------------------
-        // tasks 0 .. m-1: panel blocks (kb+1+t, kb); tasks m .. m+kb-1: row block (kb, t-m) -> global, then L~
-        {
-            const int m = NBK - 1 - kb;
-            for (int t = w; t < m + kb; t += NW) {
-                if (t < m) {
-                    double* P = sA + bidx(kb + 1 + t, kb) * BSZ;
-                    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-                    acc = blk_mma_nt(P, sD + kb * BSZ, acc, lr, lk, 1.0);
-                    blk_store_cd(P, acc, lr, lk, 1.0);
-                } else {
-                    const int k = t - m;
-                    double* Bk = sA + bidx(kb, k) * BSZ;
-                    blk_to_global(Bk, A, kb, k, lane, 64);
-                    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-                    acc = blk_mma_nn(sD + kb * BSZ, Bk, acc, lr, lk);
-                    blk_store_cd(Bk, acc, lr, lk, 1.0);  // same wave read it: LDS accesses of one wave stay in order
-                }
-            }
-            if (w == NW - 1) blk_to_global(sA + bidx(kb, kb) * BSZ, A, kb, kb, lane, 64);  // the diagonal block of L
-            // ---------------- look-ahead: only what the next potrf16 needs, by the wave that runs it -----------------
-            // wave 0 solved the panel block (kb+1, kb) itself (task 0 above): the next diagonal block gets this step's
-            // update right away; the rest of column kb+1 is updated by the other waves while wave 0 factorises it.
-            if (w == 0 && kb + 1 < NBK) {
-                const int jc = kb + 1;
-                double* Cb = sA + bidx(jc, jc) * BSZ;
-                double4_t acc = blk_load_cd(Cb, lr, lk);
-                acc = blk_mma_nt(sA + bidx(jc, kb) * BSZ, sA + bidx(jc, kb) * BSZ, acc, lr, lk, -1.0);
-                blk_store_cd(Cb, acc, lr, lk, 1.0);
-            }
-        }
-        __syncthreads();
-        POTRF_STAMP();
-    }
-    // last row of L^-1 (r = NBK-1), all four waves
-    {
-        const int r = NBK - 1;
-        double4_t T[(NBK - 1 + NW - 1) / NW];
-        int nt = 0;
-        for (int j = w; j < r; j += NW, ++nt) {
-            double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-            for (int k = j; k < r; ++k) {
-                const double* Y = (k == j) ? (sD + j * BSZ) : (sA + bidx(k, j) * BSZ);
-                acc = blk_mma_nn(sA + bidx(r, k) * BSZ, Y, acc, lr, lk);
-            }
-            T[nt] = acc;
-        }
-        __syncthreads();
-        nt = 0;
-        for (int j = w; j < r; j += NW, ++nt) blk_store_cd(sA + bidx(r, j) * BSZ, T[nt], lr, lk, -1.0);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int bi = 0; bi < NBK; ++bi) {
-        const int per_row = 8 * (bi + 1), cnt = 16 * per_row;
-        for (int idx = tid; idx < cnt; idx += NT) {
-            const int rr = idx / per_row, c2 = idx - rr * per_row;
-            const int bj = c2 >> 3;
-            const double* src = ((bj == bi) ? (sD + bi * BSZ) : (sA + bidx(bi, bj) * BSZ)) + rr * BP + 2 * (c2 & 7);
-            double2 v; v.x = src[0]; v.y = src[1];
-            *reinterpret_cast<double2*>(Linv + (size_t)(16 * bi + rr) * NB + 2 * c2) = v;
-        }
-    }
-    if (tid == 0 && bad) atomicCAS(fail, 0, K + 1);
-    POTRF_STAMP();
-}
-
 // ------------------------------------------------------------------------------------------
-// potrf + inverse, round 4 (default, "potrf_lookahead" 12 = twelve waves; 9 = eight waves): the same blocked schedule as k_potrf_inv_la with the serial part
+// potrf + inverse on the matrix pipe (round 4; twelve waves): the blocked schedule above with the serial part
 // -- wave 0's 16 x 16 Cholesky and the inverse of its factor -- rewritten for the matrix pipe.  The look-ahead kernel
 // spent 4.1 of its 5.4 us per block step there: lane r owned row r, so every one of the 16 pivots broadcast its column
 // through ~30 v_readlane (SGPR round trips) for the rank-1 update, and the inverse was a second pass of 16 steps.
@@ -1608,7 +1167,6 @@ constexpr int kFlowFactorThreadsC = 768;   // (= kFlowFactorThreads, needed by t
 // strips are requested in one go (12 16-byte loads per lane, one round trip) and staged whole -- no K loop, one barrier.
 // 36 MFMAs per wave, summed over k in the order of the level kernels (k ascending, four per instruction): same bits.
 constexpr int kFlowPK = NB + 2;   // LDS pitch of a full-K operand row: 292 dwords = 36 mod 64 -> conflict-free b64 operand reads
-template <bool DYN>
 __device__ __forceinline__ void flow_update_unit(const FactorUnit& u, double* __restrict__ sA, double* __restrict__ sB,
                                                  int* __restrict__ ver, int* __restrict__ err, unsigned long long* __restrict__ trace) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1616,7 +1174,7 @@ __device__ __forceinline__ void flow_update_unit(const FactorUnit& u, double* __
     const int wr = w / 3, wc = w % 3;
     const int bi = u.strip / 3, bj = u.strip % 3;
     const __amdgpu_buffer_rsrc_t rC = coh_rsrc(u.C), rA = coh_rsrc(u.A), rB = coh_rsrc(u.B);
-    if (!DYN) flow_wait_unit(ver, u, tid, err);   // the previous writer of the target is done, both operands are final
+    flow_wait_unit(ver, u, tid, err);   // the previous writer of the target is done, both operands are final
     if (trace && tid == 0) trace[1] = wall_clock64();
     const bool act = tid < 576;   // (the workgroup has 12 waves for the potrf units' sake: nine of them work here)
     double cv[4] = {0.0, 0.0, 0.0, 0.0};   // the old values of the block: requested with the operands, consumed last
@@ -1652,13 +1210,12 @@ __device__ __forceinline__ void flow_update_unit(const FactorUnit& u, double* __
         for (int r = 0; r < 4; ++r)
             coh_st1(rC, (48 * bi + 16 * wr + lk + 4 * r) * NB + 48 * bj + 16 * wc + lr, -1.0 * acc[r] + 1.0 * cv[r]);
     }
-    if (!DYN) flow_publish(ver + u.pub, tid);
+    flow_publish(ver + u.pub, tid);
 }
 
 // A PANEL-SOLVE unit: rows 16 s .. 16 s + 15 of C = A Linv^T IN PLACE (C aliases A): a unit reads only the rows it
 // writes, all of them before its first store, so the nine units of a tile do not race.  Wave w owns the 16 x 16 block of
 // columns 16 w; Linv comes whole (18 16-byte loads per lane in flight at once) and is staged in three 48-wide K chunks.
-template <bool DYN>
 __device__ __forceinline__ void flow_solve_unit(const FactorUnit& u, double* __restrict__ sA, double* __restrict__ sB,
                                                 int* __restrict__ ver, int* __restrict__ err, unsigned long long* __restrict__ trace) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1667,7 +1224,7 @@ __device__ __forceinline__ void flow_solve_unit(const FactorUnit& u, double* __r
     const __amdgpu_buffer_rsrc_t rC = coh_rsrc(u.C), rB = coh_rsrc(u.B);
     constexpr int C2 = KS / 2, NCH = NB / KS, NRB = NB * C2 / 576;   // per chunk: 16 x 24 double2 of A (lanes < 384), 6 per thread of B
     static_assert(NB * C2 % 576 == 0 && 16 * C2 <= 576, "staging loops assume whole rounds");
-    if (!DYN) flow_wait_unit(ver, u, tid, err);   // the tile carries all its updates, L^-1 of the column's diagonal tile is there
+    flow_wait_unit(ver, u, tid, err);   // the tile carries all its updates, L^-1 of the column's diagonal tile is there
     if (trace && tid == 0) trace[1] = wall_clock64();
     const bool act = tid < 576;   // (nine of the workgroup's twelve waves work here)
     double2 ra[NCH], rb[NCH][NRB];
@@ -1706,7 +1263,7 @@ __device__ __forceinline__ void flow_solve_unit(const FactorUnit& u, double* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r) coh_st1(rC, (row0 + lk + 4 * r) * NB + 16 * w + lr, acc[r]);
     }
-    if (!DYN) flow_publish(ver + u.pub, tid);
+    flow_publish(ver + u.pub, tid);
 }
 
 
@@ -1719,13 +1276,12 @@ __device__ __forceinline__ void flow_solve_unit(const FactorUnit& u, double* __r
 // chunk.  ~20 us of matrix work per unit and CU = the level kernels' rate, without their launch chain.  Same MFMA sequence per
 // block (k ascending, four per instruction) and the same epilogue expression as the 48 x 48 units and the level kernels: the
 // factor is bit-identical.  Publishes all nine counts of a writer at once.
-template <bool DYN>
 __device__ __forceinline__ void flow_update_tile_unit(const FactorUnit& u, double* __restrict__ sA, double* __restrict__ sB,
                                                       int* __restrict__ ver, int* __restrict__ err, unsigned long long* __restrict__ trace) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     const __amdgpu_buffer_rsrc_t rC = coh_rsrc(u.C), rA = coh_rsrc(u.A), rB = coh_rsrc(u.B);
-    if (!DYN) flow_wait_unit(ver, u, tid, err);   // the previous writer of the target is done, both operands are final
+    flow_wait_unit(ver, u, tid, err);   // the previous writer of the target is done, both operands are final
     if (trace && tid == 0) trace[1] = wall_clock64();
     constexpr int NBW = 7;                                     // blocks per wave (waves 9..11: six)
     const int nb = w < 9 ? 7 : 6, b0 = w < 9 ? 7 * w : 63 + 6 * (w - 9);
@@ -1787,7 +1343,6 @@ __device__ __forceinline__ void flow_update_tile_unit(const FactorUnit& u, doubl
             for (int r = 0; r < 4; ++r) coh_st1(rC, (16 * br + lk + 4 * r) * NB + 16 * bc + lr, -1.0 * acc[q][r] + 1.0 * cv[q][r]);
         }
     }
-    if (DYN) return;
     __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(ver + u.pub, kFlowUnitsPerTile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1816,119 +1371,13 @@ __global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow(const Factor
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ver + u.pub, kFlowUnitsPerTile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (kind == 1) {
-        flow_solve_unit<false>(u, smem, smem + 16 * PS, ver, err, trace);
+        flow_solve_unit(u, smem, smem + 16 * PS, ver, err, trace);
     } else if (kind == 3) {
-        flow_update_tile_unit<false>(u, smem, smem + NB * PS, ver, err, trace);
+        flow_update_tile_unit(u, smem, smem + NB * PS, ver, err, trace);
     } else {
-        flow_update_unit<false>(u, smem, smem + 48 * kFlowPK, ver, err, trace);
+        flow_update_unit(u, smem, smem + 48 * kFlowPK, ver, err, trace);
     }
     if (trace && tid == 0) trace[2] = wall_clock64();
-}
-
-// ------------------------------------------------------------------------------------------
-// The same units, DYNAMICALLY scheduled (round 5; "factor_flow_dyn" 1 -- NOT the default: measured below).  k_factor_flow above gives every unit a
-// workgroup of its own, dispatched in list order, and a unit whose inputs are not there yet holds its CU while it polls: by
-// the launch's own stamps 40 % of the CU time of a dense 32 x 32-tile block is such waiting (tools/flow_bench), more where
-// the real durations drift from the simulated ones the order was made from -- which is what lost the throughput-bound middle
-// levels of final-13682 to the level launches.  Here one persistent workgroup per CU takes READY units from a queue:
-//   pop      slot = head++ (one atomic); wait until q[slot] holds a unit index (only when nothing is ready)
-//   run      the unit, no polling: everything it reads is final
-//   finish   stores acknowledged, barrier; ver[pub] += inc; the unit whose add completes a writer (the count reaches a
-//            multiple of nine) WAKES the units registered for that (tile, writer) node: pending[x] -= 1, and whoever takes
-//            it to zero appends x to the queue (q[tail++] = x).
-// Units, version counters and per-tile writer order are those of the static launch: the factor is bit-identical.  No unit
-// is pushed before its producers' stores were acknowledged, every unit is pushed exactly once, and the units form a DAG:
-// the earliest unfinished unit is always ready or running, so the queue cannot stall whatever the number of resident
-// workgroups.  A workgroup that polls an empty slot for ~2 s raises the error word (as the static launch does); the others
-// watch it and leave.
-// MEASURED (profiles/r05_flow_bench_dyn.txt, r05_flow_dyn_sweep.txt): bit-identical, no CU ever waits with a unit in hand --
-// and slower: dense 18 x 18 tiles 1,017 us against 947 static, 32 x 32 2,216 against 1,823, final-13682 6.85 against 6.58 ms.
-// These launches are bound by their dependency CHAIN, and a chain hop through finish -> wake -> push -> pop -> descriptor
-// load costs ~4 us more than a waiting workgroup's polled flag; the CU time the static launch wastes on waiting (40 % on the
-// 32 x 32 block) was idle capacity, not lost throughput.  Kept as the A/B.
-// ------------------------------------------------------------------------------------------
-// (the four unit bodies as real functions: inlined into one loop the register allocator keeps pieces of all of them alive around
-// the back edge and spills 134 VGPRs -- every unit then ran 30-40 % longer than in the static launch)
-__device__ __noinline__ void dyn_unit_potrf(const FactorUnit* up, int* fail, double* smem, int* bad, int* sync_cnt) {
-    const FactorUnit u = *up;
-    potrf_tile_mf<kFlowFactorThreadsC / 64, true>(u.C, const_cast<double*>(u.A), u.strip, fail, smem, smem + NLB * BSZ, bad, sync_cnt);
-}
-__device__ __noinline__ void dyn_unit_solve(const FactorUnit* up, double* smem, unsigned long long* trace) {
-    flow_solve_unit<true>(*up, smem, smem + 16 * PS, nullptr, nullptr, trace);
-}
-__device__ __noinline__ void dyn_unit_update(const FactorUnit* up, double* smem, unsigned long long* trace) {
-    flow_update_unit<true>(*up, smem, smem + 48 * kFlowPK, nullptr, nullptr, trace);
-}
-__device__ __noinline__ void dyn_unit_update_tile(const FactorUnit* up, double* smem, unsigned long long* trace) {
-    flow_update_tile_unit<true>(*up, smem, smem + NB * PS, nullptr, nullptr, trace);
-}
-struct FlowDyn {
-    int* pending;            // [n_units] unfinished inputs of every unit (reset from the plan's image before the launch)
-    int* q;                  // [n_units] the ready queue: unit indices in push order, -1 = not yet pushed
-    int* ctr;                // [0] head (next slot to pop), [1] tail (next slot to push)
-    const int* wl_ptr;       // [nodes + 1] waiters of node (tile, writer m): FactorUnit::pad + m - 1
-    const int* wl;           // unit indices
-};
-__global__ __launch_bounds__(kFlowFactorThreads) void k_factor_flow_dyn(const FactorUnit* __restrict__ units, int n_units, int* __restrict__ ver,
-                                                                         int* __restrict__ fail, int* __restrict__ err, FlowDyn d,
-                                                                         unsigned long long* __restrict__ trace0) {
-    __shared__ double smem[(NLB + NBK) * BSZ];
-    __shared__ int bad, sync_cnt, s_idx, s_node;
-    const int tid = threadIdx.x;
-    for (;;) {
-        if (tid < 64) {   // wave 0 pops: lane 0 owns the slot, lane 1 watches the error word
-            int idx = -2;
-            int slot = 0;
-            if (tid == 0) slot = __hip_atomic_fetch_add(d.ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            slot = __builtin_amdgcn_readfirstlane(slot);
-            if (slot < n_units) {
-                int spins = 0;
-                for (;;) {
-                    const int v = tid == 0 ? __hip_atomic_load(d.q + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-                    const bool dead = tid == 1 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                    idx = __builtin_amdgcn_readfirstlane(v);
-                    if (idx >= 0) break;
-                    if (__any(dead)) { idx = -2; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > kFlowSpinLimit) { if (tid == 0) atomicOr(err, 1); idx = -2; break; }
-                }
-            }
-            if (tid == 0) s_idx = idx;
-        }
-        __syncthreads();
-        const int idx = s_idx;
-        if (idx < 0) return;
-        const FactorUnit u = units[idx];
-        unsigned long long* trace = trace0 ? trace0 + 3 * (size_t)idx : nullptr;
-        if (trace && tid == 0) { trace[0] = wall_clock64(); trace[1] = trace[0]; }
-        if ((u.kind & 15) == 0) dyn_unit_potrf(units + idx, fail, smem, &bad, &sync_cnt);
-        else if ((u.kind & 15) == 1) dyn_unit_solve(units + idx, smem, trace);
-        else if ((u.kind & 15) == 3) dyn_unit_update_tile(units + idx, smem, trace);
-        else dyn_unit_update(units + idx, smem, trace);
-        // ---- finish: publish, and wake whoever waited for the writer this unit completes --------------------------------------
-        __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
-        __syncthreads();                 // ... every wave's; also: all reads of smem and s_idx are done
-        if (tid == 0) {
-            const int inc = ((u.kind & 15) == 0 || (u.kind & 15) == 3) ? kFlowUnitsPerTile : 1;
-            const int old = __hip_atomic_fetch_add(ver + u.pub, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int m = (old + inc) / kFlowUnitsPerTile;
-            s_node = (old >= 0 && m > old / kFlowUnitsPerTile) ? u.pad + m - 1 : -1;
-            if (trace) trace[2] = wall_clock64();
-        }
-        __syncthreads();
-        const int node = s_node;
-        if (node >= 0) {
-            const int w0 = d.wl_ptr[node], w1 = d.wl_ptr[node + 1];
-            for (int k = w0 + tid; k < w1; k += kFlowFactorThreads) {
-                const int x = d.wl[k];
-                if (__hip_atomic_fetch_add(d.pending + x, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) {
-                    const int sl = __hip_atomic_fetch_add(d.ctr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(d.q + sl, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        __syncthreads();   // (s_node / s_idx are rewritten by the next trip)
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2248,12 +1697,6 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int n, double beta, const 
 }
 
 // ------------------------------------------------------------------------------------------
-static int g_potrf_lookahead = 12;   // 0: k_potrf_inv; 1 / 6 / 8: look-ahead kernel (round 3) with 4 / 6 / 8 waves; 9 / 12 (default): matrix-pipe form, 8 / 12 waves
-void set_potrf_lookahead(int mode) { g_potrf_lookahead = mode; }
-static int g_panel_tri = 1;   // 1: the panel solves skip the zero blocks of Linv (k_tile_gemm_nt<true>); 0: full products (A/B)
-void set_panel_tri(int on) { g_panel_tri = on; }
-static int g_small_max_panel = kGemmSmallMax, g_small_max_update = kGemmSmallMax;
-void set_gemm_small_max(int panel, int update) { if (panel >= 0) g_small_max_panel = panel; if (update >= 0) g_small_max_update = update; }
 // The flood gate (TilePlan::enqueue_factor): one lane that ends when `expected` potrf workgroups have announced themselves
 // in *arrived, or after max_ticks of the 100 MHz clock -- a scheduling hint in front of the bulk updates of a level, so
 // that they do not take the CUs the next level's potrf is about to need.  Never waited for: a gate that times out only
@@ -2265,37 +1708,25 @@ __global__ __launch_bounds__(64) void k_gate(const int* __restrict__ arrived, in
         __builtin_amdgcn_s_sleep(16);
 }
 void launch_gate(const int* arrived, int expected, int max_micros, hipStream_t s) {
-    if (g_potrf_lookahead == 0) return;   // k_potrf_inv does not count its workgroups in: the gate would spin to its limit
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, arrived, expected, (long long)max_micros * 100);
 }
 void launch_factor_flow(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, hipStream_t s, unsigned long long* trace) {
     if (n_units <= 0) return;
     hipLaunchKernelGGL(k_factor_flow, dim3(n_units), dim3(kFlowFactorThreads), 0, s, units, ver, fail, err, trace);
 }
-void launch_factor_flow_dyn(const FactorUnit* units, int n_units, int* ver, int* fail, int* err, int* pending, int* q, int* ctr,
-                            const int* wl_ptr, const int* wl, int n_workgroups, hipStream_t s, unsigned long long* trace) {
-    if (n_units <= 0) return;
-    FlowDyn d{pending, q, ctr, wl_ptr, wl};
-    hipLaunchKernelGGL(k_factor_flow_dyn, dim3(std::min(n_units, n_workgroups)), dim3(kFlowFactorThreads), 0, s, units, n_units, ver, fail, err, d, trace);
-}
 void launch_potrf_inv(const PotrfTask* tasks, int n, int* fail, hipStream_t s, int* arrived) {
     if (n <= 0) return;
-    if (g_potrf_lookahead == 9) hipLaunchKernelGGL(k_potrf_inv_mf<8>, dim3(n), dim3(512), 0, s, tasks, fail, arrived);
-    else if (g_potrf_lookahead == 12) hipLaunchKernelGGL(k_potrf_inv_mf<12>, dim3(n), dim3(768), 0, s, tasks, fail, arrived);
-    else if (g_potrf_lookahead == 1) hipLaunchKernelGGL(k_potrf_inv_la<4>, dim3(n), dim3(256), 0, s, tasks, fail, arrived);
-    else if (g_potrf_lookahead == 6) hipLaunchKernelGGL(k_potrf_inv_la<6>, dim3(n), dim3(384), 0, s, tasks, fail, arrived);
-    else if (g_potrf_lookahead) hipLaunchKernelGGL(k_potrf_inv_la<8>, dim3(n), dim3(512), 0, s, tasks, fail, arrived);
-    else hipLaunchKernelGGL(k_potrf_inv, dim3(n), dim3(256), 0, s, tasks, fail);
+    hipLaunchKernelGGL(k_potrf_inv_mf<12>, dim3(n), dim3(768), 0, s, tasks, fail, arrived);
 }
 void launch_tile_gemm_nt(const GemmTask* tasks, int n, double alpha, double beta, hipStream_t s, bool tri_b) {
     if (n <= 0) return;
-    if (n <= (beta != 0.0 ? g_small_max_update : g_small_max_panel)) {  // latency kernels; the 9-workgroup form never for the in-place panel solves (C aliases A)
+    if (n <= kGemmSmallMax) {  // latency kernels; the 9-workgroup form never for the in-place panel solves (C aliases A)
         if (beta != 0.0) hipLaunchKernelGGL(k_tile_gemm_nt_small, dim3(9 * n), dim3(192), 0, s, tasks, 9 * n, alpha, beta);
         else hipLaunchKernelGGL(k_tile_gemm_nt_small_strip, dim3(3 * n), dim3(576), 0, s, tasks, 3 * n, alpha, beta);
         return;
     }
     const int units = n * NSTRIP, per_xcd = (units + 7) / 8;
-    if (tri_b && g_panel_tri) hipLaunchKernelGGL(k_tile_gemm_nt<true>, dim3(8 * per_xcd), dim3(256), 0, s, tasks, units, alpha, beta);
+    if (tri_b) hipLaunchKernelGGL(k_tile_gemm_nt<true>, dim3(8 * per_xcd), dim3(256), 0, s, tasks, units, alpha, beta);
     else hipLaunchKernelGGL(k_tile_gemm_nt<false>, dim3(8 * per_xcd), dim3(256), 0, s, tasks, units, alpha, beta);
 }
 void launch_tri_step(bool trans, const TriTask* tasks, int n, double* vwork, double* vout, hipStream_t s) {

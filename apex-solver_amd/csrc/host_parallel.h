@@ -182,11 +182,30 @@ struct SetupTrace {
 // a background thread it still stalls the caller: while the pages of buffers the GPU driver has seen (hipMemcpy from pageable
 // memory registers them) are unmapped, the caller's next apexgpu_set_params took 0.2-0.39 s instead of 0.012
 // (tools/setup_probe.py, APEX_SETUP_FREE=bg / sync / leak).  A block handed back is kept (up to kKeepBytes in all) and serves the
-// next handle's set-up, which then also skips the first-touch page faults of fresh memory; apexgpu_trim_host_cache() (or
-// APEX_HOST_CACHE=0) returns everything to the system.
+// next handle's set-up, which then also skips the first-touch page faults of fresh memory.
+// Round 6 (what the cache may hold, and for how long): only blocks of the LAST set-up (end_setup drops what an older, larger
+// structure left behind), only while a solver handle is alive (release() by the last ~Solver returns everything: the page
+// zapping then falls into apexgpu_destroy), never more than kKeepBytes; apexgpu_trim_host_cache() returns everything at once,
+// APEX_HOST_CACHE=0 turns the cache off, apexgpu_host_cache_bytes() says what it holds.  The object is never destroyed (a thread
+// of a leaked handle may still give a block back at process exit).
 class HostBlockCache {
    public:
-    static HostBlockCache& get() { static HostBlockCache c; return c; }
+    static HostBlockCache& get() { static HostBlockCache* c = new HostBlockCache; return *c; }
+    void retain() { std::lock_guard<std::mutex> lk(mu_); ++handles_; }
+    void release() { bool last; { std::lock_guard<std::mutex> lk(mu_); last = --handles_ <= 0; if (last) handles_ = 0; } if (last) (void)trim(); }
+    void begin_setup() { std::lock_guard<std::mutex> lk(mu_); ++gen_; }
+    size_t end_setup() {   // the blocks no set-up since begin_setup() has used go back to the system; returns the bytes released
+        std::vector<Block> drop;
+        size_t n = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t i = 0; i < kept_.size();)
+                if (kept_[i].gen < gen_) { drop.push_back(kept_[i]); n += kept_[i].bytes; kept_bytes_ -= kept_[i].bytes; kept_.erase(kept_.begin() + (long)i); }
+                else ++i;
+        }
+        for (const Block& b : drop) free(b.p);
+        return n;
+    }
     void* take(size_t bytes) {
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -196,6 +215,7 @@ class HostBlockCache {
             if (best >= 0) {
                 void* p = kept_[best].p;
                 kept_bytes_ -= kept_[best].bytes;
+                kept_[best].gen = gen_;
                 live_.push_back(kept_[best]);
                 kept_.erase(kept_.begin() + best);
                 return p;
@@ -205,16 +225,17 @@ class HostBlockCache {
         if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0 || !p) throw std::bad_alloc();
         (void)madvise(p, bytes, MADV_HUGEPAGE);
         std::lock_guard<std::mutex> lk(mu_);
-        live_.push_back(Block{p, bytes});
+        live_.push_back(Block{p, bytes, gen_});
         return p;
     }
     void give(void* p, size_t) {
         std::lock_guard<std::mutex> lk(mu_);
         size_t bytes = 0;
+        int gen = 0;
         for (size_t i = 0; i < live_.size(); ++i)
-            if (live_[i].p == p) { bytes = live_[i].bytes; live_.erase(live_.begin() + i); break; }
-        if (bytes == 0 || !enabled_ || kept_bytes_ + bytes > kKeepBytes) { free(p); return; }
-        kept_.push_back(Block{p, bytes});
+            if (live_[i].p == p) { bytes = live_[i].bytes; gen = live_[i].gen; live_.erase(live_.begin() + (long)i); break; }
+        if (bytes == 0 || !enabled_ || handles_ <= 0 || kept_bytes_ + bytes > kKeepBytes) { free(p); return; }
+        kept_.push_back(Block{p, bytes, gen});
         kept_bytes_ += bytes;
     }
     size_t trim() {   // everything kept goes back to the system; returns the bytes released
@@ -227,12 +248,13 @@ class HostBlockCache {
     size_t kept_bytes() { std::lock_guard<std::mutex> lk(mu_); return kept_bytes_; }
 
    private:
-    struct Block { void* p; size_t bytes; };
+    struct Block { void* p; size_t bytes; int gen; };
     HostBlockCache() { const char* e = getenv("APEX_HOST_CACHE"); enabled_ = !(e && e[0] == '0'); }
     static constexpr size_t kKeepBytes = (size_t)8 << 30;
     std::mutex mu_;
     std::vector<Block> kept_, live_;
     size_t kept_bytes_ = 0;
+    int handles_ = 0, gen_ = 0;
     bool enabled_ = true;
 };
 

@@ -59,21 +59,14 @@ class PoseGraphSolver : public LmBackend {
     int sweep_timeouts() const { return tp_.sweep_timeouts(); }
     void debug_poison_next_solve(int which) { tp_.debug_poison_next_solve(which); }
     void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
-    void set_panel_split(int min_rest) { tp_.set_panel_split(min_rest); }
     void set_one_wait(bool on) { one_wait_ = on; }
     void set_eager_step_eval(bool on) { eager_eval_ = on; }
-    void set_fwd_beside_top(bool on) { tp_.set_fwd_beside_top(on); }
-    void set_tri_inline(int max_cols) { tp_.set_tri_inline(max_cols); }
-    void set_first_writer(bool on) { tp_.set_first_writer(on); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
     void set_two_side(int mode) { tp_.set_two_side(mode); }
     void set_factor_flow(int max_cols, int max_rows) { tp_.set_factor_flow(max_cols, max_rows); }
-    void set_factor_flow_tile(bool on) { tp_.set_flow_tile_units(on); }
-    void set_factor_flow_dyn(bool on) { tp_.set_flow_dyn(on); }
     int factor_flow_timeouts() const { return n_factor_flow_timeouts_; }
     void debug_poison_next_factor() { tp_.debug_poison_next_factor(); }
-    void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void enable_stage_timing(bool on) { timer_.enable(on); }
     void enable_stage_timing_only(uint32_t stage_mask) { timer_.enable_only(stage_mask); }

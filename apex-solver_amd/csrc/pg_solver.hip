@@ -227,6 +227,7 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
     if (variant != 0) return fail(kInvalidInput, "the pose-graph backend has the sparse Cholesky solver only");
     HIP_TRY(hipSetDevice(device_));
     have_step_ = false;
+    have_trial_ = false;   // (this solve's eager step evaluation overwrites the trial poses)
     ++step_serial_;
     last_lambda_ = lambda;
     int rc = assemble(lambda);
@@ -238,7 +239,7 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
     // (one_wait_: the pivot flags and the dataflow launch's time-out word are read at the final wait below; the sweeps over a
     // failed factor are then void and the old path runs from the assembly on)
     bool speculative = one_wait_;
-    HIP_TRY(tp_.factor(&failed, rhs_, work_, /*defer_flags=*/speculative));  // the forward sweep rides along
+    HIP_TRY(tp_.factor(&failed, /*defer_flags=*/speculative));
     auto after_time_out = [&]() -> int {
         // the dataflow launch of the top groups timed out (the plan is back on the level launches): H is half updated
         ++n_factor_flow_timeouts_;
@@ -247,7 +248,7 @@ int PoseGraphSolver::solve_augmented(double lambda, int variant, double* step_ou
         launch_pg_negate(n_pad_, g_, rhs_, stream_);
         if (scaled_) launch_vec_mul(n_pad_, rhs_, scale_, rhs_, stream_);
         timer_.begin(kPgFactor, stream_);
-        HIP_TRY(tp_.factor(&failed, rhs_, work_));
+        HIP_TRY(tp_.factor(&failed));
         timer_.end(kPgFactor, stream_);
         if (tp_.factor_flow_gave_up()) return fail(kDeviceError, "dataflow factorisation timed out twice");
         return kOk;

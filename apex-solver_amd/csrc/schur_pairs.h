@@ -59,9 +59,9 @@ struct PairQDesc {    // queue g < 7 of a chunk: the block its nonet belongs to;
     uint32_t cj;      // the block's partner camera (a valid camera index also in an empty queue)
     uint32_t flags;   // kPairBlock* | kPairQFlush: the block (piece) ends with this nonet -- store / add it after this chunk
 };
-// (round 5) the same layout for SIX-column cameras (BundleAdjustment mode): a 6 x 6 block is four 3 x 3 sub-blocks, a lane group four
-// lanes -- SIXTEEN queues of QUARTETS (slot g + 16 t of a chunk is pair t < 4 of queue g, no idle slot), 16 + 1 descriptors and
-// 1 + 16 cameras per chunk, pieces of 256 pairs.  pair_queue_len / pair_queues give (9, 7) or (4, 16).
+// (Round 5 built the same layout for SIX-column cameras -- sixteen queues of quartets -- and measured it slower than form 3 there,
+// 3.52 against 2.90 ms, profiles/r05_bench_final13682_ba6.json: the kernel side was removed in round 6; the host builder and the
+// replay tests keep the (4, 16) parameters of pair_queue_len / pair_queues as a second shape of the same code.)
 constexpr int pair_queue_len(int dc) { return dc == 9 ? 9 : 4; }
 constexpr int pair_queues(int dc) { return dc == 9 ? 7 : 16; }
 constexpr uint32_t kPairQFlush = 4;
@@ -105,22 +105,15 @@ struct PairDeviceTables {
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
                       int task_slots = 0 /* 0: default */, bool queued = false,
-                      PairDeviceTables* dev_tables = nullptr /* queued only: leave out->recs empty and fill these instead */,
-                      const int* bun_ptr = nullptr /* landmark bundles (BAView::bun_ptr): the records then hold 32-byte UNIT offsets --
-                                                      i, j = the two projection records, l = the bundle's header -- instead of indices */);
+                      PairDeviceTables* dev_tables = nullptr /* queued only: leave out->recs empty and fill these instead */);
 // the records of the queued layout from those tables (all pointers device memory; recs is cleared to padding first)
 hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* run_ptr, const uint32_t* run_cj, const int* run_piece0,
                                     const int2* piece, const int2* task, const int* cam_ptr, const int* cam_obs, const uint32_t* o_pt,
-                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s, int dc = 9,
-                                    const int* bun_ptr = nullptr);
+                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s);
 
 // The pair kernel (record form: J rebuilt from the 32-byte projection records k_landmark_reduce writes, orec).
-// ablation: timing experiments only (results are wrong when != 0)
-// ablation 64 (record form): per-phase shader cycles summed over all waves since the last reset (see k_schur_pairs_r)
-void pairs_phase_cycles(unsigned long long out[8], bool reset);
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
-                        const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, int ablation,
-                        const double* orec, const PairQDesc* qdesc = nullptr /* the queued layout's descriptors */,
-                        int pad_unit = 0, int pad_header = 0 /* bundles (v.bun_ptr): what the padding slots read -- a real record and its header */);
+                        const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, const double* orec,
+                        const PairQDesc* qdesc = nullptr /* the queued layout's descriptors */);
 
 }  // namespace apex

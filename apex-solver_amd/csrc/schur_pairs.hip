@@ -28,14 +28,8 @@ struct Run { uint32_t cj; int len; int piece0; };   // the pairs of one row with
 
 void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int* cam_ext, const uint32_t* o_cam,
                       const uint32_t* o_pt, const int* pt_ptr, const int* cam_ptr, const int* cam_obs, PairLists* out,
-                      int task_slots, bool queued, PairDeviceTables* dev_tables, const int* bun_ptr) {
+                      int task_slots, bool queued, PairDeviceTables* dev_tables) {
     SetupTrace tr;
-    // (landmark bundles: what a record names is a 32-byte unit of the bundle array -- header of l, records of i and j)
-    auto make_rec = [&](int i, int j, uint32_t l, uint32_t w) -> PairRec {
-        if (!bun_ptr) return PairRec{(uint32_t)i, (uint32_t)j, l, w};
-        const uint32_t ul = (uint32_t)bun_ptr[l], b = (uint32_t)pt_ptr[l];
-        return PairRec{ul + 2u + ((uint32_t)i - b), ul + 2u + ((uint32_t)j - b), ul, w};
-    };
     const int cpt = kNB / dc;
     const int kTask = std::min(task_slots > 0 ? (task_slots + 63) / 64 * 64 : kPairTaskSlots, kPairMaxBlockSlots / 2);
     // rows in the caller's camera order
@@ -215,7 +209,7 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                             const QPiece& pc = pieces[run.piece0 + k / kPiecePairs];
                             const QTask& tk = qtasks[pc.task];
                             const int kk = k % kPiecePairs, idx = pc.nonet0 + kk / QL, g = idx / tk.nchunks;
-                            out->recs[((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + g + NQ * (kk % QL)] = make_rec(i, j, l, (uint32_t)g);
+                            out->recs[((int64_t)tk.chunk0 + idx % tk.nchunks) * 64 + g + NQ * (kk % QL)] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
                         }
                 }
             }
@@ -300,7 +294,7 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
                     const int k = pos[cj]++;
                     const int pi = run.piece0 + k / kPairMaxBlockSlots;   // (only a split block has more than one piece)
                     const int64_t s = pieces[pi].slot0 + k % kPairMaxBlockSlots;
-                    out->recs[s] = make_rec(i, j, l, (uint32_t)(pi - out->chunks[s / 64].first_block));
+                    out->recs[s] = PairRec{(uint32_t)i, (uint32_t)j, l, (uint32_t)(pi - out->chunks[s / 64].first_block)};
                 }
             }
         }
@@ -337,7 +331,7 @@ __global__ __launch_bounds__(64) void k_build_pair_recs_q(int64_t n_rows, const 
                                                            const int* __restrict__ cam_ptr, const int* __restrict__ cam_obs,
                                                            const uint32_t* __restrict__ o_pt, const int* __restrict__ pt_ptr,
                                                            const uint32_t* __restrict__ o_cam, int* __restrict__ cnt_global,
-                                                           PairRec* __restrict__ recs, int QL, int NQ, const int* __restrict__ bun_ptr) {
+                                                           PairRec* __restrict__ recs, int QL, int NQ) {
     __shared__ int cnt_lds[kRecsLdsPartners];
     const int64_t r = blockIdx.x;
     if (r >= n_rows) return;
@@ -394,7 +388,6 @@ __global__ __launch_bounds__(64) void k_build_pair_recs_q(int64_t n_rows, const 
                 const int2 tk = task[pc.x];
                 const int kk = k % piece_pairs, idx = pc.y + kk / QL, g = idx / tk.y;
                 PairRec rec{(uint32_t)i, (uint32_t)j, l, (uint32_t)g};
-                if (bun_ptr) { const uint32_t ul = (uint32_t)bun_ptr[l]; rec.i = ul + 2u + (uint32_t)(i - b); rec.j = ul + 2u + (uint32_t)s; rec.l = ul; }
                 recs[((int64_t)tk.x + idx % tk.y) * 64 + g + NQ * (kk % QL)] = rec;
             }
         }
@@ -402,8 +395,7 @@ __global__ __launch_bounds__(64) void k_build_pair_recs_q(int64_t n_rows, const 
 }
 hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* run_ptr, const uint32_t* run_cj, const int* run_piece0,
                                     const int2* piece, const int2* task, const int* cam_ptr, const int* cam_obs, const uint32_t* o_pt,
-                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s, int dc,
-                                    const int* bun_ptr) {
+                                    const int* pt_ptr, const uint32_t* o_cam, PairRec* recs, int64_t n_slots, hipStream_t s) {
     if (n_rows <= 0 || n_slots <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(recs, 0xFF, (size_t)n_slots * sizeof(PairRec), s);   // i = kPairPad everywhere: padding unless written below
     if (e != hipSuccess) return e;
@@ -420,7 +412,7 @@ hipError_t launch_build_pair_recs_q(int64_t n_rows, const int* rows, const int* 
     e = hipMemsetAsync(scratch, 0, (size_t)std::max(n_runs, 1) * sizeof(int), s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_build_pair_recs_q, dim3((unsigned)n_rows), dim3(64), 0, s, n_rows, rows, run_ptr, run_cj, run_piece0, piece, task,
-                           cam_ptr, cam_obs, o_pt, pt_ptr, o_cam, scratch, recs, pair_queue_len(dc), pair_queues(dc), bun_ptr);
+                           cam_ptr, cam_obs, o_pt, pt_ptr, o_cam, scratch, recs, pair_queue_len(9), pair_queues(9));
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
@@ -459,11 +451,6 @@ __device__ __forceinline__ uint32_t pairs_dma_cam(const PairBlock* __restrict__ 
 // MASKED: OptimizeParams modes that drop a column group (mask code in slot 15 of the camera); the default modes never pay for it.
 // The finished block: the NG groups' partial sums are folded into group 0 and stored.  Fast path (a block owned by one wave,
 // off the diagonal of S: all but a handful): nine plain stores by the nine lanes of group 0, no branches per element.
-__device__ unsigned long long g_pair_phase[8];
-void pairs_phase_cycles(unsigned long long out[8], bool reset) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_phase), 8 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_phase), z, sizeof z); }
-}
 struct Acc9 { double a0, a1, a2, a3, a4, a5, a6, a7, a8; };   // by value: an array argument would pin acc[] to scratch memory
 template <int DC>
 __device__ __noinline__ void pairs_flush_slow(double* __restrict__ dst, const uint32_t flags, const Acc9 av, int sub) {
@@ -504,9 +491,8 @@ __device__ __noinline__ void pairs_flush_slow_col(double* __restrict__ dst, cons
 // dependent round trips through the LDS crossbar (ds_bpermute): sub-blocks 0..7 own one aligned OCTET of lanes each
 // (lane = 8 sub + g, g = 0..6) and sub-block 8 takes the octets' eighth lanes (lane = 8 g + 7; lane 63 idles and ends up
 // holding sub-block 8's total).
-template <int DC, bool LEGACY = false>
+template <int DC>
 __device__ __forceinline__ void pairs_lane_map(int lane, int& g, int& sub) {
-    if (DC == 9 && LEGACY) { g = lane / 9; sub = lane - 9 * g; return; }   // lane = 9 g + sub, fold by ds_bpermute (A/B)
     if (DC == 9) {
         const bool eighth = (lane & 7) == 7;
         sub = eighth ? 8 : lane >> 3;
@@ -521,18 +507,15 @@ __device__ __forceinline__ double dpp_add_masked(double x) {   // x + (x moved b
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, BANK_MASK, true);
     return x + __hiloint2double(hi, lo);
 }
-template <int DC, bool LEGACY = false, int FABL = 0>   // FABL (timing experiments): 1 no fold over the groups, 2 no stores
+template <int DC>
 __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const int64_t pb_dst, const uint32_t pb_flags,
                                              double acc[9], int lane) {
     constexpr int NB3 = DC / 3, GL = NB3 * NB3;
     constexpr int NG = (DC == 9) ? 7 : 16, P2 = (DC == 9) ? 8 : 16;
     int g, sub;
-    pairs_lane_map<DC, LEGACY>(lane, g, sub);
+    pairs_lane_map<DC>(lane, g, sub);
     bool storer;
-    if (FABL & 1) {
-        storer = DC == 9 ? (lane == 63 || (lane & 7) == 6) : lane < GL;
-        if (DC == 9) sub = lane == 63 ? 8 : lane >> 3;
-    } else if (DC == 9 && !LEGACY) {
+    if (DC == 9) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             // sub-blocks 0..7: sum over the octet's lanes 0..6 into lane 6 (row_shr 4, 2, 1 into the upper half-octets only)
@@ -562,7 +545,6 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
         }
         storer = lane < GL;
     }
-    if ((FABL & 2) && acc[0] != 1.2345e300) return;
     if (storer) {
         double* dst = tiles + pb_dst;
         if (pb_flags == 0) {
@@ -578,16 +560,6 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
     }
 }
 
-// ABL (timing experiments only, results wrong when != 0): 1 no per-pair gathers, 2 no block products, 4 no U / V stores,
-// 8 no flush (fold + store of the finished block) -- NOTE: with the flush gone seven of the nine accumulators are dead and the
-// compiler drops their FMAs, so 8 measures "no flush and 7/9 of the products", not the flush (round 4: 512 / 1024 below do) --,
-// 512 no fold over the groups, 1024 no stores of the finished block, 16 no camera reads, 32 no Jacobian arithmetic; 64 (results RIGHT): phase
-// stamps -- every wave adds the shader cycles it spent in each phase of its chunks to g_pair_phase (read with
-// pairs_phase_cycles): 0 wait for the gathers, 1 unstage, 2 cameras + both Jacobians + U / V stores, 3 issue, 4 products and
-// flushes, 5 chunks, 6 flushes alone, 7 number of flushes.  Queued layout only: 4096 no transposition of the finished block
-// through LDS (its elements land in the wrong places); 1024 together
-// with 4096 leaves the accumulators without a use and removes the PRODUCT PHASE as well (it does not measure the stores).
-//
 // Nothing in the loop goes through the scalar memory path: s_load shares the lgkm counter with the LDS and returns out of
 // order, so one descriptor load in flight turns every LDS wait of the product loop into a wait for memory (the first
 // version of this kernel stalled ~1 us per chunk on its own chunk descriptor).  The task's chunk descriptors are loaded
@@ -595,15 +567,19 @@ __device__ __forceinline__ void pairs_flush2(double* __restrict__ tiles, const i
 // a vector load by the first lanes and are read the same way.
 // QL: the QUEUED layout (schur_pairs.h): every lane group owns a block of its own -- nine product steps per chunk without
 // segment bookkeeping, no fold over the groups, one descriptor per (chunk, queue) fetched by the lanes that store.
-template <int DC, bool MASKED, int ABL = 0, bool QL = false>
+// (The per-phase ablations and cycle stamps that rounds 3-5 timed this kernel with -- no gathers, no products, no stores, no
+// transposition ... -- are gone from the source: their numbers are profiles/r03_pairs_ablation.txt, r04_pairs_queued_*.txt,
+// r05_pairs_bundle_ablation.txt; the code is in the history, last at the round-5 head.)
+template <int DC, bool MASKED, bool QL = false>
 __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __restrict__ tiles, const PairTask* __restrict__ tasks,
                                                           int n_tasks, const PairChunk* __restrict__ chunks,
                                                           const PairBlock* __restrict__ blocks, const PairRec* __restrict__ recs,
                                                           const double* __restrict__ lmrec, const double* __restrict__ orec,
-                                                          const PairQDesc* __restrict__ qdesc, int lm_stride, int pad_unit, int pad_header) {
-    // the queued layout: d_c = 9 seven groups of nine lanes, nonets; d_c = 6 (round 5) sixteen groups of four lanes, quartets
-    constexpr int QLEN = pair_queue_len(DC), NQ = pair_queues(DC), ND = NQ + 1;
-    constexpr int NCAMS = (QL && DC == 6) ? 16 : 8;   // cameras staged per chunk: d_c = 6 the sixteen partners (two rounds of 64 pieces)
+                                                          const PairQDesc* __restrict__ qdesc) {
+    // the queued layout (d_c = 9 only): seven groups of nine lanes, nonets
+    static_assert(!QL || DC == 9, "the queued layout exists for nine-column cameras");
+    constexpr int NQ = pair_queues(DC), ND = NQ + 1;
+    constexpr int NCAMS = 8;   // cameras staged per chunk
     constexpr int UV = 2 * DC;
     constexpr int NB3 = DC / 3;
     constexpr int GL = NB3 * NB3;
@@ -621,8 +597,6 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     // 16 LDS cycles instead of 4 (tools/lds_conflict_sim.py: 96 of a chunk's 556 LDS cycles)
     constexpr int kCamLds = kCamStride + 2;
     __shared__ double lds_cams[4 * NCAMS * kCamLds];
-    __shared__ double lds_occ[(ABL & 128) ? 6000 : 1];   // ABL 128: +47 KB of LDS = ONE workgroup per CU (occupancy experiment)
-    if ((ABL & 128) && n_tasks == -12345) { lds_occ[threadIdx.x * 23] = 1.0; __syncthreads(); tiles[0] = lds_occ[threadIdx.x * 7 + 1]; }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int wg = blockIdx.x;
@@ -638,9 +612,8 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     double* Z = V + 64 * UV;
     if (lane < UV) Z[lane] = 0.0;
     int g, sub;
-    pairs_lane_map<DC, (ABL & 256) != 0>(lane, g, sub);
-    if (QL && DC == 9) { g = lane == 63 ? 0 : lane / 9; sub = lane == 63 ? 0 : lane - 9 * g; }   // (lane 63 shadows lane 0 and never stores)
-    // (QL, d_c = 6: pairs_lane_map's lane = 4 g + sub is the queue / sub-block mapping as it stands; every lane works)
+    pairs_lane_map<DC>(lane, g, sub);
+    if (QL) { g = lane == 63 ? 0 : lane / 9; sub = lane == 63 ? 0 : lane - 9 * g; }   // (lane 63 shadows lane 0 and never stores)
     const int bi = sub / NB3, bj = sub - bi * NB3;
     const bool worker = g < NG;
     double acc[NACC];
@@ -657,28 +630,16 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     uint32_t pend_fl = 0;
     bool pend_on = false;
     auto store_pending = [&]() {   // pend[r] = element (r, sub) of the block: store instruction r writes one whole 72-byte row per group
-        if (QL && pend_on && !(ABL & 1024)) {
+        if (QL && pend_on) {
             double* dst = tiles + (((int64_t)pend_dst.y << 32) | (uint32_t)pend_dst.x);
             const uint32_t fl = pend_fl & (kPairBlockAtomic | kPairBlockDiag);
 #define PEND_ACC9 Acc9{pend[0], pend[1 % (QL ? 9 : 1)], pend[2 % (QL ? 9 : 1)], pend[3 % (QL ? 9 : 1)], pend[4 % (QL ? 9 : 1)], pend[5 % (QL ? 9 : 1)], \
                       pend[6 % (QL ? 9 : 1)], pend[7 % (QL ? 9 : 1)], pend[8 % (QL ? 9 : 1)]}
-            if constexpr (DC == 9) {   // pend[r] = element (r, sub): one column per lane
-                if (fl == 0) {
+            if (fl == 0) {
 #pragma unroll
-                    for (int r = 0; r < 9; ++r) dst[r * kNB + sub] = pend[r % (QL ? 9 : 1)];
-                } else {
-                    pairs_flush_slow_col<DC>(dst, fl, PEND_ACC9, sub);
-                }
-            } else {         // d_c = 6: pend = the lane's 3 x 3 sub-block (bi, bj): a 48-byte row of the block is two adjacent lanes' stores
-                if (fl == 0) {
-                    double* d0 = dst + (3 * bi) * kNB + 3 * bj;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) d0[r * kNB + c] = pend[(3 * r + c) % (QL ? 9 : 1)];
-                } else {
-                    pairs_flush_slow<DC>(dst, fl, PEND_ACC9, sub);
-                }
+                for (int r = 0; r < 9; ++r) dst[r * kNB + sub] = pend[r % (QL ? 9 : 1)];
+            } else {
+                pairs_flush_slow_col<DC>(dst, fl, PEND_ACC9, sub);
             }
 #undef PEND_ACC9
         }
@@ -726,23 +687,12 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     };
     auto issue = [&](const uint4 rr, Coop& d) {
         const bool valid = rr.x != kPairPad;
-        // padding lanes read element 0 (bundles: a real record and its header, handed in -- unit 0 is a header, not a record)
-        const int i = valid ? (int)rr.x : pad_unit, j = valid ? (int)rr.y : pad_unit, l = valid ? (int)rr.z : pad_header;
+        // padding lanes read element 0
+        const int i = valid ? (int)rr.x : 0, j = valid ? (int)rr.y : 0, l = valid ? (int)rr.z : 0;
         const int qq = lane & 3, h = lane & 1;
-        // (lm_stride: 16 doubles = the landmark records; 4 = the bundle array, whose units the records then name: launch_schur_pairs)
-        auto lm0 = [&](auto sel) { return *reinterpret_cast<const double2*>(lmrec + (size_t)lm_stride * (size_t)quad_bcast(l, sel) + 2 * qq); };
+        auto lm0 = [&](auto sel) { return *reinterpret_cast<const double2*>(lmrec + (size_t)kLmStride * (size_t)quad_bcast(l, sel) + 2 * qq); };
         d.a0 = lm0(std::integral_constant<int, 0>{}); d.a1 = lm0(std::integral_constant<int, 1>{});
         d.a2 = lm0(std::integral_constant<int, 2>{}); d.a3 = lm0(std::integral_constant<int, 3>{});
-        if (ABL & 8192) {   // timing only (round 5): both projection records read from the landmark record's own 128-byte line --
-            // what a bundle [header | records] would cost if every pair's three pieces shared ONE L2 line (its best case)
-            const std::integral_constant<int, 0> k0{};
-            const std::integral_constant<int, 1> k1{};
-            d.i0 = *reinterpret_cast<const double2*>(lmrec + (size_t)lm_stride * (size_t)pair_bcast(l, k0) + 8 + 2 * h);
-            d.j0 = *reinterpret_cast<const double2*>(lmrec + (size_t)lm_stride * (size_t)pair_bcast(l, k0) + 12 + 2 * h);
-            d.i1 = *reinterpret_cast<const double2*>(lmrec + (size_t)lm_stride * (size_t)pair_bcast(l, k1) + 8 + 2 * h);
-            d.j1 = *reinterpret_cast<const double2*>(lmrec + (size_t)lm_stride * (size_t)pair_bcast(l, k1) + 12 + 2 * h);
-            return;
-        }
         {
             const std::integral_constant<int, 0> k{};
             d.i0 = *reinterpret_cast<const double2*>(orec + 4 * (size_t)pair_bcast(i, k) + 2 * h);
@@ -799,12 +749,8 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     };
     // the chunk's cameras, eight lanes each: queued layout = the row's camera (entry 7) and the seven queues' partners
     auto chunk_cam = [&](const PairChunk c, int qrel) -> uint32_t {
-        if (QL && DC == 6) return qdesc[ND * (size_t)(chunk0 + qrel) + (lane >> 3)].cj;   // partners of queues 0..7 (chunk_cam2: 8..15)
         if (QL) { const int cc = lane >> 3; return qdesc[ND * (size_t)(chunk0 + qrel) + (cc == 0 ? NQ : cc - 1)].cj; }
         return pairs_dma_cam(blocks, c, lane);
-    };
-    auto chunk_cam2 = [&](int qrel) -> uint32_t {   // (d_c = 6, queued: the second round of camera pieces)
-        return (QL && DC == 6) ? qdesc[ND * (size_t)(chunk0 + qrel) + 8 + (lane >> 3)].cj : 0u;
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ckv
     const uint4* rec4 = reinterpret_cast<const uint4*>(recs);
@@ -822,11 +768,9 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         return *reinterpret_cast<const double2*>(v.camp + kCamStride * (size_t)cam + 2 * (lane & 7));
     };
     double2 cam_stage = cam_piece(chunk_cam(ck, 0));
-    double2 cam_stage2 = (QL && DC == 6) ? cam_piece(chunk_cam2(0)) : make_double2(0.0, 0.0);
     PairChunk ck_next = chunk_desc(min(1, nchunks - 1));
     uint4 rr_next = rec4[(size_t)(chunk0 + min(1, nchunks - 1)) * 64 + lane];
     uint32_t cam_next = chunk_cam(ck_next, min(1, nchunks - 1));
-    uint32_t cam_next2 = chunk_cam2(min(1, nchunks - 1));
 
     // queued layout: the row's camera is the same for every pair of the task -- it stays in registers (the same address in
     // every lane: one request per load), and only the seven partners are read from the staged copy chunk by chunk
@@ -836,29 +780,19 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
 #pragma unroll
         for (int k = 0; k < 8; ++k) { const double2 a = pc[k]; cvi_task[2 * k] = a.x; cvi_task[2 * k + 1] = a.y; }
     }
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto stamp = [&]() -> unsigned long long { return (ABL & 64) ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull; };
     for (; q < nchunks; ++q) {
         const bool valid = rr.x != kPairPad;
         const uint32_t blk = valid ? rr.w : 0u;   // (queued layout: the slot's queue)
-        const unsigned long long t0 = stamp();
         // ---- cameras of this lane's pair: LDS (DMA issued a chunk ago) or, in a chunk of many tiny blocks, memory ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // gathers, block descriptors, and the LDS-DMA (it writes LDS behind the VM counter)
         *reinterpret_cast<double2*>(CAMS + (lane >> 3) * kCamLds + 2 * (lane & 7)) = cam_stage;   // (the previous chunk's camera reads are long done)
-        if constexpr (QL && DC == 6) *reinterpret_cast<double2*>(CAMS + (8 + (lane >> 3)) * kCamLds + 2 * (lane & 7)) = cam_stage2;
         __builtin_amdgcn_wave_barrier();
-        const unsigned long long t1 = stamp();
         Gather dat;
         unstage_dpp(coop, dat);
-        if (ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long t2 = stamp();
         double cvi[16], cvj[16];
-        if (ABL & 16) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { cvi[k] = dat.lm[k % 4].x + k; cvj[k] = dat.lm[k % 4].y - k; }
-        } else {
+        {
             if (QL) {
-                const double2* cj = reinterpret_cast<const double2*>(CAMS + ((DC == 9 ? 1 : 0) + blk) * kCamLds);
+                const double2* cj = reinterpret_cast<const double2*>(CAMS + (1 + blk) * kCamLds);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const double2 b = cj[k]; cvj[2 * k] = b.x; cvj[2 * k + 1] = b.y; }
 #pragma unroll
@@ -889,8 +823,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         double Q[3][2];
         {
             RecJac J;
-            if (ABL & 32) { J.a[0][0] = dat.rj0.x; J.a[0][1] = dat.rj0.y; J.a[0][2] = rj1.x; J.a[1][0] = rj1.y; J.a[1][1] = cvj[0]; J.a[1][2] = cvj[1]; J.xw = cvj[2]; J.yw = cvj[3]; J.t[0] = cvj[4]; J.t[1] = cvj[5]; J.t[2] = cvj[6]; }
-            else jac_from_rec(cvj, dat.rj0, rj1, pw, J);
+            jac_from_rec(cvj, dat.rj0, rj1, pw, J);
             double Jc[2][DC];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -913,15 +846,13 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             for (int k = 0; k < DC; ++k) {
                 const int e0 = 2 * k, e1 = 2 * k + 1;
                 const int s0 = e0 / 6, m0 = (e0 % 6) / 3, c0 = e0 % 3, s1 = e1 / 6, m1 = (e1 % 6) / 3, c1 = e1 % 3;
-                if (!(ABL & 4) || k == 0) pv[k] = make_double2(Jc[m0][3 * s0 + c0], Jc[m1][3 * s1 + c1]);
-                else asm volatile("" ::"v"(Jc[m0][3 * s0 + c0]), "v"(Jc[m1][3 * s1 + c1]));
+                pv[k] = make_double2(Jc[m0][3 * s0 + c0], Jc[m1][3 * s1 + c1]);
             }
         }
         // ---- row side i: M = -Jl_i Q, U = Jc_i^T M = [G ; p_w x G ; t (s M)], G = a_i^T M -----------------------------------
         {
             RecJac J;
-            if (ABL & 32) { J.a[0][0] = dat.ri0.x; J.a[0][1] = dat.ri0.y; J.a[0][2] = ri1.x; J.a[1][0] = ri1.y; J.a[1][1] = cvi[0]; J.a[1][2] = cvi[1]; J.xw = cvi[2]; J.yw = cvi[3]; J.t[0] = cvi[4]; J.t[1] = cvi[5]; J.t[2] = cvi[6]; }
-            else jac_from_rec(cvi, dat.ri0, ri1, pw, J);
+            jac_from_rec(cvi, dat.ri0, ri1, pw, J);
             double M[2][2];
 #pragma unroll
             for (int n = 0; n < 2; ++n)
@@ -944,14 +875,9 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             }
             double2* pu = reinterpret_cast<double2*>(U + lane * UV);
 #pragma unroll
-            for (int k = 0; k < UV / 2; ++k) {
-                if (!(ABL & 4) || k == 0) pu[k] = make_double2(u[2 * k], u[2 * k + 1]);
-                else asm volatile("" ::"v"(u[2 * k]), "v"(u[2 * k + 1]));
-            }
+            for (int k = 0; k < UV / 2; ++k) pu[k] = make_double2(u[2 * k], u[2 * k + 1]);
         }
         __builtin_amdgcn_wave_barrier();
-        if (ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long t3 = stamp();
         // ---- the next chunk's gathers, block descriptors and cameras go out now and land during the product phase ------------
         const PairChunk ck_cur = ck;
         const BlockDesc bd_cur = bd_next;     // (the descriptors of THIS chunk: loaded a chunk ago, or before the loop)
@@ -960,28 +886,25 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             // loop-carried register makes the compiler resolve the phi with a copy right behind the load -- and wait for
             // every outstanding load (s_waitcnt vmcnt(0)) to do it, i.e. for the gathers issued three lines earlier.
             ck = ck_next; rr = rr_next;
-            if (!(ABL & 1)) issue(rr, coop);
+            issue(rr, coop);
             load_blocks(ck, bd_next, min(q + 1, nchunks - 1));
             dma = QL || 1 + __popc(ck.mask & ~1u) <= kPairDmaBlocks;
             cam_stage = cam_piece(cam_next);
-            if constexpr (QL && DC == 6) cam_stage2 = cam_piece(cam_next2);
             const int q2 = min(q + 2, nchunks - 1);
             ck_next = chunk_desc(q2);
             rr_next = rec4[(size_t)(chunk0 + q2) * 64 + lane];
             cam_next = chunk_cam(ck_next, q2);
-            cam_next2 = chunk_cam2(q2);
         }
         // The block finished by the PREVIOUS chunk goes to memory here, behind this chunk's gathers: the vector-memory counter
         // counts stores too and in issue order, so stores issued before loads that the code waits for (the compiler puts its own
         // s_waitcnt vmcnt(small) in front of the first use of a prefetched descriptor) stall the wave until they are ACKNOWLEDGED --
         // 0.5 ms of the kernel when they sat at the top of the chunk.  Here the next wait for memory is a whole product phase away.
         if constexpr (QL) store_pending();
-        const unsigned long long t4 = stamp();
         // ---- block products over the 64 slots.  Uniform loop, two pairs per trip with all twelve operand reads issued up
         // front; a lane whose pair lies beyond the segment (and the idle 64th lane) reads the zero row instead.
         if constexpr (QL) {
             // nine steps, pair g + 7 t of the chunk in step t; ping-pong operand registers as below
-            if (!(ABL & 2)) {
+            {
                 auto ld = [&](int t, double2& u0, double2& u1, double2& u2, double2& v0, double2& v1, double2& v2) {
                     const double2* qu = reinterpret_cast<const double2*>(U + (g + NQ * t) * UV + bi * 6);
                     const double2* qv = reinterpret_cast<const double2*>(V + (g + NQ * t) * UV + bj * 6);
@@ -997,29 +920,18 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
                 };
                 double2 a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5;
                 ld(0, a0, a1, a2, a3, a4, a5);
-                if constexpr (QLEN == 9) {
 #pragma unroll
-                    for (int t = 0; t < 8; t += 2) {
-                        ld(t + 1, b0, b1, b2, b3, b4, b5);
-                        mac(a0, a1, a2, a3, a4, a5);
-                        ld(t + 2, a0, a1, a2, a3, a4, a5);
-                        mac(b0, b1, b2, b3, b4, b5);
-                    }
+                for (int t = 0; t < 8; t += 2) {
+                    ld(t + 1, b0, b1, b2, b3, b4, b5);
                     mac(a0, a1, a2, a3, a4, a5);
-                } else {   // four steps
-                    ld(1, b0, b1, b2, b3, b4, b5);
-                    mac(a0, a1, a2, a3, a4, a5);
-                    ld(2, a0, a1, a2, a3, a4, a5);
-                    mac(b0, b1, b2, b3, b4, b5);
-                    ld(3, b0, b1, b2, b3, b4, b5);
-                    mac(a0, a1, a2, a3, a4, a5);
+                    ld(t + 2, a0, a1, a2, a3, a4, a5);
                     mac(b0, b1, b2, b3, b4, b5);
                 }
+                mac(a0, a1, a2, a3, a4, a5);
             }
             // a queue whose block (piece) ends with this chunk: its nine lanes hold the finished 3 x 3 sub-blocks.  They are
             // parked and stored at the top of the NEXT chunk, behind its wait for the gathers: stored here they would be the
             // youngest entries of the memory counter that wait drains, i.e. a store round trip on every chunk's critical path
-            const unsigned long long f0 = stamp();
             // (a block cut between queue g's tail and queue g + 1's head: the head's sum waits in `carry` for the last chunk)
             if (q == nchunks - 1) {   // wave-uniform: the tails that join a carried head (kPairQJoin only occurs here)
                 const bool join = ((ck_cur.mask >> g) & 1u) && (bd_cur.flags & kPairQJoin);
@@ -1034,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
                 const bool mine = (ck_cur.mask >> g) & 1u;
                 const bool keep = mine && (bd_cur.flags & kPairQCarry) != 0;
                 double* T = U + 81 * g;
-                if (DC == 9 && mine && !keep && lane < 63 && !(ABL & 4096)) {   // (lane 63 shadows lane 0 except in a join: it must not write)
+                if (mine && !keep && lane < 63) {   // (lane 63 shadows lane 0 except in a join: it must not write)
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -1044,15 +956,14 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
                 if (mine) {
                     if (!keep) {
 #pragma unroll
-                        for (int r = 0; r < 9; ++r) pend[r] = ((ABL & 4096) || DC == 6) ? acc[r] : T[9 * sub + r];   // (4096: timing only, no transposition; d_c = 6: the sub-block as it stands)
-                        pend_dst = bd_cur.dst; pend_fl = bd_cur.flags; pend_on = DC == 6 || lane < 63;
+                        for (int r = 0; r < 9; ++r) pend[r] = T[9 * sub + r];
+                        pend_dst = bd_cur.dst; pend_fl = bd_cur.flags; pend_on = lane < 63;
                     }
 #pragma unroll
                     for (int k = 0; k < 9; ++k) { carry[k] = keep ? acc[k] : carry[k]; acc[k] = 0.0; }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            if (ABL & 64) { ph[6] += stamp() - f0; ph[7] += 1; }
         } else {
         uint32_t mask = ck_cur.mask;
         int seg0 = 0, lb = 0;                 // lb: index of the running block inside this chunk's descriptors
@@ -1063,10 +974,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
             for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
         };
         auto flush = [&]() {
-            const unsigned long long f0 = stamp();
-            if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0, (ABL >> 9) & 3>(tiles, cur_dst, cur_flags, acc, lane);
-            else if (acc[0] == 1.2345e300) tiles[0] = acc[1];
-            if (ABL & 64) { ph[6] += stamp() - f0; ph[7] += 1; }
+            pairs_flush2<DC>(tiles, cur_dst, cur_flags, acc, lane);
         };
         if (mask & 1u) {   // the chunk opens a new block
             if (cur >= 0) flush();
@@ -1079,7 +987,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         mask &= ~1u;
         for (;;) {
             const int seg1 = mask ? 2 * (__ffs(mask) - 1) : 64;      // wave-uniform
-            if (!(ABL & 2)) {
+            {
                 // One pair per step and lane, ping-pong operand registers: the six reads of the NEXT pair are in flight while
                 // the 18 FMA of this one run.  Uniform control flow; a lane whose pair lies beyond the segment (and the idle
                 // lane) reads the zero row.
@@ -1122,70 +1030,27 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
         }
         __builtin_amdgcn_wave_barrier();
         bd = bd_next;
-        if (ABL & 64) {
-            const unsigned long long t5 = stamp();
-            ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4; ph[5] += 1;
-        }
-    }
-    if ((ABL & 64) && lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_pair_phase[k], ph[k]);
     }
     if constexpr (QL) store_pending();
     if (!QL && cur >= 0) {
-        if (!(ABL & 8)) pairs_flush2<DC, (ABL & 256) != 0>(tiles, cur_dst, cur_flags, acc, lane);
-        else if (acc[0] == 1.2345e300) tiles[0] = acc[1];
+        pairs_flush2<DC>(tiles, cur_dst, cur_flags, acc, lane);
     }
 }
 
 // The pair kernel is the record form (k_schur_pairs_r): it needs the projection records k_landmark_reduce writes.
-// ablation: timing experiments only (tools/schur_bench.py --abl; results are WRONG when != 0), per-solver state handed in
-// by the caller.  Rounds 2-3 kept three more pair kernels for A/B (fused one pair per lane, fused two lanes per pair,
-// record form two lanes per pair: 3.96 / 3.75-3.91 / 3.94 ms against 3.43-3.8 for this one on final-13682,
-// profiles/r03_pairs_ablation.txt); they were deleted in round 4.
+// qdesc != NULL: the queued layout (nine-column cameras).  Rounds 2-3 kept three more pair kernels for A/B (fused one pair per
+// lane, fused two lanes per pair, record form two lanes per pair: 3.96 / 3.75-3.91 / 3.94 ms against 3.43-3.8 for this one on
+// final-13682, profiles/r03_pairs_ablation.txt); they were deleted in round 4, the LDS row form of round 2 in round 6.
 void launch_schur_pairs(int dc, const BAView& v, double* tiles, const PairTask* tasks, int n_tasks, const PairChunk* chunks,
-                        const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, int ablation,
-                        const double* orec, const PairQDesc* qdesc, int pad_unit, int pad_header) {
+                        const PairBlock* blocks, const PairRec* recs, const double* lmrec, hipStream_t s, const double* orec,
+                        const PairQDesc* qdesc) {
     if (n_tasks == 0) return;
     const unsigned grid = (unsigned)((n_tasks + 3) / 4);
-    // landmark bundles: the first line of a landmark's record is read from the bundle array (32-byte units), not from lmrec
-    const double* lmb = v.bun_ptr ? orec : lmrec;
-    const int lms = v.bun_ptr ? 4 : kLmStride;
-    if (!v.bun_ptr) { pad_unit = 0; pad_header = 0; }
-    if (qdesc && dc == 6) {   // the queued layout for six-column cameras (round 5): sixteen queues of four pairs
-        if (v.mask_code != 6) hipLaunchKernelGGL((k_schur_pairs_r<6, true, 0, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmb, orec, qdesc, lms, pad_unit, pad_header);
-        else hipLaunchKernelGGL((k_schur_pairs_r<6, false, 0, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmb, orec, qdesc, lms, pad_unit, pad_header);
-        return;
-    }
-    if (qdesc) {   // the queued layout, nine columns per camera
-#define PAIRS_Q(MK, A) hipLaunchKernelGGL((k_schur_pairs_r<9, MK, A, true>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmb, orec, qdesc, lms, pad_unit, pad_header)
-        if (v.mask_code != 7) PAIRS_Q(true, 0);
-        else if (ablation == 64) PAIRS_Q(false, 64);
-        else if (ablation == 1) PAIRS_Q(false, 1);
-        else if (ablation == 2) PAIRS_Q(false, 2);
-        else if (ablation == 1024) PAIRS_Q(false, 1024);
-        else if (ablation == 4096) PAIRS_Q(false, 4096);
-        else if (ablation == 16) PAIRS_Q(false, 16);
-        else if (ablation == 64 + 1024) PAIRS_Q(false, 64 + 1024);
-        else if (ablation == 64 + 4096) PAIRS_Q(false, 64 + 4096);
-        else if (ablation == 64 + 5120) PAIRS_Q(false, 64 + 5120);
-        else if (ablation == 4096 + 1024) PAIRS_Q(false, 4096 + 1024);
-        else if (ablation == 8192) PAIRS_Q(false, 8192);
-        else PAIRS_Q(false, 0);
-#undef PAIRS_Q
-        return;
-    }
-    if (ablation != 0 && dc == 9) {   // timing experiments (SelfCalibration only)
-#define PAIRS_RA(A) case A: hipLaunchKernelGGL((k_schur_pairs_r<9, false, A>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmb, orec, nullptr, lms, pad_unit, pad_header); return
-        switch (ablation) { PAIRS_RA(512); PAIRS_RA(1024); PAIRS_RA(256); PAIRS_RA(128); PAIRS_RA(64); PAIRS_RA(1); PAIRS_RA(2); PAIRS_RA(4); PAIRS_RA(8); PAIRS_RA(16); PAIRS_RA(32); PAIRS_RA(6); PAIRS_RA(14); PAIRS_RA(15); PAIRS_RA(47); PAIRS_RA(63); PAIRS_RA(3);
-            default: break;   // an unlisted value: the plain kernel below, never a missing launch
-        }
-#undef PAIRS_RA
-    }
     const bool masked = v.mask_code != (dc == 9 ? 7 : 6);
-#define PAIRS_R(DCV, MK) hipLaunchKernelGGL((k_schur_pairs_r<DCV, MK>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmb, orec, nullptr, lms, pad_unit, pad_header)
-    if (dc == 9) { if (masked) PAIRS_R(9, true); else PAIRS_R(9, false); }
-    else { if (masked) PAIRS_R(6, true); else PAIRS_R(6, false); }
+#define PAIRS_R(DCV, MK, Q) hipLaunchKernelGGL((k_schur_pairs_r<DCV, MK, Q>), dim3(grid), dim3(256), 0, s, v, tiles, tasks, n_tasks, chunks, blocks, recs, lmrec, orec, qdesc)
+    if (dc == 9 && qdesc) { if (masked) PAIRS_R(9, true, true); else PAIRS_R(9, false, true); }
+    else if (dc == 9) { if (masked) PAIRS_R(9, true, false); else PAIRS_R(9, false, false); }
+    else { if (masked) PAIRS_R(6, true, false); else PAIRS_R(6, false, false); }
 #undef PAIRS_R
 }
 

@@ -89,54 +89,41 @@ class Solver : public LmBackend {
     void enable_graphs(bool on) { use_graphs_ = on; tp_.enable_graphs(on); }
     void enable_overlap(bool on) { tp_.enable_overlap(on); }
     void enable_tri_flow(bool on) { tp_.enable_tri_flow(on); }
-    void set_rec_backsub(bool on) { rec_backsub_ = on; }        // before set_structure: back-substitution / matrix-free operator from the projection records
-    void set_cam_staging(bool on) { cam_staging_ = on; }        // landmark-major kernels: the workgroup's cameras staged in LDS
-    void set_pairs_ablation(int bits) { pairs_ablation_ = bits; }   // timing experiments only (results are wrong when != 0)
     int sweep_timeouts() const { return tp_.sweep_timeouts(); }   // dataflow sweeps that gave up and were repeated level by level
     void debug_poison_next_solve(int which) { tp_.debug_poison_next_solve(which); }
     int debug_occupy_cus(int n_cus, int micros) { return check_hip(tp_.debug_occupy_cus(n_cus, micros), "debug_occupy_cus"); }
     void set_split_u1(int min_tasks) { tp_.set_split_u1(min_tasks); }
-    void set_panel_split(int min_rest) { tp_.set_panel_split(min_rest); }
-    void set_fwd_beside_top(bool on) { tp_.set_fwd_beside_top(on); }
-    void set_tri_inline(int max_cols) { tp_.set_tri_inline(max_cols); }
-    void set_first_writer(bool on) { tp_.set_first_writer(on); }
     void set_overlap_min(int n) { tp_.set_overlap_min(n); }
     void set_gate_min(int n) { tp_.set_gate_min(n); }
-    void set_gate_pos(int p) { tp_.set_gate_pos(p); }
     // before set_structure: the handle will only run the matrix-free variant (2, IterativeSchurSolver).  S is never formed, so
     // neither is its tile structure beyond the diagonal blocks the Schur-Jacobi preconditioner needs, nor the pair list: the
     // set-up and the LM iteration no longer depend on the fill of S (a photo collection whose S is dense: tools/structure_sweep.py)
-    void set_matrix_free_only(bool on) { matrix_free_only_ = on; }
+    void set_matrix_free_only(bool on) { matrix_free_only_opt_ = on; }
     // Automatic variant selection (round 5; the LM dispatch of levenberg_marquardt.rs:1039-1082 never fails on the fill of S,
     // so a drop-in backend may not either): when the tile plan of S is refused at set_structure -- its update list beyond
     // TilePlan's limit, or (single rank) its tiles beyond the free HBM -- the handle is built matrix-free only by itself and
     // variants 0 / 1 are answered by the matrix-free PCG (IterativeSchurSolver semantics, implicit_schur.rs:835-946): variant 0
     // at that solver's own defaults (500 iterations, 1e-9: implicit_schur.rs:94-95), variant 1 at the caller's cg parameters.
     // "auto_variant" 0 restores the refusal.  variant_used() / variant_reason() say what happened (apexgpu_variant_info).
-    void set_queued6(bool on) { queued6_ = on; }
-    void set_bundles(bool on) { bundles_ = on; }
-    void set_prezero(bool on) { prezero_ = on; }
     void set_eager_step_eval(bool on) { eager_eval_ = on; }
-    void set_device_gathers(bool on) { device_gathers_ = on; }
-    void set_implicit_cam_records(bool on) { cam_records_ = on; }
-    void set_cam_beside_pairs(bool on) { cam_beside_ = on; }
-    void set_zero_beside_lm(bool on) { zero_beside_lm_ = on; }
     void set_one_wait(bool on) { one_wait_ = on; }
     void set_device_pair_recs(bool on) { device_pair_recs_ = on; }   // before set_structure ("device_pair_list")
     int get_pair_records(uint32_t* recs4_out, int64_t cap_slots);     // tests: the pair records as they sit on the device
     void set_auto_variant(bool on) { auto_variant_ = on; }
+    void set_variant_cost_percent(int pct) { variant_cost_percent_ = pct < 0 ? 0 : pct; }   // before set_structure (see build_plan)
+    // [0] predicted ms per solve of the direct path (tile Cholesky + sweeps; 0: never evaluated -- "matrix_free_only"), [1] of the
+    // matrix-free PCG at IterativeSchurSolver's cap, [2] what set_structure chose: 0 direct, 1 matrix-free by predicted cost,
+    // 2 matrix-free because the plan was refused (size / memory), 3 matrix-free by the caller's option, [3] the cap behind [1]
+    void variant_costs(double out[4]) const { out[0] = pred_direct_ms_; out[1] = pred_mf_ms_; out[2] = variant_choice_; out[3] = 500.0; }
     void set_max_tile_updates(int64_t n) { tp_.set_max_updates(n); }   // tests: force the refusal on a small problem
     int variant_used(int asked) const { return (auto_fallback_ && asked != 2) ? 2 : asked; }
     bool auto_fallback() const { return auto_fallback_; }
     const std::string& variant_reason() const { return fallback_reason_; }
     void set_two_side(int mode) { tp_.set_two_side(mode); }
     void set_factor_flow(int max_cols, int max_rows) { tp_.set_factor_flow(max_cols, max_rows); }
-    void set_factor_flow_tile(bool on) { tp_.set_flow_tile_units(on); }
-    void set_factor_flow_dyn(bool on) { tp_.set_flow_dyn(on); }
     int factor_flow_timeouts() const { return n_factor_flow_timeouts_; }
     void debug_poison_next_factor() { tp_.debug_poison_next_factor(); }
-    void enable_fused_forward(bool on) { tp_.enable_fused_forward(on); }
-    void use_row_schur(int v) { rows_form_ = v == 2 ? 2 : (v == 4 ? 4 : 3); }   // 3 sorted pair list (default), 2 LDS rows (the A/B)
+    void set_schur_form(int v) { rows_form_ = v == 4 ? 4 : 3; }   // 4 queued layout (default; nine-column cameras), 3 one running block per wave
     bool has_structure() const { return have_structure_; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void set_hubs_last(bool on) { hubs_last_ = on; }
@@ -152,7 +139,7 @@ class Solver : public LmBackend {
     double schur_scatter_pairs() const { return (double)n_pairs_; }
     double pair_blocks() const { return (double)n_pair_blocks_; }
     double pair_slots() const { return (double)n_pair_slots_; }
-    // the form that RUNS (4 = the queued layout: nine-column cameras, and six-column ones with "pairs_queued6")
+    // the form that RUNS (4 = the queued layout: nine-column cameras)
     int schur_form() const { return (rows_form_ == 4 && !pair_queued_) ? 3 : rows_form_; }
     const double* setup_seconds() const { return setup_s_; }
     double touched_tiles() const { return (double)n_present_; }
@@ -227,9 +214,6 @@ class Solver : public LmBackend {
     bool pin_busy_[2] = {false, false};   // pin_ev_[b] has been recorded behind a DMA out of pin_[b] and not waited for yet
     double *poses_[2] = {nullptr, nullptr}, *intr_[2] = {nullptr, nullptr}, *pts_[2] = {nullptr, nullptr};
     double* camp_[2] = {nullptr, nullptr};  // prepared cameras of the two parameter sets
-    RowTask* rtasks2_ = nullptr;     // k_schur_rows2: the same row tasks over chunks of entries
-    RowChunk* rchunks_ = nullptr;
-    RowEntry* rentries_ = nullptr;
     PairTask* ptasks_ = nullptr;     // rows_form_ 3: the sorted camera-pair list (schur_pairs.h)
     PairChunk* pchunks_ = nullptr;
     PairBlock* pblocks_ = nullptr;
@@ -237,21 +221,9 @@ class Solver : public LmBackend {
     PairQDesc* pqdesc_ = nullptr;    // rows_form_ 4 (and d_c = 9): the queued layout's descriptors, else null
     uint8_t *o_slot_ = nullptr, *wg_cam_n_ = nullptr;   // camera staging lists of the landmark-major kernels (BAView::o_slot)
     uint32_t* wg_cam_list_ = nullptr;
-    bool cam_staging_ = true;
-    bool matrix_free_only_ = false;
-    // "prezero_tiles": the 1.34 GB of S tiles cleared for the NEXT assembly on a side stream right behind a finished Cholesky
-    // solve -- beside the step statistics, the retraction and the trial cost -- instead of at the head of the assembly (0.19 ms).
-    // Measured (round 5, profiles/r05_ab_one_wait_prezero.txt): the clear is not hidden, it moves -- the camera stage loses 0.17
-    // ms and k_step_stats / k_retract_points, which stream the same HBM, gain 0.18: 12.77 against 12.78 ms.  Off.
+    bool matrix_free_only_opt_ = false;   // the caller's option ("matrix_free_only")
+    bool matrix_free_only_ = false;       // the effective state of the structure that is built: the option, or the automatic selection
     bool one_wait_ = true;   // "one_wait": one host wait per Cholesky solve (solve_augmented); 0 = three, as in rounds 1-4
-    bool prezero_ = false, tiles_prezeroed_ = false;
-    hipStream_t zero_stream_ = nullptr;
-    hipEvent_t zero_ev_ = nullptr;
-    // "cam_beside_pairs": k_cam_reduce (the diagonal blocks of S, g_c, g_red) on zero_stream_ beside the pair kernel (every other
-    // block of S): disjoint outputs, both read what k_landmark_reduce wrote
-    bool cam_beside_ = false;
-    bool zero_beside_lm_ = false;   // "zero_beside_lm": the tile clears on the side stream beside k_landmark_reduce
-    hipEvent_t cam_ev_[2] = {nullptr, nullptr};
     // "eager_step_eval" (round 5): what the LM loop asks next of every solve -- the step statistics (apexgpu_step_stats) and the
     // trial point with its cost (apexgpu_eval_step) -- is enqueued behind the back-substitution and read at the solve's own wait:
     // the two calls then answer from the host, without a launch or a wait of their own (three device round trips per LM
@@ -263,39 +235,22 @@ class Solver : public LmBackend {
     double* eager_host_ = nullptr;               // pinned: [0..5] step statistics, [6] sum of squares at the trial point
     double* pcg_host_ = nullptr;                 // pinned: two slots of the matrix-free PCG's scalars (read one iteration behind)
     hipEvent_t pcg_ev_[2] = {nullptr, nullptr};
-    bool bundles_ = false;           // "landmark_bundles": BAView::bun_ptr (ba_kernels.h).  Built and measured in round 5 (profiles/
-                                     // r05_ab_landmark_bundles.txt): the pair kernel gains 0.10 ms (2.90 against 3.00), k_landmark_reduce
-                                     // loses 0.33 (1.05 against 0.72: a header per landmark, records no longer one contiguous stream) and
-                                     // k_back_substitute 0.05 -- a net loss of 0.2-0.3 ms per LM iteration.  Off.
-    int* bun_ptr_ = nullptr;         // [n_pt] device copy
-    int bun_pad_unit_ = 0, bun_pad_header_ = 0;
-    bool queued6_ = false;           // "pairs_queued6": the queued layout for six-column cameras too (measured slower: ba_structure.h)
     bool device_pair_recs_ = true;   // queued layout: the pair records are written by the device (k_build_pair_recs_q), not built on the host and copied
     bool auto_variant_ = true, auto_fallback_ = false;   // see set_auto_variant
+    int variant_cost_percent_ = 100, variant_choice_ = 0;
+    double pred_direct_ms_ = 0.0, pred_mf_ms_ = 0.0;
     std::string fallback_reason_;
-    bool rec_backsub_ = true;
     bool orec_fresh_ = false;   // orec_ holds the records of the current parameters' last linearisation
-    const double* backsub_records() const { return rec_backsub_ && orec_fresh_ ? orec_ : nullptr; }
-    // the same records in camera-major order for the camera half of the matrix-free operator ("implicit_cam_records"):
-    // allocated by the first matrix-free assembly, gathered once per linearisation (k_gather_records).  Built and measured in
-    // round 5: S x to 1e-12 of the CPU restatement's, ~130 instead of ~500 fp64 instructions per observation -- and SLOWER, 0.547 against
-    // 0.518 ms per PCG iteration on synthetic-10k (profiles/r05_ab_implicit_cam_records.txt): the camera half is bound by its
-    // 64-byte landmark gathers, and the records add 32 bytes per observation to the stream.  Off.
-    double* corec_ = nullptr;
-    bool corec_fresh_ = false, cam_records_ = false;
+    const double* backsub_records() const { return orec_fresh_ ? orec_ : nullptr; }   // the projection records of THIS linearisation
     double* orec_ = nullptr;   // [local observations][4] projection records written by k_landmark_reduce (pair kernel, record form)
     int n_ptasks_ = 0;
     int64_t n_pair_blocks_ = 0, n_pair_slots_ = 0;
     bool pair_queued_ = false;       // what build_pair_lists arrived at (PairLists::queued)
     int rows_form_ = 4;              // 4 (default): the sorted pair list in the QUEUED layout (every lane group owns a block, no fold:
                                      // schur_pairs.h); 3: the same list reduced over the lanes of a wave (k_schur_pairs_r: every block
-                                     // S(ci, cj) stored once by one wave, no atomics, no LDS accumulators); 2: the LDS row form,
-                                     // one lane per observation (k_schur_rows2: 6.0 ms against 3.6-3.8 on final-13682), kept
-                                     // as the A/B.  Select before set_structure.  (Rounds 1-3 also carried a global-atomics
-                                     // form, 135 ms, and a one-lane-per-pair row form, 9.7 ms: deleted in round 4.)
-    int* nbr_ = nullptr;
-    int n_rtasks_ = 0;
-    int pairs_ablation_ = 0;   // k_schur_pairs_r: timing-only ablation bits
+                                     // S(ci, cj) stored once by one wave, no atomics, no LDS accumulators: what six-column cameras
+                                     // run).  Select before set_structure.  (Rounds 1-3 also carried a global-atomics form, 135 ms,
+                                     // and two LDS row forms, 9.7 / 6.0 ms: deleted in rounds 4 and 6.)
     uint32_t *o_cam_ = nullptr, *o_pt_ = nullptr, *co_pt_ = nullptr;
     double2* co_uv_ = nullptr;
     int* co_rank_ = nullptr;

@@ -44,21 +44,20 @@ int mode_mask(int mode) {
 Solver::Solver(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int device)
     : n_cam_(n_cam), n_pt_(n_pt), n_obs_(n_obs), mode_(mode), dc_(mode_mask(mode) & 1 ? 9 : 6), device_(device) {
     lm_lo_ = 0; lm_hi_ = n_pt;
+    HostBlockCache::get().retain();   // (the set-up's host blocks are cached only while a handle is alive: host_parallel.h)
 }
 
 Solver::~Solver() {
     if (free_thread_.joinable()) free_thread_.join();
+    HostBlockCache::get().release();   // the last handle returns the cached blocks to the system
     hipSetDevice(device_);
     if (stream_) hipStreamSynchronize(stream_);
-    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], rtasks2_, rchunks_, rentries_, ptasks_, pchunks_, pblocks_, precs_, pqdesc_, orec_, corec_, bun_ptr_, o_slot_, wg_cam_n_, wg_cam_list_, nbr_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
+    void* ptrs[] = {poses_[0], poses_[1], intr_[0], intr_[1], pts_[0], pts_[1], camp_[0], camp_[1], ptasks_, pchunks_, pblocks_, precs_, pqdesc_, orec_, o_slot_, wg_cam_n_, wg_cam_list_, o_cam_, o_pt_, o_uv_, o_orig_, pt_ptr_,
                     cam_ptr_, cam_obs_, co_pt_, co_uv_, co_rank_, fix_pose_, fix_intr_, fix_pt_, g_c_, g_red_,
                     dcam_, hinv_, g_l_, dl_, partial_, scal_, flags_, pcg_buf_, lmu_, sd_, minv_, cam_scale_, pt_scale_, lam_mask_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     comm_.reset();
-    if (zero_stream_) { (void)hipStreamSynchronize(zero_stream_); (void)hipStreamDestroy(zero_stream_); }
-    if (zero_ev_) (void)hipEventDestroy(zero_ev_);
-    for (hipEvent_t e : cam_ev_) if (e) (void)hipEventDestroy(e);
     if (pcg_host_) (void)hipHostFree(pcg_host_);
     if (eager_host_) (void)hipHostFree(eager_host_);
     for (hipEvent_t e : pcg_ev_) if (e) (void)hipEventDestroy(e);
@@ -115,8 +114,7 @@ BAView Solver::view(int which) const {
     v.cam_scale = scaled_ ? cam_scale_ : nullptr;
     v.pt_scale = scaled_ ? pt_scale_ : nullptr;
     v.lam_mask = tree_shard_ ? lam_mask_ : nullptr;
-    v.o_slot = cam_staging_ ? o_slot_ : nullptr; v.wg_cam_n = wg_cam_n_; v.wg_cam_list = wg_cam_list_;
-    v.bun_ptr = bun_ptr_;
+    v.o_slot = o_slot_; v.wg_cam_n = wg_cam_n_; v.wg_cam_list = wg_cam_list_;
     return v;
 }
 
@@ -195,14 +193,16 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     struct RawFree { double*& p; ~RawFree() { if (p) { (void)hipFree(p); p = nullptr; } } } raw_free{raw_uv};
     std::promise<hipError_t> init_p;
     std::shared_future<hipError_t> init_f = init_p.get_future().share();
-    std::thread warmer([this, &init_p, &raw_uv, raw_uv_wanted, obs_uv] {
+    std::promise<bool> validated_p;   // (the 0.5 GB copy of the measurements does not start for a call that is about to be refused)
+    std::shared_future<bool> validated_f = validated_p.get_future().share();
+    std::thread warmer([this, &init_p, &raw_uv, raw_uv_wanted, obs_uv, validated_f] {
         SetupTrace wt;
         hipError_t e = hipSetDevice(device_);
         if (e == hipSuccess && !stream_) e = hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
         init_p.set_value(e);
         wt.mark("device thread: device, stream");
         if (e != hipSuccess) return;
-        if (raw_uv_wanted) {   // the caller's measurements as they are, beside the host's list building (device_gathers_)
+        if (raw_uv_wanted && validated_f.get()) {   // the caller's measurements as they are, beside the host's list building -- once the lists are valid
             if (hipMalloc(reinterpret_cast<void**>(&raw_uv), std::max<size_t>(2 * (size_t)n_obs_, 2) * sizeof(double)) != hipSuccess ||
                 hipMemcpy(raw_uv, obs_uv, 2 * (size_t)n_obs_ * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
                 if (raw_uv) { (void)hipFree(raw_uv); raw_uv = nullptr; }
@@ -222,6 +222,8 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         return e != hipSuccess ? e : hipSetDevice(device_);
     };
     struct WJoiner { std::thread& t; ~WJoiner() { if (t.joinable()) t.join(); } } wjoiner{warmer};
+    // (declared behind the joiner: destroyed before it, so an early return releases the device thread before it is joined)
+    struct Unblock { std::promise<bool>& p; bool done = false; void set(bool v) { if (!done) { done = true; p.set_value(v); } } ~Unblock() { set(false); } } validated{validated_p};
     SetupTrace tr;
     {
         std::atomic<int64_t> bad(n_obs_);   // first observation that references a missing variable
@@ -235,6 +237,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         });
         if (bad.load() < n_obs_) return fail(kInvalidInput, "observation " + std::to_string(bad.load()) + " references a missing variable");
     }
+    validated.set(true);
     huber_delta_ = huber_delta;
     intr_col_.assign(intr_col, intr_col + n_cam_);
     pose_col_.assign(pose_col, pose_col + n_cam_);
@@ -247,12 +250,14 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     // cameras last, nested dissection of the tile graph), tile structure, landmark sharding, observation lists ------
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    HostBlockCache::get().begin_setup();
+    matrix_free_only_ = matrix_free_only_opt_;   // (an automatic selection of an earlier set_structure on this handle does not stick)
+    auto_fallback_ = false; fallback_reason_.clear();
     BaStructOptions so;
     so.dc = dc_; so.use_nd = use_nd_; so.nd_leaf = nd_leaf_; so.hubs_last = hubs_last_;
     so.rank = rank_; so.world = world_; so.dist_factor = dist_factor_; so.tree_sharding = tree_sharding_;
-    so.dist_selftest = dist_selftest_; so.schur_form = rows_form_; so.pair_task_slots = pair_task_slots_; so.queued6 = queued6_;
+    so.dist_selftest = dist_selftest_; so.schur_form = rows_form_; so.pair_task_slots = pair_task_slots_;
     so.device_gathers = device_gathers_ && world_ == 1;
-    so.bundles = bundles_ && (rows_form_ == 3 || rows_form_ == 4) && !matrix_free_only_;   // (the pair kernel's layout; a matrix-free handle keeps plain records)
     std::unique_ptr<BaHostStructure> hs_owner(new BaHostStructure);
     BaHostStructure& hs = *hs_owner;
     // Camera order and tile structure first; then the tile plan (symbolic fill, task lists, 1.4 GB of device allocations: 0.06-
@@ -272,15 +277,29 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         }
         tp_.enable_graphs(use_graphs_);
         auto_fallback_ = false; fallback_reason_.clear();
+        // Variant selection by predicted cost (round 6; the reference's dispatch never fails on the fill of S and a drop-in backend
+        // should not spend 10 s where it owns a 0.5 s way to the same step: levenberg_marquardt.rs:1039-1082).  The matrix-free
+        // PCG costs at most its cap times one S p -- two passes over the observations, 160 bytes each at the 4.5 TB/s the two
+        // kernels sustain (1.01 ms on final-13682, 0.45 ms on synthetic-10k: DESIGN section 5) -- whatever the structure; the tile
+        // plan refuses to be built when its own prediction (TilePlan::predict_solve_ms) is above that.  Both numbers are host
+        // arithmetic on the replicated structure: every rank decides alike.  "variant_cost_percent" scales the matrix-free side
+        // (tests move the crossover onto small problems; 0: the rule is off).
+        pred_mf_ms_ = 500.0 * (160.0 * (double)n_obs_ / 4.5e12 * 1e3 + 0.02) * (double)variant_cost_percent_ / 100.0;
+        pred_direct_ms_ = 0.0; variant_choice_ = matrix_free_only_ ? 3 : 0;
+        tp_.set_cost_limit_ms((auto_variant_ && !matrix_free_only_ && variant_cost_percent_ > 0) ? pred_mf_ms_ : 0.0);
         std::string e = tp_.build(nt_, present_plan, stream_);
+        if (!matrix_free_only_) pred_direct_ms_ = tp_.predicted_ms();
         // A structure whose direct factorisation is out of reach (a photo collection: S dense at tile granularity) is not an
         // error of the caller's: the reference's LM never fails on the fill of S.  The handle becomes matrix-free only by itself
         // and answers every variant with the matrix-free PCG (set_auto_variant).  The update-list rule is pure host arithmetic
         // on the replicated structure (every rank decides alike); the memory rule depends on the device and is single-rank only.
-        const bool refused_size = tp_.refused_too_large(), refused_mem = tp_.refused_no_memory() && world_ == 1;
-        if (!e.empty() && auto_variant_ && !matrix_free_only_ && (refused_size || refused_mem)) {
+        const bool refused_size = tp_.refused_too_large(), refused_mem = tp_.refused_no_memory() && world_ == 1, refused_cost = tp_.refused_by_cost();
+        if (!e.empty() && auto_variant_ && !matrix_free_only_ && (refused_size || refused_mem || refused_cost)) {
             auto_fallback_ = true; matrix_free_only_ = true;
-            fallback_reason_ = "the direct factorisation of S was refused (" + e + "): matrix-free PCG (IterativeSchurSolver semantics) selected";
+            variant_choice_ = refused_cost ? 1 : 2;
+            fallback_reason_ = (refused_cost ? "matrix-free PCG (IterativeSchurSolver semantics) selected by predicted cost (" : "the direct factorisation of S was refused (") + e +
+                               (refused_cost ? ")" : "): matrix-free PCG (IterativeSchurSolver semantics) selected");
+            tp_.set_cost_limit_ms(0.0);
             std::fill(present_plan.begin(), present_plan.end(), (uint8_t)0);
             for (int I = 0; I < nt_; ++I) present_plan[(size_t)I * nt_ + I] = 1;
             e = tp_.build(nt_, present_plan, stream_);
@@ -340,10 +359,12 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         if (e != hipSuccess) return e;
         return hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(double));
     };
-    const bool want_orec = rows_form_ == 3 || rows_form_ == 4 || rec_backsub_;
+    // (the uploader thread keeps its own error text: err_ belongs to the calling thread)
+    std::string up_err;
+#define UP_TRY(expr) do { const hipError_t _e = (expr); if (_e != hipSuccess) { up_err = std::string("HIP error in " #expr ": ") + hipGetErrorString(_e); return (int)kDeviceError; } } while (0)
     auto upload_lists = [&]() -> int {
         const auto t0 = std::chrono::steady_clock::now();
-        HIP_TRY(hipSetDevice(device_));
+        UP_TRY(hipSetDevice(device_));
         {   // camera staging lists of the landmark-major kernels (ba_kernels.h, BAView::o_slot)
             const int64_t n_wg = (n_pt_ + kLmWg - 1) / kLmWg;
             raw_vector<uint8_t> slot(o_cam.size());
@@ -365,17 +386,17 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
                 }
             });
             static_assert(kCamStageCap <= 254, "slot 255 means not staged");
-            HIP_TRY(up(&o_slot_, slot));
-            HIP_TRY(up(&wg_cam_n_, wn));
-            HIP_TRY(up(&wg_cam_list_, wlist));
+            UP_TRY(up(&o_slot_, slot));
+            UP_TRY(up(&wg_cam_n_, wn));
+            UP_TRY(up(&wg_cam_list_, wlist));
         }
-        HIP_TRY(up(&o_cam_, o_cam));
-        HIP_TRY(up(&o_pt_, o_pt));
-        HIP_TRY(up(&o_orig_, o_orig_h_));
-        HIP_TRY(up(&pt_ptr_, pt_ptr));
-        HIP_TRY(up(&cam_ptr_, cam_ptr));
-        HIP_TRY(up(&cam_obs_, cam_obs));
-        HIP_TRY(up(&co_rank_, co_rank));
+        UP_TRY(up(&o_cam_, o_cam));
+        UP_TRY(up(&o_pt_, o_pt));
+        UP_TRY(up(&o_orig_, o_orig_h_));
+        UP_TRY(up(&pt_ptr_, pt_ptr));
+        UP_TRY(up(&cam_ptr_, cam_ptr));
+        UP_TRY(up(&cam_obs_, cam_obs));
+        UP_TRY(up(&co_rank_, co_rank));
         if (so.device_gathers) {
             // the caller's measurements go up as they are (one contiguous copy, no host gather), the three lists that are
             // permutations of what is on the device already are made there
@@ -384,7 +405,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
             double* raw = raw_uv;
             hipError_t ge = hipSuccess;
             if (!raw) {
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&raw_uv), std::max<size_t>(2 * (size_t)n_obs_, 2) * sizeof(double)));
+                UP_TRY(hipMalloc(reinterpret_cast<void**>(&raw_uv), std::max<size_t>(2 * (size_t)n_obs_, 2) * sizeof(double)));
                 raw = raw_uv;
                 ge = hipMemcpy(raw, obs_uv, 2 * (size_t)n_obs_ * sizeof(double), hipMemcpyHostToDevice);
             }
@@ -405,11 +426,11 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
                 ge = hipStreamSynchronize(stream_);
             }
             (void)hipFree(raw_uv); raw_uv = nullptr;
-            HIP_TRY(ge);
+            UP_TRY(ge);
         } else {
-            HIP_TRY(up(reinterpret_cast<double**>(&o_uv_), o_uv));
-            HIP_TRY(up(&co_pt_, co_pt));
-            HIP_TRY(up(reinterpret_cast<double**>(&co_uv_), co_uv));
+            UP_TRY(up(reinterpret_cast<double**>(&o_uv_), o_uv));
+            UP_TRY(up(&co_pt_, co_pt));
+            UP_TRY(up(reinterpret_cast<double**>(&co_uv_), co_uv));
         }
         {
             std::vector<uint8_t> fp(6 * n_cam_, 0), fi(3 * n_cam_, 0), fl(3 * n_pt_, 0);
@@ -419,49 +440,44 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
             }
             if (fix_pt)
                 for (int64_t l = 0; l < n_pt_; ++l) memcpy(fl.data() + 3 * (size_t)lmap_[l], fix_pt + 3 * l, 3);
-            HIP_TRY(up(&fix_pose_, fp));
-            HIP_TRY(up(&fix_intr_, fi));
-            HIP_TRY(up(&fix_pt_, fl));
+            UP_TRY(up(&fix_pose_, fp));
+            UP_TRY(up(&fix_intr_, fi));
+            UP_TRY(up(&fix_pt_, fl));
         }
         for (int w = 0; w < 2; ++w) {
-            HIP_TRY(alloc(&poses_[w], 7 * n_cam_));
-            HIP_TRY(alloc(&intr_[w], 3 * n_cam_));
-            HIP_TRY(alloc(&pts_[w], 3 * n_pt_));
-            HIP_TRY(alloc(&camp_[w], (size_t)(kCamStride + kCamQStride) * n_cam_));   // [n_cam][16] records | [n_cam][10] compact form
+            UP_TRY(alloc(&poses_[w], 7 * n_cam_));
+            UP_TRY(alloc(&intr_[w], 3 * n_cam_));
+            UP_TRY(alloc(&pts_[w], 3 * n_pt_));
+            UP_TRY(alloc(&camp_[w], (size_t)(kCamStride + kCamQStride) * n_cam_));   // [n_cam][16] records | [n_cam][10] compact form
         }
-        HIP_TRY(alloc(&g_c_, n_c_pad_));
-        HIP_TRY(alloc(&g_red_, n_c_pad_));
-        HIP_TRY(alloc(&dcam_, n_c_pad_));
-        HIP_TRY(alloc(&hinv_, (size_t)kLmStride * n_pt_));  // landmark records: Hll^-1 | g_l | point
-        // projection records of the local observations (xn, yn, p_w.z, sqrt(rho')): the record form of the pair kernel --
-        // inside the landmark bundles when those are on (4 doubles per 32-byte unit)
-        if (corec_) { (void)hipFree(corec_); corec_ = nullptr; corec_fresh_ = false; }   // (sized by the structure; re-made by the next matrix-free assembly)
-        if (want_orec) HIP_TRY(alloc(&orec_, 4 * (hs.bun_ptr.empty() ? (size_t)o_cam.size() : (size_t)hs.bun_units)));
-        if (bun_ptr_) { hipFree(bun_ptr_); bun_ptr_ = nullptr; }
-        if (!hs.bun_ptr.empty()) HIP_TRY(up(&bun_ptr_, hs.bun_ptr));
-        bun_pad_unit_ = hs.bun_pad_unit; bun_pad_header_ = hs.bun_pad_header;
-        HIP_TRY(alloc(&g_l_, 3 * n_pt_));
-        HIP_TRY(alloc(&dl_, 3 * n_pt_));
-        HIP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
-        HIP_TRY(alloc(&scal_, 32));
-        HIP_TRY(alloc(&pcg_buf_, 7 * (size_t)n_c_pad_));
-        HIP_TRY(alloc(&lmu_, (size_t)kLmuStride * n_pt_));
-        HIP_TRY(alloc(&sd_, (size_t)n_cam_ * dc_ * dc_));
-        HIP_TRY(alloc(&minv_, (size_t)n_cam_ * dc_ * dc_));
+        UP_TRY(alloc(&g_c_, n_c_pad_));
+        UP_TRY(alloc(&g_red_, n_c_pad_));
+        UP_TRY(alloc(&dcam_, n_c_pad_));
+        UP_TRY(alloc(&hinv_, (size_t)kLmStride * n_pt_));  // landmark records: Hll^-1 | g_l | point
+        // projection records of the local observations (xn, yn, p_w.z, sqrt(rho')): the record form of the pair kernel
+        UP_TRY(alloc(&orec_, 4 * (size_t)o_cam.size()));
+        UP_TRY(alloc(&g_l_, 3 * n_pt_));
+        UP_TRY(alloc(&dl_, 3 * n_pt_));
+        UP_TRY(alloc(&partial_, 3 * (size_t)n_partial_));
+        UP_TRY(alloc(&scal_, 32));
+        UP_TRY(alloc(&pcg_buf_, 7 * (size_t)n_c_pad_));
+        UP_TRY(alloc(&lmu_, (size_t)kLmuStride * n_pt_));
+        UP_TRY(alloc(&sd_, (size_t)n_cam_ * dc_ * dc_));
+        UP_TRY(alloc(&minv_, (size_t)n_cam_ * dc_ * dc_));
         if (flags_) hipFree(flags_);
-        HIP_TRY(dev_alloc(&flags_, 4));
-        HIP_TRY(hipMemset(flags_, 0, 4 * sizeof(int)));
+        UP_TRY(dev_alloc(&flags_, 4));
+        UP_TRY(hipMemset(flags_, 0, 4 * sizeof(int)));
         for (int b = 0; b < 2; ++b) {   // the pinned chunks of upload_staged: mapped here, not in the caller's first set_params
-            if (!pin_[b]) HIP_TRY(hipHostMalloc(&pin_[b], (size_t)16 << 20, hipHostMallocDefault));
-            if (!pin_ev_[b]) HIP_TRY(hipEventCreateWithFlags(&pin_ev_[b], hipEventDisableTiming));
+            if (!pin_[b]) UP_TRY(hipHostMalloc(&pin_[b], (size_t)16 << 20, hipHostMallocDefault));
+            if (!pin_ev_[b]) UP_TRY(hipEventCreateWithFlags(&pin_ev_[b], hipEventDisableTiming));
         }
         up_seconds = since(t0);
         return kOk;
     };
+#undef UP_TRY
     int up_rc = kOk;
-    std::string up_err;
     std::thread uploader([&] {   // (nothing may escape a thread: an allocation failure becomes this call's status)
-        try { up_rc = upload_lists(); if (up_rc != kOk) up_err = err_; }
+        try { up_rc = upload_lists(); }
         catch (const std::exception& ex) { up_rc = kDeviceError; up_err = std::string("set_structure uploads: ") + ex.what(); }
     });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
@@ -475,25 +491,17 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     // (tried in round 5: the pair list built from a host-only twin's slot map BEFORE the planner thread is done -- the host pool
     // is shared, the three threads then slow one another down: set-up 0.26-0.28 s against 0.24)
     PairDeviceTables dtab;
-    const bool recs_on_device = device_pair_recs_ && so.schur_form == 4 && (dc_ == 9 || queued6_);
+    const bool recs_on_device = device_pair_recs_ && so.schur_form == 4 && dc_ == 9;
     hs.build_schur_lists(so, tp_.slot_host(), recs_on_device ? &dtab : nullptr);
-    n_rtasks_ = (int)hs.rtasks2.size();
     n_ptasks_ = (int)hs.pl.tasks.size();
     n_pair_blocks_ = hs.pl.n_blocks; pair_queued_ = hs.pl.queued;
     n_pair_slots_ = (recs_on_device && hs.pl.queued) ? dtab.n_slots : (int64_t)hs.pl.recs.size();
-    const auto& nbr = hs.nbr;
-    const std::vector<RowTask>& rtasks2 = hs.rtasks2;
-    const std::vector<RowChunk>& rchunks = hs.rchunks;
-    const std::vector<RowEntry>& rentries = hs.rentries;
     const PairLists& pl = hs.pl;
     uploader.join();
     if (up_rc != kOk) return fail(up_rc, up_err);
     hs.release_scratch();
     tr.mark("plan + Schur lists (observation lists uploading beside them)");
     const auto t_up2 = std::chrono::steady_clock::now();
-    HIP_TRY(up(&rtasks2_, rtasks2));
-    HIP_TRY(up(&rchunks_, rchunks));
-    HIP_TRY(up(&rentries_, rentries));
     HIP_TRY(up(&ptasks_, pl.tasks));
     HIP_TRY(up(&pchunks_, pl.chunks));
     HIP_TRY(up(&pblocks_, pl.blocks));
@@ -513,7 +521,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         if (e == hipSuccess) e = up(&d_task, dtab.task);
         if (e == hipSuccess)
             e = launch_build_pair_recs_q(n_cam_, d_rows, d_run_ptr, d_run_cj, d_run_piece0, d_piece, d_task, cam_ptr_, cam_obs_, o_pt_, pt_ptr_, o_cam_,
-                                         precs_, dtab.n_slots, stream_, dc_, bun_ptr_);
+                                         precs_, dtab.n_slots, stream_);
         for (void* q : {(void*)d_rows, (void*)d_run_ptr, (void*)d_run_cj, (void*)d_run_piece0, (void*)d_piece, (void*)d_task})
             if (q) (void)hipFree(q);
         HIP_TRY(e);
@@ -522,7 +530,6 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     }
     if (pqdesc_) { hipFree(pqdesc_); pqdesc_ = nullptr; }
     if (pl.queued) HIP_TRY(up(&pqdesc_, pl.qdesc));
-    HIP_TRY(up(&nbr_, nbr));
     up_seconds += since(t_up2);
     (void)t_up;
 
@@ -537,7 +544,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         const char* fm = getenv("APEX_SETUP_FREE");   // experiment switch: "sync" frees on the caller's path, "leak" never
         if (fm && !strcmp(fm, "sync")) hs_owner.reset();
         else if (fm && !strcmp(fm, "leak")) (void)hs_owner.release();
-        else free_thread_ = std::thread([p = hs_owner.release()] { delete p; });
+        else free_thread_ = std::thread([p = hs_owner.release()] { delete p; (void)HostBlockCache::get().end_setup(); });   // (what only an older, larger structure used goes back to the system)
     }
     tr.mark("host lists handed to the free thread");
 
@@ -567,7 +574,7 @@ int Solver::set_params(const double* poses, const double* intr, const double* po
     { const int rc = upload_staged(pts_[cur_], src_pts, 3 * (size_t)n_pt_ * sizeof(double)); if (rc != kOk) return rc; }
     launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], mode_mask(mode_), stream_);
     HIP_TRY(hipStreamSynchronize(stream_));
-    have_params_ = true; have_step_ = have_trial_ = false; orec_fresh_ = false; corec_fresh_ = false;
+    have_params_ = true; have_step_ = have_trial_ = false; orec_fresh_ = false;
     return kOk;
 }
 
@@ -671,61 +678,22 @@ int Solver::assemble_local(double lambda, double diag_extra, bool for_factor) {
     stage_begin(kStAssembleCam);
     // (a tree-sharded rank that assembles for its distributed factorisation adds to its own and the top tiles only; every
     // other use of S -- PCG, exports, the ladder's diagonal -- all-reduces every touched tile and needs them all cleared)
-    // "zero_beside_lm" (round 5): the 1.34 GB of tile clears run on the side stream BESIDE k_landmark_reduce -- which touches no
-    // tile and is bound by the latency of its dependent loads (3 TB/s), not by HBM -- instead of in front of it
-    const bool zero_beside = zero_beside_lm_ && !tiles_prezeroed_ && world_ == 1;
-    if (tiles_prezeroed_) {   // cleared on the side stream behind the previous solve (solve_augmented)
-        tiles_prezeroed_ = false;
-        HIP_TRY(hipStreamWaitEvent(stream_, zero_ev_, 0));
-    } else if (zero_beside) {
-        if (!zero_stream_) HIP_TRY(hipStreamCreateWithFlags(&zero_stream_, hipStreamNonBlocking));
-        if (!zero_ev_) HIP_TRY(hipEventCreateWithFlags(&zero_ev_, hipEventDisableTiming));
-        for (hipEvent_t& e : cam_ev_) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(cam_ev_[0], stream_));            // (whatever used the tiles before is behind this point)
-        HIP_TRY(hipStreamWaitEvent(zero_stream_, cam_ev_[0], 0));
-        HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor, zero_stream_, for_factor && world_ == 1));
-        HIP_TRY(hipEventRecord(zero_ev_, zero_stream_));
-    } else {
-        HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor, nullptr, for_factor && world_ == 1));   // (the fill tiles stay as they are: tile_plan.h, first_writer_)
-    }
+    HIP_TRY(tp_.zero_tiles(tree_shard_ && for_factor, nullptr, for_factor && world_ == 1));   // (the fill tiles stay as they are: tile_plan.h, first_writer_)
     launch_clear3(g_red_, g_c_, n_c_pad_, flags_, 4, stream_);   // (one launch instead of three fills)
     // identity on the padding rows of the last tile (rank 0 only: the all-reduce sums the ranks)
     // (tree sharding: by the owner of the last tile column, whose tiles are never summed -- pad_rank_)
-    if (!zero_beside) tp_.add_diag((int)n_c_, 0.0, rank_ == pad_rank_ ? 1.0 : 0.0);
+    tp_.add_diag((int)n_c_, 0.0, rank_ == pad_rank_ ? 1.0 : 0.0);
     stage_end(kStAssembleCam);
     stage_begin(kStAssembleLm);
-    const bool rec_form = rows_form_ == 3 || rows_form_ == 4;   // the pair kernel reads the projection records (allocated with the form: set_structure)
-    const bool want_rec = rec_form || (rec_backsub_ && orec_ != nullptr);
-    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_, want_rec ? orec_ : nullptr);
-    orec_fresh_ = want_rec; corec_fresh_ = false;
+    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, nullptr, stream_, orec_);   // (the pair kernel and the back-substitution read the projection records)
+    orec_fresh_ = true;
     stage_end(kStAssembleLm);
-    if (zero_beside) {
-        stage_begin(kStAssembleCam);
-        HIP_TRY(hipStreamWaitEvent(stream_, zero_ev_, 0));
-        tp_.add_diag((int)n_c_, 0.0, rank_ == pad_rank_ ? 1.0 : 0.0);
-        stage_end(kStAssembleCam);
-    }
-    const bool beside = cam_beside_ && rec_form && world_ == 1;
-    hipStream_t cam_stream = stream_;
-    if (beside) {
-        if (!zero_stream_) HIP_TRY(hipStreamCreateWithFlags(&zero_stream_, hipStreamNonBlocking));
-        for (hipEvent_t& e : cam_ev_) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(cam_ev_[0], stream_));
-        HIP_TRY(hipStreamWaitEvent(zero_stream_, cam_ev_[0], 0));
-        cam_stream = zero_stream_;
-    }
-    if (!beside) stage_begin(kStAssembleCam);
+    stage_begin(kStAssembleCam);
     launch_cam_reduce(dc_, v, tm, cam_ptr_, cam_obs_, lambda + diag_extra, rank_ == 0 ? 1 : 0, hinv_, g_l_, 1,
-                      g_c_, g_red_, cam_stream);
-    if (!beside) stage_end(kStAssembleCam);
-    else HIP_TRY(hipEventRecord(cam_ev_[1], zero_stream_));
+                      g_c_, g_red_, stream_);
+    stage_end(kStAssembleCam);
     stage_begin(kStScatter);
-    if (rec_form)
-        launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, pairs_ablation_, orec_, pqdesc_,
-                           bun_pad_unit_, bun_pad_header_);
-    else
-        launch_schur_rows2(dc_, v, tm, rtasks2_, n_rtasks_, rchunks_, rentries_, nbr_, hinv_, stream_);
-    if (beside) HIP_TRY(hipStreamWaitEvent(stream_, cam_ev_[1], 0));
+    launch_schur_pairs(dc_, v, tp_.tiles(), ptasks_, n_ptasks_, pchunks_, pblocks_, precs_, hinv_, stream_, orec_, pqdesc_);
     stage_end(kStScatter);
     return check_hip(hipGetLastError(), "assembly kernels");
 }
@@ -744,7 +712,7 @@ int Solver::assemble_finish() {
 
 int Solver::cholesky_attempt(int* failed_at) {
     stage_begin(kStFactor);
-    const hipError_t fe = tp_.factor(failed_at, g_red_, pcg_buf_);  // the forward sweep for g_red rides along
+    const hipError_t fe = tp_.factor(failed_at);
     if (fe != hipSuccess && !comm_err_.empty()) return fail(kDeviceError, comm_err_);
     HIP_TRY(fe);
     stage_end(kStFactor);
@@ -824,22 +792,11 @@ int Solver::pcg_solve() {
 // Sharded: g_red, g_c and the diagonal blocks are all-reduced once, every S p once per iteration.
 // ---------------------------------------------------------------------------------------------
 int Solver::assemble_implicit(double lambda) {
-    if (tiles_prezeroed_) {   // the side stream may still be clearing the tiles this pass stores its diagonal blocks into
-        tiles_prezeroed_ = false;
-        HIP_TRY(hipStreamWaitEvent(stream_, zero_ev_, 0));
-    }
     const BAView v = view(cur_);
     stage_begin(kStAssembleLm);
     HIP_TRY(hipMemsetAsync(flags_, 0, 4 * sizeof(int), stream_));
-    const bool want_rec = rec_backsub_ && orec_ != nullptr;
-    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, lmu_, stream_, want_rec ? orec_ : nullptr);
-    orec_fresh_ = want_rec;
-    corec_fresh_ = false;
-    if (want_rec && cam_records_ && !bun_ptr_ && v.n_obs > 0) {   // (records indexed by observation: not the bundle layout)
-        if (!corec_) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&corec_), (size_t)v.n_obs * 4 * sizeof(double)));
-        launch_gather_records(v.n_obs, cam_obs_, orec_, corec_, stream_);
-        corec_fresh_ = true;
-    }
+    launch_landmark_reduce(dc_, v, lambda, hinv_, g_l_, flags_, lmu_, stream_, orec_);
+    orec_fresh_ = orec_ != nullptr;
     stage_end(kStAssembleLm);
     stage_begin(kStAssembleCam);
     launch_cam_reduce(dc_, v, tilemap(), cam_ptr_, cam_obs_, lambda, rank_ == 0 ? 1 : 0, hinv_, g_l_, 1, g_c_, g_red_, stream_);
@@ -874,8 +831,7 @@ int Solver::implicit_matvec(const double* x, double lam_local, double* y, bool r
         launch_vec_mul(n_c_, x, cam_scale_, t, stream_);
         xin = t;
     }
-    launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xin, lam_local, y, stream_, backsub_records(),
-                           corec_fresh_ && backsub_records() ? corec_ : nullptr);
+    launch_implicit_matvec(dc_, view(cur_), cam_ptr_, hinv_, lmu_, xin, lam_local, y, stream_, backsub_records());
     if (reduce && comm_ && world_ > 1)
         COMM_TRY(comm_->all_reduce_sum(y, (size_t)n_c_, stream_));
     if (scaled_) launch_vec_mul(n_c_, y, cam_scale_, y, stream_);
@@ -939,6 +895,7 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     if (!have_params_) return fail(kInvalidState, "Block structure not built or parameters not set");
     HIP_TRY(hipSetDevice(device_));
     have_step_ = false;
+    have_trial_ = false;   // (the eager step evaluation of this solve overwrites the trial parameter set: an earlier eval_step is void)
     ++step_serial_;
     last_lambda_ = lambda;
     int pcg_max = cg_max_iter_;
@@ -960,7 +917,7 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
         int failed = 0;
         last_reg_ = 0.0;
         stage_begin(kStFactor);
-        const hipError_t fe = tp_.factor(&failed, g_red_, pcg_buf_, /*defer_flags=*/true);
+        const hipError_t fe = tp_.factor(&failed, /*defer_flags=*/true);
         HIP_TRY(fe);
         stage_end(kStFactor);
         rc = tri_solve();
@@ -1013,14 +970,6 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
                 attempt = -1;   // (the loop's counter is for the sweep time-outs of the solve that follows)
                 continue;       // back-substitution and export once more
             }
-        }
-        if (rc == kOk && variant == 0 && one_wait && prezero_ && !tp_.sweep_timed_out_peek()) {
-            // the factor is used up (the step is out): clear the tiles for the next assembly beside what the caller does next
-            if (!zero_stream_) HIP_TRY(hipStreamCreateWithFlags(&zero_stream_, hipStreamNonBlocking));
-            if (!zero_ev_) HIP_TRY(hipEventCreateWithFlags(&zero_ev_, hipEventDisableTiming));
-            HIP_TRY(tp_.zero_tiles(false, zero_stream_));
-            HIP_TRY(hipEventRecord(zero_ev_, zero_stream_));
-            tiles_prezeroed_ = true;
         }
         if (rc != kOk || variant != 0 || !tp_.sweep_timed_out()) {
             if (rc == kOk && eager) eager_serial_ = step_serial_;   // (the answers of THIS solve: step_stats / eval_step)
@@ -1221,7 +1170,7 @@ int Solver::eval_step(double* trial_cost) {
 int Solver::commit_step() {
     if (!have_trial_) return fail(kInvalidState, "no trial point");
     cur_ ^= 1;
-    have_trial_ = false; have_step_ = false; orec_fresh_ = false; corec_fresh_ = false;
+    have_trial_ = false; have_step_ = false; orec_fresh_ = false;
     return kOk;
 }
 
@@ -1237,7 +1186,7 @@ int Solver::discard_step() {
     launch_prepare_cams(n_cam_, poses_[cur_], intr_[cur_], camp_[cur_], mode_mask(mode_), stream_);
     stage_end(kStRetract);
     HIP_TRY(hipStreamSynchronize(stream_));
-    have_trial_ = false; have_step_ = false; orec_fresh_ = false; corec_fresh_ = false;
+    have_trial_ = false; have_step_ = false; orec_fresh_ = false;
     return kOk;
 }
 

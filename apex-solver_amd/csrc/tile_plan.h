@@ -115,15 +115,13 @@ class TilePlan {
     void enable_overlap(bool on) { overlap_ = on; }  // before the first factor()
     void set_overlap_min(int n) { overlap_min_ = n; }
     void set_two_side(int mode) { two_side_ = mode; }   // 0 off, 1 by plan size (default), 2 always (tests); before build()
-    void set_gate_pos(int p) { gate_pos_ = p; }   // 0: in front of U2a, 1: between U2a and U2b
     void set_gate_min(int n) { gate_min_ = n; }   // flood gate in front of U2 batches of at least n tasks (0: off); before the first factor()
     // The top of the elimination tree as one dataflow launch (k_factor_flow): the trailing level groups of a phase whose
     // groups have at most max_cols columns each, every column with at most max_rows off-diagonal tiles.  0 columns: off;
     // < 0 (default): where the launch starts is chosen by a cost model.  Before build().
     void set_factor_flow(int max_cols, int max_rows) { flow_cols_ = max_cols; if (max_rows > 0) flow_rows_ = max_rows; }
-    // level groups inside the dataflow launches THAT RUN: none once a launch has timed out (flow_on_) or while the forward
-    // sweep rides inside the factorisation graph ("fused_forward": enqueue_factor then keeps the level launches)
-    int factor_flow_groups() const { return (!flow_on_ || fuse_forward_) ? 0 : (flow_g1_[0] - flow_g0_[0]) + (flow_g1_[1] - flow_g0_[1]); }
+    // level groups inside the dataflow launches THAT RUN: none once a launch has timed out (flow_on_)
+    int factor_flow_groups() const { return !flow_on_ ? 0 : (flow_g1_[0] - flow_g0_[0]) + (flow_g1_[1] - flow_g0_[1]); }
     int factor_flow_cols() const { return flow_cols_; }
     double factor_flow_sim_us() const { return flow_sim_us_[0] + flow_sim_us_[1]; }
     int factor_flow_units() const { return flow_n_[0] + flow_n_[1]; }
@@ -134,20 +132,20 @@ class TilePlan {
     hipError_t read_flow_trace(std::vector<FactorUnit>* units, std::vector<unsigned long long>* stamps);
     bool refused_too_large() const { return refused_ == 1; }
     bool refused_no_memory() const { return refused_ == 2; }
-    void set_flow_tile_units(bool on) { flow_tile_units_ = on; }   // before build()
-    void set_flow_dyn(bool on) { flow_dyn_ = on; }                 // before build()
-    bool flow_dyn() const { return flow_dyn_; }
+    bool refused_by_cost() const { return refused_ == 3; }
+    // Predicted milliseconds of one factorisation + both sweeps of a plan with these operation counts on one MI355X: the tile
+    // products at the rate the factorisation sustains end to end on the headline shape (0.251 TFLOP in 6.5 ms = 38-40 TF/s, DESIGN
+    // section 5; panel products count 45 / 81, a diagonal tile's Cholesky + inverse a third of a product), the sweeps at two
+    // passes over the tiles of L at 4.2 TB/s, 30 us of dependent launches per elimination-tree level.  Host arithmetic on the
+    // structure: every rank of a distributed plan arrives at the same number.
+    static double predict_solve_ms(int64_t n_potrf, int64_t n_trsm, int64_t n_upd, int64_t n_tiles, int n_levels) {
+        const double prod = (double)n_upd + (double)n_trsm * (45.0 / 81.0) + (double)n_potrf / 3.0;
+        return prod * (2.0 * kNB * kNB * kNB) / 40e12 * 1e3 + 2.0 * (double)n_tiles * kNB * kNB * 8.0 / 4.2e12 * 1e3 + 0.03 * n_levels;
+    }
+    double predicted_ms() const { return predicted_ms_; }          // of the structure the last build() saw (also when it refused)
+    void set_cost_limit_ms(double ms) { cost_limit_ms_ = ms; }     // before build(); <= 0: no limit
     void set_max_updates(int64_t n) { max_updates_ = n > 0 ? n : 80000000LL; }   // (tests lower it to force the refusal on a small problem)
     bool factor_flow_gave_up() { const bool g = flow_gave_up_; flow_gave_up_ = false; return g; }
-    // panel lookahead (round 5): the panel solves of a level in two launches -- the tiles whose rows belong to the NEXT level
-    // (all that U1d and the next potrf need) on the main stream, the rest on a stream of their own beside them; 0 = one launch.
-    // Built, race free (check_schedule), bit-identical -- and no gain: 6.60 against 6.53 ms on final-13682.  The timeline
-    // (profiles/r05_factor_timeline_panel_split.txt) shows U1d(lv) starting ~90 us after the critical panel tiles are done:
-    // it also follows U2a(lv-1) -- the updates of the same diagonal tiles from two levels below --, which follows ALL panel
-    // solves of level lv-1 and the U2 stream's older work; the period of a bulk level stays at ~360 us.  Off by default.
-    void set_fwd_beside_top(bool on) { fwd_beside_top_ = on; }   // before the first factor()
-    void set_tri_inline(int max_cols) { tri_inline_ = max_cols; }   // before build(): levels of at most that many columns (0: off)
-    void set_panel_split(int min_rest) { panel_split_ = min_rest > 0; if (min_rest > 0) panel_split_min_ = min_rest; }   // before the first factor()
     void set_split_u1(int min_tasks) { split_u1_ = min_tasks > 0; if (min_tasks > 0) split_u1_min_ = min_tasks; }   // before the first factor()
     hipError_t read_flags(int* failed_at);   // pivot flag of the last factorisation (syncs)
     void enable_tri_flow(bool on);   // triangular sweeps as one dataflow launch each (default) or level by level
@@ -173,17 +171,13 @@ class TilePlan {
     // (first_writers_flagged()): the fill tiles are not cleared -- their first update does not read them
     hipError_t zero_tiles(bool own_touched_only = false, hipStream_t on = nullptr /* nullptr: the plan's stream */, bool skip_fill = false);
     bool first_writers_flagged() const { return first_ok_; }
-    void set_first_writer(bool on) { first_writer_ = on; }   // before build()
     void add_diag(int n_valid, double add_valid, double pad_value);  // diagonal += / padding rows := value
     void diag(double* out) const;                        // out[n_pad] = diagonal
     void scale_sym(const double* scale);                 // A := D A D on the unfactored tiles, D = diag(scale[n_pad])
     // Cholesky in place; *failed_at = 0 or (tile column + 1) of the first non-positive pivot.  Syncs.
-    // With rhs/work (2*n_pad doubles) the forward sweep L y = rhs rides along on a third stream; the next
-    // solve(rhs, x, work) with the same pointers then only runs the backward sweep.
     // defer_flags: do not wait for the pivot flag (single-rank plans only): the caller enqueues the sweeps behind the
     // factorisation and calls read_flags() at its own synchronisation point (Solver::solve_augmented: one host wait per solve)
-    hipError_t factor(int* failed_at, const double* rhs = nullptr, double* work = nullptr, bool defer_flags = false);
-    void enable_fused_forward(bool on) { fuse_forward_ = on; }
+    hipError_t factor(int* failed_at, bool defer_flags = false);
     // x = (L L^T)^-1 rhs ; work: 2*n_pad doubles ; all on the plan's stream, no sync.  hipErrorUnknown: a collective of
     // the distributed sweeps failed (the communicator's own message is with the caller)
     hipError_t solve(const double* rhs, double* x, double* work);
@@ -194,8 +188,8 @@ class TilePlan {
 
    private:
     std::vector<std::vector<int>> symbolic_slots(const std::vector<uint8_t>& present);
-    void enqueue_factor(const double* rhs, double* work, int g0, int g1);
-    void enqueue_solve(const double* rhs, double* x, double* work, bool backward_only, bool upper_only = false);
+    void enqueue_factor(int g0, int g1);
+    void enqueue_solve(const double* rhs, double* x, double* work);
     void launch_fwd_group(int lv, double* bvec, double* yvec, hipStream_t s);
     void enqueue_dist_solve(int phase, const double* rhs, double* x, double* work);
     bool run_graph(int which, const double* rhs, double* x, double* work);
@@ -226,17 +220,11 @@ class TilePlan {
     int two_side_ = 1;            // option; two_side_plan_: what build() decided for this plan
     bool two_side_plan_ = false;
     hipStream_t so_ = nullptr;    // U1o: updates of the next level's off-diagonal tiles, beside its potrf
-    hipStream_t sp_ = nullptr;    // panel lookahead: the non-critical panel solves of a level (waits for the main stream only -- see enqueue_factor)
-    std::vector<hipEvent_t> ev_p_, ev_pr_;   // panel lookahead: after the potrf of the level; after the rest of its panel solves
-    std::vector<int> lv_trsm_crit_;          // [level]: end of the level's critical panel tasks (rows in the next level) in trsm_tasks_
-    bool panel_split_ = false;
-    int panel_split_min_ = 96;
     std::vector<hipEvent_t> ev_t_, ev_u2_, ev_o_, ev_b_, ev_b2_;   // ev_u2_: after U2a of the level; ev_b_: after its U2b
     std::vector<bool> u2_pending_, o_pending_;
     bool split_u1_ = true;
     int split_u1_min_ = 4;
     bool overlap_ = true;
-    int gate_pos_ = 0;
     int gate_min_ = 256;  // U2 batches of at least this many tasks get the flood gate.  Before U2 was split into U2a / U2b the gate was worth 0.3-0.4 ms on
                           // final-13682 (8.3 -> 7.9, any threshold 2 .. 250); after the split it is neutral there (7.6-7.7 either way), +2-3 % on the
                           // dense fronts of ladybug / venice, -2 % on sphere2500's small batches: kept for the large batches only
@@ -261,7 +249,8 @@ class TilePlan {
     hipStream_t occ_stream_ = nullptr;
     bool post_sweep_status(bool reduce);   // false: the max-reduction over the ranks failed
     bool dry_run_ = false;
-    int refused_ = 0;                       // why the last build() gave up: 1 update list beyond max_updates_, 2 tiles beyond the free memory
+    int refused_ = 0;                       // why the last build() gave up: 1 update list beyond max_updates_, 2 tiles beyond the free memory, 3 predicted cost above cost_limit_ms_
+    double predicted_ms_ = 0.0, cost_limit_ms_ = 0.0;
     int64_t max_updates_ = 80000000LL;      // tile products per factorisation a plan may hold (12.7 s at 45 TF/s)
     bool debug_skip_idle_wait_ = false;   // tests only: bring back the round-3 schedule bug (no wait after a level without side-stream work)
     std::vector<SchedOp>* sched_trace_ = nullptr;
@@ -276,18 +265,8 @@ class TilePlan {
     int flow_first_[2] = {0, 0}, flow_n_[2] = {0, 0};
     double flow_sim_us_[2] = {0.0, 0.0};   // makespan of the list schedule that ordered the units (build())
     bool flow_on_ = true, flow_gave_up_ = false;
-    bool flow_tile_units_ = true;   // off-chain updates of the dataflow launch as whole-tile units (k_factor_flow kind 3)
     // dynamic scheduling of the dataflow launch (k_factor_flow_dyn): one image per plan, both phases back to back --
     // [pending | queue] initial values (copied over the live arrays before every launch), waiter lists, {head, tail} per phase
-    bool flow_dyn_ = false;          // measured slower than the static launch wherever it was tried (chol_kernels.hip, k_factor_flow_dyn): the A/B
-    int* flow_dyn_init_ = nullptr;   // [2 * units]: pending of every unit, then the queue (ready units first, -1 behind)
-    int* flow_dyn_live_ = nullptr;   // the same, live
-    int* flow_wl_ptr_ = nullptr;     // waiter lists of the (tile, writer) nodes, the phases' node numbers back to back
-    int* flow_wl_ = nullptr;
-    int* flow_ctr_init_ = nullptr;   // [4]: {0, ready units of phase 0, 0, ready units of phase 1}
-    int* flow_ctr_ = nullptr;
-    int flow_node_first_[2] = {0, 0};
-    int flow_cus_ = 256;
     int n_flow_tasks_ = 0, n_flow_bwd_ = 0, n_flow_parts_ = 0;
     int n_flow_local_ = 0;   // distributed plans: the forward tasks of phase 0 (the rest: the top columns, phase 1)
     bool tri_flow_ = true;
@@ -296,33 +275,16 @@ class TilePlan {
     int* sym_row_ptr_ = nullptr;
     SymEntry* sym_entries_ = nullptr;
     double *sym_part_ = nullptr, *row_dot_ = nullptr, *blk_part_ = nullptr, *scal_ = nullptr;
-    static constexpr int kGraphs = 7;  // 0 factor (local levels), 1 both sweeps, 2 backward sweep, 3 factor (top levels), 4/5 distributed solve phases, 6 upper forward + backward
+    static constexpr int kGraphs = 6;  // 0 factor (local levels), 1 both sweeps, 3 factor (top levels), 4/5 distributed solve phases (2: unused)
     hipGraphExec_t graph_exec_[kGraphs] = {};
     const double* graph_rhs_[kGraphs] = {};
     double *graph_x_[kGraphs] = {}, *graph_work_[kGraphs] = {};
     bool graph_failed_[kGraphs] = {};
-    hipStream_t fwd_ = nullptr;       // fused forward sweep
-    hipEvent_t ev_fwd_ = nullptr, ev_fwd2_ = nullptr;
-    // The forward sweep in two launches (round 5, "fwd_beside_top"): the part over the columns BELOW the dataflow launch of the
-    // factorisation's top runs on fwd_ beside that launch -- their L tiles are final at its start, the launch is a latency chain
-    // that leaves the chip nearly empty, the sweep part is bound by HBM --, the part over the top columns follows the
-    // factorisation (same tasks, same order, the counters of the first part stand: bit-identical).
-    // Measured (profiles/r05_ab_fwd_beside_top.txt): the sweeps go from 0.69 to 0.45 ms and the factorisation from 6.51 to 6.77 --
-    // the sweep part takes from the dataflow launch what it saves (its units read their operands past the L2, from the same
-    // HBM).  Zero sum: off.
-    bool fwd_beside_top_ = false, lower_fwd_now_ = false;
     // The FIRST update of every fill tile (a tile of L that is structurally zero in S) is flagged -- bit 0 of GemmTask::C in the
     // level lists, kFlowFirstWriter in the dataflow units -- and does not read its target (beta = 0): the 0.63 GB of fill tiles
     // of final-13682 are then neither cleared before a factorisation nor read by those updates (round 5).
-    bool first_writer_ = true, first_ok_ = false;
-    int tri_inline_ = 8;       // (swept 0 / 4 / 8 / 16 / 32 / all: profiles/r05_sweep_tri_inline.txt) the dataflow sweeps: in levels of at most this many columns a block's solve task forms its last-arriving product itself (FlowTask::mat2)
-    std::vector<int> lv_flow_fwd_;            // [level]: first forward dataflow task of the level (plans that are not distributed)
-    const double* fwd_lower_rhs_ = nullptr;   // right-hand side whose lower forward part the last factor() carried
-    double* fwd_lower_work_ = nullptr;
-    int fwd_lower_count_ = 0;
-    const double* fwd_rhs_ = nullptr;  // right-hand side whose forward sweep the last factor() carried
-    double* fwd_work_ = nullptr;
-    bool fuse_forward_ = false;  // measured: the extra cross-stream edges cost the factorisation more than the sweep saves (+0.3 ms)
+    bool first_ok_ = false;   // (this plan qualifies: not distributed, has fill tiles, no dataflow launch over shared top groups)
+    static constexpr int kTriInline = 8;       // (swept 0 / 4 / 8 / 16 / 32 / all: profiles/r05_sweep_tri_inline.txt) the dataflow sweeps: in levels of at most this many columns a block's solve task forms its last-arriving product itself (FlowTask::mat2)
     bool use_graphs_ = true;
 };
 

@@ -101,12 +101,12 @@ std::vector<int> TilePlan::order(int nt, const std::vector<uint8_t>& adjm, bool 
 void TilePlan::release() {
     if (dry_run_) {   // a host-only plan owns no device memory, streams or events
         tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = exch_ = nullptr; flag_ = nullptr; gate_cnt_ = nullptr;
-        side_ = side2_ = so_ = sp_ = fwd_ = nullptr; ev_fwd_ = nullptr; ev_fwd2_ = nullptr;
-        ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear(); ev_b2_.clear(); ev_p_.clear(); ev_pr_.clear();
+        side_ = side2_ = so_ = nullptr;
+        ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear(); ev_b2_.clear();
         return;
     }
     void* ptrs[] = {tiles_, linv_, slot_, diag_slot_, flag_, potrf_tasks_, trsm_tasks_, upd_tasks_, tri_fwd_, tri_bwd_,
-                    flow_fwd_, flow_bwd_, flow_part_, flow_flags_, flow_units_, flow_ver_, flow_trace_, flow_dyn_init_, flow_dyn_live_, flow_wl_ptr_, flow_wl_, flow_ctr_init_, flow_ctr_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_, gate_cnt_};
+                    flow_fwd_, flow_bwd_, flow_part_, flow_flags_, flow_units_, flow_ver_, flow_trace_, sym_tiles_, sym_row_ptr_, sym_entries_, sym_part_, row_dot_, blk_part_, scal_, cls_, exch_, gate_cnt_};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     tiles_ = linv_ = sym_part_ = row_dot_ = blk_part_ = scal_ = exch_ = nullptr;
@@ -114,27 +114,21 @@ void TilePlan::release() {
     potrf_tasks_ = nullptr; trsm_tasks_ = upd_tasks_ = nullptr; tri_fwd_ = tri_bwd_ = nullptr;
     flow_fwd_ = flow_bwd_ = nullptr; flow_part_ = nullptr; flow_flags_ = nullptr; n_flow_tasks_ = 0;
     flow_units_ = nullptr; flow_ver_ = nullptr; flow_trace_ = nullptr; flow_n_[0] = flow_n_[1] = 0; flow_on_ = true; flow_gave_up_ = false;
-    flow_dyn_init_ = flow_dyn_live_ = flow_wl_ptr_ = flow_wl_ = flow_ctr_init_ = flow_ctr_ = nullptr;
     sym_tiles_ = nullptr; sym_entries_ = nullptr;
     gate_cnt_ = nullptr;
     for (int i = 0; i < kGraphs; ++i) {
         if (graph_exec_[i]) { (void)hipGraphExecDestroy(graph_exec_[i]); graph_exec_[i] = nullptr; }
         graph_failed_[i] = false;
     }
-    fwd_rhs_ = nullptr;
     if (flow_err_host_) { (void)hipHostFree(flow_err_host_); flow_err_host_ = nullptr; flow_err_host_dev_ = nullptr; }
     if (pcg_host_) { (void)hipHostFree(pcg_host_); pcg_host_ = nullptr; for (hipEvent_t& ev : pcg_ev_) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; } }
     if (occ_stream_) { (void)hipStreamSynchronize(occ_stream_); (void)hipStreamDestroy(occ_stream_); occ_stream_ = nullptr; }
-    if (ev_fwd_) { (void)hipEventDestroy(ev_fwd_); ev_fwd_ = nullptr; }
-    if (ev_fwd2_) { (void)hipEventDestroy(ev_fwd2_); ev_fwd2_ = nullptr; }
     for (hipEvent_t e : ev_t_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_u2_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_o_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_b_) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_b2_) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ev_p_) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ev_pr_) (void)hipEventDestroy(e);
-    ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear(); ev_b2_.clear(); ev_p_.clear(); ev_pr_.clear();
+    ev_t_.clear(); ev_u2_.clear(); ev_o_.clear(); ev_b_.clear(); ev_b2_.clear();
 }
 
 TilePlan::~TilePlan() {
@@ -142,8 +136,6 @@ TilePlan::~TilePlan() {
     if (side_) (void)hipStreamDestroy(side_);
     if (side2_) { (void)hipStreamDestroy(side2_); side2_ = nullptr; }
     if (so_) { (void)hipStreamDestroy(so_); so_ = nullptr; }
-    if (sp_) { (void)hipStreamDestroy(sp_); sp_ = nullptr; }
-    if (fwd_) (void)hipStreamDestroy(fwd_);
 }
 
 // Cut the elimination tree into part_world_ groups of subtrees plus a shared top.  Deterministic: every rank
@@ -334,8 +326,24 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     std::vector<std::vector<int>> col_rows = symbolic_slots(present);
     int64_t n_upd = 0;
     for (int K = 0; K < nt_; ++K) n_upd += (int64_t)col_rows[K].size() * (col_rows[K].size() + 1) / 2;
+    // what this plan is predicted to cost per solve (reported whatever follows)
+    {
+        int n_lv = 1;
+        std::vector<int> lvl(nt_, 0);
+        for (int K = 0; K < nt_; ++K)
+            if (!col_rows[K].empty()) { lvl[col_rows[K][0]] = std::max(lvl[col_rows[K][0]], lvl[K] + 1); n_lv = std::max(n_lv, lvl[col_rows[K][0]] + 1); }
+        predicted_ms_ = predict_solve_ms(n_potrf_, n_trsm_, n_upd_, n_slots_, n_lv);
+    }
     // (the size rule first: it is host arithmetic on the structure, so every rank of a distributed plan decides alike)
     if (n_upd > max_updates_) { refused_ = 1; return "tile update list too large (" + std::to_string(n_upd) + " tile products per factorisation, limit " + std::to_string(max_updates_) + ")"; }
+    // (round 6) ... then the cost rule, the same kind of arithmetic: a caller that owns a cheaper way to the same step (the
+    // matrix-free PCG, Solver::set_structure) hands in what that way costs, and a plan predicted to cost more is not built
+    if (cost_limit_ms_ > 0.0 && predicted_ms_ > cost_limit_ms_) {
+        refused_ = 3;
+        char buf[160];
+        snprintf(buf, sizeof buf, "predicted cost of the direct factorisation %.1f ms per solve, above the %.1f ms of the alternative", predicted_ms_, cost_limit_ms_);
+        return buf;
+    }
     if (!dry_run_) {
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
@@ -396,7 +404,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     std::vector<PotrfTask> potrf;
     std::vector<GemmTask> trsm, upd;
     std::vector<TriTask> tf, tb;
-    lv_potrf_.assign(n_levels_ + 1, 0); lv_trsm_.assign(n_levels_ + 1, 0); lv_trsm_crit_.assign(n_levels_, 0);
+    lv_potrf_.assign(n_levels_ + 1, 0); lv_trsm_.assign(n_levels_ + 1, 0);
     lv_fwd_.assign(n_levels_ + 1, 0); lv_bwd_.assign(n_levels_ + 1, 0);
     fwd_cut_.assign(n_levels_, std::vector<int>());
     lv_upd_round_.assign(n_levels_ + 1, 0);
@@ -420,16 +428,15 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             if (cls_h_[K] == 2) fwd_cut_[lv].push_back((int)tf.size());
             tf.push_back({linv_ptr(K), nullptr, K, -1});
             for (int I : rows) {
-                if (group_of[I] == lv + 1) trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});   // critical: see below
+                if (group_of[I] == lv + 1) trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});   // (first: see below)
                 tf.push_back({linv_ptr(K), tile_ptr(I, K), K, I});
             }
             for (size_t a = 0; a < rows.size(); ++a)
                 for (size_t b = 0; b <= a; ++b)
                     us.push_back({(int64_t)rows[a] * nt_ + rows[b], K, {tile_ptr(rows[a], rows[b]), tile_ptr(rows[a], K), tile_ptr(rows[b], K)}});
         }
-        // the panel solves of the level: first the tiles whose ROW belongs to the next level -- all that U1d(lv) reads, hence all
-        // that the next potrf waits for (panel lookahead, enqueue_factor) --, then the others; by column inside each part
-        lv_trsm_crit_[lv] = (int)trsm.size();
+        // the panel solves of the level: first the tiles whose ROW belongs to the next level (all that U1d(lv) reads), then the
+        // others; by column inside each part
         for (int K : level_cols[lv])
             for (int I : col_rows[K])
                 if (group_of[I] != lv + 1) trsm.push_back({tile_ptr(I, K), tile_ptr(I, K), linv_ptr(K)});
@@ -503,17 +510,17 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             slot_of[K].reserve(row_cols[K].size());
             for (int J : row_cols[K]) slot_of[K].push_back(cls_h_[J] == 1 ? a++ : b++);
         }
-        // Single-GPU plans (tri_inline_, round 5): the solve task of a block forms the product of its LAST-ARRIVING source itself
+        // Single-GPU plans (kTriInline, round 5): the solve task of a block forms the product of its LAST-ARRIVING source itself
         // (FlowTask::mat2 / src2 / slot2: the source solved latest, i.e. of the highest level forward, of the lowest backward) --
         // the link of the dependency chain loses a flag hop and a trip through memory; that product task leaves the list.
-        // Only in the NARROW levels (at most tri_inline_ columns): where a level is wide the sweeps are bound by HBM and the
+        // Only in the NARROW levels (at most kTriInline columns): where a level is wide the sweeps are bound by HBM and the
         // second tile of a solve task only serialises two products (final-13682 with every block inlined: sweeps 0.71 -> 0.79 ms;
         // ladybug-1723, narrow everywhere: 0.35 -> 0.28).
-        const bool inl = tri_inline_ > 0 && !distributed();
+        const bool inl = kTriInline > 0 && !distributed();
         std::vector<int> fwd_inl(nt_, -1), bwd_inl(nt_, -1);
         if (inl)
             for (int K = 0; K < nt_; ++K) {
-                if ((int)level_cols[(size_t)group_of[K]].size() > tri_inline_) continue;
+                if ((int)level_cols[(size_t)group_of[K]].size() > kTriInline) continue;
                 for (int J : row_cols[K]) if (fwd_inl[K] < 0 || group_of[J] >= group_of[fwd_inl[K]]) fwd_inl[K] = J;
                 for (int I : col_rows[K]) if (bwd_inl[K] < 0 || group_of[I] < group_of[bwd_inl[K]]) bwd_inl[K] = I;
             }
@@ -534,10 +541,8 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             }
             return t;
         };
-        lv_flow_fwd_.assign(n_levels_ + 1, 0);
         if (!distributed()) {
             for (int lv = 0; lv < n_levels_; ++lv) {
-                lv_flow_fwd_[lv] = (int)ft.size();
                 for (int K : level_cols[lv]) ft.push_back(fwd_solve(K));
                 for (int K : level_cols[lv]) products_of(K);
             }
@@ -643,7 +648,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
             const int st = slot_of(I, J);
             for (int n = 0; n < n_upd_of(st); ++n) {
                 const int K = src_of[(size_t)st][n], sa = slot_of(I, K), sb = slot_of(J, K);
-                const bool whole = flow_tile_units_ && group_of[J] > group_of[K] + 1;
+                const bool whole = group_of[J] > group_of[K] + 1;
                 if (whole) {
                     emit(FactorUnit{tile_ptr(I, J), tile_ptr(I, K), tile_ptr(J, K), {n > 0 ? st : -1, sa, sb},
                                     {W * n, W * (n_upd_of(sa) + 1), W * (n_upd_of(sb) + 1)}, st, 3, 0, 0}, W);
@@ -797,7 +802,7 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
                     ok = ok && m <= 96;
                     units += 1 + kFlowUnitsPerTile * (m + m * (m + 1) / 2);
                 }
-                if (!ok || units > (flow_tile_units_ ? 400000 : 120000)) break;   // (the model is evaluated per candidate start: keep plan building in the milliseconds)
+                if (!ok || units > 400000) break;   // (the model is evaluated per candidate start: keep plan building in the milliseconds)
                 level_tail += level_us(gf);
                 if (g1 - gf >= 2) cands.push_back({gf, level_tail});
             }
@@ -833,61 +838,12 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         flow_sim_us_[ph] = best_sim;
         funits.insert(funits.end(), best_units.begin(), best_units.end());
     }
-    // ---- dynamic scheduling of the launches (k_factor_flow_dyn): per unit its number of unfinished inputs, per (tile, writer)
-    // node the units that wait for it, the initially ready units at the head of the queue.  Unit and node numbers are local
-    // to a phase; FactorUnit::pad = first node of the unit's target tile.
-    {
-        constexpr int W = kFlowUnitsPerTile;
-        const int n_all = (int)funits.size();
-        std::vector<int> image((size_t)2 * std::max(n_all, 1), -1), wl_ptr(1, 0), wl, ctr(4, 0);
-        for (int ph = 0; ph < 2; ++ph) {
-            const int first = flow_first_[ph], n = flow_n_[ph];
-            flow_node_first_[ph] = (int)wl_ptr.size() - 1;
-            if (n == 0) continue;
-            std::vector<int> total((size_t)n_slots_, 0), node0((size_t)n_slots_ + 1, 0);
-            for (int x = 0; x < n; ++x) { const FactorUnit& u = funits[(size_t)first + x]; total[(size_t)u.pub] += (u.kind == 0 || u.kind == 3) ? W : 1; }
-            for (int sl = 0; sl < n_slots_; ++sl) node0[(size_t)sl + 1] = node0[(size_t)sl] + total[(size_t)sl] / W;
-            const int n_nodes = node0[(size_t)n_slots_];
-            std::vector<std::vector<int>> lists((size_t)n_nodes);
-            int* pending = image.data() + 2 * (size_t)first;          // [n] pending, then [n] queue
-            int* queue = pending + n;
-            int n_ready = 0;
-            for (int x = 0; x < n; ++x) {
-                FactorUnit& u = funits[(size_t)first + x];
-                u.pad = node0[(size_t)u.pub];
-                int cnt = 0;
-                for (int q = 0; q < 3; ++q)
-                    if (u.wait_flag[q] >= 0) {
-                        const int m = u.wait_val[q] / W;
-                        if (u.wait_val[q] % W != 0 || m < 1 || m > total[(size_t)u.wait_flag[q]] / W) return "internal error: a dataflow unit waits for a version nobody publishes";
-                        lists[(size_t)node0[(size_t)u.wait_flag[q]] + m - 1].push_back(x);
-                        ++cnt;
-                    }
-                pending[x] = cnt;
-                if (cnt == 0) queue[n_ready++] = x;
-            }
-            if (n_ready == 0) return "internal error: the dataflow launch has no ready unit";
-            ctr[2 * ph] = 0; ctr[2 * ph + 1] = n_ready;
-            for (int nd = 0; nd < n_nodes; ++nd) {
-                wl.insert(wl.end(), lists[(size_t)nd].begin(), lists[(size_t)nd].end());
-                wl_ptr.push_back((int)wl.size());
-            }
-        }
-        if (wl.empty()) wl.push_back(0);
-        TP_TRY(upload(&flow_dyn_init_, image));
-        TP_TRY(upload(&flow_dyn_live_, image));
-        TP_TRY(upload(&flow_wl_ptr_, wl_ptr));
-        TP_TRY(upload(&flow_wl_, wl));
-        TP_TRY(upload(&flow_ctr_init_, ctr));
-        TP_TRY(upload(&flow_ctr_, ctr));
-        if (!dry_run_) { int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) flow_cus_ = cus; }
-    }
-    // ---- first writers of the fill tiles (tile_plan.h, first_writer_) ---------------------------------------------------------
+    // ---- first writers of the fill tiles (tile_plan.h, first_ok_) ------------------------------------------------------------
     // Two execution orders exist: the level launches alone (the lists of every level, in list order) and the level launches of
     // the levels below a dataflow launch followed by its units (in unit order: the writers of a tile are chained in that order).
     // A fill tile's first writer is flagged in both; touched tiles hold S and are never "first written".
     first_ok_ = false;
-    if (first_writer_ && !distributed() && n_slots_ > n_touched_ && flow_n_[1] == 0) {
+    if (!distributed() && n_slots_ > n_touched_ && flow_n_[1] == 0) {
         const size_t te = tile_elems;
         auto slot_of_ptr = [&](const double* c) { return (int64_t)((c - tiles_) / (ptrdiff_t)te); };
         std::vector<char> seen_a((size_t)n_slots_, 0);
@@ -957,23 +913,15 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
     // (and so was a CU-masked one that leaves 1 CU in 8 / 4 / 2 to the critical path: the same, either way)
     if (!side_) TP_TRY(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
     if (!so_) TP_TRY(hipStreamCreateWithFlags(&so_, hipStreamNonBlocking));
-    if (!sp_) TP_TRY(hipStreamCreateWithFlags(&sp_, hipStreamNonBlocking));
     if (!side2_) TP_TRY(hipStreamCreateWithFlags(&side2_, hipStreamNonBlocking));
-    if (!fwd_) TP_TRY(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
-    TP_TRY(hipEventCreateWithFlags(&ev_fwd_, hipEventDisableTiming));
-    TP_TRY(hipEventCreateWithFlags(&ev_fwd2_, hipEventDisableTiming));
     ev_t_.resize(n_levels_); ev_u2_.resize(n_levels_); ev_o_.resize(n_levels_); ev_b_.resize(n_levels_); ev_b2_.resize(n_levels_);
-    ev_p_.resize(n_levels_); ev_pr_.resize(n_levels_);
     if (dry_run_) {   // handles that identify streams and events in a schedule trace
         side_ = reinterpret_cast<hipStream_t>(uintptr_t(0x52)); side2_ = reinterpret_cast<hipStream_t>(uintptr_t(0x53));
-        so_ = reinterpret_cast<hipStream_t>(uintptr_t(0x54)); fwd_ = reinterpret_cast<hipStream_t>(uintptr_t(0x55));
-        sp_ = reinterpret_cast<hipStream_t>(uintptr_t(0x56));
-        ev_fwd_ = reinterpret_cast<hipEvent_t>(uintptr_t(0x1000)); ev_fwd2_ = reinterpret_cast<hipEvent_t>(uintptr_t(0x1001));
+        so_ = reinterpret_cast<hipStream_t>(uintptr_t(0x54));
         for (int i = 0; i < n_levels_; ++i) {
             ev_t_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10000 + 8 * i)); ev_u2_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10001 + 8 * i));
             ev_o_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10002 + 8 * i)); ev_b_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10003 + 8 * i));
             ev_b2_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10004 + 8 * i));
-            ev_p_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10005 + 8 * i)); ev_pr_[i] = reinterpret_cast<hipEvent_t>(uintptr_t(0x10006 + 8 * i));
         }
         gate_cnt_ = reinterpret_cast<int*>(uintptr_t(1) << 46);
     }
@@ -985,8 +933,6 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
         TP_TRY(hipEventCreateWithFlags(&ev_o_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_b_[i], hipEventDisableTiming));
         TP_TRY(hipEventCreateWithFlags(&ev_b2_[i], hipEventDisableTiming));
-        TP_TRY(hipEventCreateWithFlags(&ev_p_[i], hipEventDisableTiming));
-        TP_TRY(hipEventCreateWithFlags(&ev_pr_[i], hipEventDisableTiming));
     }
     TP_TRY(hipMalloc(&gate_cnt_, (size_t)(n_levels_ + 1) * sizeof(int)));
     TP_TRY(hipDeviceSynchronize());  // the null-stream memsets above precede any work on the stream
@@ -997,7 +943,6 @@ std::string TilePlan::build(int nt, const std::vector<uint8_t>& present, hipStre
 
 hipError_t TilePlan::zero_tiles(bool own_touched_only, hipStream_t on, bool skip_fill) {
     const hipStream_t zs = on ? on : stream_;
-    fwd_rhs_ = nullptr; fwd_lower_rhs_ = nullptr;
     const size_t te = (size_t)kNB * kNB * sizeof(double);
     hipError_t e = hipSuccess;
     auto clear = [&](int64_t first, int64_t count) {
@@ -1043,7 +988,7 @@ void TilePlan::launch_fwd_group(int lv, double* bvec, double* yvec, hipStream_t 
 // The factorisation and the triangular solves are static launch sequences for a given structure:
 // they are captured once into hipGraphs (a few hundred dependent launches would otherwise be paced by
 // host launch overhead) and replayed every iteration.
-void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
+void TilePlan::enqueue_factor(int g0, int g1) {
     // Three streams.  Main: potrf(lv), panel solves(lv), U1d(lv) = the updates of the next level's DIAGONAL tiles (all
     // its potrf needs).  Third: U1o(lv) = the updates of the other tiles of the next level's columns, beside that
     // potrf; the next panel solves wait for them.  Side: U2(lv) = every other update of level lv, overlapped with
@@ -1081,19 +1026,10 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         apex::launch_factor_flow(u, n, ver, fail, err, s, trace);
     };
     const bool two = overlap_ && side_ != nullptr && n_levels_ > 2;
-    // Forward substitution L y = rhs fused into the factorisation (when the right-hand side is known now): the
-    // step of level lv needs only that level's L^-1 and panel tiles, which are final after its panel solves, so it
-    // runs on a third stream beside the trailing updates -- a chain of tiny latency-bound launches that costs
-    // nothing there.  solve() then starts at the backward sweep.
-    const bool lower_fwd = lower_fwd_now_ && rhs != nullptr && work != nullptr && fwd_ != nullptr && !distributed() && !tr;
-    const bool fwd = !lower_fwd && rhs != nullptr && work != nullptr && fwd_ != nullptr && !distributed();
     // the trailing groups [gf, g1) of this phase run as one dataflow launch behind the level launches (build())
     const int ph = (g0 == n_local_groups_ && g1 == n_levels_ && n_local_groups_ < n_levels_) ? 1 : 0;
     const int g_end = g1;
-    if (flow_on_ && !fwd && flow_n_[ph] > 0 && flow_g0_[ph] >= g0 && flow_g1_[ph] == g1) g1 = flow_g0_[ph];
-    double* bvec = work;
-    double* yvec = work ? work + n_pad() : nullptr;
-    if (fwd) (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
+    if (flow_on_ && flow_n_[ph] > 0 && flow_g0_[ph] >= g0 && flow_g1_[ph] == g1) g1 = flow_g0_[ph];
     if (gate_min_ > 0 && gate_cnt_) launch_clear_i32(gate_cnt_, n_levels_ + 1, stream_);
     int last_a = -1, last_b = -1;   // last levels with work on the side streams A / B that the main stream has not waited for
     std::vector<int> lastb((size_t)std::max(g1 - g0, 1), -1);   // lastb[lv - g0]: the last level <= lv with U2b2 work on stream B
@@ -1113,35 +1049,10 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         // a cross-stream edge costs a few microseconds in the graph: only worth it when the batch is a real one
         const bool has_u2 = two && n_u2 >= overlap_min_;
         const bool has_o = two && so_ != nullptr && split_u1_ && n_o >= split_u1_min_;
-        // Panel lookahead (round 5).  In the bulk levels the period of a level WAS its dependency chain: potrf (100 us beside
-        // the updates) -> all panel solves (1,536 workgroups: 190 us) -> U1d (80 us) -> next potrf (profiles/
-        // r05_factor_timeline.txt) -- but U1d reads only the panel tiles whose rows belong to the next level.  Those go first,
-        // on the main stream; the others run on a stream of their own (sp_) behind the potrf, and every reader of theirs waits
-        // for them (ev_pr_): U1o(lv) on the third stream -- which is what the next level's panel solves wait for (ev_o_) -- and
-        // the U2 streams.  Same tasks, same order on every tile: bit-identical.
-        // (Why a FIFTH stream: sp_ waits for events of the main stream only.  On the third stream the rest made the U2 stream
-        // wait for an event of the third stream, which itself waits for events of the U2 stream -- and ending the capture then
-        // recursed for ever inside the runtime, which walks "streams that joined through me" without a visited set.)
-        const int t0 = lv_trsm_[lv], tc = lv_trsm_crit_[lv], t1 = lv_trsm_[lv + 1];
-        const bool psplit = panel_split_ && sp_ != nullptr && has_u2 && has_o && !fwd && !distributed() && tc > t0 && t1 - tc >= panel_split_min_;
-        if (psplit) {
-            (void)hipEventRecord(ev_p_[lv], stream_);   // after the potrf and everything the main stream has waited for
-            launch_tile_gemm_nt(trsm_tasks_ + t0, tc - t0, 1.0, 0.0, stream_);
-            (void)hipStreamWaitEvent(sp_, ev_p_[lv], 0);
-            launch_tile_gemm_nt(trsm_tasks_ + tc, t1 - tc, 1.0, 0.0, sp_);
-            (void)hipEventRecord(ev_pr_[lv], sp_);
-        } else {
-            launch_tile_gemm_nt(trsm_tasks_ + t0, t1 - t0, 1.0, 0.0, stream_);
-        }
-        if (has_u2 || fwd || has_o) (void)hipEventRecord(ev_t_[lv], stream_);
+        launch_tile_gemm_nt(trsm_tasks_ + lv_trsm_[lv], lv_trsm_[lv + 1] - lv_trsm_[lv], 1.0, 0.0, stream_);
+        if (has_u2 || has_o) (void)hipEventRecord(ev_t_[lv], stream_);
         if (has_u2) (void)hipStreamWaitEvent(side_, ev_t_[lv], 0);
-        if (has_u2 && psplit) (void)hipStreamWaitEvent(side_, ev_pr_[lv], 0);
         if (has_o) (void)hipStreamWaitEvent(so_, ev_t_[lv], 0);
-        if (has_o && psplit) (void)hipStreamWaitEvent(so_, ev_pr_[lv], 0);
-        if (fwd) {
-            (void)hipStreamWaitEvent(fwd_, ev_t_[lv], 0);
-            launch_fwd_group(lv, bvec, yvec, fwd_);
-        }
         if (two && lv > g0 && u2_pending_[lv - 1]) {
             (void)hipStreamWaitEvent(stream_, ev_u2_[lv - 1], 0);
             if (has_o) (void)hipStreamWaitEvent(so_, ev_u2_[lv - 1], 0);
@@ -1179,7 +1090,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         // follow U1d on the main stream) -- otherwise the update's grid takes every CU first and the potrf, 124 KB of LDS per
         // workgroup, waits for it to drain
         const bool gated = has_u2 && gate_min_ > 0 && gate_cnt_ && n_u2 >= gate_min_ && lv + 1 < g1;
-        if (gated && gate_pos_ == 0) launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);
+        if (gated) launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);
         // a small U2 stays on the main stream: earlier levels' U2b may still be at work on the same targets over there
         if (!has_u2 && r1 > rs) {
             if (last_a >= 0) { (void)hipStreamWaitEvent(stream_, ev_b_[last_a], 0); last_a = -1; }
@@ -1195,10 +1106,7 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
         if (has_u2) (void)hipEventRecord(ev_u2_[lv], side_);   // ... and, in stream order, every earlier update on A
         if (b2_side) {
             (void)hipStreamWaitEvent(side2_, ev_t_[lv], 0);
-            if (psplit) (void)hipStreamWaitEvent(side2_, ev_pr_[lv], 0);
             if (gated) launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side2_);
-        } else if (gated && gate_pos_ == 1) {
-            launch_gate(gate_cnt_ + lv + 1, lv_potrf_[lv + 2] - lv_potrf_[lv + 1], 150, side_);
         }
         if (has_u2 && lv - 1 >= g0) a_wait_upto(lastb[lv - 1 - g0]);   // ... and U2b1(lv) [level lv+3] every U2b2 of levels <= lv-1
         for (int r = ra; r < rb; ++r)   // U2b1
@@ -1213,56 +1121,27 @@ void TilePlan::enqueue_factor(const double* rhs, double* work, int g0, int g1) {
     // join: the last side-stream work precedes whatever follows on the main stream
     if (last_a >= 0) (void)hipStreamWaitEvent(stream_, ev_b_[last_a], 0);
     if (last_b >= 0) (void)hipStreamWaitEvent(stream_, ev_b2_[last_b], 0);
-    if (fwd) {
-        (void)hipEventRecord(ev_fwd_, fwd_);
-        (void)hipStreamWaitEvent(stream_, ev_fwd_, 0);
-    }
-    const bool lower_now = lower_fwd && g1 < g_end && ph == 0 && fwd_lower_count_ > 0;
-    if (lower_now) {
-        // the forward sweep over the columns below this launch, beside it (tile_plan.h, fwd_beside_top_): their L tiles and
-        // L^-1 are final here; the sweep's counters are cleared by this first part and stand for the second (TilePlan::solve)
-        (void)hipEventRecord(ev_fwd_, stream_);
-        (void)hipStreamWaitEvent(fwd_, ev_fwd_, 0);
-        apex::launch_tri_flow(false, flow_fwd_, fwd_lower_count_, rhs, yvec, flow_part_, flow_flags_, nt_, fwd_, nullptr, nullptr);
-        (void)hipEventRecord(ev_fwd2_, fwd_);
-    }
     if (g1 < g_end) {   // every update the level launches add to the region's tiles is in: the joins above
         launch_clear_i32(flow_ver_, n_slots_, stream_);
         if (poison_factor_ && !tr)   // (tests: the version of the first unit's tile starts hugely negative and is never reached)
             (void)hipMemsetAsync(flow_ver_ + flow_units_h_[(size_t)flow_first_[ph]].pub, 0x80, sizeof(int), stream_);
-        if (flow_dyn_ && !tr) {
-            const size_t first = (size_t)flow_first_[ph], n = (size_t)flow_n_[ph];
-            (void)hipMemcpyAsync(flow_dyn_live_ + 2 * first, flow_dyn_init_ + 2 * first, 2 * n * sizeof(int), hipMemcpyDeviceToDevice, stream_);
-            (void)hipMemcpyAsync(flow_ctr_ + 2 * ph, flow_ctr_init_ + 2 * ph, 2 * sizeof(int), hipMemcpyDeviceToDevice, stream_);
-            if (poison_factor_)   // (tests: the first ready unit is never found in the queue -- its slot stays empty)
-                (void)hipMemsetAsync(flow_dyn_live_ + 2 * first + n, 0xFF, sizeof(int), stream_);
-            launch_factor_flow_dyn(flow_units_ + first, (int)n, flow_ver_, flag_, flag_ + 1, flow_dyn_live_ + 2 * first, flow_dyn_live_ + 2 * first + n,
-                                   flow_ctr_ + 2 * ph, flow_wl_ptr_ + flow_node_first_[ph], flow_wl_, flow_cus_, stream_,
-                                   flow_trace_ ? flow_trace_ + 3 * first : nullptr);
-        } else
         launch_factor_flow(flow_units_ + flow_first_[ph], flow_n_[ph], flow_ver_, flag_, flag_ + 1, stream_,
                            flow_trace_ ? flow_trace_ + 3 * (size_t)flow_first_[ph] : nullptr);
     }
-    if (lower_now) (void)hipStreamWaitEvent(stream_, ev_fwd2_, 0);   // (the side stream comes back to the capture)
 }
 
-void TilePlan::enqueue_solve(const double* rhs, double* x, double* work, bool backward_only, bool upper_only) {
+void TilePlan::enqueue_solve(const double* rhs, double* x, double* work) {
     // L y = rhs (work vector bvec), then L^T x = y (work vector yvec); level by level
     double* bvec = work;
     double* yvec = work + n_pad();
     const bool flow = tri_flow_ && n_flow_tasks_ > 0;
-    if (!backward_only) {
-        if (flow && upper_only) {   // the part below the factorisation's dataflow launch ran beside it (enqueue_factor)
-            launch_tri_flow(false, flow_fwd_ + fwd_lower_count_, n_flow_tasks_ - fwd_lower_count_, rhs, yvec, flow_part_, flow_flags_, nt_, stream_,
-                            nullptr, nullptr, -1, /*keep_flags=*/true);
-        } else if (flow) {
-            launch_tri_flow(false, flow_fwd_, n_flow_tasks_, rhs, yvec, flow_part_, flow_flags_, nt_, stream_, nullptr, nullptr,
-                            poison_ == 1 ? nt_ - 1 : -1);
-        } else {
-            (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
-            for (int lv = 0; lv < n_levels_; ++lv)
-                launch_fwd_group(lv, bvec, yvec, stream_);
-        }
+    if (flow) {
+        launch_tri_flow(false, flow_fwd_, n_flow_tasks_, rhs, yvec, flow_part_, flow_flags_, nt_, stream_, nullptr, nullptr,
+                        poison_ == 1 ? nt_ - 1 : -1);
+    } else {
+        (void)hipMemcpyAsync(bvec, rhs, n_pad() * sizeof(double), hipMemcpyDeviceToDevice, stream_);
+        for (int lv = 0; lv < n_levels_; ++lv)
+            launch_fwd_group(lv, bvec, yvec, stream_);
     }
     if (flow) {
         launch_tri_flow(true, flow_bwd_, n_flow_bwd_, yvec, x, flow_part_, flow_flags_, nt_, stream_, nullptr, nullptr,
@@ -1324,10 +1203,10 @@ bool TilePlan::run_graph(int which, const double* rhs, double* x, double* work) 
         if (graph_failed_[which]) return false;
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_failed_[which] = true; return false; }
-        if (which == 0) enqueue_factor(rhs, work, 0, n_local_groups_);
-        else if (which == 3) enqueue_factor(nullptr, nullptr, n_local_groups_, n_levels_);
+        if (which == 0) enqueue_factor(0, n_local_groups_);
+        else if (which == 3) enqueue_factor(n_local_groups_, n_levels_);
         else if (which == 4 || which == 5) enqueue_dist_solve(which - 4, rhs, x, work);
-        else enqueue_solve(rhs, x, work, which == 2, which == 6);
+        else enqueue_solve(rhs, x, work);
         if (hipStreamEndCapture(stream_, &g) != hipSuccess || !g) { graph_failed_[which] = true; (void)hipGetLastError(); return false; }
         hipGraphExec_t ex = nullptr;
         if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); graph_failed_[which] = true; (void)hipGetLastError(); return false; }
@@ -1341,7 +1220,7 @@ bool TilePlan::run_graph(int which, const double* rhs, double* x, double* work) 
 void TilePlan::enable_tri_flow(bool on) {
     if (on == tri_flow_) return;
     tri_flow_ = on;
-    for (int which : {1, 2, 4, 5})   // the captured sweeps change
+    for (int which : {1, 4, 5})   // the captured sweeps change
         if (graph_exec_[which]) { (void)hipGraphExecDestroy(graph_exec_[which]); graph_exec_[which] = nullptr; }
 }
 
@@ -1367,8 +1246,8 @@ hipError_t TilePlan::read_flow_trace(std::vector<FactorUnit>* units, std::vector
 std::vector<SchedOp> TilePlan::schedule_trace(int phase) {
     std::vector<SchedOp> ops;
     sched_trace_ = &ops;
-    if (phase == 0) enqueue_factor(nullptr, nullptr, 0, n_local_groups_);
-    else enqueue_factor(nullptr, nullptr, n_local_groups_, n_levels_);
+    if (phase == 0) enqueue_factor(0, n_local_groups_);
+    else enqueue_factor(n_local_groups_, n_levels_);
     sched_trace_ = nullptr;
     return ops;
 }
@@ -1456,18 +1335,17 @@ void TilePlan::top_slot_ranges(std::pair<int64_t, int64_t> out[2]) const {
 }
 
 void TilePlan::factor_phase(int phase) {
-    if (phase == 0) { if (!run_graph(0, nullptr, nullptr, nullptr)) enqueue_factor(nullptr, nullptr, 0, n_local_groups_); }
-    else if (!run_graph(3, nullptr, nullptr, nullptr)) enqueue_factor(nullptr, nullptr, n_local_groups_, n_levels_);
+    if (phase == 0) { if (!run_graph(0, nullptr, nullptr, nullptr)) enqueue_factor(0, n_local_groups_); }
+    else if (!run_graph(3, nullptr, nullptr, nullptr)) enqueue_factor(n_local_groups_, n_levels_);
 }
 
 void TilePlan::solve_phase(int phase, const double* rhs, double* x, double* work) {
     if (phase == 2 || !run_graph(4 + phase, rhs, x, work)) enqueue_dist_solve(phase, rhs, x, work);
 }
 
-hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work, bool defer_flags) {
+hipError_t TilePlan::factor(int* failed_at, bool defer_flags) {
     if (distributed()) {
         if (!comm_.sum || !comm_.max_int) return hipErrorNotInitialized;  // a distributed plan needs its communicator
-        fwd_rhs_ = nullptr;
         factor_phase(0);
         std::pair<int64_t, int64_t> rg[2];
         top_slot_ranges(rg);
@@ -1478,22 +1356,10 @@ hipError_t TilePlan::factor(int* failed_at, const double* rhs, double* work, boo
         if (!comm_.max_int(flag_, 2, stream_)) return hipErrorUnknown;  // a failed pivot (or a dataflow time-out) anywhere fails the factorisation everywhere
         return read_flags(failed_at);
     }
-    // the lower part of the forward sweep beside the dataflow launch of the top (tile_plan.h): plans with such a launch only
-    const int lower_count = (flow_on_ && flow_n_[0] > 0 && flow_g1_[0] == n_levels_ && flow_g0_[0] > 0 && flow_g0_[0] < (int)lv_flow_fwd_.size())
-                                ? lv_flow_fwd_[(size_t)flow_g0_[0]] : 0;
-    const bool lower = !fuse_forward_ && fwd_beside_top_ && tri_flow_ && n_flow_tasks_ > 0 && rhs != nullptr && work != nullptr && fwd_ != nullptr &&
-                       !poison_factor_ && poison_ == 0 && !dry_run_ && lower_count > 0 && lower_count < n_flow_tasks_;
-    if (!fuse_forward_ && !lower) { rhs = nullptr; work = nullptr; }
-    lower_fwd_now_ = lower;
-    fwd_lower_count_ = lower ? lower_count : 0;
     if (poison_factor_) {   // (tests: the poisoned launch is not part of the captured graphs)
-        enqueue_factor(rhs, work, 0, n_levels_);
+        enqueue_factor(0, n_levels_);
         poison_factor_ = false;
-    } else if (!run_graph(0, rhs, nullptr, work)) enqueue_factor(rhs, work, 0, n_levels_);
-    lower_fwd_now_ = false;
-    if (lower) { fwd_lower_rhs_ = rhs; fwd_lower_work_ = work; rhs = nullptr; work = nullptr; }
-    else fwd_lower_rhs_ = nullptr;
-    fwd_rhs_ = rhs; fwd_work_ = work;  // the forward sweep for this right-hand side is part of the factorisation
+    } else if (!run_graph(0, nullptr, nullptr, nullptr)) enqueue_factor(0, n_levels_);
     if (defer_flags) { *failed_at = 0; return hipGetLastError(); }
     return read_flags(failed_at);
 }
@@ -1563,15 +1429,10 @@ hipError_t TilePlan::solve(const double* rhs, double* x, double* work) {
         if (tri_flow_ && !post_sweep_status(true)) return hipErrorUnknown;
         return hipGetLastError();
     }
-    const bool backward_only = fwd_rhs_ != nullptr && rhs == fwd_rhs_ && work == fwd_work_;
-    const bool upper_only = !backward_only && poison_ == 0 && tri_flow_ && fwd_lower_count_ > 0 && fwd_lower_rhs_ != nullptr && rhs == fwd_lower_rhs_ &&
-                            work == fwd_lower_work_;
-    fwd_rhs_ = nullptr;  // one solve per fused sweep: the backward sweep consumes yvec's partner bvec
-    fwd_lower_rhs_ = nullptr;
     if (poison_ != 0) {   // (tests: the poisoned launch is not part of the captured graphs)
-        enqueue_solve(rhs, x, work, backward_only);
+        enqueue_solve(rhs, x, work);
         poison_ = 0;
-    } else if (!run_graph(upper_only ? 6 : (backward_only ? 2 : 1), rhs, x, work)) enqueue_solve(rhs, x, work, backward_only, upper_only);
+    } else if (!run_graph(1, rhs, x, work)) enqueue_solve(rhs, x, work);
     if (tri_flow_ && n_flow_tasks_ > 0) (void)post_sweep_status(false);
     return hipGetLastError();
 }

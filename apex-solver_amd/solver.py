@@ -271,6 +271,24 @@ class GpuSchurComplementSolver:
         self.setup_wall = dict(create_handle=t1 - t0, host_arrays=t2 - t1, set_structure=t3 - t2)
         return self
 
+    def reinitialize_structure(self, problem: Problem):
+        """A second initialize_structure on the SAME handle (StructureAware::initialize_structure may be called again,
+        src/linalg/mod.rs:116-123): the counts are those the handle was created with, the lists and every decision that follows
+        from them (tile plan, variant selection) are made afresh.  Options stay as they were set."""
+        h = self._need()
+        d, old = problem.data, self._problem.data
+        if (d.n_cam, d.n_pt, d.n_obs) != (old.n_cam, old.n_pt, old.n_obs) or problem.optimization_type != self._problem.optimization_type:
+            raise capi.LinAlgError(-5, "reinitialize_structure: the handle was created for other counts")
+        lay = problem.layout
+        self._keep = [np.ascontiguousarray(a) for a in (
+            d.cam_idx.astype(np.uint32, copy=False), d.pt_idx.astype(np.uint32, copy=False), d.obs_uv.astype(np.float64, copy=False),
+            lay.intr_col, lay.pose_col, lay.pt_col, problem.fix_pose, problem.fix_intr, problem.fix_pt)]
+        hd = -1.0 if problem.huber_delta is None else float(problem.huber_delta)
+        h.check(h.L.apexgpu_set_structure(h.h, *[capi.ptr(a) for a in self._keep], hd))
+        h.check(h.L.apexgpu_set_cg_params(h.h, self.cg_max_iterations, self.cg_tolerance))
+        self._problem = problem
+        return self
+
     def _need(self) -> capi.Handle:
         if self._h is None:
             raise capi.LinAlgError(-5, "Block structure not built. Call initialize_structure() first.")
@@ -418,7 +436,11 @@ class GpuSchurComplementSolver:
         asked = self.variant if asked is None else asked
         used = C.c_int(0); buf = C.create_string_buffer(512)
         h.check(h.L.apexgpu_variant_info(h.h, asked.value, C.byref(used), buf, 512))
-        return dict(variant_asked=asked.name, variant_used=SchurVariant(used.value).name, reason=buf.value.decode())
+        c = (C.c_double * 4)()
+        h.check(h.L.apexgpu_variant_costs(h.h, C.byref(c)))
+        return dict(variant_asked=asked.name, variant_used=SchurVariant(used.value).name, reason=buf.value.decode(),
+                    predicted_direct_ms=float(c[0]), predicted_matrix_free_ms=float(c[1]),
+                    variant_choice=("direct", "matrix-free by predicted cost", "matrix-free: plan refused", "matrix-free by option")[int(c[2])])
 
     def counters(self) -> dict:
         """Events of this handle's life: dataflow triangular sweeps that timed out and were repeated level by level."""

@@ -192,7 +192,7 @@ def factor_roofline(info, f_ms, note=None):
     """The tile Cholesky against the fp64 MFMA peak (78.6 TF/s, MI355X_MICROARCH.md): flops of one factorisation from the
     plan's own operation counts (apexgpu_info[9..11]) -- a panel product or trailing update is 2 x 144^3, a diagonal tile's
     Cholesky + triangular inverse 2/3 x 144^3 -- `achieved` on ALL of them (comparable across rounds), `executed` without the
-    36 of 81 block products per panel solve that multiply by the zero blocks of the triangular inverse ("panel_tri")."""
+    36 of 81 block products per panel solve that multiply by the zero blocks of the triangular inverse."""
     t3 = 144.0 ** 3
     flops = 2.0 * t3 * (info["n_trsm"] + info["n_update"]) + info["n_potrf"] * (2.0 / 3.0) * t3
     executed = 2.0 * t3 * (info["n_trsm"] * 45.0 / 81.0 + info["n_update"]) + info["n_potrf"] * (2.0 / 3.0) * t3
@@ -564,8 +564,8 @@ def main():
     # ---- roofline of the graded Schur-reduction kernel, per launch -------------------------------------------------------
     dc = 9 if args.mode == "selfcal" else 6
     form = info.get("schur_form", 3)
-    kernel = {4: "k_schur_pairs_r", 3: "k_schur_pairs_r", 2: "k_schur_rows2"}[form]   # (4: the queued layout of the pair list)
-    record_form = form in (3, 4)
+    kernel = "k_schur_pairs_r"   # (form 4: the queued layout of the pair list, 3: one running block per wave)
+    record_form = True
     n_obs_local = info["local_obs"]
     tile_bytes = 144 * 144 * 8
     # SURVEY §8(d), fused form (J never stored): each input read once, each output written once.  The record form (the

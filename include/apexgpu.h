@@ -72,13 +72,16 @@ int apexgpu_create(int64_t n_cam, int64_t n_pt, int64_t n_obs, int mode, int dev
 void apexgpu_destroy(apexgpu_solver* h);
 const char* apexgpu_last_error(const apexgpu_solver* h);
 const char* apexgpu_version(void);
-/* The structure set-up builds its lists (3.7 GB on BAL final-13682) in host blocks that are KEPT by the process, up to 8 GB,
- * when a handle lets go of them, and serve the next apexgpu_set_structure: handing them back to the system costs 0.2 s of page
- * zapping that stalls the caller's next GPU calls even from a background thread (tools/setup_probe.py).  This call returns
- * everything kept to the system (*released_bytes, may be NULL); the environment variable APEX_HOST_CACHE=0 switches the
- * cache off (blocks are then freed where they are released).  No counterpart in the reference: its symbolic structures
- * live and die with the solver (src/linearizer/cpu/sparse.rs:54-105). */
+/* The structure set-up builds its lists (3.7 GB on BAL final-13682) in host blocks that are cached WHILE A HANDLE IS ALIVE and
+ * serve the next apexgpu_set_structure: handing them back to the system costs 0.2 s of page zapping that stalls the caller's
+ * next GPU calls even from a background thread (tools/setup_probe.py).  The cache holds the blocks of the last set-up only (a
+ * smaller structure after a larger one releases the surplus), at most 8 GB, and the apexgpu_destroy of the last live handle
+ * returns everything to the system.  apexgpu_trim_host_cache does that at once (*released_bytes, may be NULL),
+ * apexgpu_host_cache_bytes reports what is held, the environment variable APEX_HOST_CACHE=0 switches the cache off (blocks are
+ * then freed where they are released).  No counterpart in the reference: its symbolic structures live and die with the solver
+ * (src/linearizer/cpu/sparse.rs:54-105). */
 int apexgpu_trim_host_cache(int64_t* released_bytes);
+int64_t apexgpu_host_cache_bytes(void);
 
 /* ---- structure -------------------------------------------------------------------------------
  * Replaces StructureAware::initialize_structure (src/linalg/mod.rs:116-123; explicit_schur.rs:
@@ -297,7 +300,12 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     the free HBM -- does NOT fail apexgpu_set_structure: the handle is built matrix-free only by itself and
  *                     apexgpu_solve_augmented / apexgpu_lm_optimize answer variants 0 and 1 with the matrix-free PCG (variant 2;
  *                     for variant 0 at IterativeSchurSolver's defaults, 500 iterations / 1e-9, for variant 1 at the caller's
- *                     cg parameters).  apexgpu_variant_info tells.  0: the refusal is APEXGPU_ERR_INVALID_INPUT as before
+ *                     cg parameters).  Round 6: the same happens when the plan is PREDICTED to cost more per solve than the
+ *                     matrix-free PCG at its cap (apexgpu_variant_costs) -- between 0.5 s and the 12.7 s of the size limit the direct
+ *                     path used to be chosen although the handle owns a 0.5-s way to the same step.  apexgpu_variant_info tells.
+ *                     0: a refusal is APEXGPU_ERR_INVALID_INPUT as before, and no plan is refused by cost
+ *   "variant_cost_percent" (100)  before set_structure: scales the matrix-free side of that comparison (tests move the crossover
+ *                     onto small problems; 0 switches the cost rule off)
  *   "max_tile_updates" (80000000)  tests: the limit of tile products per factorisation above which the plan is refused
  *   "factor_flow" (-1), "factor_flow_rows" (24)  the TOP of the elimination tree -- the trailing level groups with at most
  *                     that many tile columns each, every column with at most "factor_flow_rows" off-diagonal tiles -- is
@@ -361,14 +369,16 @@ int apexgpu_info(apexgpu_solver* h, double info[16]);
  * The reference never needs it: its LM dispatch (src/optimizer/levenberg_marquardt.rs:1039-1082) does not depend on the
  * fill of S, and IterativeSchurSolver (src/linalg/sparse/implicit_schur.rs:835-946) is the solver the fall-back restates. */
 int apexgpu_variant_info(apexgpu_solver* h, int asked_variant, int* used_variant, char* reason, int reason_len);
+/* What apexgpu_set_structure predicted and chose (round 6): out[0] = milliseconds per solve of the direct path (tile Cholesky
+ * + both sweeps; from the plan's operation counts at the rates DESIGN.md section 5 measures; 0 on a handle built with
+ * "matrix_free_only"), out[1] = of the matrix-free PCG at IterativeSchurSolver's cap (out[3] = 500 iterations x one S p = two
+ * passes over the observations), out[2] = the choice: 0 direct, 1 matrix-free by predicted cost (out[0] > out[1]), 2 matrix-free
+ * because the plan was refused (size / memory), 3 matrix-free by the caller's option. */
+int apexgpu_variant_costs(apexgpu_solver* h, double out[4]);
 /* out[0] = dataflow triangular sweeps that timed out and were repeated level by level (see "tri_dataflow"),
  * out[1] = 1 while the handle still uses the dataflow sweeps, out[2] = dataflow factorisations that timed out and were
  * repeated by the level launches (see "factor_flow"), out[3] = level groups inside the dataflow launches of this plan */
 int apexgpu_counters(apexgpu_solver* h, int64_t out[4]);
-/* Profiling aid of the Schur pair kernel (record form run with "pairs_ablation" 64: results stay right): shader cycles summed
- * over all waves since the last reset, out[0..4] = wait for the gathers, un-staging, Jacobians + U / V stores, issue of the next
- * chunk's loads, block products + flushes; out[5] chunks, out[6] cycles inside flushes, out[7] flushes. */
-int apexgpu_debug_pair_phases(int64_t out[8], int reset);
 /* Tests: the records of the sorted pair list as they sit on the device, recs4_out[slots][4] = {i, j, landmark, queue}
  * (i = 0xFFFFFFFF: padding; slots = counts[2] of apexgpu_setup_times). */
 int apexgpu_debug_get_pair_records(apexgpu_solver* h, uint32_t* recs4_out, int64_t cap_slots);
@@ -416,13 +426,12 @@ int apexgpu_debug_partition(int nt, const uint8_t* present, int world, int* owne
  * instead of issuing them, and every two launches that touch one tile with a writer among them must be ordered by stream
  * order + event edges; tasks of one launch must not share a written tile.  present: lower-triangular nt x nt structure in
  * the final tile order.  opts = {two_side, update_overlap (>1: minimum batch), split_u1, flood_gate, factor_flow,
- * factor_flow_rows, tests: bring back the round-3 idle-level bug, tests: drop that stream wait of phase 0 (-1: none),
- * panel_split (round 5: 0 off, > 0 the smallest rest that is split off)}.
+ * factor_flow_rows, tests: bring back the round-3 idle-level bug, tests: drop that stream wait of phase 0 (-1: none)}.
  * out = {calls, launches, violations of phase 0 (local level groups / everything), violations of phase 1 (shared top of a
  * distributed plan), dataflow units, level groups inside dataflow launches, stream waits, 1 if a wait was dropped}.
  * Returns the number of level groups (>= 0) or an error; msg receives the first violation.  (round-3 advice: the U2 split
  * had dropped the edge behind a level without side-stream work; the checker finds it on the advisor's pattern.) */
-int apexgpu_debug_check_schedule(int nt, const uint8_t* present, int world, int rank, const int opts[9], int64_t out[8], char* msg, int msg_len);
+int apexgpu_debug_check_schedule(int nt, const uint8_t* present, int world, int rank, const int opts[8], int64_t out[8], char* msg, int msg_len);
 /* Host arithmetic only: the sorted camera-pair lists of the default Schur reduction for an observation list, with the
  * caller's camera order and a dense tile map (slot(I, J) = I (I + 1) / 2 + J).  counts[4] = {slots, chunks, blocks, tasks};
  * outputs may be NULL (size query): recs4 [slots][4] = {i, j, landmark, block local to the chunk} (i = 0xFFFFFFFF:

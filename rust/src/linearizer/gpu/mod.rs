@@ -49,8 +49,10 @@ extern "C" {
     /// which variant a solve asked with `asked_variant` runs on this handle, and why (round 5: automatic selection of the
     /// matrix-free PCG when the tile plan of S is refused -- the CPU path never fails on the fill of S)
     pub fn apexgpu_variant_info(h: *mut ApexGpuSolver, asked_variant: c_int, used_variant: *mut c_int, reason: *mut c_char, reason_len: c_int) -> c_int;
-    /// hand the set-up's cached host blocks back to the system (a long-lived host between two optimize() calls)
+    /// hand the set-up's cached host blocks back to the system at once (the `apexgpu_destroy` of the last live handle does
+    /// it by itself: the cache only lives while a solver does); `apexgpu_host_cache_bytes`: what is held right now
     pub fn apexgpu_trim_host_cache(released_bytes: *mut i64) -> c_int;
+    pub fn apexgpu_host_cache_bytes() -> i64;
     pub fn apexgpu_set_params(h: *mut ApexGpuSolver, poses: *const f64, intr: *const f64, points: *const f64) -> c_int;
     pub fn apexgpu_solve_augmented(h: *mut ApexGpuSolver, lambda: f64, variant: c_int, step_out: *mut f64, grad_out: *mut f64) -> c_int;
     pub fn apexgpu_column_norms(h: *mut ApexGpuSolver, norms_out: *mut f64) -> c_int;
@@ -142,6 +144,7 @@ unsafe impl Sync for GpuContext {}
 
 impl Drop for GpuContext {
     fn drop(&mut self) {
+        // (the last context to go also returns the cached set-up blocks of the library to the system: apexgpu.h)
         unsafe { apexgpu_destroy(self.h) }
     }
 }

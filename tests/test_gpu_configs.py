@@ -446,3 +446,50 @@ def test_refused_plan_selects_the_matrix_free_variant_by_itself(oracle):
     assert res.final_cost < 0.5 * res.initial_cost
     assert res.iterations == ores.iterations and res.final_cost == pytest.approx(ores.final_cost, rel=1e-6)
     s2.close()
+
+
+# ---- variant selection by predicted cost (round 6) ---------------------------------------------------------------------------
+def test_variant_is_selected_by_predicted_cost(oracle):
+    """Between "cheap" and "refused" the direct factorisation used to be chosen whatever it cost (up to 12.7 s at the plan limit)
+    although the handle owns the matrix-free PCG, whose cost does not depend on the fill of S.  apexgpu_set_structure now
+    predicts both (apexgpu_variant_costs: the plan's operation counts at the measured rates; the PCG cap times two passes over
+    the observations) and builds the cheaper one.  Two structures of the same size on either side of the crossover -- the banded
+    final-13682 shape and its mix with 5 % long-range landmarks (S dense at tile granularity), the crossover moved onto this
+    small size with "variant_cost_percent" -- through the plain LM surface (SchurVariant::Sparse), each against the oracle's
+    matching variant: Cholesky for the one, IterativeSchurSolver's PCG for the other."""
+    from apex_solver_amd.solver import LevenbergMarquardt, LevenbergMarquardtConfig
+
+    lo = pkg.synthetic.make_named("final-13682", 0.02)
+    hi = pkg.synthetic.make_named("final-13682-mix:0.05", 0.02)
+    pred = []
+    for d in (lo, hi):
+        _, s = make(d, "selfcal")
+        vi = s.variant_info()
+        assert vi["variant_choice"] == "direct" and vi["predicted_direct_ms"] > 0 and vi["predicted_matrix_free_ms"] > vi["predicted_direct_ms"], vi
+        pred.append(vi)
+        s.close()
+    d_lo, d_hi, mf = pred[0]["predicted_direct_ms"], pred[1]["predicted_direct_ms"], pred[0]["predicted_matrix_free_ms"]
+    print(f"predicted ms per solve at 1/50: direct banded {d_lo:.3f}, direct mix {d_hi:.3f}, matrix-free {mf:.3f}")
+    assert d_hi > 1.2 * d_lo
+    pct = int(np.ceil(100.0 * d_lo / mf + 1e-9))
+    if 100.0 * d_lo / mf >= pct - 1e-9:
+        pct += 1
+    assert pct * mf / 100.0 < d_hi, "no whole percentage separates the two structures at this size"
+    for d, want, ovar in ((lo, "direct", 0), (hi, "matrix-free by predicted cost", 2)):
+        prob, s = make(d, "selfcal", opts=(("variant_cost_percent", pct),))
+        vi = s.variant_info()
+        print("variant by cost:", d.name, vi)
+        assert vi["variant_choice"] == want, vi
+        assert vi["variant_used"] == ("Sparse" if ovar == 0 else "Implicit")
+        assert ("predicted cost" in vi["reason"]) == (ovar == 2)
+        res = LevenbergMarquardt.with_config(LevenbergMarquardtConfig().with_max_iterations(2)).optimize(prob, solver=s)
+        o = oracle.from_data(d, prob.layout, mode="selfcal", huber_delta=1.0)
+        o.set_cg_params(500, 1e-9)
+        ores = o.optimize(oracle.LMConfig.default(max_iterations=2, variant=ovar))
+        print("   LM:", res.status.name, res.iterations, res.initial_cost, "->", res.final_cost, "| oracle variant", ovar, ores.final_cost)
+        assert res.iterations == ores.iterations and res.final_cost == pytest.approx(ores.final_cost, rel=1e-6)
+        s.close()
+    # "auto_variant" 0: no plan is refused by cost either
+    _, s = make(hi, "selfcal", opts=(("variant_cost_percent", pct), ("auto_variant", 0)))
+    assert s.variant_info()["variant_choice"] == "direct"
+    s.close()

@@ -205,17 +205,12 @@ def test_factorisation_schedule_switches_agree():
     assert info["etree_levels"] >= 8
     nrm = np.linalg.norm(ref)
     for opts in ({"two_side": 2}, {"two_side": 2, "flood_gate": 2}, {"two_side": 0, "flood_gate": 2}, {"two_side": 2, "flood_gate": 0},
-                 {"two_side": 2, "split_u1": 0}, {"two_side": 2, "flood_gate": 2, "flood_gate_pos": 1},
+                 {"two_side": 2, "split_u1": 0}, {"update_overlap": 1, "two_side": 0},
                  # round 4: the top of the tree by level launches only / as one dataflow launch down to wide groups (the default
-                 # lets a cost model choose), and the panel solves with and without the triangular skip (process-wide switch)
-                 {"factor_flow": 0}, {"factor_flow": 64}, {"factor_flow": 0, "panel_tri": 0}, {"panel_tri": 1},
-                 # round 5: the panel lookahead off / on every level that has both kinds of panel tiles (default: rest >= 96 tiles)
-                 {"panel_split": 0}, {"panel_split": 1}, {"panel_split": 1, "factor_flow": 0},
-                 # the forward sweep as one launch behind the factorisation / its lower part beside the dataflow launch of the top
-                 {"fwd_beside_top": 0}, {"fwd_beside_top": 1, "factor_flow": 64}, {"fwd_beside_top": 1, "one_wait": 0},
-                 # the fill tiles cleared and read by their first update as until round 4 / neither (the default), by level launches
-                 # alone and with the dataflow launch of the top
-                 {"first_writer": 0}, {"first_writer": 0, "factor_flow": 0}, {"first_writer": 1, "factor_flow": 0}, {"first_writer": 1, "factor_flow": 64}):
+                 # lets a cost model choose)
+                 {"factor_flow": 0}, {"factor_flow": 64}, {"factor_flow": 64, "factor_flow_rows": 1000},
+                 # one host wait per solve / three; the step statistics and the trial point behind the solve / on request
+                 {"one_wait": 0}, {"one_wait": 0, "factor_flow": 0}, {"eager_step_eval": 0}, {"graphs": 0}):
         (a, b), _ = step(opts)
         # Bit for bit (round 4): with the queued pair layout S is assembled without atomics on this shape (no block longer than
         # a piece, no camera that sees a landmark twice), every schedule adds a tile's updates in the same order, the dataflow

@@ -201,7 +201,28 @@ def test_cholesky_ladder_on_a_zero_pivot(oracle, mode):
     print(mode, "ladder: backward error", bwd, "step vs oracle", err, "cond(S + reg I)", np.linalg.cond(A))
     assert bwd < 1e-13 and err < 1e-10
     assert rel(s.get_gradient(), ograd) < 1e-12
+    # the step statistics and the trial cost of the ladder's step (the speculative path enqueued them behind a failed factor:
+    # they must be those of the repeated solve)
+    gn, sn, pred = s.step_stats()
+    trial = s.eval_step()
+    s.discard_step()
     # and with damping the same problem needs no ladder
     s.solve_augmented_equation(1e-3)
     assert s.info()["last_reg"] == 0.0
     s.close()
+    # the same failed pivot with three host waits per solve ("one_wait" 0: the flags are read before anything is enqueued behind
+    # the factorisation) and without the eager step evaluation: same ladder, same step, same statistics, same trial cost
+    for opts in ({"one_wait": 0}, {"eager_step_eval": 0}, {"one_wait": 0, "eager_step_eval": 0}):
+        s2 = GpuSchurComplementSolver(0)
+        for k, v in opts.items():
+            s2.with_option(k, v)
+        s2.initialize_structure(prob)
+        s2.set_parameters(d.poses, d.intr, d.points)
+        step2 = s2.solve_augmented_equation(lam)
+        assert s2.info()["last_reg"] == pytest.approx(reg, rel=1e-15), opts
+        assert np.array_equal(step2, step), (opts, rel(step2, step))
+        gn2, sn2, pred2 = s2.step_stats()
+        assert (gn2, sn2, pred2) == pytest.approx((gn, sn, pred), rel=1e-13), opts
+        assert s2.eval_step() == pytest.approx(trial, rel=1e-13), opts
+        s2.discard_step()
+        s2.close()

@@ -260,35 +260,9 @@ def test_schur_matvec_both_forms_vs_oracle(oracle, mode):
     s.close()
 
 
-@pytest.mark.parametrize("mode", ["selfcal", "ba"])
-def test_round5_switches_that_stayed_off_still_compute_the_same_system(oracle, mode):
-    """Options built and measured in round 5 and left off stay correct: the matrix-free operator's camera
-    half from camera-major projection records ("implicit_cam_records") gives S x to 1e-12 of the oracle's S, and the camera
-    reduce beside the pair kernel ("cam_beside_pairs") / the landmark bundles assemble the same S and solve to the same step."""
-    d = pkg.synthetic.make_problem(30, 1500, 3, 7, config_id=80)
-    prob, base = gpu_solver(d, mode)
-    o = oracle_problem(oracle, d, prob, mode)
-    o.linearize()
-    _, _, oS, _ = o.solve_augmented(1e-2, 0, want_schur=True)
-    x = np.random.default_rng(0).normal(size=prob.layout.cam_dof)
-    ref_step = base.solve_augmented_equation(1e-2).copy()
-    base.close()
-    _, s = gpu_solver(d, mode, options={"implicit_cam_records": 1})
-    ye, yi = s.schur_matvec(1e-2, x)
-    assert rel(ye, oS @ x) < 1e-12 and rel(yi, oS @ x) < 1e-12
-    s.close()
-    for opts in ({"cam_beside_pairs": 1}, {"landmark_bundles": 1}):
-        _, s = gpu_solver(d, mode, options=opts)
-        ye, _ = s.schur_matvec(1e-2, x)
-        assert rel(ye, oS @ x) < 1e-12, opts
-        step = s.solve_augmented_equation(1e-2)
-        assert rel(step, ref_step) < 1e-10, (opts, rel(step, ref_step))
-        s.close()
-
-
 def test_full_size_explicit_and_matrix_free_schur_agree():
     """BASELINE configs[3]/[4] headline shape at FULL size (final-13682: 29 M observations, 1.2e8 camera-pair
-    blocks): S x through the tiles built by k_cam_reduce + k_schur_rows equals S x through the matrix-free
+    blocks): S x through the tiles built by k_cam_reduce + k_schur_pairs_r equals S x through the matrix-free
     operator -- two independent code paths over all observations -- and S is symmetric positive definite on
     the probes (x.Sy == y.Sx, x.Sx > 0)."""
     d = pkg.synthetic.make_named("final-13682")
@@ -375,7 +349,7 @@ def test_ragged_landmarks(oracle, mode):
     landmarks use the off-diagonal scatter tasks), mixed in one problem."""
     n_cam = 320
     rng = np.random.default_rng(9)
-    # range(300): more partners than one k_schur_rows batch (256) and more neighbours than one LDS
+    # range(300): more partners than one batch of the first row kernels (256) and more neighbours than one LDS
     # chunk (112 cameras at 9 DOF) -> split batches and several row tasks per camera
     lists = [[], [3], [5, 5, 9], list(range(64)), list(range(65)), list(range(40, 169)), list(range(200)),
              [7, 8, 7, 8, 100], list(range(300)), [319, 0, 319]]
@@ -402,13 +376,12 @@ def test_ragged_landmarks(oracle, mode):
 
 
 @pytest.mark.parametrize("mode", ["selfcal", "ba"])
-def test_row_and_atomic_schur_forms_agree(mode):
-    """The implementations of the Schur reduction that are left after round 4 -- the sorted pair list in its queued layout
-    (4, the default with nine columns per camera: every lane group owns a block), in its first layout (3: seven groups share a
-    block and fold; what six-column cameras use) and the LDS row form with one lane per observation (2, the A/B) -- build the same S, g_red and gradient, also
-    on landmarks with more than 64 partners per observation (split entries), more neighbours than one LDS chunk, and camera
-    pairs with more common landmarks than one chunk of the pair list.  (The fused pair kernels, the one-lane-per-pair row
-    form and the global-atomics form of rounds 1-3 are deleted; their switch values are refused.)"""
+def test_the_two_layouts_of_the_pair_list_agree(mode):
+    """The two layouts of the sorted pair list -- queued (4, the default with nine columns per camera: every lane group owns a
+    block) and the first one (3: seven groups share a running block and fold; what six-column cameras run, where asking for 4
+    arrives at 3) -- build the same S, g_red and gradient, also on landmarks with more than 64 partners per observation, and
+    camera pairs with more common landmarks than one chunk of the pair list.  (The fused pair kernels, the LDS row forms and
+    the global-atomics form of rounds 1-3 are deleted; their switch values are refused.)"""
     rng = np.random.default_rng(5)
     base = pkg.synthetic.make_problem(150, 6000, 3, 9, config_id=61)
     lists = [sorted(rng.choice(150, size=int(k), replace=False).tolist()) for k in rng.integers(2, 9, size=500)]
@@ -421,18 +394,19 @@ def test_row_and_atomic_schur_forms_agree(mode):
     heavy = _custom(20, len(heavy_lists), heavy_lists, seed=8)
     for d in (base, wide, heavy):
         out = []
-        for rows in (4, 3, 2):
+        for form in (4, 3):
             ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
             prob = Problem.bundle_adjustment(d, ot, 1.0)
-            s = GpuSchurComplementSolver(0).with_option("schur_rows", rows).initialize_structure(prob)
+            s = GpuSchurComplementSolver(0).with_option("schur_form", form).initialize_structure(prob)
             s.set_parameters(d.poses, d.intr, d.points)
             step = s.solve_augmented_equation(1e-3)
             S, gred = s.get_schur()
             out.append((S, gred, s.get_gradient(), step))
             s.close()
-        for k in (1, 2):
-            assert rel(out[0][0], out[k][0]) < 1e-13 and rel(out[0][1], out[k][1]) < 1e-12
-            assert rel(out[0][2], out[k][2]) < 1e-13
+        assert rel(out[0][0], out[1][0]) < 1e-13 and rel(out[0][1], out[1][1]) < 1e-12
+        assert rel(out[0][2], out[1][2]) < 1e-13
+    with pytest.raises(Exception):
+        GpuSchurComplementSolver(0).with_option("schur_form", 2).initialize_structure(prob)   # the LDS row form is gone
 
 
 @pytest.mark.parametrize("mode", ["selfcal", "ba"])
@@ -804,33 +778,28 @@ def test_get_hessian_matches_jtj_of_the_exported_blocks(mode):
 
 @pytest.mark.parametrize("mode", ["selfcal", "ba"])
 def test_record_form_of_the_back_substitution(oracle, mode):
-    """k_back_substitute<.., REC>: the landmark steps from the projection records k_landmark_reduce wrote for the same
-    linearisation ("rec_backsub", default on) against the form that linearises every observation again; explicit and
-    matrix-free Schur variants (the matrix-free operator's landmark half is the same kernel).  The two forms differ in
-    the rounding of J (1e-16 per entry); the landmark step is well conditioned given the camera step."""
+    """k_back_substitute<.., REC>: the landmark steps come from the projection records k_landmark_reduce wrote for the same
+    linearisation; explicit and matrix-free Schur variants (the matrix-free operator's landmark half is the same kernel).
+    The records must be those of the NEW parameters after a committed step: the same solve on a fresh handle at these
+    parameters (stale records would be off by ~1e-3); the step itself is held to the oracle by the parity cases above."""
     d = pkg.synthetic.make_problem(14, 900, 3, 8, config_id=33)
     for variant in (SchurVariant.Sparse, SchurVariant.Iterative):
-        steps = {}
-        for rec in (0, 1):
-            ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
-            prob = Problem.bundle_adjustment(d, ot, 1.0)
-            s = GpuSchurComplementSolver(0).with_variant(variant).with_option("rec_backsub", rec)
-            s.initialize_structure(prob)
-            s.set_parameters(d.poses, d.intr, d.points)
-            steps[rec] = s.solve_augmented_equation(1e-3)
-            s.eval_step(); s.commit_step()
-            # the records must be those of the NEW parameters: the same solve on a fresh handle at these parameters
-            after = s.solve_augmented_equation(1e-3)
-            params = s.get_parameters()
-            s.close()
-            s = GpuSchurComplementSolver(0).with_variant(variant).with_option("rec_backsub", rec)
-            s.initialize_structure(prob)
-            s.set_parameters(*params)
-            # (not bitwise: blocks of S shared by several waves are summed with atomics; stale records would be off by ~1e-3)
-            assert rel(after, s.solve_augmented_equation(1e-3)) < 1e-7
-            s.close()
-        tol = 1e-11 if variant == SchurVariant.Sparse else 1e-6       # (PCG: the operator's rounding moves the iterates)
-        assert rel(steps[1], steps[0]) < tol, (variant, rel(steps[1], steps[0]))
+        ot = OptimizationType.SelfCalibration if mode == "selfcal" else OptimizationType.BundleAdjustment
+        prob = Problem.bundle_adjustment(d, ot, 1.0)
+        s = GpuSchurComplementSolver(0).with_variant(variant)
+        s.initialize_structure(prob)
+        s.set_parameters(d.poses, d.intr, d.points)
+        s.solve_augmented_equation(1e-3)
+        s.eval_step(); s.commit_step()
+        after = s.solve_augmented_equation(1e-3)
+        params = s.get_parameters()
+        s.close()
+        s = GpuSchurComplementSolver(0).with_variant(variant)
+        s.initialize_structure(prob)
+        s.set_parameters(*params)
+        # (not bitwise: blocks of S shared by several waves are summed with atomics)
+        assert rel(after, s.solve_augmented_equation(1e-3)) < 1e-7
+        s.close()
 
 
 def test_schur_assembly_is_reproducible_bit_for_bit():
@@ -895,27 +864,78 @@ def test_device_built_pair_list_is_the_host_list():
     assert rh.shape == rd.shape and np.array_equal(real_h, real_d)
     assert np.array_equal(rh[real_h], rd[real_d])          # also with duplicated cameras, split blocks and pieces
     assert rel(Sd, Sh) < 1e-13 and rel(gd, gh) < 1e-13      # (blocks that add atomically: the order of the adds is not fixed)
-    # six-column cameras (BundleAdjustment mode): sixteen queues of four pairs, the same builder pair
-    def build6(dev):
-        prob = Problem.bundle_adjustment(d, OptimizationType.BundleAdjustment, 1.0)
-        s = GpuSchurComplementSolver(0).with_option("device_pair_list", dev).with_option("pairs_queued6", 1)
-        s.initialize_structure(prob)
-        s.set_parameters(d.poses, d.intr, d.points)
-        assert s.info()["schur_form"] == 4
-        recs = s.pair_records()
-        s.assemble(1e-3)
-        S, _ = s.get_schur()
-        s.close()
-        return recs, S
-    (r6h, S6h), (r6d, S6d) = build6(0), build6(1)
-    assert r6h.shape == r6d.shape and np.array_equal(r6h[:, 0] != PAD, r6d[:, 0] != PAD)
-    assert np.array_equal(r6h[r6h[:, 0] != PAD], r6d[r6d[:, 0] != PAD])
-    # ... and the queued kernel for six-column cameras (an option: measured slower than form 3) gives form 3's S
+    # six-column cameras (BundleAdjustment mode) run form 3 whatever is asked
     prob = Problem.bundle_adjustment(d, OptimizationType.BundleAdjustment, 1.0)
-    s3 = GpuSchurComplementSolver(0)
+    s3 = GpuSchurComplementSolver(0).with_option("schur_form", 4)
     s3.initialize_structure(prob); s3.set_parameters(d.poses, d.intr, d.points)
     assert s3.info()["schur_form"] == 3
-    s3.assemble(1e-3)
-    S3, _ = s3.get_schur()
     s3.close()
-    assert rel(S6d, S3) < 1e-13 and rel(S6h, S3) < 1e-13
+
+
+# ---- round 6: decisions of a handle's life that must not stick, and state a new solve must void ---------------------------------
+def test_a_second_structure_on_one_handle_is_decided_afresh(oracle):
+    """the automatic matrix-free selection of one set_structure must not survive into the next one on the same
+    handle.  Structure A (every landmark seen by cameras from all over: S dense at tile granularity) is refused at a lowered
+    plan limit and answered matrix-free; structure B (the same counts, banded) fits: variant 0 is the Cholesky again -- S exists,
+    the step is the oracle's -- and back to A the handle is matrix-free again."""
+    n_cam, n_pt, k = 160, 1200, 4
+    rng = np.random.default_rng(3)
+    dense = [sorted(rng.choice(n_cam, size=k, replace=False).tolist()) for _ in range(n_pt)]
+    banded = [sorted(((l * n_cam) // n_pt + rng.choice(12, size=k, replace=False)) % n_cam) for l in range(n_pt)]
+    dA, dB = _custom(n_cam, n_pt, dense, seed=11), _custom(n_cam, n_pt, banded, seed=11)
+    assert dA.n_obs == dB.n_obs
+    probA = Problem.bundle_adjustment(dA, OptimizationType.SelfCalibration, 1.0)
+    probB = Problem.bundle_adjustment(dB, OptimizationType.SelfCalibration, 1.0)
+    s = GpuSchurComplementSolver(0).with_option("max_tile_updates", 60).with_option("variant_cost_percent", 0)
+    s.initialize_structure(probA)
+    assert s.variant_info()["variant_used"] == "Implicit" and s.variant_info()["variant_choice"] == "matrix-free: plan refused"
+    s.set_parameters(dA.poses, dA.intr, dA.points)
+    s.solve_augmented_equation(1e-3)
+    assert s.info()["pcg_iterations"] > 0
+    s.reinitialize_structure(probB)
+    vi = s.variant_info()
+    assert vi["variant_used"] == "Sparse" and vi["reason"] == "" and vi["variant_choice"] == "direct", vi
+    s.set_parameters(dB.poses, dB.intr, dB.points)
+    step = s.solve_augmented_equation(1e4)
+    assert s.info()["pcg_iterations"] == 0 and s.info()["tiles"] > s.info()["tile_rows"]
+    o = oracle_problem(oracle, dB, probB, "selfcal")
+    o.linearize()
+    ostep, _, oS, _ = o.solve_augmented(1e4, 0, want_schur=True)
+    assert rel(step, ostep) < 1e-10
+    S, _ = s.get_schur()
+    assert rel(S, oS) < 1e-12
+    s.reinitialize_structure(probA)
+    assert s.variant_info()["variant_used"] == "Implicit"
+    s.close()
+
+
+def test_a_new_solve_voids_the_evaluated_trial_point():
+    """with the eager step evaluation every solve overwrites the trial parameter set; a commit_step that follows
+    eval_step -> solve_augmented must not silently take the NEW solve's trial point: it is refused until that step is evaluated."""
+    d = pkg.synthetic.make_problem(20, 800, 3, 7, config_id=12)
+    _, s = gpu_solver(d, "selfcal")
+    s.solve_augmented_equation(1e-3)
+    s.eval_step()
+    s.solve_augmented_equation(1e-1)
+    with pytest.raises(pkg.capi.LinAlgError):
+        s.commit_step()
+    c = s.eval_step()          # the step of the second solve, evaluated: now it can be committed
+    s.commit_step()
+    assert s.compute_cost() == pytest.approx(c, rel=1e-13)
+    s.close()
+
+
+def test_eager_step_evaluation_does_not_change_the_lm_history():
+    """ "eager_step_eval" 0 (statistics, trial point and trial cost on request, three device round trips per LM iteration) against
+    the default (enqueued behind the back-substitution, read at the solve's wait): the same LM history, cost for cost."""
+    from apex_solver_amd.solver import LevenbergMarquardt, LevenbergMarquardtConfig
+    d = pkg.synthetic.make_problem(30, 1500, 3, 7, config_id=14)
+    hist = []
+    for eager in (1, 0):
+        prob, s = gpu_solver(d, "selfcal", options={"eager_step_eval": eager})
+        res = LevenbergMarquardt.with_config(LevenbergMarquardtConfig().with_max_iterations(6)).optimize(prob, solver=s)
+        hist.append((res.iterations, res.initial_cost, res.final_cost, np.asarray(res.history, dtype=float)))
+        s.close()
+    assert hist[0][0] == hist[1][0] and hist[0][1] == hist[1][1] and hist[0][2] == pytest.approx(hist[1][2], rel=1e-12), hist
+    assert hist[0][3].shape == hist[1][3].shape and hist[0][3].size > 0
+    assert np.allclose(hist[0][3], hist[1][3], rtol=1e-11, atol=0.0), np.abs(hist[0][3] - hist[1][3]).max()

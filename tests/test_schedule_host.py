@@ -74,28 +74,9 @@ def test_schedule_switches_are_race_free(name, p):
             for split_u1 in (0, 1, 4):
                 for gate in (0, 2):
                     for flow in (0, -1, 3):
-                        for psplit in (0, 1):   # (1: every level with a critical and a non-critical panel tile is split)
-                            r = chk(p, two_side=two_side, overlap=overlap, split_u1=split_u1, flood_gate=gate, factor_flow=flow, factor_flow_rows=64,
-                                    panel_split=psplit)
-                            assert r["violations"] == 0, (name, two_side, overlap, split_u1, gate, flow, psplit, r)
+                        r = chk(p, two_side=two_side, overlap=overlap, split_u1=split_u1, flood_gate=gate, factor_flow=flow, factor_flow_rows=64)
+                        assert r["violations"] == 0, (name, two_side, overlap, split_u1, gate, flow, r)
 
-
-def test_panel_lookahead_splits_the_panel_launch_and_its_waits_carry_the_order():
-    """Round 5: the panel solves of a level in two launches (rows of the next level first, the rest on the third stream).  The
-    split adds launches and waits; the sequence stays race free, and some of the added waits are load-bearing."""
-    nt = 40
-    p = lower(nt, [(i, j) for i in range(nt) for j in range(max(0, i - 5), i)])
-    kw = dict(two_side=2, overlap=1, split_u1=1, flood_gate=0, factor_flow=0)
-    off = chk(p, panel_split=0, **kw)
-    on = chk(p, panel_split=1, **kw)
-    assert off["violations"] == 0 and on["violations"] == 0, (off, on)
-    assert on["launches"] > off["launches"] and on["waits"] > off["waits"], (off, on)
-    needed = 0
-    for k in range(on["waits"]):
-        r = chk(p, panel_split=1, drop_wait=k, **kw)
-        needed += r["violations"] > 0
-    needed_off = sum(chk(p, panel_split=0, drop_wait=k, **kw)["violations"] > 0 for k in range(off["waits"]))
-    assert needed > needed_off, (needed, needed_off)
 
 
 def test_distributed_cuts_are_race_free_in_both_phases():

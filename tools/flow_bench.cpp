@@ -16,8 +16,6 @@ using namespace apex;
 
 int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 18, reps = argc > 2 ? atoi(argv[2]) : 5;
-    const bool tile_units = argc > 3 ? atoi(argv[3]) != 0 : true;   // whole-tile update units off the chain (round 5)
-    const bool dyn = argc > 4 ? atoi(argv[4]) != 0 : true;          // dynamic scheduling of the units (round 5)
     const size_t te = (size_t)kNB * kNB;
     std::vector<uint8_t> present((size_t)T * T, 0);
     for (int i = 0; i < T; ++i) for (int j = 0; j <= i; ++j) present[(size_t)i * T + j] = 1;
@@ -29,8 +27,6 @@ int main(int argc, char** argv) {
     for (int mode = 0; mode < 2; ++mode) {   // 0: level launches, 1: dataflow
         TilePlan tp;
         tp.set_factor_flow(mode ? 64 : 0, 1000);
-        tp.set_flow_tile_units(tile_units);
-        tp.set_flow_dyn(dyn);
         const std::string err = tp.build(T, present, st);
         if (!err.empty()) { printf("build: %s\n", err.c_str()); return 1; }
         for (int I = 0; I < T; ++I)

@@ -23,7 +23,7 @@ def main():
     d = pkg.synthetic.make_sphere(rings, per)
     prob = PoseGraphProblem.pose_graph(d)
     s = GpuSparseCholeskySolver().with_option("nested_dissection", nd)
-    for opt in ("update_overlap", "potrf_lookahead", "fused_forward"):
+    for opt in ("update_overlap", "factor_flow", "two_side"):
         if "--" + opt in sys.argv:
             s.with_option(opt, int(sys.argv[sys.argv.index("--" + opt) + 1]))
     t0 = time.perf_counter(); s.initialize_structure(prob); setup = time.perf_counter() - t0

@@ -1,4 +1,4 @@
-// Latency of the diagonal-tile Cholesky + inverse (k_potrf_inv_la) on one tile and on a batch, with wall-clock
+// Latency of the diagonal-tile Cholesky + inverse (k_potrf_inv_mf) on one tile and on a batch, with wall-clock
 // stamps of workgroup 0 at the phase boundaries (P1 | P2 | P3 per 16-pivot block step).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAPEX_POTRF_TRACE -I apex-solver_amd/csrc tools/potrf_bench.hip -o tools/potrf_bench
 #include "../apex-solver_amd/csrc/chol_kernels.hip"
@@ -34,8 +34,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nb; ++i) t[i] = {A + i * te, Li + i * te, i};
     hipMemcpy(d, t.data(), nb * sizeof(PotrfTask), hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode : {8, 9, 12}) {   // round-3 look-ahead kernel, matrix-pipe form with 8 and with 12 waves
-        set_potrf_lookahead(mode);
+    for (int mode : {12}) {   // the matrix-pipe kernel, twelve waves (the vector-unit kernels of rounds 1-3 are gone: profiles/r04_potrf_*)
         for (int n : {1, 64}) {
             float best = 1e9f;
             for (int rep = 0; rep < 6; ++rep) {

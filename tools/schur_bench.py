@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of the Schur-reduction forms on one workload (stage timers = HIP events on the solver's stream).
-  python tools/schur_bench.py [--workload final-13682] [--scale 1.0] [--forms 3,2] [--iters 10] [--mode selfcal]
+  python tools/schur_bench.py [--workload final-13682] [--scale 1.0] [--forms 4,3] [--iters 10] [--mode selfcal]
 Prints one line per form: ms per assembly stage, set-up seconds by phase."""
 import argparse
 import os
@@ -9,7 +9,6 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("APEX_SYNTH_CACHE", "/tmp/apex_synth_cache")
-os.environ.setdefault("APEX_ALLOW_ABLATION", "1")   # "pairs_ablation" (wrong results, timing only) is refused without it
 
 import numpy as np  # noqa: E402
 
@@ -21,11 +20,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="final-13682")
     ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--forms", default="3,2")
+    ap.add_argument("--forms", default="4,3")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--mode", default="selfcal")
     ap.add_argument("--task-slots", default="0", help="comma list of pair_task_slots values to try with form 3")
-    ap.add_argument("--abl", default="0", help="comma list of ablation bit sets for the pair kernel (timing only)")
     ap.add_argument("--check", action="store_true", help="compare S x of every form with the first one's")
     a = ap.parse_args()
     t = time.time()
@@ -37,30 +35,19 @@ def main():
     x = np.random.default_rng(0).normal(size=prob.layout.cam_dof)
     runs = [(int(f), int(ts), None) for f in a.forms.split(",") for ts in (a.task_slots.split(",") if int(f) in (3, 4) else ["0"])]
     for form, ts, pv in runs:
-        s = GpuSchurComplementSolver(0).with_option("schur_rows", form).with_option("pair_task_slots", ts)
+        s = GpuSchurComplementSolver(0).with_option("schur_form", form).with_option("pair_task_slots", ts)
         t = time.time()
         s.initialize_structure(prob)
         s.set_parameters(d.poses, d.intr, d.points)
         setup = time.time() - t
         for _ in range(2):
             s.assemble(1e-3)
-        for abl in [int(x) for x in a.abl.split(",")]:
-            s.set_option("pairs_ablation", abl)
+        s.enable_stage_timing(True); s.reset_stage_times()
+        for _ in range(a.iters):
             s.assemble(1e-3)
-            s.enable_stage_timing(True); s.reset_stage_times()
-            for _ in range(a.iters):
-                s.assemble(1e-3)
-            st = s.stage_times()
-            line = {k: round(v[0] / max(v[1], 1), 3) for k, v in st.items() if v[1] > 0}
-            print(f"form {form} variant {pv} task_slots {ts} abl {abl}: {line}", flush=True)
-            if abl & 64:
-                import ctypes as C
-                out = (C.c_int64 * 8)()
-                pkg.capi.load().apexgpu_debug_pair_phases(C.byref(out), 1)
-                n = max(out[5], 1)
-                print("   cycles per chunk and wave: wait %.0f  unstage %.0f  jacobians+stores %.0f  issue %.0f  products+flush %.0f  (flush %.0f per flush, %.2f flushes per chunk)  total %.0f" %
-                      (out[0] / n, out[1] / n, out[2] / n, out[3] / n, out[4] / n, out[6] / max(out[7], 1), out[7] / n, sum(out[:5]) / n), flush=True)
-        s.set_option("pairs_ablation", 0)
+        st = s.stage_times()
+        line = {k: round(v[0] / max(v[1], 1), 3) for k, v in st.items() if v[1] > 0}
+        print(f"form {form} task_slots {ts}: {line}", flush=True)
         print(f"   setup {setup:.2f} s  {s.setup_times()}", flush=True)
         if a.check:
             y, _ = s.schur_matvec(1e-3, x, implicit=False)
