@@ -37,6 +37,12 @@ struct BAView {
     // (wg_cam_list[w][0 .. wg_cam_n[w]), first-appearance order) and gives every observation its camera's slot in that list
     // (o_slot[i], 255 = not staged: the list is capped at kCamStageCap).  The workgroup copies those cameras to LDS once
     // -- a few hundred line accesses instead of ten scattered 16-byte loads per observation and lane.
+    // Landmark sharding (round 6): a rank's landmarks are ONE internal range, and the landmark-major kernels (k_landmark_reduce,
+    // k_back_substitute and its matrix-free form) are launched over the workgroups that cover it -- lm_wgn of them from workgroup
+    // lm_wg0 on (0, 0: every landmark).  Until round 5 they ran over all n_pt landmarks on every rank (a record, g_l and a step
+    // for 4.4 M landmarks without local observations: 0.39 of 0.09 + 0.30 ms at eight ranks).  The other ranks' entries of hinv,
+    // g_l, dl stay zero.
+    int lm_wg0 = 0, lm_wgn = 0;
     const uint8_t* o_slot;        // [n_obs]
     const uint8_t* wg_cam_n;      // [workgroups]
     const uint32_t* wg_cam_list;  // [workgroups][kCamStageCap]

@@ -98,11 +98,16 @@ __global__ __launch_bounds__(kCamThreads, 2) void k_cam_reduce(BAView v, TileMap
     // iteration starts at once instead of after a round trip for its address (affordable since the self term goes through the
     // 2 x 2 matrix P: at 256 VGPRs the three extra live registers spilled, 1.14 -> 1.29 ms)
     const int k_first = max(min(b + (int)threadIdx.x, e - 1), 0);
-    uint32_t l_next = v.co_pt[k_first];
-    double2 uv_next = v.co_uv[k_first];
+    uint32_t l_next = 0;
+    double2 uv_next = make_double2(0.0, 0.0);
     double rec_next[kLmStride];
-    load_lm_record(hinv, l_next, rec_next);
-    if (k_first + kCamThreads < e) l_next = v.co_pt[k_first + kCamThreads];
+    if (b < e) {   // (wave-uniform.  A camera without observations on this rank -- seven in eight on a tree-sharded rank of eight --
+                   // only writes its zeros / lambda: no dependent index -> record round trips)
+        l_next = v.co_pt[k_first];
+        uv_next = v.co_uv[k_first];
+        load_lm_record(hinv, l_next, rec_next);
+        if (k_first + kCamThreads < e) l_next = v.co_pt[k_first + kCamThreads];
+    }
     for (int k = b + (int)threadIdx.x; k < e; k += kCamThreads) {
         const double2 uv = uv_next;
         double rec[kLmStride];
@@ -207,8 +212,9 @@ struct CamStager {
     int n;
     __device__ __forceinline__ void issue_indices(const BAView& v) {
         // (the list is zero-padded to kCamStageCap entries: no need to wait for n before reading it)
-        n = v.o_slot ? v.wg_cam_n[blockIdx.x] : 0;
-        const uint32_t* __restrict__ list = v.wg_cam_list + (size_t)blockIdx.x * kCamStageCap;
+        const size_t wg = (size_t)blockIdx.x + (size_t)v.lm_wg0;   // (the landmark-major kernels run over the rank's own workgroups: BAView::lm_wg0)
+        n = v.o_slot ? v.wg_cam_n[wg] : 0;
+        const uint32_t* __restrict__ list = v.wg_cam_list + wg * kCamStageCap;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) ci[j] = list[min(((int)threadIdx.x + NT * j) / IT, kCamStageCap - 1)];
     }
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(kLmWg * kLmLanes) void k_landmark_reduce(BAView v, 
     static_assert(kLmWg * kLmLanes <= 1024 && kLmWg * kBsLanes <= 1024, "a workgroup is kLmWg landmarks (the camera staging lists are built per kLmWg landmarks)");
     __shared__ double sCam[kCamStageCap * kCamQStride];
     const int g = threadIdx.x & (kLmLanes - 1);
-    const int64_t l = (int64_t)blockIdx.x * kLmWg + threadIdx.x / kLmLanes;
+    const int64_t l = ((int64_t)blockIdx.x + v.lm_wg0) * kLmWg + threadIdx.x / kLmLanes;
     const bool active = l < v.n_pt;
     double h[6] = {0, 0, 0, 0, 0, 0}, gl[3] = {0, 0, 0}, pw[3] = {0, 0, 0};
     // two round trips to memory before the arithmetic starts: (list, pt_ptr), then (cameras, point, first observation)
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(kLmWg * LANES) __attribute__((amdgpu_waves_per_eu(4
     constexpr int STR = CAMD + DC + ((CAMD + DC) & 1);   // camera | its step, 16-byte pieces
     __shared__ double sCam[kCamStageCap * STR];
     const int g = threadIdx.x & (LANES - 1);
-    const int64_t l = (int64_t)blockIdx.x * kLmWg + threadIdx.x / LANES;
+    const int64_t l = ((int64_t)blockIdx.x + v.lm_wg0) * kLmWg + threadIdx.x / LANES;
     const bool active = l < v.n_pt;
     double acc[3] = {0, 0, 0};
     CamStager<STR, DC, CAMD, kLmWg * LANES> stager;   // (see k_landmark_reduce: the staging chain and the landmark's own chain interleaved)
@@ -890,6 +896,8 @@ __global__ __launch_bounds__(256) void k_export_linearization(BAView v, const in
 // ------------------------------------------------------------------------------------------
 // launchers (the only symbols the host code sees)
 // ------------------------------------------------------------------------------------------
+// workgroups of a landmark-major launch: the rank's own landmark range (BAView::lm_wg0 / lm_wgn; every landmark on a single rank)
+static inline int lm_grid(const BAView& v) { return v.lm_wgn > 0 ? v.lm_wgn : (int)((v.n_pt + kLmWg - 1) / kLmWg); }
 static inline int grid_for(int64_t n, int per_block, int cap) {
     int64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -916,7 +924,7 @@ void launch_cam_reduce(int dc, const BAView& v, const TileMap& tm, const int* ca
 void launch_landmark_reduce(int dc, const BAView& v, double lambda, double* hinv, double* g_l, int* err_flag, double* lmu,
                             hipStream_t s, double* orec) {
     if (v.n_pt == 0) return;
-    const int grid = grid_for(v.n_pt, kLmWg, 0);
+    const int grid = lm_grid(v);
     if (dc == 9) hipLaunchKernelGGL(k_landmark_reduce<9>, dim3(grid), dim3(kLmWg * kLmLanes), 0, s, v, lambda, hinv, g_l, err_flag, lmu, orec);
     else hipLaunchKernelGGL(k_landmark_reduce<6>, dim3(grid), dim3(kLmWg * kLmLanes), 0, s, v, lambda, hinv, g_l, err_flag, lmu, orec);
 }
@@ -931,7 +939,7 @@ static bool rec_form_ok(int dc, const BAView& v, const double* orec) { return or
 void launch_back_substitute(int dc, const BAView& v, const double* hinv, const double* g_l, const double* dcam,
                             double* dl, hipStream_t s, const double* orec, const uint8_t* fix_pt, double* pts_trial) {
     if (v.n_pt == 0) return;
-    const int grid = grid_for(v.n_pt, kLmWg, 0);
+    const int grid = lm_grid(v);
     if (rec_form_ok(dc, v, orec)) {
         if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, false, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, orec, fix_pt, pts_trial);
         else hipLaunchKernelGGL((k_back_substitute<6, false, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, g_l, dcam, dl, orec, fix_pt, pts_trial);
@@ -1020,7 +1028,7 @@ void launch_gather_u32(int64_t n, const int* idx, const uint32_t* src, uint32_t*
 void launch_implicit_matvec(int dc, const BAView& v, const int* cam_ptr, const double* hinv, double* lmu, const double* x,
                             double lambda, double* y, hipStream_t s, const double* orec) {
     if (v.n_pt > 0) {
-        const int grid = (int)((v.n_pt + kLmWg - 1) / kLmWg);
+        const int grid = lm_grid(v);
         if (rec_form_ok(dc, v, orec)) {
             if (dc == 9) hipLaunchKernelGGL((k_back_substitute<9, true, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, orec, nullptr, nullptr);
             else hipLaunchKernelGGL((k_back_substitute<6, true, true>), dim3(grid), dim3(kLmWg * kBsLanes), 0, s, v, hinv, nullptr, x, lmu, orec, nullptr, nullptr);

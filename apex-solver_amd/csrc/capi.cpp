@@ -287,7 +287,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     // hold are rejected once the structure exists: flipping them later would launch kernels over lists that were never built.
     static const char* const structural[] = {"schur_form", "hubs_last", "dist_factor", "tree_sharding", "dist_selftest", "nested_dissection", "update_overlap",
                                              "split_u1", "flood_gate", "two_side", "factor_flow", "factor_flow_rows", "device_pair_list", "matrix_free_only",
-                                             "auto_variant", "variant_cost_percent", "max_tile_updates"};
+                                             "auto_variant", "variant_cost_permille", "max_tile_updates"};
     if (h->s->has_structure())
         for (const char* k : structural)
             if (n == k) return APEXGPU_ERR_INVALID_STATE;
@@ -303,7 +303,7 @@ int apexgpu_set_option(apexgpu_solver* h, const char* name, int value) {
     else if (n == "two_side") h->s->set_two_side(value);
     else if (n == "matrix_free_only") h->s->set_matrix_free_only(value != 0);
     else if (n == "auto_variant") h->s->set_auto_variant(value != 0);
-    else if (n == "variant_cost_percent") h->s->set_variant_cost_percent(value);
+    else if (n == "variant_cost_permille") h->s->set_variant_cost_permille(value);
     else if (n == "device_pair_list") h->s->set_device_pair_recs(value != 0);
     else if (n == "eager_step_eval") h->s->set_eager_step_eval(value != 0);
     else if (n == "one_wait") h->s->set_one_wait(value != 0);

@@ -613,7 +613,11 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
     if (lane < UV) Z[lane] = 0.0;
     int g, sub;
     pairs_lane_map<DC>(lane, g, sub);
-    if (QL) { g = lane == 63 ? 0 : lane / 9; sub = lane == 63 ? 0 : lane - 9 * g; }   // (lane 63 shadows lane 0 and never stores)
+    // (lane 63 has no sub-block of its own: it shadows lane 62 -- queue 6, sub-block 8 -- and never stores.  Lane 62, not lane 0
+    // as until round 5: a shadow of lane 0 read row 7t of U / V from inside the lane group that reads rows 4 + 7t .. 6 + 7t --
+    // a different address on busy banks, one conflict cycle on every ds_read_b128 of the product phase, 54 of a chunk's 270 read
+    // cycles (tools/lds_conflict_sim.py); beside lane 62 it reads lane 62's address and rides on the broadcast)
+    if (QL) { g = lane == 63 ? 6 : lane / 9; sub = lane == 63 ? 8 : lane - 9 * g; }
     const int bi = sub / NB3, bj = sub - bi * NB3;
     const bool worker = g < NG;
     double acc[NACC];
@@ -946,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void k_schur_pairs_r(BAView v, double* __re
                 const bool mine = (ck_cur.mask >> g) & 1u;
                 const bool keep = mine && (bd_cur.flags & kPairQCarry) != 0;
                 double* T = U + 81 * g;
-                if (mine && !keep && lane < 63) {   // (lane 63 shadows lane 0 except in a join: it must not write)
+                if (mine && !keep && lane < 63) {   // (lane 63 is a shadow: it must not write)
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
 #pragma unroll

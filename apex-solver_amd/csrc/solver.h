@@ -110,7 +110,7 @@ class Solver : public LmBackend {
     void set_device_pair_recs(bool on) { device_pair_recs_ = on; }   // before set_structure ("device_pair_list")
     int get_pair_records(uint32_t* recs4_out, int64_t cap_slots);     // tests: the pair records as they sit on the device
     void set_auto_variant(bool on) { auto_variant_ = on; }
-    void set_variant_cost_percent(int pct) { variant_cost_percent_ = pct < 0 ? 0 : pct; }   // before set_structure (see build_plan)
+    void set_variant_cost_permille(int pct) { variant_cost_permille_ = pct < 0 ? 0 : pct; }   // before set_structure (see build_plan)
     // [0] predicted ms per solve of the direct path (tile Cholesky + sweeps; 0: never evaluated -- "matrix_free_only"), [1] of the
     // matrix-free PCG at IterativeSchurSolver's cap, [2] what set_structure chose: 0 direct, 1 matrix-free by predicted cost,
     // 2 matrix-free because the plan was refused (size / memory), 3 matrix-free by the caller's option, [3] the cap behind [1]
@@ -127,7 +127,6 @@ class Solver : public LmBackend {
     bool has_structure() const { return have_structure_; }
     void set_nd(bool on, int leaf) { use_nd_ = on; if (leaf > 0) nd_leaf_ = leaf; }
     void set_hubs_last(bool on) { hubs_last_ = on; }
-    void set_pair_task_slots(int n) { pair_task_slots_ = n; }
     int n_hubs() const { return n_hubs_; }
     void set_dist_factor(bool on) { dist_factor_ = on; }   // before set_structure
     void set_tree_sharding(bool on) { tree_sharding_ = on; }  // before set_structure
@@ -237,7 +236,7 @@ class Solver : public LmBackend {
     hipEvent_t pcg_ev_[2] = {nullptr, nullptr};
     bool device_pair_recs_ = true;   // queued layout: the pair records are written by the device (k_build_pair_recs_q), not built on the host and copied
     bool auto_variant_ = true, auto_fallback_ = false;   // see set_auto_variant
-    int variant_cost_percent_ = 100, variant_choice_ = 0;
+    int variant_cost_permille_ = 1000, variant_choice_ = 0;
     double pred_direct_ms_ = 0.0, pred_mf_ms_ = 0.0;
     std::string fallback_reason_;
     bool orec_fresh_ = false;   // orec_ holds the records of the current parameters' last linearisation
@@ -263,7 +262,6 @@ class Solver : public LmBackend {
     int* flags_ = nullptr;                          // [0] landmark inversion error
     std::vector<int> cmap_, cinv_;   // external camera -> internal camera and back
     bool use_nd_ = true;
-    int pair_task_slots_ = 0;
     bool hubs_last_ = true;     // order cameras covisible with > max(16, 10 sqrt(n_cam)) others last (ba_structure.h)
     int n_hubs_ = 0, n_border_tiles_ = 1;
     int nd_leaf_ = 16;

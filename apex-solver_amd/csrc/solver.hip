@@ -115,6 +115,10 @@ BAView Solver::view(int which) const {
     v.pt_scale = scaled_ ? pt_scale_ : nullptr;
     v.lam_mask = tree_shard_ ? lam_mask_ : nullptr;
     v.o_slot = o_slot_; v.wg_cam_n = wg_cam_n_; v.wg_cam_list = wg_cam_list_;
+    if (world_ > 1 && lm_hi_ > lm_lo_) {   // the rank's own landmark range, in whole workgroups of kLmWg
+        v.lm_wg0 = (int)(lm_lo_ / kLmWg);
+        v.lm_wgn = (int)((lm_hi_ + kLmWg - 1) / kLmWg) - v.lm_wg0;
+    }
     return v;
 }
 
@@ -256,7 +260,7 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
     BaStructOptions so;
     so.dc = dc_; so.use_nd = use_nd_; so.nd_leaf = nd_leaf_; so.hubs_last = hubs_last_;
     so.rank = rank_; so.world = world_; so.dist_factor = dist_factor_; so.tree_sharding = tree_sharding_;
-    so.dist_selftest = dist_selftest_; so.schur_form = rows_form_; so.pair_task_slots = pair_task_slots_;
+    so.dist_selftest = dist_selftest_; so.schur_form = rows_form_;
     so.device_gathers = device_gathers_ && world_ == 1;
     std::unique_ptr<BaHostStructure> hs_owner(new BaHostStructure);
     BaHostStructure& hs = *hs_owner;
@@ -282,11 +286,11 @@ int Solver::set_structure(const uint32_t* cam_idx, const uint32_t* pt_idx, const
         // PCG costs at most its cap times one S p -- two passes over the observations, 160 bytes each at the 4.5 TB/s the two
         // kernels sustain (1.01 ms on final-13682, 0.45 ms on synthetic-10k: DESIGN section 5) -- whatever the structure; the tile
         // plan refuses to be built when its own prediction (TilePlan::predict_solve_ms) is above that.  Both numbers are host
-        // arithmetic on the replicated structure: every rank decides alike.  "variant_cost_percent" scales the matrix-free side
+        // arithmetic on the replicated structure: every rank decides alike.  "variant_cost_permille" scales the matrix-free side
         // (tests move the crossover onto small problems; 0: the rule is off).
-        pred_mf_ms_ = 500.0 * (160.0 * (double)n_obs_ / 4.5e12 * 1e3 + 0.02) * (double)variant_cost_percent_ / 100.0;
+        pred_mf_ms_ = 500.0 * (160.0 * (double)n_obs_ / 4.5e12 * 1e3 + 0.02) * (double)variant_cost_permille_ / 1000.0;
         pred_direct_ms_ = 0.0; variant_choice_ = matrix_free_only_ ? 3 : 0;
-        tp_.set_cost_limit_ms((auto_variant_ && !matrix_free_only_ && variant_cost_percent_ > 0) ? pred_mf_ms_ : 0.0);
+        tp_.set_cost_limit_ms((auto_variant_ && !matrix_free_only_ && variant_cost_permille_ > 0) ? pred_mf_ms_ : 0.0);
         std::string e = tp_.build(nt_, present_plan, stream_);
         if (!matrix_free_only_) pred_direct_ms_ = tp_.predicted_ms();
         // A structure whose direct factorisation is out of reach (a photo collection: S dense at tile granularity) is not an
@@ -896,6 +900,7 @@ int Solver::solve_augmented(double lambda, int variant, double* step_out, double
     HIP_TRY(hipSetDevice(device_));
     have_step_ = false;
     have_trial_ = false;   // (the eager step evaluation of this solve overwrites the trial parameter set: an earlier eval_step is void)
+    last_pcg_iters_ = 0;   // (the PCG variants set it: apexgpu_info[5] is about THIS solve)
     ++step_serial_;
     last_lambda_ = lambda;
     int pcg_max = cg_max_iter_;

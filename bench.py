@@ -130,9 +130,9 @@ def cpu_baseline_worker(workload, shape_scale, mode, dense_too=True, n_iter=2):
     stats = o.last_sparse_stats()
     out = {
         "value": ms, "unit": "ms per LM iter on the sample", "cores": cores, "kind": "port", "solve": "sparse",
-        "sample": f"{d.name}: {d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations, "
-                  f"{n_iter} LM iteration(s) of oracle/ba_oracle.c (linearise + explicit Schur into a dense S + sparsify at 1e-12 + "
-                  f"envelope Cholesky in reverse Cuthill-McKee order + trial cost)",
+        "sample": f"{d.name}: {d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations; SINGLE-THREADED envelope Cholesky "
+                  f"(the solve is {n_iter} x serial: only the linearisation uses the cores); {n_iter} LM iteration(s) of oracle/ba_oracle.c "
+                  f"(linearise + explicit Schur into a dense S + sparsify at 1e-12 + envelope Cholesky in reverse Cuthill-McKee order + trial cost)",
         "obs_per_s": d.n_obs / (ms * 1e-3),
         "solve_ms": ms_solve,   # H = J^T J, Schur complement, factorisation, back-substitution
         "sparse_s": dict(stats, n=o.cam_dof),
@@ -185,6 +185,9 @@ def cpu_baseline(args, shape_scale, mode, full_size):
     out["one_thread"] = {k: v for k, v in run(1, third, False, 1 if not full_size else 2).items() if k in keep}
     if cores > 32:
         out["all_cores"] = {k: v for k, v in run(cores, shape_scale / 3.0 if not full_size else shape_scale / 6.0).items() if k in keep}
+    if not full_size and out["one_thread"].get("value"):   # (same sample: comparable)
+        out["thread_scaling"] = out["one_thread"]["value"] / out["value"]   # x faster on `cores` threads than on one
+        out["one_thread_ms"] = out["one_thread"]["value"]
     return out
 
 
@@ -602,6 +605,9 @@ def main():
                 "fp64_executed_gflops": executed_flop / (sc_avg * 1e-3) / 1e9 if sc_avg > 0 else 0.0,
                 "fp64_vector_peak_gflops": 78600.0,
                 "fp64_useful_frac": useful_flop / (sc_avg * 1e-3) / 78.6e12 if sc_avg > 0 else 0.0,
+                # the roof that BINDS this kernel at d_c = 9: 40 % of HBM on the algorithmic bytes would need 75 of the chip's 78.6 TF/s
+                # of fp64 (matrix and vector instructions share that pipe) -- DESIGN.md section 4
+                "fp64_pipe_frac": useful_flop / (sc_avg * 1e-3) / 78.6e12 if sc_avg > 0 else 0.0,
                 "schur_stage": {"kernels": "k_landmark_reduce + k_cam_reduce + " + kernel, "ms": stage_ms,
                                 "achieved": alg_bytes / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0,
                                 "frac": alg_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms > 0 else 0.0}}
@@ -620,6 +626,12 @@ def main():
     except Exception:
         pass
 
+    fac = (factor_roofline(info, stages["factor"][0] / max(stages["factor"][1], 1),
+                           "levels 0-8 at the tile GEMM's rate, the middle levels and the top latency-bound (profiles/r06_factor_timeline.txt)")
+           if args.variant == "sparse" and not s.variant_info()["reason"] else None)
+    if fac:   # (scalars the driver's record keeps: the factorisation against ITS roof, the fp64 MFMA peak)
+        roofline["factor_ms"] = fac["avg_factor_ms"]
+        roofline["factor_mfma_frac"] = fac["frac"]
     out = {
         "metric": "ms per LM iter (Jacobian+Schur+solve)", "value": ms_per_step, "unit": "ms", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False,
@@ -627,12 +639,11 @@ def main():
         "config": {"workload": f"{d.name} {data_kind} ({d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations)" + (f" from {data_src}" if data_src else ""),
                    "optimization_type": args.mode, "camera_dof": dc, "schur_variant": args.variant, "huber": 1.0,
                    "s_tile_rows": info["tile_rows"], "s_tiles": info["tiles"], "s_tiles_touched": info["touched_tiles"],
-                   "etree_levels": info["etree_levels"], "border_cameras": st["hub_cameras"], "schur_form": form, **s.variant_info(), **({"transport": comm_kind} if world > 1 else {}), "parallelism": f"landmark-shard x{world}" + (f", landmarks and Cholesky distributed by elimination subtree ({info['dist_top_columns']} shared top tile columns, tree_sharded={info.get('tree_sharded')})" if info.get("dist_top_columns") else "")},
+                   "etree_levels": info["etree_levels"], "border_cameras": st["hub_cameras"], "schur_form": form, "setup_s": setup_s,
+                   "host_cache_bytes": int(pkg.capi.load().apexgpu_host_cache_bytes()), **s.variant_info(), **({"transport": comm_kind} if world > 1 else {}), "parallelism": f"landmark-shard x{world}" + (f", landmarks and Cholesky distributed by elimination subtree ({info['dist_top_columns']} shared top tile columns, tree_sharded={info.get('tree_sharded')})" if info.get("dist_top_columns") else "")},
         "roofline": roofline,
         # the stage that is half the step, against ITS roof (fp64 MFMA); only where a factorisation ran
-        **({"factor": factor_roofline(info, stages["factor"][0] / max(stages["factor"][1], 1),
-                                      "levels 0-8 at the tile GEMM's rate, the middle levels and the top latency-bound (profiles/r05_factor_timeline.txt)")}
-           if args.variant == "sparse" and not s.variant_info()["reason"] else {}),
+        **({"factor": fac} if fac else {}),
         "stages_ms_per_step": per_step,
         "stage_launches": {k: int(v[1]) for k, v in stages.items()},
         "stages_measured": f"schur_scatter (the graded kernel): HIP events inside the timed region, {args.steps} iterations; the other stages: {stage_steps} "

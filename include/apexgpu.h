@@ -220,42 +220,37 @@ int apexgpu_get_hessian_csc(apexgpu_solver* h, int64_t* nnz_out, int64_t* colptr
  * order; either output may be NULL.  A size-independent parity property: the two must agree. */
 int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, double* y_explicit, double* y_implicit);
 
-/* Implementation switches (defaults in parentheses), for A/B tests and profiling:
- * Switches that shape what apexgpu_set_structure builds or what the captured hipGraphs hold ("schur_rows",
- * "potrf_lookahead", "update_overlap", "split_u1", "fused_forward", "nested_dissection", "dist_factor", "tree_sharding",
- * "dist_selftest") return APEXGPU_ERR_INVALID_STATE once the structure is set.
- *   "schur_rows" (4)  form of the Schur reduction (alias "schur_form"); set before set_structure:
- *                     4 = the pair list of form 3 in the QUEUED layout (round 4; nine columns per camera, six-column
- *                     cameras get form 3's lists): a task is the blocks of one row padded to nonets of nine slots and cut
- *                     into seven queues, every lane group of the product phase owns a block of its own -- nine fixed
- *                     steps per chunk, no fold over the groups, a block cut between two queues carried in registers and
- *                     stored once (k_schur_pairs_r<.., QL>, csrc/schur_pairs.h);
- *                     3 = every camera pair of a landmark in a list sorted by the block S(ci, cj) it adds to, one pair per
- *                     lane as a rank-2 update U V parked in LDS (J rebuilt from the projection records k_landmark_reduce
- *                     writes), the block sums taken over the lanes as 3 x 3 sub-block products on the vector unit, every
- *                     block stored once (k_schur_pairs_r, csrc/schur_pairs.h);
- *                     2 = LDS row form, one lane per observation, block rows walked in a per-lane rotated order
- *                     (k_schur_rows2), kept as the A/B.  The forms 1 / 0 of rounds 1-3 (one lane per camera pair;
- *                     landmark-major global atomics) and the three other pair kernels ("pairs_variant" 0 / 1 / 3) were
- *                     deleted in round 4: those values answer APEXGPU_ERR_INVALID_INPUT
- *   "pairs_ablation" (0)  per handle, TIMING EXPERIMENTS ONLY (the results are wrong when != 0): refused with
- *                     APEXGPU_ERR_INVALID_INPUT unless the process runs with APEX_ALLOW_ABLATION set
+/* Implementation switches (defaults in parentheses).  Round 6 removed every switch whose committed A/B said "loses" or
+ * "neutral", with its code (the row form of the Schur reduction, landmark bundles, the queued layout for six-column cameras, the
+ * pair kernel's ablations, camera-major records for the matrix-free operator, the vector-unit potrf kernels, dynamic scheduling
+ * of the dataflow units, panel lookahead, the forward sweep beside / inside the factorisation, tile clears on side streams, the
+ * small-batch limits; the winners "first_writer", "tri_inline", "panel_tri", "factor_flow_tile", "device_gathers", "cam_staging"
+ * are what the library does): measurements in profiles/, code in the history (DESIGN_HISTORY.md names the commits).  What is
+ * left selects between implementations that are BOTH in use somewhere, shapes the structure, or serves the tests.
+ * Switches that shape what apexgpu_set_structure builds or what the captured hipGraphs hold return APEXGPU_ERR_INVALID_STATE
+ * once the structure is set ("schur_form", "hubs_last", "nested_dissection", "dist_factor", "tree_sharding", "dist_selftest",
+ * "update_overlap", "split_u1", "flood_gate", "two_side", "factor_flow", "factor_flow_rows", "device_pair_list",
+ * "matrix_free_only", "auto_variant", "variant_cost_permille", "max_tile_updates").
+ *   "schur_form" (4)  layout of the sorted pair list of the Schur reduction: 4 = QUEUED (nine columns per camera; six-column
+ *                     cameras always get 3): a task is the blocks of one row padded to nonets of nine slots and cut into seven
+ *                     queues, every lane group of the product phase owns a block of its own -- nine fixed steps per chunk, no
+ *                     fold over the groups, a block cut between two queues carried in registers and stored once
+ *                     (k_schur_pairs_r<.., QL>, csrc/schur_pairs.h); 3 = every camera pair of a landmark in a list sorted by
+ *                     the block S(ci, cj) it adds to, the lane groups share ONE running block and fold at its end.  Other
+ *                     values (the forms of rounds 1-3) answer APEXGPU_ERR_INVALID_INPUT
  *   "graphs"     (1)  replay the factorisation / triangular solves as captured hipGraphs
  *   "update_overlap" (1)  run the trailing updates the next elimination level does not need on a second
- *                     stream, overlapped with that level's potrf / panel solves (before the first solve)
+ *                     stream, overlapped with that level's potrf / panel solves; > 1: the smallest batch that moves there
  *   "split_u1" (4)    the updates a level sends into the NEXT level's columns are split: those of its diagonal tiles stay on
  *                     the main stream (the next potrf needs nothing else), the others run on a third stream beside that
- *                     potrf when they are at least this many tasks; 0 = one batch on the main stream (before set_structure)
- *   "potrf_lookahead" (12)  diagonal-tile Cholesky + inverse: 12 (default) / 9 = the 16 x 16 pivot blocks on the matrix pipe
- *                     (k_potrf_inv_mf, round 4) with twelve / eight waves per workgroup (768 / 512 threads; twelve = nine helper
- *                     waves for the trailing update, 37 against 40 us per tile), 8 / 6 / 1 = look-ahead schedule of round 3
- *                     (k_potrf_inv_la) with 8 / 6 / 4 waves per workgroup, 0 = without look-ahead (k_potrf_inv)
- *   "panel_tri" (1)   the panel solves L_IK = S_IK Linv_KK^T skip the 36 of 81 16 x 16 block products that multiply by the zero
- *                     blocks of the triangular inverse (process-wide, before set_structure; 0 = full products, for A/B)
- *   "matrix_free_only" (0)  before set_structure: the handle will only be asked for variant 2 (IterativeSchurSolver semantics):
- *                     S is never formed, so only its diagonal tiles are allocated and no pair list is built -- set-up and LM
- *                     iteration are then independent of the fill of S (an input whose S is dense costs what a banded one
- *                     does); variants 0 / 1 and the exports of S answer APEXGPU_ERR_INVALID_STATE on such a handle
+ *                     potrf when they are at least this many tasks; 0 = one batch on the main stream
+ *   "flood_gate" (256)  the bulk updates of a level of at least this many tasks start when the next level's potrf workgroups
+ *                     sit on their CUs (a one-lane gate kernel; 0: off)
+ *   "two_side" (1)    the bulk updates on two side streams (targets two / three levels up; four and more): 0 off, 1 by plan
+ *                     size, 2 always (tests)
+ *   "matrix_free_only" (0)  the handle will only be asked for variant 2 (IterativeSchurSolver semantics): S is never formed,
+ *                     so only its diagonal tiles are allocated and no pair list is built -- set-up and LM iteration are then
+ *                     independent of the fill of S; variants 0 / 1 and the exports of S answer APEXGPU_ERR_INVALID_STATE
  *   "one_wait" (1)    single rank, Cholesky variant: apexgpu_solve_augmented enqueues factorisation, sweeps and back-substitution
  *                     back to back and waits for the device ONCE (the landmark-inversion and pivot flags are read at that
  *                     wait; a failure repeats the solve on the old path, ladder included); 0: three waits as in rounds 1-4
@@ -263,39 +258,11 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     every solve -- are enqueued behind the back-substitution and read at the solve's own wait; apexgpu_step_stats
  *                     and apexgpu_eval_step then answer from the host (three device round trips per LM iteration become one).
  *                     A caller that never asks (a level-1 binding that only takes the step) sets 0 and saves the kernels
- *   "prezero_tiles" (0)  single rank, Cholesky variant; 1: the tiles of S are cleared for the next assembly on a side stream right
- *                     behind a finished solve (beside the caller's step statistics / trial cost) instead of at the head of the
- *                     assembly.  Measured neutral (the clear moves into the statistics / retraction kernels' time): off
- *   "panel_split" (0)  before set_structure; n > 0: panel lookahead -- the panel solves of a level in two launches when at least
- *                     n tiles are not critical: those whose rows belong to the next level (all that its potrf waits for) first,
- *                     the others on a stream of their own.  Race free, bit-identical, measured no gain (round 5): off
- *   "first_writer" (1)  before set_structure: the first update of every fill tile is flagged in the plan and does not read its
- *                     target, and the fill tiles are not cleared before a factorisation (0: every tile cleared, every update
- *                     reads its target, as until round 4).  Bit-identical; final-13682 -0.16 ms per LM iteration
- *   "tri_inline" (8)  before set_structure: in the levels of at most this many tile columns the solve task of a block of the
- *                     dataflow sweeps forms the product of its last-arriving source itself (the link of the dependency chain:
- *                     one flag hop and one trip through memory less per level); 0 = every product is a task of its own.
- *                     Bit-identical.  ladybug-1723: sweeps 0.35 -> 0.28 ms; wide levels lose (HBM-bound), hence the limit
- *   "fwd_beside_top" (0)  before set_structure; 1: the forward sweep in two launches, the part over the columns below the
- *                     factorisation's dataflow launch on a side stream beside that launch.  Bit-identical; zero sum (round 5): off
- *   "cam_beside_pairs" (0)  single rank; 1: k_cam_reduce on a second stream beside the pair kernel (disjoint outputs).  Neutral: off
- *   "panel_small_max" / "update_small_max" (56)  process-wide, before set_structure: the largest batch of panel solves / updates
- *                     that uses the latency kernels instead of the throughput kernel (measured flat, round 5)
- *   "implicit_cam_records" (0)  1: the camera half of the matrix-free operator builds its Jacobians from camera-major projection
- *                     records instead of re-linearising (fewer instructions, 32 more bytes per observation).  Measured slower: off
- *   "landmark_bundles" (0)  before set_structure; 1: the projection records of a landmark sit right behind a 64-byte copy of its
- *                     record's first line ([Hll^-1 p.x p.y | record 0 | record 1 | ...], 128-byte aligned) and the pair list
- *                     names 32-byte units of that array: an L2 miss costs per 128-byte line, and a pair of the Schur kernel
- *                     then touches 2.1 lines instead of 2.6.  Built and measured in round 5: the pair kernel gains 0.10 ms,
- *                     k_landmark_reduce loses 0.33 -- off; 0 = records indexed by observation (rounds 3-5)
- *   "pairs_queued6" (0)  before set_structure: the queued layout of the pair list ("schur_form" 4) also for SIX-column cameras
- *                     (BundleAdjustment mode): sixteen queues of four pairs per chunk.  Built and measured in round 5: slower than
- *                     form 3 there (3.52 against 2.90 ms on final-13682), so six-column cameras keep form 3 unless this is set
- *   "device_pair_list" (1)  before set_structure: the RECORDS of the sorted pair list (queued layout, nine-column cameras: 1.56 GB
- *                     on final-13682) are written by the device from the observation lists (k_build_pair_recs_q: the host keeps
- *                     the small, serial part -- blocks, tasks, descriptors); 0 = built on the host and copied (rounds 2-4):
- *                     0.1-0.18 s + 35 ms of upload of every apexgpu_set_structure.  The same list, slot for slot
- *   "auto_variant" (1)  before set_structure: a structure whose direct factorisation is refused -- more than 8e7 tile products
+ *   "device_pair_list" (1)  the RECORDS of the queued pair list (1.56 GB on final-13682) are written by the device from the
+ *                     observation lists (k_build_pair_recs_q: the host keeps the small, serial part -- blocks, tasks,
+ *                     descriptors); 0 = built on the host and copied: the same list, slot for slot (the tests hold one against
+ *                     the other), 0.1-0.18 s + 35 ms of upload more per apexgpu_set_structure
+ *   "auto_variant" (1)  a structure whose direct factorisation is refused -- more than 8e7 tile products
  *                     per factorisation (S dense at tile granularity: a photo collection), or, on a single rank, tiles beyond
  *                     the free HBM -- does NOT fail apexgpu_set_structure: the handle is built matrix-free only by itself and
  *                     apexgpu_solve_augmented / apexgpu_lm_optimize answer variants 0 and 1 with the matrix-free PCG (variant 2;
@@ -304,29 +271,18 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *                     matrix-free PCG at its cap (apexgpu_variant_costs) -- between 0.5 s and the 12.7 s of the size limit the direct
  *                     path used to be chosen although the handle owns a 0.5-s way to the same step.  apexgpu_variant_info tells.
  *                     0: a refusal is APEXGPU_ERR_INVALID_INPUT as before, and no plan is refused by cost
- *   "variant_cost_percent" (100)  before set_structure: scales the matrix-free side of that comparison (tests move the crossover
+ *   "variant_cost_permille" (1000)  scales the matrix-free side of that comparison (tests move the crossover
  *                     onto small problems; 0 switches the cost rule off)
  *   "max_tile_updates" (80000000)  tests: the limit of tile products per factorisation above which the plan is refused
  *   "factor_flow" (-1), "factor_flow_rows" (24)  the TOP of the elimination tree -- the trailing level groups with at most
  *                     that many tile columns each, every column with at most "factor_flow_rows" off-diagonal tiles -- is
  *                     factorised by ONE dataflow launch (-1, the default: where the launch starts is chosen by a cost
  *                     model of both schedules) (k_factor_flow: a workgroup per potrf / per 48-row strip of a
- *                     panel solve or update, per-tile version counters) instead of three dependent launches per level;
- *                     same summation order, bit-identical factor.  0 = level launches everywhere.  Its waits are bounded
- *                     like the sweeps': a launch that gives up is detected in the same apexgpu_solve_augmented, S is
- *                     assembled again and factorised by the level launches, which the handle then keeps
- *                     (apexgpu_counters()[2]); before set_structure
- *   "factor_flow_tile" (1)  inside that launch an update whose target column lies two level groups or more above its source
- *                     column runs as ONE whole-tile unit (the level kernels' rate per CU) instead of nine 48 x 48 units built
- *                     for latency, which lets the cost model hand the launch the throughput-bound MIDDLE levels as well
- *                     (round 5); 0 = nine units everywhere (round 4); before set_structure
- *   "factor_flow_dyn" (0)  1: the units of that launch are scheduled DYNAMICALLY -- one persistent workgroup per CU takes ready
- *                     units from a queue, and the unit that completes a writer of a tile wakes the units that waited for it
- *                     (k_factor_flow_dyn, round 5): no CU is held by a unit that polls for its inputs.  Same units, same order
- *                     of writers per tile, same bits -- and SLOWER wherever measured (a hop through the queue costs ~4 us more
- *                     than a polled flag, and the launches are chain-bound: profiles/r05_flow_bench_dyn.txt), hence off: the
- *                     A/B of the static launch (one workgroup per unit, dispatched in list order).  Before set_structure
- *   "fused_forward" (0)  run the forward triangular sweep inside the factorisation graph on a third stream
+ *                     panel solve or update on the chain, per whole tile off it; per-tile version counters) instead of three
+ *                     dependent launches per level; same summation order, bit-identical factor.  0 = level launches
+ *                     everywhere.  Its waits are bounded like the sweeps': a launch that gives up is detected in the same
+ *                     apexgpu_solve_augmented, S is assembled again and factorised by the level launches, which the handle
+ *                     then keeps (apexgpu_counters()[2])
  *   "tri_dataflow" (1)  triangular sweeps of a single-GPU plan as ONE launch each: one workgroup per tile, dependencies
  *                     through per-block flags (k_tri_fwd_flow / k_tri_bwd_flow); 0 = one launch per elimination-tree level.
  *                     The flag waits are bounded (~2 s): a sweep that gives up is detected IN THE SAME apexgpu_solve_augmented
@@ -335,12 +291,12 @@ int apexgpu_schur_matvec(apexgpu_solver* h, double lambda, const double* x_in, d
  *   "debug_poison_factor"  tests only: the next factorisation's dataflow launch ("factor_flow") cannot finish and times out
  *   "debug_poison_sweep", "debug_occupy_cus"  tests only: the next solve's forward (1) / backward (2) dataflow sweep runs
  *                     into its spin limit on purpose; block that many compute units for 40 ms starting now
- *   "nested_dissection" (1)  order camera tiles by nested dissection (call before set_structure);
+ *   "nested_dissection" (1)  order camera tiles by nested dissection;
  *                     0 keeps the caller's camera order, a value > 1 sets the leaf size in tiles
  *   "hubs_last" (1)   order a vertex cover of the camera pairs that share landmarks across tiles more than two strong
  *                     hops apart (hub cameras, accidental long-range matches) after all the others: a dense border of S
- *                     instead of fill everywhere (csrc/ba_structure.h); before set_structure
- *   "dist_factor" (1), "tree_sharding" (1)  multi-GPU only, before set_structure: see the multi-GPU section
+ *                     instead of fill everywhere (csrc/ba_structure.h)
+ *   "dist_factor" (1), "tree_sharding" (1)  multi-GPU only: see the multi-GPU section
  *   "dist_selftest" (0)  single rank, before set_structure: cut the elimination tree as for that many ranks and run
  *                     the distributed schedule (own levels, top levels, phased triangular sweeps) with this rank
  *                     owning every subtree and no-op exchanges -- results must equal the plain schedule's      */
@@ -362,7 +318,7 @@ int apexgpu_stage_times(apexgpu_solver* h, double ms[APEXGPU_NUM_STAGES], int64_
  * [9..11] = tile operations per factorisation: potrf, panel products, trailing updates (2*144^3 flop each for the last two),
  * [12] = shared top tile columns of a distributed factorisation (0: replicated), [13] = this rank's share of the tile
  * operations below them (1 when not distributed), [14] = 1 when the landmarks are sharded by the elimination tree,
- * [15] = form of the Schur reduction in use ("schur_rows") */
+ * [15] = form of the Schur reduction in use ("schur_form") */
 int apexgpu_info(apexgpu_solver* h, double info[16]);
 /* Which variant a solve asked with `asked_variant` runs on this handle (*used_variant; differs only after the automatic
  * selection of "auto_variant") and why (reason: NUL-terminated, cut to reason_len; empty when nothing was overridden).

@@ -886,7 +886,7 @@ def test_a_second_structure_on_one_handle_is_decided_afresh(oracle):
     assert dA.n_obs == dB.n_obs
     probA = Problem.bundle_adjustment(dA, OptimizationType.SelfCalibration, 1.0)
     probB = Problem.bundle_adjustment(dB, OptimizationType.SelfCalibration, 1.0)
-    s = GpuSchurComplementSolver(0).with_option("max_tile_updates", 60).with_option("variant_cost_percent", 0)
+    s = GpuSchurComplementSolver(0).with_option("max_tile_updates", 60).with_option("variant_cost_permille", 0)
     s.initialize_structure(probA)
     assert s.variant_info()["variant_used"] == "Implicit" and s.variant_info()["variant_choice"] == "matrix-free: plan refused"
     s.set_parameters(dA.poses, dA.intr, dA.points)

@@ -24,8 +24,10 @@ for world in worlds:
     print(name, "world", world, "top columns", i0["dist_top_columns"], "groups", i0["etree_levels"], flush=True)
     for r, s in enumerate(ranks):
         st = s.stage_times(); inf = s.info()
-        print("  rank", r, "share %.3f" % inf["dist_local_fraction"],
-              "assemble %.2f" % ((st["cam_reduce"][0] + st["landmark_reduce"][0] + st["schur_scatter"][0]) / reps),
-              "factor local %.2f" % (st["factor"][0] / reps), "factor top %.2f" % (st["all_reduce"][0] / reps),
-              "tri %.2f" % (st["tri_solve"][0] / reps), flush=True)
+        ms = {k: v[0] / reps for k, v in st.items()}
+        print("  rank", r, "share %.3f" % inf["dist_local_fraction"], "obs %.3f" % (inf["local_obs"] / d.n_obs),
+              "assemble %.2f" % (ms["cam_reduce"] + ms["landmark_reduce"] + ms["schur_scatter"]),
+              "(clears+cam_reduce %.2f landmark_reduce %.2f pairs %.2f)" % (ms["cam_reduce"], ms["landmark_reduce"], ms["schur_scatter"]),
+              "factor local %.2f" % ms["factor"], "factor top %.2f" % ms["all_reduce"],
+              "tri %.2f" % ms["tri_solve"], "back-subst %.2f" % ms.get("back_substitute", 0.0), flush=True)
     for s in ranks: s.close()

@@ -1,15 +1,15 @@
 #!/bin/bash
-# Round-5 evidence in one gpurun call (copy what is wanted from gpurun_out/ into profiles/ afterwards):
-#   tools/profile_r05.sh [parts]     parts: any of  bench stats pmc timeline other lockstep pairs micro  (default: all)
+# Round-6 evidence in one gpurun call (copy what is wanted from gpurun_out/ into profiles/ afterwards):
+#   tools/profile_r06.sh [parts]     parts: any of  bench stats pmc timeline other lockstep pairs micro  (default: all)
 set -u
 PARTS=${1:-"bench stats pmc timeline other lockstep pairs micro"}
 export APEX_SYNTH_CACHE=/tmp/apex_synth_cache
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out; T=r05
+O=gpurun_out; T=r06
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 if has bench; then
   timeout 900 python3 bench.py --steps 20 --warmup 5 > $O/${T}_bench_final13682.json 2> $O/${T}_bench.err
-  python3 -c "import json; b=json.load(open('$O/${T}_bench_final13682.json')); print('final-13682', b['value'], b['stages_ms_per_step'], 'iterative', b.get('iterative_ms'), 'implicit', b.get('fallback_implicit'), b['roofline']['frac'], b['factor']['frac'], b['setup_s'], b['cpu_baseline'].get('value'))"
+  python3 -c "import json; b=json.load(open('$O/${T}_bench_final13682.json')); print('final-13682', b['value'], b['stages_ms_per_step'], 'iterative', b.get('iterative_ms'), 'implicit', b.get('fallback_implicit'), b['roofline']['frac'], b['roofline'].get('fp64_pipe_frac'), b['factor']['frac'], b['setup_s'], b['cpu_baseline'].get('value'))"
 fi
 if has stats; then
   timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o st --output-format csv -- python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-other-variants --no-other-workloads > $O/prof_stats.log 2>&1
@@ -33,7 +33,7 @@ if has other; then
   for f in ladybug1723 venice1778 sphere2500 final13682hub final13682_ba6 synthetic10k synthetic10k_implicit; do python3 - $f <<'PY'
 import json, sys
 try:
-    b = json.load(open(f"gpurun_out/r05_bench_{sys.argv[1]}.json")); cb = b.get("cpu_baseline") or {}
+    b = json.load(open(f"gpurun_out/r06_bench_{sys.argv[1]}.json")); cb = b.get("cpu_baseline") or {}
     print(sys.argv[1], round(b["value"], 3), b["unit"], "factor", round(b["stages_ms_per_step"].get("factor", 0), 3), "| cpu", cb.get("value"), cb.get("solve"), cb.get("cores"),
           "dense", (cb.get("dense_solve") or {}).get("value"), "| iterative", b.get("iterative_ms"), "implicit", b.get("fallback_implicit"), "| pcg", (b.get("pcg_iterations_per_step") or [])[:3])
 except Exception as e:
@@ -42,11 +42,10 @@ PY
   done
 fi
 if has lockstep; then timeout 1500 python3 tools/dist_lockstep_times.py final-13682 2,4,8 > $O/${T}_lockstep_rank_times.txt 2>&1; cat $O/${T}_lockstep_rank_times.txt | grep -v "^  rank [1-6]"; fi
-if has pairs; then   # the queued layout (form 4, the default); the form-3 evidence of the first half of the round stays as r05_k_schur_pairs_counters / r05_pairs_ablation
+if has pairs; then   # counters of the pair kernel in the queued layout (form 4, the default)
   timeout 900 tools/profile_pairs.sh ${T}_queued > /dev/null 2>&1; mv $O/${T}_queued_k_schur_pairs_counters.txt $O/${T}_pairs_queued_counters.txt
   grep -E "SQ_LDS_BANK|TCC_MISS|SQ_INSTS_VALU |SQ_INSTS_LDS|SQ_INSTS_SALU|^form" $O/${T}_pairs_queued_counters.txt
-  { python3 tools/schur_bench.py --forms 4,3,2 --iters 10 --abl 0,1,2,1024,64 2>&1 | grep -E "^form|cycles per chunk"
-    python3 tools/schur_bench.py --forms 4 --task-slots 4032,2592,2016,1152 --iters 10 2>&1 | grep -E "^form"; } > $O/${T}_pairs_queued_ablation.txt; cat $O/${T}_pairs_queued_ablation.txt
+  python3 tools/schur_bench.py --forms 4,3 --iters 10 2>&1 | grep -E "^form" > $O/${T}_pairs_forms.txt; cat $O/${T}_pairs_forms.txt
 fi
 if has micro; then
   tools/potrf_bench > $O/${T}_potrf_bench.txt 2>&1; grep -A4 "mode 12,  1" $O/${T}_potrf_bench.txt | grep -v stamps

@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--forms", default="4,3")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--mode", default="selfcal")
-    ap.add_argument("--task-slots", default="0", help="comma list of pair_task_slots values to try with form 3")
     ap.add_argument("--check", action="store_true", help="compare S x of every form with the first one's")
     a = ap.parse_args()
     t = time.time()
@@ -33,9 +32,8 @@ def main():
     prob = Problem.bundle_adjustment(d, ot, 1.0)
     ref = None
     x = np.random.default_rng(0).normal(size=prob.layout.cam_dof)
-    runs = [(int(f), int(ts), None) for f in a.forms.split(",") for ts in (a.task_slots.split(",") if int(f) in (3, 4) else ["0"])]
-    for form, ts, pv in runs:
-        s = GpuSchurComplementSolver(0).with_option("schur_form", form).with_option("pair_task_slots", ts)
+    for form in [int(f) for f in a.forms.split(",")]:
+        s = GpuSchurComplementSolver(0).with_option("schur_form", form)
         t = time.time()
         s.initialize_structure(prob)
         s.set_parameters(d.poses, d.intr, d.points)
@@ -47,7 +45,7 @@ def main():
             s.assemble(1e-3)
         st = s.stage_times()
         line = {k: round(v[0] / max(v[1], 1), 3) for k, v in st.items() if v[1] > 0}
-        print(f"form {form} task_slots {ts}: {line}", flush=True)
+        print(f"form {form}: {line}", flush=True)
         print(f"   setup {setup:.2f} s  {s.setup_times()}", flush=True)
         if a.check:
             y, _ = s.schur_matvec(1e-3, x, implicit=False)
