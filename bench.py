@@ -131,7 +131,7 @@ def cpu_baseline_worker(workload, shape_scale, mode, dense_too=True, n_iter=2):
     out = {
         "value": ms, "unit": "ms per LM iter on the sample", "cores": cores, "kind": "port", "solve": "sparse",
         "sample": f"{d.name}: {d.n_cam} cameras / {d.n_pt} landmarks / {d.n_obs} observations; SINGLE-THREADED envelope Cholesky "
-                  f"(the solve is {n_iter} x serial: only the linearisation uses the cores); {n_iter} LM iteration(s) of oracle/ba_oracle.c "
+                  f"(the solve is serial: only the linearisation and the Schur formation use the cores); {n_iter} LM iteration(s) of oracle/ba_oracle.c "
                   f"(linearise + explicit Schur into a dense S + sparsify at 1e-12 + envelope Cholesky in reverse Cuthill-McKee order + trial cost)",
         "obs_per_s": d.n_obs / (ms * 1e-3),
         "solve_ms": ms_solve,   # H = J^T J, Schur complement, factorisation, back-substitution
@@ -615,7 +615,7 @@ def main():
     # HBM traffic of the same kernel from the committed PMC pass (rocprofv3 cannot run inside this
     # process); only attached when the committed profile is of this very workload and kernel
     try:
-        pm_path = next(p for p in (os.path.join(ROOT, "profiles", f"r0{r}_final13682_pmc_summary.json") for r in (5, 4, 3, 2)) if os.path.exists(p))
+        pm_path = next(p for p in (os.path.join(ROOT, "profiles", f"r0{r}_final13682_pmc_summary.json") for r in (6, 5, 4, 3, 2)) if os.path.exists(p))
         pm = json.load(open(pm_path))
         if world == 1 and args.workload == "final-13682" and args.scale == 1.0 and args.mode == "selfcal":
             k = [v for n, v in pm["kernels"].items() if kernel in n]
