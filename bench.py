@@ -529,12 +529,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Inside the timed region only the graded kernel's stage is timed (HIP events on the solver's stream around
-    # k_schur_pairs_r: roofline.avg_launch_ms is measured live, over these very steps); the eighteen events per iteration of the
-    # full stage table cost the stream ~0.1 ms per iteration (round 5: 12.88 against 12.69 ms, three pairs of runs), so the other
-    # stages are timed over `stage_steps` further iterations right behind the timed region.
-    sc_stage = pkg.capi.STAGE_NAMES.index("schur_scatter")
-    s.enable_stage_timing(2 << sc_stage)
+    # Inside the timed region only the two stages with a roofline of their own are timed (HIP events on the solver's stream around
+    # k_schur_pairs_r, the graded kernel, and around the factorisation: roofline.avg_launch_ms and factor.avg_factor_ms are measured
+    # live, over these very steps); the eighteen events per iteration of the full stage table cost the stream ~0.1 ms per
+    # iteration (round 5: 12.88 against 12.69 ms, three pairs of runs), so the other stages are timed over `stage_steps` further
+    # iterations right behind the timed region (a later LM state: `stage_sum_ms` beside `value` says how far the table is off).
+    sc_stage, fa_stage = pkg.capi.STAGE_NAMES.index("schur_scatter"), pkg.capi.STAGE_NAMES.index("factor")
+    s.enable_stage_timing((2 << sc_stage) | ((2 << fa_stage) if args.variant == "sparse" else 0))
     s.reset_stage_times()
     accepted_before = state["accepted"]
     barrier()
@@ -560,6 +561,9 @@ def main():
     barrier()
     stages = s.stage_times()
     stages["schur_scatter"] = stages_timed["schur_scatter"]   # (the graded kernel: from the timed region itself)
+    factor_in_region = args.variant == "sparse" and stages_timed["factor"][1] > 0
+    if factor_in_region:
+        stages["factor"] = stages_timed["factor"]
     # (what follows -- the other variants on this handle -- starts from the end of the timed region, as in rounds 1-4)
     s.set_parameters(*saved_params)
     state.clear(); state.update(saved_state)
@@ -589,7 +593,8 @@ def main():
     off_pairs = info["pair_blocks"] - n_obs_local      # pair contributions without the self pairs
     useful_flop = 2.0 * (12 + 4 * dc + 2 * dc * dc) * off_pairs + 250.0 * n_obs_local
     executed_flop = ((2.0 * (12 + 4 * dc + 2 * dc * dc) + 2 * 120.0 + 36.0) if record_form else (2.0 * (12 + 4 * dc + 2 * dc * dc) + 2 * 250.0 + 36.0)) * off_pairs
-    per_step = {k: v[0] / (args.steps if k == "schur_scatter" else stage_steps) for k, v in stages.items()}   # ms per LM iteration
+    in_region = ("schur_scatter",) + (("factor",) if factor_in_region else ())
+    per_step = {k: v[0] / (args.steps if k in in_region else stage_steps) for k, v in stages.items()}   # ms per LM iteration
     stage_ms = per_step["landmark_reduce"] + per_step["cam_reduce"] + sc_avg
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
@@ -646,7 +651,8 @@ def main():
         **({"factor": fac} if fac else {}),
         "stages_ms_per_step": per_step,
         "stage_launches": {k: int(v[1]) for k, v in stages.items()},
-        "stages_measured": f"schur_scatter (the graded kernel): HIP events inside the timed region, {args.steps} iterations; the other stages: {stage_steps} "
+        "stage_sum_ms": sum(per_step.values()),
+        "stages_measured": f"schur_scatter (the graded kernel) and factor: HIP events inside the timed region, {args.steps} iterations; the other stages: {stage_steps} "
                            "further iterations right behind it with every stage event on (the full table costs the stream ~0.1 ms per iteration)",
         "setup_s": setup_s, "setup_by_phase_s": {k: st[k] for k in ("order", "lists", "tile_plan", "schur_lists", "uploads", "total")},
         # the whole of setup_s by piece: handle creation (the process's first HIP call = runtime start-up), the host-side
