@@ -155,7 +155,11 @@ impl GpuSchurComplementSolver {
             check(h, unsafe { apexgpu_variant_info(h, asked, &mut used, why.as_mut_ptr(), why.len() as c_int) })?;
             if used != asked {
                 let msg = unsafe { std::ffi::CStr::from_ptr(why.as_ptr()) }.to_string_lossy().into_owned();
-                tracing::warn!("GpuSchurComplementSolver: variant {asked} requested, variant {used} runs: {msg}");
+                // (round 6: also when the direct path was merely predicted to cost more than the matrix-free PCG at its cap)
+                let mut c = [0f64; 4];
+                check(h, unsafe { apexgpu_variant_costs(h, c.as_mut_ptr()) })?;
+                tracing::warn!("GpuSchurComplementSolver: variant {asked} requested, variant {used} runs: {msg} \
+                                (predicted ms per solve: direct {:.1}, matrix-free {:.1})", c[0], c[1]);
             }
         }
         let key = problem as *const Problem as usize;

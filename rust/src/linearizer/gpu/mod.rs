@@ -49,6 +49,9 @@ extern "C" {
     /// which variant a solve asked with `asked_variant` runs on this handle, and why (round 5: automatic selection of the
     /// matrix-free PCG when the tile plan of S is refused -- the CPU path never fails on the fill of S)
     pub fn apexgpu_variant_info(h: *mut ApexGpuSolver, asked_variant: c_int, used_variant: *mut c_int, reason: *mut c_char, reason_len: c_int) -> c_int;
+    /// what `apexgpu_set_structure` predicted for the two ways to the step and which one it built (round 6): out[0] ms per solve of the
+    /// direct factorisation, out[1] of the matrix-free PCG at its cap, out[2] the choice (0 direct, 1 matrix-free by cost, 2 by refusal, 3 by option)
+    pub fn apexgpu_variant_costs(h: *mut ApexGpuSolver, out4: *mut f64) -> c_int;
     /// hand the set-up's cached host blocks back to the system at once (the `apexgpu_destroy` of the last live handle does
     /// it by itself: the cache only lives while a solver does); `apexgpu_host_cache_bytes`: what is held right now
     pub fn apexgpu_trim_host_cache(released_bytes: *mut i64) -> c_int;

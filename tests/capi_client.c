@@ -131,6 +131,16 @@ int main(int argc, char** argv) {
         int rc = apexgpu_create(n_cam, n_pt, n_obs, (int)hdr[3], 0, &h);
         if (rc) { fprintf(stderr, "create: %d\n", rc); return 3; }
         rc = apexgpu_set_structure(h, cam, pt, uv, ic, pc, lc, fixp, NULL, NULL, 1.0);
+        if (!rc) {   /* what the Rust shim logs once per structure: the variant that runs, the two predicted costs behind the choice */
+            int used = -1; char why[256]; double costs[4] = {0, 0, -1, 0};
+            rc = apexgpu_variant_info(h, APEXGPU_VARIANT_SPARSE, &used, why, (int)sizeof why);
+            if (!rc) rc = apexgpu_variant_costs(h, costs);
+            if (!rc && (used != APEXGPU_VARIANT_SPARSE || costs[2] != 0.0 || !(costs[0] > 0.0) || !(costs[1] > costs[0]))) {
+                fprintf(stderr, "variant %d (%s), predicted %g / %g ms, choice %g\n", used, why, costs[0], costs[1], costs[2]);
+                return 5;   /* this small banded problem runs the direct path */
+            }
+            if (apexgpu_host_cache_bytes() < 0) return 5;
+        }
         apexgpu_lm_config cfg = default_config(20);
         if (!rc && strcmp(argv[1], "ba") == 0) {
             rc = apexgpu_set_params(h, poses, intr, pts);
