@@ -600,9 +600,10 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
                 "pair_list_bytes": pair_list_bytes if record_form else 0.0,
                 "avg_launch_ms": sc_avg, "launches": sc_n,
-                "actual_bound": ("vector-memory path: the gathers of a 64-pair chunk (3 x 64-byte lines per pair, ~2/3 of them L2 misses) take more than a third of a "
-                                 "wave's time to ISSUE; products and flush are no longer co-critical in the queued layout "
-                                 "(profiles/r04_pairs_queued_*.txt; DESIGN.md section 4, round 4)") if record_form else
+                "actual_bound": ("the L1's window of outstanding misses: 2.75 64-byte L1->L2 requests per pair (landmark header + two projection "
+                                 "records, compulsory in a pair-major kernel) = 16.9 GB per launch at 5.9 TB/s, ~62 requests in flight per CU at "
+                                 "418 cycles each, the L1 stalled on pending data 63 % of its busy cycles "
+                                 "(profiles/r06_pairs_mem_counters.txt; DESIGN.md section 4)") if record_form else
                                 "fp64 vector unit + LDS (the fused form moves 2 GB but executes ~60 GFLOP: DESIGN.md section 4)",
                 "projection_record_bytes": 32.0 * n_obs_local if record_form else 0.0,
                 "pair_contributions_per_launch": off_pairs,
