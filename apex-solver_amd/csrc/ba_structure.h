@@ -28,7 +28,6 @@ struct BaStructOptions {
     bool dist_factor = true, tree_sharding = true;
     int dist_selftest = 0;
     int schur_form = 3;        // 3 sorted pair list, 4 the same pairs in the queued layout (d_c = 9; schur_pairs.h); < 0: none (matrix-free only)
-    int pair_task_slots = 0;   // pair slots per wave task of the pair list (0: default)
     bool device_gathers = false;   // the measurement lists (o_uv, co_uv) and co_pt are gathered on the device from the caller's array and the
                                    // index lists (Solver::set_structure, single rank): the host does not build them
 };

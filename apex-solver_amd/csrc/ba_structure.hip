@@ -401,7 +401,7 @@ void BaHostStructure::build_schur_lists(const BaStructOptions& o, const int* slo
         // every camera pair (i, j) of a landmark, sorted by the block S(cam_i, cam_j) it adds to; nine-column cameras in the
         // queued layout (form 4), whose records the device can write itself (dev_tables)
         build_pair_lists(dc, nt, slot_host, n_cam, cinv.data(), o_cam.data(), o_pt.data(), pt_ptr.data(), cam_ptr.data(),
-                         cam_obs.data(), &pl, o.pair_task_slots, /*queued=*/o.schur_form == 4 && dc == 9,
+                         cam_obs.data(), &pl, /*task_slots=*/0, /*queued=*/o.schur_form == 4 && dc == 9,
                          (o.schur_form == 4 && dc == 9) ? dev_tables : nullptr);
     seconds[3] = now_s() - t0;
 }

@@ -73,7 +73,7 @@ void build_pair_lists(int dc, int nt, const int* slot, int64_t n_cam, const int*
     if (queued) {
         // ---- QUEUED layout (schur_pairs.h): tasks inside one row, blocks padded to nonets, seven queues per task -----------
         // nonets per task: 7 x 64 at most (a task's chunk descriptors sit one per lane); fewer = more tasks per row = fewer rows
-        // in flight per XCD, whose L2 then sees a row's landmark records again before they are evicted ("pair_task_slots")
+        // in flight per XCD, whose L2 then sees a row's landmark records again before they are evicted
         // (round 5) nine-column cameras: seven queues of NONETS (the lanes of a group hold the 9 x 9 block as nine 3 x 3 sub-blocks);
         // six-column cameras: sixteen queues of QUARTETS (four lanes, four sub-blocks).  QL = slots of a queue per chunk, NQ = queues.
         const int QL = pair_queue_len(dc), NQ = pair_queues(dc), ND = NQ + 1, kPiecePairs = 64 * QL;

@@ -265,8 +265,7 @@ class TilePlan {
     int flow_first_[2] = {0, 0}, flow_n_[2] = {0, 0};
     double flow_sim_us_[2] = {0.0, 0.0};   // makespan of the list schedule that ordered the units (build())
     bool flow_on_ = true, flow_gave_up_ = false;
-    // dynamic scheduling of the dataflow launch (k_factor_flow_dyn): one image per plan, both phases back to back --
-    // [pending | queue] initial values (copied over the live arrays before every launch), waiter lists, {head, tail} per phase
+    // the dataflow triangular sweeps (enable_tri_flow): task counts of the forward / backward launch
     int n_flow_tasks_ = 0, n_flow_bwd_ = 0, n_flow_parts_ = 0;
     int n_flow_local_ = 0;   // distributed plans: the forward tasks of phase 0 (the rest: the top columns, phase 1)
     bool tri_flow_ = true;
