@@ -602,7 +602,8 @@ def main():
                 "avg_launch_ms": sc_avg, "launches": sc_n,
                 "actual_bound": ("the L1's window of outstanding misses: 2.75 64-byte L1->L2 requests per pair (landmark header + two projection "
                                  "records, compulsory in a pair-major kernel) = 16.9 GB per launch at 5.9 TB/s, ~62 requests in flight per CU at "
-                                 "418 cycles each, the L1 stalled on pending data 63 % of its busy cycles "
+                                 "418 cycles each, the L1 stalled on pending data 63 % of its busy cycles: 0.5 ms of the launch; the other 2.3 ms are the "
+                                 "vector and LDS phases of two waves per SIMD (the kernel without any gather: 2.33-2.37 ms) "
                                  "(profiles/r06_pairs_mem_counters.txt; DESIGN.md section 4)") if record_form else
                                 "fp64 vector unit + LDS (the fused form moves 2 GB but executes ~60 GFLOP: DESIGN.md section 4)",
                 "projection_record_bytes": 32.0 * n_obs_local if record_form else 0.0,
